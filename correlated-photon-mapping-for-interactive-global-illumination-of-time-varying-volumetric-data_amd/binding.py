@@ -1,0 +1,427 @@
+"""ctypes binding of libcpm_hip.so (include/cpm/cpm.h).
+
+PyTorch is used for device memory and streams only: every buffer handed to the
+library is a ``torch.Tensor`` on the context's device, passed as its raw device
+pointer; work is enqueued on torch's current stream.  There is no CPU
+fallback: when the shared library is missing the import fails loudly, and
+``Context()`` raises when no GPU is visible.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from pathlib import Path
+
+_PKG_DIR = Path(__file__).resolve().parent
+LIB_PATH = _PKG_DIR / "libcpm_hip.so"
+
+CPM_OK = 0
+CPM_U8, CPM_U16, CPM_F32 = 0, 1, 2
+CPM_TRACE_PROGRESSIVE = 1
+CPM_TRACE_NO_SINGLE_SCATTERING = 2
+CPM_PHASE_HENYEY_GREENSTEIN, CPM_PHASE_ISOTROPIC = 0, 1
+
+#: every symbol include/cpm/cpm.h declares (checked by tests/test_abi.py against the header)
+ABI_SYMBOLS = [
+    "cpm_create", "cpm_destroy", "cpm_last_error_string", "cpm_abi_version",
+    "cpm_glibc_rand_sequence", "cpm_seed_streams", "cpm_random_fill",
+    "cpm_volume_desc_default", "cpm_volume_create", "cpm_volume_update", "cpm_volume_destroy",
+    "cpm_tf_create", "cpm_tf_update", "cpm_tf_destroy",
+    "cpm_uniform_samples_2d", "cpm_directional_light_samples", "cpm_point_light_samples",
+    "cpm_light_sample_box_intersection", "cpm_light_sample_mesh_intersection",
+    "cpm_trace",
+    "cpm_grid_desc_default", "cpm_relative_irradiance_scale",
+    "cpm_splat", "cpm_splat_selected", "cpm_copy_indexed_photons",
+    "cpm_sort_pairs", "cpm_sort_keys", "cpm_bin", "cpm_gather",
+    "cpm_volume_minmax", "cpm_volume_difference", "cpm_importance_tf",
+    "cpm_photon_importance", "cpm_photon_importance_equal", "cpm_reset_importance",
+    "cpm_select_recompute",
+]
+
+
+class VolumeDesc(C.Structure):
+    _fields_ = [("dims", C.c_int32 * 3), ("dtype", C.c_int32), ("format_scaling", C.c_float),
+                ("format_offset", C.c_float), ("texture_to_index", C.c_float * 16),
+                ("index_to_texture", C.c_float * 16)]
+
+
+class GridDesc(C.Structure):
+    _fields_ = [("dims", C.c_int32 * 3), ("channels", C.c_int32),
+                ("texture_to_index", C.c_float * 16), ("index_to_texture", C.c_float * 16)]
+
+
+class TraceParams(C.Structure):
+    _fields_ = [("material", C.c_float * 4), ("step_size", C.c_float), ("photon_offset", C.c_int32),
+                ("n_light_samples", C.c_int32), ("max_interactions", C.c_int32),
+                ("total_photons", C.c_int32), ("shading_type", C.c_int32), ("flags", C.c_int32),
+                ("iteration", C.c_int32), ("batch", C.c_int32)]
+
+
+class CpmError(RuntimeError):
+    def __init__(self, status: int, message: str):
+        super().__init__(f"libcpm_hip status {status}: {message}")
+        self.status = status
+
+
+_lib = None
+
+
+def load_library() -> C.CDLL:
+    """Load libcpm_hip.so from the package directory; fail loudly when it is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not LIB_PATH.exists():
+        raise ImportError(
+            f"{LIB_PATH} is missing: the HIP extension has not been built. Run "
+            "`python -c 'import __graft_entry__ as g; g.build()'` (hipcc --offload-arch=gfx950). "
+            "There is no CPU fallback.")
+    lib = C.CDLL(str(LIB_PATH))
+    vp, i32, f32, u32, u64, sz = C.c_void_p, C.c_int32, C.c_float, C.c_uint32, C.c_uint64, C.c_size_t
+    P = C.POINTER
+    sig = {
+        "cpm_create": (i32, [i32, P(vp)]),
+        "cpm_destroy": (None, [vp]),
+        "cpm_last_error_string": (C.c_char_p, [vp]),
+        "cpm_abi_version": (i32, []),
+        "cpm_glibc_rand_sequence": (None, [u32, vp, sz]),
+        "cpm_seed_streams": (i32, [vp, vp, sz, u64, vp]),
+        "cpm_random_fill": (i32, [vp, vp, sz, i32, vp, vp]),
+        "cpm_volume_desc_default": (None, [P(VolumeDesc), P(i32 * 3), i32]),
+        "cpm_volume_create": (i32, [vp, P(VolumeDesc), vp, i32, vp, P(vp)]),
+        "cpm_volume_update": (i32, [vp, vp, vp, i32, vp]),
+        "cpm_volume_destroy": (None, [vp, vp]),
+        "cpm_tf_create": (i32, [vp, vp, i32, i32, vp, P(vp)]),
+        "cpm_tf_update": (i32, [vp, vp, vp, i32, vp]),
+        "cpm_tf_destroy": (None, [vp, vp]),
+        "cpm_uniform_samples_2d": (i32, [vp, i32, i32, vp, vp]),
+        "cpm_directional_light_samples": (i32, [vp, vp, i32, P(f32 * 4), P(f32 * 4), P(f32 * 4), P(f32 * 4), P(f32 * 4), f32, vp, vp]),
+        "cpm_point_light_samples": (i32, [vp, vp, i32, P(f32 * 4), P(f32 * 4), vp, vp]),
+        "cpm_light_sample_box_intersection": (i32, [vp, vp, i32, P(f32 * 8), vp, vp]),
+        "cpm_light_sample_mesh_intersection": (i32, [vp, vp, vp, i32, vp, i32, vp, vp]),
+        "cpm_trace": (i32, [vp, vp, vp, vp, P(f32 * 8), P(TraceParams), vp, vp, vp, i32, vp, vp, vp]),
+        "cpm_grid_desc_default": (None, [P(GridDesc), P(i32 * 3), i32]),
+        "cpm_relative_irradiance_scale": (f32, [C.c_double, C.c_double]),
+        "cpm_splat": (i32, [vp, vp, i32, P(GridDesc), f32, f32, vp, vp]),
+        "cpm_splat_selected": (i32, [vp, vp, vp, i32, P(GridDesc), f32, f32, f32, i32, i32, vp, vp]),
+        "cpm_copy_indexed_photons": (i32, [vp, vp, vp, i32, f32, i32, i32, vp, i32, vp]),
+        "cpm_sort_pairs": (i32, [vp, vp, vp, sz, i32, vp]),
+        "cpm_sort_keys": (i32, [vp, vp, sz, i32, vp]),
+        "cpm_bin": (i32, [vp, vp, i32, P(GridDesc), vp, vp, vp, vp]),
+        "cpm_gather": (i32, [vp, vp, vp, i32, P(GridDesc), f32, f32, i32, vp, vp]),
+        "cpm_volume_minmax": (i32, [vp, vp, i32, vp, vp]),
+        "cpm_volume_difference": (i32, [vp, vp, vp, i32, vp, vp]),
+        "cpm_importance_tf": (i32, [vp, vp, vp, vp, i32, vp, vp, i32, vp, vp]),
+        "cpm_photon_importance": (i32, [vp, vp, P(i32 * 3), P(f32 * 3), P(f32 * 16), vp, i32, vp, vp, i32, i32, i32, i32, vp, vp]),
+        "cpm_photon_importance_equal": (i32, [vp, i32, i32, i32, i32, vp, vp]),
+        "cpm_reset_importance": (i32, [vp, vp, sz, sz, vp]),
+        "cpm_select_recompute": (i32, [vp, vp, sz, vp, vp, vp]),
+        # include/cpm/cpm_profile.h (measurement hooks)
+        "cpm_debug_set_step_counter": (None, [vp]),
+        "cpm_profile_enable": (None, [vp, i32]),
+        "cpm_profile_reset": (None, [vp]),
+        "cpm_profile_collect": (i32, [vp]),
+        "cpm_profile_name": (C.c_char_p, [vp, i32]),
+        "cpm_profile_total_ms": (C.c_double, [vp, i32]),
+        "cpm_profile_calls": (C.c_long, [vp, i32]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(lib, name)  # AttributeError here = a declared symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def default_volume_desc(dims, dtype) -> VolumeDesc:
+    d = VolumeDesc()
+    load_library().cpm_volume_desc_default(C.byref(d), C.byref((C.c_int32 * 3)(*dims)), dtype)
+    return d
+
+
+def default_grid_desc(dims, channels=1) -> GridDesc:
+    d = GridDesc()
+    load_library().cpm_grid_desc_default(C.byref(d), C.byref((C.c_int32 * 3)(*dims)), channels)
+    return d
+
+
+def relative_irradiance_scale(radius_relative_to_scene: float, n_photons: float) -> float:
+    return float(load_library().cpm_relative_irradiance_scale(radius_relative_to_scene, n_photons))
+
+
+def glibc_rand_sequence(seed: int, n: int):
+    import numpy as np
+    out = np.zeros(n, dtype=np.uint32)
+    load_library().cpm_glibc_rand_sequence(seed, out.ctypes.data, n)
+    return out
+
+
+def _f4(v):
+    v = list(v) + [0.0] * (4 - len(v))
+    return (C.c_float * 4)(*v[:4])
+
+
+_TORCH_DTYPES = None
+
+
+def _dtype_code(t):
+    import torch
+    return {torch.uint8: CPM_U8, torch.uint16: CPM_U16, torch.int16: CPM_U16, torch.float32: CPM_F32}[t.dtype]
+
+
+class Context:
+    """One libcpm_hip context on one GPU.  Methods take torch tensors living on that GPU."""
+
+    def __init__(self, device: int = 0):
+        import torch
+        self.lib = load_library()
+        self.device_index = device
+        h = C.c_void_p()
+        rc = self.lib.cpm_create(device, C.byref(h))
+        if rc != CPM_OK:
+            raise CpmError(rc, self.lib.cpm_last_error_string(None).decode())
+        self.h = h
+        self.torch = torch
+        self.device = torch.device("cuda", device)
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.cpm_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- plumbing
+    def _stream(self):
+        return C.c_void_p(self.torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _ptr(self, t, dtype=None):
+        if t is None:
+            return None
+        if not t.is_cuda or t.device.index != self.device_index:
+            raise ValueError("tensor is not on this context's GPU")
+        if not t.is_contiguous():
+            raise ValueError("tensor must be contiguous")
+        if dtype is not None and t.dtype != dtype:
+            raise ValueError(f"expected dtype {dtype}, got {t.dtype}")
+        return C.c_void_p(t.data_ptr())
+
+    def _check(self, rc):
+        if rc != CPM_OK:
+            raise CpmError(rc, self.lib.cpm_last_error_string(self.h).decode())
+
+    # -- measurement hooks
+    def profile_enable(self, on=True):
+        self.lib.cpm_profile_enable(self.h, int(on))
+
+    def profile_reset(self):
+        self.lib.cpm_profile_reset(self.h)
+
+    def profile_collect(self):
+        """{kernel name: (total ms, calls)} of every launch since the last reset."""
+        n = self.lib.cpm_profile_collect(self.h)
+        return {self.lib.cpm_profile_name(self.h, i).decode(): (self.lib.cpm_profile_total_ms(self.h, i),
+                                                                 self.lib.cpm_profile_calls(self.h, i)) for i in range(n)}
+
+    def set_step_counter(self, counter_tensor):
+        """int64[1] device tensor that trace launches add their Woodcock iteration counts to (None = off)."""
+        self.lib.cpm_debug_set_step_counter(self._ptr(counter_tensor))
+
+    # -- RNG
+    def seed_streams(self, state, gap=1 << 40):
+        """state: uint32 [n, 2] with state[:, 0] = per-stream base offsets; in place."""
+        self._check(self.lib.cpm_seed_streams(self.h, self._ptr(state), state.shape[0], gap, self._stream()))
+
+    def random_fill(self, state, draws):
+        out = self.torch.empty((draws, state.shape[0]), dtype=self.torch.float32, device=self.device)
+        self._check(self.lib.cpm_random_fill(self.h, self._ptr(state), state.shape[0], draws, self._ptr(out), self._stream()))
+        return out
+
+    # -- volume / tf
+    def volume_create(self, voxels, desc: VolumeDesc | None = None):
+        """voxels: torch tensor [z, y, x] (u8 / u16-as-int16|uint16 / f32) on the GPU, or a numpy array on the host."""
+        import numpy as np
+        if isinstance(voxels, np.ndarray):
+            code = {np.dtype(np.uint8): CPM_U8, np.dtype(np.uint16): CPM_U16, np.dtype(np.float32): CPM_F32}[voxels.dtype]
+            dims = voxels.shape[::-1]
+            voxels = np.ascontiguousarray(voxels)
+            ptr, is_dev = C.c_void_p(voxels.ctypes.data), 0
+        else:
+            code = _dtype_code(voxels)
+            dims = tuple(voxels.shape[::-1])
+            ptr, is_dev = self._ptr(voxels), 1
+        if desc is None:
+            desc = default_volume_desc(dims, code)
+        h = C.c_void_p()
+        self._check(self.lib.cpm_volume_create(self.h, C.byref(desc), ptr, is_dev, self._stream(), C.byref(h)))
+        return Volume(self, h, desc)
+
+    def tf_create(self, rgba):
+        """rgba: [width, 4] float32, torch (GPU) or numpy (host)."""
+        import numpy as np
+        if isinstance(rgba, np.ndarray):
+            rgba = np.ascontiguousarray(rgba, dtype=np.float32)
+            ptr, is_dev, width = C.c_void_p(rgba.ctypes.data), 0, rgba.shape[0]
+        else:
+            ptr, is_dev, width = self._ptr(rgba, self.torch.float32), 1, rgba.shape[0]
+        h = C.c_void_p()
+        self._check(self.lib.cpm_tf_create(self.h, ptr, width, is_dev, self._stream(), C.byref(h)))
+        return TransferFunction(self, h, width)
+
+    # -- emission
+    def uniform_samples_2d(self, nx, ny):
+        out = self.torch.empty((nx * ny, 4), dtype=self.torch.float32, device=self.device)
+        self._check(self.lib.cpm_uniform_samples_2d(self.h, nx, ny, self._ptr(out), self._stream()))
+        return out
+
+    def directional_light_samples(self, samples, radiance, direction, origin, tangent_u, tangent_v, area):
+        n = samples.shape[0]
+        out = self.torch.empty((n, 8), dtype=self.torch.float32, device=self.device)
+        self._check(self.lib.cpm_directional_light_samples(
+            self.h, self._ptr(samples), n, C.byref(_f4(radiance)), C.byref(_f4(direction)), C.byref(_f4(origin)),
+            C.byref(_f4(tangent_u)), C.byref(_f4(tangent_v)), float(area), self._ptr(out), self._stream()))
+        return out
+
+    def point_light_samples(self, samples, radiance, position):
+        n = samples.shape[0]
+        out = self.torch.empty((n, 8), dtype=self.torch.float32, device=self.device)
+        self._check(self.lib.cpm_point_light_samples(self.h, self._ptr(samples), n, C.byref(_f4(radiance)),
+                                                     C.byref(_f4(position)), self._ptr(out), self._stream()))
+        return out
+
+    def light_sample_box_intersection(self, light_samples, aabb):
+        n = light_samples.shape[0]
+        out = self.torch.empty((n, 2), dtype=self.torch.float32, device=self.device)
+        self._check(self.lib.cpm_light_sample_box_intersection(self.h, self._ptr(light_samples), n,
+                                                               C.byref((C.c_float * 8)(*aabb)), self._ptr(out), self._stream()))
+        return out
+
+    def light_sample_mesh_intersection(self, vertices, indices, light_samples):
+        n = light_samples.shape[0]
+        out = self.torch.empty((n, 2), dtype=self.torch.float32, device=self.device)
+        self._check(self.lib.cpm_light_sample_mesh_intersection(self.h, self._ptr(vertices), self._ptr(indices),
+                                                                indices.numel(), self._ptr(light_samples), n,
+                                                                self._ptr(out), self._stream()))
+        return out
+
+    # -- trace
+    def trace(self, vol, tf, aabb, params: TraceParams, light_samples, isect, rng_state, photons,
+              recompute_indices=None, n_recompute=0, tf_scattering=None):
+        self._check(self.lib.cpm_trace(
+            self.h, vol.h, tf.h, tf_scattering.h if tf_scattering is not None else None,
+            C.byref((C.c_float * 8)(*aabb)), C.byref(params), self._ptr(light_samples), self._ptr(isect),
+            self._ptr(recompute_indices), n_recompute, self._ptr(rng_state), self._ptr(photons), self._stream()))
+
+    # -- light volume
+    def splat(self, photons, total_photons, grid: GridDesc, radius, scale, out):
+        self._check(self.lib.cpm_splat(self.h, self._ptr(photons), total_photons, C.byref(grid), radius, scale,
+                                       self._ptr(out), self._stream()))
+
+    def splat_selected(self, photons, indices, n_indices, grid, radius, scale, multiplier, n_photons, n_interactions, out):
+        self._check(self.lib.cpm_splat_selected(self.h, self._ptr(photons), self._ptr(indices), n_indices, C.byref(grid),
+                                                radius, scale, multiplier, n_photons, n_interactions, self._ptr(out),
+                                                self._stream()))
+
+    def copy_indexed_photons(self, photons, indices, n_indices, multiplier, n_photons, n_interactions, aligned, out_offset=0):
+        self._check(self.lib.cpm_copy_indexed_photons(self.h, self._ptr(photons), self._ptr(indices), n_indices, multiplier,
+                                                      n_photons, n_interactions, self._ptr(aligned), out_offset, self._stream()))
+
+    def sort_pairs(self, keys, values, key_bits=0):
+        self._check(self.lib.cpm_sort_pairs(self.h, self._ptr(keys), self._ptr(values), keys.numel(), key_bits, self._stream()))
+
+    def sort_keys(self, keys, key_bits=0):
+        self._check(self.lib.cpm_sort_keys(self.h, self._ptr(keys), keys.numel(), key_bits, self._stream()))
+
+    def bin(self, photons, n, grid: GridDesc, order, cell_start, sorted_pos_power):
+        self._check(self.lib.cpm_bin(self.h, self._ptr(photons), n, C.byref(grid), self._ptr(order), self._ptr(cell_start),
+                                     self._ptr(sorted_pos_power), self._stream()))
+
+    def gather(self, sorted_pos_power, cell_start, n, grid, radius, scale, out, accumulate=False):
+        self._check(self.lib.cpm_gather(self.h, self._ptr(sorted_pos_power), self._ptr(cell_start), n, C.byref(grid), radius,
+                                        scale, int(accumulate), self._ptr(out), self._stream()))
+
+    # -- correlated
+    def volume_minmax(self, vol, region, out):
+        self._check(self.lib.cpm_volume_minmax(self.h, vol.h, region, self._ptr(out), self._stream()))
+
+    def volume_difference(self, cur, nxt, region, out):
+        self._check(self.lib.cpm_volume_difference(self.h, cur.h, nxt.h, region, self._ptr(out), self._stream()))
+
+    def importance_tf(self, minmax, n_cells, positions, colors, out, prev_minmax=None, volume_diff=None):
+        import numpy as np
+        positions = np.ascontiguousarray(positions, dtype=np.float32)
+        colors = np.ascontiguousarray(colors, dtype=np.float32)
+        self._check(self.lib.cpm_importance_tf(self.h, self._ptr(minmax), self._ptr(prev_minmax), self._ptr(volume_diff),
+                                               n_cells, positions.ctypes.data, colors.ctypes.data, positions.shape[0],
+                                               self._ptr(out), self._stream()))
+        self.torch.cuda.current_stream(self.device).synchronize()  # host arrays may now go away
+
+    def photon_importance(self, importance_grid, grid_dims, cell_size, texture_to_index, photons, photon_offset,
+                          light_samples, isect, n_light_samples, max_interactions, total_photons, importances,
+                          fix_exit_point=False):
+        self._check(self.lib.cpm_photon_importance(
+            self.h, self._ptr(importance_grid), C.byref((C.c_int32 * 3)(*grid_dims)), C.byref((C.c_float * 3)(*cell_size)),
+            C.byref((C.c_float * 16)(*texture_to_index)), self._ptr(photons), photon_offset, self._ptr(light_samples),
+            self._ptr(isect), n_light_samples, max_interactions, total_photons, int(fix_exit_point),
+            self._ptr(importances), self._stream()))
+
+    def photon_importance_equal(self, photon_offset, n_light_samples, percentage, iteration, importances):
+        self._check(self.lib.cpm_photon_importance_equal(self.h, photon_offset, n_light_samples, percentage, iteration,
+                                                         self._ptr(importances), self._stream()))
+
+    def reset_importance(self, importances, offset, n):
+        self._check(self.lib.cpm_reset_importance(self.h, self._ptr(importances), offset, n, self._stream()))
+
+    def select_recompute(self, importances, indices_out, n_changed):
+        self._check(self.lib.cpm_select_recompute(self.h, self._ptr(importances), importances.numel(), self._ptr(indices_out),
+                                                  self._ptr(n_changed), self._stream()))
+
+
+class Volume:
+    def __init__(self, ctx: Context, h, desc: VolumeDesc):
+        self.ctx, self.h, self.desc = ctx, h, desc
+
+    @property
+    def dims(self):
+        return tuple(self.desc.dims)
+
+    def update(self, voxels):
+        import numpy as np
+        if isinstance(voxels, np.ndarray):
+            voxels = np.ascontiguousarray(voxels)
+            ptr, is_dev = C.c_void_p(voxels.ctypes.data), 0
+        else:
+            ptr, is_dev = self.ctx._ptr(voxels), 1
+        self.ctx._check(self.ctx.lib.cpm_volume_update(self.ctx.h, self.h, ptr, is_dev, self.ctx._stream()))
+
+    def __del__(self):
+        try:
+            if self.h and self.ctx.h:
+                self.ctx.lib.cpm_volume_destroy(self.ctx.h, self.h)
+        except Exception:
+            pass
+
+
+class TransferFunction:
+    def __init__(self, ctx: Context, h, width):
+        self.ctx, self.h, self.width = ctx, h, width
+
+    def update(self, rgba):
+        import numpy as np
+        if isinstance(rgba, np.ndarray):
+            rgba = np.ascontiguousarray(rgba, dtype=np.float32)
+            ptr, is_dev = C.c_void_p(rgba.ctypes.data), 0
+        else:
+            ptr, is_dev = self.ctx._ptr(rgba), 1
+        self.ctx._check(self.ctx.lib.cpm_tf_update(self.ctx.h, self.h, ptr, is_dev, self.ctx._stream()))
+
+    def __del__(self):
+        try:
+            if self.h and self.ctx.h:
+                self.ctx.lib.cpm_tf_destroy(self.ctx.h, self.h)
+        except Exception:
+            pass

@@ -1,0 +1,271 @@
+// cpm_core.hip -- context, volume / transfer-function residency, host helpers.
+#include <math.h>
+#include <stdlib.h>
+
+#include <new>
+
+#include "cpm_ctx.h"
+#include "cpm/cpm_profile.h"
+
+static thread_local std::string g_create_error;
+
+namespace cpm {
+
+int set_error(cpm_ctx* ctx, int status, const char* what, const char* detail) {
+    std::string msg = std::string(what ? what : "") + ": " + (detail ? detail : "");
+    if (ctx) ctx->last_error = msg; else g_create_error = msg;
+    return status;
+}
+
+void* scratch(cpm_ctx* ctx, int slot, size_t bytes) {
+    if (bytes == 0) bytes = 16;
+    if (ctx->scratch_bytes[slot] >= bytes) return ctx->scratch[slot];
+    if (ctx->scratch[slot]) { (void)hipFree(ctx->scratch[slot]); ctx->scratch[slot] = nullptr; ctx->scratch_bytes[slot] = 0; }
+    size_t want = bytes + bytes / 4 + 256;  // grow with slack
+    void* p = nullptr;
+    hipError_t e = hipMalloc(&p, want);
+    if (e != hipSuccess) { set_error(ctx, CPM_ERR_OUT_OF_MEMORY, "hipMalloc(scratch)", hipGetErrorString(e)); return nullptr; }
+    ctx->scratch[slot] = p;
+    ctx->scratch_bytes[slot] = want;
+    return p;
+}
+
+bool affine_from_matrix(const float m[16], Affine& out) {
+    // column-major: m[4*col + row]; require diag + translation only
+    const int offdiag[] = { 1, 2, 3, 4, 6, 7, 8, 9, 11 };
+    for (int i : offdiag) if (m[i] != 0.0f) return false;
+    if (m[15] != 1.0f) return false;
+    out.sx = m[0]; out.sy = m[5]; out.sz = m[10];
+    out.tx = m[12]; out.ty = m[13]; out.tz = m[14];
+    return true;
+}
+
+ProfScope::ProfScope(cpm_ctx* c, const char* name, hipStream_t stream) : ctx(c), s(stream) {
+    if (!ctx || !ctx->profiling) { ctx = nullptr; return; }
+    hipEvent_t a = nullptr;
+    if (ctx->prof_pool.size() >= 2) {
+        a = ctx->prof_pool.back(); ctx->prof_pool.pop_back();
+        b = ctx->prof_pool.back(); ctx->prof_pool.pop_back();
+    } else if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) {
+        ctx = nullptr;
+        return;
+    }
+    (void)hipEventRecord(a, s);
+    ctx->prof_pending.push_back({ name, a, b });
+}
+ProfScope::~ProfScope() {
+    if (ctx) (void)hipEventRecord(b, s);
+}
+
+}  // namespace cpm
+
+using namespace cpm;
+
+extern "C" {
+
+int cpm_abi_version(void) { return CPM_ABI_VERSION; }
+
+// ---- measurement hooks (include/cpm/cpm_profile.h)
+void cpm_profile_enable(cpm_ctx* ctx, int on) { if (ctx) ctx->profiling = on != 0; }
+void cpm_profile_reset(cpm_ctx* ctx) {
+    if (!ctx) return;
+    (void)hipDeviceSynchronize();
+    for (auto& r : ctx->prof_pending) { ctx->prof_pool.push_back(r.a); ctx->prof_pool.push_back(r.b); }
+    ctx->prof_pending.clear();
+    ctx->prof_entries.clear();
+}
+int cpm_profile_collect(cpm_ctx* ctx) {
+    if (!ctx) return 0;
+    (void)hipDeviceSynchronize();
+    for (auto& r : ctx->prof_pending) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) {
+            std::string name(r.name);
+            while (!name.empty() && name.front() == '(') name.erase(name.begin());
+            while (!name.empty() && name.back() == ')') name.pop_back();
+            cpm_prof_entry* e = nullptr;
+            for (auto& x : ctx->prof_entries) if (x.name == name) { e = &x; break; }
+            if (!e) { ctx->prof_entries.push_back({ name, 0.0, 0 }); e = &ctx->prof_entries.back(); }
+            e->total_ms += ms;
+            e->calls += 1;
+        }
+        ctx->prof_pool.push_back(r.a);
+        ctx->prof_pool.push_back(r.b);
+    }
+    ctx->prof_pending.clear();
+    return (int)ctx->prof_entries.size();
+}
+const char* cpm_profile_name(const cpm_ctx* ctx, int i) { return (ctx && i >= 0 && i < (int)ctx->prof_entries.size()) ? ctx->prof_entries[i].name.c_str() : ""; }
+double cpm_profile_total_ms(const cpm_ctx* ctx, int i) { return (ctx && i >= 0 && i < (int)ctx->prof_entries.size()) ? ctx->prof_entries[i].total_ms : 0.0; }
+long cpm_profile_calls(const cpm_ctx* ctx, int i) { return (ctx && i >= 0 && i < (int)ctx->prof_entries.size()) ? ctx->prof_entries[i].calls : 0; }
+
+int cpm_create(int device, cpm_ctx** out) {
+    if (!out) return set_error(nullptr, CPM_ERR_INVALID_ARGUMENT, "cpm_create", "out == NULL");
+    *out = nullptr;
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0)
+        return set_error(nullptr, CPM_ERR_NO_DEVICE, "cpm_create",
+                         "no HIP device visible; libcpm_hip has no CPU fallback");
+    if (device < 0 || device >= count)
+        return set_error(nullptr, CPM_ERR_INVALID_ARGUMENT, "cpm_create", "device index out of range");
+    e = hipSetDevice(device);
+    if (e != hipSuccess) return set_error(nullptr, CPM_ERR_DEVICE, "hipSetDevice", hipGetErrorString(e));
+    cpm_ctx* ctx = new (std::nothrow) cpm_ctx();
+    if (!ctx) return set_error(nullptr, CPM_ERR_OUT_OF_MEMORY, "cpm_create", "host allocation failed");
+    ctx->device = device;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess) ctx->num_cus = prop.multiProcessorCount;
+    *out = ctx;
+    return CPM_OK;
+}
+
+void cpm_destroy(cpm_ctx* ctx) {
+    if (!ctx) return;
+    for (int i = 0; i < 8; ++i) if (ctx->scratch[i]) (void)hipFree(ctx->scratch[i]);
+    for (auto& r : ctx->prof_pending) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+    for (auto e : ctx->prof_pool) (void)hipEventDestroy(e);
+    delete ctx;
+}
+
+const char* cpm_last_error_string(const cpm_ctx* ctx) {
+    return ctx ? ctx->last_error.c_str() : g_create_error.c_str();
+}
+
+// glibc random_r TYPE_3 (what srand()/rand() run), see cpm.h
+void cpm_glibc_rand_sequence(uint32_t seed, uint32_t* out, size_t n) {
+    const size_t total = 344 + n;
+    int32_t* r = (int32_t*)malloc(total * sizeof(int32_t));
+    if (!r) return;
+    if (seed == 0) seed = 1;
+    r[0] = (int32_t)seed;
+    for (int i = 1; i < 31; ++i) {
+        long long hi = r[i - 1] / 127773, lo = r[i - 1] % 127773;
+        long long w = 16807 * lo - 2836 * hi;
+        if (w < 0) w += 2147483647;
+        r[i] = (int32_t)w;
+    }
+    for (int i = 31; i < 34; ++i) r[i] = r[i - 31];
+    for (size_t i = 34; i < total; ++i) r[i] = (int32_t)((uint32_t)r[i - 31] + (uint32_t)r[i - 3]);
+    for (size_t k = 0; k < n; ++k) out[k] = ((uint32_t)r[344 + k]) >> 1;
+    free(r);
+}
+
+static void default_matrices(const int32_t dims[3], float t2i[16], float i2t[16]) {
+    memset(t2i, 0, 16 * sizeof(float));
+    memset(i2t, 0, 16 * sizeof(float));
+    for (int a = 0; a < 3; ++a) {
+        // textureToIndex = scale(dim) then translate(-0.5); indexToTexture its inverse
+        t2i[5 * a] = (float)dims[a];
+        t2i[12 + a] = -0.5f;
+        i2t[5 * a] = 1.0f / (float)dims[a];
+        i2t[12 + a] = 0.5f / (float)dims[a];
+    }
+    t2i[15] = 1.0f;
+    i2t[15] = 1.0f;
+}
+
+void cpm_volume_desc_default(cpm_volume_desc* d, const int32_t dims[3], int32_t dtype) {
+    memset(d, 0, sizeof(*d));
+    for (int a = 0; a < 3; ++a) d->dims[a] = dims[a];
+    d->dtype = dtype;
+    d->format_scaling = 0.0f;
+    d->format_offset = 0.0f;
+    default_matrices(dims, d->texture_to_index, d->index_to_texture);
+}
+
+void cpm_grid_desc_default(cpm_grid_desc* d, const int32_t dims[3], int32_t channels) {
+    memset(d, 0, sizeof(*d));
+    for (int a = 0; a < 3; ++a) d->dims[a] = dims[a];
+    d->channels = channels;
+    default_matrices(dims, d->texture_to_index, d->index_to_texture);
+}
+
+float cpm_relative_irradiance_scale(double radius, double n_photons) {
+    const double pi = 3.14159265358979323846;
+    double vol = radius * radius * radius * (pi * 4. / 3.);
+    return (float)((1. / pi) / (vol * n_photons));
+}
+
+static size_t dtype_size(int dtype) { return dtype == CPM_U8 ? 1 : (dtype == CPM_U16 ? 2 : 4); }
+
+int cpm_volume_create(cpm_ctx* ctx, const cpm_volume_desc* desc, const void* voxels, int is_device,
+                      cpm_stream stream, cpm_volume** out) {
+    if (!ctx) return CPM_ERR_INVALID_ARGUMENT;
+    CPM_REQUIRE(ctx, desc && voxels && out, "cpm_volume_create: null argument");
+    CPM_REQUIRE(ctx, desc->dtype >= CPM_U8 && desc->dtype <= CPM_F32, "cpm_volume_create: dtype");
+    CPM_REQUIRE(ctx, desc->dims[0] >= 2 && desc->dims[1] >= 1 && desc->dims[2] >= 1, "cpm_volume_create: dims (x >= 2)");
+    Affine a;
+    if (!affine_from_matrix(desc->texture_to_index, a) || !affine_from_matrix(desc->index_to_texture, a))
+        return set_error(ctx, CPM_ERR_UNSUPPORTED, "cpm_volume_create", "texture/index matrices must be scale + translate");
+    cpm_volume* v = new (std::nothrow) cpm_volume();
+    if (!v) return set_error(ctx, CPM_ERR_OUT_OF_MEMORY, "cpm_volume_create", "host allocation failed");
+    v->desc = *desc;
+    v->bytes = (size_t)desc->dims[0] * desc->dims[1] * desc->dims[2] * dtype_size(desc->dtype);
+    hipError_t e = hipMalloc(&v->voxels, v->bytes + 16);  // tail pad: paired x loads never leave the allocation
+    if (e != hipSuccess) { delete v; return set_error(ctx, CPM_ERR_OUT_OF_MEMORY, "hipMalloc(volume)", hipGetErrorString(e)); }
+    *out = v;
+    int rc = cpm_volume_update(ctx, v, voxels, is_device, stream);
+    if (rc != CPM_OK) { cpm_volume_destroy(ctx, v); *out = nullptr; }
+    return rc;
+}
+
+int cpm_volume_update(cpm_ctx* ctx, cpm_volume* vol, const void* voxels, int is_device, cpm_stream stream) {
+    if (!ctx) return CPM_ERR_INVALID_ARGUMENT;
+    CPM_REQUIRE(ctx, vol && voxels, "cpm_volume_update: null argument");
+    hipStream_t s = (hipStream_t)stream;
+    CPM_HIP_CHECK(ctx, hipMemsetAsync((char*)vol->voxels + vol->bytes, 0, 16, s));
+    CPM_HIP_CHECK(ctx, hipMemcpyAsync(vol->voxels, voxels, vol->bytes,
+                                      is_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, s));
+    if (!is_device) CPM_HIP_CHECK(ctx, hipStreamSynchronize(s));  // caller may free the host buffer
+    return CPM_OK;
+}
+
+void cpm_volume_destroy(cpm_ctx* ctx, cpm_volume* vol) {
+    (void)ctx;
+    if (!vol) return;
+    if (vol->voxels) (void)hipFree(vol->voxels);
+    delete vol;
+}
+
+__global__ void tf_alpha_kernel(const float* __restrict__ rgba, int width, float* __restrict__ alpha) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < width) alpha[i] = rgba[4 * i + 3];
+}
+
+int cpm_tf_create(cpm_ctx* ctx, const float* rgba, int width, int is_device, cpm_stream stream, cpm_tf** out) {
+    if (!ctx) return CPM_ERR_INVALID_ARGUMENT;
+    CPM_REQUIRE(ctx, rgba && out, "cpm_tf_create: null argument");
+    CPM_REQUIRE(ctx, width >= 2 && width <= 16384, "cpm_tf_create: width must be in [2, 16384]");
+    cpm_tf* tf = new (std::nothrow) cpm_tf();
+    if (!tf) return set_error(ctx, CPM_ERR_OUT_OF_MEMORY, "cpm_tf_create", "host allocation failed");
+    tf->width = width;
+    hipError_t e = hipMalloc((void**)&tf->rgba, (size_t)width * 5 * sizeof(float));
+    if (e != hipSuccess) { delete tf; return set_error(ctx, CPM_ERR_OUT_OF_MEMORY, "hipMalloc(tf)", hipGetErrorString(e)); }
+    tf->alpha = tf->rgba + (size_t)width * 4;
+    *out = tf;
+    int rc = cpm_tf_update(ctx, tf, rgba, is_device, stream);
+    if (rc != CPM_OK) { cpm_tf_destroy(ctx, tf); *out = nullptr; }
+    return rc;
+}
+
+int cpm_tf_update(cpm_ctx* ctx, cpm_tf* tf, const float* rgba, int is_device, cpm_stream stream) {
+    if (!ctx) return CPM_ERR_INVALID_ARGUMENT;
+    CPM_REQUIRE(ctx, tf && rgba, "cpm_tf_update: null argument");
+    hipStream_t s = (hipStream_t)stream;
+    CPM_HIP_CHECK(ctx, hipMemcpyAsync(tf->rgba, rgba, (size_t)tf->width * 4 * sizeof(float),
+                                      is_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, s));
+    CPM_LAUNCH(ctx, tf_alpha_kernel, dim3(div_up(tf->width, 256)), dim3(256), 0, s, tf->rgba, tf->width, tf->alpha);
+    CPM_LAUNCH_CHECK(ctx, "tf_alpha_kernel");
+    if (!is_device) CPM_HIP_CHECK(ctx, hipStreamSynchronize(s));
+    return CPM_OK;
+}
+
+void cpm_tf_destroy(cpm_ctx* ctx, cpm_tf* tf) {
+    (void)ctx;
+    if (!tf) return;
+    if (tf->rgba) (void)hipFree(tf->rgba);
+    delete tf;
+}
+
+}  // extern "C"

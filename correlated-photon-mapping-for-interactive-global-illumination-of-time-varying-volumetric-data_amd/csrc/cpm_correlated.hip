@@ -1,0 +1,428 @@
+// cpm_correlated.hip -- helpers of the correlated re-trace (C1-C6, S2-S4): min/max bricks,
+// temporal difference bricks, TF-difference importance per brick, per-photon importance by
+// DDA through the importance grid, and the fused threshold + count + iota + sort selection.
+#include "cpm_ctx.h"
+
+using namespace cpm;
+
+namespace cpm {
+int radix_sort(cpm_ctx* ctx, uint32_t* keys, uint32_t* vals, size_t n, int key_bits, hipStream_t s);
+}
+
+namespace {
+
+struct BrickVol {
+    const void* voxels;
+    int dx, dy, dz, dtype;
+    int ox, oy, oz, region;
+    float norm, offset, one_minus_scaling;
+};
+
+CPM_DEV float raw_voxel(const void* v, int dtype, size_t idx) {
+    if (dtype == CPM_U8) return (float)static_cast<const uint8_t*>(v)[idx];
+    if (dtype == CPM_U16) return (float)static_cast<const uint16_t*>(v)[idx];
+    return static_cast<const float*>(v)[idx];
+}
+
+// volumeMinMaxKernel (ref uniformgridcl/cl/uniformgrid/volumeminmax.cl:33-61).  One wave per
+// brick: lane = one (y, z) row of the brick, contiguous in x; min/max are order-free, so the
+// wave reduction gives the reference's values exactly.
+__global__ __launch_bounds__(64) void minmax_kernel(BrickVol V, uint16_t* __restrict__ out) {
+    const int brick = blockIdx.x;
+    const int gx = brick % V.ox, gy = (brick / V.ox) % V.oy, gz = brick / (V.ox * V.oy);
+    const int x0 = gx * V.region, y0 = gy * V.region, z0 = gz * V.region;
+    const int ex = min(x0 + V.region, V.dx), ey = min(y0 + V.region, V.dy), ez = min(z0 + V.region, V.dz);
+    float mn = kFltMax, mx = 0.f;
+    const int rows = V.region * V.region;
+    for (int r = threadIdx.x; r < rows; r += 64) {
+        int y = y0 + r % V.region, z = z0 + r / V.region;
+        if (y >= ey || z >= ez) continue;
+        size_t base = (size_t)V.dx * ((size_t)y + (size_t)V.dy * (size_t)z);
+        for (int x = x0; x < ex; ++x) {
+            float s = raw_voxel(V.voxels, V.dtype, base + x) * V.norm;
+            float val = (s + V.offset) * V.one_minus_scaling;
+            mn = min_(mn, val);
+            mx = max_(mx, val);
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        mn = min_(mn, __shfl_down(mn, off, 64));
+        mx = max_(mx, __shfl_down(mx, off, 64));
+    }
+    if (threadIdx.x == 0) {
+        out[2 * (size_t)brick] = (uint16_t)__builtin_rintf(min_(max_(mn, 0.f), 1.f) * 65535.f);
+        out[2 * (size_t)brick + 1] = (uint16_t)__builtin_rintf(min_(max_(mx, 0.f), 1.f) * 65535.f);
+    }
+}
+
+// VolumeRAMDifferenceAnalysisDispatcher (ref uniformgridcl/processors/dynamicvolumedifferenceanalysis.h:96-151):
+// mean |b - a| per brick over the format's range; integer formats sum exactly (u64),
+// float volumes are summed by one lane in the reference's x-y-z order (double).
+__global__ __launch_bounds__(64) void difference_kernel(BrickVol A, const void* __restrict__ bvox, double range,
+                                                        float* __restrict__ out) {
+    const int brick = blockIdx.x;
+    const int gx = brick % A.ox, gy = (brick / A.ox) % A.oy, gz = brick / (A.ox * A.oy);
+    const int x0 = gx * A.region, y0 = gy * A.region, z0 = gz * A.region;
+    const int ex = min(x0 + A.region, A.dx), ey = min(y0 + A.region, A.dy), ez = min(z0 + A.region, A.dz);
+    const double cnt = (double)A.region * A.region * A.region;
+    if (A.dtype == CPM_F32) {
+        if (threadIdx.x != 0) return;
+        double sum = 0;
+        for (int z = z0; z < ez; ++z)
+            for (int y = y0; y < ey; ++y)
+                for (int x = x0; x < ex; ++x) {
+                    size_t i = (size_t)x + (size_t)A.dx * ((size_t)y + (size_t)A.dy * (size_t)z);
+                    sum += fabs((double)static_cast<const float*>(bvox)[i] - (double)static_cast<const float*>(A.voxels)[i]);
+                }
+        out[brick] = (float)((sum / cnt) / range);
+        return;
+    }
+    unsigned long long sum = 0;
+    const int rows = A.region * A.region;
+    for (int r = threadIdx.x; r < rows; r += 64) {
+        int y = y0 + r % A.region, z = z0 + r / A.region;
+        if (y >= ey || z >= ez) continue;
+        size_t base = (size_t)A.dx * ((size_t)y + (size_t)A.dy * (size_t)z);
+        for (int x = x0; x < ex; ++x) {
+            int a, b;
+            if (A.dtype == CPM_U8) { a = static_cast<const uint8_t*>(A.voxels)[base + x]; b = static_cast<const uint8_t*>(bvox)[base + x]; }
+            else { a = static_cast<const uint16_t*>(A.voxels)[base + x]; b = static_cast<const uint16_t*>(bvox)[base + x]; }
+            sum += (unsigned long long)(a > b ? a - b : b - a);
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) sum += __shfl_down(sum, off, 64);
+    if (threadIdx.x == 0) out[brick] = (float)(((double)sum / cnt) / range);
+}
+
+CPM_DEV float4 mix4(float4 a, float4 b, float t) {
+    return make_float4(a.x + (b.x - a.x) * t, a.y + (b.y - a.y) * t, a.z + (b.z - a.z) * t, a.w + (b.w - a.w) * t);
+}
+CPM_DEV float4 min4(float4 a, float4 b) { return make_float4(min_(a.x, b.x), min_(a.y, b.y), min_(a.z, b.z), min_(a.w, b.w)); }
+CPM_DEV float4 max4(float4 a, float4 b) { return make_float4(max_(a.x, b.x), max_(a.y, b.y), max_(a.z, b.z), max_(a.w, b.w)); }
+
+// importanceForRangeTF + tfPointsImportance with -D INCREMENTAL_TF_IMPORTANCE
+// (ref importancesamplingcl/cl/minmaxuniformgrid3dimportance.cl:163-169,186-227)
+CPM_DEV float importance_for_range_tf(float rx, float ry, const float* __restrict__ pos, const float4* __restrict__ col, int nPoints) {
+    int i = 0;
+    while (i < nPoints - 1 && rx > pos[i + 1]) ++i;
+    float4 color = mix4(col[i], col[i + 1], (rx - pos[i]) / (pos[i + 1] - pos[i]));
+    float4 mn = color, mx = color;
+    if (ry <= pos[i + 1]) {
+        float4 nc = mix4(col[i], col[i + 1], (ry - pos[i]) / (pos[i + 1] - pos[i]));
+        mx = max4(mx, nc);
+        return mx.x + mx.y + mx.z + mx.w;
+    } else {
+        float4 nc = col[i + 1];
+        mn = min4(mn, nc); mx = max4(mx, nc);
+        ++i;
+    }
+    while (i < nPoints - 1 && ry > pos[i + 1]) {
+        float4 nc = col[i + 1];
+        mn = min4(mn, nc); mx = max4(mx, nc);
+        ++i;
+    }
+    if (i < nPoints - 1) {
+        color = mix4(col[i], col[i + 1], (ry - pos[i]) / (pos[i + 1] - pos[i]));
+        mn = min4(mn, color); mx = max4(mx, color);
+    }
+    (void)mn;
+    return mx.x + mx.y + mx.z + mx.w;
+}
+
+// classifyMinMaxUniformGrid3DImportanceKernel / classifyTimeVarying... (ref ...importance.cl:269-330)
+__global__ __launch_bounds__(256) void importance_tf_kernel(const uint16_t* __restrict__ mm, const uint16_t* __restrict__ prev,
+                                                            const float* __restrict__ diff, int n_cells,
+                                                            const float* __restrict__ pos, const float4* __restrict__ col,
+                                                            int n_points, float* __restrict__ out) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_cells) return;
+    uint16_t lo = mm[2 * i], hi = mm[2 * i + 1];
+    if (prev) {
+        uint16_t pl = prev[2 * i], ph = prev[2 * i + 1];
+        lo = pl < lo ? pl : lo;
+        hi = ph > hi ? ph : hi;
+    }
+    float rx = (1.f / 65535.f) * (float)lo, ry = (1.f / 65535.f) * (float)hi;
+    float imp = importance_for_range_tf(rx, ry, pos, col, n_points);
+    out[i] = prev ? diff[i] * imp : imp;
+}
+
+struct ImpGrid {
+    const float* grid;
+    int dims[3];
+    float cell[3];
+    Affine t2i;
+};
+
+// setupUniformGridTraversal + stepToNextCellNextHit (OPTIMIZE_STEP_FOR_SIMD) driven by
+// uniformGridImportance (ref uniformgridcl/cl/uniformgrid/uniformgrid.cl:38-69,147-167;
+// progressivephotonmapping/cl/photonrecomputationdetector.cl:55-90)
+CPM_DEV float uniform_grid_importance(const ImpGrid& G, const float x1[3], const float x2[3]) {
+    int cell[3], cellEnd[3], di[3];
+    float dt[3], deltatx[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        float maxc = (float)(G.dims[a] - 1);
+        float cf = min_(max_(__builtin_floorf(x1[a] / G.cell[a]), 0.f), maxc);
+        cell[a] = (int)cf;
+        float ef = x2[a] / G.cell[a];
+        ef = min_(max_(ef, -1.f), (float)G.dims[a]);
+        int ei = (int)ef;
+        cellEnd[a] = ei < 0 ? 0 : (ei > G.dims[a] - 1 ? G.dims[a] - 1 : ei);
+        di[a] = (x1[a] < x2[a]) ? 1 : ((x1[a] > x2[a]) ? -1 : 0);
+        float invAbsDir = 1.f / __builtin_fabsf(x2[a] - x1[a]);
+        float minx = G.cell[a] * cf;
+        float maxx = minx + G.cell[a];
+        dt[a] = ((x1[a] > x2[a]) ? (x1[a] - minx) : (maxx - x1[a])) * invAbsDir;
+        deltatx[a] = G.cell[a] * invAbsDir;
+    }
+    float importance = 0.f, dt1 = 0.f;
+    bool cont = true;
+    int cap = G.dims[0] + G.dims[1] + G.dims[2] + 4;  // every wave reaches its exit, NaN input included
+    while (cont && cap-- > 0) {
+        float val = G.grid[(size_t)cell[0] + (size_t)cell[1] * G.dims[0] + (size_t)cell[2] * G.dims[0] * G.dims[1]];
+        float dt0 = dt1;
+        bool ax0 = dt[0] <= dt[1] && dt[0] <= dt[2];
+        bool ax1 = !ax0 && (dt[0] > dt[1] && dt[1] <= dt[2]);
+        // branch-free axis select (the reference's SIMD variant)
+        float dsel = ax0 ? dt[0] : (ax1 ? dt[1] : dt[2]);
+        int csel = ax0 ? cell[0] : (ax1 ? cell[1] : cell[2]);
+        int esel = ax0 ? cellEnd[0] : (ax1 ? cellEnd[1] : cellEnd[2]);
+        dt1 = dsel;
+        if (csel == esel) {
+            cont = false;
+        } else {
+            if (ax0) { dt[0] += deltatx[0]; cell[0] += di[0]; }
+            else if (ax1) { dt[1] += deltatx[1]; cell[1] += di[1]; }
+            else { dt[2] += deltatx[2]; cell[2] += di[2]; }
+        }
+        importance += val * (min_(1.f, dt1) - dt0);
+    }
+    float lx = x2[0] - x1[0], ly = x2[1] - x1[1], lz = x2[2] - x1[2];
+    float len = __builtin_sqrtf(fma_(lz, lz, fma_(ly, ly, lx * lx)));
+    return importance * len;
+}
+
+// convert_uint_sat_rtp(100 * imp) clamped to 0x7fffffff
+CPM_DEV uint32_t importance_to_uint(float imp100) {
+    if (!(imp100 > 0.f)) return 0u;
+    float c = __builtin_ceilf(imp100);
+    if (c >= 2147483648.f) return 2147483647u;
+    uint32_t u = (uint32_t)c;
+    return u > 2147483647u ? 2147483647u : u;
+}
+
+// photonRecomputationDetectorKernel (ref progressivephotonmapping/cl/photonrecomputationdetector.cl:92-157)
+__global__ __launch_bounds__(256) void photon_importance_kernel(ImpGrid G, const float* __restrict__ photons,
+                                                                int photon_offset, const float* __restrict__ ls,
+                                                                const float* __restrict__ isect, int n_light_samples,
+                                                                int max_interactions, int total_photons,
+                                                                int fix_exit_point, uint32_t* __restrict__ importances) {
+    int threadId = blockIdx.x * blockDim.x + threadIdx.x;
+    if (threadId >= n_light_samples) return;
+    const float bmin[3] = { 0.f, 0.f, 0.f }, bmax[3] = { 1.f, 1.f, 1.f };
+    float recomputationImportance = 0.f;
+    const float4* lsp = reinterpret_cast<const float4*>(ls) + 2 * (size_t)threadId;
+    float4 l0 = lsp[0], l1 = lsp[1];
+    f3 origin = { l0.x, l0.y, l0.z };
+    f3 direction = decode_direction_(l1.z, l1.w);
+    float2 ip = reinterpret_cast<const float2*>(isect)[threadId];
+    float tStart = ip.x, tEnd = ip.y;
+    if (tStart < tEnd) {
+        f3 entry = { fma_(tStart, direction.x, origin.x), fma_(tStart, direction.y, origin.y), fma_(tStart, direction.z, origin.z) };
+        for (int interaction = 0; interaction < max_interactions; ++interaction) {
+            size_t photonId = (size_t)photon_offset + (size_t)interaction * total_photons + threadId;
+            const float4* q = reinterpret_cast<const float4*>(photons) + 2 * photonId;
+            float4 a = q[0], b = q[1];
+            f3 exitp = { a.x, a.y, a.z };
+            if (a.x == kFltMax || a.y == kFltMax || a.z == kFltMax) {
+                if (interaction == 0) {
+                    if (fix_exit_point) {
+                        exitp.x = fma_(tEnd, direction.x, origin.x);
+                        exitp.y = fma_(tEnd, direction.y, origin.y);
+                        exitp.z = fma_(tEnd, direction.z, origin.z);
+                    } else {  // origin omitted
+                        exitp.x = tEnd * direction.x; exitp.y = tEnd * direction.y; exitp.z = tEnd * direction.z;
+                    }
+                } else if (entry.x == kFltMax || entry.y == kFltMax || entry.z == kFltMax) {
+                    break;
+                } else {
+                    float t0 = 0.f, t1 = kFltMax;
+                    f3 pd = decode_direction_(b.z, b.w);
+                    if (a.w != kFltMax && ray_box_(bmin, bmax, entry, pd, t0, t1)) {
+                        exitp.x = fma_(t1, pd.x, entry.x);
+                        exitp.y = fma_(t1, pd.y, entry.y);
+                        exitp.z = fma_(t1, pd.z, entry.z);
+                    } else {
+                        break;
+                    }
+                }
+            }
+            f3 ia = transform_(G.t2i, entry), ib = transform_(G.t2i, exitp);
+            float x1[3] = { ia.x + 0.5f, ia.y + 0.5f, ia.z + 0.5f };
+            float x2[3] = { ib.x + 0.5f, ib.y + 0.5f, ib.z + 0.5f };
+            recomputationImportance += uniform_grid_importance(G, x1, x2);
+            entry.x = a.x; entry.y = a.y; entry.z = a.z;
+        }
+    }
+    importances[photon_offset + threadId] -= importance_to_uint(100.f * recomputationImportance);
+}
+
+// photonRecomputationDetectorEqualImportanceKernel (ref ...detector.cl:160-194)
+__global__ __launch_bounds__(256) void photon_importance_equal_kernel(int photon_offset, int n_light_samples, int percentage,
+                                                                      int iteration, uint32_t* __restrict__ importances) {
+    int threadId = blockIdx.x * blockDim.x + threadIdx.x;
+    if (threadId >= n_light_samples) return;
+    float imp = 0.f;
+    int photonId = photon_offset + threadId;
+    if ((photonId + iteration) % (100 / percentage) == 0) imp = 1.f;
+    importances[photon_offset + threadId] -= importance_to_uint(100.f * imp);
+}
+
+__global__ __launch_bounds__(256) void fill_u32_kernel(uint32_t* __restrict__ p, size_t n, uint32_t v) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+
+// thresholdKernel + clogs::Reduce + indexToBufferKernel in one pass
+// (ref cl/threshold.cl:33-40, radixsortcl/ext/clogs/kernels/reduce.cl:96-154, cl/indextobuffer.cl:33-40)
+__global__ __launch_bounds__(256) void threshold_count_iota_kernel(const uint32_t* __restrict__ imp, size_t n,
+                                                                   uint32_t* __restrict__ idx, int* __restrict__ count) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    bool changed = false;
+    if (i < n) { changed = imp[i] < 2147483647u; idx[i] = (uint32_t)i; }
+    unsigned long long m = __ballot(changed);
+    if ((threadIdx.x & 63) == 0 && m) atomicAdd(count, (int)__popcll(m));
+}
+
+int make_brick_vol(cpm_ctx* ctx, const cpm_volume* vol, int region, BrickVol& V) {
+    if (!vol) return set_error(ctx, CPM_ERR_INVALID_ARGUMENT, "volume", "null");
+    if (region < 1 || region > 64) return set_error(ctx, CPM_ERR_INVALID_ARGUMENT, "region", "must be in [1, 64]");
+    const cpm_volume_desc& d = vol->desc;
+    V.voxels = vol->voxels;
+    V.dx = d.dims[0]; V.dy = d.dims[1]; V.dz = d.dims[2]; V.dtype = d.dtype;
+    V.region = region;
+    V.ox = (V.dx + region - 1) / region; V.oy = (V.dy + region - 1) / region; V.oz = (V.dz + region - 1) / region;
+    V.norm = d.dtype == CPM_U8 ? (1.0f / 255.0f) : (d.dtype == CPM_U16 ? (1.0f / 65535.0f) : 1.0f);
+    V.offset = d.format_offset;
+    V.one_minus_scaling = 1.0f - d.format_scaling;
+    return CPM_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int cpm_volume_minmax(cpm_ctx* ctx, const cpm_volume* vol, int region, uint16_t* minmax2, cpm_stream stream) {
+    if (!ctx) return CPM_ERR_INVALID_ARGUMENT;
+    BrickVol V;
+    int rc = make_brick_vol(ctx, vol, region, V);
+    if (rc) return rc;
+    CPM_REQUIRE(ctx, minmax2, "cpm_volume_minmax: null output");
+    CPM_LAUNCH(ctx, minmax_kernel, dim3(V.ox * V.oy * V.oz), dim3(64), 0, (hipStream_t)stream, V, minmax2);
+    CPM_LAUNCH_CHECK(ctx, "minmax_kernel");
+    return CPM_OK;
+}
+
+int cpm_volume_difference(cpm_ctx* ctx, const cpm_volume* cur, const cpm_volume* next, int region, float* out,
+                          cpm_stream stream) {
+    if (!ctx) return CPM_ERR_INVALID_ARGUMENT;
+    BrickVol V;
+    int rc = make_brick_vol(ctx, cur, region, V);
+    if (rc) return rc;
+    CPM_REQUIRE(ctx, next && out, "cpm_volume_difference: null argument");
+    CPM_REQUIRE(ctx, memcmp(cur->desc.dims, next->desc.dims, sizeof(cur->desc.dims)) == 0 && cur->desc.dtype == next->desc.dtype,
+                "cpm_volume_difference: volumes differ in shape or type");
+    double range = V.dtype == CPM_U8 ? 255.0 : (V.dtype == CPM_U16 ? 65535.0 : 1.0);
+    CPM_LAUNCH(ctx, difference_kernel, dim3(V.ox * V.oy * V.oz), dim3(64), 0, (hipStream_t)stream, V, next->voxels, range, out);
+    CPM_LAUNCH_CHECK(ctx, "difference_kernel");
+    return CPM_OK;
+}
+
+int cpm_importance_tf(cpm_ctx* ctx, const uint16_t* minmax2, const uint16_t* prev_minmax2, const float* volume_diff,
+                      int n_cells, const float* positions_host, const float* colors4_host, int n_points,
+                      float* importance, cpm_stream stream) {
+    if (!ctx) return CPM_ERR_INVALID_ARGUMENT;
+    CPM_REQUIRE(ctx, n_cells >= 0, "cpm_importance_tf: n_cells < 0");
+    CPM_REQUIRE(ctx, n_points >= 2 && n_points <= 4096, "cpm_importance_tf: n_points must be in [2, 4096]");
+    CPM_REQUIRE(ctx, positions_host && colors4_host, "cpm_importance_tf: null TF points");
+    CPM_REQUIRE(ctx, (prev_minmax2 == nullptr) == (volume_diff == nullptr), "cpm_importance_tf: prev_minmax2 and volume_diff go together");
+    if (n_cells == 0) return CPM_OK;
+    CPM_REQUIRE(ctx, minmax2 && importance, "cpm_importance_tf: null buffer");
+    hipStream_t s = (hipStream_t)stream;
+    // colours first (16-byte aligned), then positions
+    float* dev = (float*)scratch(ctx, CPM_SCR_SMALL, (size_t)n_points * 5 * sizeof(float));
+    if (!dev) return CPM_ERR_OUT_OF_MEMORY;
+    CPM_HIP_CHECK(ctx, hipMemcpyAsync(dev, colors4_host, (size_t)n_points * 4 * sizeof(float), hipMemcpyHostToDevice, s));
+    CPM_HIP_CHECK(ctx, hipMemcpyAsync(dev + (size_t)n_points * 4, positions_host, (size_t)n_points * sizeof(float), hipMemcpyHostToDevice, s));
+    CPM_LAUNCH(ctx, importance_tf_kernel, dim3(div_up(n_cells, 256)), dim3(256), 0, s, minmax2, prev_minmax2, volume_diff,
+                       n_cells, dev + (size_t)n_points * 4, reinterpret_cast<const float4*>(dev), n_points, importance);
+    CPM_LAUNCH_CHECK(ctx, "importance_tf_kernel");
+    return CPM_OK;
+}
+
+int cpm_photon_importance(cpm_ctx* ctx, const float* importance_grid, const int32_t grid_dims[3], const float cell_size[3],
+                          const float texture_to_index[16], const float* photons8, int photon_offset,
+                          const float* light_samples8, const float* isect2, int n_light_samples, int max_interactions,
+                          int total_photons, int fix_exit_point, uint32_t* importances, cpm_stream stream) {
+    if (!ctx) return CPM_ERR_INVALID_ARGUMENT;
+    CPM_REQUIRE(ctx, grid_dims && cell_size && texture_to_index, "cpm_photon_importance: null argument");
+    CPM_REQUIRE(ctx, n_light_samples >= 0 && photon_offset >= 0 && max_interactions >= 1 && total_photons >= 0,
+                "cpm_photon_importance: bad size");
+    if (n_light_samples == 0) return CPM_OK;
+    CPM_REQUIRE(ctx, importance_grid && photons8 && light_samples8 && isect2 && importances, "cpm_photon_importance: null buffer");
+    ImpGrid G;
+    G.grid = importance_grid;
+    for (int a = 0; a < 3; ++a) {
+        CPM_REQUIRE(ctx, grid_dims[a] >= 1 && cell_size[a] > 0.f, "cpm_photon_importance: grid dims / cell size");
+        G.dims[a] = grid_dims[a];
+        G.cell[a] = cell_size[a];
+    }
+    if (!affine_from_matrix(texture_to_index, G.t2i))
+        return set_error(ctx, CPM_ERR_UNSUPPORTED, "cpm_photon_importance", "textureToIndex must be scale + translate");
+    CPM_LAUNCH(ctx, photon_importance_kernel, dim3(div_up(n_light_samples, 256)), dim3(256), 0, (hipStream_t)stream, G,
+                       photons8, photon_offset, light_samples8, isect2, n_light_samples, max_interactions, total_photons,
+                       fix_exit_point, importances);
+    CPM_LAUNCH_CHECK(ctx, "photon_importance_kernel");
+    return CPM_OK;
+}
+
+int cpm_photon_importance_equal(cpm_ctx* ctx, int photon_offset, int n_light_samples, int percentage, int iteration,
+                                uint32_t* importances, cpm_stream stream) {
+    if (!ctx) return CPM_ERR_INVALID_ARGUMENT;
+    CPM_REQUIRE(ctx, n_light_samples >= 0 && photon_offset >= 0, "cpm_photon_importance_equal: bad size");
+    CPM_REQUIRE(ctx, percentage >= 1 && percentage <= 100, "cpm_photon_importance_equal: percentage must be in [1, 100]");
+    if (n_light_samples == 0) return CPM_OK;
+    CPM_REQUIRE(ctx, importances, "cpm_photon_importance_equal: null buffer");
+    CPM_LAUNCH(ctx, photon_importance_equal_kernel, dim3(div_up(n_light_samples, 256)), dim3(256), 0, (hipStream_t)stream,
+                       photon_offset, n_light_samples, percentage, iteration, importances);
+    CPM_LAUNCH_CHECK(ctx, "photon_importance_equal_kernel");
+    return CPM_OK;
+}
+
+int cpm_reset_importance(cpm_ctx* ctx, uint32_t* importances, size_t offset, size_t n, cpm_stream stream) {
+    if (!ctx) return CPM_ERR_INVALID_ARGUMENT;
+    if (n == 0) return CPM_OK;
+    CPM_REQUIRE(ctx, importances, "cpm_reset_importance: null buffer");
+    CPM_LAUNCH(ctx, fill_u32_kernel, dim3(div_up((long long)n, 256)), dim3(256), 0, (hipStream_t)stream,
+                       importances + offset, n, 2147483647u);
+    CPM_LAUNCH_CHECK(ctx, "fill_u32_kernel");
+    return CPM_OK;
+}
+
+int cpm_select_recompute(cpm_ctx* ctx, uint32_t* importances, size_t n, uint32_t* indices_out, int32_t* n_changed_dev,
+                         cpm_stream stream) {
+    if (!ctx) return CPM_ERR_INVALID_ARGUMENT;
+    CPM_REQUIRE(ctx, n_changed_dev, "cpm_select_recompute: null counter");
+    hipStream_t s = (hipStream_t)stream;
+    CPM_HIP_CHECK(ctx, hipMemsetAsync(n_changed_dev, 0, sizeof(int32_t), s));
+    if (n == 0) return CPM_OK;
+    CPM_REQUIRE(ctx, importances && indices_out, "cpm_select_recompute: null buffer");
+    CPM_LAUNCH(ctx, threshold_count_iota_kernel, dim3(div_up((long long)n, 256)), dim3(256), 0, s, importances, n,
+                       indices_out, n_changed_dev);
+    CPM_LAUNCH_CHECK(ctx, "threshold_count_iota_kernel");
+    // keys are <= 0x7fffffff: 31 significant bits
+    return cpm::radix_sort(ctx, importances, indices_out, n, 31, s);
+}
+
+}  // extern "C"

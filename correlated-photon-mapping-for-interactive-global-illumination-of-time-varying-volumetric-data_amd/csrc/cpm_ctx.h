@@ -1,0 +1,98 @@
+// cpm_ctx.h -- context, error plumbing and device-side descriptors shared by the
+// translation units of libcpm_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "cpm/cpm.h"
+#include "cpm_math.hip.h"
+
+struct cpm_prof_record { const char* name; hipEvent_t a, b; };
+struct cpm_prof_entry { std::string name; double total_ms = 0; long calls = 0; };
+
+struct cpm_ctx {
+    // per-kernel HIP-event profiling (include/cpm/cpm_profile.h); off by default
+    bool profiling = false;
+    std::vector<cpm_prof_record> prof_pending;
+    std::vector<hipEvent_t> prof_pool;
+    std::vector<cpm_prof_entry> prof_entries;
+    int device = 0;
+    int num_cus = 256;
+    std::string last_error;
+    // grow-only scratch arenas (no allocation in steady state)
+    void* scratch[8] = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };
+    size_t scratch_bytes[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+};
+
+// scratch slots
+enum {
+    CPM_SCR_SORT_KEYS = 0,   // ping-pong keys
+    CPM_SCR_SORT_VALS = 1,   // ping-pong values
+    CPM_SCR_SORT_HIST = 2,   // per-tile digit histograms
+    CPM_SCR_BIN_KEYS = 3,    // cell keys of cpm_bin
+    CPM_SCR_SMALL = 4,       // TF points etc.
+    CPM_SCR_MISC = 5
+};
+
+struct cpm_volume {
+    cpm_volume_desc desc;
+    void* voxels = nullptr;  // device, x fastest, padded by 16 bytes
+    size_t bytes = 0;
+};
+
+struct cpm_tf {
+    int width = 0;
+    float* rgba = nullptr;   // device, width * 4
+    float* alpha = nullptr;  // device, width (what the tracer stages into LDS)
+};
+
+namespace cpm {
+
+int set_error(cpm_ctx* ctx, int status, const char* what, const char* detail);
+void* scratch(cpm_ctx* ctx, int slot, size_t bytes);  // nullptr on failure (error set)
+bool affine_from_matrix(const float m[16], Affine& out);
+
+#define CPM_HIP_CHECK(ctx, expr)                                                        \
+    do {                                                                                \
+        hipError_t e_ = (expr);                                                         \
+        if (e_ != hipSuccess) return cpm::set_error((ctx), CPM_ERR_DEVICE, #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+#define CPM_LAUNCH_CHECK(ctx, name)                                                     \
+    do {                                                                                \
+        hipError_t e_ = hipGetLastError();                                              \
+        if (e_ != hipSuccess) return cpm::set_error((ctx), CPM_ERR_DEVICE, name, hipGetErrorString(e_)); \
+    } while (0)
+
+#define CPM_REQUIRE(ctx, cond, msg)                                                     \
+    do {                                                                                \
+        if (!(cond)) return cpm::set_error((ctx), CPM_ERR_INVALID_ARGUMENT, msg, #cond); \
+    } while (0)
+
+// Records a start/stop hipEvent pair around one kernel launch when ctx->profiling is set.
+struct ProfScope {
+    cpm_ctx* ctx; hipStream_t s; hipEvent_t b = nullptr;
+    ProfScope(cpm_ctx* c, const char* name, hipStream_t stream);
+    ~ProfScope();
+};
+
+#define CPM_LAUNCH(ctx, kernel, grid, block, lds, stream, ...)                          \
+    do {                                                                                \
+        cpm::ProfScope cpm_ps_((ctx), #kernel, (stream));                               \
+        hipLaunchKernelGGL(kernel, grid, block, lds, stream, __VA_ARGS__);              \
+    } while (0)
+
+inline int div_up(long long a, long long b) { return (int)((a + b - 1) / b); }
+
+// device-side grid description
+struct GridDev {
+    int dx, dy, dz, channels;
+    Affine t2i, i2t;
+};
+
+}  // namespace cpm

@@ -1,0 +1,362 @@
+// cpm_trace.hip -- Woodcock (delta-tracking) photon tracer (R3, R4, R5).
+//
+// Replaces photonTracerKernel (ref progressivephotonmapping/cl/photontracer.cl:69-216) and
+// woodcockTracking (ref cl/transmittance.cl:126-144).
+//
+// MI355X mapping
+//   * one work-item per light sample, 256-thread workgroups (4 waves, one per SIMD);
+//     consecutive lanes trace consecutive samples of the emission lattice, i.e. parallel,
+//     ~quarter-voxel-apart rays: the 8 trilinear corners of neighbouring lanes share cache
+//     lines, which is the property the reference's index sort preserves
+//     (processor/progressivephotontracercl.cpp:467-473).
+//   * CDNA4 has no sampler hardware.  The image3d_t fetch becomes 4 paired loads (the two
+//     x-neighbours of a corner pair are adjacent bytes: one 2/4/8-byte load for u8/u16/f32)
+//     plus 7 two-fma lerps; the clamp-to-edge rule is applied to the coordinate so the pair
+//     is always in range (DESIGN.md "Arithmetic contract").
+//   * the transfer function is read only through its alpha channel (color.w, scattering.w):
+//     the alpha column is staged once per workgroup into LDS (width*4 bytes = 4 KiB for
+//     Inviwo's 1024-texel LUT) and sampled with two ds_read + one lerp.
+//   * MWC64X state lives in two VGPRs; photons and light samples move as 2 x float4
+//     (coalesced 2 KiB per wave-instruction).
+#include "cpm_ctx.h"
+
+using namespace cpm;
+
+namespace {
+
+struct VolDev {
+    const void* voxels;
+    float fx, fy, fz;        // (float)dim
+    float mx1, my1, mz1;     // dim - 1
+    float mx2, my2, mz2;     // max(dim - 2, 0)
+    uint32_t sy, sz;         // row / slice stride in elements
+    int ny1, nz1;            // dim - 1 (int) for i1 clamp
+    float norm, offset, one_minus_scaling;
+};
+
+struct TraceArgs {
+    VolDev vol;
+    const float* tf_alpha;
+    const float* tfs_alpha;   // == tf_alpha when the reference's "tf passed twice" quirk applies
+    int tf_width;
+    float tf_wf, tf_m1, tf_m2;
+    float bmin[3], bmax[3];
+    cpm_trace_params p;
+    const float* light_samples;
+    const float* isect;
+    const uint32_t* recompute_indices;
+    int n_threads;
+    uint32_t* rng;
+    float* photons;
+    unsigned long long* step_counter;  // nullable (statistics build of the launch)
+};
+
+template <int DT> struct PairLoad;
+template <> struct PairLoad<CPM_U8> {
+    static CPM_DEV void load(const void* base, uint32_t idx, float& lo, float& hi) {
+        uint16_t v;
+        __builtin_memcpy(&v, static_cast<const uint8_t*>(base) + idx, 2);
+        lo = (float)(v & 0xffu);
+        hi = (float)(v >> 8);
+    }
+};
+template <> struct PairLoad<CPM_U16> {
+    static CPM_DEV void load(const void* base, uint32_t idx, float& lo, float& hi) {
+        uint32_t v;
+        __builtin_memcpy(&v, static_cast<const uint16_t*>(base) + idx, 4);
+        lo = (float)(v & 0xffffu);
+        hi = (float)(v >> 16);
+    }
+};
+template <> struct PairLoad<CPM_F32> {
+    static CPM_DEV void load(const void* base, uint32_t idx, float& lo, float& hi) {
+        float v[2];
+        __builtin_memcpy(v, static_cast<const float*>(base) + idx, 8);
+        lo = v[0];
+        hi = v[1];
+    }
+};
+
+CPM_DEV void coord(float s, float dimf, float m1, float m2, float& fl, float& a) {
+    float u = fma_(s, dimf, -0.5f);
+    u = max_(u, 0.0f);
+    u = min_(u, m1);
+    fl = __builtin_floorf(u);
+    fl = max_(min_(fl, m2), 0.0f);
+    a = u - fl;
+}
+
+// getNormalizedVoxel(volume, params, pos).x with smpNormClampEdgeLinear
+template <int DT>
+CPM_DEV float sample_volume(const VolDev& V, float px, float py, float pz) {
+    float flx, fly, flz, ax, ay, az;
+    coord(px, V.fx, V.mx1, V.mx2, flx, ax);
+    coord(py, V.fy, V.my1, V.my2, fly, ay);
+    coord(pz, V.fz, V.mz1, V.mz2, flz, az);
+    int ix = (int)flx, iy = (int)fly, iz = (int)flz;
+    uint32_t dy = (iy < V.ny1) ? V.sy : 0u;
+    uint32_t dz = (iz < V.nz1) ? V.sz : 0u;
+    uint32_t b00 = (uint32_t)ix + V.sy * (uint32_t)iy + V.sz * (uint32_t)iz;
+    float v000, v100, v010, v110, v001, v101, v011, v111;
+    PairLoad<DT>::load(V.voxels, b00, v000, v100);
+    PairLoad<DT>::load(V.voxels, b00 + dy, v010, v110);
+    PairLoad<DT>::load(V.voxels, b00 + dz, v001, v101);
+    PairLoad<DT>::load(V.voxels, b00 + dy + dz, v011, v111);
+    float c00 = lerp_(v000, v100, ax);
+    float c10 = lerp_(v010, v110, ax);
+    float c01 = lerp_(v001, v101, ax);
+    float c11 = lerp_(v011, v111, ax);
+    float c0 = lerp_(c00, c10, ay);
+    float c1 = lerp_(c01, c11, ay);
+    float c = lerp_(c0, c1, az);
+    float s = c * V.norm;
+    return (s + V.offset) * V.one_minus_scaling;
+}
+
+// read_imagef(tf, smpNormClampEdgeLinear, (float2)(v, 0.5f)).w from the LDS alpha column
+CPM_DEV float sample_alpha(const float* lut, float wf, float m1, float m2, float v) {
+    float fl, a;
+    coord(v, wf, m1, m2, fl, a);
+    int i = (int)fl;
+    return lerp_(lut[i], lut[i + 1], a);
+}
+
+// build-defined phase-function sampling (Inviwo sampleShadingFunction is not in the
+// reference tree): Henyey-Greenstein (g = material.x) or isotropic about `w`.
+CPM_DEV float phase_cos(int type, float g, float u1) {
+    if (type == CPM_PHASE_ISOTROPIC || __builtin_fabsf(g) < 1e-3f) return fma_(-2.0f, u1, 1.0f);
+    float g2 = g * g;
+    float sq = (1.0f - g2) / fma_(2.0f * g, u1, 1.0f - g);
+    return (1.0f + g2 - sq * sq) / (2.0f * g);
+}
+CPM_DEV float phase_pdf(int type, float g, float cosT) {
+    if (type == CPM_PHASE_ISOTROPIC || __builtin_fabsf(g) < 1e-3f) return kInv4Pi;
+    float g2 = g * g;
+    float den = fma_(-2.0f * g, cosT, 1.0f + g2);
+    return kInv4Pi * (1.0f - g2) / (den * __builtin_sqrtf(den));
+}
+CPM_DEV f3 phase_sample(int type, float g, f3 w, float u1, float u2, float* pdf) {
+    float cosT = phase_cos(type, g, u1);
+    cosT = min_(max_(cosT, -1.0f), 1.0f);
+    float sinT = __builtin_sqrtf(max_(0.0f, fma_(-cosT, cosT, 1.0f)));
+    float sp, cp;
+    sincos_(kTwoPi * u2, sp, cp);
+    f3 a;
+    if (__builtin_fabsf(w.z) < 0.999f) { a.x = 0; a.y = 0; a.z = 1; } else { a.x = 1; a.y = 0; a.z = 0; }
+    f3 u = cross3_(a, w);
+    float il = 1.0f / __builtin_sqrtf(dot3_(u, u));
+    u.x *= il; u.y *= il; u.z *= il;
+    f3 v = cross3_(w, u);
+    float ku = sinT * cp, kv = sinT * sp;
+    f3 d;
+    d.x = fma_(cosT, w.x, fma_(kv, v.x, ku * u.x));
+    d.y = fma_(cosT, w.y, fma_(kv, v.y, ku * u.y));
+    d.z = fma_(cosT, w.z, fma_(kv, v.z, ku * u.z));
+    if (pdf) *pdf = phase_pdf(type, g, cosT);
+    return d;
+}
+
+CPM_DEV void write_photon(float* photons, size_t id, f3 p, f3 pw, float th, float ph) {
+    float4* q = reinterpret_cast<float4*>(photons) + 2 * id;
+    q[0] = make_float4(p.x, p.y, p.z, pw.x);
+    q[1] = make_float4(pw.y, pw.z, th, ph);
+}
+
+template <int DT>
+CPM_DEV float woodcock(const VolDev& V, const float* lut, float wf, float m1, float m2, f3 o, f3 d, float tStart,
+                       float tEnd, uint32_t& rx, uint32_t& rc, unsigned& steps) {
+    constexpr float invTauMaxSampleBaseInterval = 1.f / (1.f * 150.f);  // tauMax = 1 (photontracer.cl:160)
+    float t = tStart;
+    float opacity, u2;
+    do {
+        float u1 = rand01_(rx, rc);
+        t = fma_(-log_(u1), invTauMaxSampleBaseInterval, t);
+        // the fetched value cannot influence the result once t > tEnd (the loop ends
+        // whatever it is), so the fetch is skipped there; the RNG draw is not.
+        opacity = 0.f;
+        if (t <= tEnd) {
+            float vs = sample_volume<DT>(V, fma_(t, d.x, o.x), fma_(t, d.y, o.y), fma_(t, d.z, o.z));
+            opacity = sample_alpha(lut, wf, m1, m2, vs);
+        }
+        u2 = rand01_(rx, rc);
+        ++steps;
+    } while (u2 >= opacity && t <= tEnd);
+    return t;
+}
+
+template <int DT>
+__global__ __launch_bounds__(256) void trace_kernel(const TraceArgs A) {
+    extern __shared__ float lds[];
+    float* lut = lds;
+    float* luts = lds;
+    for (int i = threadIdx.x; i < A.tf_width; i += blockDim.x) lut[i] = A.tf_alpha[i];
+    if (A.tfs_alpha != A.tf_alpha) {
+        luts = lds + A.tf_width;
+        for (int i = threadIdx.x; i < A.tf_width; i += blockDim.x) luts[i] = A.tfs_alpha[i];
+    }
+    __syncthreads();
+
+    int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= A.n_threads) return;
+    int threadId = gid;
+    if (A.recompute_indices) {  // -D PHOTON_RECOMPUTATION (photontracer.cl:97-106)
+        threadId = (int)A.recompute_indices[gid] - A.p.photon_offset;
+        if (threadId < 0 || threadId >= A.p.n_light_samples) return;
+    }
+    const int photonOffset = A.p.photon_offset;
+    const uint32_t maxInteractions = (uint32_t)A.p.max_interactions;
+    const size_t totalPhotons = (size_t)A.p.total_photons;
+    uint2* rng = reinterpret_cast<uint2*>(A.rng);
+    uint2 rs = rng[photonOffset + threadId];
+    uint32_t rx = rs.x, rc = rs.y;
+    uint32_t nInteractions = 0;
+    unsigned steps = 0;
+
+    const float4* lsp = reinterpret_cast<const float4*>(A.light_samples) + 2 * (size_t)threadId;
+    float4 l0 = lsp[0], l1 = lsp[1];
+    f3 origin = { l0.x, l0.y, l0.z };
+    float mi = (float)maxInteractions;
+    f3 power = { l0.w / mi, l1.x / mi, l1.y / mi };
+    f3 direction = decode_direction_(l1.z, l1.w);
+    float2 ip = reinterpret_cast<const float2*>(A.isect)[threadId];
+    float tStart = ip.x, tEnd = ip.y;
+    bool scatterEvent = tStart < tEnd;
+
+    const float wf = A.tf_wf, m1 = A.tf_m1, m2 = A.tf_m2;
+
+    if (A.p.flags & CPM_TRACE_NO_SINGLE_SCATTERING) {  // photontracer.cl:143-157
+        float t = woodcock<DT>(A.vol, lut, wf, m1, m2, origin, direction, tStart, tEnd, rx, rc, steps);
+        if (scatterEvent) {
+            origin.x = fma_(t, direction.x, origin.x);
+            origin.y = fma_(t, direction.y, origin.y);
+            origin.z = fma_(t, direction.z, origin.z);
+            tStart = 0.f; tEnd = kFltMax;
+            float u1 = rand01_(rx, rc), u2 = rand01_(rx, rc);
+            float pdf;
+            direction = phase_sample(A.p.shading_type, A.p.material[0], direction, u1, u2, &pdf);
+            scatterEvent = ray_box_(A.bmin, A.bmax, origin, direction, tStart, tEnd);
+            power.x = power.x / pdf; power.y = power.y / pdf; power.z = power.z / pdf;
+            tStart = tStart + 0.5f * A.p.step_size;
+        }
+    }
+    while (scatterEvent) {  // photontracer.cl:158-197
+        float t = woodcock<DT>(A.vol, lut, wf, m1, m2, origin, direction, tStart, tEnd, rx, rc, steps);
+        scatterEvent = t <= tEnd;
+        if (scatterEvent) {
+            origin.x = fma_(t, direction.x, origin.x);
+            origin.y = fma_(t, direction.y, origin.y);
+            origin.z = fma_(t, direction.z, origin.z);
+            size_t photonId = (size_t)photonOffset + nInteractions * totalPhotons + (size_t)threadId;
+            float th, ph;
+            encode_direction_(direction, th, ph);
+            float volumeSample = sample_volume<DT>(A.vol, origin.x, origin.y, origin.z);
+            float colorW = sample_alpha(lut, wf, m1, m2, volumeSample);
+            float scatW = sample_alpha(luts, wf, m1, m2, volumeSample);
+            float scatteringAlbedo = scatW / (scatW + colorW);
+            float dv = max_(colorW, 0.01f);
+            power.x = power.x / dv; power.y = power.y / dv; power.z = power.z / dv;
+            ++nInteractions;
+            if (nInteractions < maxInteractions && rand01_(rx, rc) < scatteringAlbedo) {
+                power.x *= scatteringAlbedo; power.y *= scatteringAlbedo; power.z *= scatteringAlbedo;
+                write_photon(A.photons, photonId, origin, power, th, ph);
+                tStart = 0.f; tEnd = kFltMax;
+                float u1 = rand01_(rx, rc), u2 = rand01_(rx, rc);
+                direction = phase_sample(A.p.shading_type, A.p.material[0], direction, u1, u2, nullptr);
+                scatterEvent = ray_box_(A.bmin, A.bmax, origin, direction, tStart, tEnd);
+                tStart = tStart + 0.5f * A.p.step_size;
+            } else {
+                write_photon(A.photons, photonId, origin, power, th, ph);
+                power.x = power.y = power.z = kFltMax;  // read by the recomputation detector
+                scatterEvent = false;
+            }
+        }
+    }
+    float th, ph;
+    encode_direction_(direction, th, ph);
+    for (uint32_t i = nInteractions; i < maxInteractions; ++i) {  // photontracer.cl:199-209
+        size_t photonId = (size_t)photonOffset + i * totalPhotons + (size_t)threadId;
+        f3 p = { kFltMax, kFltMax, kFltMax };
+        f3 pw = { power.x, kFltMax, kFltMax };
+        write_photon(A.photons, photonId, p, pw, th, ph);
+    }
+    if (A.p.flags & CPM_TRACE_PROGRESSIVE) rng[photonOffset + threadId] = make_uint2(rx, rc);  // :211-215
+    if (A.step_counter) {
+        // statistics only: wave-level sum, one atomic per wave
+        unsigned s = steps;
+        for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+        if ((threadIdx.x & 63) == 0) atomicAdd(A.step_counter, (unsigned long long)s);
+    }
+}
+
+}  // namespace
+
+namespace cpm {
+// exposed to cpm_correlated.hip (min/max bricks use the same normalisation)
+}
+
+extern "C" {
+
+// statistics hook used by bench.py: when non-null, trace launches add their Woodcock
+// iteration counts to this device counter (not part of cpm.h's stable surface)
+static unsigned long long* g_step_counter = nullptr;
+void cpm_debug_set_step_counter(unsigned long long* dev_counter) { g_step_counter = dev_counter; }
+
+int cpm_trace(cpm_ctx* ctx, const cpm_volume* vol, const cpm_tf* tf, const cpm_tf* tf_scattering, const float aabb[8],
+              const cpm_trace_params* params, const float* light_samples8, const float* isect2,
+              const uint32_t* recompute_indices, int n_recompute, uint32_t* rng_state, float* photons8,
+              cpm_stream stream) {
+    if (!ctx) return CPM_ERR_INVALID_ARGUMENT;
+    CPM_REQUIRE(ctx, vol && tf && aabb && params, "cpm_trace: null argument");
+    const cpm_trace_params& p = *params;
+    CPM_REQUIRE(ctx, p.n_light_samples >= 0 && p.photon_offset >= 0 && p.total_photons >= 0, "cpm_trace: negative size");
+    CPM_REQUIRE(ctx, p.max_interactions >= 1 && p.max_interactions <= 64, "cpm_trace: max_interactions in [1, 64]");
+    CPM_REQUIRE(ctx, (long long)p.photon_offset + p.n_light_samples <= (long long)p.total_photons,
+                "cpm_trace: photon_offset + n_light_samples exceeds total_photons");
+    CPM_REQUIRE(ctx, n_recompute >= 0, "cpm_trace: n_recompute < 0");
+    if (tf_scattering) CPM_REQUIRE(ctx, tf_scattering->width == tf->width, "cpm_trace: tf widths differ");
+    int n_threads = recompute_indices ? n_recompute : p.n_light_samples;
+    if (n_threads == 0) return CPM_OK;
+    CPM_REQUIRE(ctx, light_samples8 && isect2 && rng_state && photons8, "cpm_trace: null buffer");
+    const cpm_volume_desc& d = vol->desc;
+    CPM_REQUIRE(ctx, (unsigned long long)d.dims[0] * d.dims[1] * d.dims[2] < (1ull << 32), "cpm_trace: volume too large");
+
+    TraceArgs A;
+    A.vol.voxels = vol->voxels;
+    A.vol.fx = (float)d.dims[0]; A.vol.fy = (float)d.dims[1]; A.vol.fz = (float)d.dims[2];
+    A.vol.mx1 = (float)(d.dims[0] - 1); A.vol.my1 = (float)(d.dims[1] - 1); A.vol.mz1 = (float)(d.dims[2] - 1);
+    A.vol.mx2 = (float)(d.dims[0] - 2);
+    A.vol.my2 = (float)(d.dims[1] > 2 ? d.dims[1] - 2 : 0);
+    A.vol.mz2 = (float)(d.dims[2] > 2 ? d.dims[2] - 2 : 0);
+    A.vol.sy = (uint32_t)d.dims[0];
+    A.vol.sz = (uint32_t)d.dims[0] * (uint32_t)d.dims[1];
+    A.vol.ny1 = d.dims[1] - 1; A.vol.nz1 = d.dims[2] - 1;
+    A.vol.norm = d.dtype == CPM_U8 ? (1.0f / 255.0f) : (d.dtype == CPM_U16 ? (1.0f / 65535.0f) : 1.0f);
+    A.vol.offset = d.format_offset;
+    A.vol.one_minus_scaling = 1.0f - d.format_scaling;
+    A.tf_alpha = tf->alpha;
+    A.tfs_alpha = tf_scattering ? tf_scattering->alpha : tf->alpha;
+    A.tf_width = tf->width;
+    A.tf_wf = (float)tf->width; A.tf_m1 = (float)(tf->width - 1); A.tf_m2 = (float)(tf->width - 2);
+    for (int a = 0; a < 3; ++a) { A.bmin[a] = aabb[a]; A.bmax[a] = aabb[4 + a]; }
+    A.p = p;
+    A.light_samples = light_samples8;
+    A.isect = isect2;
+    A.recompute_indices = recompute_indices;
+    A.n_threads = n_threads;
+    A.rng = rng_state;
+    A.photons = photons8;
+    A.step_counter = g_step_counter;
+
+    size_t lds = (size_t)tf->width * sizeof(float) * (A.tfs_alpha != A.tf_alpha ? 2 : 1);
+    dim3 grid(div_up(n_threads, 256)), block(256);
+    hipStream_t s = (hipStream_t)stream;
+    switch (d.dtype) {
+        case CPM_U8: CPM_LAUNCH(ctx, trace_kernel<CPM_U8>, grid, block, lds, s, A); break;
+        case CPM_U16: CPM_LAUNCH(ctx, trace_kernel<CPM_U16>, grid, block, lds, s, A); break;
+        default: CPM_LAUNCH(ctx, trace_kernel<CPM_F32>, grid, block, lds, s, A); break;
+    }
+    CPM_LAUNCH_CHECK(ctx, "trace_kernel");
+    return CPM_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,243 @@
+"""Frame orchestration over the C-ABI: emission -> trace -> bin -> gather.
+
+This is the thin Python driver used by bench.py, smoke() and the parity tests.
+It mirrors what the reference's two processors do per evaluation
+(ProgressivePhotonTracerCL::process, ref
+progressivephotonmapping/processor/progressivephotontracercl.cpp:219-260,541-560 and
+PhotonToLightVolumeProcessorCL::process, ref
+.../photontolightvolumeprocessorcl.cpp:137-170,299-339,356-412) and nothing else;
+the C++ drop-in surface lives in host/.
+"""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+
+from . import binding as B
+from . import synthetic as S
+
+
+# --------------------------------------------------------------------------- E2 (host, CPU in the reference too)
+
+def _normalize(v):
+    v = np.asarray(v, dtype=np.float32)
+    return v / np.float32(np.sqrt(np.sum(v * v, dtype=np.float32)))
+
+
+def project_points_on_plane(points, plane_point, normal, u, v):
+    """ref lightcl/pointplaneprojection.cpp:39-54"""
+    n = np.asarray(normal, np.float32)
+    d = np.float32(np.dot(n, plane_point))
+    out = []
+    for p in np.asarray(points, np.float32):
+        dist = np.float32(np.dot(n, p)) - d
+        proj = p - dist * n
+        o2p = proj - plane_point
+        out.append((np.float32(np.dot(u, o2p)), np.float32(np.dot(v, o2p))))
+    return out
+
+
+def convex_hull_2d(points):
+    """Andrew's monotone chain as written in ref lightcl/convexhull2d.cpp:38-130
+    (the hull is returned closed: first point repeated at the end)."""
+    pts = sorted(points, key=lambda p: (p[0], p[1]))
+    if len(pts) < 4:
+        return pts
+
+    def left(p0, p1, q):
+        return (p1[0] - p0[0]) * (q[1] - p0[1]) - (q[0] - p0[0]) * (p1[1] - p0[1])
+
+    n = len(pts)
+    min_min = 0
+    min_max = 1
+    while min_max < n and pts[0][0] == pts[min_max][0]:
+        min_max += 1
+    min_max -= 1
+    if min_max == n - 1:
+        hull = [pts[min_min]]
+        if pts[min_max][1] != pts[min_min][1]:
+            hull.append(pts[min_max])
+        hull.append(pts[min_min])
+        return hull
+    max_min = n - 1
+    max_max = n - 2
+    while max_max >= 0 and not (pts[n - 1][0] > pts[max_max][0]):
+        max_max -= 1
+    max_max += 1
+    hull = [pts[min_min]]
+    for i in range(min_max + 1, max_min + 1):
+        if left(pts[min_min], pts[max_min], pts[i]) >= 0 and i < max_min:
+            continue
+        while len(hull) >= 2:
+            if left(hull[-2], hull[-1], pts[i]) > 0:
+                break
+            hull.pop()
+        hull.append(pts[i])
+    if max_max != max_min:
+        hull.append(pts[max_max])
+    bottom = len(hull) - 1
+    for i in range(max_max, min_max, -1):
+        if left(pts[max_max], pts[min_max], pts[i]) >= 0 and i > min_max:
+            continue
+        while len(hull) - bottom >= 2:
+            if left(hull[-2], hull[-1], pts[i]) > 0:
+                break
+            hull.pop()
+        hull.append(pts[i])
+    if min_max != min_min:
+        hull.append(pts[max_min])
+    return hull
+
+
+def minimum_bounding_rectangle(hull):
+    """ref lightcl/orientedboundingbox2d.cpp:40-78 (rotating edges)"""
+    f = np.float32
+    best = None
+    min_area = f(np.finfo(np.float32).max)
+    n = len(hull)
+    j = n - 1
+    for i in range(n):
+        e = np.array([hull[i][0] - hull[j][0], hull[i][1] - hull[j][1]], np.float32)
+        ln = f(np.sqrt(e[0] * e[0] + e[1] * e[1]))
+        if ln == 0 or not np.isfinite(ln):
+            j = i
+            continue
+        e0 = e / ln
+        e1 = np.array([-e0[1], e0[0]], np.float32)
+        min0 = max0 = min1 = max1 = f(0)
+        for k in range(n):
+            d = np.array([hull[k][0] - hull[j][0], hull[k][1] - hull[j][1]], np.float32)
+            t = f(np.dot(d, e0))
+            min0, max0 = min(min0, t), max(max0, t)
+            t = f(np.dot(d, e1))
+            min1, max1 = min(min1, t), max(max1, t)
+        area = (max0 - min0) * (max1 - min1)
+        if area < min_area:
+            min_area = area
+            origin = np.array(hull[j], np.float32) + min(min0, f(0)) * e0 + min(min1, f(0)) * e1
+            best = (origin, e0 * (max0 - min0), e1 * (max1 - min1))
+        j = i
+    return best
+
+
+def fit_plane_aligned_obb(points, plane_point, plane_normal):
+    """ref lightcl/orientedboundingbox2d.cpp:80-100: (origin, u, v) of the minimum-area
+    rectangle, in the light plane, covering the projected points."""
+    n = _normalize(plane_normal)
+    plane_point = np.asarray(plane_point, np.float32)
+
+    def project(p):
+        p = np.asarray(p, np.float32)
+        return p - (np.float32(np.dot(n, p)) - np.float32(np.dot(n, plane_point))) * n
+
+    if abs(n[0]) > abs(n[1]):
+        u = _normalize(project((1.0, 0.0, 0.0)) - plane_point)
+    else:
+        u = _normalize(project((0.0, 1.0, 0.0)) - plane_point)
+    v = _normalize(np.cross(n, u).astype(np.float32))
+    projected = project_points_on_plane(points, plane_point, n, u, v)
+    hull = convex_hull_2d(projected)
+    o2, u2, v2 = minimum_bounding_rectangle(hull)
+    origin = plane_point + o2[0] * u + o2[1] * v
+    return origin.astype(np.float32), (u2[0] * u + u2[1] * v).astype(np.float32), (v2[0] * u + v2[1] * v).astype(np.float32)
+
+
+# --------------------------------------------------------------------------- frame
+
+class PhotonFrame:
+    """One light, one volume: owns the device buffers of the path and runs its stages.
+
+    photon_range = (lo, hi) restricts this instance to a contiguous shard of the N = n_side^2
+    photons (multi-GPU: one shard per rank); photon i keeps light sample i and RNG stream i
+    of the unsharded run, so results do not depend on the number of shards.
+    """
+
+    def __init__(self, ctx: B.Context, volume, tf_rgba, n_side: int, grid_dims, *,
+                 light_travel_direction=(0.0, 0.0, 1.0), light_distance: float = 2.0,
+                 radiance=(1.0, 1.0, 1.0), radius_voxels: float = 1.0, max_interactions: int = 1,
+                 channels: int = 1, photon_range=None, point_light_position=None, seed: int = 0,
+                 shading_type: int = B.CPM_PHASE_HENYEY_GREENSTEIN, material=(0.0, 0.0, 0.0, 0.0)):
+        torch = ctx.torch
+        self.ctx = ctx
+        self.torch = torch
+        dev = ctx.device
+        self.vol = volume if isinstance(volume, B.Volume) else ctx.volume_create(volume)
+        self.tf = tf_rgba if isinstance(tf_rgba, B.TransferFunction) else ctx.tf_create(tf_rgba)
+        self.n_total = n_side * n_side
+        lo, hi = photon_range if photon_range is not None else (0, self.n_total)
+        self.lo, self.hi = lo, hi
+        self.n = hi - lo
+        self.I = max_interactions
+        self.aabb = S.UNIT_CUBE_AABB
+        vdims = self.vol.dims
+        self.grid = B.default_grid_desc(grid_dims, channels)
+        self.cells = int(grid_dims[0]) * int(grid_dims[1]) * int(grid_dims[2])
+        self.radius = S.photon_radius_texture(vdims, radius_voxels)
+        self.scale = B.relative_irradiance_scale(self.radius, float(self.n_total))
+
+        # E1: emission lattice, E2: light plane, E3/E5: light samples, E4: entry/exit
+        samples = ctx.uniform_samples_2d(n_side, n_side)[lo:hi].contiguous()
+        if point_light_position is not None:
+            self.light_samples = ctx.point_light_samples(samples, radiance, point_light_position)
+        else:
+            d = _normalize(light_travel_direction)
+            origin = np.array([0.5, 0.5, 0.5], np.float32) - np.float32(light_distance) * d
+            o, u, v = fit_plane_aligned_obb(S.UNIT_CUBE_VERTICES, origin, d)
+            area = float(np.float32(np.linalg.norm(u)) * np.float32(np.linalg.norm(v)))
+            self.light_plane = (o, u, v, area, d)
+            self.light_samples = ctx.directional_light_samples(samples, radiance, d, o, u, v, area)
+        self.isect = ctx.light_sample_box_intersection(self.light_samples, self.aabb)
+
+        # R2: per-photon MWC64X streams (glibc srand(seed) bases, gap 2^40), seeded over the
+        # unsharded index range so that stream i is the same whatever the shard
+        bases = B.glibc_rand_sequence(seed, self.n_total)
+        st = np.zeros((self.n_total, 2), dtype=np.uint32)
+        st[:, 0] = bases
+        full = torch.from_numpy(st.view(np.int32)).to(dev).view(torch.int32)
+        ctx.seed_streams(full)
+        self.rng = full[lo:hi].contiguous()
+        self.rng_initial = self.rng.clone()
+
+        self.params = B.TraceParams()
+        for i in range(4):
+            self.params.material[i] = material[i]
+        self.params.step_size = 1.0 / max(vdims)
+        self.params.photon_offset = 0
+        self.params.n_light_samples = self.n
+        self.params.max_interactions = self.I
+        self.params.total_photons = self.n
+        self.params.shading_type = shading_type
+        self.params.flags = 0
+
+        f32 = torch.float32
+        self.photons = torch.empty((self.n * self.I, 8), dtype=f32, device=dev)
+        self.order = torch.empty(self.n * self.I, dtype=torch.int32, device=dev)
+        self.cell_start = torch.empty(self.cells + 1, dtype=torch.int32, device=dev)
+        self.sorted = torch.empty((self.n * self.I, 4 if channels == 1 else 8), dtype=f32, device=dev)
+        self.light_volume = torch.zeros((self.cells, channels) if channels > 1 else (self.cells,), dtype=f32, device=dev)
+
+    # stages
+    def trace(self):
+        self.ctx.trace(self.vol, self.tf, self.aabb, self.params, self.light_samples, self.isect, self.rng, self.photons)
+
+    def bin(self):
+        self.ctx.bin(self.photons, self.n * self.I, self.grid, self.order, self.cell_start, self.sorted)
+
+    def gather(self, accumulate=False):
+        self.ctx.gather(self.sorted, self.cell_start, self.n * self.I, self.grid, self.radius, self.scale,
+                        self.light_volume, accumulate=accumulate)
+
+    def splat(self, out=None):
+        """Reference formulation (atomic splat), for comparison: clear + splat."""
+        out = self.light_volume if out is None else out
+        out.zero_()
+        self.ctx.splat(self.photons, self.n, self.grid, self.radius, self.scale, out)
+        return out
+
+    def frame(self):
+        """The hot path: trace -> bin -> gather."""
+        self.trace()
+        self.bin()
+        self.gather()
+        return self.light_volume

@@ -1,0 +1,27 @@
+/*
+ * cpm_profile.h -- measurement hooks of libcpm_hip.so (not part of the drop-in surface).
+ *
+ * When enabled, every kernel the library launches is bracketed by a hipEvent pair on the
+ * launch stream; cpm_profile_collect() synchronises the device and folds the pairs into
+ * per-kernel totals.  bench.py uses this to time the dominant kernel for the roofline
+ * figure; rocprofv3 --kernel-trace --stats of the same command must agree.
+ * Also here: the Woodcock iteration counter used to report Gsamples/s.
+ */
+#ifndef CPM_CPM_PROFILE_H
+#define CPM_CPM_PROFILE_H
+#include "cpm/cpm.h"
+#ifdef __cplusplus
+extern "C" {
+#endif
+void cpm_profile_enable(cpm_ctx* ctx, int on);
+void cpm_profile_reset(cpm_ctx* ctx);
+int cpm_profile_collect(cpm_ctx* ctx);                 /* returns the number of kernels seen */
+const char* cpm_profile_name(const cpm_ctx* ctx, int i);
+double cpm_profile_total_ms(const cpm_ctx* ctx, int i);
+long cpm_profile_calls(const cpm_ctx* ctx, int i);
+/* when non-NULL, cpm_trace launches add their Woodcock iteration counts to *dev_counter */
+void cpm_debug_set_step_counter(unsigned long long* dev_counter);
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -192,19 +192,21 @@ static inline float norm_scale(int dtype) {
 }
 
 /* OpenCL 1.2 s8.2 linear filter, normalised coords, CLK_ADDRESS_CLAMP_TO_EDGE:
- * u = s*w, i0 = floor(u - 0.5), i1 = i0 + 1 (both clamped), a = frac(u - 0.5). */
+ * u = s*w, i0 = floor(u - 0.5), i1 = i0 + 1 (both clamped to [0, w-1]), a = frac(u - 0.5).
+ * Restated with the clamp applied to the coordinate instead of the indices:
+ *   u' = clamp(u - 0.5, 0, w - 1), i0 = min(floor(u'), w - 2), i1 = i0 + 1, a = u' - i0,
+ * which selects the same texels with the same weights inside the image and returns the
+ * edge texel exactly outside it (om_lerp is exact at a = 0 and a = 1); NaN maps to 0. */
 static inline void linear_coord(float s, int dim, int* i0, int* i1, float* a) {
     float u = om_fma(s, (float)dim, -0.5f);
+    u = om_max(u, 0.0f);
+    u = om_min(u, (float)(dim - 1));
     float fl = floorf(u);
+    fl = om_max(om_min(fl, (float)(dim - 2)), 0.0f);
     *a = u - fl;
-    float flc = om_min(om_max(fl, -1.0f), (float)dim); /* NaN/inf-safe before conversion */
-    int j = (int)flc;
-    int j1 = j + 1;
-    if (j < 0) j = 0;
-    if (j > dim - 1) j = dim - 1;
-    if (j1 > dim - 1) j1 = dim - 1;
+    int j = (int)fl;
     *i0 = j;
-    *i1 = j1;
+    *i1 = j + 1 > dim - 1 ? dim - 1 : j + 1;
 }
 
 /* getNormalizedVoxel(volume, params, pos).x =

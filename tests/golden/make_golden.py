@@ -1,0 +1,60 @@
+"""Generate tests/golden/ref_kernels.npz from the reference's own OpenCL C kernels.
+
+Run in the build container, where /root/reference exists:
+    make -C oracle ref && python tests/golden/make_golden.py
+The kernels are compiled by oracle/Makefile from where they lie under
+/root/reference/modules (rndgenmwc64x/cl/randstategen.cl + random.cl + skip_mwc.cl,
+progressivephotonmapping/cl/{densityestimationkernel,threshold,indextobuffer}.cl) and driven by
+oracle/ref_harness.c.  The fixture holds inputs and the outputs those kernels produced --
+data only; no reference source travels.
+"""
+import ctypes
+import sys
+from pathlib import Path
+
+import numpy as np
+
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+from oracle_binding import Ref  # noqa: E402
+
+OUT = Path(__file__).resolve().parent / "ref_kernels.npz"
+
+
+def main():
+    ref = Ref()
+    n = 4096
+    libc = ctypes.CDLL("libc.so.6")
+    libc.srand(0)
+    bases = np.array([libc.rand() for _ in range(n)], dtype=np.uint32)  # what mwc64xseedgenerator.cpp:56-64 draws
+
+    state = np.zeros((n, 2), np.uint32)
+    state[:, 0] = bases
+    ref.generate_random_state(state)                      # MWC64X_GenerateRandomState, gap 2^40
+    seeded = state.copy()
+    r01, ruint = ref.random_fill(state, 8)                # random_01 / MWC64X_NextUint
+    state_after = state.copy()
+
+    ps = np.zeros((257, 2), np.uint32)
+    ps[:, 0] = bases[:257]
+    ref.generate_per_stream_random_state(ps, 1000)        # MWC64X_GeneratePerStreamRandomState
+
+    rng = np.random.default_rng(12345)
+    kx = np.concatenate([np.linspace(0, 1.5, 2049, dtype=np.float32),
+                         rng.random(2048, dtype=np.float32),
+                         np.array([1.0, np.nextafter(np.float32(1), np.float32(2)), np.nextafter(np.float32(1), np.float32(0))], np.float32)])
+    ky = ref.density_kernel(kx)                           # densityEstimationKernel
+
+    tdata = rng.integers(0, 2**32, 1000, dtype=np.uint64).astype(np.uint32)
+    tdata[::7] = 2147483647
+    tdata[::11] = 2147483646
+    tout = ref.threshold(tdata, 2147483647)               # thresholdKernel
+    iota = ref.index_to_buffer(777)                       # indexToBufferKernel
+
+    np.savez_compressed(OUT, bases=bases, seeded=seeded, random01=r01, random_uint=ruint, state_after=state_after,
+                        per_stream_seeded=ps, per_stream_gap=np.uint64(1000), kernel_x=kx, kernel_y=ky,
+                        threshold_in=tdata, threshold_out=tout, iota=iota)
+    print("wrote", OUT, OUT.stat().st_size, "bytes")
+
+
+if __name__ == "__main__":
+    main()

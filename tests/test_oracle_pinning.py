@@ -1,0 +1,88 @@
+"""The oracle against the reference: golden vectors produced by the reference's own OpenCL C
+kernels (tests/golden/ref_kernels.npz, generator tests/golden/make_golden.py) and, where
+oracle/_ref exists, those kernels themselves."""
+import ctypes
+
+import numpy as np
+import pytest
+
+
+def test_glibc_rand_bases(oracle, golden):
+    # rndgenmwc64x/mwc64xseedgenerator.cpp:56-64: srand(0); rand() per stream
+    b = oracle.glibc_rand_sequence(0, golden["bases"].size)
+    assert np.array_equal(b, golden["bases"])
+    assert b[0] == 1804289383 and b[1] == 846930886
+
+
+def test_glibc_rand_other_seeds(oracle):
+    libc = ctypes.CDLL("libc.so.6")
+    for seed in (1, 2, 12345, 0xFFFFFFFF):
+        libc.srand(seed)
+        want = np.array([libc.rand() for _ in range(500)], np.uint32)
+        assert np.array_equal(oracle.glibc_rand_sequence(seed, 500), want)
+
+
+def test_seed_streams_golden(oracle, golden):
+    st = np.zeros_like(golden["seeded"])
+    st[:, 0] = golden["bases"]
+    st[:, 1] = 0xDEADBEEF  # ignored on input
+    oracle.seed_streams(st, 1 << 40)
+    assert np.array_equal(st, golden["seeded"])
+    # SURVEY 8c known answers
+    assert tuple(st[0]) == (1691772326, 3037691698) and tuple(st[1]) == (2872186077, 58936352)
+
+
+def test_per_stream_seed_golden(oracle, golden):
+    st = np.zeros_like(golden["per_stream_seeded"])
+    st[:, 0] = golden["bases"][: st.shape[0]]
+    oracle.seed_streams(st, int(golden["per_stream_gap"]))
+    assert np.array_equal(st, golden["per_stream_seeded"])
+
+
+def test_random_01_golden(oracle, golden):
+    st = golden["seeded"].copy()
+    out = oracle.random_fill(st, golden["random01"].shape[0])
+    assert np.array_equal(out.view(np.uint32), golden["random01"].view(np.uint32))
+    assert np.array_equal(st, golden["state_after"])
+    np.testing.assert_allclose(out[:3, 0], [0.819719017, 0.756750345, 0.331362218], rtol=0, atol=1e-9)
+    # random_01 is the 32-bit output converted to float and scaled by 2^-32
+    want = golden["random_uint"].astype(np.float32) * np.float32(2.0 ** -32)
+    assert np.array_equal(out, want)
+
+
+def test_density_kernel_golden(oracle, golden):
+    y = np.array([oracle.lib.cpmo_density_kernel(float(x)) for x in golden["kernel_x"]], np.float32)
+    assert np.array_equal(y.view(np.uint32), golden["kernel_y"].view(np.uint32))
+
+
+def test_threshold_count_iota_golden(oracle, golden):
+    imp = golden["threshold_in"].copy()
+    idx, cnt = oracle.select_recompute(imp)
+    assert cnt == int(golden["threshold_out"].sum())
+    assert np.array_equal(np.sort(idx), np.arange(imp.size, dtype=np.uint32))
+    assert np.array_equal(np.arange(golden["iota"].size, dtype=np.uint32), golden["iota"])
+    # stable ascending by importance
+    order = np.argsort(golden["threshold_in"], kind="stable").astype(np.uint32)
+    assert np.array_equal(idx, order)
+    assert np.array_equal(imp, golden["threshold_in"][order])
+
+
+def test_live_reference_rng(oracle, ref):
+    rng = np.random.default_rng(7)
+    n = 3000
+    st = np.zeros((n, 2), np.uint32)
+    st[:, 0] = rng.integers(0, 2**31, n)
+    a, b = st.copy(), st.copy()
+    oracle.seed_streams(a, 1 << 40)
+    ref.generate_random_state(b)
+    assert np.array_equal(a, b)
+    oa = oracle.random_fill(a, 16)
+    ob, _ = ref.random_fill(b, 16)
+    assert np.array_equal(oa.view(np.uint32), ob.view(np.uint32)) and np.array_equal(a, b)
+
+
+def test_live_reference_density_kernel(oracle, ref):
+    x = np.random.default_rng(3).random(20000, dtype=np.float32) * np.float32(1.2)
+    want = ref.density_kernel(x)
+    got = np.array([oracle.lib.cpmo_density_kernel(float(v)) for v in x], np.float32)
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
