@@ -143,14 +143,19 @@ __global__ __launch_bounds__(256) void bin_keys_kernel(const float* __restrict__
     vals[i] = (uint32_t)i;
 }
 
-// order[j] = sorted photon index; compact (pos, power) records in cell order
+// order[j] = sorted photon index; compact (pos, power) records in cell order; and the start of
+// every run of equal keys is dropped into cell_start[key] (the table was preset to 0xffffffff).
+// Work is partitioned by photon, so clustered photons do not unbalance it.
 __global__ __launch_bounds__(256) void bin_finalize_kernel(const float* __restrict__ photons,
+                                                           const uint32_t* __restrict__ sorted_keys,
                                                            const uint32_t* __restrict__ sorted_vals, int n,
                                                            int channels, uint32_t* __restrict__ order,
-                                                           float* __restrict__ sorted) {
+                                                           float* __restrict__ sorted, uint32_t* __restrict__ cell_start) {
     int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= n) return;
     uint32_t id = sorted_vals[j];
+    uint32_t key = sorted_keys[j];
+    if (j == 0 || sorted_keys[j - 1] != key) cell_start[key] = (uint32_t)j;  // key <= cells: inside the table
     order[j] = id;
     const float4* q = reinterpret_cast<const float4*>(photons) + 2 * (size_t)id;
     float4 a = q[0];
@@ -164,64 +169,187 @@ __global__ __launch_bounds__(256) void bin_finalize_kernel(const float* __restri
     }
 }
 
-// cell_start[c] = first j with key[j] >= c, c = 0..cells (binary search in the sorted keys)
+// cell_start[c] = first j with key[j] >= c, c = 0..cells: a reverse (suffix) min-scan over the
+// table of run starts.  One workgroup owns kCsTile consecutive entries; what lies behind its
+// tile is summarised by one binary search in the sorted keys (the first j with key >= tile end),
+// so the tiles are independent: one coalesced read and one coalesced write of the table.
+constexpr int kCsTile = 2048;
+constexpr int kCsPer = kCsTile / 256;
+
 __global__ __launch_bounds__(256) void cell_start_kernel(const uint32_t* __restrict__ keys, uint32_t n, uint32_t cells,
                                                          uint32_t* __restrict__ cell_start) {
-    uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c > cells) return;
-    uint32_t lo = 0, hi = n;
-    while (lo < hi) {
-        uint32_t mid = (lo + hi) >> 1;
-        if (keys[mid] < c) lo = mid + 1; else hi = mid;
+    __shared__ uint32_t s_hi;
+    __shared__ uint32_t wmin[4];
+    const uint32_t t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const uint32_t c0 = blockIdx.x * (uint32_t)kCsTile;
+    const uint32_t c1 = min(c0 + (uint32_t)kCsTile, cells + 1);  // entries [c0, c1)
+    if (t == 0) {
+        uint32_t lo = 0, hi = n;
+        while (lo < hi) {
+            uint32_t mid = (lo + hi) >> 1;
+            if (keys[mid] < c1) lo = mid + 1; else hi = mid;
+        }
+        s_hi = lo;
     }
-    cell_start[c] = lo;
+    // thread t owns entries [c0 + t*kCsPer, +kCsPer): two 16-byte loads
+    uint32_t v[kCsPer];
+    const uint32_t base = c0 + t * kCsPer;
+#pragma unroll
+    for (int i = 0; i < kCsPer; ++i) v[i] = (base + i < c1) ? cell_start[base + i] : 0xffffffffu;
+    uint32_t m = 0xffffffffu;
+#pragma unroll
+    for (int i = kCsPer - 1; i >= 0; --i) { m = min(m, v[i]); v[i] = m; }
+    uint32_t sfx = m;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        uint32_t o = __shfl_down(sfx, off, 64);
+        if (lane + off < 64) sfx = min(sfx, o);
+    }
+    if (lane == 0) wmin[wave] = sfx;
+    __syncthreads();
+    uint32_t after = s_hi;
+#pragma unroll
+    for (int w = 3; w >= 0; --w) if (w > (int)wave) after = min(after, wmin[w]);
+    uint32_t next_lane = __shfl_down(sfx, 1, 64);
+    uint32_t behind = (lane == 63) ? after : min(next_lane, after);
+#pragma unroll
+    for (int i = 0; i < kCsPer; ++i)
+        if (base + i < c1) cell_start[base + i] = min(v[i], behind);
 }
 
 // ---- gather
+//
+// One work-item per voxel; a wave owns a compact 4x4x4 brick of voxels (photons cluster on
+// surfaces: with row-shaped waves every wave would carry a few heavy lanes, with bricks whole
+// waves are heavy or idle).  Per neighbour row the records of cells [x-R, x+R] are one
+// contiguous run of the cell-sorted array; rows and records are visited in ascending order,
+// i.e. per voxel in ascending sorted index: the sequential fp32 sum the contract defines.
+constexpr int kGW = 4;  // brick edge (voxels)
 
 template <int CH>
+CPM_DEV void gather_pair(const GridDev& G, float4 a, float pg, float pb, f3 c, int x, int y, int z, float radius,
+                         float d2, float k, float& sr, float& sg, float& sb) {
+    f3 p = { a.x, a.y, a.z };
+    Box3 bb = splat_box(G, p, radius);
+    if (x < bb.sx || x >= bb.ex || y < bb.sy || y >= bb.ey || z < bb.sz || z >= bb.ez) return;
+    float w = density_kernel_(__builtin_sqrtf(d2) / radius);
+    float vr = (a.w * k) * w;
+    if (vr != 0.f) sr += vr;
+    if (CH == 4) {
+        float vg = (pg * k) * w, vb = (pb * k) * w;
+        if (vg != 0.f) sg += vg;
+        if (vb != 0.f) sb += vb;
+    }
+}
+
+// The kernel:
+//   * a brick-level early-out: 36 lanes fetch the two cell-start boundaries of the brick's halo
+//     rows; an empty halo (the common case) costs one load latency and one store;
+//   * compaction: the cheap exact reject runs per record, survivors are parked as (j, d^2) in a
+//     per-lane LDS queue ([slot][thread]: conflict-free), and the reference's box test, sqrt and
+//     division run over the queues when some lane's queue is full -- so the expensive path
+//     executes with most lanes busy instead of once per record with one lane in ten active.
+//     A lane drains its queue in the order it filled it: the summation order is unchanged.
+constexpr int kQ = 8;
+template <int CH, int BATCH>
 __global__ __launch_bounds__(256) void gather_kernel(const float* __restrict__ sorted,
-                                                     const uint32_t* __restrict__ cell_start, GridDev G, float radius,
-                                                     float k, int Rx, int Ry, int Rz, int accumulate,
-                                                     float* __restrict__ out) {
-    const uint32_t cells = (uint32_t)G.dx * G.dy * G.dz;
-    uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
-    if (v >= cells) return;
-    int x = (int)(v % (uint32_t)G.dx);
-    int y = (int)((v / (uint32_t)G.dx) % (uint32_t)G.dy);
-    int z = (int)(v / ((uint32_t)G.dx * (uint32_t)G.dy));
-    f3 vi = { (float)x, (float)y, (float)z };
-    f3 c = transform_(G.i2t, vi);
+                                                            const uint32_t* __restrict__ cell_start, GridDev G, float radius,
+                                                            float r2max, float k, int Rx, int Ry, int Rz, int accumulate,
+                                                            int bxn, int byn, float* __restrict__ out,
+                                                            unsigned long long* __restrict__ dbg) {
+    constexpr int STRIDE = (CH == 1 ? 1 : 2);
+    __shared__ uint32_t q_j[kQ][256];
+    __shared__ float q_d2[kQ][256];
+    const unsigned long long t_start = dbg ? __builtin_amdgcn_s_memrealtime() : 0ull;
+    unsigned tests = 0;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int gb = blockIdx.x * 4 + wave;
+    const int by = (gb / bxn) % byn, bz = gb / (bxn * byn);
+    const int bx = (gb % bxn + 4 * (by + bz)) % bxn;
+    // Workgroups are dealt round-robin to the 8 XCDs by index.  Photons pile up on surfaces, so the
+    // brick a slot gets is rotated along x by 4 (by + bz): every XCD then owns an even share of each
+    // face of the volume instead of one XCD owning the whole x = 0 face (measured: 859 -> 180 us).
+    const int x0 = bx * kGW, y0 = by * kGW, z0 = bz * kGW;
+    if (z0 >= G.dz) return;
+    const int x = x0 + (lane & 3), y = y0 + ((lane >> 2) & 3), z = z0 + (lane >> 4);
+    const bool valid = x < G.dx && y < G.dy && z < G.dz;
+    // ---- brick-level early-out
+    const int nry = kGW + 2 * Ry, nrows = nry * (kGW + 2 * Rz);
+    bool any = false;
+    for (int r = lane; r < nrows; r += 64) {
+        const int cy = y0 - Ry + (r % nry), cz = z0 - Rz + (r / nry);
+        if (cy >= 0 && cy < G.dy && cz >= 0 && cz < G.dz) {
+            const uint32_t row = (uint32_t)G.dx * ((uint32_t)cy + (uint32_t)G.dy * (uint32_t)cz);
+            any |= cell_start[row + (uint32_t)min(x0 + kGW - 1 + Rx, G.dx - 1) + 1] != cell_start[row + (uint32_t)max(x0 - Rx, 0)];
+        }
+    }
     float sr = 0.f, sg = 0.f, sb = 0.f;
-    int xlo = max(x - Rx, 0), xhi = min(x + Rx, G.dx - 1);
-    for (int cz = z - Rz; cz <= z + Rz; ++cz) {
-        if (cz < 0 || cz >= G.dz) continue;
-        for (int cy = y - Ry; cy <= y + Ry; ++cy) {
-            if (cy < 0 || cy >= G.dy) continue;
-            uint32_t row = (uint32_t)G.dx * ((uint32_t)cy + (uint32_t)G.dy * (uint32_t)cz);
-            uint32_t jb = cell_start[row + xlo], je = cell_start[row + xhi + 1];
-            for (uint32_t j = jb; j < je; ++j) {
-                float4 a = reinterpret_cast<const float4*>(sorted)[(CH == 1 ? 1 : 2) * (size_t)j];
-                f3 p = { a.x, a.y, a.z };
-                Box3 bx = splat_box(G, p, radius);
-                if (x < bx.sx || x >= bx.ex || y < bx.sy || y >= bx.ey || z < bx.sz || z >= bx.ez) continue;
-                float w = splat_weight(c, p, radius);
-                float vr = (a.w * k) * w;
-                if (vr != 0.f) sr += vr;
-                if (CH == 4) {
-                    float4 b = reinterpret_cast<const float4*>(sorted)[2 * (size_t)j + 1];
-                    float vg = (b.x * k) * w, vb = (b.y * k) * w;
-                    if (vg != 0.f) sg += vg;
-                    if (vb != 0.f) sb += vb;
+    if (__any(any) && valid) {
+        f3 vi = { (float)x, (float)y, (float)z };
+        const f3 c = transform_(G.i2t, vi);
+        const int xlo = max(x - Rx, 0), xhi = min(x + Rx, G.dx - 1);
+        const float4* __restrict__ rec = reinterpret_cast<const float4*>(sorted);
+        int qn = 0;
+        auto drain = [&]() {
+            for (int s = 0; s < kQ; ++s) {
+                if (!__any(s < qn)) break;
+                if (s < qn) {
+                    const uint32_t jj = q_j[s][t];
+                    const float d2 = q_d2[s][t];
+                    float4 a = rec[STRIDE * (size_t)jj];
+                    float pg = 0.f, pb = 0.f;
+                    if (CH == 4) { float4 q = rec[2 * (size_t)jj + 1]; pg = q.x; pb = q.y; }
+                    gather_pair<CH>(G, a, pg, pb, c, x, y, z, radius, d2, k, sr, sg, sb);
+                }
+            }
+            qn = 0;
+        };
+        for (int cz = z - Rz; cz <= z + Rz; ++cz) {
+            if (cz < 0 || cz >= G.dz) continue;
+            for (int cy = y - Ry; cy <= y + Ry; ++cy) {
+                if (cy < 0 || cy >= G.dy) continue;
+                uint32_t row = (uint32_t)G.dx * ((uint32_t)cy + (uint32_t)G.dy * (uint32_t)cz);
+                uint32_t j = cell_start[row + xlo];
+                const uint32_t je = cell_start[row + xhi + 1];
+                while (j < je) {
+                    float4 a[BATCH];
+#pragma unroll
+                    for (int u = 0; u < BATCH; ++u) a[u] = rec[STRIDE * (size_t)min(j + u, je - 1)];
+                    if (__any(qn > kQ - BATCH)) drain();  // wave-uniform: everyone drains together
+#pragma unroll
+                    for (int u = 0; u < BATCH; ++u) {
+                        float ddx = c.x - a[u].x, ddy = c.y - a[u].y, ddz = c.z - a[u].z;
+                        float d2 = fma_(ddz, ddz, fma_(ddy, ddy, ddx * ddx));
+                        if (j + u < je) {
+                            ++tests;
+                            if (d2 <= r2max) { q_j[qn][t] = j + u; q_d2[qn][t] = d2; ++qn; }  // else: exactly no contribution
+                        }
+                    }
+                    j += BATCH;
                 }
             }
         }
+        drain();
     }
+    if (dbg) {
+        unsigned mx = tests, sm = tests;
+        for (int off = 32; off > 0; off >>= 1) { mx = max(mx, (unsigned)__shfl_xor(mx, off, 64)); sm += __shfl_xor(sm, off, 64); }
+        if (lane == 0) {
+            unsigned xcc = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11));
+            const size_t gbs = (size_t)bx + (size_t)bxn * ((size_t)by + (size_t)byn * (size_t)bz);
+            dbg[4 * gbs + 0] = t_start;
+            dbg[4 * gbs + 1] = __builtin_amdgcn_s_memrealtime();
+            dbg[4 * gbs + 2] = ((unsigned long long)mx << 32) | sm;
+            dbg[4 * gbs + 3] = xcc;
+        }
+    }
+    if (!valid) return;
+    const uint32_t v = (uint32_t)x + (uint32_t)G.dx * ((uint32_t)y + (uint32_t)G.dy * (uint32_t)z);
     if (CH == 1) {
         out[v] = accumulate ? out[v] + sr : sr;
     } else {
         float4* o = reinterpret_cast<float4*>(out) + v;
-        if (accumulate) { float4 t = *o; *o = make_float4(t.x + sr, t.y + sg, t.z + sb, t.w); }
+        if (accumulate) { float4 tt = *o; *o = make_float4(tt.x + sr, tt.y + sg, tt.z + sb, tt.w); }
         else *o = make_float4(sr, sg, sb, 0.f);
     }
 }
@@ -235,6 +363,10 @@ int key_bits_for(uint32_t max_key) {  // bits needed to represent max_key
 }  // namespace
 
 extern "C" {
+
+// diagnostic hook (include/cpm/cpm_profile.h): 4 x u64 per 4x4x4 brick = (start, end [100 MHz ticks], records, XCC id)
+static unsigned long long* g_gather_stamps = nullptr;
+void cpm_debug_set_gather_stamps(unsigned long long* dev) { g_gather_stamps = dev; }
 
 int cpm_splat(cpm_ctx* ctx, const float* photons8, int total_photons, const cpm_grid_desc* grid, float radius,
               float scale, float* grid_out, cpm_stream stream) {
@@ -301,11 +433,15 @@ int cpm_bin(cpm_ctx* ctx, const float* photons8, int n, const cpm_grid_desc* gri
         CPM_LAUNCH_CHECK(ctx, "bin_keys_kernel");
         rc = cpm::radix_sort(ctx, keys, vals, (size_t)n, key_bits_for(cells), s);
         if (rc) return rc;
-        CPM_LAUNCH(ctx, bin_finalize_kernel, dim3(div_up(n, 256)), dim3(256), 0, s, photons8, vals, n, G.channels,
-                           order, sorted_pos_power);
+    }
+    // run starts -> table (preset to "none"), then the suffix-min scan turns it into cell starts
+    CPM_HIP_CHECK(ctx, hipMemsetAsync(cell_start, 0xff, ((size_t)cells + 1) * sizeof(uint32_t), s));
+    if (n > 0) {
+        CPM_LAUNCH(ctx, bin_finalize_kernel, dim3(div_up(n, 256)), dim3(256), 0, s, photons8, keys, vals, n, G.channels,
+                           order, sorted_pos_power, cell_start);
         CPM_LAUNCH_CHECK(ctx, "bin_finalize_kernel");
     }
-    CPM_LAUNCH(ctx, cell_start_kernel, dim3(div_up((long long)cells + 1, 256)), dim3(256), 0, s, keys, (uint32_t)n,
+    CPM_LAUNCH(ctx, cell_start_kernel, dim3(div_up((long long)cells + 1, kCsTile)), dim3(256), 0, s, keys, (uint32_t)n,
                        cells, cell_start);
     CPM_LAUNCH_CHECK(ctx, "cell_start_kernel");
     return CPM_OK;
@@ -327,13 +463,19 @@ int cpm_gather(cpm_ctx* ctx, const float* sorted_pos_power, const uint32_t* cell
     int Ry = (int)floorf(fmaf(radius, (float)G.dy, 0.501f));
     int Rz = (int)floorf(fmaf(radius, (float)G.dz, 0.501f));
     float k = kInv4Pi * scale;
-    dim3 gridDim(div_up(cells, 256)), block(256);
+    // cheap exact reject: d^2 > r^2 (1 + 1e-5)  =>  fl(fl(sqrt(d^2)) / r) > 1  =>  weight 0
+    float r2max = (radius * radius) * 1.00001f;
+    (void)cells;
+    CPM_REQUIRE(ctx, Rx <= 2 && Ry <= 2 && Rz <= 2, "cpm_gather: radius above 2.5 light-volume voxels is not supported");
+    int bxn = div_up(G.dx, 4), byn = div_up(G.dy, 4), bzn = div_up(G.dz, 4);
+    dim3 gridDim((unsigned)div_up((long long)bxn * byn * bzn, 4)), block(256);
+    hipStream_t hs = (hipStream_t)stream;
     if (G.channels == 1)
-        CPM_LAUNCH(ctx, gather_kernel<1>, gridDim, block, 0, (hipStream_t)stream, sorted_pos_power, cell_start, G,
-                           radius, k, Rx, Ry, Rz, accumulate, grid_out);
+        CPM_LAUNCH(ctx, (gather_kernel<1, 4>), gridDim, block, 0, hs, sorted_pos_power, cell_start, G, radius, r2max, k, Rx, Ry, Rz,
+                   accumulate, bxn, byn, grid_out, g_gather_stamps);
     else
-        CPM_LAUNCH(ctx, gather_kernel<4>, gridDim, block, 0, (hipStream_t)stream, sorted_pos_power, cell_start, G,
-                           radius, k, Rx, Ry, Rz, accumulate, grid_out);
+        CPM_LAUNCH(ctx, (gather_kernel<4, 4>), gridDim, block, 0, hs, sorted_pos_power, cell_start, G, radius, r2max, k, Rx, Ry, Rz,
+                   accumulate, bxn, byn, grid_out, g_gather_stamps);
     CPM_LAUNCH_CHECK(ctx, "gather_kernel");
     return CPM_OK;
 }

@@ -148,7 +148,8 @@ def fit_plane_aligned_obb(points, plane_point, plane_normal):
 class PhotonFrame:
     """One light, one volume: owns the device buffers of the path and runs its stages.
 
-    photon_range = (lo, hi) restricts this instance to a contiguous shard of the N = n_side^2
+    n_side: an int (n_side x n_side emission lattice) or a pair (nx, ny).
+    photon_range = (lo, hi) restricts this instance to a contiguous shard of the N = nx * ny
     photons (multi-GPU: one shard per rank); photon i keeps light sample i and RNG stream i
     of the unsharded run, so results do not depend on the number of shards.
     """
@@ -164,7 +165,8 @@ class PhotonFrame:
         dev = ctx.device
         self.vol = volume if isinstance(volume, B.Volume) else ctx.volume_create(volume)
         self.tf = tf_rgba if isinstance(tf_rgba, B.TransferFunction) else ctx.tf_create(tf_rgba)
-        self.n_total = n_side * n_side
+        nx, ny = (n_side, n_side) if isinstance(n_side, int) else n_side
+        self.n_total = nx * ny
         lo, hi = photon_range if photon_range is not None else (0, self.n_total)
         self.lo, self.hi = lo, hi
         self.n = hi - lo
@@ -177,7 +179,7 @@ class PhotonFrame:
         self.scale = B.relative_irradiance_scale(self.radius, float(self.n_total))
 
         # E1: emission lattice, E2: light plane, E3/E5: light samples, E4: entry/exit
-        samples = ctx.uniform_samples_2d(n_side, n_side)[lo:hi].contiguous()
+        samples = ctx.uniform_samples_2d(nx, ny)[lo:hi].contiguous()
         if point_light_position is not None:
             self.light_samples = ctx.point_light_samples(samples, radiance, point_light_position)
         else:

@@ -21,6 +21,8 @@ double cpm_profile_total_ms(const cpm_ctx* ctx, int i);
 long cpm_profile_calls(const cpm_ctx* ctx, int i);
 /* when non-NULL, cpm_trace launches add their Woodcock iteration counts to *dev_counter */
 void cpm_debug_set_step_counter(unsigned long long* dev_counter);
+/* when non-NULL, cpm_gather launches write (start, end [100 MHz ticks], records, XCC id) per 4x4x4 brick */
+void cpm_debug_set_gather_stamps(unsigned long long* dev_stamps);
 #ifdef __cplusplus
 }
 #endif
