@@ -243,3 +243,187 @@ class PhotonFrame:
         self.bin()
         self.gather()
         return self.light_volume
+
+
+# --------------------------------------------------------------------------- C2 (host, CPU in the reference too)
+
+def _mix_prim(a, b, t):
+    """TFPrimitive mix by parameter t (ref minmaxuniformgrid3dimportanceclprocessor.cpp:519-524)."""
+    return (a[0] + (b[0] - a[0]) * t, tuple(np.float32(x) + (np.float32(y) - np.float32(x)) * np.float32(t) for x, y in zip(a[1], b[1])))
+
+
+def _mix_at(a, b, at):
+    return _mix_prim(a, b, (at[0] - a[0]) / (b[0] - a[0]))
+
+
+def _color_diff(p1, p2, associated=False):
+    """|p2 - p1| per channel (ref ...processor.cpp:503-507)."""
+    a = np.asarray(p1, np.float32) * (np.float32(p1[3]) if associated else np.float32(1))
+    b = np.asarray(p2, np.float32) * (np.float32(p2[3]) if associated else np.float32(1))
+    return tuple(np.abs(b - a).astype(np.float32))
+
+
+def tf_difference_points(tf_points, prev_points, eps=1e-4, associated=False):
+    """Break-point list of |TF_new - TF_old|, zero-padded at 0 and 1
+    (MinMaxUniformGrid3DImportanceCLProcessor::updateTransferFunctionDifferenceData,
+    ref importancesamplingcl/processors/minmaxuniformgrid3dimportanceclprocessor.cpp:364-501).
+    tf_points / prev_points: sorted lists of (position, r, g, b, a).  Returns (positions, colors4)."""
+    tf = [(float(p[0]), tuple(np.float32(c) for c in p[1:])) for p in sorted(tf_points)]
+    prev = [(float(p[0]), tuple(np.float32(c) for c in p[1:])) for p in sorted(prev_points)]
+    if not tf and not prev:
+        return np.array([0, 0], np.float32), np.zeros((2, 4), np.float32)
+
+    def ne0(c):
+        return any(abs(float(x)) > eps for x in c)
+
+    positions, colors = [], []
+    first, pfirst = tf[0], prev[0]
+    p1 = p2 = (first[0] if first[0] < pfirst[0] else pfirst[0], _color_diff(first[1], pfirst[1], associated))
+    if first[0] != pfirst[0] and first[1][3] == 0.0 and pfirst[1][3] == 0.0:
+        if first[0] < pfirst[0]:
+            a2 = tf[min(1, len(tf) - 1)]
+            p = _mix_at(first, a2, pfirst)
+            p2 = (pfirst[0], _color_diff(pfirst[1], p[1], associated))
+        else:
+            a2 = prev[min(1, len(prev) - 1)]
+            p = _mix_at(pfirst, a2, first)
+            p2 = (first[0], _color_diff(first[1], p[1], associated))
+    if p1[0] > 0.0 and (first[1][3] > 0.0 or pfirst[1][3] > 0.0) and ne0(p1[1]):
+        positions.append(0.0); colors.append(p1[1])
+    else:
+        positions.append(0.0); colors.append((0.0, 0.0, 0.0, 0.0))
+    i = j = 0
+    while i < len(tf) or j < len(prev):
+        if (ne0(p1[1]) or ne0(p2[1])) and (p1[1][3] > 0.0 or p2[1][3] > 0.0):
+            if len(positions) == 1:
+                positions.append(p1[0]); colors.append(p1[1])
+            positions.append(p2[0]); colors.append(p2[1])
+        a1 = tf[min(i, len(tf) - 1)]
+        a2 = tf[i + 1] if i + 1 < len(tf) - 1 else (1.0, tf[-1][1])
+        b1 = prev[min(j, len(prev) - 1)]
+        b2 = prev[j + 1] if j + 1 < len(prev) - 1 else (1.0, prev[-1][1])
+        p1 = p2
+        if a2[0] < b2[0]:
+            p = _mix_at(b1, b2, a2)
+            p2 = (a2[0], _color_diff(a2[1], p[1], associated)); i += 1
+        elif b2[0] < a2[0]:
+            p = _mix_at(a1, a2, b2)
+            p2 = (b2[0], _color_diff(b2[1], p[1], associated)); j += 1
+        else:
+            p2 = (b2[0] if a2[1][3] < b2[1][3] else a2[0], _color_diff(a2[1], b2[1], associated)); i += 1; j += 1
+    if p2[0] < 1.0 and p2[1][3] > 0.0:
+        positions.append(p2[0]); colors.append(p2[1])
+    if positions[-1] < 1.0:
+        positions.append(1.0); colors.append((0.0, 0.0, 0.0, 0.0))
+    return np.asarray(positions, np.float32), np.asarray(colors, np.float32).reshape(-1, 4)
+
+
+# --------------------------------------------------------------------------- correlated re-trace (C7 + G5)
+
+class CorrelatedPhotonMapper(PhotonFrame):
+    """PhotonFrame plus the correlated update after a transfer-function edit or a time step:
+    min/max bricks -> TF-difference importance per brick -> per-photon importance by DDA ->
+    select (threshold + count + iota + sort by importance) -> index-ordered re-trace of the n
+    most important photons with their ORIGINAL RNG streams -> light-volume update
+    (ProgressivePhotonTracerCL::process importance branch, ref
+    progressivephotonmapping/processor/progressivephotontracercl.cpp:265-541, and
+    PhotonToLightVolumeProcessorCL::process, ref .../photontolightvolumeprocessorcl.cpp:196-354).
+    """
+
+    def __init__(self, *args, region: int = 8, max_incremental_percent: float = 100.0,
+                 incremental_threshold_percent: float = 50.0, fix_exit_point: bool = False, tf_points=None, **kw):
+        super().__init__(*args, **kw)
+        torch, dev, ctx = self.torch, self.ctx.device, self.ctx
+        self.region = region
+        self.max_incremental_percent = max_incremental_percent
+        self.incremental_threshold_percent = incremental_threshold_percent
+        self.fix_exit_point = fix_exit_point
+        self.tf_points = list(tf_points) if tf_points is not None else list(S.WORKSPACE_TF_POINTS)
+        vd = self.vol.dims
+        self.brick_dims = tuple((d + region - 1) // region for d in vd)
+        nb = self.brick_dims[0] * self.brick_dims[1] * self.brick_dims[2]
+        self.minmax = torch.zeros((nb, 2), dtype=torch.int16, device=dev)
+        ctx.volume_minmax(self.vol, region, self.minmax)          # VolumeMinMaxCLProcessor
+        self.importance_grid = torch.zeros(nb, dtype=torch.float32, device=dev)
+        self.importance = torch.empty(self.n, dtype=torch.int32, device=dev)
+        ctx.reset_importance(self.importance, 0, self.n)
+        self.indices = torch.empty(self.n, dtype=torch.int32, device=dev)
+        self.n_changed = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.prev_photons = None
+        self.remaining_offset = 0
+        self.remaining = -1
+        self.n_recomputed = -1
+        self.last_path = None
+
+    def full_frame(self):
+        """Light / everything changed: full trace, bin + gather, snapshot (tracercl.cpp:541-560)."""
+        self.frame()
+        self.ctx.reset_importance(self.importance, 0, self.n)
+        self.prev_photons = self.photons.clone()
+        self.n_recomputed = -1
+        self.remaining, self.remaining_offset = 0, 0
+        self.last_path = "full"
+        return self.light_volume
+
+    def set_transfer_function(self, tf_points, width=1024, moved=None):
+        """A TF edit: updates the LUT and the importance grid (MinMaxUniformGrid3DImportanceCLProcessor)."""
+        pos, col = tf_difference_points(tf_points, self.tf_points)
+        self.tf_points = list(tf_points)
+        self.tf.update(S.tf_from_points(tf_points, width))
+        nb = self.importance_grid.numel()
+        self.ctx.importance_tf(self.minmax, nb, pos, col, self.importance_grid)
+        return pos, col
+
+    def correlated_update(self):
+        """One evaluation of the importance branch + the light-volume processor.  Returns n re-traced."""
+        ctx, torch = self.ctx, self.torch
+        n_total = self.n
+        vd = self.vol.dims
+        ctx.photon_importance(self.importance_grid, self.brick_dims, (float(self.region),) * 3,
+                              list(self.vol.desc.texture_to_index), self.photons, 0, self.light_samples, self.isect,
+                              n_total, self.I, n_total, self.importance, fix_exit_point=self.fix_exit_point)
+        ctx.select_recompute(self.importance, self.indices, self.n_changed)
+        n_changed = int(self.n_changed.item())              # the reference's single host sync (tracercl.cpp:374)
+        self.remaining_offset = 0
+        if self.remaining < 0 or n_changed > 0:
+            self.remaining = n_changed
+        return self._retrace_batch()
+
+    def continue_update(self):
+        """Progressive continuation on the 100 ms timer (tracercl.cpp:387-419,534-540)."""
+        if self.remaining <= 0:
+            return 0
+        return self._retrace_batch()
+
+    def _retrace_batch(self):
+        ctx, torch = self.ctx, self.torch
+        n_total = self.n
+        max_update = int((self.max_incremental_percent / 100.0) * n_total)
+        n = min(self.remaining, max_update)
+        self.n_recomputed = n
+        if n > 0:
+            idx = self.indices[self.remaining_offset:self.remaining_offset + n].contiguous()
+            ctx.sort_keys(idx, 0)                            # ascending index = emission-lattice order (:467-473)
+            self.params.flags = 0                            # correlated: RNG state is NOT written back
+            ctx.trace(self.vol, self.tf, self.aabb, self.params, self.light_samples, self.isect, self.rng, self.photons,
+                      recompute_indices=idx, n_recompute=n)
+            # importance is sorted alongside the indices: entries [offset, offset+n) belong to the re-traced photons
+            ctx.reset_importance(self.importance, self.remaining_offset, n)
+            self._update_light_volume(idx, n)
+        self.remaining_offset += n
+        self.remaining -= n
+        return n
+
+    def _update_light_volume(self, idx, n):
+        ctx = self.ctx
+        max_recomp = int(self.n * (self.incremental_threshold_percent / 100.0))
+        if self.prev_photons is not None and 0 < n < max_recomp:
+            # incremental: remove the old contributions, add the new ones (processorcl.cpp:196-298)
+            ctx.splat_selected(self.prev_photons, idx, n, self.grid, self.radius, self.scale, -1.0, self.n, self.I, self.light_volume)
+            ctx.splat_selected(self.photons, idx, n, self.grid, self.radius, self.scale, 1.0, self.n, self.I, self.light_volume)
+            self.last_path = "incremental"
+        else:
+            self.bin()
+            self.gather()
+            self.last_path = "full"
+        self.prev_photons = self.photons.clone()             # async snapshot in the reference (:343-352)

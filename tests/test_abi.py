@@ -1,0 +1,71 @@
+"""The C-ABI library loads without a GPU and exports every symbol include/cpm/*.h declares."""
+import ctypes as C
+import re
+from pathlib import Path
+
+import pytest
+
+REPO = Path(__file__).resolve().parent.parent
+
+
+def declared_functions(header: Path):
+    text = re.sub(r"/\*.*?\*/", "", header.read_text(), flags=re.S)
+    return sorted(set(re.findall(r"\b(cpm_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol(cpm):
+    lib = cpm.binding.load_library()
+    declared = declared_functions(REPO / "include" / "cpm" / "cpm.h")
+    assert len(declared) >= 30
+    missing = [f for f in declared if not hasattr(lib, f)]
+    assert not missing, f"declared in cpm.h but not exported: {missing}"
+    assert sorted(cpm.binding.ABI_SYMBOLS) == declared, "binding.ABI_SYMBOLS is out of sync with cpm.h"
+    for f in declared_functions(REPO / "include" / "cpm" / "cpm_profile.h"):
+        assert hasattr(lib, f), f
+    assert lib.cpm_abi_version() == 1
+
+
+def test_struct_layouts_match_header(cpm):
+    B = cpm.binding
+    assert C.sizeof(B.VolumeDesc) == 4 * (3 + 1 + 2 + 16 + 16)
+    assert C.sizeof(B.GridDesc) == 4 * (3 + 1 + 16 + 16)
+    assert C.sizeof(B.TraceParams) == 4 * (4 + 1 + 8)
+
+
+def test_default_descriptors_and_host_helpers(cpm, oracle):
+    import numpy as np
+    from oracle_binding import default_matrices
+    B = cpm.binding
+    for dims in ((128, 128, 128), (50, 33, 19), (512, 512, 96)):
+        g = B.default_grid_desc(dims, 1)
+        v = B.default_volume_desc(dims, B.CPM_U8)
+        t2i, i2t = default_matrices(dims)
+        assert list(g.texture_to_index) == t2i.tolist() == list(v.texture_to_index)
+        assert list(g.index_to_texture) == i2t.tolist() == list(v.index_to_texture)
+    assert np.array_equal(B.glibc_rand_sequence(0, 1000), oracle.glibc_rand_sequence(0, 1000))
+    for r, n in ((0.0067658, 1048576), (0.02, 65536), (0.5, 7)):
+        assert B.relative_irradiance_scale(r, n) == oracle.relative_irradiance_scale(r, n)
+    # SURVEY appendix B walk-through: 0.2340 at config 2
+    assert abs(B.relative_irradiance_scale(3 ** 0.5 / 256, 1048576) - 0.2340) < 2e-4
+
+
+def test_no_cpu_fallback(cpm):
+    """Without a GPU the product path must fail loudly (never compute on the CPU)."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is visible")
+    B = cpm.binding
+    lib = B.load_library()
+    h = C.c_void_p()
+    rc = lib.cpm_create(0, C.byref(h))
+    assert rc == -5 and not h.value  # CPM_ERR_NO_DEVICE
+    assert b"no HIP device" in lib.cpm_last_error_string(None)
+    with pytest.raises(B.CpmError):
+        B.Context(0)
+
+
+def test_oracle_is_not_imported_by_the_product():
+    pkg = next(p for p in REPO.iterdir() if p.is_dir() and p.name.endswith("_amd"))
+    for f in list(pkg.rglob("*.py")) + list(pkg.rglob("*.hip")) + list(pkg.rglob("*.h")) + list(pkg.rglob("*.cpp")):
+        text = f.read_text()
+        assert "oracle_binding" not in text and "cpm_oracle" not in text and "libcpm_oracle" not in text, f

@@ -1,0 +1,191 @@
+"""Parity of the correlated re-trace helpers (C1-C6, S2-S4) against the oracle, on the GPU."""
+import numpy as np
+import pytest
+
+from test_parity_gpu import _t, _n, bits, _light_setup
+
+pytestmark = pytest.mark.gpu
+FLT_MAX = np.float32(3.402823466e+38)
+
+
+@pytest.mark.parametrize("shape,dtype,region", [((64, 64, 64), np.uint8, 8), ((19, 33, 50), np.uint8, 8),
+                                                 ((32, 32, 32), np.uint16, 4), ((24, 24, 24), np.float32, 8)])
+def test_volume_minmax_and_difference(ctx, oracle, shape, dtype, region):
+    rng = np.random.default_rng(sum(shape))
+    if dtype == np.float32:
+        a, b = rng.random(shape, dtype=np.float32), rng.random(shape, dtype=np.float32)
+    else:
+        hi = np.iinfo(dtype).max + 1
+        a, b = rng.integers(0, hi, shape).astype(dtype), rng.integers(0, hi, shape).astype(dtype)
+    # smooth some structure in so that bricks differ
+    a[: shape[0] // 2] = a[: shape[0] // 2] // 4 if dtype != np.float32 else a[: shape[0] // 2] * 0.25
+    va, vb = ctx.volume_create(a), ctx.volume_create(b)
+    oa, ob = oracle.volume(a), oracle.volume(b)
+    dims = shape[::-1]
+    nb = int(np.prod([(d + region - 1) // region for d in dims]))
+    mm = ctx.torch.zeros((nb, 2), dtype=ctx.torch.int16, device=ctx.device)
+    ctx.volume_minmax(va, region, mm)
+    assert np.array_equal(_n(mm, np.uint16), oracle.volume_minmax(oa, region))
+    diff = ctx.torch.zeros(nb, dtype=ctx.torch.float32, device=ctx.device)
+    ctx.volume_difference(va, vb, region, diff)
+    assert np.array_equal(bits(_n(diff)), bits(oracle.volume_difference(oa, ob, region)))
+
+
+def _tf_diff_points():
+    # |TF_new - TF_old| break points as the processor would build them: zero-padded at 0 and 1
+    pos = np.array([0.0, 0.20, 0.2218, 0.26, 0.2851, 0.40, 1.0], np.float32)
+    col = np.array([[0, 0, 0, 0], [0, 0, 0, 0], [0.1, 0.05, 0.02, 0.19], [0.3, 0.1, 0.15, 0.2],
+                    [0.05, 0.0, 0.01, 0.02], [0, 0, 0, 0], [0, 0, 0, 0]], np.float32)
+    return pos, col
+
+
+def test_importance_tf(ctx, oracle):
+    rng = np.random.default_rng(3)
+    n = 40_000
+    lo = rng.integers(0, 65536, n)
+    hi = np.minimum(lo + rng.integers(0, 20000, n), 65535)
+    mm = np.stack([lo, hi], 1).astype(np.uint16)
+    mm[:50, 1] = mm[:50, 0]  # degenerate ranges
+    mm[50:60] = (0, 65535)
+    pos, col = _tf_diff_points()
+    out = ctx.torch.zeros(n, dtype=ctx.torch.float32, device=ctx.device)
+    ctx.importance_tf(_t(ctx, mm), n, pos, col, out)
+    want = oracle.importance_tf(mm, pos, col)
+    assert np.array_equal(bits(_n(out)), bits(want))
+    assert want.max() > 0 and (want == 0).any()
+    # time-varying variant
+    prev = mm.copy()
+    prev[:, 0] = np.maximum(prev[:, 0].astype(np.int64) - 3000, 0)
+    diff = rng.random(n, dtype=np.float32)
+    ctx.importance_tf(_t(ctx, mm), n, pos, col, out, prev_minmax=_t(ctx, prev), volume_diff=_t(ctx, diff))
+    want = oracle.importance_tf(mm, pos, col, prev=prev, diff=diff)
+    assert np.array_equal(bits(_n(out)), bits(want))
+
+
+@pytest.mark.parametrize("max_inter,fix", [(1, False), (1, True), (3, False)])
+def test_photon_importance(ctx, oracle, cpm, max_inter, fix):
+    from oracle_binding import OTraceParams, default_matrices
+    S = cpm.synthetic
+    n_side, vdim, region = 96, 64, 8
+    n = n_side * n_side
+    vol_np, tf = S.heterogeneous_volume(vdim), S.tf_from_points([(0.0, 1, 1, 1, 0.0), (0.6, 1, 1, 1, 0.0), (1.0, 1, 1, 1, 0.4)])
+    d, o, u, v, area = _light_setup(cpm, (0.3, 0.5, -1.0))
+    s = oracle.uniform_samples_2d(n_side, n_side)
+    ls = oracle.directional_light_samples(s, (1, 1, 1), d, o, u, v, area)
+    isect = oracle.light_sample_box_intersection(ls, S.UNIT_CUBE_AABB)
+    st = np.zeros((n, 2), np.uint32)
+    st[:, 0] = oracle.glibc_rand_sequence(0, n)
+    oracle.seed_streams(st, 1 << 40)
+    p = OTraceParams()
+    p.material[0] = 0.3
+    p.step_size = 1 / vdim
+    p.n_light_samples = n
+    p.max_interactions = max_inter
+    p.total_photons = n
+    ph = np.zeros((n * max_inter, 8), np.float32)
+    oracle.trace(oracle.volume(vol_np), tf, S.UNIT_CUBE_AABB, p, ls, isect, st, ph)
+    assert (ph[:n, 0] == FLT_MAX).any() and (ph[:n, 0] != FLT_MAX).any()
+    gd = (vdim // region,) * 3
+    rng = np.random.default_rng(9)
+    grid = rng.random(gd[0] * gd[1] * gd[2], dtype=np.float32)
+    grid[rng.random(grid.size) < 0.5] = 0
+    t2i, _ = default_matrices((vdim,) * 3)
+    imp0 = np.full(n + 10, 2147483647, np.uint32)
+    imp_o = imp0.copy()
+    oracle.photon_importance(grid, gd, (region,) * 3, t2i, ph, 5, ls, isect, n - 5, max_inter, n, imp_o, fix_exit_point=fix)
+    imp_d = _t(ctx, imp0)
+    ctx.photon_importance(_t(ctx, grid), gd, (float(region),) * 3, t2i.tolist(), _t(ctx, ph), 5, _t(ctx, ls), _t(ctx, isect),
+                          n - 5, max_inter, n, imp_d, fix_exit_point=fix)
+    assert np.array_equal(_n(imp_d, np.uint32), imp_o)
+    assert (imp_o[5:n] < 2147483647).any()
+    assert (imp_o[:5] == 2147483647).all() and (imp_o[n:] == 2147483647).all()
+
+
+def test_equal_importance_reset_and_select(ctx, oracle):
+    n = 100_000
+    imp0 = np.full(n, 2147483647, np.uint32)
+    a = imp0.copy()
+    oracle.photon_importance_equal(1000, n - 1000, 25, 3, a)
+    d = _t(ctx, imp0)
+    ctx.photon_importance_equal(1000, n - 1000, 25, 3, d)
+    assert np.array_equal(_n(d, np.uint32), a)
+    assert (a < 2147483647).sum() == ((np.arange(1000, n) + 3) % 4 == 0).sum()
+    # select: threshold + count + iota + stable sort by importance
+    rng = np.random.default_rng(4)
+    imp = np.full(n, 2147483647, np.uint32)
+    changed = rng.random(n) < 0.3
+    imp[changed] -= rng.integers(1, 5000, changed.sum()).astype(np.uint32)
+    want_imp = imp.copy()
+    want_idx, want_cnt = oracle.select_recompute(want_imp)
+    dimp = _t(ctx, imp)
+    didx = ctx.torch.zeros(n, dtype=ctx.torch.int32, device=ctx.device)
+    dcnt = ctx.torch.full((1,), -7, dtype=ctx.torch.int32, device=ctx.device)
+    ctx.select_recompute(dimp, didx, dcnt)
+    assert int(dcnt.item()) == want_cnt == int(changed.sum())
+    assert np.array_equal(_n(didx, np.uint32), want_idx)
+    assert np.array_equal(_n(dimp, np.uint32), want_imp)
+    # reset
+    ctx.reset_importance(dimp, 10, 500)
+    got = _n(dimp, np.uint32)
+    assert (got[10:510] == 2147483647).all() and np.array_equal(got[:10], want_imp[:10]) and np.array_equal(got[510:], want_imp[510:])
+    ctx.select_recompute(ctx.torch.zeros(0, dtype=ctx.torch.int32, device=ctx.device), didx[:0], dcnt)
+    assert int(dcnt.item()) == 0
+
+
+def test_correlated_update_end_to_end(ctx, oracle, cpm):
+    """BASELINE config 3 at reduced size: after a TF edit the importance-driven re-trace (same
+    RNG streams) reproduces a full re-trace photon for photon, the +-delta light-volume update
+    matches a full gather within fp32 tolerance, and the selection equals the oracle's."""
+    from oracle_binding import default_matrices
+    S, P = cpm.synthetic, cpm.pipeline
+    vol_np = S.heterogeneous_volume(64)
+    # a TF whose low end is transparent, so that photons travel and bricks differ in importance
+    base = [(0.0, 1, 1, 1, 0.0), (0.45, 1, 0.5, 0.2, 0.0), (0.55, 0.6, 0.3, 0.1, 0.05), (0.8, 0.9, 0.2, 0.3, 0.4), (1.0, 0.1, 0.6, 0.7, 0.5)]
+    edit = list(base)
+    edit[3] = (0.85,) + base[3][1:]
+    kw = dict(light_travel_direction=(0.3, 0.5, -1.0), tf_points=base, incremental_threshold_percent=100.0)
+    cm = P.CorrelatedPhotonMapper(ctx, vol_np, S.tf_from_points(base), 160, (32, 32, 32), **kw)
+    cm.full_frame()
+    before = _n(cm.photons).copy()
+    lv_before = _n(cm.light_volume).copy()
+    pos, col = cm.set_transfer_function(edit)
+    n = cm.correlated_update()
+    assert 0 < n < cm.n
+    after = _n(cm.photons)
+    # reference run: everything from scratch with the edited TF
+    full = P.PhotonFrame(ctx, vol_np, S.tf_from_points(edit), 160, (32, 32, 32), light_travel_direction=(0.3, 0.5, -1.0))
+    lv_full = _n(full.frame())
+    assert np.array_equal(bits(after), bits(_n(full.photons)))          # correlated == full re-trace
+    changed = (bits(after) != bits(before)).any(axis=1)
+    assert 0 < changed.sum() <= n                                        # only selected photons moved
+    idx = np.sort(_n(cm.indices, np.uint32)[:n])
+    assert np.isin(np.nonzero(changed)[0], idx).all()
+    # light volume: incremental path taken, equals the full gather within fp32 tolerance
+    assert cm.last_path == "incremental"
+    lv = _n(cm.light_volume)
+    np.testing.assert_allclose(lv, lv_full, rtol=1e-3, atol=2e-5 * float(lv_full.max()))
+    assert np.abs(lv - lv_before).max() > 0
+    # the selection against the oracle
+    t2i, _ = default_matrices((64, 64, 64))
+    ovol = oracle.volume(vol_np)
+    mm = oracle.volume_minmax(ovol, 8)
+    grid = oracle.importance_tf(mm, pos, col)
+    assert np.array_equal(bits(grid), bits(_n(cm.importance_grid)))
+    imp = np.full(cm.n, 2147483647, np.uint32)
+    oracle.photon_importance(grid, (8, 8, 8), (8.0,) * 3, t2i, before, 0, _n(cm.light_samples), _n(cm.isect), cm.n, 1, cm.n, imp)
+    oidx, ocnt = oracle.select_recompute(imp)
+    assert ocnt == n
+    assert np.array_equal(np.sort(oidx[:n]), idx)
+    # all importances are back to "unchanged" after a 100 % update
+    assert (_n(cm.importance, np.uint32) == 2147483647).all()
+    # progressive batches (25 % per evaluation) converge to the same photons
+    cm2 = P.CorrelatedPhotonMapper(ctx, vol_np, S.tf_from_points(base), 160, (32, 32, 32), max_incremental_percent=5.0, **kw)
+    cm2.full_frame()
+    cm2.set_transfer_function(edit)
+    done = cm2.correlated_update()
+    rounds = 1
+    while cm2.remaining > 0:
+        done += cm2.continue_update()
+        rounds += 1
+    assert done == n and rounds > 1
+    assert np.array_equal(bits(_n(cm2.photons)), bits(after))
