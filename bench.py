@@ -113,7 +113,9 @@ def main():
     import numpy as np
     import torch
     import cpm_amd
+    import importlib
     S, P, B = cpm_amd.synthetic, cpm_amd.pipeline, cpm_amd.binding
+    sharding = importlib.import_module(cpm_amd.__name__ + ".sharding")
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -135,14 +137,14 @@ def main():
     n_rank = nx * ny
     ctx = B.Context(local_rank)
     fr = P.PhotonFrame(ctx, vol_np, tf, (nx, ny * world), (gdim,) * 3, light_travel_direction=light_dir,
-                       photon_range=(rank * n_rank, (rank + 1) * n_rank))
+                       photon_range=sharding.shard_range(n_rank * world, rank, world))
 
     def step():
         fr.trace()
         fr.bin()
         fr.gather()
         if dist is not None:
-            dist.all_reduce(fr.light_volume)  # the one exchange step: sum of the per-rank irradiance grids over xGMI
+            sharding.allreduce_light_volume(fr.light_volume)  # the one exchange step: sum of the per-rank grids over xGMI
 
     def barrier():
         torch.cuda.synchronize()

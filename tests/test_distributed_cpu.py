@@ -1,0 +1,120 @@
+"""The N > 1 path on CPU: world_size-2 gloo.  Each rank owns a photon shard, builds its own full-size
+irradiance grid and the grids are summed with one all-reduce -- the structure bench.py runs on GPUs.
+The per-rank compute is done by the oracle here (no GPU in this container); what is under test is
+the sharding and the collective: shards tile the photon range, photon i does not depend on the
+shard it lands in, and the reduced grid equals the unsharded one within summation-order tolerance."""
+import os
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+REPO = Path(__file__).resolve().parent.parent
+
+
+def test_shard_ranges_tile(cpm):
+    sr = cpm.sharding.shard_range if hasattr(cpm, "sharding") else None
+    import importlib
+    sh = importlib.import_module(cpm.__name__ + ".sharding")
+    for n, w in ((1 << 20, 8), (10, 3), (7, 8), (0, 2)):
+        r = [sh.shard_range(n, k, w) for k in range(w)]
+        assert r[0][0] == 0 and r[-1][1] == n
+        assert all(r[k][1] == r[k + 1][0] for k in range(w - 1))
+        assert max(b - a for a, b in r) - min(b - a for a, b in r) <= 1
+    with pytest.raises(ValueError):
+        sh.shard_range(10, 2, 2)
+
+
+def _worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    sys.path.insert(0, str(REPO))
+    sys.path.insert(0, str(REPO / "tests"))
+    import importlib
+    import torch
+    import torch.distributed as dist
+    import cpm_amd
+    from oracle_binding import Oracle, OTraceParams
+    sh = importlib.import_module(cpm_amd.__name__ + ".sharding")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    S, P = cpm_amd.synthetic, cpm_amd.pipeline
+    o = Oracle()
+    nx, ny = 96, 96 * world  # weak scaling: per-rank lattice rows, as bench.py does
+    n_total = nx * ny
+    lo, hi = sh.shard_range(n_total, rank, world)
+    vol_np, tf = S.heterogeneous_volume(32), S.workspace_tf()
+    d = P._normalize((0.3, 0.5, -1.0))
+    origin = np.array([0.5] * 3, np.float32) - np.float32(2) * d
+    po, u, v = P.fit_plane_aligned_obb(S.UNIT_CUBE_VERTICES, origin, d)
+    area = float(np.float32(np.linalg.norm(u)) * np.float32(np.linalg.norm(v)))
+    s = o.uniform_samples_2d(nx, ny)[lo:hi].copy()
+    ls = o.directional_light_samples(s, (1, 1, 1), d, po, u, v, area)
+    isect = o.light_sample_box_intersection(ls, S.UNIT_CUBE_AABB)
+    st = np.zeros((n_total, 2), np.uint32)
+    st[:, 0] = o.glibc_rand_sequence(0, n_total)
+    o.seed_streams(st, 1 << 40)
+    st = st[lo:hi].copy()
+    p = OTraceParams()
+    p.step_size = 1 / 32
+    p.n_light_samples = hi - lo
+    p.max_interactions = 1
+    p.total_photons = hi - lo
+    ph = np.zeros((hi - lo, 8), np.float32)
+    o.trace(o.volume(vol_np), tf, S.UNIT_CUBE_AABB, p, ls, isect, st, ph)
+    og = o.grid((16, 16, 16), 1)
+    radius = S.photon_radius_texture((32, 32, 32), 1.0)
+    scale = o.relative_irradiance_scale(radius, n_total)  # normalised by the photons of ALL ranks
+    _, cs, srt = o.bin(ph, hi - lo, og)
+    grid = np.zeros(16 ** 3, np.float32)
+    o.gather(srt, cs, hi - lo, og, radius, scale, grid)
+    t = torch.from_numpy(grid)
+    sh.allreduce_light_volume(t)                           # the one collective of the path
+    np.save(os.path.join(out_dir, f"photons_{rank}.npy"), ph)
+    if rank == 0:
+        np.save(os.path.join(out_dir, "grid.npy"), t.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_photon_sharding_and_grid_allreduce(tmp_path, oracle, cpm):
+    import socket
+    import torch.multiprocessing as mp
+    from oracle_binding import OTraceParams
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    world = 2
+    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    # unsharded reference
+    S, P = cpm.synthetic, cpm.pipeline
+    nx, ny = 96, 96 * world
+    n = nx * ny
+    vol_np, tf = S.heterogeneous_volume(32), S.workspace_tf()
+    d = P._normalize((0.3, 0.5, -1.0))
+    origin = np.array([0.5] * 3, np.float32) - np.float32(2) * d
+    po, u, v = P.fit_plane_aligned_obb(S.UNIT_CUBE_VERTICES, origin, d)
+    area = float(np.float32(np.linalg.norm(u)) * np.float32(np.linalg.norm(v)))
+    smp = oracle.uniform_samples_2d(nx, ny)
+    ls = oracle.directional_light_samples(smp, (1, 1, 1), d, po, u, v, area)
+    isect = oracle.light_sample_box_intersection(ls, S.UNIT_CUBE_AABB)
+    st = np.zeros((n, 2), np.uint32)
+    st[:, 0] = oracle.glibc_rand_sequence(0, n)
+    oracle.seed_streams(st, 1 << 40)
+    p = OTraceParams()
+    p.step_size = 1 / 32
+    p.n_light_samples = n
+    p.max_interactions = 1
+    p.total_photons = n
+    ph = np.zeros((n, 8), np.float32)
+    oracle.trace(oracle.volume(vol_np), tf, S.UNIT_CUBE_AABB, p, ls, isect, st, ph)
+    sharded = np.concatenate([np.load(tmp_path / f"photons_{r}.npy") for r in range(world)])
+    assert np.array_equal(sharded.view(np.uint32), ph.view(np.uint32))  # photon i is shard-independent
+    og = oracle.grid((16, 16, 16), 1)
+    radius = S.photon_radius_texture((32, 32, 32), 1.0)
+    scale = oracle.relative_irradiance_scale(radius, n)
+    _, cs, srt = oracle.bin(ph, n, og)
+    want = np.zeros(16 ** 3, np.float32)
+    oracle.gather(srt, cs, n, og, radius, scale, want)
+    got = np.load(tmp_path / "grid.npy")
+    np.testing.assert_allclose(got, want, rtol=2e-5, atol=1e-6 * float(want.max()))
+    assert want.sum() > 0
