@@ -1,0 +1,687 @@
+// cpm_processors.cpp -- see cpm_processors.h.  Host logic only; all device work goes through
+// include/cpm/cpm.h.  Error behaviour follows the reference: log, skip the step, carry on.
+#include "cpm_processors.h"
+
+#include <algorithm>
+#include <cfloat>
+#include <cmath>
+
+namespace inviwo {
+
+void LogErrorImpl(const std::string& source, const std::string& msg) { fprintf(stderr, "[error] %s: %s\n", source.c_str(), msg.c_str()); }
+void LogInfoImpl(const std::string& source, const std::string& msg) { fprintf(stderr, "[info] %s: %s\n", source.c_str(), msg.c_str()); }
+
+// ---- runtime ----------------------------------------------------------------------------------------
+
+CpmRuntime& CpmRuntime::get() {
+    static CpmRuntime rt;
+    return rt;
+}
+CpmRuntime::CpmRuntime() {
+    int rc = cpm_create(0, &ctx_);
+    if (rc != CPM_OK) {
+        LogError(std::string("cpm_create failed: ") + cpm_last_error_string(nullptr));
+        ctx_ = nullptr;
+    }
+}
+CpmRuntime::~CpmRuntime() { cpm_destroy(ctx_); }
+bool CpmRuntime::check(int status, const char* what) const {
+    if (status == CPM_OK) return true;
+    LogError(std::string(what) + ": " + cpm_last_error_string(ctx_));
+    return false;
+}
+
+// ---- data ---------------------------------------------------------------------------------------------
+
+void TransferFunction::sort() {
+    std::stable_sort(points_.begin(), points_.end(), [](const TFPrimitive& a, const TFPrimitive& b) { return a.pos < b.pos; });
+}
+
+std::vector<float> TransferFunction::lut(int width) const {
+    std::vector<float> out((size_t)width * 4, 0.f);
+    if (points_.empty()) return out;
+    for (int i = 0; i < width; ++i) {
+        const double x = ((double)i + 0.5) / (double)width;
+        double c[4];
+        if (x <= points_.front().pos) {
+            const vec4& k = points_.front().color; c[0] = k.x; c[1] = k.y; c[2] = k.z; c[3] = k.w;
+        } else if (x >= points_.back().pos) {
+            const vec4& k = points_.back().color; c[0] = k.x; c[1] = k.y; c[2] = k.z; c[3] = k.w;
+        } else {
+            size_t j = 0;
+            while (j + 1 < points_.size() && points_[j + 1].pos <= x) ++j;
+            const TFPrimitive &a = points_[j], &b = points_[j + 1];
+            const double fa[4] = { a.color.x, a.color.y, a.color.z, a.color.w }, fb[4] = { b.color.x, b.color.y, b.color.z, b.color.w };
+            for (int k = 0; k < 4; ++k) c[k] = (fb[k] - fa[k]) / (b.pos - a.pos) * (x - a.pos) + fa[k];
+        }
+        for (int k = 0; k < 4; ++k) out[4 * (size_t)i + k] = (float)c[k];
+    }
+    return out;
+}
+
+// progressivephotonmapping/photondata.cpp:100-117
+void Photon::setDirection(vec3 dir) {
+    float phi = std::atan2(dir.y, dir.x);
+    float theta = std::acos(std::min(std::max(dir.z, -1.f), 1.f));
+    encodedDirection = vec2{ theta, phi };
+}
+vec3 Photon::getDirection() const {
+    return vec3{ std::sin(encodedDirection.x) * std::cos(encodedDirection.y), std::sin(encodedDirection.x) * std::sin(encodedDirection.y),
+                 std::cos(encodedDirection.x) };
+}
+
+const double PhotonData::scaleToMakeLightPowerOfOneVisibleForDirectionalLightSource = 1. / M_PI;  // photondata.cpp:38
+void PhotonData::setSize(size_t numberOfPhotons, int maxPhotonInteractions) {  // :53-59
+    maxPhotonInteractions_ = maxPhotonInteractions;
+    if (numberOfPhotons > 0) photons_.setSize(numberOfPhotons * 2 * maxPhotonInteractions);
+}
+void PhotonData::setRadius(double radiusRelativeToSceneSize, double sceneRadius) {  // :61-65
+    sceneRadius_ = sceneRadius;
+    worldSpaceRadius_ = radiusRelativeToSceneSize * sceneRadius;
+}
+void PhotonData::advanceToNextIteration(double alpha) {  // :67-70
+    setRadius(progressiveSphereRadius(getRadius(), iteration_, alpha));
+    iteration_++;
+}
+double PhotonData::progressiveSphereRadius(double radius, int iteration, double alpha) {  // :72-77 (Knaus & Zwicker eq. 20)
+    return radius * std::pow(((double)iteration + alpha) / (1.0 + (double)iteration), 1. / 3.);
+}
+double PhotonData::sphereVolume(double radius) { return std::pow(radius, 3) * (M_PI * 4. / 3.); }  // :79-81
+
+std::shared_ptr<Mesh> Mesh::unitCube() {
+    auto m = std::make_shared<Mesh>();
+    for (int z = 0; z < 2; ++z) for (int y = 0; y < 2; ++y) for (int x = 0; x < 2; ++x) m->vertices.push_back(vec3((float)x, (float)y, (float)z));
+    const int quads[6][4] = { { 0, 1, 3, 2 }, { 4, 6, 7, 5 }, { 0, 4, 5, 1 }, { 2, 3, 7, 6 }, { 0, 2, 6, 4 }, { 1, 5, 7, 3 } };
+    for (auto& q : quads) { const int t[6] = { q[0], q[1], q[2], q[0], q[2], q[3] }; m->indices.insert(m->indices.end(), t, t + 6); }
+    return m;
+}
+
+// ---- host geometry --------------------------------------------------------------------------------------
+
+namespace geometry {
+
+void projectPointsOnPlane(const std::vector<vec3>& points, const Plane& plane, vec3 u, vec3 v, std::vector<vec2>& out) {
+    vec3 n = plane.normal;
+    float d = dot(n, plane.point);
+    out.reserve(points.size());
+    for (const auto& elem : points) {
+        float distanceFromPlane = dot(n, elem) - d;
+        vec3 projectedPoint = elem - distanceFromPlane * n;
+        vec3 originToProjectedPoint = projectedPoint - plane.point;
+        out.push_back(vec2{ dot(u, originToProjectedPoint), dot(v, originToProjectedPoint) });
+    }
+}
+
+std::vector<vec2> convexHull2D(std::vector<vec2> points) {
+    std::sort(points.begin(), points.end(), [](vec2 a, vec2 b) { return a.x != b.x ? a.x < b.x : a.y < b.y; });
+    if (points.size() < 4) return points;
+    auto isPointLeftOfLine = [](vec2 p0, vec2 p1, vec2 p) { return (p1.x - p0.x) * (p.y - p0.y) - (p.x - p0.x) * (p1.y - p0.y); };
+    const int n = (int)points.size();
+    int minXMinYId = 0, minXMaxYId = 1;
+    for (; minXMaxYId < n; ++minXMaxYId) if (points[0].x != points[minXMaxYId].x) break;
+    --minXMaxYId;
+    if (minXMaxYId == n - 1) {
+        std::vector<vec2> hull{ points[minXMinYId] };
+        if (points[minXMaxYId].y != points[minXMinYId].y) hull.push_back(points[minXMaxYId]);
+        hull.push_back(points[minXMinYId]);
+        return hull;
+    }
+    int maxXMinYId = n - 1, maxXMaxYId = n - 2;  // names as in the reference (convexhull2d.cpp:84-91)
+    for (; maxXMaxYId >= 0; --maxXMaxYId) if (points[n - 1].x > points[maxXMaxYId].x) break;
+    ++maxXMaxYId;
+    std::vector<vec2> hull{ points[minXMinYId] };
+    for (int i = minXMaxYId + 1; i <= maxXMinYId; ++i) {
+        if (isPointLeftOfLine(points[minXMinYId], points[maxXMinYId], points[i]) >= 0 && i < maxXMinYId) continue;
+        while (hull.size() >= 2) {
+            if (isPointLeftOfLine(hull[hull.size() - 2], hull[hull.size() - 1], points[i]) > 0) break;
+            hull.pop_back();
+        }
+        hull.push_back(points[i]);
+    }
+    if (maxXMaxYId != maxXMinYId) hull.push_back(points[maxXMaxYId]);
+    size_t bottomHull = hull.size() - 1;
+    for (int i = maxXMaxYId; i > minXMaxYId; --i) {
+        if (isPointLeftOfLine(points[maxXMaxYId], points[minXMaxYId], points[i]) >= 0 && i > minXMaxYId) continue;
+        while (hull.size() - bottomHull >= 2) {
+            if (isPointLeftOfLine(hull[hull.size() - 2], hull[hull.size() - 1], points[i]) > 0) break;
+            hull.pop_back();
+        }
+        hull.push_back(points[i]);
+    }
+    if (minXMaxYId != minXMinYId) hull.push_back(points[maxXMinYId]);
+    return hull;
+}
+
+std::tuple<vec2, vec2, vec2> mimumBoundingRectangle(const std::vector<vec2>& hull) {
+    float minArea = FLT_MAX;
+    vec2 origin, u, v;
+    const size_t nPoints = hull.size();
+    for (size_t i = 0, j = nPoints - 1; i < nPoints; j = i, ++i) {
+        vec2 e{ hull[i].x - hull[j].x, hull[i].y - hull[j].y };
+        float len = std::sqrt(e.x * e.x + e.y * e.y);
+        vec2 e0{ e.x / len, e.y / len };
+        if (std::isnan(e0.x) || std::isnan(e0.y)) continue;
+        vec2 e1{ -e0.y, e0.x };
+        float min0 = 0.f, min1 = 0.f, max0 = 0.f, max1 = 0.f;
+        for (size_t k = 0; k < nPoints; ++k) {
+            vec2 d{ hull[k].x - hull[j].x, hull[k].y - hull[j].y };
+            float t = d.x * e0.x + d.y * e0.y;
+            min0 = std::min(min0, t); max0 = std::max(max0, t);
+            t = d.x * e1.x + d.y * e1.y;
+            min1 = std::min(min1, t); max1 = std::max(max1, t);
+        }
+        float area = (max0 - min0) * (max1 - min1);
+        if (area < minArea) {
+            minArea = area;
+            float a = std::min(min0, 0.f), b = std::min(min1, 0.f);
+            origin = vec2{ hull[j].x + a * e0.x + b * e1.x, hull[j].y + a * e0.y + b * e1.y };
+            u = vec2{ e0.x * (max0 - min0), e0.y * (max0 - min0) };
+            v = vec2{ e1.x * (max1 - min1), e1.y * (max1 - min1) };
+        }
+    }
+    return std::make_tuple(origin, u, v);
+}
+
+std::tuple<vec3, vec3, vec3> fitPlaneAlignedOrientedBoundingBox2D(const std::vector<vec3>& points, const Plane& plane) {
+    auto projectPoint = [&](vec3 p) { return p - (dot(plane.normal, p) - dot(plane.normal, plane.point)) * plane.normal; };
+    vec3 u, v;
+    if (std::fabs(plane.normal.x) > std::fabs(plane.normal.y)) u = normalize(projectPoint(vec3(1.f, 0.f, 0.f)) - plane.point);
+    else u = normalize(projectPoint(vec3(0.f, 1.f, 0.f)) - plane.point);
+    v = normalize(cross(plane.normal, u));
+    std::vector<vec2> projected;
+    projectPointsOnPlane(points, plane, u, v, projected);
+    auto hull = convexHull2D(projected);
+    vec2 bo, bu, bv;
+    std::tie(bo, bu, bv) = mimumBoundingRectangle(hull);
+    vec3 origin = plane.point + bo.x * u + bo.y * v;
+    return std::make_tuple(origin, bu.x * u + bu.y * v, bv.x * u + bv.y * v);
+}
+
+}  // namespace geometry
+
+// ---- algorithm classes ------------------------------------------------------------------------------------
+
+void MWC64XSeedGenerator::generateRandomSeeds(Buffer<uvec2>* buffer, unsigned int seed) {  // mwc64xseedgenerator.cpp:51-90
+    auto& rt = CpmRuntime::get();
+    if (!rt.valid()) return;
+    const size_t n = buffer->getSize();
+    std::vector<uint32_t> bases(n);
+    cpm_glibc_rand_sequence(seed, bases.data(), n);  // srand(seed); rand() per stream (Q13: platform independent)
+    auto& ram = buffer->ram();
+    for (size_t i = 0; i < n; ++i) ram[i] = uvec2{ bases[i], 0u };
+    buffer->upload(rt.stream());
+    rt.check(cpm_seed_streams(rt.ctx(), reinterpret_cast<uint32_t*>(buffer->device()), n, 1099511627776ull, rt.stream()), "cpm_seed_streams");
+}
+
+void UniformSampleGenerator2DCL::generateNextSamples(SampleBuffer& out, ivec2 n) {
+    auto& rt = CpmRuntime::get();
+    if (!rt.valid()) return;
+    out.setSize((size_t)n.x * n.y);
+    rt.check(cpm_uniform_samples_2d(rt.ctx(), n.x, n.y, reinterpret_cast<float*>(out.device()), rt.stream()), "cpm_uniform_samples_2d");
+}
+
+void DirectionalLightSamplerCL::sampleLightSource(const Mesh* mesh, const SampleBuffer* samples, const DirectionalLight* light, LightSamples& out) {
+    auto& rt = CpmRuntime::get();  // directionallightsamplercl.cpp:57-112
+    if (!rt.valid() || mesh->vertices.empty()) return;
+    if (samples->getSize() != out.getSize()) out.setSize(samples->getSize());
+    vec3 lightDirection = normalize(light->direction);
+    std::tie(origin_, u_, v_) = geometry::fitPlaneAlignedOrientedBoundingBox2D(mesh->vertices, geometry::Plane{ light->position, lightDirection });
+    area_ = length(u_) * length(v_);
+    const float rad[4] = { light->radiance.x, light->radiance.y, light->radiance.z, 1.f }, dir[4] = { lightDirection.x, lightDirection.y, lightDirection.z, 0.f };
+    const float o[4] = { origin_.x, origin_.y, origin_.z, 1.f }, u[4] = { u_.x, u_.y, u_.z, 0.f }, v[4] = { v_.x, v_.y, v_.z, 0.f };
+    rt.check(cpm_directional_light_samples(rt.ctx(), reinterpret_cast<const float*>(samples->device()), (int)samples->getSize(), rad, dir, o, u, v,
+                                           area_, reinterpret_cast<float*>(out.getLightSamples()->device()), rt.stream()),
+             "cpm_directional_light_samples");
+    out.advanceIteration();
+    ++out.changeStamp;
+}
+
+void LightSampleMeshIntersectionCL::meshSampleIntersection(const Mesh* mesh, LightSamples* samples) {  // lightsamplemeshintersectioncl.cpp:51-99
+    auto& rt = CpmRuntime::get();
+    if (!rt.valid() || samples->getSize() == 0) return;
+    Buffer<vec3> vtx(mesh->vertices.size());
+    vtx.ram() = mesh->vertices;
+    vtx.upload(rt.stream());
+    Buffer<int> idx(mesh->indices.size());
+    idx.ram() = mesh->indices;
+    idx.upload(rt.stream());
+    rt.check(cpm_light_sample_mesh_intersection(rt.ctx(), reinterpret_cast<const float*>(vtx.device()), idx.device(), (int)idx.getSize(),
+                                                reinterpret_cast<const float*>(samples->getLightSamples()->device()), (int)samples->getSize(),
+                                                reinterpret_cast<float*>(samples->getIntersectionPoints()->device()), rt.stream()),
+             "cpm_light_sample_mesh_intersection");
+    (void)hipStreamSynchronize(rt.stream());  // vtx / idx go out of scope
+}
+
+PhotonTracerCL::~PhotonTracerCL() {
+    auto& rt = CpmRuntime::get();
+    if (vol_) cpm_volume_destroy(rt.ctx(), vol_);
+    if (tf_) cpm_tf_destroy(rt.ctx(), tf_);
+}
+void PhotonTracerCL::setRandomSeedSize(size_t nPhotons) {
+    if (nPhotons > 0) {
+        randomState_.setSize(nPhotons);
+        MWC64XSeedGenerator().generateRandomSeeds(&randomState_, 0);
+    }
+}
+void PhotonTracerCL::syncVolume(const Volume* volume) {
+    auto& rt = CpmRuntime::get();
+    if (vol_ && volSrc_ == volume) return;
+    if (vol_) { cpm_volume_destroy(rt.ctx(), vol_); vol_ = nullptr; }
+    cpm_volume_desc d;
+    const size3_t s = volume->getDimensions();
+    const int32_t dims[3] = { (int32_t)s.x, (int32_t)s.y, (int32_t)s.z };
+    cpm_volume_desc_default(&d, dims, volume->dtype());
+    if (rt.check(cpm_volume_create(rt.ctx(), &d, volume->ramBytes.data(), 0, rt.stream(), &vol_), "cpm_volume_create")) volSrc_ = volume;
+}
+void PhotonTracerCL::syncTF(const TransferFunction& tf) {
+    auto& rt = CpmRuntime::get();
+    std::vector<float> lut = tf.lut(1024);
+    if (tf_ && lut == tfLut_) return;
+    if (!tf_) rt.check(cpm_tf_create(rt.ctx(), lut.data(), 1024, 0, rt.stream(), &tf_), "cpm_tf_create");
+    else rt.check(cpm_tf_update(rt.ctx(), tf_, lut.data(), 0, rt.stream()), "cpm_tf_update");
+    tfLut_ = std::move(lut);
+}
+void PhotonTracerCL::tracePhotons(const Volume* volume, const TransferFunction& transferFunction, const float aabb[8],
+                                  const AdvancedMaterialProperty& material, float stepSize, const LightSamples* lightSamples,
+                                  const Buffer<unsigned int>* photonsToRecomputeIndices, int nInvalidPhotons, int photonOffset, int batch,
+                                  int maxInteractions, PhotonData* photonOutData) {
+    auto& rt = CpmRuntime::get();
+    if (!rt.valid()) return;
+    if (randomState_.getSize() != photonOutData->getNumberOfPhotons()) setRandomSeedSize(photonOutData->getNumberOfPhotons());
+    syncVolume(volume);
+    syncTF(transferFunction);
+    if (!vol_ || !tf_) return;
+    cpm_trace_params p = {};
+    const vec4 m = material.getCombinedMaterialParameters();
+    p.material[0] = m.x; p.material[1] = m.y; p.material[2] = m.z; p.material[3] = m.w;
+    p.step_size = stepSize;
+    p.photon_offset = photonOffset;
+    p.n_light_samples = (int)lightSamples->getSize();
+    p.max_interactions = maxInteractions;
+    p.total_photons = (int)photonOutData->getNumberOfPhotons();
+    p.shading_type = material.getPhaseFunctionEnum();
+    // photontracercl.cpp:198-210, with the += the reference meant (Q5)
+    p.flags = (onlyMultipleScattering_ ? CPM_TRACE_NO_SINGLE_SCATTERING : 0) | (progressive_ ? CPM_TRACE_PROGRESSIVE : 0);
+    p.iteration = photonOutData->iteration();
+    p.batch = batch;
+    rt.check(cpm_trace(rt.ctx(), vol_, tf_, nullptr, aabb, &p, reinterpret_cast<const float*>(lightSamples->getLightSamples()->device()),
+                       reinterpret_cast<const float*>(lightSamples->getIntersectionPoints()->device()),
+                       photonsToRecomputeIndices ? photonsToRecomputeIndices->device() : nullptr, nInvalidPhotons,
+                       reinterpret_cast<uint32_t*>(randomState_.device()), reinterpret_cast<float*>(photonOutData->photons_.device()), rt.stream()),
+             "cpm_trace");
+}
+
+void PhotonRecomputationDetector::photonRecomputationImportance(const PhotonData* photonData, int photonOffset, const Volume* origVolume,
+                                                                const ImportanceUniformGrid3D* grid, const LightSamples& lightSamples,
+                                                                Buffer<unsigned int>& imp) {
+    auto& rt = CpmRuntime::get();  // photonrecomputationdetector.cpp:49-121 (size check fixed: Q11)
+    if (!rt.valid()) return;
+    if (imp.getSize() != photonData->getNumberOfPhotons()) imp.setSize(photonData->getNumberOfPhotons());
+    if (getEqualImportance()) {
+        rt.check(cpm_photon_importance_equal(rt.ctx(), photonOffset, (int)lightSamples.getSize(), getPercentage(), getIteration(), imp.device(), rt.stream()),
+                 "cpm_photon_importance_equal");
+        return;
+    }
+    const size3_t gd = grid->getDimensions(), cd = grid->getCellDimension(), vd = origVolume->getDimensions();
+    const int32_t dims[3] = { (int32_t)gd.x, (int32_t)gd.y, (int32_t)gd.z };
+    const float cell[3] = { (float)cd.x, (float)cd.y, (float)cd.z };
+    cpm_volume_desc d;
+    const int32_t vdims[3] = { (int32_t)vd.x, (int32_t)vd.y, (int32_t)vd.z };
+    cpm_volume_desc_default(&d, vdims, origVolume->dtype());
+    rt.check(cpm_photon_importance(rt.ctx(), grid->data.device(), dims, cell, d.texture_to_index,
+                                   reinterpret_cast<const float*>(photonData->photons_.device()), photonOffset,
+                                   reinterpret_cast<const float*>(lightSamples.getLightSamples()->device()),
+                                   reinterpret_cast<const float*>(lightSamples.getIntersectionPoints()->device()), (int)lightSamples.getSize(),
+                                   photonData->getMaxPhotonInteractions(), (int)photonData->getNumberOfPhotons(), 0, imp.device(), rt.stream()),
+             "cpm_photon_importance");
+}
+
+// ---- processors ----------------------------------------------------------------------------------------------
+
+UniformSampleGenerator2DProcessorCL::UniformSampleGenerator2DProcessorCL() {
+    addPortId("samples", false);
+    addProperty(nSamplesProp_);
+}
+void UniformSampleGenerator2DProcessorCL::process() {  // uniformsamplegenerator2dprocessorcl.cpp:77-96
+    generator_.generateNextSamples(*samples_, nSamplesProp_.get());
+    samplesPort_.setData(samples_);
+}
+
+DirectionalLightSamplerCLProcessor::DirectionalLightSamplerCLProcessor() {
+    addPortId("SceneGeometry", true); addPortId("samples", true); addPortId("light", true); addPortId("LightSamples", false);
+}
+void DirectionalLightSamplerCLProcessor::process() {  // directionallightsamplerclprocessor.cpp:79-89
+    if (!boundingVolumePort_.isReady() || !samplesPort_.isReady() || !lightsPort_.isReady()) return;
+    lightSamples_->resetIteration();  // the light / samples changed
+    lightSampler_.sampleLightSource(boundingVolumePort_.getData().get(), samplesPort_.getData().get(), lightsPort_.getData().get(), *lightSamples_);
+    intersector_.meshSampleIntersection(boundingVolumePort_.getData().get(), lightSamples_.get());
+    lightSamplesPort_.setData(lightSamples_);
+}
+
+VolumeMinMaxCLProcessor::VolumeMinMaxCLProcessor() {
+    addPortId("volume", true); addPortId("output", false);
+    addProperty(volumeRegionSize_);
+}
+void VolumeMinMaxCLProcessor::process() {  // volumeminmaxclprocessor.cpp:88-184
+    auto& rt = CpmRuntime::get();
+    if (!rt.valid() || !inport_.isReady()) return;
+    const Volume* volume = inport_.getData().get();
+    if (!vol_ || volSrc_ != volume) {
+        if (vol_) cpm_volume_destroy(rt.ctx(), vol_);
+        vol_ = nullptr;
+        cpm_volume_desc d;
+        const size3_t s = volume->getDimensions();
+        const int32_t dims[3] = { (int32_t)s.x, (int32_t)s.y, (int32_t)s.z };
+        cpm_volume_desc_default(&d, dims, volume->dtype());
+        if (!rt.check(cpm_volume_create(rt.ctx(), &d, volume->ramBytes.data(), 0, rt.stream(), &vol_), "cpm_volume_create")) return;
+        volSrc_ = volume;
+    }
+    const size_t r = (size_t)volumeRegionSize_.get();
+    const size3_t s = volume->getDimensions();
+    grid_->setCellDimension(size3_t{ r, r, r });
+    grid_->setDimensions(size3_t{ (s.x + r - 1) / r, (s.y + r - 1) / r, (s.z + r - 1) / r });
+    rt.check(cpm_volume_minmax(rt.ctx(), vol_, (int)r, grid_->data.device(), rt.stream()), "cpm_volume_minmax");
+    outport_.setData(grid_);
+}
+
+MinMaxUniformGrid3DImportanceCLProcessor::MinMaxUniformGrid3DImportanceCLProcessor() {
+    addPortId("minMaxUniformGrid3D", true); addPortId("volumeDifferenceInfo", true); addPortId("importanceUniformGrid3D", false);
+    addProperty(incrementalImportance); addProperty(useAssociatedColor_); addProperty(TFPointEpsilon_);
+}
+void MinMaxUniformGrid3DImportanceCLProcessor::setTransferFunction(const TransferFunction& tf) {
+    transferFunction_ = tf;
+    tfChanged_ = true;
+}
+vec4 MinMaxUniformGrid3DImportanceCLProcessor::tfPointColorDiff(const vec4& p1, const vec4& p2) const {
+    const float s1 = useAssociatedColor_ ? p1.w : 1.f, s2 = useAssociatedColor_ ? p2.w : 1.f;
+    return vec4(std::fabs(p2.x * s2 - p1.x * s1), std::fabs(p2.y * s2 - p1.y * s1), std::fabs(p2.z * s2 - p1.z * s1), std::fabs(p2.w * s2 - p1.w * s1));
+}
+void MinMaxUniformGrid3DImportanceCLProcessor::updateTransferFunctionData() {
+    positions_.clear(); colors_.clear();
+    const auto& tf = transferFunction_;
+    auto col = [&](const TFPrimitive& p) { return useAssociatedColor_ ? vec4(p.color.x * p.color.w, p.color.y * p.color.w, p.color.z * p.color.w, p.color.w * p.color.w) : p.color; };
+    if (tf.size() == 0) { positions_ = { 0.f, 1.f }; colors_ = { vec4(), vec4() }; return; }
+    if (tf.get(0).pos > 0.) { positions_.push_back(0.f); colors_.push_back(col(tf.get(0))); }
+    for (size_t i = 0; i < tf.size(); ++i) { positions_.push_back((float)tf.get(i).pos); colors_.push_back(col(tf.get(i))); }
+    if (tf.get(tf.size() - 1).pos < 1.) { positions_.push_back(1.f); colors_.push_back(col(tf.get(tf.size() - 1))); }
+}
+void MinMaxUniformGrid3DImportanceCLProcessor::updateTransferFunctionDifferenceData() {
+    positions_.clear(); colors_.clear();
+    const auto& tf = transferFunction_.points();
+    const auto& prev = prevTransferFunction_.points();
+    if (tf.empty() && prev.empty()) { positions_ = { 0.f, 0.f }; colors_ = { vec4(), vec4() }; return; }
+    const float eps = TFPointEpsilon_.get();
+    auto ne0 = [&](const vec4& c) { return std::fabs(c.x) > eps || std::fabs(c.y) > eps || std::fabs(c.z) > eps || std::fabs(c.w) > eps; };
+    auto mixT = [](const TFPrimitive& a, const TFPrimitive& b, double t) {
+        const float tf_ = (float)t;
+        return TFPrimitive{ a.pos + (b.pos - a.pos) * t, vec4(a.color.x + (b.color.x - a.color.x) * tf_, a.color.y + (b.color.y - a.color.y) * tf_,
+                                                              a.color.z + (b.color.z - a.color.z) * tf_, a.color.w + (b.color.w - a.color.w) * tf_) };
+    };
+    auto mixAt = [&](const TFPrimitive& a, const TFPrimitive& b, const TFPrimitive& at) { return mixT(a, b, (at.pos - a.pos) / (b.pos - a.pos)); };
+    const TFPrimitive first = tf.front(), pfirst = prev.front();
+    TFPrimitive p1, p2;
+    p1 = p2 = TFPrimitive{ first.pos < pfirst.pos ? first.pos : pfirst.pos, tfPointColorDiff(first.color, pfirst.color) };
+    if (first.pos != pfirst.pos && first.color.w == 0.f && pfirst.color.w == 0.f) {
+        if (first.pos < pfirst.pos) {
+            const TFPrimitive a2 = tf[std::min<size_t>(1, tf.size() - 1)];
+            p2 = TFPrimitive{ pfirst.pos, tfPointColorDiff(pfirst.color, mixAt(first, a2, pfirst).color) };
+        } else {
+            const TFPrimitive a2 = prev[std::min<size_t>(1, prev.size() - 1)];
+            p2 = TFPrimitive{ first.pos, tfPointColorDiff(first.color, mixAt(pfirst, a2, first).color) };
+        }
+    }
+    positions_.push_back(0.f);
+    colors_.push_back((p1.pos > 0. && (first.color.w > 0.f || pfirst.color.w > 0.f) && ne0(p1.color)) ? p1.color : vec4());
+    size_t id = 0, prevId = 0;
+    while (id < tf.size() || prevId < prev.size()) {
+        if ((ne0(p1.color) || ne0(p2.color)) && (p1.color.w > 0.f || p2.color.w > 0.f)) {
+            if (positions_.size() == 1) { positions_.push_back((float)p1.pos); colors_.push_back(p1.color); }
+            positions_.push_back((float)p2.pos); colors_.push_back(p2.color);
+        }
+        const TFPrimitive a1 = tf[std::min(id, tf.size() - 1)];
+        const TFPrimitive a2 = (id + 1 + 1 < tf.size()) ? tf[id + 1] : TFPrimitive{ 1., tf.back().color };
+        const TFPrimitive b1 = prev[std::min(prevId, prev.size() - 1)];
+        const TFPrimitive b2 = (prevId + 1 + 1 < prev.size()) ? prev[prevId + 1] : TFPrimitive{ 1., prev.back().color };
+        p1 = p2;
+        if (a2.pos < b2.pos) { p2 = TFPrimitive{ a2.pos, tfPointColorDiff(a2.color, mixAt(b1, b2, a2).color) }; ++id; }
+        else if (b2.pos < a2.pos) { p2 = TFPrimitive{ b2.pos, tfPointColorDiff(b2.color, mixAt(a1, a2, b2).color) }; ++prevId; }
+        else { p2 = TFPrimitive{ a2.color.w < b2.color.w ? b2.pos : a2.pos, tfPointColorDiff(a2.color, b2.color) }; ++id; ++prevId; }
+    }
+    if (p2.pos < 1. && p2.color.w > 0.f) { positions_.push_back((float)p2.pos); colors_.push_back(p2.color); }
+    if (positions_.back() < 1.f) { positions_.push_back(1.f); colors_.push_back(vec4()); }
+}
+void MinMaxUniformGrid3DImportanceCLProcessor::process() {  // minmaxuniformgrid3dimportanceclprocessor.cpp:110-216
+    auto& rt = CpmRuntime::get();
+    if (!rt.valid() || !minMaxUniformGrid3DInport_.isReady()) return;
+    auto minMax = std::dynamic_pointer_cast<MinMaxUniformGrid3D>(minMaxUniformGrid3DInport_.getData());
+    if (!minMax) { LogError("minMaxUniformGrid3DInport_ expects MinMaxUniformGrid3D as input"); return; }
+    const size3_t d = minMax->getDimensions();
+    const size3_t cur = importance_->getDimensions();
+    if (cur.x != d.x || cur.y != d.y || cur.z != d.z) { importance_->setDimensions(d); importance_->setCellDimension(minMax->getCellDimension()); }
+    if (tfChanged_) {
+        if (prevTransferFunction_.size() == 0 || !incrementalImportance) updateTransferFunctionData();
+        else updateTransferFunctionDifferenceData();
+        prevTransferFunction_ = transferFunction_;
+        tfChanged_ = false;
+    } else if (positions_.empty()) {
+        updateTransferFunctionData();
+    }
+    const int nElements = (int)(d.x * d.y * d.z);
+    rt.check(cpm_importance_tf(rt.ctx(), minMax->data.device(), nullptr, nullptr, nElements, positions_.data(), reinterpret_cast<const float*>(colors_.data()),
+                               (int)positions_.size(), importance_->data.device(), rt.stream()),
+             "cpm_importance_tf");
+    importanceUniformGrid3DOutport_.setData(importance_);
+}
+
+ProgressivePhotonTracerCL::ProgressivePhotonTracerCL() {
+    for (const char* id : { "volume", "recomputationImportance", "LightSamples" }) addPortId(id, true);
+    for (const char* id : { "photons", "recomputedIndices" }) addPortId(id, false);
+    recomputationImportanceGrid_.setOptional(true);
+    recomputationImportanceGrid_.onConnect([this]() { invalidateProgressiveRendering(PhotonData::InvalidationReason::All); });
+    for (PropertyBase* p : std::initializer_list<PropertyBase*>{ &samplingRate_, &radius_, &sceneRadianceScaling_, &maxIncrementalPhotonsToUpdate_,
+                                                                &equalIncrementalImportance_, &spatialSorting_, &maxScatteringEvents_, &noSingleScattering_,
+                                                                &alphaProp_, &workGroupSize_, &useGLSharing_, &enableProgressiveRefinement_,
+                                                                &enableProgressivePhotonRecomputation_, &clipX_, &clipY_, &clipZ_ })
+        addProperty(*p);
+    equalIncrementalImportance_.onChange([this]() { photonRecomputationDetector_.setEqualImportance(equalIncrementalImportance_.get()); });
+    noSingleScattering_.onChange([this]() { photonTracer_.setNoSingleScattering(noSingleScattering_.get()); });
+    maxScatteringEvents_.onChange([this]() { invalidateProgressiveRendering(PhotonData::InvalidationReason::All); });
+    clipX_.onChange([this]() { onClipChange(); });
+    clipY_.onChange([this]() { onClipChange(); });
+    clipZ_.onChange([this]() { onClipChange(); });
+}
+void ProgressivePhotonTracerCL::onClipChange() {  // progressivephotontracercl.cpp:672-686
+    if (!volumePort_.isReady()) return;
+    const size3_t d = volumePort_.getData()->getDimensions();
+    aabb_[0] = (float)clipX_.get().x / (float)d.x; aabb_[1] = (float)clipY_.get().x / (float)d.y; aabb_[2] = (float)clipZ_.get().x / (float)d.z; aabb_[3] = 1.f;
+    aabb_[4] = (float)clipX_.get().y / (float)d.x; aabb_[5] = (float)clipY_.get().y / (float)d.y; aabb_[6] = (float)clipZ_.get().y / (float)d.z; aabb_[7] = 1.f;
+    invalidateProgressiveRendering(PhotonData::InvalidationReason::All);
+}
+void ProgressivePhotonTracerCL::resetPhotonImportance(size_t offset, size_t n) {  // :607-611
+    auto& rt = CpmRuntime::get();
+    rt.check(cpm_reset_importance(rt.ctx(), photonRecomputationImportance_.device(), offset, n, rt.stream()), "cpm_reset_importance");
+}
+void ProgressivePhotonTracerCL::process() {  // progressivephotontracercl.cpp:219-605
+    auto& rt = CpmRuntime::get();
+    if (!photonTracer_.isValid() || !volumePort_.isReady()) return;
+    const auto lights = lightSamples_.getVectorData();
+    size_t nPhotons = 0;
+    // lightSamples_.onChange (tracercl.cpp:119-126): a light whose samples were rewritten since the last
+    // evaluation and that reports isReset() invalidates with reason Light
+    std::vector<std::pair<const LightSamples*, size_t>> now;
+    for (auto& l : lights) {
+        nPhotons += l->getSize();
+        now.emplace_back(l.get(), l->changeStamp);
+        bool seen = false;
+        for (auto& s : seenLights_) seen |= (s.first == l.get() && s.second == l->changeStamp);
+        if (!seen && l->isReset()) invalidateProgressiveRendering(PhotonData::InvalidationReason::Light);
+    }
+    seenLights_ = std::move(now);
+    if (nPhotons != photonData_->getNumberOfPhotons() || maxScatteringEvents_.get() != photonData_->getMaxPhotonInteractions()) {
+        photonData_->setSize(nPhotons, maxScatteringEvents_.get());
+        invalidateProgressiveRendering(PhotonData::InvalidationReason::All);
+    }
+    const Volume* volume = volumePort_.getData().get();
+    const size3_t vd = volume->getDimensions();
+    const float sceneRadius = getSceneRadius();
+    const float spacing = std::min(1.f / (float)vd.x, std::min(1.f / (float)vd.y, 1.f / (float)vd.z));
+    const float stepSize = samplingRate_.get() * spacing;
+    const int maxInteractions = maxScatteringEvents_.get();
+    const int flag = static_cast<int>(invalidationFlag_);
+    const int lightFlag = static_cast<int>(PhotonData::InvalidationReason::Light), tfFlag = static_cast<int>(PhotonData::InvalidationReason::TransferFunction),
+              volFlag = static_cast<int>(PhotonData::InvalidationReason::Volume), camFlag = static_cast<int>(PhotonData::InvalidationReason::Camera);
+    if (flag == 0 || (flag & (lightFlag | camFlag | tfFlag | volFlag))) photonData_->resetIteration();
+    if (photonData_->iteration() == 0) {
+        const float r = radius_.get();
+        const float rx = r / (float)vd.x, ry = r / (float)vd.y, rz = r / (float)vd.z;  // indexToTexture * (r, r, r, 0)
+        photonData_->setRadius(std::sqrt(rx * rx + ry * ry + rz * rz), sceneRadius);
+        photonData_->setIteration(1);
+    } else {
+        photonData_->advanceToNextIteration(alphaProp_.get());
+    }
+    size_t nPhotonsToCompute = photonData_->getNumberOfPhotons();
+    if (!(flag & lightFlag) && recomputationImportanceGrid_.isReady() && photonRecomputationDetector_.isValid()) {
+        if (photonRecomputationImportance_.getSize() != photonData_->getNumberOfPhotons()) {
+            photonRecomputationImportance_.setSize(photonData_->getNumberOfPhotons());
+            resetPhotonImportance(0, photonRecomputationImportance_.getSize());
+        }
+        if (recomputedPhotonIndices_->indicesToRecomputedPhotons.getSize() != photonData_->getNumberOfPhotons())
+            recomputedPhotonIndices_->indicesToRecomputedPhotons.setSize(photonData_->getNumberOfPhotons());
+        if (flag & (tfFlag | volFlag)) {
+            auto grid = std::dynamic_pointer_cast<ImportanceUniformGrid3D>(recomputationImportanceGrid_.getData());
+            if (!grid) { LogError("UniformGrid3DInport require ImportanceUniformGrid3D as input"); return; }
+            photonRecomputationDetector_.setPercentage((int)maxIncrementalPhotonsToUpdate_.get());
+            photonRecomputationDetector_.setIteration(photonRecomputationDetector_.getIteration() + 1);
+            int offset = 0;
+            for (auto& l : lights) {
+                photonRecomputationDetector_.photonRecomputationImportance(photonData_.get(), offset, volume, grid.get(), *l, photonRecomputationImportance_);
+                offset += (int)l->getSize();
+            }
+            // threshold + count + iota + sort by importance, fused; the count is read once (Q10)
+            rt.check(cpm_select_recompute(rt.ctx(), photonRecomputationImportance_.device(), photonRecomputationImportance_.getSize(),
+                                          recomputedPhotonIndices_->indicesToRecomputedPhotons.device(), nChanged_.device(), rt.stream()),
+                     "cpm_select_recompute");
+            nChanged_.download(rt.stream());
+            const int nPhotonsToRecompute = nChanged_.ram()[0];
+            remainingPhotonsOffset_ = 0;
+            if (remainingPhotonsToUpdate_ < 0 || nPhotonsToRecompute > 0) remainingPhotonsToUpdate_ = nPhotonsToRecompute;
+        }
+        const int maxPhotonsToUpdate = (int)((maxIncrementalPhotonsToUpdate_.get() / 100.f) * (float)photonData_->getNumberOfPhotons());
+        nPhotonsToCompute = (size_t)std::max(0, std::min(remainingPhotonsToUpdate_, maxPhotonsToUpdate));
+        unsigned int* idx = recomputedPhotonIndices_->indicesToRecomputedPhotons.device();
+        if (remainingPhotonsOffset_ > 0 && nPhotonsToCompute > 0)  // the reference's overlap-safe block move (:389-419)
+            (void)hipMemcpyAsync(idx, idx + remainingPhotonsOffset_, nPhotonsToCompute * sizeof(unsigned int), hipMemcpyDeviceToDevice, rt.stream());
+        recomputedPhotonIndices_->nRecomputedPhotons = (int)nPhotonsToCompute;
+        if (recomputedPhotonIndices_->nRecomputedPhotons > 0) {
+            if (spatialSorting_.get())  // ascending index = emission-lattice order (:467-473)
+                rt.check(cpm_sort_keys(rt.ctx(), idx, nPhotonsToCompute, 0, rt.stream()), "cpm_sort_keys");
+            int offset = 0;
+            for (auto& l : lights) {
+                photonTracer_.tracePhotons(volume, transferFunction_, aabb_, advancedMaterial_, stepSize, l.get(),
+                                           &recomputedPhotonIndices_->indicesToRecomputedPhotons, recomputedPhotonIndices_->nRecomputedPhotons, offset, 0,
+                                           maxInteractions, photonData_.get());
+                offset += (int)l->getSize();
+            }
+            resetPhotonImportance((size_t)remainingPhotonsOffset_, nPhotonsToCompute);
+        }
+        remainingPhotonsOffset_ += (int)nPhotonsToCompute;
+        remainingPhotonsToUpdate_ -= (int)nPhotonsToCompute;
+        enableProgressiveRefinement_.set(remainingPhotonsToUpdate_ > 0 && enableProgressivePhotonRecomputation_.get());
+    } else {
+        int offset = 0;
+        for (auto& l : lights) {
+            photonTracer_.tracePhotons(volume, transferFunction_, aabb_, advancedMaterial_, stepSize, l.get(), nullptr, 0, offset, 0, maxInteractions,
+                                       photonData_.get());
+            offset += (int)l->getSize();
+        }
+        recomputedPhotonIndices_->nRecomputedPhotons = -1;
+        remainingPhotonsToUpdate_ = 0;
+        remainingPhotonsOffset_ = 0;
+        if (photonRecomputationImportance_.getSize() > 0) resetPhotonImportance(0, photonRecomputationImportance_.getSize());
+    }
+    (void)nPhotonsToCompute;
+    recomputedIndicesPort_.setData(recomputedPhotonIndices_);
+    photonData_->setInvalidationReason(invalidationFlag_);
+    invalidationFlag_ = PhotonData::InvalidationReason(0);
+    outport_.setData(photonData_);
+}
+
+PhotonToLightVolumeProcessorCL::PhotonToLightVolumeProcessorCL() {
+    for (const char* id : { "volume", "photons", "recomputedPhotonIndices" }) addPortId(id, true);
+    addPortId("lightvolume", false);
+    recomputedPhotonIndicesPort_.setOptional(true);
+    for (PropertyBase* p : std::initializer_list<PropertyBase*>{ &incrementalRecomputationThreshold_, &volumeSizeOption_, &volumeDataTypeOption_,
+                                                                &alignChangedPhotons_, &workGroupSize_, &useGLSharing_, &formulation_ })
+        addProperty(*p);
+    volumeSizeOption_.onChange([this]() { volumeSizeOptionChanged(); });
+    volumeDataTypeOption_.onChange([this]() {
+        lightVolume_->channels = volumeDataTypeOption_.get() == "4xfloat32" ? 4 : 1;
+        lightVolume_->data.setSize(0);
+        prevPhotons_.setSize(0);
+    });
+    outport_.setData(lightVolume_);
+}
+void PhotonToLightVolumeProcessorCL::volumeSizeOptionChanged() {  // photontolightvolumeprocessorcl.cpp:474-488
+    if (volumeInport_.hasData() && volumeSizeOption_.get() != 0) {
+        const size3_t in = volumeInport_.getData()->getDimensions();
+        const size_t k = (size_t)volumeSizeOption_.get();
+        const size3_t ns{ in.x / k, in.y / k, in.z / k }, cur = lightVolume_->getDimensions();
+        if (ns.x != cur.x || ns.y != cur.y || ns.z != cur.z) { lightVolume_->setDimensions(ns); prevPhotons_.setSize(0); }
+    }
+}
+void PhotonToLightVolumeProcessorCL::process() {  // photontolightvolumeprocessorcl.cpp:137-354
+    auto& rt = CpmRuntime::get();
+    if (!rt.valid() || !photons_.isReady() || !volumeInport_.isReady()) return;
+    auto photonData = photons_.getData();
+    if (volumeSizeOption_.get() == 0) {  // size from the photon radius (:144-163, Q15)
+        const size_t n = (size_t)std::ceil(1.0 / photonData->getRadiusRelativeToSceneSize());
+        const size3_t cur = lightVolume_->getDimensions();
+        if (cur.x != n || cur.y != n || cur.z != n) { lightVolume_->setDimensions(size3_t{ n, n, n }); prevPhotons_.setSize(0); }
+    } else {
+        volumeSizeOptionChanged();
+    }
+    const size3_t outDim = lightVolume_->getDimensions();
+    const size_t cells = outDim.x * outDim.y * outDim.z;
+    const int channels = lightVolume_->channels;
+    bool fresh = false;
+    if (lightVolume_->data.getSize() != cells * channels) { lightVolume_->data.setSize(cells * channels); fresh = true; }
+    cpm_grid_desc g;
+    const int32_t gd[3] = { (int32_t)outDim.x, (int32_t)outDim.y, (int32_t)outDim.z };
+    cpm_grid_desc_default(&g, gd, channels);
+    const int nPhotons = (int)photonData->getNumberOfPhotons(), nInter = photonData->getMaxPhotonInteractions();
+    const float radius = (float)photonData->getRadiusRelativeToSceneSize();
+    const float scale = cpm_relative_irradiance_scale(photonData->getRadiusRelativeToSceneSize(), (double)nPhotons);
+    const float* photons = reinterpret_cast<const float*>(photonData->photons_.device());
+    float* out = lightVolume_->data.device();
+    const int maxRecomputationPhotons = (int)((float)nPhotons * (incrementalRecomputationThreshold_.get() / 100.f));
+    const bool haveIdx = recomputedPhotonIndicesPort_.isReady();
+    const int nRecomputed = haveIdx ? recomputedPhotonIndicesPort_.getData()->nRecomputedPhotons : -1;
+    if (!fresh && haveIdx && prevPhotons_.getSize() == photonData->photons_.getSize() && nRecomputed > 0 && nRecomputed < maxRecomputationPhotons) {
+        // add-remove (:196-298): -old, +new over the re-traced photons
+        const unsigned int* idx = recomputedPhotonIndicesPort_.getData()->indicesToRecomputedPhotons.device();
+        rt.check(cpm_splat_selected(rt.ctx(), reinterpret_cast<const float*>(prevPhotons_.device()), idx, nRecomputed, &g, radius, scale, -1.f, nPhotons,
+                                    nInter, out, rt.stream()), "cpm_splat_selected(-)");
+        rt.check(cpm_splat_selected(rt.ctx(), photons, idx, nRecomputed, &g, radius, scale, 1.f, nPhotons, nInter, out, rt.stream()), "cpm_splat_selected(+)");
+        lastPath_ = "incremental";
+    } else if (fresh || prevPhotons_.getSize() != photonData->photons_.getSize() || nRecomputed < 0 || nRecomputed >= maxRecomputationPhotons) {
+        if (formulation_.get() == "splat") {  // the reference's formulation: clear + atomic splat (:299-339)
+            (void)hipMemsetAsync(out, 0, cells * channels * sizeof(float), rt.stream());
+            rt.check(cpm_splat(rt.ctx(), photons, nPhotons, &g, radius, scale, out, rt.stream()), "cpm_splat");
+        } else {  // sort/bin + deterministic per-cell gather
+            const size_t m = (size_t)nPhotons * nInter;
+            order_.setSize(m); cellStart_.setSize(cells + 1); sorted_.setSize(m * (channels == 1 ? 4 : 8));
+            if (rt.check(cpm_bin(rt.ctx(), photons, (int)m, &g, order_.device(), cellStart_.device(), sorted_.device(), rt.stream()), "cpm_bin"))
+                rt.check(cpm_gather(rt.ctx(), sorted_.device(), cellStart_.device(), (int)m, &g, radius, scale, 0, out, rt.stream()), "cpm_gather");
+        }
+        lastPath_ = "full";
+    } else {
+        lastPath_ = "unchanged";
+    }
+    if (haveIdx && nRecomputed != 0) {  // snapshot for the next add-remove (:343-352)
+        if (prevPhotons_.getSize() != photonData->photons_.getSize()) prevPhotons_.setSize(photonData->photons_.getSize());
+        (void)hipMemcpyAsync(prevPhotons_.device(), photonData->photons_.device(), photonData->photons_.getSizeInBytes(), hipMemcpyDeviceToDevice, rt.stream());
+    }
+    outport_.setData(lightVolume_);
+}
+
+}  // namespace inviwo

@@ -1,0 +1,384 @@
+// cpm_processors.h -- host layer above the C-ABI, mirroring the reference's operator / plugin
+// interface for the path: same class names, class identifiers, port ids, property ids,
+// defaults and error behaviour (log and carry on), so that the modules stay a drop-in for the
+// CorrelatedPhotonMappingSingleVolume workspace.  Each class cites what it mirrors (paths
+// relative to /root/reference/modules).  Everything below calls only include/cpm/cpm.h.
+#pragma once
+#include <memory>
+#include <string>
+#include <tuple>
+#include <vector>
+
+#include "cpm/cpm.h"
+#include "inviwo_lite.h"
+
+namespace inviwo {
+
+// The one libcpm_hip context of the process (stands where OpenCL::getPtr() stood).
+class CpmRuntime {
+public:
+    static CpmRuntime& get();
+    cpm_ctx* ctx() const { return ctx_; }
+    hipStream_t stream() const { return nullptr; }
+    bool valid() const { return ctx_ != nullptr; }
+    // log-and-swallow, like the reference's catch (cl::Error&) { LogError(...) }
+    bool check(int status, const char* what) const;
+private:
+    CpmRuntime();
+    ~CpmRuntime();
+    cpm_ctx* ctx_ = nullptr;
+};
+
+// ---- data types (L2) ---------------------------------------------------------------------------
+
+// progressivephotonmapping/photondata.h:47-56
+struct Photon {
+    vec3 pos;
+    vec3 power;
+    vec2 encodedDirection;
+    void setDirection(vec3 dir);
+    vec3 getDirection() const;
+};
+static_assert(sizeof(Photon) == 32, "Photon must match the 32-byte device record");
+
+// progressivephotonmapping/photondata.h:58-63
+struct RecomputedPhotonIndices {
+    Buffer<unsigned int> indicesToRecomputedPhotons;
+    int nRecomputedPhotons = -1;
+    bool isInitialized() const { return nRecomputedPhotons != -1; }
+    void setUninitialized() { nRecomputedPhotons = -1; }
+};
+
+// progressivephotonmapping/photondata.h:65-156, photondata.cpp:36-98
+class PhotonData {
+public:
+    enum class InvalidationReason { Camera = 1, TransferFunction = 2, Light = 4, Progressive = 8, Volume = 16, All = 31 };
+    void setSize(size_t numberOfPhotons, int maxPhotonInteractions);
+    size_t getNumberOfPhotons() const { return photons_.getSize() / (2 * maxPhotonInteractions_); }
+    int getMaxPhotonInteractions() const { return maxPhotonInteractions_; }
+    void setRadius(double radiusRelativeToSceneSize, double sceneRadius);
+    void setRadius(double radius) { worldSpaceRadius_ = radius; }
+    void advanceToNextIteration(double alpha = 0.5);
+    double getRadiusRelativeToSceneSize() const { return getRadius() / sceneRadius_; }
+    double getRadius() const { return worldSpaceRadius_; }
+    static double progressiveSphereRadius(double radius, int iteration, double alpha);
+    static double sphereVolume(double radius);
+    double getSceneRadius() const { return sceneRadius_; }
+    void resetIteration() { iteration_ = 0; }
+    int iteration() const { return iteration_; }
+    void setIteration(int v) { iteration_ = v; }
+    InvalidationReason getInvalidationReason() const { return invalidationFlag_; }
+    void setInvalidationReason(InvalidationReason v) { invalidationFlag_ = v; }
+    Buffer<vec4> photons_;  // 2 vec4 per photon record, N * I records
+    static const double scaleToMakeLightPowerOfOneVisibleForDirectionalLightSource;
+private:
+    int maxPhotonInteractions_ = 1;
+    double sceneRadius_ = 1.0, worldSpaceRadius_ = 0.01;
+    int iteration_ = 0;
+    InvalidationReason invalidationFlag_ = InvalidationReason::All;
+};
+inline PhotonData::InvalidationReason operator|(PhotonData::InvalidationReason a, PhotonData::InvalidationReason b) {
+    return static_cast<PhotonData::InvalidationReason>(static_cast<int>(a) | static_cast<int>(b));
+}
+
+// lightcl/lightsample.h:88-115 (32-byte POD samples: SURVEY Q12)
+class LightSamples {
+public:
+    explicit LightSamples(size_t n = 0) { setSize(n); }
+    Buffer<Photon>* getLightSamples() { return &lightSamples_; }
+    const Buffer<Photon>* getLightSamples() const { return &lightSamples_; }
+    Buffer<vec2>* getIntersectionPoints() { return &intersectionPoints_; }
+    const Buffer<vec2>* getIntersectionPoints() const { return &intersectionPoints_; }
+    void setSize(size_t n) { lightSamples_.setSize(n); intersectionPoints_.setSize(n); }
+    size_t getSize() const { return lightSamples_.getSize(); }
+    void resetIteration() { iteration_ = 0; }
+    void advanceIteration() { ++iteration_; }
+    bool isReset() const { return iteration_ <= 1; }
+    size_t getIteration() const { return iteration_; }
+    size_t changeStamp = 0;  // bumped by the sampler whenever the samples are rewritten (stands for the port's onChange)
+private:
+    Buffer<Photon> lightSamples_;
+    Buffer<vec2> intersectionPoints_;
+    size_t iteration_ = 0;
+};
+using SampleBuffer = Buffer<vec4>;  // lightcl/sample.h
+
+// uniformgridcl/uniformgrid3d.h:63-136
+class UniformGrid3DBase {
+public:
+    virtual ~UniformGrid3DBase() = default;
+    size3_t getDimensions() const { return dims_; }
+    void setDimensions(size3_t d) { dims_ = d; resize(d.x * d.y * d.z); }
+    size3_t getCellDimension() const { return cellDim_; }
+    void setCellDimension(size3_t c) { cellDim_ = c; }
+protected:
+    virtual void resize(size_t n) = 0;
+    size3_t dims_{ 0, 0, 0 }, cellDim_{ 8, 8, 8 };
+};
+struct MinMaxUniformGrid3D : UniformGrid3DBase {   // u16 x 2 per cell
+    Buffer<uint16_t> data;
+    void resize(size_t n) override { data.setSize(2 * n); }
+};
+struct ImportanceUniformGrid3D : UniformGrid3DBase {  // f32 per cell
+    Buffer<float> data;
+    void resize(size_t n) override { data.setSize(n); }
+};
+struct DynamicVolumeInfoUniformGrid3D : UniformGrid3DBase {
+    Buffer<float> data;
+    void resize(size_t n) override { data.setSize(n); }
+};
+
+struct DirectionalLight {  // what baseLightToPackedLight yields in data space
+    vec3 position{ 0.5f, 0.5f, -1.5f };
+    vec3 direction{ 0.f, 0.f, 1.f };   // photon travel direction
+    vec3 radiance{ 1.f, 1.f, 1.f };
+};
+struct Mesh {  // proxy geometry: vertex positions (data space) + triangle indices
+    std::vector<vec3> vertices;
+    std::vector<int> indices;
+    static std::shared_ptr<Mesh> unitCube();
+};
+
+// ---- host geometry (lightcl/*.cpp) ---------------------------------------------------------------
+
+namespace geometry {
+struct Plane { vec3 point, normal; };
+void projectPointsOnPlane(const std::vector<vec3>& points, const Plane& plane, vec3 u, vec3 v, std::vector<vec2>& out);  // pointplaneprojection.cpp:39-54
+std::vector<vec2> convexHull2D(std::vector<vec2> points);                                                                 // convexhull2d.cpp:38-130
+std::tuple<vec2, vec2, vec2> mimumBoundingRectangle(const std::vector<vec2>& hull);                                      // orientedboundingbox2d.cpp:40-78
+std::tuple<vec3, vec3, vec3> fitPlaneAlignedOrientedBoundingBox2D(const std::vector<vec3>& points, const Plane& plane);  // :80-100
+}  // namespace geometry
+
+// ---- algorithm classes (L3) ------------------------------------------------------------------------
+
+// rndgenmwc64x/mwc64xseedgenerator.{h,cpp}
+class MWC64XSeedGenerator {
+public:
+    void generateRandomSeeds(Buffer<uvec2>* buffer, unsigned int seed);
+};
+
+// importancesamplingcl/uniformsamplegenerator2dcl.{h,cpp}
+class UniformSampleGenerator2DCL {
+public:
+    void generateNextSamples(SampleBuffer& positionSamplesOut, ivec2 nSamples);
+};
+
+// lightcl/directionallightsamplercl.{h,cpp} + lightcl/lightsamplemeshintersectioncl.{h,cpp}
+class DirectionalLightSamplerCL {
+public:
+    void sampleLightSource(const Mesh* mesh, const SampleBuffer* samples, const DirectionalLight* light, LightSamples& lightSamplesOut);
+    std::tuple<vec3, vec3, vec3, float> lastPlane() const { return std::make_tuple(origin_, u_, v_, area_); }
+private:
+    vec3 origin_, u_, v_;
+    float area_ = 0;
+};
+class LightSampleMeshIntersectionCL {
+public:
+    void meshSampleIntersection(const Mesh* mesh, LightSamples* samples);
+};
+
+struct AdvancedMaterialProperty {
+    vec4 combined{ 0.f, 0.f, 0.f, 0.f };  // .x = anisotropy g
+    int phaseFunction = CPM_PHASE_HENYEY_GREENSTEIN;
+    vec4 getCombinedMaterialParameters() const { return combined; }
+    int getPhaseFunctionEnum() const { return phaseFunction; }
+};
+
+// progressivephotonmapping/photontracercl.{h,cpp}
+class PhotonTracerCL {
+public:
+    PhotonTracerCL() = default;
+    ~PhotonTracerCL();
+    bool isValid() const { return CpmRuntime::get().valid(); }
+    // photontracercl.cpp:67-132 (Volume/TF overload) and :135-174 (device overload) folded into one
+    void tracePhotons(const Volume* volume, const TransferFunction& transferFunction, const float aabb[8],
+                      const AdvancedMaterialProperty& material, float stepSize, const LightSamples* lightSamples,
+                      const Buffer<unsigned int>* photonsToRecomputeIndices, int nInvalidPhotons, int photonOffset,
+                      int batch, int maxInteractions, PhotonData* photonOutData);
+    void setNoSingleScattering(bool v) { onlyMultipleScattering_ = v; }
+    void setProgressive(bool v) { progressive_ = v; }
+    bool isProgressive() const { return progressive_; }
+    void setRandomSeedSize(size_t nPhotons);   // :176-182
+    Buffer<uvec2>& randomState() { return randomState_; }
+private:
+    void syncVolume(const Volume* volume);
+    void syncTF(const TransferFunction& tf);
+    Buffer<uvec2> randomState_;
+    bool onlyMultipleScattering_ = false, progressive_ = false;
+    cpm_volume* vol_ = nullptr;
+    const Volume* volSrc_ = nullptr;
+    cpm_tf* tf_ = nullptr;
+    std::vector<float> tfLut_;
+    friend class VolumeMinMaxCLProcessor;
+};
+
+// progressivephotonmapping/photonrecomputationdetector.{h,cpp}
+class PhotonRecomputationDetector {
+public:
+    bool isValid() const { return CpmRuntime::get().valid(); }
+    void photonRecomputationImportance(const PhotonData* photonData, int photonOffset, const Volume* origVolume,
+                                       const ImportanceUniformGrid3D* uniformGridVolume, const LightSamples& lightSamples,
+                                       Buffer<unsigned int>& recomputationImportance);
+    void setPercentage(int p) { percentage_ = p; }
+    int getPercentage() const { return percentage_; }
+    void setIteration(int i) { iteration_ = i; }
+    int getIteration() const { return iteration_; }
+    void setEqualImportance(bool e) { equalImportance_ = e; }
+    bool getEqualImportance() const { return equalImportance_; }
+private:
+    int percentage_ = 100, iteration_ = 0;
+    bool equalImportance_ = false;
+};
+
+// ---- processors (L4) ----------------------------------------------------------------------------------
+
+// importancesamplingcl/processors/uniformsamplegenerator2dprocessorcl.{h,cpp}
+class UniformSampleGenerator2DProcessorCL : public Processor {
+public:
+    UniformSampleGenerator2DProcessorCL();
+    const ProcessorInfo getProcessorInfo() const override { return { "org.inviwo.UniformSampleGenerator2DCL", "UniformSampleGenerator2DCL", "Sampling" }; }
+    void process() override;
+    DataOutport<SampleBuffer> samplesPort_{ "samples" };
+    Property<ivec2> nSamplesProp_{ "nSamples", "N samples", ivec2{ 256, 256 } };
+private:
+    UniformSampleGenerator2DCL generator_;
+    std::shared_ptr<SampleBuffer> samples_ = std::make_shared<SampleBuffer>();
+};
+
+// lightcl/processors/directionallightsamplerclprocessor.{h,cpp}
+class DirectionalLightSamplerCLProcessor : public Processor {
+public:
+    DirectionalLightSamplerCLProcessor();
+    const ProcessorInfo getProcessorInfo() const override { return { "org.inviwo.DirectionalLightSamplerCL", "DirectionalLightSamplerCL", "Light sampling" }; }
+    void process() override;
+    DataInport<Mesh> boundingVolumePort_{ "SceneGeometry" };
+    DataInport<SampleBuffer> samplesPort_{ "samples" };
+    DataInport<DirectionalLight> lightsPort_{ "light" };
+    DataOutport<LightSamples> lightSamplesPort_{ "LightSamples" };
+    DirectionalLightSamplerCL lightSampler_;
+private:
+    LightSampleMeshIntersectionCL intersector_;
+    std::shared_ptr<LightSamples> lightSamples_ = std::make_shared<LightSamples>();
+};
+
+// uniformgridcl/processors/volumeminmaxclprocessor.{h,cpp}
+class VolumeMinMaxCLProcessor : public Processor {
+public:
+    VolumeMinMaxCLProcessor();
+    const ProcessorInfo getProcessorInfo() const override { return { "org.inviwo.VolumeMinMaxCLProcessor", "VolumeMinMaxCLProcessor", "UniformGrid3D" }; }
+    void process() override;
+    DataInport<Volume> inport_{ "volume" };
+    DataOutport<UniformGrid3DBase> outport_{ "output" };
+    IntProperty volumeRegionSize_{ "region", "Region size", 8 };
+private:
+    std::shared_ptr<MinMaxUniformGrid3D> grid_ = std::make_shared<MinMaxUniformGrid3D>();
+    cpm_volume* vol_ = nullptr;
+    const Volume* volSrc_ = nullptr;
+};
+
+// importancesamplingcl/processors/minmaxuniformgrid3dimportanceclprocessor.{h,cpp}
+class MinMaxUniformGrid3DImportanceCLProcessor : public Processor {
+public:
+    MinMaxUniformGrid3DImportanceCLProcessor();
+    const ProcessorInfo getProcessorInfo() const override { return { "org.inviwo.MinMaxUniformGrid3DImportanceCLProcessor", "MinMaxUniformGrid3DImportance", "UniformGrid3D" }; }
+    void process() override;
+    // TF edit entry point (the TransferFunctionProperty's onChange in the reference, :86-90)
+    void setTransferFunction(const TransferFunction& tf);
+    DataInport<UniformGrid3DBase> minMaxUniformGrid3DInport_{ "minMaxUniformGrid3D" };
+    DataInport<UniformGrid3DBase> volumeDifferenceInfoInport_{ "volumeDifferenceInfo" };
+    DataOutport<UniformGrid3DBase> importanceUniformGrid3DOutport_{ "importanceUniformGrid3D" };
+    BoolProperty incrementalImportance{ "incrementalImportance", "Incremental importance", true };
+    BoolProperty useAssociatedColor_{ "useAssociatedColor", "Associated color", false };
+    FloatProperty TFPointEpsilon_{ "TFPointEpsilon", "Minimum change threshold", 1e-4f };
+    const std::vector<float>& tfPointPositions() const { return positions_; }
+    const std::vector<vec4>& tfPointColors() const { return colors_; }
+private:
+    void updateTransferFunctionData();            // :304-362
+    void updateTransferFunctionDifferenceData();  // :364-501
+    vec4 tfPointColorDiff(const vec4& p1, const vec4& p2) const;  // :503-507
+    TransferFunction transferFunction_, prevTransferFunction_;
+    bool tfChanged_ = false;
+    std::vector<float> positions_;
+    std::vector<vec4> colors_;
+    std::shared_ptr<ImportanceUniformGrid3D> importance_ = std::make_shared<ImportanceUniformGrid3D>();
+};
+
+// progressivephotonmapping/processor/progressivephotontracercl.{h,cpp}
+class ProgressivePhotonTracerCL : public Processor {
+public:
+    ProgressivePhotonTracerCL();
+    const ProcessorInfo getProcessorInfo() const override { return { "org.inviwo.ProgressivePhotonTracerCL", "ProgressivePhotonTracer", "Photons" }; }
+    void process() override;
+    void invalidateProgressiveRendering(PhotonData::InvalidationReason r) { invalidationFlag_ = invalidationFlag_ | r; }
+    void setTransferFunction(const TransferFunction& tf) { transferFunction_ = tf; invalidateProgressiveRendering(PhotonData::InvalidationReason::TransferFunction); }
+    int remainingPhotonsToUpdate() const { return remainingPhotonsToUpdate_; }
+
+    DataInport<Volume> volumePort_{ "volume" };
+    DataInport<UniformGrid3DBase> recomputationImportanceGrid_{ "recomputationImportance" };
+    DataInport<LightSamples> lightSamples_{ "LightSamples" };  // multi-inport
+    DataOutport<PhotonData> outport_{ "photons" };
+    DataOutport<RecomputedPhotonIndices> recomputedIndicesPort_{ "recomputedIndices" };
+
+    FloatProperty samplingRate_{ "samplingRate", "Sampling rate", 1.0f };
+    FloatProperty radius_{ "radius", "Photon radius (# voxels)", 1.f };
+    FloatProperty sceneRadianceScaling_{ "radianceScale", "Scene radiance scale", 1.f };
+    FloatProperty maxIncrementalPhotonsToUpdate_{ "maxIncrementalPhotonsToUpdate", "Max photons per update (%)", 100.f };
+    BoolProperty equalIncrementalImportance_{ "equalImportance", "Equal importance", false };
+    BoolProperty spatialSorting_{ "spatialSorting", "Spatial sorting", true };
+    IntProperty maxScatteringEvents_{ "maxScatteringEvents", "Max scattering events", 1 };
+    BoolProperty noSingleScattering_{ "noSingleScattering", "No single scattering", false };
+    FloatProperty alphaProp_{ "alpha", "Progressive alpha", 0.5f };
+    IntVec2Property workGroupSize_{ "wgsize", "Work group size", ivec2{ 8, 8 } };   // inert: kept for the workspace
+    BoolProperty useGLSharing_{ "glsharing", "Use OpenGL sharing", true };          // inert
+    BoolProperty enableProgressiveRefinement_{ "enableRefinement", "Progressive refinement", false };
+    BoolProperty enableProgressivePhotonRecomputation_{ "enableProgressiveRecomputation", "Progressive recomputation", true };
+    Property<ivec2> clipX_{ "clipX", "Clip X Slices", ivec2{ 0, 256 } }, clipY_{ "clipY", "Clip Y Slices", ivec2{ 0, 256 } },
+        clipZ_{ "clipZ", "Clip Z Slices", ivec2{ 0, 256 } };
+    AdvancedMaterialProperty advancedMaterial_;
+    TransferFunction transferFunction_;
+    PhotonTracerCL photonTracer_;
+    bool fixExitPoint = false;
+private:
+    void onClipChange();
+    float getSceneRadius() const { return 0.5f * std::sqrt(12.f); }  // unit-model volume spanning [-1, 1]^3
+    void resetPhotonImportance(size_t offset, size_t n);
+    std::shared_ptr<PhotonData> photonData_ = std::make_shared<PhotonData>();
+    std::shared_ptr<RecomputedPhotonIndices> recomputedPhotonIndices_ = std::make_shared<RecomputedPhotonIndices>();
+    PhotonRecomputationDetector photonRecomputationDetector_;
+    Buffer<unsigned int> photonRecomputationImportance_;
+    Buffer<int> nChanged_{ 1 };
+    PhotonData::InvalidationReason invalidationFlag_ = PhotonData::InvalidationReason::All;
+    float aabb_[8] = { 0, 0, 0, 1, 1, 1, 1, 1 };
+    int remainingPhotonsOffset_ = 0, remainingPhotonsToUpdate_ = -1;
+    std::vector<std::pair<const LightSamples*, size_t>> seenLights_;  // (samples, change stamp) at the last evaluation
+};
+
+// progressivephotonmapping/processor/photontolightvolumeprocessorcl.{h,cpp}
+class PhotonToLightVolumeProcessorCL : public Processor {
+public:
+    PhotonToLightVolumeProcessorCL();
+    const ProcessorInfo getProcessorInfo() const override { return { "org.inviwo.PhotonToLightVolumeProcessorCL", "PhotonToLightVolumeProcessorCL", "Photons" }; }
+    void process() override;
+    DataInport<Volume> volumeInport_{ "volume" };
+    DataInport<PhotonData> photons_{ "photons" };
+    DataInport<RecomputedPhotonIndices> recomputedPhotonIndicesPort_{ "recomputedPhotonIndices" };
+    DataOutport<Volume> outport_{ "lightvolume" };
+    FloatProperty incrementalRecomputationThreshold_{ "incrementalRecomputationThreshold", "Max % invalid photons to use add-remove", 50.f };
+    IntProperty volumeSizeOption_{ "volumeSizeOption", "Light Volume Size", 0 };  // 0 = radius, 1, 2, 4 = input dims / n
+    StringOptionProperty volumeDataTypeOption_{ "volumeDataType", "Output data type", "float32" };
+    BoolProperty alignChangedPhotons_{ "alignChangedPhotons", "Mem-align changed photons", false };
+    IntProperty workGroupSize_{ "wgsize", "Work group size", 128 };      // inert
+    BoolProperty useGLSharing_{ "glsharing", "Use OpenGL sharing", true };  // inert
+    // "gather" (default: sort/bin + deterministic gather) or "splat" (the reference's atomic formulation)
+    StringOptionProperty formulation_{ "formulation", "Density estimation", "gather" };
+    const char* lastPath() const { return lastPath_; }
+private:
+    void volumeSizeOptionChanged();
+    std::shared_ptr<Volume> lightVolume_ = std::make_shared<Volume>(size3_t{ 1, 1, 1 }, CPM_F32);
+    Buffer<vec4> prevPhotons_;
+    Buffer<unsigned int> order_, cellStart_;
+    Buffer<float> sorted_;
+    const char* lastPath_ = "none";
+};
+
+}  // namespace inviwo

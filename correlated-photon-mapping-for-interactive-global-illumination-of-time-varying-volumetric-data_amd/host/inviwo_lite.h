@@ -1,0 +1,224 @@
+// inviwo_lite.h -- the sliver of Inviwo's public API the six modules' processors touch, so that
+// the host layer of this build compiles and runs without Inviwo (which is not in this image).
+// A maintainer integrating into a real Inviwo checkout deletes this header and includes Inviwo's
+// own: names, ids and call shapes below are Inviwo's.
+//
+// What differs on purpose: Buffer<T>/Volume keep ONE device representation (HIP memory) next to
+// the RAM one instead of Inviwo's RAM/CL/GL/CLGL zoo -- there is no OpenCL or OpenGL here.
+#pragma once
+#include <hip/hip_runtime_api.h>
+
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <functional>
+#include <map>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+namespace inviwo {
+
+struct vec2 { float x = 0, y = 0; };
+struct vec3 {
+    float x = 0, y = 0, z = 0;
+    vec3() = default;
+    vec3(float a, float b, float c) : x(a), y(b), z(c) {}
+    explicit vec3(float a) : x(a), y(a), z(a) {}
+};
+struct vec4 {
+    float x = 0, y = 0, z = 0, w = 0;
+    vec4() = default;
+    vec4(float a, float b, float c, float d) : x(a), y(b), z(c), w(d) {}
+    vec4(vec3 v, float d) : x(v.x), y(v.y), z(v.z), w(d) {}
+};
+struct ivec2 { int x = 0, y = 0; };
+struct uvec2 { uint32_t x = 0, y = 0; };
+struct size3_t { size_t x = 0, y = 0, z = 0; };
+inline vec3 operator+(vec3 a, vec3 b) { return { a.x + b.x, a.y + b.y, a.z + b.z }; }
+inline vec3 operator-(vec3 a, vec3 b) { return { a.x - b.x, a.y - b.y, a.z - b.z }; }
+inline vec3 operator*(vec3 a, float s) { return { a.x * s, a.y * s, a.z * s }; }
+inline vec3 operator*(float s, vec3 a) { return a * s; }
+inline float dot(vec3 a, vec3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+inline vec3 cross(vec3 a, vec3 b) { return { a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x }; }
+inline float length(vec3 a) { return std::sqrt(dot(a, a)); }
+inline vec3 normalize(vec3 a) { return a * (1.0f / length(a)); }
+
+void LogErrorImpl(const std::string& source, const std::string& msg);
+void LogInfoImpl(const std::string& source, const std::string& msg);
+#define LogError(msg) ::inviwo::LogErrorImpl(__func__, std::string(msg))
+#define LogInfo(msg) ::inviwo::LogInfoImpl(__func__, std::string(msg))
+
+// ---- data --------------------------------------------------------------------------------------
+
+template <typename T>
+class Buffer {
+public:
+    explicit Buffer(size_t n = 0) { setSize(n); }
+    ~Buffer() { release(); }
+    Buffer(const Buffer&) = delete;
+    Buffer& operator=(const Buffer&) = delete;
+    void setSize(size_t n) {
+        if (n == size_) return;
+        release();
+        size_ = n;
+        ram_.clear();
+    }
+    size_t getSize() const { return size_; }
+    size_t getSizeInBytes() const { return size_ * sizeof(T); }
+    // device representation (allocated on first use)
+    T* device() {
+        if (!dev_ && size_) {
+            if (hipMalloc((void**)&dev_, size_ * sizeof(T)) != hipSuccess) throw std::runtime_error("hipMalloc failed");
+        }
+        return dev_;
+    }
+    const T* device() const { return const_cast<Buffer*>(this)->device(); }
+    // RAM representation: download on request, upload explicitly
+    std::vector<T>& ram() { ram_.resize(size_); return ram_; }
+    void upload(hipStream_t s = nullptr) { if (size_) (void)hipMemcpyAsync(device(), ram_.data(), size_ * sizeof(T), hipMemcpyHostToDevice, s); }
+    void download(hipStream_t s = nullptr) {
+        ram_.resize(size_);
+        if (size_) { (void)hipMemcpyAsync(ram_.data(), device(), size_ * sizeof(T), hipMemcpyDeviceToHost, s); (void)hipStreamSynchronize(s); }
+    }
+
+private:
+    void release() { if (dev_) (void)hipFree(dev_); dev_ = nullptr; }
+    size_t size_ = 0;
+    T* dev_ = nullptr;
+    std::vector<T> ram_;
+};
+
+struct TFPrimitive {
+    double pos = 0;
+    vec4 color;
+};
+
+class TransferFunction {
+public:
+    void clear() { points_.clear(); }
+    void add(double pos, vec4 color) { points_.push_back({ pos, color }); sort(); }
+    size_t size() const { return points_.size(); }
+    const TFPrimitive& get(size_t i) const { return points_[i]; }
+    std::vector<TFPrimitive>& points() { return points_; }
+    const std::vector<TFPrimitive>& points() const { return points_; }
+    // Inviwo: 1024 x 1 RGBA32F layer, texel i at (i + 0.5) / width, constant outside the end points
+    std::vector<float> lut(int width = 1024) const;
+
+private:
+    void sort();
+    std::vector<TFPrimitive> points_;
+};
+
+class Volume {
+public:
+    Volume(size3_t dims, int dtype) : dims_(dims), dtype_(dtype) {}
+    size3_t getDimensions() const { return dims_; }
+    void setDimensions(size3_t d) { dims_ = d; data.setSize(0); }
+    int dtype() const { return dtype_; }
+    size_t elementSize() const { return dtype_ == 0 ? 1 : (dtype_ == 1 ? 2 : 4); }
+    int channels = 1;               // light volumes: 1 (float32) or 4 (4xfloat32)
+    std::vector<uint8_t> ramBytes;  // scalar source volumes live here until uploaded
+    Buffer<float> data;             // light volumes: device float storage
+private:
+    size3_t dims_;
+    int dtype_;
+};
+
+// ---- ports, properties, processors -----------------------------------------------------------------
+
+template <typename T>
+class DataOutport {
+public:
+    explicit DataOutport(std::string id) : id_(std::move(id)) {}
+    const std::string& getIdentifier() const { return id_; }
+    void setData(std::shared_ptr<T> d) { data_ = std::move(d); }
+    std::shared_ptr<T> getData() const { return data_; }
+private:
+    std::string id_;
+    std::shared_ptr<T> data_;
+};
+
+template <typename T>
+class DataInport {
+public:
+    explicit DataInport(std::string id) : id_(std::move(id)) {}
+    const std::string& getIdentifier() const { return id_; }
+    void connectTo(DataOutport<T>* out) { sources_.push_back(out); if (onConnect_) onConnect_(); }
+    void disconnectAll() { sources_.clear(); }
+    bool isConnected() const { return !sources_.empty(); }
+    bool isReady() const { return !sources_.empty() && sources_[0]->getData() != nullptr; }
+    bool hasData() const { return isReady(); }
+    std::shared_ptr<T> getData() const { return sources_.empty() ? nullptr : sources_[0]->getData(); }
+    std::vector<std::shared_ptr<T>> getVectorData() const {  // multi-inport
+        std::vector<std::shared_ptr<T>> v;
+        for (auto* s : sources_) if (s->getData()) v.push_back(s->getData());
+        return v;
+    }
+    void setOptional(bool o) { optional_ = o; }
+    void onConnect(std::function<void()> f) { onConnect_ = std::move(f); }
+private:
+    std::string id_;
+    std::vector<DataOutport<T>*> sources_;
+    bool optional_ = false;
+    std::function<void()> onConnect_;
+};
+
+class PropertyBase {
+public:
+    PropertyBase(std::string id, std::string name) : id_(std::move(id)), name_(std::move(name)) {}
+    virtual ~PropertyBase() = default;
+    const std::string& getIdentifier() const { return id_; }
+    void onChange(std::function<void()> f) { onChange_ = std::move(f); }
+protected:
+    void changed() { if (onChange_) onChange_(); }
+    std::string id_, name_;
+    std::function<void()> onChange_;
+};
+
+template <typename T>
+class Property : public PropertyBase {
+public:
+    Property(std::string id, std::string name, T value) : PropertyBase(std::move(id), std::move(name)), value_(value) {}
+    const T& get() const { return value_; }
+    operator T() const { return value_; }
+    void set(const T& v) { value_ = v; changed(); }
+private:
+    T value_;
+};
+using FloatProperty = Property<float>;
+using IntProperty = Property<int>;
+using BoolProperty = Property<bool>;
+using IntVec2Property = Property<ivec2>;
+using StringOptionProperty = Property<std::string>;
+
+struct ProcessorInfo {
+    std::string classIdentifier, displayName, category;
+};
+
+class Processor {
+public:
+    virtual ~Processor() = default;
+    virtual const ProcessorInfo getProcessorInfo() const = 0;
+    virtual void process() = 0;
+    void addProperty(PropertyBase& p) { properties_[p.getIdentifier()] = &p; }
+    void addPortId(const std::string& id, bool inport) { (inport ? inports_ : outports_).push_back(id); }
+    PropertyBase* getPropertyByIdentifier(const std::string& id) const {
+        auto it = properties_.find(id);
+        return it == properties_.end() ? nullptr : it->second;
+    }
+    const std::vector<std::string>& getInportIds() const { return inports_; }
+    const std::vector<std::string>& getOutportIds() const { return outports_; }
+    std::vector<std::string> getPropertyIds() const {
+        std::vector<std::string> v;
+        for (auto& kv : properties_) v.push_back(kv.first);
+        return v;
+    }
+private:
+    std::map<std::string, PropertyBase*> properties_;
+    std::vector<std::string> inports_, outports_;
+};
+
+}  // namespace inviwo

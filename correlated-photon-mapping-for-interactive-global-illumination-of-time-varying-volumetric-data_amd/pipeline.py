@@ -158,7 +158,8 @@ class PhotonFrame:
                  light_travel_direction=(0.0, 0.0, 1.0), light_distance: float = 2.0,
                  radiance=(1.0, 1.0, 1.0), radius_voxels: float = 1.0, max_interactions: int = 1,
                  channels: int = 1, photon_range=None, point_light_position=None, seed: int = 0,
-                 shading_type: int = B.CPM_PHASE_HENYEY_GREENSTEIN, material=(0.0, 0.0, 0.0, 0.0)):
+                 shading_type: int = B.CPM_PHASE_HENYEY_GREENSTEIN, material=(0.0, 0.0, 0.0, 0.0), light_plane=None,
+                 mesh_intersection=None):
         torch = ctx.torch
         self.ctx = ctx
         self.torch = torch
@@ -183,13 +184,21 @@ class PhotonFrame:
         if point_light_position is not None:
             self.light_samples = ctx.point_light_samples(samples, radiance, point_light_position)
         else:
-            d = _normalize(light_travel_direction)
-            origin = np.array([0.5, 0.5, 0.5], np.float32) - np.float32(light_distance) * d
-            o, u, v = fit_plane_aligned_obb(S.UNIT_CUBE_VERTICES, origin, d)
-            area = float(np.float32(np.linalg.norm(u)) * np.float32(np.linalg.norm(v)))
+            d = np.asarray(light_travel_direction, np.float32) if light_plane is not None else _normalize(light_travel_direction)
+            if light_plane is not None:  # (origin, u, v, area) fitted elsewhere (e.g. by the C++ host layer)
+                o, u, v, area = light_plane
+            else:
+                origin = np.array([0.5, 0.5, 0.5], np.float32) - np.float32(light_distance) * d
+                o, u, v = fit_plane_aligned_obb(S.UNIT_CUBE_VERTICES, origin, d)
+                area = float(np.float32(np.linalg.norm(u)) * np.float32(np.linalg.norm(v)))
             self.light_plane = (o, u, v, area, d)
             self.light_samples = ctx.directional_light_samples(samples, radiance, d, o, u, v, area)
-        self.isect = ctx.light_sample_box_intersection(self.light_samples, self.aabb)
+        if mesh_intersection is not None:  # (vertices [n,3] f32, indices int32): the proxy-mesh variant of E4
+            vtx = torch.from_numpy(np.ascontiguousarray(mesh_intersection[0], np.float32)).to(dev)
+            idx = torch.from_numpy(np.ascontiguousarray(mesh_intersection[1], np.int32)).to(dev)
+            self.isect = ctx.light_sample_mesh_intersection(vtx, idx, self.light_samples)
+        else:
+            self.isect = ctx.light_sample_box_intersection(self.light_samples, self.aabb)
 
         # R2: per-photon MWC64X streams (glibc srand(seed) bases, gap 2^40), seeded over the
         # unsharded index range so that stream i is the same whatever the shard

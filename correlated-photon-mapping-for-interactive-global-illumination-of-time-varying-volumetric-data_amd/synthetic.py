@@ -86,4 +86,4 @@ UNIT_CUBE_AABB = (0.0, 0.0, 0.0, 1.0, 1.0, 1.0, 1.0, 1.0)
 def photon_radius_texture(volume_dims, radius_voxels: float = 1.0) -> float:
     """|indexToTexture * (r, r, r, 0)| (ref processor/progressivephotontracercl.cpp:252-254)."""
     v = np.float32(radius_voxels) / np.asarray(volume_dims, dtype=np.float32)
-    return float(np.sqrt(np.sum(v.astype(np.float64) ** 2)))
+    return float(np.sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2], dtype=np.float32))  # glm::length in fp32

@@ -1,0 +1,209 @@
+"""The C++ host layer (host/: Processor/Port mirror over the C-ABI), driven through its C facade."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from test_parity_gpu import _n, bits
+
+pytestmark = pytest.mark.gpu
+
+CUBE_QUADS = [(0, 1, 3, 2), (4, 6, 7, 5), (0, 4, 5, 1), (2, 3, 7, 6), (0, 2, 6, 4), (1, 5, 7, 3)]
+
+# what the CorrelatedPhotonMappingSingleVolume workspace binds (ref tracercl.cpp:61-99,
+# ...processorcl.cpp:45-108, directionallightsamplerclprocessor.cpp:38-64, ...)
+SURFACE = {
+    "org.inviwo.ProgressivePhotonTracerCL": (
+        {"volume", "recomputationImportance", "LightSamples"}, {"photons", "recomputedIndices"},
+        {"samplingRate", "radius", "radianceScale", "maxIncrementalPhotonsToUpdate", "equalImportance", "spatialSorting",
+         "maxScatteringEvents", "noSingleScattering", "alpha", "wgsize", "glsharing", "enableRefinement",
+         "enableProgressiveRecomputation", "clipX", "clipY", "clipZ"}),
+    "org.inviwo.PhotonToLightVolumeProcessorCL": (
+        {"volume", "photons", "recomputedPhotonIndices"}, {"lightvolume"},
+        {"incrementalRecomputationThreshold", "volumeSizeOption", "volumeDataType", "alignChangedPhotons", "wgsize", "glsharing"}),
+    "org.inviwo.DirectionalLightSamplerCL": ({"SceneGeometry", "samples", "light"}, {"LightSamples"}, set()),
+    "org.inviwo.UniformSampleGenerator2DCL": (set(), {"samples"}, {"nSamples"}),
+    "org.inviwo.MinMaxUniformGrid3DImportanceCLProcessor": ({"minMaxUniformGrid3D", "volumeDifferenceInfo"}, {"importanceUniformGrid3D"},
+                                                            {"incrementalImportance", "useAssociatedColor", "TFPointEpsilon"}),
+    "org.inviwo.VolumeMinMaxCLProcessor": ({"volume"}, {"output"}, {"region"}),
+}
+
+
+@pytest.fixture(scope="module")
+def host(cpm, ctx):
+    # ctx first: torch must bring up ITS HIP runtime before another library initialises one
+    # (two libamdhip64 copies in one process do not both see the GPU)
+    cpm.build.build_host_library()
+    lib = C.CDLL(str(cpm.binding.LIB_PATH.parent / "libcpm_host.so"))
+    lib.cpmh_create.restype = C.c_void_p
+    lib.cpmh_create.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float * 3),
+                                C.POINTER(C.c_float * 3), C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]
+    for name, res, args in [("cpmh_destroy", None, [C.c_void_p]), ("cpmh_evaluate", C.c_int, [C.c_void_p, C.c_int]),
+                            ("cpmh_set_transfer_function", None, [C.c_void_p, C.c_void_p, C.c_int]),
+                            ("cpmh_set_property_float", C.c_int, [C.c_void_p, C.c_char_p, C.c_char_p, C.c_float]),
+                            ("cpmh_set_property_string", C.c_int, [C.c_void_p, C.c_char_p, C.c_char_p, C.c_char_p]),
+                            ("cpmh_light_volume_dims", None, [C.c_void_p, C.POINTER(C.c_int * 3), C.POINTER(C.c_int)]),
+                            ("cpmh_download_light_volume", C.c_int, [C.c_void_p, C.c_void_p]),
+                            ("cpmh_n_photons", C.c_int, [C.c_void_p]), ("cpmh_download_photons", C.c_int, [C.c_void_p, C.c_void_p]),
+                            ("cpmh_n_recomputed", C.c_int, [C.c_void_p]), ("cpmh_remaining", C.c_int, [C.c_void_p]),
+                            ("cpmh_last_light_volume_path", C.c_char_p, [C.c_void_p]), ("cpmh_radius", C.c_double, [C.c_void_p]),
+                            ("cpmh_light_plane", None, [C.c_void_p, C.POINTER(C.c_float * 10)]),
+                            ("cpmh_light_direction", None, [C.c_void_p, C.POINTER(C.c_float * 3)]),
+                            ("cpmh_tf_lut", None, [C.c_void_p, C.c_void_p]),
+                            ("cpmh_describe_surface", C.c_char_p, [C.c_void_p])]:
+        f = getattr(lib, name)
+        f.restype, f.argtypes = res, args
+    return lib
+
+
+class Net:
+    def __init__(self, lib, vol, n_side, light_pos, light_dir, tf_points, size_option=2, max_scattering=1, correlated=False):
+        self.lib = lib
+        vol = np.ascontiguousarray(vol)
+        pts = np.ascontiguousarray(np.asarray(tf_points, np.float32))
+        self.h = lib.cpmh_create(vol.ctypes.data, 0, vol.shape[2], vol.shape[1], vol.shape[0], n_side, n_side,
+                                 C.byref((C.c_float * 3)(*light_pos)), C.byref((C.c_float * 3)(*light_dir)), pts.ctypes.data,
+                                 pts.shape[0], size_option, max_scattering, int(correlated))
+        assert self.h
+
+    def evaluate(self, first=False):
+        assert self.lib.cpmh_evaluate(self.h, int(first)) == 0
+
+    def set_tf(self, tf_points):
+        pts = np.ascontiguousarray(np.asarray(tf_points, np.float32))
+        self.lib.cpmh_set_transfer_function(self.h, pts.ctypes.data, pts.shape[0])
+
+    def light_volume(self):
+        dims, ch = (C.c_int * 3)(), C.c_int()
+        self.lib.cpmh_light_volume_dims(self.h, C.byref(dims), C.byref(ch))
+        out = np.zeros(dims[0] * dims[1] * dims[2] * ch.value, np.float32)
+        assert self.lib.cpmh_download_light_volume(self.h, out.ctypes.data) == 0
+        return out, tuple(dims), ch.value
+
+    def photons(self):
+        out = np.zeros((self.lib.cpmh_n_photons(self.h), 8), np.float32)
+        assert self.lib.cpmh_download_photons(self.h, out.ctypes.data) == 0
+        return out
+
+    def plane(self):
+        p = (C.c_float * 10)()
+        self.lib.cpmh_light_plane(self.h, C.byref(p))
+        a = np.array(list(p), np.float32)
+        return a[0:3], a[3:6], a[6:9], float(a[9])
+
+    def direction(self):
+        d = (C.c_float * 3)()
+        self.lib.cpmh_light_direction(self.h, C.byref(d))
+        return np.array(list(d), np.float32)
+
+    def tf_lut(self):
+        out = np.zeros((1024, 4), np.float32)
+        self.lib.cpmh_tf_lut(self.h, out.ctypes.data)
+        return out
+
+    def close(self):
+        self.lib.cpmh_destroy(self.h)
+
+
+def _light(cpm, direction, dist=2.0):
+    d = cpm.pipeline._normalize(direction)
+    return (np.array([0.5, 0.5, 0.5], np.float32) - np.float32(dist) * d), d
+
+
+def test_drop_in_surface(host, cpm):
+    S = cpm.synthetic
+    pos, d = _light(cpm, (0.3, 0.5, -1.0))
+    net = Net(host, S.homogeneous_volume(16), 16, pos, d, S.WORKSPACE_TF_POINTS, correlated=True)
+    text = host.cpmh_describe_surface(net.h).decode()
+    seen = {}
+    for line in text.strip().splitlines():
+        cid, i, o, p = line.split("|")
+        seen[cid] = (set(filter(None, i[3:].split(","))), set(filter(None, o[4:].split(","))), set(filter(None, p[5:].split(","))))
+    for cid, (ins, outs, props) in SURFACE.items():
+        assert cid in seen, cid
+        assert ins <= seen[cid][0], (cid, ins - seen[cid][0])
+        assert outs <= seen[cid][1], (cid, outs - seen[cid][1])
+        assert props <= seen[cid][2], (cid, props - seen[cid][2])
+    net.close()
+
+
+def test_network_matches_abi_pipeline(host, ctx, cpm):
+    """The C++ network (workspace wiring, light volume = 1/2 of the input volume) produces the photons and
+    the light volume the thin Python driver produces from the same light plane: bit for bit."""
+    S, P = cpm.synthetic, cpm.pipeline
+    vol = S.heterogeneous_volume(64)
+    pos, d = _light(cpm, (0.3, 0.5, -1.0))
+    net = Net(host, vol, 160, pos, d, S.WORKSPACE_TF_POINTS, size_option=2)
+    net.evaluate(first=True)
+    o, u, v, area = net.plane()
+    # the host fit agrees with the Python twin of the reference's CPU code
+    po, pu, pv = P.fit_plane_aligned_obb(S.UNIT_CUBE_VERTICES, pos, d)
+    assert abs(area - float(np.linalg.norm(pu) * np.linalg.norm(pv))) < 1e-5
+    idx = np.array([i for q in CUBE_QUADS for i in (q[0], q[1], q[2], q[0], q[2], q[3])], np.int32)
+    # the host's LUT (Inviwo: 1024 texels, piecewise linear) equals the Python twin's
+    lut = net.tf_lut()
+    np.testing.assert_allclose(lut, S.workspace_tf(), rtol=0, atol=1e-7)
+    fr = P.PhotonFrame(ctx, vol, lut, 160, (32, 32, 32), light_travel_direction=net.direction(), light_plane=(o, u, v, area),
+                       mesh_intersection=(S.UNIT_CUBE_VERTICES, idx))
+    lv = _n(fr.frame())
+    hv, dims, ch = net.light_volume()
+    assert dims == (32, 32, 32) and ch == 1
+    assert abs(host.cpmh_radius(net.h) - fr.radius) < 1e-12
+    assert np.array_equal(bits(net.photons()), bits(_n(fr.photons)))
+    assert np.array_equal(bits(hv), bits(lv))
+    # the reference formulation through the same processor: atomic splat, tolerance
+    assert host.cpmh_set_property_string(net.h, b"lightvolume", b"formulation", b"splat") == 0
+    net.evaluate()
+    sv, _, _ = net.light_volume()
+    np.testing.assert_allclose(sv, lv, rtol=1e-4, atol=1e-5 * float(lv.max()))
+    # 4 x float32 output and radius-sized grid (volumeSizeOption "radius": ceil(1/r)^3)
+    assert host.cpmh_set_property_string(net.h, b"lightvolume", b"volumeDataType", b"4xfloat32") == 0
+    assert host.cpmh_set_property_float(net.h, b"lightvolume", b"volumeSizeOption", 0.0) == 0
+    net.evaluate()
+    rv, dims, ch = net.light_volume()
+    n = int(np.ceil(1.0 / fr.radius))
+    assert dims == (n, n, n) and ch == 4 and rv.reshape(-1, 4)[:, :3].sum() > 0
+    net.close()
+
+
+def test_network_correlated_tf_edit(host, cpm):
+    """TF edit through the processor network: the importance branch re-traces only selected photons with
+    their original RNG streams and lands on the photons of a from-scratch evaluation."""
+    S = cpm.synthetic
+    vol = S.heterogeneous_volume(64)
+    base = [(0.0, 1, 1, 1, 0.0), (0.45, 1, 0.5, 0.2, 0.0), (0.55, 0.6, 0.3, 0.1, 0.05), (0.8, 0.9, 0.2, 0.3, 0.4), (1.0, 0.1, 0.6, 0.7, 0.5)]
+    edit = list(base)
+    edit[3] = (0.85,) + base[3][1:]
+    pos, d = _light(cpm, (0.3, 0.5, -1.0))
+    net = Net(host, vol, 128, pos, d, base, correlated=True)
+    net.evaluate(first=True)
+    assert host.cpmh_n_recomputed(net.h) == -1 and host.cpmh_last_light_volume_path(net.h) == b"full"
+    before = net.photons()
+    assert host.cpmh_set_property_float(net.h, b"lightvolume", b"incrementalRecomputationThreshold", 100.0) == 0
+    net.set_tf(edit)
+    net.evaluate()
+    n = host.cpmh_n_recomputed(net.h)
+    assert 0 < n < before.shape[0]
+    assert host.cpmh_last_light_volume_path(net.h) == b"incremental"
+    after = net.photons()
+    lv_inc, _, _ = net.light_volume()
+    fresh = Net(host, vol, 128, pos, d, edit, correlated=False)
+    fresh.evaluate(first=True)
+    assert np.array_equal(bits(after), bits(fresh.photons()))
+    assert 0 < (bits(after) != bits(before)).any(axis=1).sum() <= n
+    lv_full, _, _ = fresh.light_volume()
+    np.testing.assert_allclose(lv_inc, lv_full, rtol=1e-3, atol=2e-5 * float(lv_full.max()))
+    # progressive: 10 % per evaluation, continued until nothing remains
+    net2 = Net(host, vol, 128, pos, d, base, correlated=True)
+    net2.evaluate(first=True)
+    assert host.cpmh_set_property_float(net2.h, b"tracer", b"maxIncrementalPhotonsToUpdate", 10.0) == 0
+    net2.set_tf(edit)
+    net2.evaluate()
+    rounds = 1
+    while host.cpmh_remaining(net2.h) > 0:
+        net2.evaluate()
+        rounds += 1
+    assert rounds > 1
+    assert np.array_equal(bits(net2.photons()), bits(after))
+    for x in (net, fresh, net2):
+        x.close()

@@ -63,6 +63,7 @@ def test_tf_lut_and_workloads(cpm):
     assert np.array_equal(v, S.heterogeneous_volume(32))  # deterministic
     assert (S.homogeneous_volume(8) == 128).all()
     assert abs(S.photon_radius_texture((256, 256, 256)) - 3 ** 0.5 / 256) < 1e-9
+    assert S.photon_radius_texture((256, 256, 256)) == float(np.float32(S.photon_radius_texture((256, 256, 256))))
     c0, c31 = S.sequence_blob_center(0), S.sequence_blob_center(31)
     assert abs(c0[0] - 0.3) < 1e-12 and abs(c31[0] - 0.7) < 1e-12
 
