@@ -6,7 +6,8 @@
 using namespace cpm;
 
 namespace cpm {
-int radix_sort(cpm_ctx* ctx, uint32_t* keys, uint32_t* vals, size_t n, int key_bits, hipStream_t s);
+int radix_sort(cpm_ctx* ctx, uint32_t* keys, uint32_t* vals, size_t n, int key_bits, hipStream_t s,
+               uint32_t** res_keys = nullptr, uint32_t** res_vals = nullptr);
 }
 
 namespace {

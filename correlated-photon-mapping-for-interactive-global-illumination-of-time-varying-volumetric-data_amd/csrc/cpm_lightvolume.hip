@@ -13,7 +13,8 @@
 using namespace cpm;
 
 namespace cpm {
-int radix_sort(cpm_ctx* ctx, uint32_t* keys, uint32_t* vals, size_t n, int key_bits, hipStream_t s);
+int radix_sort(cpm_ctx* ctx, uint32_t* keys, uint32_t* vals, size_t n, int key_bits, hipStream_t s,
+               uint32_t** res_keys = nullptr, uint32_t** res_vals = nullptr);
 }
 
 namespace {
@@ -252,7 +253,7 @@ CPM_DEV void gather_pair(const GridDev& G, float4 a, float pg, float pb, f3 c, i
 //     A lane drains its queue in the order it filled it: the summation order is unchanged.
 constexpr int kQ = 8;
 template <int CH, int BATCH>
-__global__ __launch_bounds__(256) void gather_kernel(const float* __restrict__ sorted,
+__global__ __launch_bounds__(256) void gather_voxel_kernel(const float* __restrict__ sorted,
                                                             const uint32_t* __restrict__ cell_start, GridDev G, float radius,
                                                             float r2max, float k, int Rx, int Ry, int Rz, int accumulate,
                                                             int bxn, int byn, float* __restrict__ out,
@@ -354,6 +355,338 @@ __global__ __launch_bounds__(256) void gather_kernel(const float* __restrict__ s
     }
 }
 
+// ---- record-major gather (single channel, <= 3 candidate voxels per axis) ---------------------------
+//
+// The voxel-major kernel above makes every lane stream its own window of records: a wave-load
+// touches up to 64 cache lines and the heaviest voxel (hundreds of candidates) sets the kernel
+// time.  Here lanes own RECORDS instead.  One wave = one 4x4x4 brick of voxels:
+//   1. halo row runs (jb, len) -> exclusive prefix: the brick's records form one flat sequence,
+//      ascending in sorted index; it is consumed 64 records per step, lane l = record base + l
+//      (coalesced 16-byte loads);
+//   2. a record can only reach voxels whose centre lies within r (+1e-3 slack) of it per axis:
+//      <= 2 per axis at r < 1 voxel, i.e. <= 8 candidates (<= 27 in general here).  The box test
+//      is per record; per candidate: centre, d^2, exact cheap reject, sqrt, division, kernel.
+//      A non-zero contribution goes to the LDS slot s_val[candidate][lane] and the lane's bit is
+//      OR-ed into the target voxel's 64-bit mask (ds_or_b64: order-free, hence deterministic);
+//   3. lane v then walks the set bits of its voxel's mask in ascending lane order and adds the
+//      slots -- ascending lanes and ascending steps are ascending sorted index, so each voxel
+//      performs exactly the sequential fp32 sum the contract defines.
+// No global-memory divergence, no per-lane chains, no workgroup barrier.
+template <int MAXC>
+__global__ __launch_bounds__(256) void gather_records_kernel(const float* __restrict__ sorted,
+                                                             const uint32_t* __restrict__ cell_start, GridDev G, float radius,
+                                                             float r2max, float k, int Rx, int Ry, int Rz, int accumulate,
+                                                             int bxn, int byn, float* __restrict__ out,
+                                                             unsigned long long* __restrict__ dbg) {
+    constexpr int NC = MAXC * MAXC * MAXC;
+    constexpr int MAXROWS = 64;
+    __shared__ float s_val_all[4][NC][64];
+    __shared__ unsigned long long s_mask_all[4][64];
+    __shared__ uint32_t s_base_all[4][64];
+    __shared__ uint32_t s_off_all[4][MAXROWS + 1];
+    __shared__ uint32_t s_jb_all[4][MAXROWS];
+    const unsigned long long t_start = dbg ? __builtin_amdgcn_s_memrealtime() : 0ull;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float (*s_val)[64] = s_val_all[wave];
+    unsigned long long* s_mask = s_mask_all[wave];
+    uint32_t* s_base = s_base_all[wave];
+    uint32_t* s_off = s_off_all[wave];
+    uint32_t* s_jb = s_jb_all[wave];
+
+    const int gb = blockIdx.x * 4 + wave;
+    const int by = (gb / bxn) % byn, bz = gb / (bxn * byn);
+    const int bx = (gb % bxn + 4 * (by + bz)) % bxn;  // XCD-balancing rotation (see gather_voxel_kernel)
+    const int x0 = bx * kGW, y0 = by * kGW, z0 = bz * kGW;
+    if (z0 >= G.dz) return;
+    const int x = x0 + (lane & 3), y = y0 + ((lane >> 2) & 3), z = z0 + (lane >> 4);
+    const bool valid = x < G.dx && y < G.dy && z < G.dz;
+
+    // ---- 1. halo rows
+    const int nry = kGW + 2 * Ry, nrows = nry * (kGW + 2 * Rz);
+    uint32_t jb = 0, len = 0;
+    if (lane < nrows) {
+        const int cy = y0 - Ry + (lane % nry), cz = z0 - Rz + (lane / nry);
+        if (cy >= 0 && cy < G.dy && cz >= 0 && cz < G.dz) {
+            const uint32_t row = (uint32_t)G.dx * ((uint32_t)cy + (uint32_t)G.dy * (uint32_t)cz);
+            jb = cell_start[row + (uint32_t)max(x0 - Rx, 0)];
+            len = cell_start[row + (uint32_t)min(x0 + kGW - 1 + Rx, G.dx - 1) + 1] - jb;
+        }
+    }
+    uint32_t incl = len;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        uint32_t o = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += o;
+    }
+    const uint32_t total = __shfl(incl, 63, 64);
+    float sum = 0.f;
+    if (total != 0) {  // wave-uniform
+        if (lane < nrows) { s_off[lane] = incl - len; s_jb[lane] = jb; }
+        if (lane == 0) s_off[nrows] = total;
+        s_mask[lane] = 0ull;
+        __builtin_amdgcn_wave_barrier();
+        const float4* __restrict__ rec = reinterpret_cast<const float4*>(sorted);
+        const float rgx = radius * (float)G.dx + 1e-3f, rgy = radius * (float)G.dy + 1e-3f, rgz = radius * (float)G.dz + 1e-3f;
+        const int x1 = min(x0 + kGW - 1, G.dx - 1), y1 = min(y0 + kGW - 1, G.dy - 1), z1 = min(z0 + kGW - 1, G.dz - 1);
+        for (uint32_t base = 0; base < total; base += 64) {
+            const uint32_t i = base + lane;
+            const bool have = i < total;
+            // row of record i: the last r with s_off[r] <= i
+            int lo = 0, hi = nrows - 1;
+#pragma unroll
+            for (int it = 0; it < 6; ++it) {
+                const int mid = (lo + hi + 1) >> 1;
+                if (s_off[mid] <= i) lo = mid; else hi = mid - 1;
+            }
+            const uint32_t j = s_jb[lo] + (i - s_off[lo]);
+            float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (have) a = rec[j];
+            const f3 p = { a.x, a.y, a.z };
+            // candidate voxels: centres within r (+ slack) per axis, inside this brick
+            const f3 u = transform_(G.t2i, p);  // index space: voxel v has its centre at u == v
+            int sx = max((int)__builtin_ceilf(u.x - rgx), x0), ex = min((int)__builtin_floorf(u.x + rgx), x1);
+            int sy = max((int)__builtin_ceilf(u.y - rgy), y0), ey = min((int)__builtin_floorf(u.y + rgy), y1);
+            int sz = max((int)__builtin_ceilf(u.z - rgz), z0), ez = min((int)__builtin_floorf(u.z + rgz), z1);
+            const int nx = max(ex - sx + 1, 0), ny = max(ey - sy + 1, 0), nz = max(ez - sz + 1, 0);
+            const int ncand = have ? nx * ny * nz : 0;
+            s_base[lane] = (uint32_t)(sx - x0) | ((uint32_t)(sy - y0) << 2) | ((uint32_t)(sz - z0) << 4) | ((uint32_t)nx << 6) | ((uint32_t)ny << 8);
+            const Box3 bb = splat_box(G, p, radius);
+            const float pk = a.w * k;
+            int cx = 0, cy = 0, cz = 0;
+            for (int c = 0; c < NC; ++c) {
+                if (!__any(c < ncand)) break;
+                if (c < ncand) {
+                    const int vx = sx + cx, vy = sy + cy, vz = sz + cz;
+                    f3 vi = { (float)vx, (float)vy, (float)vz };
+                    const f3 cc = transform_(G.i2t, vi);
+                    const float ddx = cc.x - a.x, ddy = cc.y - a.y, ddz = cc.z - a.z;
+                    const float d2 = fma_(ddz, ddz, fma_(ddy, ddy, ddx * ddx));
+                    if (d2 <= r2max &&  // otherwise exactly no contribution
+                        vx >= bb.sx && vx < bb.ex && vy >= bb.sy && vy < bb.ey && vz >= bb.sz && vz < bb.ez) {
+                        const float w = density_kernel_(__builtin_sqrtf(d2) / radius);
+                        const float val = pk * w;
+                        if (val != 0.f) {
+                            s_val[c][lane] = val;
+                            const int vl = (vx - x0) + 4 * (vy - y0) + 16 * (vz - z0);
+                            atomicOr(&s_mask[vl], 1ull << lane);
+                        }
+                    }
+                    if (++cx == nx) { cx = 0; if (++cy == ny) { cy = 0; ++cz; } }
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            // ---- 3. lane = voxel: add this step's contributors in ascending lane (= sorted index) order
+            unsigned long long m = s_mask[lane];
+            if (m) {
+                s_mask[lane] = 0ull;
+                const int lx = lane & 3, ly = (lane >> 2) & 3, lz = lane >> 4;
+                do {
+                    const int l = __builtin_ctzll(m);
+                    m &= m - 1;
+                    const uint32_t b = s_base[l];
+                    const int bsx = b & 3, bsy = (b >> 2) & 3, bsz = (b >> 4) & 3, bnx = (b >> 6) & 3, bny = (b >> 8) & 3;
+                    const int c = ((lz - bsz) * bny + (ly - bsy)) * bnx + (lx - bsx);
+                    sum += s_val[c][l];
+                } while (m);
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+    if (dbg && lane == 0) {
+        unsigned xcc = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11));
+        const size_t gbs = (size_t)bx + (size_t)bxn * ((size_t)by + (size_t)byn * (size_t)bz);
+        dbg[4 * gbs + 0] = t_start;
+        dbg[4 * gbs + 1] = __builtin_amdgcn_s_memrealtime();
+        dbg[4 * gbs + 2] = total;
+        dbg[4 * gbs + 3] = xcc;
+    }
+    if (!valid) return;
+    const uint32_t v = (uint32_t)x + (uint32_t)G.dx * ((uint32_t)y + (uint32_t)G.dy * (uint32_t)z);
+    out[v] = accumulate ? out[v] + sum : sum;
+}
+
+// ---- record-major gather, specialised for <= 2 candidate voxels per axis (r < 1 voxel) ------------
+// Same algorithm and the same per-voxel summation order as gather_records_kernel, tuned:
+//   * the 2x2x2 candidates are unrolled; per axis the two centre offsets d = c - p and the box
+//     verdicts are computed once per record, so a candidate costs two fma and a compare
+//     (d^2 = fma(dz, dz, fma(dy, dy, dx*dx)) is evaluated with exactly the contract's operands);
+//   * the next step's records are fetched before the current step is processed;
+//   * the flattened-index -> row lookup is a popcount over a bitmask of row starts instead of a
+//     binary search;
+//   * z-slabs are visited from both faces inwards (photons pile up where light enters the volume,
+//     i.e. on faces): the heaviest bricks are dispatched first instead of last.
+__global__ __launch_bounds__(256) void gather_records2_kernel(const float* __restrict__ sorted,
+                                                              const uint32_t* __restrict__ cell_start, GridDev G, float radius,
+                                                              float r2max, float k, int Rx, int Ry, int Rz, int accumulate,
+                                                              int bxn, int byn, int bzn, float* __restrict__ out,
+                                                              unsigned long long* __restrict__ dbg) {
+    constexpr int MAXROWS = 64;
+    constexpr int MAXWORDS = 64;  // row-start bitmask: up to 4096 records per brick halo, else the generic kernel's path
+    __shared__ float s_val_all[4][8][64];
+    __shared__ unsigned long long s_mask_all[4][64];
+    __shared__ uint32_t s_base_all[4][64];
+    __shared__ unsigned long long s_start_all[4][MAXWORDS];
+    __shared__ uint32_t s_rowjb_all[4][MAXROWS];   // per NON-EMPTY row (compacted): jb - exclusive offset
+    __shared__ uint32_t s_rowoff_all[4][MAXROWS];  // per non-empty row: exclusive offset
+    const unsigned long long t_start = dbg ? __builtin_amdgcn_s_memrealtime() : 0ull;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float (*s_val)[64] = s_val_all[wave];
+    unsigned long long* s_mask = s_mask_all[wave];
+    uint32_t* s_base = s_base_all[wave];
+    unsigned long long* s_start = s_start_all[wave];
+    uint32_t* s_rowjb = s_rowjb_all[wave];
+    uint32_t* s_rowoff = s_rowoff_all[wave];
+
+    const int gb = blockIdx.x * 4 + wave;
+    const int by = (gb / bxn) % byn;
+    const int bzi = gb / (bxn * byn);
+    if (bzi >= bzn) return;
+    const int bz = (bzi & 1) ? (bzi >> 1) : (bzn - 1 - (bzi >> 1));  // bzn-1, 0, bzn-2, 1, ...
+    const int bx = (gb % bxn + 4 * (by + bzi)) % bxn;                // XCD-balancing rotation
+    const int x0 = bx * kGW, y0 = by * kGW, z0 = bz * kGW;
+    const int x = x0 + (lane & 3), y = y0 + ((lane >> 2) & 3), z = z0 + (lane >> 4);
+    const bool valid = x < G.dx && y < G.dy && z < G.dz;
+
+    const int nry = kGW + 2 * Ry, nrows = nry * (kGW + 2 * Rz);
+    uint32_t jb = 0, len = 0;
+    if (lane < nrows) {
+        const int cy = y0 - Ry + (lane % nry), cz = z0 - Rz + (lane / nry);
+        if (cy >= 0 && cy < G.dy && cz >= 0 && cz < G.dz) {
+            const uint32_t row = (uint32_t)G.dx * ((uint32_t)cy + (uint32_t)G.dy * (uint32_t)cz);
+            jb = cell_start[row + (uint32_t)max(x0 - Rx, 0)];
+            len = cell_start[row + (uint32_t)min(x0 + kGW - 1 + Rx, G.dx - 1) + 1] - jb;
+        }
+    }
+    uint32_t incl = len;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        uint32_t o = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += o;
+    }
+    const uint32_t total = __shfl(incl, 63, 64);
+    float sum = 0.f;
+    if (total != 0) {  // wave-uniform
+        const int nwords = (int)((total + 63) >> 6);
+        s_mask[lane] = 0ull;
+        if (lane < MAXWORDS) s_start[lane] = 0ull;
+        __builtin_amdgcn_wave_barrier();
+        // compacted non-empty rows: row k starts at flattened index off_k; lookup value = jb - off
+        const unsigned long long ne = __ballot(len != 0);
+        if (len != 0) {
+            const uint32_t off = incl - len;
+            const int kk = __popcll(ne & ((1ull << lane) - 1ull));
+            s_rowjb[kk] = jb - off;
+            s_rowoff[kk] = off;
+            if (total <= (uint32_t)MAXWORDS * 64u) atomicOr(&s_start[off >> 6], 1ull << (off & 63));
+        }
+        __builtin_amdgcn_wave_barrier();
+        const float4* __restrict__ rec = reinterpret_cast<const float4*>(sorted);
+        const float rgx = radius * (float)G.dx + 1e-3f, rgy = radius * (float)G.dy + 1e-3f, rgz = radius * (float)G.dz + 1e-3f;
+        const int x1 = min(x0 + kGW - 1, G.dx - 1), y1 = min(y0 + kGW - 1, G.dy - 1), z1 = min(z0 + kGW - 1, G.dz - 1);
+        const bool fast_rows = total <= (uint32_t)MAXWORDS * 64u;
+
+        // record index of flattened position i (step `w`, lane l): the row is found by counting the row
+        // starts at or before i -- a popcount over the start bitmask (or, for > 4096 records around one
+        // brick, a binary search over the compacted row offsets)
+        const int nne = __popcll(ne);
+        uint32_t rows_before = 0;  // non-empty rows that start before the current step (wave-uniform)
+        auto locate = [&](int w, uint32_t& rb_next) -> uint32_t {
+            const uint32_t i = (uint32_t)w * 64u + lane;
+            if (fast_rows) {
+                const unsigned long long sb = s_start[w];
+                const int kk = (int)rows_before + __popcll(sb & ((2ull << lane) - 1ull)) - 1;
+                rb_next = rows_before + (uint32_t)__popcll(sb);
+                return s_rowjb[max(kk, 0)] + i;
+            }
+            int lo = 0, hi = nne - 1;
+            for (int it = 0; it < 6; ++it) {
+                const int mid = (lo + hi + 1) >> 1;
+                if (s_rowoff[mid] <= i) lo = mid; else hi = mid - 1;
+            }
+            rb_next = rows_before;
+            return s_rowjb[lo] + i;
+        };
+
+        uint32_t rb_next = 0;
+        uint32_t jcur = locate(0, rb_next);
+        float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+        if ((uint32_t)lane < total) a = rec[jcur];
+        for (int w = 0; w < nwords; ++w) {
+            const bool have = (uint32_t)w * 64u + lane < total;
+            rows_before = rb_next;
+            // prefetch the next step's records
+            float4 an = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (w + 1 < nwords) {
+                const uint32_t jn = locate(w + 1, rb_next);
+                if ((uint32_t)(w + 1) * 64u + lane < total) an = rec[jn];
+            }
+            const f3 p = { a.x, a.y, a.z };
+            const f3 u = transform_(G.t2i, p);
+            const int sx = max((int)__builtin_ceilf(u.x - rgx), x0), ex = min((int)__builtin_floorf(u.x + rgx), x1);
+            const int sy = max((int)__builtin_ceilf(u.y - rgy), y0), ey = min((int)__builtin_floorf(u.y + rgy), y1);
+            const int sz = max((int)__builtin_ceilf(u.z - rgz), z0), ez = min((int)__builtin_floorf(u.z + rgz), z1);
+            const int nx = have ? max(ex - sx + 1, 0) : 0, ny = max(ey - sy + 1, 0), nz = max(ez - sz + 1, 0);
+            s_base[lane] = (uint32_t)(sx - x0) | ((uint32_t)(sy - y0) << 2) | ((uint32_t)(sz - z0) << 4);
+            const Box3 bb = splat_box(G, p, radius);
+            const float pk = a.w * k;
+            // per-axis terms for the two candidates of each axis
+            float dxv[2], dyv[2], dzv[2];
+            bool okx[2], oky[2], okz[2];
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int vx = sx + q, vy = sy + q, vz = sz + q;
+                dxv[q] = fma_(G.i2t.sx, (float)vx, G.i2t.tx) - a.x;
+                dyv[q] = fma_(G.i2t.sy, (float)vy, G.i2t.ty) - a.y;
+                dzv[q] = fma_(G.i2t.sz, (float)vz, G.i2t.tz) - a.z;
+                okx[q] = q < nx && vx >= bb.sx && vx < bb.ex;
+                oky[q] = q < ny && vy >= bb.sy && vy < bb.ey;
+                okz[q] = q < nz && vz >= bb.sz && vz < bb.ez;
+            }
+            const int vl0 = (sx - x0) + 4 * (sy - y0) + 16 * (sz - z0);
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                const int qx = c & 1, qy = (c >> 1) & 1, qz = c >> 2;
+                const float d2 = fma_(dzv[qz], dzv[qz], fma_(dyv[qy], dyv[qy], dxv[qx] * dxv[qx]));
+                if (okx[qx] && oky[qy] && okz[qz] && d2 <= r2max) {  // d2 > r2max: exactly no contribution
+                    const float wgt = density_kernel_(__builtin_sqrtf(d2) / radius);
+                    const float val = pk * wgt;
+                    if (val != 0.f) {
+                        s_val[c][lane] = val;
+                        atomicOr(&s_mask[vl0 + qx + 4 * qy + 16 * qz], 1ull << lane);
+                    }
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            // lane = voxel: add this step's contributors in ascending lane (= sorted index) order
+            unsigned long long m = s_mask[lane];
+            if (m) {
+                s_mask[lane] = 0ull;
+                const int lx = lane & 3, ly = (lane >> 2) & 3, lz = lane >> 4;
+                do {
+                    const int l = __builtin_ctzll(m);
+                    m &= m - 1;
+                    const uint32_t b = s_base[l];
+                    const int c = (lx - (int)(b & 3)) + 2 * (ly - (int)((b >> 2) & 3)) + 4 * (lz - (int)((b >> 4) & 3));
+                    sum += s_val[c][l];
+                } while (m);
+            }
+            __builtin_amdgcn_wave_barrier();
+            a = an;
+        }
+    }
+    if (dbg && lane == 0) {
+        unsigned xcc = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11));
+        const size_t gbs = (size_t)bx + (size_t)bxn * ((size_t)by + (size_t)byn * (size_t)bz);
+        dbg[4 * gbs + 0] = t_start;
+        dbg[4 * gbs + 1] = __builtin_amdgcn_s_memrealtime();
+        dbg[4 * gbs + 2] = total;
+        dbg[4 * gbs + 3] = xcc;
+    }
+    if (!valid) return;
+    const uint32_t v = (uint32_t)x + (uint32_t)G.dx * ((uint32_t)y + (uint32_t)G.dy * (uint32_t)z);
+    out[v] = accumulate ? out[v] + sum : sum;
+}
+
 int key_bits_for(uint32_t max_key) {  // bits needed to represent max_key
     int b = 1;
     while (b < 32 && (max_key >> b) != 0) ++b;
@@ -367,6 +700,9 @@ extern "C" {
 // diagnostic hook (include/cpm/cpm_profile.h): 4 x u64 per 4x4x4 brick = (start, end [100 MHz ticks], records, XCC id)
 static unsigned long long* g_gather_stamps = nullptr;
 void cpm_debug_set_gather_stamps(unsigned long long* dev) { g_gather_stamps = dev; }
+// test hook: 1 = voxel-major kernel for every gather, 2 = generic record-major kernel instead of the r < 1 specialisation
+static int g_gather_force_voxel = 0;
+void cpm_debug_force_voxel_gather(int on) { g_gather_force_voxel = on; }
 
 int cpm_splat(cpm_ctx* ctx, const float* photons8, int total_photons, const cpm_grid_desc* grid, float radius,
               float scale, float* grid_out, cpm_stream stream) {
@@ -431,7 +767,9 @@ int cpm_bin(cpm_ctx* ctx, const float* photons8, int n, const cpm_grid_desc* gri
     if (n > 0) {
         CPM_LAUNCH(ctx, bin_keys_kernel, dim3(div_up(n, 256)), dim3(256), 0, s, photons8, n, G, cells, keys, vals);
         CPM_LAUNCH_CHECK(ctx, "bin_keys_kernel");
-        rc = cpm::radix_sort(ctx, keys, vals, (size_t)n, key_bits_for(cells), s);
+        // no copy-back after an odd number of passes: the finalize / cell-start kernels read the
+        // result wherever the ping-pong left it
+        rc = cpm::radix_sort(ctx, keys, vals, (size_t)n, key_bits_for(cells), s, &keys, &vals);
         if (rc) return rc;
     }
     // run starts -> table (preset to "none"), then the suffix-min scan turns it into cell starts
@@ -470,11 +808,23 @@ int cpm_gather(cpm_ctx* ctx, const float* sorted_pos_power, const uint32_t* cell
     int bxn = div_up(G.dx, 4), byn = div_up(G.dy, 4), bzn = div_up(G.dz, 4);
     dim3 gridDim((unsigned)div_up((long long)bxn * byn * bzn, 4)), block(256);
     hipStream_t hs = (hipStream_t)stream;
-    if (G.channels == 1)
-        CPM_LAUNCH(ctx, (gather_kernel<1, 4>), gridDim, block, 0, hs, sorted_pos_power, cell_start, G, radius, r2max, k, Rx, Ry, Rz,
+    // candidates per axis a record can reach: floor(2 (r' + 1e-3)) + 1
+    const float rmax = fmaxf(radius * (float)G.dx, fmaxf(radius * (float)G.dy, radius * (float)G.dz)) + 1e-3f;
+    const int cand_axis = (int)floorf(2.f * rmax) + 1;
+    if (G.channels == 1 && cand_axis <= 2 && Rx <= 1 && Ry <= 1 && Rz <= 1 && g_gather_force_voxel == 0)
+        CPM_LAUNCH(ctx, gather_records2_kernel, gridDim, block, 0, hs, sorted_pos_power, cell_start, G, radius, r2max, k, Rx, Ry, Rz,
+                   accumulate, bxn, byn, bzn, grid_out, g_gather_stamps);
+    else if (G.channels == 1 && cand_axis <= 2 && g_gather_force_voxel != 1)
+        CPM_LAUNCH(ctx, gather_records_kernel<2>, gridDim, block, 0, hs, sorted_pos_power, cell_start, G, radius, r2max, k, Rx, Ry, Rz,
+                   accumulate, bxn, byn, grid_out, g_gather_stamps);
+    else if (G.channels == 1 && cand_axis <= 3 && g_gather_force_voxel != 1)
+        CPM_LAUNCH(ctx, gather_records_kernel<3>, gridDim, block, 0, hs, sorted_pos_power, cell_start, G, radius, r2max, k, Rx, Ry, Rz,
+                   accumulate, bxn, byn, grid_out, g_gather_stamps);
+    else if (G.channels == 1)
+        CPM_LAUNCH(ctx, (gather_voxel_kernel<1, 4>), gridDim, block, 0, hs, sorted_pos_power, cell_start, G, radius, r2max, k, Rx, Ry, Rz,
                    accumulate, bxn, byn, grid_out, g_gather_stamps);
     else
-        CPM_LAUNCH(ctx, (gather_kernel<4, 4>), gridDim, block, 0, hs, sorted_pos_power, cell_start, G, radius, r2max, k, Rx, Ry, Rz,
+        CPM_LAUNCH(ctx, (gather_voxel_kernel<4, 4>), gridDim, block, 0, hs, sorted_pos_power, cell_start, G, radius, r2max, k, Rx, Ry, Rz,
                    accumulate, bxn, byn, grid_out, g_gather_stamps);
     CPM_LAUNCH_CHECK(ctx, "gather_kernel");
     return CPM_OK;

@@ -191,8 +191,11 @@ __global__ __launch_bounds__(kSortThreads) void radix_scatter_kernel(const uint3
     }
 }
 
+// res_keys / res_vals (nullable): when given, the result is NOT copied back after an odd number of
+// passes; instead they receive the buffers that hold it (keys/vals or the scratch ping-pong).
 template <int ITEMS>
-static int sort_passes(cpm_ctx* ctx, uint32_t* keys, uint32_t* vals, uint32_t n, int key_bits, hipStream_t s) {
+static int sort_passes(cpm_ctx* ctx, uint32_t* keys, uint32_t* vals, uint32_t n, int key_bits, hipStream_t s,
+                       uint32_t** res_keys, uint32_t** res_vals) {
     const uint32_t tile = kSortThreads * ITEMS;
     const uint32_t num_tiles = (n + tile - 1) / tile;
     uint32_t* k2 = (uint32_t*)scratch(ctx, CPM_SCR_SORT_KEYS, (size_t)n * 4);
@@ -212,6 +215,11 @@ static int sort_passes(cpm_ctx* ctx, uint32_t* keys, uint32_t* vals, uint32_t n,
         uint32_t* tmp = ks; ks = kd; kd = tmp;
         tmp = vs; vs = vd; vd = tmp;
     }
+    if (res_keys) {
+        *res_keys = ks;
+        if (res_vals) *res_vals = vs;
+        return CPM_OK;
+    }
     if (ks != keys) {  // odd number of passes: result back in place (clogs does the same, radixsort.cpp:250-256)
         CPM_HIP_CHECK(ctx, hipMemcpyAsync(keys, ks, (size_t)n * 4, hipMemcpyDeviceToDevice, s));
         if (vals) CPM_HIP_CHECK(ctx, hipMemcpyAsync(vals, vs, (size_t)n * 4, hipMemcpyDeviceToDevice, s));
@@ -220,14 +228,17 @@ static int sort_passes(cpm_ctx* ctx, uint32_t* keys, uint32_t* vals, uint32_t n,
 }
 
 // keys/vals sorted in place; vals may be null (keys only)
-int radix_sort(cpm_ctx* ctx, uint32_t* keys, uint32_t* vals, size_t n, int key_bits, hipStream_t s) {
+int radix_sort(cpm_ctx* ctx, uint32_t* keys, uint32_t* vals, size_t n, int key_bits, hipStream_t s,
+               uint32_t** res_keys, uint32_t** res_vals) {
+    if (res_keys) *res_keys = keys;
+    if (res_vals) *res_vals = vals;
     if (n <= 1) return CPM_OK;
     if (n >= (1ull << 31)) return set_error(ctx, CPM_ERR_INVALID_ARGUMENT, "radix_sort", "n must be < 2^31");
     if (key_bits <= 0 || key_bits > 32) key_bits = 32;
     // enough workgroups to cover 256 CUs several times over at small n
-    if (n <= (1u << 21)) return sort_passes<4>(ctx, keys, vals, (uint32_t)n, key_bits, s);
-    if (n <= (1u << 23)) return sort_passes<8>(ctx, keys, vals, (uint32_t)n, key_bits, s);
-    return sort_passes<16>(ctx, keys, vals, (uint32_t)n, key_bits, s);
+    if (n <= (1u << 21)) return sort_passes<4>(ctx, keys, vals, (uint32_t)n, key_bits, s, res_keys, res_vals);
+    if (n <= (1u << 23)) return sort_passes<8>(ctx, keys, vals, (uint32_t)n, key_bits, s, res_keys, res_vals);
+    return sort_passes<16>(ctx, keys, vals, (uint32_t)n, key_bits, s, res_keys, res_vals);
 }
 
 }  // namespace cpm
@@ -237,13 +248,13 @@ extern "C" {
 int cpm_sort_pairs(cpm_ctx* ctx, uint32_t* keys, uint32_t* values, size_t n, int key_bits, cpm_stream stream) {
     if (!ctx) return CPM_ERR_INVALID_ARGUMENT;
     CPM_REQUIRE(ctx, (keys && values) || n == 0, "cpm_sort_pairs: null argument");
-    return cpm::radix_sort(ctx, keys, values, n, key_bits, (hipStream_t)stream);
+    return cpm::radix_sort(ctx, keys, values, n, key_bits, (hipStream_t)stream, nullptr, nullptr);
 }
 
 int cpm_sort_keys(cpm_ctx* ctx, uint32_t* keys, size_t n, int key_bits, cpm_stream stream) {
     if (!ctx) return CPM_ERR_INVALID_ARGUMENT;
     CPM_REQUIRE(ctx, keys || n == 0, "cpm_sort_keys: null argument");
-    return cpm::radix_sort(ctx, keys, nullptr, n, key_bits, (hipStream_t)stream);
+    return cpm::radix_sort(ctx, keys, nullptr, n, key_bits, (hipStream_t)stream, nullptr, nullptr);
 }
 
 }  // extern "C"

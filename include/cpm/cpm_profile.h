@@ -23,6 +23,8 @@ long cpm_profile_calls(const cpm_ctx* ctx, int i);
 void cpm_debug_set_step_counter(unsigned long long* dev_counter);
 /* when non-NULL, cpm_gather launches write (start, end [100 MHz ticks], records, XCC id) per 4x4x4 brick */
 void cpm_debug_set_gather_stamps(unsigned long long* dev_stamps);
+/* test hook: force the voxel-major gather kernel (default: record-major for 1 channel and r < 1.5 voxels) */
+void cpm_debug_force_voxel_gather(int on);
 #ifdef __cplusplus
 }
 #endif

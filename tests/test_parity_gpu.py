@@ -351,8 +351,25 @@ def _random_photons(rng, n, sentinel_every=0, spread=1.0, rgb=False):
     return ph
 
 
-@pytest.mark.parametrize("dims,channels,radius_vox", [((32, 32, 32), 1, 0.866), ((24, 40, 16), 4, 1.7), ((16, 16, 16), 1, 0.3)])
-def test_bin_and_gather_bit_exact(ctx, oracle, cpm, dims, channels, radius_vox):
+@pytest.mark.parametrize("dims,channels,radius_vox,force_voxel", [
+    ((32, 32, 32), 1, 0.866, 0),       # record-major kernel specialised for r < 1 voxel (BASELINE geometry)
+    ((32, 32, 32), 1, 0.866, 2),       # generic record-major kernel on the same input
+    ((32, 32, 32), 1, 0.866, 1),       # voxel-major kernel on the same input
+    ((30, 21, 9), 1, 0.7, 0),          # bricks cut by the grid edge
+    ((24, 40, 16), 4, 1.7, 0),     # 4 x float32: voxel-major
+    ((16, 16, 16), 1, 0.3, 0),
+    ((20, 28, 36), 1, 1.2, 0),     # record-major kernel, 3 candidates per axis, bricks cut by the grid edge
+    ((32, 32, 32), 1, 2.2, 0),     # radius too large for the record-major kernel: falls back
+])
+def test_bin_and_gather_bit_exact(ctx, oracle, cpm, dims, channels, radius_vox, force_voxel):
+    ctx.lib.cpm_debug_force_voxel_gather(int(force_voxel))
+    try:
+        _bin_and_gather_case(ctx, oracle, cpm, dims, channels, radius_vox)
+    finally:
+        ctx.lib.cpm_debug_force_voxel_gather(0)
+
+
+def _bin_and_gather_case(ctx, oracle, cpm, dims, channels, radius_vox):
     rng = np.random.default_rng(sum(dims))
     n = 20_000
     ph = _random_photons(rng, n, sentinel_every=13, spread=1.1)  # some photons outside [0,1]^3 and on the faces
@@ -361,6 +378,7 @@ def test_bin_and_gather_bit_exact(ctx, oracle, cpm, dims, channels, radius_vox):
     radius = float(np.float32(radius_vox / max(dims)))
     scale = oracle.relative_irradiance_scale(radius, n)
     assert scale == cpm.binding.relative_irradiance_scale(radius, n)
+    ph[7:400, :3] = ph[7, :3] + (rng.random((393, 3), dtype=np.float32) - 0.5) * np.float32(0.5 / max(dims))  # a dense cluster
     g = cpm.binding.default_grid_desc(dims, channels)
     og = oracle.grid(dims, channels)
     assert list(g.index_to_texture) == list(og.index_to_texture)
@@ -515,3 +533,18 @@ def test_frame_config2_properties(ctx, oracle, cpm):
     ph_o = np.zeros((sel.size, 8), np.float32)
     oracle.trace(oracle.volume(vol_np), tf, S.UNIT_CUBE_AABB, po, ls, isect, rng_o, ph_o)
     assert np.array_equal(bits(photons[sel]), bits(ph_o))
+
+
+def test_frame_graph_replay_equals_eager(ctx, cpm):
+    """The captured HIP graph of the frame produces exactly what the eager launches produce."""
+    S, P = cpm.synthetic, cpm.pipeline
+    fr = P.PhotonFrame(ctx, S.heterogeneous_volume(64), S.workspace_tf(), 256, (32, 32, 32), light_travel_direction=(0.3, 0.5, -1.0))
+    eager = fr.frame().clone()
+    photons = fr.photons.clone()
+    fr.capture()
+    fr.light_volume.zero_()
+    fr.photons.zero_()
+    for _ in range(3):
+        fr.replay()
+    ctx.torch.cuda.synchronize()
+    assert ctx.torch.equal(fr.light_volume, eager) and ctx.torch.equal(fr.photons, photons)
