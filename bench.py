@@ -128,7 +128,7 @@ def main():
         raise SystemExit("bench.py needs a GPU: libcpm_hip has no CPU fallback")
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or "TORCHELASTIC_RUN_ID" in os.environ:  # launched by torch.distributed.run (also at N = 1)
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))  # backend nccl = RCCL on ROCm
 

@@ -129,8 +129,10 @@ __global__ __launch_bounds__(256) void copy_indexed_kernel(const float* __restri
 // sort needs only bits(cells) key bits and they still land behind every real cell
 __global__ __launch_bounds__(256) void bin_keys_kernel(const float* __restrict__ photons, int n, GridDev G,
                                                        uint32_t cells, uint32_t* __restrict__ keys,
-                                                       uint32_t* __restrict__ vals) {
+                                                       uint32_t* __restrict__ vals, uint32_t* __restrict__ cell_start) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
+    // preset the run-start table to "none" on the way (saves a separate fill launch)
+    for (uint32_t e = (uint32_t)i; e <= cells; e += gridDim.x * blockDim.x) cell_start[e] = 0xffffffffu;
     if (i >= n) return;
     float4 a = reinterpret_cast<const float4*>(photons)[2 * (size_t)i];
     uint32_t key = cells;
@@ -524,7 +526,6 @@ __global__ __launch_bounds__(256) void gather_records2_kernel(const float* __res
     constexpr int MAXWORDS = 64;  // row-start bitmask: up to 4096 records per brick halo, else the generic kernel's path
     __shared__ float s_val_all[4][8][64];
     __shared__ unsigned long long s_mask_all[4][64];
-    __shared__ uint32_t s_base_all[4][64];
     __shared__ unsigned long long s_start_all[4][MAXWORDS];
     __shared__ uint32_t s_rowjb_all[4][MAXROWS];   // per NON-EMPTY row (compacted): jb - exclusive offset
     __shared__ uint32_t s_rowoff_all[4][MAXROWS];  // per non-empty row: exclusive offset
@@ -532,7 +533,6 @@ __global__ __launch_bounds__(256) void gather_records2_kernel(const float* __res
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float (*s_val)[64] = s_val_all[wave];
     unsigned long long* s_mask = s_mask_all[wave];
-    uint32_t* s_base = s_base_all[wave];
     unsigned long long* s_start = s_start_all[wave];
     uint32_t* s_rowjb = s_rowjb_all[wave];
     uint32_t* s_rowoff = s_rowoff_all[wave];
@@ -546,6 +546,7 @@ __global__ __launch_bounds__(256) void gather_records2_kernel(const float* __res
     const int x0 = bx * kGW, y0 = by * kGW, z0 = bz * kGW;
     const int x = x0 + (lane & 3), y = y0 + ((lane >> 2) & 3), z = z0 + (lane >> 4);
     const bool valid = x < G.dx && y < G.dy && z < G.dz;
+    const int my_par = (x & 1) | ((y & 1) << 1) | ((z & 1) << 2);
 
     const int nry = kGW + 2 * Ry, nrows = nry * (kGW + 2 * Rz);
     uint32_t jb = 0, len = 0;
@@ -626,7 +627,6 @@ __global__ __launch_bounds__(256) void gather_records2_kernel(const float* __res
             const int sy = max((int)__builtin_ceilf(u.y - rgy), y0), ey = min((int)__builtin_floorf(u.y + rgy), y1);
             const int sz = max((int)__builtin_ceilf(u.z - rgz), z0), ez = min((int)__builtin_floorf(u.z + rgz), z1);
             const int nx = have ? max(ex - sx + 1, 0) : 0, ny = max(ey - sy + 1, 0), nz = max(ez - sz + 1, 0);
-            s_base[lane] = (uint32_t)(sx - x0) | ((uint32_t)(sy - y0) << 2) | ((uint32_t)(sz - z0) << 4);
             const Box3 bb = splat_box(G, p, radius);
             const float pk = a.w * k;
             // per-axis terms for the two candidates of each axis
@@ -642,7 +642,11 @@ __global__ __launch_bounds__(256) void gather_records2_kernel(const float* __res
                 oky[q] = q < ny && vy >= bb.sy && vy < bb.ey;
                 okz[q] = q < nz && vz >= bb.sz && vz < bb.ez;
             }
+            // A record's candidates are consecutive integers per axis, so they differ in the parity of each
+            // coordinate: the slot a value goes to is the parity triple of the TARGET voxel -- which the
+            // voxel's own lane knows without looking anything up.
             const int vl0 = (sx - x0) + 4 * (sy - y0) + 16 * (sz - z0);
+            const int par0 = (sx & 1) | ((sy & 1) << 1) | ((sz & 1) << 2);
 #pragma unroll
             for (int c = 0; c < 8; ++c) {
                 const int qx = c & 1, qy = (c >> 1) & 1, qz = c >> 2;
@@ -651,7 +655,7 @@ __global__ __launch_bounds__(256) void gather_records2_kernel(const float* __res
                     const float wgt = density_kernel_(__builtin_sqrtf(d2) / radius);
                     const float val = pk * wgt;
                     if (val != 0.f) {
-                        s_val[c][lane] = val;
+                        s_val[par0 ^ c][lane] = val;  // parity of (sx+qx, sy+qy, sz+qz)
                         atomicOr(&s_mask[vl0 + qx + 4 * qy + 16 * qz], 1ull << lane);
                     }
                 }
@@ -661,13 +665,17 @@ __global__ __launch_bounds__(256) void gather_records2_kernel(const float* __res
             unsigned long long m = s_mask[lane];
             if (m) {
                 s_mask[lane] = 0ull;
-                const int lx = lane & 3, ly = (lane >> 2) & 3, lz = lane >> 4;
-                do {
-                    const int l = __builtin_ctzll(m);
-                    m &= m - 1;
-                    const uint32_t b = s_base[l];
-                    const int c = (lx - (int)(b & 3)) + 2 * (ly - (int)((b >> 2) & 3)) + 4 * (lz - (int)((b >> 4) & 3));
-                    sum += s_val[c][l];
+                const float* mine = s_val[my_par];
+                do {  // up to four contributors are fetched together, then added in order
+                    const int l0 = __builtin_ctzll(m); m &= m - 1;
+                    const int l1 = m ? __builtin_ctzll(m) : l0; const bool h1 = m != 0; m &= m - 1;
+                    const int l2 = m ? __builtin_ctzll(m) : l0; const bool h2 = m != 0; m &= m - 1;
+                    const int l3 = m ? __builtin_ctzll(m) : l0; const bool h3 = m != 0; m &= m - 1;
+                    const float v0 = mine[l0], v1 = mine[l1], v2 = mine[l2], v3 = mine[l3];
+                    sum += v0;
+                    if (h1) sum += v1;
+                    if (h2) sum += v2;
+                    if (h3) sum += v3;
                 } while (m);
             }
             __builtin_amdgcn_wave_barrier();
@@ -765,15 +773,15 @@ int cpm_bin(cpm_ctx* ctx, const float* photons8, int n, const cpm_grid_desc* gri
     if (!keys) return CPM_ERR_OUT_OF_MEMORY;
     uint32_t* vals = keys + (n > 0 ? n : 1);
     if (n > 0) {
-        CPM_LAUNCH(ctx, bin_keys_kernel, dim3(div_up(n, 256)), dim3(256), 0, s, photons8, n, G, cells, keys, vals);
+        CPM_LAUNCH(ctx, bin_keys_kernel, dim3(div_up(n, 256)), dim3(256), 0, s, photons8, n, G, cells, keys, vals, cell_start);
         CPM_LAUNCH_CHECK(ctx, "bin_keys_kernel");
         // no copy-back after an odd number of passes: the finalize / cell-start kernels read the
         // result wherever the ping-pong left it
         rc = cpm::radix_sort(ctx, keys, vals, (size_t)n, key_bits_for(cells), s, &keys, &vals);
         if (rc) return rc;
     }
-    // run starts -> table (preset to "none"), then the suffix-min scan turns it into cell starts
-    CPM_HIP_CHECK(ctx, hipMemsetAsync(cell_start, 0xff, ((size_t)cells + 1) * sizeof(uint32_t), s));
+    // run starts -> table (preset to "none" by bin_keys_kernel), then the suffix-min scan turns it into cell starts
+    if (n == 0) CPM_HIP_CHECK(ctx, hipMemsetAsync(cell_start, 0xff, ((size_t)cells + 1) * sizeof(uint32_t), s));
     if (n > 0) {
         CPM_LAUNCH(ctx, bin_finalize_kernel, dim3(div_up(n, 256)), dim3(256), 0, s, photons8, keys, vals, n, G.channels,
                            order, sorted_pos_power, cell_start);

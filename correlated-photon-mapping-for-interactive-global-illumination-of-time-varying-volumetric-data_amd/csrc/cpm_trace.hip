@@ -164,7 +164,7 @@ CPM_DEV void write_photon(float* photons, size_t id, f3 p, f3 pw, float th, floa
 
 template <int DT>
 CPM_DEV float woodcock(const VolDev& V, const float* lut, float wf, float m1, float m2, f3 o, f3 d, float tStart,
-                       float tEnd, uint32_t& rx, uint32_t& rc, unsigned& steps) {
+                       float tEnd, uint32_t& rx, uint32_t& rc, unsigned& steps, float& last_sample, float& last_opacity) {
     constexpr float invTauMaxSampleBaseInterval = 1.f / (1.f * 150.f);  // tauMax = 1 (photontracer.cl:160)
     float t = tStart;
     float opacity, u2;
@@ -177,10 +177,12 @@ CPM_DEV float woodcock(const VolDev& V, const float* lut, float wf, float m1, fl
         if (t <= tEnd) {
             float vs = sample_volume<DT>(V, fma_(t, d.x, o.x), fma_(t, d.y, o.y), fma_(t, d.z, o.z));
             opacity = sample_alpha(lut, wf, m1, m2, vs);
+            last_sample = vs;
         }
         u2 = rand01_(rx, rc);
         ++steps;
     } while (u2 >= opacity && t <= tEnd);
+    last_opacity = opacity;
     return t;
 }
 
@@ -216,7 +218,8 @@ __global__ __launch_bounds__(256) void trace_kernel(const TraceArgs A) {
     float4 l0 = lsp[0], l1 = lsp[1];
     f3 origin = { l0.x, l0.y, l0.z };
     float mi = (float)maxInteractions;
-    f3 power = { l0.w / mi, l1.x / mi, l1.y / mi };
+    f3 power = { l0.w, l1.x, l1.y };
+    if (maxInteractions != 1) { power.x = power.x / mi; power.y = power.y / mi; power.z = power.z / mi; }  // x / 1.0f == x
     f3 direction = decode_direction_(l1.z, l1.w);
     float2 ip = reinterpret_cast<const float2*>(A.isect)[threadId];
     float tStart = ip.x, tEnd = ip.y;
@@ -225,7 +228,8 @@ __global__ __launch_bounds__(256) void trace_kernel(const TraceArgs A) {
     const float wf = A.tf_wf, m1 = A.tf_m1, m2 = A.tf_m2;
 
     if (A.p.flags & CPM_TRACE_NO_SINGLE_SCATTERING) {  // photontracer.cl:143-157
-        float t = woodcock<DT>(A.vol, lut, wf, m1, m2, origin, direction, tStart, tEnd, rx, rc, steps);
+        float vs_unused, op_unused;
+        float t = woodcock<DT>(A.vol, lut, wf, m1, m2, origin, direction, tStart, tEnd, rx, rc, steps, vs_unused, op_unused);
         if (scatterEvent) {
             origin.x = fma_(t, direction.x, origin.x);
             origin.y = fma_(t, direction.y, origin.y);
@@ -240,7 +244,8 @@ __global__ __launch_bounds__(256) void trace_kernel(const TraceArgs A) {
         }
     }
     while (scatterEvent) {  // photontracer.cl:158-197
-        float t = woodcock<DT>(A.vol, lut, wf, m1, m2, origin, direction, tStart, tEnd, rx, rc, steps);
+        float volumeSample = 0.f, colorW = 0.f;
+        float t = woodcock<DT>(A.vol, lut, wf, m1, m2, origin, direction, tStart, tEnd, rx, rc, steps, volumeSample, colorW);
         scatterEvent = t <= tEnd;
         if (scatterEvent) {
             origin.x = fma_(t, direction.x, origin.x);
@@ -249,9 +254,10 @@ __global__ __launch_bounds__(256) void trace_kernel(const TraceArgs A) {
             size_t photonId = (size_t)photonOffset + nInteractions * totalPhotons + (size_t)threadId;
             float th, ph;
             encode_direction_(direction, th, ph);
-            float volumeSample = sample_volume<DT>(A.vol, origin.x, origin.y, origin.z);
-            float colorW = sample_alpha(lut, wf, m1, m2, volumeSample);
-            float scatW = sample_alpha(luts, wf, m1, m2, volumeSample);
+            // The reference samples the volume and the TF again at the collision point
+            // (photontracer.cl:170-173).  The accepted Woodcock iteration sampled exactly that point --
+            // fma(t, d, o) with the same t, d, o -- so its volume sample and alpha ARE those values.
+            float scatW = (luts == lut) ? colorW : sample_alpha(luts, wf, m1, m2, volumeSample);
             float scatteringAlbedo = scatW / (scatW + colorW);
             float dv = max_(colorW, 0.01f);
             power.x = power.x / dv; power.y = power.y / dv; power.z = power.z / dv;
