@@ -402,6 +402,34 @@ class CorrelatedPhotonMapper(PhotonFrame):
         self.ctx.importance_tf(self.minmax, nb, pos, col, self.importance_grid)
         return pos, col
 
+    def set_volume(self, voxels):
+        """A time step: new voxel data (same shape).  Computes, on the GPU, the per-brick mean |v_new - v_old|
+        (CPU in the reference: DynamicVolumeDifferenceAnalysis), the new min/max bricks and the time-varying
+        importance = difference x TF importance over the union of the old and new brick ranges
+        (classifyTimeVaryingMinMaxUniformGrid3DImportanceKernel), then swaps the volume in."""
+        ctx, torch = self.ctx, self.torch
+        nb = self.importance_grid.numel()
+        if getattr(self, "_vol_next", None) is None:
+            self._vol_next = ctx.volume_create(voxels)
+            self._minmax_next = torch.zeros_like(self.minmax)
+            self._diff = torch.zeros(nb, dtype=torch.float32, device=ctx.device)
+        else:
+            self._vol_next.update(voxels)
+        ctx.volume_difference(self.vol, self._vol_next, self.region, self._diff)
+        ctx.volume_minmax(self._vol_next, self.region, self._minmax_next)
+        # TF unchanged: importance of a range = the TF itself (updateTransferFunctionData), zero-padded to [0, 1]
+        pts = sorted(self.tf_points)
+        pos = [p[0] for p in pts]
+        col = [list(p[1:]) for p in pts]
+        if pos[0] > 0.0:
+            pos.insert(0, 0.0); col.insert(0, col[0])
+        if pos[-1] < 1.0:
+            pos.append(1.0); col.append(col[-1])
+        ctx.importance_tf(self._minmax_next, nb, np.asarray(pos, np.float32), np.asarray(col, np.float32), self.importance_grid,
+                          prev_minmax=self.minmax, volume_diff=self._diff)
+        self.vol, self._vol_next = self._vol_next, self.vol
+        self.minmax, self._minmax_next = self._minmax_next, self.minmax
+
     def correlated_update(self):
         """One evaluation of the importance branch + the light-volume processor.  Returns n re-traced."""
         ctx, torch = self.ctx, self.torch
