@@ -5,7 +5,8 @@
 // 4 bits per pass with byte counters in local memory, a single-work-group scan, and 24
 // launches for 32-bit keys; its autotuner and sqlite kernel cache are out of scope.
 //
-// MI355X design: 8 bits per pass, one pass = 3 launches:
+// MI355X design: 8 bits per pass, one pass = 3 launches (a single-launch onesweep variant with ticketed
+// tiles and decoupled look-back is kept as a tested alternative; it measured slower here):
 //   hist    : per-tile digit histogram, 256 LDS counters per workgroup (ds_add_u32)
 //   rowscan : 256 workgroups, one per digit: exclusive prefix of that digit's counts over tiles
 //   scatter : per wave a ballot-based multi-split gives every key its stable rank among
@@ -73,15 +74,45 @@ __global__ __launch_bounds__(kSortThreads) void radix_rowscan_kernel(uint32_t* _
     if (t == 0) digit_total[blockIdx.x] = carry;
 }
 
-template <int ITEMS, bool HAS_VALUES>
+// status word of the look-back: 2 flag bits + 30 value bits in ONE 32-bit word, so publishing needs
+// no ordering between separate locations (agent-scope relaxed atomic store / load = sc1 accesses).
+constexpr uint32_t kFlagAggregate = 1u << 30, kFlagPrefix = 2u << 30, kValueMask = (1u << 30) - 1u;
+constexpr uint32_t kSpinLimit = 1u << 24;  // polls before a wait gives up (sets the error word; never hangs the GPU)
+
+// global digit histograms of every pass in one read of the keys (onesweep's only pre-pass)
+__global__ __launch_bounds__(kSortThreads) void radix_global_hist_kernel(const uint32_t* __restrict__ keys, uint32_t n,
+                                                                         int passes, uint32_t* __restrict__ ghist) {
+    __shared__ uint32_t h[4][kRadix];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) h[p][threadIdx.x] = 0;
+    __syncthreads();
+    for (uint32_t i = blockIdx.x * kSortThreads + threadIdx.x; i < n; i += gridDim.x * kSortThreads) {
+        const uint32_t k = keys[i];
+        for (int p = 0; p < passes; ++p) atomicAdd(&h[p][(k >> (kRadixBits * p)) & (kRadix - 1)], 1u);
+    }
+    __syncthreads();
+    for (int p = 0; p < passes; ++p) {
+        const uint32_t c = h[p][threadIdx.x];
+        if (c) atomicAdd(&ghist[p * kRadix + threadIdx.x], c);
+    }
+}
+
+// ONESWEEP = false: tile offsets come from the (hist, rowscan) pre-passes (3 launches per pass).
+// ONESWEEP = true : one launch per pass.  Tiles take a ticket (so every earlier tile is already running:
+//   forward progress does not depend on dispatch order), publish their per-digit counts, and obtain the
+//   count of the same digit in all earlier tiles by decoupled look-back over the status words
+//   (Merrill & Garland's single-pass scan, as used by onesweep radix sorts).
+template <int ITEMS, bool HAS_VALUES, bool ONESWEEP>
 __global__ __launch_bounds__(kSortThreads) void radix_scatter_kernel(const uint32_t* __restrict__ keys_in,
                                                                      const uint32_t* __restrict__ vals_in,
                                                                      uint32_t* __restrict__ keys_out,
                                                                      uint32_t* __restrict__ vals_out, uint32_t n,
                                                                      int shift, const uint32_t* __restrict__ hist,
                                                                      const uint32_t* __restrict__ digit_total,
-                                                                     uint32_t num_tiles) {
+                                                                     uint32_t num_tiles, uint32_t* __restrict__ ticket,
+                                                                     uint32_t* __restrict__ status, uint32_t* __restrict__ error) {
     constexpr int TILE = kSortThreads * ITEMS;
+    __shared__ uint32_t s_tile;
     __shared__ uint32_t wcount[kSortWaves][kRadix];  // per-wave digit counters, later (wave, digit) local starts
     __shared__ uint32_t gofs[kRadix];                // global start of the digit's run minus its local start
     __shared__ uint32_t wsum[kSortWaves];
@@ -90,14 +121,14 @@ __global__ __launch_bounds__(kSortThreads) void radix_scatter_kernel(const uint3
 
     const uint32_t t = threadIdx.x;
     const uint32_t lane = t & 63, wave = t >> 6;
-    const uint32_t tile = blockIdx.x;
-    const uint32_t tile_base = tile * (uint32_t)TILE;
-    const uint32_t tile_count = (n - tile_base) < (uint32_t)TILE ? (n - tile_base) : (uint32_t)TILE;
-    const uint64_t lt_mask = (1ull << lane) - 1ull;
-
+    if (ONESWEEP && t == 0) s_tile = atomicAdd(ticket, 1u);
 #pragma unroll
     for (int w = 0; w < kSortWaves; ++w) wcount[w][t] = 0;
     __syncthreads();
+    const uint32_t tile = ONESWEEP ? s_tile : blockIdx.x;
+    const uint32_t tile_base = tile * (uint32_t)TILE;
+    const uint32_t tile_count = (n - tile_base) < (uint32_t)TILE ? (n - tile_base) : (uint32_t)TILE;
+    const uint64_t lt_mask = (1ull << lane) - 1ull;
 
     uint32_t key[ITEMS], val[ITEMS], rank[ITEMS];
     const uint32_t wave_base = tile_base + wave * (uint32_t)(64 * ITEMS);
@@ -164,7 +195,32 @@ __global__ __launch_bounds__(kSortThreads) void radix_scatter_kernel(const uint3
     uint32_t gwave_off = 0;
 #pragma unroll
     for (int w = 0; w < kSortWaves; ++w) gwave_off += (w < (int)wave) ? wsum[w] : 0u;
-    gofs[t] = (gwave_off + gv - gt) + hist[(size_t)t * num_tiles + tile] - local_start;
+    uint32_t earlier;  // keys with digit t in earlier tiles
+    if (ONESWEEP) {
+        uint32_t* mine = status + (size_t)tile * kRadix + t;
+        earlier = 0;
+        if (tile == 0) {
+            __hip_atomic_store(mine, total | kFlagPrefix, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            __hip_atomic_store(mine, total | kFlagAggregate, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            uint32_t polls = 0;
+            for (int p = (int)tile - 1; p >= 0;) {
+                const uint32_t w = __hip_atomic_load(status + (size_t)p * kRadix + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if ((w >> 30) == 0) {  // not published yet
+                    if (++polls > kSpinLimit) { atomicOr(error, 1u); break; }
+                    __builtin_amdgcn_s_sleep(1);
+                    continue;
+                }
+                earlier += w & kValueMask;
+                if (w & kFlagPrefix) break;
+                --p;
+            }
+            __hip_atomic_store(mine, ((earlier + total) & kValueMask) | kFlagPrefix, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    } else {
+        earlier = hist[(size_t)t * num_tiles + tile];
+    }
+    gofs[t] = (gwave_off + gv - gt) + earlier - local_start;
     __syncthreads();
 
 #pragma unroll
@@ -193,24 +249,55 @@ __global__ __launch_bounds__(kSortThreads) void radix_scatter_kernel(const uint3
 
 // res_keys / res_vals (nullable): when given, the result is NOT copied back after an odd number of
 // passes; instead they receive the buffers that hold it (keys/vals or the scratch ping-pong).
+// 0 = hist + rowscan + scatter (default), 1 = onesweep (cpm_debug_set_sort_mode).  Measured on MI355X at 1 M pairs:
+// 20 us per pass for the three short launches vs 39 us for the single onesweep launch (+25 us for its
+// global histogram): with all ~1000 tiles in flight at once the per-digit look-back chain is long.
+static int g_sort_mode = 0;
+
 template <int ITEMS>
 static int sort_passes(cpm_ctx* ctx, uint32_t* keys, uint32_t* vals, uint32_t n, int key_bits, hipStream_t s,
                        uint32_t** res_keys, uint32_t** res_vals) {
     const uint32_t tile = kSortThreads * ITEMS;
     const uint32_t num_tiles = (n + tile - 1) / tile;
+    const int passes = (key_bits + kRadixBits - 1) / kRadixBits;
+    const bool onesweep = g_sort_mode == 1 && passes <= 4;
     uint32_t* k2 = (uint32_t*)scratch(ctx, CPM_SCR_SORT_KEYS, (size_t)n * 4);
     uint32_t* v2 = vals ? (uint32_t*)scratch(ctx, CPM_SCR_SORT_VALS, (size_t)n * 4) : nullptr;
-    uint32_t* hist = (uint32_t*)scratch(ctx, CPM_SCR_SORT_HIST, ((size_t)kRadix * num_tiles + kRadix) * 4);
-    if (!k2 || (vals && !v2) || !hist) return CPM_ERR_OUT_OF_MEMORY;
-    uint32_t* digit_total = hist + (size_t)kRadix * num_tiles;
+    // control block: [error | tickets[4] | pad | ghist[4][256] | status[passes][tiles][256]]  or  hist[256][tiles] + totals
+    const size_t ctl_words = 8 + 4 * (size_t)kRadix + (size_t)(onesweep ? passes : 1) * num_tiles * kRadix + kRadix;
+    uint32_t* ctl = (uint32_t*)scratch(ctx, CPM_SCR_SORT_HIST, ctl_words * 4);
+    if (!k2 || (vals && !v2) || !ctl) return CPM_ERR_OUT_OF_MEMORY;
+    uint32_t* error = ctl;
+    uint32_t* tickets = ctl + 1;
+    uint32_t* ghist = ctl + 8;
+    uint32_t* status = ghist + 4 * kRadix;       // onesweep: per pass [tiles][256]; else: hist[256][tiles]
+    uint32_t* digit_total = status + (size_t)num_tiles * kRadix;  // non-onesweep only
     uint32_t *ks = keys, *kd = k2, *vs = vals, *vd = v2;
-    for (int shift = 0; shift < key_bits; shift += kRadixBits) {
-        CPM_LAUNCH(ctx, radix_hist_kernel<ITEMS>, dim3(num_tiles), dim3(kSortThreads), 0, s, ks, n, shift, hist, num_tiles);
-        CPM_LAUNCH(ctx, radix_rowscan_kernel, dim3(kRadix), dim3(kSortThreads), 0, s, hist, num_tiles, digit_total);
-        if (vals)
-            CPM_LAUNCH(ctx, (radix_scatter_kernel<ITEMS, true>), dim3(num_tiles), dim3(kSortThreads), 0, s, ks, vs, kd, vd, n, shift, hist, digit_total, num_tiles);
-        else
-            CPM_LAUNCH(ctx, (radix_scatter_kernel<ITEMS, false>), dim3(num_tiles), dim3(kSortThreads), 0, s, ks, nullptr, kd, nullptr, n, shift, hist, digit_total, num_tiles);
+    if (onesweep) {
+        CPM_HIP_CHECK(ctx, hipMemsetAsync(ctl, 0, (8 + 4 * (size_t)kRadix + (size_t)passes * num_tiles * kRadix) * 4, s));
+        const int hist_blocks = (int)(num_tiles < 1024u ? num_tiles : 1024u);
+        CPM_LAUNCH(ctx, radix_global_hist_kernel, dim3(hist_blocks), dim3(kSortThreads), 0, s, ks, n, passes, ghist);
+    }
+    for (int p = 0; p < passes; ++p) {
+        const int shift = p * kRadixBits;
+        if (onesweep) {
+            uint32_t* st = status + (size_t)p * num_tiles * kRadix;
+            if (vals)
+                CPM_LAUNCH(ctx, (radix_scatter_kernel<ITEMS, true, true>), dim3(num_tiles), dim3(kSortThreads), 0, s, ks, vs, kd, vd, n, shift,
+                           nullptr, ghist + p * kRadix, num_tiles, tickets + p, st, error);
+            else
+                CPM_LAUNCH(ctx, (radix_scatter_kernel<ITEMS, false, true>), dim3(num_tiles), dim3(kSortThreads), 0, s, ks, nullptr, kd, nullptr, n,
+                           shift, nullptr, ghist + p * kRadix, num_tiles, tickets + p, st, error);
+        } else {
+            CPM_LAUNCH(ctx, radix_hist_kernel<ITEMS>, dim3(num_tiles), dim3(kSortThreads), 0, s, ks, n, shift, status, num_tiles);
+            CPM_LAUNCH(ctx, radix_rowscan_kernel, dim3(kRadix), dim3(kSortThreads), 0, s, status, num_tiles, digit_total);
+            if (vals)
+                CPM_LAUNCH(ctx, (radix_scatter_kernel<ITEMS, true, false>), dim3(num_tiles), dim3(kSortThreads), 0, s, ks, vs, kd, vd, n, shift,
+                           status, digit_total, num_tiles, nullptr, nullptr, nullptr);
+            else
+                CPM_LAUNCH(ctx, (radix_scatter_kernel<ITEMS, false, false>), dim3(num_tiles), dim3(kSortThreads), 0, s, ks, nullptr, kd, nullptr, n,
+                           shift, status, digit_total, num_tiles, nullptr, nullptr, nullptr);
+        }
         CPM_LAUNCH_CHECK(ctx, "radix sort pass");
         uint32_t* tmp = ks; ks = kd; kd = tmp;
         tmp = vs; vs = vd; vd = tmp;
@@ -244,6 +331,9 @@ int radix_sort(cpm_ctx* ctx, uint32_t* keys, uint32_t* vals, size_t n, int key_b
 }  // namespace cpm
 
 extern "C" {
+
+// test / measurement hook (include/cpm/cpm_profile.h): 0 = hist + rowscan + scatter (default), 1 = onesweep passes
+void cpm_debug_set_sort_mode(int mode) { cpm::g_sort_mode = mode; }
 
 int cpm_sort_pairs(cpm_ctx* ctx, uint32_t* keys, uint32_t* values, size_t n, int key_bits, cpm_stream stream) {
     if (!ctx) return CPM_ERR_INVALID_ARGUMENT;

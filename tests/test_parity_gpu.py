@@ -548,3 +548,25 @@ def test_frame_graph_replay_equals_eager(ctx, cpm):
         fr.replay()
     ctx.torch.cuda.synchronize()
     assert ctx.torch.equal(fr.light_volume, eager) and ctx.torch.equal(fr.photons, photons)
+
+
+@pytest.mark.parametrize("mode", [1, 0])
+@pytest.mark.parametrize("n,bits_", [(5, 32), (1023, 8), (1024, 9), (70_001, 22), (1 << 20, 22), (3_000_017, 31), (1 << 20, 32)])
+def test_sort_pass_structures(ctx, mode, n, bits_):
+    """Both pass structures -- onesweep (ticketed tiles + decoupled look-back, one launch per pass) and
+    hist + rowscan + scatter -- give the stable ascending order, including skewed digit distributions."""
+    rng = np.random.default_rng(n + bits_)
+    keys = rng.integers(0, 1 << bits_, n, dtype=np.uint64).astype(np.uint32)
+    keys[: n // 3] &= np.uint32(0xFF00FF)            # few distinct digits in some passes
+    keys[n // 2:] = np.sort(keys[n // 2:])           # long presorted run: whole tiles with one digit
+    vals = np.arange(n, dtype=np.uint32)
+    ctx.lib.cpm_debug_set_sort_mode(mode)
+    try:
+        for rep in range(3):                         # repeated: scratch reuse, look-back state reset
+            kd, vd = _t(ctx, keys), _t(ctx, vals)
+            ctx.sort_pairs(kd, vd, bits_)
+            order = np.argsort(keys & np.uint32((1 << bits_) - 1 if bits_ < 32 else 0xFFFFFFFF), kind="stable")
+            assert np.array_equal(_n(vd, np.uint32), vals[order])
+            assert np.array_equal(_n(kd, np.uint32), keys[order])
+    finally:
+        ctx.lib.cpm_debug_set_sort_mode(0)
