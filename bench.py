@@ -215,7 +215,7 @@ def main():
         stages = {"trace": stage(["trace_kernel"]),
                   "bin": stage(["bin_", "radix_", "cell_start"]),
                   "gather": stage(["gather_kernel"])}
-        tile = 256 * (4 if n_rank <= (1 << 21) else 8 if n_rank <= (1 << 23) else 16)
+        tile = 256 * (4 if n_rank <= (1 << 15) else 8 if n_rank <= (1 << 23) else 16)
         tiles = -(-n_rank // tile)
         key_bits = int(gdim ** 3).bit_length()
         passes = -(-key_bits // 8)

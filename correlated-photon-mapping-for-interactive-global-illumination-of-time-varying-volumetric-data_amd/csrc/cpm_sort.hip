@@ -253,6 +253,7 @@ __global__ __launch_bounds__(kSortThreads) void radix_scatter_kernel(const uint3
 // 20 us per pass for the three short launches vs 39 us for the single onesweep launch (+25 us for its
 // global histogram): with all ~1000 tiles in flight at once the per-digit look-back chain is long.
 static int g_sort_mode = 0;
+static int g_sort_items = 0;  // 0 = by size; 8 / 16 force the tile size (tuning hook)
 
 template <int ITEMS>
 static int sort_passes(cpm_ctx* ctx, uint32_t* keys, uint32_t* vals, uint32_t n, int key_bits, hipStream_t s,
@@ -322,9 +323,12 @@ int radix_sort(cpm_ctx* ctx, uint32_t* keys, uint32_t* vals, size_t n, int key_b
     if (n <= 1) return CPM_OK;
     if (n >= (1ull << 31)) return set_error(ctx, CPM_ERR_INVALID_ARGUMENT, "radix_sort", "n must be < 2^31");
     if (key_bits <= 0 || key_bits > 32) key_bits = 32;
-    // enough workgroups to cover 256 CUs several times over at small n
-    if (n <= (1u << 21)) return sort_passes<4>(ctx, keys, vals, (uint32_t)n, key_bits, s, res_keys, res_vals);
-    if (n <= (1u << 23)) return sort_passes<8>(ctx, keys, vals, (uint32_t)n, key_bits, s, res_keys, res_vals);
+    if (g_sort_items == 4) return sort_passes<4>(ctx, keys, vals, (uint32_t)n, key_bits, s, res_keys, res_vals);
+    if (g_sort_items == 16) return sort_passes<16>(ctx, keys, vals, (uint32_t)n, key_bits, s, res_keys, res_vals);
+    // tile = 256 threads x ITEMS keys.  Measured at 1 M pairs, 22 key bits (3 passes + copy-back):
+    // ITEMS 4: 73 us, 8: 61 us, 16: 70 us -- 2048-key tiles balance table size against workgroup count.
+    if (n <= (1u << 15)) return sort_passes<4>(ctx, keys, vals, (uint32_t)n, key_bits, s, res_keys, res_vals);
+    if (n <= (1u << 23) || g_sort_items == 8) return sort_passes<8>(ctx, keys, vals, (uint32_t)n, key_bits, s, res_keys, res_vals);
     return sort_passes<16>(ctx, keys, vals, (uint32_t)n, key_bits, s, res_keys, res_vals);
 }
 
@@ -334,6 +338,7 @@ extern "C" {
 
 // test / measurement hook (include/cpm/cpm_profile.h): 0 = hist + rowscan + scatter (default), 1 = onesweep passes
 void cpm_debug_set_sort_mode(int mode) { cpm::g_sort_mode = mode; }
+void cpm_debug_set_sort_items(int items) { cpm::g_sort_items = items; }
 
 int cpm_sort_pairs(cpm_ctx* ctx, uint32_t* keys, uint32_t* values, size_t n, int key_bits, cpm_stream stream) {
     if (!ctx) return CPM_ERR_INVALID_ARGUMENT;
