@@ -100,6 +100,23 @@ def cpu_baseline(workload, vol_np, tf, n_lattice, grid_dim, light_dir):
     }
 
 
+def pmc_traffic(kernel):
+    """L2<->fabric bytes per launch of `kernel` from the newest committed PMC summary (profiles/*pmc_traffic.json,
+    written by tools/profile_round.sh: separate FETCH_SIZE / WRITE_SIZE passes, gfx950 corrections applied).
+    PMC counters cannot be collected from inside this process, so the figure is the committed measurement of the
+    same command; None when no summary exists for the workload's dominant kernel."""
+    import glob
+    files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "*pmc_traffic.json")))
+    for f in reversed(files):
+        try:
+            k = json.load(open(f))["kernels"].get(kernel)
+        except (OSError, ValueError, KeyError):
+            continue
+        if k:
+            return int(k["traffic_bytes"]), "profiles/" + os.path.basename(f)
+    return None, None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -108,6 +125,8 @@ def main():
     ap.add_argument("--workload", default="config2", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--splat", action="store_true", help="also time the reference formulation (atomic splat)")
+    ap.add_argument("--streams", type=int, default=4,
+                    help="frames in flight for the extra 'pipelined' figure (0 = skip it); 'value' is always one stream")
     ap.add_argument("--graph", action="store_true",
                     help="replay a captured HIP graph of the frame instead of eager launches (measured slower here: 0.299 vs 0.251 ms)")
     args = ap.parse_args()
@@ -191,6 +210,31 @@ def main():
     ctx.set_step_counter(None)
     woodcock_steps = int(counter.item())
 
+    # ---- extra figure (never `value`): S independent frames in flight on S streams.  The kernels of one
+    # 1 M-photon frame are latency-bound, so frames of different time steps / progressive
+    # batches overlap; each frame owns its context, buffers and stream.
+    pipelined = None
+    if world == 1 and args.streams > 1:
+        ctxs = [B.Context(local_rank) for _ in range(args.streams)]
+        frames = [P.PhotonFrame(c, vol_np, tf, (nx, ny), (gdim,) * 3, light_travel_direction=light_dir) for c in ctxs]
+        streams = [torch.cuda.Stream() for _ in range(args.streams)]
+        rounds = max(1, args.steps // args.streams)
+        for it in range(rounds + 2):
+            if it == 2:
+                torch.cuda.synchronize()
+                tp = time.perf_counter()
+            for f, st in zip(frames, streams):
+                with torch.cuda.stream(st):
+                    f.trace(); f.bin(); f.gather()
+        torch.cuda.synchronize()
+        dtp = time.perf_counter() - tp
+        same = all(bool(torch.equal(f.light_volume, fr.light_volume)) for f in frames)
+        pipelined = {"streams": args.streams, "frames": rounds * args.streams,
+                     "value": round(rounds * args.streams * n_rank / dtp / 1e6, 2), "unit": "Mphotons/s",
+                     "ms_per_frame": round(dtp / (rounds * args.streams) * 1e3, 4),
+                     "light_volumes_identical_to_single_stream": same}
+        del frames, ctxs
+
     splat_ms = None
     if args.splat:
         tmp = torch.zeros_like(fr.light_volume)
@@ -214,7 +258,7 @@ def main():
 
         stages = {"trace": stage(["trace_kernel"]),
                   "bin": stage(["bin_", "radix_", "cell_start"]),
-                  "gather": stage(["gather_kernel"])}
+                  "gather": stage(["gather"])}
         tile = 256 * (4 if n_rank <= (1 << 15) else 8 if n_rank <= (1 << 23) else 16)
         tiles = -(-n_rank // tile)
         key_bits = int(gdim ** 3).bit_length()
@@ -228,6 +272,7 @@ def main():
         achieved = ab[dom_base] / (dom_avg_ms * 1e-3) / 1e9
         frame_bytes = (ab["trace_kernel"] + ab["bin_keys_kernel"] + passes * (ab["radix_hist_kernel"] + ab["radix_rowscan_kernel"] + ab["radix_scatter_kernel"])
                        + ab["bin_finalize_kernel"] + ab["cell_start_kernel"] + ab["gather_kernel"])
+        traffic, traffic_src = pmc_traffic(dom.split("<")[0])
         out = {
             "metric": "Mphotons/s traced+binned+gathered",
             "value": round(value, 2), "unit": "Mphotons/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -240,7 +285,7 @@ def main():
                        "parallelism": f"photon-sharded x{world}, one RCCL all-reduce of the grid per frame" if world > 1 else "single GPU",
                        "launch": "captured HIP graph replay" if use_graph else "eager launches"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": ab[dom_base], "avg_launch_ms": round(dom_avg_ms, 5),
                          "launches_per_frame": round(per_frame[dom][1], 2)},
             "frame": {"kernel_ms_per_frame": {k: round(v[0], 5) for k, v in sorted(per_frame.items(), key=lambda kv: -kv[1][0])},
@@ -250,6 +295,8 @@ def main():
                       "woodcock_steps_per_frame": woodcock_steps,
                       "gsamples_per_s": round(woodcock_steps / max(stages["trace"], 1e-9) / 1e6, 3)},
         }
+        if pipelined is not None:
+            out["pipelined"] = pipelined
         if splat_ms is not None:
             out["frame"]["reference_formulation_splat_ms"] = round(splat_ms, 4)
         if world == 1 and not args.no_cpu_baseline:

@@ -121,6 +121,7 @@ def load_library() -> C.CDLL:
         "cpm_debug_set_gather_stamps": (None, [vp]),
         "cpm_debug_force_voxel_gather": (None, [i32]),
         "cpm_debug_set_sort_mode": (None, [i32]),
+        "cpm_debug_set_sort_items": (None, [i32]),
         "cpm_profile_enable": (None, [vp, i32]),
         "cpm_profile_reset": (None, [vp]),
         "cpm_profile_collect": (i32, [vp]),

@@ -27,6 +27,8 @@ void cpm_debug_set_gather_stamps(unsigned long long* dev_stamps);
 void cpm_debug_force_voxel_gather(int on);
 /* test hook: radix sort pass structure: 0 = hist + rowscan + scatter (default), 1 = onesweep (one launch per pass) */
 void cpm_debug_set_sort_mode(int mode);
+/* radix tile: 0 = by size, 4 / 8 / 16 = keys per thread (256-thread tiles) */
+void cpm_debug_set_sort_items(int items);
 #ifdef __cplusplus
 }
 #endif
