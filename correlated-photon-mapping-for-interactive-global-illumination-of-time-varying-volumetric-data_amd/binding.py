@@ -26,6 +26,7 @@ ABI_SYMBOLS = [
     "cpm_create", "cpm_destroy", "cpm_last_error_string", "cpm_abi_version",
     "cpm_glibc_rand_sequence", "cpm_seed_streams", "cpm_random_fill",
     "cpm_volume_desc_default", "cpm_volume_create", "cpm_volume_update", "cpm_volume_destroy",
+    "cpm_volume_device_data", "cpm_volume_download",
     "cpm_tf_create", "cpm_tf_update", "cpm_tf_destroy",
     "cpm_uniform_samples_2d", "cpm_directional_light_samples", "cpm_point_light_samples",
     "cpm_light_sample_box_intersection", "cpm_light_sample_mesh_intersection",
@@ -36,7 +37,11 @@ ABI_SYMBOLS = [
     "cpm_volume_minmax", "cpm_volume_difference", "cpm_importance_tf",
     "cpm_photon_importance", "cpm_photon_importance_equal", "cpm_reset_importance",
     "cpm_select_recompute",
+    "cpm_mix_buffers", "cpm_volume_mix",
 ]
+
+
+CPM_MIX_F32, CPM_MIX_U16X2 = 0, 1
 
 
 class VolumeDesc(C.Structure):
@@ -116,12 +121,17 @@ def load_library() -> C.CDLL:
         "cpm_photon_importance_equal": (i32, [vp, i32, i32, i32, i32, vp, vp]),
         "cpm_reset_importance": (i32, [vp, vp, sz, sz, vp]),
         "cpm_select_recompute": (i32, [vp, vp, sz, vp, vp, vp]),
+        "cpm_mix_buffers": (i32, [vp, vp, vp, f32, sz, i32, vp, vp]),
+        "cpm_volume_mix": (i32, [vp, vp, vp, f32, vp, vp]),
+        "cpm_volume_device_data": (vp, [vp, P(sz)]),
+        "cpm_volume_download": (i32, [vp, vp, vp, vp]),
         # include/cpm/cpm_profile.h (measurement hooks)
         "cpm_debug_set_step_counter": (None, [vp]),
         "cpm_debug_set_gather_stamps": (None, [vp]),
         "cpm_debug_force_voxel_gather": (None, [i32]),
         "cpm_debug_set_sort_mode": (None, [i32]),
         "cpm_debug_set_sort_items": (None, [i32]),
+        "cpm_debug_set_stream_wg_per_cu": (None, [i32]),
         "cpm_profile_enable": (None, [vp, i32]),
         "cpm_profile_reset": (None, [vp]),
         "cpm_profile_collect": (i32, [vp]),
@@ -348,6 +358,17 @@ class Context:
         self._check(self.lib.cpm_gather(self.h, self._ptr(sorted_pos_power), self._ptr(cell_start), n, C.byref(grid), radius,
                                         scale, int(accumulate), self._ptr(out), self._stream()))
 
+    # -- temporal interpolation
+    def mix_buffers(self, x, y, a, out, kind=None):
+        """out = mix(x, y, a); float32 tensors, or (n, 2) uint16 min/max pairs (passed as int16/uint16 tensors)."""
+        if kind is None:
+            kind = CPM_MIX_F32 if x.dtype == self.torch.float32 else CPM_MIX_U16X2
+        n = x.numel() if kind == CPM_MIX_F32 else x.numel() // 2
+        self._check(self.lib.cpm_mix_buffers(self.h, self._ptr(x), self._ptr(y), float(a), n, kind, self._ptr(out), self._stream()))
+
+    def volume_mix(self, v0, v1, weight, out):
+        self._check(self.lib.cpm_volume_mix(self.h, v0.h, v1.h, float(weight), out.h, self._stream()))
+
     # -- correlated
     def volume_minmax(self, vol, region, out):
         self._check(self.lib.cpm_volume_minmax(self.h, vol.h, region, self._ptr(out), self._stream()))
@@ -401,6 +422,14 @@ class Volume:
         else:
             ptr, is_dev = self.ctx._ptr(voxels), 1
         self.ctx._check(self.ctx.lib.cpm_volume_update(self.ctx.h, self.h, ptr, is_dev, self.ctx._stream()))
+
+    def download(self):
+        """Voxels as a numpy array [z, y, x] (blocking device -> host copy)."""
+        import numpy as np
+        dt = {0: np.uint8, 1: np.uint16, 2: np.float32}[int(self.desc.dtype)]
+        out = np.empty(tuple(self.desc.dims)[::-1], dtype=dt)
+        self.ctx._check(self.ctx.lib.cpm_volume_download(self.ctx.h, self.h, C.c_void_p(out.ctypes.data), self.ctx._stream()))
+        return out
 
     def __del__(self):
         try:

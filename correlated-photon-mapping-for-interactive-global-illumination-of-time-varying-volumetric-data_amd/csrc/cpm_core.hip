@@ -221,6 +221,21 @@ int cpm_volume_update(cpm_ctx* ctx, cpm_volume* vol, const void* voxels, int is_
     return CPM_OK;
 }
 
+void* cpm_volume_device_data(const cpm_volume* vol, size_t* bytes) {
+    if (!vol) return nullptr;
+    if (bytes) *bytes = vol->bytes;
+    return vol->voxels;
+}
+
+int cpm_volume_download(cpm_ctx* ctx, const cpm_volume* vol, void* voxels_host, cpm_stream stream) {
+    if (!ctx) return CPM_ERR_INVALID_ARGUMENT;
+    CPM_REQUIRE(ctx, vol && voxels_host, "cpm_volume_download: null argument");
+    hipStream_t s = (hipStream_t)stream;
+    CPM_HIP_CHECK(ctx, hipMemcpyAsync(voxels_host, vol->voxels, vol->bytes, hipMemcpyDeviceToHost, s));
+    CPM_HIP_CHECK(ctx, hipStreamSynchronize(s));
+    return CPM_OK;
+}
+
 void cpm_volume_destroy(cpm_ctx* ctx, cpm_volume* vol) {
     (void)ctx;
     if (!vol) return;

@@ -115,6 +115,11 @@ int cpm_volume_create(cpm_ctx* ctx, const cpm_volume_desc* desc, const void* vox
 int cpm_volume_update(cpm_ctx* ctx, cpm_volume* vol, const void* voxels, int voxels_is_device,
                       cpm_stream stream);
 void cpm_volume_destroy(cpm_ctx* ctx, cpm_volume* vol);
+/* Device address and byte size of the voxel block (for consumers that read a volume produced on
+ * the device, e.g. cpm_volume_mix's output); and a blocking device->host copy of it
+ * (Volume::getRepresentation<VolumeRAM>() of a volume whose valid representation is the device one). */
+void* cpm_volume_device_data(const cpm_volume* vol, size_t* bytes);
+int cpm_volume_download(cpm_ctx* ctx, const cpm_volume* vol, void* voxels_host, cpm_stream stream);
 
 /* Transfer function LUT: `width` RGBA32F texels (Inviwo: 1024x1 layer,
  * ref photontracercl.cpp:118).  The tracer reads only alpha. */
@@ -325,6 +330,29 @@ int cpm_reset_importance(cpm_ctx* ctx, uint32_t* importances, size_t offset, siz
  *  processor/progressivephotontracercl.cpp:325-363,689-706,727-741). */
 int cpm_select_recompute(cpm_ctx* ctx, uint32_t* importances, size_t n, uint32_t* indices_out,
                          int32_t* n_changed_dev, cpm_stream stream);
+
+/* ------------------------------------------------------------------ temporal interpolation (time-varying data) */
+
+typedef enum cpm_mix_type { CPM_MIX_F32 = 0, CPM_MIX_U16X2 = 1 } cpm_mix_type;
+
+/* out[i] = mix(x[i], y[i], a) = x + (y - x) * a over device buffers (16-byte aligned).
+ * CPM_MIX_F32: n_elements floats (any float/floatN grid).  CPM_MIX_U16X2: n_elements
+ * (min, max) pairs of a MinMaxUniformGrid3D; integer vector formats go through
+ * convert_float2 / convert_ushort2 (round toward zero) as BufferMixerCL compiles them.
+ * Replaces mixKernel (ref uniformgridcl/cl/buffermixer.cl:37-48; uniformgridcl/buffermixercl.cpp:47-92,230-243)
+ * as used by UniformGrid3DPlayerProcessor::process
+ * (ref uniformgridcl/processors/uniformgrid3dplayerprocessor.cpp:87-115). */
+int cpm_mix_buffers(cpm_ctx* ctx, const void* x, const void* y, float a, size_t n_elements,
+                    int type, void* out, cpm_stream stream);
+
+/* out = mix of two time steps of a volume sequence, voxel by voxel:
+ * normalised values (v / 255, v / 65535, or the float itself) mixed as x * (1 - w) + y * w,
+ * stored back in the same format (normalised integers: clamp, scale, round to nearest).
+ * `out` is a volume of the same desc (it may alias neither input).
+ * Replaces VolumeSequencePlayer::process + glsl/volume_mix.frag
+ * (ref uniformgridcl/processors/volumesequenceplayer.cpp:87-140; uniformgridcl/glsl/volume_mix.frag:42-52). */
+int cpm_volume_mix(cpm_ctx* ctx, const cpm_volume* v0, const cpm_volume* v1, float weight,
+                   cpm_volume* out, cpm_stream stream);
 
 #ifdef __cplusplus
 }

@@ -29,6 +29,8 @@ void cpm_debug_force_voxel_gather(int on);
 void cpm_debug_set_sort_mode(int mode);
 /* radix tile: 0 = by size, 4 / 8 / 16 = keys per thread (256-thread tiles) */
 void cpm_debug_set_sort_items(int items);
+/* streaming kernels (temporal mix): workgroups per CU; 0 = one vector per lane, -1 = by size (default) */
+void cpm_debug_set_stream_wg_per_cu(int n);
 #ifdef __cplusplus
 }
 #endif

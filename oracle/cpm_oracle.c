@@ -1013,3 +1013,45 @@ void cpmo_select_recompute(uint32_t* importances, size_t n, uint32_t* indices_ou
     cpmo_sort_pairs(importances, indices_out, n, 32);
     *n_changed = cnt;
 }
+
+/* ---------------------------------------------------------------------------------------------
+ * temporal interpolation */
+
+/* uniformgridcl/cl/buffermixer.cl:37-48 with MIX_T float: out = mix(x, y, a) = x + (y - x) * a */
+void cpmo_mix_f32(const float* x, const float* y, float a, size_t n, float* out) {
+    for (size_t i = 0; i < n; ++i) out[i] = x[i] + (y[i] - x[i]) * a;
+}
+
+/* the same kernel as BufferMixerCL::compileKernel builds it for Vec2UINT16 (buffermixercl.cpp:235-239):
+ * convert_ushort2(mix(convert_float2(x), convert_float2(y), a)); float -> integer conversion rounds
+ * toward zero (OpenCL 1.2 section 6.2.3.3) */
+void cpmo_mix_u16x2(const uint16_t* x, const uint16_t* y, float a, size_t n_pairs, uint16_t* out) {
+    for (size_t i = 0; i < 2 * n_pairs; ++i) {
+        float fx = (float)x[i], fy = (float)y[i];
+        float r = fx + (fy - fx) * a;
+        out[i] = (uint16_t)(int)r;
+    }
+}
+
+/* uniformgridcl/glsl/volume_mix.frag:42-52 driven by volumesequenceplayer.cpp:87-140: texture() of a
+ * normalised integer format yields v / (2^b - 1); GLSL mix(x, y, a) = x * (1 - a) + y * a; the colour
+ * attachment of the same format stores round(clamp(f, 0, 1) * (2^b - 1)) (nearest, ties to even). */
+void cpmo_volume_mix(const cpmo_volume* v0, const cpmo_volume* v1, float weight, void* out_voxels) {
+    size_t n = (size_t)v0->dims[0] * v0->dims[1] * v0->dims[2];
+    float oma = 1.0f - weight;
+    for (size_t i = 0; i < n; ++i) {
+        if (v0->dtype == CPMO_F32) {
+            float x = ((const float*)v0->voxels)[i], y = ((const float*)v1->voxels)[i];
+            ((float*)out_voxels)[i] = x * oma + y * weight;
+        } else {
+            float maxv = v0->dtype == CPMO_U8 ? 255.0f : 65535.0f;
+            float x = v0->dtype == CPMO_U8 ? (float)((const uint8_t*)v0->voxels)[i] : (float)((const uint16_t*)v0->voxels)[i];
+            float y = v0->dtype == CPMO_U8 ? (float)((const uint8_t*)v1->voxels)[i] : (float)((const uint16_t*)v1->voxels)[i];
+            float r = (x / maxv) * oma + (y / maxv) * weight;
+            r = om_min(om_max(r, 0.0f), 1.0f);
+            int q = (int)rintf(r * maxv);
+            if (v0->dtype == CPMO_U8) ((uint8_t*)out_voxels)[i] = (uint8_t)q;
+            else ((uint16_t*)out_voxels)[i] = (uint16_t)q;
+        }
+    }
+}

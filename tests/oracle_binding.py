@@ -236,6 +236,24 @@ class Oracle:
         self.lib.cpmo_gather(_p(sorted_pp), _p(cell_start), n, C.byref(grid), C.c_float(radius), C.c_float(scale),
                              int(accumulate), _p(out))
 
+    # ---- temporal interpolation
+    def mix_f32(self, x, y, a):
+        x = np.ascontiguousarray(x, np.float32); y = np.ascontiguousarray(y, np.float32)
+        out = np.empty_like(x)
+        self.lib.cpmo_mix_f32(_p(x), _p(y), C.c_float(a), C.c_size_t(x.size), _p(out))
+        return out
+
+    def mix_u16x2(self, x, y, a):
+        x = np.ascontiguousarray(x, np.uint16); y = np.ascontiguousarray(y, np.uint16)
+        out = np.empty_like(x)
+        self.lib.cpmo_mix_u16x2(_p(x), _p(y), C.c_float(a), C.c_size_t(x.size // 2), _p(out))
+        return out
+
+    def volume_mix(self, a: OVolume, b: OVolume, weight, like):
+        out = np.empty_like(like)
+        self.lib.cpmo_volume_mix(C.byref(a), C.byref(b), C.c_float(weight), _p(out))
+        return out
+
     # ---- correlated
     def volume_minmax(self, vol: OVolume, region):
         o = [(vol.dims[a] + region - 1) // region for a in range(3)]

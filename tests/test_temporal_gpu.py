@@ -1,0 +1,93 @@
+"""Temporal interpolation between time steps (mixKernel / volume_mix.frag) against the oracle, on the GPU."""
+import numpy as np
+import pytest
+
+from test_parity_gpu import _t, _n, bits
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("n", [0, 1, 3, 4, 1023, 262144 + 5])
+@pytest.mark.parametrize("a", [0.0, 0.37, 1.0])
+def test_mix_f32(ctx, oracle, n, a):
+    rng = np.random.default_rng(n)
+    x = (rng.standard_normal(n) * 10).astype(np.float32)
+    y = (rng.standard_normal(n) * 10).astype(np.float32)
+    xd, yd = _t(ctx, x), _t(ctx, y)
+    out = ctx.torch.full((n,), -1.0, dtype=ctx.torch.float32, device=ctx.device)
+    ctx.mix_buffers(xd, yd, a, out)
+    assert np.array_equal(bits(_n(out)), bits(oracle.mix_f32(x, y, a)))
+    if a == 0.0:
+        assert np.array_equal(_n(out), x)  # x + (y - x) * 0
+
+
+@pytest.mark.parametrize("n_pairs", [1, 5, 4096, 32 * 32 * 32 + 3])
+@pytest.mark.parametrize("a", [0.0, 0.25, 0.999, 1.0])
+def test_mix_minmax_grid(ctx, oracle, n_pairs, a):
+    """MinMaxUniformGrid3D (Vec2UINT16) through convert_float2 / convert_ushort2 (round toward zero)."""
+    rng = np.random.default_rng(n_pairs)
+    x = rng.integers(0, 65536, (n_pairs, 2)).astype(np.uint16)
+    y = rng.integers(0, 65536, (n_pairs, 2)).astype(np.uint16)
+    x[0], y[0] = (0, 65535), (65535, 0)
+    xd = _t(ctx, x.view(np.int16))
+    yd = _t(ctx, y.view(np.int16))
+    out = ctx.torch.zeros((n_pairs, 2), dtype=ctx.torch.int16, device=ctx.device)
+    ctx.mix_buffers(xd, yd, a, out)
+    want = oracle.mix_u16x2(x, y, a)
+    assert np.array_equal(_n(out, np.uint16), want)
+    if a == 0.0:
+        assert np.array_equal(want, x)
+
+
+@pytest.mark.parametrize("shape,dtype", [((32, 32, 32), np.uint8), ((7, 9, 11), np.uint8), ((16, 20, 24), np.uint16),
+                                          ((12, 12, 12), np.float32)])
+@pytest.mark.parametrize("w", [0.0, 0.5, 0.3125, 1.0])
+def test_volume_mix(ctx, oracle, shape, dtype, w):
+    rng = np.random.default_rng(sum(shape))
+    if dtype == np.float32:
+        a, b = rng.random(shape, dtype=np.float32), rng.random(shape, dtype=np.float32)
+    else:
+        hi = np.iinfo(dtype).max + 1
+        a, b = rng.integers(0, hi, shape).astype(dtype), rng.integers(0, hi, shape).astype(dtype)
+    va, vb, vo = ctx.volume_create(a), ctx.volume_create(b), ctx.volume_create(np.zeros_like(a))
+    ctx.volume_mix(va, vb, w, vo)
+    got = vo.download()
+    want = oracle.volume_mix(oracle.volume(a), oracle.volume(b), w, a)
+    assert np.array_equal(got.view(np.uint8), want.view(np.uint8))
+    if w == 0.0 and dtype != np.float32:
+        assert np.array_equal(got, a)  # v/255 * 1 + y * 0 -> rint(v/255 * 255) == v
+    if w == 1.0 and dtype != np.float32:
+        assert np.array_equal(got, b)
+
+
+def test_volume_mix_full_size_properties(ctx, cpm):
+    """Config 5 size (256^3 u8): the mix is monotone in w voxel by voxel and stays between its inputs."""
+    S = cpm.synthetic
+    a = S.heterogeneous_volume(256, S.sequence_blob_center(3))
+    b = S.heterogeneous_volume(256, S.sequence_blob_center(4))
+    va, vb, vo = ctx.volume_create(a), ctx.volume_create(b), ctx.volume_create(np.zeros_like(a))
+    lo, hi = np.minimum(a, b), np.maximum(a, b)
+    prev = None
+    for w in (0.0, 0.25, 0.5, 0.75, 1.0):
+        ctx.volume_mix(va, vb, w, vo)
+        got = vo.download()
+        assert (got >= lo).all() and (got <= hi).all()
+        if prev is not None:
+            d0 = got.astype(np.int16) - prev.astype(np.int16)
+            sign = np.sign(b.astype(np.int16) - a.astype(np.int16))
+            assert (d0 * sign >= 0).all()
+        prev = got
+    assert np.array_equal(prev, b)
+
+
+def test_mix_errors(ctx, cpm):
+    t = ctx.torch
+    x = t.zeros(16, dtype=t.float32, device=ctx.device)
+    with pytest.raises(cpm.binding.CpmError):
+        ctx.mix_buffers(x, x, 0.5, x, kind=7)
+    with pytest.raises(cpm.binding.CpmError):
+        ctx.mix_buffers(x[1:], x[1:], 0.5, x[1:])  # not 16-byte aligned
+    a = ctx.volume_create(np.zeros((4, 4, 4), np.uint8))
+    b = ctx.volume_create(np.zeros((4, 4, 8), np.uint8))
+    with pytest.raises(cpm.binding.CpmError):
+        ctx.volume_mix(a, b, 0.5, a)
