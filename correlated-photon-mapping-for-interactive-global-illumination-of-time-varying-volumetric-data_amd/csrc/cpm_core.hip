@@ -192,7 +192,7 @@ static size_t dtype_size(int dtype) { return dtype == CPM_U8 ? 1 : (dtype == CPM
 int cpm_volume_create(cpm_ctx* ctx, const cpm_volume_desc* desc, const void* voxels, int is_device,
                       cpm_stream stream, cpm_volume** out) {
     if (!ctx) return CPM_ERR_INVALID_ARGUMENT;
-    CPM_REQUIRE(ctx, desc && voxels && out, "cpm_volume_create: null argument");
+    CPM_REQUIRE(ctx, desc && out, "cpm_volume_create: null argument");
     CPM_REQUIRE(ctx, desc->dtype >= CPM_U8 && desc->dtype <= CPM_F32, "cpm_volume_create: dtype");
     CPM_REQUIRE(ctx, desc->dims[0] >= 2 && desc->dims[1] >= 1 && desc->dims[2] >= 1, "cpm_volume_create: dims (x >= 2)");
     Affine a;
@@ -205,6 +205,11 @@ int cpm_volume_create(cpm_ctx* ctx, const cpm_volume_desc* desc, const void* vox
     hipError_t e = hipMalloc(&v->voxels, v->bytes + 16);  // tail pad: paired x loads never leave the allocation
     if (e != hipSuccess) { delete v; return set_error(ctx, CPM_ERR_OUT_OF_MEMORY, "hipMalloc(volume)", hipGetErrorString(e)); }
     *out = v;
+    if (!voxels) {  // storage for a volume produced on the device (cpm_volume_mix): zero-filled
+        e = hipMemsetAsync(v->voxels, 0, v->bytes + 16, (hipStream_t)stream);
+        if (e != hipSuccess) { cpm_volume_destroy(ctx, v); *out = nullptr; return set_error(ctx, CPM_ERR_DEVICE, "hipMemsetAsync(volume)", hipGetErrorString(e)); }
+        return CPM_OK;
+    }
     int rc = cpm_volume_update(ctx, v, voxels, is_device, stream);
     if (rc != CPM_OK) { cpm_volume_destroy(ctx, v); *out = nullptr; }
     return rc;

@@ -6,7 +6,7 @@
 #include <cstring>
 #include <sstream>
 
-#include "cpm_processors.h"
+#include "cpm_timevarying.h"
 
 using namespace inviwo;
 
@@ -163,6 +163,178 @@ const char* cpmh_describe_surface(cpmh_network* net) {
     }
     s = os.str();
     return s.c_str();
+}
+
+// ---- time-varying data: .u3d files and the sequence processors ------------------------------------------
+
+static std::string g_u3d_error;
+const char* cpmh_last_error() { return g_u3d_error.c_str(); }
+
+static std::shared_ptr<UniformGrid3DBase> make_grid(int format) {
+    if (format == 0) return std::make_shared<MinMaxUniformGrid3D>();
+    return std::make_shared<ImportanceUniformGrid3D>();
+}
+
+// format 0 = Vec2UINT16 (min/max grid), 1 = FLOAT32; `data` holds `count` elements back to back.  Host only.
+int cpmh_u3d_write(const char* path, int format, const int dims[3], const int cell[3], const float model[16], const float world[16],
+                   const void* data, int count, int overwrite) {
+    try {
+        UniformGrid3DVector v;
+        const char* src = (const char*)data;
+        for (int t = 0; t < count; ++t) {
+            auto g = make_grid(format);
+            g->setCellDimension(size3_t{ (size_t)cell[0], (size_t)cell[1], (size_t)cell[2] });
+            mat4 m, w;
+            for (int i = 0; i < 16; ++i) { m[i] = model[i]; w[i] = world[i]; }
+            g->setModelMatrix(m); g->setWorldMatrix(w);
+            g->setDimensions(size3_t{ (size_t)dims[0], (size_t)dims[1], (size_t)dims[2] });
+            std::memcpy(g->hostData(), src + (size_t)t * g->getSizeInBytes(), g->getSizeInBytes());
+            v.push_back(g);
+        }
+        UniformGrid3DWriter w;
+        w.setOverwrite(overwrite != 0);
+        w.writeData(&v, path);
+        return 0;
+    } catch (const std::exception& e) {
+        g_u3d_error = e.what();
+        return -1;
+    }
+}
+
+static std::shared_ptr<UniformGrid3DVector> g_u3d_last;
+int cpmh_u3d_read(const char* path, int* format, int dims[3], int cell[3], float model[16], float world[16], int* count,
+                  unsigned long long* element_bytes) {
+    try {
+        g_u3d_last = UniformGrid3DReader().readData(path);
+        auto& g = *g_u3d_last->front();
+        *format = std::string(g.getDataFormatString()) == "Vec2UINT16" ? 0 : 1;
+        dims[0] = (int)g.getDimensions().x; dims[1] = (int)g.getDimensions().y; dims[2] = (int)g.getDimensions().z;
+        cell[0] = (int)g.getCellDimension().x; cell[1] = (int)g.getCellDimension().y; cell[2] = (int)g.getCellDimension().z;
+        for (int i = 0; i < 16; ++i) { model[i] = g.getModelMatrix()[i]; world[i] = g.getWorldMatrix()[i]; }
+        *count = (int)g_u3d_last->size();
+        *element_bytes = g.getSizeInBytes();
+        return 0;
+    } catch (const std::exception& e) {
+        g_u3d_error = e.what();
+        g_u3d_last.reset();
+        return -1;
+    }
+}
+int cpmh_u3d_read_data(void* out) {  // the elements of the last successful cpmh_u3d_read
+    if (!g_u3d_last) return -1;
+    char* dst = (char*)out;
+    for (auto& g : *g_u3d_last) { std::memcpy(dst, g->hostData(), g->getSizeInBytes()); dst += g->getSizeInBytes(); }
+    return 0;
+}
+
+// volume sequence -> { VolumeSequencePlayer, VolumeMinMaxCLProcessor (sequence ports) -> UniformGrid3DPlayerProcessor,
+//                      DynamicVolumeDifferenceAnalysis -> UniformGrid3DPlayerProcessor }
+struct cpmh_sequence {
+    std::shared_ptr<VolumeSequence> volumes = std::make_shared<VolumeSequence>();
+    DataOutport<VolumeSequence> source{ "data" };
+    VolumeSequencePlayer volumePlayer;
+    VolumeMinMaxCLProcessor minMax;
+    DynamicVolumeDifferenceAnalysis difference;
+    UniformGrid3DPlayerProcessor minMaxPlayer, differencePlayer;
+    UniformGrid3DVectorSource gridSource;
+    UniformGrid3DPlayerProcessor gridSourcePlayer;
+    bool analysed = false;
+};
+
+cpmh_sequence* cpmh_sequence_create(const void* voxels, int dtype, int dx, int dy, int dz, int count, int region) {
+    if (!CpmRuntime::get().valid()) return nullptr;
+    auto* s = new cpmh_sequence();
+    for (int t = 0; t < count; ++t) {
+        auto v = std::make_shared<Volume>(size3_t{ (size_t)dx, (size_t)dy, (size_t)dz }, dtype);
+        const size_t bytes = (size_t)dx * dy * dz * v->elementSize();
+        v->ramBytes.assign((const uint8_t*)voxels + (size_t)t * bytes, (const uint8_t*)voxels + (size_t)(t + 1) * bytes);
+        s->volumes->push_back(v);
+    }
+    s->source.setData(s->volumes);
+    s->minMax.volumeRegionSize_.set(region);
+    s->difference.volumeRegionSize_.set(region);
+    s->volumePlayer.inport_.connectTo(&s->source);
+    s->minMax.vectorInport_.connectTo(&s->source);
+    s->difference.inport_.connectTo(&s->source);
+    s->minMaxPlayer.inport_.connectTo(&s->minMax.vectorOutport_);
+    s->differencePlayer.inport_.connectTo(&s->difference.outport_);
+    s->gridSourcePlayer.inport_.connectTo(&s->gridSource.port_);
+    return s;
+}
+void cpmh_sequence_destroy(cpmh_sequence* s) { delete s; }
+
+static void for_each_clock(cpmh_sequence* s, const std::function<void(SequenceClock&)>& f) {
+    f(s->volumePlayer.clock_); f(s->minMaxPlayer.clock_); f(s->differencePlayer.clock_); f(s->gridSourcePlayer.clock_);
+}
+int cpmh_sequence_evaluate(cpmh_sequence* s) {
+    if (!s->analysed) {  // per-sequence analysis runs once (the sequence does not change)
+        s->minMax.process();
+        s->difference.process();
+        s->analysed = true;
+    }
+    s->volumePlayer.process();
+    s->minMaxPlayer.process();
+    s->differencePlayer.process();
+    s->gridSource.process();
+    s->gridSourcePlayer.process();
+    return (s->volumePlayer.outport_.getData() && s->minMaxPlayer.outport_.getData() && s->differencePlayer.outport_.getData()) ? 0 : -1;
+}
+void cpmh_sequence_set_time_per_element(cpmh_sequence* s, float seconds) {
+    for_each_clock(s, [&](SequenceClock& c) { c.timePerElement_.set(seconds); });
+}
+int cpmh_sequence_set_time(cpmh_sequence* s, float time) {
+    for_each_clock(s, [&](SequenceClock& c) { c.time_.set(time); });
+    return s->volumePlayer.clock_.index_.get();
+}
+int cpmh_sequence_tick(cpmh_sequence* s) {  // one firing of the play timers
+    for_each_clock(s, [&](SequenceClock& c) { c.onSequenceTimerEvent(); });
+    return s->volumePlayer.clock_.index_.get();
+}
+float cpmh_sequence_time(cpmh_sequence* s) { return s->volumePlayer.clock_.time_.get(); }
+float cpmh_sequence_max_time(cpmh_sequence* s) { return s->volumePlayer.clock_.time_.getMaxValue(); }
+float cpmh_sequence_weight(cpmh_sequence* s) { return s->volumePlayer.clock_.weight(); }
+// what: 0 = interpolated volume, 1 = interpolated min/max grid, 2 = interpolated difference grid, 3 = grid from the .u3d source
+int cpmh_sequence_download(cpmh_sequence* s, int what, void* out) {
+    if (what == 0) {
+        auto v = s->volumePlayer.outport_.getData();
+        if (!v || !v->downloadToRAM()) return -1;
+        std::memcpy(out, v->ramBytes.data(), v->ramBytes.size());
+        return 0;
+    }
+    auto g = what == 1 ? s->minMaxPlayer.outport_.getData() : (what == 2 ? s->differencePlayer.outport_.getData() : s->gridSourcePlayer.outport_.getData());
+    if (!g) return -1;
+    std::memcpy(out, g->hostData(), g->getSizeInBytes());
+    return 0;
+}
+// what: 1 = the min/max grids of all time steps, 2 = the difference grids
+int cpmh_sequence_export(cpmh_sequence* s, int what, const char* path) {
+    UniformGrid3DExport exp;
+    DataOutport<UniformGrid3DVector>* src = what == 1 ? &s->minMax.vectorOutport_ : &s->difference.outport_;
+    if (!src->getData()) return -1;
+    exp.port_.connectTo(src);
+    exp.file_.set(path);
+    exp.overwrite_.set(true);
+    exp.exportData();
+    return 0;
+}
+void cpmh_sequence_load_grids(cpmh_sequence* s, const char* path) { s->gridSource.filePath.set(path); }
+const char* cpmh_sequence_describe_surface(cpmh_sequence* s) {
+    static std::string str;
+    std::ostringstream os;
+    UniformGrid3DExport exp;
+    UniformGrid3DSequenceSelector sel;
+    Processor* ps[] = { &s->volumePlayer, &s->minMax, &s->difference, &s->minMaxPlayer, &s->gridSource, &exp, &sel };
+    for (Processor* p : ps) {
+        os << p->getProcessorInfo().classIdentifier << "|in:";
+        for (auto& i : p->getInportIds()) os << i << ",";
+        os << "|out:";
+        for (auto& o : p->getOutportIds()) os << o << ",";
+        os << "|prop:";
+        for (auto& q : p->getPropertyIds()) os << q << ",";
+        os << "\n";
+    }
+    str = os.str();
+    return str.c_str();
 }
 
 }  // extern "C"

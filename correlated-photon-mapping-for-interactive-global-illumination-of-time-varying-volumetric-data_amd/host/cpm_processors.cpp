@@ -254,7 +254,6 @@ void LightSampleMeshIntersectionCL::meshSampleIntersection(const Mesh* mesh, Lig
 
 PhotonTracerCL::~PhotonTracerCL() {
     auto& rt = CpmRuntime::get();
-    if (vol_) cpm_volume_destroy(rt.ctx(), vol_);
     if (tf_) cpm_tf_destroy(rt.ctx(), tf_);
 }
 void PhotonTracerCL::setRandomSeedSize(size_t nPhotons) {
@@ -262,16 +261,6 @@ void PhotonTracerCL::setRandomSeedSize(size_t nPhotons) {
         randomState_.setSize(nPhotons);
         MWC64XSeedGenerator().generateRandomSeeds(&randomState_, 0);
     }
-}
-void PhotonTracerCL::syncVolume(const Volume* volume) {
-    auto& rt = CpmRuntime::get();
-    if (vol_ && volSrc_ == volume) return;
-    if (vol_) { cpm_volume_destroy(rt.ctx(), vol_); vol_ = nullptr; }
-    cpm_volume_desc d;
-    const size3_t s = volume->getDimensions();
-    const int32_t dims[3] = { (int32_t)s.x, (int32_t)s.y, (int32_t)s.z };
-    cpm_volume_desc_default(&d, dims, volume->dtype());
-    if (rt.check(cpm_volume_create(rt.ctx(), &d, volume->ramBytes.data(), 0, rt.stream(), &vol_), "cpm_volume_create")) volSrc_ = volume;
 }
 void PhotonTracerCL::syncTF(const TransferFunction& tf) {
     auto& rt = CpmRuntime::get();
@@ -288,7 +277,7 @@ void PhotonTracerCL::tracePhotons(const Volume* volume, const TransferFunction& 
     auto& rt = CpmRuntime::get();
     if (!rt.valid()) return;
     if (randomState_.getSize() != photonOutData->getNumberOfPhotons()) setRandomSeedSize(photonOutData->getNumberOfPhotons());
-    syncVolume(volume);
+    cpm_volume* vol_ = volume->getDeviceRepresentation();  // volume->getRepresentation<VolumeCL>() (:111)
     syncTF(transferFunction);
     if (!vol_ || !tf_) return;
     cpm_trace_params p = {};
@@ -360,28 +349,60 @@ void DirectionalLightSamplerCLProcessor::process() {  // directionallightsampler
 
 VolumeMinMaxCLProcessor::VolumeMinMaxCLProcessor() {
     addPortId("volume", true); addPortId("output", false);
+    addPortId("VolumeSequenceInput", true); addPortId("UniformGrid3DVectorOut", false);
+    inport_.setOptional(true); vectorInport_.setOptional(true);
     addProperty(volumeRegionSize_);
 }
-void VolumeMinMaxCLProcessor::process() {  // volumeminmaxclprocessor.cpp:88-184
-    auto& rt = CpmRuntime::get();
-    if (!rt.valid() || !inport_.isReady()) return;
-    const Volume* volume = inport_.getData().get();
-    if (!vol_ || volSrc_ != volume) {
-        if (vol_) cpm_volume_destroy(rt.ctx(), vol_);
-        vol_ = nullptr;
-        cpm_volume_desc d;
-        const size3_t s = volume->getDimensions();
-        const int32_t dims[3] = { (int32_t)s.x, (int32_t)s.y, (int32_t)s.z };
-        cpm_volume_desc_default(&d, dims, volume->dtype());
-        if (!rt.check(cpm_volume_create(rt.ctx(), &d, volume->ramBytes.data(), 0, rt.stream(), &vol_), "cpm_volume_create")) return;
-        volSrc_ = volume;
+void VolumeMinMaxCLProcessor::process() {  // volumeminmaxclprocessor.cpp:88-122
+    if (!CpmRuntime::get().valid()) return;
+    if (vectorInport_.isReady()) {
+        outport_.setData(nullptr);
+        auto output = std::make_shared<UniformGrid3DVector>();
+        for (auto& elem : *vectorInport_.getData())
+            if (auto result = compute(elem.get())) output->emplace_back(std::move(result));
+        vectorOutport_.setData(output);
     }
+    if (inport_.isReady())
+        if (auto result = compute(inport_.getData().get())) outport_.setData(result);
+}
+std::shared_ptr<MinMaxUniformGrid3D> VolumeMinMaxCLProcessor::compute(const Volume* volume) {  // :148-184
+    auto& rt = CpmRuntime::get();
+    cpm_volume* vol = volume->getDeviceRepresentation();
+    if (!vol) return nullptr;
     const size_t r = (size_t)volumeRegionSize_.get();
     const size3_t s = volume->getDimensions();
-    grid_->setCellDimension(size3_t{ r, r, r });
-    grid_->setDimensions(size3_t{ (s.x + r - 1) / r, (s.y + r - 1) / r, (s.z + r - 1) / r });
-    rt.check(cpm_volume_minmax(rt.ctx(), vol_, (int)r, grid_->data.device(), rt.stream()), "cpm_volume_minmax");
-    outport_.setData(grid_);
+    auto grid = std::make_shared<MinMaxUniformGrid3D>();
+    grid->setCellDimension(size3_t{ r, r, r });
+    grid->setModelMatrix(volume->getModelMatrix());
+    grid->setWorldMatrix(volume->getWorldMatrix());
+    grid->setDimensions(size3_t{ (s.x + r - 1) / r, (s.y + r - 1) / r, (s.z + r - 1) / r });
+    if (!rt.check(cpm_volume_minmax(rt.ctx(), vol, (int)r, grid->data.device(), rt.stream()), "cpm_volume_minmax")) return nullptr;
+    return grid;
+}
+
+// ---- Volume device representation -------------------------------------------------------------------
+Volume::~Volume() { invalidateDeviceRepresentation(); }
+void Volume::invalidateDeviceRepresentation() {
+    if (dev_) cpm_volume_destroy(CpmRuntime::get().ctx(), dev_);
+    dev_ = nullptr;
+}
+cpm_volume* Volume::getDeviceRepresentation() const {
+    if (dev_) return dev_;
+    auto& rt = CpmRuntime::get();
+    if (!rt.valid()) return nullptr;
+    cpm_volume_desc d;
+    const int32_t dims[3] = { (int32_t)dims_.x, (int32_t)dims_.y, (int32_t)dims_.z };
+    cpm_volume_desc_default(&d, dims, dtype_);
+    const size_t bytes = dims_.x * dims_.y * dims_.z * elementSize();
+    const void* src = ramBytes.size() == bytes ? ramBytes.data() : nullptr;
+    if (!rt.check(cpm_volume_create(rt.ctx(), &d, src, 0, rt.stream(), &dev_), "cpm_volume_create")) dev_ = nullptr;
+    return dev_;
+}
+bool Volume::downloadToRAM() {
+    if (!dev_) return !ramBytes.empty();
+    auto& rt = CpmRuntime::get();
+    ramBytes.resize(dims_.x * dims_.y * dims_.z * elementSize());
+    return rt.check(cpm_volume_download(rt.ctx(), dev_, ramBytes.data(), rt.stream()), "cpm_volume_download");
 }
 
 MinMaxUniformGrid3DImportanceCLProcessor::MinMaxUniformGrid3DImportanceCLProcessor() {

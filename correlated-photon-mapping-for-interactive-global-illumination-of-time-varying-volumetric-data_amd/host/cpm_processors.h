@@ -111,21 +111,65 @@ public:
     void setDimensions(size3_t d) { dims_ = d; resize(d.x * d.y * d.z); }
     size3_t getCellDimension() const { return cellDim_; }
     void setCellDimension(size3_t c) { cellDim_ = c; }
+    const mat4& getModelMatrix() const { return model_; }
+    const mat4& getWorldMatrix() const { return world_; }
+    void setModelMatrix(const mat4& m) { model_ = m; }
+    void setWorldMatrix(const mat4& m) { world_ = m; }
+    // format-generic access (getDataFormat()->getString(), getSizeInBytes(), getData(), clone())
+    virtual const char* getDataFormatString() const = 0;
+    virtual size_t getSizeInBytes() const = 0;
+    virtual void* deviceData() = 0;
+    virtual void* hostData() = 0;       // current RAM representation (downloads when the device copy is the master)
+    virtual void uploadHostData() = 0;  // after writing through hostData()
+    virtual bool hasDeviceData() const = 0;
+    virtual int mixType() const = 0;    // cpm_mix_type for BufferMixerCL::mix
+    virtual size_t mixElements() const = 0;
+    virtual std::shared_ptr<UniformGrid3DBase> clone() const = 0;  // same shape, metadata and data
 protected:
     virtual void resize(size_t n) = 0;
+    void copyMetaTo(UniformGrid3DBase& o) const { o.cellDim_ = cellDim_; o.model_ = model_; o.world_ = world_; o.setDimensions(dims_); }
     size3_t dims_{ 0, 0, 0 }, cellDim_{ 8, 8, 8 };
+    mat4 model_ = identityMatrix(), world_ = identityMatrix();
 };
-struct MinMaxUniformGrid3D : UniformGrid3DBase {   // u16 x 2 per cell
-    Buffer<uint16_t> data;
-    void resize(size_t n) override { data.setSize(2 * n); }
+using UniformGrid3DVector = std::vector<std::shared_ptr<UniformGrid3DBase>>;
+
+template <typename Derived, typename T, int Components>
+struct UniformGrid3DTyped : UniformGrid3DBase {
+    Buffer<T> data;
+    size_t getSizeInBytes() const override { return data.getSizeInBytes(); }
+    void* deviceData() override { return data.device(); }
+    void* hostData() override { return data.hostData(); }
+    void uploadHostData() override { data.upload(); }
+    bool hasDeviceData() const override { return data.hasDevice(); }
+    size_t mixElements() const override { return data.getSize() / (Components == 2 ? 2 : 1); }
+    std::shared_ptr<UniformGrid3DBase> clone() const override {
+        auto c = std::make_shared<Derived>();
+        copyMetaTo(*c);
+        auto& src = const_cast<Buffer<T>&>(data);
+        if (src.hasDevice()) {
+            if (data.getSize()) (void)hipMemcpy(c->data.device(), src.device(), data.getSizeInBytes(), hipMemcpyDeviceToDevice);
+        } else {
+            c->data.ram() = src.ram();
+        }
+        return c;
+    }
+protected:
+    void resize(size_t n) override { data.setSize(Components * n); }
 };
-struct ImportanceUniformGrid3D : UniformGrid3DBase {  // f32 per cell
-    Buffer<float> data;
-    void resize(size_t n) override { data.setSize(n); }
+// uniformgridcl/minmaxuniformgrid3d.h:41-42: UniformGrid3D<DataVec2UInt16::type>
+struct MinMaxUniformGrid3D : UniformGrid3DTyped<MinMaxUniformGrid3D, uint16_t, 2> {
+    const char* getDataFormatString() const override { return "Vec2UINT16"; }
+    int mixType() const override { return CPM_MIX_U16X2; }
 };
-struct DynamicVolumeInfoUniformGrid3D : UniformGrid3DBase {
-    Buffer<float> data;
-    void resize(size_t n) override { data.setSize(n); }
+// UniformGrid3D<float>: importance grids (importancesamplingcl) and per-brick volume differences
+// (DynamicVolumeInfoUniformGrid3D, uniformgridcl/processors/dynamicvolumedifferenceanalysis.h)
+struct ImportanceUniformGrid3D : UniformGrid3DTyped<ImportanceUniformGrid3D, float, 1> {
+    const char* getDataFormatString() const override { return "FLOAT32"; }
+    int mixType() const override { return CPM_MIX_F32; }
+};
+struct DynamicVolumeInfoUniformGrid3D : UniformGrid3DTyped<DynamicVolumeInfoUniformGrid3D, float, 1> {
+    const char* getDataFormatString() const override { return "FLOAT32"; }
+    int mixType() const override { return CPM_MIX_F32; }
 };
 
 struct DirectionalLight {  // what baseLightToPackedLight yields in data space
@@ -201,15 +245,11 @@ public:
     void setRandomSeedSize(size_t nPhotons);   // :176-182
     Buffer<uvec2>& randomState() { return randomState_; }
 private:
-    void syncVolume(const Volume* volume);
     void syncTF(const TransferFunction& tf);
     Buffer<uvec2> randomState_;
     bool onlyMultipleScattering_ = false, progressive_ = false;
-    cpm_volume* vol_ = nullptr;
-    const Volume* volSrc_ = nullptr;
     cpm_tf* tf_ = nullptr;
     std::vector<float> tfLut_;
-    friend class VolumeMinMaxCLProcessor;
 };
 
 // progressivephotonmapping/photonrecomputationdetector.{h,cpp}
@@ -269,11 +309,11 @@ public:
     void process() override;
     DataInport<Volume> inport_{ "volume" };
     DataOutport<UniformGrid3DBase> outport_{ "output" };
+    DataInport<VolumeSequence> vectorInport_{ "VolumeSequenceInput" };          // :62
+    DataOutport<UniformGrid3DVector> vectorOutport_{ "UniformGrid3DVectorOut" };  // :63
     IntProperty volumeRegionSize_{ "region", "Region size", 8 };
 private:
-    std::shared_ptr<MinMaxUniformGrid3D> grid_ = std::make_shared<MinMaxUniformGrid3D>();
-    cpm_volume* vol_ = nullptr;
-    const Volume* volSrc_ = nullptr;
+    std::shared_ptr<MinMaxUniformGrid3D> compute(const Volume* volume);  // :148-184
 };
 
 // importancesamplingcl/processors/minmaxuniformgrid3dimportanceclprocessor.{h,cpp}

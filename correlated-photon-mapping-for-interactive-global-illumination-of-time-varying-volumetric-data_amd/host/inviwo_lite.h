@@ -8,6 +8,7 @@
 #pragma once
 #include <hip/hip_runtime_api.h>
 
+#include <array>
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
@@ -19,7 +20,12 @@
 #include <string>
 #include <vector>
 
+struct cpm_volume;  // include/cpm/cpm.h
+
 namespace inviwo {
+
+using mat4 = std::array<float, 16>;  // column-major like glm::mat4
+inline mat4 identityMatrix() { return { 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1 }; }
 
 struct vec2 { float x = 0, y = 0; };
 struct vec3 {
@@ -83,6 +89,12 @@ public:
         ram_.resize(size_);
         if (size_) { (void)hipMemcpyAsync(ram_.data(), device(), size_ * sizeof(T), hipMemcpyDeviceToHost, s); (void)hipStreamSynchronize(s); }
     }
+    // getRepresentation<BufferRAM>(): once a device block exists it is the master copy
+    bool hasDevice() const { return dev_ != nullptr; }
+    T* hostData() {
+        if (dev_) download(); else ram_.resize(size_);
+        return ram_.data();
+    }
 
 private:
     void release() { if (dev_) (void)hipFree(dev_); dev_ = nullptr; }
@@ -115,17 +127,34 @@ private:
 class Volume {
 public:
     Volume(size3_t dims, int dtype) : dims_(dims), dtype_(dtype) {}
+    ~Volume();
+    Volume(const Volume&) = delete;
+    Volume& operator=(const Volume&) = delete;
     size3_t getDimensions() const { return dims_; }
-    void setDimensions(size3_t d) { dims_ = d; data.setSize(0); }
+    void setDimensions(size3_t d) { dims_ = d; data.setSize(0); invalidateDeviceRepresentation(); }
     int dtype() const { return dtype_; }
     size_t elementSize() const { return dtype_ == 0 ? 1 : (dtype_ == 1 ? 2 : 4); }
+    const mat4& getModelMatrix() const { return model_; }
+    const mat4& getWorldMatrix() const { return world_; }
+    void setModelMatrix(const mat4& m) { model_ = m; }
+    void setWorldMatrix(const mat4& m) { world_ = m; }
     int channels = 1;               // light volumes: 1 (float32) or 4 (4xfloat32)
     std::vector<uint8_t> ramBytes;  // scalar source volumes live here until uploaded
     Buffer<float> data;             // light volumes: device float storage
+    // getRepresentation<VolumeCL>() of a scalar volume: uploaded from ramBytes on first use and shared by every
+    // processor that reads the volume; zero-filled device storage when there is no RAM data (a volume produced
+    // on the device, e.g. VolumeSequencePlayer's output).  nullptr (error logged) without a device.
+    ::cpm_volume* getDeviceRepresentation() const;
+    void invalidateDeviceRepresentation();  // after editing ramBytes
+    // getRepresentation<VolumeRAM>() of a device-produced volume: download into ramBytes
+    bool downloadToRAM();
 private:
     size3_t dims_;
     int dtype_;
+    mat4 model_ = identityMatrix(), world_ = identityMatrix();
+    mutable ::cpm_volume* dev_ = nullptr;
 };
+using VolumeSequence = std::vector<std::shared_ptr<Volume>>;
 
 // ---- ports, properties, processors -----------------------------------------------------------------
 
@@ -185,8 +214,17 @@ public:
     const T& get() const { return value_; }
     operator T() const { return value_; }
     void set(const T& v) { value_ = v; changed(); }
+    // ordinal properties: range (no clamping here, as OrdinalProperty::set does not clamp either)
+    const T& getMinValue() const { return min_; }
+    const T& getMaxValue() const { return max_; }
+    void setMinValue(const T& v) { min_ = v; }
+    void setMaxValue(const T& v) { max_ = v; }
+    void setReadOnly(bool r) { readOnly_ = r; }
+    bool getReadOnly() const { return readOnly_; }
 private:
     T value_;
+    T min_{}, max_{};
+    bool readOnly_ = false;
 };
 using FloatProperty = Property<float>;
 using IntProperty = Property<int>;

@@ -108,7 +108,8 @@ void cpm_volume_desc_default(cpm_volume_desc* desc, const int32_t dims[3], int32
 /* Upload (or adopt a device copy of) a scalar volume, x fastest.
  * Replaces Volume::getRepresentation<VolumeCL>() + getVolumeStruct
  * (ref progressivephotonmapping/photontracercl.cpp:111-118,139-140).
- * voxels_is_device != 0: `voxels` is a device pointer (device->device copy). */
+ * voxels_is_device != 0: `voxels` is a device pointer (device->device copy).
+ * voxels == NULL: zero-filled storage (the output of cpm_volume_mix). */
 int cpm_volume_create(cpm_ctx* ctx, const cpm_volume_desc* desc, const void* voxels,
                       int voxels_is_device, cpm_stream stream, cpm_volume** out);
 /* Replace the voxel data (time-varying sequences; same desc). */

@@ -25,7 +25,7 @@ SURFACE = {
     "org.inviwo.UniformSampleGenerator2DCL": (set(), {"samples"}, {"nSamples"}),
     "org.inviwo.MinMaxUniformGrid3DImportanceCLProcessor": ({"minMaxUniformGrid3D", "volumeDifferenceInfo"}, {"importanceUniformGrid3D"},
                                                             {"incrementalImportance", "useAssociatedColor", "TFPointEpsilon"}),
-    "org.inviwo.VolumeMinMaxCLProcessor": ({"volume"}, {"output"}, {"region"}),
+    "org.inviwo.VolumeMinMaxCLProcessor": ({"volume", "VolumeSequenceInput"}, {"output", "UniformGrid3DVectorOut"}, {"region"}),
 }
 
 
