@@ -537,35 +537,39 @@ __global__ __launch_bounds__(256) void gather_records2_kernel(const float* __res
     uint32_t* s_rowjb = s_rowjb_all[wave];
     uint32_t* s_rowoff = s_rowoff_all[wave];
 
-    const int gb = blockIdx.x * 4 + wave;
-    const int by = (gb / bxn) % byn;
-    const int bzi = gb / (bxn * byn);
-    if (bzi >= bzn) return;
+    // 3-D launch (x: 4 bricks per workgroup, y, z): no integer divisions on the way to the brick -- four fifths of
+    // the waves find an empty halo and exit, so their prologue is a sixth of the kernel's instructions
+    const int bxr = (int)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(wave);
+    if (bxr >= bxn) return;
+    const int by = (int)blockIdx.y, bzi = (int)blockIdx.z;
     const int bz = (bzi & 1) ? (bzi >> 1) : (bzn - 1 - (bzi >> 1));  // bzn-1, 0, bzn-2, 1, ...
-    const int bx = (gb % bxn + 4 * (by + bzi)) % bxn;                // XCD-balancing rotation
+    const int bx = (bxr + 4 * (by + bzi)) % bxn;                     // XCD-balancing rotation (scalar)
     const int x0 = bx * kGW, y0 = by * kGW, z0 = bz * kGW;
     const int x = x0 + (lane & 3), y = y0 + ((lane >> 2) & 3), z = z0 + (lane >> 4);
     const bool valid = x < G.dx && y < G.dy && z < G.dz;
     const int my_par = (x & 1) | ((y & 1) << 1) | ((z & 1) << 2);
 
-    const int nry = kGW + 2 * Ry, nrows = nry * (kGW + 2 * Rz);
+    const int nry = kGW + 2 * Ry, nrows = nry * (kGW + 2 * Rz);  // Ry <= 1: 4 or 6 rows per slab
     uint32_t jb = 0, len = 0;
     if (lane < nrows) {
-        const int cy = y0 - Ry + (lane % nry), cz = z0 - Rz + (lane / nry);
+        const int rz = Ry ? (lane * 43) >> 8 : lane >> 2;  // lane / 6 (exact for lane < 64) or lane / 4
+        const int cy = y0 - Ry + (lane - rz * nry), cz = z0 - Rz + rz;
         if (cy >= 0 && cy < G.dy && cz >= 0 && cz < G.dz) {
             const uint32_t row = (uint32_t)G.dx * ((uint32_t)cy + (uint32_t)G.dy * (uint32_t)cz);
             jb = cell_start[row + (uint32_t)max(x0 - Rx, 0)];
             len = cell_start[row + (uint32_t)min(x0 + kGW - 1 + Rx, G.dx - 1) + 1] - jb;
         }
     }
-    uint32_t incl = len;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        uint32_t o = __shfl_up(incl, off, 64);
-        if (lane >= off) incl += o;
-    }
-    const uint32_t total = __shfl(incl, 63, 64);
     float sum = 0.f;
+    uint32_t incl = len, total = 0;
+    if (__any(len != 0)) {  // wave-uniform; an empty halo skips the prefix sum as well
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            uint32_t o = __shfl_up(incl, off, 64);
+            if (lane >= off) incl += o;
+        }
+        total = __shfl(incl, 63, 64);
+    }
     if (total != 0) {  // wave-uniform
         const int nwords = (int)((total + 63) >> 6);
         s_mask[lane] = 0ull;
@@ -820,8 +824,8 @@ int cpm_gather(cpm_ctx* ctx, const float* sorted_pos_power, const uint32_t* cell
     const float rmax = fmaxf(radius * (float)G.dx, fmaxf(radius * (float)G.dy, radius * (float)G.dz)) + 1e-3f;
     const int cand_axis = (int)floorf(2.f * rmax) + 1;
     if (G.channels == 1 && cand_axis <= 2 && Rx <= 1 && Ry <= 1 && Rz <= 1 && g_gather_force_voxel == 0)
-        CPM_LAUNCH(ctx, gather_records2_kernel, gridDim, block, 0, hs, sorted_pos_power, cell_start, G, radius, r2max, k, Rx, Ry, Rz,
-                   accumulate, bxn, byn, bzn, grid_out, g_gather_stamps);
+        CPM_LAUNCH(ctx, gather_records2_kernel, dim3((unsigned)div_up(bxn, 4), (unsigned)byn, (unsigned)bzn), block, 0, hs,
+                   sorted_pos_power, cell_start, G, radius, r2max, k, Rx, Ry, Rz, accumulate, bxn, byn, bzn, grid_out, g_gather_stamps);
     else if (G.channels == 1 && cand_axis <= 2 && g_gather_force_voxel != 1)
         CPM_LAUNCH(ctx, gather_records_kernel<2>, gridDim, block, 0, hs, sorted_pos_power, cell_start, G, radius, r2max, k, Rx, Ry, Rz,
                    accumulate, bxn, byn, grid_out, g_gather_stamps);
