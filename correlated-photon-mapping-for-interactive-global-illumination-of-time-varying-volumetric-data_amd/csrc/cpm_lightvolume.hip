@@ -651,16 +651,30 @@ __global__ __launch_bounds__(256) void gather_records2_kernel(const float* __res
             // voxel's own lane knows without looking anything up.
             const int vl0 = (sx - x0) + 4 * (sy - y0) + 16 * (sz - z0);
             const int par0 = (sx & 1) | ((sy & 1) << 1) | ((sz & 1) << 2);
+            // The cheap exact test runs for all 8 candidates; about 2 % of the (record, candidate) pairs pass, most
+            // records with none or one.  The weight (sqrt, division, kernel: ~40 instructions) is then evaluated per
+            // surviving candidate RANK -- first survivor of every lane together, then second, ... -- i.e. two or
+            // three times per step instead of once per candidate with one or two lanes active.
+            float d2c[8];
+            uint32_t hits = 0;
 #pragma unroll
             for (int c = 0; c < 8; ++c) {
                 const int qx = c & 1, qy = (c >> 1) & 1, qz = c >> 2;
-                const float d2 = fma_(dzv[qz], dzv[qz], fma_(dyv[qy], dyv[qy], dxv[qx] * dxv[qx]));
-                if (okx[qx] && oky[qy] && okz[qz] && d2 <= r2max) {  // d2 > r2max: exactly no contribution
+                d2c[c] = fma_(dzv[qz], dzv[qz], fma_(dyv[qy], dyv[qy], dxv[qx] * dxv[qx]));
+                if (okx[qx] && oky[qy] && okz[qz] && d2c[c] <= r2max) hits |= 1u << c;  // d2 > r2max: exactly no contribution
+            }
+            while (__any(hits != 0)) {
+                if (hits != 0) {
+                    const int c = __builtin_ctz(hits);
+                    hits &= hits - 1;
+                    float d2 = d2c[0];
+#pragma unroll
+                    for (int q = 1; q < 8; ++q) d2 = (c == q) ? d2c[q] : d2;
                     const float wgt = density_kernel_(__builtin_sqrtf(d2) / radius);
                     const float val = pk * wgt;
                     if (val != 0.f) {
                         s_val[par0 ^ c][lane] = val;  // parity of (sx+qx, sy+qy, sz+qz)
-                        atomicOr(&s_mask[vl0 + qx + 4 * qy + 16 * qz], 1ull << lane);
+                        atomicOr(&s_mask[vl0 + (c & 1) + 4 * ((c >> 1) & 1) + 16 * (c >> 2)], 1ull << lane);
                     }
                 }
             }
