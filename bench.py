@@ -100,7 +100,7 @@ def cpu_baseline(workload, vol_np, tf, n_lattice, grid_dim, light_dir):
     }
 
 
-def pmc_traffic(kernel):
+def pmc_traffic(kernel, workload):
     """L2<->fabric bytes per launch of `kernel` from the newest committed PMC summary (profiles/*pmc_traffic.json,
     written by tools/profile_round.sh: separate FETCH_SIZE / WRITE_SIZE passes, gfx950 corrections applied).
     PMC counters cannot be collected from inside this process, so the figure is the committed measurement of the
@@ -109,7 +109,8 @@ def pmc_traffic(kernel):
     files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "*pmc_traffic.json")))
     for f in reversed(files):
         try:
-            k = json.load(open(f))["kernels"].get(kernel)
+            d = json.load(open(f))
+            k = d["kernels"].get(kernel) if d.get("workload") == workload else None
         except (OSError, ValueError, KeyError):
             continue
         if k:
@@ -272,7 +273,7 @@ def main():
         achieved = ab[dom_base] / (dom_avg_ms * 1e-3) / 1e9
         frame_bytes = (ab["trace_kernel"] + ab["bin_keys_kernel"] + passes * (ab["radix_hist_kernel"] + ab["radix_rowscan_kernel"] + ab["radix_scatter_kernel"])
                        + ab["bin_finalize_kernel"] + ab["cell_start_kernel"] + ab["gather_kernel"])
-        traffic, traffic_src = pmc_traffic(dom.split("<")[0])
+        traffic, traffic_src = pmc_traffic(dom.split("<")[0], args.workload)
         out = {
             "metric": "Mphotons/s traced+binned+gathered",
             "value": round(value, 2), "unit": "Mphotons/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Per-kernel HBM-side traffic from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE).
 
-usage: pmc_traffic.py <fetch_dir> <write_dir> <out.json>
+usage: pmc_traffic.py <fetch_dir> <write_dir> <out.json> [workload]
 
 Units and corrections follow /opt/skills/guides/MI355X_MICROARCH.md "HBM [CDNA4]":
 FETCH_SIZE / WRITE_SIZE are KiB per dispatch; on gfx950 FETCH_SIZE tallies 128-B read
@@ -26,7 +26,8 @@ def collect(d, counter):
 
 fetch = collect(sys.argv[1], "FETCH_SIZE")
 write = collect(sys.argv[2], "WRITE_SIZE")
-out = {"unit": "bytes per launch (mean over dispatches)",
+out = {"workload": sys.argv[4] if len(sys.argv) > 4 else "config2",
+       "unit": "bytes per launch (mean over dispatches)",
        "corrections": "FETCH_SIZE KiB x 1024 x 2 (gfx950 half-count of 128-B requests); WRITE_SIZE KiB x 1024",
        "kernels": {}}
 for k in sorted(set(fetch) | set(write)):
