@@ -235,9 +235,9 @@ class PhotonFrame:
     def bin(self):
         self.ctx.bin(self.photons, self.n * self.I, self.grid, self.order, self.cell_start, self.sorted)
 
-    def gather(self, accumulate=False):
+    def gather(self, accumulate=False, out=None):
         self.ctx.gather(self.sorted, self.cell_start, self.n * self.I, self.grid, self.radius, self.scale,
-                        self.light_volume, accumulate=accumulate)
+                        self.light_volume if out is None else out, accumulate=accumulate)
 
     def splat(self, out=None):
         """Reference formulation (atomic splat), for comparison: clear + splat."""

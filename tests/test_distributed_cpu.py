@@ -118,3 +118,60 @@ def test_two_rank_photon_sharding_and_grid_allreduce(tmp_path, oracle, cpm):
     got = np.load(tmp_path / "grid.npy")
     np.testing.assert_allclose(got, want, rtol=2e-5, atol=1e-6 * float(want.max()))
     assert want.sum() > 0
+
+
+def _overlap_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    sys.path.insert(0, str(REPO))
+    import importlib
+    import torch
+    import torch.distributed as dist
+    import cpm_amd
+    sh = importlib.import_module(cpm_amd.__name__ + ".sharding")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    first = torch.zeros(4096)
+    red = sh.OverlappedGridReducer(first)
+    assert red.active and red.buffers[0] is first
+    results = []
+    K = 7
+    for k in range(K):
+        # "trace + bin" of frame k would run here, overlapping the reduce of frame k - 1
+        out = red.acquire(k)                       # waits for the reduce of frame k - 2 (same buffer)
+        if k >= 2:
+            results.append((k - 2, out.clone()))   # ... so that frame's reduced grid is complete here
+        out.copy_(torch.full((4096,), float((rank + 1) * (k + 1))))   # the "gather" of frame k
+        red.reduce(k)
+    red.flush()
+    results.append((K - 2, red.result(K - 2).clone()))
+    results.append((K - 1, red.result(K - 1).clone()))
+    want_scale = sum(r + 1 for r in range(world))
+    ok = all(bool((g == want_scale * (k + 1)).all()) for k, g in results) and len(results) == K
+    with open(os.path.join(out_dir, f"ok_{rank}"), "w") as f:
+        f.write("1" if ok else "0")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_overlapped_grid_reduce_double_buffering(tmp_path, cpm):
+    """bench.py's collective: asynchronous all-reduce of frame k's grid while frame k + 1 is computed, two
+    buffers, the wait placed where a buffer is reused.  Every frame's reduced grid must be the rank sum."""
+    import socket
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_overlap_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    assert (tmp_path / "ok_0").read_text() == "1" and (tmp_path / "ok_1").read_text() == "1"
+
+
+def test_overlapped_grid_reduce_without_process_group(cpm):
+    import importlib
+    import torch
+    sh = importlib.import_module(cpm.__name__ + ".sharding")
+    red = sh.OverlappedGridReducer(torch.zeros(8))
+    assert not red.active
+    for k in range(3):
+        red.acquire(k).fill_(k + 1.0)
+        red.reduce(k)
+    red.flush()
+    assert float(red.result(2)[0]) == 3.0 and float(red.result(1)[0]) == 2.0
