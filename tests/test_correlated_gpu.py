@@ -228,3 +228,46 @@ def test_time_varying_sequence(ctx, oracle, cpm):
         assert np.abs(lv - lv_full).sum() < 0.05 * np.abs(lv_full).sum()
         cm.full_frame()  # resynchronise before the next step so that the errors do not accumulate in the test
     assert all(0 < f < 1 for f in fractions), fractions
+
+
+def test_sharded_correlated_update(ctx, cpm):
+    """Multi-GPU semantics of the correlated path (per-shard selection), two shards emulated on one
+    GPU: every rank scores, selects and re-traces its own photon range; the union of the selections and the
+    re-traced photons equal the unsharded run's (photon i does not depend on its shard), and the sum of the
+    per-rank light volumes -- what the one all-reduce per frame produces -- equals the unsharded light volume
+    within summation-order tolerance, before and after the TF edit."""
+    import importlib
+    S, P = cpm.synthetic, cpm.pipeline
+    sh = importlib.import_module(cpm.__name__ + ".sharding")
+    vol_np = S.heterogeneous_volume(64)
+    base = [(0.0, 1, 1, 1, 0.0), (0.45, 1, 0.5, 0.2, 0.0), (0.55, 0.6, 0.3, 0.1, 0.05), (0.8, 0.9, 0.2, 0.3, 0.4), (1.0, 0.1, 0.6, 0.7, 0.5)]
+    edit = list(base)
+    edit[3] = (0.85,) + base[3][1:]
+    kw = dict(light_travel_direction=(0.3, 0.5, -1.0), tf_points=base, incremental_threshold_percent=100.0)
+    n_side, world = 128, 2
+    whole = P.CorrelatedPhotonMapper(ctx, vol_np, S.tf_from_points(base), n_side, (32, 32, 32), **kw)
+    shards = [P.CorrelatedPhotonMapper(ctx, vol_np, S.tf_from_points(base), n_side, (32, 32, 32),
+                                       photon_range=sh.shard_range(n_side * n_side, r, world), **kw) for r in range(world)]
+    whole.full_frame()
+    for s in shards:
+        s.full_frame()
+    lv = _n(whole.light_volume)
+    tol = dict(rtol=1e-4, atol=2e-6 * float(lv.max()))
+    np.testing.assert_allclose(sum(_n(s.light_volume) for s in shards), lv, **tol)
+    assert np.array_equal(bits(np.concatenate([_n(s.photons) for s in shards])), bits(_n(whole.photons)))
+
+    whole.set_transfer_function(edit)
+    n_whole = whole.correlated_update()
+    picked = []
+    for r, s in enumerate(shards):
+        s.set_transfer_function(edit)
+        n = s.correlated_update()
+        lo, _ = sh.shard_range(n_side * n_side, r, world)
+        picked.append(_n(s.indices, np.uint32)[:n].astype(np.int64) + lo)   # shard-local -> global photon index
+    picked = np.sort(np.concatenate(picked))
+    assert 0 < n_whole < whole.n and picked.size == n_whole
+    assert np.array_equal(picked, np.sort(_n(whole.indices, np.uint32)[:n_whole].astype(np.int64)))
+    assert np.array_equal(bits(np.concatenate([_n(s.photons) for s in shards])), bits(_n(whole.photons)))
+    lv2 = _n(whole.light_volume)
+    np.testing.assert_allclose(sum(_n(s.light_volume) for s in shards), lv2, rtol=1e-3, atol=2e-5 * float(lv2.max()))
+    assert np.abs(lv2 - lv).max() > 0
