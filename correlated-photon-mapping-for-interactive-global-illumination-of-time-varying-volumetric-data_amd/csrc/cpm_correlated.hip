@@ -6,8 +6,6 @@
 using namespace cpm;
 
 namespace cpm {
-int radix_sort(cpm_ctx* ctx, uint32_t* keys, uint32_t* vals, size_t n, int key_bits, hipStream_t s,
-               uint32_t** res_keys = nullptr, uint32_t** res_vals = nullptr);
 }
 
 namespace {
@@ -423,7 +421,7 @@ int cpm_select_recompute(cpm_ctx* ctx, uint32_t* importances, size_t n, uint32_t
                        indices_out, n_changed_dev);
     CPM_LAUNCH_CHECK(ctx, "threshold_count_iota_kernel");
     // keys are <= 0x7fffffff: 31 significant bits
-    return cpm::radix_sort(ctx, importances, indices_out, n, 31, s);
+    return cpm::radix_sort(ctx, importances, indices_out, n, 31, s, nullptr, nullptr, nullptr, nullptr);
 }
 
 }  // extern "C"

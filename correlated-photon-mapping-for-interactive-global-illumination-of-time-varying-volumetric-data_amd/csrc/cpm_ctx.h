@@ -89,6 +89,20 @@ struct ProfScope {
 
 inline int div_up(long long a, long long b) { return (int)((a + b - 1) / b); }
 
+// what the last scatter pass of cpm_bin's sort also produces (cpm_sort.hip, radix_scatter_kernel<..., BINSINK>)
+struct BinSink {
+    const float* photons = nullptr;   // float8 photon records
+    int channels = 1;
+    uint32_t* order = nullptr;        // sorted photon indices
+    float* sorted = nullptr;          // compact (pos, power) records in cell order
+    uint32_t* cell_start = nullptr;   // run-start table, preset to 0xffffffff
+};
+
+// keys/vals sorted in place (or left in *res_keys / *res_vals without the copy-back when those are given);
+// sink (nullable): see BinSink; *sink_done tells whether the last pass consumed it (then *res_vals is not written)
+int radix_sort(cpm_ctx* ctx, uint32_t* keys, uint32_t* vals, size_t n, int key_bits, hipStream_t s,
+               uint32_t** res_keys, uint32_t** res_vals, const BinSink* sink, bool* sink_done);
+
 // device-side grid description
 struct GridDev {
     int dx, dy, dz, channels;

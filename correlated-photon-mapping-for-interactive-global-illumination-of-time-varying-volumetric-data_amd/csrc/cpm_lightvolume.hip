@@ -13,8 +13,6 @@
 using namespace cpm;
 
 namespace cpm {
-int radix_sort(cpm_ctx* ctx, uint32_t* keys, uint32_t* vals, size_t n, int key_bits, hipStream_t s,
-               uint32_t** res_keys = nullptr, uint32_t** res_vals = nullptr);
 }
 
 namespace {
@@ -727,6 +725,9 @@ extern "C" {
 static unsigned long long* g_gather_stamps = nullptr;
 void cpm_debug_set_gather_stamps(unsigned long long* dev) { g_gather_stamps = dev; }
 // test hook: 1 = voxel-major kernel for every gather, 2 = generic record-major kernel instead of the r < 1 specialisation
+// test / measurement hook: 1 (default) = the last sort pass finalises the bin, 0 = separate bin_finalize_kernel
+static int g_bin_fused = 1;
+void cpm_debug_set_bin_fused(int on) { g_bin_fused = on; }
 static int g_gather_force_voxel = 0;
 void cpm_debug_force_voxel_gather(int on) { g_gather_force_voxel = on; }
 
@@ -790,17 +791,21 @@ int cpm_bin(cpm_ctx* ctx, const float* photons8, int n, const cpm_grid_desc* gri
     uint32_t* keys = (uint32_t*)scratch(ctx, CPM_SCR_BIN_KEYS, (size_t)(n > 0 ? n : 1) * 8);
     if (!keys) return CPM_ERR_OUT_OF_MEMORY;
     uint32_t* vals = keys + (n > 0 ? n : 1);
+    bool finalized = false;
     if (n > 0) {
         CPM_LAUNCH(ctx, bin_keys_kernel, dim3(div_up(n, 256)), dim3(256), 0, s, photons8, n, G, cells, keys, vals, cell_start);
         CPM_LAUNCH_CHECK(ctx, "bin_keys_kernel");
-        // no copy-back after an odd number of passes: the finalize / cell-start kernels read the
-        // result wherever the ping-pong left it
-        rc = cpm::radix_sort(ctx, keys, vals, (size_t)n, key_bits_for(cells), s, &keys, &vals);
+        // no copy-back after an odd number of passes: the cell-start kernel reads the keys wherever the
+        // ping-pong left them; the last scatter pass writes order / records / run starts itself (BinSink)
+        BinSink sink;
+        sink.photons = photons8; sink.channels = G.channels; sink.order = order; sink.sorted = sorted_pos_power;
+        sink.cell_start = cell_start;
+        rc = cpm::radix_sort(ctx, keys, vals, (size_t)n, key_bits_for(cells), s, &keys, &vals, g_bin_fused ? &sink : nullptr, &finalized);
         if (rc) return rc;
     }
     // run starts -> table (preset to "none" by bin_keys_kernel), then the suffix-min scan turns it into cell starts
     if (n == 0) CPM_HIP_CHECK(ctx, hipMemsetAsync(cell_start, 0xff, ((size_t)cells + 1) * sizeof(uint32_t), s));
-    if (n > 0) {
+    if (n > 0 && !finalized) {  // n == 1, the onesweep test mode, or cpm_debug_set_bin_fused(0)
         CPM_LAUNCH(ctx, bin_finalize_kernel, dim3(div_up(n, 256)), dim3(256), 0, s, photons8, keys, vals, n, G.channels,
                            order, sorted_pos_power, cell_start);
         CPM_LAUNCH_CHECK(ctx, "bin_finalize_kernel");

@@ -102,7 +102,12 @@ __global__ __launch_bounds__(kSortThreads) void radix_global_hist_kernel(const u
 //   forward progress does not depend on dispatch order), publish their per-digit counts, and obtain the
 //   count of the same digit in all earlier tiles by decoupled look-back over the status words
 //   (Merrill & Garland's single-pass scan, as used by onesweep radix sorts).
-template <int ITEMS, bool HAS_VALUES, bool ONESWEEP>
+// BINSINK (the last pass of cpm_bin's sort): the tile's output loop also does what bin_finalize_kernel would do in
+// a launch of its own -- order[pos] = photon index, the compact (pos, power) record fetched from the photon
+// array, and the run starts of the cell table.  Inside a tile's digit run the output is final and contiguous,
+// so "key differs from its predecessor" is decided in LDS; only the first element of a digit run of a tile
+// cannot see its predecessor (it lies in another tile) and takes an atomicMin on the preset table instead.
+template <int ITEMS, bool HAS_VALUES, bool ONESWEEP, bool BINSINK>
 __global__ __launch_bounds__(kSortThreads) void radix_scatter_kernel(const uint32_t* __restrict__ keys_in,
                                                                      const uint32_t* __restrict__ vals_in,
                                                                      uint32_t* __restrict__ keys_out,
@@ -110,7 +115,8 @@ __global__ __launch_bounds__(kSortThreads) void radix_scatter_kernel(const uint3
                                                                      int shift, const uint32_t* __restrict__ hist,
                                                                      const uint32_t* __restrict__ digit_total,
                                                                      uint32_t num_tiles, uint32_t* __restrict__ ticket,
-                                                                     uint32_t* __restrict__ status, uint32_t* __restrict__ error) {
+                                                                     uint32_t* __restrict__ status, uint32_t* __restrict__ error,
+                                                                     const BinSink sink) {
     constexpr int TILE = kSortThreads * ITEMS;
     __shared__ uint32_t s_tile;
     __shared__ uint32_t wcount[kSortWaves][kRadix];  // per-wave digit counters, later (wave, digit) local starts
@@ -242,7 +248,25 @@ __global__ __launch_bounds__(kSortThreads) void radix_scatter_kernel(const uint3
             uint32_t d = (kk >> shift) & (kRadix - 1);
             uint32_t pos = gofs[d] + i;
             keys_out[pos] = kk;
-            if (HAS_VALUES) vals_out[pos] = svals[i];
+            if (BINSINK) {
+                const uint32_t id = svals[i];
+                sink.order[pos] = id;
+                const float4* q = reinterpret_cast<const float4*>(sink.photons) + 2 * (size_t)id;
+                const float4 a = q[0];
+                if (sink.channels == 1) {
+                    reinterpret_cast<float4*>(sink.sorted)[pos] = a;
+                } else {
+                    const float4 b = q[1];
+                    float4* o = reinterpret_cast<float4*>(sink.sorted) + 2 * (size_t)pos;
+                    o[0] = a;
+                    o[1] = make_float4(b.x, b.y, 0.f, 0.f);
+                }
+                const uint32_t pk = i ? skeys[i - 1] : 0u;
+                if (i == 0 || ((pk >> shift) & (kRadix - 1)) != d) atomicMin(&sink.cell_start[kk], pos);  // predecessor in another tile
+                else if (pk != kk) sink.cell_start[kk] = pos;                                              // run start, decided here
+            } else if (HAS_VALUES) {
+                vals_out[pos] = svals[i];
+            }
         }
     }
 }
@@ -257,7 +281,7 @@ static int g_sort_items = 0;  // 0 = by size; 8 / 16 force the tile size (tuning
 
 template <int ITEMS>
 static int sort_passes(cpm_ctx* ctx, uint32_t* keys, uint32_t* vals, uint32_t n, int key_bits, hipStream_t s,
-                       uint32_t** res_keys, uint32_t** res_vals) {
+                       uint32_t** res_keys, uint32_t** res_vals, const BinSink* sink, bool* sink_done) {
     const uint32_t tile = kSortThreads * ITEMS;
     const uint32_t num_tiles = (n + tile - 1) / tile;
     const int passes = (key_bits + kRadixBits - 1) / kRadixBits;
@@ -284,20 +308,24 @@ static int sort_passes(cpm_ctx* ctx, uint32_t* keys, uint32_t* vals, uint32_t n,
         if (onesweep) {
             uint32_t* st = status + (size_t)p * num_tiles * kRadix;
             if (vals)
-                CPM_LAUNCH(ctx, (radix_scatter_kernel<ITEMS, true, true>), dim3(num_tiles), dim3(kSortThreads), 0, s, ks, vs, kd, vd, n, shift,
-                           nullptr, ghist + p * kRadix, num_tiles, tickets + p, st, error);
+                CPM_LAUNCH(ctx, (radix_scatter_kernel<ITEMS, true, true, false>), dim3(num_tiles), dim3(kSortThreads), 0, s, ks, vs, kd, vd, n, shift,
+                           nullptr, ghist + p * kRadix, num_tiles, tickets + p, st, error, BinSink{});
             else
-                CPM_LAUNCH(ctx, (radix_scatter_kernel<ITEMS, false, true>), dim3(num_tiles), dim3(kSortThreads), 0, s, ks, nullptr, kd, nullptr, n,
-                           shift, nullptr, ghist + p * kRadix, num_tiles, tickets + p, st, error);
+                CPM_LAUNCH(ctx, (radix_scatter_kernel<ITEMS, false, true, false>), dim3(num_tiles), dim3(kSortThreads), 0, s, ks, nullptr, kd, nullptr, n,
+                           shift, nullptr, ghist + p * kRadix, num_tiles, tickets + p, st, error, BinSink{});
         } else {
             CPM_LAUNCH(ctx, radix_hist_kernel<ITEMS>, dim3(num_tiles), dim3(kSortThreads), 0, s, ks, n, shift, status, num_tiles);
             CPM_LAUNCH(ctx, radix_rowscan_kernel, dim3(kRadix), dim3(kSortThreads), 0, s, status, num_tiles, digit_total);
-            if (vals)
-                CPM_LAUNCH(ctx, (radix_scatter_kernel<ITEMS, true, false>), dim3(num_tiles), dim3(kSortThreads), 0, s, ks, vs, kd, vd, n, shift,
-                           status, digit_total, num_tiles, nullptr, nullptr, nullptr);
+            if (vals && sink && p == passes - 1) {
+                CPM_LAUNCH(ctx, (radix_scatter_kernel<ITEMS, true, false, true>), dim3(num_tiles), dim3(kSortThreads), 0, s, ks, vs, kd, vd, n, shift,
+                           status, digit_total, num_tiles, nullptr, nullptr, nullptr, *sink);
+                if (sink_done) *sink_done = true;
+            } else if (vals)
+                CPM_LAUNCH(ctx, (radix_scatter_kernel<ITEMS, true, false, false>), dim3(num_tiles), dim3(kSortThreads), 0, s, ks, vs, kd, vd, n, shift,
+                           status, digit_total, num_tiles, nullptr, nullptr, nullptr, BinSink{});
             else
-                CPM_LAUNCH(ctx, (radix_scatter_kernel<ITEMS, false, false>), dim3(num_tiles), dim3(kSortThreads), 0, s, ks, nullptr, kd, nullptr, n,
-                           shift, status, digit_total, num_tiles, nullptr, nullptr, nullptr);
+                CPM_LAUNCH(ctx, (radix_scatter_kernel<ITEMS, false, false, false>), dim3(num_tiles), dim3(kSortThreads), 0, s, ks, nullptr, kd, nullptr, n,
+                           shift, status, digit_total, num_tiles, nullptr, nullptr, nullptr, BinSink{});
         }
         CPM_LAUNCH_CHECK(ctx, "radix sort pass");
         uint32_t* tmp = ks; ks = kd; kd = tmp;
@@ -317,19 +345,20 @@ static int sort_passes(cpm_ctx* ctx, uint32_t* keys, uint32_t* vals, uint32_t n,
 
 // keys/vals sorted in place; vals may be null (keys only)
 int radix_sort(cpm_ctx* ctx, uint32_t* keys, uint32_t* vals, size_t n, int key_bits, hipStream_t s,
-               uint32_t** res_keys, uint32_t** res_vals) {
+               uint32_t** res_keys, uint32_t** res_vals, const BinSink* sink, bool* sink_done) {
     if (res_keys) *res_keys = keys;
     if (res_vals) *res_vals = vals;
+    if (sink_done) *sink_done = false;
     if (n <= 1) return CPM_OK;
     if (n >= (1ull << 31)) return set_error(ctx, CPM_ERR_INVALID_ARGUMENT, "radix_sort", "n must be < 2^31");
     if (key_bits <= 0 || key_bits > 32) key_bits = 32;
-    if (g_sort_items == 4) return sort_passes<4>(ctx, keys, vals, (uint32_t)n, key_bits, s, res_keys, res_vals);
-    if (g_sort_items == 16) return sort_passes<16>(ctx, keys, vals, (uint32_t)n, key_bits, s, res_keys, res_vals);
+    if (g_sort_items == 4) return sort_passes<4>(ctx, keys, vals, (uint32_t)n, key_bits, s, res_keys, res_vals, sink, sink_done);
+    if (g_sort_items == 16) return sort_passes<16>(ctx, keys, vals, (uint32_t)n, key_bits, s, res_keys, res_vals, sink, sink_done);
     // tile = 256 threads x ITEMS keys.  Measured at 1 M pairs, 22 key bits (3 passes + copy-back):
     // ITEMS 4: 73 us, 8: 61 us, 16: 70 us -- 2048-key tiles balance table size against workgroup count.
-    if (n <= (1u << 15)) return sort_passes<4>(ctx, keys, vals, (uint32_t)n, key_bits, s, res_keys, res_vals);
-    if (n <= (1u << 23) || g_sort_items == 8) return sort_passes<8>(ctx, keys, vals, (uint32_t)n, key_bits, s, res_keys, res_vals);
-    return sort_passes<16>(ctx, keys, vals, (uint32_t)n, key_bits, s, res_keys, res_vals);
+    if (n <= (1u << 15)) return sort_passes<4>(ctx, keys, vals, (uint32_t)n, key_bits, s, res_keys, res_vals, sink, sink_done);
+    if (n <= (1u << 23) || g_sort_items == 8) return sort_passes<8>(ctx, keys, vals, (uint32_t)n, key_bits, s, res_keys, res_vals, sink, sink_done);
+    return sort_passes<16>(ctx, keys, vals, (uint32_t)n, key_bits, s, res_keys, res_vals, sink, sink_done);
 }
 
 }  // namespace cpm
@@ -343,13 +372,13 @@ void cpm_debug_set_sort_items(int items) { cpm::g_sort_items = items; }
 int cpm_sort_pairs(cpm_ctx* ctx, uint32_t* keys, uint32_t* values, size_t n, int key_bits, cpm_stream stream) {
     if (!ctx) return CPM_ERR_INVALID_ARGUMENT;
     CPM_REQUIRE(ctx, (keys && values) || n == 0, "cpm_sort_pairs: null argument");
-    return cpm::radix_sort(ctx, keys, values, n, key_bits, (hipStream_t)stream, nullptr, nullptr);
+    return cpm::radix_sort(ctx, keys, values, n, key_bits, (hipStream_t)stream, nullptr, nullptr, nullptr, nullptr);
 }
 
 int cpm_sort_keys(cpm_ctx* ctx, uint32_t* keys, size_t n, int key_bits, cpm_stream stream) {
     if (!ctx) return CPM_ERR_INVALID_ARGUMENT;
     CPM_REQUIRE(ctx, keys || n == 0, "cpm_sort_keys: null argument");
-    return cpm::radix_sort(ctx, keys, nullptr, n, key_bits, (hipStream_t)stream, nullptr, nullptr);
+    return cpm::radix_sort(ctx, keys, nullptr, n, key_bits, (hipStream_t)stream, nullptr, nullptr, nullptr, nullptr);
 }
 
 }  // extern "C"

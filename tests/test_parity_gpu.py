@@ -369,6 +369,17 @@ def test_bin_and_gather_bit_exact(ctx, oracle, cpm, dims, channels, radius_vox, 
         ctx.lib.cpm_debug_force_voxel_gather(0)
 
 
+@pytest.mark.parametrize("dims,channels", [((32, 32, 32), 1), ((24, 40, 16), 4)])
+def test_bin_with_separate_finalize_launch(ctx, oracle, cpm, dims, channels):
+    """cpm_bin's default lets the last radix pass write order / records / run starts; the separate
+    bin_finalize_kernel (used for n == 1 and the onesweep test mode) produces the same bin."""
+    ctx.lib.cpm_debug_set_bin_fused(0)
+    try:
+        _bin_and_gather_case(ctx, oracle, cpm, dims, channels, 0.866)
+    finally:
+        ctx.lib.cpm_debug_set_bin_fused(1)
+
+
 def _bin_and_gather_case(ctx, oracle, cpm, dims, channels, radius_vox):
     rng = np.random.default_rng(sum(dims))
     n = 20_000
