@@ -421,7 +421,7 @@ int cpm_select_recompute(cpm_ctx* ctx, uint32_t* importances, size_t n, uint32_t
                        indices_out, n_changed_dev);
     CPM_LAUNCH_CHECK(ctx, "threshold_count_iota_kernel");
     // keys are <= 0x7fffffff: 31 significant bits
-    return cpm::radix_sort(ctx, importances, indices_out, n, 31, s, nullptr, nullptr, nullptr, nullptr);
+    return cpm::radix_sort(ctx, importances, indices_out, n, 31, s, nullptr, nullptr, nullptr, nullptr, false);
 }
 
 }  // extern "C"

@@ -100,8 +100,11 @@ struct BinSink {
 
 // keys/vals sorted in place (or left in *res_keys / *res_vals without the copy-back when those are given);
 // sink (nullable): see BinSink; *sink_done tells whether the last pass consumed it (then *res_vals is not written)
+// first_hist_done: pass 0's per-tile digit histogram is already in sort_first_hist()'s table
 int radix_sort(cpm_ctx* ctx, uint32_t* keys, uint32_t* vals, size_t n, int key_bits, hipStream_t s,
-               uint32_t** res_keys, uint32_t** res_vals, const BinSink* sink, bool* sink_done);
+               uint32_t** res_keys, uint32_t** res_vals, const BinSink* sink, bool* sink_done, bool first_hist_done);
+int sort_items_for(size_t n);
+uint32_t* sort_first_hist(cpm_ctx* ctx, size_t n, int key_bits, uint32_t* num_tiles_out);
 
 // device-side grid description
 struct GridDev {

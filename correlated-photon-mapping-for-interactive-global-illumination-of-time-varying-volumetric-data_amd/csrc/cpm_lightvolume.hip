@@ -125,23 +125,40 @@ __global__ __launch_bounds__(256) void copy_indexed_kernel(const float* __restri
 
 // cell key (template: cl/hashlightsample.cl:55-64); sentinels get key == cells so that the
 // sort needs only bits(cells) key bits and they still land behind every real cell
+// One workgroup = one tile of the radix sort that follows (256 x ITEMS keys): while the keys are in registers the
+// tile's histogram of the first digit is counted in LDS and written where the sort's first pass expects it
+// (digit-major hist[256][tiles]), which saves that pass's histogram launch.
+template <int ITEMS>
 __global__ __launch_bounds__(256) void bin_keys_kernel(const float* __restrict__ photons, int n, GridDev G,
                                                        uint32_t cells, uint32_t* __restrict__ keys,
-                                                       uint32_t* __restrict__ vals, uint32_t* __restrict__ cell_start) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
+                                                       uint32_t* __restrict__ vals, uint32_t* __restrict__ cell_start,
+                                                       uint32_t* __restrict__ hist, uint32_t num_tiles) {
+    __shared__ uint32_t h[256];
+    h[threadIdx.x] = 0;
     // preset the run-start table to "none" on the way (saves a separate fill launch)
-    for (uint32_t e = (uint32_t)i; e <= cells; e += gridDim.x * blockDim.x) cell_start[e] = 0xffffffffu;
-    if (i >= n) return;
-    float4 a = reinterpret_cast<const float4*>(photons)[2 * (size_t)i];
-    uint32_t key = cells;
-    if (!(a.x == kFltMax || a.y == kFltMax || a.z == kFltMax)) {
-        float fx = min_(max_(__builtin_floorf(a.x * (float)G.dx), 0.0f), (float)(G.dx - 1));
-        float fy = min_(max_(__builtin_floorf(a.y * (float)G.dy), 0.0f), (float)(G.dy - 1));
-        float fz = min_(max_(__builtin_floorf(a.z * (float)G.dz), 0.0f), (float)(G.dz - 1));
-        key = (uint32_t)(int)fx + (uint32_t)G.dx * ((uint32_t)(int)fy + (uint32_t)G.dy * (uint32_t)(int)fz);
+    for (uint32_t e = blockIdx.x * blockDim.x + threadIdx.x; e <= cells; e += gridDim.x * blockDim.x) cell_start[e] = 0xffffffffu;
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < ITEMS; ++k) {
+        const int i = (int)blockIdx.x * (256 * ITEMS) + k * 256 + (int)threadIdx.x;
+        if (i < n) {
+            float4 a = reinterpret_cast<const float4*>(photons)[2 * (size_t)i];
+            uint32_t key = cells;
+            if (!(a.x == kFltMax || a.y == kFltMax || a.z == kFltMax)) {
+                float fx = min_(max_(__builtin_floorf(a.x * (float)G.dx), 0.0f), (float)(G.dx - 1));
+                float fy = min_(max_(__builtin_floorf(a.y * (float)G.dy), 0.0f), (float)(G.dy - 1));
+                float fz = min_(max_(__builtin_floorf(a.z * (float)G.dz), 0.0f), (float)(G.dz - 1));
+                key = (uint32_t)(int)fx + (uint32_t)G.dx * ((uint32_t)(int)fy + (uint32_t)G.dy * (uint32_t)(int)fz);
+            }
+            keys[i] = key;
+            vals[i] = (uint32_t)i;
+            if (hist) atomicAdd(&h[key & 255u], 1u);
+        }
     }
-    keys[i] = key;
-    vals[i] = (uint32_t)i;
+    if (hist) {
+        __syncthreads();
+        hist[(size_t)threadIdx.x * num_tiles + blockIdx.x] = h[threadIdx.x];
+    }
 }
 
 // order[j] = sorted photon index; compact (pos, power) records in cell order; and the start of
@@ -793,14 +810,23 @@ int cpm_bin(cpm_ctx* ctx, const float* photons8, int n, const cpm_grid_desc* gri
     uint32_t* vals = keys + (n > 0 ? n : 1);
     bool finalized = false;
     if (n > 0) {
-        CPM_LAUNCH(ctx, bin_keys_kernel, dim3(div_up(n, 256)), dim3(256), 0, s, photons8, n, G, cells, keys, vals, cell_start);
+        const int kb = key_bits_for(cells);
+        const int items = cpm::sort_items_for((size_t)n);
+        uint32_t num_tiles = 0;
+        uint32_t* hist = g_bin_fused ? cpm::sort_first_hist(ctx, (size_t)n, kb, &num_tiles) : nullptr;
+        const dim3 kgrid((unsigned)div_up(n, 256 * items));
+        switch (items) {
+            case 4: CPM_LAUNCH(ctx, bin_keys_kernel<4>, kgrid, dim3(256), 0, s, photons8, n, G, cells, keys, vals, cell_start, hist, num_tiles); break;
+            case 8: CPM_LAUNCH(ctx, bin_keys_kernel<8>, kgrid, dim3(256), 0, s, photons8, n, G, cells, keys, vals, cell_start, hist, num_tiles); break;
+            default: CPM_LAUNCH(ctx, bin_keys_kernel<16>, kgrid, dim3(256), 0, s, photons8, n, G, cells, keys, vals, cell_start, hist, num_tiles); break;
+        }
         CPM_LAUNCH_CHECK(ctx, "bin_keys_kernel");
         // no copy-back after an odd number of passes: the cell-start kernel reads the keys wherever the
         // ping-pong left them; the last scatter pass writes order / records / run starts itself (BinSink)
         BinSink sink;
         sink.photons = photons8; sink.channels = G.channels; sink.order = order; sink.sorted = sorted_pos_power;
         sink.cell_start = cell_start;
-        rc = cpm::radix_sort(ctx, keys, vals, (size_t)n, key_bits_for(cells), s, &keys, &vals, g_bin_fused ? &sink : nullptr, &finalized);
+        rc = cpm::radix_sort(ctx, keys, vals, (size_t)n, kb, s, &keys, &vals, g_bin_fused ? &sink : nullptr, &finalized, hist != nullptr);
         if (rc) return rc;
     }
     // run starts -> table (preset to "none" by bin_keys_kernel), then the suffix-min scan turns it into cell starts

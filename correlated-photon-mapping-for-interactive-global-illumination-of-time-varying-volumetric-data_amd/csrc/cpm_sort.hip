@@ -281,7 +281,7 @@ static int g_sort_items = 0;  // 0 = by size; 8 / 16 force the tile size (tuning
 
 template <int ITEMS>
 static int sort_passes(cpm_ctx* ctx, uint32_t* keys, uint32_t* vals, uint32_t n, int key_bits, hipStream_t s,
-                       uint32_t** res_keys, uint32_t** res_vals, const BinSink* sink, bool* sink_done) {
+                       uint32_t** res_keys, uint32_t** res_vals, const BinSink* sink, bool* sink_done, bool first_hist_done) {
     const uint32_t tile = kSortThreads * ITEMS;
     const uint32_t num_tiles = (n + tile - 1) / tile;
     const int passes = (key_bits + kRadixBits - 1) / kRadixBits;
@@ -314,7 +314,8 @@ static int sort_passes(cpm_ctx* ctx, uint32_t* keys, uint32_t* vals, uint32_t n,
                 CPM_LAUNCH(ctx, (radix_scatter_kernel<ITEMS, false, true, false>), dim3(num_tiles), dim3(kSortThreads), 0, s, ks, nullptr, kd, nullptr, n,
                            shift, nullptr, ghist + p * kRadix, num_tiles, tickets + p, st, error, BinSink{});
         } else {
-            CPM_LAUNCH(ctx, radix_hist_kernel<ITEMS>, dim3(num_tiles), dim3(kSortThreads), 0, s, ks, n, shift, status, num_tiles);
+            if (!(p == 0 && first_hist_done))  // cpm_bin's key kernel has already counted pass 0's digits per tile
+                CPM_LAUNCH(ctx, radix_hist_kernel<ITEMS>, dim3(num_tiles), dim3(kSortThreads), 0, s, ks, n, shift, status, num_tiles);
             CPM_LAUNCH(ctx, radix_rowscan_kernel, dim3(kRadix), dim3(kSortThreads), 0, s, status, num_tiles, digit_total);
             if (vals && sink && p == passes - 1) {
                 CPM_LAUNCH(ctx, (radix_scatter_kernel<ITEMS, true, false, true>), dim3(num_tiles), dim3(kSortThreads), 0, s, ks, vs, kd, vd, n, shift,
@@ -344,21 +345,40 @@ static int sort_passes(cpm_ctx* ctx, uint32_t* keys, uint32_t* vals, uint32_t n,
 }
 
 // keys/vals sorted in place; vals may be null (keys only)
+// keys per thread of a tile (256 threads) for n keys.  Measured at 1 M pairs, 22 key bits (3 passes + copy-back):
+// ITEMS 4: 73 us, 8: 61 us, 16: 70 us -- 2048-key tiles balance table size against workgroup count.
+int sort_items_for(size_t n) {
+    if (g_sort_items == 4 || g_sort_items == 8 || g_sort_items == 16) return g_sort_items;
+    return n <= (1u << 15) ? 4 : (n <= (1u << 23) ? 8 : 16);
+}
+
+// Where pass 0's per-tile digit histogram goes (digit-major [256][tiles]) when the caller counts it itself while
+// producing the keys (cpm_bin); nullptr when the sort will not use it (n <= 1, onesweep test mode).
+uint32_t* sort_first_hist(cpm_ctx* ctx, size_t n, int key_bits, uint32_t* num_tiles_out) {
+    if (n <= 1 || n >= (1ull << 31) || g_sort_mode == 1) return nullptr;
+    if (key_bits <= 0 || key_bits > 32) key_bits = 32;
+    const uint32_t tile = kSortThreads * (uint32_t)sort_items_for(n);
+    const uint32_t num_tiles = ((uint32_t)n + tile - 1) / tile;
+    const size_t ctl_words = 8 + 4 * (size_t)kRadix + (size_t)num_tiles * kRadix + kRadix;  // as sort_passes lays it out
+    uint32_t* ctl = (uint32_t*)scratch(ctx, CPM_SCR_SORT_HIST, ctl_words * 4);
+    if (!ctl) return nullptr;
+    *num_tiles_out = num_tiles;
+    return ctl + 8 + 4 * kRadix;
+}
+
 int radix_sort(cpm_ctx* ctx, uint32_t* keys, uint32_t* vals, size_t n, int key_bits, hipStream_t s,
-               uint32_t** res_keys, uint32_t** res_vals, const BinSink* sink, bool* sink_done) {
+               uint32_t** res_keys, uint32_t** res_vals, const BinSink* sink, bool* sink_done, bool first_hist_done) {
     if (res_keys) *res_keys = keys;
     if (res_vals) *res_vals = vals;
     if (sink_done) *sink_done = false;
     if (n <= 1) return CPM_OK;
     if (n >= (1ull << 31)) return set_error(ctx, CPM_ERR_INVALID_ARGUMENT, "radix_sort", "n must be < 2^31");
     if (key_bits <= 0 || key_bits > 32) key_bits = 32;
-    if (g_sort_items == 4) return sort_passes<4>(ctx, keys, vals, (uint32_t)n, key_bits, s, res_keys, res_vals, sink, sink_done);
-    if (g_sort_items == 16) return sort_passes<16>(ctx, keys, vals, (uint32_t)n, key_bits, s, res_keys, res_vals, sink, sink_done);
-    // tile = 256 threads x ITEMS keys.  Measured at 1 M pairs, 22 key bits (3 passes + copy-back):
-    // ITEMS 4: 73 us, 8: 61 us, 16: 70 us -- 2048-key tiles balance table size against workgroup count.
-    if (n <= (1u << 15)) return sort_passes<4>(ctx, keys, vals, (uint32_t)n, key_bits, s, res_keys, res_vals, sink, sink_done);
-    if (n <= (1u << 23) || g_sort_items == 8) return sort_passes<8>(ctx, keys, vals, (uint32_t)n, key_bits, s, res_keys, res_vals, sink, sink_done);
-    return sort_passes<16>(ctx, keys, vals, (uint32_t)n, key_bits, s, res_keys, res_vals, sink, sink_done);
+    switch (sort_items_for(n)) {
+        case 4: return sort_passes<4>(ctx, keys, vals, (uint32_t)n, key_bits, s, res_keys, res_vals, sink, sink_done, first_hist_done);
+        case 8: return sort_passes<8>(ctx, keys, vals, (uint32_t)n, key_bits, s, res_keys, res_vals, sink, sink_done, first_hist_done);
+        default: return sort_passes<16>(ctx, keys, vals, (uint32_t)n, key_bits, s, res_keys, res_vals, sink, sink_done, first_hist_done);
+    }
 }
 
 }  // namespace cpm
@@ -372,13 +392,13 @@ void cpm_debug_set_sort_items(int items) { cpm::g_sort_items = items; }
 int cpm_sort_pairs(cpm_ctx* ctx, uint32_t* keys, uint32_t* values, size_t n, int key_bits, cpm_stream stream) {
     if (!ctx) return CPM_ERR_INVALID_ARGUMENT;
     CPM_REQUIRE(ctx, (keys && values) || n == 0, "cpm_sort_pairs: null argument");
-    return cpm::radix_sort(ctx, keys, values, n, key_bits, (hipStream_t)stream, nullptr, nullptr, nullptr, nullptr);
+    return cpm::radix_sort(ctx, keys, values, n, key_bits, (hipStream_t)stream, nullptr, nullptr, nullptr, nullptr, false);
 }
 
 int cpm_sort_keys(cpm_ctx* ctx, uint32_t* keys, size_t n, int key_bits, cpm_stream stream) {
     if (!ctx) return CPM_ERR_INVALID_ARGUMENT;
     CPM_REQUIRE(ctx, keys || n == 0, "cpm_sort_keys: null argument");
-    return cpm::radix_sort(ctx, keys, nullptr, n, key_bits, (hipStream_t)stream, nullptr, nullptr, nullptr, nullptr);
+    return cpm::radix_sort(ctx, keys, nullptr, n, key_bits, (hipStream_t)stream, nullptr, nullptr, nullptr, nullptr, false);
 }
 
 }  // extern "C"
