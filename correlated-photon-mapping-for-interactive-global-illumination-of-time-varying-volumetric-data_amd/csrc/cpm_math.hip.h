@@ -181,11 +181,11 @@ CPM_DEV float density_kernel_(float x) { return x <= 1.f ? 0.75f * (1.f - x * x)
 constexpr uint32_t kMwcA = 4294883355u;
 CPM_DEV uint32_t mwc_next_(uint32_t& x, uint32_t& c) {
     uint32_t res = x ^ c;
-    uint32_t xn = kMwcA * x + c;
-    uint32_t carry = (uint32_t)(xn < c);
-    uint32_t cn = __umulhi(kMwcA, x) + carry;
-    x = xn;
-    c = cn;
+    // x' = lo(A x + c), c' = hi(A x + c): one v_mad_u64_u32 instead of mul_lo + mul_hi + add + addc
+    // (32-bit integer multiplies issue at quarter rate: this is 8 of them per Woodcock step otherwise)
+    const uint64_t t = (uint64_t)kMwcA * (uint64_t)x + (uint64_t)c;
+    x = (uint32_t)t;
+    c = (uint32_t)(t >> 32);
     return res;
 }
 // random_01: uint -> float (RNE) / 4294967295.0f; the divisor rounds to 2^32, so the
