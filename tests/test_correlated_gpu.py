@@ -8,9 +8,22 @@ pytestmark = pytest.mark.gpu
 FLT_MAX = np.float32(3.402823466e+38)
 
 
+@pytest.mark.parametrize("streaming", [1, 0])
 @pytest.mark.parametrize("shape,dtype,region", [((64, 64, 64), np.uint8, 8), ((19, 33, 50), np.uint8, 8),
-                                                 ((32, 32, 32), np.uint16, 4), ((24, 24, 24), np.float32, 8)])
-def test_volume_minmax_and_difference(ctx, oracle, shape, dtype, region):
+                                                 ((32, 32, 32), np.uint16, 4), ((24, 24, 24), np.float32, 8),
+                                                 ((21, 30, 48), np.uint8, 8),      # aligned rows, bricks clipped in y and z
+                                                 ((17, 9, 32), np.uint8, 5),       # bricks that straddle 16-byte chunks
+                                                 ((10, 12, 40), np.uint16, 16), ((12, 20, 36), np.float32, 3),
+                                                 ((8, 8, 16), np.uint8, 1)])
+def test_volume_minmax_and_difference(ctx, oracle, shape, dtype, region, streaming):
+    ctx.lib.cpm_debug_set_brick_streaming(streaming)
+    try:
+        _minmax_difference_case(ctx, oracle, shape, dtype, region)
+    finally:
+        ctx.lib.cpm_debug_set_brick_streaming(1)
+
+
+def _minmax_difference_case(ctx, oracle, shape, dtype, region):
     rng = np.random.default_rng(sum(shape))
     if dtype == np.float32:
         a, b = rng.random(shape, dtype=np.float32), rng.random(shape, dtype=np.float32)
