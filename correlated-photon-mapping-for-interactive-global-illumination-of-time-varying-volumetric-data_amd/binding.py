@@ -36,7 +36,7 @@ ABI_SYMBOLS = [
     "cpm_sort_pairs", "cpm_sort_keys", "cpm_bin", "cpm_gather",
     "cpm_volume_minmax", "cpm_volume_difference", "cpm_importance_tf",
     "cpm_photon_importance", "cpm_photon_importance_equal", "cpm_reset_importance",
-    "cpm_select_recompute",
+    "cpm_select_recompute", "cpm_select_changed",
     "cpm_mix_buffers", "cpm_volume_mix",
 ]
 
@@ -121,6 +121,7 @@ def load_library() -> C.CDLL:
         "cpm_photon_importance_equal": (i32, [vp, i32, i32, i32, i32, vp, vp]),
         "cpm_reset_importance": (i32, [vp, vp, sz, sz, vp]),
         "cpm_select_recompute": (i32, [vp, vp, sz, vp, vp, vp]),
+        "cpm_select_changed": (i32, [vp, vp, sz, vp, vp, vp]),
         "cpm_mix_buffers": (i32, [vp, vp, vp, f32, sz, i32, vp, vp]),
         "cpm_volume_mix": (i32, [vp, vp, vp, f32, vp, vp]),
         "cpm_volume_device_data": (vp, [vp, P(sz)]),
@@ -402,6 +403,10 @@ class Context:
 
     def reset_importance(self, importances, offset, n):
         self._check(self.lib.cpm_reset_importance(self.h, self._ptr(importances), offset, n, self._stream()))
+
+    def select_changed(self, importances, indices_out, n_changed):
+        self._check(self.lib.cpm_select_changed(self.h, self._ptr(importances), importances.numel(), self._ptr(indices_out),
+                                                self._ptr(n_changed), self._stream()))
 
     def select_recompute(self, importances, indices_out, n_changed):
         self._check(self.lib.cpm_select_recompute(self.h, self._ptr(importances), importances.numel(), self._ptr(indices_out),

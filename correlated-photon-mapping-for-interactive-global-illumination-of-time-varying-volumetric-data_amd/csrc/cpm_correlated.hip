@@ -389,6 +389,19 @@ __global__ __launch_bounds__(256) void threshold_count_iota_kernel(const uint32_
     if ((threadIdx.x & 63) == 0 && m) atomicAdd(count, (int)__popcll(m));
 }
 
+// cpm_select_changed: flag = 0 for a photon whose importance says "re-trace" (key < 0x7fffffff), 1 otherwise; iota.
+// One stable radix pass over the flag then partitions the indices (changed first, both parts ascending) and its
+// digit total IS the count -- no atomics, no 31-bit sort.
+__global__ __launch_bounds__(256) void changed_flag_iota_kernel(const uint32_t* __restrict__ imp, size_t n,
+                                                                uint32_t* __restrict__ flag, uint32_t* __restrict__ idx) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { flag[i] = imp[i] < 2147483647u ? 0u : 1u; idx[i] = (uint32_t)i; }
+}
+__global__ void select_single_kernel(const uint32_t* __restrict__ imp, uint32_t* __restrict__ idx, int32_t* __restrict__ count) {
+    idx[0] = 0u;
+    *count = imp[0] < 2147483647u ? 1 : 0;
+}
+
 int make_brick_vol(cpm_ctx* ctx, const cpm_volume* vol, int region, BrickVol& V) {
     if (!vol) return set_error(ctx, CPM_ERR_INVALID_ARGUMENT, "volume", "null");
     if (region < 1 || region > 64) return set_error(ctx, CPM_ERR_INVALID_ARGUMENT, "region", "must be in [1, 64]");
@@ -542,6 +555,33 @@ int cpm_select_recompute(cpm_ctx* ctx, uint32_t* importances, size_t n, uint32_t
     CPM_LAUNCH_CHECK(ctx, "threshold_count_iota_kernel");
     // keys are <= 0x7fffffff: 31 significant bits
     return cpm::radix_sort(ctx, importances, indices_out, n, 31, s, nullptr, nullptr, nullptr, nullptr, false);
+}
+
+int cpm_select_changed(cpm_ctx* ctx, const uint32_t* importances, size_t n, uint32_t* indices_out, int32_t* n_changed_dev,
+                       cpm_stream stream) {
+    if (!ctx) return CPM_ERR_INVALID_ARGUMENT;
+    CPM_REQUIRE(ctx, n_changed_dev, "cpm_select_changed: null counter");
+    CPM_REQUIRE(ctx, n < (1ull << 31), "cpm_select_changed: n must be < 2^31");
+    hipStream_t s = (hipStream_t)stream;
+    if (n == 0) { CPM_HIP_CHECK(ctx, hipMemsetAsync(n_changed_dev, 0, sizeof(int32_t), s)); return CPM_OK; }
+    CPM_REQUIRE(ctx, importances && indices_out, "cpm_select_changed: null buffer");
+    if (n == 1) {
+        CPM_LAUNCH(ctx, select_single_kernel, dim3(1), dim3(1), 0, s, importances, indices_out, n_changed_dev);
+        CPM_LAUNCH_CHECK(ctx, "select_single_kernel");
+        return CPM_OK;
+    }
+    uint32_t* flags = (uint32_t*)scratch(ctx, CPM_SCR_MISC, n * sizeof(uint32_t));
+    if (!flags) return CPM_ERR_OUT_OF_MEMORY;
+    CPM_LAUNCH(ctx, changed_flag_iota_kernel, dim3(div_up((long long)n, 256)), dim3(256), 0, s, importances, n, flags, indices_out);
+    CPM_LAUNCH_CHECK(ctx, "changed_flag_iota_kernel");
+    uint32_t *rk = nullptr, *rv = nullptr;
+    int rc = cpm::radix_sort(ctx, flags, indices_out, n, 1, s, &rk, &rv, nullptr, nullptr, false);
+    if (rc) return rc;
+    if (rv != indices_out) CPM_HIP_CHECK(ctx, hipMemcpyAsync(indices_out, rv, n * sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
+    const uint32_t* totals = cpm::sort_last_digit_totals(ctx, n);
+    CPM_REQUIRE(ctx, totals, "cpm_select_changed: not available in the onesweep sort test mode");
+    CPM_HIP_CHECK(ctx, hipMemcpyAsync(n_changed_dev, totals, sizeof(int32_t), hipMemcpyDeviceToDevice, s));  // keys with flag 0
+    return CPM_OK;
 }
 
 }  // extern "C"

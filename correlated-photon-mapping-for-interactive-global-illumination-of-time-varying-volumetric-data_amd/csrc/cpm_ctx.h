@@ -105,6 +105,7 @@ int radix_sort(cpm_ctx* ctx, uint32_t* keys, uint32_t* vals, size_t n, int key_b
                uint32_t** res_keys, uint32_t** res_vals, const BinSink* sink, bool* sink_done, bool first_hist_done);
 int sort_items_for(size_t n);
 uint32_t* sort_first_hist(cpm_ctx* ctx, size_t n, int key_bits, uint32_t* num_tiles_out);
+const uint32_t* sort_last_digit_totals(cpm_ctx* ctx, size_t n);
 
 // device-side grid description
 struct GridDev {

@@ -366,6 +366,16 @@ uint32_t* sort_first_hist(cpm_ctx* ctx, size_t n, int key_bits, uint32_t* num_ti
     return ctl + 8 + 4 * kRadix;
 }
 
+// After a sort of n > 1 keys in the default pass structure: digit_total[d] of the LAST pass (keys per digit value),
+// device memory inside the sort's scratch block, valid until the next sort on this context.
+const uint32_t* sort_last_digit_totals(cpm_ctx* ctx, size_t n) {
+    if (n <= 1 || g_sort_mode == 1) return nullptr;
+    const uint32_t tile = kSortThreads * (uint32_t)sort_items_for(n);
+    const uint32_t num_tiles = ((uint32_t)n + tile - 1) / tile;
+    const uint32_t* ctl = (const uint32_t*)ctx->scratch[CPM_SCR_SORT_HIST];
+    return ctl ? ctl + 8 + 4 * kRadix + (size_t)num_tiles * kRadix : nullptr;
+}
+
 int radix_sort(cpm_ctx* ctx, uint32_t* keys, uint32_t* vals, size_t n, int key_bits, hipStream_t s,
                uint32_t** res_keys, uint32_t** res_vals, const BinSink* sink, bool* sink_done, bool first_hist_done) {
     if (res_keys) *res_keys = keys;

@@ -578,12 +578,20 @@ void ProgressivePhotonTracerCL::process() {  // progressivephotontracercl.cpp:21
                 photonRecomputationDetector_.photonRecomputationImportance(photonData_.get(), offset, volume, grid.get(), *l, photonRecomputationImportance_);
                 offset += (int)l->getSize();
             }
-            // threshold + count + iota + sort by importance, fused; the count is read once (Q10)
-            rt.check(cpm_select_recompute(rt.ctx(), photonRecomputationImportance_.device(), photonRecomputationImportance_.getSize(),
-                                          recomputedPhotonIndices_->indicesToRecomputedPhotons.device(), nChanged_.device(), rt.stream()),
-                     "cpm_select_recompute");
+            // threshold + count + iota as one stable partition (changed photons first, ascending); the count is read
+            // once (Q10).  The 31-bit sort by importance (sortIndicesByImportance, :358-363) runs only when the changed
+            // photons exceed this evaluation's budget -- otherwise all of them are traced now, in index order.
+            rt.check(cpm_select_changed(rt.ctx(), photonRecomputationImportance_.device(), photonRecomputationImportance_.getSize(),
+                                        recomputedPhotonIndices_->indicesToRecomputedPhotons.device(), nChanged_.device(), rt.stream()),
+                     "cpm_select_changed");
             nChanged_.download(rt.stream());
             const int nPhotonsToRecompute = nChanged_.ram()[0];
+            const int budget = (int)((maxIncrementalPhotonsToUpdate_.get() / 100.f) * (float)photonData_->getNumberOfPhotons());
+            rankedByImportance_ = nPhotonsToRecompute > budget;
+            if (rankedByImportance_)
+                rt.check(cpm_select_recompute(rt.ctx(), photonRecomputationImportance_.device(), photonRecomputationImportance_.getSize(),
+                                              recomputedPhotonIndices_->indicesToRecomputedPhotons.device(), nChanged_.device(), rt.stream()),
+                         "cpm_select_recompute");
             remainingPhotonsOffset_ = 0;
             if (remainingPhotonsToUpdate_ < 0 || nPhotonsToRecompute > 0) remainingPhotonsToUpdate_ = nPhotonsToRecompute;
         }
@@ -594,7 +602,7 @@ void ProgressivePhotonTracerCL::process() {  // progressivephotontracercl.cpp:21
             (void)hipMemcpyAsync(idx, idx + remainingPhotonsOffset_, nPhotonsToCompute * sizeof(unsigned int), hipMemcpyDeviceToDevice, rt.stream());
         recomputedPhotonIndices_->nRecomputedPhotons = (int)nPhotonsToCompute;
         if (recomputedPhotonIndices_->nRecomputedPhotons > 0) {
-            if (spatialSorting_.get())  // ascending index = emission-lattice order (:467-473)
+            if (spatialSorting_.get() && rankedByImportance_)  // ascending index = emission-lattice order (:467-473)
                 rt.check(cpm_sort_keys(rt.ctx(), idx, nPhotonsToCompute, 0, rt.stream()), "cpm_sort_keys");
             int offset = 0;
             for (auto& l : lights) {
@@ -603,7 +611,8 @@ void ProgressivePhotonTracerCL::process() {  // progressivephotontracercl.cpp:21
                                            maxInteractions, photonData_.get());
                 offset += (int)l->getSize();
             }
-            resetPhotonImportance((size_t)remainingPhotonsOffset_, nPhotonsToCompute);
+            if (rankedByImportance_) resetPhotonImportance((size_t)remainingPhotonsOffset_, nPhotonsToCompute);
+            else resetPhotonImportance(0, photonRecomputationImportance_.getSize());  // every changed photon was traced
         }
         remainingPhotonsOffset_ += (int)nPhotonsToCompute;
         remainingPhotonsToUpdate_ -= (int)nPhotonsToCompute;

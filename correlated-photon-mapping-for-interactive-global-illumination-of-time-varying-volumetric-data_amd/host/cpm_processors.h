@@ -390,6 +390,7 @@ private:
     PhotonData::InvalidationReason invalidationFlag_ = PhotonData::InvalidationReason::All;
     float aabb_[8] = { 0, 0, 0, 1, 1, 1, 1, 1 };
     int remainingPhotonsOffset_ = 0, remainingPhotonsToUpdate_ = -1;
+    bool rankedByImportance_ = true;  // indices / importances are sorted by importance (cpm_select_recompute ran)
     std::vector<std::pair<const LightSamples*, size_t>> seenLights_;  // (samples, change stamp) at the last evaluation
 };
 

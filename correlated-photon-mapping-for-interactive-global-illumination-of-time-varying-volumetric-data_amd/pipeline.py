@@ -438,11 +438,18 @@ class CorrelatedPhotonMapper(PhotonFrame):
         ctx.photon_importance(self.importance_grid, self.brick_dims, (float(self.region),) * 3,
                               list(self.vol.desc.texture_to_index), self.photons, 0, self.light_samples, self.isect,
                               n_total, self.I, n_total, self.importance, fix_exit_point=self.fix_exit_point)
-        ctx.select_recompute(self.importance, self.indices, self.n_changed)
-        n_changed = int(self.n_changed.item())              # the reference's single host sync (tracercl.cpp:374)
+        # The changed photons, ascending: one radix pass over a flag; the count is read once (the reference's single
+        # host sync, tracercl.cpp:374).  Ranking them by importance only matters when they do not all fit this
+        # evaluation's budget -- otherwise the batch is re-sorted by index for the trace anyway (:467-473).
+        ctx.select_changed(self.importance, self.indices, self.n_changed)
+        n_changed = int(self.n_changed.item())
         self.remaining_offset = 0
         if self.remaining < 0 or n_changed > 0:
             self.remaining = n_changed
+        max_update = int((self.max_incremental_percent / 100.0) * n_total)
+        if n_changed <= max_update:
+            return self._retrace_batch(ranked=False)
+        ctx.select_recompute(self.importance, self.indices, self.n_changed)   # thresholdKernel ... sortIndicesByImportance
         return self._retrace_batch()
 
     def continue_update(self):
@@ -451,7 +458,9 @@ class CorrelatedPhotonMapper(PhotonFrame):
             return 0
         return self._retrace_batch()
 
-    def _retrace_batch(self):
+    def _retrace_batch(self, ranked=True):
+        """ranked: self.indices / self.importance are sorted by importance (cpm_select_recompute); otherwise
+        self.indices[:remaining] is the complete, ascending list of changed photons (cpm_select_changed)."""
         ctx, torch = self.ctx, self.torch
         n_total = self.n
         max_update = int((self.max_incremental_percent / 100.0) * n_total)
@@ -459,12 +468,15 @@ class CorrelatedPhotonMapper(PhotonFrame):
         self.n_recomputed = n
         if n > 0:
             idx = self.indices[self.remaining_offset:self.remaining_offset + n].contiguous()
-            ctx.sort_keys(idx, 0)                            # ascending index = emission-lattice order (:467-473)
+            if ranked:
+                ctx.sort_keys(idx, 0)                        # ascending index = emission-lattice order (:467-473)
             self.params.flags = 0                            # correlated: RNG state is NOT written back
             ctx.trace(self.vol, self.tf, self.aabb, self.params, self.light_samples, self.isect, self.rng, self.photons,
                       recompute_indices=idx, n_recompute=n)
-            # importance is sorted alongside the indices: entries [offset, offset+n) belong to the re-traced photons
-            ctx.reset_importance(self.importance, self.remaining_offset, n)
+            if ranked:  # importance is sorted alongside the indices: entries [offset, offset+n) belong to the re-traced photons
+                ctx.reset_importance(self.importance, self.remaining_offset, n)
+            else:       # every changed photon was re-traced
+                ctx.reset_importance(self.importance, 0, n_total)
             self._update_light_volume(idx, n)
         self.remaining_offset += n
         self.remaining -= n

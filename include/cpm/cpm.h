@@ -332,6 +332,18 @@ int cpm_reset_importance(cpm_ctx* ctx, uint32_t* importances, size_t offset, siz
 int cpm_select_recompute(cpm_ctx* ctx, uint32_t* importances, size_t n, uint32_t* indices_out,
                          int32_t* n_changed_dev, cpm_stream stream);
 
+/* The changed photons only: indices_out = [photons with importance key < 0x7fffffff, ascending index |
+ * the others, ascending index], *n_changed_dev = size of the first part; `importances` is not modified.
+ * When every changed photon fits the update budget (the usual case after a small edit) their
+ * importance ORDER is irrelevant -- the tracer re-sorts the batch by index anyway
+ * (ref processor/progressivephotontracercl.cpp:467-473) -- so the caller can use this instead of
+ * cpm_select_recompute's 31-bit sort and fall back to it only when n_changed exceeds the budget:
+ * one stable radix pass over a 1-bit flag, the count is that pass's digit total (no atomics).
+ * Replaces thresholdKernel + clogs::Reduce + indexToBufferKernel
+ * (ref cl/threshold.cl:33-40, cl/indextobuffer.cl:33-40, ...tracercl.cpp:325-356). */
+int cpm_select_changed(cpm_ctx* ctx, const uint32_t* importances, size_t n, uint32_t* indices_out,
+                       int32_t* n_changed_dev, cpm_stream stream);
+
 /* ------------------------------------------------------------------ temporal interpolation (time-varying data) */
 
 typedef enum cpm_mix_type { CPM_MIX_F32 = 0, CPM_MIX_U16X2 = 1 } cpm_mix_type;

@@ -1014,6 +1014,15 @@ void cpmo_select_recompute(uint32_t* importances, size_t n, uint32_t* indices_ou
     *n_changed = cnt;
 }
 
+/* the selection without the ranking: changed photons first, both parts in ascending index order
+ * (cl/threshold.cl:33-40 + count + cl/indextobuffer.cl:33-40, followed by a stable partition) */
+void cpmo_select_changed(const uint32_t* importances, size_t n, uint32_t* indices_out, int32_t* n_changed) {
+    size_t k = 0;
+    for (size_t i = 0; i < n; ++i) if (importances[i] < 2147483647u) indices_out[k++] = (uint32_t)i;
+    *n_changed = (int32_t)k;
+    for (size_t i = 0; i < n; ++i) if (!(importances[i] < 2147483647u)) indices_out[k++] = (uint32_t)i;
+}
+
 /* ---------------------------------------------------------------------------------------------
  * temporal interpolation */
 

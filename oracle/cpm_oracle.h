@@ -140,6 +140,9 @@ void cpmo_photon_importance_equal(int photon_offset, int n_light_samples, int pe
 void cpmo_select_recompute(uint32_t* importances, size_t n, uint32_t* indices_out,
                            int32_t* n_changed);
 
+void cpmo_select_changed(const uint32_t* importances, size_t n, uint32_t* indices_out,
+                         int32_t* n_changed);
+
 /* temporal interpolation */
 void cpmo_mix_f32(const float* x, const float* y, float a, size_t n, float* out);
 void cpmo_mix_u16x2(const uint16_t* x, const uint16_t* y, float a, size_t n_pairs, uint16_t* out);

@@ -291,6 +291,13 @@ class Oracle:
         return idx, cnt.value
 
 
+    def select_changed(self, importances):
+        idx = np.zeros(importances.size, np.uint32)
+        cnt = C.c_int32(0)
+        self.lib.cpmo_select_changed(_p(np.ascontiguousarray(importances, np.uint32)), importances.size, _p(idx), C.byref(cnt))
+        return idx, cnt.value
+
+
 class Ref:
     """The reference's own kernels (oracle/_ref), when that build exists."""
 

@@ -284,3 +284,21 @@ def test_sharded_correlated_update(ctx, cpm):
     lv2 = _n(whole.light_volume)
     np.testing.assert_allclose(sum(_n(s.light_volume) for s in shards), lv2, rtol=1e-3, atol=2e-5 * float(lv2.max()))
     assert np.abs(lv2 - lv).max() > 0
+
+
+@pytest.mark.parametrize("n,frac", [(1, 1.0), (1, 0.0), (2, 0.5), (1000, 0.0), (1000, 1.0), (70_001, 0.013), (300_000, 0.4)])
+def test_select_changed(ctx, oracle, n, frac):
+    """cpm_select_changed: changed photons first, both parts in ascending index order, the importances untouched."""
+    rng = np.random.default_rng(n)
+    imp = np.full(n, 2147483647, np.uint32)
+    pick = rng.random(n) < frac
+    imp[pick] = rng.integers(0, 2147483647, int(pick.sum()), dtype=np.uint32)
+    imp_d = _t(ctx, imp.view(np.int32))
+    idx = ctx.torch.full((n,), -1, dtype=ctx.torch.int32, device=ctx.device)
+    cnt = ctx.torch.full((1,), -7, dtype=ctx.torch.int32, device=ctx.device)
+    for _ in range(2):
+        ctx.select_changed(imp_d, idx, cnt)
+        want_idx, want_cnt = oracle.select_changed(imp)
+        assert int(cnt.item()) == want_cnt == int(pick.sum())
+        assert np.array_equal(_n(idx, np.uint32), want_idx)
+        assert np.array_equal(_n(imp_d, np.uint32), imp)
