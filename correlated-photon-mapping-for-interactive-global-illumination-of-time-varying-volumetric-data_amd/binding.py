@@ -130,6 +130,7 @@ def load_library() -> C.CDLL:
         "cpm_debug_set_step_counter": (None, [vp]),
         "cpm_debug_set_gather_stamps": (None, [vp]),
         "cpm_debug_force_voxel_gather": (None, [i32]),
+        "cpm_debug_set_gather_coop": (None, [i32]),
         "cpm_debug_set_brick_streaming": (None, [i32]),
         "cpm_debug_set_bin_fused": (None, [i32]),
         "cpm_debug_set_sort_mode": (None, [i32]),

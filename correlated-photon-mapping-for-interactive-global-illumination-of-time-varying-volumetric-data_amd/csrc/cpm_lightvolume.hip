@@ -728,6 +728,227 @@ __global__ __launch_bounds__(256) void gather_records2_kernel(const float* __res
     out[v] = accumulate ? out[v] + sum : sum;
 }
 
+// ---- cooperative record-major gather --------------------------------------------------------------------
+// gather_records2_kernel ends when its heaviest bricks do: photons pile up on faces, a face brick holds 1000+
+// records, and ONE wave walks them 64 at a time -- 16+ dependent steps of ~650 instructions (45-68 us of the
+// kernel's 80) while most SIMDs have run dry.  Here a workgroup's four waves own four bricks TOGETHER:
+//   * the bricks of a workgroup are taken from four z-slabs a quarter of the grid apart (one near a face, three
+//     further in), so workgroups carry similar amounts of work;
+//   * phase 0: wave b builds brick b's row tables in LDS (as before); barrier;
+//   * phase 1: the steps of the four bricks form one sequence g = 0, 1, ...; wave w takes g = w, w+4, ...:
+//     it loads the 64 records of step g and evaluates their candidates into ITS OWN slot matrix and masks --
+//     the expensive part, now four steps at a time per workgroup whatever brick they belong to;
+//   * the drains must stay in record order per voxel (the summation contract), so they take turns: a wave waits
+//     until the LDS turn counter reaches g, its voxel lanes add the step's contributions to the brick's running
+//     sums in LDS, and it passes the turn on.  All four waves are resident (one workgroup), the holder of the
+//     turn never waits: no deadlock;
+//   * phase 2: wave b writes brick b's sums.
+// Same additions in the same order as gather_records2_kernel: bit-identical results.
+__global__ __launch_bounds__(256) void gather_coop_kernel(const float* __restrict__ sorted,
+                                                          const uint32_t* __restrict__ cell_start, GridDev G, float radius,
+                                                          float r2max, float k, int Rx, int Ry, int Rz, int accumulate,
+                                                          int bxn, int byn, int bzn, int zq, float* __restrict__ out,
+                                                          unsigned long long* __restrict__ dbg) {
+    constexpr int MAXROWS = 64;
+    constexpr int MAXWORDS = 64;  // row-start bitmask: up to 4096 records per brick halo, else a binary search
+    __shared__ float s_val_all[4][8][64];               // per WAVE: this step's contributions by target parity
+    __shared__ unsigned long long s_mask_all[4][64];    // per WAVE: this step's contributor lanes per voxel
+    __shared__ unsigned long long s_start_all[4][MAXWORDS];  // per BRICK
+    __shared__ uint32_t s_rb_all[4][MAXWORDS];          // per BRICK: non-empty rows that start before step w
+    __shared__ uint32_t s_rowjb_all[4][MAXROWS];        // per BRICK, compacted non-empty rows: jb - exclusive offset
+    __shared__ uint32_t s_rowoff_all[4][MAXROWS];       // per BRICK: exclusive offset
+    __shared__ float s_sum_all[4][64];                  // per BRICK: running per-voxel sums
+    __shared__ uint32_t s_total[4], s_nne[4];
+    __shared__ uint32_t s_turn;
+    const unsigned long long t_start = dbg ? __builtin_amdgcn_s_memrealtime() : 0ull;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int byw = (int)blockIdx.y, bxr = (int)blockIdx.x, zj = (int)blockIdx.z;
+    // Brick b of this workgroup lies a quarter of the grid further along y AND along z (z in faces-first order) than
+    // brick b - 1: photons pile up on the faces light enters through, and a workgroup should not own four bricks of
+    // one face.  x is rotated by (y + z) so that the bricks of the x = 0 face meet every residue of blockIdx.x mod 8,
+    // i.e. every XCD (workgroups are dealt to XCDs round-robin by linear index).  For fixed b the map from
+    // (blockIdx.x, .y, .z) to bricks is a bijection onto the b-th quarter of the z-slabs: every brick exactly once.
+    const int yq = (byn + 3) >> 2;
+    auto brick_origin = [&](int b, int& x0, int& y0, int& z0) -> bool {
+        const int bzi = zj + b * zq;
+        if (bzi >= bzn) return false;
+        const int bz = (bzi & 1) ? (bzi >> 1) : (bzn - 1 - (bzi >> 1));  // bzn-1, 0, bzn-2, 1, ...
+        const int by = (byw + b * yq) % byn;
+        const int bx = (bxr + by + bzi) % bxn;
+        x0 = bx * kGW; y0 = by * kGW; z0 = bz * kGW;
+        return true;
+    };
+
+    // ---- phase 0: wave b prepares brick b
+    {
+        int x0 = 0, y0 = 0, z0 = 0;
+        const bool exists = brick_origin(wave, x0, y0, z0);
+        const int nry = kGW + 2 * Ry, nrows = nry * (kGW + 2 * Rz);
+        uint32_t jb = 0, len = 0;
+        if (exists && lane < nrows) {
+            const int rz = Ry ? (lane * 43) >> 8 : lane >> 2;  // lane / 6 (exact for lane < 64) or lane / 4
+            const int cy = y0 - Ry + (lane - rz * nry), cz = z0 - Rz + rz;
+            if (cy >= 0 && cy < G.dy && cz >= 0 && cz < G.dz) {
+                const uint32_t row = (uint32_t)G.dx * ((uint32_t)cy + (uint32_t)G.dy * (uint32_t)cz);
+                jb = cell_start[row + (uint32_t)max(x0 - Rx, 0)];
+                len = cell_start[row + (uint32_t)min(x0 + kGW - 1 + Rx, G.dx - 1) + 1] - jb;
+            }
+        }
+        uint32_t incl = len, total = 0;
+        const unsigned long long ne = __ballot(len != 0);
+        if (ne) {
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                uint32_t o = __shfl_up(incl, off, 64);
+                if (lane >= off) incl += o;
+            }
+            total = __shfl(incl, 63, 64);
+        }
+        s_sum_all[wave][lane] = 0.f;
+        s_mask_all[wave][lane] = 0ull;
+        s_start_all[wave][lane] = 0ull;
+        if (lane == 0) { s_total[wave] = total; s_nne[wave] = (uint32_t)__popcll(ne); if (wave == 0) s_turn = 0u; }
+        __builtin_amdgcn_wave_barrier();
+        if (len != 0) {
+            const uint32_t off = incl - len;
+            const int kk = __popcll(ne & ((1ull << lane) - 1ull));
+            s_rowjb_all[wave][kk] = jb - off;
+            s_rowoff_all[wave][kk] = off;
+            if (total <= (uint32_t)MAXWORDS * 64u) atomicOr(&s_start_all[wave][off >> 6], 1ull << (off & 63));
+        }
+        __builtin_amdgcn_wave_barrier();
+        // exclusive prefix over the words of the start mask: rows that start before step w
+        uint32_t pc = (uint32_t)__popcll(s_start_all[wave][lane]), pin = pc;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            uint32_t o = __shfl_up(pin, off, 64);
+            if (lane >= off) pin += o;
+        }
+        s_rb_all[wave][lane] = pin - pc;
+    }
+    __syncthreads();
+    const uint32_t T0 = s_total[0], T1 = s_total[1], T2 = s_total[2], T3 = s_total[3];
+    const uint32_t P1 = (T0 + 63) >> 6, P2 = P1 + ((T1 + 63) >> 6), P3 = P2 + ((T2 + 63) >> 6), GS = P3 + ((T3 + 63) >> 6);
+
+    // ---- phase 1: steps g = wave, wave + 4, ... of the workgroup's sequence
+    const float4* __restrict__ rec = reinterpret_cast<const float4*>(sorted);
+    const float rgx = radius * (float)G.dx + 1e-3f, rgy = radius * (float)G.dy + 1e-3f, rgz = radius * (float)G.dz + 1e-3f;
+    const int my_par = (lane & 1) | (((lane >> 2) & 1) << 1) | (((lane >> 4) & 1) << 2);  // brick origins are even
+    float (*s_val)[64] = s_val_all[wave];
+    unsigned long long* s_mask = s_mask_all[wave];
+    for (uint32_t g = (uint32_t)wave; g < GS; g += 4) {
+        const int b = g < P1 ? 0 : (g < P2 ? 1 : (g < P3 ? 2 : 3));
+        const uint32_t w = g - (b == 0 ? 0u : (b == 1 ? P1 : (b == 2 ? P2 : P3)));
+        const uint32_t total = b == 0 ? T0 : (b == 1 ? T1 : (b == 2 ? T2 : T3));
+        int x0 = 0, y0 = 0, z0 = 0;
+        brick_origin(b, x0, y0, z0);
+        const int x1 = min(x0 + kGW - 1, G.dx - 1), y1 = min(y0 + kGW - 1, G.dy - 1), z1 = min(z0 + kGW - 1, G.dz - 1);
+        const uint32_t i = w * 64u + lane;
+        const bool have = i < total;
+        uint32_t j;
+        if (total <= (uint32_t)MAXWORDS * 64u) {
+            const unsigned long long sb = s_start_all[b][w];
+            const int kk = max((int)s_rb_all[b][w] + __popcll(sb & ((2ull << lane) - 1ull)) - 1, 0);
+            j = s_rowjb_all[b][kk] + i;
+        } else {
+            int lo = 0, hi = (int)s_nne[b] - 1;
+            for (int it = 0; it < 6; ++it) {
+                const int mid = (lo + hi + 1) >> 1;
+                if (s_rowoff_all[b][mid] <= i) lo = mid; else hi = mid - 1;
+            }
+            j = s_rowjb_all[b][lo] + i;
+        }
+        float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (have) a = rec[j];
+        const f3 p = { a.x, a.y, a.z };
+        const f3 u = transform_(G.t2i, p);
+        const int sx = max((int)__builtin_ceilf(u.x - rgx), x0), ex = min((int)__builtin_floorf(u.x + rgx), x1);
+        const int sy = max((int)__builtin_ceilf(u.y - rgy), y0), ey = min((int)__builtin_floorf(u.y + rgy), y1);
+        const int sz = max((int)__builtin_ceilf(u.z - rgz), z0), ez = min((int)__builtin_floorf(u.z + rgz), z1);
+        const int nx = have ? max(ex - sx + 1, 0) : 0, ny = max(ey - sy + 1, 0), nz = max(ez - sz + 1, 0);
+        const Box3 bb = splat_box(G, p, radius);
+        const float pk = a.w * k;
+        float dxv[2], dyv[2], dzv[2];
+        bool okx[2], oky[2], okz[2];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int vx = sx + q, vy = sy + q, vz = sz + q;
+            dxv[q] = fma_(G.i2t.sx, (float)vx, G.i2t.tx) - a.x;
+            dyv[q] = fma_(G.i2t.sy, (float)vy, G.i2t.ty) - a.y;
+            dzv[q] = fma_(G.i2t.sz, (float)vz, G.i2t.tz) - a.z;
+            okx[q] = q < nx && vx >= bb.sx && vx < bb.ex;
+            oky[q] = q < ny && vy >= bb.sy && vy < bb.ey;
+            okz[q] = q < nz && vz >= bb.sz && vz < bb.ez;
+        }
+        const int vl0 = (sx - x0) + 4 * (sy - y0) + 16 * (sz - z0);
+        const int par0 = (sx & 1) | ((sy & 1) << 1) | ((sz & 1) << 2);
+        float d2c[8];
+        uint32_t hits = 0;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const int qx = c & 1, qy = (c >> 1) & 1, qz = c >> 2;
+            d2c[c] = fma_(dzv[qz], dzv[qz], fma_(dyv[qy], dyv[qy], dxv[qx] * dxv[qx]));
+            if (okx[qx] && oky[qy] && okz[qz] && d2c[c] <= r2max) hits |= 1u << c;  // d2 > r2max: exactly no contribution
+        }
+        while (__any(hits != 0)) {
+            if (hits != 0) {
+                const int c = __builtin_ctz(hits);
+                hits &= hits - 1;
+                float d2 = d2c[0];
+#pragma unroll
+                for (int q = 1; q < 8; ++q) d2 = (c == q) ? d2c[q] : d2;
+                const float wgt = density_kernel_(__builtin_sqrtf(d2) / radius);
+                const float val = pk * wgt;
+                if (val != 0.f) {
+                    s_val[par0 ^ c][lane] = val;
+                    atomicOr(&s_mask[vl0 + (c & 1) + 4 * ((c >> 1) & 1) + 16 * (c >> 2)], 1ull << lane);
+                }
+            }
+        }
+        // ---- the drain of step g, in turn
+        while (__hip_atomic_load(&s_turn, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != g) __builtin_amdgcn_s_sleep(1);
+        unsigned long long m = s_mask[lane];
+        if (m) {
+            s_mask[lane] = 0ull;
+            const float* mine = s_val[my_par];
+            float sum = s_sum_all[b][lane];
+            do {  // up to four contributors are fetched together, then added in order
+                const int l0 = __builtin_ctzll(m); m &= m - 1;
+                const int l1 = m ? __builtin_ctzll(m) : l0; const bool h1 = m != 0; m &= m - 1;
+                const int l2 = m ? __builtin_ctzll(m) : l0; const bool h2 = m != 0; m &= m - 1;
+                const int l3 = m ? __builtin_ctzll(m) : l0; const bool h3 = m != 0; m &= m - 1;
+                const float v0 = mine[l0], v1 = mine[l1], v2 = mine[l2], v3 = mine[l3];
+                sum += v0;
+                if (h1) sum += v1;
+                if (h2) sum += v2;
+                if (h3) sum += v3;
+            } while (m);
+            s_sum_all[b][lane] = sum;
+        }
+        if (lane == 0) __hip_atomic_store(&s_turn, g + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    __syncthreads();
+
+    // ---- phase 2: wave b writes brick b
+    int x0 = 0, y0 = 0, z0 = 0;
+    if (!brick_origin(wave, x0, y0, z0)) return;
+    const int x = x0 + (lane & 3), y = y0 + ((lane >> 2) & 3), z = z0 + (lane >> 4);
+    if (dbg && lane == 0) {
+        unsigned xcc = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11));
+        const size_t gbs = (size_t)(x0 / kGW) + (size_t)bxn * ((size_t)(y0 / kGW) + (size_t)byn * (size_t)(z0 / kGW));
+        dbg[4 * gbs + 0] = t_start;
+        dbg[4 * gbs + 1] = __builtin_amdgcn_s_memrealtime();
+        dbg[4 * gbs + 2] = s_total[wave];
+        dbg[4 * gbs + 3] = xcc;
+    }
+    if (x < G.dx && y < G.dy && z < G.dz) {
+        const float sum = s_sum_all[wave][lane];
+        const uint32_t v = (uint32_t)x + (uint32_t)G.dx * ((uint32_t)y + (uint32_t)G.dy * (uint32_t)z);
+        out[v] = accumulate ? out[v] + sum : sum;
+    }
+}
+
 int key_bits_for(uint32_t max_key) {  // bits needed to represent max_key
     int b = 1;
     while (b < 32 && (max_key >> b) != 0) ++b;
@@ -745,6 +966,9 @@ void cpm_debug_set_gather_stamps(unsigned long long* dev) { g_gather_stamps = de
 // test / measurement hook: 1 (default) = the last sort pass finalises the bin, 0 = separate bin_finalize_kernel
 static int g_bin_fused = 1;
 void cpm_debug_set_bin_fused(int on) { g_bin_fused = on; }
+// 1 (default): the four waves of a workgroup share four bricks (gather_coop_kernel); 0: one wave per brick
+static int g_gather_coop = 1;
+void cpm_debug_set_gather_coop(int on) { g_gather_coop = on; }
 static int g_gather_force_voxel = 0;
 void cpm_debug_force_voxel_gather(int on) { g_gather_force_voxel = on; }
 
@@ -868,7 +1092,11 @@ int cpm_gather(cpm_ctx* ctx, const float* sorted_pos_power, const uint32_t* cell
     // candidates per axis a record can reach: floor(2 (r' + 1e-3)) + 1
     const float rmax = fmaxf(radius * (float)G.dx, fmaxf(radius * (float)G.dy, radius * (float)G.dz)) + 1e-3f;
     const int cand_axis = (int)floorf(2.f * rmax) + 1;
-    if (G.channels == 1 && cand_axis <= 2 && Rx <= 1 && Ry <= 1 && Rz <= 1 && g_gather_force_voxel == 0)
+    if (G.channels == 1 && cand_axis <= 2 && Rx <= 1 && Ry <= 1 && Rz <= 1 && g_gather_force_voxel == 0 && g_gather_coop) {
+        const int zq = div_up(bzn, 4);
+        CPM_LAUNCH(ctx, gather_coop_kernel, dim3((unsigned)bxn, (unsigned)byn, (unsigned)zq), block, 0, hs, sorted_pos_power, cell_start,
+                   G, radius, r2max, k, Rx, Ry, Rz, accumulate, bxn, byn, bzn, zq, grid_out, g_gather_stamps);
+    } else if (G.channels == 1 && cand_axis <= 2 && Rx <= 1 && Ry <= 1 && Rz <= 1 && g_gather_force_voxel == 0)
         CPM_LAUNCH(ctx, gather_records2_kernel, dim3((unsigned)div_up(bxn, 4), (unsigned)byn, (unsigned)bzn), block, 0, hs,
                    sorted_pos_power, cell_start, G, radius, r2max, k, Rx, Ry, Rz, accumulate, bxn, byn, bzn, grid_out, g_gather_stamps);
     else if (G.channels == 1 && cand_axis <= 2 && g_gather_force_voxel != 1)

@@ -429,6 +429,18 @@ def _bin_and_gather_case(ctx, oracle, cpm, dims, channels, radius_vox):
     np.testing.assert_allclose(_n(spd), sp, rtol=2e-5, atol=tol)
 
 
+@pytest.mark.parametrize("dims,radius_vox", [((32, 32, 32), 0.866), ((30, 21, 9), 0.7), ((16, 16, 16), 0.3), ((40, 12, 52), 0.8)])
+def test_gather_one_wave_per_brick_kernel(ctx, oracle, cpm, dims, radius_vox):
+    """The r < 1 voxel gather has two kernels with the same summation order: the cooperative one (default: a
+    workgroup's four waves share four bricks, drains take turns) and one wave per brick."""
+    ctx.lib.cpm_debug_set_gather_coop(0)
+    try:
+        _bin_and_gather_case(ctx, oracle, cpm, dims, 1, radius_vox)
+    finally:
+        ctx.lib.cpm_debug_set_gather_coop(1)
+    _bin_and_gather_case(ctx, oracle, cpm, dims, 1, radius_vox)
+
+
 def test_bin_empty_and_all_sentinel(ctx, oracle, cpm):
     dims = (8, 8, 8)
     g, og = cpm.binding.default_grid_desc(dims, 1), oracle.grid(dims, 1)
