@@ -744,21 +744,22 @@ __global__ __launch_bounds__(256) void gather_records2_kernel(const float* __res
 //     turn never waits: no deadlock;
 //   * phase 2: wave b writes brick b's sums.
 // Same additions in the same order as gather_records2_kernel: bit-identical results.
-__global__ __launch_bounds__(256) void gather_coop_kernel(const float* __restrict__ sorted,
+template <int NB>  // bricks = waves per workgroup
+__global__ __launch_bounds__(64 * NB) void gather_coop_kernel(const float* __restrict__ sorted,
                                                           const uint32_t* __restrict__ cell_start, GridDev G, float radius,
                                                           float r2max, float k, int Rx, int Ry, int Rz, int accumulate,
                                                           int bxn, int byn, int bzn, int zq, float* __restrict__ out,
                                                           unsigned long long* __restrict__ dbg) {
     constexpr int MAXROWS = 64;
     constexpr int MAXWORDS = 64;  // row-start bitmask: up to 4096 records per brick halo, else a binary search
-    __shared__ float s_val_all[4][8][64];               // per WAVE: this step's contributions by target parity
-    __shared__ unsigned long long s_mask_all[4][64];    // per WAVE: this step's contributor lanes per voxel
-    __shared__ unsigned long long s_start_all[4][MAXWORDS];  // per BRICK
-    __shared__ uint32_t s_rb_all[4][MAXWORDS];          // per BRICK: non-empty rows that start before step w
-    __shared__ uint32_t s_rowjb_all[4][MAXROWS];        // per BRICK, compacted non-empty rows: jb - exclusive offset
-    __shared__ uint32_t s_rowoff_all[4][MAXROWS];       // per BRICK: exclusive offset
-    __shared__ float s_sum_all[4][64];                  // per BRICK: running per-voxel sums
-    __shared__ uint32_t s_total[4], s_nne[4];
+    __shared__ float s_val_all[NB][8][64];               // per WAVE: this step's contributions by target parity
+    __shared__ unsigned long long s_mask_all[NB][64];    // per WAVE: this step's contributor lanes per voxel
+    __shared__ unsigned long long s_start_all[NB][MAXWORDS];  // per BRICK
+    __shared__ uint32_t s_rb_all[NB][MAXWORDS];          // per BRICK: non-empty rows that start before step w
+    __shared__ uint32_t s_rowjb_all[NB][MAXROWS];        // per BRICK, compacted non-empty rows: jb - exclusive offset
+    __shared__ uint32_t s_rowoff_all[NB][MAXROWS];       // per BRICK: exclusive offset
+    __shared__ float s_sum_all[NB][64];                  // per BRICK: running per-voxel sums
+    __shared__ uint32_t s_total[NB], s_nne[NB], s_first[NB + 1];
     __shared__ uint32_t s_turn;
     const unsigned long long t_start = dbg ? __builtin_amdgcn_s_memrealtime() : 0ull;
     const int lane = threadIdx.x & 63;
@@ -769,7 +770,7 @@ __global__ __launch_bounds__(256) void gather_coop_kernel(const float* __restric
     // one face.  x is rotated by (y + z) so that the bricks of the x = 0 face meet every residue of blockIdx.x mod 8,
     // i.e. every XCD (workgroups are dealt to XCDs round-robin by linear index).  For fixed b the map from
     // (blockIdx.x, .y, .z) to bricks is a bijection onto the b-th quarter of the z-slabs: every brick exactly once.
-    const int yq = (byn + 3) >> 2;
+    const int yq = (byn + NB - 1) / NB;
     auto brick_origin = [&](int b, int& x0, int& y0, int& z0) -> bool {
         const int bzi = zj + b * zq;
         if (bzi >= bzn) return false;
@@ -828,8 +829,13 @@ __global__ __launch_bounds__(256) void gather_coop_kernel(const float* __restric
         s_rb_all[wave][lane] = pin - pc;
     }
     __syncthreads();
-    const uint32_t T0 = s_total[0], T1 = s_total[1], T2 = s_total[2], T3 = s_total[3];
-    const uint32_t P1 = (T0 + 63) >> 6, P2 = P1 + ((T1 + 63) >> 6), P3 = P2 + ((T2 + 63) >> 6), GS = P3 + ((T3 + 63) >> 6);
+    if (threadIdx.x == 0) {  // first step of every brick in the workgroup's step sequence
+        uint32_t acc = 0;
+        for (int b = 0; b < NB; ++b) { s_first[b] = acc; acc += (s_total[b] + 63) >> 6; }
+        s_first[NB] = acc;
+    }
+    __syncthreads();
+    const uint32_t GS = s_first[NB];
 
     // ---- phase 1: steps g = wave, wave + 4, ... of the workgroup's sequence
     const float4* __restrict__ rec = reinterpret_cast<const float4*>(sorted);
@@ -837,10 +843,12 @@ __global__ __launch_bounds__(256) void gather_coop_kernel(const float* __restric
     const int my_par = (lane & 1) | (((lane >> 2) & 1) << 1) | (((lane >> 4) & 1) << 2);  // brick origins are even
     float (*s_val)[64] = s_val_all[wave];
     unsigned long long* s_mask = s_mask_all[wave];
-    for (uint32_t g = (uint32_t)wave; g < GS; g += 4) {
-        const int b = g < P1 ? 0 : (g < P2 ? 1 : (g < P3 ? 2 : 3));
-        const uint32_t w = g - (b == 0 ? 0u : (b == 1 ? P1 : (b == 2 ? P2 : P3)));
-        const uint32_t total = b == 0 ? T0 : (b == 1 ? T1 : (b == 2 ? T2 : T3));
+    for (uint32_t g = (uint32_t)wave; g < GS; g += NB) {
+        int b = 0;
+#pragma unroll
+        for (int q = 1; q < NB; ++q) b += (g >= s_first[q]) ? 1 : 0;
+        const uint32_t w = g - s_first[b];
+        const uint32_t total = s_total[b];
         int x0 = 0, y0 = 0, z0 = 0;
         brick_origin(b, x0, y0, z0);
         const int x1 = min(x0 + kGW - 1, G.dx - 1), y1 = min(y0 + kGW - 1, G.dy - 1), z1 = min(z0 + kGW - 1, G.dz - 1);
@@ -1093,9 +1101,19 @@ int cpm_gather(cpm_ctx* ctx, const float* sorted_pos_power, const uint32_t* cell
     const float rmax = fmaxf(radius * (float)G.dx, fmaxf(radius * (float)G.dy, radius * (float)G.dz)) + 1e-3f;
     const int cand_axis = (int)floorf(2.f * rmax) + 1;
     if (G.channels == 1 && cand_axis <= 2 && Rx <= 1 && Ry <= 1 && Rz <= 1 && g_gather_force_voxel == 0 && g_gather_coop) {
-        const int zq = div_up(bzn, 4);
-        CPM_LAUNCH(ctx, gather_coop_kernel, dim3((unsigned)bxn, (unsigned)byn, (unsigned)zq), block, 0, hs, sorted_pos_power, cell_start,
-                   G, radius, r2max, k, Rx, Ry, Rz, accumulate, bxn, byn, bzn, zq, grid_out, g_gather_stamps);
+        if (g_gather_coop == 2) {
+            const int zq = div_up(bzn, 2);
+            CPM_LAUNCH(ctx, gather_coop_kernel<2>, dim3((unsigned)bxn, (unsigned)byn, (unsigned)zq), dim3(128), 0, hs, sorted_pos_power,
+                       cell_start, G, radius, r2max, k, Rx, Ry, Rz, accumulate, bxn, byn, bzn, zq, grid_out, g_gather_stamps);
+        } else if (g_gather_coop == 8) {
+            const int zq = div_up(bzn, 8);
+            CPM_LAUNCH(ctx, gather_coop_kernel<8>, dim3((unsigned)bxn, (unsigned)byn, (unsigned)zq), dim3(512), 0, hs, sorted_pos_power,
+                       cell_start, G, radius, r2max, k, Rx, Ry, Rz, accumulate, bxn, byn, bzn, zq, grid_out, g_gather_stamps);
+        } else {
+            const int zq = div_up(bzn, 4);
+            CPM_LAUNCH(ctx, gather_coop_kernel<4>, dim3((unsigned)bxn, (unsigned)byn, (unsigned)zq), block, 0, hs, sorted_pos_power,
+                       cell_start, G, radius, r2max, k, Rx, Ry, Rz, accumulate, bxn, byn, bzn, zq, grid_out, g_gather_stamps);
+        }
     } else if (G.channels == 1 && cand_axis <= 2 && Rx <= 1 && Ry <= 1 && Rz <= 1 && g_gather_force_voxel == 0)
         CPM_LAUNCH(ctx, gather_records2_kernel, dim3((unsigned)div_up(bxn, 4), (unsigned)byn, (unsigned)bzn), block, 0, hs,
                    sorted_pos_power, cell_start, G, radius, r2max, k, Rx, Ry, Rz, accumulate, bxn, byn, bzn, grid_out, g_gather_stamps);
