@@ -25,7 +25,8 @@ void cpm_debug_set_step_counter(unsigned long long* dev_counter);
 void cpm_debug_set_gather_stamps(unsigned long long* dev_stamps);
 /* test hook: force the voxel-major gather kernel (default: record-major for 1 channel and r < 1.5 voxels) */
 void cpm_debug_force_voxel_gather(int on);
-/* r < 1 voxel gather: 1 (default) = cooperative kernel (a workgroup's waves share its bricks), 0 = one wave per brick */
+/* r < 1 voxel gather: 1 (default) = cooperative kernel (4 waves share 4 bricks) up to 64 Ki bricks, one wave per brick
+ * above; 0 = always one wave per brick; 2 / 4 / 8 = always cooperative with that many waves */
 void cpm_debug_set_gather_coop(int on);
 /* cpm_volume_minmax / cpm_volume_difference: 1 (default) = streaming brick-row kernels, 0 = one wave per brick */
 void cpm_debug_set_brick_streaming(int on);

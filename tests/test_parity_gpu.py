@@ -433,12 +433,12 @@ def _bin_and_gather_case(ctx, oracle, cpm, dims, channels, radius_vox):
 def test_gather_one_wave_per_brick_kernel(ctx, oracle, cpm, dims, radius_vox):
     """The r < 1 voxel gather has two kernels with the same summation order: the cooperative one (default: a
     workgroup's four waves share four bricks, drains take turns) and one wave per brick."""
-    ctx.lib.cpm_debug_set_gather_coop(0)
-    try:
-        _bin_and_gather_case(ctx, oracle, cpm, dims, 1, radius_vox)
-    finally:
-        ctx.lib.cpm_debug_set_gather_coop(1)
-    _bin_and_gather_case(ctx, oracle, cpm, dims, 1, radius_vox)
+    for mode in (0, 2, 8, 4):
+        ctx.lib.cpm_debug_set_gather_coop(mode)
+        try:
+            _bin_and_gather_case(ctx, oracle, cpm, dims, 1, radius_vox)
+        finally:
+            ctx.lib.cpm_debug_set_gather_coop(1)
 
 
 def test_bin_empty_and_all_sentinel(ctx, oracle, cpm):
