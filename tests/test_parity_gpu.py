@@ -441,6 +441,39 @@ def test_gather_one_wave_per_brick_kernel(ctx, oracle, cpm, dims, radius_vox):
             ctx.lib.cpm_debug_set_gather_coop(1)
 
 
+@pytest.mark.parametrize("mode", [1, 0])
+def test_gather_dense_clusters(ctx, oracle, cpm, mode):
+    """6000 photons in one cell (more records around one brick than the 4096-record row-start bitmask holds: the
+    binary-search row lookup), 600 at one identical position in a corner row, repeated launches."""
+    dims, n = (24, 20, 28), 30_000
+    rng = np.random.default_rng(5)
+    ph = _random_photons(rng, n, sentinel_every=17, spread=1.05)
+    ph[100:6100, :3] = np.float32(0.52) + (rng.random((6000, 3), dtype=np.float32) - 0.5) * np.float32(0.9 / max(dims))
+    ph[7000:7600, :3] = (np.float32(0.999), np.float32(0.001), np.float32(0.5))
+    radius = float(np.float32(0.8 / max(dims)))
+    scale = oracle.relative_irradiance_scale(radius, n)
+    g = cpm.binding.default_grid_desc(dims, 1)
+    og = oracle.grid(dims, 1)
+    cells = dims[0] * dims[1] * dims[2]
+    torch = ctx.torch
+    order = torch.empty(n, dtype=torch.int32, device=ctx.device)
+    cs = torch.empty(cells + 1, dtype=torch.int32, device=ctx.device)
+    srt = torch.empty((n, 4), dtype=torch.float32, device=ctx.device)
+    ctx.bin(_t(ctx, ph), n, g, order, cs, srt)
+    o_order, o_cs, o_srt = oracle.bin(ph, n, og)
+    assert np.array_equal(_n(order, np.uint32), o_order) and np.array_equal(_n(cs, np.uint32), o_cs)
+    want = np.zeros(cells, np.float32)
+    oracle.gather(o_srt, o_cs, n, og, radius, scale, want)
+    ctx.lib.cpm_debug_set_gather_coop(mode)
+    try:
+        for rep in range(3):
+            out = torch.full((cells,), -3.0, dtype=torch.float32, device=ctx.device)
+            ctx.gather(srt, cs, n, g, radius, scale, out)
+            assert np.array_equal(bits(_n(out)), bits(want)), rep
+    finally:
+        ctx.lib.cpm_debug_set_gather_coop(1)
+
+
 def test_bin_empty_and_all_sentinel(ctx, oracle, cpm):
     dims = (8, 8, 8)
     g, og = cpm.binding.default_grid_desc(dims, 1), oracle.grid(dims, 1)
