@@ -84,19 +84,43 @@ def cpu_baseline(workload, vol_np, tf, n_lattice, grid_dim, light_dir):
     radius = S.photon_radius_texture(vol_np.shape[::-1], 1.0)
     scale = o.relative_irradiance_scale(radius, n)
     out = np.zeros(grid_dim ** 3, np.float32)
-    t0 = time.perf_counter()
-    steps = o.trace(ovol, tf, S.UNIT_CUBE_AABB, p, ls, isect, st, photons)
-    t1 = time.perf_counter()
-    _, cs, srt = o.bin(photons, n, og)
-    t2 = time.perf_counter()
-    o.gather(srt, cs, n, og, radius, scale, out)
-    t3 = time.perf_counter()
-    total = t3 - t0
+    # one warm-up frame, then the median of 5; the RNG state is not written back, so every
+    # frame traces the same photons
+    frames = []
+    steps = 0
+    for rep in range(6):
+        t0 = time.perf_counter()
+        steps = o.trace(ovol, tf, S.UNIT_CUBE_AABB, p, ls, isect, st, photons)
+        t1 = time.perf_counter()
+        _, cs, srt = o.bin(photons, n, og)
+        t2 = time.perf_counter()
+        o.gather(srt, cs, n, og, radius, scale, out)
+        t3 = time.perf_counter()
+        if rep > 0:
+            frames.append((t3 - t0, t1 - t0, t2 - t1, t3 - t2))
+    frames.sort()
+    total, tt, tb, tg = frames[len(frames) // 2]
+    # the reference formulation on the CPU (sequential splat, the order its CAS loop would have on one thread)
+    sp = np.zeros(grid_dim ** 3, np.float32)
+    ts = time.perf_counter()
+    o.splat(photons, n, og, radius, scale, sp)
+    splat_s = time.perf_counter() - ts
+    model = ""
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    model = line.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
     return {
-        "value": round(n / total / 1e6, 4), "unit": "Mphotons/s", "cores": cores, "kind": "port",
-        "sample": f"one full frame of {workload} ({n} photons): trace {t1 - t0:.3f} s (OpenMP x{cores}) + "
-                  f"bin {t2 - t1:.3f} s (1 thread) + gather {t3 - t2:.3f} s (OpenMP x{cores})",
+        "value": round(n / total / 1e6, 4), "unit": "Mphotons/s", "cores": cores, "kind": "port", "cpu_model": model,
+        "sample": f"median of 5 full frames (after 1 warm-up) of {workload} ({n} photons): trace {tt:.3f} s (OpenMP x{cores}) + "
+                  f"bin {tb:.3f} s (1 thread) + gather {tg:.3f} s (OpenMP x{cores}); the reference's OpenCL cannot be timed "
+                  f"here (no CPU OpenCL device, Inviwo absent): this is the oracle, a plain-C port of the same path",
         "ms_per_frame": round(total * 1e3, 1), "woodcock_steps": int(steps),
+        "splat_formulation_ms": round(splat_s * 1e3, 1),
     }
 
 
