@@ -2,6 +2,10 @@
 // include/cpm/cpm.h.  Error behaviour follows the reference: log, skip the step, carry on.
 #include "cpm_processors.h"
 
+#include <cpm/cpm_profile.h>
+
+#include <cstdlib>
+
 #include <algorithm>
 #include <cfloat>
 #include <cmath>
@@ -23,6 +27,27 @@ CpmRuntime::CpmRuntime() {
         LogError(std::string("cpm_create failed: ") + cpm_last_error_string(nullptr));
         ctx_ = nullptr;
     }
+    const char* e = std::getenv("CPM_PROFILING");
+    profiling_ = ctx_ && e && e[0] && e[0] != '0';
+    if (profiling_) cpm_profile_enable(ctx_, 1);
+}
+void CpmRuntime::beginProfile() const {
+    if (profiling_) cpm_profile_reset(ctx_);
+}
+void CpmRuntime::logProfile(const char* label) const {
+    if (!profiling_) return;
+    const int n = cpm_profile_collect(ctx_);  // synchronises, like the reference's wait on the last event
+    std::string line = std::string(label) + ": ";
+    double total = 0;
+    char buf[160];
+    for (int i = 0; i < n; ++i) {
+        const double ms = cpm_profile_total_ms(ctx_, i);
+        total += ms;
+        std::snprintf(buf, sizeof buf, "%s%s x%ld %.3f ms", i ? " + " : "", cpm_profile_name(ctx_, i), cpm_profile_calls(ctx_, i), ms);
+        line += buf;
+    }
+    std::snprintf(buf, sizeof buf, " = %.3f ms", total);
+    LogInfo(line + buf);
 }
 CpmRuntime::~CpmRuntime() { cpm_destroy(ctx_); }
 bool CpmRuntime::check(int status, const char* what) const {
@@ -525,6 +550,7 @@ void ProgressivePhotonTracerCL::resetPhotonImportance(size_t offset, size_t n) {
 void ProgressivePhotonTracerCL::process() {  // progressivephotontracercl.cpp:219-605
     auto& rt = CpmRuntime::get();
     if (!photonTracer_.isValid() || !volumePort_.isReady()) return;
+    rt.beginProfile();
     const auto lights = lightSamples_.getVectorData();
     size_t nPhotons = 0;
     // lightSamples_.onChange (tracercl.cpp:119-126): a light whose samples were rewritten since the last
@@ -634,6 +660,14 @@ void ProgressivePhotonTracerCL::process() {  // progressivephotontracercl.cpp:21
     photonData_->setInvalidationReason(invalidationFlag_);
     invalidationFlag_ = PhotonData::InvalidationReason(0);
     outport_.setData(photonData_);
+    if (rt.profiling()) {  // "Photon tracing: ... = X ms", "Computed photons: n = p %" (tracercl.cpp:562-598)
+        rt.logProfile("Photon tracing");
+        const int nr = recomputedPhotonIndices_->nRecomputedPhotons;
+        const size_t np = photonData_->getNumberOfPhotons();
+        char buf[96];
+        std::snprintf(buf, sizeof buf, "Computed photons: %zu = %.2f %%", nr < 0 ? np : (size_t)nr, np ? 100.0 * (double)(nr < 0 ? np : (size_t)nr) / (double)np : 0.0);
+        LogInfo(buf);
+    }
 }
 
 PhotonToLightVolumeProcessorCL::PhotonToLightVolumeProcessorCL() {
@@ -662,6 +696,8 @@ void PhotonToLightVolumeProcessorCL::volumeSizeOptionChanged() {  // photontolig
 void PhotonToLightVolumeProcessorCL::process() {  // photontolightvolumeprocessorcl.cpp:137-354
     auto& rt = CpmRuntime::get();
     if (!rt.valid() || !photons_.isReady() || !volumeInport_.isReady()) return;
+    rt.beginProfile();
+    struct LogAtExit { const CpmRuntime& r; ~LogAtExit() { r.logProfile("Photons to light volume"); } } logAtExit{ rt };
     auto photonData = photons_.getData();
     if (volumeSizeOption_.get() == 0) {  // size from the photon radius (:144-163, Q15)
         const size_t n = (size_t)std::ceil(1.0 / photonData->getRadiusRelativeToSceneSize());

@@ -23,7 +23,14 @@ public:
     bool valid() const { return ctx_ != nullptr; }
     // log-and-swallow, like the reference's catch (cl::Error&) { LogError(...) }
     bool check(int status, const char* what) const;
+    // IVW_PROFILING's counterpart (the reference logs OpenCL event times per stage: tracercl.cpp:562-598,
+    // ...processorcl.cpp:247-261,328-338): with CPM_PROFILING=1 in the environment every kernel launch is bracketed by
+    // HIP events and a processor logs "<label>: kernel a ms + kernel b ms + ... = X ms" after it has evaluated.
+    bool profiling() const { return profiling_; }
+    void beginProfile() const;
+    void logProfile(const char* label) const;
 private:
+    bool profiling_ = false;
     CpmRuntime();
     ~CpmRuntime();
     cpm_ctx* ctx_ = nullptr;

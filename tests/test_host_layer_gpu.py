@@ -207,3 +207,36 @@ def test_network_correlated_tf_edit(host, cpm):
     assert np.array_equal(bits(net2.photons()), bits(after))
     for x in (net, fresh, net2):
         x.close()
+
+
+def test_stage_timing_log(cpm, ctx):
+    """CPM_PROFILING=1: the processors log per-stage kernel times like the reference's IVW_PROFILING lines
+    (tracercl.cpp:562-598, ...processorcl.cpp:247-261).  Run in a child process: the flag is read once per process."""
+    import os
+    import subprocess
+    import sys
+    code = r'''
+import ctypes as C, sys
+sys.path.insert(0, %r)
+import numpy as np, torch
+torch.zeros(1, device="cuda")
+import cpm_amd
+S = cpm_amd.synthetic
+lib = C.CDLL(str(cpm_amd.binding.LIB_PATH.parent / "libcpm_host.so"))
+lib.cpmh_create.restype = C.c_void_p
+lib.cpmh_create.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float * 3),
+                            C.POINTER(C.c_float * 3), C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]
+lib.cpmh_evaluate.argtypes = [C.c_void_p, C.c_int]
+vol = S.homogeneous_volume(16)
+tf = np.array(S.WORKSPACE_TF_POINTS, np.float32)
+pos, d = (C.c_float * 3)(0.5, 0.5, 2.5), (C.c_float * 3)(0.0, 0.0, -1.0)
+h = lib.cpmh_create(vol.ctypes.data, 0, 16, 16, 16, 32, 32, C.byref(pos), C.byref(d), tf.ctypes.data, tf.shape[0], 2, 1, 0)
+assert h and lib.cpmh_evaluate(h, 1) == 0
+''' % (str(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))),)
+    env = dict(os.environ, CPM_PROFILING="1")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=600)
+    log = r.stdout + r.stderr
+    assert r.returncode == 0, log[-3000:]
+    assert "Photon tracing: " in log and "trace_kernel" in log and " ms" in log
+    assert "Computed photons: 1024 = 100.00 %" in log
+    assert "Photons to light volume: " in log and "gather" in log
