@@ -522,16 +522,108 @@ __global__ __launch_bounds__(256) void gather_records_kernel(const float* __rest
     out[v] = accumulate ? out[v] + sum : sum;
 }
 
-// ---- record-major gather, specialised for <= 2 candidate voxels per axis (r < 1 voxel) ------------
+// ---- the record phase shared by the tuned record-major kernels ---------------------------------------
+// MAXC = candidate voxels per axis a record can reach (2 at r < 1 cell, 3 at r < 1.5 cells).  A record's candidates
+// are consecutive integers per axis, so they differ in their residues mod MAXC: the slot a contribution is parked
+// in is the residue triple of the TARGET voxel -- which the voxel's own lane knows without looking anything up.
+//   * per axis the MAXC centre offsets d = c - p and box verdicts are computed once per record, so the exact cheap
+//     test of a candidate costs two fma and a compare (d^2 = fma(dz, dz, fma(dy, dy, dx*dx)), the contract's operands);
+//   * about 2 % (MAXC = 2) of the (record, candidate) pairs pass; the weight (sqrt, division, kernel: ~40
+//     instructions) is evaluated per surviving candidate RANK -- first survivor of every lane together, then the
+//     second, ... -- i.e. a few times per step instead of once per candidate with one or two lanes active.
+template <int MAXC> struct CandSlots { static constexpr int N = MAXC * MAXC * MAXC; };
+CPM_DEV int mod3_(int v) { return v - 3 * ((v * 43691) >> 17); }  // v in [0, 2^15): grid coordinates
+
+template <int MAXC>
+CPM_DEV int voxel_slot(int x, int y, int z) {
+    if (MAXC == 2) return (x & 1) | ((y & 1) << 1) | ((z & 1) << 2);
+    if (MAXC == 4) return (x & 3) | ((y & 3) << 2) | ((z & 3) << 4);
+    return mod3_(x) + 3 * mod3_(y) + 9 * mod3_(z);
+}
+
+template <int MAXC>
+CPM_DEV void gather_record_phase(const GridDev& G, float4 a, bool have, int x0, int y0, int z0, int x1, int y1, int z1,
+                                 float rgx, float rgy, float rgz, float radius, float r2max, float k, int lane,
+                                 float (*s_val)[64], unsigned long long* s_mask) {
+    constexpr int NC = MAXC * MAXC * MAXC;
+    const f3 p = { a.x, a.y, a.z };
+    const f3 u = transform_(G.t2i, p);  // index space: voxel v has its centre at u == v
+    const int sx = max((int)__builtin_ceilf(u.x - rgx), x0), ex = min((int)__builtin_floorf(u.x + rgx), x1);
+    const int sy = max((int)__builtin_ceilf(u.y - rgy), y0), ey = min((int)__builtin_floorf(u.y + rgy), y1);
+    const int sz = max((int)__builtin_ceilf(u.z - rgz), z0), ez = min((int)__builtin_floorf(u.z + rgz), z1);
+    const int nx = have ? max(ex - sx + 1, 0) : 0, ny = max(ey - sy + 1, 0), nz = max(ez - sz + 1, 0);
+    const Box3 bb = splat_box(G, p, radius);
+    const float pk = a.w * k;
+    float dxv[MAXC], dyv[MAXC], dzv[MAXC];
+    bool okx[MAXC], oky[MAXC], okz[MAXC];
+#pragma unroll
+    for (int q = 0; q < MAXC; ++q) {
+        const int vx = sx + q, vy = sy + q, vz = sz + q;
+        dxv[q] = fma_(G.i2t.sx, (float)vx, G.i2t.tx) - a.x;
+        dyv[q] = fma_(G.i2t.sy, (float)vy, G.i2t.ty) - a.y;
+        dzv[q] = fma_(G.i2t.sz, (float)vz, G.i2t.tz) - a.z;
+        okx[q] = q < nx && vx >= bb.sx && vx < bb.ex;
+        oky[q] = q < ny && vy >= bb.sy && vy < bb.ey;
+        okz[q] = q < nz && vz >= bb.sz && vz < bb.ez;
+    }
+    unsigned long long hits = 0;  // one bit per candidate (64 at MAXC = 4)
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        const int qx = c % MAXC, qy = (c / MAXC) % MAXC, qz = c / (MAXC * MAXC);
+        const float d2 = fma_(dzv[qz], dzv[qz], fma_(dyv[qy], dyv[qy], dxv[qx] * dxv[qx]));
+        if (okx[qx] && oky[qy] && okz[qz] && d2 <= r2max) hits |= 1ull << c;  // d2 > r2max: exactly no contribution
+    }
+    const int vl0 = (sx - x0) + 4 * (sy - y0) + 16 * (sz - z0);
+    // residues of the first candidate; candidate q's residue is (r0 + q) mod MAXC
+    const int rx0 = MAXC == 3 ? mod3_(sx) : (sx & (MAXC - 1)), ry0 = MAXC == 3 ? mod3_(sy) : (sy & (MAXC - 1)),
+              rz0 = MAXC == 3 ? mod3_(sz) : (sz & (MAXC - 1));
+    while (__any(hits != 0)) {
+        if (hits != 0) {
+            const int c = __builtin_ctzll(hits);
+            hits &= hits - 1;
+            int qx, qy, qz;
+            if (MAXC == 2) { qx = c & 1; qy = (c >> 1) & 1; qz = c >> 2; }
+            else if (MAXC == 4) { qx = c & 3; qy = (c >> 2) & 3; qz = c >> 4; }
+            else { qz = (c * 57) >> 9; const int r = c - 9 * qz; qy = (r * 11) >> 5; qx = r - 3 * qy; }  // c / 9, (c % 9) / 3, c % 3 for c < 27
+            float ddx = dxv[0], ddy = dyv[0], ddz = dzv[0];
+#pragma unroll
+            for (int q = 1; q < MAXC; ++q) {
+                ddx = (qx == q) ? dxv[q] : ddx;
+                ddy = (qy == q) ? dyv[q] : ddy;
+                ddz = (qz == q) ? dzv[q] : ddz;
+            }
+            const float d2 = fma_(ddz, ddz, fma_(ddy, ddy, ddx * ddx));  // the same operands as above: the same value
+            const float wgt = density_kernel_(__builtin_sqrtf(d2) / radius);
+            const float val = pk * wgt;
+            if (val != 0.f) {
+                int slot;
+                if (MAXC == 2) {
+                    slot = (rx0 ^ qx) | ((ry0 ^ qy) << 1) | ((rz0 ^ qz) << 2);
+                } else if (MAXC == 4) {
+                    slot = ((rx0 + qx) & 3) | (((ry0 + qy) & 3) << 2) | (((rz0 + qz) & 3) << 4);
+                } else {
+                    int rx = rx0 + qx, ry = ry0 + qy, rz = rz0 + qz;
+                    rx -= rx >= 3 ? 3 : 0; ry -= ry >= 3 ? 3 : 0; rz -= rz >= 3 ? 3 : 0;
+                    slot = rx + 3 * ry + 9 * rz;
+                }
+                s_val[slot][lane] = val;
+                atomicOr(&s_mask[vl0 + qx + 4 * qy + 16 * qz], 1ull << lane);
+            }
+        }
+    }
+}
+
+// ---- tuned record-major gather: one wave per brick (MAXC = 2, 3 or 4 candidate voxels per axis, halo of <= 2 cells)
 // Same algorithm and the same per-voxel summation order as gather_records_kernel, tuned:
-//   * the 2x2x2 candidates are unrolled; per axis the two centre offsets d = c - p and the box
-//     verdicts are computed once per record, so a candidate costs two fma and a compare
-//     (d^2 = fma(dz, dz, fma(dy, dy, dx*dx)) is evaluated with exactly the contract's operands);
+//   * the record phase above (per-axis terms once per record, survivors weighted per rank, residue slots);
 //   * the next step's records are fetched before the current step is processed;
-//   * the flattened-index -> row lookup is a popcount over a bitmask of row starts instead of a
-//     binary search;
-//   * z-slabs are visited from both faces inwards (photons pile up where light enters the volume,
-//     i.e. on faces): the heaviest bricks are dispatched first instead of last.
+//   * the flattened-index -> row lookup is a popcount over a bitmask of row starts instead of a binary search;
+//   * z-slabs are visited from both faces inwards (photons pile up where light enters the volume, i.e. on faces):
+//     the heaviest bricks are dispatched first instead of last;
+//   * 3-D launch, no integer division on the way to the brick (four fifths of the waves find an empty halo).
+// Used above 64 Ki bricks, where the hardware's wave scheduling balances the load by itself; below that
+// gather_coop_kernel shares bricks between waves.
+template <int MAXC>
 __global__ __launch_bounds__(256) void gather_records2_kernel(const float* __restrict__ sorted,
                                                               const uint32_t* __restrict__ cell_start, GridDev G, float radius,
                                                               float r2max, float k, int Rx, int Ry, int Rz, int accumulate,
@@ -539,7 +631,7 @@ __global__ __launch_bounds__(256) void gather_records2_kernel(const float* __res
                                                               unsigned long long* __restrict__ dbg) {
     constexpr int MAXROWS = 64;
     constexpr int MAXWORDS = 64;  // row-start bitmask: up to 4096 records per brick halo, else the generic kernel's path
-    __shared__ float s_val_all[4][8][64];
+    __shared__ float s_val_all[4][MAXC * MAXC * MAXC][64];
     __shared__ unsigned long long s_mask_all[4][64];
     __shared__ unsigned long long s_start_all[4][MAXWORDS];
     __shared__ uint32_t s_rowjb_all[4][MAXROWS];   // per NON-EMPTY row (compacted): jb - exclusive offset
@@ -562,12 +654,12 @@ __global__ __launch_bounds__(256) void gather_records2_kernel(const float* __res
     const int x0 = bx * kGW, y0 = by * kGW, z0 = bz * kGW;
     const int x = x0 + (lane & 3), y = y0 + ((lane >> 2) & 3), z = z0 + (lane >> 4);
     const bool valid = x < G.dx && y < G.dy && z < G.dz;
-    const int my_par = (x & 1) | ((y & 1) << 1) | ((z & 1) << 2);
+    const int my_par = voxel_slot<MAXC>(x, y, z);
 
     const int nry = kGW + 2 * Ry, nrows = nry * (kGW + 2 * Rz);  // Ry <= 1: 4 or 6 rows per slab
     uint32_t jb = 0, len = 0;
     if (lane < nrows) {
-        const int rz = Ry ? (lane * 43) >> 8 : lane >> 2;  // lane / 6 (exact for lane < 64) or lane / 4
+        const int rz = nry == 4 ? lane >> 2 : (nry == 6 ? (lane * 43) >> 8 : lane >> 3);  // lane / nry (exact for lane < 64)
         const int cy = y0 - Ry + (lane - rz * nry), cz = z0 - Rz + rz;
         if (cy >= 0 && cy < G.dy && cz >= 0 && cz < G.dz) {
             const uint32_t row = (uint32_t)G.dx * ((uint32_t)cy + (uint32_t)G.dy * (uint32_t)cz);
@@ -640,59 +732,7 @@ __global__ __launch_bounds__(256) void gather_records2_kernel(const float* __res
                 const uint32_t jn = locate(w + 1, rb_next);
                 if ((uint32_t)(w + 1) * 64u + lane < total) an = rec[jn];
             }
-            const f3 p = { a.x, a.y, a.z };
-            const f3 u = transform_(G.t2i, p);
-            const int sx = max((int)__builtin_ceilf(u.x - rgx), x0), ex = min((int)__builtin_floorf(u.x + rgx), x1);
-            const int sy = max((int)__builtin_ceilf(u.y - rgy), y0), ey = min((int)__builtin_floorf(u.y + rgy), y1);
-            const int sz = max((int)__builtin_ceilf(u.z - rgz), z0), ez = min((int)__builtin_floorf(u.z + rgz), z1);
-            const int nx = have ? max(ex - sx + 1, 0) : 0, ny = max(ey - sy + 1, 0), nz = max(ez - sz + 1, 0);
-            const Box3 bb = splat_box(G, p, radius);
-            const float pk = a.w * k;
-            // per-axis terms for the two candidates of each axis
-            float dxv[2], dyv[2], dzv[2];
-            bool okx[2], oky[2], okz[2];
-#pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                const int vx = sx + q, vy = sy + q, vz = sz + q;
-                dxv[q] = fma_(G.i2t.sx, (float)vx, G.i2t.tx) - a.x;
-                dyv[q] = fma_(G.i2t.sy, (float)vy, G.i2t.ty) - a.y;
-                dzv[q] = fma_(G.i2t.sz, (float)vz, G.i2t.tz) - a.z;
-                okx[q] = q < nx && vx >= bb.sx && vx < bb.ex;
-                oky[q] = q < ny && vy >= bb.sy && vy < bb.ey;
-                okz[q] = q < nz && vz >= bb.sz && vz < bb.ez;
-            }
-            // A record's candidates are consecutive integers per axis, so they differ in the parity of each
-            // coordinate: the slot a value goes to is the parity triple of the TARGET voxel -- which the
-            // voxel's own lane knows without looking anything up.
-            const int vl0 = (sx - x0) + 4 * (sy - y0) + 16 * (sz - z0);
-            const int par0 = (sx & 1) | ((sy & 1) << 1) | ((sz & 1) << 2);
-            // The cheap exact test runs for all 8 candidates; about 2 % of the (record, candidate) pairs pass, most
-            // records with none or one.  The weight (sqrt, division, kernel: ~40 instructions) is then evaluated per
-            // surviving candidate RANK -- first survivor of every lane together, then second, ... -- i.e. two or
-            // three times per step instead of once per candidate with one or two lanes active.
-            float d2c[8];
-            uint32_t hits = 0;
-#pragma unroll
-            for (int c = 0; c < 8; ++c) {
-                const int qx = c & 1, qy = (c >> 1) & 1, qz = c >> 2;
-                d2c[c] = fma_(dzv[qz], dzv[qz], fma_(dyv[qy], dyv[qy], dxv[qx] * dxv[qx]));
-                if (okx[qx] && oky[qy] && okz[qz] && d2c[c] <= r2max) hits |= 1u << c;  // d2 > r2max: exactly no contribution
-            }
-            while (__any(hits != 0)) {
-                if (hits != 0) {
-                    const int c = __builtin_ctz(hits);
-                    hits &= hits - 1;
-                    float d2 = d2c[0];
-#pragma unroll
-                    for (int q = 1; q < 8; ++q) d2 = (c == q) ? d2c[q] : d2;
-                    const float wgt = density_kernel_(__builtin_sqrtf(d2) / radius);
-                    const float val = pk * wgt;
-                    if (val != 0.f) {
-                        s_val[par0 ^ c][lane] = val;  // parity of (sx+qx, sy+qy, sz+qz)
-                        atomicOr(&s_mask[vl0 + (c & 1) + 4 * ((c >> 1) & 1) + 16 * (c >> 2)], 1ull << lane);
-                    }
-                }
-            }
+            gather_record_phase<MAXC>(G, a, have, x0, y0, z0, x1, y1, z1, rgx, rgy, rgz, radius, r2max, k, lane, s_val, s_mask);
             __builtin_amdgcn_wave_barrier();
             // lane = voxel: add this step's contributors in ascending lane (= sorted index) order
             unsigned long long m = s_mask[lane];
@@ -744,7 +784,7 @@ __global__ __launch_bounds__(256) void gather_records2_kernel(const float* __res
 //     turn never waits: no deadlock;
 //   * phase 2: wave b writes brick b's sums.
 // Same additions in the same order as gather_records2_kernel: bit-identical results.
-template <int NB>  // bricks = waves per workgroup
+template <int NB, int MAXC>  // NB bricks = waves per workgroup; MAXC candidate voxels per axis
 __global__ __launch_bounds__(64 * NB) void gather_coop_kernel(const float* __restrict__ sorted,
                                                           const uint32_t* __restrict__ cell_start, GridDev G, float radius,
                                                           float r2max, float k, int Rx, int Ry, int Rz, int accumulate,
@@ -752,7 +792,7 @@ __global__ __launch_bounds__(64 * NB) void gather_coop_kernel(const float* __res
                                                           unsigned long long* __restrict__ dbg) {
     constexpr int MAXROWS = 64;
     constexpr int MAXWORDS = 64;  // row-start bitmask: up to 4096 records per brick halo, else a binary search
-    __shared__ float s_val_all[NB][8][64];               // per WAVE: this step's contributions by target parity
+    __shared__ float s_val_all[NB][MAXC * MAXC * MAXC][64];               // per WAVE: this step's contributions by target parity
     __shared__ unsigned long long s_mask_all[NB][64];    // per WAVE: this step's contributor lanes per voxel
     __shared__ unsigned long long s_start_all[NB][MAXWORDS];  // per BRICK
     __shared__ uint32_t s_rb_all[NB][MAXWORDS];          // per BRICK: non-empty rows that start before step w
@@ -791,7 +831,7 @@ __global__ __launch_bounds__(64 * NB) void gather_coop_kernel(const float* __res
         const int nry = kGW + 2 * Ry, nrows = nry * (kGW + 2 * Rz);
         uint32_t jb = 0, len = 0;
         if (exists && lane < nrows) {
-            const int rz = Ry ? (lane * 43) >> 8 : lane >> 2;  // lane / 6 (exact for lane < 64) or lane / 4
+            const int rz = nry == 4 ? lane >> 2 : (nry == 6 ? (lane * 43) >> 8 : lane >> 3);  // lane / nry (exact for lane < 64)
             const int cy = y0 - Ry + (lane - rz * nry), cz = z0 - Rz + rz;
             if (cy >= 0 && cy < G.dy && cz >= 0 && cz < G.dz) {
                 const uint32_t row = (uint32_t)G.dx * ((uint32_t)cy + (uint32_t)G.dy * (uint32_t)cz);
@@ -843,7 +883,6 @@ __global__ __launch_bounds__(64 * NB) void gather_coop_kernel(const float* __res
     // ---- phase 1: steps g = wave, wave + 4, ... of the workgroup's sequence
     const float4* __restrict__ rec = reinterpret_cast<const float4*>(sorted);
     const float rgx = radius * (float)G.dx + 1e-3f, rgy = radius * (float)G.dy + 1e-3f, rgz = radius * (float)G.dz + 1e-3f;
-    const int my_par = (lane & 1) | (((lane >> 2) & 1) << 1) | (((lane >> 4) & 1) << 2);  // brick origins are even
     float (*s_val)[64] = s_val_all[wave];
     unsigned long long* s_mask = s_mask_all[wave];
     for (uint32_t g = (uint32_t)wave; g < GS; g += NB) {
@@ -872,51 +911,8 @@ __global__ __launch_bounds__(64 * NB) void gather_coop_kernel(const float* __res
         }
         float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
         if (have) a = rec[j];
-        const f3 p = { a.x, a.y, a.z };
-        const f3 u = transform_(G.t2i, p);
-        const int sx = max((int)__builtin_ceilf(u.x - rgx), x0), ex = min((int)__builtin_floorf(u.x + rgx), x1);
-        const int sy = max((int)__builtin_ceilf(u.y - rgy), y0), ey = min((int)__builtin_floorf(u.y + rgy), y1);
-        const int sz = max((int)__builtin_ceilf(u.z - rgz), z0), ez = min((int)__builtin_floorf(u.z + rgz), z1);
-        const int nx = have ? max(ex - sx + 1, 0) : 0, ny = max(ey - sy + 1, 0), nz = max(ez - sz + 1, 0);
-        const Box3 bb = splat_box(G, p, radius);
-        const float pk = a.w * k;
-        float dxv[2], dyv[2], dzv[2];
-        bool okx[2], oky[2], okz[2];
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            const int vx = sx + q, vy = sy + q, vz = sz + q;
-            dxv[q] = fma_(G.i2t.sx, (float)vx, G.i2t.tx) - a.x;
-            dyv[q] = fma_(G.i2t.sy, (float)vy, G.i2t.ty) - a.y;
-            dzv[q] = fma_(G.i2t.sz, (float)vz, G.i2t.tz) - a.z;
-            okx[q] = q < nx && vx >= bb.sx && vx < bb.ex;
-            oky[q] = q < ny && vy >= bb.sy && vy < bb.ey;
-            okz[q] = q < nz && vz >= bb.sz && vz < bb.ez;
-        }
-        const int vl0 = (sx - x0) + 4 * (sy - y0) + 16 * (sz - z0);
-        const int par0 = (sx & 1) | ((sy & 1) << 1) | ((sz & 1) << 2);
-        float d2c[8];
-        uint32_t hits = 0;
-#pragma unroll
-        for (int c = 0; c < 8; ++c) {
-            const int qx = c & 1, qy = (c >> 1) & 1, qz = c >> 2;
-            d2c[c] = fma_(dzv[qz], dzv[qz], fma_(dyv[qy], dyv[qy], dxv[qx] * dxv[qx]));
-            if (okx[qx] && oky[qy] && okz[qz] && d2c[c] <= r2max) hits |= 1u << c;  // d2 > r2max: exactly no contribution
-        }
-        while (__any(hits != 0)) {
-            if (hits != 0) {
-                const int c = __builtin_ctz(hits);
-                hits &= hits - 1;
-                float d2 = d2c[0];
-#pragma unroll
-                for (int q = 1; q < 8; ++q) d2 = (c == q) ? d2c[q] : d2;
-                const float wgt = density_kernel_(__builtin_sqrtf(d2) / radius);
-                const float val = pk * wgt;
-                if (val != 0.f) {
-                    s_val[par0 ^ c][lane] = val;
-                    atomicOr(&s_mask[vl0 + (c & 1) + 4 * ((c >> 1) & 1) + 16 * (c >> 2)], 1ull << lane);
-                }
-            }
-        }
+        gather_record_phase<MAXC>(G, a, have, x0, y0, z0, x1, y1, z1, rgx, rgy, rgz, radius, r2max, k, lane, s_val, s_mask);
+        const int my_par = voxel_slot<MAXC>(x0 + (lane & 3), y0 + ((lane >> 2) & 3), z0 + (lane >> 4));
         // ---- the drain of step g, in turn
         while (__hip_atomic_load(&s_turn, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != g) __builtin_amdgcn_s_sleep(1);
         unsigned long long m = s_mask[lane];
@@ -1095,7 +1091,6 @@ int cpm_gather(cpm_ctx* ctx, const float* sorted_pos_power, const uint32_t* cell
     float k = kInv4Pi * scale;
     // cheap exact reject: d^2 > r^2 (1 + 1e-5)  =>  fl(fl(sqrt(d^2)) / r) > 1  =>  weight 0
     float r2max = (radius * radius) * 1.00001f;
-    (void)cells;
     CPM_REQUIRE(ctx, Rx <= 2 && Ry <= 2 && Rz <= 2, "cpm_gather: radius above 2.5 light-volume voxels is not supported");
     int bxn = div_up(G.dx, 4), byn = div_up(G.dy, 4), bzn = div_up(G.dz, 4);
     dim3 gridDim((unsigned)div_up((long long)bxn * byn * bzn, 4)), block(256);
@@ -1107,23 +1102,44 @@ int cpm_gather(cpm_ctx* ctx, const float* sorted_pos_power, const uint32_t* cell
     // set its length (128^3 grid, 32 K bricks: 80 -> 61 us); with 8x the bricks the hardware's own wave scheduling
     // balances the load and the turn-taking only costs (256^3 grid: 203 us one wave per brick, 224 us shared).
     const bool coop = g_gather_coop > 1 || (g_gather_coop == 1 && (long long)bxn * byn * bzn <= 65536);
-    if (G.channels == 1 && cand_axis <= 2 && Rx <= 1 && Ry <= 1 && Rz <= 1 && g_gather_force_voxel == 0 && coop) {
-        if (g_gather_coop == 2) {
-            const int zq = div_up(bzn, 2);
-            CPM_LAUNCH(ctx, gather_coop_kernel<2>, dim3((unsigned)bxn, (unsigned)byn, (unsigned)zq), dim3(128), 0, hs, sorted_pos_power,
-                       cell_start, G, radius, r2max, k, Rx, Ry, Rz, accumulate, bxn, byn, bzn, zq, grid_out, g_gather_stamps);
-        } else if (g_gather_coop == 8) {
-            const int zq = div_up(bzn, 8);
-            CPM_LAUNCH(ctx, gather_coop_kernel<8>, dim3((unsigned)bxn, (unsigned)byn, (unsigned)zq), dim3(512), 0, hs, sorted_pos_power,
-                       cell_start, G, radius, r2max, k, Rx, Ry, Rz, accumulate, bxn, byn, bzn, zq, grid_out, g_gather_stamps);
+    // the tuned record-major kernels: one channel, halo of <= 2 cells, 2 to 4 candidate voxels per axis (r < 2 cells)
+    // Measured on config 2's photons (128^3 grid): r = 0.87 / 1.0 / 1.2 / 1.45 / 1.73 cells -> tuned cooperative kernel
+    // 64 / 105 / 118 / 147 / 390 us against 157 / 194 / 258 / 351 / 722 us for the better of the generic kernels.  At 4
+    // candidates per axis (64 per record, ~20 survivors) the record-major form only wins where photons are dense:
+    // 256^3 grid, 0.06 photons per cell: 742 us against 577 us voxel-major -- hence the density condition.
+    const bool dense = (long long)n * 4 >= (long long)cells;
+    const bool tuned = G.channels == 1 && (cand_axis <= 3 || (cand_axis == 4 && dense)) && Rx <= 2 && Ry <= 2 && Rz <= 2 &&
+                       g_gather_force_voxel == 0;
+#define CPM_COOP_LAUNCH(NB, MAXC)                                                                                              \
+    do {                                                                                                                       \
+        const int zq = div_up(bzn, NB);                                                                                        \
+        CPM_LAUNCH(ctx, (gather_coop_kernel<NB, MAXC>), dim3((unsigned)bxn, (unsigned)byn, (unsigned)zq), dim3(64 * NB), 0, hs, \
+                   sorted_pos_power, cell_start, G, radius, r2max, k, Rx, Ry, Rz, accumulate, bxn, byn, bzn, zq, grid_out,     \
+                   g_gather_stamps);                                                                                           \
+    } while (0)
+    if (tuned && coop) {
+        if (cand_axis <= 2) {
+            if (g_gather_coop == 2) CPM_COOP_LAUNCH(2, 2);
+            else if (g_gather_coop == 8) CPM_COOP_LAUNCH(8, 2);
+            else CPM_COOP_LAUNCH(4, 2);
+        } else if (cand_axis == 3) {
+            CPM_COOP_LAUNCH(4, 3);
         } else {
-            const int zq = div_up(bzn, 4);
-            CPM_LAUNCH(ctx, gather_coop_kernel<4>, dim3((unsigned)bxn, (unsigned)byn, (unsigned)zq), block, 0, hs, sorted_pos_power,
-                       cell_start, G, radius, r2max, k, Rx, Ry, Rz, accumulate, bxn, byn, bzn, zq, grid_out, g_gather_stamps);
+            CPM_COOP_LAUNCH(4, 4);
         }
-    } else if (G.channels == 1 && cand_axis <= 2 && Rx <= 1 && Ry <= 1 && Rz <= 1 && g_gather_force_voxel == 0)
-        CPM_LAUNCH(ctx, gather_records2_kernel, dim3((unsigned)div_up(bxn, 4), (unsigned)byn, (unsigned)bzn), block, 0, hs,
-                   sorted_pos_power, cell_start, G, radius, r2max, k, Rx, Ry, Rz, accumulate, bxn, byn, bzn, grid_out, g_gather_stamps);
+    } else if (tuned) {
+        const dim3 g3((unsigned)div_up(bxn, 4), (unsigned)byn, (unsigned)bzn);
+        if (cand_axis <= 2)
+            CPM_LAUNCH(ctx, gather_records2_kernel<2>, g3, block, 0, hs, sorted_pos_power, cell_start, G, radius, r2max, k, Rx, Ry, Rz,
+                       accumulate, bxn, byn, bzn, grid_out, g_gather_stamps);
+        else if (cand_axis == 3)
+            CPM_LAUNCH(ctx, gather_records2_kernel<3>, g3, block, 0, hs, sorted_pos_power, cell_start, G, radius, r2max, k, Rx, Ry, Rz,
+                       accumulate, bxn, byn, bzn, grid_out, g_gather_stamps);
+        else
+            CPM_LAUNCH(ctx, gather_records2_kernel<4>, g3, block, 0, hs, sorted_pos_power, cell_start, G, radius, r2max, k, Rx, Ry, Rz,
+                       accumulate, bxn, byn, bzn, grid_out, g_gather_stamps);
+    }
+#undef CPM_COOP_LAUNCH
     else if (G.channels == 1 && cand_axis <= 2 && g_gather_force_voxel != 1)
         CPM_LAUNCH(ctx, gather_records_kernel<2>, gridDim, block, 0, hs, sorted_pos_power, cell_start, G, radius, r2max, k, Rx, Ry, Rz,
                    accumulate, bxn, byn, grid_out, g_gather_stamps);

@@ -360,6 +360,8 @@ def _random_photons(rng, n, sentinel_every=0, spread=1.0, rgb=False):
     ((16, 16, 16), 1, 0.3, 0),
     ((20, 28, 36), 1, 1.2, 0),     # record-major kernel, 3 candidates per axis, bricks cut by the grid edge
     ((32, 32, 32), 1, 2.2, 0),     # radius too large for the record-major kernel: falls back
+    ((32, 32, 32), 1, 1.7320508, 0),   # 1 voxel of a same-size volume (|(r, r, r)| = sqrt 3 cells): 4 candidates per axis, halo of 2
+    ((26, 30, 21), 1, 1.9, 0),
 ])
 def test_bin_and_gather_bit_exact(ctx, oracle, cpm, dims, channels, radius_vox, force_voxel):
     ctx.lib.cpm_debug_force_voxel_gather(int(force_voxel))
@@ -429,7 +431,9 @@ def _bin_and_gather_case(ctx, oracle, cpm, dims, channels, radius_vox):
     np.testing.assert_allclose(_n(spd), sp, rtol=2e-5, atol=tol)
 
 
-@pytest.mark.parametrize("dims,radius_vox", [((32, 32, 32), 0.866), ((30, 21, 9), 0.7), ((16, 16, 16), 0.3), ((40, 12, 52), 0.8)])
+@pytest.mark.parametrize("dims,radius_vox", [((32, 32, 32), 0.866), ((30, 21, 9), 0.7), ((16, 16, 16), 0.3), ((40, 12, 52), 0.8),
+                                             ((20, 28, 36), 1.2), ((33, 17, 26), 1.0), ((24, 24, 24), 1.45),   # 3 candidates per axis
+                                             ((24, 24, 24), 1.8), ((19, 22, 35), 1.7320508)])                     # 4, halo of 2 cells
 def test_gather_one_wave_per_brick_kernel(ctx, oracle, cpm, dims, radius_vox):
     """The r < 1 voxel gather has two kernels with the same summation order: the cooperative one (default: a
     workgroup's four waves share four bricks, drains take turns) and one wave per brick."""
