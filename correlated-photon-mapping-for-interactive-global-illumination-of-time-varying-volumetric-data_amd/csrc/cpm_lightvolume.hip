@@ -541,9 +541,12 @@ CPM_DEV int voxel_slot(int x, int y, int z) {
     return mod3_(x) + 3 * mod3_(y) + 9 * mod3_(z);
 }
 
-template <int MAXC>
-CPM_DEV void gather_record_phase(const GridDev& G, float4 a, bool have, int x0, int y0, int z0, int x1, int y1, int z1,
-                                 float rgx, float rgy, float rgz, float radius, float r2max, float k, int lane,
+// CH = 1: one value per contribution (power.r); CH = 4: three (r, g, b), parked in three planes of NC slots each.  A
+// contribution is kept when any channel is non-zero and the drain adds all of its channels: adding a zero is the
+// identity here (sums are never -0), so this equals the per-channel `if (v != 0) s += v` of the contract.
+template <int MAXC, int CH>
+CPM_DEV void gather_record_phase(const GridDev& G, float4 a, float pg, float pb, bool have, int x0, int y0, int z0, int x1,
+                                 int y1, int z1, float rgx, float rgy, float rgz, float radius, float r2max, float k, int lane,
                                  float (*s_val)[64], unsigned long long* s_mask) {
     constexpr int NC = MAXC * MAXC * MAXC;
     const f3 p = { a.x, a.y, a.z };
@@ -553,7 +556,7 @@ CPM_DEV void gather_record_phase(const GridDev& G, float4 a, bool have, int x0, 
     const int sz = max((int)__builtin_ceilf(u.z - rgz), z0), ez = min((int)__builtin_floorf(u.z + rgz), z1);
     const int nx = have ? max(ex - sx + 1, 0) : 0, ny = max(ey - sy + 1, 0), nz = max(ez - sz + 1, 0);
     const Box3 bb = splat_box(G, p, radius);
-    const float pk = a.w * k;
+    const float pk = a.w * k, pkg = pg * k, pkb = pb * k;
     float dxv[MAXC], dyv[MAXC], dzv[MAXC];
     bool okx[MAXC], oky[MAXC], okz[MAXC];
 #pragma unroll
@@ -595,7 +598,8 @@ CPM_DEV void gather_record_phase(const GridDev& G, float4 a, bool have, int x0, 
             const float d2 = fma_(ddz, ddz, fma_(ddy, ddy, ddx * ddx));  // the same operands as above: the same value
             const float wgt = density_kernel_(__builtin_sqrtf(d2) / radius);
             const float val = pk * wgt;
-            if (val != 0.f) {
+            const float valg = CH == 4 ? pkg * wgt : 0.f, valb = CH == 4 ? pkb * wgt : 0.f;
+            if (val != 0.f || (CH == 4 && (valg != 0.f || valb != 0.f))) {
                 int slot;
                 if (MAXC == 2) {
                     slot = (rx0 ^ qx) | ((ry0 ^ qy) << 1) | ((rz0 ^ qz) << 2);
@@ -607,10 +611,38 @@ CPM_DEV void gather_record_phase(const GridDev& G, float4 a, bool have, int x0, 
                     slot = rx + 3 * ry + 9 * rz;
                 }
                 s_val[slot][lane] = val;
+                if (CH == 4) { s_val[NC + slot][lane] = valg; s_val[2 * NC + slot][lane] = valb; }
                 atomicOr(&s_mask[vl0 + qx + 4 * qy + 16 * qz], 1ull << lane);
             }
         }
     }
+}
+
+// lane = voxel: add a step's contributors (bits of m) in ascending lane (= sorted index) order to the voxel's sums
+template <int NC, int CH>
+CPM_DEV void gather_drain(unsigned long long m, const float (*s_val)[64], int my_slot, float& sr, float& sg, float& sb) {
+    const float* mine = s_val[my_slot];
+    do {  // up to four contributors are fetched together, then added in order
+        const int l0 = __builtin_ctzll(m); m &= m - 1;
+        const int l1 = m ? __builtin_ctzll(m) : l0; const bool h1 = m != 0; m &= m - 1;
+        const int l2 = m ? __builtin_ctzll(m) : l0; const bool h2 = m != 0; m &= m - 1;
+        const int l3 = m ? __builtin_ctzll(m) : l0; const bool h3 = m != 0; m &= m - 1;
+        const float v0 = mine[l0], v1 = mine[l1], v2 = mine[l2], v3 = mine[l3];
+        sr += v0;
+        if (h1) sr += v1;
+        if (h2) sr += v2;
+        if (h3) sr += v3;
+        if (CH == 4) {
+            const float* mg = s_val[NC + my_slot];
+            const float* mb = s_val[2 * NC + my_slot];
+            const float g0 = mg[l0], g1 = mg[l1], g2 = mg[l2], g3 = mg[l3];
+            const float b0 = mb[l0], b1 = mb[l1], b2 = mb[l2], b3 = mb[l3];
+            sg += g0; sb += b0;
+            if (h1) { sg += g1; sb += b1; }
+            if (h2) { sg += g2; sb += b2; }
+            if (h3) { sg += g3; sb += b3; }
+        }
+    } while (m);
 }
 
 // ---- tuned record-major gather: one wave per brick (MAXC = 2, 3 or 4 candidate voxels per axis, halo of <= 2 cells)
@@ -623,7 +655,7 @@ CPM_DEV void gather_record_phase(const GridDev& G, float4 a, bool have, int x0, 
 //   * 3-D launch, no integer division on the way to the brick (four fifths of the waves find an empty halo).
 // Used above 64 Ki bricks, where the hardware's wave scheduling balances the load by itself; below that
 // gather_coop_kernel shares bricks between waves.
-template <int MAXC>
+template <int MAXC, int CH>
 __global__ __launch_bounds__(256) void gather_records2_kernel(const float* __restrict__ sorted,
                                                               const uint32_t* __restrict__ cell_start, GridDev G, float radius,
                                                               float r2max, float k, int Rx, int Ry, int Rz, int accumulate,
@@ -631,7 +663,8 @@ __global__ __launch_bounds__(256) void gather_records2_kernel(const float* __res
                                                               unsigned long long* __restrict__ dbg) {
     constexpr int MAXROWS = 64;
     constexpr int MAXWORDS = 64;  // row-start bitmask: up to 4096 records per brick halo, else the generic kernel's path
-    __shared__ float s_val_all[4][MAXC * MAXC * MAXC][64];
+    constexpr int NC = MAXC * MAXC * MAXC, CH3 = CH == 4 ? 3 : 1, STRIDE = CH == 4 ? 2 : 1;
+    __shared__ float s_val_all[4][CH3 * NC][64];
     __shared__ unsigned long long s_mask_all[4][64];
     __shared__ unsigned long long s_start_all[4][MAXWORDS];
     __shared__ uint32_t s_rowjb_all[4][MAXROWS];   // per NON-EMPTY row (compacted): jb - exclusive offset
@@ -667,7 +700,7 @@ __global__ __launch_bounds__(256) void gather_records2_kernel(const float* __res
             len = cell_start[row + (uint32_t)min(x0 + kGW - 1 + Rx, G.dx - 1) + 1] - jb;
         }
     }
-    float sum = 0.f;
+    float sum = 0.f, sumg = 0.f, sumb = 0.f;
     uint32_t incl = len, total = 0;
     if (__any(len != 0)) {  // wave-uniform; an empty halo skips the prefix sum as well
 #pragma unroll
@@ -721,38 +754,28 @@ __global__ __launch_bounds__(256) void gather_records2_kernel(const float* __res
 
         uint32_t rb_next = 0;
         uint32_t jcur = locate(0, rb_next);
-        float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
-        if ((uint32_t)lane < total) a = rec[jcur];
+        float4 a = make_float4(0.f, 0.f, 0.f, 0.f), a2 = a;
+        if ((uint32_t)lane < total) { a = rec[STRIDE * (size_t)jcur]; if (CH == 4) a2 = rec[2 * (size_t)jcur + 1]; }
         for (int w = 0; w < nwords; ++w) {
             const bool have = (uint32_t)w * 64u + lane < total;
             rows_before = rb_next;
             // prefetch the next step's records
-            float4 an = make_float4(0.f, 0.f, 0.f, 0.f);
+            float4 an = make_float4(0.f, 0.f, 0.f, 0.f), an2 = an;
             if (w + 1 < nwords) {
                 const uint32_t jn = locate(w + 1, rb_next);
-                if ((uint32_t)(w + 1) * 64u + lane < total) an = rec[jn];
+                if ((uint32_t)(w + 1) * 64u + lane < total) { an = rec[STRIDE * (size_t)jn]; if (CH == 4) an2 = rec[2 * (size_t)jn + 1]; }
             }
-            gather_record_phase<MAXC>(G, a, have, x0, y0, z0, x1, y1, z1, rgx, rgy, rgz, radius, r2max, k, lane, s_val, s_mask);
+            gather_record_phase<MAXC, CH>(G, a, a2.x, a2.y, have, x0, y0, z0, x1, y1, z1, rgx, rgy, rgz, radius, r2max, k, lane, s_val,
+                                          s_mask);
             __builtin_amdgcn_wave_barrier();
             // lane = voxel: add this step's contributors in ascending lane (= sorted index) order
             unsigned long long m = s_mask[lane];
             if (m) {
                 s_mask[lane] = 0ull;
-                const float* mine = s_val[my_par];
-                do {  // up to four contributors are fetched together, then added in order
-                    const int l0 = __builtin_ctzll(m); m &= m - 1;
-                    const int l1 = m ? __builtin_ctzll(m) : l0; const bool h1 = m != 0; m &= m - 1;
-                    const int l2 = m ? __builtin_ctzll(m) : l0; const bool h2 = m != 0; m &= m - 1;
-                    const int l3 = m ? __builtin_ctzll(m) : l0; const bool h3 = m != 0; m &= m - 1;
-                    const float v0 = mine[l0], v1 = mine[l1], v2 = mine[l2], v3 = mine[l3];
-                    sum += v0;
-                    if (h1) sum += v1;
-                    if (h2) sum += v2;
-                    if (h3) sum += v3;
-                } while (m);
+                gather_drain<NC, CH>(m, s_val, my_par, sum, sumg, sumb);
             }
             __builtin_amdgcn_wave_barrier();
-            a = an;
+            a = an; a2 = an2;
         }
     }
     if (dbg && lane == 0) {
@@ -765,7 +788,13 @@ __global__ __launch_bounds__(256) void gather_records2_kernel(const float* __res
     }
     if (!valid) return;
     const uint32_t v = (uint32_t)x + (uint32_t)G.dx * ((uint32_t)y + (uint32_t)G.dy * (uint32_t)z);
-    out[v] = accumulate ? out[v] + sum : sum;
+    if (CH == 1) {
+        out[v] = accumulate ? out[v] + sum : sum;
+    } else {
+        float4* o = reinterpret_cast<float4*>(out) + v;
+        if (accumulate) { float4 tt = *o; *o = make_float4(tt.x + sum, tt.y + sumg, tt.z + sumb, tt.w); }
+        else *o = make_float4(sum, sumg, sumb, 0.f);
+    }
 }
 
 // ---- cooperative record-major gather --------------------------------------------------------------------
@@ -784,7 +813,7 @@ __global__ __launch_bounds__(256) void gather_records2_kernel(const float* __res
 //     turn never waits: no deadlock;
 //   * phase 2: wave b writes brick b's sums.
 // Same additions in the same order as gather_records2_kernel: bit-identical results.
-template <int NB, int MAXC>  // NB bricks = waves per workgroup; MAXC candidate voxels per axis
+template <int NB, int MAXC, int CH>  // NB bricks = waves per workgroup; MAXC candidate voxels per axis; CH channels
 __global__ __launch_bounds__(64 * NB) void gather_coop_kernel(const float* __restrict__ sorted,
                                                           const uint32_t* __restrict__ cell_start, GridDev G, float radius,
                                                           float r2max, float k, int Rx, int Ry, int Rz, int accumulate,
@@ -792,13 +821,14 @@ __global__ __launch_bounds__(64 * NB) void gather_coop_kernel(const float* __res
                                                           unsigned long long* __restrict__ dbg) {
     constexpr int MAXROWS = 64;
     constexpr int MAXWORDS = 64;  // row-start bitmask: up to 4096 records per brick halo, else a binary search
-    __shared__ float s_val_all[NB][MAXC * MAXC * MAXC][64];               // per WAVE: this step's contributions by target parity
+    constexpr int NC = MAXC * MAXC * MAXC, CH3 = CH == 4 ? 3 : 1, STRIDE = CH == 4 ? 2 : 1;
+    __shared__ float s_val_all[NB][CH3 * NC][64];               // per WAVE: this step's contributions by target parity
     __shared__ unsigned long long s_mask_all[NB][64];    // per WAVE: this step's contributor lanes per voxel
     __shared__ unsigned long long s_start_all[NB][MAXWORDS];  // per BRICK
     __shared__ uint32_t s_rb_all[NB][MAXWORDS];          // per BRICK: non-empty rows that start before step w
     __shared__ uint32_t s_rowjb_all[NB][MAXROWS];        // per BRICK, compacted non-empty rows: jb - exclusive offset
     __shared__ uint32_t s_rowoff_all[NB][MAXROWS];       // per BRICK: exclusive offset
-    __shared__ float s_sum_all[NB][64];                  // per BRICK: running per-voxel sums
+    __shared__ float s_sum_all[NB][CH3][64];             // per BRICK: running per-voxel sums
     __shared__ uint32_t s_total[NB], s_nne[NB], s_first[NB + 1];
     __shared__ uint32_t s_turn;
     const unsigned long long t_start = dbg ? __builtin_amdgcn_s_memrealtime() : 0ull;
@@ -849,7 +879,8 @@ __global__ __launch_bounds__(64 * NB) void gather_coop_kernel(const float* __res
             }
             total = __shfl(incl, 63, 64);
         }
-        s_sum_all[wave][lane] = 0.f;
+#pragma unroll
+        for (int ch = 0; ch < CH3; ++ch) s_sum_all[wave][ch][lane] = 0.f;
         s_mask_all[wave][lane] = 0ull;
         s_start_all[wave][lane] = 0ull;
         if (lane == 0) { s_total[wave] = total; s_nne[wave] = (uint32_t)__popcll(ne); if (wave == 0) s_turn = 0u; }
@@ -909,29 +940,20 @@ __global__ __launch_bounds__(64 * NB) void gather_coop_kernel(const float* __res
             }
             j = s_rowjb_all[b][lo] + i;
         }
-        float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (have) a = rec[j];
-        gather_record_phase<MAXC>(G, a, have, x0, y0, z0, x1, y1, z1, rgx, rgy, rgz, radius, r2max, k, lane, s_val, s_mask);
+        float4 a = make_float4(0.f, 0.f, 0.f, 0.f), a2 = a;
+        if (have) { a = rec[STRIDE * (size_t)j]; if (CH == 4) a2 = rec[2 * (size_t)j + 1]; }
+        gather_record_phase<MAXC, CH>(G, a, a2.x, a2.y, have, x0, y0, z0, x1, y1, z1, rgx, rgy, rgz, radius, r2max, k, lane, s_val,
+                                      s_mask);
         const int my_par = voxel_slot<MAXC>(x0 + (lane & 3), y0 + ((lane >> 2) & 3), z0 + (lane >> 4));
         // ---- the drain of step g, in turn
         while (__hip_atomic_load(&s_turn, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != g) __builtin_amdgcn_s_sleep(1);
         unsigned long long m = s_mask[lane];
         if (m) {
             s_mask[lane] = 0ull;
-            const float* mine = s_val[my_par];
-            float sum = s_sum_all[b][lane];
-            do {  // up to four contributors are fetched together, then added in order
-                const int l0 = __builtin_ctzll(m); m &= m - 1;
-                const int l1 = m ? __builtin_ctzll(m) : l0; const bool h1 = m != 0; m &= m - 1;
-                const int l2 = m ? __builtin_ctzll(m) : l0; const bool h2 = m != 0; m &= m - 1;
-                const int l3 = m ? __builtin_ctzll(m) : l0; const bool h3 = m != 0; m &= m - 1;
-                const float v0 = mine[l0], v1 = mine[l1], v2 = mine[l2], v3 = mine[l3];
-                sum += v0;
-                if (h1) sum += v1;
-                if (h2) sum += v2;
-                if (h3) sum += v3;
-            } while (m);
-            s_sum_all[b][lane] = sum;
+            float sum = s_sum_all[b][0][lane], sumg = CH == 4 ? s_sum_all[b][CH3 - 2][lane] : 0.f, sumb = CH == 4 ? s_sum_all[b][CH3 - 1][lane] : 0.f;
+            gather_drain<NC, CH>(m, s_val, my_par, sum, sumg, sumb);
+            s_sum_all[b][0][lane] = sum;
+            if (CH == 4) { s_sum_all[b][CH3 - 2][lane] = sumg; s_sum_all[b][CH3 - 1][lane] = sumb; }
         }
         if (lane == 0) __hip_atomic_store(&s_turn, g + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
@@ -950,9 +972,16 @@ __global__ __launch_bounds__(64 * NB) void gather_coop_kernel(const float* __res
         dbg[4 * gbs + 3] = xcc;
     }
     if (x < G.dx && y < G.dy && z < G.dz) {
-        const float sum = s_sum_all[wave][lane];
+        const float sum = s_sum_all[wave][0][lane];
         const uint32_t v = (uint32_t)x + (uint32_t)G.dx * ((uint32_t)y + (uint32_t)G.dy * (uint32_t)z);
-        out[v] = accumulate ? out[v] + sum : sum;
+        if (CH == 1) {
+            out[v] = accumulate ? out[v] + sum : sum;
+        } else {
+            const float sumg = s_sum_all[wave][CH3 - 2][lane], sumb = s_sum_all[wave][CH3 - 1][lane];
+            float4* o = reinterpret_cast<float4*>(out) + v;
+            if (accumulate) { float4 tt = *o; *o = make_float4(tt.x + sum, tt.y + sumg, tt.z + sumb, tt.w); }
+            else *o = make_float4(sum, sumg, sumb, 0.f);
+        }
     }
 }
 
@@ -1108,38 +1137,46 @@ int cpm_gather(cpm_ctx* ctx, const float* sorted_pos_power, const uint32_t* cell
     // candidates per axis (64 per record, ~20 survivors) the record-major form only wins where photons are dense:
     // 256^3 grid, 0.06 photons per cell: 742 us against 577 us voxel-major -- hence the density condition.
     const bool dense = (long long)n * 4 >= (long long)cells;
-    const bool tuned = G.channels == 1 && (cand_axis <= 3 || (cand_axis == 4 && dense)) && Rx <= 2 && Ry <= 2 && Rz <= 2 &&
+    // the tuned record-major kernels: halo of <= 2 cells, 2 to 4 candidate voxels per axis (r < 2 cells); 4-channel
+    // light volumes up to 3 candidates (the slot planes of 4 x 4 x 4 x 3 would not fit a workgroup's LDS)
+    const bool tuned = (cand_axis <= 3 || (cand_axis == 4 && dense && G.channels == 1)) && Rx <= 2 && Ry <= 2 && Rz <= 2 &&
                        g_gather_force_voxel == 0;
-#define CPM_COOP_LAUNCH(NB, MAXC)                                                                                              \
+#define CPM_COOP_LAUNCH(NB, MAXC, CH)                                                                                          \
     do {                                                                                                                       \
         const int zq = div_up(bzn, NB);                                                                                        \
-        CPM_LAUNCH(ctx, (gather_coop_kernel<NB, MAXC>), dim3((unsigned)bxn, (unsigned)byn, (unsigned)zq), dim3(64 * NB), 0, hs, \
-                   sorted_pos_power, cell_start, G, radius, r2max, k, Rx, Ry, Rz, accumulate, bxn, byn, bzn, zq, grid_out,     \
+        CPM_LAUNCH(ctx, (gather_coop_kernel<NB, MAXC, CH>), dim3((unsigned)bxn, (unsigned)byn, (unsigned)zq), dim3(64 * NB), 0, \
+                   hs, sorted_pos_power, cell_start, G, radius, r2max, k, Rx, Ry, Rz, accumulate, bxn, byn, bzn, zq, grid_out, \
                    g_gather_stamps);                                                                                           \
     } while (0)
+#define CPM_REC2_LAUNCH(MAXC, CH)                                                                                              \
+    CPM_LAUNCH(ctx, (gather_records2_kernel<MAXC, CH>), dim3((unsigned)div_up(bxn, 4), (unsigned)byn, (unsigned)bzn), block, 0, \
+               hs, sorted_pos_power, cell_start, G, radius, r2max, k, Rx, Ry, Rz, accumulate, bxn, byn, bzn, grid_out,         \
+               g_gather_stamps)
     if (tuned && coop) {
-        if (cand_axis <= 2) {
-            if (g_gather_coop == 2) CPM_COOP_LAUNCH(2, 2);
-            else if (g_gather_coop == 8) CPM_COOP_LAUNCH(8, 2);
-            else CPM_COOP_LAUNCH(4, 2);
+        if (G.channels == 4) {
+            if (cand_axis <= 2) CPM_COOP_LAUNCH(4, 2, 4); else CPM_COOP_LAUNCH(4, 3, 4);
+        } else if (cand_axis <= 2) {
+            if (g_gather_coop == 2) CPM_COOP_LAUNCH(2, 2, 1);
+            else if (g_gather_coop == 8) CPM_COOP_LAUNCH(8, 2, 1);
+            else CPM_COOP_LAUNCH(4, 2, 1);
         } else if (cand_axis == 3) {
-            CPM_COOP_LAUNCH(4, 3);
+            CPM_COOP_LAUNCH(4, 3, 1);
         } else {
-            CPM_COOP_LAUNCH(4, 4);
+            CPM_COOP_LAUNCH(4, 4, 1);
         }
     } else if (tuned) {
-        const dim3 g3((unsigned)div_up(bxn, 4), (unsigned)byn, (unsigned)bzn);
-        if (cand_axis <= 2)
-            CPM_LAUNCH(ctx, gather_records2_kernel<2>, g3, block, 0, hs, sorted_pos_power, cell_start, G, radius, r2max, k, Rx, Ry, Rz,
-                       accumulate, bxn, byn, bzn, grid_out, g_gather_stamps);
-        else if (cand_axis == 3)
-            CPM_LAUNCH(ctx, gather_records2_kernel<3>, g3, block, 0, hs, sorted_pos_power, cell_start, G, radius, r2max, k, Rx, Ry, Rz,
-                       accumulate, bxn, byn, bzn, grid_out, g_gather_stamps);
-        else
-            CPM_LAUNCH(ctx, gather_records2_kernel<4>, g3, block, 0, hs, sorted_pos_power, cell_start, G, radius, r2max, k, Rx, Ry, Rz,
-                       accumulate, bxn, byn, bzn, grid_out, g_gather_stamps);
+        if (G.channels == 4) {
+            if (cand_axis <= 2) CPM_REC2_LAUNCH(2, 4); else CPM_REC2_LAUNCH(3, 4);
+        } else if (cand_axis <= 2) {
+            CPM_REC2_LAUNCH(2, 1);
+        } else if (cand_axis == 3) {
+            CPM_REC2_LAUNCH(3, 1);
+        } else {
+            CPM_REC2_LAUNCH(4, 1);
+        }
     }
 #undef CPM_COOP_LAUNCH
+#undef CPM_REC2_LAUNCH
     else if (G.channels == 1 && cand_axis <= 2 && g_gather_force_voxel != 1)
         CPM_LAUNCH(ctx, gather_records_kernel<2>, gridDim, block, 0, hs, sorted_pos_power, cell_start, G, radius, r2max, k, Rx, Ry, Rz,
                    accumulate, bxn, byn, grid_out, g_gather_stamps);

@@ -356,7 +356,9 @@ def _random_photons(rng, n, sentinel_every=0, spread=1.0, rgb=False):
     ((32, 32, 32), 1, 0.866, 2),       # generic record-major kernel on the same input
     ((32, 32, 32), 1, 0.866, 1),       # voxel-major kernel on the same input
     ((30, 21, 9), 1, 0.7, 0),          # bricks cut by the grid edge
-    ((24, 40, 16), 4, 1.7, 0),     # 4 x float32: voxel-major
+    ((24, 40, 16), 4, 1.7, 0),     # 4 x float32, 4 candidates per axis: voxel-major
+    ((24, 40, 16), 4, 0.8, 0),     # 4 x float32 through the tuned record-major kernels (2 and 3 candidates per axis)
+    ((22, 19, 33), 4, 1.3, 0),
     ((16, 16, 16), 1, 0.3, 0),
     ((20, 28, 36), 1, 1.2, 0),     # record-major kernel, 3 candidates per axis, bricks cut by the grid edge
     ((32, 32, 32), 1, 2.2, 0),     # radius too large for the record-major kernel: falls back
@@ -441,6 +443,8 @@ def test_gather_one_wave_per_brick_kernel(ctx, oracle, cpm, dims, radius_vox):
         ctx.lib.cpm_debug_set_gather_coop(mode)
         try:
             _bin_and_gather_case(ctx, oracle, cpm, dims, 1, radius_vox)
+            if mode in (0, 4) and radius_vox < 1.5:
+                _bin_and_gather_case(ctx, oracle, cpm, dims, 4, radius_vox)   # 4 x float32 light volume
         finally:
             ctx.lib.cpm_debug_set_gather_coop(1)
 
