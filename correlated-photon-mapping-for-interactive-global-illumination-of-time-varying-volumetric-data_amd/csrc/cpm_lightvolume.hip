@@ -893,14 +893,16 @@ __global__ __launch_bounds__(64 * NB) void gather_coop_kernel(const float* __res
             if (total <= (uint32_t)MAXWORDS * 64u) atomicOr(&s_start_all[wave][off >> 6], 1ull << (off & 63));
         }
         __builtin_amdgcn_wave_barrier();
-        // exclusive prefix over the words of the start mask: rows that start before step w
-        uint32_t pc = (uint32_t)__popcll(s_start_all[wave][lane]), pin = pc;
+        if (total != 0) {  // (four bricks in five are empty: they skip this)
+            // exclusive prefix over the words of the start mask: rows that start before step w
+            uint32_t pc = (uint32_t)__popcll(s_start_all[wave][lane]), pin = pc;
 #pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            uint32_t o = __shfl_up(pin, off, 64);
-            if (lane >= off) pin += o;
+            for (int off = 1; off < 64; off <<= 1) {
+                uint32_t o = __shfl_up(pin, off, 64);
+                if (lane >= off) pin += o;
+            }
+            s_rb_all[wave][lane] = pin - pc;
         }
-        s_rb_all[wave][lane] = pin - pc;
     }
     __syncthreads();
     if (threadIdx.x == 0) {  // first step of every brick in the workgroup's step sequence
