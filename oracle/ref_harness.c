@@ -9,6 +9,7 @@
  *     modules/progressivephotonmapping/cl/densityestimationkernel.cl
  *     modules/progressivephotonmapping/cl/threshold.cl
  *     modules/progressivephotonmapping/cl/indextobuffer.cl
+ *     modules/uniformgridcl/cl/buffermixer.cl (driven by ref_harness_vec.c)
  * No header of the reference or of Inviwo is stubbed.  What this file supplies
  * is the execution harness an OpenCL runtime would: the work-item id and the
  * two integer built-ins those kernels call, whose results the OpenCL 1.2
@@ -21,6 +22,7 @@
 #include <stdint.h>
 
 static __thread size_t g_global_id;
+void ref_set_global_id(size_t id) { g_global_id = id; }  /* for ref_harness_vec.c */
 
 /* size_t get_global_id(uint) -- Itanium mangling used by clang's OpenCL C front end */
 size_t _Z13get_global_idj(unsigned dim) { return dim == 0 ? g_global_id : 0; }

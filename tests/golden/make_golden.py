@@ -4,8 +4,8 @@ Run in the build container, where /root/reference exists:
     make -C oracle ref && python tests/golden/make_golden.py
 The kernels are compiled by oracle/Makefile from where they lie under
 /root/reference/modules (rndgenmwc64x/cl/randstategen.cl + random.cl + skip_mwc.cl,
-progressivephotonmapping/cl/{densityestimationkernel,threshold,indextobuffer}.cl) and driven by
-oracle/ref_harness.c.  The fixture holds inputs and the outputs those kernels produced --
+progressivephotonmapping/cl/{densityestimationkernel,threshold,indextobuffer}.cl, uniformgridcl/cl/buffermixer.cl)
+and driven by oracle/ref_harness.c and oracle/ref_harness_vec.c.  The fixture holds inputs and the outputs those kernels produced --
 data only; no reference source travels.
 """
 import ctypes
@@ -50,7 +50,17 @@ def main():
     tout = ref.threshold(tdata, 2147483647)               # thresholdKernel
     iota = ref.index_to_buffer(777)                       # indexToBufferKernel
 
-    np.savez_compressed(OUT, bases=bases, seeded=seeded, random01=r01, random_uint=ruint, state_after=state_after,
+    # mixKernel (uniformgridcl/cl/buffermixer.cl) as built for float grids and for the min/max grid
+    mx = (rng.standard_normal(1003) * 7).astype(np.float32)
+    my = (rng.standard_normal(1003) * 7).astype(np.float32)
+    mix_a = np.array([0.0, 0.25, 0.37, 0.999, 1.0], np.float32)
+    mix_f = np.stack([ref.mix_f32(mx, my, float(a)) for a in mix_a])
+    ux = rng.integers(0, 65536, (517, 2)).astype(np.uint16)
+    uy = rng.integers(0, 65536, (517, 2)).astype(np.uint16)
+    ux[0], uy[0] = (0, 65535), (65535, 0)
+    mix_u = np.stack([ref.mix_u16x2(ux, uy, float(a)) for a in mix_a])
+
+    np.savez_compressed(OUT, mix_x=mx, mix_y=my, mix_a=mix_a, mix_f32=mix_f, mix_ux=ux, mix_uy=uy, mix_u16x2=mix_u, bases=bases, seeded=seeded, random01=r01, random_uint=ruint, state_after=state_after,
                         per_stream_seeded=ps, per_stream_gap=np.uint64(1000), kernel_x=kx, kernel_y=ky,
                         threshold_in=tdata, threshold_out=tout, iota=iota)
     print("wrote", OUT, OUT.stat().st_size, "bytes")

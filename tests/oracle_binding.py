@@ -333,3 +333,15 @@ class Ref:
         out = np.zeros(n, np.uint32)
         self.lib.ref_index_to_buffer(_p(out), n)
         return out
+
+    def mix_f32(self, x, y, a, wg=128):
+        x = np.ascontiguousarray(x, np.float32); y = np.ascontiguousarray(y, np.float32)
+        out = np.full_like(x, np.float32(-1))
+        self.lib.ref_mix_f32(_p(x), _p(y), C.c_float(a), C.c_uint(x.size), _p(out), C.c_uint(wg))
+        return out
+
+    def mix_u16x2(self, x, y, a, wg=128):
+        x = np.ascontiguousarray(x, np.uint16); y = np.ascontiguousarray(y, np.uint16)
+        out = np.full_like(x, 0xffff)
+        self.lib.ref_mix_u16x2(_p(x), _p(y), C.c_float(a), C.c_uint(x.size // 2), _p(out), C.c_uint(wg))
+        return out

@@ -86,3 +86,27 @@ def test_live_reference_density_kernel(oracle, ref):
     want = ref.density_kernel(x)
     got = np.array([oracle.lib.cpmo_density_kernel(float(v)) for v in x], np.float32)
     assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+
+
+def test_mix_kernel_golden(oracle, golden):
+    """mixKernel (uniformgridcl/cl/buffermixer.cl) as the reference builds it for float grids and for the min/max
+    grid (ushort2 through convert_float2 / convert_ushort2): the oracle reproduces the captured outputs bit for bit,
+    including the index guard (the launch is rounded up to the work-group size)."""
+    for k, a in enumerate(golden["mix_a"]):
+        got = oracle.mix_f32(golden["mix_x"], golden["mix_y"], float(a))
+        assert np.array_equal(got.view(np.uint32), golden["mix_f32"][k].view(np.uint32)), float(a)
+        gotu = oracle.mix_u16x2(golden["mix_ux"], golden["mix_uy"], float(a))
+        assert np.array_equal(gotu, golden["mix_u16x2"][k]), float(a)
+    assert np.array_equal(golden["mix_f32"][0], golden["mix_x"])          # a = 0
+    assert np.array_equal(golden["mix_u16x2"][0], golden["mix_ux"])
+
+
+def test_live_reference_mix_kernel(oracle, ref):
+    rng = np.random.default_rng(11)
+    x = (rng.standard_normal(5000) * 100).astype(np.float32)
+    y = (rng.standard_normal(5000) * 100).astype(np.float32)
+    ux = rng.integers(0, 65536, (3001, 2)).astype(np.uint16)
+    uy = rng.integers(0, 65536, (3001, 2)).astype(np.uint16)
+    for a in (0.0, 0.1, 0.5, 0.73, 1.0):
+        assert np.array_equal(oracle.mix_f32(x, y, a).view(np.uint32), ref.mix_f32(x, y, a).view(np.uint32))
+        assert np.array_equal(oracle.mix_u16x2(ux, uy, a), ref.mix_u16x2(ux, uy, a))
