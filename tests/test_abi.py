@@ -69,3 +69,20 @@ def test_oracle_is_not_imported_by_the_product():
     for f in list(pkg.rglob("*.py")) + list(pkg.rglob("*.hip")) + list(pkg.rglob("*.h")) + list(pkg.rglob("*.cpp")):
         text = f.read_text()
         assert "oracle_binding" not in text and "cpm_oracle" not in text and "libcpm_oracle" not in text, f
+
+
+def test_headers_are_plain_c_and_cxx(tmp_path):
+    """include/cpm/*.h is the boundary: it must compile on its own as C99 and as C++11 (no torch, no HIP types)."""
+    import shutil
+    import subprocess
+    from pathlib import Path
+    repo = Path(__file__).resolve().parent.parent
+    src = tmp_path / "hdr.c"
+    src.write_text('#include <cpm/cpm.h>\n#include <cpm/cpm_profile.h>\n'
+                   'int main(void) { cpm_trace_params p; p.max_interactions = 1; return p.max_interactions - 1 + (CPM_OK != 0); }\n')
+    for cc, std, extra in (("gcc", "-std=c99", []), ("g++", "-std=c++11", ["-x", "c++"])):
+        if not shutil.which(cc):
+            continue
+        r = subprocess.run([cc, std, "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", str(repo / "include"), "-fsyntax-only", *extra, str(src)],
+                           capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
