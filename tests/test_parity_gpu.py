@@ -482,6 +482,35 @@ def test_gather_dense_clusters(ctx, oracle, cpm, mode):
         ctx.lib.cpm_debug_set_gather_coop(1)
 
 
+@pytest.mark.parametrize("n", [1, 2, 63, 64, 65, 255, 257, 2047, 2048, 2049, 32768, 32769, 70_001])
+@pytest.mark.parametrize("channels", [1, 4])
+def test_bin_sizes_around_tile_boundaries(ctx, oracle, cpm, n, channels):
+    """cpm_bin at sizes around the wave / workgroup / sort-tile boundaries (the key kernel counts the first digit per
+    sort tile, the last radix pass writes order / records / run starts): order, cell starts and records equal the
+    oracle's, and a gather over them equals the oracle's gather."""
+    dims = (12, 10, 14)
+    rng = np.random.default_rng(n * 7 + channels)
+    ph = _random_photons(rng, n, sentinel_every=5 if n > 4 else 0, spread=1.1)
+    g, og = cpm.binding.default_grid_desc(dims, channels), oracle.grid(dims, channels)
+    cells = dims[0] * dims[1] * dims[2]
+    torch = ctx.torch
+    order = torch.full((n,), -1, dtype=torch.int32, device=ctx.device)
+    cs = torch.full((cells + 1,), -1, dtype=torch.int32, device=ctx.device)
+    srt = torch.full((n, 4 if channels == 1 else 8), -1.0, dtype=torch.float32, device=ctx.device)
+    ctx.bin(_t(ctx, ph), n, g, order, cs, srt)
+    o_order, o_cs, o_srt = oracle.bin(ph, n, og)
+    assert np.array_equal(_n(order, np.uint32), o_order)
+    assert np.array_equal(_n(cs, np.uint32), o_cs)
+    assert np.array_equal(bits(_n(srt)), bits(o_srt))
+    radius = float(np.float32(0.8 / max(dims)))
+    shape = (cells,) if channels == 1 else (cells, 4)
+    out = torch.full(shape, 5.0, dtype=torch.float32, device=ctx.device)
+    want = np.full(shape, 5.0, np.float32)
+    ctx.gather(srt, cs, n, g, radius, 1.0, out)
+    oracle.gather(o_srt, o_cs, n, og, radius, 1.0, want)
+    assert np.array_equal(bits(_n(out)), bits(want))
+
+
 def test_bin_empty_and_all_sentinel(ctx, oracle, cpm):
     dims = (8, 8, 8)
     g, og = cpm.binding.default_grid_desc(dims, 1), oracle.grid(dims, 1)
