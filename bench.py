@@ -119,7 +119,7 @@ def cpu_baseline(workload, vol_np, tf, n_lattice, grid_dim, light_dir):
     return {
         "value": round(n / total / 1e6, 4), "unit": "Mphotons/s", "cores": cores, "kind": "port", "cpu_model": model,
         "sample": f"median of 5 full frames (after 1 warm-up) of {workload} ({n} photons): trace {tt:.3f} s (OpenMP x{cores}) + "
-                  f"bin {tb:.3f} s (1 thread) + gather {tg:.3f} s (OpenMP x{cores}); the reference's OpenCL cannot be timed "
+                  f"bin {tb:.3f} s (OpenMP, counting sort on <= 16 threads) + gather {tg:.3f} s (OpenMP x{cores}); the reference's OpenCL cannot be timed "
                   f"here (no CPU OpenCL device, Inviwo absent): this is the oracle, a plain-C port of the same path",
         "ms_per_frame": round(total * 1e3, 1), "woodcock_steps": int(steps),
         "splat_formulation_ms": round(splat_s * 1e3, 1),

@@ -638,23 +638,41 @@ void cpmo_copy_indexed_photons(const float* photons, const uint32_t* indices, in
  * stable, ascending on the low key_bits bits, result in place. */
 void cpmo_sort_pairs(uint32_t* keys, uint32_t* values, size_t n, int key_bits) {
     if (key_bits <= 0 || key_bits > 32) key_bits = 32;
-    uint32_t* k2 = (uint32_t*)malloc(n * sizeof(uint32_t));
-    uint32_t* v2 = values ? (uint32_t*)malloc(n * sizeof(uint32_t)) : NULL;
-    size_t* cnt = (size_t*)malloc(65537 * sizeof(size_t));
+    uint32_t* k2 = (uint32_t*)malloc((n ? n : 1) * sizeof(uint32_t));
+    uint32_t* v2 = values ? (uint32_t*)malloc((n ? n : 1) * sizeof(uint32_t)) : NULL;
+    /* LSD counting sort on 16-bit digits.  With OpenMP threads the input is cut into contiguous chunks, one per
+     * thread: per-(digit, chunk) counts, offsets taken in (digit, chunk) order, every chunk scattered in its own
+     * order -- the same stable result as the one-thread loop, whatever the thread count. */
+    int T = g_threads < 1 ? 1 : (g_threads > 16 ? 16 : g_threads);
+    if (n < 65536) T = 1;
+    size_t* cnt = (size_t*)malloc((size_t)T * 65536 * sizeof(size_t));
     uint32_t *ks = keys, *kd = k2, *vs = values, *vd = v2;
     for (int shift = 0; shift < key_bits; shift += 16) {
         int bits = key_bits - shift < 16 ? key_bits - shift : 16;
         uint32_t mask = (1u << bits) - 1u;
-        for (int i = 0; i <= 65536; ++i) cnt[i] = 0;
-        for (size_t i = 0; i < n; ++i) cnt[((ks[i] >> shift) & mask) + 1]++;
-        for (int i = 0; i < 65536; ++i) cnt[i + 1] += cnt[i];
-        for (size_t i = 0; i < n; ++i) {
-            size_t d = cnt[(ks[i] >> shift) & mask]++;
-            kd[d] = ks[i];
-            if (vs) vd[d] = vs[i];
+        const size_t chunk = (n + (size_t)T - 1) / (size_t)T;
+#pragma omp parallel for num_threads(T) schedule(static, 1)
+        for (int t = 0; t < T; ++t) {
+            size_t* c = cnt + (size_t)t * 65536;
+            memset(c, 0, 65536 * sizeof(size_t));
+            size_t lo = (size_t)t * chunk, hi = lo + chunk < n ? lo + chunk : n;
+            for (size_t i = lo; i < hi; ++i) c[(ks[i] >> shift) & mask]++;
         }
-        uint32_t* t = ks; ks = kd; kd = t;
-        t = vs; vs = vd; vd = t;
+        size_t run = 0;
+        for (uint32_t d = 0; d <= mask; ++d)
+            for (int t = 0; t < T; ++t) { size_t c = cnt[(size_t)t * 65536 + d]; cnt[(size_t)t * 65536 + d] = run; run += c; }
+#pragma omp parallel for num_threads(T) schedule(static, 1)
+        for (int t = 0; t < T; ++t) {
+            size_t* c = cnt + (size_t)t * 65536;
+            size_t lo = (size_t)t * chunk, hi = lo + chunk < n ? lo + chunk : n;
+            for (size_t i = lo; i < hi; ++i) {
+                size_t d = c[(ks[i] >> shift) & mask]++;
+                kd[d] = ks[i];
+                if (vs) vd[d] = vs[i];
+            }
+        }
+        uint32_t* tp = ks; ks = kd; kd = tp;
+        tp = vs; vs = vd; vd = tp;
     }
     if (ks != keys) {
         memcpy(keys, ks, n * sizeof(uint32_t));
@@ -686,17 +704,24 @@ static inline uint32_t cell_key(const float* ph, const cpmo_grid_desc* g) {
 void cpmo_bin(const float* photons, int n, const cpmo_grid_desc* g, uint32_t* order,
               uint32_t* cell_start, float* sorted) {
     uint32_t cells = (uint32_t)g->dims[0] * g->dims[1] * g->dims[2];
-    uint32_t* keys = (uint32_t*)malloc((size_t)n * sizeof(uint32_t));
+    uint32_t* keys = (uint32_t*)malloc(((size_t)n ? (size_t)n : 1) * sizeof(uint32_t));
+#pragma omp parallel for num_threads(g_threads) schedule(static)
     for (int i = 0; i < n; ++i) { keys[i] = cell_key(photons + 8 * (size_t)i, g); order[i] = (uint32_t)i; }
     /* all 32 bits: the sentinel key 0xffffffff must sort last */
     cpmo_sort_pairs(keys, order, (size_t)n, 32);
     (void)key_bits_for;
-    size_t j = 0;
-    for (uint32_t c = 0; c <= cells; ++c) {
-        while (j < (size_t)n && keys[j] < c) ++j;
-        cell_start[c] = (uint32_t)j;
+    /* cell_start[c] = first sorted position with key >= c: one lower bound per entry */
+#pragma omp parallel for num_threads(g_threads) schedule(static)
+    for (long long c = 0; c <= (long long)cells; ++c) {
+        size_t lo = 0, hi = (size_t)n;
+        while (lo < hi) {
+            size_t mid = (lo + hi) >> 1;
+            if (keys[mid] < (uint32_t)c) lo = mid + 1; else hi = mid;
+        }
+        cell_start[c] = (uint32_t)lo;
     }
     int stride = g->channels == 1 ? 4 : 8;
+#pragma omp parallel for num_threads(g_threads) schedule(static)
     for (int i = 0; i < n; ++i) {
         const float* ph = photons + 8 * (size_t)order[i];
         float* q = sorted + (size_t)stride * i;
