@@ -634,6 +634,10 @@ void cpmo_copy_indexed_photons(const float* photons, const uint32_t* indices, in
 
 /* ------------------------------------------------------------------ sort / bin / gather */
 
+/* Team size of the short parallel regions of the sort / bin: their barriers do not scale to hundreds of threads
+ * (measured on a 2 x 64-core host: 9 ms at 64 threads, 800 ms at 256 for one bin of 1 M photons). */
+static int bin_threads(void) { return g_threads < 1 ? 1 : (g_threads > 64 ? 64 : g_threads); }
+
 /* Semantics of clogs::Radixsort::enqueue (radixsortcl/ext/clogs/src/radixsort.cpp:169-259):
  * stable, ascending on the low key_bits bits, result in place. */
 void cpmo_sort_pairs(uint32_t* keys, uint32_t* values, size_t n, int key_bits) {
@@ -651,7 +655,7 @@ void cpmo_sort_pairs(uint32_t* keys, uint32_t* values, size_t n, int key_bits) {
         int bits = key_bits - shift < 16 ? key_bits - shift : 16;
         uint32_t mask = (1u << bits) - 1u;
         const size_t chunk = (n + (size_t)T - 1) / (size_t)T;
-#pragma omp parallel for num_threads(T) schedule(static, 1)
+#pragma omp parallel for num_threads(bin_threads()) schedule(static, 1)
         for (int t = 0; t < T; ++t) {
             size_t* c = cnt + (size_t)t * 65536;
             memset(c, 0, 65536 * sizeof(size_t));
@@ -661,7 +665,7 @@ void cpmo_sort_pairs(uint32_t* keys, uint32_t* values, size_t n, int key_bits) {
         size_t run = 0;
         for (uint32_t d = 0; d <= mask; ++d)
             for (int t = 0; t < T; ++t) { size_t c = cnt[(size_t)t * 65536 + d]; cnt[(size_t)t * 65536 + d] = run; run += c; }
-#pragma omp parallel for num_threads(T) schedule(static, 1)
+#pragma omp parallel for num_threads(bin_threads()) schedule(static, 1)
         for (int t = 0; t < T; ++t) {
             size_t* c = cnt + (size_t)t * 65536;
             size_t lo = (size_t)t * chunk, hi = lo + chunk < n ? lo + chunk : n;
@@ -705,13 +709,13 @@ void cpmo_bin(const float* photons, int n, const cpmo_grid_desc* g, uint32_t* or
               uint32_t* cell_start, float* sorted) {
     uint32_t cells = (uint32_t)g->dims[0] * g->dims[1] * g->dims[2];
     uint32_t* keys = (uint32_t*)malloc(((size_t)n ? (size_t)n : 1) * sizeof(uint32_t));
-#pragma omp parallel for num_threads(g_threads) schedule(static)
+#pragma omp parallel for num_threads(bin_threads()) schedule(static)
     for (int i = 0; i < n; ++i) { keys[i] = cell_key(photons + 8 * (size_t)i, g); order[i] = (uint32_t)i; }
     /* all 32 bits: the sentinel key 0xffffffff must sort last */
     cpmo_sort_pairs(keys, order, (size_t)n, 32);
     (void)key_bits_for;
     /* cell_start[c] = first sorted position with key >= c: one lower bound per entry */
-#pragma omp parallel for num_threads(g_threads) schedule(static)
+#pragma omp parallel for num_threads(bin_threads()) schedule(static)
     for (long long c = 0; c <= (long long)cells; ++c) {
         size_t lo = 0, hi = (size_t)n;
         while (lo < hi) {
@@ -721,7 +725,7 @@ void cpmo_bin(const float* photons, int n, const cpmo_grid_desc* g, uint32_t* or
         cell_start[c] = (uint32_t)lo;
     }
     int stride = g->channels == 1 ? 4 : 8;
-#pragma omp parallel for num_threads(g_threads) schedule(static)
+#pragma omp parallel for num_threads(bin_threads()) schedule(static)
     for (int i = 0; i < n; ++i) {
         const float* ph = photons + 8 * (size_t)order[i];
         float* q = sorted + (size_t)stride * i;
@@ -743,7 +747,8 @@ void cpmo_gather(const float* sorted, const uint32_t* cell_start, int n, const c
     const int Ry = (int)floorf(om_fma(radius, (float)dy_, 0.501f));
     const int Rz = (int)floorf(om_fma(radius, (float)dz_, 0.501f));
     const int stride = g->channels == 1 ? 4 : 8;
-#pragma omp parallel for num_threads(g_threads) schedule(dynamic, 1)
+    /* (z, y) rows are the tasks: photons pile up on a few faces, whole z-slabs would leave most threads idle */
+#pragma omp parallel for collapse(2) num_threads(g_threads) schedule(dynamic, 4)
     for (int z = 0; z < dz_; ++z)
         for (int y = 0; y < dy_; ++y)
             for (int x = 0; x < dx_; ++x) {
