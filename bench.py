@@ -168,6 +168,9 @@ def main():
     ap.add_argument("--splat", action="store_true", help="also time the reference formulation (atomic splat)")
     ap.add_argument("--streams", type=int, default=4,
                     help="frames in flight for the extra 'pipelined' figure (0 = skip it); 'value' is always one stream")
+    ap.add_argument("--test-backend", default="nccl", choices=["nccl", "gloo"],
+                    help="(testing) process-group backend; gloo lets the N > 1 code path run with every rank on one GPU")
+    ap.add_argument("--test-one-device", action="store_true", help="(testing) every rank uses cuda:0")
     ap.add_argument("--graph", action="store_true",
                     help="replay a captured HIP graph of the frame instead of eager launches (measured slower here: 0.299 vs 0.251 ms)")
     args = ap.parse_args()
@@ -181,7 +184,7 @@ def main():
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    local_rank = 0 if args.test_one_device else int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus and rank == 0:
         print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
     if not torch.cuda.is_available():
@@ -190,7 +193,10 @@ def main():
     dist = None
     if world > 1 or "TORCHELASTIC_RUN_ID" in os.environ:  # launched by torch.distributed.run (also at N = 1)
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))  # backend nccl = RCCL on ROCm
+        if args.test_backend == "gloo":
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))  # backend nccl = RCCL on ROCm
 
     vdim, (nx, ny), gdim = WORKLOADS[args.workload]
     light_dir = (0.3, 0.5, -1.0)

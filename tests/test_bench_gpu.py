@@ -1,0 +1,47 @@
+"""bench.py end to end on the GPU: the single-GPU line, and the N > 1 code path (photon shards, overlapped grid
+reduction, max-over-ranks timing, rank-0 JSON) with two ranks sharing the one GPU of the test box over gloo."""
+import json
+import os
+import subprocess
+import sys
+from pathlib import Path
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+REPO = Path(__file__).resolve().parent.parent
+KEYS = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+        "data", "config", "roofline"}
+
+
+def _last_json(out):
+    lines = [l for l in out.splitlines() if l.startswith("{")]
+    assert lines, out[-2000:]
+    return json.loads(lines[-1])
+
+
+def test_bench_single_gpu_line():
+    r = subprocess.run([sys.executable, str(REPO / "bench.py"), "--steps", "10", "--warmup", "2", "--workload", "config1", "--streams", "2"],
+                       capture_output=True, text=True, timeout=900, cwd=str(REPO))
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = _last_json(r.stdout)
+    assert KEYS <= set(d) and {"cpu_baseline", "pipelined", "frame"} <= set(d)
+    assert d["n_gpus"] == 1 and d["steps"] == 10 and d["warmup"] == 2 and d["value"] > 0 and d["scaling"] == "weak"
+    assert set(d["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic"}
+    assert set(d["cpu_baseline"]) >= {"value", "unit", "cores", "kind", "sample"} and d["cpu_baseline"]["kind"] == "port"
+    assert d["pipelined"]["light_volumes_identical_to_single_stream"] is True
+
+
+def test_bench_two_ranks_code_path():
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29533", str(REPO / "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2", "--workload", "config1",
+           "--test-backend", "gloo", "--test-one-device"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=str(REPO), env=env)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-4000:]
+    d = _last_json(r.stdout)
+    assert KEYS <= set(d)
+    assert d["n_gpus"] == 2 and d["steps"] == 6 and d["value"] > 0
+    assert "cpu_baseline" not in d                      # rank 0 at N = 1 only
+    assert "all-reduce" in d["config"]["parallelism"]
+    assert d["config"]["photons_per_gpu"] == 65536     # weak scaling: the per-rank work is fixed
