@@ -33,7 +33,7 @@ ABI_SYMBOLS = [
     "cpm_trace",
     "cpm_grid_desc_default", "cpm_relative_irradiance_scale",
     "cpm_splat", "cpm_splat_selected", "cpm_copy_indexed_photons",
-    "cpm_sort_pairs", "cpm_sort_keys", "cpm_bin", "cpm_gather",
+    "cpm_sort_pairs", "cpm_sort_keys", "cpm_bin", "cpm_gather", "cpm_mark_touched_bricks", "cpm_gather_bricks",
     "cpm_volume_minmax", "cpm_volume_difference", "cpm_importance_tf",
     "cpm_photon_importance", "cpm_photon_importance_equal", "cpm_reset_importance",
     "cpm_select_recompute", "cpm_select_changed",
@@ -114,6 +114,8 @@ def load_library() -> C.CDLL:
         "cpm_sort_keys": (i32, [vp, vp, sz, i32, vp]),
         "cpm_bin": (i32, [vp, vp, i32, P(GridDesc), vp, vp, vp, vp]),
         "cpm_gather": (i32, [vp, vp, vp, i32, P(GridDesc), f32, f32, i32, vp, vp]),
+        "cpm_mark_touched_bricks": (i32, [vp, vp, vp, i32, i32, i32, P(GridDesc), f32, vp, vp]),
+        "cpm_gather_bricks": (i32, [vp, vp, vp, i32, P(GridDesc), f32, f32, vp, vp, vp]),
         "cpm_volume_minmax": (i32, [vp, vp, i32, vp, vp]),
         "cpm_volume_difference": (i32, [vp, vp, vp, i32, vp, vp]),
         "cpm_importance_tf": (i32, [vp, vp, vp, vp, i32, vp, vp, i32, vp, vp]),
@@ -361,6 +363,14 @@ class Context:
     def gather(self, sorted_pos_power, cell_start, n, grid, radius, scale, out, accumulate=False):
         self._check(self.lib.cpm_gather(self.h, self._ptr(sorted_pos_power), self._ptr(cell_start), n, C.byref(grid), radius,
                                         scale, int(accumulate), self._ptr(out), self._stream()))
+
+    def mark_touched_bricks(self, photons, indices, n_indices, n_photons, n_interactions, grid, radius, brick_mask):
+        self._check(self.lib.cpm_mark_touched_bricks(self.h, self._ptr(photons), self._ptr(indices), n_indices, n_photons,
+                                                     n_interactions, C.byref(grid), radius, self._ptr(brick_mask), self._stream()))
+
+    def gather_bricks(self, sorted_pos_power, cell_start, n, grid, radius, scale, brick_mask, out):
+        self._check(self.lib.cpm_gather_bricks(self.h, self._ptr(sorted_pos_power), self._ptr(cell_start), n, C.byref(grid), radius,
+                                               scale, self._ptr(brick_mask), self._ptr(out), self._stream()))
 
     # -- temporal interpolation
     def mix_buffers(self, x, y, a, out, kind=None):

@@ -660,7 +660,8 @@ __global__ __launch_bounds__(256) void gather_records2_kernel(const float* __res
                                                               const uint32_t* __restrict__ cell_start, GridDev G, float radius,
                                                               float r2max, float k, int Rx, int Ry, int Rz, int accumulate,
                                                               int bxn, int byn, int bzn, float* __restrict__ out,
-                                                              unsigned long long* __restrict__ dbg) {
+                                                              unsigned long long* __restrict__ dbg,
+                                                              const uint8_t* __restrict__ bmask) {
     constexpr int MAXROWS = 64;
     constexpr int MAXWORDS = 64;  // row-start bitmask: up to 4096 records per brick halo, else the generic kernel's path
     constexpr int NC = MAXC * MAXC * MAXC, CH3 = CH == 4 ? 3 : 1, STRIDE = CH == 4 ? 2 : 1;
@@ -684,6 +685,7 @@ __global__ __launch_bounds__(256) void gather_records2_kernel(const float* __res
     const int by = (int)blockIdx.y, bzi = (int)blockIdx.z;
     const int bz = (bzi & 1) ? (bzi >> 1) : (bzn - 1 - (bzi >> 1));  // bzn-1, 0, bzn-2, 1, ...
     const int bx = (bxr + 4 * (by + bzi)) % bxn;                     // XCD-balancing rotation (scalar)
+    if (bmask && !bmask[(size_t)bx + (size_t)bxn * ((size_t)by + (size_t)byn * (size_t)bz)]) return;  // cpm_gather_bricks: brick not selected
     const int x0 = bx * kGW, y0 = by * kGW, z0 = bz * kGW;
     const int x = x0 + (lane & 3), y = y0 + ((lane >> 2) & 3), z = z0 + (lane >> 4);
     const bool valid = x < G.dx && y < G.dy && z < G.dz;
@@ -818,7 +820,8 @@ __global__ __launch_bounds__(64 * NB) void gather_coop_kernel(const float* __res
                                                           const uint32_t* __restrict__ cell_start, GridDev G, float radius,
                                                           float r2max, float k, int Rx, int Ry, int Rz, int accumulate,
                                                           int bxn, int byn, int bzn, int zq, float* __restrict__ out,
-                                                          unsigned long long* __restrict__ dbg) {
+                                                          unsigned long long* __restrict__ dbg,
+                                                          const uint8_t* __restrict__ bmask) {
     constexpr int MAXROWS = 64;
     constexpr int MAXWORDS = 64;  // row-start bitmask: up to 4096 records per brick halo, else a binary search
     constexpr int NC = MAXC * MAXC * MAXC, CH3 = CH == 4 ? 3 : 1, STRIDE = CH == 4 ? 2 : 1;
@@ -851,7 +854,8 @@ __global__ __launch_bounds__(64 * NB) void gather_coop_kernel(const float* __res
         const int by = (byw + b * yq) % byn;
         const int bx = (bxr + by + bzi) % bxn;
         x0 = bx * kGW; y0 = by * kGW; z0 = bz * kGW;
-        return true;
+        // cpm_gather_bricks: a brick that is not selected has no records here and is not written
+        return !bmask || bmask[(size_t)bx + (size_t)bxn * ((size_t)by + (size_t)byn * (size_t)bz)] != 0;
     };
 
     // ---- phase 0: wave b prepares brick b
@@ -987,6 +991,24 @@ __global__ __launch_bounds__(64 * NB) void gather_coop_kernel(const float* __res
     }
 }
 
+// splat boxes of the selected photons (all interactions) -> the 4x4x4 voxel bricks they overlap
+__global__ __launch_bounds__(256) void mark_bricks_kernel(const float* __restrict__ photons, const uint32_t* __restrict__ indices,
+                                                          int n_indices, int n_photons, int n_interactions, GridDev G,
+                                                          float radius, int bxn, int byn, uint8_t* __restrict__ mask) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n_indices * n_interactions) return;
+    const size_t id = (size_t)indices[j % n_indices] + (size_t)(j / n_indices) * (size_t)n_photons;
+    const float4 a = reinterpret_cast<const float4*>(photons)[2 * id];
+    if (a.x == kFltMax || a.y == kFltMax || a.z == kFltMax) return;
+    const f3 p = { a.x, a.y, a.z };
+    const Box3 bb = splat_box(G, p, radius);
+    if (bb.ex <= bb.sx || bb.ey <= bb.sy || bb.ez <= bb.sz) return;
+    for (int bz = bb.sz >> 2; bz <= (bb.ez - 1) >> 2; ++bz)
+        for (int by = bb.sy >> 2; by <= (bb.ey - 1) >> 2; ++by)
+            for (int bx = bb.sx >> 2; bx <= (bb.ex - 1) >> 2; ++bx)
+                mask[(size_t)bx + (size_t)bxn * ((size_t)by + (size_t)byn * (size_t)bz)] = 1;  // same value from every writer
+}
+
 int key_bits_for(uint32_t max_key) {  // bits needed to represent max_key
     int b = 1;
     while (b < 32 && (max_key >> b) != 0) ++b;
@@ -1104,9 +1126,44 @@ int cpm_bin(cpm_ctx* ctx, const float* photons8, int n, const cpm_grid_desc* gri
     return CPM_OK;
 }
 
+static int gather_impl(cpm_ctx* ctx, const float* sorted_pos_power, const uint32_t* cell_start, int n,
+                       const cpm_grid_desc* grid, float radius, float scale, int accumulate, float* grid_out,
+                       const uint8_t* brick_mask, cpm_stream stream);
+
 int cpm_gather(cpm_ctx* ctx, const float* sorted_pos_power, const uint32_t* cell_start, int n,
                const cpm_grid_desc* grid, float radius, float scale, int accumulate, float* grid_out,
                cpm_stream stream) {
+    return gather_impl(ctx, sorted_pos_power, cell_start, n, grid, radius, scale, accumulate, grid_out, nullptr, stream);
+}
+
+int cpm_gather_bricks(cpm_ctx* ctx, const float* sorted_pos_power, const uint32_t* cell_start, int n,
+                      const cpm_grid_desc* grid, float radius, float scale, const uint8_t* brick_mask, float* grid_out,
+                      cpm_stream stream) {
+    if (!ctx) return CPM_ERR_INVALID_ARGUMENT;
+    CPM_REQUIRE(ctx, brick_mask, "cpm_gather_bricks: null mask");
+    return gather_impl(ctx, sorted_pos_power, cell_start, n, grid, radius, scale, 0, grid_out, brick_mask, stream);
+}
+
+int cpm_mark_touched_bricks(cpm_ctx* ctx, const float* photons8, const uint32_t* indices, int n_indices, int n_photons,
+                            int n_interactions, const cpm_grid_desc* grid, float radius, uint8_t* brick_mask, cpm_stream stream) {
+    if (!ctx) return CPM_ERR_INVALID_ARGUMENT;
+    GridDev G;
+    int rc = make_grid_dev(ctx, grid, G);
+    if (rc) return rc;
+    CPM_REQUIRE(ctx, n_indices >= 0 && n_photons >= 0 && n_interactions >= 1 && radius > 0.f, "cpm_mark_touched_bricks: bad size or radius");
+    if (n_indices == 0) return CPM_OK;
+    CPM_REQUIRE(ctx, photons8 && indices && brick_mask, "cpm_mark_touched_bricks: null buffer");
+    const int bxn = div_up(G.dx, 4), byn = div_up(G.dy, 4);
+    const long long threads = (long long)n_indices * n_interactions;
+    CPM_LAUNCH(ctx, mark_bricks_kernel, dim3((unsigned)div_up(threads, 256)), dim3(256), 0, (hipStream_t)stream, photons8, indices,
+               n_indices, n_photons, n_interactions, G, radius, bxn, byn, brick_mask);
+    CPM_LAUNCH_CHECK(ctx, "mark_bricks_kernel");
+    return CPM_OK;
+}
+
+static int gather_impl(cpm_ctx* ctx, const float* sorted_pos_power, const uint32_t* cell_start, int n,
+                       const cpm_grid_desc* grid, float radius, float scale, int accumulate, float* grid_out,
+                       const uint8_t* brick_mask, cpm_stream stream) {
     if (!ctx) return CPM_ERR_INVALID_ARGUMENT;
     GridDev G;
     int rc = make_grid_dev(ctx, grid, G);
@@ -1148,12 +1205,12 @@ int cpm_gather(cpm_ctx* ctx, const float* sorted_pos_power, const uint32_t* cell
         const int zq = div_up(bzn, NB);                                                                                        \
         CPM_LAUNCH(ctx, (gather_coop_kernel<NB, MAXC, CH>), dim3((unsigned)bxn, (unsigned)byn, (unsigned)zq), dim3(64 * NB), 0, \
                    hs, sorted_pos_power, cell_start, G, radius, r2max, k, Rx, Ry, Rz, accumulate, bxn, byn, bzn, zq, grid_out, \
-                   g_gather_stamps);                                                                                           \
+                   g_gather_stamps, brick_mask);                                                                               \
     } while (0)
 #define CPM_REC2_LAUNCH(MAXC, CH)                                                                                              \
     CPM_LAUNCH(ctx, (gather_records2_kernel<MAXC, CH>), dim3((unsigned)div_up(bxn, 4), (unsigned)byn, (unsigned)bzn), block, 0, \
                hs, sorted_pos_power, cell_start, G, radius, r2max, k, Rx, Ry, Rz, accumulate, bxn, byn, bzn, grid_out,         \
-               g_gather_stamps)
+               g_gather_stamps, brick_mask)
     if (tuned && coop) {
         if (G.channels == 4) {
             if (cand_axis <= 2) CPM_COOP_LAUNCH(4, 2, 4); else CPM_COOP_LAUNCH(4, 3, 4);

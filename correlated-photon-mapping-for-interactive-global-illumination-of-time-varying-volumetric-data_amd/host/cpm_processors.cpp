@@ -675,7 +675,8 @@ PhotonToLightVolumeProcessorCL::PhotonToLightVolumeProcessorCL() {
     addPortId("lightvolume", false);
     recomputedPhotonIndicesPort_.setOptional(true);
     for (PropertyBase* p : std::initializer_list<PropertyBase*>{ &incrementalRecomputationThreshold_, &volumeSizeOption_, &volumeDataTypeOption_,
-                                                                &alignChangedPhotons_, &workGroupSize_, &useGLSharing_, &formulation_ })
+                                                                &alignChangedPhotons_, &workGroupSize_, &useGLSharing_, &formulation_,
+                                                                &exactIncrementalUpdate_ })
         addProperty(*p);
     volumeSizeOption_.onChange([this]() { volumeSizeOptionChanged(); });
     volumeDataTypeOption_.onChange([this]() {
@@ -723,12 +724,29 @@ void PhotonToLightVolumeProcessorCL::process() {  // photontolightvolumeprocesso
     const bool haveIdx = recomputedPhotonIndicesPort_.isReady();
     const int nRecomputed = haveIdx ? recomputedPhotonIndicesPort_.getData()->nRecomputedPhotons : -1;
     if (!fresh && haveIdx && prevPhotons_.getSize() == photonData->photons_.getSize() && nRecomputed > 0 && nRecomputed < maxRecomputationPhotons) {
-        // add-remove (:196-298): -old, +new over the re-traced photons
         const unsigned int* idx = recomputedPhotonIndicesPort_.getData()->indicesToRecomputedPhotons.device();
+        if (exactIncrementalUpdate_.get() && formulation_.get() != "splat") {
+            // exact add-remove: mark the bricks an old or new position touches, re-bin, re-gather those bricks only
+            const size_t nb = ((outDim.x + 3) / 4) * ((outDim.y + 3) / 4) * ((outDim.z + 3) / 4);
+            brickMask_.setSize(nb);
+            (void)hipMemsetAsync(brickMask_.device(), 0, nb, rt.stream());
+            const size_t m = (size_t)nPhotons * nInter;
+            order_.setSize(m); cellStart_.setSize(cells + 1); sorted_.setSize(m * (channels == 1 ? 4 : 8));
+            bool ok = rt.check(cpm_mark_touched_bricks(rt.ctx(), reinterpret_cast<const float*>(prevPhotons_.device()), idx, nRecomputed, nPhotons,
+                                                       nInter, &g, radius, brickMask_.device(), rt.stream()), "cpm_mark_touched_bricks(old)");
+            ok = ok && rt.check(cpm_mark_touched_bricks(rt.ctx(), photons, idx, nRecomputed, nPhotons, nInter, &g, radius, brickMask_.device(),
+                                                        rt.stream()), "cpm_mark_touched_bricks(new)");
+            ok = ok && rt.check(cpm_bin(rt.ctx(), photons, (int)m, &g, order_.device(), cellStart_.device(), sorted_.device(), rt.stream()), "cpm_bin");
+            if (ok) rt.check(cpm_gather_bricks(rt.ctx(), sorted_.device(), cellStart_.device(), (int)m, &g, radius, scale, brickMask_.device(), out,
+                                               rt.stream()), "cpm_gather_bricks");
+            lastPath_ = "exact incremental";
+        } else {
+        // add-remove (:196-298): -old, +new over the re-traced photons
         rt.check(cpm_splat_selected(rt.ctx(), reinterpret_cast<const float*>(prevPhotons_.device()), idx, nRecomputed, &g, radius, scale, -1.f, nPhotons,
                                     nInter, out, rt.stream()), "cpm_splat_selected(-)");
         rt.check(cpm_splat_selected(rt.ctx(), photons, idx, nRecomputed, &g, radius, scale, 1.f, nPhotons, nInter, out, rt.stream()), "cpm_splat_selected(+)");
         lastPath_ = "incremental";
+        }
     } else if (fresh || prevPhotons_.getSize() != photonData->photons_.getSize() || nRecomputed < 0 || nRecomputed >= maxRecomputationPhotons) {
         if (formulation_.get() == "splat") {  // the reference's formulation: clear + atomic splat (:299-339)
             (void)hipMemsetAsync(out, 0, cells * channels * sizeof(float), rt.stream());

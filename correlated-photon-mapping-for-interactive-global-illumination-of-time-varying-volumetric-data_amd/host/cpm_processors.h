@@ -419,6 +419,9 @@ public:
     BoolProperty useGLSharing_{ "glsharing", "Use OpenGL sharing", true };  // inert
     // "gather" (default: sort/bin + deterministic gather) or "splat" (the reference's atomic formulation)
     StringOptionProperty formulation_{ "formulation", "Density estimation", "gather" };
+    // add-remove of the re-traced photons: false (default) = the reference's -old / +new atomic splats; true = re-bin and
+    // re-gather exactly the bricks they touch (bit-identical to a full gather) -- not a property of the reference
+    BoolProperty exactIncrementalUpdate_{ "exactIncrementalUpdate", "Exact incremental update", false };
     const char* lastPath() const { return lastPath_; }
 private:
     void volumeSizeOptionChanged();
@@ -426,6 +429,7 @@ private:
     Buffer<vec4> prevPhotons_;
     Buffer<unsigned int> order_, cellStart_;
     Buffer<float> sorted_;
+    Buffer<uint8_t> brickMask_;
     const char* lastPath_ = "none";
 };
 

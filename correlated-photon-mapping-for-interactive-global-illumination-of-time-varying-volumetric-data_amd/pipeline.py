@@ -359,13 +359,18 @@ class CorrelatedPhotonMapper(PhotonFrame):
     """
 
     def __init__(self, *args, region: int = 8, max_incremental_percent: float = 100.0,
-                 incremental_threshold_percent: float = 50.0, fix_exit_point: bool = False, tf_points=None, **kw):
+                 incremental_threshold_percent: float = 50.0, fix_exit_point: bool = False, tf_points=None,
+                 exact_update: bool = False, **kw):
         super().__init__(*args, **kw)
         torch, dev, ctx = self.torch, self.ctx.device, self.ctx
         self.region = region
         self.max_incremental_percent = max_incremental_percent
         self.incremental_threshold_percent = incremental_threshold_percent
         self.fix_exit_point = fix_exit_point
+        # exact_update: re-bin and re-gather exactly the bricks a changed photon touches (bit-identical to a full frame)
+        # instead of the reference's -old / +new atomic splats (cheaper, within fp32 tolerance, not reproducible)
+        self.exact_update = exact_update
+        self.brick_mask = None
         self.tf_points = list(tf_points) if tf_points is not None else list(S.WORKSPACE_TF_POINTS)
         vd = self.vol.dims
         self.brick_dims = tuple((d + region - 1) // region for d in vd)
@@ -485,7 +490,19 @@ class CorrelatedPhotonMapper(PhotonFrame):
     def _update_light_volume(self, idx, n):
         ctx = self.ctx
         max_recomp = int(self.n * (self.incremental_threshold_percent / 100.0))
-        if self.prev_photons is not None and 0 < n < max_recomp:
+        if self.prev_photons is not None and 0 < n < max_recomp and self.exact_update:
+            gd = self.grid.dims
+            nb = ((gd[0] + 3) // 4) * ((gd[1] + 3) // 4) * ((gd[2] + 3) // 4)
+            if self.brick_mask is None:
+                self.brick_mask = self.torch.empty(nb, dtype=self.torch.uint8, device=ctx.device)
+            self.brick_mask.zero_()
+            ctx.mark_touched_bricks(self.prev_photons, idx, n, self.n, self.I, self.grid, self.radius, self.brick_mask)
+            ctx.mark_touched_bricks(self.photons, idx, n, self.n, self.I, self.grid, self.radius, self.brick_mask)
+            self.bin()
+            ctx.gather_bricks(self.sorted, self.cell_start, self.n * self.I, self.grid, self.radius, self.scale, self.brick_mask,
+                              self.light_volume)
+            self.last_path = "exact incremental"
+        elif self.prev_photons is not None and 0 < n < max_recomp:
             # incremental: remove the old contributions, add the new ones (processorcl.cpp:196-298)
             ctx.splat_selected(self.prev_photons, idx, n, self.grid, self.radius, self.scale, -1.0, self.n, self.I, self.light_volume)
             ctx.splat_selected(self.photons, idx, n, self.grid, self.radius, self.scale, 1.0, self.n, self.I, self.light_volume)

@@ -273,6 +273,24 @@ int cpm_gather(cpm_ctx* ctx, const float* sorted_pos_power, const uint32_t* cell
                const cpm_grid_desc* grid, float radius, float relative_irradiance_scale,
                int accumulate, float* grid_out, cpm_stream stream);
 
+/* Exact incremental update of a light volume (the "delta gather restricted to touched cells"):
+ * after n photons have been re-traced, only voxels inside the splat box of an old or a new position of
+ * one of them can change.  cpm_mark_touched_bricks sets brick_mask[b] = 1 for every 4x4x4 voxel brick
+ * (b = bx + ceil(dx/4) * (by + ceil(dy/4) * bz)) overlapped by the splat boxes of the selected photons --
+ * call it once with the previous photon buffer and once with the new one, on a mask the caller has zeroed
+ * (ceil(dx/4) * ceil(dy/4) * ceil(dz/4) bytes).  cpm_gather_bricks then recomputes exactly those bricks
+ * from the re-binned photons and leaves every other voxel as it is: the result is bit-identical to a full
+ * cpm_gather (unchanged photons keep their relative order, so untouched sums are the same additions).
+ * The reference updates with two atomic splats instead (-old, +new: cpm_splat_selected), which is
+ * cheaper but neither exact nor reproducible
+ * (ref processor/photontolightvolumeprocessorcl.cpp:196-298). */
+int cpm_mark_touched_bricks(cpm_ctx* ctx, const float* photons8, const uint32_t* indices, int n_indices,
+                            int n_photons, int n_interactions, const cpm_grid_desc* grid, float radius,
+                            uint8_t* brick_mask, cpm_stream stream);
+int cpm_gather_bricks(cpm_ctx* ctx, const float* sorted_pos_power, const uint32_t* cell_start, int n,
+                      const cpm_grid_desc* grid, float radius, float relative_irradiance_scale,
+                      const uint8_t* brick_mask, float* grid_out, cpm_stream stream);
+
 /* ------------------------------------------------------------------ correlated re-trace (C1-C7, S2-S4) */
 
 /* Per region^3 brick min/max of the normalised voxel value -> 2 x uint16

@@ -302,3 +302,89 @@ def test_select_changed(ctx, oracle, n, frac):
         assert int(cnt.item()) == want_cnt == int(pick.sum())
         assert np.array_equal(_n(idx, np.uint32), want_idx)
         assert np.array_equal(_n(imp_d, np.uint32), imp)
+
+
+@pytest.mark.parametrize("interactions", [1, 3])
+def test_exact_incremental_update_is_bit_identical_to_a_full_frame(ctx, cpm, interactions):
+    """exact_update: after the correlated re-trace, the bricks touched by an old or new position of a changed photon
+    are re-gathered from the re-binned photons and nothing else is written -- the light volume equals, bit for bit,
+    the one a full trace + bin + gather with the edited TF produces (the +-splat update only matches it within
+    tolerance).  Also through progressive batches."""
+    S, P = cpm.synthetic, cpm.pipeline
+    vol_np = S.heterogeneous_volume(64)
+    base = [(0.0, 1, 1, 1, 0.0), (0.45, 1, 0.5, 0.2, 0.0), (0.55, 0.6, 0.3, 0.1, 0.05), (0.8, 0.9, 0.2, 0.3, 0.4), (1.0, 0.1, 0.6, 0.7, 0.5)]
+    edit = list(base)
+    edit[3] = (0.85,) + base[3][1:]
+    kw = dict(light_travel_direction=(0.3, 0.5, -1.0), tf_points=base, incremental_threshold_percent=100.0, exact_update=True,
+              max_interactions=interactions, material=(0.3, 0, 0, 0))
+    full = P.PhotonFrame(ctx, vol_np, S.tf_from_points(edit), 160, (32, 32, 32), light_travel_direction=(0.3, 0.5, -1.0),
+                         max_interactions=interactions, material=(0.3, 0, 0, 0))
+    lv_full = _n(full.frame()).copy()
+    for pct in (100.0, 7.0):
+        cm = P.CorrelatedPhotonMapper(ctx, vol_np, S.tf_from_points(base), 160, (32, 32, 32), max_incremental_percent=pct, **kw)
+        cm.full_frame()
+        lv_before = _n(cm.light_volume).copy()
+        cm.set_transfer_function(edit)
+        n = cm.correlated_update()
+        assert n > 0 and cm.last_path == "exact incremental"
+        while cm.remaining > 0:
+            assert cm.continue_update() > 0 and cm.last_path == "exact incremental"
+        assert np.array_equal(bits(_n(cm.photons)), bits(_n(full.photons)))
+        lv = _n(cm.light_volume)
+        assert np.array_equal(bits(lv), bits(lv_full))
+        changed = bits(lv) != bits(lv_before)
+        assert 0 < changed.sum() < lv.size          # a local update, not a rewrite of everything
+
+
+def test_mark_touched_bricks_and_gather_bricks(ctx, oracle, cpm):
+    """cpm_mark_touched_bricks marks exactly the bricks the selected photons' splat boxes overlap; cpm_gather_bricks
+    rewrites exactly the marked bricks."""
+    rng = np.random.default_rng(9)
+    dims, n = (24, 20, 28), 5000
+    ph = np.zeros((n, 8), np.float32)
+    ph[:, :3] = rng.random((n, 3), dtype=np.float32)
+    ph[:, 3:6] = rng.random((n, 3), dtype=np.float32)
+    ph[::50, :3] = np.float32(3.402823466e+38)
+    radius = float(np.float32(0.8 / max(dims)))
+    g, og = cpm.binding.default_grid_desc(dims, 1), oracle.grid(dims, 1)
+    bdim = [(d + 3) // 4 for d in dims]
+    nb = bdim[0] * bdim[1] * bdim[2]
+    sel = np.sort(rng.choice(n, 60, replace=False)).astype(np.uint32)
+    torch = ctx.torch
+    mask = torch.zeros(nb, dtype=torch.uint8, device=ctx.device)
+    ctx.mark_touched_bricks(_t(ctx, ph), _t(ctx, sel.view(np.int32)), sel.size, n, 1, g, radius, mask)
+    # expected: bricks overlapped by the oracle's splat of each selected photon alone (any voxel inside its box)
+    want = np.zeros(nb, np.uint8)
+    t2i = np.array(og.texture_to_index, np.float32)
+    for i in sel:
+        p = ph[i, :3]
+        if (p == np.float32(3.402823466e+38)).any():
+            continue
+        lo = [int(np.float32(np.float32(p[a] - np.float32(radius)) * t2i[5 * a] + t2i[12 + a])) for a in range(3)]
+        hi = [int(np.float32(np.float32(np.float32(p[a] + np.float32(radius)) * t2i[5 * a] + t2i[12 + a]) + np.float32(1))) for a in range(3)]
+        lo = [max(v, 0) for v in lo]
+        hi = [min(v, dims[a]) for a, v in enumerate(hi)]
+        for bz in range(lo[2] >> 2, ((hi[2] - 1) >> 2) + 1):
+            for by in range(lo[1] >> 2, ((hi[1] - 1) >> 2) + 1):
+                for bx in range(lo[0] >> 2, ((hi[0] - 1) >> 2) + 1):
+                    want[bx + bdim[0] * (by + bdim[1] * bz)] = 1
+    got = mask.cpu().numpy()
+    assert np.array_equal(got, want) and 0 < want.sum() < nb
+    cells = dims[0] * dims[1] * dims[2]
+    order = torch.empty(n, dtype=torch.int32, device=ctx.device)
+    cs = torch.empty(cells + 1, dtype=torch.int32, device=ctx.device)
+    srt = torch.empty((n, 4), dtype=torch.float32, device=ctx.device)
+    ctx.bin(_t(ctx, ph), n, g, order, cs, srt)
+    out = torch.full((cells,), -5.0, dtype=torch.float32, device=ctx.device)
+    ctx.gather_bricks(srt, cs, n, g, radius, 1.0, mask, out)
+    fullv = torch.empty(cells, dtype=torch.float32, device=ctx.device)
+    ctx.gather(srt, cs, n, g, radius, 1.0, fullv)
+    o, f = _n(out).reshape(dims[::-1]), _n(fullv).reshape(dims[::-1])
+    for bz in range(bdim[2]):
+        for by in range(bdim[1]):
+            for bx in range(bdim[0]):
+                blk = (slice(4 * bz, 4 * bz + 4), slice(4 * by, 4 * by + 4), slice(4 * bx, 4 * bx + 4))
+                if want[bx + bdim[0] * (by + bdim[1] * bz)]:
+                    assert np.array_equal(bits(o[blk]), bits(f[blk]))
+                else:
+                    assert (o[blk] == np.float32(-5.0)).all()

@@ -205,7 +205,17 @@ def test_network_correlated_tf_edit(host, cpm):
         rounds += 1
     assert rounds > 1
     assert np.array_equal(bits(net2.photons()), bits(after))
-    for x in (net, fresh, net2):
+    # exact incremental update (not a reference property): bit-identical to the from-scratch light volume
+    net3 = Net(host, vol, 128, pos, d, base, correlated=True)
+    net3.evaluate(first=True)
+    assert host.cpmh_set_property_float(net3.h, b"lightvolume", b"incrementalRecomputationThreshold", 100.0) == 0
+    assert host.cpmh_set_property_float(net3.h, b"lightvolume", b"exactIncrementalUpdate", 1.0) == 0
+    net3.set_tf(edit)
+    net3.evaluate()
+    assert host.cpmh_last_light_volume_path(net3.h) == b"exact incremental"
+    lv_exact, _, _ = net3.light_volume()
+    assert np.array_equal(bits(lv_exact), bits(lv_full))
+    for x in (net, fresh, net2, net3):
         x.close()
 
 

@@ -16,9 +16,9 @@ out = {}
 # ---- config 3: TF edit (point 4: 0.2218 -> 0.26), 100 % and 25 % per evaluation
 vol = S.heterogeneous_volume(256)
 base = list(S.WORKSPACE_TF_POINTS); edit = list(base); edit[3] = (0.26,) + base[3][1:]
-for pct in (100.0, 25.0):
+for pct, exact in ((100.0, False), (25.0, False), (100.0, True)):
     cm = P.CorrelatedPhotonMapper(ctx, vol, S.workspace_tf(), 1024, (128,)*3, light_travel_direction=(0.3, 0.5, -1.0),
-                                  tf_points=base, max_incremental_percent=pct)
+                                  tf_points=base, max_incremental_percent=pct, exact_update=exact)
     cm.full_frame(); cm.full_frame()
     full_ms, _ = sync_ms(cm.full_frame, 20)
     res = []
@@ -32,7 +32,7 @@ for pct in (100.0, 25.0):
             tm, _ = sync_ms(cm.continue_update); t_more += tm; rounds += 1
         res.append((t_imp, t_upd, n / cm.n, rounds, t_more, cm.last_path))
     r = res[2:]
-    out[f"config3_{int(pct)}pct"] = {"full_frame_ms": round(full_ms, 4), "importance_ms": round(np.mean([x[0] for x in r]), 4),
+    out[f"config3_{int(pct)}pct" + ("_exact_update" if exact else "")] = {"full_frame_ms": round(full_ms, 4), "importance_ms": round(np.mean([x[0] for x in r]), 4),
                                        "first_update_ms": round(np.mean([x[1] for x in r]), 4), "fraction_first_batch": round(np.mean([x[2] for x in r]), 4),
                                        "rounds": r[0][3], "continuation_ms": round(np.mean([x[4] for x in r]), 4), "light_volume_path": r[0][5]}
     del cm
