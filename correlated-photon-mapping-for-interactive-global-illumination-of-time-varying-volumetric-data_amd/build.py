@@ -36,7 +36,7 @@ def build_library(force: bool = False, verbose: bool = True) -> Path:
     return out
 
 
-HOST_SOURCES = ["cpm_processors.cpp", "cpm_timevarying.cpp", "cpm_host_c.cpp"]
+HOST_SOURCES = ["cpm_processors.cpp", "cpm_timevarying.cpp", "cpm_modules.cpp", "cpm_host_c.cpp"]
 
 
 def build_host_library(force: bool = False, verbose: bool = True) -> Path:

@@ -6,7 +6,7 @@
 #include <cstring>
 #include <sstream>
 
-#include "cpm_timevarying.h"
+#include "cpm_modules.h"
 
 using namespace inviwo;
 
@@ -335,6 +335,64 @@ const char* cpmh_sequence_describe_surface(cpmh_sequence* s) {
     }
     str = os.str();
     return str.c_str();
+}
+
+// ---- modules and the processor factory ---------------------------------------------------------------------------
+
+// "module|version|processor ids,|port class ids,|data formats," per line; registers the modules on first use
+const char* cpmh_modules_describe() {
+    static std::vector<std::unique_ptr<InviwoModule>> modules = registerCorrelatedPhotonMappingModules();
+    static std::string str;
+    std::ostringstream os;
+    for (auto& m : modules) {
+        os << m->getIdentifier() << "|" << m->getVersion() << "|";
+        for (auto& p : m->processors()) os << p << ",";
+        os << "|";
+        for (auto& p : m->ports()) os << p << ",";
+        os << "|";
+        for (auto& f : m->dataFormats()) os << f << ",";
+        os << "\n";
+    }
+    str = os.str();
+    return str.c_str();
+}
+// instantiate a processor by class identifier (what deserialising a workspace does); returns its surface line or ""
+const char* cpmh_factory_create(const char* class_identifier) {
+    static std::string str;
+    cpmh_modules_describe();
+    auto p = ProcessorFactory::get().create(class_identifier);
+    if (!p) { str.clear(); return str.c_str(); }
+    std::ostringstream os;
+    os << p->getProcessorInfo().classIdentifier << "|in:";
+    for (auto& i : p->getInportIds()) os << i << ",";
+    os << "|out:";
+    for (auto& o : p->getOutportIds()) os << o << ",";
+    os << "|prop:";
+    for (auto& q : p->getPropertyIds()) os << q << ",";
+    str = os.str();
+    return str.c_str();
+}
+// RadixSortCL processor: sorts n (key, data) u32 pairs on the device through the processor's ports
+int cpmh_radixsort_processor(uint32_t* keys, uint32_t* data, int n) {
+    if (!CpmRuntime::get().valid()) return -1;
+    cpmh_modules_describe();
+    auto p = ProcessorFactory::get().create("org.inviwo.RadixSortCL");
+    auto* rs = dynamic_cast<RadixSortCL*>(p.get());
+    if (!rs) return -2;
+    auto kb = std::make_shared<Buffer<uint32_t>>((size_t)n);
+    auto db = std::make_shared<Buffer<uint32_t>>((size_t)n);
+    std::memcpy(kb->ram().data(), keys, (size_t)n * 4);
+    std::memcpy(db->ram().data(), data, (size_t)n * 4);
+    DataOutport<Buffer<uint32_t>> ko{ "keys" }, dout{ "data" };
+    ko.setData(kb); dout.setData(db);
+    rs->keysPort_.connectTo(&ko);
+    rs->inputPort_.connectTo(&dout);
+    rs->process();
+    auto out = rs->outputPort_.getData();
+    if (!out) return -3;
+    std::memcpy(keys, kb->hostData(), (size_t)n * 4);
+    std::memcpy(data, out->hostData(), (size_t)n * 4);
+    return 0;
 }
 
 }  // extern "C"

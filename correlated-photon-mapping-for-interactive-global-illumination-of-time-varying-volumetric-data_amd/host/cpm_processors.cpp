@@ -353,16 +353,25 @@ void PhotonRecomputationDetector::photonRecomputationImportance(const PhotonData
 // ---- processors ----------------------------------------------------------------------------------------------
 
 UniformSampleGenerator2DProcessorCL::UniformSampleGenerator2DProcessorCL() {
-    addPortId("samples", false);
-    addProperty(nSamplesProp_);
+    addPortId("samples", false); addPortId("DirectionalSamples", false);
+    addProperty(nSamplesProp_); addProperty(workGroupSize_); addProperty(useGLSharing_);
 }
 void UniformSampleGenerator2DProcessorCL::process() {  // uniformsamplegenerator2dprocessorcl.cpp:77-96
     generator_.generateNextSamples(*samples_, nSamplesProp_.get());
     samplesPort_.setData(samples_);
+    if (directionalSamplesPort_.isConnected()) {  // uniformsamplegenerator2dcl.cpp:79-101: a device copy of the position samples
+        directionalSamples_->setSize(samples_->getSize());
+        (void)hipMemcpyAsync(directionalSamples_->device(), samples_->device(), samples_->getSizeInBytes(), hipMemcpyDeviceToDevice,
+                             CpmRuntime::get().stream());
+    } else if (directionalSamples_->getSize() != 0) {
+        directionalSamples_->setSize(0);
+    }
+    directionalSamplesPort_.setData(directionalSamples_);
 }
 
 DirectionalLightSamplerCLProcessor::DirectionalLightSamplerCLProcessor() {
     addPortId("SceneGeometry", true); addPortId("samples", true); addPortId("light", true); addPortId("LightSamples", false);
+    addProperty(workGroupSize_);
 }
 void DirectionalLightSamplerCLProcessor::process() {  // directionallightsamplerclprocessor.cpp:79-89
     if (!boundingVolumePort_.isReady() || !samplesPort_.isReady() || !lightsPort_.isReady()) return;
@@ -376,7 +385,7 @@ VolumeMinMaxCLProcessor::VolumeMinMaxCLProcessor() {
     addPortId("volume", true); addPortId("output", false);
     addPortId("VolumeSequenceInput", true); addPortId("UniformGrid3DVectorOut", false);
     inport_.setOptional(true); vectorInport_.setOptional(true);
-    addProperty(volumeRegionSize_);
+    addProperty(volumeRegionSize_); addProperty(workGroupSize_); addProperty(useGLSharing_);
 }
 void VolumeMinMaxCLProcessor::process() {  // volumeminmaxclprocessor.cpp:88-122
     if (!CpmRuntime::get().valid()) return;
@@ -433,6 +442,10 @@ bool Volume::downloadToRAM() {
 MinMaxUniformGrid3DImportanceCLProcessor::MinMaxUniformGrid3DImportanceCLProcessor() {
     addPortId("minMaxUniformGrid3D", true); addPortId("volumeDifferenceInfo", true); addPortId("importanceUniformGrid3D", false);
     addProperty(incrementalImportance); addProperty(useAssociatedColor_); addProperty(TFPointEpsilon_);
+    for (PropertyBase* q : std::initializer_list<PropertyBase*>{ &opacityWeight_, &opacityDiffWeight_, &colorWeight_, &colorDiffWeight_,
+                                                                &transferFunctionProperty_, &workGroupSize_, &useGLSharing_ })
+        addProperty(*q);
+    transferFunctionProperty_.onChange([this]() { setTransferFunction(transferFunctionProperty_.get()); });  // .cpp:94-96
 }
 void MinMaxUniformGrid3DImportanceCLProcessor::setTransferFunction(const TransferFunction& tf) {
     transferFunction_ = tf;
@@ -529,6 +542,11 @@ ProgressivePhotonTracerCL::ProgressivePhotonTracerCL() {
                                                                 &alphaProp_, &workGroupSize_, &useGLSharing_, &enableProgressiveRefinement_,
                                                                 &enableProgressivePhotonRecomputation_, &clipX_, &clipY_, &clipZ_ })
         addProperty(*p);
+    addProperty(advancedMaterial_); addProperty(camera_); addProperty(invalidateRendering_); addProperty(transferFunctionProperty_);
+    transferFunctionProperty_.onChange([this]() { setTransferFunction(transferFunctionProperty_.get()); });             // tracercl.cpp:148
+    camera_.onChange([this]() { invalidateProgressiveRendering(PhotonData::InvalidationReason::Camera); });            // :161-165
+    invalidateRendering_.onChange([this]() { invalidateProgressiveRendering(PhotonData::InvalidationReason::All); });  // :172, 612-615
+    advancedMaterial_.onChange([this]() { invalidateProgressiveRendering(PhotonData::InvalidationReason::All); });     // kernelArgChanged
     equalIncrementalImportance_.onChange([this]() { photonRecomputationDetector_.setEqualImportance(equalIncrementalImportance_.get()); });
     noSingleScattering_.onChange([this]() { photonTracer_.setNoSingleScattering(noSingleScattering_.get()); });
     maxScatteringEvents_.onChange([this]() { invalidateProgressiveRendering(PhotonData::InvalidationReason::All); });
@@ -676,7 +694,7 @@ PhotonToLightVolumeProcessorCL::PhotonToLightVolumeProcessorCL() {
     recomputedPhotonIndicesPort_.setOptional(true);
     for (PropertyBase* p : std::initializer_list<PropertyBase*>{ &incrementalRecomputationThreshold_, &volumeSizeOption_, &volumeDataTypeOption_,
                                                                 &alignChangedPhotons_, &workGroupSize_, &useGLSharing_, &formulation_,
-                                                                &exactIncrementalUpdate_ })
+                                                                &exactIncrementalUpdate_, &information_ })
         addProperty(*p);
     volumeSizeOption_.onChange([this]() { volumeSizeOptionChanged(); });
     volumeDataTypeOption_.onChange([this]() {
@@ -709,6 +727,8 @@ void PhotonToLightVolumeProcessorCL::process() {  // photontolightvolumeprocesso
     }
     const size3_t outDim = lightVolume_->getDimensions();
     const size_t cells = outDim.x * outDim.y * outDim.z;
+    information_.dimensions.set(std::to_string(outDim.x) + " x " + std::to_string(outDim.y) + " x " + std::to_string(outDim.z));
+    information_.format.set(volumeDataTypeOption_.get() == "float32" ? "FLOAT32" : "Vec4FLOAT32");
     const int channels = lightVolume_->channels;
     bool fresh = false;
     if (lightVolume_->data.getSize() != cells * channels) { lightVolume_->data.setSize(cells * channels); fresh = true; }

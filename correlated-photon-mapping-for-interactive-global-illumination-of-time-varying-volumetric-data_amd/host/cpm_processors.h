@@ -228,11 +228,42 @@ public:
     void meshSampleIntersection(const Mesh* mesh, LightSamples* samples);
 };
 
-struct AdvancedMaterialProperty {
+// Inviwo's AdvancedMaterialProperty (composite "material": phaseFunction, IOR, roughness, specularColor, anisotropy) as far
+// as the tracer reads it: the phase function enum and the combined parameters, .x = anisotropy g
+struct AdvancedMaterialProperty : CompositeProperty {
+    AdvancedMaterialProperty() : CompositeProperty("material", "Material") {
+        addProperty(phaseFunctionProp); addProperty(indexOfRefractionProp); addProperty(roughnessProp);
+        addProperty(specularColorProp); addProperty(anisotropyProp);
+        anisotropyProp.onChange([this]() { combined.x = anisotropyProp.get(); changed(); });
+        phaseFunctionProp.onChange([this]() {
+            phaseFunction = phaseFunctionProp.get() == "Isotropic" ? CPM_PHASE_ISOTROPIC : CPM_PHASE_HENYEY_GREENSTEIN;
+            changed();
+        });
+    }
+    StringOptionProperty phaseFunctionProp{ "phaseFunction", "Phase function", "HenyeyGreenstein" };
+    FloatProperty indexOfRefractionProp{ "IOR", "Index of refraction", 1.f };   // unused by the volumetric tracer
+    FloatProperty roughnessProp{ "roughness", "Roughness", 0.1f };              // unused by the volumetric tracer
+    FloatVec4Property specularColorProp{ "specularColor", "Specular color", vec4(1.f, 1.f, 1.f, 1.f) };  // unused
+    FloatProperty anisotropyProp{ "anisotropy", "Anisotropy (g)", 0.f };
     vec4 combined{ 0.f, 0.f, 0.f, 0.f };  // .x = anisotropy g
     int phaseFunction = CPM_PHASE_HENYEY_GREENSTEIN;
     vec4 getCombinedMaterialParameters() const { return combined; }
     int getPhaseFunctionEnum() const { return phaseFunction; }
+};
+// Inviwo's CameraProperty as the tracer uses it: a change invalidates with reason Camera (tracercl.cpp:161-165)
+struct CameraProperty : CompositeProperty {
+    CameraProperty() : CompositeProperty("camera", "Camera") {
+        for (PropertyBase* q : std::initializer_list<PropertyBase*>{ &cameraType, &lookFrom, &lookTo, &lookUp, &aspectRatio, &nearPlane, &farPlane, &fov,
+                                                                    &fitToBasis, &mouseChangeFocusPoint })
+            addProperty(*q);
+        for (PropertyBase* q : getProperties()) q->onChange([this]() { changed(); });
+    }
+    StringOptionProperty cameraType{ "cameraType", "Camera Type", "PerspectiveCamera" };
+    FloatVec3Property lookFrom{ "lookFrom", "Look from", vec3(0.f, 0.f, -2.f) }, lookTo{ "lookTo", "Look to", vec3(0.f, 0.f, 0.f) },
+        lookUp{ "lookUp", "Look up", vec3(0.f, 1.f, 0.f) };
+    FloatProperty aspectRatio{ "aspectRatio", "Aspect Ratio", 1.f }, nearPlane{ "near", "Near Plane", 0.1f }, farPlane{ "far", "Far Plane", 100.f },
+        fov{ "fov", "FOV", 38.f };
+    BoolProperty fitToBasis{ "fitToBasis_", "Fit to basis", true }, mouseChangeFocusPoint{ "mouseChangeFocusPoint", "Change Focus Point", false };
 };
 
 // progressivephotonmapping/photontracercl.{h,cpp}
@@ -286,10 +317,14 @@ public:
     const ProcessorInfo getProcessorInfo() const override { return { "org.inviwo.UniformSampleGenerator2DCL", "UniformSampleGenerator2DCL", "Sampling" }; }
     void process() override;
     DataOutport<SampleBuffer> samplesPort_{ "samples" };
+    DataOutport<SampleBuffer> directionalSamplesPort_{ "DirectionalSamples" };  // a copy of the samples, filled when connected (:79-101)
     Property<ivec2> nSamplesProp_{ "nSamples", "N samples", ivec2{ 256, 256 } };
+    IntVec2Property workGroupSize_{ "wgsize", "Work group size", ivec2{ 8, 8 } };  // inert
+    BoolProperty useGLSharing_{ "glsharing", "Use OpenGL sharing", true };           // inert
 private:
     UniformSampleGenerator2DCL generator_;
     std::shared_ptr<SampleBuffer> samples_ = std::make_shared<SampleBuffer>();
+    std::shared_ptr<SampleBuffer> directionalSamples_ = std::make_shared<SampleBuffer>();
 };
 
 // lightcl/processors/directionallightsamplerclprocessor.{h,cpp}
@@ -302,6 +337,7 @@ public:
     DataInport<SampleBuffer> samplesPort_{ "samples" };
     DataInport<DirectionalLight> lightsPort_{ "light" };
     DataOutport<LightSamples> lightSamplesPort_{ "LightSamples" };
+    IntProperty workGroupSize_{ "wgsize", "Work group size", 64 };  // inert: kept for the workspace
     DirectionalLightSamplerCL lightSampler_;
 private:
     LightSampleMeshIntersectionCL intersector_;
@@ -319,6 +355,8 @@ public:
     DataInport<VolumeSequence> vectorInport_{ "VolumeSequenceInput" };          // :62
     DataOutport<UniformGrid3DVector> vectorOutport_{ "UniformGrid3DVectorOut" };  // :63
     IntProperty volumeRegionSize_{ "region", "Region size", 8 };
+    Property<ivec2> workGroupSize_{ "wgsize", "Work group size", ivec2{ 4, 4 } };   // inert (ivec3 in the reference)
+    BoolProperty useGLSharing_{ "glsharing", "Use OpenGL sharing", true };          // inert
 private:
     std::shared_ptr<MinMaxUniformGrid3D> compute(const Volume* volume);  // :148-184
 };
@@ -337,6 +375,13 @@ public:
     BoolProperty incrementalImportance{ "incrementalImportance", "Incremental importance", true };
     BoolProperty useAssociatedColor_{ "useAssociatedColor", "Associated color", false };
     FloatProperty TFPointEpsilon_{ "TFPointEpsilon", "Minimum change threshold", 1e-4f };
+    // weights of the non-incremental importance (tfPointsImportance without -D INCREMENTAL_TF_IMPORTANCE): the reference builds
+    // the kernel WITH the define (.cpp:101), so they do not enter the result; kept for the workspace
+    FloatProperty opacityWeight_{ "constantWeight", "Opacity weight", 1.f }, opacityDiffWeight_{ "opacityDiffWeight", "Opacity difference weight", 0.f },
+        colorWeight_{ "colorWeight", "Color weight", 0.f }, colorDiffWeight_{ "colorDiffWeight", "Color difference weight", 0.f };
+    TransferFunctionProperty transferFunctionProperty_{ "transferfunction", "Transfer function", TransferFunction() };  // .set() == setTransferFunction
+    IntProperty workGroupSize_{ "wgsize", "Work group size", 128 };      // inert
+    BoolProperty useGLSharing_{ "glsharing", "Use OpenGL sharing", true };  // inert
     const std::vector<float>& tfPointPositions() const { return positions_; }
     const std::vector<vec4>& tfPointColors() const { return colors_; }
 private:
@@ -382,6 +427,9 @@ public:
     Property<ivec2> clipX_{ "clipX", "Clip X Slices", ivec2{ 0, 256 } }, clipY_{ "clipY", "Clip Y Slices", ivec2{ 0, 256 } },
         clipZ_{ "clipZ", "Clip Z Slices", ivec2{ 0, 256 } };
     AdvancedMaterialProperty advancedMaterial_;
+    CameraProperty camera_;
+    ButtonProperty invalidateRendering_{ "invalidate", "Invalidate rendering" };
+    TransferFunctionProperty transferFunctionProperty_{ "transferFunction", "Transfer function", TransferFunction() };  // .set() == setTransferFunction
     TransferFunction transferFunction_;
     PhotonTracerCL photonTracer_;
     bool fixExitPoint = false;
@@ -418,6 +466,15 @@ public:
     IntProperty workGroupSize_{ "wgsize", "Work group size", 128 };      // inert
     BoolProperty useGLSharing_{ "glsharing", "Use OpenGL sharing", true };  // inert
     // "gather" (default: sort/bin + deterministic gather) or "splat" (the reference's atomic formulation)
+    // VolumeInformationProperty "Information" of the output volume (read-only in the reference's UI)
+    struct InformationProperty : CompositeProperty {
+        InformationProperty() : CompositeProperty("Information", "Light volume information") {
+            addProperty(dimensions); addProperty(format); addProperty(dataRange); addProperty(valueRange); addProperty(valueUnit);
+        }
+        StringOptionProperty dimensions{ "dimensions", "Dimensions", "" }, format{ "format", "Format", "FLOAT32" };
+        FloatVec2Property dataRange{ "dataRange", "Data range", vec2{ 0.f, 1.f } }, valueRange{ "valueRange", "Value range", vec2{ 0.f, 1.f } };
+        StringOptionProperty valueUnit{ "valueUnit", "Value unit", "arb. unit." };
+    } information_;
     StringOptionProperty formulation_{ "formulation", "Density estimation", "gather" };
     // add-remove of the re-traced photons: false (default) = the reference's -old / +new atomic splats; true = re-bin and
     // re-gather exactly the bricks they touch (bit-identical to a full gather) -- not a property of the reference

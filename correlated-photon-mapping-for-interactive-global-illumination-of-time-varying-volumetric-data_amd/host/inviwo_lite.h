@@ -165,9 +165,12 @@ public:
     const std::string& getIdentifier() const { return id_; }
     void setData(std::shared_ptr<T> d) { data_ = std::move(d); }
     std::shared_ptr<T> getData() const { return data_; }
+    bool isConnected() const { return nConnections_ > 0; }
+    void connectionAdded() { ++nConnections_; }
 private:
     std::string id_;
     std::shared_ptr<T> data_;
+    int nConnections_ = 0;
 };
 
 template <typename T>
@@ -175,7 +178,7 @@ class DataInport {
 public:
     explicit DataInport(std::string id) : id_(std::move(id)) {}
     const std::string& getIdentifier() const { return id_; }
-    void connectTo(DataOutport<T>* out) { sources_.push_back(out); if (onConnect_) onConnect_(); }
+    void connectTo(DataOutport<T>* out) { sources_.push_back(out); out->connectionAdded(); if (onConnect_) onConnect_(); }
     void disconnectAll() { sources_.clear(); }
     bool isConnected() const { return !sources_.empty(); }
     bool isReady() const { return !sources_.empty() && sources_[0]->getData() != nullptr; }
@@ -226,11 +229,30 @@ private:
     T min_{}, max_{};
     bool readOnly_ = false;
 };
+// ButtonProperty: pressButton() runs the onChange callback
+class ButtonProperty : public PropertyBase {
+public:
+    using PropertyBase::PropertyBase;
+    void pressButton() { changed(); }
+};
+// CompositeProperty: a named group; its members are also reachable by their own identifiers from the processor
+class CompositeProperty : public PropertyBase {
+public:
+    using PropertyBase::PropertyBase;
+    void addProperty(PropertyBase& p) { members_.push_back(&p); }
+    const std::vector<PropertyBase*>& getProperties() const { return members_; }
+private:
+    std::vector<PropertyBase*> members_;
+};
 using FloatProperty = Property<float>;
 using IntProperty = Property<int>;
 using BoolProperty = Property<bool>;
 using IntVec2Property = Property<ivec2>;
 using StringOptionProperty = Property<std::string>;
+using FloatVec2Property = Property<vec2>;
+using FloatVec3Property = Property<vec3>;
+using FloatVec4Property = Property<vec4>;
+using TransferFunctionProperty = Property<TransferFunction>;
 
 struct ProcessorInfo {
     std::string classIdentifier, displayName, category;
@@ -241,7 +263,11 @@ public:
     virtual ~Processor() = default;
     virtual const ProcessorInfo getProcessorInfo() const = 0;
     virtual void process() = 0;
-    void addProperty(PropertyBase& p) { properties_[p.getIdentifier()] = &p; }
+    void addProperty(PropertyBase& p) {
+        properties_[p.getIdentifier()] = &p;
+        if (auto* c = dynamic_cast<CompositeProperty*>(&p))
+            for (PropertyBase* m : c->getProperties()) addProperty(*m);
+    }
     void addPortId(const std::string& id, bool inport) { (inport ? inports_ : outports_).push_back(id); }
     PropertyBase* getPropertyByIdentifier(const std::string& id) const {
         auto it = properties_.find(id);

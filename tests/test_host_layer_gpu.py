@@ -250,3 +250,17 @@ assert h and lib.cpmh_evaluate(h, 1) == 0
     assert "Photon tracing: " in log and "trace_kernel" in log and " ms" in log
     assert "Computed photons: 1024 = 100.00 %" in log
     assert "Photons to light volume: " in log and "gather" in log
+
+
+def test_radixsort_processor(host, ctx):
+    """org.inviwo.RadixSortCL created through the module factory: keys sorted ascending, data permuted with them
+    (stable), pass-through of the data buffer (radixsortcl.cpp:208-259)."""
+    host.cpmh_radixsort_processor.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+    rng = np.random.default_rng(4)
+    n = 100_003
+    keys = rng.integers(0, 1 << 20, n).astype(np.uint32)
+    data = np.arange(n, dtype=np.uint32)
+    k, d = keys.copy(), data.copy()
+    assert host.cpmh_radixsort_processor(k.ctypes.data, d.ctypes.data, n) == 0
+    order = np.argsort(keys, kind="stable")
+    assert np.array_equal(k, keys[order]) and np.array_equal(d, data[order])
