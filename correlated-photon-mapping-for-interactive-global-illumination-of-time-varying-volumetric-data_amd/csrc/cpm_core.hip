@@ -191,7 +191,7 @@ static size_t dtype_size(int dtype) { return dtype == CPM_U8 ? 1 : (dtype == CPM
 
 int cpm_volume_create(cpm_ctx* ctx, const cpm_volume_desc* desc, const void* voxels, int is_device,
                       cpm_stream stream, cpm_volume** out) {
-    if (!ctx) return CPM_ERR_INVALID_ARGUMENT;
+    CPM_ENTER(ctx);
     CPM_REQUIRE(ctx, desc && out, "cpm_volume_create: null argument");
     CPM_REQUIRE(ctx, desc->dtype >= CPM_U8 && desc->dtype <= CPM_F32, "cpm_volume_create: dtype");
     CPM_REQUIRE(ctx, desc->dims[0] >= 2 && desc->dims[1] >= 1 && desc->dims[2] >= 1, "cpm_volume_create: dims (x >= 2)");
@@ -216,7 +216,7 @@ int cpm_volume_create(cpm_ctx* ctx, const cpm_volume_desc* desc, const void* vox
 }
 
 int cpm_volume_update(cpm_ctx* ctx, cpm_volume* vol, const void* voxels, int is_device, cpm_stream stream) {
-    if (!ctx) return CPM_ERR_INVALID_ARGUMENT;
+    CPM_ENTER(ctx);
     CPM_REQUIRE(ctx, vol && voxels, "cpm_volume_update: null argument");
     hipStream_t s = (hipStream_t)stream;
     CPM_HIP_CHECK(ctx, hipMemsetAsync((char*)vol->voxels + vol->bytes, 0, 16, s));
@@ -233,7 +233,7 @@ void* cpm_volume_device_data(const cpm_volume* vol, size_t* bytes) {
 }
 
 int cpm_volume_download(cpm_ctx* ctx, const cpm_volume* vol, void* voxels_host, cpm_stream stream) {
-    if (!ctx) return CPM_ERR_INVALID_ARGUMENT;
+    CPM_ENTER(ctx);
     CPM_REQUIRE(ctx, vol && voxels_host, "cpm_volume_download: null argument");
     hipStream_t s = (hipStream_t)stream;
     CPM_HIP_CHECK(ctx, hipMemcpyAsync(voxels_host, vol->voxels, vol->bytes, hipMemcpyDeviceToHost, s));
@@ -254,7 +254,7 @@ __global__ void tf_alpha_kernel(const float* __restrict__ rgba, int width, float
 }
 
 int cpm_tf_create(cpm_ctx* ctx, const float* rgba, int width, int is_device, cpm_stream stream, cpm_tf** out) {
-    if (!ctx) return CPM_ERR_INVALID_ARGUMENT;
+    CPM_ENTER(ctx);
     CPM_REQUIRE(ctx, rgba && out, "cpm_tf_create: null argument");
     CPM_REQUIRE(ctx, width >= 2 && width <= 16384, "cpm_tf_create: width must be in [2, 16384]");
     cpm_tf* tf = new (std::nothrow) cpm_tf();
@@ -270,7 +270,7 @@ int cpm_tf_create(cpm_ctx* ctx, const float* rgba, int width, int is_device, cpm
 }
 
 int cpm_tf_update(cpm_ctx* ctx, cpm_tf* tf, const float* rgba, int is_device, cpm_stream stream) {
-    if (!ctx) return CPM_ERR_INVALID_ARGUMENT;
+    CPM_ENTER(ctx);
     CPM_REQUIRE(ctx, tf && rgba, "cpm_tf_update: null argument");
     hipStream_t s = (hipStream_t)stream;
     CPM_HIP_CHECK(ctx, hipMemcpyAsync(tf->rgba, rgba, (size_t)tf->width * 4 * sizeof(float),

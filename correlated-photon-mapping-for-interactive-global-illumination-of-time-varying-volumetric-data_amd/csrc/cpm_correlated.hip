@@ -424,7 +424,7 @@ extern "C" {
 void cpm_debug_set_brick_streaming(int on) { g_brick_streaming = on; }
 
 int cpm_volume_minmax(cpm_ctx* ctx, const cpm_volume* vol, int region, uint16_t* minmax2, cpm_stream stream) {
-    if (!ctx) return CPM_ERR_INVALID_ARGUMENT;
+    CPM_ENTER(ctx);
     BrickVol V;
     int rc = make_brick_vol(ctx, vol, region, V);
     if (rc) return rc;
@@ -448,7 +448,7 @@ int cpm_volume_minmax(cpm_ctx* ctx, const cpm_volume* vol, int region, uint16_t*
 
 int cpm_volume_difference(cpm_ctx* ctx, const cpm_volume* cur, const cpm_volume* next, int region, float* out,
                           cpm_stream stream) {
-    if (!ctx) return CPM_ERR_INVALID_ARGUMENT;
+    CPM_ENTER(ctx);
     BrickVol V;
     int rc = make_brick_vol(ctx, cur, region, V);
     if (rc) return rc;
@@ -474,7 +474,7 @@ int cpm_volume_difference(cpm_ctx* ctx, const cpm_volume* cur, const cpm_volume*
 int cpm_importance_tf(cpm_ctx* ctx, const uint16_t* minmax2, const uint16_t* prev_minmax2, const float* volume_diff,
                       int n_cells, const float* positions_host, const float* colors4_host, int n_points,
                       float* importance, cpm_stream stream) {
-    if (!ctx) return CPM_ERR_INVALID_ARGUMENT;
+    CPM_ENTER(ctx);
     CPM_REQUIRE(ctx, n_cells >= 0, "cpm_importance_tf: n_cells < 0");
     CPM_REQUIRE(ctx, n_points >= 2 && n_points <= 4096, "cpm_importance_tf: n_points must be in [2, 4096]");
     CPM_REQUIRE(ctx, positions_host && colors4_host, "cpm_importance_tf: null TF points");
@@ -497,7 +497,7 @@ int cpm_photon_importance(cpm_ctx* ctx, const float* importance_grid, const int3
                           const float texture_to_index[16], const float* photons8, int photon_offset,
                           const float* light_samples8, const float* isect2, int n_light_samples, int max_interactions,
                           int total_photons, int fix_exit_point, uint32_t* importances, cpm_stream stream) {
-    if (!ctx) return CPM_ERR_INVALID_ARGUMENT;
+    CPM_ENTER(ctx);
     CPM_REQUIRE(ctx, grid_dims && cell_size && texture_to_index, "cpm_photon_importance: null argument");
     CPM_REQUIRE(ctx, n_light_samples >= 0 && photon_offset >= 0 && max_interactions >= 1 && total_photons >= 0,
                 "cpm_photon_importance: bad size");
@@ -521,7 +521,7 @@ int cpm_photon_importance(cpm_ctx* ctx, const float* importance_grid, const int3
 
 int cpm_photon_importance_equal(cpm_ctx* ctx, int photon_offset, int n_light_samples, int percentage, int iteration,
                                 uint32_t* importances, cpm_stream stream) {
-    if (!ctx) return CPM_ERR_INVALID_ARGUMENT;
+    CPM_ENTER(ctx);
     CPM_REQUIRE(ctx, n_light_samples >= 0 && photon_offset >= 0, "cpm_photon_importance_equal: bad size");
     CPM_REQUIRE(ctx, percentage >= 1 && percentage <= 100, "cpm_photon_importance_equal: percentage must be in [1, 100]");
     if (n_light_samples == 0) return CPM_OK;
@@ -533,7 +533,7 @@ int cpm_photon_importance_equal(cpm_ctx* ctx, int photon_offset, int n_light_sam
 }
 
 int cpm_reset_importance(cpm_ctx* ctx, uint32_t* importances, size_t offset, size_t n, cpm_stream stream) {
-    if (!ctx) return CPM_ERR_INVALID_ARGUMENT;
+    CPM_ENTER(ctx);
     if (n == 0) return CPM_OK;
     CPM_REQUIRE(ctx, importances, "cpm_reset_importance: null buffer");
     CPM_LAUNCH(ctx, fill_u32_kernel, dim3(div_up((long long)n, 256)), dim3(256), 0, (hipStream_t)stream,
@@ -544,7 +544,7 @@ int cpm_reset_importance(cpm_ctx* ctx, uint32_t* importances, size_t offset, siz
 
 int cpm_select_recompute(cpm_ctx* ctx, uint32_t* importances, size_t n, uint32_t* indices_out, int32_t* n_changed_dev,
                          cpm_stream stream) {
-    if (!ctx) return CPM_ERR_INVALID_ARGUMENT;
+    CPM_ENTER(ctx);
     CPM_REQUIRE(ctx, n_changed_dev, "cpm_select_recompute: null counter");
     hipStream_t s = (hipStream_t)stream;
     CPM_HIP_CHECK(ctx, hipMemsetAsync(n_changed_dev, 0, sizeof(int32_t), s));
@@ -559,7 +559,7 @@ int cpm_select_recompute(cpm_ctx* ctx, uint32_t* importances, size_t n, uint32_t
 
 int cpm_select_changed(cpm_ctx* ctx, const uint32_t* importances, size_t n, uint32_t* indices_out, int32_t* n_changed_dev,
                        cpm_stream stream) {
-    if (!ctx) return CPM_ERR_INVALID_ARGUMENT;
+    CPM_ENTER(ctx);
     CPM_REQUIRE(ctx, n_changed_dev, "cpm_select_changed: null counter");
     CPM_REQUIRE(ctx, n < (1ull << 31), "cpm_select_changed: n must be < 2^31");
     hipStream_t s = (hipStream_t)stream;

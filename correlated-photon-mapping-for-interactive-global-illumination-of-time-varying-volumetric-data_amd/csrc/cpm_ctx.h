@@ -69,6 +69,18 @@ bool affine_from_matrix(const float m[16], Affine& out);
         if (e_ != hipSuccess) return cpm::set_error((ctx), CPM_ERR_DEVICE, name, hipGetErrorString(e_)); \
     } while (0)
 
+// Every entry point: a null context is an argument error; the context's device becomes the calling thread's current
+// device (a host thread that drives several contexts -- one per GPU -- may call them in any order).
+#define CPM_ENTER(ctx)                                                                  \
+    do {                                                                                \
+        if (!(ctx)) return CPM_ERR_INVALID_ARGUMENT;                                    \
+        int cur_ = -1;                                                                  \
+        if (hipGetDevice(&cur_) != hipSuccess || cur_ != (ctx)->device) {               \
+            hipError_t e_ = hipSetDevice((ctx)->device);                                \
+            if (e_ != hipSuccess) return cpm::set_error((ctx), CPM_ERR_DEVICE, "hipSetDevice", hipGetErrorString(e_)); \
+        }                                                                               \
+    } while (0)
+
 #define CPM_REQUIRE(ctx, cond, msg)                                                     \
     do {                                                                                \
         if (!(cond)) return cpm::set_error((ctx), CPM_ERR_INVALID_ARGUMENT, msg, #cond); \

@@ -1034,7 +1034,7 @@ void cpm_debug_force_voxel_gather(int on) { g_gather_force_voxel = on; }
 
 int cpm_splat(cpm_ctx* ctx, const float* photons8, int total_photons, const cpm_grid_desc* grid, float radius,
               float scale, float* grid_out, cpm_stream stream) {
-    if (!ctx) return CPM_ERR_INVALID_ARGUMENT;
+    CPM_ENTER(ctx);
     GridDev G;
     int rc = make_grid_dev(ctx, grid, G);
     if (rc) return rc;
@@ -1051,7 +1051,7 @@ int cpm_splat(cpm_ctx* ctx, const float* photons8, int total_photons, const cpm_
 int cpm_splat_selected(cpm_ctx* ctx, const float* photons8, const uint32_t* indices, int n_indices,
                        const cpm_grid_desc* grid, float radius, float scale, float multiplier, int n_photons,
                        int n_interactions, float* grid_out, cpm_stream stream) {
-    if (!ctx) return CPM_ERR_INVALID_ARGUMENT;
+    CPM_ENTER(ctx);
     GridDev G;
     int rc = make_grid_dev(ctx, grid, G);
     if (rc) return rc;
@@ -1068,7 +1068,7 @@ int cpm_splat_selected(cpm_ctx* ctx, const float* photons8, const uint32_t* indi
 int cpm_copy_indexed_photons(cpm_ctx* ctx, const float* photons8, const uint32_t* indices, int n_indices,
                              float multiplier, int n_photons, int n_interactions, float* aligned8, int out_offset,
                              cpm_stream stream) {
-    if (!ctx) return CPM_ERR_INVALID_ARGUMENT;
+    CPM_ENTER(ctx);
     CPM_REQUIRE(ctx, n_indices >= 0 && n_photons >= 0 && n_interactions >= 1 && out_offset >= 0, "cpm_copy_indexed_photons: bad size");
     if (n_indices == 0) return CPM_OK;
     CPM_REQUIRE(ctx, photons8 && indices && aligned8, "cpm_copy_indexed_photons: null buffer");
@@ -1080,7 +1080,7 @@ int cpm_copy_indexed_photons(cpm_ctx* ctx, const float* photons8, const uint32_t
 
 int cpm_bin(cpm_ctx* ctx, const float* photons8, int n, const cpm_grid_desc* grid, uint32_t* order,
             uint32_t* cell_start, float* sorted_pos_power, cpm_stream stream) {
-    if (!ctx) return CPM_ERR_INVALID_ARGUMENT;
+    CPM_ENTER(ctx);
     GridDev G;
     int rc = make_grid_dev(ctx, grid, G);
     if (rc) return rc;
@@ -1139,14 +1139,14 @@ int cpm_gather(cpm_ctx* ctx, const float* sorted_pos_power, const uint32_t* cell
 int cpm_gather_bricks(cpm_ctx* ctx, const float* sorted_pos_power, const uint32_t* cell_start, int n,
                       const cpm_grid_desc* grid, float radius, float scale, const uint8_t* brick_mask, float* grid_out,
                       cpm_stream stream) {
-    if (!ctx) return CPM_ERR_INVALID_ARGUMENT;
+    CPM_ENTER(ctx);
     CPM_REQUIRE(ctx, brick_mask, "cpm_gather_bricks: null mask");
     return gather_impl(ctx, sorted_pos_power, cell_start, n, grid, radius, scale, 0, grid_out, brick_mask, stream);
 }
 
 int cpm_mark_touched_bricks(cpm_ctx* ctx, const float* photons8, const uint32_t* indices, int n_indices, int n_photons,
                             int n_interactions, const cpm_grid_desc* grid, float radius, uint8_t* brick_mask, cpm_stream stream) {
-    if (!ctx) return CPM_ERR_INVALID_ARGUMENT;
+    CPM_ENTER(ctx);
     GridDev G;
     int rc = make_grid_dev(ctx, grid, G);
     if (rc) return rc;
@@ -1164,7 +1164,7 @@ int cpm_mark_touched_bricks(cpm_ctx* ctx, const float* photons8, const uint32_t*
 static int gather_impl(cpm_ctx* ctx, const float* sorted_pos_power, const uint32_t* cell_start, int n,
                        const cpm_grid_desc* grid, float radius, float scale, int accumulate, float* grid_out,
                        const uint8_t* brick_mask, cpm_stream stream) {
-    if (!ctx) return CPM_ERR_INVALID_ARGUMENT;
+    CPM_ENTER(ctx);
     GridDev G;
     int rc = make_grid_dev(ctx, grid, G);
     if (rc) return rc;

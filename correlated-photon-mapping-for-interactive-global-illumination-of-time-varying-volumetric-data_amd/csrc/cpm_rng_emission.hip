@@ -180,7 +180,7 @@ __global__ void mesh_intersection_kernel(const float* __restrict__ vtx, const in
 extern "C" {
 
 int cpm_seed_streams(cpm_ctx* ctx, uint32_t* state, size_t n, uint64_t gap, cpm_stream stream) {
-    if (!ctx) return CPM_ERR_INVALID_ARGUMENT;
+    CPM_ENTER(ctx);
     CPM_REQUIRE(ctx, state || n == 0, "cpm_seed_streams: null state");
     if (n == 0) return CPM_OK;
     CPM_LAUNCH(ctx, seed_streams_kernel, dim3(div_up((long long)n, 256)), dim3(256), 0, (hipStream_t)stream, state, n, gap);
@@ -189,7 +189,7 @@ int cpm_seed_streams(cpm_ctx* ctx, uint32_t* state, size_t n, uint64_t gap, cpm_
 }
 
 int cpm_random_fill(cpm_ctx* ctx, uint32_t* state, size_t n, int draws, float* out, cpm_stream stream) {
-    if (!ctx) return CPM_ERR_INVALID_ARGUMENT;
+    CPM_ENTER(ctx);
     CPM_REQUIRE(ctx, (state && out) || n == 0, "cpm_random_fill: null argument");
     CPM_REQUIRE(ctx, draws >= 0, "cpm_random_fill: draws < 0");
     if (n == 0) return CPM_OK;
@@ -199,7 +199,7 @@ int cpm_random_fill(cpm_ctx* ctx, uint32_t* state, size_t n, int draws, float* o
 }
 
 int cpm_uniform_samples_2d(cpm_ctx* ctx, int nx, int ny, float* samples4, cpm_stream stream) {
-    if (!ctx) return CPM_ERR_INVALID_ARGUMENT;
+    CPM_ENTER(ctx);
     CPM_REQUIRE(ctx, nx >= 0 && ny >= 0 && (long long)nx * ny < (1ll << 24), "cpm_uniform_samples_2d: 0 <= nx*ny < 2^24");
     int n = nx * ny;
     if (n == 0) return CPM_OK;
@@ -213,7 +213,7 @@ int cpm_uniform_samples_2d(cpm_ctx* ctx, int nx, int ny, float* samples4, cpm_st
 int cpm_directional_light_samples(cpm_ctx* ctx, const float* samples4, int n, const float radiance[4],
                                   const float direction[4], const float plane_origin[4], const float tangent_u[4],
                                   const float tangent_v[4], float plane_area, float* ls, cpm_stream stream) {
-    if (!ctx) return CPM_ERR_INVALID_ARGUMENT;
+    CPM_ENTER(ctx);
     CPM_REQUIRE(ctx, n >= 0, "cpm_directional_light_samples: n < 0");
     if (n == 0) return CPM_OK;
     CPM_REQUIRE(ctx, samples4 && radiance && direction && plane_origin && tangent_u && tangent_v && ls,
@@ -232,7 +232,7 @@ int cpm_directional_light_samples(cpm_ctx* ctx, const float* samples4, int n, co
 
 int cpm_point_light_samples(cpm_ctx* ctx, const float* samples4, int n, const float radiance[4],
                             const float position[4], float* ls, cpm_stream stream) {
-    if (!ctx) return CPM_ERR_INVALID_ARGUMENT;
+    CPM_ENTER(ctx);
     CPM_REQUIRE(ctx, n >= 0, "cpm_point_light_samples: n < 0");
     if (n == 0) return CPM_OK;
     CPM_REQUIRE(ctx, samples4 && radiance && position && ls, "cpm_point_light_samples: null argument");
@@ -246,7 +246,7 @@ int cpm_point_light_samples(cpm_ctx* ctx, const float* samples4, int n, const fl
 
 int cpm_light_sample_box_intersection(cpm_ctx* ctx, const float* ls, int n, const float aabb[8], float* isect2,
                                       cpm_stream stream) {
-    if (!ctx) return CPM_ERR_INVALID_ARGUMENT;
+    CPM_ENTER(ctx);
     CPM_REQUIRE(ctx, n >= 0, "cpm_light_sample_box_intersection: n < 0");
     if (n == 0) return CPM_OK;
     CPM_REQUIRE(ctx, ls && aabb && isect2, "cpm_light_sample_box_intersection: null argument");
@@ -260,7 +260,7 @@ int cpm_light_sample_box_intersection(cpm_ctx* ctx, const float* ls, int n, cons
 
 int cpm_light_sample_mesh_intersection(cpm_ctx* ctx, const float* vertices3, const int32_t* indices, int n_indices,
                                        const float* ls, int n, float* isect2, cpm_stream stream) {
-    if (!ctx) return CPM_ERR_INVALID_ARGUMENT;
+    CPM_ENTER(ctx);
     CPM_REQUIRE(ctx, n >= 0 && n_indices >= 0, "cpm_light_sample_mesh_intersection: negative size");
     if (n == 0) return CPM_OK;
     CPM_REQUIRE(ctx, (vertices3 && indices) || n_indices == 0, "cpm_light_sample_mesh_intersection: null mesh");

@@ -408,13 +408,13 @@ void cpm_debug_set_sort_mode(int mode) { cpm::g_sort_mode = mode; }
 void cpm_debug_set_sort_items(int items) { cpm::g_sort_items = items; }
 
 int cpm_sort_pairs(cpm_ctx* ctx, uint32_t* keys, uint32_t* values, size_t n, int key_bits, cpm_stream stream) {
-    if (!ctx) return CPM_ERR_INVALID_ARGUMENT;
+    CPM_ENTER(ctx);
     CPM_REQUIRE(ctx, (keys && values) || n == 0, "cpm_sort_pairs: null argument");
     return cpm::radix_sort(ctx, keys, values, n, key_bits, (hipStream_t)stream, nullptr, nullptr, nullptr, nullptr, false);
 }
 
 int cpm_sort_keys(cpm_ctx* ctx, uint32_t* keys, size_t n, int key_bits, cpm_stream stream) {
-    if (!ctx) return CPM_ERR_INVALID_ARGUMENT;
+    CPM_ENTER(ctx);
     CPM_REQUIRE(ctx, keys || n == 0, "cpm_sort_keys: null argument");
     return cpm::radix_sort(ctx, keys, nullptr, n, key_bits, (hipStream_t)stream, nullptr, nullptr, nullptr, nullptr, false);
 }

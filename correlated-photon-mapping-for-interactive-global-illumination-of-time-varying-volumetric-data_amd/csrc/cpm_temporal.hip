@@ -135,7 +135,7 @@ void cpm_debug_set_stream_wg_per_cu(int n) { g_stream_wg_per_cu = n; }
 
 int cpm_mix_buffers(cpm_ctx* ctx, const void* x, const void* y, float a, size_t n_elements, int type, void* out,
                     cpm_stream stream) {
-    if (!ctx) return CPM_ERR_INVALID_ARGUMENT;
+    CPM_ENTER(ctx);
     CPM_REQUIRE(ctx, type == CPM_MIX_F32 || type == CPM_MIX_U16X2, "cpm_mix_buffers: type");
     if (n_elements == 0) return CPM_OK;
     CPM_REQUIRE(ctx, x && y && out, "cpm_mix_buffers: null buffer");
@@ -155,7 +155,7 @@ int cpm_mix_buffers(cpm_ctx* ctx, const void* x, const void* y, float a, size_t 
 
 int cpm_volume_mix(cpm_ctx* ctx, const cpm_volume* v0, const cpm_volume* v1, float weight, cpm_volume* out,
                    cpm_stream stream) {
-    if (!ctx) return CPM_ERR_INVALID_ARGUMENT;
+    CPM_ENTER(ctx);
     CPM_REQUIRE(ctx, v0 && v1 && out, "cpm_volume_mix: null argument");
     CPM_REQUIRE(ctx, memcmp(v0->desc.dims, v1->desc.dims, sizeof(v0->desc.dims)) == 0 && v0->desc.dtype == v1->desc.dtype &&
                          memcmp(v0->desc.dims, out->desc.dims, sizeof(v0->desc.dims)) == 0 && v0->desc.dtype == out->desc.dtype,

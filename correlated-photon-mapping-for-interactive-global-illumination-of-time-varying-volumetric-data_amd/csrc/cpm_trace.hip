@@ -312,7 +312,7 @@ int cpm_trace(cpm_ctx* ctx, const cpm_volume* vol, const cpm_tf* tf, const cpm_t
               const cpm_trace_params* params, const float* light_samples8, const float* isect2,
               const uint32_t* recompute_indices, int n_recompute, uint32_t* rng_state, float* photons8,
               cpm_stream stream) {
-    if (!ctx) return CPM_ERR_INVALID_ARGUMENT;
+    CPM_ENTER(ctx);
     CPM_REQUIRE(ctx, vol && tf && aabb && params, "cpm_trace: null argument");
     const cpm_trace_params& p = *params;
     CPM_REQUIRE(ctx, p.n_light_samples >= 0 && p.photon_offset >= 0 && p.total_photons >= 0, "cpm_trace: negative size");
