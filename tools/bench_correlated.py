@@ -42,12 +42,17 @@ vols = [S.heterogeneous_volume(256, S.sequence_blob_center(t, n_steps)) for t in
 cm = P.CorrelatedPhotonMapper(ctx, vols[0], S.workspace_tf(), 1024, (128,)*3, light_travel_direction=(0.3, 0.5, -1.0), tf_points=base)
 cm.full_frame()
 dvols = [torch.from_numpy(v).to(ctx.device) for v in vols]   # resident: the upload is not part of the update
+# the host -> device upload of one time step (16 MiB), reported separately: pinned and pageable host memory
+pinned = torch.from_numpy(vols[1]).pin_memory()
+staging = torch.empty_like(dvols[1])
+up_pinned, _ = sync_ms(lambda: staging.copy_(pinned, non_blocking=True), 10)
+up_pageable, _ = sync_ms(lambda: staging.copy_(torch.from_numpy(vols[2])), 10)
 steps = []
 for t in range(1, n_steps):
     t_vol, _ = sync_ms(lambda: cm.set_volume(dvols[t]))
     t_upd, n = sync_ms(cm.correlated_update)
     steps.append((t_vol, t_upd, n / cm.n, cm.last_path))
-out["config5_sequence"] = {"steps": n_steps - 1, "volume_step_ms(diff+minmax+importance)": round(np.mean([x[0] for x in steps]), 4),
+out["config5_sequence"] = {"steps": n_steps - 1, "volume_upload_ms_pinned": round(up_pinned, 4), "volume_upload_ms_pageable": round(up_pageable, 4), "volume_step_ms(diff+minmax+importance)": round(np.mean([x[0] for x in steps]), 4),
                            "update_ms": round(np.mean([x[1] for x in steps]), 4), "fraction_retraced": round(np.mean([x[2] for x in steps]), 4),
                            "paths": sorted(set(x[3] for x in steps))}
 print(json.dumps(out))
