@@ -274,7 +274,8 @@ __global__ __launch_bounds__(256) void gather_voxel_kernel(const float* __restri
                                                             const uint32_t* __restrict__ cell_start, GridDev G, float radius,
                                                             float r2max, float k, int Rx, int Ry, int Rz, int accumulate,
                                                             int bxn, int byn, float* __restrict__ out,
-                                                            unsigned long long* __restrict__ dbg) {
+                                                            unsigned long long* __restrict__ dbg,
+                                                            const uint8_t* __restrict__ bmask) {
     constexpr int STRIDE = (CH == 1 ? 1 : 2);
     __shared__ uint32_t q_j[kQ][256];
     __shared__ float q_d2[kQ][256];
@@ -289,6 +290,7 @@ __global__ __launch_bounds__(256) void gather_voxel_kernel(const float* __restri
     // face of the volume instead of one XCD owning the whole x = 0 face (measured: 859 -> 180 us).
     const int x0 = bx * kGW, y0 = by * kGW, z0 = bz * kGW;
     if (z0 >= G.dz) return;
+    if (bmask && !bmask[(size_t)bx + (size_t)bxn * ((size_t)by + (size_t)byn * (size_t)bz)]) return;  // cpm_gather_bricks: brick not selected
     const int x = x0 + (lane & 3), y = y0 + ((lane >> 2) & 3), z = z0 + (lane >> 4);
     const bool valid = x < G.dx && y < G.dy && z < G.dz;
     // ---- brick-level early-out
@@ -394,7 +396,8 @@ __global__ __launch_bounds__(256) void gather_records_kernel(const float* __rest
                                                              const uint32_t* __restrict__ cell_start, GridDev G, float radius,
                                                              float r2max, float k, int Rx, int Ry, int Rz, int accumulate,
                                                              int bxn, int byn, float* __restrict__ out,
-                                                             unsigned long long* __restrict__ dbg) {
+                                                             unsigned long long* __restrict__ dbg,
+                                                             const uint8_t* __restrict__ bmask) {
     constexpr int NC = MAXC * MAXC * MAXC;
     constexpr int MAXROWS = 64;
     __shared__ float s_val_all[4][NC][64];
@@ -415,6 +418,7 @@ __global__ __launch_bounds__(256) void gather_records_kernel(const float* __rest
     const int bx = (gb % bxn + 4 * (by + bz)) % bxn;  // XCD-balancing rotation (see gather_voxel_kernel)
     const int x0 = bx * kGW, y0 = by * kGW, z0 = bz * kGW;
     if (z0 >= G.dz) return;
+    if (bmask && !bmask[(size_t)bx + (size_t)bxn * ((size_t)by + (size_t)byn * (size_t)bz)]) return;  // cpm_gather_bricks
     const int x = x0 + (lane & 3), y = y0 + ((lane >> 2) & 3), z = z0 + (lane >> 4);
     const bool valid = x < G.dx && y < G.dy && z < G.dz;
 
@@ -1179,7 +1183,7 @@ static int gather_impl(cpm_ctx* ctx, const float* sorted_pos_power, const uint32
     float k = kInv4Pi * scale;
     // cheap exact reject: d^2 > r^2 (1 + 1e-5)  =>  fl(fl(sqrt(d^2)) / r) > 1  =>  weight 0
     float r2max = (radius * radius) * 1.00001f;
-    CPM_REQUIRE(ctx, Rx <= 2 && Ry <= 2 && Rz <= 2, "cpm_gather: radius above 2.5 light-volume voxels is not supported");
+    // any radius: the voxel-major kernel takes the halo widths at run time (the tuned record-major kernels need R <= 2)
     int bxn = div_up(G.dx, 4), byn = div_up(G.dy, 4), bzn = div_up(G.dz, 4);
     dim3 gridDim((unsigned)div_up((long long)bxn * byn * bzn, 4)), block(256);
     hipStream_t hs = (hipStream_t)stream;
@@ -1238,16 +1242,16 @@ static int gather_impl(cpm_ctx* ctx, const float* sorted_pos_power, const uint32
 #undef CPM_REC2_LAUNCH
     else if (G.channels == 1 && cand_axis <= 2 && g_gather_force_voxel != 1)
         CPM_LAUNCH(ctx, gather_records_kernel<2>, gridDim, block, 0, hs, sorted_pos_power, cell_start, G, radius, r2max, k, Rx, Ry, Rz,
-                   accumulate, bxn, byn, grid_out, g_gather_stamps);
+                   accumulate, bxn, byn, grid_out, g_gather_stamps, brick_mask);
     else if (G.channels == 1 && cand_axis <= 3 && g_gather_force_voxel != 1)
         CPM_LAUNCH(ctx, gather_records_kernel<3>, gridDim, block, 0, hs, sorted_pos_power, cell_start, G, radius, r2max, k, Rx, Ry, Rz,
-                   accumulate, bxn, byn, grid_out, g_gather_stamps);
+                   accumulate, bxn, byn, grid_out, g_gather_stamps, brick_mask);
     else if (G.channels == 1)
         CPM_LAUNCH(ctx, (gather_voxel_kernel<1, 4>), gridDim, block, 0, hs, sorted_pos_power, cell_start, G, radius, r2max, k, Rx, Ry, Rz,
-                   accumulate, bxn, byn, grid_out, g_gather_stamps);
+                   accumulate, bxn, byn, grid_out, g_gather_stamps, brick_mask);
     else
         CPM_LAUNCH(ctx, (gather_voxel_kernel<4, 4>), gridDim, block, 0, hs, sorted_pos_power, cell_start, G, radius, r2max, k, Rx, Ry, Rz,
-                   accumulate, bxn, byn, grid_out, g_gather_stamps);
+                   accumulate, bxn, byn, grid_out, g_gather_stamps, brick_mask);
     CPM_LAUNCH_CHECK(ctx, "gather_kernel");
     return CPM_OK;
 }

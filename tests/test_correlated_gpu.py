@@ -336,16 +336,25 @@ def test_exact_incremental_update_is_bit_identical_to_a_full_frame(ctx, cpm, int
         assert 0 < changed.sum() < lv.size          # a local update, not a rewrite of everything
 
 
-def test_mark_touched_bricks_and_gather_bricks(ctx, oracle, cpm):
+@pytest.mark.parametrize("radius_vox,force_voxel", [(0.8, 0), (0.8, 1), (0.8, 2), (1.3, 0), (1.3, 2), (2.7, 0)])
+def test_mark_touched_bricks_and_gather_bricks(ctx, oracle, cpm, radius_vox, force_voxel):
     """cpm_mark_touched_bricks marks exactly the bricks the selected photons' splat boxes overlap; cpm_gather_bricks
-    rewrites exactly the marked bricks."""
+    rewrites exactly the marked bricks -- whichever gather kernel the radius (or the test hook) selects."""
+    ctx.lib.cpm_debug_force_voxel_gather(int(force_voxel))
+    try:
+        _mark_and_gather_bricks(ctx, oracle, cpm, radius_vox)
+    finally:
+        ctx.lib.cpm_debug_force_voxel_gather(0)
+
+
+def _mark_and_gather_bricks(ctx, oracle, cpm, radius_vox):
     rng = np.random.default_rng(9)
     dims, n = (24, 20, 28), 5000
     ph = np.zeros((n, 8), np.float32)
     ph[:, :3] = rng.random((n, 3), dtype=np.float32)
     ph[:, 3:6] = rng.random((n, 3), dtype=np.float32)
     ph[::50, :3] = np.float32(3.402823466e+38)
-    radius = float(np.float32(0.8 / max(dims)))
+    radius = float(np.float32(radius_vox / max(dims)))
     g, og = cpm.binding.default_grid_desc(dims, 1), oracle.grid(dims, 1)
     bdim = [(d + 3) // 4 for d in dims]
     nb = bdim[0] * bdim[1] * bdim[2]

@@ -1,0 +1,105 @@
+"""Seeded random sweeps of the bin + gather path (through the C-ABI) against the oracle.
+
+The parametrised parity tests pin the geometries the kernels specialise on; this file throws
+shapes at the dispatch that nobody chose by hand: degenerate grids (an axis of 1 cell), grids
+smaller than a brick, photon counts around wave / tile sizes, radii across every kernel's range,
+photons piled into one cell or spread past the volume's faces.  Bit-exact, as everywhere.
+"""
+import numpy as np
+import pytest
+
+from test_parity_gpu import _n, _t, bits
+
+pytestmark = pytest.mark.gpu
+
+F32_MAX = np.float32(3.402823466e+38)
+
+
+def _case(seed):
+    rng = np.random.default_rng(1000 + seed)
+    pick = lambda *xs: xs[int(rng.integers(len(xs)))]
+    shape_kind = pick("cube", "slab", "line", "tiny", "ragged", "ragged")
+    if shape_kind == "cube":
+        d = int(pick(8, 16, 24, 32)); dims = (d, d, d)
+    elif shape_kind == "slab":
+        dims = tuple(int(x) for x in rng.permutation([1, int(rng.integers(5, 40)), int(rng.integers(5, 40))]))
+    elif shape_kind == "line":
+        dims = tuple(int(x) for x in rng.permutation([1, 1, int(rng.integers(1, 70))]))
+    elif shape_kind == "tiny":
+        dims = tuple(int(x) for x in rng.integers(1, 4, 3))
+    else:
+        dims = tuple(int(x) for x in rng.integers(2, 41, 3))
+    channels = int(pick(1, 1, 4))
+    radius_vox = float(pick(0.05, 0.3, 0.7, 0.866, 0.999, 1.0, 1.2, 1.4999, 1.5, 1.7320508, 1.99, 2.0, 2.4, 3.1))
+    n = int(pick(1, 2, 63, 64, 65, 255, 2047, 2048, 2049, 4100, 9000, 30000))
+    layout = pick("uniform", "uniform", "overspill", "one_cell", "faces", "all_missed")
+    ph = np.zeros((n, 8), np.float32)
+    if layout == "uniform":
+        ph[:, :3] = rng.random((n, 3), dtype=np.float32)
+    elif layout == "overspill":
+        ph[:, :3] = (0.5 + (rng.random((n, 3)) - 0.5) * 1.3).astype(np.float32)
+    elif layout == "one_cell":
+        c = rng.random(3, dtype=np.float32)
+        ph[:, :3] = c + (rng.random((n, 3), dtype=np.float32) - 0.5) * np.float32(0.4 / max(dims))
+    elif layout == "faces":
+        ph[:, :3] = rng.integers(0, 2, (n, 3)).astype(np.float32)
+        ph[:, int(rng.integers(3))] = rng.random(n, dtype=np.float32)
+    else:
+        ph[:, :3] = F32_MAX
+    if layout != "all_missed" and n > 4:
+        ph[:: int(pick(3, 7, 50)), :3] = F32_MAX                    # photons that left the volume
+    ph[:, 3:6] = rng.random((n, 3), dtype=np.float32) * 3
+    ph[:, 6:] = rng.random((n, 2), dtype=np.float32)
+    return dims, channels, radius_vox, n, ph, f"{shape_kind}/{layout}"
+
+
+@pytest.mark.parametrize("seed", range(48))
+def test_bin_and_gather_random_shapes(ctx, oracle, cpm, seed):
+    dims, channels, radius_vox, n, ph, what = _case(seed)
+    note = f"seed {seed}: {what} dims={dims} C={channels} r={radius_vox} vox n={n}"
+    radius = float(np.float32(radius_vox / max(dims)))
+    scale = oracle.relative_irradiance_scale(radius, n)
+    g = cpm.binding.default_grid_desc(dims, channels)
+    og = oracle.grid(dims, channels)
+    cells = dims[0] * dims[1] * dims[2]
+    torch = ctx.torch
+    order = torch.empty(n, dtype=torch.int32, device=ctx.device)
+    cs = torch.empty(cells + 1, dtype=torch.int32, device=ctx.device)
+    srt = torch.empty((n, 4 if channels == 1 else 8), dtype=torch.float32, device=ctx.device)
+    ctx.bin(_t(ctx, ph), n, g, order, cs, srt)
+    o_order, o_cs, o_srt = oracle.bin(ph, n, og)
+    assert np.array_equal(_n(order, np.uint32), o_order), note
+    assert np.array_equal(_n(cs, np.uint32), o_cs), note
+    valid = int(o_cs[cells])
+    assert np.array_equal(bits(_n(srt))[:valid], bits(o_srt)[:valid]), note
+
+    shape = (cells,) if channels == 1 else (cells, 4)
+    out = torch.full(shape, -3.0, dtype=torch.float32, device=ctx.device)
+    ctx.gather(srt, cs, n, g, radius, scale, out)
+    want = np.full(shape, -3.0, np.float32)
+    oracle.gather(o_srt, o_cs, n, og, radius, scale, want)
+    assert np.array_equal(bits(_n(out)), bits(want)), note
+    ctx.gather(srt, cs, n, g, radius, scale, out, accumulate=True)
+    oracle.gather(o_srt, o_cs, n, og, radius, scale, want, accumulate=True)
+    assert np.array_equal(bits(_n(out)), bits(want)), note
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_sort_pairs_random_lengths_and_bits(ctx, seed):
+    rng = np.random.default_rng(77 + seed)
+    n = int(rng.choice([1, 2, 63, 65, 2047, 2049, 4096, 6143, 50_001, 300_000]))
+    key_bits = int(rng.choice([1, 3, 8, 9, 16, 17, 22, 24, 25, 32]))
+    hi = (1 << key_bits) - 1
+    kind = int(rng.integers(3))
+    if kind == 0:
+        keys = rng.integers(0, hi + 1, n, dtype=np.uint64).astype(np.uint32)
+    elif kind == 1:                                                # a handful of distinct keys
+        keys = rng.choice(rng.integers(0, hi + 1, 5, dtype=np.uint64), n).astype(np.uint32)
+    else:                                                          # already sorted, descending
+        keys = np.sort(rng.integers(0, hi + 1, n, dtype=np.uint64).astype(np.uint32))[::-1].copy()
+    vals = rng.permutation(n).astype(np.uint32)
+    kd, vd = _t(ctx, keys), _t(ctx, vals)
+    ctx.sort_pairs(kd, vd, key_bits)
+    o = np.argsort(keys, kind="stable")
+    assert np.array_equal(_n(kd, np.uint32), keys[o]), (n, key_bits, kind)
+    assert np.array_equal(_n(vd, np.uint32), vals[o]), (n, key_bits, kind)
