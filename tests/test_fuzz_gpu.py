@@ -5,6 +5,8 @@ shapes at the dispatch that nobody chose by hand: degenerate grids (an axis of 1
 smaller than a brick, photon counts around wave / tile sizes, radii across every kernel's range,
 photons piled into one cell or spread past the volume's faces.  Bit-exact, as everywhere.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -13,6 +15,7 @@ from test_parity_gpu import _n, _t, bits
 pytestmark = pytest.mark.gpu
 
 F32_MAX = np.float32(3.402823466e+38)
+MORE = int(os.environ.get("CPM_FUZZ_SCALE", "1"))      # CPM_FUZZ_SCALE=20 pytest ...: a longer hunt, same seeds first
 
 
 def _case(seed):
@@ -53,7 +56,7 @@ def _case(seed):
     return dims, channels, radius_vox, n, ph, f"{shape_kind}/{layout}"
 
 
-@pytest.mark.parametrize("seed", range(48))
+@pytest.mark.parametrize("seed", range(48 * MORE))
 def test_bin_and_gather_random_shapes(ctx, oracle, cpm, seed):
     dims, channels, radius_vox, n, ph, what = _case(seed)
     note = f"seed {seed}: {what} dims={dims} C={channels} r={radius_vox} vox n={n}"
@@ -84,7 +87,7 @@ def test_bin_and_gather_random_shapes(ctx, oracle, cpm, seed):
     assert np.array_equal(bits(_n(out)), bits(want)), note
 
 
-@pytest.mark.parametrize("seed", range(12))
+@pytest.mark.parametrize("seed", range(12 * MORE))
 def test_sort_pairs_random_lengths_and_bits(ctx, seed):
     rng = np.random.default_rng(77 + seed)
     n = int(rng.choice([1, 2, 63, 65, 2047, 2049, 4096, 6143, 50_001, 300_000]))
@@ -103,3 +106,64 @@ def test_sort_pairs_random_lengths_and_bits(ctx, seed):
     o = np.argsort(keys, kind="stable")
     assert np.array_equal(_n(kd, np.uint32), keys[o]), (n, key_bits, kind)
     assert np.array_equal(_n(vd, np.uint32), vals[o]), (n, key_bits, kind)
+
+
+@pytest.mark.parametrize("seed", range(24 * MORE))
+def test_trace_random_setups(ctx, oracle, cpm, seed):
+    """Random volumes (shape, voxel type, content), transfer functions (width, opacity range), light
+    directions / point lights, interaction counts, phase functions and kernel flags: photons and
+    RNG streams bit-identical to the oracle's."""
+    from test_parity_gpu import _trace_case
+    rng = np.random.default_rng(4000 + seed)
+    pick = lambda *xs: xs[int(rng.integers(len(xs)))]
+    S, B = cpm.synthetic, cpm.binding
+    shape = tuple(int(x) for x in rng.integers(2, 49, 3))            # [z, y, x]
+    if pick(0, 0, 1):
+        shape = tuple(int(x) for x in rng.permutation([1, int(rng.integers(2, 40)), int(rng.integers(2, 40))]))
+        if shape[2] < 2:                                              # cpm_volume_create: at least 2 voxels along x
+            shape = (shape[2], shape[1], shape[0])
+    content = pick("noise", "smooth", "constant", "empty")
+    if content == "noise":
+        v01 = rng.random(shape)
+    elif content == "smooth":
+        z, y, x = np.meshgrid(*[np.linspace(0, 1, s) for s in shape], indexing="ij")
+        v01 = 0.5 + 0.5 * np.sin(7 * x + 3 * y * y + 5 * z)
+    elif content == "constant":
+        v01 = np.full(shape, rng.random())
+    else:
+        v01 = np.zeros(shape)
+    dtype = pick(np.uint8, np.uint8, np.uint16, np.float32)
+    fmt = (0.0, 0.0)
+    if dtype == np.uint8:
+        vol = np.rint(v01 * 255).astype(np.uint8)
+    elif dtype == np.uint16:
+        if pick(0, 1):
+            vol, fmt = np.rint(v01 * 4095).astype(np.uint16), (1.0 - 65535.0 / 4095.0, 0.0)
+        else:
+            vol = np.rint(v01 * 65535).astype(np.uint16)
+    else:
+        vol = v01.astype(np.float32)
+    width = int(pick(2, 17, 256, 1024))
+    a_hi = float(pick(0.0, 0.05, 0.6, 1.0))
+    pts = [(0, 1, 1, 1, float(pick(0.0, 0.02))), (float(rng.uniform(0.2, 0.8)), 0.3, 0.9, 0.2, a_hi * float(rng.random())),
+           (1, 1, 0.5, 0.1, a_hi)]
+    tf = S.tf_from_points(pts, width=width)
+    max_inter = int(pick(1, 1, 2, 5))
+    flags = 0
+    if max_inter > 1 and pick(0, 1):
+        flags |= B.CPM_TRACE_NO_SINGLE_SCATTERING
+    if pick(0, 1):
+        flags |= B.CPM_TRACE_PROGRESSIVE
+    shading, g = pick((0, 0.0), (1, 0.0), (0, 0.7), (0, -0.5), (0, 0.95))
+    tfs = S.tf_from_points([(0, 1, 1, 1, 0.1), (1, 1, 1, 1, 0.9)], width=width) if (max_inter > 1 and pick(0, 1)) else None   # Inviwo TFs share one texture width
+    direction = tuple(float(x) for x in rng.normal(size=3))
+    if pick(0, 0, 0, 1):
+        direction = pick((1.0, 0.0, 0.0), (0.0, -1.0, 0.0), (0.0, 0.0, 1.0))     # axis-aligned rays along cell boundaries
+    point = tuple(float(x) for x in rng.uniform(-1.5, 2.5, 3)) if pick(0, 0, 1) else None
+    n_side = int(pick(1, 7, 33, 64, 100))
+    note = (f"seed {seed}: vol {shape} {np.dtype(dtype).name} {content} tf{width} a<={a_hi} I={max_inter} flags={flags} "
+            f"shading={shading} g={g} dir={direction} point={point} n={n_side}^2")
+    got, want, rng_g, rng_w, *_ = _trace_case(ctx, oracle, cpm, vol, tf, n_side, direction, max_inter=max_inter, flags=flags,
+                                              point=point, shading=shading, g=g, tfs=tfs, fmt=fmt)
+    assert np.array_equal(bits(got), bits(want)), note
+    assert np.array_equal(rng_g, rng_w), note
