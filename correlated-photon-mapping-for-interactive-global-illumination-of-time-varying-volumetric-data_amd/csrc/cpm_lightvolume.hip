@@ -136,7 +136,12 @@ __global__ __launch_bounds__(256) void bin_keys_kernel(const float* __restrict__
     __shared__ uint32_t h[256];
     h[threadIdx.x] = 0;
     // preset the run-start table to "none" on the way (saves a separate fill launch)
-    for (uint32_t e = blockIdx.x * blockDim.x + threadIdx.x; e <= cells; e += gridDim.x * blockDim.x) cell_start[e] = 0xffffffffu;
+    {
+        const uint32_t gt = blockIdx.x * blockDim.x + threadIdx.x, gn = gridDim.x * blockDim.x;
+        const uint32_t nvec = (reinterpret_cast<uintptr_t>(cell_start) & 15u) == 0 ? (cells + 1) / 4 : 0;  // 16-byte stores
+        for (uint32_t e = gt; e < nvec; e += gn) reinterpret_cast<uint4*>(cell_start)[e] = make_uint4(~0u, ~0u, ~0u, ~0u);
+        for (uint32_t e = 4 * nvec + gt; e <= cells; e += gn) cell_start[e] = 0xffffffffu;
+    }
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < ITEMS; ++k) {
@@ -189,7 +194,7 @@ __global__ __launch_bounds__(256) void bin_finalize_kernel(const float* __restri
 
 // cell_start[c] = first j with key[j] >= c, c = 0..cells: a reverse (suffix) min-scan over the
 // table of run starts.  One workgroup owns kCsTile consecutive entries; what lies behind its
-// tile is summarised by one binary search in the sorted keys (the first j with key >= tile end),
+// tile is summarised by one (wave-wide, 64-ary) search in the sorted keys (the first j with key >= tile end),
 // so the tiles are independent: one coalesced read and one coalesced write of the table.
 constexpr int kCsTile = 2048;
 constexpr int kCsPer = kCsTile / 256;
@@ -201,19 +206,36 @@ __global__ __launch_bounds__(256) void cell_start_kernel(const uint32_t* __restr
     const uint32_t t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const uint32_t c0 = blockIdx.x * (uint32_t)kCsTile;
     const uint32_t c1 = min(c0 + (uint32_t)kCsTile, cells + 1);  // entries [c0, c1)
-    if (t == 0) {
-        uint32_t lo = 0, hi = n;
-        while (lo < hi) {
-            uint32_t mid = (lo + hi) >> 1;
-            if (keys[mid] < c1) lo = mid + 1; else hi = mid;
-        }
-        s_hi = lo;
-    }
-    // thread t owns entries [c0 + t*kCsPer, +kCsPer): two 16-byte loads
+    // thread t owns entries [c0 + t*kCsPer, +kCsPer): two 16-byte loads, issued before the search so that their latency
+    // hides behind it (the ragged last tile, or a table that is not 16-byte aligned, goes entry by entry)
+    static_assert(kCsPer == 8, "two uint4 per thread");
     uint32_t v[kCsPer];
     const uint32_t base = c0 + t * kCsPer;
+    const bool vec = base + kCsPer <= c1 && (reinterpret_cast<uintptr_t>(cell_start) & 15u) == 0;
+    if (vec) {
+        const uint4 a = *reinterpret_cast<const uint4*>(cell_start + base);
+        const uint4 b = *reinterpret_cast<const uint4*>(cell_start + base + 4);
+        v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+    } else {
 #pragma unroll
-    for (int i = 0; i < kCsPer; ++i) v[i] = (base + i < c1) ? cell_start[base + i] : 0xffffffffu;
+        for (int i = 0; i < kCsPer; ++i) v[i] = (base + i < c1) ? cell_start[base + i] : 0xffffffffu;
+    }
+    if (wave == 0) {
+        // first j with keys[j] >= c1 by a 64-ary search: 64 probes per round trip instead of one (a binary search is 20
+        // DEPENDENT loads, ~10 us of latency that was the whole kernel; 1 M keys -> 16 K -> 256 -> 4 -> done)
+        uint32_t lo = 0, hi = n;
+        while (lo < hi) {
+            const uint32_t step = (hi - lo + 63u) >> 6;
+            const uint32_t pos = lo + lane * step;
+            const bool below = pos < hi && keys[pos] < c1;           // monotone in lane: keys are sorted
+            const uint32_t cnt = (uint32_t)__popcll(__ballot(below));
+            if (cnt == 0) break;                                      // keys[lo] >= c1
+            const uint32_t last_below = lo + (cnt - 1) * step;
+            hi = min(hi, last_below + step);                          // first probe that was not below (or the old end)
+            lo = last_below + 1;
+        }
+        if (lane == 0) s_hi = lo;
+    }
     uint32_t m = 0xffffffffu;
 #pragma unroll
     for (int i = kCsPer - 1; i >= 0; --i) { m = min(m, v[i]); v[i] = m; }
@@ -230,9 +252,14 @@ __global__ __launch_bounds__(256) void cell_start_kernel(const uint32_t* __restr
     for (int w = 3; w >= 0; --w) if (w > (int)wave) after = min(after, wmin[w]);
     uint32_t next_lane = __shfl_down(sfx, 1, 64);
     uint32_t behind = (lane == 63) ? after : min(next_lane, after);
+    if (vec) {
+        *reinterpret_cast<uint4*>(cell_start + base) = make_uint4(min(v[0], behind), min(v[1], behind), min(v[2], behind), min(v[3], behind));
+        *reinterpret_cast<uint4*>(cell_start + base + 4) = make_uint4(min(v[4], behind), min(v[5], behind), min(v[6], behind), min(v[7], behind));
+    } else {
 #pragma unroll
-    for (int i = 0; i < kCsPer; ++i)
-        if (base + i < c1) cell_start[base + i] = min(v[i], behind);
+        for (int i = 0; i < kCsPer; ++i)
+            if (base + i < c1) cell_start[base + i] = min(v[i], behind);
+    }
 }
 
 // ---- gather
