@@ -503,6 +503,8 @@ int cpm_photon_importance(cpm_ctx* ctx, const float* importance_grid, const int3
                 "cpm_photon_importance: bad size");
     if (n_light_samples == 0) return CPM_OK;
     CPM_REQUIRE(ctx, importance_grid && photons8 && light_samples8 && isect2 && importances, "cpm_photon_importance: null buffer");
+    CPM_REQUIRE_ALIGNED16(ctx, photons8, "cpm_photon_importance");
+    CPM_REQUIRE_ALIGNED16(ctx, light_samples8, "cpm_photon_importance");
     ImpGrid G;
     G.grid = importance_grid;
     for (int a = 0; a < 3; ++a) {

@@ -86,6 +86,10 @@ bool affine_from_matrix(const float m[16], Affine& out);
         if (!(cond)) return cpm::set_error((ctx), CPM_ERR_INVALID_ARGUMENT, msg, #cond); \
     } while (0)
 
+// float8 / float4 buffers are read and written with 16-byte accesses (include/cpm/cpm.h, conventions)
+#define CPM_REQUIRE_ALIGNED16(ctx, ptr, msg) \
+    CPM_REQUIRE(ctx, (reinterpret_cast<uintptr_t>(ptr) & 15u) == 0, msg ": buffer is not 16-byte aligned")
+
 // Records a start/stop hipEvent pair around one kernel launch when ctx->profiling is set.
 struct ProfScope {
     cpm_ctx* ctx; hipStream_t s; hipEvent_t b = nullptr;

@@ -1072,6 +1072,7 @@ int cpm_splat(cpm_ctx* ctx, const float* photons8, int total_photons, const cpm_
     CPM_REQUIRE(ctx, total_photons >= 0 && radius > 0.f, "cpm_splat: bad size or radius");
     if (total_photons == 0) return CPM_OK;
     CPM_REQUIRE(ctx, photons8 && grid_out, "cpm_splat: null buffer");
+    CPM_REQUIRE_ALIGNED16(ctx, photons8, "cpm_splat");
     float k = kInv4Pi * scale;
     CPM_LAUNCH(ctx, splat_kernel, dim3(div_up(total_photons, 256)), dim3(256), 0, (hipStream_t)stream, photons8,
                        total_photons, G, radius, k, grid_out);
@@ -1089,6 +1090,7 @@ int cpm_splat_selected(cpm_ctx* ctx, const float* photons8, const uint32_t* indi
     CPM_REQUIRE(ctx, n_indices >= 0 && n_photons >= 0 && n_interactions >= 1 && radius > 0.f, "cpm_splat_selected: bad size");
     if (n_indices == 0) return CPM_OK;
     CPM_REQUIRE(ctx, photons8 && indices && grid_out, "cpm_splat_selected: null buffer");
+    CPM_REQUIRE_ALIGNED16(ctx, photons8, "cpm_splat_selected");
     float k = kInv4Pi * scale;
     CPM_LAUNCH(ctx, splat_selected_kernel, dim3(div_up(n_indices, 256)), dim3(256), 0, (hipStream_t)stream, photons8,
                        indices, n_indices, G, radius, k, multiplier, n_photons, n_interactions, grid_out);
@@ -1103,6 +1105,8 @@ int cpm_copy_indexed_photons(cpm_ctx* ctx, const float* photons8, const uint32_t
     CPM_REQUIRE(ctx, n_indices >= 0 && n_photons >= 0 && n_interactions >= 1 && out_offset >= 0, "cpm_copy_indexed_photons: bad size");
     if (n_indices == 0) return CPM_OK;
     CPM_REQUIRE(ctx, photons8 && indices && aligned8, "cpm_copy_indexed_photons: null buffer");
+    CPM_REQUIRE_ALIGNED16(ctx, photons8, "cpm_copy_indexed_photons");
+    CPM_REQUIRE_ALIGNED16(ctx, aligned8, "cpm_copy_indexed_photons");
     CPM_LAUNCH(ctx, copy_indexed_kernel, dim3(div_up(n_indices, 256)), dim3(256), 0, (hipStream_t)stream, photons8,
                        indices, n_indices, multiplier, n_photons, n_interactions, aligned8, out_offset);
     CPM_LAUNCH_CHECK(ctx, "copy_indexed_kernel");
@@ -1118,6 +1122,8 @@ int cpm_bin(cpm_ctx* ctx, const float* photons8, int n, const cpm_grid_desc* gri
     CPM_REQUIRE(ctx, n >= 0, "cpm_bin: n < 0");
     CPM_REQUIRE(ctx, cell_start, "cpm_bin: null cell_start");
     CPM_REQUIRE(ctx, n == 0 || (photons8 && order && sorted_pos_power), "cpm_bin: null buffer");
+    CPM_REQUIRE_ALIGNED16(ctx, photons8, "cpm_bin");
+    CPM_REQUIRE_ALIGNED16(ctx, sorted_pos_power, "cpm_bin");
     hipStream_t s = (hipStream_t)stream;
     const uint32_t cells = (uint32_t)G.dx * G.dy * G.dz;
     uint32_t* keys = (uint32_t*)scratch(ctx, CPM_SCR_BIN_KEYS, (size_t)(n > 0 ? n : 1) * 8);
@@ -1184,6 +1190,7 @@ int cpm_mark_touched_bricks(cpm_ctx* ctx, const float* photons8, const uint32_t*
     CPM_REQUIRE(ctx, n_indices >= 0 && n_photons >= 0 && n_interactions >= 1 && radius > 0.f, "cpm_mark_touched_bricks: bad size or radius");
     if (n_indices == 0) return CPM_OK;
     CPM_REQUIRE(ctx, photons8 && indices && brick_mask, "cpm_mark_touched_bricks: null buffer");
+    CPM_REQUIRE_ALIGNED16(ctx, photons8, "cpm_mark_touched_bricks");
     const int bxn = div_up(G.dx, 4), byn = div_up(G.dy, 4);
     const long long threads = (long long)n_indices * n_interactions;
     CPM_LAUNCH(ctx, mark_bricks_kernel, dim3((unsigned)div_up(threads, 256)), dim3(256), 0, (hipStream_t)stream, photons8, indices,
@@ -1201,6 +1208,8 @@ static int gather_impl(cpm_ctx* ctx, const float* sorted_pos_power, const uint32
     if (rc) return rc;
     CPM_REQUIRE(ctx, n >= 0 && radius > 0.f, "cpm_gather: bad size or radius");
     CPM_REQUIRE(ctx, cell_start && grid_out && (sorted_pos_power || n == 0), "cpm_gather: null buffer");
+    CPM_REQUIRE_ALIGNED16(ctx, sorted_pos_power, "cpm_gather");
+    if (G.channels == 4) CPM_REQUIRE_ALIGNED16(ctx, grid_out, "cpm_gather");   // float4 stores
     const uint32_t cells = (uint32_t)G.dx * G.dy * G.dz;
     // cells whose photons can reach a voxel: |cell - voxel| <= floor(r * dim + 0.5) per axis,
     // with 1e-3 of slack for the fp32 rounding of the box / distance tests

@@ -324,6 +324,10 @@ int cpm_trace(cpm_ctx* ctx, const cpm_volume* vol, const cpm_tf* tf, const cpm_t
     int n_threads = recompute_indices ? n_recompute : p.n_light_samples;
     if (n_threads == 0) return CPM_OK;
     CPM_REQUIRE(ctx, light_samples8 && isect2 && rng_state && photons8, "cpm_trace: null buffer");
+    CPM_REQUIRE_ALIGNED16(ctx, light_samples8, "cpm_trace");
+    CPM_REQUIRE_ALIGNED16(ctx, photons8, "cpm_trace");
+    CPM_REQUIRE(ctx, ((reinterpret_cast<uintptr_t>(isect2) | reinterpret_cast<uintptr_t>(rng_state)) & 7u) == 0,
+                "cpm_trace: isect2 / rng_state must be 8-byte aligned");
     const cpm_volume_desc& d = vol->desc;
     CPM_REQUIRE(ctx, (unsigned long long)d.dims[0] * d.dims[1] * d.dims[2] < (1ull << 32), "cpm_trace: volume too large");
 

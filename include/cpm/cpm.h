@@ -23,6 +23,11 @@
  *     stride: (x, y, z, powerR, powerG, powerB, theta, phi)
  *     (ref progressivephotonmapping/photondata.h:47-56, cl/photon.cl:35,
  *      lightcl/cl/datastructures/lightsample.cl:75-101).
+ *   - float8 buffers, the compact (pos, power) records of cpm_bin and 4-channel
+ *     grids must be 16-byte aligned, (tStart, tEnd) pairs and RNG states
+ *     8-byte aligned (every allocator block is); misaligned pointers are
+ *     refused with CPM_ERR_INVALID_ARGUMENT.  u32 index / table buffers need
+ *     only their natural 4 bytes.
  *   - 4x4 matrices are 16 floats, column-major (OpenCL float16 as uploaded by
  *     Inviwo: element [4*col + row]).
  */

@@ -167,3 +167,41 @@ def test_trace_random_setups(ctx, oracle, cpm, seed):
                                               point=point, shading=shading, g=g, tfs=tfs, fmt=fmt)
     assert np.array_equal(bits(got), bits(want)), note
     assert np.array_equal(rng_g, rng_w), note
+
+
+def test_pointer_alignment_rules(ctx, oracle, cpm):
+    """include/cpm/cpm.h, conventions: float8 / record buffers must be 16-byte aligned (refused otherwise);
+    u32 tables need only 4 bytes -- the cell-start kernel's 16-byte fast path must not assume more."""
+    rng = np.random.default_rng(3)
+    dims, n = (20, 17, 9), 3000
+    ph = np.zeros((n, 8), np.float32)
+    ph[:, :3] = rng.random((n, 3), dtype=np.float32)
+    ph[:, 3:6] = rng.random((n, 3), dtype=np.float32)
+    g, og = cpm.binding.default_grid_desc(dims, 1), oracle.grid(dims, 1)
+    cells = dims[0] * dims[1] * dims[2]
+    torch = ctx.torch
+    o_order, o_cs, o_srt = oracle.bin(ph, n, og)
+    srt = torch.empty((n, 4), dtype=torch.float32, device=ctx.device)
+    for shift in (1, 2, 3):                                    # tables at 4, 8, 12 bytes past a 16-byte boundary
+        order = torch.empty(n + shift, dtype=torch.int32, device=ctx.device)[shift:]
+        cs = torch.empty(cells + 1 + shift, dtype=torch.int32, device=ctx.device)[shift:]
+        assert cs.data_ptr() % 16 == 4 * shift
+        ctx.bin(_t(ctx, ph), n, g, order, cs, srt)
+        assert np.array_equal(_n(order, np.uint32), o_order)
+        assert np.array_equal(_n(cs, np.uint32), o_cs)
+        out = torch.empty(cells + shift, dtype=torch.float32, device=ctx.device)[shift:]
+        radius = float(np.float32(0.9 / max(dims)))
+        ctx.gather(srt, cs, n, g, radius, 1.0, out)
+        want = np.zeros(cells, np.float32)
+        oracle.gather(o_srt, o_cs, n, og, radius, 1.0, want)
+        assert np.array_equal(bits(_n(out)), bits(want))
+    order = torch.empty(n, dtype=torch.int32, device=ctx.device)
+    cs = torch.empty(cells + 1, dtype=torch.int32, device=ctx.device)
+    flat = torch.zeros(n * 8 + 1, dtype=torch.float32, device=ctx.device)
+    with pytest.raises(cpm.binding.CpmError, match="16-byte aligned"):
+        ctx.bin(flat[1:].view(n, 8), n, g, order, cs, srt)     # photons 4 bytes off
+    rec = torch.zeros(n * 4 + 2, dtype=torch.float32, device=ctx.device)
+    with pytest.raises(cpm.binding.CpmError, match="16-byte aligned"):
+        ctx.bin(_t(ctx, ph), n, g, order, cs, rec[2:].view(n, 4))
+    with pytest.raises(cpm.binding.CpmError, match="16-byte aligned"):
+        ctx.gather(rec[2:].view(n, 4), cs, n, g, 0.05, 1.0, torch.empty(cells, dtype=torch.float32, device=ctx.device))
