@@ -32,7 +32,7 @@ ABI_SYMBOLS = [
     "cpm_light_sample_box_intersection", "cpm_light_sample_mesh_intersection",
     "cpm_trace",
     "cpm_grid_desc_default", "cpm_relative_irradiance_scale",
-    "cpm_splat", "cpm_splat_selected", "cpm_copy_indexed_photons",
+    "cpm_splat", "cpm_splat_selected", "cpm_copy_indexed_photons", "cpm_snapshot_selected_photons",
     "cpm_sort_pairs", "cpm_sort_keys", "cpm_bin", "cpm_gather", "cpm_mark_touched_bricks", "cpm_gather_bricks",
     "cpm_volume_minmax", "cpm_volume_difference", "cpm_importance_tf",
     "cpm_photon_importance", "cpm_photon_importance_equal", "cpm_reset_importance",
@@ -110,6 +110,7 @@ def load_library() -> C.CDLL:
         "cpm_splat": (i32, [vp, vp, i32, P(GridDesc), f32, f32, vp, vp]),
         "cpm_splat_selected": (i32, [vp, vp, vp, i32, P(GridDesc), f32, f32, f32, i32, i32, vp, vp]),
         "cpm_copy_indexed_photons": (i32, [vp, vp, vp, i32, f32, i32, i32, vp, i32, vp]),
+        "cpm_snapshot_selected_photons": (i32, [vp, vp, vp, i32, i32, i32, vp, vp]),
         "cpm_sort_pairs": (i32, [vp, vp, vp, sz, i32, vp]),
         "cpm_sort_keys": (i32, [vp, vp, sz, i32, vp]),
         "cpm_bin": (i32, [vp, vp, i32, P(GridDesc), vp, vp, vp, vp]),
@@ -349,6 +350,10 @@ class Context:
     def copy_indexed_photons(self, photons, indices, n_indices, multiplier, n_photons, n_interactions, aligned, out_offset=0):
         self._check(self.lib.cpm_copy_indexed_photons(self.h, self._ptr(photons), self._ptr(indices), n_indices, multiplier,
                                                       n_photons, n_interactions, self._ptr(aligned), out_offset, self._stream()))
+
+    def snapshot_selected_photons(self, photons, indices, n_indices, n_photons, n_interactions, snapshot):
+        self._check(self.lib.cpm_snapshot_selected_photons(self.h, self._ptr(photons), self._ptr(indices), n_indices, n_photons,
+                                                           n_interactions, self._ptr(snapshot), self._stream()))
 
     def sort_pairs(self, keys, values, key_bits=0):
         self._check(self.lib.cpm_sort_pairs(self.h, self._ptr(keys), self._ptr(values), keys.numel(), key_bits, self._stream()))

@@ -187,6 +187,7 @@ bool rows_are_16_byte_aligned(const BrickVol& V) {
     return ((size_t)V.dx * es) % 16 == 0;
 }
 int g_brick_streaming = 1;  // test hook: 0 = always the per-brick kernels
+int g_select_partition = 1;  // test hook: 0 = cpm_select_changed through a radix pass over a 1-bit flag
 
 CPM_DEV float4 mix4(float4 a, float4 b, float t) {
     return make_float4(a.x + (b.x - a.x) * t, a.y + (b.y - a.y) * t, a.z + (b.z - a.z) * t, a.w + (b.w - a.w) * t);
@@ -389,7 +390,77 @@ __global__ __launch_bounds__(256) void threshold_count_iota_kernel(const uint32_
     if ((threadIdx.x & 63) == 0 && m) atomicAdd(count, (int)__popcll(m));
 }
 
-// cpm_select_changed: flag = 0 for a photon whose importance says "re-trace" (key < 0x7fffffff), 1 otherwise; iota.
+// cpm_select_changed as a two-launch stable partition (default).  A tile = `per_tile` consecutive photons (a multiple of
+// 256; at most kPartMaxTiles tiles).  Launch 1 counts the changed photons of every tile.  In launch 2 every workgroup
+// sums the counts of the tiles before it itself (<= 1024 loads, no scan launch), then walks its tile 256 photons at
+// a time: a ballot gives each photon its rank among the changed / unchanged ones of its wave, the four wave totals go
+// through LDS, and the index is written behind everything that precedes it in its part.  Ascending in both parts,
+// no atomics, importances read twice (8 MB at 1 M photons), indices written once.
+constexpr int kPartMaxTiles = 1024;
+
+__global__ __launch_bounds__(256) void partition_count_kernel(const uint32_t* __restrict__ imp, uint32_t n, uint32_t per_tile,
+                                                              uint32_t* __restrict__ tile_count) {
+    __shared__ uint32_t wsum[4];
+    const uint32_t t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const uint32_t b0 = blockIdx.x * per_tile, b1 = min(b0 + per_tile, n);
+    uint32_t c = 0;
+    for (uint32_t i = b0 + t; i < b1; i += 256) c += imp[i] < 2147483647u ? 1u : 0u;
+    for (int off = 32; off > 0; off >>= 1) c += __shfl_down(c, off, 64);
+    if (lane == 0) wsum[wave] = c;
+    __syncthreads();
+    if (t == 0) tile_count[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+}
+
+__global__ __launch_bounds__(256) void partition_write_kernel(const uint32_t* __restrict__ imp, uint32_t n, uint32_t per_tile,
+                                                              const uint32_t* __restrict__ tile_count, uint32_t num_tiles,
+                                                              uint32_t* __restrict__ idx, int32_t* __restrict__ n_changed) {
+    __shared__ uint32_t red[2][4];
+    __shared__ uint32_t wcnt[2][4];
+    const uint32_t t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    // changed photons in the tiles before this one, and in all tiles
+    uint32_t before = 0, total = 0;
+    for (uint32_t i = t; i < num_tiles; i += 256) {
+        const uint32_t c = tile_count[i];
+        total += c;
+        before += i < blockIdx.x ? c : 0u;
+    }
+    for (int off = 32; off > 0; off >>= 1) { before += __shfl_down(before, off, 64); total += __shfl_down(total, off, 64); }
+    if (lane == 0) { red[0][wave] = before; red[1][wave] = total; }
+    __syncthreads();
+    before = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+    total = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+    if (blockIdx.x == 0 && t == 0) *n_changed = (int32_t)total;
+    const uint32_t b0 = blockIdx.x * per_tile, b1 = min(b0 + per_tile, n);
+    uint32_t out_c = before;                 // next free slot of the changed part
+    uint32_t out_u = total + (b0 - before);  // ... of the unchanged part: unchanged photons before this tile
+    const uint64_t lt_mask = (1ull << lane) - 1ull;
+    for (uint32_t base = b0; base < b1; base += 256) {
+        const uint32_t i = base + t;
+        const bool valid = i < b1;
+        const bool ch = valid && imp[i] < 2147483647u;
+        const uint64_t mc = __ballot(ch), mv = __ballot(valid);
+        const uint32_t wc = (uint32_t)__popcll(mc), wu = (uint32_t)__popcll(mv) - wc;
+        if (lane == 0) { wcnt[0][wave] = wc; wcnt[1][wave] = wu; }
+        __syncthreads();
+        uint32_t pc = 0, pu = 0, tc = 0, tu = 0;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const uint32_t c = wcnt[0][w], u = wcnt[1][w];
+            pc += w < (int)wave ? c : 0u; pu += w < (int)wave ? u : 0u;
+            tc += c; tu += u;
+        }
+        if (valid) {
+            const uint32_t rc = (uint32_t)__popcll(mc & lt_mask);
+            if (ch) idx[out_c + pc + rc] = i;
+            else idx[out_u + pu + (lane - rc - (uint32_t)__popcll(~mv & lt_mask))] = i;
+        }
+        out_c += tc; out_u += tu;
+        __syncthreads();  // wcnt is rewritten by the next chunk
+    }
+}
+
+// The radix-pass form of cpm_select_changed (cpm_debug_set_select_partition(0)): flag = 0 for a photon whose importance
+// says "re-trace" (key < 0x7fffffff), 1 otherwise; iota.
 // One stable radix pass over the flag then partitions the indices (changed first, both parts ascending) and its
 // digit total IS the count -- no atomics, no 31-bit sort.
 __global__ __launch_bounds__(256) void changed_flag_iota_kernel(const uint32_t* __restrict__ imp, size_t n,
@@ -422,6 +493,7 @@ extern "C" {
 
 // test hook (include/cpm/cpm_profile.h): 1 (default) = streaming brick-row kernels where rows are 16-byte aligned
 void cpm_debug_set_brick_streaming(int on) { g_brick_streaming = on; }
+void cpm_debug_set_select_partition(int on) { g_select_partition = on; }
 
 int cpm_volume_minmax(cpm_ctx* ctx, const cpm_volume* vol, int region, uint16_t* minmax2, cpm_stream stream) {
     CPM_ENTER(ctx);
@@ -570,6 +642,20 @@ int cpm_select_changed(cpm_ctx* ctx, const uint32_t* importances, size_t n, uint
     if (n == 1) {
         CPM_LAUNCH(ctx, select_single_kernel, dim3(1), dim3(1), 0, s, importances, indices_out, n_changed_dev);
         CPM_LAUNCH_CHECK(ctx, "select_single_kernel");
+        return CPM_OK;
+    }
+    if (g_select_partition) {
+        uint32_t num_tiles = (uint32_t)div_up((long long)n, 2048);
+        if (num_tiles > (uint32_t)kPartMaxTiles) num_tiles = kPartMaxTiles;
+        const uint32_t per_tile = (uint32_t)div_up(div_up((long long)n, num_tiles), 256) * 256u;
+        num_tiles = (uint32_t)div_up((long long)n, per_tile);
+        uint32_t* counts = (uint32_t*)scratch(ctx, CPM_SCR_MISC, kPartMaxTiles * sizeof(uint32_t));
+        if (!counts) return CPM_ERR_OUT_OF_MEMORY;
+        CPM_LAUNCH(ctx, partition_count_kernel, dim3(num_tiles), dim3(256), 0, s, importances, (uint32_t)n, per_tile, counts);
+        CPM_LAUNCH_CHECK(ctx, "partition_count_kernel");
+        CPM_LAUNCH(ctx, partition_write_kernel, dim3(num_tiles), dim3(256), 0, s, importances, (uint32_t)n, per_tile, counts, num_tiles,
+                   indices_out, n_changed_dev);
+        CPM_LAUNCH_CHECK(ctx, "partition_write_kernel");
         return CPM_OK;
     }
     uint32_t* flags = (uint32_t*)scratch(ctx, CPM_SCR_MISC, n * sizeof(uint32_t));

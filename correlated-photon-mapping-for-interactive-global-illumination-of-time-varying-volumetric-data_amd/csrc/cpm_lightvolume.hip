@@ -121,6 +121,22 @@ __global__ __launch_bounds__(256) void copy_indexed_kernel(const float* __restri
     }
 }
 
+// previous-photon snapshot refresh: only the re-traced photons move (two 16-byte accesses each way)
+__global__ __launch_bounds__(256) void snapshot_selected_kernel(const float* __restrict__ photons, const uint32_t* __restrict__ indices,
+                                                                int n_indices, int n_photons, int n_interactions,
+                                                                float* __restrict__ snapshot) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n_indices * n_interactions) return;
+    const uint32_t idx = indices[j % n_indices];
+    if (idx >= (uint32_t)n_photons) return;
+    const size_t id = (size_t)idx + (size_t)(j / n_indices) * (size_t)n_photons;
+    const float4* q = reinterpret_cast<const float4*>(photons) + 2 * id;
+    float4* o = reinterpret_cast<float4*>(snapshot) + 2 * id;
+    const float4 a = q[0], b = q[1];
+    o[0] = a;
+    o[1] = b;
+}
+
 // ---- bin
 
 // cell key (template: cl/hashlightsample.cl:55-64); sentinels get key == cells so that the
@@ -1110,6 +1126,22 @@ int cpm_copy_indexed_photons(cpm_ctx* ctx, const float* photons8, const uint32_t
     CPM_LAUNCH(ctx, copy_indexed_kernel, dim3(div_up(n_indices, 256)), dim3(256), 0, (hipStream_t)stream, photons8,
                        indices, n_indices, multiplier, n_photons, n_interactions, aligned8, out_offset);
     CPM_LAUNCH_CHECK(ctx, "copy_indexed_kernel");
+    return CPM_OK;
+}
+
+int cpm_snapshot_selected_photons(cpm_ctx* ctx, const float* photons8, const uint32_t* indices, int n_indices, int n_photons,
+                                  int n_interactions, float* snapshot8, cpm_stream stream) {
+    CPM_ENTER(ctx);
+    CPM_REQUIRE(ctx, n_indices >= 0 && n_photons >= 0 && n_interactions >= 1, "cpm_snapshot_selected_photons: bad sizes");
+    CPM_REQUIRE(ctx, (long long)n_indices * n_interactions < (1ll << 31), "cpm_snapshot_selected_photons: too many photons");
+    if (n_indices == 0) return CPM_OK;
+    CPM_REQUIRE(ctx, photons8 && indices && snapshot8, "cpm_snapshot_selected_photons: null buffer");
+    CPM_REQUIRE_ALIGNED16(ctx, photons8, "cpm_snapshot_selected_photons");
+    CPM_REQUIRE_ALIGNED16(ctx, snapshot8, "cpm_snapshot_selected_photons");
+    const int threads = n_indices * n_interactions;
+    CPM_LAUNCH(ctx, snapshot_selected_kernel, dim3((unsigned)div_up(threads, 256)), dim3(256), 0, (hipStream_t)stream, photons8, indices,
+               n_indices, n_photons, n_interactions, snapshot8);
+    CPM_LAUNCH_CHECK(ctx, "snapshot_selected_kernel");
     return CPM_OK;
 }
 

@@ -743,7 +743,9 @@ void PhotonToLightVolumeProcessorCL::process() {  // photontolightvolumeprocesso
     const int maxRecomputationPhotons = (int)((float)nPhotons * (incrementalRecomputationThreshold_.get() / 100.f));
     const bool haveIdx = recomputedPhotonIndicesPort_.isReady();
     const int nRecomputed = haveIdx ? recomputedPhotonIndicesPort_.getData()->nRecomputedPhotons : -1;
+    bool partialUpdate = false;  // this evaluation only touched the re-traced photons
     if (!fresh && haveIdx && prevPhotons_.getSize() == photonData->photons_.getSize() && nRecomputed > 0 && nRecomputed < maxRecomputationPhotons) {
+        partialUpdate = true;
         const unsigned int* idx = recomputedPhotonIndicesPort_.getData()->indicesToRecomputedPhotons.device();
         if (exactIncrementalUpdate_.get() && formulation_.get() != "splat") {
             // exact add-remove: mark the bricks an old or new position touches, re-bin, re-gather those bricks only
@@ -782,8 +784,15 @@ void PhotonToLightVolumeProcessorCL::process() {  // photontolightvolumeprocesso
         lastPath_ = "unchanged";
     }
     if (haveIdx && nRecomputed != 0) {  // snapshot for the next add-remove (:343-352)
-        if (prevPhotons_.getSize() != photonData->photons_.getSize()) prevPhotons_.setSize(photonData->photons_.getSize());
-        (void)hipMemcpyAsync(prevPhotons_.device(), photonData->photons_.device(), photonData->photons_.getSizeInBytes(), hipMemcpyDeviceToDevice, rt.stream());
+        if (partialUpdate) {  // only the re-traced photons differ from the snapshot: move those (the reference copies everything)
+            const unsigned int* idx = recomputedPhotonIndicesPort_.getData()->indicesToRecomputedPhotons.device();
+            rt.check(cpm_snapshot_selected_photons(rt.ctx(), photons, idx, nRecomputed, nPhotons, nInter,
+                                                   reinterpret_cast<float*>(prevPhotons_.device()), rt.stream()),
+                     "cpm_snapshot_selected_photons");
+        } else {
+            if (prevPhotons_.getSize() != photonData->photons_.getSize()) prevPhotons_.setSize(photonData->photons_.getSize());
+            (void)hipMemcpyAsync(prevPhotons_.device(), photonData->photons_.device(), photonData->photons_.getSizeInBytes(), hipMemcpyDeviceToDevice, rt.stream());
+        }
     }
     outport_.setData(lightVolume_);
 }

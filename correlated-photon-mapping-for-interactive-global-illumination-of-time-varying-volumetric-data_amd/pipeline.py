@@ -511,4 +511,9 @@ class CorrelatedPhotonMapper(PhotonFrame):
             self.bin()
             self.gather()
             self.last_path = "full"
-        self.prev_photons = self.photons.clone()             # async snapshot in the reference (:343-352)
+        # snapshot for the next add-remove (a whole-buffer copy in the reference, :343-352): after a partial re-trace
+        # only the re-traced photons differ from the snapshot, so only they move
+        if self.last_path == "full" or self.prev_photons is None:
+            self.prev_photons = self.photons.clone()
+        else:
+            ctx.snapshot_selected_photons(self.photons, idx, n, self.n, self.I, self.prev_photons)

@@ -246,6 +246,13 @@ int cpm_copy_indexed_photons(cpm_ctx* ctx, const float* photons8, const uint32_t
                              int n_indices, float multiplier, int n_photons, int n_interactions,
                              float* aligned8, int out_offset, cpm_stream stream);
 
+/* snapshot[id] = photons[id] for id = indices[j] + k*n_photons, k < n_interactions: refreshes the
+ * previous-photons snapshot after a partial re-trace by moving only what changed.  The reference copies the
+ * whole buffer every time (ref processor/photontolightvolumeprocessorcl.cpp:343-352: 64 MiB of traffic for
+ * a 1 M photon frame of which 0.5 % changed); same result when snapshot held the photons before the re-trace. */
+int cpm_snapshot_selected_photons(cpm_ctx* ctx, const float* photons8, const uint32_t* indices, int n_indices,
+                                  int n_photons, int n_interactions, float* snapshot8, cpm_stream stream);
+
 /* ---- MI355X formulation: sort/bin + per-cell gather (S6, G1-G3 restated) */
 
 /* Stable LSD radix sort of (key, value) pairs / keys, ascending, `key_bits`

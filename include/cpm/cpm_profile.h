@@ -30,6 +30,8 @@ void cpm_debug_force_voxel_gather(int on);
 void cpm_debug_set_gather_coop(int on);
 /* cpm_volume_minmax / cpm_volume_difference: 1 (default) = streaming brick-row kernels, 0 = one wave per brick */
 void cpm_debug_set_brick_streaming(int on);
+/* cpm_select_changed: 1 (default) = two-launch stable partition, 0 = one radix pass over a 1-bit flag */
+void cpm_debug_set_select_partition(int on);
 /* cpm_bin: 1 (default) = the last radix pass writes order / records / run starts itself, 0 = separate finalize launch */
 void cpm_debug_set_bin_fused(int on);
 /* test hook: radix sort pass structure: 0 = hist + rowscan + scatter (default), 1 = onesweep (one launch per pass) */

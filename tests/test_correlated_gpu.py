@@ -286,9 +286,20 @@ def test_sharded_correlated_update(ctx, cpm):
     assert np.abs(lv2 - lv).max() > 0
 
 
-@pytest.mark.parametrize("n,frac", [(1, 1.0), (1, 0.0), (2, 0.5), (1000, 0.0), (1000, 1.0), (70_001, 0.013), (300_000, 0.4)])
-def test_select_changed(ctx, oracle, n, frac):
-    """cpm_select_changed: changed photons first, both parts in ascending index order, the importances untouched."""
+@pytest.mark.parametrize("partition", [1, 0])
+@pytest.mark.parametrize("n,frac", [(1, 1.0), (1, 0.0), (2, 0.5), (255, 0.3), (256, 0.5), (257, 0.9), (1000, 0.0), (1000, 1.0), (2048, 0.5),
+                                    (2049, 0.01), (70_001, 0.013), (300_000, 0.4), (2_500_003, 0.07)])
+def test_select_changed(ctx, oracle, n, frac, partition):
+    """cpm_select_changed: changed photons first, both parts in ascending index order, the importances untouched --
+    through the two-launch partition (default; tiles grow past 2048 photons beyond 1024 tiles) and the radix-pass form."""
+    ctx.lib.cpm_debug_set_select_partition(partition)
+    try:
+        _select_changed_case(ctx, oracle, n, frac)
+    finally:
+        ctx.lib.cpm_debug_set_select_partition(1)
+
+
+def _select_changed_case(ctx, oracle, n, frac):
     rng = np.random.default_rng(n)
     imp = np.full(n, 2147483647, np.uint32)
     pick = rng.random(n) < frac

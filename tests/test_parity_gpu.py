@@ -550,6 +550,17 @@ def test_splat_selected_and_copy_indexed(ctx, oracle, cpm):
     wa = np.zeros((idx.size * I + 5, 8), np.float32)
     oracle.copy_indexed_photons(ph, idx, -1.0, n, I, wa, 5)
     assert np.array_equal(bits(_n(al)), bits(wa))
+    # snapshot refresh: only the selected photons (every interaction) move; out-of-range indices are ignored
+    snap = rng.random((n * I, 8), dtype=np.float32)
+    snap_d = _t(ctx, snap)
+    idx_bad = np.concatenate([idx, np.array([n, n + 7, 0xffffffff], np.uint32)])
+    ctx.snapshot_selected_photons(_t(ctx, ph), _t(ctx, idx_bad), idx_bad.size, n, I, snap_d)
+    want = snap.copy()
+    for k in range(I):
+        want[idx.astype(np.int64) + k * n] = ph[idx.astype(np.int64) + k * n]
+    assert np.array_equal(bits(_n(snap_d)), bits(want))
+    ctx.snapshot_selected_photons(_t(ctx, ph), _t(ctx, idx), 0, n, I, snap_d)      # nothing selected: no-op
+    assert np.array_equal(bits(_n(snap_d)), bits(want))
 
 
 # ----------------------------------------------------------------------------- end to end
