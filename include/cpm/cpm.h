@@ -18,7 +18,10 @@
  *   - A context is bound to one device and is not thread-safe (Inviwo
  *     evaluates process() on one thread: ref processor/progressivephotontracercl.cpp:219).
  *   - Scratch memory is owned by the context, grows on demand and is reused;
- *     no allocation happens in steady state.
+ *     no allocation happens in steady state.  Calls on ONE context must
+ *     therefore be ordered with respect to each other (one stream, or streams
+ *     the caller chains with events): for frames in flight on several
+ *     streams use one context per stream (bench.py's `pipelined` figure does).
  *   - float8 photons / light samples are 8 consecutive floats, 32-byte
  *     stride: (x, y, z, powerR, powerG, powerB, theta, phi)
  *     (ref progressivephotonmapping/photondata.h:47-56, cl/photon.cl:35,
