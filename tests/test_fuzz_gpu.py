@@ -35,6 +35,8 @@ def _case(seed):
     channels = int(pick(1, 1, 4))
     radius_vox = float(pick(0.05, 0.3, 0.7, 0.866, 0.999, 1.0, 1.2, 1.4999, 1.5, 1.7320508, 1.99, 2.0, 2.4, 3.1))
     n = int(pick(1, 2, 63, 64, 65, 255, 2047, 2048, 2049, 4100, 9000, 30000))
+    if pick(0, 0, 0, 0, 0, 1):                                    # now and then a radius of many cells (voxel-major kernel)
+        radius_vox, n = float(pick(6.0, 17.0, 40.0)), min(n, 2049)
     layout = pick("uniform", "uniform", "overspill", "one_cell", "faces", "all_missed")
     ph = np.zeros((n, 8), np.float32)
     if layout == "uniform":
