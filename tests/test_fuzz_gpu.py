@@ -207,3 +207,94 @@ def test_pointer_alignment_rules(ctx, oracle, cpm):
         ctx.bin(_t(ctx, ph), n, g, order, cs, rec[2:].view(n, 4))
     with pytest.raises(cpm.binding.CpmError, match="16-byte aligned"):
         ctx.gather(rec[2:].view(n, 4), cs, n, g, 0.05, 1.0, torch.empty(cells, dtype=torch.float32, device=ctx.device))
+
+
+@pytest.mark.parametrize("seed", range(16 * MORE))
+def test_brick_analysis_random_shapes(ctx, oracle, seed):
+    """min/max bricks, mean-abs-difference bricks and the TF importance over random volume shapes (rows that are and
+    are not 16-byte multiples, bricks cut by every face), voxel types and brick sizes."""
+    rng = np.random.default_rng(8000 + seed)
+    pick = lambda *xs: xs[int(rng.integers(len(xs)))]
+    dtype = pick(np.uint8, np.uint8, np.uint16, np.float32)
+    shape = tuple(int(x) for x in rng.integers(2, 70, 3))             # [z, y, x]
+    if pick(0, 1):
+        shape = shape[:2] + (int(pick(16, 32, 48, 64, 80)),)            # rows the streaming kernels take
+    region = int(pick(1, 2, 3, 4, 5, 8, 8, 16, 64))
+    if dtype == np.float32:
+        a, b = rng.random(shape, dtype=np.float32), rng.random(shape, dtype=np.float32)
+    else:
+        hi = np.iinfo(dtype).max + 1
+        a, b = rng.integers(0, hi, shape).astype(dtype), rng.integers(0, hi, shape).astype(dtype)
+    if pick(0, 1):
+        b = a.copy()                                                  # nothing changed between the time steps
+    note = f"seed {seed}: {shape} {np.dtype(dtype).name} region {region}"
+    va, vb = ctx.volume_create(a), ctx.volume_create(b)
+    oa, ob = oracle.volume(a), oracle.volume(b)
+    nb = int(np.prod([(d + region - 1) // region for d in shape]))
+    mm = ctx.torch.zeros((nb, 2), dtype=ctx.torch.int16, device=ctx.device)
+    ctx.volume_minmax(va, region, mm)
+    want_mm = oracle.volume_minmax(oa, region)
+    assert np.array_equal(_n(mm, np.uint16), want_mm), note
+    diff = ctx.torch.zeros(nb, dtype=ctx.torch.float32, device=ctx.device)
+    ctx.volume_difference(va, vb, region, diff)
+    want_diff = oracle.volume_difference(oa, ob, region)
+    assert np.array_equal(bits(_n(diff)), bits(want_diff)), note
+    # TF importance of those bricks: random |TF_new - TF_old| break points, zero-padded at 0 and 1
+    k = int(rng.integers(1, 9))
+    pos = np.concatenate([[0.0], np.sort(rng.random(k)), [1.0]]).astype(np.float32)
+    col = np.concatenate([np.zeros((1, 4)), rng.random((k, 4)) * (rng.random((k, 1)) < 0.7), np.zeros((1, 4))]).astype(np.float32)
+    out = ctx.torch.zeros(nb, dtype=ctx.torch.float32, device=ctx.device)
+    ctx.importance_tf(mm, nb, pos, col, out)
+    assert np.array_equal(bits(_n(out)), bits(oracle.importance_tf(want_mm, pos, col))), note
+    mm2 = ctx.torch.zeros((nb, 2), dtype=ctx.torch.int16, device=ctx.device)
+    ctx.volume_minmax(vb, region, mm2)
+    ctx.importance_tf(mm2, nb, pos, col, out, prev_minmax=mm, volume_diff=diff)
+    want = oracle.importance_tf(_n(mm2, np.uint16), pos, col, prev=want_mm, diff=want_diff)
+    assert np.array_equal(bits(_n(out)), bits(want)), note
+
+
+@pytest.mark.parametrize("seed", range(16 * MORE))
+def test_photon_importance_random_segments(ctx, oracle, cpm, seed):
+    """The importance DDA over random grids (shape, cell size), random light samples (hits, misses, grazing and
+    axis-parallel rays) and random stored photons (interior points, sentinels, multiple interactions)."""
+    from oracle_binding import default_matrices
+    rng = np.random.default_rng(9000 + seed)
+    pick = lambda *xs: xs[int(rng.integers(len(xs)))]
+    S = cpm.synthetic
+    region = int(pick(1, 2, 4, 8, 8, 16))
+    gd = tuple(int(x) for x in rng.integers(1, 20, 3))                # importance cells per axis
+    vdims = tuple(g * region - int(pick(0, 0, region - 1)) for g in gd)
+    vdims = tuple(max(v, 2) for v in vdims)
+    gd = tuple((v + region - 1) // region for v in vdims)
+    n, I = int(pick(1, 63, 64, 1000, 5000)), int(pick(1, 1, 2, 4))
+    ls = np.zeros((n, 8), np.float32)
+    ls[:, :3] = rng.uniform(-1.0, 2.0, (n, 3)).astype(np.float32)
+    ls[:, 3:6] = 1
+    ls[:, 6] = rng.uniform(0, np.pi, n).astype(np.float32)
+    ls[:, 7] = rng.uniform(-np.pi, np.pi, n).astype(np.float32)
+    ax = rng.random(n) < 0.15                                         # axis-parallel directions
+    ls[ax, 6] = rng.choice(np.array([0.0, np.pi / 2, np.pi], np.float32), int(ax.sum()))
+    ls[ax, 7] = rng.choice(np.array([0.0, np.pi / 2, -np.pi / 2, np.pi], np.float32), int(ax.sum()))
+    isect = oracle.light_sample_box_intersection(ls, S.UNIT_CUBE_AABB)
+    ph = np.zeros((n * I, 8), np.float32)
+    ph[:, :3] = rng.random((n * I, 3), dtype=np.float32)
+    ph[:, 3:6] = rng.random((n * I, 3), dtype=np.float32)
+    ph[:, 6] = rng.uniform(0, np.pi, n * I).astype(np.float32)
+    ph[:, 7] = rng.uniform(-np.pi, np.pi, n * I).astype(np.float32)
+    gone = rng.random(n * I) < 0.3
+    ph[gone, :3] = F32_MAX
+    dead = gone & (rng.random(n * I) < 0.5)
+    ph[dead, 3] = F32_MAX                                             # absorbed: power.x == FLT_MAX
+    grid = rng.random(gd[0] * gd[1] * gd[2], dtype=np.float32) * np.float32(pick(1.0, 1e-3, 50.0))
+    grid[rng.random(grid.size) < 0.4] = 0
+    t2i, _ = default_matrices(vdims)
+    fix = bool(pick(0, 1))
+    off = int(pick(0, 0, 3)) if n > 8 else 0
+    imp0 = np.full(n + 4, 2147483647, np.uint32)
+    imp0[::7] = 2147483000                                            # already carrying importance from an earlier edit
+    imp_o = imp0.copy()
+    oracle.photon_importance(grid, gd, (region,) * 3, t2i, ph, off, ls, isect, n - off, I, n, imp_o, fix_exit_point=fix)
+    imp_d = _t(ctx, imp0)
+    ctx.photon_importance(_t(ctx, grid), gd, (float(region),) * 3, t2i.tolist(), _t(ctx, ph), off, _t(ctx, ls), _t(ctx, isect),
+                          n - off, I, n, imp_d, fix_exit_point=fix)
+    assert np.array_equal(_n(imp_d, np.uint32), imp_o), f"seed {seed}: grid {gd} region {region} vol {vdims} n={n} I={I} fix={fix} off={off}"
