@@ -983,7 +983,7 @@ __global__ __launch_bounds__(64 * NB) void gather_coop_kernel(const float* __res
         uint32_t j;
         if (total <= (uint32_t)MAXWORDS * 64u) {
             const unsigned long long sb = s_start_all[b][w];
-            const int kk = max((int)s_rb_all[b][w] + __popcll(sb & ((2ull << lane) - 1ull)) - 1, 0);
+            const int kk = max((int)s_rb_all[b][w] + (int)__popcll(sb & ((2ull << lane) - 1ull)) - 1, 0);  // (int): unsigned + int picks max(double, double)
             j = s_rowjb_all[b][kk] + i;
         } else {
             int lo = 0, hi = (int)s_nne[b] - 1;
