@@ -371,7 +371,8 @@ int cpm_select_recompute(cpm_ctx* ctx, uint32_t* importances, size_t n, uint32_t
  * importance ORDER is irrelevant -- the tracer re-sorts the batch by index anyway
  * (ref processor/progressivephotontracercl.cpp:467-473) -- so the caller can use this instead of
  * cpm_select_recompute's 31-bit sort and fall back to it only when n_changed exceeds the budget:
- * one stable radix pass over a 1-bit flag, the count is that pass's digit total (no atomics).
+ * a two-launch stable partition (per-tile counts, then ballot ranks behind the counts of the earlier
+ * tiles; no atomics), the count is the sum of the tile counts.
  * Replaces thresholdKernel + clogs::Reduce + indexToBufferKernel
  * (ref cl/threshold.cl:33-40, cl/indextobuffer.cl:33-40, ...tracercl.cpp:325-356). */
 int cpm_select_changed(cpm_ctx* ctx, const uint32_t* importances, size_t n, uint32_t* indices_out,
