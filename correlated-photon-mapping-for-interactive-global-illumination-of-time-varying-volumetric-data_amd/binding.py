@@ -34,6 +34,7 @@ ABI_SYMBOLS = [
     "cpm_grid_desc_default", "cpm_relative_irradiance_scale",
     "cpm_splat", "cpm_splat_selected", "cpm_copy_indexed_photons", "cpm_snapshot_selected_photons",
     "cpm_sort_pairs", "cpm_sort_keys", "cpm_bin", "cpm_gather", "cpm_mark_touched_bricks", "cpm_gather_bricks",
+    "cpm_fast_table_entries", "cpm_gather_fast_supported", "cpm_bin_fast", "cpm_gather_fast",
     "cpm_volume_minmax", "cpm_volume_difference", "cpm_importance_tf",
     "cpm_photon_importance", "cpm_photon_importance_equal", "cpm_reset_importance",
     "cpm_select_recompute", "cpm_select_changed",
@@ -117,6 +118,10 @@ def load_library() -> C.CDLL:
         "cpm_gather": (i32, [vp, vp, vp, i32, P(GridDesc), f32, f32, i32, vp, vp]),
         "cpm_mark_touched_bricks": (i32, [vp, vp, vp, i32, i32, i32, P(GridDesc), f32, vp, vp]),
         "cpm_gather_bricks": (i32, [vp, vp, vp, i32, P(GridDesc), f32, f32, vp, vp, vp]),
+        "cpm_fast_table_entries": (sz, [P(GridDesc), i32]),
+        "cpm_gather_fast_supported": (i32, [P(GridDesc), f32]),
+        "cpm_bin_fast": (i32, [vp, vp, i32, P(GridDesc), vp, vp, vp]),
+        "cpm_gather_fast": (i32, [vp, vp, vp, i32, P(GridDesc), f32, f32, i32, vp, vp]),
         "cpm_volume_minmax": (i32, [vp, vp, i32, vp, vp]),
         "cpm_volume_difference": (i32, [vp, vp, vp, i32, vp, vp]),
         "cpm_importance_tf": (i32, [vp, vp, vp, vp, i32, vp, vp, i32, vp, vp]),
@@ -368,6 +373,20 @@ class Context:
     def gather(self, sorted_pos_power, cell_start, n, grid, radius, scale, out, accumulate=False):
         self._check(self.lib.cpm_gather(self.h, self._ptr(sorted_pos_power), self._ptr(cell_start), n, C.byref(grid), radius,
                                         scale, int(accumulate), self._ptr(out), self._stream()))
+
+    def fast_table_entries(self, grid: GridDesc, n: int) -> int:
+        return int(self.lib.cpm_fast_table_entries(C.byref(grid), n))
+
+    def gather_fast_supported(self, grid: GridDesc, radius: float) -> bool:
+        return bool(self.lib.cpm_gather_fast_supported(C.byref(grid), radius))
+
+    def bin_fast(self, photons, n, grid: GridDesc, brick_table, sorted_pos_power):
+        self._check(self.lib.cpm_bin_fast(self.h, self._ptr(photons), n, C.byref(grid), self._ptr(brick_table),
+                                          self._ptr(sorted_pos_power), self._stream()))
+
+    def gather_fast(self, sorted_pos_power, brick_table, n, grid, radius, scale, out, accumulate=False):
+        self._check(self.lib.cpm_gather_fast(self.h, self._ptr(sorted_pos_power), self._ptr(brick_table), n, C.byref(grid), radius,
+                                             scale, int(accumulate), self._ptr(out), self._stream()))
 
     def mark_touched_bricks(self, photons, indices, n_indices, n_photons, n_interactions, grid, radius, brick_mask):
         self._check(self.lib.cpm_mark_touched_bricks(self.h, self._ptr(photons), self._ptr(indices), n_indices, n_photons,

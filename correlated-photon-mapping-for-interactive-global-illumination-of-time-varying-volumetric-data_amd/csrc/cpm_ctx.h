@@ -27,6 +27,7 @@ struct cpm_ctx {
     // grow-only scratch arenas (no allocation in steady state)
     void* scratch[8] = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };
     size_t scratch_bytes[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+    size_t fast_hist_words = 0;  // cpm_bin_fast: size of the histogram whose all-zero state is established (0 = none)
 };
 
 // scratch slots
@@ -36,7 +37,9 @@ enum {
     CPM_SCR_SORT_HIST = 2,   // per-tile digit histograms
     CPM_SCR_BIN_KEYS = 3,    // cell keys of cpm_bin
     CPM_SCR_SMALL = 4,       // TF points etc.
-    CPM_SCR_MISC = 5
+    CPM_SCR_MISC = 5,
+    CPM_SCR_FAST_BIN = 6,    // cpm_bin_fast: brick histogram (kept zero between calls) + per-photon ranks
+    CPM_SCR_FAST_SLABS = 7   // cpm_gather_fast: one fixed-point tile per work item
 };
 
 struct cpm_volume {

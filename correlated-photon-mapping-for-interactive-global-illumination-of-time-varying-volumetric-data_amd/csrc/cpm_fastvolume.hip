@@ -1,0 +1,517 @@
+// cpm_fastvolume.hip -- photons -> light volume, the MI355X formulation in TOLERANCE MODE
+// (cpm_bin_fast + cpm_gather_fast; include/cpm/cpm.h "fast formulation").
+//
+// What it computes: for every voxel the sum over photons of  power * k * 0.75 * (1 - d^2 / r^2)  for d <= r --
+// the terms splatPhoton adds (ref progressivephotonmapping/cl/photonstolightvolume.cl:31-79, kernel
+// cl/densityestimationkernel.cl:43-60) with the weight taken from d^2 directly (no sqrt, no division: the
+// reference's own sum order is undefined -- CAS float atomics, :15-29 -- so only a tolerance is defined anyway).
+// The bit-exact per-voxel sequential contract stays in cpm_bin / cpm_gather (cpm_lightvolume.hip).
+//
+// How (five short streaming launches instead of eleven latency chains):
+//   bin   fast_count_kernel    photon -> brick key (bricks of 8x8x8 voxels, wider along x for big grids: <= 16 Ki
+//                              bricks), per-workgroup histogram in LDS (ds_add_rtn_u32 = the photon's rank inside its
+//                              (workgroup, brick) run), one returning global atomic per NON-EMPTY (workgroup, brick)
+//                              pair = that run's offset inside the brick; max |power| on the way
+//         fast_scan_kernel     one workgroup: brick starts, and the list of work items = (brick, chunk of <= 4096
+//                              photons): a face brick with 8000 photons becomes 2 items, an empty brick none
+//         fast_scatter_kernel  compact 16-byte (pos, power) records to brick_start[key] + rank
+//   gather fast_tile_kernel    one workgroup per item: lanes own records, the brick's voxels (+ halo) are an LDS tile of
+//                              64-bit FIXED-POINT sums (ds_add_u64): integer addition is associative, so the result does
+//                              not depend on the order lanes, waves or items add in -- bitwise reproducible with no
+//                              ordering protocol at all.  The tile is stored to the item's slab with plain stores
+//         fast_combine_kernel  per voxel: the integer sum of the <= 8 slabs that cover it (own brick + neighbours'
+//                              halos, every chunk), ONE rounding to float, plain coalesced store of the light volume
+// No global float atomics, no sort passes, no per-voxel ordering: every launch streams its bytes once.
+#include "cpm_ctx.h"
+
+using namespace cpm;
+
+namespace {
+
+constexpr int kTileThreads = 1024;
+constexpr int kFastChunk = 4096;   // photons per tile-gather work item (1024 threads x 4)
+constexpr int kCountItems = 4;     // photons per thread of fast_count_kernel (1024 threads)
+constexpr int kCountTile = 1024 * kCountItems;
+constexpr int kMaxBricks = 16384;  // LDS histogram of fast_count_kernel: 64 KiB
+
+// table layout (u32 entries): [0, nb] brick starts | 4 meta | [nb+5, 2nb+5] item starts | items
+constexpr int kMetaMaxPow = 0, kMetaItems = 1;
+
+struct BrickLayout {
+    int lx, ly, lz;        // log2 brick size (voxels)
+    int nbx, nby, nbz, nb; // bricks
+    int hx, hy, hz;        // halo (voxels a photon of the brick can reach beyond it)
+    int tx, ty, tz, tile;  // tile = brick + halo; voxels per tile
+    int maxc;              // candidate voxels per axis
+};
+CPM_DEV uint32_t off_meta(const BrickLayout& L) { return (uint32_t)L.nb + 1u; }
+CPM_DEV uint32_t off_item_start(const BrickLayout& L) { return (uint32_t)L.nb + 5u; }
+CPM_DEV uint32_t off_items(const BrickLayout& L) { return 2u * (uint32_t)L.nb + 6u; }
+
+__host__ int make_grid_dev_fast(cpm_ctx* ctx, const cpm_grid_desc* g, GridDev& G) {
+    if (!g) return set_error(ctx, CPM_ERR_INVALID_ARGUMENT, "grid", "null grid desc");
+    if (g->dims[0] < 1 || g->dims[1] < 1 || g->dims[2] < 1) return set_error(ctx, CPM_ERR_INVALID_ARGUMENT, "grid", "dims < 1");
+    if ((unsigned long long)g->dims[0] * g->dims[1] * g->dims[2] >= (1ull << 31))
+        return set_error(ctx, CPM_ERR_INVALID_ARGUMENT, "grid", "more than 2^31 cells");
+    if (g->channels != 1 && g->channels != 4) return set_error(ctx, CPM_ERR_INVALID_ARGUMENT, "grid", "channels must be 1 or 4");
+    G.dx = g->dims[0]; G.dy = g->dims[1]; G.dz = g->dims[2]; G.channels = g->channels;
+    if (!affine_from_matrix(g->texture_to_index, G.t2i) || !affine_from_matrix(g->index_to_texture, G.i2t))
+        return set_error(ctx, CPM_ERR_UNSUPPORTED, "grid", "texture/index matrices must be scale + translate");
+    if (!(G.t2i.sx > 0.f && G.t2i.sy > 0.f && G.t2i.sz > 0.f))
+        return set_error(ctx, CPM_ERR_UNSUPPORTED, "grid", "fast formulation needs positive texture-to-index scales");
+    return CPM_OK;
+}
+
+// brick shape from the grid alone: 8 x 8 x 8 voxels, doubled along x, y, z in turn while there are more than 16 Ki bricks
+__host__ void brick_shape(const int dims[3], BrickLayout& L) {
+    int lg[3] = { 3, 3, 3 };
+    auto count = [&](int a) { return (dims[a] + (1 << lg[a]) - 1) >> lg[a]; };
+    int axis = 0;
+    while ((long long)count(0) * count(1) * count(2) > kMaxBricks) { ++lg[axis]; axis = (axis + 1) % 3; }
+    L.lx = lg[0]; L.ly = lg[1]; L.lz = lg[2];
+    L.nbx = count(0); L.nby = count(1); L.nbz = count(2);
+    L.nb = L.nbx * L.nby * L.nbz;
+    L.hx = L.hy = L.hz = 0; L.tx = L.ty = L.tz = L.tile = 0; L.maxc = 0;
+}
+
+// halo / tile / candidates from the radius (gather side); false when the tuned kernels do not cover it
+__host__ bool brick_reach(const GridDev& G, float radius, BrickLayout& L) {
+    const float rx = radius * G.t2i.sx, ry = radius * G.t2i.sy, rz = radius * G.t2i.sz;  // radius in voxels per axis
+    L.hx = (int)floorf(rx + 0.501f); L.hy = (int)floorf(ry + 0.501f); L.hz = (int)floorf(rz + 0.501f);
+    const float rmax = fmaxf(rx, fmaxf(ry, rz)) + 1e-3f;
+    L.maxc = (int)floorf(2.f * rmax) + 1;
+    L.tx = (1 << L.lx) + 2 * L.hx; L.ty = (1 << L.ly) + 2 * L.hy; L.tz = (1 << L.lz) + 2 * L.hz;
+    L.tile = L.tx * L.ty * L.tz;
+    if (!(radius > 0.f) || L.maxc > 4) return false;
+    if (2 * L.hx > (1 << L.lx) || 2 * L.hy > (1 << L.ly) || 2 * L.hz > (1 << L.lz)) return false;
+    return true;
+}
+
+__host__ size_t table_entries(const BrickLayout& L, int n) {
+    return 2 * (size_t)L.nb + 6 + (size_t)L.nb + (size_t)div_up(n > 0 ? n : 1, kFastChunk);
+}
+__host__ int ceil_log2(long long n) { int b = 1; while (b < 62 && (1ll << b) < n) ++b; return b; }
+
+// the photon's cell (the voxel whose centre is nearest: floor(index + 0.5), clamped) and brick
+CPM_DEV uint32_t brick_key(const GridDev& G, const BrickLayout& L, float4 a) {
+    const f3 p = { a.x, a.y, a.z };
+    const f3 u = transform_(G.t2i, p);
+    const int cx = (int)min_(max_(__builtin_floorf(u.x + 0.5f), 0.0f), (float)(G.dx - 1));
+    const int cy = (int)min_(max_(__builtin_floorf(u.y + 0.5f), 0.0f), (float)(G.dy - 1));
+    const int cz = (int)min_(max_(__builtin_floorf(u.z + 0.5f), 0.0f), (float)(G.dz - 1));
+    return (uint32_t)(cx >> L.lx) + (uint32_t)L.nbx * ((uint32_t)(cy >> L.ly) + (uint32_t)L.nby * (uint32_t)(cz >> L.lz));
+}
+CPM_DEV bool is_sentinel(float4 a) { return a.x == kFltMax || a.y == kFltMax || a.z == kFltMax; }
+
+// Fixed-point scale 2^sh: every |contribution| <= m = maxpow * |k| * 0.75 < 2^e, at most 2^n_log2 of them per voxel:
+// sh = 62 - n_log2 - e keeps every partial sum inside int64.  A function of (maxpow, k, n) only.
+CPM_DEV float fixed_scale(float maxpow, float k, int n_log2) {
+    const float m = maxpow * __builtin_fabsf(k) * 0.75f;
+    if (!(m > 0.f) || m > kFltMax) return 1.0f;
+    const int e = (int)((__float_as_uint(m) >> 23) & 0xffu) - 126;  // m < 2^e
+    int sh = 62 - n_log2 - e;
+    sh = sh > 100 ? 100 : (sh < -100 ? -100 : sh);
+    return __uint_as_float((uint32_t)(sh + 127) << 23);
+}
+
+template <int CH>
+__global__ __launch_bounds__(1024) void fast_count_kernel(const float* __restrict__ photons, int n, GridDev G, BrickLayout L,
+                                                          uint32_t* __restrict__ hist, uint32_t* __restrict__ rank,
+                                                          uint32_t* __restrict__ maxpow) {
+    extern __shared__ uint32_t s_hist[];
+    const int t = threadIdx.x;
+    for (int b = t; b < L.nb; b += 1024) s_hist[b] = 0u;
+    __syncthreads();
+    const float4* __restrict__ ph = reinterpret_cast<const float4*>(photons);
+    uint32_t key[kCountItems], lr[kCountItems];
+    float mp = 0.f;
+#pragma unroll
+    for (int k = 0; k < kCountItems; ++k) {
+        const long long i = (long long)blockIdx.x * kCountTile + k * 1024 + t;
+        key[k] = 0xffffffffu; lr[k] = 0u;
+        if (i < n) {
+            const float4 a = ph[2 * i];
+            if (!is_sentinel(a)) {
+                key[k] = brick_key(G, L, a);
+                lr[k] = atomicAdd(&s_hist[key[k]], 1u);
+                mp = max_(mp, __builtin_fabsf(a.w));
+                if (CH == 4) { const float4 b = ph[2 * i + 1]; mp = max_(mp, max_(__builtin_fabsf(b.x), __builtin_fabsf(b.y))); }
+            }
+        }
+    }
+    __syncthreads();
+    // one returning global atomic per non-empty (workgroup, brick) pair: the run's offset inside the brick
+    for (int b = t; b < L.nb; b += 1024) {
+        const uint32_t c = s_hist[b];
+        if (c) s_hist[b] = atomicAdd(&hist[b], c);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < kCountItems; ++k) {
+        const long long i = (long long)blockIdx.x * kCountTile + k * 1024 + t;
+        if (i < n) rank[i] = key[k] != 0xffffffffu ? s_hist[key[k]] + lr[k] : 0xffffffffu;
+    }
+    // max |power| (a finite, non-negative float orders like its bit pattern); NaN / inf powers are ignored.
+    // One atomic per workgroup at most, and none once the running maximum has reached this workgroup's.
+    if (!(mp <= kFltMax)) mp = 0.f;
+    for (int off = 32; off > 0; off >>= 1) mp = max_(mp, __shfl_xor(mp, off, 64));
+    __shared__ float s_mp[16];
+    if ((t & 63) == 0) s_mp[t >> 6] = mp;
+    __syncthreads();
+    if (t == 0) {
+        float m = s_mp[0];
+#pragma unroll
+        for (int w = 1; w < 16; ++w) m = max_(m, s_mp[w]);
+        const uint32_t mb = __float_as_uint(m);
+        if (m > 0.f && __hip_atomic_load(maxpow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < mb) atomicMax(maxpow, mb);
+    }
+}
+
+// one workgroup: exclusive scans of the brick counts (-> brick starts) and of the bricks' chunk counts (-> item
+// starts), the item list, the totals; clears the histogram for the next call
+__global__ __launch_bounds__(1024) void fast_scan_kernel(uint32_t* __restrict__ hist, BrickLayout L, uint32_t* __restrict__ table) {
+    __shared__ uint32_t s_c[16], s_i[16];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int per = (L.nb + 1023) / 1024;
+    const int b0 = t * per, b1 = min(b0 + per, L.nb);
+    uint32_t c = 0, it = 0;
+    for (int b = b0; b < b1; ++b) { const uint32_t h = hist[b]; c += h; it += (h + kFastChunk - 1) / kFastChunk; }
+    uint32_t ci = c, ii = it;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t oc = __shfl_up(ci, off, 64), oi = __shfl_up(ii, off, 64);
+        if (lane >= off) { ci += oc; ii += oi; }
+    }
+    if (lane == 63) { s_c[wave] = ci; s_i[wave] = ii; }
+    __syncthreads();
+    uint32_t bc = 0, bi = 0, tc = 0, ti = 0;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) { if (w < wave) { bc += s_c[w]; bi += s_i[w]; } tc += s_c[w]; ti += s_i[w]; }
+    uint32_t ac = bc + ci - c, ai = bi + ii - it;  // exclusive prefixes of this thread's first brick
+    uint32_t* __restrict__ bstart = table;
+    uint32_t* __restrict__ istart = table + off_item_start(L);
+    uint32_t* __restrict__ items = table + off_items(L);
+    for (int b = b0; b < b1; ++b) {
+        const uint32_t h = hist[b];
+        hist[b] = 0u;
+        bstart[b] = ac; istart[b] = ai;
+        const uint32_t nc = (h + kFastChunk - 1) / kFastChunk;
+        for (uint32_t q = 0; q < nc; ++q) items[ai + q] = (uint32_t)b;
+        ac += h; ai += nc;
+    }
+    if (t == 0) { bstart[L.nb] = tc; istart[L.nb] = ti; table[off_meta(L) + kMetaItems] = ti; }
+}
+
+template <int CH>
+__global__ __launch_bounds__(256) void fast_scatter_kernel(const float* __restrict__ photons, int n, GridDev G, BrickLayout L,
+                                                           const uint32_t* __restrict__ rank, const uint32_t* __restrict__ bstart,
+                                                           float* __restrict__ sorted) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t r = rank[i];
+    if (r == 0xffffffffu) return;
+    const float4* __restrict__ ph = reinterpret_cast<const float4*>(photons);
+    const float4 a = ph[2 * i];
+    const size_t pos = (size_t)bstart[brick_key(G, L, a)] + r;
+    if (CH == 1) {
+        reinterpret_cast<float4*>(sorted)[pos] = a;
+    } else {
+        const float4 b = ph[2 * i + 1];
+        float4* o = reinterpret_cast<float4*>(sorted) + 2 * pos;
+        o[0] = a;
+        o[1] = make_float4(b.x, b.y, 0.f, 0.f);
+    }
+}
+
+// One record into the LDS tile.  Candidates per axis: the integers within r' (+ slack) of the photon's index-space
+// coordinate, clipped to the grid and to the tile; d^2 in texture space with the contract's operands
+// (c = indexToTexture * v, d = c - p, d^2 = fma(dz, dz, fma(dy, dy, dx * dx))); weight 0.75 * (1 - d^2 / r^2) for
+// d^2 <= r^2; value -> fixed point by truncation.
+template <int MAXC, int CH>
+CPM_DEV void tile_record(const GridDev& G, float4 a, float pg, float pb, int ox, int oy, int oz, int tx, int ty, int tz, float rgx,
+                         float rgy, float rgz, float r2, float inv_r2, float k, float S, long long* __restrict__ tile, int plane) {
+    const f3 p = { a.x, a.y, a.z };
+    const f3 u = transform_(G.t2i, p);
+    const int sx = max(max((int)__builtin_ceilf(u.x - rgx), 0), ox), ex = min(min((int)__builtin_floorf(u.x + rgx), G.dx - 1), ox + tx - 1);
+    const int sy = max(max((int)__builtin_ceilf(u.y - rgy), 0), oy), ey = min(min((int)__builtin_floorf(u.y + rgy), G.dy - 1), oy + ty - 1);
+    const int sz = max(max((int)__builtin_ceilf(u.z - rgz), 0), oz), ez = min(min((int)__builtin_floorf(u.z + rgz), G.dz - 1), oz + tz - 1);
+    const float pk = a.w * k, pkg = pg * k, pkb = pb * k;
+    float dxv[MAXC], dyv[MAXC], dzv[MAXC];
+    bool okx[MAXC], oky[MAXC], okz[MAXC];
+#pragma unroll
+    for (int q = 0; q < MAXC; ++q) {
+        const int vx = sx + q, vy = sy + q, vz = sz + q;
+        dxv[q] = fma_(G.i2t.sx, (float)vx, G.i2t.tx) - a.x;
+        dyv[q] = fma_(G.i2t.sy, (float)vy, G.i2t.ty) - a.y;
+        dzv[q] = fma_(G.i2t.sz, (float)vz, G.i2t.tz) - a.z;
+        okx[q] = vx <= ex; oky[q] = vy <= ey; okz[q] = vz <= ez;
+    }
+    const int base = (sx - ox) + tx * ((sy - oy) + ty * (sz - oz));
+#pragma unroll
+    for (int qz = 0; qz < MAXC; ++qz)
+#pragma unroll
+        for (int qy = 0; qy < MAXC; ++qy)
+#pragma unroll
+            for (int qx = 0; qx < MAXC; ++qx) {
+                const float d2 = fma_(dzv[qz], dzv[qz], fma_(dyv[qy], dyv[qy], dxv[qx] * dxv[qx]));
+                if (okx[qx] && oky[qy] && okz[qz] && d2 <= r2) {
+                    const float w = 0.75f * (1.0f - d2 * inv_r2);
+                    const int idx = base + qx + tx * (qy + ty * qz);
+                    const long long q0 = (long long)((pk * w) * S);
+                    if (q0 != 0) atomicAdd(reinterpret_cast<unsigned long long*>(tile + idx), (unsigned long long)q0);
+                    if (CH == 4) {
+                        const long long q1 = (long long)((pkg * w) * S), q2 = (long long)((pkb * w) * S);
+                        if (q1 != 0) atomicAdd(reinterpret_cast<unsigned long long*>(tile + plane + idx), (unsigned long long)q1);
+                        if (q2 != 0) atomicAdd(reinterpret_cast<unsigned long long*>(tile + 2 * plane + idx), (unsigned long long)q2);
+                    }
+                }
+            }
+}
+
+template <int MAXC, int CH>
+__global__ __launch_bounds__(kTileThreads) void fast_tile_kernel(const float* __restrict__ sorted, const uint32_t* __restrict__ table, GridDev G,
+                                                        BrickLayout L, float radius, float k, int n_log2,
+                                                        long long* __restrict__ slabs) {
+    extern __shared__ long long s_tile[];
+    constexpr int CH3 = CH == 4 ? 3 : 1, STRIDE = CH == 4 ? 2 : 1;
+    const uint32_t item = blockIdx.x;
+    if (item >= table[off_meta(L) + kMetaItems]) return;  // the launch covers the worst case; most workgroups end here
+    const int t = threadIdx.x;
+    const uint32_t b = table[off_items(L) + item];
+    const uint32_t chunk = item - table[off_item_start(L) + b];
+    const uint32_t j0 = table[b] + chunk * (uint32_t)kFastChunk;
+    const uint32_t j1 = min(j0 + (uint32_t)kFastChunk, table[b + 1]);
+    const int words = CH3 * L.tile;
+    for (int w = t; w < words; w += kTileThreads) s_tile[w] = 0ll;
+    const int bx = (int)(b % (uint32_t)L.nbx), by = (int)((b / (uint32_t)L.nbx) % (uint32_t)L.nby), bz = (int)(b / (uint32_t)(L.nbx * L.nby));
+    const int ox = (bx << L.lx) - L.hx, oy = (by << L.ly) - L.hy, oz = (bz << L.lz) - L.hz;
+    const float rgx = radius * G.t2i.sx + 1e-3f, rgy = radius * G.t2i.sy + 1e-3f, rgz = radius * G.t2i.sz + 1e-3f;
+    const float r2 = radius * radius, inv_r2 = 1.0f / r2;
+    const float S = fixed_scale(__uint_as_float(table[off_meta(L) + kMetaMaxPow]), k, n_log2);
+    const float4* __restrict__ rec = reinterpret_cast<const float4*>(sorted);
+    // all of this thread's records first (<= 4 independent 16-byte loads in flight), then the tile
+    float4 a[kFastChunk / kTileThreads], a2[kFastChunk / kTileThreads];
+#pragma unroll
+    for (int q = 0; q < kFastChunk / kTileThreads; ++q) {
+        const uint32_t j = j0 + (uint32_t)(q * kTileThreads + t);
+        a[q] = make_float4(0.f, 0.f, 0.f, 0.f); a2[q] = a[q];
+        if (j < j1) { a[q] = rec[STRIDE * (size_t)j]; if (CH == 4) a2[q] = rec[2 * (size_t)j + 1]; }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < kFastChunk / kTileThreads; ++q) {
+        const uint32_t j = j0 + (uint32_t)(q * kTileThreads + t);
+        if (j < j1)
+            tile_record<MAXC, CH>(G, a[q], a2[q].x, a2[q].y, ox, oy, oz, L.tx, L.ty, L.tz, rgx, rgy, rgz, r2, inv_r2, k, S, s_tile, L.tile);
+    }
+    __syncthreads();
+    long long* __restrict__ slab = slabs + (size_t)item * (size_t)words;
+    for (int w = t; w < words; w += kTileThreads) slab[w] = s_tile[w];
+}
+
+// per voxel: integer sum of every slab that covers it (chunks of the own brick and of the <= 26 neighbours whose halo
+// reaches it), one rounding to float
+template <int CH>
+__global__ __launch_bounds__(256) void fast_combine_kernel(const long long* __restrict__ slabs, const uint32_t* __restrict__ table,
+                                                           GridDev G, BrickLayout L, float k, int n_log2, int accumulate,
+                                                           float* __restrict__ out) {
+    constexpr int CH3 = CH == 4 ? 3 : 1;
+    __shared__ uint32_t s_lo[27], s_hi[27];
+    __shared__ int s_any;
+    const int t = threadIdx.x;
+    const uint32_t b = blockIdx.x;
+    const int bx = (int)(b % (uint32_t)L.nbx), by = (int)((b / (uint32_t)L.nbx) % (uint32_t)L.nby), bz = (int)(b / (uint32_t)(L.nbx * L.nby));
+    if (t == 0) s_any = 0;
+    __syncthreads();
+    if (t < 27) {
+        const int dx = t % 3 - 1, dy = (t / 3) % 3 - 1, dz = t / 9 - 1;
+        const int qx = bx + dx, qy = by + dy, qz = bz + dz;
+        uint32_t lo = 0, hi = 0;
+        if (qx >= 0 && qx < L.nbx && qy >= 0 && qy < L.nby && qz >= 0 && qz < L.nbz) {
+            const uint32_t q = (uint32_t)qx + (uint32_t)L.nbx * ((uint32_t)qy + (uint32_t)L.nby * (uint32_t)qz);
+            lo = table[off_item_start(L) + q]; hi = table[off_item_start(L) + q + 1];
+        }
+        s_lo[t] = lo; s_hi[t] = hi;
+        if (hi > lo) s_any = 1;
+    }
+    __syncthreads();
+    const bool any = s_any != 0;
+    if (!any && accumulate) return;
+    const float S = fixed_scale(__uint_as_float(table[off_meta(L) + kMetaMaxPow]), k, n_log2);
+    const float invS = 1.0f / S;  // a power of two: exact
+    const int BX = 1 << L.lx, BY = 1 << L.ly, bvox = BX * BY * (1 << L.lz);
+    const size_t words = (size_t)CH3 * (size_t)L.tile;
+    for (int v = t; v < bvox; v += 256) {
+        const int lx = v & (BX - 1), ly = (v >> L.lx) & (BY - 1), lz = v >> (L.lx + L.ly);
+        const int gx = (bx << L.lx) + lx, gy = (by << L.ly) + ly, gz = (bz << L.lz) + lz;
+        if (gx >= G.dx || gy >= G.dy || gz >= G.dz) continue;
+        long long sr = 0, sg = 0, sb = 0;
+        if (any) {
+            // the tiles that cover this voxel: its own brick's, and per axis at most ONE neighbour's halo (2 * halo <= brick):
+            // the lower neighbour's when the voxel lies in the brick's first `halo` layers, the upper one's in the last
+            const int BZ = 1 << L.lz;
+            const int nx = lx < L.hx ? -1 : (lx >= BX - L.hx ? 1 : 0);
+            const int ny = ly < L.hy ? -1 : (ly >= BY - L.hy ? 1 : 0);
+            const int nz = lz < L.hz ? -1 : (lz >= BZ - L.hz ? 1 : 0);
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                const int ax = (c & 1) ? nx : 0, ay = (c & 2) ? ny : 0, az = (c & 4) ? nz : 0;
+                const bool covers = !((c & 1) && nx == 0) && !((c & 2) && ny == 0) && !((c & 4) && nz == 0);
+                const int d = (ax + 1) + 3 * (ay + 1) + 9 * (az + 1);
+                const uint32_t lo = s_lo[d], hi = covers ? s_hi[d] : 0u;
+                // this voxel inside that brick's tile (origin = brick origin - halo)
+                const int ix = lx - ax * BX + L.hx, iy = ly - ay * BY + L.hy, iz = lz - az * BZ + L.hz;
+                const size_t idx = (size_t)ix + (size_t)L.tx * ((size_t)iy + (size_t)L.ty * (size_t)iz);
+                for (uint32_t item = lo; item < hi; ++item) {
+                    const long long* __restrict__ slab = slabs + (size_t)item * words;
+                    sr += slab[idx];
+                    if (CH == 4) { sg += slab[(size_t)L.tile + idx]; sb += slab[2 * (size_t)L.tile + idx]; }
+                }
+            }
+        }
+        const size_t o = (size_t)gx + (size_t)G.dx * ((size_t)gy + (size_t)G.dy * (size_t)gz);
+        const float fr = (float)sr * invS;
+        if (CH == 1) {
+            out[o] = accumulate ? out[o] + fr : fr;
+        } else {
+            const float fg = (float)sg * invS, fb = (float)sb * invS;
+            float4* q = reinterpret_cast<float4*>(out) + o;
+            if (accumulate) { const float4 tt = *q; *q = make_float4(tt.x + fr, tt.y + fg, tt.z + fb, tt.w); }
+            else *q = make_float4(fr, fg, fb, 0.f);
+        }
+    }
+}
+
+template <typename K>
+__host__ int allow_lds(cpm_ctx* ctx, K kernel, size_t bytes) {
+    if (bytes <= 48 * 1024) return CPM_OK;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e != hipSuccess) return set_error(ctx, CPM_ERR_DEVICE, "hipFuncSetAttribute(MaxDynamicSharedMemorySize)", hipGetErrorString(e));
+    return CPM_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t cpm_fast_table_entries(const cpm_grid_desc* grid, int n) {
+    if (!grid || n < 0 || grid->dims[0] < 1 || grid->dims[1] < 1 || grid->dims[2] < 1) return 0;
+    BrickLayout L;
+    brick_shape(grid->dims, L);
+    return table_entries(L, n);
+}
+
+int cpm_gather_fast_supported(const cpm_grid_desc* grid, float radius) {
+    if (!grid || grid->dims[0] < 1 || grid->dims[1] < 1 || grid->dims[2] < 1) return 0;
+    if (grid->channels != 1 && grid->channels != 4) return 0;
+    GridDev G;
+    G.dx = grid->dims[0]; G.dy = grid->dims[1]; G.dz = grid->dims[2]; G.channels = grid->channels;
+    if (!affine_from_matrix(grid->texture_to_index, G.t2i) || !affine_from_matrix(grid->index_to_texture, G.i2t)) return 0;
+    if (!(G.t2i.sx > 0.f && G.t2i.sy > 0.f && G.t2i.sz > 0.f)) return 0;
+    BrickLayout L;
+    brick_shape(grid->dims, L);
+    if (!brick_reach(G, radius, L)) return 0;
+    return (size_t)(G.channels == 4 ? 3 : 1) * (size_t)L.tile * 8 <= 160 * 1024 - 1024;
+}
+
+int cpm_bin_fast(cpm_ctx* ctx, const float* photons8, int n, const cpm_grid_desc* grid, uint32_t* brick_table,
+                 float* sorted_pos_power, cpm_stream stream) {
+    CPM_ENTER(ctx);
+    GridDev G;
+    int rc = make_grid_dev_fast(ctx, grid, G);
+    if (rc) return rc;
+    CPM_REQUIRE(ctx, n >= 0, "cpm_bin_fast: n < 0");
+    CPM_REQUIRE(ctx, brick_table, "cpm_bin_fast: null brick_table");
+    CPM_REQUIRE(ctx, n == 0 || (photons8 && sorted_pos_power), "cpm_bin_fast: null buffer");
+    CPM_REQUIRE_ALIGNED16(ctx, photons8, "cpm_bin_fast");
+    CPM_REQUIRE_ALIGNED16(ctx, sorted_pos_power, "cpm_bin_fast");
+    hipStream_t s = (hipStream_t)stream;
+    BrickLayout L;
+    brick_shape(grid->dims, L);
+    // histogram (nb, kept zero between calls by the scan kernel) + per-photon ranks
+    const size_t hist_words = (size_t)L.nb + 4;
+    const bool had = ctx->scratch_bytes[CPM_SCR_FAST_BIN] >= (hist_words + (size_t)(n > 0 ? n : 1)) * 4;
+    uint32_t* hist = (uint32_t*)scratch(ctx, CPM_SCR_FAST_BIN, (hist_words + (size_t)(n > 0 ? n : 1)) * 4);
+    if (!hist) return CPM_ERR_OUT_OF_MEMORY;
+    if (!had || ctx->fast_hist_words != hist_words) {  // new arena or another grid: the histogram's zero state is not established
+        CPM_HIP_CHECK(ctx, hipMemsetAsync(hist, 0, hist_words * 4, s));
+    }
+    uint32_t* rank = hist + hist_words;
+    ctx->fast_hist_words = 0;  // re-established below once the scan kernel (which clears the histogram) is enqueued
+    // meta: max |power| is an atomicMax target
+    CPM_HIP_CHECK(ctx, hipMemsetAsync(brick_table + (size_t)L.nb + 1, 0, 4 * sizeof(uint32_t), s));
+    if (n > 0) {
+        const dim3 cgrid((unsigned)div_up(n, kCountTile));
+        const size_t lds = (size_t)L.nb * 4;
+        if (G.channels == 1) {
+            rc = allow_lds(ctx, fast_count_kernel<1>, lds); if (rc) return rc;
+            CPM_LAUNCH(ctx, fast_count_kernel<1>, cgrid, dim3(1024), lds, s, photons8, n, G, L, hist, rank, brick_table + (size_t)L.nb + 1 + kMetaMaxPow);
+        } else {
+            rc = allow_lds(ctx, fast_count_kernel<4>, lds); if (rc) return rc;
+            CPM_LAUNCH(ctx, fast_count_kernel<4>, cgrid, dim3(1024), lds, s, photons8, n, G, L, hist, rank, brick_table + (size_t)L.nb + 1 + kMetaMaxPow);
+        }
+        CPM_LAUNCH_CHECK(ctx, "fast_count_kernel");
+    }
+    CPM_LAUNCH(ctx, fast_scan_kernel, dim3(1), dim3(1024), 0, s, hist, L, brick_table);
+    CPM_LAUNCH_CHECK(ctx, "fast_scan_kernel");
+    ctx->fast_hist_words = hist_words;
+    if (n > 0) {
+        if (G.channels == 1)
+            CPM_LAUNCH(ctx, fast_scatter_kernel<1>, dim3((unsigned)div_up(n, 256)), dim3(256), 0, s, photons8, n, G, L, rank, brick_table, sorted_pos_power);
+        else
+            CPM_LAUNCH(ctx, fast_scatter_kernel<4>, dim3((unsigned)div_up(n, 256)), dim3(256), 0, s, photons8, n, G, L, rank, brick_table, sorted_pos_power);
+        CPM_LAUNCH_CHECK(ctx, "fast_scatter_kernel");
+    }
+    return CPM_OK;
+}
+
+int cpm_gather_fast(cpm_ctx* ctx, const float* sorted_pos_power, const uint32_t* brick_table, int n, const cpm_grid_desc* grid,
+                    float radius, float scale, int accumulate, float* grid_out, cpm_stream stream) {
+    CPM_ENTER(ctx);
+    GridDev G;
+    int rc = make_grid_dev_fast(ctx, grid, G);
+    if (rc) return rc;
+    CPM_REQUIRE(ctx, n >= 0 && radius > 0.f, "cpm_gather_fast: bad size or radius");
+    CPM_REQUIRE(ctx, brick_table && grid_out && (sorted_pos_power || n == 0), "cpm_gather_fast: null buffer");
+    CPM_REQUIRE_ALIGNED16(ctx, sorted_pos_power, "cpm_gather_fast");
+    if (G.channels == 4) CPM_REQUIRE_ALIGNED16(ctx, grid_out, "cpm_gather_fast");
+    BrickLayout L;
+    brick_shape(grid->dims, L);
+    if (!brick_reach(G, radius, L))
+        return set_error(ctx, CPM_ERR_UNSUPPORTED, "cpm_gather_fast", "radius beyond 2 voxels (or beyond half a brick): use cpm_bin + cpm_gather");
+    const int ch3 = G.channels == 4 ? 3 : 1;
+    const size_t tile_bytes = (size_t)ch3 * (size_t)L.tile * 8;
+    if (tile_bytes > 160 * 1024 - 1024)
+        return set_error(ctx, CPM_ERR_UNSUPPORTED, "cpm_gather_fast", "tile does not fit the LDS: use cpm_bin + cpm_gather");
+    const size_t max_items = (size_t)(n < L.nb ? n : L.nb) + (size_t)div_up(n > 0 ? n : 1, kFastChunk);
+    long long* slabs = (long long*)scratch(ctx, CPM_SCR_FAST_SLABS, max_items * tile_bytes);
+    if (!slabs) return CPM_ERR_OUT_OF_MEMORY;
+    const float k = kInv4Pi * scale;
+    const int n_log2 = ceil_log2(n > 2 ? n : 2);
+    hipStream_t s = (hipStream_t)stream;
+    if (n > 0) {
+        const dim3 tgrid((unsigned)max_items);
+#define CPM_TILE_LAUNCH(MAXC, CH)                                                                                        \
+    do {                                                                                                                 \
+        rc = allow_lds(ctx, fast_tile_kernel<MAXC, CH>, tile_bytes);                                                     \
+        if (rc) return rc;                                                                                               \
+        CPM_LAUNCH(ctx, (fast_tile_kernel<MAXC, CH>), tgrid, dim3(kTileThreads), tile_bytes, s, sorted_pos_power, brick_table, G, L, radius, \
+                   k, n_log2, slabs);                                                                                    \
+    } while (0)
+        if (G.channels == 1) {
+            if (L.maxc <= 2) CPM_TILE_LAUNCH(2, 1); else if (L.maxc == 3) CPM_TILE_LAUNCH(3, 1); else CPM_TILE_LAUNCH(4, 1);
+        } else {
+            if (L.maxc <= 2) CPM_TILE_LAUNCH(2, 4); else if (L.maxc == 3) CPM_TILE_LAUNCH(3, 4); else CPM_TILE_LAUNCH(4, 4);
+        }
+#undef CPM_TILE_LAUNCH
+        CPM_LAUNCH_CHECK(ctx, "fast_tile_kernel");
+    }
+    if (G.channels == 1)
+        CPM_LAUNCH(ctx, fast_combine_kernel<1>, dim3((unsigned)L.nb), dim3(256), 0, s, slabs, brick_table, G, L, k, n_log2, accumulate, grid_out);
+    else
+        CPM_LAUNCH(ctx, fast_combine_kernel<4>, dim3((unsigned)L.nb), dim3(256), 0, s, slabs, brick_table, G, L, k, n_log2, accumulate, grid_out);
+    CPM_LAUNCH_CHECK(ctx, "fast_combine_kernel");
+    return CPM_OK;
+}
+
+}  // extern "C"

@@ -227,6 +227,7 @@ class PhotonFrame:
         self.cell_start = torch.empty(self.cells + 1, dtype=torch.int32, device=dev)
         self.sorted = torch.empty((self.n * self.I, 4 if channels == 1 else 8), dtype=f32, device=dev)
         self.light_volume = torch.zeros((self.cells, channels) if channels > 1 else (self.cells,), dtype=f32, device=dev)
+        self.brick_table = None   # cpm_bin_fast's table, allocated on first use
 
     # stages
     def trace(self):
@@ -238,6 +239,24 @@ class PhotonFrame:
     def gather(self, accumulate=False, out=None):
         self.ctx.gather(self.sorted, self.cell_start, self.n * self.I, self.grid, self.radius, self.scale,
                         self.light_volume if out is None else out, accumulate=accumulate)
+
+    # tolerance-mode formulation: brick bin + LDS-tile gather (cpm_bin_fast / cpm_gather_fast)
+    def bin_fast(self):
+        if self.brick_table is None:
+            entries = self.ctx.fast_table_entries(self.grid, self.n * self.I)
+            self.brick_table = self.torch.zeros(entries, dtype=self.torch.int32, device=self.ctx.device)
+        self.ctx.bin_fast(self.photons, self.n * self.I, self.grid, self.brick_table, self.sorted)
+
+    def gather_fast(self, accumulate=False, out=None):
+        self.ctx.gather_fast(self.sorted, self.brick_table, self.n * self.I, self.grid, self.radius, self.scale,
+                             self.light_volume if out is None else out, accumulate=accumulate)
+
+    def frame_fast(self):
+        """The hot path in tolerance mode: trace -> brick bin -> tile gather."""
+        self.trace()
+        self.bin_fast()
+        self.gather_fast()
+        return self.light_volume
 
     def splat(self, out=None):
         """Reference formulation (atomic splat), for comparison: clear + splat."""

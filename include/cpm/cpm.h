@@ -269,7 +269,8 @@ int cpm_sort_keys(cpm_ctx* ctx, uint32_t* keys, size_t n, int key_bits, cpm_stre
 
 /* Bin photons into light-volume cells.
  *   key(p) = cx + dims.x * (cy + dims.y * cz), c = clamp(floor(p * dims), 0, dims-1);
- *   sentinel photons (any position component == FLT_MAX) get key 0xffffffff.
+ *   sentinel photons (any position component == FLT_MAX) get key == cells: they sort behind every real
+ *   cell, and cell_start[cells] is the number of stored photons.
  * Sorts (key, photon index) stably, then writes
  *   order[j]        = index (into photons8) of the j-th photon in cell order,
  *   cell_start[c]   = first j with key >= c, c = 0..cells (cells+1 entries),
@@ -305,6 +306,35 @@ int cpm_mark_touched_bricks(cpm_ctx* ctx, const float* photons8, const uint32_t*
 int cpm_gather_bricks(cpm_ctx* ctx, const float* sorted_pos_power, const uint32_t* cell_start, int n,
                       const cpm_grid_desc* grid, float radius, float relative_irradiance_scale,
                       const uint8_t* brick_mask, float* grid_out, cpm_stream stream);
+
+/* ---- MI355X formulation, tolerance mode: brick bin + LDS-tile gather (S6, G1-G3 restated)
+ *
+ * Same light volume as cpm_bin + cpm_gather within a stated fp32 tolerance (rtol 2e-5, atol 1e-5 * max, the
+ * tolerance the reference's own atomic splat is held to): the Epanechnikov weight is evaluated as
+ * 0.75 * (1 - d^2 / r^2) for d^2 <= r^2 (no sqrt, no division -- ref cl/densityestimationkernel.cl:43-60 takes
+ * x = d / r), and per-voxel sums are accumulated as 64-bit fixed-point integers, so they do not depend on any
+ * order: the result is bitwise reproducible run to run although nothing is sorted inside a brick.
+ * Photons are grouped by BRICK (8x8x8 voxels; wider for grids beyond 16 Ki bricks) with an unstable counting
+ * sort -- the order of the records inside a brick is unspecified.  Sentinel photons are dropped.
+ * The reference adds with CAS float atomics in arrival order (ref cl/photonstolightvolume.cl:15-29,62-75). */
+
+/* u32 entries of the brick table cpm_bin_fast fills for n records on this grid (0 = bad arguments). */
+size_t cpm_fast_table_entries(const cpm_grid_desc* grid, int n);
+/* 1 when cpm_gather_fast covers this grid / radius (radius < 2 voxels per axis, positive axis-aligned
+ * textureToIndex); otherwise use cpm_bin + cpm_gather. */
+int cpm_gather_fast_supported(const cpm_grid_desc* grid, float radius);
+
+/* brick_table (device, cpm_fast_table_entries(grid, n) u32): brick starts, work-item list, max |power|.
+ * sorted_pos_power: n compact records, float4 (x, y, z, powerR) when channels == 1, 2 x float4
+ * (x, y, z, powerR | powerG, powerB, 0, 0) when == 4; the first brick_table[bricks] of them are written. */
+int cpm_bin_fast(cpm_ctx* ctx, const float* photons8, int n, const cpm_grid_desc* grid, uint32_t* brick_table,
+                 float* sorted_pos_power, cpm_stream stream);
+
+/* grid_out[v] = (accumulate ? grid_out[v] : 0) + float(sum over photons of fixed(power * k * w(v, photon))) with
+ * k = relative_irradiance_scale / (4 pi) as in cpm_splat.  n, grid: as given to cpm_bin_fast. */
+int cpm_gather_fast(cpm_ctx* ctx, const float* sorted_pos_power, const uint32_t* brick_table, int n,
+                    const cpm_grid_desc* grid, float radius, float relative_irradiance_scale, int accumulate,
+                    float* grid_out, cpm_stream stream);
 
 /* ------------------------------------------------------------------ correlated re-trace (C1-C7, S2-S4) */
 

@@ -799,6 +799,108 @@ void cpmo_gather(const float* sorted, const uint32_t* cell_start, int n, const c
             }
 }
 
+/* ---- tolerance-mode formulation (cpm_bin_fast + cpm_gather_fast): NO reference counterpart -- the reference adds
+ * the same terms with CAS float atomics in arrival order (cl/photonstolightvolume.cl:15-29,62-75).  Restated here
+ * so that the HIP path can be checked bit for bit: the weight is 0.75 * (1 - d^2 / r^2) for d^2 <= r^2
+ * (cl/densityestimationkernel.cl:43-60 with x^2 = d^2 / r^2), every contribution is truncated to 64-bit fixed
+ * point with the scale below, the per-voxel sums are exact integers (order-free), one rounding to float.
+ * The brick / tile bookkeeping only decides which candidate voxels are considered; it is restated because a
+ * candidate outside the photon's brick tile is dropped by the kernel. */
+typedef struct { int lg[3], nb[3], h[3], t[3]; } fast_layout;
+
+static void fast_brick_layout(const cpmo_grid_desc* g, float radius, fast_layout* L) {
+    for (int a = 0; a < 3; ++a) L->lg[a] = 3;
+    int axis = 0;
+    for (;;) {
+        long long cnt = 1;
+        for (int a = 0; a < 3; ++a) { L->nb[a] = (g->dims[a] + (1 << L->lg[a]) - 1) >> L->lg[a]; cnt *= L->nb[a]; }
+        if (cnt <= 16384) break;
+        ++L->lg[axis]; axis = (axis + 1) % 3;
+    }
+    for (int a = 0; a < 3; ++a) {
+        L->h[a] = (int)floorf(radius * g->texture_to_index[5 * a] + 0.501f);
+        L->t[a] = (1 << L->lg[a]) + 2 * L->h[a];
+    }
+}
+
+static float fast_fixed_scale(float maxpow, float k, int n_log2) {
+    float m = maxpow * fabsf(k) * 0.75f;
+    if (!(m > 0.f) || m > FLT_MAX) return 1.0f;
+    union { float f; uint32_t u; } b; b.f = m;
+    int e = (int)((b.u >> 23) & 0xffu) - 126; /* m < 2^e */
+    int sh = 62 - n_log2 - e;
+    sh = sh > 100 ? 100 : (sh < -100 ? -100 : sh);
+    b.u = (uint32_t)(sh + 127) << 23;
+    return b.f;
+}
+
+void cpmo_gather_fast(const float* photons, int n, const cpmo_grid_desc* g, float radius, float scale,
+                      int accumulate, float* out) {
+    const int dims[3] = { g->dims[0], g->dims[1], g->dims[2] };
+    const size_t cells = (size_t)dims[0] * dims[1] * dims[2];
+    const int ch3 = g->channels == 1 ? 1 : 3;
+    const float k = 0.0795774715459476679f * scale;
+    fast_layout L;
+    fast_brick_layout(g, radius, &L);
+    int n_log2 = 1;
+    while (n_log2 < 62 && (1ll << n_log2) < (n > 2 ? n : 2)) ++n_log2;
+    float maxpow = 0.f;
+    for (int i = 0; i < n; ++i) {
+        const float* ph = photons + 8 * (size_t)i;
+        if (ph[0] == FLT_MAX || ph[1] == FLT_MAX || ph[2] == FLT_MAX) continue;
+        for (int c = 0; c < ch3; ++c) { float a = fabsf(ph[3 + c]); if (a <= FLT_MAX && a > maxpow) maxpow = a; }
+    }
+    const float S = fast_fixed_scale(maxpow, k, n_log2);
+    const float invS = 1.0f / S;
+    long long* acc = (long long*)calloc(cells * (size_t)ch3, sizeof(long long));
+    const float* T = g->texture_to_index; const float* I = g->index_to_texture;
+    const float sT[3] = { T[0], T[5], T[10] }, tT[3] = { T[12], T[13], T[14] };
+    const float sI[3] = { I[0], I[5], I[10] }, tI[3] = { I[12], I[13], I[14] };
+    const float r2 = radius * radius, inv_r2 = 1.0f / r2;
+    for (int i = 0; i < n; ++i) {
+        const float* ph = photons + 8 * (size_t)i;
+        if (ph[0] == FLT_MAX || ph[1] == FLT_MAX || ph[2] == FLT_MAX) continue;
+        int s[3], e[3];
+        for (int a = 0; a < 3; ++a) {
+            const float u = om_fma(sT[a], ph[a], tT[a]);
+            const float rg = radius * sT[a] + 1e-3f;
+            const int cell = (int)om_min(om_max(floorf(u + 0.5f), 0.0f), (float)(dims[a] - 1));
+            const int o = ((cell >> L.lg[a]) << L.lg[a]) - L.h[a]; /* tile origin of the photon's brick */
+            int lo = (int)ceilf(u - rg), hi = (int)floorf(u + rg);
+            if (lo < 0) lo = 0; if (lo < o) lo = o;
+            if (hi > dims[a] - 1) hi = dims[a] - 1; if (hi > o + L.t[a] - 1) hi = o + L.t[a] - 1;
+            s[a] = lo; e[a] = hi;
+        }
+        const float pk[3] = { ph[3] * k, ph[4] * k, ph[5] * k };
+        for (int z = s[2]; z <= e[2]; ++z) {
+            const float dz = om_fma(sI[2], (float)z, tI[2]) - ph[2];
+            for (int y = s[1]; y <= e[1]; ++y) {
+                const float dy = om_fma(sI[1], (float)y, tI[1]) - ph[1];
+                for (int x = s[0]; x <= e[0]; ++x) {
+                    const float dx = om_fma(sI[0], (float)x, tI[0]) - ph[0];
+                    const float d2 = om_fma(dz, dz, om_fma(dy, dy, dx * dx));
+                    if (!(d2 <= r2)) continue;
+                    const float w = 0.75f * (1.0f - d2 * inv_r2);
+                    const size_t v = (size_t)x + (size_t)dims[0] * ((size_t)y + (size_t)dims[1] * (size_t)z);
+                    for (int c = 0; c < ch3; ++c) acc[(size_t)c * cells + v] += (long long)((pk[c] * w) * S);
+                }
+            }
+        }
+    }
+    for (size_t v = 0; v < cells; ++v) {
+        if (ch3 == 1) {
+            const float f = (float)acc[v] * invS;
+            out[v] = accumulate ? out[v] + f : f;
+        } else {
+            float* o = out + 4 * v;
+            const float fr = (float)acc[v] * invS, fg = (float)acc[cells + v] * invS, fb = (float)acc[2 * cells + v] * invS;
+            if (accumulate) { o[0] += fr; o[1] += fg; o[2] += fb; }
+            else { o[0] = fr; o[1] = fg; o[2] = fb; o[3] = 0.f; }
+        }
+    }
+    free(acc);
+}
+
 /* ------------------------------------------------------------------ correlated re-trace */
 
 static inline float normalized_voxel(const cpmo_volume* v, int x, int y, int z) {

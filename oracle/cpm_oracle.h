@@ -123,6 +123,10 @@ void cpmo_gather(const float* sorted_pos_power, const uint32_t* cell_start, int 
                  const cpmo_grid_desc* grid, float radius, float scale, int accumulate,
                  float* grid_out);
 
+/* tolerance-mode formulation (cpm_bin_fast + cpm_gather_fast), straight from the photon records: fixed-point sums */
+void cpmo_gather_fast(const float* photons8, int n, const cpmo_grid_desc* grid, float radius, float scale,
+                      int accumulate, float* grid_out);
+
 /* correlated re-trace */
 void cpmo_volume_minmax(const cpmo_volume* vol, int region, uint16_t* minmax2);
 void cpmo_volume_difference(const cpmo_volume* cur, const cpmo_volume* next, int region,

@@ -236,6 +236,10 @@ class Oracle:
         self.lib.cpmo_gather(_p(sorted_pp), _p(cell_start), n, C.byref(grid), C.c_float(radius), C.c_float(scale),
                              int(accumulate), _p(out))
 
+    def gather_fast(self, photons, n, grid: OGrid, radius, scale, out, accumulate=False):
+        """The tolerance-mode formulation (cpm_bin_fast + cpm_gather_fast) restated: fixed-point sums, order-free."""
+        self.lib.cpmo_gather_fast(_p(photons), n, C.byref(grid), C.c_float(radius), C.c_float(scale), int(accumulate), _p(out))
+
     # ---- temporal interpolation
     def mix_f32(self, x, y, a):
         x = np.ascontiguousarray(x, np.float32); y = np.ascontiguousarray(y, np.float32)

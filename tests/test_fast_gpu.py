@@ -1,0 +1,215 @@
+"""The tolerance-mode formulation (cpm_bin_fast + cpm_gather_fast, include/cpm/cpm.h) on a real MI355X.
+
+Two bars, both through the C-ABI:
+  * bit for bit against the oracle's restatement of the SAME formulation (cpmo_gather_fast: fixed-point
+    contributions, exact integer sums, one rounding) -- integer sums do not depend on order, so the
+    unordered brick bin and the LDS atomics leave nothing to tolerate;
+  * within the stated fp32 tolerance (rtol 2e-5, atol 1e-5 * max -- what the reference formulation's
+    atomic splat is held to, tests/test_parity_gpu.py) against the oracle's reference-semantics gather
+    (sequential fp32 sum, weight through sqrt and division: ref cl/photonstolightvolume.cl:42-75).
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+FLT_MAX = np.float32(3.402823466e+38)
+RTOL, ATOL_OF_MAX = 2e-5, 1e-5
+
+
+def _t(ctx, a):
+    torch = ctx.torch
+    a = np.ascontiguousarray(a)
+    if a.dtype == np.uint32:
+        return torch.from_numpy(a.view(np.int32)).to(ctx.device)
+    return torch.from_numpy(a).to(ctx.device)
+
+
+def _n(t, dtype=None):
+    a = t.detach().cpu().numpy()
+    return a.view(dtype) if dtype is not None else a
+
+
+def bits(a):
+    return np.ascontiguousarray(a, np.float32).view(np.uint32)
+
+
+def make_photons(rng, n, dims, *, sentinels=0.1, outside=0.02, cluster=None, negative=False):
+    ph = np.zeros((n, 8), np.float32)
+    ph[:, :3] = rng.random((n, 3), dtype=np.float32)
+    if cluster is not None:  # pile a share of the photons onto one face / one cell, as light entering a volume does
+        m = rng.random(n) < 0.5
+        ph[m, 2] = np.float32(cluster) + rng.random(m.sum(), dtype=np.float32) * np.float32(0.5 / dims[2])
+    out = rng.random(n) < outside
+    ph[out, :3] = (rng.random((out.sum(), 3), dtype=np.float32) - np.float32(0.5)) * np.float32(3.0)
+    ph[:, 3:6] = rng.random((n, 3), dtype=np.float32) * np.float32(10.0) + np.float32(0.01)
+    if negative:
+        ph[rng.random(n) < 0.3, 3:6] *= np.float32(-1.0)
+    ph[:, 6:] = rng.random((n, 2), dtype=np.float32)
+    s = rng.random(n) < sentinels
+    ph[s, :3] = FLT_MAX
+    ph[s, 4:6] = FLT_MAX
+    return ph
+
+
+def brick_count(dims):
+    """Bricks of 8^3 voxels, doubled along x, y, z in turn while there are more than 16 Ki of them (cpm.h)."""
+    lg, axis = [3, 3, 3], 0
+    cnt = lambda: [(d + (1 << l) - 1) >> l for d, l in zip(dims, lg)]
+    while np.prod(cnt()) > 16384:
+        lg[axis] += 1
+        axis = (axis + 1) % 3
+    return int(np.prod(cnt()))
+
+
+def run_fast(ctx, cpm, ph, dims, channels, radius, scale, accumulate_into=None):
+    B = cpm.binding
+    n = ph.shape[0]
+    grid = B.default_grid_desc(dims, channels)
+    cells = dims[0] * dims[1] * dims[2]
+    table = ctx.torch.zeros(max(ctx.fast_table_entries(grid, n), 1), dtype=ctx.torch.int32, device=ctx.device)
+    srt = ctx.torch.zeros((max(n, 1), 4 if channels == 1 else 8), dtype=ctx.torch.float32, device=ctx.device)
+    d_ph = _t(ctx, ph) if n else ctx.torch.zeros((1, 8), dtype=ctx.torch.float32, device=ctx.device)
+    ctx.bin_fast(d_ph, n, grid, table, srt)
+    if accumulate_into is None:
+        out = ctx.torch.full((cells,) if channels == 1 else (cells, 4), 7.0, dtype=ctx.torch.float32, device=ctx.device)
+        ctx.gather_fast(srt, table, n, grid, radius, scale, out)
+    else:
+        out = _t(ctx, accumulate_into)
+        ctx.gather_fast(srt, table, n, grid, radius, scale, out, accumulate=True)
+    return _n(out), _n(table, np.uint32), _n(srt)
+
+
+def oracle_both(oracle, ph, dims, channels, radius, scale, accumulate_into=None):
+    n = ph.shape[0]
+    og = oracle.grid(dims, channels)
+    cells = dims[0] * dims[1] * dims[2]
+    shape = (cells,) if channels == 1 else (cells, 4)
+    fast = np.zeros(shape, np.float32) if accumulate_into is None else accumulate_into.copy()
+    oracle.gather_fast(ph, n, og, radius, scale, fast, accumulate=accumulate_into is not None)
+    _, cs, srt = oracle.bin(ph, n, og)
+    exact = np.zeros(shape, np.float32) if accumulate_into is None else accumulate_into.copy()
+    oracle.gather(srt, cs, n, og, radius, scale, exact, accumulate=accumulate_into is not None)
+    return fast, exact
+
+
+CASES = [
+    # dims, channels, n, radius in voxels of the longest axis, kwargs
+    ((32, 32, 32), 1, 20_000, 0.866, {}),
+    ((32, 32, 32), 4, 20_000, 0.866, {}),
+    ((64, 64, 64), 1, 200_000, 0.866, dict(cluster=0.0)),
+    ((64, 64, 64), 1, 50_000, 1.3, dict(cluster=0.97)),
+    ((64, 64, 64), 1, 30_000, 1.9, {}),
+    ((40, 24, 56), 1, 30_000, 0.7, {}),          # ragged: partial bricks on every axis, anisotropic radius in voxels
+    ((40, 24, 56), 4, 30_000, 1.2, dict(negative=True)),
+    ((1, 5, 17), 1, 3_000, 0.4, {}),             # degenerate
+    ((7, 1, 3), 4, 1_000, 0.9, {}),
+    ((128, 128, 128), 1, 300_000, 0.866, dict(cluster=0.0)),
+    ((256, 128, 64), 1, 100_000, 1.0, {}),       # > 16 Ki bricks of 8^3: wider bricks
+    ((16, 16, 16), 1, 1, 0.866, dict(sentinels=0.0, outside=0.0)),
+    ((16, 16, 16), 1, 63, 0.866, {}),
+    ((16, 16, 16), 1, 4097, 0.866, {}),
+]
+
+
+@pytest.mark.parametrize("dims,channels,n,rvox,kw", CASES)
+def test_fast_equals_restatement_and_reference_semantics(ctx, oracle, cpm, dims, channels, n, rvox, kw):
+    rng = np.random.default_rng(n + dims[0] * 7 + channels)
+    ph = make_photons(rng, n, dims, **kw)
+    radius = float(np.float32(rvox) / np.float32(max(dims)))    # rvox voxels along the longest axis, fewer along the others
+    scale = float(cpm.binding.relative_irradiance_scale(radius, float(n)))
+    got, table, srt = run_fast(ctx, cpm, ph, dims, channels, radius, scale)
+    want_fast, want_exact = oracle_both(oracle, ph, dims, channels, radius, scale)
+    assert np.array_equal(bits(got), bits(want_fast))
+    np.testing.assert_allclose(got, want_exact, rtol=RTOL, atol=ATOL_OF_MAX * float(np.abs(want_exact).max()))
+    # the table: brick starts are the counts of the stored photons per brick; records are a permutation of them
+    stored = ph[ph[:, 0] != FLT_MAX]
+    nb = brick_count(dims)
+    total = stored.shape[0]
+    assert table[0] == 0 and table[nb] == total and (np.diff(table[: nb + 1].astype(np.int64)) >= 0).all()
+    rec = srt[:total]
+    want_rec = stored[:, :4] if channels == 1 else np.concatenate([stored[:, :6], np.zeros((total, 2), np.float32)], axis=1)
+    a = np.sort(rec.view([("", np.uint32)] * rec.shape[1]).reshape(-1))
+    b = np.sort(np.ascontiguousarray(want_rec).view([("", np.uint32)] * rec.shape[1]).reshape(-1))
+    assert np.array_equal(a, b)
+    # bitwise reproducible although nothing orders the records inside a brick
+    again, _, _ = run_fast(ctx, cpm, ph, dims, channels, radius, scale)
+    assert np.array_equal(bits(again), bits(got))
+
+
+def test_fast_accumulate_empty_and_all_sentinels(ctx, oracle, cpm):
+    dims, radius = (32, 32, 32), 0.866 / 32
+    rng = np.random.default_rng(3)
+    ph = make_photons(rng, 10_000, dims)
+    scale = 0.01
+    base = rng.random(32 ** 3, dtype=np.float32)
+    got, _, _ = run_fast(ctx, cpm, ph, dims, 1, radius, scale, accumulate_into=base)
+    want_fast, want_exact = oracle_both(oracle, ph, dims, 1, radius, scale, accumulate_into=base)
+    assert np.array_equal(bits(got), bits(want_fast))
+    np.testing.assert_allclose(got, want_exact, rtol=RTOL, atol=ATOL_OF_MAX * float(want_exact.max()))
+    # no photons, and only sentinels: a cleared light volume (accumulate: untouched)
+    empty = np.zeros((0, 8), np.float32)
+    got, _, _ = run_fast(ctx, cpm, empty, dims, 1, radius, scale)
+    assert not got.any()
+    sent = make_photons(rng, 500, dims, sentinels=1.1)
+    got, table, _ = run_fast(ctx, cpm, sent, dims, 4, radius, scale)
+    assert not got.any() and table[64] == 0
+    got, _, _ = run_fast(ctx, cpm, sent, dims, 1, radius, scale, accumulate_into=base)
+    assert np.array_equal(bits(got), bits(base))
+
+
+def test_fast_after_bigger_call_and_other_grid(ctx, oracle, cpm):
+    """Scratch reuse: the histogram must be back to zero whatever ran before (bigger n, other grid, other channels)."""
+    rng = np.random.default_rng(11)
+    for dims, ch, n in [((64, 64, 64), 1, 100_000), ((32, 32, 32), 4, 5_000), ((64, 64, 64), 1, 1_000), ((24, 40, 8), 1, 7_000)]:
+        ph = make_photons(rng, n, dims)
+        radius = 0.9 / dims[0]
+        got, _, _ = run_fast(ctx, cpm, ph, dims, ch, radius, 0.5)
+        want_fast, _ = oracle_both(oracle, ph, dims, ch, radius, 0.5)
+        assert np.array_equal(bits(got), bits(want_fast))
+
+
+def test_fast_unsupported_radius_is_refused(ctx, cpm):
+    B = cpm.binding
+    grid = B.default_grid_desc((32, 32, 32), 1)
+    assert ctx.gather_fast_supported(grid, 0.866 / 32)
+    assert not ctx.gather_fast_supported(grid, 2.2 / 32)
+    table = ctx.torch.zeros(ctx.fast_table_entries(grid, 16), dtype=ctx.torch.int32, device=ctx.device)
+    srt = ctx.torch.zeros((16, 4), dtype=ctx.torch.float32, device=ctx.device)
+    out = ctx.torch.zeros(32 ** 3, dtype=ctx.torch.float32, device=ctx.device)
+    ctx.bin_fast(ctx.torch.zeros((16, 8), dtype=ctx.torch.float32, device=ctx.device), 16, grid, table, srt)
+    with pytest.raises(B.CpmError) as e:
+        ctx.gather_fast(srt, table, 16, grid, 2.2 / 32, 1.0, out)
+    assert e.value.status == -4  # CPM_ERR_UNSUPPORTED: callers fall back to cpm_bin + cpm_gather
+
+
+def test_fast_non_default_grid_matrices(ctx, oracle, cpm):
+    """A scaled and offset light volume (texture -> index is not dims * p - 0.5): the fast path reads the matrices."""
+    B = cpm.binding
+    dims = (32, 24, 16)
+    rng = np.random.default_rng(5)
+    ph = make_photons(rng, 20_000, dims, outside=0.0)
+    grid = B.default_grid_desc(dims, 1)
+    og = oracle.grid(dims, 1)
+    # the light volume covers [0.1, 0.9]^3 of texture space: index = (p - 0.1) / 0.8 * dim - 0.5
+    for a in range(3):
+        s = np.float32(dims[a]) / np.float32(0.8)
+        t = np.float32(-0.1) * s - np.float32(0.5)
+        for m in (grid, og):
+            m.texture_to_index[5 * a] = s
+            m.texture_to_index[12 + a] = t
+            m.index_to_texture[5 * a] = np.float32(1.0) / s
+            m.index_to_texture[12 + a] = -t / s
+    n = ph.shape[0]
+    radius, scale = 0.02, 0.3
+    table = ctx.torch.zeros(ctx.fast_table_entries(grid, n), dtype=ctx.torch.int32, device=ctx.device)
+    srt = ctx.torch.zeros((n, 4), dtype=ctx.torch.float32, device=ctx.device)
+    out = ctx.torch.zeros(dims[0] * dims[1] * dims[2], dtype=ctx.torch.float32, device=ctx.device)
+    ctx.bin_fast(_t(ctx, ph), n, grid, table, srt)
+    ctx.gather_fast(srt, table, n, grid, radius, scale, out)
+    want = np.zeros(out.numel(), np.float32)
+    oracle.gather_fast(ph, n, og, radius, scale, want)
+    assert np.array_equal(bits(_n(out)), bits(want))
+    sp = np.zeros(out.numel(), np.float32)
+    oracle.splat(ph, n, og, radius, scale, sp)       # the reference formulation with the same matrices
+    np.testing.assert_allclose(_n(out), sp, rtol=1e-4, atol=ATOL_OF_MAX * float(sp.max()))

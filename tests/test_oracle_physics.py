@@ -164,3 +164,34 @@ def test_multiple_scattering_bookkeeping(oracle, cpm):
     # sentinel records carry (P.x, FLT_MAX, FLT_MAX); an absorbed photon's tracked power is FLT_MAX
     sent = ph[~stored]
     assert (sent[:, 4] == FLT_MAX).all() and (sent[:, 5] == FLT_MAX).all()
+
+
+def test_fast_formulation_restatement_matches_reference_semantics(oracle):
+    """cpmo_gather_fast (fixed-point sums, weight from d^2) against cpmo_gather (sequential fp32 sum, weight through
+    sqrt and division) and the sequential splat: the tolerance the GPU tests hold cpm_gather_fast to."""
+    rng = np.random.default_rng(17)
+    for dims, ch, rvox in [((24, 24, 24), 1, 0.866), ((20, 12, 28), 4, 1.3), ((16, 16, 16), 1, 1.9)]:
+        n = 20_000
+        ph = np.zeros((n, 8), np.float32)
+        ph[:, :3] = rng.random((n, 3), dtype=np.float32) * np.float32(1.2) - np.float32(0.1)
+        ph[:, 3:6] = rng.random((n, 3), dtype=np.float32) * np.float32(5.0)
+        s = rng.random(n) < 0.1
+        ph[s, :3] = np.float32(3.402823466e+38)
+        radius, scale = float(np.float32(rvox) / np.float32(dims[0])), 0.37
+        og = oracle.grid(dims, ch)
+        cells = dims[0] * dims[1] * dims[2]
+        shape = (cells,) if ch == 1 else (cells, 4)
+        fast = np.zeros(shape, np.float32)
+        oracle.gather_fast(ph, n, og, radius, scale, fast)
+        _, cs, srt = oracle.bin(ph, n, og)
+        exact = np.zeros(shape, np.float32)
+        oracle.gather(srt, cs, n, og, radius, scale, exact)
+        np.testing.assert_allclose(fast, exact, rtol=2e-5, atol=1e-5 * float(exact.max()))
+        sp = np.zeros(shape, np.float32)
+        oracle.splat(ph, n, og, radius, scale, sp)
+        np.testing.assert_allclose(fast, sp, rtol=2e-5, atol=1e-5 * float(sp.max()))
+        # order-free: any permutation of the photons gives the same bits
+        perm = rng.permutation(n)
+        again = np.zeros(shape, np.float32)
+        oracle.gather_fast(np.ascontiguousarray(ph[perm]), n, og, radius, scale, again)
+        assert np.array_equal(fast.view(np.uint32), again.view(np.uint32))
