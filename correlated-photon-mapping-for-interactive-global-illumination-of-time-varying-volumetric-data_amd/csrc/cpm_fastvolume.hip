@@ -34,8 +34,11 @@ constexpr int kCountItems = 4;     // photons per thread of fast_count_kernel (1
 constexpr int kCountTile = 1024 * kCountItems;
 constexpr int kMaxBricks = 16384;  // LDS histogram of fast_count_kernel: 64 KiB
 
-// table layout (u32 entries): [0, nb] brick starts | 4 meta | [nb+5, 2nb+5] item starts | items
+// table layout (u32 entries): [0, nb] brick starts | 4 meta | [nb+5, 2nb+5] item starts | work items, 4 words each
+// (brick, first record, end record, 0), 16-byte aligned
 constexpr int kMetaMaxPow = 0, kMetaItems = 1;
+// accumulator behind the scratch histogram (zero between calls, like the histogram): max |power| bits
+constexpr int kAccMaxPow = 0;
 
 struct BrickLayout {
     int lx, ly, lz;        // log2 brick size (voxels)
@@ -46,7 +49,7 @@ struct BrickLayout {
 };
 CPM_DEV uint32_t off_meta(const BrickLayout& L) { return (uint32_t)L.nb + 1u; }
 CPM_DEV uint32_t off_item_start(const BrickLayout& L) { return (uint32_t)L.nb + 5u; }
-CPM_DEV uint32_t off_items(const BrickLayout& L) { return 2u * (uint32_t)L.nb + 6u; }
+CPM_DEV uint32_t off_items(const BrickLayout& L) { return (2u * (uint32_t)L.nb + 6u + 3u) & ~3u; }
 
 __host__ int make_grid_dev_fast(cpm_ctx* ctx, const cpm_grid_desc* g, GridDev& G) {
     if (!g) return set_error(ctx, CPM_ERR_INVALID_ARGUMENT, "grid", "null grid desc");
@@ -87,8 +90,11 @@ __host__ bool brick_reach(const GridDev& G, float radius, BrickLayout& L) {
     return true;
 }
 
+__host__ size_t max_items_for(const BrickLayout& L, int n) {
+    return (size_t)(n < L.nb ? n : L.nb) + (size_t)div_up(n > 0 ? n : 1, kFastChunk);
+}
 __host__ size_t table_entries(const BrickLayout& L, int n) {
-    return 2 * (size_t)L.nb + 6 + (size_t)L.nb + (size_t)div_up(n > 0 ? n : 1, kFastChunk);
+    return (((size_t)2 * L.nb + 6 + 3) & ~(size_t)3) + 4 * max_items_for(L, n);
 }
 __host__ int ceil_log2(long long n) { int b = 1; while (b < 62 && (1ll << b) < n) ++b; return b; }
 
@@ -114,68 +120,14 @@ CPM_DEV float fixed_scale(float maxpow, float k, int n_log2) {
     return __uint_as_float((uint32_t)(sh + 127) << 23);
 }
 
-template <int CH>
-__global__ __launch_bounds__(1024) void fast_count_kernel(const float* __restrict__ photons, int n, GridDev G, BrickLayout L,
-                                                          uint32_t* __restrict__ hist, uint32_t* __restrict__ rank,
-                                                          uint32_t* __restrict__ maxpow) {
-    extern __shared__ uint32_t s_hist[];
-    const int t = threadIdx.x;
-    for (int b = t; b < L.nb; b += 1024) s_hist[b] = 0u;
-    __syncthreads();
-    const float4* __restrict__ ph = reinterpret_cast<const float4*>(photons);
-    uint32_t key[kCountItems], lr[kCountItems];
-    float mp = 0.f;
-#pragma unroll
-    for (int k = 0; k < kCountItems; ++k) {
-        const long long i = (long long)blockIdx.x * kCountTile + k * 1024 + t;
-        key[k] = 0xffffffffu; lr[k] = 0u;
-        if (i < n) {
-            const float4 a = ph[2 * i];
-            if (!is_sentinel(a)) {
-                key[k] = brick_key(G, L, a);
-                lr[k] = atomicAdd(&s_hist[key[k]], 1u);
-                mp = max_(mp, __builtin_fabsf(a.w));
-                if (CH == 4) { const float4 b = ph[2 * i + 1]; mp = max_(mp, max_(__builtin_fabsf(b.x), __builtin_fabsf(b.y))); }
-            }
-        }
-    }
-    __syncthreads();
-    // one returning global atomic per non-empty (workgroup, brick) pair: the run's offset inside the brick
-    for (int b = t; b < L.nb; b += 1024) {
-        const uint32_t c = s_hist[b];
-        if (c) s_hist[b] = atomicAdd(&hist[b], c);
-    }
-    __syncthreads();
-#pragma unroll
-    for (int k = 0; k < kCountItems; ++k) {
-        const long long i = (long long)blockIdx.x * kCountTile + k * 1024 + t;
-        if (i < n) rank[i] = key[k] != 0xffffffffu ? s_hist[key[k]] + lr[k] : 0xffffffffu;
-    }
-    // max |power| (a finite, non-negative float orders like its bit pattern); NaN / inf powers are ignored.
-    // One atomic per workgroup at most, and none once the running maximum has reached this workgroup's.
-    if (!(mp <= kFltMax)) mp = 0.f;
-    for (int off = 32; off > 0; off >>= 1) mp = max_(mp, __shfl_xor(mp, off, 64));
-    __shared__ float s_mp[16];
-    if ((t & 63) == 0) s_mp[t >> 6] = mp;
-    __syncthreads();
-    if (t == 0) {
-        float m = s_mp[0];
-#pragma unroll
-        for (int w = 1; w < 16; ++w) m = max_(m, s_mp[w]);
-        const uint32_t mb = __float_as_uint(m);
-        if (m > 0.f && __hip_atomic_load(maxpow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < mb) atomicMax(maxpow, mb);
-    }
-}
-
-// one workgroup: exclusive scans of the brick counts (-> brick starts) and of the bricks' chunk counts (-> item
-// starts), the item list, the totals; clears the histogram for the next call
-__global__ __launch_bounds__(1024) void fast_scan_kernel(uint32_t* __restrict__ hist, BrickLayout L, uint32_t* __restrict__ table) {
-    __shared__ uint32_t s_c[16], s_i[16];
+// Exclusive scans of the brick counts (-> brick starts) and of the bricks' chunk counts (-> item starts), the work
+// items, the totals.  One 1024-thread workgroup; `counts` are in LDS.
+CPM_DEV void fast_scan(const uint32_t* counts, const BrickLayout& L, uint32_t* __restrict__ table, uint32_t* s_c, uint32_t* s_i) {
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int per = (L.nb + 1023) / 1024;
     const int b0 = t * per, b1 = min(b0 + per, L.nb);
     uint32_t c = 0, it = 0;
-    for (int b = b0; b < b1; ++b) { const uint32_t h = hist[b]; c += h; it += (h + kFastChunk - 1) / kFastChunk; }
+    for (int b = b0; b < b1; ++b) { const uint32_t h = counts[b]; c += h; it += (h + kFastChunk - 1) / kFastChunk; }
     uint32_t ci = c, ii = it;
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) {
@@ -190,16 +142,98 @@ __global__ __launch_bounds__(1024) void fast_scan_kernel(uint32_t* __restrict__ 
     uint32_t ac = bc + ci - c, ai = bi + ii - it;  // exclusive prefixes of this thread's first brick
     uint32_t* __restrict__ bstart = table;
     uint32_t* __restrict__ istart = table + off_item_start(L);
-    uint32_t* __restrict__ items = table + off_items(L);
+    uint4* __restrict__ items = reinterpret_cast<uint4*>(table + off_items(L));
     for (int b = b0; b < b1; ++b) {
-        const uint32_t h = hist[b];
-        hist[b] = 0u;
+        const uint32_t h = counts[b];
         bstart[b] = ac; istart[b] = ai;
         const uint32_t nc = (h + kFastChunk - 1) / kFastChunk;
-        for (uint32_t q = 0; q < nc; ++q) items[ai + q] = (uint32_t)b;
+        for (uint32_t q = 0; q < nc; ++q)
+            items[ai + q] = make_uint4((uint32_t)b, ac + q * (uint32_t)kFastChunk, min(ac + (q + 1u) * (uint32_t)kFastChunk, ac + h), 0u);
         ac += h; ai += nc;
     }
     if (t == 0) { bstart[L.nb] = tc; istart[L.nb] = ti; table[off_meta(L) + kMetaItems] = ti; }
+}
+
+// bin, launch 1 of 3.  Per workgroup (1024 threads, 4096 photons): brick keys, a histogram in LDS whose returning
+// ds_add gives every photon its rank inside its (workgroup, brick) run, then ONE returning global atomic per non-empty
+// (workgroup, brick) pair: the run's offset inside the brick.  rank = offset + local rank: an unstable counting sort.
+template <int CH>
+__global__ __launch_bounds__(1024) void fast_count_kernel(const float* __restrict__ photons, int n, GridDev G, BrickLayout L,
+                                                          uint32_t* __restrict__ hist, uint32_t* __restrict__ acc,
+                                                          uint32_t* __restrict__ rank) {
+    extern __shared__ uint32_t s_hist[];
+    __shared__ float s_mp[16];
+    const int t = threadIdx.x;
+    for (int b = t; b < L.nb; b += 1024) s_hist[b] = 0u;
+    __syncthreads();
+    const float4* __restrict__ ph = reinterpret_cast<const float4*>(photons);
+    uint32_t key[kCountItems], lr[kCountItems];
+    float mp = 0.f;
+    float4 a[kCountItems];
+#pragma unroll
+    for (int k = 0; k < kCountItems; ++k) {  // the loads first, all in flight together
+        const long long i = (long long)blockIdx.x * kCountTile + k * 1024 + t;
+        a[k] = make_float4(kFltMax, kFltMax, kFltMax, 0.f);
+        if (i < n) a[k] = ph[2 * i];
+    }
+#pragma unroll
+    for (int k = 0; k < kCountItems; ++k) {
+        const long long i = (long long)blockIdx.x * kCountTile + k * 1024 + t;
+        key[k] = 0xffffffffu; lr[k] = 0u;
+        if (i < n && !is_sentinel(a[k])) {
+            key[k] = brick_key(G, L, a[k]);
+            lr[k] = atomicAdd(&s_hist[key[k]], 1u);
+            mp = max_(mp, __builtin_fabsf(a[k].w));
+            if (CH == 4) { const float4 b = ph[2 * i + 1]; mp = max_(mp, max_(__builtin_fabsf(b.x), __builtin_fabsf(b.y))); }
+        }
+    }
+    // max |power| of the workgroup (a finite, non-negative float orders like its bit pattern); NaN / inf are ignored
+    if (!(mp <= kFltMax)) mp = 0.f;
+    for (int off = 32; off > 0; off >>= 1) mp = max_(mp, __shfl_xor(mp, off, 64));
+    if ((t & 63) == 0) s_mp[t >> 6] = mp;
+    __syncthreads();
+    // the runs' offsets: four bins at a time, the atomics of a group issued together
+    for (int b = t; b < L.nb; b += 4 * 1024) {
+        uint32_t c[4], base[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { const int bb = b + q * 1024; c[q] = bb < L.nb ? s_hist[bb] : 0u; }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { base[q] = 0u; if (c[q]) base[q] = atomicAdd(&hist[b + q * 1024], c[q]); }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) if (c[q]) s_hist[b + q * 1024] = base[q];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < kCountItems; ++k) {
+        const long long i = (long long)blockIdx.x * kCountTile + k * 1024 + t;
+        if (i < n) rank[i] = key[k] != 0xffffffffu ? s_hist[key[k]] + lr[k] : 0xffffffffu;
+    }
+    // one atomic per workgroup at most, and none once the running maximum has reached this workgroup's
+    if (t == 0) {
+        float m = s_mp[0];
+#pragma unroll
+        for (int w = 1; w < 16; ++w) m = max_(m, s_mp[w]);
+        const uint32_t mb = __float_as_uint(m);
+        if (m > 0.f && __hip_atomic_load(&acc[kAccMaxPow], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < mb) atomicMax(&acc[kAccMaxPow], mb);
+    }
+}
+
+// bin, launch 2 of 3: one workgroup turns the finished histogram into the table -- brick starts, work items, max |power|
+// -- and puts histogram and accumulator back to zero for the next call, so that no memset is needed in steady state.
+// (Folding this into the count kernel's last-arriving workgroup was built and measured: 27 us against 11 + 6.3 us --
+// the ticket is one more memory-side round trip behind every workgroup's atomics, and the tail runs on one CU either way.)
+__global__ __launch_bounds__(1024) void fast_scan_kernel(uint32_t* __restrict__ hist, uint32_t* __restrict__ acc, BrickLayout L,
+                                                         uint32_t* __restrict__ table) {
+    extern __shared__ uint32_t s_hist[];
+    __shared__ uint32_t s_c[16], s_i[16];
+    const int t = threadIdx.x;
+    for (int b = t; b < L.nb; b += 1024) { s_hist[b] = hist[b]; hist[b] = 0u; }
+    if (t == 0) {
+        table[off_meta(L) + kMetaMaxPow] = acc[kAccMaxPow];
+        acc[kAccMaxPow] = 0u;
+    }
+    __syncthreads();
+    fast_scan(s_hist, L, table, s_c, s_i);
 }
 
 template <int CH>
@@ -277,10 +311,8 @@ __global__ __launch_bounds__(kTileThreads) void fast_tile_kernel(const float* __
     const uint32_t item = blockIdx.x;
     if (item >= table[off_meta(L) + kMetaItems]) return;  // the launch covers the worst case; most workgroups end here
     const int t = threadIdx.x;
-    const uint32_t b = table[off_items(L) + item];
-    const uint32_t chunk = item - table[off_item_start(L) + b];
-    const uint32_t j0 = table[b] + chunk * (uint32_t)kFastChunk;
-    const uint32_t j1 = min(j0 + (uint32_t)kFastChunk, table[b + 1]);
+    const uint4 desc = reinterpret_cast<const uint4*>(table + off_items(L))[item];  // (brick, first record, end record, -)
+    const uint32_t b = desc.x, j0 = desc.y, j1 = desc.z;
     const int words = CH3 * L.tile;
     for (int w = t; w < words; w += kTileThreads) s_tile[w] = 0ll;
     const int bx = (int)(b % (uint32_t)L.nbx), by = (int)((b / (uint32_t)L.nbx) % (uint32_t)L.nby), bz = (int)(b / (uint32_t)(L.nbx * L.nby));
@@ -428,31 +460,32 @@ int cpm_bin_fast(cpm_ctx* ctx, const float* photons8, int n, const cpm_grid_desc
     hipStream_t s = (hipStream_t)stream;
     BrickLayout L;
     brick_shape(grid->dims, L);
-    // histogram (nb, kept zero between calls by the scan kernel) + per-photon ranks
+    // scratch: histogram (nb) + accumulators (4) -- all zero between calls, restored by the last workgroup of the count
+    // kernel -- then the per-photon ranks
     const size_t hist_words = (size_t)L.nb + 4;
     const bool had = ctx->scratch_bytes[CPM_SCR_FAST_BIN] >= (hist_words + (size_t)(n > 0 ? n : 1)) * 4;
     uint32_t* hist = (uint32_t*)scratch(ctx, CPM_SCR_FAST_BIN, (hist_words + (size_t)(n > 0 ? n : 1)) * 4);
     if (!hist) return CPM_ERR_OUT_OF_MEMORY;
-    if (!had || ctx->fast_hist_words != hist_words) {  // new arena or another grid: the histogram's zero state is not established
+    if (!had || ctx->fast_hist_words != hist_words)  // new arena or another brick count: the zero state is not established
         CPM_HIP_CHECK(ctx, hipMemsetAsync(hist, 0, hist_words * 4, s));
-    }
+    uint32_t* acc = hist + L.nb;
     uint32_t* rank = hist + hist_words;
-    ctx->fast_hist_words = 0;  // re-established below once the scan kernel (which clears the histogram) is enqueued
-    // meta: max |power| is an atomicMax target
-    CPM_HIP_CHECK(ctx, hipMemsetAsync(brick_table + (size_t)L.nb + 1, 0, 4 * sizeof(uint32_t), s));
+    ctx->fast_hist_words = 0;  // re-established below once the kernel that restores the zero state is enqueued
     if (n > 0) {
         const dim3 cgrid((unsigned)div_up(n, kCountTile));
         const size_t lds = (size_t)L.nb * 4;
         if (G.channels == 1) {
             rc = allow_lds(ctx, fast_count_kernel<1>, lds); if (rc) return rc;
-            CPM_LAUNCH(ctx, fast_count_kernel<1>, cgrid, dim3(1024), lds, s, photons8, n, G, L, hist, rank, brick_table + (size_t)L.nb + 1 + kMetaMaxPow);
+            CPM_LAUNCH(ctx, fast_count_kernel<1>, cgrid, dim3(1024), lds, s, photons8, n, G, L, hist, acc, rank);
         } else {
             rc = allow_lds(ctx, fast_count_kernel<4>, lds); if (rc) return rc;
-            CPM_LAUNCH(ctx, fast_count_kernel<4>, cgrid, dim3(1024), lds, s, photons8, n, G, L, hist, rank, brick_table + (size_t)L.nb + 1 + kMetaMaxPow);
+            CPM_LAUNCH(ctx, fast_count_kernel<4>, cgrid, dim3(1024), lds, s, photons8, n, G, L, hist, acc, rank);
         }
         CPM_LAUNCH_CHECK(ctx, "fast_count_kernel");
     }
-    CPM_LAUNCH(ctx, fast_scan_kernel, dim3(1), dim3(1024), 0, s, hist, L, brick_table);
+    rc = allow_lds(ctx, fast_scan_kernel, (size_t)L.nb * 4);
+    if (rc) return rc;
+    CPM_LAUNCH(ctx, fast_scan_kernel, dim3(1), dim3(1024), (size_t)L.nb * 4, s, hist, acc, L, brick_table);
     CPM_LAUNCH_CHECK(ctx, "fast_scan_kernel");
     ctx->fast_hist_words = hist_words;
     if (n > 0) {
@@ -483,7 +516,7 @@ int cpm_gather_fast(cpm_ctx* ctx, const float* sorted_pos_power, const uint32_t*
     const size_t tile_bytes = (size_t)ch3 * (size_t)L.tile * 8;
     if (tile_bytes > 160 * 1024 - 1024)
         return set_error(ctx, CPM_ERR_UNSUPPORTED, "cpm_gather_fast", "tile does not fit the LDS: use cpm_bin + cpm_gather");
-    const size_t max_items = (size_t)(n < L.nb ? n : L.nb) + (size_t)div_up(n > 0 ? n : 1, kFastChunk);
+    const size_t max_items = max_items_for(L, n);
     long long* slabs = (long long*)scratch(ctx, CPM_SCR_FAST_SLABS, max_items * tile_bytes);
     if (!slabs) return CPM_ERR_OUT_OF_MEMORY;
     const float k = kInv4Pi * scale;

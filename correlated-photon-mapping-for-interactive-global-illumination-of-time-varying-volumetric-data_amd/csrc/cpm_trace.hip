@@ -188,41 +188,68 @@ CPM_DEV float woodcock(const VolDev& V, const float* lut, float wf, float m1, fl
 }
 
 template <int DT>
-__global__ __launch_bounds__(256) void trace_kernel(const TraceArgs A) {
+__global__ __launch_bounds__(256, 8) void trace_kernel(const TraceArgs A) {
     extern __shared__ float lds[];
+    // One decoded / re-encoded direction per workgroup: a directional light gives every sample the same (theta, phi),
+    // and decodeDirection + encodeDirection (two sincos, acos, atan2, a division: ~200 instructions) is a pure function of
+    // those two words.  Thread 0 evaluates it for ITS sample; a wave whose lanes all carry the same bit patterns takes
+    // the shared result (the same operations on the same inputs: the same bits), any other wave evaluates per lane.
+    __shared__ float s_dir[8];
     float* lut = lds;
     float* luts = lds;
-    for (int i = threadIdx.x; i < A.tf_width; i += blockDim.x) lut[i] = A.tf_alpha[i];
-    if (A.tfs_alpha != A.tf_alpha) {
-        luts = lds + A.tf_width;
-        for (int i = threadIdx.x; i < A.tf_width; i += blockDim.x) luts[i] = A.tfs_alpha[i];
-    }
-    __syncthreads();
 
-    int gid = blockIdx.x * blockDim.x + threadIdx.x;
-    if (gid >= A.n_threads) return;
+    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
     int threadId = gid;
-    if (A.recompute_indices) {  // -D PHOTON_RECOMPUTATION (photontracer.cl:97-106)
+    bool live = gid < A.n_threads;
+    if (live && A.recompute_indices) {  // -D PHOTON_RECOMPUTATION (photontracer.cl:97-106)
         threadId = (int)A.recompute_indices[gid] - A.p.photon_offset;
-        if (threadId < 0 || threadId >= A.p.n_light_samples) return;
+        live = threadId >= 0 && threadId < A.p.n_light_samples;
     }
     const int photonOffset = A.p.photon_offset;
     const uint32_t maxInteractions = (uint32_t)A.p.max_interactions;
     const size_t totalPhotons = (size_t)A.p.total_photons;
     uint2* rng = reinterpret_cast<uint2*>(A.rng);
-    uint2 rs = rng[photonOffset + threadId];
+    // this lane's inputs, requested before the LUT is staged so that the loads overlap it
+    float4 l0 = make_float4(0.f, 0.f, 0.f, 0.f), l1 = l0;
+    float2 ip = make_float2(0.f, -1.f);
+    uint2 rs = make_uint2(0u, 0u);
+    if (live) {
+        const float4* lsp = reinterpret_cast<const float4*>(A.light_samples) + 2 * (size_t)threadId;
+        l0 = lsp[0]; l1 = lsp[1];
+        ip = reinterpret_cast<const float2*>(A.isect)[threadId];
+        rs = rng[photonOffset + threadId];
+    }
+    for (int i = threadIdx.x; i < A.tf_width; i += blockDim.x) lut[i] = A.tf_alpha[i];
+    if (A.tfs_alpha != A.tf_alpha) {
+        luts = lds + A.tf_width;
+        for (int i = threadIdx.x; i < A.tf_width; i += blockDim.x) luts[i] = A.tfs_alpha[i];
+    }
+    if (threadIdx.x == 0) {
+        const f3 d0 = decode_direction_(l1.z, l1.w);
+        float t0, p0;
+        encode_direction_(d0, t0, p0);
+        s_dir[0] = l1.z; s_dir[1] = l1.w; s_dir[2] = d0.x; s_dir[3] = d0.y; s_dir[4] = d0.z; s_dir[5] = t0; s_dir[6] = p0;
+    }
+    __syncthreads();
+    if (!live) return;
+
     uint32_t rx = rs.x, rc = rs.y;
     uint32_t nInteractions = 0;
     unsigned steps = 0;
 
-    const float4* lsp = reinterpret_cast<const float4*>(A.light_samples) + 2 * (size_t)threadId;
-    float4 l0 = lsp[0], l1 = lsp[1];
     f3 origin = { l0.x, l0.y, l0.z };
     float mi = (float)maxInteractions;
     f3 power = { l0.w, l1.x, l1.y };
     if (maxInteractions != 1) { power.x = power.x / mi; power.y = power.y / mi; power.z = power.z / mi; }  // x / 1.0f == x
-    f3 direction = decode_direction_(l1.z, l1.w);
-    float2 ip = reinterpret_cast<const float2*>(A.isect)[threadId];
+    f3 direction;
+    float th, ph;  // encodeDirection(direction), kept current: re-evaluated only where the direction changes
+    if (__all(__float_as_uint(l1.z) == __float_as_uint(s_dir[0]) && __float_as_uint(l1.w) == __float_as_uint(s_dir[1]))) {
+        direction.x = s_dir[2]; direction.y = s_dir[3]; direction.z = s_dir[4];
+        th = s_dir[5]; ph = s_dir[6];
+    } else {
+        direction = decode_direction_(l1.z, l1.w);
+        encode_direction_(direction, th, ph);
+    }
     float tStart = ip.x, tEnd = ip.y;
     bool scatterEvent = tStart < tEnd;
 
@@ -239,6 +266,7 @@ __global__ __launch_bounds__(256) void trace_kernel(const TraceArgs A) {
             float u1 = rand01_(rx, rc), u2 = rand01_(rx, rc);
             float pdf;
             direction = phase_sample(A.p.shading_type, A.p.material[0], direction, u1, u2, &pdf);
+            encode_direction_(direction, th, ph);
             scatterEvent = ray_box_(A.bmin, A.bmax, origin, direction, tStart, tEnd);
             power.x = power.x / pdf; power.y = power.y / pdf; power.z = power.z / pdf;
             tStart = tStart + 0.5f * A.p.step_size;
@@ -253,22 +281,27 @@ __global__ __launch_bounds__(256) void trace_kernel(const TraceArgs A) {
             origin.y = fma_(t, direction.y, origin.y);
             origin.z = fma_(t, direction.z, origin.z);
             size_t photonId = (size_t)photonOffset + nInteractions * totalPhotons + (size_t)threadId;
-            float th, ph;
-            encode_direction_(direction, th, ph);
+            // (th, ph) = encodeDirection(direction) (photontracer.cl:167): current, see above.
             // The reference samples the volume and the TF again at the collision point
             // (photontracer.cl:170-173).  The accepted Woodcock iteration sampled exactly that point --
             // fma(t, d, o) with the same t, d, o -- so its volume sample and alpha ARE those values.
-            float scatW = (luts == lut) ? colorW : sample_alpha(luts, wf, m1, m2, volumeSample);
-            float scatteringAlbedo = scatW / (scatW + colorW);
             float dv = max_(colorW, 0.01f);
             power.x = power.x / dv; power.y = power.y / dv; power.z = power.z / dv;
             ++nInteractions;
-            if (nInteractions < maxInteractions && rand01_(rx, rc) < scatteringAlbedo) {
+            bool scatter = false;
+            float scatteringAlbedo = 0.f;
+            if (nInteractions < maxInteractions) {  // the albedo is only read behind this test (photontracer.cl:179)
+                float scatW = (luts == lut) ? colorW : sample_alpha(luts, wf, m1, m2, volumeSample);
+                scatteringAlbedo = scatW / (scatW + colorW);
+                scatter = rand01_(rx, rc) < scatteringAlbedo;
+            }
+            if (scatter) {
                 power.x *= scatteringAlbedo; power.y *= scatteringAlbedo; power.z *= scatteringAlbedo;
                 write_photon(A.photons, photonId, origin, power, th, ph);
                 tStart = 0.f; tEnd = kFltMax;
                 float u1 = rand01_(rx, rc), u2 = rand01_(rx, rc);
                 direction = phase_sample(A.p.shading_type, A.p.material[0], direction, u1, u2, nullptr);
+                encode_direction_(direction, th, ph);
                 scatterEvent = ray_box_(A.bmin, A.bmax, origin, direction, tStart, tEnd);
                 tStart = tStart + 0.5f * A.p.step_size;
             } else {
@@ -278,9 +311,7 @@ __global__ __launch_bounds__(256) void trace_kernel(const TraceArgs A) {
             }
         }
     }
-    float th, ph;
-    encode_direction_(direction, th, ph);
-    for (uint32_t i = nInteractions; i < maxInteractions; ++i) {  // photontracer.cl:199-209
+    for (uint32_t i = nInteractions; i < maxInteractions; ++i) {  // photontracer.cl:199-209 (th, ph: the current direction)
         size_t photonId = (size_t)photonOffset + i * totalPhotons + (size_t)threadId;
         f3 p = { kFltMax, kFltMax, kFltMax };
         f3 pw = { power.x, kFltMax, kFltMax };
@@ -360,8 +391,8 @@ int cpm_trace(cpm_ctx* ctx, const cpm_volume* vol, const cpm_tf* tf, const cpm_t
     A.step_counter = g_step_counter;
 
     size_t lds = (size_t)tf->width * sizeof(float) * (A.tfs_alpha != A.tf_alpha ? 2 : 1);
-    dim3 grid(div_up(n_threads, 256)), block(256);
     hipStream_t s = (hipStream_t)stream;
+    dim3 grid(div_up(n_threads, 256)), block(256);
     switch (d.dtype) {
         case CPM_U8: CPM_LAUNCH(ctx, trace_kernel<CPM_U8>, grid, block, lds, s, A); break;
         case CPM_U16: CPM_LAUNCH(ctx, trace_kernel<CPM_U16>, grid, block, lds, s, A); break;
