@@ -39,6 +39,8 @@ ABI_SYMBOLS = [
     "cpm_photon_importance", "cpm_photon_importance_equal", "cpm_reset_importance",
     "cpm_select_recompute", "cpm_select_changed",
     "cpm_mix_buffers", "cpm_volume_mix",
+    "cpm_comm_get_unique_id", "cpm_comm_create", "cpm_comm_create_all", "cpm_comm_destroy", "cpm_comm_rank", "cpm_comm_size",
+    "cpm_allreduce_grid", "cpm_reduce_grid", "cpm_allreduce_grids", "cpm_allreduce_grid_bricks",
 ]
 
 
@@ -132,6 +134,16 @@ def load_library() -> C.CDLL:
         "cpm_select_changed": (i32, [vp, vp, sz, vp, vp, vp]),
         "cpm_mix_buffers": (i32, [vp, vp, vp, f32, sz, i32, vp, vp]),
         "cpm_volume_mix": (i32, [vp, vp, vp, f32, vp, vp]),
+        "cpm_comm_get_unique_id": (i32, [vp, vp]),
+        "cpm_comm_create": (i32, [vp, vp, i32, i32, P(vp)]),
+        "cpm_comm_create_all": (i32, [P(vp), i32, P(vp)]),
+        "cpm_comm_destroy": (None, [vp]),
+        "cpm_comm_rank": (i32, [vp]),
+        "cpm_comm_size": (i32, [vp]),
+        "cpm_allreduce_grid": (i32, [vp, vp, vp, sz, vp]),
+        "cpm_reduce_grid": (i32, [vp, vp, vp, vp, sz, i32, vp]),
+        "cpm_allreduce_grids": (i32, [P(vp), P(vp), P(vp), sz, P(vp), i32]),
+        "cpm_allreduce_grid_bricks": (i32, [vp, vp, vp, vp, P(GridDesc), vp, P(u32), vp]),
         "cpm_volume_device_data": (vp, [vp, P(sz)]),
         "cpm_volume_download": (i32, [vp, vp, vp, vp]),
         # include/cpm/cpm_profile.h (measurement hooks)
@@ -396,6 +408,31 @@ class Context:
         self._check(self.lib.cpm_gather_bricks(self.h, self._ptr(sorted_pos_power), self._ptr(cell_start), n, C.byref(grid), radius,
                                                scale, self._ptr(brick_mask), self._ptr(out), self._stream()))
 
+    # -- multi-GPU: the one exchange step (RCCL through the C-ABI)
+    def comm_unique_id(self) -> bytes:
+        buf = (C.c_uint8 * 128)()
+        self._check(self.lib.cpm_comm_get_unique_id(self.h, buf))
+        return bytes(buf)
+
+    def comm_create(self, unique_id: bytes, rank: int, n_ranks: int) -> "Comm":
+        h = C.c_void_p()
+        buf = (C.c_uint8 * 128).from_buffer_copy(unique_id)
+        self._check(self.lib.cpm_comm_create(self.h, buf, rank, n_ranks, C.byref(h)))
+        return Comm(self, h)
+
+    def allreduce_grid(self, comm: "Comm", grid):
+        self._check(self.lib.cpm_allreduce_grid(self.h, comm.h, self._ptr(grid), grid.numel(), self._stream()))
+
+    def reduce_grid(self, comm: "Comm", send, recv, root: int):
+        self._check(self.lib.cpm_reduce_grid(self.h, comm.h, self._ptr(send), self._ptr(recv) if recv is not None else None,
+                                             send.numel(), root, self._stream()))
+
+    def allreduce_grid_bricks(self, comm: "Comm", partial, total, grid: GridDesc, brick_mask) -> int:
+        n_union = C.c_uint32(0)
+        self._check(self.lib.cpm_allreduce_grid_bricks(self.h, comm.h, self._ptr(partial), self._ptr(total), C.byref(grid),
+                                                       self._ptr(brick_mask), C.byref(n_union), self._stream()))
+        return int(n_union.value)
+
     # -- temporal interpolation
     def mix_buffers(self, x, y, a, out, kind=None):
         """out = mix(x, y, a); float32 tensors, or (n, 2) uint16 min/max pairs (passed as int16/uint16 tensors)."""
@@ -446,6 +483,32 @@ class Context:
     def select_recompute(self, importances, indices_out, n_changed):
         self._check(self.lib.cpm_select_recompute(self.h, self._ptr(importances), importances.numel(), self._ptr(indices_out),
                                                   self._ptr(n_changed), self._stream()))
+
+
+class Comm:
+    """One end of the photon-shard communicator (cpm_comm): see cpm.h, multi-GPU."""
+
+    def __init__(self, ctx: "Context", h):
+        self.ctx, self.h = ctx, h
+
+    @property
+    def rank(self):
+        return int(self.ctx.lib.cpm_comm_rank(self.h))
+
+    @property
+    def size(self):
+        return int(self.ctx.lib.cpm_comm_size(self.h))
+
+    def close(self):
+        if self.h:
+            self.ctx.lib.cpm_comm_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class Volume:

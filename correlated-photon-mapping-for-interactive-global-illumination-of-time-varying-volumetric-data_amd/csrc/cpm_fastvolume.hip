@@ -29,6 +29,7 @@ using namespace cpm;
 namespace {
 
 constexpr int kTileThreads = 1024;
+constexpr int kCombineThreads = 128;
 constexpr int kFastChunk = 4096;   // photons per tile-gather work item (1024 threads x 4)
 constexpr int kCountItems = 4;     // photons per thread of fast_count_kernel (1024 threads)
 constexpr int kCountTile = 1024 * kCountItems;
@@ -302,49 +303,55 @@ CPM_DEV void tile_record(const GridDev& G, float4 a, float pg, float pb, int ox,
             }
 }
 
+// gather, launch 1 of 2.  A fixed grid of resident workgroups (two per CU) walks the work items: the number of items
+// is only known on the device, and a launch sized for the worst case (bricks + chunks) spent its time dispatching
+// thousands of 16-wave workgroups that found nothing to do.
 template <int MAXC, int CH>
 __global__ __launch_bounds__(kTileThreads) void fast_tile_kernel(const float* __restrict__ sorted, const uint32_t* __restrict__ table, GridDev G,
                                                         BrickLayout L, float radius, float k, int n_log2,
                                                         long long* __restrict__ slabs) {
     extern __shared__ long long s_tile[];
-    constexpr int CH3 = CH == 4 ? 3 : 1, STRIDE = CH == 4 ? 2 : 1;
-    const uint32_t item = blockIdx.x;
-    if (item >= table[off_meta(L) + kMetaItems]) return;  // the launch covers the worst case; most workgroups end here
+    constexpr int CH3 = CH == 4 ? 3 : 1, STRIDE = CH == 4 ? 2 : 1, PER = kFastChunk / kTileThreads;
+    const uint32_t n_items = table[off_meta(L) + kMetaItems];
     const int t = threadIdx.x;
-    const uint4 desc = reinterpret_cast<const uint4*>(table + off_items(L))[item];  // (brick, first record, end record, -)
-    const uint32_t b = desc.x, j0 = desc.y, j1 = desc.z;
     const int words = CH3 * L.tile;
-    for (int w = t; w < words; w += kTileThreads) s_tile[w] = 0ll;
-    const int bx = (int)(b % (uint32_t)L.nbx), by = (int)((b / (uint32_t)L.nbx) % (uint32_t)L.nby), bz = (int)(b / (uint32_t)(L.nbx * L.nby));
-    const int ox = (bx << L.lx) - L.hx, oy = (by << L.ly) - L.hy, oz = (bz << L.lz) - L.hz;
     const float rgx = radius * G.t2i.sx + 1e-3f, rgy = radius * G.t2i.sy + 1e-3f, rgz = radius * G.t2i.sz + 1e-3f;
     const float r2 = radius * radius, inv_r2 = 1.0f / r2;
     const float S = fixed_scale(__uint_as_float(table[off_meta(L) + kMetaMaxPow]), k, n_log2);
     const float4* __restrict__ rec = reinterpret_cast<const float4*>(sorted);
-    // all of this thread's records first (<= 4 independent 16-byte loads in flight), then the tile
-    float4 a[kFastChunk / kTileThreads], a2[kFastChunk / kTileThreads];
+    const uint4* __restrict__ items = reinterpret_cast<const uint4*>(table + off_items(L));
+    for (uint32_t item = blockIdx.x; item < n_items; item += gridDim.x) {
+        const uint4 desc = items[item];  // (brick, first record, end record, -)
+        const uint32_t b = desc.x, j0 = desc.y, j1 = desc.z;
+        // all of this thread's records first (independent 16-byte loads in flight), the tile is cleared meanwhile
+        float4 a[PER], a2[PER];
 #pragma unroll
-    for (int q = 0; q < kFastChunk / kTileThreads; ++q) {
-        const uint32_t j = j0 + (uint32_t)(q * kTileThreads + t);
-        a[q] = make_float4(0.f, 0.f, 0.f, 0.f); a2[q] = a[q];
-        if (j < j1) { a[q] = rec[STRIDE * (size_t)j]; if (CH == 4) a2[q] = rec[2 * (size_t)j + 1]; }
-    }
-    __syncthreads();
+        for (int q = 0; q < PER; ++q) {
+            const uint32_t j = j0 + (uint32_t)(q * kTileThreads + t);
+            a[q] = make_float4(0.f, 0.f, 0.f, 0.f); a2[q] = a[q];
+            if (j < j1) { a[q] = rec[STRIDE * (size_t)j]; if (CH == 4) a2[q] = rec[2 * (size_t)j + 1]; }
+        }
+        for (int w = t; w < words; w += kTileThreads) s_tile[w] = 0ll;
+        const int bx = (int)(b % (uint32_t)L.nbx), by = (int)((b / (uint32_t)L.nbx) % (uint32_t)L.nby), bz = (int)(b / (uint32_t)(L.nbx * L.nby));
+        const int ox = (bx << L.lx) - L.hx, oy = (by << L.ly) - L.hy, oz = (bz << L.lz) - L.hz;
+        __syncthreads();
 #pragma unroll
-    for (int q = 0; q < kFastChunk / kTileThreads; ++q) {
-        const uint32_t j = j0 + (uint32_t)(q * kTileThreads + t);
-        if (j < j1)
-            tile_record<MAXC, CH>(G, a[q], a2[q].x, a2[q].y, ox, oy, oz, L.tx, L.ty, L.tz, rgx, rgy, rgz, r2, inv_r2, k, S, s_tile, L.tile);
+        for (int q = 0; q < PER; ++q) {
+            const uint32_t j = j0 + (uint32_t)(q * kTileThreads + t);
+            if (j < j1)
+                tile_record<MAXC, CH>(G, a[q], a2[q].x, a2[q].y, ox, oy, oz, L.tx, L.ty, L.tz, rgx, rgy, rgz, r2, inv_r2, k, S, s_tile, L.tile);
+        }
+        __syncthreads();
+        long long* __restrict__ slab = slabs + (size_t)item * (size_t)words;
+        for (int w = t; w < words; w += kTileThreads) slab[w] = s_tile[w];
+        __syncthreads();  // the tile is cleared again at the top
     }
-    __syncthreads();
-    long long* __restrict__ slab = slabs + (size_t)item * (size_t)words;
-    for (int w = t; w < words; w += kTileThreads) slab[w] = s_tile[w];
 }
 
 // per voxel: integer sum of every slab that covers it (chunks of the own brick and of the <= 26 neighbours whose halo
 // reaches it), one rounding to float
 template <int CH>
-__global__ __launch_bounds__(256) void fast_combine_kernel(const long long* __restrict__ slabs, const uint32_t* __restrict__ table,
+__global__ __launch_bounds__(kCombineThreads) void fast_combine_kernel(const long long* __restrict__ slabs, const uint32_t* __restrict__ table,
                                                            GridDev G, BrickLayout L, float k, int n_log2, int accumulate,
                                                            float* __restrict__ out) {
     constexpr int CH3 = CH == 4 ? 3 : 1;
@@ -373,7 +380,7 @@ __global__ __launch_bounds__(256) void fast_combine_kernel(const long long* __re
     const float invS = 1.0f / S;  // a power of two: exact
     const int BX = 1 << L.lx, BY = 1 << L.ly, bvox = BX * BY * (1 << L.lz);
     const size_t words = (size_t)CH3 * (size_t)L.tile;
-    for (int v = t; v < bvox; v += 256) {
+    for (int v = t; v < bvox; v += kCombineThreads) {
         const int lx = v & (BX - 1), ly = (v >> L.lx) & (BY - 1), lz = v >> (L.lx + L.ly);
         const int gx = (bx << L.lx) + lx, gy = (by << L.ly) + ly, gz = (bz << L.lz) + lz;
         if (gx >= G.dx || gy >= G.dy || gz >= G.dz) continue;
@@ -523,7 +530,9 @@ int cpm_gather_fast(cpm_ctx* ctx, const float* sorted_pos_power, const uint32_t*
     const int n_log2 = ceil_log2(n > 2 ? n : 2);
     hipStream_t s = (hipStream_t)stream;
     if (n > 0) {
-        const dim3 tgrid((unsigned)max_items);
+        // resident workgroups: two of 1024 threads per CU, fewer when the worst case has fewer items
+        const size_t resident = (size_t)2 * (size_t)ctx->num_cus;
+        const dim3 tgrid((unsigned)(max_items < resident ? max_items : resident));
 #define CPM_TILE_LAUNCH(MAXC, CH)                                                                                        \
     do {                                                                                                                 \
         rc = allow_lds(ctx, fast_tile_kernel<MAXC, CH>, tile_bytes);                                                     \
@@ -540,9 +549,9 @@ int cpm_gather_fast(cpm_ctx* ctx, const float* sorted_pos_power, const uint32_t*
         CPM_LAUNCH_CHECK(ctx, "fast_tile_kernel");
     }
     if (G.channels == 1)
-        CPM_LAUNCH(ctx, fast_combine_kernel<1>, dim3((unsigned)L.nb), dim3(256), 0, s, slabs, brick_table, G, L, k, n_log2, accumulate, grid_out);
+        CPM_LAUNCH(ctx, fast_combine_kernel<1>, dim3((unsigned)L.nb), dim3(kCombineThreads), 0, s, slabs, brick_table, G, L, k, n_log2, accumulate, grid_out);
     else
-        CPM_LAUNCH(ctx, fast_combine_kernel<4>, dim3((unsigned)L.nb), dim3(256), 0, s, slabs, brick_table, G, L, k, n_log2, accumulate, grid_out);
+        CPM_LAUNCH(ctx, fast_combine_kernel<4>, dim3((unsigned)L.nb), dim3(kCombineThreads), 0, s, slabs, brick_table, G, L, k, n_log2, accumulate, grid_out);
     CPM_LAUNCH_CHECK(ctx, "fast_combine_kernel");
     return CPM_OK;
 }

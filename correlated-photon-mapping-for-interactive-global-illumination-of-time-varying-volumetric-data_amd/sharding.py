@@ -2,8 +2,14 @@
 
 Photon i depends only on light sample i, RNG stream i and the read-only volume / TF, so a rank
 simply owns a contiguous range of photon indices; every rank bins and gathers its photons into its
-own full-size irradiance grid and the grids are summed with ONE collective per frame
-(RCCL all-reduce over xGMI; backend "nccl" is RCCL on ROCm).  No other data-path communication.
+own full-size irradiance grid and the grids are summed with ONE collective per frame.  No other
+data-path communication.
+
+The collective goes through the C-ABI: ``cpm_allreduce_grid`` (RCCL over xGMI on the caller's stream,
+``include/cpm/cpm.h``), the call a C++ host makes.  ``torch.distributed`` only carries the 128-byte
+communicator id to the ranks (and the benchmark's barriers).  For the CPU tests (gloo, no GPU, no
+RCCL) the same classes run over ``TorchTransport``: identical sharding, buffering and waiting logic,
+``dist.all_reduce`` as the wire.
 """
 from __future__ import annotations
 
@@ -17,11 +23,71 @@ def shard_range(n_total: int, rank: int, world: int):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
-def allreduce_light_volume(grid, group=None):
-    """Sum the per-rank irradiance grids in place (no-op without an initialised process group)."""
-    import torch.distributed as dist
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
-        dist.all_reduce(grid, op=dist.ReduceOp.SUM, group=group)
+# --------------------------------------------------------------------------- transports
+
+class TorchTransport:
+    """all-reduce over torch.distributed (gloo in the CPU tests; any backend).  No-op for one rank."""
+
+    def __init__(self, group=None):
+        import torch.distributed as dist
+        self._dist, self.group = dist, group
+        self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+
+    def start(self, grid):
+        if self.world > 1:
+            return self._dist.all_reduce(grid, op=self._dist.ReduceOp.SUM, group=self.group, async_op=True)
+        return None
+
+    @staticmethod
+    def wait(handle):
+        if handle is not None:
+            handle.wait()
+
+
+class RcclTransport:
+    """all-reduce through the C-ABI (cpm_allreduce_grid) on a side stream of the rank's GPU.
+
+    The communicator id is created on rank 0 (cpm_comm_get_unique_id) and handed to the other ranks over
+    whatever the host has -- here one torch.distributed broadcast (any backend)."""
+
+    def __init__(self, ctx, rank: int, world: int, group=None):
+        import torch
+        import torch.distributed as dist
+        self.ctx, self.torch, self.world = ctx, torch, world
+        if world > 1:
+            uid = [ctx.comm_unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(uid, src=0, group=group)
+            uid = uid[0]
+        else:
+            uid = ctx.comm_unique_id()
+        self.comm = ctx.comm_create(uid, rank, world)
+        self.stream = torch.cuda.Stream(device=ctx.device)
+
+    def start(self, grid):
+        """Enqueue the reduce behind everything already enqueued on the current stream; returns an event."""
+        torch = self.torch
+        ready = torch.cuda.Event()
+        ready.record(torch.cuda.current_stream(self.ctx.device))
+        with torch.cuda.stream(self.stream):
+            self.stream.wait_event(ready)
+            self.ctx.allreduce_grid(self.comm, grid)
+            done = torch.cuda.Event()
+            done.record(self.stream)
+        return done
+
+    def wait(self, handle):
+        """The CURRENT stream waits for the reduce (no host wait)."""
+        if handle is not None:
+            self.torch.cuda.current_stream(self.ctx.device).wait_event(handle)
+
+    def close(self):
+        self.comm.close()
+
+
+def allreduce_light_volume(grid, transport=None, group=None):
+    """Sum the per-rank irradiance grids in place and wait for the result."""
+    tr = transport if transport is not None else TorchTransport(group)
+    tr.wait(tr.start(grid))
     return grid
 
 
@@ -29,13 +95,13 @@ class OverlappedGridReducer:
     """The frame's one collective, taken off the critical path.
 
     The all-reduce of frame k's irradiance grid (8 MiB at 128^3: latency-bound on xGMI, of the order of
-    the 0.2 ms frame itself) runs asynchronously while the rank already traces and bins frame k + 1,
-    which do not touch the grid.  Grids are double-buffered: frame k gathers into buffer k mod 2, and
-    before a buffer is gathered into again the reduce that was using it (frame k - 2) is waited for --
-    on the stream, not on the host.  `flush()` waits for everything outstanding (end of a timed
-    region / before the grid is read).
+    the frame itself) runs asynchronously while the rank already traces and bins frame k + 1, which do
+    not touch the grid.  Grids are double-buffered: frame k gathers into buffer k mod 2, and before a
+    buffer is gathered into again the reduce that was using it (frame k - 2) is waited for -- on the
+    stream, not on the host.  `flush()` waits for everything outstanding (end of a timed region / before
+    the grid is read).
 
-        red = OverlappedGridReducer(like=frame.light_volume)
+        red = OverlappedGridReducer(frame.light_volume, transport)
         for k in range(K):
             frame.trace(); frame.bin()
             out = red.acquire(k)          # buffer of frame k, safe to overwrite
@@ -45,32 +111,29 @@ class OverlappedGridReducer:
         grid = red.result(K - 1)
     """
 
-    def __init__(self, like, group=None):
+    def __init__(self, like, transport=None, group=None):
         import torch
-        import torch.distributed as dist
-        self._dist = dist
-        self.group = group
-        self.active = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+        self.transport = transport if transport is not None else TorchTransport(group)
+        self.active = self.transport.world > 1
         self.buffers = [like, torch.empty_like(like)]
         self._pending = [None, None]
 
     def acquire(self, k: int):
         b = k & 1
         if self._pending[b] is not None:
-            self._pending[b].wait()
+            self.transport.wait(self._pending[b])
             self._pending[b] = None
         return self.buffers[b]
 
     def reduce(self, k: int):
         if self.active:
             b = k & 1
-            self._pending[b] = self._dist.all_reduce(self.buffers[b], op=self._dist.ReduceOp.SUM, group=self.group,
-                                                     async_op=True)
+            self._pending[b] = self.transport.start(self.buffers[b])
 
     def flush(self):
         for b in (0, 1):
             if self._pending[b] is not None:
-                self._pending[b].wait()
+                self.transport.wait(self._pending[b])
                 self._pending[b] = None
 
     def result(self, k: int):

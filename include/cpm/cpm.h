@@ -431,6 +431,45 @@ int cpm_mix_buffers(cpm_ctx* ctx, const void* x, const void* y, float a, size_t 
 int cpm_volume_mix(cpm_ctx* ctx, const cpm_volume* v0, const cpm_volume* v1, float weight,
                    cpm_volume* out, cpm_stream stream);
 
+/* ------------------------------------------------------------------ multi-GPU: photon shards + one reduce
+ *
+ * Photon i depends only on light sample i, RNG stream i and read-only data, so GPU g of D traces photons
+ * [g N/D, (g+1) N/D) -- cpm_trace_params.photon_offset / n_light_samples address exactly that
+ * (ref cl/photontracer.cl:102,123,166) -- bins and gathers them into its OWN full-size light volume, and the
+ * volumes are summed with one collective per frame: RCCL over xGMI, enqueued on the caller's stream.
+ * The call site in the reference is where PhotonToLightVolumeProcessorCL::process hands the volume on
+ * (ref processor/photontolightvolumeprocessorcl.cpp:356-412).  RCCL is loaded on first use (dlopen): a single-GPU
+ * host needs none; without it these return CPM_ERR_UNSUPPORTED. */
+
+typedef struct cpm_comm cpm_comm;
+#define CPM_COMM_ID_BYTES 128
+
+/* One process per GPU: rank 0 obtains an id, the host distributes it (any channel), every rank creates its end.
+ * cpm_comm_create is collective over the n_ranks participants (ncclCommInitRank). */
+int cpm_comm_get_unique_id(cpm_ctx* ctx, uint8_t* id_out /* CPM_COMM_ID_BYTES */);
+int cpm_comm_create(cpm_ctx* ctx, const uint8_t* id /* CPM_COMM_ID_BYTES */, int rank, int n_ranks, cpm_comm** out);
+/* One process driving n devices (Inviwo's single process; one context per device): all ends at once (ncclCommInitAll). */
+int cpm_comm_create_all(cpm_ctx* const* ctxs, int n, cpm_comm** comms_out /* n */);
+void cpm_comm_destroy(cpm_comm* comm);
+int cpm_comm_rank(const cpm_comm* comm);
+int cpm_comm_size(const cpm_comm* comm);
+
+/* grid[i] = sum over ranks of grid[i], in place, count floats (cells * channels).  A communicator of size 1 is a no-op.
+ * The sum's order differs from a single GPU's: tolerance, not bit equality (as in the reference's atomics). */
+int cpm_allreduce_grid(cpm_ctx* ctx, cpm_comm* comm, float* grid, size_t count, cpm_stream stream);
+/* The same to one display GPU only (ncclReduce); recv is read on `root` only. */
+int cpm_reduce_grid(cpm_ctx* ctx, cpm_comm* comm, const float* send, float* recv, size_t count, int root, cpm_stream stream);
+/* Single-process form: the n ends of cpm_comm_create_all in one grouped call, streams[i] on device i (NULL = null streams). */
+int cpm_allreduce_grids(cpm_ctx* const* ctxs, cpm_comm* const* comms, float* const* grids, size_t count,
+                        const cpm_stream* streams, int n);
+
+/* Delta path: total[brick] = sum over ranks of partial[brick] for the UNION of the ranks' touched 4x4x4 bricks
+ * (brick_mask as filled by cpm_mark_touched_bricks; replaced by the union), everything else of `total` untouched.
+ * Two small collectives (mask, packed voxels) instead of the whole grid; dense fall-back beyond a quarter of the
+ * bricks.  Synchronises the stream once (4-byte read-back of the union's size, returned in *n_union_out). */
+int cpm_allreduce_grid_bricks(cpm_ctx* ctx, cpm_comm* comm, const float* partial, float* total,
+                              const cpm_grid_desc* grid, uint8_t* brick_mask, uint32_t* n_union_out, cpm_stream stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -26,7 +26,13 @@ def test_shard_ranges_tile(cpm):
         sh.shard_range(10, 2, 2)
 
 
-def _worker(rank, world, port, out_dir):
+def _lattice(world, scaling):
+    """weak: every rank brings its own 96 x 96 lattice rows (bench.py --scaling weak); strong: ONE fixed lattice whatever
+    the number of ranks (BASELINE configs 4 and 5: a fixed photon count sharded over the GPUs)."""
+    return (96, 96 * world) if scaling == "weak" else (96, 160)
+
+
+def _worker(rank, world, port, out_dir, scaling):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     sys.path.insert(0, str(REPO))
     sys.path.insert(0, str(REPO / "tests"))
@@ -39,7 +45,7 @@ def _worker(rank, world, port, out_dir):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     S, P = cpm_amd.synthetic, cpm_amd.pipeline
     o = Oracle()
-    nx, ny = 96, 96 * world  # weak scaling: per-rank lattice rows, as bench.py does
+    nx, ny = _lattice(world, scaling)
     n_total = nx * ny
     lo, hi = sh.shard_range(n_total, rank, world)
     vol_np, tf = S.heterogeneous_volume(32), S.workspace_tf()
@@ -76,7 +82,8 @@ def _worker(rank, world, port, out_dir):
     dist.destroy_process_group()
 
 
-def test_two_rank_photon_sharding_and_grid_allreduce(tmp_path, oracle, cpm):
+@pytest.mark.parametrize("scaling", ["weak", "strong"])
+def test_two_rank_photon_sharding_and_grid_allreduce(tmp_path, oracle, cpm, scaling):
     import socket
     import torch.multiprocessing as mp
     from oracle_binding import OTraceParams
@@ -84,10 +91,10 @@ def test_two_rank_photon_sharding_and_grid_allreduce(tmp_path, oracle, cpm):
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     world = 2
-    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, port, str(tmp_path), scaling), nprocs=world, join=True)
     # unsharded reference
     S, P = cpm.synthetic, cpm.pipeline
-    nx, ny = 96, 96 * world
+    nx, ny = _lattice(world, scaling)
     n = nx * ny
     vol_np, tf = S.heterogeneous_volume(32), S.workspace_tf()
     d = P._normalize((0.3, 0.5, -1.0))
