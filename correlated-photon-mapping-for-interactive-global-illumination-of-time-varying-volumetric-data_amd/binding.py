@@ -140,7 +140,7 @@ def load_library() -> C.CDLL:
         "cpm_comm_destroy": (None, [vp]),
         "cpm_comm_rank": (i32, [vp]),
         "cpm_comm_size": (i32, [vp]),
-        "cpm_allreduce_grid": (i32, [vp, vp, vp, sz, vp]),
+        "cpm_allreduce_grid": (i32, [vp, vp, vp, vp, sz, vp]),
         "cpm_reduce_grid": (i32, [vp, vp, vp, vp, sz, i32, vp]),
         "cpm_allreduce_grids": (i32, [P(vp), P(vp), P(vp), sz, P(vp), i32]),
         "cpm_allreduce_grid_bricks": (i32, [vp, vp, vp, vp, P(GridDesc), vp, P(u32), vp]),
@@ -420,8 +420,10 @@ class Context:
         self._check(self.lib.cpm_comm_create(self.h, buf, rank, n_ranks, C.byref(h)))
         return Comm(self, h)
 
-    def allreduce_grid(self, comm: "Comm", grid):
-        self._check(self.lib.cpm_allreduce_grid(self.h, comm.h, self._ptr(grid), grid.numel(), self._stream()))
+    def allreduce_grid(self, comm: "Comm", grid, out=None):
+        """out (default: in place) = sum over ranks of grid."""
+        recv = grid if out is None else out
+        self._check(self.lib.cpm_allreduce_grid(self.h, comm.h, self._ptr(grid), self._ptr(recv), grid.numel(), self._stream()))
 
     def reduce_grid(self, comm: "Comm", send, recv, root: int):
         self._check(self.lib.cpm_reduce_grid(self.h, comm.h, self._ptr(send), self._ptr(recv) if recv is not None else None,

@@ -201,14 +201,14 @@ void cpm_comm_destroy(cpm_comm* c) {
 int cpm_comm_rank(const cpm_comm* c) { return c ? c->rank : -1; }
 int cpm_comm_size(const cpm_comm* c) { return c ? c->size : 0; }
 
-int cpm_allreduce_grid(cpm_ctx* ctx, cpm_comm* comm, float* grid, size_t count, cpm_stream stream) {
+int cpm_allreduce_grid(cpm_ctx* ctx, cpm_comm* comm, const float* send, float* recv, size_t count, cpm_stream stream) {
     CPM_ENTER(ctx);
-    CPM_REQUIRE(ctx, comm && (grid || count == 0), "cpm_allreduce_grid: null argument");
+    CPM_REQUIRE(ctx, comm && ((send && recv) || count == 0), "cpm_allreduce_grid: null argument");
     if (count == 0) return CPM_OK;
     const Rccl* R = rccl(ctx);
     if (!R) return CPM_ERR_UNSUPPORTED;
     ProfScope ps(ctx, "rccl_allreduce_grid", (hipStream_t)stream);
-    CPM_NCCL_CHECK(ctx, R, R->AllReduce(grid, grid, count, ncclFloat32, ncclSum, comm->comm, (hipStream_t)stream));
+    CPM_NCCL_CHECK(ctx, R, R->AllReduce(send, recv, count, ncclFloat32, ncclSum, comm->comm, (hipStream_t)stream));
     return CPM_OK;
 }
 

@@ -23,6 +23,8 @@ struct cpmh_network {
     PhotonToLightVolumeProcessorCL lightVolume;
     TransferFunction tf;
     bool correlated = false;
+    cpm_comm* comm = nullptr;  // cpmh_enable_shard_reduce
+    ~cpmh_network() { if (comm) cpm_comm_destroy(comm); }
 };
 
 static TransferFunction make_tf(const float* p5, int n) {
@@ -128,6 +130,18 @@ int cpmh_download_photons(cpmh_network* net, float* out) {
 int cpmh_n_recomputed(cpmh_network* net) { auto r = net->tracer.recomputedIndicesPort_.getData(); return r ? r->nRecomputedPhotons : -1; }
 int cpmh_remaining(cpmh_network* net) { return net->tracer.remainingPhotonsToUpdate(); }
 const char* cpmh_last_light_volume_path(cpmh_network* net) { return net->lightVolume.lastPath(); }
+// Multi-GPU call site, driven with a communicator of size 1 on this process's device (a real RCCL communicator: the
+// network's photons are then "the one shard", the outport carries the reduced volume).
+int cpmh_enable_shard_reduce(cpmh_network* net) {
+    if (net->comm) return 0;
+    uint8_t id[CPM_COMM_ID_BYTES];
+    auto& rt = CpmRuntime::get();
+    if (!rt.check(cpm_comm_get_unique_id(rt.ctx(), id), "cpm_comm_get_unique_id")) return -1;
+    if (!rt.check(cpm_comm_create(rt.ctx(), id, 0, 1, &net->comm), "cpm_comm_create")) return -2;
+    net->lightVolume.setCommunicator(net->comm);
+    return 0;
+}
+const char* cpmh_last_reduce(cpmh_network* net) { return net->lightVolume.lastReduce(); }
 double cpmh_radius(cpmh_network* net) { return net->tracer.outport_.getData()->getRadiusRelativeToSceneSize(); }
 // light plane the directional sampler fitted: origin, u, v (3 floats each), area
 void cpmh_light_plane(cpmh_network* net, float out[10]) {

@@ -747,7 +747,7 @@ void PhotonToLightVolumeProcessorCL::process() {  // photontolightvolumeprocesso
     if (!fresh && haveIdx && prevPhotons_.getSize() == photonData->photons_.getSize() && nRecomputed > 0 && nRecomputed < maxRecomputationPhotons) {
         partialUpdate = true;
         const unsigned int* idx = recomputedPhotonIndicesPort_.getData()->indicesToRecomputedPhotons.device();
-        if (exactIncrementalUpdate_.get() && formulation_.get() != "splat") {
+        if (exactIncrementalUpdate_.get() && formulation_.get() == "gather") {
             // exact add-remove: mark the bricks an old or new position touches, re-bin, re-gather those bricks only
             const size_t nb = ((outDim.x + 3) / 4) * ((outDim.y + 3) / 4) * ((outDim.z + 3) / 4);
             brickMask_.setSize(nb);
@@ -764,6 +764,13 @@ void PhotonToLightVolumeProcessorCL::process() {  // photontolightvolumeprocesso
             lastPath_ = "exact incremental";
         } else {
         // add-remove (:196-298): -old, +new over the re-traced photons
+        if (comm_) {  // multi-GPU: remember which bricks the OLD positions touch (the snapshot is refreshed below)
+            const size_t nb = ((outDim.x + 3) / 4) * ((outDim.y + 3) / 4) * ((outDim.z + 3) / 4);
+            brickMask_.setSize(nb);
+            (void)hipMemsetAsync(brickMask_.device(), 0, nb, rt.stream());
+            rt.check(cpm_mark_touched_bricks(rt.ctx(), reinterpret_cast<const float*>(prevPhotons_.device()), idx, nRecomputed, nPhotons, nInter, &g,
+                                             radius, brickMask_.device(), rt.stream()), "cpm_mark_touched_bricks(old)");
+        }
         rt.check(cpm_splat_selected(rt.ctx(), reinterpret_cast<const float*>(prevPhotons_.device()), idx, nRecomputed, &g, radius, scale, -1.f, nPhotons,
                                     nInter, out, rt.stream()), "cpm_splat_selected(-)");
         rt.check(cpm_splat_selected(rt.ctx(), photons, idx, nRecomputed, &g, radius, scale, 1.f, nPhotons, nInter, out, rt.stream()), "cpm_splat_selected(+)");
@@ -773,6 +780,12 @@ void PhotonToLightVolumeProcessorCL::process() {  // photontolightvolumeprocesso
         if (formulation_.get() == "splat") {  // the reference's formulation: clear + atomic splat (:299-339)
             (void)hipMemsetAsync(out, 0, cells * channels * sizeof(float), rt.stream());
             rt.check(cpm_splat(rt.ctx(), photons, nPhotons, &g, radius, scale, out, rt.stream()), "cpm_splat");
+        } else if (formulation_.get() == "fast" && cpm_gather_fast_supported(&g, radius)) {
+            // brick bin + LDS-tile gather, fixed-point sums: the reference's terms within the stated fp32 tolerance
+            const size_t m = (size_t)nPhotons * nInter;
+            brickTable_.setSize(cpm_fast_table_entries(&g, (int)m)); sorted_.setSize(m * (channels == 1 ? 4 : 8));
+            if (rt.check(cpm_bin_fast(rt.ctx(), photons, (int)m, &g, brickTable_.device(), sorted_.device(), rt.stream()), "cpm_bin_fast"))
+                rt.check(cpm_gather_fast(rt.ctx(), sorted_.device(), brickTable_.device(), (int)m, &g, radius, scale, 0, out, rt.stream()), "cpm_gather_fast");
         } else {  // sort/bin + deterministic per-cell gather
             const size_t m = (size_t)nPhotons * nInter;
             order_.setSize(m); cellStart_.setSize(cells + 1); sorted_.setSize(m * (channels == 1 ? 4 : 8));
@@ -794,7 +807,43 @@ void PhotonToLightVolumeProcessorCL::process() {  // photontolightvolumeprocesso
             (void)hipMemcpyAsync(prevPhotons_.device(), photonData->photons_.device(), photonData->photons_.getSizeInBytes(), hipMemcpyDeviceToDevice, rt.stream());
         }
     }
+    if (comm_ && lastPath_[0] != 'u') {
+        const unsigned int* idx = partialUpdate ? recomputedPhotonIndicesPort_.getData()->indicesToRecomputedPhotons.device() : nullptr;
+        // NOTE: the snapshot above has already been refreshed; the touched bricks of the OLD positions were marked before it
+        reduceOverShards(g, cells * channels, partialUpdate, nullptr, photons, idx, nRecomputed, nPhotons, nInter, radius);
+        outport_.setData(reducedVolume_);
+        return;
+    }
     outport_.setData(lightVolume_);
+}
+
+// The one exchange step of the path: sum of the shards' partial light volumes.
+void PhotonToLightVolumeProcessorCL::reduceOverShards(const cpm_grid_desc& g, size_t count, bool partialUpdate, const float*,
+                                                      const float* photons, const unsigned int* idx, int nRecomputed, int nPhotons,
+                                                      int nInter, float radius) {
+    auto& rt = CpmRuntime::get();
+    const size3_t outDim = lightVolume_->getDimensions();
+    if (!reducedVolume_ || reducedVolume_->data.getSize() != count) {
+        reducedVolume_ = std::make_shared<Volume>(outDim, CPM_F32);
+        reducedVolume_->channels = lightVolume_->channels;
+        reducedVolume_->data.setSize(count);
+        partialUpdate = false;  // nothing to update incrementally yet
+    }
+    if (partialUpdate && brickMask_.getSize() != 0 && idx) {
+        // add-remove: only bricks touched by an old or a new position of a re-traced photon changed on this shard.  The old
+        // positions were marked into brickMask_ before the snapshot moved on (see process()); add the new ones, then sum
+        // the union of all shards' bricks only.
+        uint32_t nUnion = 0;
+        bool ok = rt.check(cpm_mark_touched_bricks(rt.ctx(), photons, idx, nRecomputed, nPhotons, nInter, &g, radius, brickMask_.device(),
+                                                   rt.stream()), "cpm_mark_touched_bricks(new)");
+        if (ok && rt.check(cpm_allreduce_grid_bricks(rt.ctx(), comm_, lightVolume_->data.device(), reducedVolume_->data.device(), &g,
+                                                     brickMask_.device(), &nUnion, rt.stream()), "cpm_allreduce_grid_bricks")) {
+            lastReduce_ = "touched bricks";
+            return;
+        }
+    }
+    rt.check(cpm_allreduce_grid(rt.ctx(), comm_, lightVolume_->data.device(), reducedVolume_->data.device(), count, rt.stream()), "cpm_allreduce_grid");
+    lastReduce_ = "dense";
 }
 
 }  // namespace inviwo

@@ -475,13 +475,28 @@ public:
         FloatVec2Property dataRange{ "dataRange", "Data range", vec2{ 0.f, 1.f } }, valueRange{ "valueRange", "Value range", vec2{ 0.f, 1.f } };
         StringOptionProperty valueUnit{ "valueUnit", "Value unit", "arb. unit." };
     } information_;
-    StringOptionProperty formulation_{ "formulation", "Density estimation", "gather" };
+    // "fast" (default): brick bin + LDS-tile gather with fixed-point sums (tolerance mode, bitwise reproducible; falls back
+    // to "gather" where cpm_gather_fast_supported says no); "gather": cell sort + per-voxel sequential gather (bit-exact
+    // contract, what exactIncrementalUpdate needs); "splat": the reference's atomic formulation
+    StringOptionProperty formulation_{ "formulation", "Density estimation", "fast" };
     // add-remove of the re-traced photons: false (default) = the reference's -old / +new atomic splats; true = re-bin and
     // re-gather exactly the bricks they touch (bit-identical to a full gather) -- not a property of the reference
     BoolProperty exactIncrementalUpdate_{ "exactIncrementalUpdate", "Exact incremental update", false };
     const char* lastPath() const { return lastPath_; }
+    // Multi-GPU: this processor's photons are ONE shard of the frame's photons and lightVolume_ is the shard's
+    // partial light volume; with a communicator set, the outport carries the sum over the shards -- one cpm_allreduce_grid
+    // per full evaluation, cpm_allreduce_grid_bricks (touched bricks only) after an add-remove update.  The call site is
+    // where the reference hands the finished volume to the outport (photontolightvolumeprocessorcl.cpp:404-411).
+    void setCommunicator(cpm_comm* comm) { comm_ = comm; }
+    const char* lastReduce() const { return lastReduce_; }
 private:
     void volumeSizeOptionChanged();
+    void reduceOverShards(const cpm_grid_desc& g, size_t count, bool partialUpdate, const float* prevPhotons, const float* photons,
+                          const unsigned int* idx, int nRecomputed, int nPhotons, int nInter, float radius);
+    cpm_comm* comm_ = nullptr;
+    std::shared_ptr<Volume> reducedVolume_;
+    Buffer<uint32_t> brickTable_;
+    const char* lastReduce_ = "none";
     std::shared_ptr<Volume> lightVolume_ = std::make_shared<Volume>(size3_t{ 1, 1, 1 }, CPM_F32);
     Buffer<vec4> prevPhotons_;
     Buffer<unsigned int> order_, cellStart_;

@@ -454,9 +454,10 @@ void cpm_comm_destroy(cpm_comm* comm);
 int cpm_comm_rank(const cpm_comm* comm);
 int cpm_comm_size(const cpm_comm* comm);
 
-/* grid[i] = sum over ranks of grid[i], in place, count floats (cells * channels).  A communicator of size 1 is a no-op.
+/* recv[i] = sum over ranks of send[i], count floats (cells * channels); recv may be send (in place), or a separate
+ * buffer when the rank keeps its partial light volume for incremental updates.
  * The sum's order differs from a single GPU's: tolerance, not bit equality (as in the reference's atomics). */
-int cpm_allreduce_grid(cpm_ctx* ctx, cpm_comm* comm, float* grid, size_t count, cpm_stream stream);
+int cpm_allreduce_grid(cpm_ctx* ctx, cpm_comm* comm, const float* send, float* recv, size_t count, cpm_stream stream);
 /* The same to one display GPU only (ncclReduce); recv is read on `root` only. */
 int cpm_reduce_grid(cpm_ctx* ctx, cpm_comm* comm, const float* send, float* recv, size_t count, int root, cpm_stream stream);
 /* Single-process form: the n ends of cpm_comm_create_all in one grouped call, streams[i] on device i (NULL = null streams). */

@@ -50,6 +50,7 @@ def host(cpm, ctx):
                             ("cpmh_light_plane", None, [C.c_void_p, C.POINTER(C.c_float * 10)]),
                             ("cpmh_light_direction", None, [C.c_void_p, C.POINTER(C.c_float * 3)]),
                             ("cpmh_tf_lut", None, [C.c_void_p, C.c_void_p]),
+                            ("cpmh_enable_shard_reduce", C.c_int, [C.c_void_p]), ("cpmh_last_reduce", C.c_char_p, [C.c_void_p]),
                             ("cpmh_describe_surface", C.c_char_p, [C.c_void_p])]:
         f = getattr(lib, name)
         f.restype, f.argtypes = res, args
@@ -145,12 +146,21 @@ def test_network_matches_abi_pipeline(host, ctx, cpm):
     np.testing.assert_allclose(lut, S.workspace_tf(), rtol=0, atol=1e-7)
     fr = P.PhotonFrame(ctx, vol, lut, 160, (32, 32, 32), light_travel_direction=net.direction(), light_plane=(o, u, v, area),
                        mesh_intersection=(S.UNIT_CUBE_VERTICES, idx))
-    lv = _n(fr.frame())
+    # the processor's default formulation is the tolerance-mode one (brick bin + fixed-point tile gather): bit for bit what
+    # cpm_bin_fast + cpm_gather_fast give the Python driver
+    lvf = _n(fr.frame_fast()).copy()
     hv, dims, ch = net.light_volume()
     assert dims == (32, 32, 32) and ch == 1
     assert abs(host.cpmh_radius(net.h) - fr.radius) < 1e-12
     assert np.array_equal(bits(net.photons()), bits(_n(fr.photons)))
+    assert np.array_equal(bits(hv), bits(lvf))
+    # "gather": the bit-exact sequential contract
+    lv = _n(fr.frame())
+    assert host.cpmh_set_property_string(net.h, b"lightvolume", b"formulation", b"gather") == 0
+    net.evaluate()
+    hv, _, _ = net.light_volume()
     assert np.array_equal(bits(hv), bits(lv))
+    np.testing.assert_allclose(lvf, lv, rtol=2e-5, atol=1e-5 * float(lv.max()))
     # the reference formulation through the same processor: atomic splat, tolerance
     assert host.cpmh_set_property_string(net.h, b"lightvolume", b"formulation", b"splat") == 0
     net.evaluate()
@@ -164,6 +174,39 @@ def test_network_matches_abi_pipeline(host, ctx, cpm):
     n = int(np.ceil(1.0 / fr.radius))
     assert dims == (n, n, n) and ch == 4 and rv.reshape(-1, 4)[:, :3].sum() > 0
     net.close()
+
+
+def test_network_shard_reduce_call_site(host, cpm):
+    """The multi-GPU call site of the light-volume processor with a real RCCL communicator of size 1: a full evaluation
+    goes through cpm_allreduce_grid, an add-remove update through cpm_allreduce_grid_bricks (touched bricks only), and the
+    outport carries what a network without communicator produces."""
+    S = cpm.synthetic
+    vol = S.heterogeneous_volume(64)
+    base = [(0.0, 1, 1, 1, 0.0), (0.45, 1, 0.5, 0.2, 0.0), (0.55, 0.6, 0.3, 0.1, 0.05), (0.8, 0.9, 0.2, 0.3, 0.4), (1.0, 0.1, 0.6, 0.7, 0.5)]
+    edit = list(base)
+    edit[3] = (0.85,) + base[3][1:]
+    pos, d = _light(cpm, (0.3, 0.5, -1.0))
+    nets = [Net(host, vol, 128, pos, d, base, correlated=True) for _ in range(2)]
+    assert host.cpmh_enable_shard_reduce(nets[0].h) == 0
+    for net in nets:
+        net.evaluate(first=True)
+        assert host.cpmh_set_property_float(net.h, b"lightvolume", b"incrementalRecomputationThreshold", 100.0) == 0
+    assert host.cpmh_last_reduce(nets[0].h) == b"dense" and host.cpmh_last_reduce(nets[1].h) == b"none"
+    a, _, _ = nets[0].light_volume()
+    b, _, _ = nets[1].light_volume()
+    assert np.array_equal(bits(a), bits(b))
+    for net in nets:
+        net.set_tf(edit)
+        net.evaluate()
+        assert host.cpmh_last_light_volume_path(net.h) == b"incremental"
+    assert host.cpmh_last_reduce(nets[0].h) == b"touched bricks"
+    a, _, _ = nets[0].light_volume()
+    b, _, _ = nets[1].light_volume()
+    # the reduced volume was refreshed in the touched bricks only; elsewhere it still holds the previous sum -- which is what
+    # the partial volume holds there too (atomic +- splats leave untouched voxels alone)
+    np.testing.assert_allclose(a, b, rtol=1e-4, atol=2e-5 * float(b.max()))
+    for net in nets:
+        net.close()
 
 
 def test_network_correlated_tf_edit(host, cpm):
@@ -206,7 +249,12 @@ def test_network_correlated_tf_edit(host, cpm):
     assert rounds > 1
     assert np.array_equal(bits(net2.photons()), bits(after))
     # exact incremental update (not a reference property): bit-identical to the from-scratch light volume
+    # (needs the bit-exact "gather" formulation on both sides)
     net3 = Net(host, vol, 128, pos, d, base, correlated=True)
+    assert host.cpmh_set_property_string(net3.h, b"lightvolume", b"formulation", b"gather") == 0
+    assert host.cpmh_set_property_string(fresh.h, b"lightvolume", b"formulation", b"gather") == 0
+    fresh.evaluate()
+    lv_full, _, _ = fresh.light_volume()
     net3.evaluate(first=True)
     assert host.cpmh_set_property_float(net3.h, b"lightvolume", b"incrementalRecomputationThreshold", 100.0) == 0
     assert host.cpmh_set_property_float(net3.h, b"lightvolume", b"exactIncrementalUpdate", 1.0) == 0
@@ -249,7 +297,7 @@ assert h and lib.cpmh_evaluate(h, 1) == 0
     assert r.returncode == 0, log[-3000:]
     assert "Photon tracing: " in log and "trace_kernel" in log and " ms" in log
     assert "Computed photons: 1024 = 100.00 %" in log
-    assert "Photons to light volume: " in log and "gather" in log
+    assert "Photons to light volume: " in log and "fast_tile_kernel" in log and "fast_combine_kernel" in log
 
 
 def test_radixsort_processor(host, ctx):
