@@ -142,6 +142,18 @@ int cpmh_enable_shard_reduce(cpmh_network* net) {
     return 0;
 }
 const char* cpmh_last_reduce(cpmh_network* net) { return net->lightVolume.lastReduce(); }
+// progressive refinement: switch it on (the tracer then writes its RNG state back), one timer tick + evaluation per call
+int cpmh_enable_refinement(cpmh_network* net, int on) {
+    net->tracer.enableProgressiveRefinement_.set(on != 0);
+    net->tracer.progressiveRefinementChanged();
+    return 0;
+}
+int cpmh_refine(cpmh_network* net) {
+    net->tracer.onTimerEvent();
+    net->tracer.process();
+    net->lightVolume.process();
+    return hipDeviceSynchronize() == hipSuccess ? net->tracer.outport_.getData()->iteration() : -2;
+}
 double cpmh_radius(cpmh_network* net) { return net->tracer.outport_.getData()->getRadiusRelativeToSceneSize(); }
 // light plane the directional sampler fitted: origin, u, v (3 floats each), area
 void cpmh_light_plane(cpmh_network* net, float out[10]) {

@@ -693,7 +693,7 @@ PhotonToLightVolumeProcessorCL::PhotonToLightVolumeProcessorCL() {
     addPortId("lightvolume", false);
     recomputedPhotonIndicesPort_.setOptional(true);
     for (PropertyBase* p : std::initializer_list<PropertyBase*>{ &incrementalRecomputationThreshold_, &volumeSizeOption_, &volumeDataTypeOption_,
-                                                                &alignChangedPhotons_, &workGroupSize_, &useGLSharing_, &formulation_,
+                                                                &alignChangedPhotons_, &workGroupSize_, &useGLSharing_, &formulation_, &progressiveAccumulation_,
                                                                 &exactIncrementalUpdate_, &information_ })
         addProperty(*p);
     volumeSizeOption_.onChange([this]() { volumeSizeOptionChanged(); });
@@ -740,6 +740,13 @@ void PhotonToLightVolumeProcessorCL::process() {  // photontolightvolumeprocesso
     const float scale = cpm_relative_irradiance_scale(photonData->getRadiusRelativeToSceneSize(), (double)nPhotons);
     const float* photons = reinterpret_cast<const float*>(photonData->photons_.device());
     float* out = lightVolume_->data.device();
+    // a progressive iteration (i > 1): this evaluation's estimate goes to a side buffer and is averaged in below
+    const bool progressiveIteration = progressiveAccumulation_.get() && !fresh && photonData->iteration() > 1 &&
+                                      static_cast<int>(photonData->getInvalidationReason()) == static_cast<int>(PhotonData::InvalidationReason::Progressive);
+    if (progressiveIteration) {
+        estimate_.setSize(cells * channels);
+        out = estimate_.device();
+    }
     const int maxRecomputationPhotons = (int)((float)nPhotons * (incrementalRecomputationThreshold_.get() / 100.f));
     const bool haveIdx = recomputedPhotonIndicesPort_.isReady();
     const int nRecomputed = haveIdx ? recomputedPhotonIndicesPort_.getData()->nRecomputedPhotons : -1;
@@ -806,6 +813,11 @@ void PhotonToLightVolumeProcessorCL::process() {  // photontolightvolumeprocesso
             if (prevPhotons_.getSize() != photonData->photons_.getSize()) prevPhotons_.setSize(photonData->photons_.getSize());
             (void)hipMemcpyAsync(prevPhotons_.device(), photonData->photons_.device(), photonData->photons_.getSizeInBytes(), hipMemcpyDeviceToDevice, rt.stream());
         }
+    }
+    if (progressiveIteration && lastPath_[0] == 'f') {  // L_i = mix(L_(i-1), E_i, 1 / i)
+        rt.check(cpm_mix_buffers(rt.ctx(), lightVolume_->data.device(), estimate_.device(), 1.0f / (float)photonData->iteration(), cells * channels,
+                                 CPM_MIX_F32, lightVolume_->data.device(), rt.stream()), "cpm_mix_buffers(progressive average)");
+        lastPath_ = "progressive";
     }
     if (comm_ && lastPath_[0] != 'u') {
         const unsigned int* idx = partialUpdate ? recomputedPhotonIndicesPort_.getData()->indicesToRecomputedPhotons.device() : nullptr;

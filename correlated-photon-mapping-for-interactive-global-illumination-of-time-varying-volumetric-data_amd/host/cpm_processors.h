@@ -402,6 +402,11 @@ public:
     const ProcessorInfo getProcessorInfo() const override { return { "org.inviwo.ProgressivePhotonTracerCL", "ProgressivePhotonTracer", "Photons" }; }
     void process() override;
     void invalidateProgressiveRendering(PhotonData::InvalidationReason r) { invalidationFlag_ = invalidationFlag_ | r; }
+    // One firing of the 100 ms refinement timer (the caller owns the timer; ref progressivephotontracercl.cpp:622-626,
+    // 642-645): the next evaluation is a progressive iteration -- same light samples, continued RNG streams, next radius.
+    void onTimerEvent() { invalidationFlag_ = invalidationFlag_ | PhotonData::InvalidationReason::Progressive; }
+    // ref :647-651: the tracer writes its RNG state back only when refinement is on and no importance grid is connected
+    void progressiveRefinementChanged() { photonTracer_.setProgressive(enableProgressiveRefinement_.get() && !recomputationImportanceGrid_.isConnected()); }
     void setTransferFunction(const TransferFunction& tf) { transferFunction_ = tf; invalidateProgressiveRendering(PhotonData::InvalidationReason::TransferFunction); }
     int remainingPhotonsToUpdate() const { return remainingPhotonsToUpdate_; }
 
@@ -482,6 +487,10 @@ public:
     // add-remove of the re-traced photons: false (default) = the reference's -old / +new atomic splats; true = re-bin and
     // re-gather exactly the bricks they touch (bit-identical to a full gather) -- not a property of the reference
     BoolProperty exactIncrementalUpdate_{ "exactIncrementalUpdate", "Exact incremental update", false };
+    // progressive refinement: an evaluation whose only invalidation reason is Progressive (iteration i > 1) contributes its
+    // estimate E_i to the running average L_i = L_(i-1) + (E_i - L_(i-1)) / i instead of replacing the light volume.  Not a
+    // property of the reference (it re-splats every iteration and leaves the averaging to the consumer).
+    BoolProperty progressiveAccumulation_{ "progressiveAccumulation", "Average progressive iterations", true };
     const char* lastPath() const { return lastPath_; }
     // Multi-GPU: this processor's photons are ONE shard of the frame's photons and lightVolume_ is the shard's
     // partial light volume; with a communicator set, the outport carries the sum over the shards -- one cpm_allreduce_grid
@@ -496,6 +505,7 @@ private:
     cpm_comm* comm_ = nullptr;
     std::shared_ptr<Volume> reducedVolume_;
     Buffer<uint32_t> brickTable_;
+    Buffer<float> estimate_;  // E_i of a progressive iteration
     const char* lastReduce_ = "none";
     std::shared_ptr<Volume> lightVolume_ = std::make_shared<Volume>(size3_t{ 1, 1, 1 }, CPM_F32);
     Buffer<vec4> prevPhotons_;

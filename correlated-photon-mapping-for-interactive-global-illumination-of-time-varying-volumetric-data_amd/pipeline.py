@@ -292,6 +292,60 @@ class PhotonFrame:
         return self.light_volume
 
 
+# --------------------------------------------------------------------------- progressive refinement
+
+def progressive_sphere_radius(radius: float, iteration: int, alpha: float) -> float:
+    """r_(i+1) = r_i ((i + alpha) / (i + 1))^(1/3), in double (Knaus & Zwicker eq. 20;
+    ref progressivephotonmapping/photondata.cpp:72-77)."""
+    return radius * math.pow((float(iteration) + alpha) / (1.0 + float(iteration)), 1.0 / 3.0)
+
+
+class ProgressivePhotonMapper(PhotonFrame):
+    """Progressive photon mapping on the path: every iteration traces the SAME light samples with the RNG streams where the
+    previous iteration left them (-D PROGRESSIVE_PHOTON_MAPPING: the state is written back, ref cl/photontracer.cl:211-215),
+    with the radius shrunk by the schedule above (PhotonData::advanceToNextIteration, ref photondata.cpp:67-79, driven by
+    ProgressivePhotonTracerCL::process, ref processor/progressivephotontracercl.cpp:252-260), and the light volume becomes
+    the running average of the iterations' estimates: L_i = L_(i-1) + (E_i - L_(i-1)) / i  (cpm_mix_buffers: the OpenCL mix).
+    The reference re-splats each iteration's photons and leaves the averaging to the consumer; the average is this build's."""
+
+    def __init__(self, *args, alpha: float = 0.5, formulation: str = "fast", **kw):
+        super().__init__(*args, **kw)
+        self.alpha = alpha
+        self.formulation = formulation
+        self.iteration = 0
+        self.radius0 = self.radius
+        self.estimate = self.torch.zeros_like(self.light_volume)
+        self.params.flags |= B.CPM_TRACE_PROGRESSIVE
+
+    def reset(self):
+        """Light / camera / TF / volume changed (ref tracercl.cpp:240-247): iteration 0, original streams and radius."""
+        self.iteration = 0
+        self.radius = self.radius0
+        self.rng.copy_(self.rng_initial)
+
+    def iterate(self):
+        if self.iteration == 0:
+            self.radius = self.radius0
+            self.iteration = 1
+        else:
+            self.radius = progressive_sphere_radius(self.radius, self.iteration, self.alpha)
+            self.iteration += 1
+        self.scale = B.relative_irradiance_scale(self.radius, float(self.n_total))
+        self.params.iteration = self.iteration
+        self.trace()
+        out = self.light_volume if self.iteration == 1 else self.estimate
+        fast = self.formulation == "fast" and self.ctx.gather_fast_supported(self.grid, self.radius)
+        if fast:
+            self.bin_fast()
+            self.gather_fast(out=out)
+        else:
+            self.bin()
+            self.gather(out=out)
+        if self.iteration > 1:
+            self.ctx.mix_buffers(self.light_volume, self.estimate, 1.0 / self.iteration, self.light_volume)
+        return self.light_volume
+
+
 # --------------------------------------------------------------------------- C2 (host, CPU in the reference too)
 
 def _mix_prim(a, b, t):

@@ -50,6 +50,7 @@ def host(cpm, ctx):
                             ("cpmh_light_plane", None, [C.c_void_p, C.POINTER(C.c_float * 10)]),
                             ("cpmh_light_direction", None, [C.c_void_p, C.POINTER(C.c_float * 3)]),
                             ("cpmh_tf_lut", None, [C.c_void_p, C.c_void_p]),
+                            ("cpmh_enable_refinement", C.c_int, [C.c_void_p, C.c_int]), ("cpmh_refine", C.c_int, [C.c_void_p]),
                             ("cpmh_enable_shard_reduce", C.c_int, [C.c_void_p]), ("cpmh_last_reduce", C.c_char_p, [C.c_void_p]),
                             ("cpmh_describe_surface", C.c_char_p, [C.c_void_p])]:
         f = getattr(lib, name)
@@ -173,6 +174,38 @@ def test_network_matches_abi_pipeline(host, ctx, cpm):
     rv, dims, ch = net.light_volume()
     n = int(np.ceil(1.0 / fr.radius))
     assert dims == (n, n, n) and ch == 4 and rv.reshape(-1, 4)[:, :3].sum() > 0
+    net.close()
+
+
+def test_network_progressive_refinement(host, ctx, cpm):
+    """enableRefinement through the processor network: every timer tick is one more iteration (continued RNG streams, the
+    radius schedule of PhotonData::advanceToNextIteration) and the light-volume processor keeps the running average --
+    bit for bit what the Python driver's ProgressivePhotonMapper computes from the same light plane."""
+    S, P = cpm.synthetic, cpm.pipeline
+    vol = S.heterogeneous_volume(64)
+    pos, d = _light(cpm, (0.3, 0.5, -1.0))
+    net = Net(host, vol, 160, pos, d, S.WORKSPACE_TF_POINTS, size_option=2)
+    assert host.cpmh_enable_refinement(net.h, 1) == 0
+    net.evaluate(first=True)
+    o, u, v, area = net.plane()
+    idx = np.array([i for q in CUBE_QUADS for i in (q[0], q[1], q[2], q[0], q[2], q[3])], np.int32)
+    pm = P.ProgressivePhotonMapper(ctx, vol, net.tf_lut(), 160, (32, 32, 32), light_travel_direction=net.direction(),
+                                   light_plane=(o, u, v, area), mesh_intersection=(S.UNIT_CUBE_VERTICES, idx), alpha=0.5)
+    want = _n(pm.iterate()).copy()
+    hv, _, _ = net.light_volume()
+    assert np.array_equal(bits(hv), bits(want))
+    for it in range(2, 5):
+        assert host.cpmh_refine(net.h) == it
+        assert host.cpmh_last_light_volume_path(net.h) == b"progressive"
+        want = _n(pm.iterate()).copy()
+        assert abs(host.cpmh_radius(net.h) - pm.radius) < 1e-12
+        assert np.array_equal(bits(net.photons()), bits(_n(pm.photons)))
+        hv, _, _ = net.light_volume()
+        assert np.array_equal(bits(hv), bits(want)), it
+    # a TF edit resets the iteration: full evaluation again
+    net.set_tf(S.WORKSPACE_TF_POINTS)
+    net.evaluate()
+    assert host.cpmh_last_light_volume_path(net.h) == b"full"
     net.close()
 
 
