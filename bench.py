@@ -1,11 +1,18 @@
 #!/usr/bin/env python3
 """bench.py -- Mphotons/s traced + binned + gathered (BASELINE.json metric).
 
-One "step" = one frame of the hot path over resident inputs: trace -> bin -> gather
-(+ one RCCL all-reduce of the irradiance grid when N > 1).  Workload at N = 1: BASELINE
-config 2 (256^3 heterogeneous volume, 1 048 576 photons, 128^3 light volume).  Multi-GPU is
-weak scaling: every rank traces its own 1 048 576-photon shard of a 1024 x (1024 N) emission
-lattice into a full-size grid; the grids are summed with one all-reduce per frame.
+One "step" = one frame of the hot path over resident inputs: trace -> bin -> gather (+ one RCCL all-reduce of the
+irradiance grid, through the C-ABI, when N > 1).  Workload at N = 1: BASELINE config 2 (256^3 heterogeneous volume,
+1 048 576 photons, 128^3 light volume).
+
+  --formulation fast   (default) the tolerance-mode MI355X formulation: brick bin + fixed-point LDS-tile gather
+                       (cpm_bin_fast + cpm_gather_fast; light volume within rtol 2e-5 / atol 1e-5 max of the reference
+                       semantics, bitwise reproducible)
+                exact  cell sort + sequential per-voxel gather (cpm_bin + cpm_gather; bit-exact contract)
+  --scaling weak       (default at config 2) every rank traces its own 1024 x 1024 lattice rows (1024 x 1024 N in all)
+            strong     (default at config 4 / 5: BASELINE fixes their photon counts) ONE lattice, sharded over the ranks
+  --workload config5   a step is one time step of the 256^3 sequence: volume step (difference, min/max, importance),
+                       correlated re-trace of the rank's shard, delta light-volume update, touched-brick reduce
 
   python bench.py --gpus 1 --steps K --warmup W
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
@@ -24,23 +31,29 @@ REPO = Path(__file__).resolve().parent
 sys.path.insert(0, str(REPO))
 # multi-process GPU work on this pool needs dmabuf IPC (the image exports this already; harmless when set)
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+# the CPU baseline's OpenMP teams: one thread per core, neighbours first (measured on the GPU box: 59 vs 62 ms per frame)
+os.environ.setdefault("OMP_PLACES", "cores")
+os.environ.setdefault("OMP_PROC_BIND", "close")
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 
 WORKLOADS = {
-    # name: (volume dim, photons per rank lattice (nx, ny), grid dim)
-    "config2": (256, (1024, 1024), 128),
-    "config1": (64, (256, 256), 32),
-    "config4": (512, (2048, 2048), 256),
+    # name: (volume dim, lattice (nx, ny), grid dim, default scaling)
+    "config2": (256, (1024, 1024), 128, "weak"),
+    "config1": (64, (256, 256), 32, "weak"),
+    "config4": (512, (2048, 2048), 256, "strong"),
+    "config5": (256, (1024, 1024), 128, "strong"),
 }
+LIGHT_DIR = (0.3, 0.5, -1.0)
 
 
-def algorithmic_bytes(n, I, vol_bytes, tf_width, cells, channels, tiles, passes):
-    """Algorithmic bytes per launch of each kernel of the path (DESIGN.md 'Kernels')."""
+def algorithmic_bytes(n, I, vol_bytes, tf_width, cells, channels, tiles):
+    """Algorithmic bytes per launch of each kernel of the path."""
     m = n * I
     rec = 16 if channels == 1 else 32
     return {
         "trace_kernel": n * (32 + 8 + 8) + m * 32 + vol_bytes + tf_width * 4,
+        # exact formulation
         "bin_keys_kernel": m * 16 + m * 8,
         "radix_hist_kernel": m * 4 + 256 * tiles * 4,
         "radix_rowscan_kernel": 2 * 256 * tiles * 4,
@@ -48,13 +61,34 @@ def algorithmic_bytes(n, I, vol_bytes, tf_width, cells, channels, tiles, passes)
         "bin_finalize_kernel": m * 4 + m * rec + m * 4 + m * rec,
         "cell_start_kernel": m * 4 + (cells + 1) * 4,
         "gather_kernel": m * rec + (cells + 1) * 4 + cells * channels * 4,
+        # tolerance-mode formulation: what must move (records in, ranks, records out, light volume out); the slabs between
+        # tile and combine kernel are this build's own intermediate and count as overhead, not as algorithmic bytes
+        "fast_count_kernel": m * rec + m * 4,
+        "fast_scan_kernel": 0,
+        "fast_scatter_kernel": m * rec + m * 4 + m * rec,
+        "fast_tile_kernel": m * rec,
+        "fast_combine_kernel": cells * channels * 4,
     }
 
 
-def cpu_baseline(workload, vol_np, tf, n_lattice, grid_dim, light_dir):
-    """The oracle (a plain-C port of the reference path) on this host's cores: one full frame of
-    the same workload (trace + bin + gather).  Reported beside the GPU number, never measured
-    as the product."""
+def cpu_quota_cores():
+    """CPUs' worth of time the container may use (cgroup v2 cpu.max / v1 cfs quota); None when unlimited."""
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        return None if q == "max" else float(q) / float(p)
+    except (OSError, ValueError):
+        pass
+    try:
+        q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        return None if q <= 0 else q / p
+    except (OSError, ValueError):
+        return None
+
+
+def cpu_baseline(workload, vol_np, tf, n_lattice, grid_dim):
+    """The oracle (a plain-C port of the reference path) on this host's cores: full frames of the same workload
+    (trace + bin + gather).  Reported beside the GPU number, never measured as the product."""
     sys.path.insert(0, str(REPO / "tests"))
     import numpy as np
     from oracle_binding import Oracle, OTraceParams
@@ -62,9 +96,10 @@ def cpu_baseline(workload, vol_np, tf, n_lattice, grid_dim, light_dir):
     P, S = cpm_amd.pipeline, cpm_amd.synthetic
     o = Oracle()
     host_threads = os.cpu_count() or 1
+    quota = cpu_quota_cores()
     nx, ny = n_lattice
     n = nx * ny
-    d = P._normalize(light_dir)
+    d = P._normalize(LIGHT_DIR)
     origin = np.array([0.5, 0.5, 0.5], np.float32) - np.float32(2.0) * d
     po_, u, v = P.fit_plane_aligned_obb(S.UNIT_CUBE_VERTICES, origin, d)
     area = float(np.float32(np.linalg.norm(u)) * np.float32(np.linalg.norm(v)))
@@ -85,6 +120,7 @@ def cpu_baseline(workload, vol_np, tf, n_lattice, grid_dim, light_dir):
     radius = S.photon_radius_texture(vol_np.shape[::-1], 1.0)
     scale = o.relative_irradiance_scale(radius, n)
     out = np.zeros(grid_dim ** 3, np.float32)
+
     def one_frame():
         t0 = time.perf_counter()
         steps = o.trace(ovol, tf, S.UNIT_CUBE_AABB, p, ls, isect, st, photons)
@@ -95,10 +131,14 @@ def cpu_baseline(workload, vol_np, tf, n_lattice, grid_dim, light_dir):
         t3 = time.perf_counter()
         return (t3 - t0, t1 - t0, t2 - t1, t3 - t2), steps
 
-    # The OpenMP team size that serves this host best (all hardware threads is NOT it on a 2 x 64-core SMT box: 0.04 s
-    # per frame at 32 threads, 0.4 s at 256): try a few sizes, keep the fastest.  The RNG state is not written back, so
-    # every frame traces the same photons.
-    candidates = sorted({t for t in (16, 32, 64, 128, host_threads) if t <= host_threads} | {host_threads})
+    # OpenMP team size.  The GPU box's container carries a CPU quota (cgroup cpu.max: 16 CPUs of a 2 x 64-core host when this
+    # was written): a bigger team finishes a stage faster and is then throttled for the rest of the 100 ms period -- "more
+    # threads" measured 0.06 s at 16, 0.10 s at 64, 0.40 s at 256.  The team is the quota when there is one, else one
+    # thread per physical core; the sizes around it are tried too and the fastest kept.  The RNG state is not written back,
+    # so every frame traces the same photons.
+    physical = max(1, host_threads // 2)
+    base = int(quota) if quota and quota >= 1 else physical
+    candidates = sorted({t for t in (base // 2, base, base * 2, physical) if 1 <= t <= host_threads})
     trial = {}
     for t in candidates:
         o.set_threads(t)
@@ -106,19 +146,17 @@ def cpu_baseline(workload, vol_np, tf, n_lattice, grid_dim, light_dir):
         trial[t] = min(one_frame()[0][0], one_frame()[0][0])
     cores = min(trial, key=trial.get)
     o.set_threads(cores)
-    # one warm-up frame, then the median of 5
     frames = []
     steps = 0
-    for rep in range(6):
+    for rep in range(6):  # one warm-up frame, then the median of 5
         f, steps = one_frame()
         if rep > 0:
             frames.append(f)
     frames.sort()
     total, tt, tb, tg = frames[len(frames) // 2]
-    # the reference formulation on the CPU (sequential splat, the order its CAS loop would have on one thread)
     sp = np.zeros(grid_dim ** 3, np.float32)
     ts = time.perf_counter()
-    o.splat(photons, n, og, radius, scale, sp)
+    o.splat(photons, n, og, radius, scale, sp)  # the reference formulation, sequential (the order its CAS loop has on one thread)
     splat_s = time.perf_counter() - ts
     model = ""
     try:
@@ -129,12 +167,14 @@ def cpu_baseline(workload, vol_np, tf, n_lattice, grid_dim, light_dir):
                     break
     except OSError:
         pass
+    why = (f"the container's CPU quota is {quota:g} CPUs (cgroup cpu.max) of {host_threads} hardware threads: bigger teams are throttled"
+           if quota else f"one thread per physical core of {host_threads} hardware threads")
     return {
         "value": round(n / total / 1e6, 4), "unit": "Mphotons/s", "cores": cores, "kind": "port", "cpu_model": model,
-        "host_threads": host_threads, "frame_s_by_threads": {str(k): round(v, 4) for k, v in trial.items()},
-        "sample": f"median of 5 full frames (after 1 warm-up) of {workload} ({n} photons): trace {tt:.3f} s (OpenMP x{cores}) + "
-                  f"bin {tb:.3f} s (OpenMP x{min(cores, 64)}, counting sort on <= 16 of them) + gather {tg:.3f} s (OpenMP x{cores}), at the fastest of the OpenMP team sizes tried ({cores} of {host_threads} hardware threads); the reference's OpenCL cannot be timed "
-                  f"here (no CPU OpenCL device, Inviwo absent): this is the oracle, a plain-C port of the same path",
+        "host_threads": host_threads, "cpu_quota_cores": quota, "frame_s_by_threads": {str(k): round(v, 4) for k, v in trial.items()},
+        "sample": f"median of 5 full frames (after 1 warm-up) of {workload} ({n} photons): trace {tt:.3f} s + bin {tb:.3f} s + gather "
+                  f"{tg:.3f} s, OpenMP x{cores} ({why}; fastest of the team sizes tried); the reference's OpenCL cannot be timed here "
+                  f"(no CPU OpenCL device, Inviwo absent): this is the oracle, a plain-C port of the same path",
         "ms_per_frame": round(total * 1e3, 1), "woodcock_steps": int(steps),
         "splat_formulation_ms": round(splat_s * 1e3, 1),
     }
@@ -158,21 +198,37 @@ def pmc_traffic(kernel, workload):
     return None, None
 
 
+def timed(torch, fn, reps, warm=3):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    t = time.perf_counter()
+    for _ in range(reps):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t) / reps * 1e3
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="config2", choices=sorted(WORKLOADS))
+    ap.add_argument("--formulation", default="fast", choices=["fast", "exact"])
+    ap.add_argument("--scaling", default=None, choices=["weak", "strong"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--splat", action="store_true", help="also time the reference formulation (atomic splat)")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the labelled extra figures (other formulations, I = 4, sparse TF, configs 3 / 5, pipelined)")
     ap.add_argument("--streams", type=int, default=4,
                     help="frames in flight for the extra 'pipelined' figure (0 = skip it); 'value' is always one stream")
+    ap.add_argument("--transport", default="rccl", choices=["rccl", "torch"],
+                    help="the grid reduce: cpm_allreduce_grid through the C-ABI (default) or torch.distributed")
     ap.add_argument("--test-backend", default="nccl", choices=["nccl", "gloo"],
                     help="(testing) process-group backend; gloo lets the N > 1 code path run with every rank on one GPU")
     ap.add_argument("--test-one-device", action="store_true", help="(testing) every rank uses cuda:0")
     ap.add_argument("--graph", action="store_true",
-                    help="replay a captured HIP graph of the frame instead of eager launches (measured slower here: 0.299 vs 0.251 ms)")
+                    help="replay a captured HIP graph of the frame instead of eager launches (measured slower here)")
     args = ap.parse_args()
 
     import numpy as np
@@ -198,43 +254,92 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))  # backend nccl = RCCL on ROCm
 
-    vdim, (nx, ny), gdim = WORKLOADS[args.workload]
-    light_dir = (0.3, 0.5, -1.0)
+    vdim, (nx, ny), gdim, default_scaling = WORKLOADS[args.workload]
+    scaling = args.scaling or default_scaling
+    fast = args.formulation == "fast"
     vol_np = S.heterogeneous_volume(vdim) if args.workload != "config1" else S.homogeneous_volume(vdim)
     tf = S.workspace_tf() if args.workload != "config1" else S.homogeneous_tf(0.25)
-    n_rank = nx * ny
+    if scaling == "weak":
+        lattice, n_total = (nx, ny * world), nx * ny * world
+    else:
+        lattice, n_total = (nx, ny), nx * ny
+    lo, hi = sharding.shard_range(n_total, rank, world)
+    n_rank = hi - lo
     ctx = B.Context(local_rank)
-    fr = P.PhotonFrame(ctx, vol_np, tf, (nx, ny * world), (gdim,) * 3, light_travel_direction=light_dir,
-                       photon_range=sharding.shard_range(n_rank * world, rank, world))
+    # the one exchange step: RCCL through the C-ABI (one-process-per-GPU form); torch.distributed only carries the id
+    if world > 1 and args.transport == "rccl" and args.test_backend == "nccl" and not args.test_one_device:
+        transport = sharding.RcclTransport(ctx, rank, world)
+    else:
+        transport = sharding.TorchTransport()
 
-    use_graph = args.graph
-    if use_graph:
-        fr.capture()
+    correlated = args.workload == "config5"
+    if correlated:
+        n_steps = 32
+        vols = [S.heterogeneous_volume(vdim, S.sequence_blob_center(t, n_steps)) for t in range(n_steps)]
+        dvols = [torch.from_numpy(v).to(ctx.device) for v in vols]  # resident: the upload is not part of the step
+        fr = P.CorrelatedPhotonMapper(ctx, vols[0], tf, lattice, (gdim,) * 3, light_travel_direction=LIGHT_DIR,
+                                      tf_points=list(S.WORKSPACE_TF_POINTS), photon_range=(lo, hi))
+        fr.full_frame()
+        total_grid = fr.light_volume.clone()
+        if world > 1:
+            sharding.allreduce_light_volume(total_grid, transport)
+        fr.touched_mask = torch.zeros(((gdim + 3) // 4) ** 3, dtype=torch.uint8, device=ctx.device)
+        fractions = []
+        step_no = [0]
 
-    # the one exchange step -- the sum of the per-rank grids over xGMI -- overlaps the next frame's trace and bin
-    # (double-buffered grids, sharding.OverlappedGridReducer); everything outstanding is waited for inside the timed region
-    reducer = sharding.OverlappedGridReducer(fr.light_volume)
-    frame_no = [0]
+        def step():
+            t = 1 + step_no[0] % (n_steps - 1)
+            step_no[0] += 1
+            fr.set_volume(dvols[t])
+            fr.touched_mask.zero_()
+            n = fr.correlated_update()
+            fractions.append(n / max(fr.n, 1))
+            if world > 1 and isinstance(transport, sharding.RcclTransport):
+                # the delta path: only bricks touched by a re-traced photon (old or new position) changed on any rank
+                ctx.allreduce_grid_bricks(transport.comm, fr.light_volume, total_grid, fr.grid, fr.touched_mask)
+            elif world > 1:
+                total_grid.copy_(fr.light_volume)
+                sharding.allreduce_light_volume(total_grid, transport)
 
-    def step():
-        k = frame_no[0]
-        frame_no[0] += 1
+        def barrier():
+            torch.cuda.synchronize()
+            if dist is not None:
+                dist.barrier()
+            torch.cuda.synchronize()
+        use_graph = False
+    else:
+        fr = P.PhotonFrame(ctx, vol_np, tf, lattice, (gdim,) * 3, light_travel_direction=LIGHT_DIR, photon_range=(lo, hi))
+        use_graph = args.graph and not fast
         if use_graph:
-            k = 0  # the captured gather writes frame.light_volume (= buffer 0): no double buffering under replay
-            reducer.acquire(k)
-            fr.replay()
-        else:
-            fr.trace()
-            fr.bin()
-            fr.gather(out=reducer.acquire(k))
-        reducer.reduce(k)
+            fr.capture()
+        # the sum of the per-rank grids overlaps the next frame's trace and bin (double-buffered grids,
+        # sharding.OverlappedGridReducer); everything outstanding is waited for inside the timed region
+        reducer = sharding.OverlappedGridReducer(fr.light_volume, transport)
+        frame_no = [0]
 
-    def barrier():
-        reducer.flush()
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
+        def step():
+            k = frame_no[0]
+            frame_no[0] += 1
+            if use_graph:
+                k = 0  # the captured gather writes frame.light_volume (= buffer 0): no double buffering under replay
+                reducer.acquire(k)
+                fr.replay()
+            else:
+                fr.trace()
+                if fast:
+                    fr.bin_fast()
+                    fr.gather_fast(out=reducer.acquire(k))
+                else:
+                    fr.bin()
+                    fr.gather(out=reducer.acquire(k))
+            reducer.reduce(k)
+
+        def barrier():
+            reducer.flush()
+            torch.cuda.synchronize()
+            if dist is not None:
+                dist.barrier()
+            torch.cuda.synchronize()
 
     for _ in range(args.warmup):
         step()
@@ -250,114 +355,194 @@ def main():
         elapsed = float(t.item())
 
     # ---- second pass with per-kernel HIP events (library hook) on the same stream
+    prof_steps = min(args.steps, 100)
     ctx.profile_reset()
     ctx.profile_enable(True)
-    for _ in range(args.steps):
-        fr.trace()
-        fr.bin()
-        fr.gather()
+    for _ in range(prof_steps):
+        if correlated:
+            step()
+        else:
+            fr.trace()
+            if fast:
+                fr.bin_fast(); fr.gather_fast()
+            else:
+                fr.bin(); fr.gather()
     kern = ctx.profile_collect()
     ctx.profile_enable(False)
-    # ---- one more trace with the Woodcock iteration counter on (statistics; its atomics are not timed)
-    counter = torch.zeros(1, dtype=torch.int64, device="cuda")
-    ctx.set_step_counter(counter)
-    fr.trace()
-    torch.cuda.synchronize()
-    ctx.set_step_counter(None)
-    woodcock_steps = int(counter.item())
-
-    # ---- extra figure (never `value`): S independent frames in flight on S streams.  The kernels of one
-    # 1 M-photon frame are latency-bound, so frames of different time steps / progressive
-    # batches overlap; each frame owns its context, buffers and stream.
-    pipelined = None
-    if world == 1 and args.streams > 1:
-        ctxs = [B.Context(local_rank) for _ in range(args.streams)]
-        frames = [P.PhotonFrame(c, vol_np, tf, (nx, ny), (gdim,) * 3, light_travel_direction=light_dir) for c in ctxs]
-        streams = [torch.cuda.Stream() for _ in range(args.streams)]
-        rounds = max(1, args.steps // args.streams)
-        for it in range(rounds + 2):
-            if it == 2:
-                torch.cuda.synchronize()
-                tp = time.perf_counter()
-            for f, st in zip(frames, streams):
-                with torch.cuda.stream(st):
-                    f.trace(); f.bin(); f.gather()
+    woodcock_steps = None
+    extras = {}
+    if not correlated:
+        # one more trace with the Woodcock iteration counter on (statistics; its atomics are not timed)
+        counter = torch.zeros(1, dtype=torch.int64, device="cuda")
+        ctx.set_step_counter(counter)
+        fr.trace()
         torch.cuda.synchronize()
-        dtp = time.perf_counter() - tp
-        same = all(bool(torch.equal(f.light_volume, fr.light_volume)) for f in frames)
-        pipelined = {"streams": args.streams, "frames": rounds * args.streams,
-                     "value": round(rounds * args.streams * n_rank / dtp / 1e6, 2), "unit": "Mphotons/s",
-                     "ms_per_frame": round(dtp / (rounds * args.streams) * 1e3, 4),
-                     "light_volumes_identical_to_single_stream": same}
-        del frames, ctxs
+        ctx.set_step_counter(None)
+        woodcock_steps = int(counter.item())
 
-    splat_ms = None
-    if args.splat:
+    # ---- labelled extras (never `value`), rank 0 of a single-GPU run only
+    if world == 1 and not args.no_extras and not correlated:
+        reps = max(10, min(args.steps, 50))
+        # the other formulations of the same frame on the same photons
+        other = (lambda: (fr.trace(), fr.bin(), fr.gather())) if fast else (lambda: (fr.trace(), fr.bin_fast(), fr.gather_fast()))
+        extras["other_formulation"] = {"name": "exact" if fast else "fast", "ms_per_frame": round(timed(torch, other, reps), 4)}
         tmp = torch.zeros_like(fr.light_volume)
-        for _ in range(3):
-            fr.splat(tmp)
+        extras["reference_formulation_splat"] = {"ms_per_frame": round(timed(torch, lambda: (fr.trace(), fr.splat(tmp)), reps), 4),
+                                                 "splat_only_ms": round(timed(torch, lambda: fr.splat(tmp), reps), 4),
+                                                 "note": "trace + clear + atomic splat (the reference's own formulation, cpm_splat); order-dependent sums"}
+        # config 2 at I = 4 (multiple scattering, Henyey-Greenstein g = 0.3): N photons, up to 4 records each
+        f4 = P.PhotonFrame(ctx, fr.vol, fr.tf, lattice, (gdim,) * 3, light_travel_direction=LIGHT_DIR, max_interactions=4,
+                           material=(0.3, 0.0, 0.0, 0.0))
+        run4 = (lambda: (f4.trace(), f4.bin_fast(), f4.gather_fast())) if fast else (lambda: (f4.trace(), f4.bin(), f4.gather()))
+        ms4 = timed(torch, run4, reps)
+        stored4 = int((f4.photons[:, 0] != 3.402823466e+38).sum().item())
+        extras["i4"] = {"max_interactions": 4, "ms_per_frame": round(ms4, 4), "mphotons_per_s": round(n_rank / ms4 / 1e3, 2),
+                        "records_stored": stored4, "mrecords_per_s": round(stored4 / ms4 / 1e3, 2)}
+        del f4
+        # the tracer where it IS the frame: a sparse transfer function (~100 Woodcock steps per photon)
+        sparse = S.homogeneous_tf(0.01)
+        fs = P.PhotonFrame(ctx, fr.vol, sparse, lattice, (gdim,) * 3, light_travel_direction=LIGHT_DIR)
+        counter = torch.zeros(1, dtype=torch.int64, device="cuda")
+        ctx.set_step_counter(counter)
+        fs.trace()
         torch.cuda.synchronize()
-        ts = time.perf_counter()
-        for _ in range(args.steps):
-            fr.splat(tmp)
-        torch.cuda.synchronize()
-        splat_ms = (time.perf_counter() - ts) / args.steps * 1e3
+        ctx.set_step_counter(None)
+        ms_s = timed(torch, fs.trace, 10)
+        extras["sparse_tf_trace"] = {"tf": "constant alpha 0.01", "steps_per_photon": round(int(counter.item()) / n_rank, 2),
+                                     "trace_ms": round(ms_s, 4), "gsamples_per_s": round(int(counter.item()) / ms_s / 1e6, 3)}
+        del fs
+        if args.workload == "config2":
+            # BASELINE configs 3 and 5 on this GPU: ms per correlated update, fraction of the photons re-traced
+            base_pts = list(S.WORKSPACE_TF_POINTS)
+            edit = list(base_pts)
+            edit[3] = (0.26,) + base_pts[3][1:]
+            cm = P.CorrelatedPhotonMapper(ctx, vol_np, tf, lattice, (gdim,) * 3, light_travel_direction=LIGHT_DIR, tf_points=base_pts)  # its own volume: time steps replace it
+            cm.full_frame()
+            res = []
+            for rep in range(6):  # alternate edit / revert so that every update re-traces
+                pts = edit if rep % 2 == 0 else base_pts
+                torch.cuda.synchronize(); ta = time.perf_counter()
+                cm.set_transfer_function(pts)
+                n = cm.correlated_update()
+                torch.cuda.synchronize()
+                res.append(((time.perf_counter() - ta) * 1e3, n / cm.n))
+            extras["config3_tf_edit"] = {"update_ms": round(float(np.median([r[0] for r in res[2:]])), 4),
+                                         "fraction_retraced": round(float(np.mean([r[1] for r in res[2:]])), 5),
+                                         "includes": "TF upload, importance grid, per-photon importance, select, re-trace, +- splat, snapshot"}
+            n_steps = 6
+            vols = [torch.from_numpy(S.heterogeneous_volume(vdim, S.sequence_blob_center(t, 32))).to(ctx.device) for t in range(n_steps)]
+            cm.set_transfer_function(base_pts)
+            cm.full_frame()
+            res = []
+            for t in range(1, n_steps):
+                torch.cuda.synchronize(); ta = time.perf_counter()
+                cm.set_volume(vols[t])
+                torch.cuda.synchronize(); tb = time.perf_counter()
+                n = cm.correlated_update()
+                torch.cuda.synchronize()
+                res.append(((tb - ta) * 1e3, (time.perf_counter() - tb) * 1e3, n / cm.n))
+            extras["config5_time_step"] = {"steps": n_steps - 1, "volume_step_ms": round(float(np.median([r[0] for r in res])), 4),
+                                           "update_ms": round(float(np.median([r[1] for r in res])), 4),
+                                           "fraction_retraced": round(float(np.mean([r[2] for r in res])), 5),
+                                           "note": "time steps resident on the device (upload of 16 MiB not included)"}
+            del cm, vols
+        # S independent frames in flight on S streams (each frame owns its context, buffers and stream)
+        if args.streams > 1:
+            ctxs = [B.Context(local_rank) for _ in range(args.streams)]
+            frames = [P.PhotonFrame(c, vol_np, tf, lattice, (gdim,) * 3, light_travel_direction=LIGHT_DIR) for c in ctxs]
+            streams = [torch.cuda.Stream() for _ in range(args.streams)]
+            rounds = max(1, args.steps // args.streams)
+            for it in range(rounds + 2):
+                if it == 2:
+                    torch.cuda.synchronize()
+                    tp = time.perf_counter()
+                for f, st in zip(frames, streams):
+                    with torch.cuda.stream(st):
+                        f.trace()
+                        if fast:
+                            f.bin_fast(); f.gather_fast()
+                        else:
+                            f.bin(); f.gather()
+            torch.cuda.synchronize()
+            dtp = time.perf_counter() - tp
+            if fast:
+                fr.frame_fast()
+            else:
+                fr.frame()
+            same = all(bool(torch.equal(f.light_volume, fr.light_volume)) for f in frames)
+            extras["pipelined"] = {"streams": args.streams, "frames": rounds * args.streams,
+                                   "value": round(rounds * args.streams * n_rank / dtp / 1e6, 2), "unit": "Mphotons/s",
+                                   "ms_per_frame": round(dtp / (rounds * args.streams) * 1e3, 4),
+                                   "light_volumes_identical_to_single_stream": same}
+            del frames, ctxs
 
     if rank == 0:
-        n_photons = n_rank * world
         ms_per_step = elapsed / args.steps * 1e3
-        value = n_photons * args.steps / elapsed / 1e6
-        per_frame = {k: (tot / args.steps, calls / args.steps, tot / calls) for k, (tot, calls) in kern.items()}
+        value = n_total * args.steps / elapsed / 1e6
+        per_frame = {k: (tot / prof_steps, calls / prof_steps, tot / calls) for k, (tot, calls) in kern.items()}
 
         def stage(names):
             return round(sum(per_frame[k][0] for k in per_frame if any(k.startswith(n) for n in names)), 4)
 
         stages = {"trace": stage(["trace_kernel"]),
-                  "bin": stage(["bin_", "radix_", "cell_start"]),
-                  "gather": stage(["gather"])}
+                  "bin": stage(["bin_", "radix_", "cell_start", "fast_count", "fast_scan", "fast_scatter"]),
+                  "gather": stage(["gather", "fast_tile", "fast_combine"]),
+                  "reduce": stage(["rccl_"])}
         tile = 256 * (4 if n_rank <= (1 << 15) else 8 if n_rank <= (1 << 23) else 16)
         tiles = -(-n_rank // tile)
-        key_bits = int(gdim ** 3).bit_length()
-        passes = -(-key_bits // 8)
-        ab = algorithmic_bytes(n_rank, 1, vol_np.size, tf.shape[0], gdim ** 3, 1, tiles, passes)
-        dom = max(per_frame, key=lambda k: per_frame[k][0])
-        dom_base = dom.split("<")[0]
+        ab = algorithmic_bytes(n_rank, 1, vol_np.size, tf.shape[0], gdim ** 3, 1, tiles)
+        path_kernels = {k: v for k, v in per_frame.items() if k.split("<")[0].replace("cpm::", "") in ab or k.startswith("gather")}
+        dom = max(path_kernels or per_frame, key=lambda k: per_frame[k][0])
+        dom_base = dom.split("<")[0].replace("cpm::", "")
         if dom_base.startswith("gather"):
             dom_base = "gather_kernel"
         dom_avg_ms = per_frame[dom][2]
-        achieved = ab[dom_base] / (dom_avg_ms * 1e-3) / 1e9
-        frame_bytes = (ab["trace_kernel"] + ab["bin_keys_kernel"] + passes * (ab["radix_hist_kernel"] + ab["radix_rowscan_kernel"] + ab["radix_scatter_kernel"])
-                       + ab["bin_finalize_kernel"] + ab["cell_start_kernel"] + ab["gather_kernel"])
+        achieved = ab.get(dom_base, 0) / (dom_avg_ms * 1e-3) / 1e9
+        if fast:
+            frame_bytes = sum(ab[k] for k in ("trace_kernel", "fast_count_kernel", "fast_scatter_kernel", "fast_tile_kernel", "fast_combine_kernel"))
+        else:
+            passes = -(-int(gdim ** 3).bit_length() // 8)
+            frame_bytes = (ab["trace_kernel"] + ab["bin_keys_kernel"] + passes * (ab["radix_hist_kernel"] + ab["radix_rowscan_kernel"] + ab["radix_scatter_kernel"])
+                           + ab["bin_finalize_kernel"] + ab["cell_start_kernel"] + ab["gather_kernel"])
         traffic, traffic_src = pmc_traffic(dom.split("<")[0], args.workload)
+        what = {"fast": "brick bin + fixed-point LDS-tile gather (cpm_bin_fast + cpm_gather_fast: tolerance mode, rtol 2e-5 / atol 1e-5 max "
+                        "vs the reference semantics, bitwise reproducible)",
+                "exact": "cell sort + sequential per-voxel gather (cpm_bin + cpm_gather: bit-exact contract)"}[args.formulation]
         out = {
             "metric": "Mphotons/s traced+binned+gathered",
             "value": round(value, 2), "unit": "Mphotons/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"BASELINE {args.workload}: {vdim}^3 u8 heterogeneous volume, {n_rank} photons per GPU "
-                                   f"({nx}x{ny * world} lattice, one directional light), {gdim}^3 x1 f32 light volume, "
-                                   f"I=1, r=1 voxel, MWC64X streams from glibc srand(0)",
-                       "photons_per_gpu": n_rank, "volume": [vdim] * 3, "light_volume": [gdim] * 3,
-                       "parallelism": (f"photon-sharded x{world}, one RCCL all-reduce of the grid per frame, overlapped with the next "
-                                       f"frame's trace + bin (double-buffered grid)") if world > 1 else "single GPU",
+            "config": {"workload": (f"BASELINE {args.workload}: {vdim}^3 u8 heterogeneous volume, {n_total} photons per frame in all "
+                                    f"({lattice[0]}x{lattice[1]} lattice, one directional light; {n_rank} on rank 0), {gdim}^3 x1 f32 light volume, "
+                                    f"I=1, r=1 voxel, MWC64X streams from glibc srand(0)"
+                                    + ("; a step = one time step of the 32-step sequence: volume difference / min-max / importance, "
+                                       "correlated re-trace, delta light-volume update" if correlated else "")),
+                       "formulation": what, "photons_per_frame": n_total, "photons_rank0": n_rank, "volume": [vdim] * 3,
+                       "light_volume": [gdim] * 3,
+                       "parallelism": (f"photon-sharded x{world} ({scaling} scaling), one "
+                                       + ("touched-brick reduce (cpm_allreduce_grid_bricks)" if correlated else
+                                          "all-reduce of the grid per frame (cpm_allreduce_grid: RCCL on a side stream), overlapped with the next "
+                                          "frame's trace + bin (double-buffered grid)")
+                                       + f", transport {type(transport).__name__}") if world > 1 else "single GPU",
                        "launch": "captured HIP graph replay" if use_graph else "eager launches"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_src,
-                         "algorithmic_bytes_per_launch": ab[dom_base], "avg_launch_ms": round(dom_avg_ms, 5),
+                         "algorithmic_bytes_per_launch": ab.get(dom_base, 0), "avg_launch_ms": round(dom_avg_ms, 5),
                          "launches_per_frame": round(per_frame[dom][1], 2)},
             "frame": {"kernel_ms_per_frame": {k: round(v[0], 5) for k, v in sorted(per_frame.items(), key=lambda kv: -kv[1][0])},
                       "stage_ms": stages, "sum_kernel_ms": round(sum(v[0] for v in per_frame.values()), 4),
                       "algorithmic_bytes_per_frame": frame_bytes,
-                      "frame_hbm_frac": round(frame_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
-                      "woodcock_steps_per_frame": woodcock_steps,
-                      "gsamples_per_s": round(woodcock_steps / max(stages["trace"], 1e-9) / 1e6, 3)},
+                      "frame_hbm_frac": round(frame_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)},
         }
-        if pipelined is not None:
-            out["pipelined"] = pipelined
-        if splat_ms is not None:
-            out["frame"]["reference_formulation_splat_ms"] = round(splat_ms, 4)
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args.workload, vol_np, tf, (nx, ny), gdim, light_dir)
+        if woodcock_steps is not None:
+            out["frame"]["woodcock_steps_per_frame"] = woodcock_steps
+            out["frame"]["gsamples_per_s"] = round(woodcock_steps / max(stages["trace"], 1e-9) / 1e6, 3)
+        if correlated:
+            out["frame"]["fraction_retraced"] = round(float(np.mean(fractions[-args.steps:])), 5)
+        out.update(extras)
+        if world == 1 and not args.no_cpu_baseline and not correlated:
+            out["cpu_baseline"] = cpu_baseline(args.workload, vol_np, tf, lattice, gdim)
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

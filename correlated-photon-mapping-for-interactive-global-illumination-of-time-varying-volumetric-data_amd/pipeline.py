@@ -444,6 +444,9 @@ class CorrelatedPhotonMapper(PhotonFrame):
         # instead of the reference's -old / +new atomic splats (cheaper, within fp32 tolerance, not reproducible)
         self.exact_update = exact_update
         self.brick_mask = None
+        # multi-GPU delta path: when set (a zero-initialised uint8 tensor, one entry per 4x4x4-voxel brick), every light-volume
+        # update marks the bricks it changed -- what cpm_allreduce_grid_bricks sums over the ranks
+        self.touched_mask = None
         self.tf_points = list(tf_points) if tf_points is not None else list(S.WORKSPACE_TF_POINTS)
         vd = self.vol.dims
         self.brick_dims = tuple((d + region - 1) // region for d in vd)
@@ -577,6 +580,10 @@ class CorrelatedPhotonMapper(PhotonFrame):
             self.last_path = "exact incremental"
         elif self.prev_photons is not None and 0 < n < max_recomp:
             # incremental: remove the old contributions, add the new ones (processorcl.cpp:196-298)
+            if self.touched_mask is not None:
+                self.touched_mask.zero_()
+                ctx.mark_touched_bricks(self.prev_photons, idx, n, self.n, self.I, self.grid, self.radius, self.touched_mask)
+                ctx.mark_touched_bricks(self.photons, idx, n, self.n, self.I, self.grid, self.radius, self.touched_mask)
             ctx.splat_selected(self.prev_photons, idx, n, self.grid, self.radius, self.scale, -1.0, self.n, self.I, self.light_volume)
             ctx.splat_selected(self.photons, idx, n, self.grid, self.radius, self.scale, 1.0, self.n, self.I, self.light_volume)
             self.last_path = "incremental"
@@ -584,6 +591,8 @@ class CorrelatedPhotonMapper(PhotonFrame):
             self.bin()
             self.gather()
             self.last_path = "full"
+            if self.touched_mask is not None:
+                self.touched_mask.fill_(1)
         # snapshot for the next add-remove (a whole-buffer copy in the reference, :343-352): after a partial re-trace
         # only the re-traced photons differ from the snapshot, so only they move
         if self.last_path == "full" or self.prev_photons is None:

@@ -25,8 +25,11 @@ def test_bench_single_gpu_line():
                        capture_output=True, text=True, timeout=900, cwd=str(REPO))
     assert r.returncode == 0, r.stderr[-3000:]
     d = _last_json(r.stdout)
-    assert KEYS <= set(d) and {"cpu_baseline", "pipelined", "frame"} <= set(d)
+    assert KEYS <= set(d) and {"cpu_baseline", "pipelined", "frame", "other_formulation", "reference_formulation_splat", "i4",
+                               "sparse_tf_trace"} <= set(d)
     assert d["n_gpus"] == 1 and d["steps"] == 10 and d["warmup"] == 2 and d["value"] > 0 and d["scaling"] == "weak"
+    assert "cpm_bin_fast" in d["config"]["formulation"] and d["other_formulation"]["name"] == "exact"
+    assert any(k.startswith("fast_tile_kernel") for k in d["frame"]["kernel_ms_per_frame"])
     assert set(d["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic"}
     assert set(d["cpu_baseline"]) >= {"value", "unit", "cores", "kind", "sample"} and d["cpu_baseline"]["kind"] == "port"
     assert d["pipelined"]["light_volumes_identical_to_single_stream"] is True
@@ -43,5 +46,31 @@ def test_bench_two_ranks_code_path():
     assert KEYS <= set(d)
     assert d["n_gpus"] == 2 and d["steps"] == 6 and d["value"] > 0
     assert "cpu_baseline" not in d                      # rank 0 at N = 1 only
-    assert "all-reduce" in d["config"]["parallelism"]
-    assert d["config"]["photons_per_gpu"] == 65536     # weak scaling: the per-rank work is fixed
+    assert "all-reduce" in d["config"]["parallelism"] and d["scaling"] == "weak"
+    assert d["config"]["photons_rank0"] == 65536 and d["config"]["photons_per_frame"] == 131072   # weak: the per-rank work is fixed
+
+
+def test_bench_strong_scaling_and_exact_formulation():
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29534", str(REPO / "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1", "--workload", "config1",
+           "--scaling", "strong", "--formulation", "exact", "--test-backend", "gloo", "--test-one-device"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=str(REPO), env=env)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-4000:]
+    d = _last_json(r.stdout)
+    assert d["scaling"] == "strong" and d["config"]["photons_per_frame"] == 65536 and d["config"]["photons_rank0"] == 32768
+    assert "cpm_bin + cpm_gather" in d["config"]["formulation"]
+    assert any(k.startswith("gather") for k in d["frame"]["kernel_ms_per_frame"])
+
+
+def test_bench_single_process_rccl_world1():
+    """torch.distributed.run with one rank: the RCCL transport (cpm_comm through the C-ABI) is constructed and the line is
+    the single-GPU line."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", "29535", str(REPO / "bench.py"), "--gpus", "1", "--steps", "4", "--warmup", "1", "--workload", "config1",
+           "--no-extras", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=str(REPO), env=env)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-4000:]
+    d = _last_json(r.stdout)
+    assert d["n_gpus"] == 1 and d["value"] > 0

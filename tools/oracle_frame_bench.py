@@ -18,7 +18,7 @@ ovol = o.volume(vol_np); og = o.grid((128,)*3, 1)
 p = OTraceParams(); p.step_size = 1.0/256; p.n_light_samples = n; p.max_interactions = 1; p.total_photons = n
 photons = np.zeros((n, 8), np.float32); out = np.zeros(128**3, np.float32)
 radius = S.photon_radius_texture((256,)*3, 1.0); scale = o.relative_irradiance_scale(radius, n)
-for T in (32, 64, 128, 256):
+for T in [int(x) for x in (sys.argv[1].split(",") if len(sys.argv) > 1 else "16,32,64,128,256".split(","))]:
     o.set_threads(T)
     best = None
     for rep in range(4):
