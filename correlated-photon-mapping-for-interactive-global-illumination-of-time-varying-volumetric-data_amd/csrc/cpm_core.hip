@@ -69,6 +69,7 @@ int cpm_abi_version(void) { return CPM_ABI_VERSION; }
 void cpm_profile_enable(cpm_ctx* ctx, int on) { if (ctx) ctx->profiling = on != 0; }
 void cpm_profile_reset(cpm_ctx* ctx) {
     if (!ctx) return;
+    (void)hipSetDevice(ctx->device);  // one host thread may drive several contexts / GPUs
     (void)hipDeviceSynchronize();
     for (auto& r : ctx->prof_pending) { ctx->prof_pool.push_back(r.a); ctx->prof_pool.push_back(r.b); }
     ctx->prof_pending.clear();
@@ -76,6 +77,7 @@ void cpm_profile_reset(cpm_ctx* ctx) {
 }
 int cpm_profile_collect(cpm_ctx* ctx) {
     if (!ctx) return 0;
+    (void)hipSetDevice(ctx->device);
     (void)hipDeviceSynchronize();
     for (auto& r : ctx->prof_pending) {
         float ms = 0.f;
@@ -116,6 +118,10 @@ int cpm_create(int device, cpm_ctx** out) {
     ctx->device = device;
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) ctx->num_cus = prop.multiProcessorCount;
+    if (hipMalloc((void**)&ctx->dir_hint, 8 * sizeof(float)) != hipSuccess || hipMemset(ctx->dir_hint, 0, 8 * sizeof(float)) != hipSuccess) {
+        delete ctx;
+        return set_error(nullptr, CPM_ERR_OUT_OF_MEMORY, "cpm_create", "device allocation failed");
+    }
     *out = ctx;
     return CPM_OK;
 }
@@ -123,6 +129,7 @@ int cpm_create(int device, cpm_ctx** out) {
 void cpm_destroy(cpm_ctx* ctx) {
     if (!ctx) return;
     for (int i = 0; i < 8; ++i) if (ctx->scratch[i]) (void)hipFree(ctx->scratch[i]);
+    if (ctx->dir_hint) (void)hipFree(ctx->dir_hint);
     for (auto& r : ctx->prof_pending) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
     for (auto e : ctx->prof_pool) (void)hipEventDestroy(e);
     delete ctx;

@@ -27,6 +27,10 @@ struct cpm_ctx {
     // grow-only scratch arenas (no allocation in steady state)
     void* scratch[8] = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };
     size_t scratch_bytes[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+    // device, 8 floats: (theta, phi) of the last directional-light emission, decodeDirection of it, encodeDirection of that,
+    // valid flag -- a pure function of (theta, phi), evaluated once by the emitter so that the tracer's workgroups need not
+    // (cpm_trace.hip; used only for samples whose (theta, phi) bit patterns match)
+    float* dir_hint = nullptr;
     size_t fast_hist_words = 0;  // cpm_bin_fast: size of the histogram whose all-zero state is established (0 = none)
 };
 

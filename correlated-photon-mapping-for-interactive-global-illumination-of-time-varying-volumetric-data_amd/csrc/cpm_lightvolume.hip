@@ -29,6 +29,26 @@ __host__ int make_grid_dev(cpm_ctx* ctx, const cpm_grid_desc* g, GridDev& G) {
     return CPM_OK;
 }
 
+// cpm_bin's cell keys (floor(p * dims)) and cpm_gather's halo width (floor(r * dims + 0.5) cells) are written for Inviwo's
+// own light-volume matrices, textureToIndex = scale(dims) then translate(-0.5) and its inverse -- what
+// cpm_grid_desc_default builds and what PhotonToLightVolumeProcessorCL creates (ref processor/
+// photontolightvolumeprocessorcl.cpp:137-170).  Any other (scaled / offset) light volume is refused here rather than
+// binned against the wrong cells; cpm_splat and the tolerance-mode pair cpm_bin_fast + cpm_gather_fast read the matrices.
+__host__ bool default_matrices(const GridDev& G) {
+    const float d[3] = { (float)G.dx, (float)G.dy, (float)G.dz };
+    const float ts[3] = { G.t2i.sx, G.t2i.sy, G.t2i.sz }, tt[3] = { G.t2i.tx, G.t2i.ty, G.t2i.tz };
+    const float is[3] = { G.i2t.sx, G.i2t.sy, G.i2t.sz }, it[3] = { G.i2t.tx, G.i2t.ty, G.i2t.tz };
+    for (int a = 0; a < 3; ++a)
+        if (ts[a] != d[a] || tt[a] != -0.5f || is[a] != 1.0f / d[a] || it[a] != 0.5f / d[a]) return false;
+    return true;
+}
+#define CPM_REQUIRE_DEFAULT_MATRICES(ctx, G, who)                                                                       \
+    do {                                                                                                                \
+        if (!default_matrices(G))                                                                                       \
+            return set_error((ctx), CPM_ERR_UNSUPPORTED, who,                                                           \
+                             "needs the default light-volume matrices (scale(dims), translate(-0.5)); use cpm_bin_fast + cpm_gather_fast or cpm_splat"); \
+    } while (0)
+
 struct Box3 { int sx, sy, sz, ex, ey, ez; };
 
 // photonstolightvolume.cl:45-47: convert_int3 truncates; upper bound exclusive, +1 before truncation
@@ -1151,6 +1171,7 @@ int cpm_bin(cpm_ctx* ctx, const float* photons8, int n, const cpm_grid_desc* gri
     GridDev G;
     int rc = make_grid_dev(ctx, grid, G);
     if (rc) return rc;
+    CPM_REQUIRE_DEFAULT_MATRICES(ctx, G, "cpm_bin");
     CPM_REQUIRE(ctx, n >= 0, "cpm_bin: n < 0");
     CPM_REQUIRE(ctx, cell_start, "cpm_bin: null cell_start");
     CPM_REQUIRE(ctx, n == 0 || (photons8 && order && sorted_pos_power), "cpm_bin: null buffer");
@@ -1238,6 +1259,7 @@ static int gather_impl(cpm_ctx* ctx, const float* sorted_pos_power, const uint32
     GridDev G;
     int rc = make_grid_dev(ctx, grid, G);
     if (rc) return rc;
+    CPM_REQUIRE_DEFAULT_MATRICES(ctx, G, "cpm_gather");
     CPM_REQUIRE(ctx, n >= 0 && radius > 0.f, "cpm_gather: bad size or radius");
     CPM_REQUIRE(ctx, cell_start && grid_out && (sorted_pos_power || n == 0), "cpm_gather: null buffer");
     CPM_REQUIRE_ALIGNED16(ctx, sorted_pos_power, "cpm_gather");
@@ -1270,8 +1292,10 @@ static int gather_impl(cpm_ctx* ctx, const float* sorted_pos_power, const uint32
     const bool dense = (long long)n * 4 >= (long long)cells;
     // the tuned record-major kernels: halo of <= 2 cells, 2 to 4 candidate voxels per axis (r < 2 cells); 4-channel
     // light volumes up to 3 candidates (the slot planes of 4 x 4 x 4 x 3 would not fit a workgroup's LDS)
+    // (mod3_ of the 3-candidate kernels is exact for coordinates below 2^15 only: longer axes take the generic kernels)
+    const bool mod3_ok = cand_axis != 3 || (G.dx <= 32768 && G.dy <= 32768 && G.dz <= 32768);
     const bool tuned = (cand_axis <= 3 || (cand_axis == 4 && dense && G.channels == 1)) && Rx <= 2 && Ry <= 2 && Rz <= 2 &&
-                       g_gather_force_voxel == 0;
+                       g_gather_force_voxel == 0 && mod3_ok;
 #define CPM_COOP_LAUNCH(NB, MAXC, CH)                                                                                          \
     do {                                                                                                                       \
         const int zq = div_up(bzn, NB);                                                                                        \

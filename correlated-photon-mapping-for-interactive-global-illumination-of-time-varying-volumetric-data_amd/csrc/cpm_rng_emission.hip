@@ -86,9 +86,19 @@ __device__ __forceinline__ void store_sample(float* ls, int i, f3 o, f3 pw, floa
 }
 
 // lightcl/cl/directionallightsampler.cl:38-63
-__global__ void directional_light_kernel(const float4* __restrict__ samples, int n, Light L, float* __restrict__ ls) {
+__global__ void directional_light_kernel(const float4* __restrict__ samples, int n, Light L, float* __restrict__ ls,
+                                         float* __restrict__ dir_hint) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
+    if (i == 0) {  // every sample of this light carries the same (theta, phi): what the tracer derives from it, once
+        const f3 d0 = { L.a[0], L.a[1], L.a[2] };
+        float t0, p0, t1, p1;
+        encode_direction_(d0, t0, p0);
+        const f3 d1 = decode_direction_(t0, p0);
+        encode_direction_(d1, t1, p1);
+        dir_hint[0] = t0; dir_hint[1] = p0; dir_hint[2] = d1.x; dir_hint[3] = d1.y; dir_hint[4] = d1.z; dir_hint[5] = t1; dir_hint[6] = p1;
+        dir_hint[7] = 1.0f;
+    }
     float4 s = samples[i];
     f3 o = { fma_(L.v[0], s.y, fma_(L.u[0], s.x, L.origin[0])),
              fma_(L.v[1], s.y, fma_(L.u[1], s.x, L.origin[1])),
@@ -225,7 +235,7 @@ int cpm_directional_light_samples(cpm_ctx* ctx, const float* samples4, int n, co
     }
     L.area = plane_area;
     CPM_LAUNCH(ctx, directional_light_kernel, dim3(div_up(n, 256)), dim3(256), 0, (hipStream_t)stream,
-                       reinterpret_cast<const float4*>(samples4), n, L, ls);
+                       reinterpret_cast<const float4*>(samples4), n, L, ls, ctx->dir_hint);
     CPM_LAUNCH_CHECK(ctx, "directional_light_kernel");
     return CPM_OK;
 }

@@ -50,6 +50,7 @@ struct TraceArgs {
     uint32_t* rng;
     float* photons;
     unsigned long long* step_counter;  // nullable (statistics build of the launch)
+    const float* dir_hint;             // cpm_ctx::dir_hint
 };
 
 template <int DT> struct PairLoad;
@@ -192,8 +193,9 @@ __global__ __launch_bounds__(256, 8) void trace_kernel(const TraceArgs A) {
     extern __shared__ float lds[];
     // One decoded / re-encoded direction per workgroup: a directional light gives every sample the same (theta, phi),
     // and decodeDirection + encodeDirection (two sincos, acos, atan2, a division: ~200 instructions) is a pure function of
-    // those two words.  Thread 0 evaluates it for ITS sample; a wave whose lanes all carry the same bit patterns takes
-    // the shared result (the same operations on the same inputs: the same bits), any other wave evaluates per lane.
+    // those two words.  Thread 0 provides it for ITS sample (from the emitter's hint, else by evaluating it); a wave whose
+    // lanes all carry the same bit patterns takes the shared result (the same operations on the same inputs: the same
+    // bits), any other wave evaluates per lane.
     __shared__ float s_dir[8];
     float* lut = lds;
     float* luts = lds;
@@ -225,10 +227,17 @@ __global__ __launch_bounds__(256, 8) void trace_kernel(const TraceArgs A) {
         for (int i = threadIdx.x; i < A.tf_width; i += blockDim.x) luts[i] = A.tfs_alpha[i];
     }
     if (threadIdx.x == 0) {
-        const f3 d0 = decode_direction_(l1.z, l1.w);
-        float t0, p0;
-        encode_direction_(d0, t0, p0);
-        s_dir[0] = l1.z; s_dir[1] = l1.w; s_dir[2] = d0.x; s_dir[3] = d0.y; s_dir[4] = d0.z; s_dir[5] = t0; s_dir[6] = p0;
+        // the emitter's hint (cpm_directional_light_samples left decode / encode of ITS (theta, phi) in the context): taken
+        // when it is for this thread's (theta, phi); otherwise thread 0 evaluates them itself
+        const float4 h0 = reinterpret_cast<const float4*>(A.dir_hint)[0], h1 = reinterpret_cast<const float4*>(A.dir_hint)[1];
+        if (h1.w == 1.0f && __float_as_uint(h0.x) == __float_as_uint(l1.z) && __float_as_uint(h0.y) == __float_as_uint(l1.w)) {
+            s_dir[0] = h0.x; s_dir[1] = h0.y; s_dir[2] = h0.z; s_dir[3] = h0.w; s_dir[4] = h1.x; s_dir[5] = h1.y; s_dir[6] = h1.z;
+        } else {
+            const f3 d0 = decode_direction_(l1.z, l1.w);
+            float t0, p0;
+            encode_direction_(d0, t0, p0);
+            s_dir[0] = l1.z; s_dir[1] = l1.w; s_dir[2] = d0.x; s_dir[3] = d0.y; s_dir[4] = d0.z; s_dir[5] = t0; s_dir[6] = p0;
+        }
     }
     __syncthreads();
     if (!live) return;
@@ -389,6 +398,7 @@ int cpm_trace(cpm_ctx* ctx, const cpm_volume* vol, const cpm_tf* tf, const cpm_t
     A.rng = rng_state;
     A.photons = photons8;
     A.step_counter = g_step_counter;
+    A.dir_hint = ctx->dir_hint;
 
     size_t lds = (size_t)tf->width * sizeof(float) * (A.tfs_alpha != A.tf_alpha ? 2 : 1);
     hipStream_t s = (hipStream_t)stream;

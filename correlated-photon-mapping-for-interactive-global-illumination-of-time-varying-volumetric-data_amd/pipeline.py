@@ -258,11 +258,15 @@ class PhotonFrame:
         self.gather_fast()
         return self.light_volume
 
-    def splat(self, out=None):
-        """Reference formulation (atomic splat), for comparison: clear + splat."""
+    def splat(self, out=None, all_interactions=False):
+        """Reference formulation (atomic splat), for comparison: clear + splat.
+        The reference's full splat adds interaction 0 only (its guard compares against N although the launch covers N x I
+        work-items: ref cl/photonstolightvolume.cl:154-158, processor/photontolightvolumeprocessorcl.cpp:304,380; SURVEY
+        Q1) -- the default here; bin + gather cover all N x I records (what the reference's own incremental splat does,
+        :192-201).  all_interactions=True splats all records, the counterpart of the gather at I > 1."""
         out = self.light_volume if out is None else out
         out.zero_()
-        self.ctx.splat(self.photons, self.n, self.grid, self.radius, self.scale, out)
+        self.ctx.splat(self.photons, self.n * self.I if all_interactions else self.n, self.grid, self.radius, self.scale, out)
         return out
 
     def frame(self):

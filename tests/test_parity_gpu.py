@@ -674,3 +674,45 @@ def test_sort_pass_structures(ctx, mode, n, bits_):
             assert np.array_equal(_n(kd, np.uint32), keys[order])
     finally:
         ctx.lib.cpm_debug_set_sort_mode(0)
+
+
+def test_non_default_grid_matrices_are_refused_by_the_cell_sorted_path(ctx, cpm):
+    """cpm_bin / cpm_gather are written for Inviwo's own light-volume matrices; a scaled or offset light volume is refused
+    (CPM_ERR_UNSUPPORTED) instead of being binned against the wrong cells.  cpm_splat and the tolerance-mode
+    pair honour the matrices (tests/test_fast_gpu.py::test_fast_non_default_grid_matrices)."""
+    B = cpm.binding
+    grid = B.default_grid_desc((16, 16, 16), 1)
+    grid.texture_to_index[0] = 20.0
+    t = ctx.torch
+    ph = t.zeros((8, 8), dtype=t.float32, device=ctx.device)
+    order = t.zeros(8, dtype=t.int32, device=ctx.device)
+    cs = t.zeros(16 ** 3 + 1, dtype=t.int32, device=ctx.device)
+    srt = t.zeros((8, 4), dtype=t.float32, device=ctx.device)
+    out = t.zeros(16 ** 3, dtype=t.float32, device=ctx.device)
+    with pytest.raises(B.CpmError) as e:
+        ctx.bin(ph, 8, grid, order, cs, srt)
+    assert e.value.status == -4
+    with pytest.raises(B.CpmError) as e:
+        ctx.gather(srt, cs, 8, grid, 0.05, 1.0, out)
+    assert e.value.status == -4
+    ctx.splat(ph, 8, grid, 0.05, 1.0, out)            # the reference formulation reads the matrices
+
+
+def test_gather_and_splat_at_several_interactions(ctx, oracle, cpm):
+    """I = 3: bin + gather cover all N x I records (documented), the reference's full splat interaction 0 only (SURVEY Q1);
+    splat(all_interactions=True) is the gather's counterpart."""
+    S, P = cpm.synthetic, cpm.pipeline
+    fr = P.PhotonFrame(ctx, S.heterogeneous_volume(64), S.workspace_tf(), 160, (32, 32, 32), light_travel_direction=(0.3, 0.5, -1.0),
+                       max_interactions=3, material=(0.4, 0.0, 0.0, 0.0))
+    lv = _n(fr.frame()).copy()
+    lvf = _n(fr.frame_fast()).copy()
+    sp_all = _n(fr.splat(ctx.torch.zeros_like(fr.light_volume), all_interactions=True))
+    np.testing.assert_allclose(lv, sp_all, rtol=1e-4, atol=1e-5 * float(sp_all.max()))
+    np.testing.assert_allclose(lvf, sp_all, rtol=1e-4, atol=1e-5 * float(sp_all.max()))
+    sp0 = _n(fr.splat(ctx.torch.zeros_like(fr.light_volume)))                    # interaction 0 only
+    og = oracle.grid((32, 32, 32), 1)
+    ph = _n(fr.photons)
+    want0 = np.zeros(32 ** 3, np.float32)
+    oracle.splat(ph, fr.n, og, fr.radius, fr.scale, want0)
+    np.testing.assert_allclose(sp0, want0, rtol=1e-4, atol=1e-5 * float(want0.max()))
+    assert sp_all.sum() > sp0.sum() > 0                                          # later interactions were stored and add light
