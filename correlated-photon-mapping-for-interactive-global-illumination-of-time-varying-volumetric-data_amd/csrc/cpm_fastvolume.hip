@@ -31,7 +31,7 @@ namespace {
 constexpr int kTileThreads = 1024;
 constexpr int kCombineThreads = 128;
 constexpr int kFastChunk = 4096;   // photons per tile-gather work item (1024 threads x 4)
-constexpr int kCountItems = 4;     // photons per thread of fast_count_kernel (1024 threads)
+constexpr int kCountItems = 2;     // photons per thread of fast_count_kernel (1024 threads)
 constexpr int kCountTile = 1024 * kCountItems;
 constexpr int kMaxBricks = 16384;  // LDS histogram of fast_count_kernel: 64 KiB
 
@@ -97,7 +97,6 @@ __host__ size_t max_items_for(const BrickLayout& L, int n) {
 __host__ size_t table_entries(const BrickLayout& L, int n) {
     return (((size_t)2 * L.nb + 6 + 3) & ~(size_t)3) + 4 * max_items_for(L, n);
 }
-__host__ int ceil_log2(long long n) { int b = 1; while (b < 62 && (1ll << b) < n) ++b; return b; }
 
 // the photon's cell (the voxel whose centre is nearest: floor(index + 0.5), clamped) and brick
 CPM_DEV uint32_t brick_key(const GridDev& G, const BrickLayout& L, float4 a) {
@@ -110,15 +109,22 @@ CPM_DEV uint32_t brick_key(const GridDev& G, const BrickLayout& L, float4 a) {
 }
 CPM_DEV bool is_sentinel(float4 a) { return a.x == kFltMax || a.y == kFltMax || a.z == kFltMax; }
 
-// Fixed-point scale 2^sh: every |contribution| <= m = maxpow * |k| * 0.75 < 2^e, at most 2^n_log2 of them per voxel:
-// sh = 62 - n_log2 - e keeps every partial sum inside int64.  A function of (maxpow, k, n) only.
-CPM_DEV float fixed_scale(float maxpow, float k, int n_log2) {
+// Fixed-point scale 2^sh: every |contribution| <= m = maxpow * |k| * 0.75 < 2^e; sh = 30 - e makes every contribution
+// fit a signed 32-bit integer (one v_cvt_i32_f32 -- there is no f32 -> i64 instruction; the generic conversion is 13), and
+// fewer than 2^31 of them per voxel keep every partial sum inside int64.  Resolution: 2^-30 of the largest contribution,
+// 64 times finer than the last bit of an fp32 sum of that size.  A function of (maxpow, k) only.
+CPM_DEV float fixed_scale(float maxpow, float k) {
     const float m = maxpow * __builtin_fabsf(k) * 0.75f;
     if (!(m > 0.f) || m > kFltMax) return 1.0f;
     const int e = (int)((__float_as_uint(m) >> 23) & 0xffu) - 126;  // m < 2^e
-    int sh = 62 - n_log2 - e;
+    int sh = 30 - e;
     sh = sh > 100 ? 100 : (sh < -100 ? -100 : sh);
     return __uint_as_float((uint32_t)(sh + 127) << 23);
+}
+// value * S truncated toward zero, as a 64-bit addend
+CPM_DEV unsigned long long to_fixed(float v, float S) {
+    const int q = (int)(v * S);  // |v * S| < 2^30
+    return (unsigned long long)(long long)q;
 }
 
 // Exclusive scans of the brick counts (-> brick starts) and of the bricks' chunk counts (-> item starts), the work
@@ -289,15 +295,17 @@ CPM_DEV void tile_record(const GridDev& G, float4 a, float pg, float pb, int ox,
 #pragma unroll
             for (int qx = 0; qx < MAXC; ++qx) {
                 const float d2 = fma_(dzv[qz], dzv[qz], fma_(dyv[qy], dyv[qy], dxv[qx] * dxv[qx]));
-                if (okx[qx] && oky[qy] && okz[qz] && d2 <= r2) {
-                    const float w = 0.75f * (1.0f - d2 * inv_r2);
-                    const int idx = base + qx + tx * (qy + ty * qz);
-                    const long long q0 = (long long)((pk * w) * S);
-                    if (q0 != 0) atomicAdd(reinterpret_cast<unsigned long long*>(tile + idx), (unsigned long long)q0);
-                    if (CH == 4) {
-                        const long long q1 = (long long)((pkg * w) * S), q2 = (long long)((pkb * w) * S);
-                        if (q1 != 0) atomicAdd(reinterpret_cast<unsigned long long*>(tile + plane + idx), (unsigned long long)q1);
-                        if (q2 != 0) atomicAdd(reinterpret_cast<unsigned long long*>(tile + 2 * plane + idx), (unsigned long long)q2);
+                // the value is formed for every candidate (7 instructions); only the LDS add is conditional
+                const float w = 0.75f * (1.0f - d2 * inv_r2);
+                const int idx = base + qx + tx * (qy + ty * qz);
+                const bool hit = okx[qx] && oky[qy] && okz[qz] && d2 <= r2;
+                const unsigned long long q0 = to_fixed(pk * w, S);
+                if (hit) atomicAdd(reinterpret_cast<unsigned long long*>(tile + idx), q0);
+                if (CH == 4) {
+                    const unsigned long long q1 = to_fixed(pkg * w, S), q2 = to_fixed(pkb * w, S);
+                    if (hit) {
+                        atomicAdd(reinterpret_cast<unsigned long long*>(tile + plane + idx), q1);
+                        atomicAdd(reinterpret_cast<unsigned long long*>(tile + 2 * plane + idx), q2);
                     }
                 }
             }
@@ -305,10 +313,11 @@ CPM_DEV void tile_record(const GridDev& G, float4 a, float pg, float pb, int ox,
 
 // gather, launch 1 of 2.  A fixed grid of resident workgroups (two per CU) walks the work items: the number of items
 // is only known on the device, and a launch sized for the worst case (bricks + chunks) spent its time dispatching
-// thousands of 16-wave workgroups that found nothing to do.
+// thousands of 16-wave workgroups that found nothing to do.  The next item's records are requested before the current
+// item's are processed.
 template <int MAXC, int CH>
 __global__ __launch_bounds__(kTileThreads) void fast_tile_kernel(const float* __restrict__ sorted, const uint32_t* __restrict__ table, GridDev G,
-                                                        BrickLayout L, float radius, float k, int n_log2,
+                                                        BrickLayout L, float radius, float k,
                                                         long long* __restrict__ slabs) {
     extern __shared__ long long s_tile[];
     constexpr int CH3 = CH == 4 ? 3 : 1, STRIDE = CH == 4 ? 2 : 1, PER = kFastChunk / kTileThreads;
@@ -317,20 +326,25 @@ __global__ __launch_bounds__(kTileThreads) void fast_tile_kernel(const float* __
     const int words = CH3 * L.tile;
     const float rgx = radius * G.t2i.sx + 1e-3f, rgy = radius * G.t2i.sy + 1e-3f, rgz = radius * G.t2i.sz + 1e-3f;
     const float r2 = radius * radius, inv_r2 = 1.0f / r2;
-    const float S = fixed_scale(__uint_as_float(table[off_meta(L) + kMetaMaxPow]), k, n_log2);
+    const float S = fixed_scale(__uint_as_float(table[off_meta(L) + kMetaMaxPow]), k);
     const float4* __restrict__ rec = reinterpret_cast<const float4*>(sorted);
     const uint4* __restrict__ items = reinterpret_cast<const uint4*>(table + off_items(L));
-    for (uint32_t item = blockIdx.x; item < n_items; item += gridDim.x) {
-        const uint4 desc = items[item];  // (brick, first record, end record, -)
-        const uint32_t b = desc.x, j0 = desc.y, j1 = desc.z;
-        // all of this thread's records first (independent 16-byte loads in flight), the tile is cleared meanwhile
-        float4 a[PER], a2[PER];
+    auto fetch = [&](uint32_t item, uint4& desc, float4* a, float4* a2) {
+        desc = make_uint4(0u, 0u, 0u, 0u);
+        if (item < n_items) desc = items[item];  // (brick, first record, end record, -)
 #pragma unroll
         for (int q = 0; q < PER; ++q) {
-            const uint32_t j = j0 + (uint32_t)(q * kTileThreads + t);
+            const uint32_t j = desc.y + (uint32_t)(q * kTileThreads + t);
             a[q] = make_float4(0.f, 0.f, 0.f, 0.f); a2[q] = a[q];
-            if (j < j1) { a[q] = rec[STRIDE * (size_t)j]; if (CH == 4) a2[q] = rec[2 * (size_t)j + 1]; }
+            if (j < desc.z) { a[q] = rec[STRIDE * (size_t)j]; if (CH == 4) a2[q] = rec[2 * (size_t)j + 1]; }
         }
+    };
+    uint4 desc, desc_n;
+    float4 a[PER], a2[PER], an[PER], an2[PER];
+    fetch(blockIdx.x, desc, a, a2);
+    for (uint32_t item = blockIdx.x; item < n_items; item += gridDim.x) {
+        fetch(item + gridDim.x, desc_n, an, an2);  // the next item's records: in flight while this item is processed
+        const uint32_t b = desc.x, j0 = desc.y, j1 = desc.z;
         for (int w = t; w < words; w += kTileThreads) s_tile[w] = 0ll;
         const int bx = (int)(b % (uint32_t)L.nbx), by = (int)((b / (uint32_t)L.nbx) % (uint32_t)L.nby), bz = (int)(b / (uint32_t)(L.nbx * L.nby));
         const int ox = (bx << L.lx) - L.hx, oy = (by << L.ly) - L.hy, oz = (bz << L.lz) - L.hz;
@@ -345,6 +359,9 @@ __global__ __launch_bounds__(kTileThreads) void fast_tile_kernel(const float* __
         long long* __restrict__ slab = slabs + (size_t)item * (size_t)words;
         for (int w = t; w < words; w += kTileThreads) slab[w] = s_tile[w];
         __syncthreads();  // the tile is cleared again at the top
+        desc = desc_n;
+#pragma unroll
+        for (int q = 0; q < PER; ++q) { a[q] = an[q]; a2[q] = an2[q]; }
     }
 }
 
@@ -352,7 +369,7 @@ __global__ __launch_bounds__(kTileThreads) void fast_tile_kernel(const float* __
 // reaches it), one rounding to float
 template <int CH>
 __global__ __launch_bounds__(kCombineThreads) void fast_combine_kernel(const long long* __restrict__ slabs, const uint32_t* __restrict__ table,
-                                                           GridDev G, BrickLayout L, float k, int n_log2, int accumulate,
+                                                           GridDev G, BrickLayout L, float k, int accumulate,
                                                            float* __restrict__ out) {
     constexpr int CH3 = CH == 4 ? 3 : 1;
     __shared__ uint32_t s_lo[27], s_hi[27];
@@ -376,7 +393,7 @@ __global__ __launch_bounds__(kCombineThreads) void fast_combine_kernel(const lon
     __syncthreads();
     const bool any = s_any != 0;
     if (!any && accumulate) return;
-    const float S = fixed_scale(__uint_as_float(table[off_meta(L) + kMetaMaxPow]), k, n_log2);
+    const float S = fixed_scale(__uint_as_float(table[off_meta(L) + kMetaMaxPow]), k);
     const float invS = 1.0f / S;  // a power of two: exact
     const int BX = 1 << L.lx, BY = 1 << L.ly, bvox = BX * BY * (1 << L.lz);
     const size_t words = (size_t)CH3 * (size_t)L.tile;
@@ -392,21 +409,36 @@ __global__ __launch_bounds__(kCombineThreads) void fast_combine_kernel(const lon
             const int nx = lx < L.hx ? -1 : (lx >= BX - L.hx ? 1 : 0);
             const int ny = ly < L.hy ? -1 : (ly >= BY - L.hy ? 1 : 0);
             const int nz = lz < L.hz ? -1 : (lz >= BZ - L.hz ? 1 : 0);
+            // the first chunk of every covering tile: up to eight independent loads in flight; bricks with more chunks
+            // (more than 4096 photons) are rare and finish in the loop behind
+            long long v0[8], v1[8], v2[8];
+            uint32_t lo_[8], hi_[8];
+            size_t idx_[8];
 #pragma unroll
             for (int c = 0; c < 8; ++c) {
                 const int ax = (c & 1) ? nx : 0, ay = (c & 2) ? ny : 0, az = (c & 4) ? nz : 0;
                 const bool covers = !((c & 1) && nx == 0) && !((c & 2) && ny == 0) && !((c & 4) && nz == 0);
                 const int d = (ax + 1) + 3 * (ay + 1) + 9 * (az + 1);
-                const uint32_t lo = s_lo[d], hi = covers ? s_hi[d] : 0u;
+                lo_[c] = s_lo[d]; hi_[c] = covers ? s_hi[d] : 0u;
                 // this voxel inside that brick's tile (origin = brick origin - halo)
                 const int ix = lx - ax * BX + L.hx, iy = ly - ay * BY + L.hy, iz = lz - az * BZ + L.hz;
-                const size_t idx = (size_t)ix + (size_t)L.tx * ((size_t)iy + (size_t)L.ty * (size_t)iz);
-                for (uint32_t item = lo; item < hi; ++item) {
-                    const long long* __restrict__ slab = slabs + (size_t)item * words;
-                    sr += slab[idx];
-                    if (CH == 4) { sg += slab[(size_t)L.tile + idx]; sb += slab[2 * (size_t)L.tile + idx]; }
+                idx_[c] = (size_t)ix + (size_t)L.tx * ((size_t)iy + (size_t)L.ty * (size_t)iz);
+                v0[c] = 0; v1[c] = 0; v2[c] = 0;
+                if (hi_[c] > lo_[c]) {
+                    const long long* __restrict__ slab = slabs + (size_t)lo_[c] * words;
+                    v0[c] = slab[idx_[c]];
+                    if (CH == 4) { v1[c] = slab[(size_t)L.tile + idx_[c]]; v2[c] = slab[2 * (size_t)L.tile + idx_[c]]; }
                 }
             }
+#pragma unroll
+            for (int c = 0; c < 8; ++c) { sr += v0[c]; if (CH == 4) { sg += v1[c]; sb += v2[c]; } }
+#pragma unroll
+            for (int c = 0; c < 8; ++c)
+                for (uint32_t item = lo_[c] + 1; item < hi_[c]; ++item) {
+                    const long long* __restrict__ slab = slabs + (size_t)item * words;
+                    sr += slab[idx_[c]];
+                    if (CH == 4) { sg += slab[(size_t)L.tile + idx_[c]]; sb += slab[2 * (size_t)L.tile + idx_[c]]; }
+                }
         }
         const size_t o = (size_t)gx + (size_t)G.dx * ((size_t)gy + (size_t)G.dy * (size_t)gz);
         const float fr = (float)sr * invS;
@@ -527,7 +559,6 @@ int cpm_gather_fast(cpm_ctx* ctx, const float* sorted_pos_power, const uint32_t*
     long long* slabs = (long long*)scratch(ctx, CPM_SCR_FAST_SLABS, max_items * tile_bytes);
     if (!slabs) return CPM_ERR_OUT_OF_MEMORY;
     const float k = kInv4Pi * scale;
-    const int n_log2 = ceil_log2(n > 2 ? n : 2);
     hipStream_t s = (hipStream_t)stream;
     if (n > 0) {
         // resident workgroups: two of 1024 threads per CU, fewer when the worst case has fewer items
@@ -538,7 +569,7 @@ int cpm_gather_fast(cpm_ctx* ctx, const float* sorted_pos_power, const uint32_t*
         rc = allow_lds(ctx, fast_tile_kernel<MAXC, CH>, tile_bytes);                                                     \
         if (rc) return rc;                                                                                               \
         CPM_LAUNCH(ctx, (fast_tile_kernel<MAXC, CH>), tgrid, dim3(kTileThreads), tile_bytes, s, sorted_pos_power, brick_table, G, L, radius, \
-                   k, n_log2, slabs);                                                                                    \
+                   k, slabs);                                                                                    \
     } while (0)
         if (G.channels == 1) {
             if (L.maxc <= 2) CPM_TILE_LAUNCH(2, 1); else if (L.maxc == 3) CPM_TILE_LAUNCH(3, 1); else CPM_TILE_LAUNCH(4, 1);
@@ -549,9 +580,9 @@ int cpm_gather_fast(cpm_ctx* ctx, const float* sorted_pos_power, const uint32_t*
         CPM_LAUNCH_CHECK(ctx, "fast_tile_kernel");
     }
     if (G.channels == 1)
-        CPM_LAUNCH(ctx, fast_combine_kernel<1>, dim3((unsigned)L.nb), dim3(kCombineThreads), 0, s, slabs, brick_table, G, L, k, n_log2, accumulate, grid_out);
+        CPM_LAUNCH(ctx, fast_combine_kernel<1>, dim3((unsigned)L.nb), dim3(kCombineThreads), 0, s, slabs, brick_table, G, L, k, accumulate, grid_out);
     else
-        CPM_LAUNCH(ctx, fast_combine_kernel<4>, dim3((unsigned)L.nb), dim3(kCombineThreads), 0, s, slabs, brick_table, G, L, k, n_log2, accumulate, grid_out);
+        CPM_LAUNCH(ctx, fast_combine_kernel<4>, dim3((unsigned)L.nb), dim3(kCombineThreads), 0, s, slabs, brick_table, G, L, k, accumulate, grid_out);
     CPM_LAUNCH_CHECK(ctx, "fast_combine_kernel");
     return CPM_OK;
 }

@@ -823,12 +823,12 @@ static void fast_brick_layout(const cpmo_grid_desc* g, float radius, fast_layout
     }
 }
 
-static float fast_fixed_scale(float maxpow, float k, int n_log2) {
+static float fast_fixed_scale(float maxpow, float k) {
     float m = maxpow * fabsf(k) * 0.75f;
     if (!(m > 0.f) || m > FLT_MAX) return 1.0f;
     union { float f; uint32_t u; } b; b.f = m;
     int e = (int)((b.u >> 23) & 0xffu) - 126; /* m < 2^e */
-    int sh = 62 - n_log2 - e;
+    int sh = 30 - e;                           /* every contribution fits int32; < 2^31 of them fit int64 */
     sh = sh > 100 ? 100 : (sh < -100 ? -100 : sh);
     b.u = (uint32_t)(sh + 127) << 23;
     return b.f;
@@ -842,15 +842,13 @@ void cpmo_gather_fast(const float* photons, int n, const cpmo_grid_desc* g, floa
     const float k = 0.0795774715459476679f * scale;
     fast_layout L;
     fast_brick_layout(g, radius, &L);
-    int n_log2 = 1;
-    while (n_log2 < 62 && (1ll << n_log2) < (n > 2 ? n : 2)) ++n_log2;
     float maxpow = 0.f;
     for (int i = 0; i < n; ++i) {
         const float* ph = photons + 8 * (size_t)i;
         if (ph[0] == FLT_MAX || ph[1] == FLT_MAX || ph[2] == FLT_MAX) continue;
         for (int c = 0; c < ch3; ++c) { float a = fabsf(ph[3 + c]); if (a <= FLT_MAX && a > maxpow) maxpow = a; }
     }
-    const float S = fast_fixed_scale(maxpow, k, n_log2);
+    const float S = fast_fixed_scale(maxpow, k);
     const float invS = 1.0f / S;
     long long* acc = (long long*)calloc(cells * (size_t)ch3, sizeof(long long));
     const float* T = g->texture_to_index; const float* I = g->index_to_texture;
@@ -882,7 +880,7 @@ void cpmo_gather_fast(const float* photons, int n, const cpmo_grid_desc* g, floa
                     if (!(d2 <= r2)) continue;
                     const float w = 0.75f * (1.0f - d2 * inv_r2);
                     const size_t v = (size_t)x + (size_t)dims[0] * ((size_t)y + (size_t)dims[1] * (size_t)z);
-                    for (int c = 0; c < ch3; ++c) acc[(size_t)c * cells + v] += (long long)((pk[c] * w) * S);
+                    for (int c = 0; c < ch3; ++c) acc[(size_t)c * cells + v] += (long long)(int)((pk[c] * w) * S);
                 }
             }
         }
