@@ -520,6 +520,10 @@ static void trace_one(trace_env* e, const float aabb[8], const cpmo_trace_params
     }
 }
 
+/* statistics for tools/ (divergence models): when set, cpmo_trace stores every photon's Woodcock iteration count */
+static uint32_t* g_step_array = 0;
+void cpmo_debug_set_step_array(uint32_t* per_photon_steps) { g_step_array = per_photon_steps; }
+
 CPMO_CLONES
 void cpmo_trace(const cpmo_volume* vol, const float* tf_rgba, int tf_width,
                 const float* tf_scattering_rgba, const float aabb[8],
@@ -538,6 +542,7 @@ void cpmo_trace(const cpmo_volume* vol, const float* tf_rgba, int tf_width,
         trace_env e = { vol, tf_rgba, tf_scattering_rgba ? tf_scattering_rgba : tf_rgba, tf_width, 0 };
         trace_one(&e, aabb, P, ls, isect, threadId, rng, photons);
         total_steps += e.steps;
+        if (g_step_array) g_step_array[threadId] = (uint32_t)e.steps;
     }
     if (steps_out) *steps_out = total_steps;
 }

@@ -102,6 +102,8 @@ void cpmo_trace(const cpmo_volume* vol, const float* tf_rgba, int tf_width,
                 const cpmo_trace_params* params, const float* light_samples8, const float* isect2,
                 const uint32_t* recompute_indices, int n_recompute, uint32_t* rng_state,
                 float* photons8, uint64_t* steps_out);
+/* statistics hook: non-null = cpmo_trace also stores each light sample's Woodcock iteration count (index = threadId) */
+void cpmo_debug_set_step_array(uint32_t* per_photon_steps);
 float cpmo_sample_volume(const cpmo_volume* vol, float x, float y, float z);
 float cpmo_sample_tf_alpha(const float* tf_rgba, int width, float v);
 

@@ -196,6 +196,26 @@ def test_trace_sparse_tf_long_paths(ctx, oracle, cpm):
     assert steps / (128 * 128) > 50
 
 
+def test_trace_progressive_rng_write_back_single_interaction(ctx, oracle, cpm):
+    # photontracer.cl:211-215 at max_interactions == 1: the stream state after the photon's last draw
+    S = cpm.synthetic
+    got, want, rng_g, rng_w, steps, (_, _, st) = _trace_case(ctx, oracle, cpm, S.heterogeneous_volume(64), S.workspace_tf(), 160,
+                                                             (0.3, 0.5, -1.0), flags=cpm.binding.CPM_TRACE_PROGRESSIVE)
+    assert np.array_equal(bits(got), bits(want))
+    assert np.array_equal(rng_g, rng_w)
+    assert (rng_g != st).any()
+
+
+def test_trace_sample_counts_off_the_wave_size(ctx, oracle, cpm):
+    # sample counts that are not multiples of a wave / workgroup; a point light (per-lane directions, many misses)
+    S = cpm.synthetic
+    for n_side in (1, 7, 9, 33):
+        got, want, *_ = _trace_case(ctx, oracle, cpm, S.heterogeneous_volume(32), S.workspace_tf(), n_side, (0.3, 0.5, -1.0))
+        assert np.array_equal(bits(got), bits(want))
+    got, want, *_ = _trace_case(ctx, oracle, cpm, S.heterogeneous_volume(32), S.workspace_tf(), 77, (0, 0, 1), point=(0.4, 0.6, -0.7))
+    assert np.array_equal(bits(got), bits(want))
+
+
 @pytest.mark.parametrize("dtype", [np.uint16, np.float32])
 def test_trace_other_voxel_types(ctx, oracle, cpm, dtype):
     S = cpm.synthetic
