@@ -79,12 +79,16 @@ def load_library() -> C.CDLL:
     global _lib
     if _lib is not None:
         return _lib
-    if not LIB_PATH.exists():
+    import os
+    lib_path = LIB_PATH
+    if os.environ.get("CPM_LIB"):  # tuning experiments (tools/): another build of the same library
+        lib_path = Path(os.environ["CPM_LIB"])
+    if not lib_path.exists():
         raise ImportError(
-            f"{LIB_PATH} is missing: the HIP extension has not been built. Run "
+            f"{lib_path} is missing: the HIP extension has not been built. Run "
             "`python -c 'import __graft_entry__ as g; g.build()'` (hipcc --offload-arch=gfx950). "
             "There is no CPU fallback.")
-    lib = C.CDLL(str(LIB_PATH))
+    lib = C.CDLL(str(lib_path))
     vp, i32, f32, u32, u64, sz = C.c_void_p, C.c_int32, C.c_float, C.c_uint32, C.c_uint64, C.c_size_t
     P = C.POINTER
     sig = {

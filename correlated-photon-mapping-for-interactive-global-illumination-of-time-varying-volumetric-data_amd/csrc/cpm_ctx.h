@@ -31,7 +31,8 @@ struct cpm_ctx {
     // valid flag -- a pure function of (theta, phi), evaluated once by the emitter so that the tracer's workgroups need not
     // (cpm_trace.hip; used only for samples whose (theta, phi) bit patterns match)
     float* dir_hint = nullptr;
-    size_t fast_hist_words = 0;  // cpm_bin_fast: size of the histogram whose all-zero state is established (0 = none)
+    size_t fast_hist_words = 0;  // cpm_bin_fast: size of the histograms whose all-zero state is established (0 = none)
+    int fast_hist_parity = 0;    // which of the two histograms the next cpm_bin_fast counts into
 };
 
 // scratch slots
@@ -42,7 +43,7 @@ enum {
     CPM_SCR_BIN_KEYS = 3,    // cell keys of cpm_bin
     CPM_SCR_SMALL = 4,       // TF points etc.
     CPM_SCR_MISC = 5,
-    CPM_SCR_FAST_BIN = 6,    // cpm_bin_fast: brick histogram (kept zero between calls) + per-photon ranks
+    CPM_SCR_FAST_BIN = 6,    // cpm_bin_fast: two brick histograms (used in turn, zeroed by the call before) + per-photon ranks
     CPM_SCR_FAST_SLABS = 7   // cpm_gather_fast: one fixed-point tile per work item
 };
 

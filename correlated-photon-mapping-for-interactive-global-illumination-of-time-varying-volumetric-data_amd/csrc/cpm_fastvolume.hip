@@ -28,10 +28,26 @@ using namespace cpm;
 
 namespace {
 
-constexpr int kTileThreads = 1024;
-constexpr int kCombineThreads = 128;
-constexpr int kFastChunk = 4096;   // photons per tile-gather work item (1024 threads x 4)
-constexpr int kCountItems = 2;     // photons per thread of fast_count_kernel (1024 threads)
+// tuning experiments build variants with -DCPM_TILE_THREADS=... etc. (tools/build_variant.sh); the defaults are the measured best
+#ifndef CPM_TILE_THREADS
+#define CPM_TILE_THREADS 1024
+#endif
+#ifndef CPM_FAST_CHUNK
+#define CPM_FAST_CHUNK 4096
+#endif
+#ifndef CPM_COMBINE_THREADS
+#define CPM_COMBINE_THREADS 128
+#endif
+#ifndef CPM_COUNT_ITEMS
+#define CPM_COUNT_ITEMS 2
+#endif
+#ifndef CPM_TILE_WG_PER_CU
+#define CPM_TILE_WG_PER_CU 2
+#endif
+constexpr int kTileThreads = CPM_TILE_THREADS;
+constexpr int kCombineThreads = CPM_COMBINE_THREADS;
+constexpr int kFastChunk = CPM_FAST_CHUNK;   // photons per tile-gather work item (1024 threads x 4)
+constexpr int kCountItems = CPM_COUNT_ITEMS; // photons per thread of fast_count_kernel (1024 threads)
 constexpr int kCountTile = 1024 * kCountItems;
 constexpr int kMaxBricks = 16384;  // LDS histogram of fast_count_kernel: 64 KiB
 
@@ -127,14 +143,16 @@ CPM_DEV unsigned long long to_fixed(float v, float S) {
     return (unsigned long long)(long long)q;
 }
 
-// Exclusive scans of the brick counts (-> brick starts) and of the bricks' chunk counts (-> item starts), the work
-// items, the totals.  One 1024-thread workgroup; `counts` are in LDS.
-CPM_DEV void fast_scan(const uint32_t* counts, const BrickLayout& L, uint32_t* __restrict__ table, uint32_t* s_c, uint32_t* s_i) {
+// Exclusive scan of the brick counts (-> brick starts, left in LDS for the caller's scatter) by one 1024-thread workgroup;
+// with `table` (workgroup 0 only) also the scan of the bricks' chunk counts (-> item starts), the work items and the
+// totals.  `counts` is the finished global histogram (every workgroup reads it: nb * 4 bytes of L2 traffic each).
+CPM_DEV void fast_scan(const uint32_t* __restrict__ counts, const BrickLayout& L, uint32_t* __restrict__ s_start,
+                       uint32_t* __restrict__ table, uint32_t* s_c, uint32_t* s_i) {
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int per = (L.nb + 1023) / 1024;
     const int b0 = t * per, b1 = min(b0 + per, L.nb);
     uint32_t c = 0, it = 0;
-    for (int b = b0; b < b1; ++b) { const uint32_t h = counts[b]; c += h; it += (h + kFastChunk - 1) / kFastChunk; }
+    for (int b = b0; b < b1; ++b) { const uint32_t h = counts[b]; s_start[b] = h; c += h; it += (h + kFastChunk - 1) / kFastChunk; }
     uint32_t ci = c, ii = it;
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) {
@@ -147,21 +165,25 @@ CPM_DEV void fast_scan(const uint32_t* counts, const BrickLayout& L, uint32_t* _
 #pragma unroll
     for (int w = 0; w < 16; ++w) { if (w < wave) { bc += s_c[w]; bi += s_i[w]; } tc += s_c[w]; ti += s_i[w]; }
     uint32_t ac = bc + ci - c, ai = bi + ii - it;  // exclusive prefixes of this thread's first brick
-    uint32_t* __restrict__ bstart = table;
-    uint32_t* __restrict__ istart = table + off_item_start(L);
-    uint4* __restrict__ items = reinterpret_cast<uint4*>(table + off_items(L));
-    for (int b = b0; b < b1; ++b) {
-        const uint32_t h = counts[b];
-        bstart[b] = ac; istart[b] = ai;
-        const uint32_t nc = (h + kFastChunk - 1) / kFastChunk;
-        for (uint32_t q = 0; q < nc; ++q)
-            items[ai + q] = make_uint4((uint32_t)b, ac + q * (uint32_t)kFastChunk, min(ac + (q + 1u) * (uint32_t)kFastChunk, ac + h), 0u);
-        ac += h; ai += nc;
+    if (table) {
+        uint32_t* __restrict__ bstart = table;
+        uint32_t* __restrict__ istart = table + off_item_start(L);
+        uint4* __restrict__ items = reinterpret_cast<uint4*>(table + off_items(L));
+        for (int b = b0; b < b1; ++b) {
+            const uint32_t h = s_start[b];
+            bstart[b] = ac; istart[b] = ai; s_start[b] = ac;
+            const uint32_t nc = (h + kFastChunk - 1) / kFastChunk;
+            for (uint32_t q = 0; q < nc; ++q)
+                items[ai + q] = make_uint4((uint32_t)b, ac + q * (uint32_t)kFastChunk, min(ac + (q + 1u) * (uint32_t)kFastChunk, ac + h), 0u);
+            ac += h; ai += nc;
+        }
+        if (t == 0) { bstart[L.nb] = tc; istart[L.nb] = ti; table[off_meta(L) + kMetaItems] = ti; }
+    } else {
+        for (int b = b0; b < b1; ++b) { const uint32_t h = s_start[b]; s_start[b] = ac; ac += h; }
     }
-    if (t == 0) { bstart[L.nb] = tc; istart[L.nb] = ti; table[off_meta(L) + kMetaItems] = ti; }
 }
 
-// bin, launch 1 of 3.  Per workgroup (1024 threads, 4096 photons): brick keys, a histogram in LDS whose returning
+// bin, launch 1 of 2.  Per workgroup (1024 threads, 4096 photons): brick keys, a histogram in LDS whose returning
 // ds_add gives every photon its rank inside its (workgroup, brick) run, then ONE returning global atomic per non-empty
 // (workgroup, brick) pair: the run's offset inside the brick.  rank = offset + local rank: an unstable counting sort.
 template <int CH>
@@ -225,42 +247,55 @@ __global__ __launch_bounds__(1024) void fast_count_kernel(const float* __restric
     }
 }
 
-// bin, launch 2 of 3: one workgroup turns the finished histogram into the table -- brick starts, work items, max |power|
-// -- and puts histogram and accumulator back to zero for the next call, so that no memset is needed in steady state.
-// (Folding this into the count kernel's last-arriving workgroup was built and measured: 27 us against 11 + 6.3 us --
-// the ticket is one more memory-side round trip behind every workgroup's atomics, and the tail runs on one CU either way.)
-__global__ __launch_bounds__(1024) void fast_scan_kernel(uint32_t* __restrict__ hist, uint32_t* __restrict__ acc, BrickLayout L,
-                                                         uint32_t* __restrict__ table) {
-    extern __shared__ uint32_t s_hist[];
+// bin, launch 2 of 2.  Every workgroup (1024 threads, kScatterItems photons each) turns the finished histogram into the
+// brick starts it needs -- an exclusive scan of nb <= 16 Ki counts in LDS, while its photon loads are in flight -- and
+// moves its photons' compact records to brick_start[key] + rank.  Workgroup 0 also writes the table the gather reads
+// (brick starts, work items, max |power|).  The one-workgroup scan launch this replaces took 5.6 us of pure latency
+// between two 10 us kernels.  The histogram is used in turn with a second one: this launch zeroes the OTHER one (idle
+// until the next call), so no memset is needed in steady state and no workgroup has to know when the others have read.
+constexpr int kScatterItems = 2;
+constexpr int kScatterTile = 1024 * kScatterItems;
+template <int CH>
+__global__ __launch_bounds__(1024) void fast_scatter_kernel(const float* __restrict__ photons, int n, GridDev G, BrickLayout L,
+                                                            const uint32_t* __restrict__ rank, const uint32_t* __restrict__ hist,
+                                                            uint32_t* __restrict__ hist_next, int hist_words,
+                                                            uint32_t* __restrict__ table, float* __restrict__ sorted) {
+    extern __shared__ uint32_t s_start[];
     __shared__ uint32_t s_c[16], s_i[16];
     const int t = threadIdx.x;
-    for (int b = t; b < L.nb; b += 1024) { s_hist[b] = hist[b]; hist[b] = 0u; }
-    if (t == 0) {
-        table[off_meta(L) + kMetaMaxPow] = acc[kAccMaxPow];
-        acc[kAccMaxPow] = 0u;
-    }
-    __syncthreads();
-    fast_scan(s_hist, L, table, s_c, s_i);
-}
-
-template <int CH>
-__global__ __launch_bounds__(256) void fast_scatter_kernel(const float* __restrict__ photons, int n, GridDev G, BrickLayout L,
-                                                           const uint32_t* __restrict__ rank, const uint32_t* __restrict__ bstart,
-                                                           float* __restrict__ sorted) {
-    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    const uint32_t r = rank[i];
-    if (r == 0xffffffffu) return;
     const float4* __restrict__ ph = reinterpret_cast<const float4*>(photons);
-    const float4 a = ph[2 * i];
-    const size_t pos = (size_t)bstart[brick_key(G, L, a)] + r;
-    if (CH == 1) {
-        reinterpret_cast<float4*>(sorted)[pos] = a;
-    } else {
-        const float4 b = ph[2 * i + 1];
-        float4* o = reinterpret_cast<float4*>(sorted) + 2 * pos;
-        o[0] = a;
-        o[1] = make_float4(b.x, b.y, 0.f, 0.f);
+    const int n_tiles = (int)(((long long)n + kScatterTile - 1) / kScatterTile);
+    uint32_t r[kScatterItems];
+    float4 a[kScatterItems], b2[kScatterItems];
+    auto load = [&](int tile) {
+#pragma unroll
+        for (int k = 0; k < kScatterItems; ++k) {
+            const long long i = (long long)tile * kScatterTile + k * 1024 + t;
+            r[k] = 0xffffffffu;
+            a[k] = make_float4(0.f, 0.f, 0.f, 0.f); b2[k] = a[k];
+            if (i < n) { r[k] = rank[i]; a[k] = ph[2 * i]; if (CH == 4) b2[k] = ph[2 * i + 1]; }
+        }
+    };
+    load(blockIdx.x);  // the first tile's loads: in flight during the scan
+    for (int w = blockIdx.x * 1024 + t; w < hist_words; w += gridDim.x * 1024) hist_next[w] = 0u;
+    if (blockIdx.x == 0 && t == 0) table[off_meta(L) + kMetaMaxPow] = hist[L.nb + kAccMaxPow];
+    fast_scan(hist, L, s_start, blockIdx.x == 0 ? table : nullptr, s_c, s_i);
+    __syncthreads();
+    // big inputs: a workgroup walks several tiles, so that the scan (nb counts per workgroup) is paid once per 2 Ki+ photons
+    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        if (tile != (int)blockIdx.x) load(tile);
+#pragma unroll
+        for (int k = 0; k < kScatterItems; ++k) {
+            if (r[k] == 0xffffffffu) continue;
+            const size_t pos = (size_t)s_start[brick_key(G, L, a[k])] + r[k];
+            if (CH == 1) {
+                reinterpret_cast<float4*>(sorted)[pos] = a[k];
+            } else {
+                float4* o = reinterpret_cast<float4*>(sorted) + 2 * pos;
+                o[0] = a[k];
+                o[1] = make_float4(b2[k].x, b2[k].y, 0.f, 0.f);
+            }
+        }
     }
 }
 
@@ -499,20 +534,25 @@ int cpm_bin_fast(cpm_ctx* ctx, const float* photons8, int n, const cpm_grid_desc
     hipStream_t s = (hipStream_t)stream;
     BrickLayout L;
     brick_shape(grid->dims, L);
-    // scratch: histogram (nb) + accumulators (4) -- all zero between calls, restored by the last workgroup of the count
-    // kernel -- then the per-photon ranks
+    // scratch: two histograms (nb brick counts + 4 accumulators each), used in turn -- a call's scatter launch zeroes the
+    // one the NEXT call counts into -- then the per-photon ranks
     const size_t hist_words = (size_t)L.nb + 4;
-    const bool had = ctx->scratch_bytes[CPM_SCR_FAST_BIN] >= (hist_words + (size_t)(n > 0 ? n : 1)) * 4;
-    uint32_t* hist = (uint32_t*)scratch(ctx, CPM_SCR_FAST_BIN, (hist_words + (size_t)(n > 0 ? n : 1)) * 4);
-    if (!hist) return CPM_ERR_OUT_OF_MEMORY;
-    if (!had || ctx->fast_hist_words != hist_words)  // new arena or another brick count: the zero state is not established
-        CPM_HIP_CHECK(ctx, hipMemsetAsync(hist, 0, hist_words * 4, s));
+    const size_t arena = (2 * hist_words + (size_t)(n > 0 ? n : 1)) * 4;
+    const bool had = ctx->scratch_bytes[CPM_SCR_FAST_BIN] >= arena;
+    uint32_t* base = (uint32_t*)scratch(ctx, CPM_SCR_FAST_BIN, arena);
+    if (!base) return CPM_ERR_OUT_OF_MEMORY;
+    if (!had || ctx->fast_hist_words != hist_words) {  // new arena or another brick count: the zero state is not established
+        CPM_HIP_CHECK(ctx, hipMemsetAsync(base, 0, 2 * hist_words * 4, s));
+        ctx->fast_hist_parity = 0;
+    }
+    uint32_t* hist = base + (size_t)ctx->fast_hist_parity * hist_words;
+    uint32_t* hist_next = base + (size_t)(ctx->fast_hist_parity ^ 1) * hist_words;
     uint32_t* acc = hist + L.nb;
-    uint32_t* rank = hist + hist_words;
+    uint32_t* rank = base + 2 * hist_words;
     ctx->fast_hist_words = 0;  // re-established below once the kernel that restores the zero state is enqueued
+    const size_t lds = (size_t)L.nb * 4;
     if (n > 0) {
         const dim3 cgrid((unsigned)div_up(n, kCountTile));
-        const size_t lds = (size_t)L.nb * 4;
         if (G.channels == 1) {
             rc = allow_lds(ctx, fast_count_kernel<1>, lds); if (rc) return rc;
             CPM_LAUNCH(ctx, fast_count_kernel<1>, cgrid, dim3(1024), lds, s, photons8, n, G, L, hist, acc, rank);
@@ -522,18 +562,19 @@ int cpm_bin_fast(cpm_ctx* ctx, const float* photons8, int n, const cpm_grid_desc
         }
         CPM_LAUNCH_CHECK(ctx, "fast_count_kernel");
     }
-    rc = allow_lds(ctx, fast_scan_kernel, (size_t)L.nb * 4);
-    if (rc) return rc;
-    CPM_LAUNCH(ctx, fast_scan_kernel, dim3(1), dim3(1024), (size_t)L.nb * 4, s, hist, acc, L, brick_table);
-    CPM_LAUNCH_CHECK(ctx, "fast_scan_kernel");
-    ctx->fast_hist_words = hist_words;
-    if (n > 0) {
-        if (G.channels == 1)
-            CPM_LAUNCH(ctx, fast_scatter_kernel<1>, dim3((unsigned)div_up(n, 256)), dim3(256), 0, s, photons8, n, G, L, rank, brick_table, sorted_pos_power);
-        else
-            CPM_LAUNCH(ctx, fast_scatter_kernel<4>, dim3((unsigned)div_up(n, 256)), dim3(256), 0, s, photons8, n, G, L, rank, brick_table, sorted_pos_power);
-        CPM_LAUNCH_CHECK(ctx, "fast_scatter_kernel");
+    // n == 0 still runs one workgroup: the table (all starts 0, no items) is part of the result
+    const int stiles = n > 0 ? div_up(n, kScatterTile) : 1, smax = 2 * ctx->num_cus;
+    const dim3 sgrid((unsigned)(stiles < smax ? stiles : smax));
+    if (G.channels == 1) {
+        rc = allow_lds(ctx, fast_scatter_kernel<1>, lds); if (rc) return rc;
+        CPM_LAUNCH(ctx, fast_scatter_kernel<1>, sgrid, dim3(1024), lds, s, photons8, n, G, L, rank, hist, hist_next, (int)hist_words, brick_table, sorted_pos_power);
+    } else {
+        rc = allow_lds(ctx, fast_scatter_kernel<4>, lds); if (rc) return rc;
+        CPM_LAUNCH(ctx, fast_scatter_kernel<4>, sgrid, dim3(1024), lds, s, photons8, n, G, L, rank, hist, hist_next, (int)hist_words, brick_table, sorted_pos_power);
     }
+    CPM_LAUNCH_CHECK(ctx, "fast_scatter_kernel");
+    ctx->fast_hist_parity ^= 1;
+    ctx->fast_hist_words = hist_words;
     return CPM_OK;
 }
 
@@ -562,7 +603,7 @@ int cpm_gather_fast(cpm_ctx* ctx, const float* sorted_pos_power, const uint32_t*
     hipStream_t s = (hipStream_t)stream;
     if (n > 0) {
         // resident workgroups: two of 1024 threads per CU, fewer when the worst case has fewer items
-        const size_t resident = (size_t)2 * (size_t)ctx->num_cus;
+        const size_t resident = (size_t)CPM_TILE_WG_PER_CU * (size_t)ctx->num_cus;
         const dim3 tgrid((unsigned)(max_items < resident ? max_items : resident));
 #define CPM_TILE_LAUNCH(MAXC, CH)                                                                                        \
     do {                                                                                                                 \
