@@ -10,6 +10,8 @@
  *     modules/progressivephotonmapping/cl/threshold.cl
  *     modules/progressivephotonmapping/cl/indextobuffer.cl
  *     modules/uniformgridcl/cl/buffermixer.cl (driven by ref_harness_vec.c)
+ *     modules/progressivephotonmapping/cl/photon.cl, modules/rndgenmwc64x/cl/randomnumbergenerator.cl
+ *         (a second library, driven by ref_harness2.c)
  * No header of the reference or of Inviwo is stubbed.  What this file supplies
  * is the execution harness an OpenCL runtime would: the work-item id and the
  * two integer built-ins those kernels call, whose results the OpenCL 1.2

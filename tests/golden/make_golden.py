@@ -4,8 +4,8 @@ Run in the build container, where /root/reference exists:
     make -C oracle ref && python tests/golden/make_golden.py
 The kernels are compiled by oracle/Makefile from where they lie under
 /root/reference/modules (rndgenmwc64x/cl/randstategen.cl + random.cl + skip_mwc.cl,
-progressivephotonmapping/cl/{densityestimationkernel,threshold,indextobuffer}.cl, uniformgridcl/cl/buffermixer.cl)
-and driven by oracle/ref_harness.c and oracle/ref_harness_vec.c.  The fixture holds inputs and the outputs those kernels produced --
+progressivephotonmapping/cl/{densityestimationkernel,threshold,indextobuffer,photon}.cl, uniformgridcl/cl/buffermixer.cl,
+rndgenmwc64x/cl/randomnumbergenerator.cl) and driven by oracle/ref_harness.c, oracle/ref_harness_vec.c and oracle/ref_harness2.c.  The fixture holds inputs and the outputs those kernels produced --
 data only; no reference source travels.
 """
 import ctypes
@@ -60,7 +60,19 @@ def main():
     ux[0], uy[0] = (0, 65535), (65535, 0)
     mix_u = np.stack([ref.mix_u16x2(ux, uy, float(a)) for a in mix_a])
 
-    np.savez_compressed(OUT, mix_x=mx, mix_y=my, mix_a=mix_a, mix_f32=mix_f, mix_ux=ux, mix_uy=uy, mix_u16x2=mix_u, bases=bases, seeded=seeded, random01=r01, random_uint=ruint, state_after=state_after,
+    # randomNumberGeneratorKernel (rndgenmwc64x/cl/randomnumbergenerator.cl): loadRandState -> random_01 -> saveRandState,
+    # three launches in a row over 1000 streams (not a multiple of the launch's rounding)
+    ks = seeded[:1000].copy()
+    k_draws = np.stack([ref.random_number_kernel(ks) for _ in range(3)])
+    k_state = ks.copy()
+    # readPhoton / writePhoton (progressivephotonmapping/cl/photon.cl): 300 records written at shuffled ids of a 512-record buffer
+    ph = (rng.standard_normal((300, 8)) * 3).astype(np.float32)
+    ph[5, :3] = np.float32(3.402823466e+38)
+    ids = rng.permutation(512)[:300].astype(np.int32)
+    ph_buf, ph_back = ref.photon_write_read(ph, ids, 512)
+
+    np.savez_compressed(OUT, rng_kernel_draws=k_draws, rng_kernel_state=k_state, photon_in=ph, photon_ids=ids, photon_buffer=ph_buf,
+                        photon_read_back=ph_back, mix_x=mx, mix_y=my, mix_a=mix_a, mix_f32=mix_f, mix_ux=ux, mix_uy=uy, mix_u16x2=mix_u, bases=bases, seeded=seeded, random01=r01, random_uint=ruint, state_after=state_after,
                         per_stream_seeded=ps, per_stream_gap=np.uint64(1000), kernel_x=kx, kernel_y=ky,
                         threshold_in=tdata, threshold_out=tout, iota=iota)
     print("wrote", OUT, OUT.stat().st_size, "bytes")

@@ -309,6 +309,8 @@ class Ref:
         if not REF_LIB.exists():
             raise FileNotFoundError(REF_LIB)
         self.lib = C.CDLL(str(REF_LIB))
+        lib2 = REF_LIB.with_name("libcpm_ref2.so")  # photon.cl, randomnumbergenerator.cl (oracle/ref_harness2.c)
+        self.lib2 = C.CDLL(str(lib2)) if lib2.exists() else None
         self.lib.ref_density_kernel.restype = C.c_float
         self.lib.ref_density_kernel.argtypes = [C.c_float]
         self.lib.ref_generate_per_stream_random_state.argtypes = [C.c_void_p, C.c_uint64, C.c_int]
@@ -324,6 +326,21 @@ class Ref:
         outu = np.zeros((draws, state.shape[0]), np.uint32)
         self.lib.ref_random_fill(_p(state), state.shape[0], draws, _p(out), _p(outu))
         return out, outu
+
+    def photon_write_read(self, photons8, ids, capacity):
+        """writePhoton(photons8[i], buffer, ids[i]) for every i, then readPhoton back: (buffer as written, read-back)."""
+        photons8 = np.ascontiguousarray(photons8, np.float32)
+        ids = np.ascontiguousarray(ids, np.int32)
+        buf = np.full((capacity, 8), np.float32(-7), np.float32)
+        out = np.zeros_like(photons8)
+        self.lib2.ref_photon_write_read(_p(photons8), _p(ids), ids.size, _p(buf), _p(out))
+        return buf, out
+
+    def random_number_kernel(self, state):
+        """randomNumberGeneratorKernel: one random_01 per stream, the state loaded from and saved back to the uint2 buffer."""
+        out = np.zeros(state.shape[0], np.float32)
+        self.lib2.ref_random_number_kernel(_p(state), state.shape[0], _p(out))
+        return out
 
     def density_kernel(self, x):
         return np.array([self.lib.ref_density_kernel(float(v)) for v in np.asarray(x, np.float32).ravel()], np.float32)

@@ -110,3 +110,53 @@ def test_live_reference_mix_kernel(oracle, ref):
     for a in (0.0, 0.1, 0.5, 0.73, 1.0):
         assert np.array_equal(oracle.mix_f32(x, y, a).view(np.uint32), ref.mix_f32(x, y, a).view(np.uint32))
         assert np.array_equal(oracle.mix_u16x2(ux, uy, a), ref.mix_u16x2(ux, uy, a))
+
+
+def test_random_number_kernel_golden(oracle, golden):
+    """randomNumberGeneratorKernel (rndgenmwc64x/cl/randomnumbergenerator.cl): state loaded from the uint2 buffer, one
+    random_01, state saved back -- three launches in a row.  The oracle's draw-and-write-back gives the same numbers and
+    leaves the same states (the write-back photontracer.cl:211-215 performs through the same saveRandState)."""
+    st = golden["seeded"][: golden["rng_kernel_state"].shape[0]].copy()
+    for k in range(golden["rng_kernel_draws"].shape[0]):
+        out = oracle.random_fill(st, 1)
+        assert np.array_equal(out[0].view(np.uint32), golden["rng_kernel_draws"][k].view(np.uint32))
+    assert np.array_equal(st, golden["rng_kernel_state"])
+    # the same streams through random_01 alone (tests above): launch k of the kernel is draw k
+    assert np.array_equal(golden["rng_kernel_draws"], golden["random01"][:3, : st.shape[0]])
+
+
+def test_photon_record_layout_golden(golden):
+    """readPhoton / writePhoton (progressivephotonmapping/cl/photon.cl): record id is the 8 consecutive floats at 8 * id
+    -- the [n, 8] float32 arrays every test, the oracle and the C-ABI (cpm.h: photons8) address photons by."""
+    buf, ids, ph = golden["photon_buffer"], golden["photon_ids"], golden["photon_in"]
+    assert np.array_equal(buf[ids].view(np.uint32), ph.view(np.uint32))
+    untouched = np.setdiff1d(np.arange(buf.shape[0]), ids)
+    assert (buf[untouched] == np.float32(-7)).all()
+    assert np.array_equal(golden["photon_read_back"].view(np.uint32), ph.view(np.uint32))
+
+
+def test_copy_indexed_photons_reads_the_reference_layout(oracle, golden):
+    # the oracle's indexed photon copy (copyIndexPhotonsKernel restated) fetches what the reference's readPhoton returns
+    buf, ids = golden["photon_buffer"], golden["photon_ids"].astype(np.uint32)
+    out = np.zeros((ids.size, 8), np.float32)
+    oracle.copy_indexed_photons(np.ascontiguousarray(buf), ids, 1.0, buf.shape[0], 1, out)
+    want = golden["photon_read_back"].copy()
+    sent = want[:, 0] == np.float32(3.402823466e+38)
+    assert np.array_equal(out[~sent].view(np.uint32), want[~sent].view(np.uint32))
+
+
+def test_live_reference_random_number_kernel_and_photon_records(oracle, ref):
+    if ref.lib2 is None:
+        pytest.skip("oracle/_ref/libcpm_ref2.so not built")
+    rng = np.random.default_rng(21)
+    st = np.zeros((777, 2), np.uint32)
+    st[:, 0] = rng.integers(0, 2**31, 777)
+    oracle.seed_streams(st, 1 << 40)
+    a, b = st.copy(), st.copy()
+    for _ in range(5):
+        assert np.array_equal(oracle.random_fill(a, 1)[0].view(np.uint32), ref.random_number_kernel(b).view(np.uint32))
+    assert np.array_equal(a, b)
+    ph = rng.standard_normal((100, 8)).astype(np.float32)
+    ids = rng.permutation(128)[:100].astype(np.int32)
+    buf, back = ref.photon_write_read(ph, ids, 128)
+    assert np.array_equal(buf[ids], ph) and np.array_equal(back, ph)

@@ -55,6 +55,23 @@ def test_seed_streams_and_random_fill(ctx, oracle, golden):
     assert np.array_equal(bits(_n(out))[:, : golden["random01"].shape[1]], bits(golden["random01"]))
 
 
+def test_reference_photon_records_and_rng_kernel(ctx, golden):
+    """Golden outputs of the reference's photon.cl (writePhoton / readPhoton) and randomnumbergenerator.cl
+    (load state -> random_01 -> save state), tests/golden/ref_kernels.npz: the HIP side reads the same records and
+    draws the same numbers with the same state written back."""
+    buf, ids = golden["photon_buffer"], golden["photon_ids"].astype(np.uint32)
+    out = ctx.torch.zeros((ids.size, 8), dtype=ctx.torch.float32, device=ctx.device)
+    ctx.copy_indexed_photons(_t(ctx, buf), _t(ctx, ids), ids.size, 1.0, buf.shape[0], 1, out)
+    want = golden["photon_read_back"]
+    keep = want[:, 0] != np.float32(3.402823466e+38)  # (sentinel records are not copied by the indexed splat's copy)
+    assert np.array_equal(bits(_n(out))[keep], bits(want)[keep])
+    st = _t(ctx, golden["seeded"][: golden["rng_kernel_state"].shape[0]].copy())
+    for k in range(golden["rng_kernel_draws"].shape[0]):
+        draw = ctx.random_fill(st, 1)
+        assert np.array_equal(bits(_n(draw))[0], bits(golden["rng_kernel_draws"][k]))
+    assert np.array_equal(_n(st, np.uint32), golden["rng_kernel_state"])
+
+
 def test_seed_streams_other_gap(ctx, oracle):
     rng = np.random.default_rng(5)
     st = np.zeros((5000, 2), np.uint32)
