@@ -267,8 +267,38 @@ def main():
     n_rank = hi - lo
     ctx = B.Context(local_rank)
     # the one exchange step: RCCL through the C-ABI (one-process-per-GPU form); torch.distributed only carries the id
+    transport_note = None
     if world > 1 and args.transport == "rccl" and args.test_backend == "nccl" and not args.test_one_device:
-        transport = sharding.RcclTransport(ctx, rank, world)
+        # Every rank first checks locally that RCCL can be bound (no communication), the ranks agree, and only then
+        # enter the collective communicator setup; a probe all-reduce follows.  Should any of it fail, ALL ranks fall
+        # back to torch.distributed's all-reduce (the same RCCL wire) and the JSON line says so -- a scaling run is
+        # never lost to the transport.
+        def agree(ok):
+            flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=ctx.device)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            return bool(flag.item())
+        err = ""
+        try:
+            ctx.comm_unique_id()
+            ok = True
+        except Exception as e:  # noqa: BLE001
+            ok, err = False, str(e)
+        transport = None
+        if agree(ok):
+            try:
+                transport = sharding.RcclTransport(ctx, rank, world)
+                probe = torch.ones(8, dtype=torch.float32, device=ctx.device)
+                transport.wait(transport.start(probe))
+                torch.cuda.synchronize()
+                ok = bool((probe == float(world)).all().item())
+                err = "" if ok else "probe all-reduce returned a wrong sum"
+            except Exception as e:  # noqa: BLE001
+                ok, err = False, str(e)
+            if not agree(ok):
+                transport = None
+        if transport is None:
+            transport = sharding.TorchTransport()
+            transport_note = "torch.distributed all_reduce (RCCL through the C-ABI was not usable on some rank" + (f": {err}" if err else "") + ")"
     else:
         transport = sharding.TorchTransport()
 
@@ -524,7 +554,8 @@ def main():
                                        + ("touched-brick reduce (cpm_allreduce_grid_bricks)" if correlated else
                                           "all-reduce of the grid per frame (cpm_allreduce_grid: RCCL on a side stream), overlapped with the next "
                                           "frame's trace + bin (double-buffered grid)")
-                                       + f", transport {type(transport).__name__}") if world > 1 else "single GPU",
+                                       + f", transport {type(transport).__name__}"
+                                       + (f" [{transport_note}]" if transport_note else "")) if world > 1 else "single GPU",
                        "launch": "captured HIP graph replay" if use_graph else "eager launches"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_src,
