@@ -89,6 +89,45 @@ def test_bin_and_gather_random_shapes(ctx, oracle, cpm, seed):
     assert np.array_equal(bits(_n(out)), bits(want)), note
 
 
+@pytest.mark.parametrize("seed", range(48 * MORE))
+def test_fast_formulation_random_shapes(ctx, oracle, cpm, seed):
+    """The tolerance-mode formulation over the same random cases: bit for bit against its restatement (integer sums), within
+    rtol 2e-5 / atol 1e-5 max of the reference-semantics gather, the same bits on a second run and in accumulate mode; refused
+    (not silently wrong) where cpm_gather_fast_supported says so."""
+    dims, channels, radius_vox, n, ph, what = _case(seed)
+    note = f"seed {seed}: {what} dims={dims} C={channels} r={radius_vox} vox n={n}"
+    radius = float(np.float32(radius_vox / max(dims)))
+    scale = oracle.relative_irradiance_scale(radius, n)
+    g = cpm.binding.default_grid_desc(dims, channels)
+    og = oracle.grid(dims, channels)
+    cells = dims[0] * dims[1] * dims[2]
+    torch = ctx.torch
+    shape = (cells,) if channels == 1 else (cells, 4)
+    table = torch.zeros(ctx.fast_table_entries(g, n), dtype=torch.int32, device=ctx.device)
+    srt = torch.zeros((n, 4 if channels == 1 else 8), dtype=torch.float32, device=ctx.device)
+    out = torch.full(shape, -3.0, dtype=torch.float32, device=ctx.device)
+    d_ph = _t(ctx, ph)
+    ctx.bin_fast(d_ph, n, g, table, srt)
+    if not ctx.gather_fast_supported(g, radius):
+        with pytest.raises(cpm.binding.CpmError):
+            ctx.gather_fast(srt, table, n, g, radius, scale, out)
+        return
+    ctx.gather_fast(srt, table, n, g, radius, scale, out)
+    want = np.zeros(shape, np.float32)
+    oracle.gather_fast(ph, n, og, radius, scale, want)
+    got = _n(out).copy()
+    assert np.array_equal(bits(got), bits(want)), note
+    _, o_cs, o_srt = oracle.bin(ph, n, og)
+    exact = np.zeros(shape, np.float32)
+    oracle.gather(o_srt, o_cs, n, og, radius, scale, exact)
+    np.testing.assert_allclose(got, exact, rtol=2e-5, atol=1e-5 * float(np.abs(exact).max()), err_msg=note)
+    # again (the bin's two histograms alternate), accumulating on top
+    ctx.bin_fast(d_ph, n, g, table, srt)
+    ctx.gather_fast(srt, table, n, g, radius, scale, out, accumulate=True)
+    oracle.gather_fast(ph, n, og, radius, scale, want, accumulate=True)
+    assert np.array_equal(bits(_n(out)), bits(want)), note
+
+
 @pytest.mark.parametrize("seed", range(12 * MORE))
 def test_sort_pairs_random_lengths_and_bits(ctx, seed):
     rng = np.random.default_rng(77 + seed)
