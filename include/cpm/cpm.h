@@ -309,8 +309,10 @@ int cpm_gather_bricks(cpm_ctx* ctx, const float* sorted_pos_power, const uint32_
 
 /* ---- MI355X formulation, tolerance mode: brick bin + LDS-tile gather (S6, G1-G3 restated)
  *
- * Same light volume as cpm_bin + cpm_gather within a stated fp32 tolerance (rtol 2e-5, atol 1e-5 * max, the
- * tolerance the reference's own atomic splat is held to): the Epanechnikov weight is evaluated as
+ * Same light volume as cpm_bin + cpm_gather within a stated fp32 tolerance -- per voxel rtol 2e-5 plus atol 1e-5 of
+ * the larger of the volume's maximum and one full-weight contribution (max |power| * k * 0.75); the tolerance the
+ * reference's own atomic splat is held to; the absolute part matters for voxels reached only from the rim of the
+ * kernel, where the weight is a difference of nearly equal numbers in any formulation: the Epanechnikov weight is evaluated as
  * 0.75 * (1 - d^2 / r^2) for d^2 <= r^2 (no sqrt, no division -- ref cl/densityestimationkernel.cl:43-60 takes
  * x = d / r), and per-voxel sums are accumulated as 64-bit fixed-point integers, so they do not depend on any
  * order: the result is bitwise reproducible run to run although nothing is sorted inside a brick.
