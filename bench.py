@@ -224,6 +224,9 @@ def main():
                     help="frames in flight for the extra 'pipelined' figure (0 = skip it); 'value' is always one stream")
     ap.add_argument("--transport", default="rccl", choices=["rccl", "torch"],
                     help="the grid reduce: cpm_allreduce_grid through the C-ABI (default) or torch.distributed")
+    ap.add_argument("--collective", default="allreduce", choices=["allreduce", "reduce"],
+                    help="N > 1: every rank receives the summed light volume (cpm_allreduce_grid, default) or only rank 0, the "
+                         "display GPU (cpm_reduce_grid: half the wire traffic of a ring all-reduce)")
     ap.add_argument("--test-backend", default="nccl", choices=["nccl", "gloo"],
                     help="(testing) process-group backend; gloo lets the N > 1 code path run with every rank on one GPU")
     ap.add_argument("--test-one-device", action="store_true", help="(testing) every rank uses cuda:0")
@@ -268,6 +271,7 @@ def main():
     ctx = B.Context(local_rank)
     # the one exchange step: RCCL through the C-ABI (one-process-per-GPU form); torch.distributed only carries the id
     transport_note = None
+    root = 0 if args.collective == "reduce" else None
     if world > 1 and args.transport == "rccl" and args.test_backend == "nccl" and not args.test_one_device:
         # Every rank first checks locally that RCCL can be bound (no communication), the ranks agree, and only then
         # enter the collective communicator setup; a probe all-reduce follows.  Should any of it fail, ALL ranks fall
@@ -286,21 +290,21 @@ def main():
         transport = None
         if agree(ok):
             try:
-                transport = sharding.RcclTransport(ctx, rank, world)
+                transport = sharding.RcclTransport(ctx, rank, world, root=root)
                 probe = torch.ones(8, dtype=torch.float32, device=ctx.device)
                 transport.wait(transport.start(probe))
                 torch.cuda.synchronize()
-                ok = bool((probe == float(world)).all().item())
+                ok = bool((probe == float(world)).all().item()) if (root is None or rank == root) else True
                 err = "" if ok else "probe all-reduce returned a wrong sum"
             except Exception as e:  # noqa: BLE001
                 ok, err = False, str(e)
             if not agree(ok):
                 transport = None
         if transport is None:
-            transport = sharding.TorchTransport()
+            transport = sharding.TorchTransport(root=root)
             transport_note = "torch.distributed all_reduce (RCCL through the C-ABI was not usable on some rank" + (f": {err}" if err else "") + ")"
     else:
-        transport = sharding.TorchTransport()
+        transport = sharding.TorchTransport(root=root)
 
     correlated = args.workload == "config5"
     if correlated:
@@ -552,7 +556,8 @@ def main():
                        "light_volume": [gdim] * 3,
                        "parallelism": (f"photon-sharded x{world} ({scaling} scaling), one "
                                        + ("touched-brick reduce (cpm_allreduce_grid_bricks)" if correlated else
-                                          "all-reduce of the grid per frame (cpm_allreduce_grid: RCCL on a side stream), overlapped with the next "
+                                          ("all-reduce of the grid per frame (cpm_allreduce_grid" if root is None else "reduce of the grid to rank 0 per frame (cpm_reduce_grid")
+                                          + ": RCCL on a side stream), overlapped with the next "
                                           "frame's trace + bin (double-buffered grid)")
                                        + f", transport {type(transport).__name__}"
                                        + (f" [{transport_note}]" if transport_note else "")) if world > 1 else "single GPU",

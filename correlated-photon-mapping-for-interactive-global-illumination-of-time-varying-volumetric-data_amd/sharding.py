@@ -26,15 +26,18 @@ def shard_range(n_total: int, rank: int, world: int):
 # --------------------------------------------------------------------------- transports
 
 class TorchTransport:
-    """all-reduce over torch.distributed (gloo in the CPU tests; any backend).  No-op for one rank."""
+    """all-reduce over torch.distributed (gloo in the CPU tests; any backend).  No-op for one rank.
+    root: None = every rank receives the sum (all-reduce); an int = only that rank does (reduce: the display GPU)."""
 
-    def __init__(self, group=None):
+    def __init__(self, group=None, root=None):
         import torch.distributed as dist
-        self._dist, self.group = dist, group
+        self._dist, self.group, self.root = dist, group, root
         self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
 
     def start(self, grid):
         if self.world > 1:
+            if self.root is not None:
+                return self._dist.reduce(grid, dst=self.root, op=self._dist.ReduceOp.SUM, group=self.group, async_op=True)
             return self._dist.all_reduce(grid, op=self._dist.ReduceOp.SUM, group=self.group, async_op=True)
         return None
 
@@ -50,10 +53,10 @@ class RcclTransport:
     The communicator id is created on rank 0 (cpm_comm_get_unique_id) and handed to the other ranks over
     whatever the host has -- here one torch.distributed broadcast (any backend)."""
 
-    def __init__(self, ctx, rank: int, world: int, group=None):
+    def __init__(self, ctx, rank: int, world: int, group=None, root=None):
         import torch
         import torch.distributed as dist
-        self.ctx, self.torch, self.world = ctx, torch, world
+        self.ctx, self.torch, self.world, self.rank, self.root = ctx, torch, world, rank, root
         if world > 1:
             uid = [ctx.comm_unique_id() if rank == 0 else None]
             dist.broadcast_object_list(uid, src=0, group=group)
@@ -70,7 +73,10 @@ class RcclTransport:
         ready.record(torch.cuda.current_stream(self.ctx.device))
         with torch.cuda.stream(self.stream):
             self.stream.wait_event(ready)
-            self.ctx.allreduce_grid(self.comm, grid)
+            if self.root is None:
+                self.ctx.allreduce_grid(self.comm, grid)
+            else:  # cpm_reduce_grid: only the root's grid becomes the sum (in place there), the others only send
+                self.ctx.reduce_grid(self.comm, grid, grid if self.rank == self.root else None, self.root)
             done = torch.cuda.Event()
             done.record(self.stream)
         return done

@@ -182,3 +182,40 @@ def test_overlapped_grid_reduce_without_process_group(cpm):
         red.reduce(k)
     red.flush()
     assert float(red.result(2)[0]) == 3.0 and float(red.result(1)[0]) == 2.0
+
+
+def _root_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    sys.path.insert(0, str(REPO))
+    import importlib
+    import torch
+    import torch.distributed as dist
+    import cpm_amd
+    sh = importlib.import_module(cpm_amd.__name__ + ".sharding")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    red = sh.OverlappedGridReducer(torch.zeros(1000), sh.TorchTransport(root=0))   # bench.py --collective reduce
+    ok = True
+    for k in range(5):
+        out = red.acquire(k)
+        out.copy_(torch.full((1000,), float((rank + 1) * (k + 1))))
+        red.reduce(k)
+    red.flush()
+    for k in (3, 4):
+        got = red.result(k)
+        want = float(sum(r + 1 for r in range(world)) * (k + 1)) if rank == 0 else None
+        ok = ok and (bool((got == want).all()) if rank == 0 else True)   # only the root's grid is defined afterwards
+    with open(os.path.join(out_dir, f"ok_{rank}"), "w") as f:
+        f.write("1" if ok else "0")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_reduce_to_the_display_rank(tmp_path, cpm):
+    """The same double-buffered reducer with a root: only rank 0 (the GPU that renders) receives the summed grid."""
+    import socket
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_root_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    assert (tmp_path / "ok_0").read_text() == "1" and (tmp_path / "ok_1").read_text() == "1"
