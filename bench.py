@@ -61,13 +61,10 @@ def algorithmic_bytes(n, I, vol_bytes, tf_width, cells, channels, tiles):
         "bin_finalize_kernel": m * 4 + m * rec + m * 4 + m * rec,
         "cell_start_kernel": m * 4 + (cells + 1) * 4,
         "gather_kernel": m * rec + (cells + 1) * 4 + cells * channels * 4,
-        # tolerance-mode formulation: what must move (records in, ranks, records out, light volume out); the slabs between
-        # tile and combine kernel are this build's own intermediate and count as overhead, not as algorithmic bytes
-        "fast_count_kernel": m * rec + m * 4,
-        "fast_scan_kernel": 0,
-        "fast_scatter_kernel": m * rec + m * 4 + m * rec,
-        "fast_tile_kernel": m * rec,
-        "fast_combine_kernel": cells * channels * 4,
+        # tolerance-mode formulation: what must move (records in; records out; light volume out)
+        "fast_count_kernel": m * rec,
+        "fast_scatter_kernel": m * rec + m * rec,
+        "fast_brick_kernel": m * rec + cells * channels * 4,
     }
 
 
@@ -520,7 +517,7 @@ def main():
 
         stages = {"trace": stage(["trace_kernel"]),
                   "bin": stage(["bin_", "radix_", "cell_start", "fast_count", "fast_scan", "fast_scatter"]),
-                  "gather": stage(["gather", "fast_tile", "fast_combine"]),
+                  "gather": stage(["gather", "fast_brick"]),
                   "reduce": stage(["rccl_"])}
         tile = 256 * (4 if n_rank <= (1 << 15) else 8 if n_rank <= (1 << 23) else 16)
         tiles = -(-n_rank // tile)
@@ -533,13 +530,13 @@ def main():
         dom_avg_ms = per_frame[dom][2]
         achieved = ab.get(dom_base, 0) / (dom_avg_ms * 1e-3) / 1e9
         if fast:
-            frame_bytes = sum(ab[k] for k in ("trace_kernel", "fast_count_kernel", "fast_scatter_kernel", "fast_tile_kernel", "fast_combine_kernel"))
+            frame_bytes = sum(ab[k] for k in ("trace_kernel", "fast_count_kernel", "fast_scatter_kernel", "fast_brick_kernel"))
         else:
             passes = -(-int(gdim ** 3).bit_length() // 8)
             frame_bytes = (ab["trace_kernel"] + ab["bin_keys_kernel"] + passes * (ab["radix_hist_kernel"] + ab["radix_rowscan_kernel"] + ab["radix_scatter_kernel"])
                            + ab["bin_finalize_kernel"] + ab["cell_start_kernel"] + ab["gather_kernel"])
         traffic, traffic_src = pmc_traffic(dom.split("<")[0], args.workload)
-        what = {"fast": "brick bin + fixed-point LDS-tile gather (cpm_bin_fast + cpm_gather_fast: tolerance mode, rtol 2e-5 / atol 1e-5 max "
+        what = {"fast": "brick bin + one-launch fixed-point LDS-tile gather (cpm_bin_fast + cpm_gather_fast: tolerance mode, rtol 2e-5 / atol 1e-5 max "
                         "vs the reference semantics, bitwise reproducible)",
                 "exact": "cell sort + sequential per-voxel gather (cpm_bin + cpm_gather: bit-exact contract)"}[args.formulation]
         out = {

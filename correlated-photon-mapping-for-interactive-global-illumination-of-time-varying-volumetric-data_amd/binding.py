@@ -34,7 +34,7 @@ ABI_SYMBOLS = [
     "cpm_grid_desc_default", "cpm_relative_irradiance_scale",
     "cpm_splat", "cpm_splat_selected", "cpm_copy_indexed_photons", "cpm_snapshot_selected_photons",
     "cpm_sort_pairs", "cpm_sort_keys", "cpm_bin", "cpm_gather", "cpm_mark_touched_bricks", "cpm_gather_bricks",
-    "cpm_fast_table_entries", "cpm_gather_fast_supported", "cpm_bin_fast", "cpm_gather_fast",
+    "cpm_fast_table_entries", "cpm_gather_fast_supported", "cpm_fast_record_capacity", "cpm_bin_fast", "cpm_gather_fast",
     "cpm_volume_minmax", "cpm_volume_difference", "cpm_importance_tf",
     "cpm_photon_importance", "cpm_photon_importance_equal", "cpm_reset_importance",
     "cpm_select_recompute", "cpm_select_changed",
@@ -126,7 +126,8 @@ def load_library() -> C.CDLL:
         "cpm_gather_bricks": (i32, [vp, vp, vp, i32, P(GridDesc), f32, f32, vp, vp, vp]),
         "cpm_fast_table_entries": (sz, [P(GridDesc), i32]),
         "cpm_gather_fast_supported": (i32, [P(GridDesc), f32]),
-        "cpm_bin_fast": (i32, [vp, vp, i32, P(GridDesc), vp, vp, vp]),
+        "cpm_fast_record_capacity": (sz, [P(GridDesc), i32, f32]),
+        "cpm_bin_fast": (i32, [vp, vp, i32, P(GridDesc), f32, vp, vp, vp]),
         "cpm_gather_fast": (i32, [vp, vp, vp, i32, P(GridDesc), f32, f32, i32, vp, vp]),
         "cpm_volume_minmax": (i32, [vp, vp, i32, vp, vp]),
         "cpm_volume_difference": (i32, [vp, vp, vp, i32, vp, vp]),
@@ -396,8 +397,11 @@ class Context:
     def gather_fast_supported(self, grid: GridDesc, radius: float) -> bool:
         return bool(self.lib.cpm_gather_fast_supported(C.byref(grid), radius))
 
-    def bin_fast(self, photons, n, grid: GridDesc, brick_table, sorted_pos_power):
-        self._check(self.lib.cpm_bin_fast(self.h, self._ptr(photons), n, C.byref(grid), self._ptr(brick_table),
+    def fast_record_capacity(self, grid: GridDesc, n: int, radius: float) -> int:
+        return int(self.lib.cpm_fast_record_capacity(C.byref(grid), n, radius))
+
+    def bin_fast(self, photons, n, grid: GridDesc, radius, brick_table, sorted_pos_power):
+        self._check(self.lib.cpm_bin_fast(self.h, self._ptr(photons), n, C.byref(grid), radius, self._ptr(brick_table),
                                           self._ptr(sorted_pos_power), self._stream()))
 
     def gather_fast(self, sorted_pos_power, brick_table, n, grid, radius, scale, out, accumulate=False):

@@ -32,7 +32,9 @@ struct cpm_ctx {
     // (cpm_trace.hip; used only for samples whose (theta, phi) bit patterns match)
     float* dir_hint = nullptr;
     size_t fast_hist_words = 0;  // cpm_bin_fast: size of the histograms whose all-zero state is established (0 = none)
-    int fast_hist_parity = 0;    // which of the two histograms the next cpm_bin_fast counts into
+    int fast_hist_parity = 0;    // which of the two (histogram, cursors) pairs the next cpm_bin_fast uses
+    const void* fast_last_table = nullptr;  // the last cpm_bin_fast's table and radius: cpm_gather_fast refuses another radius for it
+    float fast_last_radius = 0.f;
 };
 
 // scratch slots
@@ -43,8 +45,8 @@ enum {
     CPM_SCR_BIN_KEYS = 3,    // cell keys of cpm_bin
     CPM_SCR_SMALL = 4,       // TF points etc.
     CPM_SCR_MISC = 5,
-    CPM_SCR_FAST_BIN = 6,    // cpm_bin_fast: two brick histograms (used in turn, zeroed by the call before) + per-photon ranks
-    CPM_SCR_FAST_SLABS = 7   // cpm_gather_fast: one fixed-point tile per work item
+    CPM_SCR_FAST_BIN = 6,    // cpm_bin_fast: two (brick histogram, cursors) pairs, used in turn, zeroed by the call before
+    CPM_SCR_FAST_SLABS = 7   // (unused since the one-launch gather)
 };
 
 struct cpm_volume {

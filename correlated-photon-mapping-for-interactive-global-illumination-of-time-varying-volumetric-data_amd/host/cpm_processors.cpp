@@ -790,8 +790,10 @@ void PhotonToLightVolumeProcessorCL::process() {  // photontolightvolumeprocesso
         } else if (formulation_.get() == "fast" && cpm_gather_fast_supported(&g, radius)) {
             // brick bin + LDS-tile gather, fixed-point sums: the reference's terms within the stated fp32 tolerance
             const size_t m = (size_t)nPhotons * nInter;
-            brickTable_.setSize(cpm_fast_table_entries(&g, (int)m)); sorted_.setSize(m * (channels == 1 ? 4 : 8));
-            if (rt.check(cpm_bin_fast(rt.ctx(), photons, (int)m, &g, brickTable_.device(), sorted_.device(), rt.stream()), "cpm_bin_fast"))
+            // (a record per (photon, brick it reaches): cpm_fast_record_capacity)
+            brickTable_.setSize(cpm_fast_table_entries(&g, (int)m));
+            sorted_.setSize(cpm_fast_record_capacity(&g, (int)m, radius) * (channels == 1 ? 4 : 8));
+            if (rt.check(cpm_bin_fast(rt.ctx(), photons, (int)m, &g, radius, brickTable_.device(), sorted_.device(), rt.stream()), "cpm_bin_fast"))
                 rt.check(cpm_gather_fast(rt.ctx(), sorted_.device(), brickTable_.device(), (int)m, &g, radius, scale, 0, out, rt.stream()), "cpm_gather_fast");
         } else {  // sort/bin + deterministic per-cell gather
             const size_t m = (size_t)nPhotons * nInter;

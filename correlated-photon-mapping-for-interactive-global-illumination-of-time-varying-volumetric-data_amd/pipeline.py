@@ -227,7 +227,8 @@ class PhotonFrame:
         self.cell_start = torch.empty(self.cells + 1, dtype=torch.int32, device=dev)
         self.sorted = torch.empty((self.n * self.I, 4 if channels == 1 else 8), dtype=f32, device=dev)
         self.light_volume = torch.zeros((self.cells, channels) if channels > 1 else (self.cells,), dtype=f32, device=dev)
-        self.brick_table = None   # cpm_bin_fast's table, allocated on first use
+        self.brick_table = None   # cpm_bin_fast's table and records (every photon in all the bricks it reaches), allocated on first use
+        self.sorted_fast = None
 
     # stages
     def trace(self):
@@ -245,10 +246,13 @@ class PhotonFrame:
         if self.brick_table is None:
             entries = self.ctx.fast_table_entries(self.grid, self.n * self.I)
             self.brick_table = self.torch.zeros(entries, dtype=self.torch.int32, device=self.ctx.device)
-        self.ctx.bin_fast(self.photons, self.n * self.I, self.grid, self.brick_table, self.sorted)
+        cap = max(self.ctx.fast_record_capacity(self.grid, self.n * self.I, self.radius), 1)
+        if self.sorted_fast is None or self.sorted_fast.shape[0] < cap:   # (a progressive radius schedule only ever shrinks it)
+            self.sorted_fast = self.torch.empty((cap, 4 if self.grid.channels == 1 else 8), dtype=self.torch.float32, device=self.ctx.device)
+        self.ctx.bin_fast(self.photons, self.n * self.I, self.grid, self.radius, self.brick_table, self.sorted_fast)
 
     def gather_fast(self, accumulate=False, out=None):
-        self.ctx.gather_fast(self.sorted, self.brick_table, self.n * self.I, self.grid, self.radius, self.scale,
+        self.ctx.gather_fast(self.sorted_fast, self.brick_table, self.n * self.I, self.grid, self.radius, self.scale,
                              self.light_volume if out is None else out, accumulate=accumulate)
 
     def frame_fast(self):

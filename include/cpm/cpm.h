@@ -316,24 +316,32 @@ int cpm_gather_bricks(cpm_ctx* ctx, const float* sorted_pos_power, const uint32_
  * 0.75 * (1 - d^2 / r^2) for d^2 <= r^2 (no sqrt, no division -- ref cl/densityestimationkernel.cl:43-60 takes
  * x = d / r), and per-voxel sums are accumulated as 64-bit fixed-point integers, so they do not depend on any
  * order: the result is bitwise reproducible run to run although nothing is sorted inside a brick.
- * Photons are grouped by BRICK (8x8x8 voxels; wider for grids beyond 16 Ki bricks) with an unstable counting
- * sort -- the order of the records inside a brick is unspecified.  Sentinel photons are dropped.
+ * Photons are filed by BRICK (8x8x8 voxels; bigger for grids beyond 8 Ki bricks) with an unstable counting sort -- the
+ * order of the records inside a brick is unspecified.  A photon whose candidate voxels (the integers within
+ * r * textureToIndex + 1e-3 of its index-space coordinate, per axis, clipped to the grid) straddle a brick face is filed
+ * under EVERY brick they lie in (at most 8; 0.3 % of the photons are filed twice at BASELINE config 2), so a brick's
+ * voxels receive from that brick's records alone and the gather is one launch.  Sentinel photons and photons that
+ * reach no voxel are dropped.
  * The reference adds with CAS float atomics in arrival order (ref cl/photonstolightvolume.cl:15-29,62-75). */
 
-/* u32 entries of the brick table cpm_bin_fast fills for n records on this grid (0 = bad arguments). */
+/* u32 entries of the brick table cpm_bin_fast fills on this grid (0 = bad arguments): brick starts, max |power|, radius. */
 size_t cpm_fast_table_entries(const cpm_grid_desc* grid, int n);
-/* 1 when cpm_gather_fast covers this grid / radius (radius < 2 voxels per axis, positive axis-aligned
- * textureToIndex); otherwise use cpm_bin + cpm_gather. */
+/* 1 when the pair covers this grid / radius (radius < 2 voxels per axis, positive axis-aligned textureToIndex);
+ * otherwise use cpm_bin + cpm_gather. */
 int cpm_gather_fast_supported(const cpm_grid_desc* grid, float radius);
+/* Records sorted_pos_power must hold for n photons at this radius (every photon in all its bricks: 8 n, or n when a
+ * candidate box is a single voxel wide); 0 when unsupported. */
+size_t cpm_fast_record_capacity(const cpm_grid_desc* grid, int n, float radius);
 
-/* brick_table (device, cpm_fast_table_entries(grid, n) u32): brick starts, work-item list, max |power|.
- * sorted_pos_power: n compact records, float4 (x, y, z, powerR) when channels == 1, 2 x float4
- * (x, y, z, powerR | powerG, powerB, 0, 0) when == 4; the first brick_table[bricks] of them are written. */
-int cpm_bin_fast(cpm_ctx* ctx, const float* photons8, int n, const cpm_grid_desc* grid, uint32_t* brick_table,
+/* brick_table (device, cpm_fast_table_entries(grid, n) u32): brick starts (brick_table[bricks] = records written), max
+ * |power|, the radius.  sorted_pos_power: cpm_fast_record_capacity(grid, n, radius) compact records, float4
+ * (x, y, z, powerR) when channels == 1, 2 x float4 (x, y, z, powerR | powerG, powerB, 0, 0) when == 4.
+ * radius: the photon radius (texture units) the gather will use -- it decides which bricks a photon is filed under. */
+int cpm_bin_fast(cpm_ctx* ctx, const float* photons8, int n, const cpm_grid_desc* grid, float radius, uint32_t* brick_table,
                  float* sorted_pos_power, cpm_stream stream);
 
 /* grid_out[v] = (accumulate ? grid_out[v] : 0) + float(sum over photons of fixed(power * k * w(v, photon))) with
- * k = relative_irradiance_scale / (4 pi) as in cpm_splat.  n, grid: as given to cpm_bin_fast. */
+ * k = relative_irradiance_scale / (4 pi) as in cpm_splat.  n, grid, radius: as given to cpm_bin_fast. */
 int cpm_gather_fast(cpm_ctx* ctx, const float* sorted_pos_power, const uint32_t* brick_table, int n,
                     const cpm_grid_desc* grid, float radius, float relative_irradiance_scale, int accumulate,
                     float* grid_out, cpm_stream stream);

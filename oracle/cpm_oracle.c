@@ -809,24 +809,8 @@ void cpmo_gather(const float* sorted, const uint32_t* cell_start, int n, const c
  * so that the HIP path can be checked bit for bit: the weight is 0.75 * (1 - d^2 / r^2) for d^2 <= r^2
  * (cl/densityestimationkernel.cl:43-60 with x^2 = d^2 / r^2), every contribution is truncated to 64-bit fixed
  * point with the scale below, the per-voxel sums are exact integers (order-free), one rounding to float.
- * The brick / tile bookkeeping only decides which candidate voxels are considered; it is restated because a
- * candidate outside the photon's brick tile is dropped by the kernel. */
-typedef struct { int lg[3], nb[3], h[3], t[3]; } fast_layout;
-
-static void fast_brick_layout(const cpmo_grid_desc* g, float radius, fast_layout* L) {
-    for (int a = 0; a < 3; ++a) L->lg[a] = 3;
-    int axis = 0;
-    for (;;) {
-        long long cnt = 1;
-        for (int a = 0; a < 3; ++a) { L->nb[a] = (g->dims[a] + (1 << L->lg[a]) - 1) >> L->lg[a]; cnt *= L->nb[a]; }
-        if (cnt <= 16384) break;
-        ++L->lg[axis]; axis = (axis + 1) % 3;
-    }
-    for (int a = 0; a < 3; ++a) {
-        L->h[a] = (int)floorf(radius * g->texture_to_index[5 * a] + 0.501f);
-        L->t[a] = (1 << L->lg[a]) + 2 * L->h[a];
-    }
-}
+ * The candidate voxels of a photon are the integers within r * textureToIndex + 1e-3 of its index-space coordinate per
+ * axis, clipped to the grid -- nothing of the kernels' brick bookkeeping enters the result. */
 
 static float fast_fixed_scale(float maxpow, float k) {
     float m = maxpow * fabsf(k) * 0.75f;
@@ -845,8 +829,6 @@ void cpmo_gather_fast(const float* photons, int n, const cpmo_grid_desc* g, floa
     const size_t cells = (size_t)dims[0] * dims[1] * dims[2];
     const int ch3 = g->channels == 1 ? 1 : 3;
     const float k = 0.0795774715459476679f * scale;
-    fast_layout L;
-    fast_brick_layout(g, radius, &L);
     float maxpow = 0.f;
     for (int i = 0; i < n; ++i) {
         const float* ph = photons + 8 * (size_t)i;
@@ -867,11 +849,10 @@ void cpmo_gather_fast(const float* photons, int n, const cpmo_grid_desc* g, floa
         for (int a = 0; a < 3; ++a) {
             const float u = om_fma(sT[a], ph[a], tT[a]);
             const float rg = radius * sT[a] + 1e-3f;
-            const int cell = (int)om_min(om_max(floorf(u + 0.5f), 0.0f), (float)(dims[a] - 1));
-            const int o = ((cell >> L.lg[a]) << L.lg[a]) - L.h[a]; /* tile origin of the photon's brick */
-            int lo = (int)ceilf(u - rg), hi = (int)floorf(u + rg);
-            if (lo < 0) lo = 0; if (lo < o) lo = o;
-            if (hi > dims[a] - 1) hi = dims[a] - 1; if (hi > o + L.t[a] - 1) hi = o + L.t[a] - 1;
+            /* the candidate voxels: the integers within rg of u, clipped to the grid (clamped as floats: a far-away photon
+             * must not reach an out-of-range float -> int conversion) */
+            int lo = (int)om_min(om_max(ceilf(u - rg), 0.0f), (float)dims[a]);
+            int hi = (int)om_max(om_min(floorf(u + rg), (float)(dims[a] - 1)), -1.0f);
             s[a] = lo; e[a] = hi;
         }
         const float pk[3] = { ph[3] * k, ph[4] * k, ph[5] * k };

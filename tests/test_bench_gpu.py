@@ -29,7 +29,7 @@ def test_bench_single_gpu_line():
                                "sparse_tf_trace"} <= set(d)
     assert d["n_gpus"] == 1 and d["steps"] == 10 and d["warmup"] == 2 and d["value"] > 0 and d["scaling"] == "weak"
     assert "cpm_bin_fast" in d["config"]["formulation"] and d["other_formulation"]["name"] == "exact"
-    assert any(k.startswith("fast_tile_kernel") for k in d["frame"]["kernel_ms_per_frame"])
+    assert any(k.startswith("fast_brick_kernel") for k in d["frame"]["kernel_ms_per_frame"])
     assert set(d["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic"}
     assert set(d["cpu_baseline"]) >= {"value", "unit", "cores", "kind", "sample"} and d["cpu_baseline"]["kind"] == "port"
     assert d["pipelined"]["light_volumes_identical_to_single_stream"] is True

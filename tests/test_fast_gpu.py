@@ -52,14 +52,45 @@ def make_photons(rng, n, dims, *, sentinels=0.1, outside=0.02, cluster=None, neg
     return ph
 
 
-def brick_count(dims):
-    """Bricks of 8^3 voxels, doubled along x, y, z in turn while there are more than 16 Ki of them (cpm.h)."""
+def brick_layout(dims):
+    """Bricks of 8^3 voxels, doubled along x, y, z in turn while there are more than 8 Ki of them (cpm.h): (log2 sizes, counts)."""
     lg, axis = [3, 3, 3], 0
     cnt = lambda: [(d + (1 << l) - 1) >> l for d, l in zip(dims, lg)]
-    while np.prod(cnt()) > 16384:
+    while np.prod(cnt()) > 8192:
         lg[axis] += 1
         axis = (axis + 1) % 3
-    return int(np.prod(cnt()))
+    return lg, cnt()
+
+
+def brick_count(dims):
+    return int(np.prod(brick_layout(dims)[1]))
+
+
+def expected_filing(ph, dims, radius, grid):
+    """(photon index, brick) pairs cpm_bin_fast must file: every stored photon under every brick its candidate voxels
+    (integers within r * textureToIndex + 1e-3 of the index-space coordinate, clipped to the grid) lie in."""
+    lg, nbk = brick_layout(dims)
+    t2i = np.array(grid.texture_to_index, np.float32)
+    pairs = []
+    stored = np.where(ph[:, 0] != FLT_MAX)[0]
+    rng_axes = []
+    for a in range(3):
+        s, t = t2i[5 * a], t2i[12 + a]
+        u = (np.float64(s) * ph[stored, a].astype(np.float64) + np.float64(t)).astype(np.float32)   # = fma(s, p, t): the product is exact in double
+        rg = np.float32(radius) * s + np.float32(1e-3)
+        lo = np.clip(np.ceil((u - rg).astype(np.float32)), 0, dims[a]).astype(np.int64)
+        hi = np.clip(np.floor((u + rg).astype(np.float32)), -1, dims[a] - 1).astype(np.int64)
+        rng_axes.append((lo, hi))
+    ok = np.ones(stored.size, bool)
+    for lo, hi in rng_axes:
+        ok &= lo <= hi
+    for j in np.where(ok)[0]:
+        (lx, hx), (ly, hy), (lz, hz) = [(int(lo[j]) >> lg[a], int(hi[j]) >> lg[a]) for a, (lo, hi) in enumerate(rng_axes)]
+        for bz in range(lz, hz + 1):
+            for by in range(ly, hy + 1):
+                for bx in range(lx, hx + 1):
+                    pairs.append((int(stored[j]), bx + nbk[0] * (by + nbk[1] * bz)))
+    return pairs
 
 
 def run_fast(ctx, cpm, ph, dims, channels, radius, scale, accumulate_into=None):
@@ -68,9 +99,9 @@ def run_fast(ctx, cpm, ph, dims, channels, radius, scale, accumulate_into=None):
     grid = B.default_grid_desc(dims, channels)
     cells = dims[0] * dims[1] * dims[2]
     table = ctx.torch.zeros(max(ctx.fast_table_entries(grid, n), 1), dtype=ctx.torch.int32, device=ctx.device)
-    srt = ctx.torch.zeros((max(n, 1), 4 if channels == 1 else 8), dtype=ctx.torch.float32, device=ctx.device)
+    srt = ctx.torch.zeros((max(ctx.fast_record_capacity(grid, n, radius), 1), 4 if channels == 1 else 8), dtype=ctx.torch.float32, device=ctx.device)
     d_ph = _t(ctx, ph) if n else ctx.torch.zeros((1, 8), dtype=ctx.torch.float32, device=ctx.device)
-    ctx.bin_fast(d_ph, n, grid, table, srt)
+    ctx.bin_fast(d_ph, n, grid, radius, table, srt)
     if accumulate_into is None:
         out = ctx.torch.full((cells,) if channels == 1 else (cells, 4), 7.0, dtype=ctx.torch.float32, device=ctx.device)
         ctx.gather_fast(srt, table, n, grid, radius, scale, out)
@@ -105,7 +136,7 @@ CASES = [
     ((1, 5, 17), 1, 3_000, 0.4, {}),             # degenerate
     ((7, 1, 3), 4, 1_000, 0.9, {}),
     ((128, 128, 128), 1, 300_000, 0.866, dict(cluster=0.0)),
-    ((256, 128, 64), 1, 100_000, 1.0, {}),       # > 16 Ki bricks of 8^3: wider bricks
+    ((256, 128, 64), 1, 100_000, 1.0, {}),       # > 8 Ki bricks of 8^3: bigger bricks
     ((16, 16, 16), 1, 1, 0.866, dict(sentinels=0.0, outside=0.0)),
     ((16, 16, 16), 1, 63, 0.866, {}),
     ((16, 16, 16), 1, 4097, 0.866, {}),
@@ -122,16 +153,25 @@ def test_fast_equals_restatement_and_reference_semantics(ctx, oracle, cpm, dims,
     want_fast, want_exact = oracle_both(oracle, ph, dims, channels, radius, scale)
     assert np.array_equal(bits(got), bits(want_fast))
     np.testing.assert_allclose(got, want_exact, rtol=RTOL, atol=ATOL_OF_MAX * float(np.abs(want_exact).max()))
-    # the table: brick starts are the counts of the stored photons per brick; records are a permutation of them
-    stored = ph[ph[:, 0] != FLT_MAX]
+    # the table: a photon is filed under every brick its candidate voxels lie in; brick starts are those counts, the records
+    # of a brick are exactly the photons filed under it (in no particular order)
+    grid = cpm.binding.default_grid_desc(dims, channels)
+    pairs = expected_filing(ph, dims, radius, grid)
     nb = brick_count(dims)
-    total = stored.shape[0]
+    total = len(pairs)
     assert table[0] == 0 and table[nb] == total and (np.diff(table[: nb + 1].astype(np.int64)) >= 0).all()
-    rec = srt[:total]
-    want_rec = stored[:, :4] if channels == 1 else np.concatenate([stored[:, :6], np.zeros((total, 2), np.float32)], axis=1)
-    a = np.sort(rec.view([("", np.uint32)] * rec.shape[1]).reshape(-1))
-    b = np.sort(np.ascontiguousarray(want_rec).view([("", np.uint32)] * rec.shape[1]).reshape(-1))
-    assert np.array_equal(a, b)
+    assert total <= ctx.fast_record_capacity(grid, n, radius)
+    counts = np.bincount(np.array([b for _, b in pairs], np.int64), minlength=nb) if pairs else np.zeros(nb, np.int64)
+    assert np.array_equal(np.diff(table[: nb + 1].astype(np.int64)), counts)
+    rec_of = (lambda i: ph[i, :4]) if channels == 1 else (lambda i: np.concatenate([ph[i, :6], np.zeros(2, np.float32)]))
+    width = 4 if channels == 1 else 8
+    by_brick = {}
+    for i, b in pairs:
+        by_brick.setdefault(b, []).append(rec_of(i))
+    for b, recs in list(by_brick.items())[:400]:  # (every brick for the small cases, a sample for the big ones)
+        got_b = np.ascontiguousarray(srt[table[b]:table[b + 1]]).view([("", np.uint32)] * width).reshape(-1)
+        want_b = np.ascontiguousarray(np.stack(recs).astype(np.float32)).view([("", np.uint32)] * width).reshape(-1)
+        assert np.array_equal(np.sort(got_b), np.sort(want_b)), b
     # bitwise reproducible although nothing orders the records inside a brick
     again, _, _ = run_fast(ctx, cpm, ph, dims, channels, radius, scale)
     assert np.array_equal(bits(again), bits(got))
@@ -175,12 +215,21 @@ def test_fast_unsupported_radius_is_refused(ctx, cpm):
     assert ctx.gather_fast_supported(grid, 0.866 / 32)
     assert not ctx.gather_fast_supported(grid, 2.2 / 32)
     table = ctx.torch.zeros(ctx.fast_table_entries(grid, 16), dtype=ctx.torch.int32, device=ctx.device)
-    srt = ctx.torch.zeros((16, 4), dtype=ctx.torch.float32, device=ctx.device)
+    assert ctx.fast_record_capacity(grid, 16, 0.866 / 32) == 8 * 16 and ctx.fast_record_capacity(grid, 16, 2.2 / 32) == 0
+    assert ctx.fast_record_capacity(grid, 16, 0.2 / 32) == 16      # a candidate box one voxel wide: one brick per photon
+    srt = ctx.torch.zeros((8 * 16, 4), dtype=ctx.torch.float32, device=ctx.device)
     out = ctx.torch.zeros(32 ** 3, dtype=ctx.torch.float32, device=ctx.device)
-    ctx.bin_fast(ctx.torch.zeros((16, 8), dtype=ctx.torch.float32, device=ctx.device), 16, grid, table, srt)
+    photons = ctx.torch.zeros((16, 8), dtype=ctx.torch.float32, device=ctx.device)
+    with pytest.raises(B.CpmError) as e:
+        ctx.bin_fast(photons, 16, grid, 2.2 / 32, table, srt)
+    assert e.value.status == -4  # CPM_ERR_UNSUPPORTED: callers fall back to cpm_bin + cpm_gather
+    ctx.bin_fast(photons, 16, grid, 0.866 / 32, table, srt)
     with pytest.raises(B.CpmError) as e:
         ctx.gather_fast(srt, table, 16, grid, 2.2 / 32, 1.0, out)
-    assert e.value.status == -4  # CPM_ERR_UNSUPPORTED: callers fall back to cpm_bin + cpm_gather
+    assert e.value.status == -4
+    with pytest.raises(B.CpmError):                                  # the records were filed for another radius
+        ctx.gather_fast(srt, table, 16, grid, 1.2 / 32, 1.0, out)
+    ctx.gather_fast(srt, table, 16, grid, 0.866 / 32, 1.0, out)
 
 
 def test_fast_non_default_grid_matrices(ctx, oracle, cpm):
@@ -203,9 +252,9 @@ def test_fast_non_default_grid_matrices(ctx, oracle, cpm):
     n = ph.shape[0]
     radius, scale = 0.02, 0.3
     table = ctx.torch.zeros(ctx.fast_table_entries(grid, n), dtype=ctx.torch.int32, device=ctx.device)
-    srt = ctx.torch.zeros((n, 4), dtype=ctx.torch.float32, device=ctx.device)
+    srt = ctx.torch.zeros((ctx.fast_record_capacity(grid, n, radius), 4), dtype=ctx.torch.float32, device=ctx.device)
     out = ctx.torch.zeros(dims[0] * dims[1] * dims[2], dtype=ctx.torch.float32, device=ctx.device)
-    ctx.bin_fast(_t(ctx, ph), n, grid, table, srt)
+    ctx.bin_fast(_t(ctx, ph), n, grid, radius, table, srt)
     ctx.gather_fast(srt, table, n, grid, radius, scale, out)
     want = np.zeros(out.numel(), np.float32)
     oracle.gather_fast(ph, n, og, radius, scale, want)

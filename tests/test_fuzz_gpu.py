@@ -104,14 +104,17 @@ def test_fast_formulation_random_shapes(ctx, oracle, cpm, seed):
     torch = ctx.torch
     shape = (cells,) if channels == 1 else (cells, 4)
     table = torch.zeros(ctx.fast_table_entries(g, n), dtype=torch.int32, device=ctx.device)
-    srt = torch.zeros((n, 4 if channels == 1 else 8), dtype=torch.float32, device=ctx.device)
     out = torch.full(shape, -3.0, dtype=torch.float32, device=ctx.device)
     d_ph = _t(ctx, ph)
-    ctx.bin_fast(d_ph, n, g, table, srt)
     if not ctx.gather_fast_supported(g, radius):
+        srt = torch.zeros((8 * n, 4 if channels == 1 else 8), dtype=torch.float32, device=ctx.device)
+        with pytest.raises(cpm.binding.CpmError):
+            ctx.bin_fast(d_ph, n, g, radius, table, srt)
         with pytest.raises(cpm.binding.CpmError):
             ctx.gather_fast(srt, table, n, g, radius, scale, out)
         return
+    srt = torch.zeros((ctx.fast_record_capacity(g, n, radius), 4 if channels == 1 else 8), dtype=torch.float32, device=ctx.device)
+    ctx.bin_fast(d_ph, n, g, radius, table, srt)
     ctx.gather_fast(srt, table, n, g, radius, scale, out)
     want = np.zeros(shape, np.float32)
     oracle.gather_fast(ph, n, og, radius, scale, want)
@@ -128,7 +131,7 @@ def test_fast_formulation_random_shapes(ctx, oracle, cpm, seed):
     one = pmax * abs(scale) * 0.0795774715459476679 * 0.75
     np.testing.assert_allclose(got, exact, rtol=2e-5, atol=1e-5 * max(float(np.abs(exact).max()), one), err_msg=note)
     # again (the bin's two histograms alternate), accumulating on top
-    ctx.bin_fast(d_ph, n, g, table, srt)
+    ctx.bin_fast(d_ph, n, g, radius, table, srt)
     ctx.gather_fast(srt, table, n, g, radius, scale, out, accumulate=True)
     oracle.gather_fast(ph, n, og, radius, scale, want, accumulate=True)
     assert np.array_equal(bits(_n(out)), bits(want)), note

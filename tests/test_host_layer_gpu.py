@@ -330,7 +330,7 @@ assert h and lib.cpmh_evaluate(h, 1) == 0
     assert r.returncode == 0, log[-3000:]
     assert "Photon tracing: " in log and "trace_kernel" in log and " ms" in log
     assert "Computed photons: 1024 = 100.00 %" in log
-    assert "Photons to light volume: " in log and "fast_tile_kernel" in log and "fast_combine_kernel" in log
+    assert "Photons to light volume: " in log and "fast_scatter_kernel" in log and "fast_brick_kernel" in log
 
 
 def test_radixsort_processor(host, ctx):
