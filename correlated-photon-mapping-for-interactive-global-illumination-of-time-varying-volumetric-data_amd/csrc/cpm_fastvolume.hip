@@ -8,10 +8,10 @@
 // The bit-exact per-voxel sequential contract stays in cpm_bin / cpm_gather (cpm_lightvolume.hip).
 //
 // How (three short launches):
-//   bin    fast_count_kernel    photon -> the bricks (8x8x8 voxels; bigger for grids beyond 8 Ki bricks) its candidate
+//   bin    fast_count_kernel    photon -> the bricks (8x8x16 voxels; bigger for grids beyond 8 Ki bricks) its candidate
 //                               voxels lie in: its own brick, and a neighbour's when the candidate box straddles a
 //                               face (0.3 % of the photons at config 2, where r is half a cell; at most 8 bricks).
-//                               Per tile of 2048 photons: histogram in LDS, ONE returning global atomic per non-empty
+//                               Per tile of 4096 photons: histogram in LDS, ONE returning global atomic per non-empty
 //                               brick = the offset of the tile's run inside that brick (run_base[tile][brick]).
 //          fast_scatter_kernel  every workgroup scans the finished histogram into brick starts (LDS, while its photon
 //                               loads are in flight); position of a copy = start + run offset + an LDS counter; a
@@ -39,7 +39,7 @@ namespace {
 #define CPM_BRICK_WG_PER_CU 2
 #endif
 #ifndef CPM_COUNT_ITEMS
-#define CPM_COUNT_ITEMS 2
+#define CPM_COUNT_ITEMS 4
 #endif
 #ifndef CPM_BRICK_PER
 #define CPM_BRICK_PER 2
@@ -48,7 +48,7 @@ constexpr int kBrickThreads = CPM_BRICK_THREADS;
 constexpr int kBrickPer = CPM_BRICK_PER;      // records per lane and batch of fast_brick_kernel
 constexpr int kCountItems = CPM_COUNT_ITEMS;  // photons per thread of fast_count_kernel (1024 threads)
 constexpr int kCountTile = 1024 * kCountItems;
-constexpr int kScatterItems = 2;              // photons per thread and tile of fast_scatter_kernel (1024 threads)
+constexpr int kScatterItems = kCountItems;    // the two launches share the tile decomposition (run_base rows)
 constexpr int kScatterTile = 1024 * kScatterItems;
 constexpr int kMaxBricks = 8192;              // two LDS words per brick in fast_scatter_kernel: 64 KiB
 
@@ -82,12 +82,23 @@ __host__ int make_grid_dev_fast(cpm_ctx* ctx, const cpm_grid_desc* g, GridDev& G
     return CPM_OK;
 }
 
-// brick shape from the grid alone: 8 x 8 x 8 voxels, doubled along x, y, z in turn while there are more than 8 Ki bricks
+// brick shape from the grid alone: 8 x 8 x 16 voxels; while there are more than 8 Ki bricks, doubled along the axis with the
+// most bricks (ties: x, then y, then z).
+// (Measured at config 2, 128^3: 4096 bricks of 8^3 -> 80.1 us per frame, 2048 of 16x8x8 -> 76.1, 2048 of 8x8x16 -> 74.9,
+// 1024 of 16x16x8 -> 81.0, 8192 of 8x4x8 -> 93.6: fewer bricks make the scans, the per-tile rows and the empty bricks
+// cheaper until the heaviest brick -- a serial chain of 1024-record batches in one workgroup -- takes over.)
 __host__ void brick_shape(const int dims[3], BrickLayout& L) {
-    int lg[3] = { 3, 3, 3 };
+#ifndef CPM_BRICK_LG
+#define CPM_BRICK_LG 3, 3, 4
+#endif
+    int lg[3] = { CPM_BRICK_LG };
     auto count = [&](int a) { return (dims[a] + (1 << lg[a]) - 1) >> lg[a]; };
-    int axis = 0;
-    while ((long long)count(0) * count(1) * count(2) > kMaxBricks) { ++lg[axis]; axis = (axis + 1) % 3; }
+    while ((long long)count(0) * count(1) * count(2) > kMaxBricks) {
+        int axis = 0;
+        if (count(1) > count(axis)) axis = 1;
+        if (count(2) > count(axis)) axis = 2;
+        ++lg[axis];
+    }
     L.lx = lg[0]; L.ly = lg[1]; L.lz = lg[2];
     L.nbx = count(0); L.nby = count(1); L.nbz = count(2);
     L.nb = L.nbx * L.nby * L.nbz;
@@ -185,7 +196,7 @@ CPM_DEV void fast_scan(const uint32_t* __restrict__ counts, const BrickLayout& L
     if (table && t == 0) { table[L.nb] = tc; table[off_meta(L) + kMetaItems] = ti; }
 }
 
-// bin, launch 1 of 2.  Per workgroup (1024 threads) = per TILE of 2048 photons: the bricks every photon's candidate box
+// bin, launch 1 of 2.  Per workgroup (1024 threads) = per TILE of 4096 photons: the bricks every photon's candidate box
 // touches, counted in an LDS histogram; ONE returning global atomic per non-empty brick reserves the tile's run inside that
 // brick -- its offset goes to run_base[tile][brick] (a dense row per tile, written only where the tile has copies) for
 // the scatter launch; max |power| of the stored photons on the way.
@@ -244,7 +255,7 @@ __global__ __launch_bounds__(1024) void fast_count_kernel(const float* __restric
 
 // bin, launch 2 of 2.  Every workgroup (1024 threads) first turns the finished histogram into the brick starts -- an
 // exclusive scan of nb <= 8 Ki counts in LDS, while its first photon loads are in flight (the one-workgroup scan launch
-// this replaces took 5.6 us of pure latency) -- then, per tile of 2048 photons: next free position of the tile's run in
+// this replaces took 5.6 us of pure latency) -- then, per tile of 4096 photons: next free position of the tile's run in
 // every brick = brick start + run_base[tile][brick] (a coalesced row read; entries of bricks the tile does not touch are
 // never used), and one LDS atomic per (photon, brick) copy hands out the positions: an unstable counting sort (the order
 // inside a brick is irrelevant to integer sums).  Workgroup 0 also writes the table.  The histogram exists twice and is
@@ -506,7 +517,7 @@ int cpm_bin_fast(cpm_ctx* ctx, const float* photons8, int n, const cpm_grid_desc
     if (!brick_reach(G, radius, L) || tile_bytes_for(G, L) > 160 * 1024 - 1024)
         return set_error(ctx, CPM_ERR_UNSUPPORTED, "cpm_bin_fast", "radius beyond 2 voxels (or not positive): use cpm_bin + cpm_gather");
     // scratch: two histograms (nb brick counts + 4 accumulators), used in turn -- a call's scatter launch zeroes the one the
-    // NEXT call counts into -- then run_base: one row of nb offsets per tile of 2048 photons (written only where a tile has
+    // NEXT call counts into -- then run_base: one row of nb offsets per tile of 4096 photons (written only where a tile has
     // copies, read as whole rows)
     static_assert(kCountTile == kScatterTile, "count and scatter launches share the tile decomposition");
     const size_t hist_words = (size_t)L.nb + kAccWords;

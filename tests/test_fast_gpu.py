@@ -53,12 +53,12 @@ def make_photons(rng, n, dims, *, sentinels=0.1, outside=0.02, cluster=None, neg
 
 
 def brick_layout(dims):
-    """Bricks of 8^3 voxels, doubled along x, y, z in turn while there are more than 8 Ki of them (cpm.h): (log2 sizes, counts)."""
-    lg, axis = [3, 3, 3], 0
+    """Bricks of 8 x 8 x 16 voxels; beyond 8 Ki of them doubled along the axis with the most bricks (cpm.h): (log2 sizes, counts)."""
+    lg = [3, 3, 4]
     cnt = lambda: [(d + (1 << l) - 1) >> l for d, l in zip(dims, lg)]
     while np.prod(cnt()) > 8192:
-        lg[axis] += 1
-        axis = (axis + 1) % 3
+        c = cnt()
+        lg[int(np.argmax(c))] += 1          # (argmax takes the first of equals: x, then y, then z)
     return lg, cnt()
 
 
@@ -136,7 +136,8 @@ CASES = [
     ((1, 5, 17), 1, 3_000, 0.4, {}),             # degenerate
     ((7, 1, 3), 4, 1_000, 0.9, {}),
     ((128, 128, 128), 1, 300_000, 0.866, dict(cluster=0.0)),
-    ((256, 128, 64), 1, 100_000, 1.0, {}),       # > 8 Ki bricks of 8^3: bigger bricks
+    ((256, 128, 64), 1, 100_000, 1.0, {}),
+    ((256, 256, 192), 1, 60_000, 1.0, {}),       # > 8 Ki bricks of 8x8x16: bigger bricks
     ((16, 16, 16), 1, 1, 0.866, dict(sentinels=0.0, outside=0.0)),
     ((16, 16, 16), 1, 63, 0.866, {}),
     ((16, 16, 16), 1, 4097, 0.866, {}),
@@ -193,7 +194,7 @@ def test_fast_accumulate_empty_and_all_sentinels(ctx, oracle, cpm):
     assert not got.any()
     sent = make_photons(rng, 500, dims, sentinels=1.1)
     got, table, _ = run_fast(ctx, cpm, sent, dims, 4, radius, scale)
-    assert not got.any() and table[64] == 0
+    assert not got.any() and table[brick_count(dims)] == 0
     got, _, _ = run_fast(ctx, cpm, sent, dims, 1, radius, scale, accumulate_into=base)
     assert np.array_equal(bits(got), bits(base))
 
