@@ -389,17 +389,22 @@ __global__ __launch_bounds__(kBrickThreads, (CH == 4 ? 4 : CPM_BRICK_WAVES)) voi
     const float S = fixed_scale(__uint_as_float(table[off_meta(L) + kMetaMaxPow]), k);
     const float invS = 1.0f / S;  // a power of two: exact
     const float4* __restrict__ rec = reinterpret_cast<const float4*>(sorted);
-    // the zeros of the bricks nothing reaches (not in accumulate mode)
+    // the zeros of the bricks nothing reaches (not in accumulate mode): one streaming pass over the volume, every lane
+    // looks its voxels' brick up itself (two cached loads) -- no per-brick chain of dependent table reads in a workgroup
     if (!accumulate) {
-        for (uint32_t b = blockIdx.x; b < (uint32_t)L.nb; b += gridDim.x) {
-            if (table[b + 1] != table[b]) continue;
-            const int bx = (int)(b % (uint32_t)L.nbx), by = (int)((b / (uint32_t)L.nbx) % (uint32_t)L.nby), bz = (int)(b / (uint32_t)(L.nbx * L.nby));
-            const int ox = bx << L.lx, oy = by << L.ly, oz = bz << L.lz;
-            for (int v = t; v < L.bvox; v += kBrickThreads) {
-                const int gx = ox + (v & (BX - 1)), gy = oy + ((v >> L.lx) & (BY - 1)), gz = oz + (v >> (L.lx + L.ly));
-                if (gx >= G.dx || gy >= G.dy || gz >= G.dz) continue;
-                const size_t o = (size_t)gx + (size_t)G.dx * ((size_t)gy + (size_t)G.dy * (size_t)gz);
-                if (CH == 1) out[o] = 0.f; else reinterpret_cast<float4*>(out)[o] = make_float4(0.f, 0.f, 0.f, 0.f);
+        const size_t cells = (size_t)G.dx * G.dy * G.dz;
+        if (CH == 1 && (G.dx & 3) == 0) {  // 4 voxels of one x-row (and one brick: bricks are >= 8 wide) per lane and turn
+            for (size_t i = ((size_t)blockIdx.x * kBrickThreads + t) * 4; i < cells; i += (size_t)gridDim.x * kBrickThreads * 4) {
+                const int x = (int)(i % (size_t)G.dx), y = (int)((i / (size_t)G.dx) % (size_t)G.dy), z = (int)(i / ((size_t)G.dx * G.dy));
+                const uint32_t b = (uint32_t)(x >> L.lx) + (uint32_t)L.nbx * ((uint32_t)(y >> L.ly) + (uint32_t)L.nby * (uint32_t)(z >> L.lz));
+                if (table[b + 1] == table[b]) *reinterpret_cast<float4*>(out + i) = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        } else {
+            for (size_t i = (size_t)blockIdx.x * kBrickThreads + t; i < cells; i += (size_t)gridDim.x * kBrickThreads) {
+                const int x = (int)(i % (size_t)G.dx), y = (int)((i / (size_t)G.dx) % (size_t)G.dy), z = (int)(i / ((size_t)G.dx * G.dy));
+                const uint32_t b = (uint32_t)(x >> L.lx) + (uint32_t)L.nbx * ((uint32_t)(y >> L.ly) + (uint32_t)L.nby * (uint32_t)(z >> L.lz));
+                if (table[b + 1] != table[b]) continue;
+                if (CH == 1) out[i] = 0.f; else reinterpret_cast<float4*>(out)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
             }
         }
     }
