@@ -441,8 +441,12 @@ class CorrelatedPhotonMapper(PhotonFrame):
 
     def __init__(self, *args, region: int = 8, max_incremental_percent: float = 100.0,
                  incremental_threshold_percent: float = 50.0, fix_exit_point: bool = False, tf_points=None,
-                 exact_update: bool = False, **kw):
+                 exact_update: bool = False, formulation: str = "fast", **kw):
         super().__init__(*args, **kw)
+        # full light volumes: "fast" = brick bin + one-launch gather (tolerance mode; the reference's own update is two atomic
+        # splats on top of it, within the same tolerance), "exact" = cell sort + sequential gather -- forced by exact_update,
+        # whose touched-brick re-gather must land on a full gather's bits
+        self.formulation = "exact" if exact_update else formulation
         torch, dev, ctx = self.torch, self.ctx.device, self.ctx
         self.region = region
         self.max_incremental_percent = max_incremental_percent
@@ -474,13 +478,22 @@ class CorrelatedPhotonMapper(PhotonFrame):
 
     def full_frame(self):
         """Light / everything changed: full trace, bin + gather, snapshot (tracercl.cpp:541-560)."""
-        self.frame()
+        self.trace()
+        self._full_light_volume()
         self.ctx.reset_importance(self.importance, 0, self.n)
         self.prev_photons = self.photons.clone()
         self.n_recomputed = -1
         self.remaining, self.remaining_offset = 0, 0
         self.last_path = "full"
         return self.light_volume
+
+    def _full_light_volume(self):
+        if self.formulation == "fast" and self.ctx.gather_fast_supported(self.grid, self.radius):
+            self.bin_fast()
+            self.gather_fast()
+        else:
+            self.bin()
+            self.gather()
 
     def set_transfer_function(self, tf_points, width=1024, moved=None):
         """A TF edit: updates the LUT and the importance grid (MinMaxUniformGrid3DImportanceCLProcessor)."""
@@ -596,8 +609,7 @@ class CorrelatedPhotonMapper(PhotonFrame):
             ctx.splat_selected(self.photons, idx, n, self.grid, self.radius, self.scale, 1.0, self.n, self.I, self.light_volume)
             self.last_path = "incremental"
         else:
-            self.bin()
-            self.gather()
+            self._full_light_volume()
             self.last_path = "full"
             if self.touched_mask is not None:
                 self.touched_mask.fill_(1)
