@@ -152,15 +152,16 @@ def load_library() -> C.CDLL:
         "cpm_volume_device_data": (vp, [vp, P(sz)]),
         "cpm_volume_download": (i32, [vp, vp, vp, vp]),
         # include/cpm/cpm_profile.h (measurement hooks)
-        "cpm_debug_set_step_counter": (None, [vp]),
-        "cpm_debug_set_gather_stamps": (None, [vp]),
-        "cpm_debug_force_voxel_gather": (None, [i32]),
-        "cpm_debug_set_gather_coop": (None, [i32]),
-        "cpm_debug_set_brick_streaming": (None, [i32]),
-        "cpm_debug_set_bin_fused": (None, [i32]),
-        "cpm_debug_set_sort_mode": (None, [i32]),
-        "cpm_debug_set_sort_items": (None, [i32]),
-        "cpm_debug_set_stream_wg_per_cu": (None, [i32]),
+        "cpm_debug_set_step_counter": (None, [vp, vp]),
+        "cpm_debug_set_gather_stamps": (None, [vp, vp]),
+        "cpm_debug_force_voxel_gather": (None, [vp, i32]),
+        "cpm_debug_set_gather_coop": (None, [vp, i32]),
+        "cpm_debug_set_brick_streaming": (None, [vp, i32]),
+        "cpm_debug_set_bin_fused": (None, [vp, i32]),
+        "cpm_debug_set_select_partition": (None, [vp, i32]),
+        "cpm_debug_set_sort_mode": (None, [vp, i32]),
+        "cpm_debug_set_sort_items": (None, [vp, i32]),
+        "cpm_debug_set_stream_wg_per_cu": (None, [vp, i32]),
         "cpm_profile_enable": (None, [vp, i32]),
         "cpm_profile_reset": (None, [vp]),
         "cpm_profile_collect": (i32, [vp]),
@@ -272,7 +273,7 @@ class Context:
 
     def set_step_counter(self, counter_tensor):
         """int64[1] device tensor that trace launches add their Woodcock iteration counts to (None = off)."""
-        self.lib.cpm_debug_set_step_counter(self._ptr(counter_tensor))
+        self.lib.cpm_debug_set_step_counter(self.h, self._ptr(counter_tensor))
 
     # -- RNG
     def seed_streams(self, state, gap=1 << 40):

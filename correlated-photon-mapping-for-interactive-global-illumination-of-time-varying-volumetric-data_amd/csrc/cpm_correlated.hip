@@ -186,8 +186,6 @@ bool rows_are_16_byte_aligned(const BrickVol& V) {
     const int es = V.dtype == CPM_U8 ? 1 : (V.dtype == CPM_U16 ? 2 : 4);
     return ((size_t)V.dx * es) % 16 == 0;
 }
-int g_brick_streaming = 1;  // test hook: 0 = always the per-brick kernels
-int g_select_partition = 1;  // test hook: 0 = cpm_select_changed through a radix pass over a 1-bit flag
 
 CPM_DEV float4 mix4(float4 a, float4 b, float t) {
     return make_float4(a.x + (b.x - a.x) * t, a.y + (b.y - a.y) * t, a.z + (b.z - a.z) * t, a.w + (b.w - a.w) * t);
@@ -492,8 +490,8 @@ int make_brick_vol(cpm_ctx* ctx, const cpm_volume* vol, int region, BrickVol& V)
 extern "C" {
 
 // test hook (include/cpm/cpm_profile.h): 1 (default) = streaming brick-row kernels where rows are 16-byte aligned
-void cpm_debug_set_brick_streaming(int on) { g_brick_streaming = on; }
-void cpm_debug_set_select_partition(int on) { g_select_partition = on; }
+void cpm_debug_set_brick_streaming(cpm_ctx* ctx, int on) { if (ctx) ctx->dbg.brick_streaming = on; }  // 0 = always the per-brick kernels
+void cpm_debug_set_select_partition(cpm_ctx* ctx, int on) { if (ctx) ctx->dbg.select_partition = on; }  // 0 = the radix-pass form
 
 int cpm_volume_minmax(cpm_ctx* ctx, const cpm_volume* vol, int region, uint16_t* minmax2, cpm_stream stream) {
     CPM_ENTER(ctx);
@@ -502,7 +500,7 @@ int cpm_volume_minmax(cpm_ctx* ctx, const cpm_volume* vol, int region, uint16_t*
     if (rc) return rc;
     CPM_REQUIRE(ctx, minmax2, "cpm_volume_minmax: null output");
     hipStream_t s = (hipStream_t)stream;
-    if (g_brick_streaming && rows_are_16_byte_aligned(V) && (size_t)V.ox * 8 <= 48 * 1024) {
+    if (ctx->dbg.brick_streaming && rows_are_16_byte_aligned(V) && (size_t)V.ox * 8 <= 48 * 1024) {
         const dim3 grid((unsigned)(V.oy * V.oz)), block(256);
         const size_t lds = (size_t)V.ox * 8;
         switch (V.dtype) {
@@ -528,7 +526,7 @@ int cpm_volume_difference(cpm_ctx* ctx, const cpm_volume* cur, const cpm_volume*
     CPM_REQUIRE(ctx, memcmp(cur->desc.dims, next->desc.dims, sizeof(cur->desc.dims)) == 0 && cur->desc.dtype == next->desc.dtype,
                 "cpm_volume_difference: volumes differ in shape or type");
     double range = V.dtype == CPM_U8 ? 255.0 : (V.dtype == CPM_U16 ? 65535.0 : 1.0);
-    if (g_brick_streaming && V.dtype != CPM_F32 && rows_are_16_byte_aligned(V) && (size_t)V.ox * 8 <= 48 * 1024) {
+    if (ctx->dbg.brick_streaming && V.dtype != CPM_F32 && rows_are_16_byte_aligned(V) && (size_t)V.ox * 8 <= 48 * 1024) {
         // (float volumes keep the per-brick kernel: their sum is defined in the reference's x-y-z order in double)
         const dim3 grid((unsigned)(V.oy * V.oz)), block(256);
         const size_t lds = (size_t)V.ox * 8;
@@ -644,7 +642,7 @@ int cpm_select_changed(cpm_ctx* ctx, const uint32_t* importances, size_t n, uint
         CPM_LAUNCH_CHECK(ctx, "select_single_kernel");
         return CPM_OK;
     }
-    if (g_select_partition) {
+    if (ctx->dbg.select_partition) {
         uint32_t num_tiles = (uint32_t)div_up((long long)n, 2048);
         if (num_tiles > (uint32_t)kPartMaxTiles) num_tiles = kPartMaxTiles;
         const uint32_t per_tile = (uint32_t)div_up(div_up((long long)n, num_tiles), 256) * 256u;

@@ -31,6 +31,16 @@ struct cpm_ctx {
     // valid flag -- a pure function of (theta, phi), evaluated once by the emitter so that the tracer's workgroups need not
     // (cpm_trace.hip; used only for samples whose (theta, phi) bit patterns match)
     float* dir_hint = nullptr;
+    // test / measurement hooks (include/cpm/cpm_profile.h: cpm_debug_*): per context, so that one context's experiment never
+    // changes what another context (another GPU, a concurrent frame) runs
+    struct {
+        unsigned long long* step_counter = nullptr;   // cpm_trace adds its Woodcock iteration counts
+        unsigned long long* gather_stamps = nullptr;  // cpm_gather writes per-brick wave stamps
+        int bin_fused = 1, gather_coop = 1, gather_force_voxel = 0;
+        int sort_mode = 0, sort_items = 0;
+        int brick_streaming = 1, select_partition = 1;
+        int stream_wg_per_cu = -1;
+    } dbg;
     size_t fast_hist_words = 0;  // cpm_bin_fast: size of the histograms whose all-zero state is established (0 = none)
     int fast_hist_parity = 0;    // which of the two (histogram, cursors) pairs the next cpm_bin_fast uses
     const void* fast_last_table = nullptr;  // the last cpm_bin_fast's table and radius: cpm_gather_fast refuses another radius for it
@@ -129,7 +139,7 @@ struct BinSink {
 // first_hist_done: pass 0's per-tile digit histogram is already in sort_first_hist()'s table
 int radix_sort(cpm_ctx* ctx, uint32_t* keys, uint32_t* vals, size_t n, int key_bits, hipStream_t s,
                uint32_t** res_keys, uint32_t** res_vals, const BinSink* sink, bool* sink_done, bool first_hist_done);
-int sort_items_for(size_t n);
+int sort_items_for(const cpm_ctx* ctx, size_t n);
 uint32_t* sort_first_hist(cpm_ctx* ctx, size_t n, int key_bits, uint32_t* num_tiles_out);
 const uint32_t* sort_last_digit_totals(cpm_ctx* ctx, size_t n);
 

@@ -1087,17 +1087,13 @@ int key_bits_for(uint32_t max_key) {  // bits needed to represent max_key
 extern "C" {
 
 // diagnostic hook (include/cpm/cpm_profile.h): 4 x u64 per 4x4x4 brick = (start, end [100 MHz ticks], records, XCC id)
-static unsigned long long* g_gather_stamps = nullptr;
-void cpm_debug_set_gather_stamps(unsigned long long* dev) { g_gather_stamps = dev; }
+void cpm_debug_set_gather_stamps(cpm_ctx* ctx, unsigned long long* dev) { if (ctx) ctx->dbg.gather_stamps = dev; }
 // test hook: 1 = voxel-major kernel for every gather, 2 = generic record-major kernel instead of the r < 1 specialisation
 // test / measurement hook: 1 (default) = the last sort pass finalises the bin, 0 = separate bin_finalize_kernel
-static int g_bin_fused = 1;
-void cpm_debug_set_bin_fused(int on) { g_bin_fused = on; }
+void cpm_debug_set_bin_fused(cpm_ctx* ctx, int on) { if (ctx) ctx->dbg.bin_fused = on; }
 // 1 (default): by launch size; 0: always one wave per brick; 2 / 4 / 8: always that many waves sharing as many bricks
-static int g_gather_coop = 1;
-void cpm_debug_set_gather_coop(int on) { g_gather_coop = on; }
-static int g_gather_force_voxel = 0;
-void cpm_debug_force_voxel_gather(int on) { g_gather_force_voxel = on; }
+void cpm_debug_set_gather_coop(cpm_ctx* ctx, int on) { if (ctx) ctx->dbg.gather_coop = on; }
+void cpm_debug_force_voxel_gather(cpm_ctx* ctx, int on) { if (ctx) ctx->dbg.gather_force_voxel = on; }
 
 int cpm_splat(cpm_ctx* ctx, const float* photons8, int total_photons, const cpm_grid_desc* grid, float radius,
               float scale, float* grid_out, cpm_stream stream) {
@@ -1185,9 +1181,9 @@ int cpm_bin(cpm_ctx* ctx, const float* photons8, int n, const cpm_grid_desc* gri
     bool finalized = false;
     if (n > 0) {
         const int kb = key_bits_for(cells);
-        const int items = cpm::sort_items_for((size_t)n);
+        const int items = cpm::sort_items_for(ctx, (size_t)n);
         uint32_t num_tiles = 0;
-        uint32_t* hist = g_bin_fused ? cpm::sort_first_hist(ctx, (size_t)n, kb, &num_tiles) : nullptr;
+        uint32_t* hist = ctx->dbg.bin_fused ? cpm::sort_first_hist(ctx, (size_t)n, kb, &num_tiles) : nullptr;
         const dim3 kgrid((unsigned)div_up(n, 256 * items));
         switch (items) {
             case 4: CPM_LAUNCH(ctx, bin_keys_kernel<4>, kgrid, dim3(256), 0, s, photons8, n, G, cells, keys, vals, cell_start, hist, num_tiles); break;
@@ -1200,7 +1196,7 @@ int cpm_bin(cpm_ctx* ctx, const float* photons8, int n, const cpm_grid_desc* gri
         BinSink sink;
         sink.photons = photons8; sink.channels = G.channels; sink.order = order; sink.sorted = sorted_pos_power;
         sink.cell_start = cell_start;
-        rc = cpm::radix_sort(ctx, keys, vals, (size_t)n, kb, s, &keys, &vals, g_bin_fused ? &sink : nullptr, &finalized, hist != nullptr);
+        rc = cpm::radix_sort(ctx, keys, vals, (size_t)n, kb, s, &keys, &vals, ctx->dbg.bin_fused ? &sink : nullptr, &finalized, hist != nullptr);
         if (rc) return rc;
     }
     // run starts -> table (preset to "none" by bin_keys_kernel), then the suffix-min scan turns it into cell starts
@@ -1283,7 +1279,7 @@ static int gather_impl(cpm_ctx* ctx, const float* sorted_pos_power, const uint32
     // Sharing bricks between the waves of a workgroup pays when the launch is small enough for a few heavy bricks to
     // set its length (128^3 grid, 32 K bricks: 80 -> 61 us); with 8x the bricks the hardware's own wave scheduling
     // balances the load and the turn-taking only costs (256^3 grid: 203 us one wave per brick, 224 us shared).
-    const bool coop = g_gather_coop > 1 || (g_gather_coop == 1 && (long long)bxn * byn * bzn <= 65536);
+    const bool coop = ctx->dbg.gather_coop > 1 || (ctx->dbg.gather_coop == 1 && (long long)bxn * byn * bzn <= 65536);
     // the tuned record-major kernels: one channel, halo of <= 2 cells, 2 to 4 candidate voxels per axis (r < 2 cells)
     // Measured on config 2's photons (128^3 grid): r = 0.87 / 1.0 / 1.2 / 1.45 / 1.73 cells -> tuned cooperative kernel
     // 64 / 105 / 118 / 147 / 390 us against 157 / 194 / 258 / 351 / 722 us for the better of the generic kernels.  At 4
@@ -1295,24 +1291,24 @@ static int gather_impl(cpm_ctx* ctx, const float* sorted_pos_power, const uint32
     // (mod3_ of the 3-candidate kernels is exact for coordinates below 2^15 only: longer axes take the generic kernels)
     const bool mod3_ok = cand_axis != 3 || (G.dx <= 32768 && G.dy <= 32768 && G.dz <= 32768);
     const bool tuned = (cand_axis <= 3 || (cand_axis == 4 && dense && G.channels == 1)) && Rx <= 2 && Ry <= 2 && Rz <= 2 &&
-                       g_gather_force_voxel == 0 && mod3_ok;
+                       ctx->dbg.gather_force_voxel == 0 && mod3_ok;
 #define CPM_COOP_LAUNCH(NB, MAXC, CH)                                                                                          \
     do {                                                                                                                       \
         const int zq = div_up(bzn, NB);                                                                                        \
         CPM_LAUNCH(ctx, (gather_coop_kernel<NB, MAXC, CH>), dim3((unsigned)bxn, (unsigned)byn, (unsigned)zq), dim3(64 * NB), 0, \
                    hs, sorted_pos_power, cell_start, G, radius, r2max, k, Rx, Ry, Rz, accumulate, bxn, byn, bzn, zq, grid_out, \
-                   g_gather_stamps, brick_mask);                                                                               \
+                   ctx->dbg.gather_stamps, brick_mask);                                                                               \
     } while (0)
 #define CPM_REC2_LAUNCH(MAXC, CH)                                                                                              \
     CPM_LAUNCH(ctx, (gather_records2_kernel<MAXC, CH>), dim3((unsigned)div_up(bxn, 4), (unsigned)byn, (unsigned)bzn), block, 0, \
                hs, sorted_pos_power, cell_start, G, radius, r2max, k, Rx, Ry, Rz, accumulate, bxn, byn, bzn, grid_out,         \
-               g_gather_stamps, brick_mask)
+               ctx->dbg.gather_stamps, brick_mask)
     if (tuned && coop) {
         if (G.channels == 4) {
             if (cand_axis <= 2) CPM_COOP_LAUNCH(4, 2, 4); else CPM_COOP_LAUNCH(4, 3, 4);
         } else if (cand_axis <= 2) {
-            if (g_gather_coop == 2) CPM_COOP_LAUNCH(2, 2, 1);
-            else if (g_gather_coop == 8) CPM_COOP_LAUNCH(8, 2, 1);
+            if (ctx->dbg.gather_coop == 2) CPM_COOP_LAUNCH(2, 2, 1);
+            else if (ctx->dbg.gather_coop == 8) CPM_COOP_LAUNCH(8, 2, 1);
             else CPM_COOP_LAUNCH(4, 2, 1);
         } else if (cand_axis == 3) {
             CPM_COOP_LAUNCH(4, 3, 1);
@@ -1332,18 +1328,18 @@ static int gather_impl(cpm_ctx* ctx, const float* sorted_pos_power, const uint32
     }
 #undef CPM_COOP_LAUNCH
 #undef CPM_REC2_LAUNCH
-    else if (G.channels == 1 && cand_axis <= 2 && g_gather_force_voxel != 1)
+    else if (G.channels == 1 && cand_axis <= 2 && ctx->dbg.gather_force_voxel != 1)
         CPM_LAUNCH(ctx, gather_records_kernel<2>, gridDim, block, 0, hs, sorted_pos_power, cell_start, G, radius, r2max, k, Rx, Ry, Rz,
-                   accumulate, bxn, byn, grid_out, g_gather_stamps, brick_mask);
-    else if (G.channels == 1 && cand_axis <= 3 && g_gather_force_voxel != 1)
+                   accumulate, bxn, byn, grid_out, ctx->dbg.gather_stamps, brick_mask);
+    else if (G.channels == 1 && cand_axis <= 3 && ctx->dbg.gather_force_voxel != 1)
         CPM_LAUNCH(ctx, gather_records_kernel<3>, gridDim, block, 0, hs, sorted_pos_power, cell_start, G, radius, r2max, k, Rx, Ry, Rz,
-                   accumulate, bxn, byn, grid_out, g_gather_stamps, brick_mask);
+                   accumulate, bxn, byn, grid_out, ctx->dbg.gather_stamps, brick_mask);
     else if (G.channels == 1)
         CPM_LAUNCH(ctx, (gather_voxel_kernel<1, 4>), gridDim, block, 0, hs, sorted_pos_power, cell_start, G, radius, r2max, k, Rx, Ry, Rz,
-                   accumulate, bxn, byn, grid_out, g_gather_stamps, brick_mask);
+                   accumulate, bxn, byn, grid_out, ctx->dbg.gather_stamps, brick_mask);
     else
         CPM_LAUNCH(ctx, (gather_voxel_kernel<4, 4>), gridDim, block, 0, hs, sorted_pos_power, cell_start, G, radius, r2max, k, Rx, Ry, Rz,
-                   accumulate, bxn, byn, grid_out, g_gather_stamps, brick_mask);
+                   accumulate, bxn, byn, grid_out, ctx->dbg.gather_stamps, brick_mask);
     CPM_LAUNCH_CHECK(ctx, "gather_kernel");
     return CPM_OK;
 }

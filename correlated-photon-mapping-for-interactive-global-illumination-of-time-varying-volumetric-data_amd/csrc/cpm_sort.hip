@@ -284,8 +284,6 @@ __global__ __launch_bounds__(kSortThreads) void radix_scatter_kernel(const uint3
 // 0 = hist + rowscan + scatter (default), 1 = onesweep (cpm_debug_set_sort_mode).  Measured on MI355X at 1 M pairs:
 // 20 us per pass for the three short launches vs 39 us for the single onesweep launch (+25 us for its
 // global histogram): with all ~1000 tiles in flight at once the per-digit look-back chain is long.
-static int g_sort_mode = 0;
-static int g_sort_items = 0;  // 0 = by size; 8 / 16 force the tile size (tuning hook)
 
 template <int ITEMS>
 static int sort_passes(cpm_ctx* ctx, uint32_t* keys, uint32_t* vals, uint32_t n, int key_bits, hipStream_t s,
@@ -293,7 +291,7 @@ static int sort_passes(cpm_ctx* ctx, uint32_t* keys, uint32_t* vals, uint32_t n,
     const uint32_t tile = kSortThreads * ITEMS;
     const uint32_t num_tiles = (n + tile - 1) / tile;
     const int passes = (key_bits + kRadixBits - 1) / kRadixBits;
-    const bool onesweep = g_sort_mode == 1 && passes <= 4;
+    const bool onesweep = ctx->dbg.sort_mode == 1 && passes <= 4;
     uint32_t* k2 = (uint32_t*)scratch(ctx, CPM_SCR_SORT_KEYS, (size_t)n * 4);
     uint32_t* v2 = vals ? (uint32_t*)scratch(ctx, CPM_SCR_SORT_VALS, (size_t)n * 4) : nullptr;
     // control block: [error | tickets[4] | pad | ghist[4][256] | status[passes][tiles][256]]  or  hist[256][tiles] + totals
@@ -355,17 +353,18 @@ static int sort_passes(cpm_ctx* ctx, uint32_t* keys, uint32_t* vals, uint32_t n,
 // keys/vals sorted in place; vals may be null (keys only)
 // keys per thread of a tile (256 threads) for n keys.  Measured at 1 M pairs, 22 key bits (3 passes + copy-back):
 // ITEMS 4: 73 us, 8: 61 us, 16: 70 us -- 2048-key tiles balance table size against workgroup count.
-int sort_items_for(size_t n) {
-    if (g_sort_items == 4 || g_sort_items == 8 || g_sort_items == 16) return g_sort_items;
+int sort_items_for(const cpm_ctx* ctx, size_t n) {
+    const int forced = ctx->dbg.sort_items;  // 0 = by size; 4 / 8 / 16 force the tile size (tuning hook)
+    if (forced == 4 || forced == 8 || forced == 16) return forced;
     return n <= (1u << 15) ? 4 : (n <= (1u << 23) ? 8 : 16);
 }
 
 // Where pass 0's per-tile digit histogram goes (digit-major [256][tiles]) when the caller counts it itself while
 // producing the keys (cpm_bin); nullptr when the sort will not use it (n <= 1, onesweep test mode).
 uint32_t* sort_first_hist(cpm_ctx* ctx, size_t n, int key_bits, uint32_t* num_tiles_out) {
-    if (n <= 1 || n >= (1ull << 31) || g_sort_mode == 1) return nullptr;
+    if (n <= 1 || n >= (1ull << 31) || ctx->dbg.sort_mode == 1) return nullptr;
     if (key_bits <= 0 || key_bits > 32) key_bits = 32;
-    const uint32_t tile = kSortThreads * (uint32_t)sort_items_for(n);
+    const uint32_t tile = kSortThreads * (uint32_t)sort_items_for(ctx, n);
     const uint32_t num_tiles = ((uint32_t)n + tile - 1) / tile;
     const size_t ctl_words = 8 + 4 * (size_t)kRadix + (size_t)num_tiles * kRadix + kRadix;  // as sort_passes lays it out
     uint32_t* ctl = (uint32_t*)scratch(ctx, CPM_SCR_SORT_HIST, ctl_words * 4);
@@ -377,8 +376,8 @@ uint32_t* sort_first_hist(cpm_ctx* ctx, size_t n, int key_bits, uint32_t* num_ti
 // After a sort of n > 1 keys in the default pass structure: digit_total[d] of the LAST pass (keys per digit value),
 // device memory inside the sort's scratch block, valid until the next sort on this context.
 const uint32_t* sort_last_digit_totals(cpm_ctx* ctx, size_t n) {
-    if (n <= 1 || g_sort_mode == 1) return nullptr;
-    const uint32_t tile = kSortThreads * (uint32_t)sort_items_for(n);
+    if (n <= 1 || ctx->dbg.sort_mode == 1) return nullptr;
+    const uint32_t tile = kSortThreads * (uint32_t)sort_items_for(ctx, n);
     const uint32_t num_tiles = ((uint32_t)n + tile - 1) / tile;
     const uint32_t* ctl = (const uint32_t*)ctx->scratch[CPM_SCR_SORT_HIST];
     return ctl ? ctl + 8 + 4 * kRadix + (size_t)num_tiles * kRadix : nullptr;
@@ -392,7 +391,7 @@ int radix_sort(cpm_ctx* ctx, uint32_t* keys, uint32_t* vals, size_t n, int key_b
     if (n <= 1) return CPM_OK;
     if (n >= (1ull << 31)) return set_error(ctx, CPM_ERR_INVALID_ARGUMENT, "radix_sort", "n must be < 2^31");
     if (key_bits <= 0 || key_bits > 32) key_bits = 32;
-    switch (sort_items_for(n)) {
+    switch (sort_items_for(ctx, n)) {
         case 4: return sort_passes<4>(ctx, keys, vals, (uint32_t)n, key_bits, s, res_keys, res_vals, sink, sink_done, first_hist_done);
         case 8: return sort_passes<8>(ctx, keys, vals, (uint32_t)n, key_bits, s, res_keys, res_vals, sink, sink_done, first_hist_done);
         default: return sort_passes<16>(ctx, keys, vals, (uint32_t)n, key_bits, s, res_keys, res_vals, sink, sink_done, first_hist_done);
@@ -404,8 +403,8 @@ int radix_sort(cpm_ctx* ctx, uint32_t* keys, uint32_t* vals, size_t n, int key_b
 extern "C" {
 
 // test / measurement hook (include/cpm/cpm_profile.h): 0 = hist + rowscan + scatter (default), 1 = onesweep passes
-void cpm_debug_set_sort_mode(int mode) { cpm::g_sort_mode = mode; }
-void cpm_debug_set_sort_items(int items) { cpm::g_sort_items = items; }
+void cpm_debug_set_sort_mode(cpm_ctx* ctx, int mode) { if (ctx) ctx->dbg.sort_mode = mode; }
+void cpm_debug_set_sort_items(cpm_ctx* ctx, int items) { if (ctx) ctx->dbg.sort_items = items; }
 
 int cpm_sort_pairs(cpm_ctx* ctx, uint32_t* keys, uint32_t* values, size_t n, int key_bits, cpm_stream stream) {
     CPM_ENTER(ctx);

@@ -117,10 +117,10 @@ __global__ __launch_bounds__(256) void volume_mix_kernel(const uint4* __restrict
 // stride streams at the copy ceiling (1 GiB operands: 6.0 TB/s, the same as torch.lerp; 8 workgroups
 // per CU grid-striding: 5.2 TB/s); launches of a few thousand workgroups (a 256^3 u8 volume) finish
 // sooner with 8 workgroups per CU looping twice (8.2 vs 9.6 us).
-int g_stream_wg_per_cu = -1;  // -1 = by size; >= 0 forces (tuning hook)
-int stream_grid(size_t vectors) {
+int stream_grid(const cpm_ctx* ctx, size_t vectors) {
     size_t blocks = (vectors + 255) / 256;
-    int per_cu = g_stream_wg_per_cu >= 0 ? g_stream_wg_per_cu : (blocks <= 16384 ? 8 : 0);
+    const int forced = ctx->dbg.stream_wg_per_cu;  // -1 = by size; >= 0 forces (tuning hook)
+    int per_cu = forced >= 0 ? forced : (blocks <= 16384 ? 8 : 0);
     const size_t cap = per_cu > 0 ? (size_t)256 * per_cu : (size_t)0x7fffffff;
     if (blocks > cap) blocks = cap;
     return blocks ? (int)blocks : 1;
@@ -131,7 +131,7 @@ int stream_grid(size_t vectors) {
 extern "C" {
 
 // tuning hook: workgroups per CU for the streaming kernels (0 = one vector per lane, no grid stride)
-void cpm_debug_set_stream_wg_per_cu(int n) { g_stream_wg_per_cu = n; }
+void cpm_debug_set_stream_wg_per_cu(cpm_ctx* ctx, int n) { if (ctx) ctx->dbg.stream_wg_per_cu = n; }
 
 int cpm_mix_buffers(cpm_ctx* ctx, const void* x, const void* y, float a, size_t n_elements, int type, void* out,
                     cpm_stream stream) {
@@ -141,7 +141,7 @@ int cpm_mix_buffers(cpm_ctx* ctx, const void* x, const void* y, float a, size_t 
     CPM_REQUIRE(ctx, x && y && out, "cpm_mix_buffers: null buffer");
     CPM_REQUIRE(ctx, (((uintptr_t)x | (uintptr_t)y | (uintptr_t)out) & 15u) == 0, "cpm_mix_buffers: buffers must be 16-byte aligned");
     hipStream_t s = (hipStream_t)stream;
-    int grid = stream_grid((n_elements >> 2) + 256);
+    int grid = stream_grid(ctx, (n_elements >> 2) + 256);
     if (type == CPM_MIX_F32) {
         CPM_LAUNCH(ctx, mix_f32_kernel, dim3(grid), dim3(256), 0, s, (const float*)x, (const float*)y, a, n_elements, (float*)out);
         CPM_LAUNCH_CHECK(ctx, "mix_f32_kernel");
@@ -164,7 +164,7 @@ int cpm_volume_mix(cpm_ctx* ctx, const cpm_volume* v0, const cpm_volume* v1, flo
     hipStream_t s = (hipStream_t)stream;
     const uint4 *x = (const uint4*)v0->voxels, *y = (const uint4*)v1->voxels;
     uint4* o = (uint4*)out->voxels;
-    int grid = stream_grid(n16);
+    int grid = stream_grid(ctx, n16);
     switch (v0->desc.dtype) {
         case CPM_U8: CPM_LAUNCH(ctx, volume_mix_kernel<CPM_U8>, dim3(grid), dim3(256), 0, s, x, y, weight, n16, o); break;
         case CPM_U16: CPM_LAUNCH(ctx, volume_mix_kernel<CPM_U16>, dim3(grid), dim3(256), 0, s, x, y, weight, n16, o); break;

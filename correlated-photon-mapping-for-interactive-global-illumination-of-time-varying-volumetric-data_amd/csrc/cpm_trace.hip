@@ -350,8 +350,7 @@ extern "C" {
 
 // statistics hook used by bench.py: when non-null, trace launches add their Woodcock
 // iteration counts to this device counter (not part of cpm.h's stable surface)
-static unsigned long long* g_step_counter = nullptr;
-void cpm_debug_set_step_counter(unsigned long long* dev_counter) { g_step_counter = dev_counter; }
+void cpm_debug_set_step_counter(cpm_ctx* ctx, unsigned long long* dev_counter) { if (ctx) ctx->dbg.step_counter = dev_counter; }
 
 int cpm_trace(cpm_ctx* ctx, const cpm_volume* vol, const cpm_tf* tf, const cpm_tf* tf_scattering, const float aabb[8],
               const cpm_trace_params* params, const float* light_samples8, const float* isect2,
@@ -402,7 +401,7 @@ int cpm_trace(cpm_ctx* ctx, const cpm_volume* vol, const cpm_tf* tf, const cpm_t
     A.n_threads = n_threads;
     A.rng = rng_state;
     A.photons = photons8;
-    A.step_counter = g_step_counter;
+    A.step_counter = ctx->dbg.step_counter;
     A.dir_hint = ctx->dir_hint;
 
     size_t lds = (size_t)tf->width * sizeof(float) * (A.tfs_alpha != A.tf_alpha ? 2 : 1);

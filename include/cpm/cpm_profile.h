@@ -19,27 +19,29 @@ int cpm_profile_collect(cpm_ctx* ctx);                 /* returns the number of 
 const char* cpm_profile_name(const cpm_ctx* ctx, int i);
 double cpm_profile_total_ms(const cpm_ctx* ctx, int i);
 long cpm_profile_calls(const cpm_ctx* ctx, int i);
+/* Test / measurement hooks: state of the context they are given (another context -- another GPU, a concurrent frame --
+ * is never affected). */
 /* when non-NULL, cpm_trace launches add their Woodcock iteration counts to *dev_counter */
-void cpm_debug_set_step_counter(unsigned long long* dev_counter);
+void cpm_debug_set_step_counter(cpm_ctx* ctx, unsigned long long* dev_counter);
 /* when non-NULL, cpm_gather launches write (start, end [100 MHz ticks], records, XCC id) per 4x4x4 brick */
-void cpm_debug_set_gather_stamps(unsigned long long* dev_stamps);
+void cpm_debug_set_gather_stamps(cpm_ctx* ctx, unsigned long long* dev_stamps);
 /* test hook: force the voxel-major gather kernel (default: record-major for 1 channel and r < 1.5 voxels) */
-void cpm_debug_force_voxel_gather(int on);
+void cpm_debug_force_voxel_gather(cpm_ctx* ctx, int on);
 /* r < 1 voxel gather: 1 (default) = cooperative kernel (4 waves share 4 bricks) up to 64 Ki bricks, one wave per brick
  * above; 0 = always one wave per brick; 2 / 4 / 8 = always cooperative with that many waves */
-void cpm_debug_set_gather_coop(int on);
+void cpm_debug_set_gather_coop(cpm_ctx* ctx, int on);
 /* cpm_volume_minmax / cpm_volume_difference: 1 (default) = streaming brick-row kernels, 0 = one wave per brick */
-void cpm_debug_set_brick_streaming(int on);
+void cpm_debug_set_brick_streaming(cpm_ctx* ctx, int on);
 /* cpm_select_changed: 1 (default) = two-launch stable partition, 0 = one radix pass over a 1-bit flag */
-void cpm_debug_set_select_partition(int on);
+void cpm_debug_set_select_partition(cpm_ctx* ctx, int on);
 /* cpm_bin: 1 (default) = the last radix pass writes order / records / run starts itself, 0 = separate finalize launch */
-void cpm_debug_set_bin_fused(int on);
+void cpm_debug_set_bin_fused(cpm_ctx* ctx, int on);
 /* test hook: radix sort pass structure: 0 = hist + rowscan + scatter (default), 1 = onesweep (one launch per pass) */
-void cpm_debug_set_sort_mode(int mode);
+void cpm_debug_set_sort_mode(cpm_ctx* ctx, int mode);
 /* radix tile: 0 = by size, 4 / 8 / 16 = keys per thread (256-thread tiles) */
-void cpm_debug_set_sort_items(int items);
+void cpm_debug_set_sort_items(cpm_ctx* ctx, int items);
 /* streaming kernels (temporal mix): workgroups per CU; 0 = one vector per lane, -1 = by size (default) */
-void cpm_debug_set_stream_wg_per_cu(int n);
+void cpm_debug_set_stream_wg_per_cu(cpm_ctx* ctx, int n);
 #ifdef __cplusplus
 }
 #endif

@@ -16,11 +16,11 @@ FLT_MAX = np.float32(3.402823466e+38)
                                                  ((10, 12, 40), np.uint16, 16), ((12, 20, 36), np.float32, 3),
                                                  ((8, 8, 16), np.uint8, 1)])
 def test_volume_minmax_and_difference(ctx, oracle, shape, dtype, region, streaming):
-    ctx.lib.cpm_debug_set_brick_streaming(streaming)
+    ctx.lib.cpm_debug_set_brick_streaming(ctx.h, streaming)
     try:
         _minmax_difference_case(ctx, oracle, shape, dtype, region)
     finally:
-        ctx.lib.cpm_debug_set_brick_streaming(1)
+        ctx.lib.cpm_debug_set_brick_streaming(ctx.h, 1)
 
 
 def _minmax_difference_case(ctx, oracle, shape, dtype, region):
@@ -292,11 +292,11 @@ def test_sharded_correlated_update(ctx, cpm):
 def test_select_changed(ctx, oracle, n, frac, partition):
     """cpm_select_changed: changed photons first, both parts in ascending index order, the importances untouched --
     through the two-launch partition (default; tiles grow past 2048 photons beyond 1024 tiles) and the radix-pass form."""
-    ctx.lib.cpm_debug_set_select_partition(partition)
+    ctx.lib.cpm_debug_set_select_partition(ctx.h, partition)
     try:
         _select_changed_case(ctx, oracle, n, frac)
     finally:
-        ctx.lib.cpm_debug_set_select_partition(1)
+        ctx.lib.cpm_debug_set_select_partition(ctx.h, 1)
 
 
 def _select_changed_case(ctx, oracle, n, frac):
@@ -351,11 +351,11 @@ def test_exact_incremental_update_is_bit_identical_to_a_full_frame(ctx, cpm, int
 def test_mark_touched_bricks_and_gather_bricks(ctx, oracle, cpm, radius_vox, force_voxel):
     """cpm_mark_touched_bricks marks exactly the bricks the selected photons' splat boxes overlap; cpm_gather_bricks
     rewrites exactly the marked bricks -- whichever gather kernel the radius (or the test hook) selects."""
-    ctx.lib.cpm_debug_force_voxel_gather(int(force_voxel))
+    ctx.lib.cpm_debug_force_voxel_gather(ctx.h, int(force_voxel))
     try:
         _mark_and_gather_bricks(ctx, oracle, cpm, radius_vox)
     finally:
-        ctx.lib.cpm_debug_force_voxel_gather(0)
+        ctx.lib.cpm_debug_force_voxel_gather(ctx.h, 0)
 
 
 def _mark_and_gather_bricks(ctx, oracle, cpm, radius_vox):

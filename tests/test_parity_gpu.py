@@ -403,22 +403,22 @@ def _random_photons(rng, n, sentinel_every=0, spread=1.0, rgb=False):
     ((26, 30, 21), 1, 1.9, 0),
 ])
 def test_bin_and_gather_bit_exact(ctx, oracle, cpm, dims, channels, radius_vox, force_voxel):
-    ctx.lib.cpm_debug_force_voxel_gather(int(force_voxel))
+    ctx.lib.cpm_debug_force_voxel_gather(ctx.h, int(force_voxel))
     try:
         _bin_and_gather_case(ctx, oracle, cpm, dims, channels, radius_vox)
     finally:
-        ctx.lib.cpm_debug_force_voxel_gather(0)
+        ctx.lib.cpm_debug_force_voxel_gather(ctx.h, 0)
 
 
 @pytest.mark.parametrize("dims,channels", [((32, 32, 32), 1), ((24, 40, 16), 4)])
 def test_bin_with_separate_finalize_launch(ctx, oracle, cpm, dims, channels):
     """cpm_bin's default lets the last radix pass write order / records / run starts; the separate
     bin_finalize_kernel (used for n == 1 and the onesweep test mode) produces the same bin."""
-    ctx.lib.cpm_debug_set_bin_fused(0)
+    ctx.lib.cpm_debug_set_bin_fused(ctx.h, 0)
     try:
         _bin_and_gather_case(ctx, oracle, cpm, dims, channels, 0.866)
     finally:
-        ctx.lib.cpm_debug_set_bin_fused(1)
+        ctx.lib.cpm_debug_set_bin_fused(ctx.h, 1)
 
 
 def _bin_and_gather_case(ctx, oracle, cpm, dims, channels, radius_vox):
@@ -477,13 +477,13 @@ def test_gather_one_wave_per_brick_kernel(ctx, oracle, cpm, dims, radius_vox):
     """The r < 1 voxel gather has two kernels with the same summation order: the cooperative one (default: a
     workgroup's four waves share four bricks, drains take turns) and one wave per brick."""
     for mode in (0, 2, 8, 4):
-        ctx.lib.cpm_debug_set_gather_coop(mode)
+        ctx.lib.cpm_debug_set_gather_coop(ctx.h, mode)
         try:
             _bin_and_gather_case(ctx, oracle, cpm, dims, 1, radius_vox)
             if mode in (0, 4) and radius_vox < 1.5:
                 _bin_and_gather_case(ctx, oracle, cpm, dims, 4, radius_vox)   # 4 x float32 light volume
         finally:
-            ctx.lib.cpm_debug_set_gather_coop(1)
+            ctx.lib.cpm_debug_set_gather_coop(ctx.h, 1)
 
 
 @pytest.mark.parametrize("mode", [1, 0])
@@ -509,14 +509,14 @@ def test_gather_dense_clusters(ctx, oracle, cpm, mode):
     assert np.array_equal(_n(order, np.uint32), o_order) and np.array_equal(_n(cs, np.uint32), o_cs)
     want = np.zeros(cells, np.float32)
     oracle.gather(o_srt, o_cs, n, og, radius, scale, want)
-    ctx.lib.cpm_debug_set_gather_coop(mode)
+    ctx.lib.cpm_debug_set_gather_coop(ctx.h, mode)
     try:
         for rep in range(3):
             out = torch.full((cells,), -3.0, dtype=torch.float32, device=ctx.device)
             ctx.gather(srt, cs, n, g, radius, scale, out)
             assert np.array_equal(bits(_n(out)), bits(want)), rep
     finally:
-        ctx.lib.cpm_debug_set_gather_coop(1)
+        ctx.lib.cpm_debug_set_gather_coop(ctx.h, 1)
 
 
 @pytest.mark.parametrize("n", [1, 2, 63, 64, 65, 255, 257, 2047, 2048, 2049, 32768, 32769, 70_001])
@@ -701,7 +701,7 @@ def test_sort_pass_structures(ctx, mode, n, bits_):
     keys[: n // 3] &= np.uint32(0xFF00FF)            # few distinct digits in some passes
     keys[n // 2:] = np.sort(keys[n // 2:])           # long presorted run: whole tiles with one digit
     vals = np.arange(n, dtype=np.uint32)
-    ctx.lib.cpm_debug_set_sort_mode(mode)
+    ctx.lib.cpm_debug_set_sort_mode(ctx.h, mode)
     try:
         for rep in range(3):                         # repeated: scratch reuse, look-back state reset
             kd, vd = _t(ctx, keys), _t(ctx, vals)
@@ -710,7 +710,7 @@ def test_sort_pass_structures(ctx, mode, n, bits_):
             assert np.array_equal(_n(vd, np.uint32), vals[order])
             assert np.array_equal(_n(kd, np.uint32), keys[order])
     finally:
-        ctx.lib.cpm_debug_set_sort_mode(0)
+        ctx.lib.cpm_debug_set_sort_mode(ctx.h, 0)
 
 
 def test_non_default_grid_matrices_are_refused_by_the_cell_sorted_path(ctx, cpm):

@@ -8,7 +8,7 @@ fr = P.PhotonFrame(ctx, S.heterogeneous_volume(256), S.workspace_tf(), 1024, (12
 for _ in range(3): fr.frame()
 torch.cuda.synchronize()
 for items in (4, 8, 16, 0):
-    ctx.lib.cpm_debug_set_sort_items(items)
+    ctx.lib.cpm_debug_set_sort_items(ctx.h, items)
     for _ in range(10): fr.frame()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -10,7 +10,7 @@ for vd, ns, gd in ((256, 1024, 128), (512, 2048, 256)):
     torch.cuda.synchronize()
     ref = None
     for mode in (0, 4, 1):
-        ctx.lib.cpm_debug_set_gather_coop(mode)
+        ctx.lib.cpm_debug_set_gather_coop(ctx.h, mode)
         for _ in range(5): fr.gather()
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -20,5 +20,5 @@ for vd, ns, gd in ((256, 1024, 128), (512, 2048, 256)):
         lv = fr.light_volume.clone()
         if ref is None: ref = lv
         print(f"volume {vd}^3 grid {gd}^3: coop {mode}: {e0.elapsed_time(e1) / 30 * 1000:.1f} us  same={bool(torch.equal(lv.view(torch.int32), ref.view(torch.int32)))}")
-    ctx.lib.cpm_debug_set_gather_coop(1)
+    ctx.lib.cpm_debug_set_gather_coop(ctx.h, 1)
     del fr

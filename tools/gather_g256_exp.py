@@ -7,7 +7,7 @@ fr = P.PhotonFrame(ctx, S.heterogeneous_volume(256), S.workspace_tf(), 1024, (25
 for _ in range(3): fr.frame()
 torch.cuda.synchronize()
 for name, force, coop in (("tuned coop4", 0, 4), ("tuned 1 wave/brick", 0, 0), ("voxel-major", 1, 1)):
-    ctx.lib.cpm_debug_force_voxel_gather(force); ctx.lib.cpm_debug_set_gather_coop(coop)
+    ctx.lib.cpm_debug_force_voxel_gather(ctx.h, force); ctx.lib.cpm_debug_set_gather_coop(ctx.h, coop)
     for _ in range(3): fr.gather()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -11,7 +11,7 @@ for rcells in (0.866, 1.0, 1.2, 1.45, 1.732):
     fr.radius = rcells / 128.0
     ref = None
     for name, force, coop in (("tuned coop", 0, 1), ("tuned 1 wave/brick", 0, 0), ("generic record-major", 2, 1), ("voxel-major", 1, 1)):
-        ctx.lib.cpm_debug_force_voxel_gather(force); ctx.lib.cpm_debug_set_gather_coop(coop)
+        ctx.lib.cpm_debug_force_voxel_gather(ctx.h, force); ctx.lib.cpm_debug_set_gather_coop(ctx.h, coop)
         for _ in range(3): fr.gather()
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -21,4 +21,4 @@ for rcells in (0.866, 1.0, 1.2, 1.45, 1.732):
         lv = fr.light_volume.clone()
         if ref is None: ref = lv
         print(f"r = {rcells} cells: {name:22s} {e0.elapsed_time(e1) / 10 * 1000:8.1f} us  same={bool(torch.equal(lv.view(torch.int32), ref.view(torch.int32)))}")
-ctx.lib.cpm_debug_force_voxel_gather(0); ctx.lib.cpm_debug_set_gather_coop(1)
+ctx.lib.cpm_debug_force_voxel_gather(ctx.h, 0); ctx.lib.cpm_debug_set_gather_coop(ctx.h, 1)

@@ -8,9 +8,9 @@ for _ in range(3): fr.frame()
 torch.cuda.synchronize()
 nb = 32*32*32
 st = torch.zeros((nb, 4), dtype=torch.int64, device='cuda')
-ctx.lib.cpm_debug_set_gather_stamps(ctypes.c_void_p(st.data_ptr()))
+ctx.lib.cpm_debug_set_gather_stamps(ctx.h, ctypes.c_void_p(st.data_ptr()))
 fr.gather(); torch.cuda.synchronize()
-ctx.lib.cpm_debug_set_gather_stamps(None)
+ctx.lib.cpm_debug_set_gather_stamps(ctx.h, None)
 a = st.cpu().numpy()
 t0 = a[:,0].min(); start = (a[:,0]-t0)/100.0; end = (a[:,1]-t0)/100.0; dur = end-start; rec = a[:,2] & 0xffffffff; mx = a[:,2] >> 32; xcc = a[:,3]
 print('kernel span us', end.max(), ' waves', nb)

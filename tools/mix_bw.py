@@ -14,7 +14,7 @@ def timeit(f, reps=20):
     return e0.elapsed_time(e1) / reps * 1e-3
 import ctypes
 for cap in (-1, 8, 0):
-  ctx.lib.cpm_debug_set_stream_wg_per_cu.argtypes=[ctypes.c_int]; ctx.lib.cpm_debug_set_stream_wg_per_cu(cap); print('wg/CU', cap)
+  ctx.lib.cpm_debug_set_stream_wg_per_cu.argtypes=[ctypes.c_void_p, ctypes.c_int]; ctx.lib.cpm_debug_set_stream_wg_per_cu(ctx.h, cap); print('wg/CU', cap)
   for n in (1 << 28,):
     x = torch.rand(n, device='cuda'); y = torch.rand(n, device='cuda'); o = torch.empty_like(x)
     t = timeit(lambda: ctx.mix_buffers(x, y, 0.3, o))
