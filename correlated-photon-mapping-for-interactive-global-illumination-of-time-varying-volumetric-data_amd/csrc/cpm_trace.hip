@@ -159,14 +159,11 @@ CPM_DEV f3 phase_sample(int type, float g, f3 w, float u1, float u2, float* pdf)
 }
 
 CPM_DEV void write_photon(float* photons, size_t id, f3 p, f3 pw, float th, float ph) {
-    // streaming stores: the record is not read again by this launch, and 32 MiB of them would push the volume's lines
-    // out of the L2s the Woodcock loop lives on (measured: 40.2 -> 38.5 us at config 2; non-temporal LOADS of the inputs
-    // cost 5 us -- the second 16-byte half of a light sample wants the line its first half fetched)
-    typedef float v4 __attribute__((ext_vector_type(4)));
-    v4* q = reinterpret_cast<v4*>(photons) + 2 * id;
-    const v4 a = { p.x, p.y, p.z, pw.x }, b = { pw.y, pw.z, th, ph };
-    __builtin_nontemporal_store(a, q);
-    __builtin_nontemporal_store(b, q + 1);
+    // (plain stores: with the tile-wise chunk order below a streaming hint no longer helps this launch, and the bin's count
+    // launch reads the records 0.8 us sooner without it -- 5 us sooner at 4 M photons)
+    float4* q = reinterpret_cast<float4*>(photons) + 2 * id;
+    q[0] = make_float4(p.x, p.y, p.z, pw.x);
+    q[1] = make_float4(pw.y, pw.z, th, ph);
 }
 
 template <int DT>
@@ -205,7 +202,18 @@ __global__ __launch_bounds__(256, 8) void trace_kernel(const TraceArgs A) {
     float* lut = lds;
     float* luts = lds;
 
-    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    // Which 256 samples: workgroups are dealt round-robin to the 8 XCDs (each with its own L2), so workgroup b does not take
+    // chunk b but a chunk of a 4096-sample tile t = b (mod 8): an XCD then works on whole tiles -- 4 rows of the emission
+    // lattice, whose rays share volume lines in that XCD's L2 -- instead of every 8th quarter row, and the tile it wrote is
+    // the tile the bin's workgroup t (same XCD) reads back.  Measured: 38.4 -> 37.0 us at config 2, 177 -> 159 us at 4 M
+    // photons / 512^3, 4-9 % on every transfer function tried (tools/trace_exp.py).  Interleaving tiles, not eighths of the
+    // lattice, keeps the XCDs balanced (round 1: contiguous eighths cost 701 -> 971 us on a sparse TF).
+    int chunk = blockIdx.x;
+    if (chunk < (int)(gridDim.x & ~127u)) {
+        const int x = chunk & 7, j = chunk >> 3;
+        chunk = ((((j >> 4) << 3) + x) << 4) + (j & 15);
+    }
+    const int gid = chunk * blockDim.x + threadIdx.x;
     int threadId = gid;
     bool live = gid < A.n_threads;
     if (live && A.recompute_indices) {  // -D PHOTON_RECOMPUTATION (photontracer.cl:97-106)
