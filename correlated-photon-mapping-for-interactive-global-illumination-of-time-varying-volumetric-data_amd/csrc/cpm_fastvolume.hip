@@ -521,6 +521,7 @@ int cpm_bin_fast(cpm_ctx* ctx, const float* photons8, int n, const cpm_grid_desc
     brick_shape(grid->dims, L);
     if (!brick_reach(G, radius, L) || tile_bytes_for(G, L) > 160 * 1024 - 1024)
         return set_error(ctx, CPM_ERR_UNSUPPORTED, "cpm_bin_fast", "radius beyond 2 voxels (or not positive): use cpm_bin + cpm_gather");
+    CPM_REQUIRE(ctx, (long long)n * copies_per_photon(L) < (1ll << 32), "cpm_bin_fast: record positions are 32-bit (n * 8 must stay below 2^32)");
     // scratch: two histograms (nb brick counts + 4 accumulators), used in turn -- a call's scatter launch zeroes the one the
     // NEXT call counts into -- then run_base: one row of nb offsets per tile of 4096 photons (written only where a tile has
     // copies, read as whole rows)
