@@ -307,7 +307,7 @@ def main():
     if correlated:
         n_steps = 32
         vols = [S.heterogeneous_volume(vdim, S.sequence_blob_center(t, n_steps)) for t in range(n_steps)]
-        dvols = [torch.from_numpy(v).to(ctx.device) for v in vols]  # resident: the upload is not part of the step
+        dvols = [ctx.volume_create(v) for v in vols]  # resident as volumes (as a sequence's VolumeCL representations are): no upload in the step
         fr = P.CorrelatedPhotonMapper(ctx, vols[0], tf, lattice, (gdim,) * 3, light_travel_direction=LIGHT_DIR,
                                       tf_points=list(S.WORKSPACE_TF_POINTS), photon_range=(lo, hi))
         fr.full_frame()
@@ -461,7 +461,7 @@ def main():
                                          "fraction_retraced": round(float(np.mean([r[1] for r in res[2:]])), 5),
                                          "includes": "TF upload, importance grid, per-photon importance, select, re-trace, +- splat, snapshot"}
             n_steps = 6
-            vols = [torch.from_numpy(S.heterogeneous_volume(vdim, S.sequence_blob_center(t, 32))).to(ctx.device) for t in range(n_steps)]
+            vols = [ctx.volume_create(S.heterogeneous_volume(vdim, S.sequence_blob_center(t, 32))) for t in range(n_steps)]
             cm.set_transfer_function(base_pts)
             cm.full_frame()
             res = []
@@ -475,7 +475,7 @@ def main():
             extras["config5_time_step"] = {"steps": n_steps - 1, "volume_step_ms": round(float(np.median([r[0] for r in res])), 4),
                                            "update_ms": round(float(np.median([r[1] for r in res])), 4),
                                            "fraction_retraced": round(float(np.mean([r[2] for r in res])), 5),
-                                           "note": "time steps resident on the device (upload of 16 MiB not included)"}
+                                           "note": "time steps resident on the device as volumes (no upload, copy or re-layout in the step)"}
             del cm, vols
         # S independent frames in flight on S streams (each frame owns its context, buffers and stream)
         if args.streams > 1:

@@ -61,6 +61,54 @@ ProfScope::~ProfScope() {
 
 using namespace cpm;
 
+// voxels -> row pairs (cpm_volume::row_pairs): a lane takes VEC elements of row (y, z) and of row (y + 1, z) (16 bytes each when
+// the row length allows) and writes them interleaved (32 bytes); COPY also writes the first row through to the volume's own
+// linear block (a device->device cpm_volume_update is this one launch instead of a copy plus a launch).
+template <typename T, int VEC, bool COPY>
+__global__ void __launch_bounds__(256) row_pairs_kernel(const T* __restrict__ src, T* __restrict__ linear, T* __restrict__ pairs,
+                                                         uint32_t dx, uint32_t dy, uint32_t chunks_per_row, uint32_t n_chunks) {
+    for (uint32_t c = blockIdx.x * 256u + threadIdx.x; c < n_chunks; c += gridDim.x * 256u) {
+        const uint32_t row = c / chunks_per_row, cx = (c - row * chunks_per_row) * VEC;
+        const uint32_t y = row % dy;
+        const size_t at = (size_t)row * dx + cx, up = (y + 1 < dy) ? at + dx : at;
+        T a[VEC], b[VEC], o[2 * VEC];
+        __builtin_memcpy(a, __builtin_assume_aligned(src + at, VEC * sizeof(T)), sizeof(a));
+        __builtin_memcpy(b, __builtin_assume_aligned(src + up, VEC * sizeof(T)), sizeof(b));
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) { o[2 * i] = a[i]; o[2 * i + 1] = b[i]; }
+        __builtin_memcpy(__builtin_assume_aligned(pairs + 2 * at, VEC * sizeof(T)), o, sizeof(o));
+        if (COPY) __builtin_memcpy(__builtin_assume_aligned(linear + at, VEC * sizeof(T)), a, sizeof(a));
+    }
+}
+
+template <typename T, bool COPY>
+static int launch_row_pairs(cpm_ctx* ctx, cpm_volume* vol, const void* src, hipStream_t s) {
+    const uint32_t dx = (uint32_t)vol->desc.dims[0], dy = (uint32_t)vol->desc.dims[1], dz = (uint32_t)vol->desc.dims[2];
+    constexpr int kVec = 16 / (int)sizeof(T);
+    const bool wide = dx % kVec == 0 && (reinterpret_cast<uintptr_t>(src) & 15u) == 0;
+    const unsigned long long chunks = (unsigned long long)(wide ? dx / kVec : dx) * dy * dz;
+    CPM_REQUIRE(ctx, chunks < (1ull << 32), "cpm_volume: too large");
+    const uint32_t grid = (uint32_t)std::min<unsigned long long>((chunks + 255) / 256, 256ull * 64);
+    if (wide)
+        CPM_LAUNCH(ctx, (row_pairs_kernel<T, kVec, COPY>), dim3(grid), dim3(256), 0, s, static_cast<const T*>(src), static_cast<T*>(vol->voxels),
+                   static_cast<T*>(vol->row_pairs), dx, dy, dx / kVec, (uint32_t)chunks);
+    else
+        CPM_LAUNCH(ctx, (row_pairs_kernel<T, 1, COPY>), dim3(grid), dim3(256), 0, s, static_cast<const T*>(src), static_cast<T*>(vol->voxels),
+                   static_cast<T*>(vol->row_pairs), dx, dy, dx, (uint32_t)chunks);
+    CPM_LAUNCH_CHECK(ctx, "row_pairs_kernel");
+    return CPM_OK;
+}
+
+namespace cpm {
+int build_row_pairs(cpm_ctx* ctx, cpm_volume* vol, const void* src, bool copy_linear, hipStream_t s) {
+    switch (vol->desc.dtype) {
+        case CPM_U8: return copy_linear ? launch_row_pairs<uint8_t, true>(ctx, vol, src, s) : launch_row_pairs<uint8_t, false>(ctx, vol, src, s);
+        case CPM_U16: return copy_linear ? launch_row_pairs<uint16_t, true>(ctx, vol, src, s) : launch_row_pairs<uint16_t, false>(ctx, vol, src, s);
+        default: return copy_linear ? launch_row_pairs<uint32_t, true>(ctx, vol, src, s) : launch_row_pairs<uint32_t, false>(ctx, vol, src, s);
+    }
+}
+}  // namespace cpm
+
 extern "C" {
 
 int cpm_abi_version(void) { return CPM_ABI_VERSION; }
@@ -196,6 +244,7 @@ float cpm_relative_irradiance_scale(double radius, double n_photons) {
 
 static size_t dtype_size(int dtype) { return dtype == CPM_U8 ? 1 : (dtype == CPM_U16 ? 2 : 4); }
 
+
 int cpm_volume_create(cpm_ctx* ctx, const cpm_volume_desc* desc, const void* voxels, int is_device,
                       cpm_stream stream, cpm_volume** out) {
     CPM_ENTER(ctx);
@@ -211,9 +260,14 @@ int cpm_volume_create(cpm_ctx* ctx, const cpm_volume_desc* desc, const void* vox
     v->bytes = (size_t)desc->dims[0] * desc->dims[1] * desc->dims[2] * dtype_size(desc->dtype);
     hipError_t e = hipMalloc(&v->voxels, v->bytes + 16);  // tail pad: paired x loads never leave the allocation
     if (e != hipSuccess) { delete v; return set_error(ctx, CPM_ERR_OUT_OF_MEMORY, "hipMalloc(volume)", hipGetErrorString(e)); }
+    e = hipMalloc(&v->row_pairs, 2 * v->bytes + 32);
+    if (e != hipSuccess) { (void)hipFree(v->voxels); delete v; return set_error(ctx, CPM_ERR_OUT_OF_MEMORY, "hipMalloc(volume row pairs)", hipGetErrorString(e)); }
     *out = v;
+    e = hipMemsetAsync((char*)v->row_pairs + 2 * v->bytes, 0, 32, (hipStream_t)stream);
+    if (e != hipSuccess) { cpm_volume_destroy(ctx, v); *out = nullptr; return set_error(ctx, CPM_ERR_DEVICE, "hipMemsetAsync(volume)", hipGetErrorString(e)); }
     if (!voxels) {  // storage for a volume produced on the device (cpm_volume_mix): zero-filled
         e = hipMemsetAsync(v->voxels, 0, v->bytes + 16, (hipStream_t)stream);
+        if (e == hipSuccess) e = hipMemsetAsync(v->row_pairs, 0, 2 * v->bytes, (hipStream_t)stream);
         if (e != hipSuccess) { cpm_volume_destroy(ctx, v); *out = nullptr; return set_error(ctx, CPM_ERR_DEVICE, "hipMemsetAsync(volume)", hipGetErrorString(e)); }
         return CPM_OK;
     }
@@ -227,10 +281,12 @@ int cpm_volume_update(cpm_ctx* ctx, cpm_volume* vol, const void* voxels, int is_
     CPM_REQUIRE(ctx, vol && voxels, "cpm_volume_update: null argument");
     hipStream_t s = (hipStream_t)stream;
     CPM_HIP_CHECK(ctx, hipMemsetAsync((char*)vol->voxels + vol->bytes, 0, 16, s));
-    CPM_HIP_CHECK(ctx, hipMemcpyAsync(vol->voxels, voxels, vol->bytes,
-                                      is_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, s));
+    if (is_device && voxels != vol->voxels && (reinterpret_cast<uintptr_t>(voxels) & 3u) == 0)
+        return build_row_pairs(ctx, vol, voxels, true, s);  // copy and row pairs in one launch
+    if (voxels != vol->voxels)
+        CPM_HIP_CHECK(ctx, hipMemcpyAsync(vol->voxels, voxels, vol->bytes, is_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, s));
     if (!is_device) CPM_HIP_CHECK(ctx, hipStreamSynchronize(s));  // caller may free the host buffer
-    return CPM_OK;
+    return build_row_pairs(ctx, vol, vol->voxels, false, s);
 }
 
 void* cpm_volume_device_data(const cpm_volume* vol, size_t* bytes) {
@@ -252,6 +308,7 @@ void cpm_volume_destroy(cpm_ctx* ctx, cpm_volume* vol) {
     (void)ctx;
     if (!vol) return;
     if (vol->voxels) (void)hipFree(vol->voxels);
+    if (vol->row_pairs) (void)hipFree(vol->row_pairs);
     delete vol;
 }
 

@@ -164,6 +164,7 @@ class PhotonFrame:
         self.ctx = ctx
         self.torch = torch
         dev = ctx.device
+        self._vol_is_own = not isinstance(volume, B.Volume)   # created here (set_volume may recycle it) or the caller's
         self.vol = volume if isinstance(volume, B.Volume) else ctx.volume_create(volume)
         self.tf = tf_rgba if isinstance(tf_rgba, B.TransferFunction) else ctx.tf_create(tf_rgba)
         nx, ny = (n_side, n_side) if isinstance(n_side, int) else n_side
@@ -508,15 +509,28 @@ class CorrelatedPhotonMapper(PhotonFrame):
         """A time step: new voxel data (same shape).  Computes, on the GPU, the per-brick mean |v_new - v_old|
         (CPU in the reference: DynamicVolumeDifferenceAnalysis), the new min/max bricks and the time-varying
         importance = difference x TF importance over the union of the old and new brick ranges
-        (classifyTimeVaryingMinMaxUniformGrid3DImportanceKernel), then swaps the volume in."""
+        (classifyTimeVaryingMinMaxUniformGrid3DImportanceKernel), then swaps the volume in.
+
+        `voxels`: an array / device tensor (copied into a volume this mapper owns), or a binding.Volume created
+        beforehand, which is adopted as it is -- the element of a sequence whose device representation already exists
+        (Inviwo caches a VolumeCL per sequence element the same way), no copy and no re-layout in the step."""
         ctx, torch = self.ctx, self.torch
         nb = self.importance_grid.numel()
-        if getattr(self, "_vol_next", None) is None:
-            self._vol_next = ctx.volume_create(voxels)
+        if getattr(self, "_minmax_next", None) is None:
             self._minmax_next = torch.zeros_like(self.minmax)
             self._diff = torch.zeros(nb, dtype=torch.float32, device=ctx.device)
+            self._vol_next = None            # a volume of this mapper's own to copy raw voxels into
+        adopted = isinstance(voxels, B.Volume)
+        if adopted:
+            if tuple(voxels.dims) != tuple(self.vol.dims) or int(voxels.desc.dtype) != int(self.vol.desc.dtype):
+                raise ValueError("set_volume: the time step differs from the current volume in shape or type")
+            nxt = voxels
+        elif self._vol_next is None:
+            nxt = ctx.volume_create(voxels)
         else:
-            self._vol_next.update(voxels)
+            nxt = self._vol_next
+            nxt.update(voxels)
+        self._vol_next = nxt
         ctx.volume_difference(self.vol, self._vol_next, self.region, self._diff)
         ctx.volume_minmax(self._vol_next, self.region, self._minmax_next)
         # TF unchanged: importance of a range = the TF itself (updateTransferFunctionData), zero-padded to [0, 1]
@@ -529,7 +543,10 @@ class CorrelatedPhotonMapper(PhotonFrame):
             pos.append(1.0); col.append(col[-1])
         ctx.importance_tf(self._minmax_next, nb, np.asarray(pos, np.float32), np.asarray(col, np.float32), self.importance_grid,
                           prev_minmax=self.minmax, volume_diff=self._diff)
-        self.vol, self._vol_next = self._vol_next, self.vol
+        # swap in; the volume swapped out is reused for the next raw-voxel step only if this mapper created it
+        previous, previous_is_own = self.vol, self._vol_is_own
+        self.vol, self._vol_is_own = nxt, not adopted
+        self._vol_next = previous if previous_is_own else None
         self.minmax, self._minmax_next = self._minmax_next, self.minmax
 
     def correlated_update(self):

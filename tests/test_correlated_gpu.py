@@ -243,6 +243,32 @@ def test_time_varying_sequence(ctx, oracle, cpm):
     assert all(0 < f < 1 for f in fractions), fractions
 
 
+def test_time_steps_as_resident_volumes(ctx, cpm):
+    """set_volume adopts a volume created beforehand (a sequence kept on the device) without copying it: same importance
+    grid, same selection, same photons and light volume as stepping with raw voxels; and raw-voxel steps after adopted
+    ones never write into a volume the caller owns."""
+    S, P = cpm.synthetic, cpm.pipeline
+    tfp = [(0.0, 1, 1, 1, 0.0), (0.55, 1, 0.5, 0.2, 0.0), (0.7, 0.6, 0.3, 0.1, 0.3), (1.0, 0.1, 0.6, 0.7, 0.6)]
+    vols = [S.heterogeneous_volume(64, S.sequence_blob_center(t * 10, 32)) for t in range(4)]
+    kw = dict(light_travel_direction=(0.3, 0.5, -1.0), tf_points=tfp, incremental_threshold_percent=100.0)
+    raw = P.CorrelatedPhotonMapper(ctx, vols[0], S.tf_from_points(tfp), 128, (32, 32, 32), **kw)
+    resident = [ctx.volume_create(v) for v in vols]
+    ado = P.CorrelatedPhotonMapper(ctx, resident[0], S.tf_from_points(tfp), 128, (32, 32, 32), **kw)
+    raw.full_frame(); ado.full_frame()
+    for t in (1, 2, 3, 1):
+        raw.set_volume(vols[t])
+        ado.set_volume(resident[t] if t != 3 else vols[3])   # a raw-voxel step in between: copied into a volume of the mapper's own
+        assert np.array_equal(bits(_n(raw.importance_grid)), bits(_n(ado.importance_grid)))
+        assert raw.correlated_update() == ado.correlated_update()
+        assert np.array_equal(bits(_n(raw.photons)), bits(_n(ado.photons)))
+        a, b = _n(raw.light_volume), _n(ado.light_volume)   # +- atomic splat of the update: order-dependent sums
+        assert np.allclose(a, b, rtol=1e-4, atol=1e-5 * float(np.abs(a).max()))
+    for v, h in zip(vols, resident):
+        assert np.array_equal(h.download(), v)
+    with pytest.raises(ValueError):
+        ado.set_volume(ctx.volume_create(S.heterogeneous_volume(32)))
+
+
 def test_sharded_correlated_update(ctx, cpm):
     """Multi-GPU semantics of the correlated path (per-shard selection), two shards emulated on one
     GPU: every rank scores, selects and re-traces its own photon range; the union of the selections and the

@@ -137,7 +137,7 @@ def test_point_light_and_mesh_intersection(ctx, oracle, cpm):
 # ----------------------------------------------------------------------------- trace
 
 def _trace_case(ctx, oracle, cpm, volume, tf, n_side, direction, max_inter=1, flags=0, point=None,
-                shading=0, g=0.0, tfs=None, fmt=(0.0, 0.0)):
+                shading=0, g=0.0, tfs=None, fmt=(0.0, 0.0), make_volume=None):
     from oracle_binding import OTraceParams
     B = cpm.binding
     n = n_side * n_side
@@ -156,7 +156,7 @@ def _trace_case(ctx, oracle, cpm, volume, tf, n_side, direction, max_inter=1, fl
     code = {np.dtype(np.uint8): 0, np.dtype(np.uint16): 1, np.dtype(np.float32): 2}[volume.dtype]
     desc = B.default_volume_desc(volume.shape[::-1], code)
     desc.format_scaling, desc.format_offset = fmt
-    vol = ctx.volume_create(volume, desc)
+    vol = ctx.volume_create(volume, desc) if make_volume is None else make_volume(volume, desc)
     tfh = ctx.tf_create(tf)
     tfsh = ctx.tf_create(tfs) if tfs is not None else None
     p = B.TraceParams()
@@ -250,6 +250,39 @@ def test_trace_nonpow2_volume_and_small_tf(ctx, oracle, cpm):
     vol = rng.integers(0, 256, (19, 33, 50), dtype=np.uint8)  # [z, y, x]
     tf = cpm.synthetic.tf_from_points([(0, 1, 1, 1, 0.02), (1, 1, 1, 1, 0.6)], width=17)
     got, want, *_ = _trace_case(ctx, oracle, cpm, vol, tf, 100, (0.2, -0.4, 1.0))
+    assert np.array_equal(bits(got), bits(want))
+
+
+@pytest.mark.parametrize("shape", [(19, 33, 50), (24, 40, 64), (1, 21, 48), (17, 1, 32), (2, 2, 2)])  # [z, y, x]
+@pytest.mark.parametrize("how", ["host update", "device update", "device update, unaligned source", "mix"])
+def test_trace_reads_what_every_volume_writer_left(ctx, oracle, cpm, shape, how):
+    """The tracer samples the volume's row-pair copy (one fetch = a 2 x 2 footprint); every writer of a volume --
+    create, update from the host or from the device (one fused launch, or copy + re-layout for a source that is not
+    4-byte aligned), volume_mix -- rebuilds it, for row lengths on and off the 16-byte path and for one-row / one-slice
+    volumes (the y + 1 / z + 1 clamps)."""
+    torch = ctx.torch
+    rng = np.random.default_rng(sum(shape) + len(how))
+    first = rng.integers(0, 256, shape, dtype=np.uint8)
+    vol = rng.integers(0, 256, shape, dtype=np.uint8)
+    tf = cpm.synthetic.tf_from_points([(0, 1, 1, 1, 0.05), (1, 1, 1, 1, 0.7)], width=64)
+
+    def make(volume, desc):
+        h = ctx.volume_create(first, desc)
+        if how == "host update":
+            h.update(volume)
+        elif how == "device update":
+            h.update(torch.from_numpy(volume).to(ctx.device))
+        elif how == "device update, unaligned source":
+            flat = torch.zeros(volume.size + 1, dtype=torch.uint8, device=ctx.device)
+            flat[1:] = torch.from_numpy(volume.reshape(-1)).to(ctx.device)
+            h.update(flat[1:])
+        else:  # weight 1 -> the mixed volume is `volume` exactly (test_volume_mix); written by the mix kernel
+            other = ctx.volume_create(volume, desc)
+            ctx.volume_mix(ctx.volume_create(first, desc), other, 1.0, h)
+        assert np.array_equal(h.download(), volume)
+        return h
+
+    got, want, *_ = _trace_case(ctx, oracle, cpm, vol, tf, 64, (0.2, -0.4, 1.0), make_volume=make)
     assert np.array_equal(bits(got), bits(want))
 
 
