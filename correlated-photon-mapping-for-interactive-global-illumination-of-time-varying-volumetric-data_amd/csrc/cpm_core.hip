@@ -61,28 +61,33 @@ ProfScope::~ProfScope() {
 
 using namespace cpm;
 
-// voxels -> row pairs (cpm_volume::row_pairs): a lane takes VEC elements of row (y, z) and of row (y + 1, z) (16 bytes each when
-// the row length allows) and writes them interleaved (32 bytes); COPY also writes the first row through to the volume's own
-// linear block (a device->device cpm_volume_update is this one launch instead of a copy plus a launch).
+// voxels -> quads (cpm_volume::quads): a lane takes VEC elements of rows (y, z), (y + 1, z), (y, z + 1), (y + 1, z + 1) (16 bytes each
+// when the row length allows) and writes them interleaved (64 bytes); COPY also writes the first row through to the volume's
+// own linear block (a device->device cpm_volume_update is this one launch instead of a copy plus a launch).
 template <typename T, int VEC, bool COPY>
-__global__ void __launch_bounds__(256) row_pairs_kernel(const T* __restrict__ src, T* __restrict__ linear, T* __restrict__ pairs,
-                                                         uint32_t dx, uint32_t dy, uint32_t chunks_per_row, uint32_t n_chunks) {
+__global__ void __launch_bounds__(256) quads_kernel(const T* __restrict__ src, T* __restrict__ linear, T* __restrict__ quads,
+                                                     uint32_t dx, uint32_t dy, uint32_t dz, uint32_t chunks_per_row, uint32_t n_chunks) {
+    const size_t slice = (size_t)dx * dy;
     for (uint32_t c = blockIdx.x * 256u + threadIdx.x; c < n_chunks; c += gridDim.x * 256u) {
         const uint32_t row = c / chunks_per_row, cx = (c - row * chunks_per_row) * VEC;
-        const uint32_t y = row % dy;
-        const size_t at = (size_t)row * dx + cx, up = (y + 1 < dy) ? at + dx : at;
-        T a[VEC], b[VEC], o[2 * VEC];
-        __builtin_memcpy(a, __builtin_assume_aligned(src + at, VEC * sizeof(T)), sizeof(a));
-        __builtin_memcpy(b, __builtin_assume_aligned(src + up, VEC * sizeof(T)), sizeof(b));
+        const uint32_t z = row / dy, y = row - z * dy;
+        const size_t at = (size_t)row * dx + cx, up = (y + 1 < dy) ? dx : 0, back = (z + 1 < dz) ? slice : 0;
+        T r[4][VEC], o[4 * VEC];
+        __builtin_memcpy(r[0], __builtin_assume_aligned(src + at, VEC * sizeof(T)), sizeof(r[0]));
+        __builtin_memcpy(r[1], __builtin_assume_aligned(src + at + up, VEC * sizeof(T)), sizeof(r[0]));
+        __builtin_memcpy(r[2], __builtin_assume_aligned(src + at + back, VEC * sizeof(T)), sizeof(r[0]));
+        __builtin_memcpy(r[3], __builtin_assume_aligned(src + at + up + back, VEC * sizeof(T)), sizeof(r[0]));
 #pragma unroll
-        for (int i = 0; i < VEC; ++i) { o[2 * i] = a[i]; o[2 * i + 1] = b[i]; }
-        __builtin_memcpy(__builtin_assume_aligned(pairs + 2 * at, VEC * sizeof(T)), o, sizeof(o));
-        if (COPY) __builtin_memcpy(__builtin_assume_aligned(linear + at, VEC * sizeof(T)), a, sizeof(a));
+        for (int i = 0; i < VEC; ++i)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) o[4 * i + k] = r[k][i];
+        __builtin_memcpy(__builtin_assume_aligned(quads + 4 * at, VEC * sizeof(T)), o, sizeof(o));
+        if (COPY) __builtin_memcpy(__builtin_assume_aligned(linear + at, VEC * sizeof(T)), r[0], sizeof(r[0]));
     }
 }
 
 template <typename T, bool COPY>
-static int launch_row_pairs(cpm_ctx* ctx, cpm_volume* vol, const void* src, hipStream_t s) {
+static int launch_quads(cpm_ctx* ctx, cpm_volume* vol, const void* src, hipStream_t s) {
     const uint32_t dx = (uint32_t)vol->desc.dims[0], dy = (uint32_t)vol->desc.dims[1], dz = (uint32_t)vol->desc.dims[2];
     constexpr int kVec = 16 / (int)sizeof(T);
     const bool wide = dx % kVec == 0 && (reinterpret_cast<uintptr_t>(src) & 15u) == 0;
@@ -90,21 +95,21 @@ static int launch_row_pairs(cpm_ctx* ctx, cpm_volume* vol, const void* src, hipS
     CPM_REQUIRE(ctx, chunks < (1ull << 32), "cpm_volume: too large");
     const uint32_t grid = (uint32_t)std::min<unsigned long long>((chunks + 255) / 256, 256ull * 64);
     if (wide)
-        CPM_LAUNCH(ctx, (row_pairs_kernel<T, kVec, COPY>), dim3(grid), dim3(256), 0, s, static_cast<const T*>(src), static_cast<T*>(vol->voxels),
-                   static_cast<T*>(vol->row_pairs), dx, dy, dx / kVec, (uint32_t)chunks);
+        CPM_LAUNCH(ctx, (quads_kernel<T, kVec, COPY>), dim3(grid), dim3(256), 0, s, static_cast<const T*>(src), static_cast<T*>(vol->voxels),
+                   static_cast<T*>(vol->quads), dx, dy, dz, dx / kVec, (uint32_t)chunks);
     else
-        CPM_LAUNCH(ctx, (row_pairs_kernel<T, 1, COPY>), dim3(grid), dim3(256), 0, s, static_cast<const T*>(src), static_cast<T*>(vol->voxels),
-                   static_cast<T*>(vol->row_pairs), dx, dy, dx, (uint32_t)chunks);
-    CPM_LAUNCH_CHECK(ctx, "row_pairs_kernel");
+        CPM_LAUNCH(ctx, (quads_kernel<T, 1, COPY>), dim3(grid), dim3(256), 0, s, static_cast<const T*>(src), static_cast<T*>(vol->voxels),
+                   static_cast<T*>(vol->quads), dx, dy, dz, dx, (uint32_t)chunks);
+    CPM_LAUNCH_CHECK(ctx, "quads_kernel");
     return CPM_OK;
 }
 
 namespace cpm {
-int build_row_pairs(cpm_ctx* ctx, cpm_volume* vol, const void* src, bool copy_linear, hipStream_t s) {
+int build_quads(cpm_ctx* ctx, cpm_volume* vol, const void* src, bool copy_linear, hipStream_t s) {
     switch (vol->desc.dtype) {
-        case CPM_U8: return copy_linear ? launch_row_pairs<uint8_t, true>(ctx, vol, src, s) : launch_row_pairs<uint8_t, false>(ctx, vol, src, s);
-        case CPM_U16: return copy_linear ? launch_row_pairs<uint16_t, true>(ctx, vol, src, s) : launch_row_pairs<uint16_t, false>(ctx, vol, src, s);
-        default: return copy_linear ? launch_row_pairs<uint32_t, true>(ctx, vol, src, s) : launch_row_pairs<uint32_t, false>(ctx, vol, src, s);
+        case CPM_U8: return copy_linear ? launch_quads<uint8_t, true>(ctx, vol, src, s) : launch_quads<uint8_t, false>(ctx, vol, src, s);
+        case CPM_U16: return copy_linear ? launch_quads<uint16_t, true>(ctx, vol, src, s) : launch_quads<uint16_t, false>(ctx, vol, src, s);
+        default: return copy_linear ? launch_quads<uint32_t, true>(ctx, vol, src, s) : launch_quads<uint32_t, false>(ctx, vol, src, s);
     }
 }
 }  // namespace cpm
@@ -260,14 +265,14 @@ int cpm_volume_create(cpm_ctx* ctx, const cpm_volume_desc* desc, const void* vox
     v->bytes = (size_t)desc->dims[0] * desc->dims[1] * desc->dims[2] * dtype_size(desc->dtype);
     hipError_t e = hipMalloc(&v->voxels, v->bytes + 16);  // tail pad: paired x loads never leave the allocation
     if (e != hipSuccess) { delete v; return set_error(ctx, CPM_ERR_OUT_OF_MEMORY, "hipMalloc(volume)", hipGetErrorString(e)); }
-    e = hipMalloc(&v->row_pairs, 2 * v->bytes + 32);
-    if (e != hipSuccess) { (void)hipFree(v->voxels); delete v; return set_error(ctx, CPM_ERR_OUT_OF_MEMORY, "hipMalloc(volume row pairs)", hipGetErrorString(e)); }
+    e = hipMalloc(&v->quads, 4 * v->bytes + 64);
+    if (e != hipSuccess) { (void)hipFree(v->voxels); delete v; return set_error(ctx, CPM_ERR_OUT_OF_MEMORY, "hipMalloc(volume quads)", hipGetErrorString(e)); }
     *out = v;
-    e = hipMemsetAsync((char*)v->row_pairs + 2 * v->bytes, 0, 32, (hipStream_t)stream);
+    e = hipMemsetAsync((char*)v->quads + 4 * v->bytes, 0, 64, (hipStream_t)stream);
     if (e != hipSuccess) { cpm_volume_destroy(ctx, v); *out = nullptr; return set_error(ctx, CPM_ERR_DEVICE, "hipMemsetAsync(volume)", hipGetErrorString(e)); }
     if (!voxels) {  // storage for a volume produced on the device (cpm_volume_mix): zero-filled
         e = hipMemsetAsync(v->voxels, 0, v->bytes + 16, (hipStream_t)stream);
-        if (e == hipSuccess) e = hipMemsetAsync(v->row_pairs, 0, 2 * v->bytes, (hipStream_t)stream);
+        if (e == hipSuccess) e = hipMemsetAsync(v->quads, 0, 4 * v->bytes, (hipStream_t)stream);
         if (e != hipSuccess) { cpm_volume_destroy(ctx, v); *out = nullptr; return set_error(ctx, CPM_ERR_DEVICE, "hipMemsetAsync(volume)", hipGetErrorString(e)); }
         return CPM_OK;
     }
@@ -282,11 +287,11 @@ int cpm_volume_update(cpm_ctx* ctx, cpm_volume* vol, const void* voxels, int is_
     hipStream_t s = (hipStream_t)stream;
     CPM_HIP_CHECK(ctx, hipMemsetAsync((char*)vol->voxels + vol->bytes, 0, 16, s));
     if (is_device && voxels != vol->voxels && (reinterpret_cast<uintptr_t>(voxels) & 3u) == 0)
-        return build_row_pairs(ctx, vol, voxels, true, s);  // copy and row pairs in one launch
+        return build_quads(ctx, vol, voxels, true, s);  // copy and quads in one launch
     if (voxels != vol->voxels)
         CPM_HIP_CHECK(ctx, hipMemcpyAsync(vol->voxels, voxels, vol->bytes, is_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, s));
     if (!is_device) CPM_HIP_CHECK(ctx, hipStreamSynchronize(s));  // caller may free the host buffer
-    return build_row_pairs(ctx, vol, vol->voxels, false, s);
+    return build_quads(ctx, vol, vol->voxels, false, s);
 }
 
 void* cpm_volume_device_data(const cpm_volume* vol, size_t* bytes) {
@@ -308,7 +313,7 @@ void cpm_volume_destroy(cpm_ctx* ctx, cpm_volume* vol) {
     (void)ctx;
     if (!vol) return;
     if (vol->voxels) (void)hipFree(vol->voxels);
-    if (vol->row_pairs) (void)hipFree(vol->row_pairs);
+    if (vol->quads) (void)hipFree(vol->quads);
     delete vol;
 }
 

@@ -62,10 +62,10 @@ enum {
 struct cpm_volume {
     cpm_volume_desc desc;
     void* voxels = nullptr;  // device, x fastest, padded by 16 bytes
-    // the tracer's copy: element (x, y, z) = { v(x, y, z), v(x, min(y + 1, dim.y - 1), z) }, x fastest -- the 2 x 2 (x, y)
-    // footprint of a trilinear fetch is ONE load of two neighbouring elements (cpm_trace.hip); 2 * bytes + 32, rebuilt
-    // by everything that writes `voxels` (cpm_volume_update, cpm_volume_mix)
-    void* row_pairs = nullptr;
+    // the tracer's copy: element (x, y, z) = { v(x, y, z), v(x, y', z), v(x, y, z'), v(x, y', z') } with y' = min(y + 1, dim.y - 1),
+    // z' likewise, x fastest -- the 2 x 2 x 2 footprint of a trilinear fetch is ONE load of two neighbouring elements
+    // (cpm_trace.hip); 4 * bytes + 64, rebuilt by everything that writes `voxels` (cpm_volume_update, cpm_volume_mix)
+    void* quads = nullptr;
     size_t bytes = 0;
 };
 
@@ -80,9 +80,9 @@ namespace cpm {
 int set_error(cpm_ctx* ctx, int status, const char* what, const char* detail);
 void* scratch(cpm_ctx* ctx, int slot, size_t bytes);  // nullptr on failure (error set)
 bool affine_from_matrix(const float m[16], Affine& out);
-// rebuild vol->row_pairs from `src` (a device block laid out like vol->voxels; vol->voxels itself, or the source of a
+// rebuild vol->quads from `src` (a device block laid out like vol->voxels; vol->voxels itself, or the source of a
 // device->device update, which is then also copied into vol->voxels by the same launch)
-int build_row_pairs(cpm_ctx* ctx, cpm_volume* vol, const void* src, bool copy_linear, hipStream_t stream);
+int build_quads(cpm_ctx* ctx, cpm_volume* vol, const void* src, bool copy_linear, hipStream_t stream);
 
 #define CPM_HIP_CHECK(ctx, expr)                                                        \
     do {                                                                                \

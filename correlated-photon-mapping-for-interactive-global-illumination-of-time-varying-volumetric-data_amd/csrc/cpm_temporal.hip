@@ -171,7 +171,7 @@ int cpm_volume_mix(cpm_ctx* ctx, const cpm_volume* v0, const cpm_volume* v1, flo
         default: CPM_LAUNCH(ctx, volume_mix_kernel<CPM_F32>, dim3(grid), dim3(256), 0, s, x, y, weight, n16, o); break;
     }
     CPM_LAUNCH_CHECK(ctx, "volume_mix_kernel");
-    return build_row_pairs(ctx, out, out->voxels, false, s);  // the tracer's copy of the mixed volume
+    return build_quads(ctx, out, out->voxels, false, s);  // the tracer's copy of the mixed volume
 }
 
 }  // extern "C"

@@ -121,14 +121,14 @@ void cpm_volume_desc_default(cpm_volume_desc* desc, const int32_t dims[3], int32
 int cpm_volume_create(cpm_ctx* ctx, const cpm_volume_desc* desc, const void* voxels,
                       int voxels_is_device, cpm_stream stream, cpm_volume** out);
 /* Replace the voxel data (time-varying sequences; same desc).  From a device source this is one launch (copy +
- * the tracer's row-paired copy, 4 x the volume's bytes of traffic); a sequence that stays on the device is better
+ * the tracer's footprint copy, 6 x the volume's bytes of traffic); a sequence that stays on the device is better
  * kept as one cpm_volume per time step, which costs nothing per step. */
 int cpm_volume_update(cpm_ctx* ctx, cpm_volume* vol, const void* voxels, int voxels_is_device,
                       cpm_stream stream);
 void cpm_volume_destroy(cpm_ctx* ctx, cpm_volume* vol);
 /* Device address and byte size of the voxel block, READ-ONLY (for consumers that read a volume produced on
- * the device, e.g. cpm_volume_mix's output): the tracer samples a second, row-paired copy of the voxels
- * (2 x the volume's bytes; one fetch per 2 x 2 footprint) that cpm_volume_create / _update / _mix keep in
+ * the device, e.g. cpm_volume_mix's output): the tracer samples a second copy of the voxels laid out
+ * by trilinear footprint (4 x the volume's bytes; one fetch per sample) that cpm_volume_create / _update / _mix keep in
  * step -- data written through this pointer would not reach it; and a blocking device->host copy of the block
  * (Volume::getRepresentation<VolumeRAM>() of a volume whose valid representation is the device one). */
 void* cpm_volume_device_data(const cpm_volume* vol, size_t* bytes);

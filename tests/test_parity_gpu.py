@@ -256,7 +256,7 @@ def test_trace_nonpow2_volume_and_small_tf(ctx, oracle, cpm):
 @pytest.mark.parametrize("shape", [(19, 33, 50), (24, 40, 64), (1, 21, 48), (17, 1, 32), (2, 2, 2)])  # [z, y, x]
 @pytest.mark.parametrize("how", ["host update", "device update", "device update, unaligned source", "mix"])
 def test_trace_reads_what_every_volume_writer_left(ctx, oracle, cpm, shape, how):
-    """The tracer samples the volume's row-pair copy (one fetch = a 2 x 2 footprint); every writer of a volume --
+    """The tracer samples the volume's footprint copy (one fetch = the 2 x 2 x 2 neighbourhood); every writer of a volume --
     create, update from the host or from the device (one fused launch, or copy + re-layout for a source that is not
     4-byte aligned), volume_mix -- rebuilds it, for row lengths on and off the 16-byte path and for one-row / one-slice
     volumes (the y + 1 / z + 1 clamps)."""
