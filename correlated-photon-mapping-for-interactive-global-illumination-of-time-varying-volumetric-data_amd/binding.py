@@ -30,7 +30,7 @@ ABI_SYMBOLS = [
     "cpm_tf_create", "cpm_tf_update", "cpm_tf_destroy",
     "cpm_uniform_samples_2d", "cpm_directional_light_samples", "cpm_point_light_samples",
     "cpm_light_sample_box_intersection", "cpm_light_sample_mesh_intersection",
-    "cpm_trace",
+    "cpm_trace", "cpm_trace_emitted",
     "cpm_grid_desc_default", "cpm_relative_irradiance_scale",
     "cpm_splat", "cpm_splat_selected", "cpm_copy_indexed_photons", "cpm_snapshot_selected_photons",
     "cpm_sort_pairs", "cpm_sort_keys", "cpm_bin", "cpm_gather", "cpm_mark_touched_bricks", "cpm_gather_bricks",
@@ -63,6 +63,27 @@ class TraceParams(C.Structure):
                 ("n_light_samples", C.c_int32), ("max_interactions", C.c_int32),
                 ("total_photons", C.c_int32), ("shading_type", C.c_int32), ("flags", C.c_int32),
                 ("iteration", C.c_int32), ("batch", C.c_int32)]
+
+
+CPM_EMIT_DIRECTIONAL, CPM_EMIT_POINT = 0, 1
+
+
+class EmitterDesc(C.Structure):
+    """cpm_emitter_desc: the light of cpm_trace_emitted (lattice + directional light plane or point light)."""
+    _fields_ = [("kind", C.c_int32), ("nx", C.c_int32), ("ny", C.c_int32), ("first_sample", C.c_int32),
+                ("radiance", C.c_float * 4), ("direction_or_position", C.c_float * 4),
+                ("plane_origin", C.c_float * 4), ("tangent_u", C.c_float * 4), ("tangent_v", C.c_float * 4),
+                ("plane_area", C.c_float)]
+
+
+def directional_emitter(nx, ny, radiance, direction, origin, u, v, area, first_sample=0) -> EmitterDesc:
+    return EmitterDesc(CPM_EMIT_DIRECTIONAL, nx, ny, first_sample, _f4(radiance), _f4(direction), _f4(origin), _f4(u),
+                       _f4(v), float(area))
+
+
+def point_emitter(nx, ny, radiance, position, first_sample=0) -> EmitterDesc:
+    z = _f4((0, 0, 0))
+    return EmitterDesc(CPM_EMIT_POINT, nx, ny, first_sample, _f4(radiance), _f4(position), z, _f4((0, 0, 0)), _f4((0, 0, 0)), 0.0)
 
 
 class CpmError(RuntimeError):
@@ -112,6 +133,7 @@ def load_library() -> C.CDLL:
         "cpm_light_sample_box_intersection": (i32, [vp, vp, i32, P(f32 * 8), vp, vp]),
         "cpm_light_sample_mesh_intersection": (i32, [vp, vp, vp, i32, vp, i32, vp, vp]),
         "cpm_trace": (i32, [vp, vp, vp, vp, P(f32 * 8), P(TraceParams), vp, vp, vp, i32, vp, vp, vp]),
+        "cpm_trace_emitted": (i32, [vp, vp, vp, vp, P(f32 * 8), P(TraceParams), P(EmitterDesc), vp, i32, vp, vp, vp]),
         "cpm_grid_desc_default": (None, [P(GridDesc), P(i32 * 3), i32]),
         "cpm_relative_irradiance_scale": (f32, [C.c_double, C.c_double]),
         "cpm_splat": (i32, [vp, vp, i32, P(GridDesc), f32, f32, vp, vp]),
@@ -358,6 +380,14 @@ class Context:
         self._check(self.lib.cpm_trace(
             self.h, vol.h, tf.h, tf_scattering.h if tf_scattering is not None else None,
             C.byref((C.c_float * 8)(*aabb)), C.byref(params), self._ptr(light_samples), self._ptr(isect),
+            self._ptr(recompute_indices), n_recompute, self._ptr(rng_state), self._ptr(photons), self._stream()))
+
+    def trace_emitted(self, vol, tf, aabb, params: TraceParams, emitter: EmitterDesc, rng_state, photons,
+                      recompute_indices=None, n_recompute=0, tf_scattering=None):
+        """cpm_trace with the emission chain evaluated in the tracer (no light-sample / intersection buffers read)."""
+        self._check(self.lib.cpm_trace_emitted(
+            self.h, vol.h, tf.h, tf_scattering.h if tf_scattering is not None else None,
+            C.byref((C.c_float * 8)(*aabb)), C.byref(params), C.byref(emitter),
             self._ptr(recompute_indices), n_recompute, self._ptr(rng_state), self._ptr(photons), self._stream()))
 
     # -- light volume

@@ -171,7 +171,7 @@ int cpm_create(int device, cpm_ctx** out) {
     ctx->device = device;
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) ctx->num_cus = prop.multiProcessorCount;
-    if (hipMalloc((void**)&ctx->dir_hint, 8 * sizeof(float)) != hipSuccess || hipMemset(ctx->dir_hint, 0, 8 * sizeof(float)) != hipSuccess) {
+    if (hipMalloc((void**)&ctx->dir_hint, 16 * sizeof(float)) != hipSuccess || hipMemset(ctx->dir_hint, 0, 16 * sizeof(float)) != hipSuccess) {
         delete ctx;
         return set_error(nullptr, CPM_ERR_OUT_OF_MEMORY, "cpm_create", "device allocation failed");
     }

@@ -31,6 +31,10 @@ struct cpm_ctx {
     // valid flag -- a pure function of (theta, phi), evaluated once by the emitter so that the tracer's workgroups need not
     // (cpm_trace.hip; used only for samples whose (theta, phi) bit patterns match)
     float* dir_hint = nullptr;
+    // dir_hint + 8: the same 8 floats for the directional light of cpm_trace_emitted (which has no emitter launch to
+    // leave them); written by a one-lane launch whenever the direction differs from the one they were made for
+    float emit_hint_for[3] = { 0.f, 0.f, 0.f };
+    bool emit_hint_valid = false;
     // test / measurement hooks (include/cpm/cpm_profile.h: cpm_debug_*): per context, so that one context's experiment never
     // changes what another context (another GPU, a concurrent frame) runs
     struct {

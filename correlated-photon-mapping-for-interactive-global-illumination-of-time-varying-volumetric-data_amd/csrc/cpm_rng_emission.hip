@@ -3,6 +3,7 @@
 // passes; they are written for clarity, one work-item per element, coalesced 16/32-byte
 // accesses.
 #include "cpm_ctx.h"
+#include "cpm_emit.hip.h"
 
 using namespace cpm;
 
@@ -66,18 +67,8 @@ __global__ void random_fill_kernel(uint32_t* __restrict__ state, size_t n, int d
 __global__ void uniform_samples_2d_kernel(float dimx, float dimy, int n, float4* __restrict__ samples) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    float fi = (float)i;
-    float cx = __builtin_fmodf(fi, dimx);
-    float cy = fi / dimx;  // row coordinate not floored
-    samples[i] = make_float4((0.5f + cx) / dimx, (0.5f + cy) / dimy, 0.f, 1.f);
+    samples[i] = lattice_sample_(i, dimx, dimy);
 }
-
-struct Light {
-    float radiance[3];
-    float a[3];  // direction (directional) or position (point)
-    float origin[3], u[3], v[3];
-    float area;
-};
 
 __device__ __forceinline__ void store_sample(float* ls, int i, f3 o, f3 pw, float th, float ph) {
     float4* q = reinterpret_cast<float4*>(ls) + 2 * (size_t)i;
@@ -90,21 +81,9 @@ __global__ void directional_light_kernel(const float4* __restrict__ samples, int
                                          float* __restrict__ dir_hint) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    if (i == 0) {  // every sample of this light carries the same (theta, phi): what the tracer derives from it, once
-        const f3 d0 = { L.a[0], L.a[1], L.a[2] };
-        float t0, p0, t1, p1;
-        encode_direction_(d0, t0, p0);
-        const f3 d1 = decode_direction_(t0, p0);
-        encode_direction_(d1, t1, p1);
-        dir_hint[0] = t0; dir_hint[1] = p0; dir_hint[2] = d1.x; dir_hint[3] = d1.y; dir_hint[4] = d1.z; dir_hint[5] = t1; dir_hint[6] = p1;
-        dir_hint[7] = 1.0f;
-    }
-    float4 s = samples[i];
-    f3 o = { fma_(L.v[0], s.y, fma_(L.u[0], s.x, L.origin[0])),
-             fma_(L.v[1], s.y, fma_(L.u[1], s.x, L.origin[1])),
-             fma_(L.v[2], s.y, fma_(L.u[2], s.x, L.origin[2])) };
-    float pdf = s.w / L.area;
-    f3 pw = { L.radiance[0] / pdf, L.radiance[1] / pdf, L.radiance[2] / pdf };
+    if (i == 0) directional_hint_(L, dir_hint);  // every sample of this light carries the same (theta, phi): what the tracer derives from it, once
+    f3 o, pw;
+    directional_sample_(L, samples[i], o, pw);
     f3 d = { L.a[0], L.a[1], L.a[2] };
     float th, ph;
     encode_direction_(d, th, ph);
@@ -115,21 +94,11 @@ __global__ void directional_light_kernel(const float4* __restrict__ samples, int
 __global__ void point_light_kernel(const float4* __restrict__ samples, int n, Light L, float* __restrict__ ls) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    float4 s = samples[i];
-    float z = fma_(-2.0f, s.x, 1.0f);
-    float r = __builtin_sqrtf(max_(0.0f, fma_(-z, z, 1.0f)));
-    float sp, cp;
-    sincos_(kTwoPi * s.y, sp, cp);
-    f3 d = { r * cp, r * sp, z };
-    float pdf = s.w * kInv4Pi;
-    f3 pw = { L.radiance[0] / pdf, L.radiance[1] / pdf, L.radiance[2] / pdf };
-    f3 o = { L.a[0], L.a[1], L.a[2] };
+    f3 o, pw;
     float th, ph;
-    encode_direction_(d, th, ph);
+    point_sample_(L, samples[i], o, pw, th, ph);
     store_sample(ls, i, o, pw, th, ph);
 }
-
-struct Box { float mn[3], mx[3]; };
 
 // lightcl/cl/intersection/lightsamplemeshintersection.cl:37-58 for the cube proxy
 __global__ void box_intersection_kernel(const float* __restrict__ ls, int n, Box b, float2* __restrict__ isect) {
@@ -138,11 +107,7 @@ __global__ void box_intersection_kernel(const float* __restrict__ ls, int n, Box
     const float4* q = reinterpret_cast<const float4*>(ls) + 2 * (size_t)i;
     float4 a = q[0], c = q[1];
     f3 o = { a.x, a.y, a.z };
-    f3 d = decode_direction_(c.z, c.w);
-    float t0 = 0.f, t1 = kFltMax;
-    bool hit = ray_box_(b.mn, b.mx, o, d, t0, t1);
-    if (!hit) { t0 = 0.f; t1 = -1.f; }
-    isect[i] = make_float2(t0, t1);
+    isect[i] = box_entry_exit_(b, o, decode_direction_(c.z, c.w));
 }
 
 // same kernel against a triangle list (Moeller-Trumbore per triangle)

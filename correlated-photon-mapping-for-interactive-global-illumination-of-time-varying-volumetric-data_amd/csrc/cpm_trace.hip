@@ -19,6 +19,7 @@
 //   * MWC64X state lives in two VGPRs; photons and light samples move as 2 x float4
 //     (coalesced 2 KiB per wave-instruction).
 #include "cpm_ctx.h"
+#include "cpm_emit.hip.h"
 
 using namespace cpm;
 
@@ -49,8 +50,14 @@ struct TraceArgs {
     uint32_t* rng;
     float* photons;
     unsigned long long* step_counter;  // nullable (statistics build of the launch)
-    const float* dir_hint;             // cpm_ctx::dir_hint
+    const float* dir_hint;             // cpm_ctx::dir_hint (emitted mode: the hint of ITS light, cpm_ctx::dir_hint + 8)
+    // emitted mode (cpm_trace_emitted): light sample and entry / exit of lattice sample first_sample + thread, in registers
+    Light light;
+    float lattice_x, lattice_y;
+    int first_sample;
 };
+
+enum { EMIT_NONE = 0, EMIT_DIRECTIONAL = 1, EMIT_POINT = 2 };
 
 // One fetch = the whole 2 x 2 x 2 footprint of a trilinear sample: two neighbouring elements of cpm_volume::quads, each
 // { v(x, y, z), v(x, y + 1, z), v(x, y, z + 1), v(x, y + 1, z + 1) } (clamped at the last row / slice).  Four x-pair fetches of
@@ -193,7 +200,7 @@ CPM_DEV float woodcock(const VolDev& V, const float* lut, float wf, float m1, fl
     return t;
 }
 
-template <int DT>
+template <int DT, int EMIT>
 __global__ __launch_bounds__(256, 8) void trace_kernel(const TraceArgs A) {
     extern __shared__ float lds[];
     // One decoded / re-encoded direction per workgroup: a directional light gives every sample the same (theta, phi),
@@ -232,9 +239,11 @@ __global__ __launch_bounds__(256, 8) void trace_kernel(const TraceArgs A) {
     float2 ip = make_float2(0.f, -1.f);
     uint2 rs = make_uint2(0u, 0u);
     if (live) {
-        const float4* lsp = reinterpret_cast<const float4*>(A.light_samples) + 2 * (size_t)threadId;
-        l0 = lsp[0]; l1 = lsp[1];
-        ip = reinterpret_cast<const float2*>(A.isect)[threadId];
+        if (EMIT == EMIT_NONE) {
+            const float4* lsp = reinterpret_cast<const float4*>(A.light_samples) + 2 * (size_t)threadId;
+            l0 = lsp[0]; l1 = lsp[1];
+            ip = reinterpret_cast<const float2*>(A.isect)[threadId];
+        }
         rs = rng[photonOffset + threadId];
     }
     for (int i = threadIdx.x; i < A.tf_width; i += blockDim.x) lut[i] = A.tf_alpha[i];
@@ -242,7 +251,9 @@ __global__ __launch_bounds__(256, 8) void trace_kernel(const TraceArgs A) {
         luts = lds + A.tf_width;
         for (int i = threadIdx.x; i < A.tf_width; i += blockDim.x) luts[i] = A.tfs_alpha[i];
     }
-    if (threadIdx.x == 0) {
+    if (EMIT == EMIT_DIRECTIONAL) {  // the hint was made for exactly this light (cpm_trace_emitted)
+        if (threadIdx.x < 7) s_dir[threadIdx.x] = A.dir_hint[threadIdx.x];
+    } else if (EMIT == EMIT_NONE && threadIdx.x == 0) {
         // the emitter's hint (cpm_directional_light_samples left decode / encode of ITS (theta, phi) in the context): taken
         // when it is for this thread's (theta, phi); otherwise thread 0 evaluates them itself
         const float4 h0 = reinterpret_cast<const float4*>(A.dir_hint)[0], h1 = reinterpret_cast<const float4*>(A.dir_hint)[1];
@@ -257,6 +268,27 @@ __global__ __launch_bounds__(256, 8) void trace_kernel(const TraceArgs A) {
     }
     __syncthreads();
     if (!live) return;
+
+    if (EMIT != EMIT_NONE) {
+        // what cpm_uniform_samples_2d -> cpm_*_light_samples -> cpm_light_sample_box_intersection leave in their buffers for this
+        // sample, from the same device functions (cpm_emit.hip.h): 40 bytes per photon not read
+        const float4 ls = lattice_sample_(A.first_sample + threadId, A.lattice_x, A.lattice_y);
+        f3 o, pw, d;
+        float t0, p0;
+        if (EMIT == EMIT_DIRECTIONAL) {
+            directional_sample_(A.light, ls, o, pw);
+            t0 = s_dir[0]; p0 = s_dir[1];
+            d = { s_dir[2], s_dir[3], s_dir[4] };
+        } else {
+            point_sample_(A.light, ls, o, pw, t0, p0);
+            d = decode_direction_(t0, p0);
+        }
+        Box b;
+        for (int a = 0; a < 3; ++a) { b.mn[a] = A.bmin[a]; b.mx[a] = A.bmax[a]; }
+        ip = box_entry_exit_(b, o, d);
+        l0 = make_float4(o.x, o.y, o.z, pw.x);
+        l1 = make_float4(pw.y, pw.z, t0, p0);
+    }
 
     uint32_t rx = rs.x, rc = rs.y;
     uint32_t nInteractions = 0;
@@ -363,10 +395,15 @@ extern "C" {
 // iteration counts to this device counter (not part of cpm.h's stable surface)
 void cpm_debug_set_step_counter(cpm_ctx* ctx, unsigned long long* dev_counter) { if (ctx) ctx->dbg.step_counter = dev_counter; }
 
-int cpm_trace(cpm_ctx* ctx, const cpm_volume* vol, const cpm_tf* tf, const cpm_tf* tf_scattering, const float aabb[8],
-              const cpm_trace_params* params, const float* light_samples8, const float* isect2,
-              const uint32_t* recompute_indices, int n_recompute, uint32_t* rng_state, float* photons8,
-              cpm_stream stream) {
+}  // extern "C"
+
+namespace {
+__global__ void emit_hint_kernel(Light L, float* __restrict__ hint) { directional_hint_(L, hint); }
+
+int trace_impl(cpm_ctx* ctx, const cpm_volume* vol, const cpm_tf* tf, const cpm_tf* tf_scattering, const float aabb[8],
+               const cpm_trace_params* params, const float* light_samples8, const float* isect2, const cpm_emitter_desc* emitter,
+               const uint32_t* recompute_indices, int n_recompute, uint32_t* rng_state, float* photons8,
+               cpm_stream stream) {
     CPM_ENTER(ctx);
     CPM_REQUIRE(ctx, vol && tf && aabb && params, "cpm_trace: null argument");
     const cpm_trace_params& p = *params;
@@ -378,11 +415,20 @@ int cpm_trace(cpm_ctx* ctx, const cpm_volume* vol, const cpm_tf* tf, const cpm_t
     if (tf_scattering) CPM_REQUIRE(ctx, tf_scattering->width == tf->width, "cpm_trace: tf widths differ");
     int n_threads = recompute_indices ? n_recompute : p.n_light_samples;
     if (n_threads == 0) return CPM_OK;
-    CPM_REQUIRE(ctx, light_samples8 && isect2 && rng_state && photons8, "cpm_trace: null buffer");
-    CPM_REQUIRE_ALIGNED16(ctx, light_samples8, "cpm_trace");
+    CPM_REQUIRE(ctx, rng_state && photons8, "cpm_trace: null buffer");
     CPM_REQUIRE_ALIGNED16(ctx, photons8, "cpm_trace");
-    CPM_REQUIRE(ctx, ((reinterpret_cast<uintptr_t>(isect2) | reinterpret_cast<uintptr_t>(rng_state)) & 7u) == 0,
-                "cpm_trace: isect2 / rng_state must be 8-byte aligned");
+    CPM_REQUIRE(ctx, (reinterpret_cast<uintptr_t>(rng_state) & 7u) == 0, "cpm_trace: rng_state must be 8-byte aligned");
+    if (!emitter) {
+        CPM_REQUIRE(ctx, light_samples8 && isect2, "cpm_trace: null buffer");
+        CPM_REQUIRE_ALIGNED16(ctx, light_samples8, "cpm_trace");
+        CPM_REQUIRE(ctx, (reinterpret_cast<uintptr_t>(isect2) & 7u) == 0, "cpm_trace: isect2 must be 8-byte aligned");
+    } else {
+        CPM_REQUIRE(ctx, emitter->kind == CPM_EMIT_DIRECTIONAL || emitter->kind == CPM_EMIT_POINT, "cpm_trace_emitted: emitter kind");
+        CPM_REQUIRE(ctx, emitter->nx > 0 && emitter->ny > 0 && (long long)emitter->nx * emitter->ny < (1ll << 24),
+                    "cpm_trace_emitted: 0 < nx*ny < 2^24 (cpm_uniform_samples_2d's range)");
+        CPM_REQUIRE(ctx, emitter->first_sample >= 0 && (long long)emitter->first_sample + p.n_light_samples <= (long long)emitter->nx * emitter->ny,
+                    "cpm_trace_emitted: first_sample + n_light_samples exceeds the lattice");
+    }
     const cpm_volume_desc& d = vol->desc;
     CPM_REQUIRE(ctx, (unsigned long long)d.dims[0] * d.dims[1] * d.dims[2] < (1ull << 32), "cpm_trace: volume too large");
 
@@ -413,17 +459,67 @@ int cpm_trace(cpm_ctx* ctx, const cpm_volume* vol, const cpm_tf* tf, const cpm_t
     A.photons = photons8;
     A.step_counter = ctx->dbg.step_counter;
     A.dir_hint = ctx->dir_hint;
+    A.light = Light{};
+    A.lattice_x = A.lattice_y = 0.f;
+    A.first_sample = 0;
 
     size_t lds = (size_t)tf->width * sizeof(float) * (A.tfs_alpha != A.tf_alpha ? 2 : 1);
     hipStream_t s = (hipStream_t)stream;
     dim3 grid(div_up(n_threads, 256)), block(256);
-    switch (d.dtype) {
-        case CPM_U8: CPM_LAUNCH(ctx, trace_kernel<CPM_U8>, grid, block, lds, s, A); break;
-        case CPM_U16: CPM_LAUNCH(ctx, trace_kernel<CPM_U16>, grid, block, lds, s, A); break;
-        default: CPM_LAUNCH(ctx, trace_kernel<CPM_F32>, grid, block, lds, s, A); break;
+    int emit = EMIT_NONE;
+    if (emitter) {
+        emit = emitter->kind == CPM_EMIT_DIRECTIONAL ? EMIT_DIRECTIONAL : EMIT_POINT;
+        for (int a = 0; a < 3; ++a) {
+            A.light.radiance[a] = emitter->radiance[a]; A.light.a[a] = emitter->direction_or_position[a];
+            A.light.origin[a] = emitter->plane_origin[a]; A.light.u[a] = emitter->tangent_u[a]; A.light.v[a] = emitter->tangent_v[a];
+        }
+        A.light.area = emitter->plane_area;
+        A.lattice_x = (float)emitter->nx; A.lattice_y = (float)emitter->ny;
+        A.first_sample = emitter->first_sample;
+        if (emit == EMIT_DIRECTIONAL) {
+            A.dir_hint = ctx->dir_hint + 8;
+            if (!ctx->emit_hint_valid || memcmp(ctx->emit_hint_for, A.light.a, sizeof(ctx->emit_hint_for)) != 0) {
+                ctx->emit_hint_valid = false;
+                CPM_LAUNCH(ctx, emit_hint_kernel, dim3(1), dim3(1), 0, s, A.light, ctx->dir_hint + 8);
+                CPM_LAUNCH_CHECK(ctx, "emit_hint_kernel");
+                memcpy(ctx->emit_hint_for, A.light.a, sizeof(ctx->emit_hint_for));
+                ctx->emit_hint_valid = true;
+            }
+        }
     }
+#define CPM_TRACE_LAUNCH(DT)                                                                          \
+    do {                                                                                              \
+        if (emit == EMIT_NONE) CPM_LAUNCH(ctx, (trace_kernel<DT, EMIT_NONE>), grid, block, lds, s, A);  \
+        else if (emit == EMIT_DIRECTIONAL) CPM_LAUNCH(ctx, (trace_kernel<DT, EMIT_DIRECTIONAL>), grid, block, lds, s, A); \
+        else CPM_LAUNCH(ctx, (trace_kernel<DT, EMIT_POINT>), grid, block, lds, s, A);                   \
+    } while (0)
+    switch (d.dtype) {
+        case CPM_U8: CPM_TRACE_LAUNCH(CPM_U8); break;
+        case CPM_U16: CPM_TRACE_LAUNCH(CPM_U16); break;
+        default: CPM_TRACE_LAUNCH(CPM_F32); break;
+    }
+#undef CPM_TRACE_LAUNCH
     CPM_LAUNCH_CHECK(ctx, "trace_kernel");
     return CPM_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int cpm_trace(cpm_ctx* ctx, const cpm_volume* vol, const cpm_tf* tf, const cpm_tf* tf_scattering, const float aabb[8],
+              const cpm_trace_params* params, const float* light_samples8, const float* isect2,
+              const uint32_t* recompute_indices, int n_recompute, uint32_t* rng_state, float* photons8,
+              cpm_stream stream) {
+    return trace_impl(ctx, vol, tf, tf_scattering, aabb, params, light_samples8, isect2, nullptr, recompute_indices, n_recompute,
+                      rng_state, photons8, stream);
+}
+
+int cpm_trace_emitted(cpm_ctx* ctx, const cpm_volume* vol, const cpm_tf* tf, const cpm_tf* tf_scattering, const float aabb[8],
+                      const cpm_trace_params* params, const cpm_emitter_desc* emitter, const uint32_t* recompute_indices,
+                      int n_recompute, uint32_t* rng_state, float* photons8, cpm_stream stream) {
+    if (ctx && !emitter) return set_error(ctx, CPM_ERR_INVALID_ARGUMENT, "cpm_trace_emitted", "null emitter");
+    return trace_impl(ctx, vol, tf, tf_scattering, aabb, params, nullptr, nullptr, emitter, recompute_indices, n_recompute,
+                      rng_state, photons8, stream);
 }
 
 }  // extern "C"

@@ -159,7 +159,7 @@ class PhotonFrame:
                  radiance=(1.0, 1.0, 1.0), radius_voxels: float = 1.0, max_interactions: int = 1,
                  channels: int = 1, photon_range=None, point_light_position=None, seed: int = 0,
                  shading_type: int = B.CPM_PHASE_HENYEY_GREENSTEIN, material=(0.0, 0.0, 0.0, 0.0), light_plane=None,
-                 mesh_intersection=None):
+                 mesh_intersection=None, emit_in_tracer: bool = False):
         torch = ctx.torch
         self.ctx = ctx
         self.torch = torch
@@ -182,8 +182,16 @@ class PhotonFrame:
 
         # E1: emission lattice, E2: light plane, E3/E5: light samples, E4: entry/exit
         samples = ctx.uniform_samples_2d(nx, ny)[lo:hi].contiguous()
+        # This driver owns its light, so the tracer can evaluate the emission chain itself (emit_in_tracer=True ->
+        # cpm_trace_emitted: same device functions, same bits, 40 input bytes per photon not read and no buffers needed by
+        # the trace).  Off by default: measured at config 2 the tracer is bound by VALU issue, not by its input bytes
+        # (34.5 us emitted against 33.9 us from the buffers -- the lattice fmod, the pdf divisions and the box test cost what
+        # the loads saved).  The buffers stay what every other consumer reads (the importance pass of the correlated update).
+        self.emitter = None
         if point_light_position is not None:
             self.light_samples = ctx.point_light_samples(samples, radiance, point_light_position)
+            if emit_in_tracer and mesh_intersection is None:
+                self.emitter = B.point_emitter(nx, ny, radiance, point_light_position, first_sample=lo)
         else:
             d = np.asarray(light_travel_direction, np.float32) if light_plane is not None else _normalize(light_travel_direction)
             if light_plane is not None:  # (origin, u, v, area) fitted elsewhere (e.g. by the C++ host layer)
@@ -194,6 +202,8 @@ class PhotonFrame:
                 area = float(np.float32(np.linalg.norm(u)) * np.float32(np.linalg.norm(v)))
             self.light_plane = (o, u, v, area, d)
             self.light_samples = ctx.directional_light_samples(samples, radiance, d, o, u, v, area)
+            if emit_in_tracer and mesh_intersection is None:
+                self.emitter = B.directional_emitter(nx, ny, radiance, d, o, u, v, area, first_sample=lo)
         if mesh_intersection is not None:  # (vertices [n,3] f32, indices int32): the proxy-mesh variant of E4
             vtx = torch.from_numpy(np.ascontiguousarray(mesh_intersection[0], np.float32)).to(dev)
             idx = torch.from_numpy(np.ascontiguousarray(mesh_intersection[1], np.int32)).to(dev)
@@ -232,8 +242,13 @@ class PhotonFrame:
         self.sorted_fast = None
 
     # stages
-    def trace(self):
-        self.ctx.trace(self.vol, self.tf, self.aabb, self.params, self.light_samples, self.isect, self.rng, self.photons)
+    def trace(self, recompute_indices=None, n_recompute=0):
+        if self.emitter is not None:
+            self.ctx.trace_emitted(self.vol, self.tf, self.aabb, self.params, self.emitter, self.rng, self.photons,
+                                   recompute_indices=recompute_indices, n_recompute=n_recompute)
+        else:
+            self.ctx.trace(self.vol, self.tf, self.aabb, self.params, self.light_samples, self.isect, self.rng, self.photons,
+                           recompute_indices=recompute_indices, n_recompute=n_recompute)
 
     def bin(self):
         self.ctx.bin(self.photons, self.n * self.I, self.grid, self.order, self.cell_start, self.sorted)
@@ -590,8 +605,7 @@ class CorrelatedPhotonMapper(PhotonFrame):
             if ranked:
                 ctx.sort_keys(idx, 0)                        # ascending index = emission-lattice order (:467-473)
             self.params.flags = 0                            # correlated: RNG state is NOT written back
-            ctx.trace(self.vol, self.tf, self.aabb, self.params, self.light_samples, self.isect, self.rng, self.photons,
-                      recompute_indices=idx, n_recompute=n)
+            self.trace(recompute_indices=idx, n_recompute=n)
             if ranked:  # importance is sorted alongside the indices: entries [offset, offset+n) belong to the re-traced photons
                 ctx.reset_importance(self.importance, self.remaining_offset, n)
             else:       # every changed photon was re-traced

@@ -213,6 +213,28 @@ int cpm_trace(cpm_ctx* ctx, const cpm_volume* vol, const cpm_tf* tf, const cpm_t
               const float* isect2, const uint32_t* recompute_indices, int n_recompute,
               uint32_t* rng_state, float* photons8, cpm_stream stream);
 
+/* The same trace with the emission chain evaluated in the tracer's registers instead of read from buffers: thread i
+ * takes lattice sample first_sample + i of cpm_uniform_samples_2d(nx, ny), turns it into the light sample of
+ * cpm_directional_light_samples / cpm_point_light_samples and into the entry / exit of cpm_light_sample_box_intersection
+ * against `aabb` -- the same device functions, bit-identical photons and RNG states -- and does not read 40 of the
+ * 48 input bytes per photon (measured at 1 M photons the launch takes the same time either way: the tracer is bound
+ * by instruction issue; what this saves is the buffers and their traffic).  For a tracer whose caller owns the light (a frame driver); a caller that is handed
+ * LightSamples of unknown origin (PhotonTracerCL's inport, mesh-intersected samples) uses cpm_trace. */
+enum { CPM_EMIT_DIRECTIONAL = 0, CPM_EMIT_POINT = 1 };
+typedef struct cpm_emitter_desc {
+    int32_t kind;                    /* CPM_EMIT_* */
+    int32_t nx, ny;                  /* the emission lattice (cpm_uniform_samples_2d) */
+    int32_t first_sample;            /* lattice index of light sample 0 of this call (a shard's first photon) */
+    float radiance[4];
+    float direction_or_position[4];  /* directional: travel direction; point: position */
+    float plane_origin[4], tangent_u[4], tangent_v[4];  /* directional light plane (unused for a point light) */
+    float plane_area;
+} cpm_emitter_desc;
+int cpm_trace_emitted(cpm_ctx* ctx, const cpm_volume* vol, const cpm_tf* tf, const cpm_tf* tf_scattering,
+                      const float aabb[8], const cpm_trace_params* params, const cpm_emitter_desc* emitter,
+                      const uint32_t* recompute_indices, int n_recompute,
+                      uint32_t* rng_state, float* photons8, cpm_stream stream);
+
 /* ------------------------------------------------------------------ light volume (grid) */
 
 /* Output light volume: dims, channels (1 = float32, 4 = 4xfloat32: rgb added,

@@ -173,6 +173,15 @@ def _trace_case(ctx, oracle, cpm, volume, tf, n_side, direction, max_inter=1, fl
     rng_d = _t(ctx, st)
     photons_d = ctx.torch.zeros((n * max_inter, 8), dtype=ctx.torch.float32, device=ctx.device)
     ctx.trace(vol, tfh, aabb, p, _t(ctx, ls), _t(ctx, isect), rng_d, photons_d, tf_scattering=tfsh)
+    # the same trace with the emission chain evaluated in the tracer (cpm_trace_emitted): identical photons and RNG states
+    rad = (1, 0.8, 0.6)
+    em = (B.directional_emitter(n_side, n_side, rad, d, o, u, v, area) if point is None
+          else B.point_emitter(n_side, n_side, rad, point))
+    rng_e = _t(ctx, st)
+    photons_e = ctx.torch.zeros((n * max_inter, 8), dtype=ctx.torch.float32, device=ctx.device)
+    ctx.trace_emitted(vol, tfh, aabb, p, em, rng_e, photons_e, tf_scattering=tfsh)
+    assert np.array_equal(bits(_n(photons_e)), bits(_n(photons_d)))
+    assert np.array_equal(_n(rng_e, np.uint32), _n(rng_d, np.uint32))
 
     ovol = oracle.volume(volume, *fmt)
     rng_o = st.copy()
@@ -251,6 +260,70 @@ def test_trace_nonpow2_volume_and_small_tf(ctx, oracle, cpm):
     tf = cpm.synthetic.tf_from_points([(0, 1, 1, 1, 0.02), (1, 1, 1, 1, 0.6)], width=17)
     got, want, *_ = _trace_case(ctx, oracle, cpm, vol, tf, 100, (0.2, -0.4, 1.0))
     assert np.array_equal(bits(got), bits(want))
+
+
+@pytest.mark.parametrize("case", ["directional", "point", "shard", "four interactions", "progressive", "re-trace by index"])
+def test_emitted_trace_equals_buffer_trace(ctx, cpm, case):
+    """PhotonFrame with the emission chain in the tracer (cpm_trace_emitted) against the same frame tracing
+    from the emitters' buffers: bit-identical photons and RNG states -- whole lattices and shards (first_sample), both
+    light kinds, several interactions, RNG write-back, and the PHOTON_RECOMPUTATION variant (thread j -> sample indices[j])."""
+    S, P, B = cpm.synthetic, cpm.pipeline, cpm.binding
+    torch = ctx.torch
+    kw = dict(light_travel_direction=(0.3, 0.5, -1.0))
+    if case == "point":
+        kw = dict(point_light_position=(0.5, 0.45, 2.5))
+    if case == "shard":
+        kw["photon_range"] = (1000, 9000)
+    if case == "four interactions":
+        kw["max_interactions"] = 4
+    vol, tf = S.heterogeneous_volume(48), S.workspace_tf()
+    a = P.PhotonFrame(ctx, vol, tf, (112, 96), (32, 32, 32), emit_in_tracer=True, **kw)
+    b = P.PhotonFrame(ctx, vol, tf, (112, 96), (32, 32, 32), **kw)
+    assert a.emitter is not None and b.emitter is None
+    if case == "progressive":
+        a.params.flags = b.params.flags = B.CPM_TRACE_PROGRESSIVE
+    idx = None
+    if case == "re-trace by index":
+        a.trace(); b.trace()
+        a.photons.zero_(); b.photons.zero_()
+        pick = np.sort(np.random.default_rng(3).choice(a.n, 777, replace=False)).astype(np.int32)
+        idx = torch.from_numpy(pick).to(ctx.device)
+    for rep in range(2):  # the second pass continues from the written-back RNG states in the progressive case
+        if idx is None:
+            a.trace(); b.trace()
+        else:
+            a.trace(recompute_indices=idx, n_recompute=idx.numel()); b.trace(recompute_indices=idx, n_recompute=idx.numel())
+        assert np.array_equal(bits(_n(a.photons)), bits(_n(b.photons)))
+        assert np.array_equal(_n(a.rng, np.uint32), _n(b.rng, np.uint32))
+    assert np.abs(_n(a.photons)[:, 3]).sum() > 0
+    if case == "directional":  # two lights taking turns on one context: the per-light direction hint follows
+        other = dict(light_travel_direction=(-0.2, 0.1, 1.0))
+        c = P.PhotonFrame(ctx, vol, tf, (112, 96), (32, 32, 32), emit_in_tracer=True, **other)
+        c2 = P.PhotonFrame(ctx, vol, tf, (112, 96), (32, 32, 32), **other)
+        c2.trace()
+        for _ in range(2):
+            c.trace(); a.trace()
+            assert np.array_equal(bits(_n(c.photons)), bits(_n(c2.photons)))
+            assert np.array_equal(bits(_n(a.photons)), bits(_n(b.photons)))
+    if case == "progressive":
+        assert not np.array_equal(_n(a.rng, np.uint32), _n(a.rng_initial, np.uint32))
+
+
+def test_emitted_trace_refusals(ctx, cpm):
+    S, P, B = cpm.synthetic, cpm.pipeline, cpm.binding
+    f = P.PhotonFrame(ctx, S.heterogeneous_volume(32), S.workspace_tf(), 64, (16, 16, 16), emit_in_tracer=True)
+    e = f.emitter
+    bad = B.directional_emitter(8, 8, (1, 1, 1), (0, 0, 1), (0, 0, 0), (1, 0, 0), (0, 1, 0), 1.0)   # lattice smaller than the trace
+    with pytest.raises(B.CpmError, match="exceeds the lattice"):
+        ctx.trace_emitted(f.vol, f.tf, f.aabb, f.params, bad, f.rng, f.photons)
+    late = B.directional_emitter(64, 64, (1, 1, 1), (0, 0, 1), (0, 0, 0), (1, 0, 0), (0, 1, 0), 1.0, first_sample=1)
+    with pytest.raises(B.CpmError, match="exceeds the lattice"):
+        ctx.trace_emitted(f.vol, f.tf, f.aabb, f.params, late, f.rng, f.photons)
+    e2 = B.EmitterDesc.from_buffer_copy(e)
+    e2.kind = 7
+    with pytest.raises(B.CpmError, match="emitter kind"):
+        ctx.trace_emitted(f.vol, f.tf, f.aabb, f.params, e2, f.rng, f.photons)
+    f.trace()  # the frame's own emitter still works after the refusals
 
 
 @pytest.mark.parametrize("shape", [(19, 33, 50), (24, 40, 64), (1, 21, 48), (17, 1, 32), (2, 2, 2)])  # [z, y, x]
