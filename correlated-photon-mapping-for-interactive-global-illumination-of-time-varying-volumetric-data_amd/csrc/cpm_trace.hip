@@ -300,7 +300,8 @@ __global__ __launch_bounds__(256, 8) void trace_kernel(const TraceArgs A) {
     if (maxInteractions != 1) { power.x = power.x / mi; power.y = power.y / mi; power.z = power.z / mi; }  // x / 1.0f == x
     f3 direction;
     float th, ph;  // encodeDirection(direction), kept current: re-evaluated only where the direction changes
-    if (__all(__float_as_uint(l1.z) == __float_as_uint(s_dir[0]) && __float_as_uint(l1.w) == __float_as_uint(s_dir[1]))) {
+    // (a point light's samples each have their own direction: s_dir is not even written in that mode)
+    if (EMIT != EMIT_POINT && __all(__float_as_uint(l1.z) == __float_as_uint(s_dir[0]) && __float_as_uint(l1.w) == __float_as_uint(s_dir[1]))) {
         direction.x = s_dir[2]; direction.y = s_dir[3]; direction.z = s_dir[4];
         th = s_dir[5]; ph = s_dir[6];
     } else {
@@ -487,11 +488,12 @@ int trace_impl(cpm_ctx* ctx, const cpm_volume* vol, const cpm_tf* tf, const cpm_
             }
         }
     }
-#define CPM_TRACE_LAUNCH(DT)                                                                          \
-    do {                                                                                              \
-        if (emit == EMIT_NONE) CPM_LAUNCH(ctx, (trace_kernel<DT, EMIT_NONE>), grid, block, lds, s, A);  \
-        else if (emit == EMIT_DIRECTIONAL) CPM_LAUNCH(ctx, (trace_kernel<DT, EMIT_DIRECTIONAL>), grid, block, lds, s, A); \
-        else CPM_LAUNCH(ctx, (trace_kernel<DT, EMIT_POINT>), grid, block, lds, s, A);                   \
+#define CPM_TRACE_LAUNCH_E(DT, E) CPM_LAUNCH(ctx, (trace_kernel<DT, E>), grid, block, lds, s, A)
+#define CPM_TRACE_LAUNCH(DT)                                                  \
+    do {                                                                      \
+        if (emit == EMIT_NONE) CPM_TRACE_LAUNCH_E(DT, EMIT_NONE);             \
+        else if (emit == EMIT_DIRECTIONAL) CPM_TRACE_LAUNCH_E(DT, EMIT_DIRECTIONAL); \
+        else CPM_TRACE_LAUNCH_E(DT, EMIT_POINT);                              \
     } while (0)
     switch (d.dtype) {
         case CPM_U8: CPM_TRACE_LAUNCH(CPM_U8); break;
@@ -499,6 +501,7 @@ int trace_impl(cpm_ctx* ctx, const cpm_volume* vol, const cpm_tf* tf, const cpm_
         default: CPM_TRACE_LAUNCH(CPM_F32); break;
     }
 #undef CPM_TRACE_LAUNCH
+#undef CPM_TRACE_LAUNCH_E
     CPM_LAUNCH_CHECK(ctx, "trace_kernel");
     return CPM_OK;
 }
