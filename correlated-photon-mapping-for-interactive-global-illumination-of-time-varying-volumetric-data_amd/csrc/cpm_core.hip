@@ -61,8 +61,8 @@ ProfScope::~ProfScope() {
 
 using namespace cpm;
 
-// voxels -> quads (cpm_volume::quads): a lane takes VEC elements of rows (y, z), (y + 1, z), (y, z + 1), (y + 1, z + 1) (16 bytes each
-// when the row length allows) and writes them interleaved (64 bytes); COPY also writes the first row through to the volume's
+// voxels -> quads (cpm_volume::quads): a lane takes VEC elements of rows (y, z), (y + 1, z), (y, z + 1), (y + 1, z + 1) (4 bytes each
+// when the row length allows) and writes them interleaved (16 bytes); COPY also writes the first row through to the volume's
 // own linear block (a device->device cpm_volume_update is this one launch instead of a copy plus a launch).
 template <typename T, int VEC, bool COPY>
 __global__ void __launch_bounds__(256) quads_kernel(const T* __restrict__ src, T* __restrict__ linear, T* __restrict__ quads,
@@ -89,8 +89,10 @@ __global__ void __launch_bounds__(256) quads_kernel(const T* __restrict__ src, T
 template <typename T, bool COPY>
 static int launch_quads(cpm_ctx* ctx, cpm_volume* vol, const void* src, hipStream_t s) {
     const uint32_t dx = (uint32_t)vol->desc.dims[0], dy = (uint32_t)vol->desc.dims[1], dz = (uint32_t)vol->desc.dims[2];
-    constexpr int kVec = 16 / (int)sizeof(T);
-    const bool wide = dx % kVec == 0 && (reinterpret_cast<uintptr_t>(src) & 15u) == 0;
+    // 4 bytes of each of the four rows in, 16 bytes out per lane: consecutive lanes write consecutive 16-byte pieces (a lane
+    // that took 16 bytes per row wrote 64 of its own: four store instructions each touching a quarter of 64 lines -- 31 us at 256^3)
+    constexpr int kVec = 4 / (int)sizeof(T);
+    const bool wide = dx % kVec == 0 && (reinterpret_cast<uintptr_t>(src) & 3u) == 0;
     const unsigned long long chunks = (unsigned long long)(wide ? dx / kVec : dx) * dy * dz;
     CPM_REQUIRE(ctx, chunks < (1ull << 32), "cpm_volume: too large");
     const uint32_t grid = (uint32_t)std::min<unsigned long long>((chunks + 255) / 256, 256ull * 64);
