@@ -129,7 +129,8 @@ void cpm_volume_destroy(cpm_ctx* ctx, cpm_volume* vol);
 /* Device address and byte size of the voxel block, READ-ONLY (for consumers that read a volume produced on
  * the device, e.g. cpm_volume_mix's output): the tracer samples a second copy of the voxels laid out
  * by trilinear footprint (4 x the volume's bytes; one fetch per sample) that cpm_volume_create / _update / _mix keep in
- * step -- data written through this pointer would not reach it; and a blocking device->host copy of the block
+ * step -- data written through this pointer does not reach it until cpm_volume_update(vol, that same pointer, 1)
+ * re-derives it (no copy in that case); and a blocking device->host copy of the block
  * (Volume::getRepresentation<VolumeRAM>() of a volume whose valid representation is the device one). */
 void* cpm_volume_device_data(const cpm_volume* vol, size_t* bytes);
 int cpm_volume_download(cpm_ctx* ctx, const cpm_volume* vol, void* voxels_host, cpm_stream stream);

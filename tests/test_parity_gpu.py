@@ -327,7 +327,7 @@ def test_emitted_trace_refusals(ctx, cpm):
 
 
 @pytest.mark.parametrize("shape", [(19, 33, 50), (24, 40, 64), (1, 21, 48), (17, 1, 32), (2, 2, 2)])  # [z, y, x]
-@pytest.mark.parametrize("how", ["host update", "device update", "device update, unaligned source", "mix"])
+@pytest.mark.parametrize("how", ["host update", "device update", "device update, unaligned source", "mix", "written in place"])
 def test_trace_reads_what_every_volume_writer_left(ctx, oracle, cpm, shape, how):
     """The tracer samples the volume's footprint copy (one fetch = the 2 x 2 x 2 neighbourhood); every writer of a volume --
     create, update from the host or from the device (one fused launch, or copy + re-layout for a source that is not
@@ -349,6 +349,17 @@ def test_trace_reads_what_every_volume_writer_left(ctx, oracle, cpm, shape, how)
             flat = torch.zeros(volume.size + 1, dtype=torch.uint8, device=ctx.device)
             flat[1:] = torch.from_numpy(volume.reshape(-1)).to(ctx.device)
             h.update(flat[1:])
+        elif how == "written in place":  # a device producer writes the block itself, then hands the same pointer to update
+            size = C.c_size_t()
+            ctx.lib.cpm_volume_device_data.restype = C.c_void_p
+            ptr = ctx.lib.cpm_volume_device_data(h.h, C.byref(size))
+            assert size.value == volume.size
+            src = torch.from_numpy(volume.reshape(-1)).to(ctx.device)
+            torch.cuda.synchronize()
+            hip = C.CDLL("libamdhip64.so")
+            hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+            assert hip.hipMemcpy(ptr, src.data_ptr(), volume.size, 3) == 0   # device -> device, behind the library's back
+            ctx._check(ctx.lib.cpm_volume_update(ctx.h, h.h, C.c_void_p(ptr), 1, ctx._stream()))   # re-derives the tracer's copy, no copy
         else:  # weight 1 -> the mixed volume is `volume` exactly (test_volume_mix); written by the mix kernel
             other = ctx.volume_create(volume, desc)
             ctx.volume_mix(ctx.volume_create(first, desc), other, 1.0, h)
