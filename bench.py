@@ -14,7 +14,8 @@ irradiance grid, through the C-ABI, when N > 1).  Workload at N = 1: BASELINE co
   --workload config5   a step is one time step of the 256^3 sequence: volume step (difference, min/max, importance),
                        correlated re-trace of the rank's shard, delta light-volume update, touched-brick reduce
 
-  python bench.py --gpus 1 --steps K --warmup W
+  python bench.py --gpus N --steps K --warmup W        (N > 1 without WORLD_SIZE in the environment: this process touches
+                                                        no GPU and starts the N ranks itself as child processes)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
          --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -206,6 +207,34 @@ def timed(torch, fn, reps, warm=3):
     return (time.perf_counter() - t) / reps * 1e3
 
 
+def launch_ranks(n_ranks):
+    """`python bench.py --gpus N` run plainly (no WORLD_SIZE): start the N ranks -- one process per GPU, torch.distributed.run
+    on 127.0.0.1 -- as CHILD processes of this one, which has not touched a GPU and never does; relay rank 0's JSON line
+    and exit with the children's return code."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_ranks}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), str(Path(__file__).resolve())] + sys.argv[1:]
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True, env=env)
+    relayed = False
+    for line in proc.stdout:
+        if line.startswith("{") and '"metric"' in line:
+            sys.stdout.write(line)
+            sys.stdout.flush()
+            relayed = True
+        else:
+            sys.stderr.write(line)
+    rc = proc.wait()
+    if rc == 0 and not relayed:
+        print("bench.py: the ranks exited cleanly but rank 0 printed no JSON line", file=sys.stderr)
+        rc = 1
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -214,6 +243,9 @@ def main():
     ap.add_argument("--workload", default="config2", choices=sorted(WORKLOADS))
     ap.add_argument("--formulation", default="fast", choices=["fast", "exact"])
     ap.add_argument("--scaling", default=None, choices=["weak", "strong"])
+    ap.add_argument("--shards", default="tiles", choices=["tiles", "range"],
+                    help="N > 1: a rank takes the lattice's 4096-sample tiles t = rank (mod N) (default: every rank sees every lit "
+                         "brick at 1/N of the density) or a contiguous range (a slab of the light plane)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the labelled extra figures (other formulations, I = 4, sparse TF, configs 3 / 5, pipelined)")
@@ -230,6 +262,8 @@ def main():
     ap.add_argument("--graph", action="store_true",
                     help="replay a captured HIP graph of the frame instead of eager launches (measured slower here)")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
+        raise SystemExit(launch_ranks(args.gpus))
 
     import numpy as np
     import torch
@@ -263,8 +297,12 @@ def main():
         lattice, n_total = (nx, ny * world), nx * ny * world
     else:
         lattice, n_total = (nx, ny), nx * ny
-    lo, hi = sharding.shard_range(n_total, rank, world)
-    n_rank = hi - lo
+    if args.shards == "tiles":
+        shard = sharding.shard_tiles(n_total, rank, world)
+    else:
+        lo, hi = sharding.shard_range(n_total, rank, world)
+        shard = np.arange(lo, hi, dtype=np.int64)
+    n_rank = int(shard.size)
     ctx = B.Context(local_rank)
     # the one exchange step: RCCL through the C-ABI (one-process-per-GPU form); torch.distributed only carries the id
     transport_note = None
@@ -309,7 +347,7 @@ def main():
         vols = [S.heterogeneous_volume(vdim, S.sequence_blob_center(t, n_steps)) for t in range(n_steps)]
         dvols = [ctx.volume_create(v) for v in vols]  # resident as volumes (as a sequence's VolumeCL representations are): no upload in the step
         fr = P.CorrelatedPhotonMapper(ctx, vols[0], tf, lattice, (gdim,) * 3, light_travel_direction=LIGHT_DIR,
-                                      tf_points=list(S.WORKSPACE_TF_POINTS), photon_range=(lo, hi))
+                                      tf_points=list(S.WORKSPACE_TF_POINTS), photon_indices=shard)
         fr.full_frame()
         total_grid = fr.light_volume.clone()
         if world > 1:
@@ -339,7 +377,7 @@ def main():
             torch.cuda.synchronize()
         use_graph = False
     else:
-        fr = P.PhotonFrame(ctx, vol_np, tf, lattice, (gdim,) * 3, light_travel_direction=LIGHT_DIR, photon_range=(lo, hi))
+        fr = P.PhotonFrame(ctx, vol_np, tf, lattice, (gdim,) * 3, light_travel_direction=LIGHT_DIR, photon_indices=shard)
         use_graph = args.graph and not fast
         if use_graph:
             fr.capture()
@@ -558,7 +596,13 @@ def main():
                                           "frame's trace + bin (double-buffered grid)")
                                        + f", transport {type(transport).__name__}"
                                        + (f" [{transport_note}]" if transport_note else "")) if world > 1 else "single GPU",
-                       "launch": "captured HIP graph replay" if use_graph else "eager launches"},
+                       "launch": "captured HIP graph replay" if use_graph else "eager launches",
+                       "shards": (f"4096-sample lattice tiles dealt round-robin (rank r: tiles t = r mod {world})" if args.shards == "tiles"
+                                  else "contiguous photon ranges (slabs of the light plane)") if world > 1 else "one shard",
+                       # the transport the reduce really used, and the size RCCL itself reports for the communicator
+                       # (cpm_comm_size; 0 = the reduce did not go through the C-ABI's RCCL communicator)
+                       "transport": type(transport).__name__,
+                       "rccl_ranks": transport.comm.size if isinstance(transport, sharding.RcclTransport) else 0},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": ab.get(dom_base, 0), "avg_launch_ms": round(dom_avg_ms, 5),

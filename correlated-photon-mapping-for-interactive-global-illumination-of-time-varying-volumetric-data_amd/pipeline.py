@@ -150,8 +150,10 @@ class PhotonFrame:
 
     n_side: an int (n_side x n_side emission lattice) or a pair (nx, ny).
     photon_range = (lo, hi) restricts this instance to a contiguous shard of the N = nx * ny
-    photons (multi-GPU: one shard per rank); photon i keeps light sample i and RNG stream i
-    of the unsharded run, so results do not depend on the number of shards.
+    photons (multi-GPU: one shard per rank); photon_indices (ascending global indices, e.g.
+    sharding.shard_tiles: the lattice's 4096-sample tiles dealt round-robin) to any other shard.
+    Photon i keeps light sample i and RNG stream i of the unsharded run, so results do not depend
+    on the number or shape of the shards; local photon j is global photon photon_indices[j].
     """
 
     def __init__(self, ctx: B.Context, volume, tf_rgba, n_side: int, grid_dims, *,
@@ -159,7 +161,7 @@ class PhotonFrame:
                  radiance=(1.0, 1.0, 1.0), radius_voxels: float = 1.0, max_interactions: int = 1,
                  channels: int = 1, photon_range=None, point_light_position=None, seed: int = 0,
                  shading_type: int = B.CPM_PHASE_HENYEY_GREENSTEIN, material=(0.0, 0.0, 0.0, 0.0), light_plane=None,
-                 mesh_intersection=None, emit_in_tracer: bool = False):
+                 mesh_intersection=None, emit_in_tracer: bool = False, photon_indices=None):
         torch = ctx.torch
         self.ctx = ctx
         self.torch = torch
@@ -169,9 +171,25 @@ class PhotonFrame:
         self.tf = tf_rgba if isinstance(tf_rgba, B.TransferFunction) else ctx.tf_create(tf_rgba)
         nx, ny = (n_side, n_side) if isinstance(n_side, int) else n_side
         self.n_total = nx * ny
+        if photon_indices is not None:
+            if photon_range is not None:
+                raise ValueError("photon_range and photon_indices are alternatives")
+            gidx = np.ascontiguousarray(photon_indices, dtype=np.int64)
+            if gidx.size and (gidx.min() < 0 or gidx.max() >= self.n_total or np.any(np.diff(gidx) <= 0)):
+                raise ValueError("photon_indices must be ascending indices into the nx * ny lattice")
+            contiguous = gidx.size > 0 and int(gidx[-1]) - int(gidx[0]) + 1 == gidx.size
+            if contiguous:  # a range after all (one rank, or a shard of one tile)
+                photon_range, photon_indices = (int(gidx[0]), int(gidx[-1]) + 1), None
+            elif gidx.size == 0:
+                photon_range, photon_indices = (0, 0), None
         lo, hi = photon_range if photon_range is not None else (0, self.n_total)
         self.lo, self.hi = lo, hi
         self.n = hi - lo
+        self.global_index = None   # device int64 [n]: global index of local photon j (None = lo + j)
+        if photon_indices is not None:
+            self.global_index = torch.from_numpy(gidx).to(dev)
+            self.n = int(gidx.size)
+            emit_in_tracer = False   # the in-register emitter addresses lattice sample first_sample + thread
         self.I = max_interactions
         self.aabb = S.UNIT_CUBE_AABB
         vdims = self.vol.dims
@@ -181,7 +199,8 @@ class PhotonFrame:
         self.scale = B.relative_irradiance_scale(self.radius, float(self.n_total))
 
         # E1: emission lattice, E2: light plane, E3/E5: light samples, E4: entry/exit
-        samples = ctx.uniform_samples_2d(nx, ny)[lo:hi].contiguous()
+        samples = ctx.uniform_samples_2d(nx, ny)
+        samples = (samples[lo:hi] if self.global_index is None else samples.index_select(0, self.global_index)).contiguous()
         # This driver owns its light, so the tracer can evaluate the emission chain itself (emit_in_tracer=True ->
         # cpm_trace_emitted: same device functions, same bits, 40 input bytes per photon not read and no buffers needed by
         # the trace).  Off by default: measured at config 2 the tracer is bound by VALU issue, not by its input bytes
@@ -218,7 +237,7 @@ class PhotonFrame:
         st[:, 0] = bases
         full = torch.from_numpy(st.view(np.int32)).to(dev).view(torch.int32)
         ctx.seed_streams(full)
-        self.rng = full[lo:hi].contiguous()
+        self.rng = (full[lo:hi] if self.global_index is None else full.index_select(0, self.global_index)).contiguous()
         self.rng_initial = self.rng.clone()
 
         self.params = B.TraceParams()

@@ -50,6 +50,23 @@ def test_bench_two_ranks_code_path():
     assert d["config"]["photons_rank0"] == 65536 and d["config"]["photons_per_frame"] == 131072   # weak: the per-rank work is fixed
 
 
+def test_bench_plain_command_starts_its_own_ranks():
+    """`python bench.py --gpus 2` with no WORLD_SIZE in the environment -- the form the driver uses: the parent starts the two
+    ranks itself (child processes), relays rank 0's line and reports n_gpus = 2."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT",
+                                                             "TORCHELASTIC_RUN_ID")}
+    cmd = [sys.executable, str(REPO / "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2", "--workload", "config1",
+           "--test-backend", "gloo", "--test-one-device"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=str(REPO), env=env)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-4000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout[-2000:]            # ONE JSON line on stdout
+    d = json.loads(lines[0])
+    assert KEYS <= set(d) and d["n_gpus"] == 2 and d["value"] > 0
+    assert d["config"]["photons_per_frame"] == 131072 and d["config"]["photons_rank0"] == 65536
+    assert "tiles" in d["config"]["shards"] and d["config"]["transport"] == "TorchTransport" and d["config"]["rccl_ranks"] == 0
+
+
 def test_bench_strong_scaling_and_exact_formulation():
     env = dict(os.environ, MASTER_ADDR="127.0.0.1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",

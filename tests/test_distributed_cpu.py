@@ -26,13 +26,31 @@ def test_shard_ranges_tile(cpm):
         sh.shard_range(10, 2, 2)
 
 
+def test_shard_tiles_partition(cpm):
+    """Tile-interleaved shards (bench.py's default): rank r owns the 4096-sample tiles t = r (mod N); the shards partition
+    the photon range, are ascending, and differ by at most one tile."""
+    import importlib
+    sh = importlib.import_module(cpm.__name__ + ".sharding")
+    for n, w, tile in ((1 << 20, 8, 4096), (15360, 2, 4096), (10, 3, 4), (7, 8, 4096), (0, 2, 4096), (8192, 2, 4096), (12289, 3, 4096)):
+        shards = [sh.shard_tiles(n, k, w, tile) for k in range(w)]
+        allidx = np.concatenate(shards) if shards else np.zeros(0, np.int64)
+        assert np.array_equal(np.sort(allidx), np.arange(n))
+        assert all(np.all(np.diff(s) > 0) for s in shards if s.size > 1)
+        assert max(s.size for s in shards) - min(s.size for s in shards) <= tile
+        for k, s in enumerate(shards):
+            assert np.all((s // tile) % w == k)
+    assert np.array_equal(sh.shard_tiles(1 << 20, 0, 1), np.arange(1 << 20))
+    with pytest.raises(ValueError):
+        sh.shard_tiles(10, 2, 2)
+
+
 def _lattice(world, scaling):
     """weak: every rank brings its own 96 x 96 lattice rows (bench.py --scaling weak); strong: ONE fixed lattice whatever
     the number of ranks (BASELINE configs 4 and 5: a fixed photon count sharded over the GPUs)."""
     return (96, 96 * world) if scaling == "weak" else (96, 160)
 
 
-def _worker(rank, world, port, out_dir, scaling):
+def _worker(rank, world, port, out_dir, scaling, shards="range"):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     sys.path.insert(0, str(REPO))
     sys.path.insert(0, str(REPO / "tests"))
@@ -47,19 +65,24 @@ def _worker(rank, world, port, out_dir, scaling):
     o = Oracle()
     nx, ny = _lattice(world, scaling)
     n_total = nx * ny
-    lo, hi = sh.shard_range(n_total, rank, world)
+    if shards == "tiles":   # (tiles of 1024 samples: the small test lattice then has several tiles per rank)
+        gidx = sh.shard_tiles(n_total, rank, world, 1024)
+    else:
+        lo, hi = sh.shard_range(n_total, rank, world)
+        gidx = np.arange(lo, hi, dtype=np.int64)
+    lo, hi = 0, int(gidx.size)   # local extent
     vol_np, tf = S.heterogeneous_volume(32), S.workspace_tf()
     d = P._normalize((0.3, 0.5, -1.0))
     origin = np.array([0.5] * 3, np.float32) - np.float32(2) * d
     po, u, v = P.fit_plane_aligned_obb(S.UNIT_CUBE_VERTICES, origin, d)
     area = float(np.float32(np.linalg.norm(u)) * np.float32(np.linalg.norm(v)))
-    s = o.uniform_samples_2d(nx, ny)[lo:hi].copy()
+    s = o.uniform_samples_2d(nx, ny)[gidx].copy()
     ls = o.directional_light_samples(s, (1, 1, 1), d, po, u, v, area)
     isect = o.light_sample_box_intersection(ls, S.UNIT_CUBE_AABB)
     st = np.zeros((n_total, 2), np.uint32)
     st[:, 0] = o.glibc_rand_sequence(0, n_total)
     o.seed_streams(st, 1 << 40)
-    st = st[lo:hi].copy()
+    st = st[gidx].copy()
     p = OTraceParams()
     p.step_size = 1 / 32
     p.n_light_samples = hi - lo
@@ -76,14 +99,15 @@ def _worker(rank, world, port, out_dir, scaling):
     t = torch.from_numpy(grid)
     sh.allreduce_light_volume(t)                           # the one collective of the path
     np.save(os.path.join(out_dir, f"photons_{rank}.npy"), ph)
+    np.save(os.path.join(out_dir, f"index_{rank}.npy"), gidx)
     if rank == 0:
         np.save(os.path.join(out_dir, "grid.npy"), t.numpy())
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("scaling", ["weak", "strong"])
-def test_two_rank_photon_sharding_and_grid_allreduce(tmp_path, oracle, cpm, scaling):
+@pytest.mark.parametrize("scaling,shards", [("weak", "range"), ("strong", "range"), ("weak", "tiles"), ("strong", "tiles")])
+def test_two_rank_photon_sharding_and_grid_allreduce(tmp_path, oracle, cpm, scaling, shards):
     import socket
     import torch.multiprocessing as mp
     from oracle_binding import OTraceParams
@@ -91,7 +115,7 @@ def test_two_rank_photon_sharding_and_grid_allreduce(tmp_path, oracle, cpm, scal
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     world = 2
-    mp.spawn(_worker, args=(world, port, str(tmp_path), scaling), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, port, str(tmp_path), scaling, shards), nprocs=world, join=True)
     # unsharded reference
     S, P = cpm.synthetic, cpm.pipeline
     nx, ny = _lattice(world, scaling)
@@ -114,7 +138,13 @@ def test_two_rank_photon_sharding_and_grid_allreduce(tmp_path, oracle, cpm, scal
     p.total_photons = n
     ph = np.zeros((n, 8), np.float32)
     oracle.trace(oracle.volume(vol_np), tf, S.UNIT_CUBE_AABB, p, ls, isect, st, ph)
-    sharded = np.concatenate([np.load(tmp_path / f"photons_{r}.npy") for r in range(world)])
+    sharded = np.zeros_like(ph)
+    seen = np.zeros(n, np.int32)
+    for r in range(world):   # local photon j of rank r is global photon index_r[j]
+        gi = np.load(tmp_path / f"index_{r}.npy")
+        sharded[gi] = np.load(tmp_path / f"photons_{r}.npy")
+        seen[gi] += 1
+    assert np.all(seen == 1)
     assert np.array_equal(sharded.view(np.uint32), ph.view(np.uint32))  # photon i is shard-independent
     og = oracle.grid((16, 16, 16), 1)
     radius = S.photon_radius_texture((32, 32, 32), 1.0)
