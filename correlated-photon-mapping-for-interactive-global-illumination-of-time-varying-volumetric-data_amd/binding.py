@@ -38,6 +38,9 @@ ABI_SYMBOLS = [
     "cpm_volume_minmax", "cpm_volume_difference", "cpm_importance_tf",
     "cpm_photon_importance", "cpm_photon_importance_equal", "cpm_reset_importance",
     "cpm_select_recompute", "cpm_select_changed",
+    "cpm_selection_create", "cpm_selection_destroy", "cpm_selection_begin", "cpm_photon_importance_select",
+    "cpm_photon_importance_equal_select", "cpm_selection_finish", "cpm_selection_count_device", "cpm_selection_count",
+    "cpm_trace_selected", "cpm_splat_delta",
     "cpm_mix_buffers", "cpm_volume_mix",
     "cpm_comm_get_unique_id", "cpm_comm_create", "cpm_comm_create_all", "cpm_comm_destroy", "cpm_comm_rank", "cpm_comm_size",
     "cpm_allreduce_grid", "cpm_reduce_grid", "cpm_allreduce_grids", "cpm_allreduce_grid_bricks",
@@ -159,6 +162,16 @@ def load_library() -> C.CDLL:
         "cpm_reset_importance": (i32, [vp, vp, sz, sz, vp]),
         "cpm_select_recompute": (i32, [vp, vp, sz, vp, vp, vp]),
         "cpm_select_changed": (i32, [vp, vp, sz, vp, vp, vp]),
+        "cpm_selection_create": (i32, [vp, sz, P(vp)]),
+        "cpm_selection_destroy": (None, [vp, vp]),
+        "cpm_selection_begin": (i32, [vp, vp]),
+        "cpm_photon_importance_select": (i32, [vp, vp, vp, P(i32 * 3), P(f32 * 3), P(f32 * 16), vp, i32, vp, vp, i32, i32, i32, i32, vp, vp]),
+        "cpm_photon_importance_equal_select": (i32, [vp, vp, i32, i32, i32, i32, vp, vp]),
+        "cpm_selection_finish": (i32, [vp, vp, vp, vp]),
+        "cpm_selection_count_device": (vp, [vp]),
+        "cpm_selection_count": (i32, [vp, vp, P(i32)]),
+        "cpm_trace_selected": (i32, [vp, vp, vp, vp, P(f32 * 8), P(TraceParams), vp, vp, vp, vp, i32, vp, vp, vp, vp, vp]),
+        "cpm_splat_delta": (i32, [vp, vp, i32, vp, vp, vp, i32, i32, P(GridDesc), f32, f32, i32, i32, vp, vp, vp]),
         "cpm_mix_buffers": (i32, [vp, vp, vp, f32, sz, i32, vp, vp]),
         "cpm_volume_mix": (i32, [vp, vp, vp, f32, vp, vp]),
         "cpm_comm_get_unique_id": (i32, [vp, vp]),
@@ -498,8 +511,7 @@ class Context:
         colors = np.ascontiguousarray(colors, dtype=np.float32)
         self._check(self.lib.cpm_importance_tf(self.h, self._ptr(minmax), self._ptr(prev_minmax), self._ptr(volume_diff),
                                                n_cells, positions.ctypes.data, colors.ctypes.data, positions.shape[0],
-                                               self._ptr(out), self._stream()))
-        self.torch.cuda.current_stream(self.device).synchronize()  # host arrays may now go away
+                                               self._ptr(out), self._stream()))   # (the call has consumed the host arrays on return)
 
     def photon_importance(self, importance_grid, grid_dims, cell_size, texture_to_index, photons, photon_offset,
                           light_samples, isect, n_light_samples, max_interactions, total_photons, importances,
@@ -524,6 +536,71 @@ class Context:
     def select_recompute(self, importances, indices_out, n_changed):
         self._check(self.lib.cpm_select_recompute(self.h, self._ptr(importances), importances.numel(), self._ptr(indices_out),
                                                   self._ptr(n_changed), self._stream()))
+
+    # -- the correlated update without a host round trip
+    def selection_create(self, max_photons: int) -> "Selection":
+        h = C.c_void_p()
+        self._check(self.lib.cpm_selection_create(self.h, max_photons, C.byref(h)))
+        return Selection(self, h)
+
+    def trace_selected(self, vol, tf, aabb, params: TraceParams, light_samples, isect, indices, selection: "Selection", max_indices,
+                       rng_state, photons, old_photons=None, reset_importances=None, tf_scattering=None):
+        self._check(self.lib.cpm_trace_selected(
+            self.h, vol.h, tf.h, tf_scattering.h if tf_scattering is not None else None,
+            C.byref((C.c_float * 8)(*aabb)), C.byref(params), self._ptr(light_samples), self._ptr(isect),
+            self._ptr(indices), selection.count_device, max_indices, self._ptr(old_photons), self._ptr(reset_importances),
+            self._ptr(rng_state), self._ptr(photons), self._stream()))
+
+    def splat_delta(self, old_photons, old_stride, photons, indices, selection: "Selection", max_indices, grid, radius, scale,
+                    n_photons, n_interactions, out, apply_below=0, brick_mask=None):
+        self._check(self.lib.cpm_splat_delta(self.h, self._ptr(old_photons), old_stride, self._ptr(photons), self._ptr(indices),
+                                             selection.count_device, max_indices, apply_below, C.byref(grid), radius, scale,
+                                             n_photons, n_interactions, self._ptr(brick_mask), self._ptr(out), self._stream()))
+
+
+class Selection:
+    """cpm_selection: the changed-photon selection of one correlated update (tile counts, lists, the count's mailbox)."""
+
+    def __init__(self, ctx: "Context", h):
+        self.ctx, self.h = ctx, h
+        self.count_device = C.c_void_p(ctx.lib.cpm_selection_count_device(h))
+
+    def begin(self):
+        self.ctx._check(self.ctx.lib.cpm_selection_begin(self.ctx.h, self.h))
+
+    def photon_importance(self, importance_grid, grid_dims, cell_size, texture_to_index, photons, photon_offset, light_samples, isect,
+                          n_light_samples, max_interactions, total_photons, importances, fix_exit_point=False):
+        c = self.ctx
+        c._check(c.lib.cpm_photon_importance_select(
+            c.h, self.h, c._ptr(importance_grid), C.byref((C.c_int32 * 3)(*grid_dims)), C.byref((C.c_float * 3)(*cell_size)),
+            C.byref((C.c_float * 16)(*texture_to_index)), c._ptr(photons), photon_offset, c._ptr(light_samples), c._ptr(isect),
+            n_light_samples, max_interactions, total_photons, int(fix_exit_point), c._ptr(importances), c._stream()))
+
+    def photon_importance_equal(self, photon_offset, n_light_samples, percentage, iteration, importances):
+        c = self.ctx
+        c._check(c.lib.cpm_photon_importance_equal_select(c.h, self.h, photon_offset, n_light_samples, percentage, iteration,
+                                                          c._ptr(importances), c._stream()))
+
+    def finish(self, indices_out):
+        c = self.ctx
+        c._check(c.lib.cpm_selection_finish(c.h, self.h, c._ptr(indices_out), c._stream()))
+
+    def count(self) -> int:
+        """The count of the last finish(), read from its host mailbox (no stream synchronisation)."""
+        n = C.c_int32(0)
+        self.ctx._check(self.ctx.lib.cpm_selection_count(self.ctx.h, self.h, C.byref(n)))
+        return int(n.value)
+
+    def close(self):
+        if self.h:
+            self.ctx.lib.cpm_selection_destroy(self.ctx.h, self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class Comm:

@@ -3,10 +3,27 @@
 // DDA through the importance grid, and the fused threshold + count + iota + sort selection.
 #include "cpm_ctx.h"
 
+#include <chrono>
+#include <new>
+
 using namespace cpm;
 
-namespace cpm {
-}
+// cpm_selection (include/cpm/cpm.h): the state of one changed-photon selection
+struct cpm_selection {
+    size_t max_photons = 0;
+    uint32_t per_tile = 0, max_tiles = 0;
+    uint2* tile = nullptr;            // device, max_tiles
+    uint32_t* local = nullptr;        // device, max_photons
+    int32_t* count_dev = nullptr;     // device
+    uint32_t* mask = nullptr;         // device, grow-only: occupancy bits of the importance grid of the last select call
+    size_t mask_words = 0;
+    unsigned long long* mailbox = nullptr;      // pinned host memory, written by selection_compact_kernel
+    unsigned long long* mailbox_dev = nullptr;  // its device address
+    uint32_t n_tiles = 0;             // tiles appended since cpm_selection_begin
+    uint32_t epoch = 0;               // of the last cpm_selection_finish enqueued
+    bool finished = false;            // a finish has been enqueued since begin
+    hipStream_t last_stream = nullptr;
+};
 
 namespace {
 
@@ -222,6 +239,31 @@ CPM_DEV float importance_for_range_tf(float rx, float ry, const float* __restric
     return mx.x + mx.y + mx.z + mx.w;
 }
 
+// The same kernel with the break points handed over as kernel arguments (<= kTfArgPoints of them: a TF has tens) and staged
+// in LDS: no host-to-device copy ahead of the launch, nothing for the caller's arrays to outlive.
+constexpr int kTfArgPoints = 48;
+struct TfPointArgs { float4 col[kTfArgPoints]; float pos[kTfArgPoints]; };
+CPM_DEV float importance_for_range_tf(float rx, float ry, const float* __restrict__ pos, const float4* __restrict__ col, int nPoints);
+__global__ __launch_bounds__(256) void importance_tf_args_kernel(const uint16_t* __restrict__ mm, const uint16_t* __restrict__ prev,
+                                                                 const float* __restrict__ diff, int n_cells, const TfPointArgs P,
+                                                                 int n_points, float* __restrict__ out) {
+    __shared__ float4 s_col[kTfArgPoints];
+    __shared__ float s_pos[kTfArgPoints];
+    if ((int)threadIdx.x < n_points) { s_col[threadIdx.x] = P.col[threadIdx.x]; s_pos[threadIdx.x] = P.pos[threadIdx.x]; }
+    __syncthreads();
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_cells) return;
+    uint16_t lo = mm[2 * i], hi = mm[2 * i + 1];
+    if (prev) {
+        uint16_t pl = prev[2 * i], ph = prev[2 * i + 1];
+        lo = pl < lo ? pl : lo;
+        hi = ph > hi ? ph : hi;
+    }
+    float rx = (1.f / 65535.f) * (float)lo, ry = (1.f / 65535.f) * (float)hi;
+    float imp = importance_for_range_tf(rx, ry, s_pos, s_col, n_points);
+    out[i] = prev ? diff[i] * imp : imp;
+}
+
 // classifyMinMaxUniformGrid3DImportanceKernel / classifyTimeVarying... (ref ...importance.cl:269-330)
 __global__ __launch_bounds__(256) void importance_tf_kernel(const uint16_t* __restrict__ mm, const uint16_t* __restrict__ prev,
                                                             const float* __restrict__ diff, int n_cells,
@@ -250,7 +292,10 @@ struct ImpGrid {
 // setupUniformGridTraversal + stepToNextCellNextHit (OPTIMIZE_STEP_FOR_SIMD) driven by
 // uniformGridImportance (ref uniformgridcl/cl/uniformgrid/uniformgrid.cl:38-69,147-167;
 // progressivephotonmapping/cl/photonrecomputationdetector.cl:55-90)
-CPM_DEV float uniform_grid_importance(const ImpGrid& G, const float x1[3], const float x2[3]) {
+// MASK: `mask` holds one bit per cell (set = the cell's importance is not +0.0f); a clear bit stands for the value +0.0f
+// without the load -- the same operand, so the same sum (the multiply and the add are still performed).
+template <bool MASK>
+CPM_DEV float uniform_grid_importance(const ImpGrid& G, const uint32_t* mask, const float x1[3], const float x2[3]) {
     int cell[3], cellEnd[3], di[3];
     float dt[3], deltatx[3];
 #pragma unroll
@@ -273,7 +318,9 @@ CPM_DEV float uniform_grid_importance(const ImpGrid& G, const float x1[3], const
     bool cont = true;
     int cap = G.dims[0] + G.dims[1] + G.dims[2] + 4;  // every wave reaches its exit, NaN input included
     while (cont && cap-- > 0) {
-        float val = G.grid[(size_t)cell[0] + (size_t)cell[1] * G.dims[0] + (size_t)cell[2] * G.dims[0] * G.dims[1]];
+        const size_t ci = (size_t)cell[0] + (size_t)cell[1] * G.dims[0] + (size_t)cell[2] * G.dims[0] * G.dims[1];
+        float val = 0.f;
+        if (!MASK || ((mask[ci >> 5] >> (ci & 31)) & 1u)) val = G.grid[ci];
         float dt0 = dt1;
         bool ax0 = dt[0] <= dt[1] && dt[0] <= dt[2];
         bool ax1 = !ax0 && (dt[0] > dt[1] && dt[1] <= dt[2]);
@@ -305,14 +352,12 @@ CPM_DEV uint32_t importance_to_uint(float imp100) {
     return u > 2147483647u ? 2147483647u : u;
 }
 
-// photonRecomputationDetectorKernel (ref progressivephotonmapping/cl/photonrecomputationdetector.cl:92-157)
-__global__ __launch_bounds__(256) void photon_importance_kernel(ImpGrid G, const float* __restrict__ photons,
-                                                                int photon_offset, const float* __restrict__ ls,
-                                                                const float* __restrict__ isect, int n_light_samples,
-                                                                int max_interactions, int total_photons,
-                                                                int fix_exit_point, uint32_t* __restrict__ importances) {
-    int threadId = blockIdx.x * blockDim.x + threadIdx.x;
-    if (threadId >= n_light_samples) return;
+// photonRecomputationDetectorKernel's body for one light sample (ref progressivephotonmapping/cl/photonrecomputationdetector.cl:92-157):
+// the importance, times 100, saturated to uint
+template <bool MASK>
+CPM_DEV uint32_t photon_importance_value(const ImpGrid& G, const uint32_t* mask, const float* __restrict__ photons, int photon_offset,
+                                         const float* __restrict__ ls, const float* __restrict__ isect, int max_interactions,
+                                         int total_photons, int fix_exit_point, int threadId) {
     const float bmin[3] = { 0.f, 0.f, 0.f }, bmax[3] = { 1.f, 1.f, 1.f };
     float recomputationImportance = 0.f;
     const float4* lsp = reinterpret_cast<const float4*>(ls) + 2 * (size_t)threadId;
@@ -354,11 +399,129 @@ __global__ __launch_bounds__(256) void photon_importance_kernel(ImpGrid G, const
             f3 ia = transform_(G.t2i, entry), ib = transform_(G.t2i, exitp);
             float x1[3] = { ia.x + 0.5f, ia.y + 0.5f, ia.z + 0.5f };
             float x2[3] = { ib.x + 0.5f, ib.y + 0.5f, ib.z + 0.5f };
-            recomputationImportance += uniform_grid_importance(G, x1, x2);
+            recomputationImportance += uniform_grid_importance<MASK>(G, mask, x1, x2);
             entry.x = a.x; entry.y = a.y; entry.z = a.z;
         }
     }
-    importances[photon_offset + threadId] -= importance_to_uint(100.f * recomputationImportance);
+    return importance_to_uint(100.f * recomputationImportance);
+}
+
+__global__ __launch_bounds__(256) void photon_importance_kernel(ImpGrid G, const float* __restrict__ photons,
+                                                                int photon_offset, const float* __restrict__ ls,
+                                                                const float* __restrict__ isect, int n_light_samples,
+                                                                int max_interactions, int total_photons,
+                                                                int fix_exit_point, uint32_t* __restrict__ importances) {
+    int threadId = blockIdx.x * blockDim.x + threadIdx.x;
+    if (threadId >= n_light_samples) return;
+    importances[photon_offset + threadId] -= photon_importance_value<false>(G, nullptr, photons, photon_offset, ls, isect, max_interactions,
+                                                                             total_photons, fix_exit_point, threadId);
+}
+
+// ---- the fused selection (cpm_photon_importance_select, cpm_selection_finish) -------------------------------------
+
+// one bit per importance-grid cell: set where the cell's importance is anything but +0.0f
+__global__ __launch_bounds__(256) void importance_mask_kernel(const float* __restrict__ grid, uint32_t n_cells, uint32_t* __restrict__ mask) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    const bool set = i < n_cells && __float_as_uint(grid[i]) != 0u;
+    const unsigned long long m = __ballot(set);
+    if ((threadIdx.x & 63u) == 0u && i < ((n_cells + 63u) & ~63u)) {
+        mask[(i >> 5)] = (uint32_t)m;
+        mask[(i >> 5) + 1] = (uint32_t)(m >> 32);
+    }
+}
+
+struct SelTiles {
+    uint2* tile;          // per tile: (count, start of its list in `local`)
+    uint32_t* local;      // tile-local lists: the tile of photons [photon_offset + b0, ...) lists its selected photons from there
+    uint32_t tile_first;  // this launch's first tile
+    uint32_t per_tile;    // photons per tile = 256 * K
+};
+
+// MODE 0: importance by DDA through the grid (mask staged in LDS when MASK); MODE 1: the equal-importance rule.
+// One workgroup = one tile of K * 256 consecutive light samples; thread t takes samples b0 + k * 256 + t.  Importances are
+// updated as by photon_importance_kernel; the photons whose key is then < 0x7fffffff are ranked with ballots (ascending
+// sample index) and listed at the tile's own place -- no atomics, no global prefix: cpm_selection_finish lines the tiles up.
+template <int MODE, bool MASK, int K>
+__global__ __launch_bounds__(256) void importance_select_kernel(ImpGrid G, const uint32_t* __restrict__ mask, uint32_t mask_words,
+                                                                const float* __restrict__ photons, int photon_offset,
+                                                                const float* __restrict__ ls, const float* __restrict__ isect,
+                                                                int n_light_samples, int max_interactions, int total_photons,
+                                                                int fix_exit_point, int eq_percentage, int eq_iteration,
+                                                                uint32_t* __restrict__ importances, SelTiles S) {
+    extern __shared__ uint32_t s_mask[];
+    __shared__ uint32_t s_wcnt[K][4];
+    const uint32_t t = threadIdx.x, lane = t & 63u, wave = t >> 6;
+    if (MODE == 0 && MASK) {
+        for (uint32_t i = t; i < mask_words; i += 256u) s_mask[i] = mask[i];
+        __syncthreads();
+    }
+    const int b0 = (int)(blockIdx.x * S.per_tile);
+    const int b1 = min(b0 + (int)S.per_tile, n_light_samples);
+    unsigned long long ballots[K];
+    uint32_t flags = 0;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const int threadId = b0 + k * 256 + (int)t;
+        bool changed = false;
+        if (threadId < b1) {
+            uint32_t u;
+            if (MODE == 0) {
+                u = photon_importance_value<MASK>(G, s_mask, photons, photon_offset, ls, isect, max_interactions, total_photons, fix_exit_point, threadId);
+            } else {
+                const int photonId = photon_offset + threadId;
+                u = ((photonId + eq_iteration) % (100 / eq_percentage) == 0) ? importance_to_uint(100.f * 1.f) : importance_to_uint(100.f * 0.f);
+            }
+            uint32_t key = importances[photon_offset + threadId];
+            if (u != 0u) { key -= u; importances[photon_offset + threadId] = key; }   // (key -= 0 leaves the word as it is)
+            changed = key < 2147483647u;
+        }
+        ballots[k] = __ballot(changed);
+        flags |= changed ? (1u << k) : 0u;
+        if (lane == 0) s_wcnt[k][wave] = (uint32_t)__popcll(ballots[k]);
+    }
+    __syncthreads();
+    uint32_t before = 0;  // selected photons of the tile ahead of (chunk k, this wave)
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    uint32_t* list = S.local + (size_t)photon_offset + (size_t)b0;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        uint32_t mine = before;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const uint32_t c = s_wcnt[k][w];
+            mine += w < (int)wave ? c : 0u;
+            before += c;
+        }
+        if (flags & (1u << k)) list[mine + (uint32_t)__popcll(ballots[k] & lt)] = (uint32_t)(photon_offset + b0 + k * 256 + (int)t);
+    }
+    if (t == 0) S.tile[S.tile_first + blockIdx.x] = make_uint2(before, (uint32_t)(photon_offset + b0));
+}
+
+// Tile lists -> one ascending list.  Workgroup b = tile b: sums the counts of the tiles before it (<= a few thousand
+// loads, no scan launch), copies its list behind them; workgroup 0 also publishes the total -- the device word the
+// following launches read and the pinned host mailbox (epoch << 32 | count) the host polls instead of synchronising.
+__global__ __launch_bounds__(256) void selection_compact_kernel(const uint2* __restrict__ tile, uint32_t n_tiles,
+                                                                const uint32_t* __restrict__ local, uint32_t* __restrict__ indices,
+                                                                int32_t* __restrict__ count_dev, unsigned long long* mailbox, uint32_t epoch) {
+    __shared__ uint32_t red[2][4];
+    const uint32_t t = threadIdx.x, lane = t & 63u, wave = t >> 6;
+    uint32_t before = 0, total = 0;
+    for (uint32_t i = t; i < n_tiles; i += 256u) {
+        const uint32_t c = tile[i].x;
+        total += c;
+        before += i < blockIdx.x ? c : 0u;
+    }
+    for (int off = 32; off > 0; off >>= 1) { before += __shfl_down(before, off, 64); total += __shfl_down(total, off, 64); }
+    if (lane == 0) { red[0][wave] = before; red[1][wave] = total; }
+    __syncthreads();
+    before = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+    total = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+    if (blockIdx.x == 0 && t == 0) {
+        *count_dev = (int32_t)total;
+        __hip_atomic_store(mailbox, ((unsigned long long)epoch << 32) | (unsigned long long)total, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    const uint2 me = tile[blockIdx.x];
+    for (uint32_t k = t; k < me.x; k += 256u) indices[before + k] = local[(size_t)me.y + k];
 }
 
 // photonRecomputationDetectorEqualImportanceKernel (ref ...detector.cl:160-194)
@@ -552,6 +715,16 @@ int cpm_importance_tf(cpm_ctx* ctx, const uint16_t* minmax2, const uint16_t* pre
     if (n_cells == 0) return CPM_OK;
     CPM_REQUIRE(ctx, minmax2 && importance, "cpm_importance_tf: null buffer");
     hipStream_t s = (hipStream_t)stream;
+    if (n_points <= kTfArgPoints) {  // the usual case: the points ride in the kernel arguments
+        TfPointArgs P;
+        memset(&P, 0, sizeof(P));
+        memcpy(P.col, colors4_host, (size_t)n_points * 4 * sizeof(float));
+        memcpy(P.pos, positions_host, (size_t)n_points * sizeof(float));
+        CPM_LAUNCH(ctx, importance_tf_args_kernel, dim3(div_up(n_cells, 256)), dim3(256), 0, s, minmax2, prev_minmax2, volume_diff, n_cells, P,
+                   n_points, importance);
+        CPM_LAUNCH_CHECK(ctx, "importance_tf_args_kernel");
+        return CPM_OK;
+    }
     // colours first (16-byte aligned), then positions
     float* dev = (float*)scratch(ctx, CPM_SCR_SMALL, (size_t)n_points * 5 * sizeof(float));
     if (!dev) return CPM_ERR_OUT_OF_MEMORY;
@@ -560,6 +733,7 @@ int cpm_importance_tf(cpm_ctx* ctx, const uint16_t* minmax2, const uint16_t* pre
     CPM_LAUNCH(ctx, importance_tf_kernel, dim3(div_up(n_cells, 256)), dim3(256), 0, s, minmax2, prev_minmax2, volume_diff,
                        n_cells, dev + (size_t)n_points * 4, reinterpret_cast<const float4*>(dev), n_points, importance);
     CPM_LAUNCH_CHECK(ctx, "importance_tf_kernel");
+    CPM_HIP_CHECK(ctx, hipStreamSynchronize(s));  // the caller's host arrays are consumed when this returns
     return CPM_OK;
 }
 
@@ -667,6 +841,207 @@ int cpm_select_changed(cpm_ctx* ctx, const uint32_t* importances, size_t n, uint
     const uint32_t* totals = cpm::sort_last_digit_totals(ctx, n);
     CPM_REQUIRE(ctx, totals, "cpm_select_changed: not available in the onesweep sort test mode");
     CPM_HIP_CHECK(ctx, hipMemcpyAsync(n_changed_dev, totals, sizeof(int32_t), hipMemcpyDeviceToDevice, s));  // keys with flag 0
+    return CPM_OK;
+}
+
+
+// ---- the fused selection ---------------------------------------------------------------------------------------
+
+int cpm_selection_create(cpm_ctx* ctx, size_t max_photons, cpm_selection** out) {
+    CPM_ENTER(ctx);
+    CPM_REQUIRE(ctx, out, "cpm_selection_create: null out");
+    *out = nullptr;
+    CPM_REQUIRE(ctx, max_photons >= 1 && max_photons < (1ull << 31), "cpm_selection_create: 1 <= max_photons < 2^31");
+    cpm_selection* s = new (std::nothrow) cpm_selection();
+    if (!s) return set_error(ctx, CPM_ERR_OUT_OF_MEMORY, "cpm_selection_create", "host allocation");
+    s->max_photons = max_photons;
+    // tiles of K * 256 photons, K in {1, 2, 4, 8}: about 2048 tiles at the sizes of the path (1 M photons: 512 per tile)
+    uint32_t k = 1;
+    while (k < 8 && max_photons / (256ull * k) > 2048) k *= 2;
+    s->per_tile = 256u * k;
+    s->max_tiles = (uint32_t)((max_photons + s->per_tile - 1) / s->per_tile) + 64u;  // + one partial tile per further light
+    bool ok = hipMalloc(&s->tile, (size_t)s->max_tiles * sizeof(uint2)) == hipSuccess &&
+              hipMalloc(&s->local, max_photons * sizeof(uint32_t)) == hipSuccess &&
+              hipMalloc(&s->count_dev, sizeof(int32_t)) == hipSuccess &&
+              hipHostMalloc(&s->mailbox, 64, hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess &&
+              hipHostGetDevicePointer((void**)&s->mailbox_dev, s->mailbox, 0) == hipSuccess &&
+              hipMemset(s->count_dev, 0, sizeof(int32_t)) == hipSuccess;
+    if (!ok) {
+        (void)hipGetLastError();
+        cpm_selection_destroy(ctx, s);
+        return set_error(ctx, CPM_ERR_OUT_OF_MEMORY, "cpm_selection_create", "device / pinned allocation");
+    }
+    *s->mailbox = 0ull;
+    *out = s;
+    return CPM_OK;
+}
+
+void cpm_selection_destroy(cpm_ctx* ctx, cpm_selection* s) {
+    if (!s) return;
+    if (ctx) (void)hipSetDevice(ctx->device);
+    if (s->last_stream || s->finished) (void)hipStreamSynchronize(s->last_stream);  // the mailbox must outlive its writer
+    if (s->tile) (void)hipFree(s->tile);
+    if (s->local) (void)hipFree(s->local);
+    if (s->count_dev) (void)hipFree(s->count_dev);
+    if (s->mask) (void)hipFree(s->mask);
+    if (s->mailbox) (void)hipHostFree(s->mailbox);
+    delete s;
+}
+
+int cpm_selection_begin(cpm_ctx* ctx, cpm_selection* s) {
+    CPM_ENTER(ctx);
+    CPM_REQUIRE(ctx, s, "cpm_selection_begin: null selection");
+    s->n_tiles = 0;
+    s->finished = false;
+    return CPM_OK;
+}
+
+}  // extern "C"
+
+namespace {
+// appends the tiles of one light's launch; *first = its first tile
+int selection_append(cpm_ctx* ctx, cpm_selection* s, int photon_offset, int n_light_samples, uint32_t* first, uint32_t* tiles) {
+    CPM_REQUIRE(ctx, !s->finished, "cpm_photon_importance_select: call cpm_selection_begin first");
+    CPM_REQUIRE(ctx, (size_t)photon_offset + (size_t)n_light_samples <= s->max_photons, "cpm_photon_importance_select: photons exceed the selection's max_photons");
+    *tiles = (uint32_t)div_up(n_light_samples, s->per_tile);
+    CPM_REQUIRE(ctx, s->n_tiles + *tiles <= s->max_tiles, "cpm_photon_importance_select: too many lights for this selection");
+    *first = s->n_tiles;
+    s->n_tiles += *tiles;
+    return CPM_OK;
+}
+
+template <int MODE, bool MASK>
+void launch_select(cpm_ctx* ctx, cpm_selection* s, hipStream_t st, uint32_t tiles, size_t lds, const ImpGrid& G, uint32_t mask_words,
+                   const float* photons8, int photon_offset, const float* ls, const float* isect, int n_light_samples, int max_interactions,
+                   int total_photons, int fix_exit_point, int pct, int iter, uint32_t* importances, const SelTiles& S) {
+    const dim3 grid(tiles), block(256);
+    switch (s->per_tile / 256u) {
+        case 1: CPM_LAUNCH(ctx, (importance_select_kernel<MODE, MASK, 1>), grid, block, lds, st, G, s->mask, mask_words, photons8, photon_offset, ls, isect,
+                           n_light_samples, max_interactions, total_photons, fix_exit_point, pct, iter, importances, S); break;
+        case 2: CPM_LAUNCH(ctx, (importance_select_kernel<MODE, MASK, 2>), grid, block, lds, st, G, s->mask, mask_words, photons8, photon_offset, ls, isect,
+                           n_light_samples, max_interactions, total_photons, fix_exit_point, pct, iter, importances, S); break;
+        case 4: CPM_LAUNCH(ctx, (importance_select_kernel<MODE, MASK, 4>), grid, block, lds, st, G, s->mask, mask_words, photons8, photon_offset, ls, isect,
+                           n_light_samples, max_interactions, total_photons, fix_exit_point, pct, iter, importances, S); break;
+        default: CPM_LAUNCH(ctx, (importance_select_kernel<MODE, MASK, 8>), grid, block, lds, st, G, s->mask, mask_words, photons8, photon_offset, ls, isect,
+                            n_light_samples, max_interactions, total_photons, fix_exit_point, pct, iter, importances, S); break;
+    }
+}
+}  // namespace
+
+extern "C" {
+
+int cpm_photon_importance_select(cpm_ctx* ctx, cpm_selection* s, const float* importance_grid, const int32_t grid_dims[3],
+                                 const float cell_size[3], const float texture_to_index[16], const float* photons8, int photon_offset,
+                                 const float* light_samples8, const float* isect2, int n_light_samples, int max_interactions,
+                                 int total_photons, int fix_exit_point, uint32_t* importances, cpm_stream stream) {
+    CPM_ENTER(ctx);
+    CPM_REQUIRE(ctx, s, "cpm_photon_importance_select: null selection");
+    CPM_REQUIRE(ctx, grid_dims && cell_size && texture_to_index, "cpm_photon_importance_select: null argument");
+    CPM_REQUIRE(ctx, n_light_samples >= 0 && photon_offset >= 0 && max_interactions >= 1 && total_photons >= 0,
+                "cpm_photon_importance_select: bad size");
+    if (n_light_samples == 0) return CPM_OK;
+    CPM_REQUIRE(ctx, importance_grid && photons8 && light_samples8 && isect2 && importances, "cpm_photon_importance_select: null buffer");
+    CPM_REQUIRE_ALIGNED16(ctx, photons8, "cpm_photon_importance_select");
+    CPM_REQUIRE_ALIGNED16(ctx, light_samples8, "cpm_photon_importance_select");
+    ImpGrid G;
+    G.grid = importance_grid;
+    unsigned long long cells = 1;
+    for (int a = 0; a < 3; ++a) {
+        CPM_REQUIRE(ctx, grid_dims[a] >= 1 && cell_size[a] > 0.f, "cpm_photon_importance_select: grid dims / cell size");
+        G.dims[a] = grid_dims[a];
+        G.cell[a] = cell_size[a];
+        cells *= (unsigned long long)grid_dims[a];
+    }
+    CPM_REQUIRE(ctx, cells < (1ull << 31), "cpm_photon_importance_select: grid too large");
+    if (!affine_from_matrix(texture_to_index, G.t2i))
+        return set_error(ctx, CPM_ERR_UNSUPPORTED, "cpm_photon_importance_select", "textureToIndex must be scale + translate");
+    uint32_t first = 0, tiles = 0;
+    int rc = selection_append(ctx, s, photon_offset, n_light_samples, &first, &tiles);
+    if (rc) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    s->last_stream = st;
+    SelTiles S{ s->tile, s->local, first, s->per_tile };
+    // occupancy mask of the grid: 1 bit per cell, staged in LDS by every workgroup (4 KiB for the 32^3 grid of a 256^3 volume);
+    // grids beyond 64 KiB of bits are walked without it
+    const size_t words = (size_t)((cells + 63) / 64) * 2;
+    const bool use_mask = words * 4 <= 64 * 1024;
+    if (use_mask) {
+        if (s->mask_words < words) {
+            if (s->mask) { CPM_HIP_CHECK(ctx, hipStreamSynchronize(st)); (void)hipFree(s->mask); s->mask = nullptr; s->mask_words = 0; }
+            CPM_HIP_CHECK(ctx, hipMalloc(&s->mask, words * 4));
+            s->mask_words = words;
+        }
+        CPM_LAUNCH(ctx, importance_mask_kernel, dim3(div_up((long long)cells, 256)), dim3(256), 0, st, importance_grid, (uint32_t)cells, s->mask);
+        CPM_LAUNCH_CHECK(ctx, "importance_mask_kernel");
+        launch_select<0, true>(ctx, s, st, tiles, words * 4, G, (uint32_t)words, photons8, photon_offset, light_samples8, isect2, n_light_samples,
+                               max_interactions, total_photons, fix_exit_point, 1, 0, importances, S);
+    } else {
+        launch_select<0, false>(ctx, s, st, tiles, 0, G, 0u, photons8, photon_offset, light_samples8, isect2, n_light_samples, max_interactions,
+                                total_photons, fix_exit_point, 1, 0, importances, S);
+    }
+    CPM_LAUNCH_CHECK(ctx, "importance_select_kernel");
+    return CPM_OK;
+}
+
+int cpm_photon_importance_equal_select(cpm_ctx* ctx, cpm_selection* s, int photon_offset, int n_light_samples, int percentage,
+                                       int iteration, uint32_t* importances, cpm_stream stream) {
+    CPM_ENTER(ctx);
+    CPM_REQUIRE(ctx, s, "cpm_photon_importance_equal_select: null selection");
+    CPM_REQUIRE(ctx, n_light_samples >= 0 && photon_offset >= 0, "cpm_photon_importance_equal_select: bad size");
+    CPM_REQUIRE(ctx, percentage >= 1 && percentage <= 100, "cpm_photon_importance_equal_select: percentage must be in [1, 100]");
+    if (n_light_samples == 0) return CPM_OK;
+    CPM_REQUIRE(ctx, importances, "cpm_photon_importance_equal_select: null buffer");
+    uint32_t first = 0, tiles = 0;
+    int rc = selection_append(ctx, s, photon_offset, n_light_samples, &first, &tiles);
+    if (rc) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    s->last_stream = st;
+    SelTiles S{ s->tile, s->local, first, s->per_tile };
+    ImpGrid G = {};
+    launch_select<1, false>(ctx, s, st, tiles, 0, G, 0u, nullptr, photon_offset, nullptr, nullptr, n_light_samples, 1, 0, 0, percentage, iteration,
+                            importances, S);
+    CPM_LAUNCH_CHECK(ctx, "importance_select_kernel");
+    return CPM_OK;
+}
+
+int cpm_selection_finish(cpm_ctx* ctx, cpm_selection* s, uint32_t* indices_out, cpm_stream stream) {
+    CPM_ENTER(ctx);
+    CPM_REQUIRE(ctx, s, "cpm_selection_finish: null selection");
+    CPM_REQUIRE(ctx, !s->finished, "cpm_selection_finish: already finished (cpm_selection_begin starts the next one)");
+    CPM_REQUIRE(ctx, indices_out || s->n_tiles == 0, "cpm_selection_finish: null indices_out");
+    hipStream_t st = (hipStream_t)stream;
+    s->last_stream = st;
+    s->finished = true;
+    ++s->epoch;
+    // (with no tiles the one workgroup only publishes a count of 0)
+    CPM_LAUNCH(ctx, selection_compact_kernel, dim3(s->n_tiles ? s->n_tiles : 1u), dim3(256), 0, st, s->tile, s->n_tiles, s->local, indices_out,
+               s->count_dev, s->mailbox_dev, s->epoch);
+    CPM_LAUNCH_CHECK(ctx, "selection_compact_kernel");
+    return CPM_OK;
+}
+
+const int32_t* cpm_selection_count_device(const cpm_selection* s) { return s ? s->count_dev : nullptr; }
+
+int cpm_selection_count(cpm_ctx* ctx, cpm_selection* s, int32_t* n_out) {
+    CPM_ENTER(ctx);
+    CPM_REQUIRE(ctx, s && n_out, "cpm_selection_count: null argument");
+    *n_out = 0;
+    if (s->epoch == 0) return CPM_OK;  // nothing was ever selected
+    // the compaction kernel of the last finish writes (epoch << 32 | count) into pinned host memory; everything enqueued
+    // behind it keeps running while the host reads it
+    const volatile unsigned long long* mb = s->mailbox;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (unsigned spin = 0;; ++spin) {
+        const unsigned long long v = __atomic_load_n(mb, __ATOMIC_ACQUIRE);
+        if ((uint32_t)(v >> 32) == s->epoch) { *n_out = (int32_t)(uint32_t)v; return CPM_OK; }
+        if ((spin & 1023u) == 1023u && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(2)) break;
+        __builtin_ia32_pause();
+    }
+    // the mailbox did not arrive (a stream that is not running?): fall back to the stream itself
+    CPM_HIP_CHECK(ctx, hipStreamSynchronize(s->last_stream));
+    const unsigned long long v = __atomic_load_n(mb, __ATOMIC_ACQUIRE);
+    if ((uint32_t)(v >> 32) == s->epoch) { *n_out = (int32_t)(uint32_t)v; return CPM_OK; }
+    CPM_HIP_CHECK(ctx, hipMemcpy(n_out, s->count_dev, sizeof(int32_t), hipMemcpyDeviceToHost));
     return CPM_OK;
 }
 

@@ -1076,6 +1076,49 @@ __global__ __launch_bounds__(256) void mark_bricks_kernel(const float* __restric
                 mask[(size_t)bx + (size_t)bxn * ((size_t)by + (size_t)byn * (size_t)bz)] = 1;  // same value from every writer
 }
 
+CPM_DEV void mark_bricks_of(const GridDev& G, f3 p, float radius, int bxn, int byn, uint8_t* __restrict__ mask) {
+    if (p.x == kFltMax || p.y == kFltMax || p.z == kFltMax) return;
+    const Box3 bb = splat_box(G, p, radius);
+    if (bb.ex <= bb.sx || bb.ey <= bb.sy || bb.ez <= bb.sz) return;
+    for (int bz = bb.sz >> 2; bz <= (bb.ez - 1) >> 2; ++bz)
+        for (int by = bb.sy >> 2; by <= (bb.ey - 1) >> 2; ++by)
+            for (int bx = bb.sx >> 2; bx <= (bb.ex - 1) >> 2; ++bx)
+                mask[(size_t)bx + (size_t)bxn * ((size_t)by + (size_t)byn * (size_t)bz)] = 1;
+}
+
+// splatSelectedPhotonsToLightVolumeKernel twice (photonstolightvolume.cl:168-202 as called at
+// processor/photontolightvolumeprocessorcl.cpp:268-274) in one launch over a device-side count: thread 2j removes the record
+// selected photon j had before its re-trace (old_photons[k * old_stride + j]), thread 2j + 1 adds the one it has now.
+__global__ __launch_bounds__(256) void splat_delta_kernel(const float* __restrict__ old_photons, uint32_t old_stride,
+                                                          const float* __restrict__ photons, const uint32_t* __restrict__ indices,
+                                                          const int32_t* __restrict__ n_dev, int max_n, int apply_below, GridDev G,
+                                                          float radius, float k, int n_photons, int n_interactions, int bxn, int byn,
+                                                          uint8_t* __restrict__ mask, float* __restrict__ out) {
+    const int n = min(*n_dev, max_n);
+    if (apply_below > 0 && n >= apply_below) return;
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int j = t >> 1;
+    if (j >= n) return;
+    const bool add = t & 1;
+    const size_t id = indices[j];
+    for (int it = 0; it < n_interactions; ++it) {
+        const float4* qo = reinterpret_cast<const float4*>(old_photons) + 2 * ((size_t)it * old_stride + (size_t)j);
+        const float4* qn = reinterpret_cast<const float4*>(photons) + 2 * ((size_t)it * n_photons + id);
+        const float4 oa = qo[0], ob = qo[1], na = qn[0], nb = qn[1];
+        // the same record before and after: its two splats cancel term by term
+        if (__float_as_uint(oa.x) == __float_as_uint(na.x) && __float_as_uint(oa.y) == __float_as_uint(na.y) && __float_as_uint(oa.z) == __float_as_uint(na.z) &&
+            __float_as_uint(oa.w) == __float_as_uint(na.w) && __float_as_uint(ob.x) == __float_as_uint(nb.x) && __float_as_uint(ob.y) == __float_as_uint(nb.y))
+            continue;
+        const float4 a = add ? na : oa, b = add ? nb : ob;
+        const float m = add ? 1.f : -1.f;
+        f3 p = { a.x, a.y, a.z };
+        f3 pw = { a.w * k, b.x * k, b.y * k };
+        pw.x *= m; pw.y *= m; pw.z *= m;
+        splat_photon(out, G, p, pw, radius);
+        if (mask) mark_bricks_of(G, p, radius, bxn, byn, mask);
+    }
+}
+
 int key_bits_for(uint32_t max_key) {  // bits needed to represent max_key
     int b = 1;
     while (b < 32 && (max_key >> b) != 0) ++b;
@@ -1127,6 +1170,27 @@ int cpm_splat_selected(cpm_ctx* ctx, const float* photons8, const uint32_t* indi
     CPM_LAUNCH(ctx, splat_selected_kernel, dim3(div_up(n_indices, 256)), dim3(256), 0, (hipStream_t)stream, photons8,
                        indices, n_indices, G, radius, k, multiplier, n_photons, n_interactions, grid_out);
     CPM_LAUNCH_CHECK(ctx, "splat_selected_kernel");
+    return CPM_OK;
+}
+
+int cpm_splat_delta(cpm_ctx* ctx, const float* old_photons8, int old_stride, const float* photons8, const uint32_t* indices,
+                    const int32_t* n_indices_dev, int max_indices, int apply_below, const cpm_grid_desc* grid, float radius,
+                    float scale, int n_photons, int n_interactions, uint8_t* brick_mask, float* grid_out, cpm_stream stream) {
+    CPM_ENTER(ctx);
+    GridDev G;
+    int rc = make_grid_dev(ctx, grid, G);
+    if (rc) return rc;
+    CPM_REQUIRE(ctx, max_indices >= 0 && old_stride >= max_indices && n_photons >= 0 && n_interactions >= 1 && radius > 0.f, "cpm_splat_delta: bad size");
+    CPM_REQUIRE(ctx, max_indices < (1 << 30), "cpm_splat_delta: too many indices");
+    if (max_indices == 0) return CPM_OK;
+    CPM_REQUIRE(ctx, old_photons8 && photons8 && indices && n_indices_dev && grid_out, "cpm_splat_delta: null buffer");
+    CPM_REQUIRE_ALIGNED16(ctx, photons8, "cpm_splat_delta");
+    CPM_REQUIRE_ALIGNED16(ctx, old_photons8, "cpm_splat_delta");
+    const float k = kInv4Pi * scale;
+    CPM_LAUNCH(ctx, splat_delta_kernel, dim3((unsigned)div_up(2ll * max_indices, 256)), dim3(256), 0, (hipStream_t)stream, old_photons8,
+               (uint32_t)old_stride, photons8, indices, n_indices_dev, max_indices, apply_below, G, radius, k, n_photons, n_interactions,
+               div_up(G.dx, 4), div_up(G.dy, 4), brick_mask, grid_out);
+    CPM_LAUNCH_CHECK(ctx, "splat_delta_kernel");
     return CPM_OK;
 }
 

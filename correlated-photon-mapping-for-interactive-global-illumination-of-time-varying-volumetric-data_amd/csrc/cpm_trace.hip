@@ -9,10 +9,11 @@
 //     ~quarter-voxel-apart rays: the 8 trilinear corners of neighbouring lanes share cache
 //     lines, which is the property the reference's index sort preserves
 //     (processor/progressivephotontracercl.cpp:467-473).
-//   * CDNA4 has no sampler hardware.  The image3d_t fetch becomes 4 paired loads (the two
-//     x-neighbours of a corner pair are adjacent bytes: one 2/4/8-byte load for u8/u16/f32)
-//     plus 7 two-fma lerps; the clamp-to-edge rule is applied to the coordinate so the pair
-//     is always in range (DESIGN.md "Arithmetic contract").
+//   * CDNA4 has no sampler hardware.  The image3d_t fetch becomes ONE load of the sample's 2 x 2 x 2
+//     footprint from the footprint-ordered copy of the volume (cpm_volume::quads: two neighbouring
+//     elements = 8 / 16 / 32 bytes for u8 / u16 / f32) plus 7 two-fma lerps; the clamp-to-edge rule
+//     is applied to the coordinate and built into the copy's last row / slice, so the footprint is
+//     always in range (DESIGN.md "Arithmetic contract").
 //   * the transfer function is read only through its alpha channel (color.w, scattering.w):
 //     the alpha column is staged once per workgroup into LDS (width*4 bytes = 4 KiB for
 //     Inviwo's 1024-texel LUT) and sampled with two ds_read + one lerp.
@@ -47,6 +48,12 @@ struct TraceArgs {
     const float* isect;
     const uint32_t* recompute_indices;
     int n_threads;
+    // cpm_trace_selected: the number of indices lives on the device (nullable: n_threads is it); the records about to be
+    // overwritten are kept in old_photons[k * old_stride + j]; the traced photons' importance keys are reset
+    const int32_t* n_threads_dev;
+    float* old_photons;
+    uint32_t old_stride;
+    uint32_t* reset_importances;
     uint32_t* rng;
     float* photons;
     unsigned long long* step_counter;  // nullable (statistics build of the launch)
@@ -225,7 +232,12 @@ __global__ __launch_bounds__(256, 8) void trace_kernel(const TraceArgs A) {
     }
     const int gid = chunk * blockDim.x + threadIdx.x;
     int threadId = gid;
-    bool live = gid < A.n_threads;
+    int nThreads = A.n_threads;
+    if (A.n_threads_dev) {  // cpm_trace_selected: the launch covers the budget, the count says how much of it is work
+        nThreads = min(nThreads, *A.n_threads_dev);
+        if (chunk * (int)blockDim.x >= nThreads) return;  // the whole workgroup, before anything is staged
+    }
+    bool live = gid < nThreads;
     if (live && A.recompute_indices) {  // -D PHOTON_RECOMPUTATION (photontracer.cl:97-106)
         threadId = (int)A.recompute_indices[gid] - A.p.photon_offset;
         live = threadId >= 0 && threadId < A.p.n_light_samples;
@@ -234,6 +246,14 @@ __global__ __launch_bounds__(256, 8) void trace_kernel(const TraceArgs A) {
     const uint32_t maxInteractions = (uint32_t)A.p.max_interactions;
     const size_t totalPhotons = (size_t)A.p.total_photons;
     uint2* rng = reinterpret_cast<uint2*>(A.rng);
+    if (live && A.old_photons) {  // what the light-volume update subtracts: the records this thread is about to replace
+        for (uint32_t k = 0; k < maxInteractions; ++k) {
+            const float4* q = reinterpret_cast<const float4*>(A.photons) + 2 * ((size_t)photonOffset + k * totalPhotons + (size_t)threadId);
+            float4* o = reinterpret_cast<float4*>(A.old_photons) + 2 * ((size_t)k * A.old_stride + (size_t)gid);
+            const float4 a = q[0], b = q[1];
+            o[0] = a; o[1] = b;
+        }
+    }
     // this lane's inputs, requested before the LUT is staged so that the loads overlap it
     float4 l0 = make_float4(0.f, 0.f, 0.f, 0.f), l1 = l0;
     float2 ip = make_float2(0.f, -1.f);
@@ -376,6 +396,7 @@ __global__ __launch_bounds__(256, 8) void trace_kernel(const TraceArgs A) {
         write_photon(A.photons, photonId, p, pw, th, ph);
     }
     if (A.p.flags & CPM_TRACE_PROGRESSIVE) rng[photonOffset + threadId] = make_uint2(rx, rc);  // :211-215
+    if (A.reset_importances) A.reset_importances[photonOffset + threadId] = 2147483647u;  // resetPhotonImportance (tracercl.cpp:529)
     if (A.step_counter) {
         // statistics only: wave-level sum, one atomic per wave
         unsigned s = steps;
@@ -401,10 +422,16 @@ void cpm_debug_set_step_counter(cpm_ctx* ctx, unsigned long long* dev_counter) {
 namespace {
 __global__ void emit_hint_kernel(Light L, float* __restrict__ hint) { directional_hint_(L, hint); }
 
+struct SelectedArgs {  // cpm_trace_selected's extras
+    const int32_t* n_dev = nullptr;
+    float* old_photons = nullptr;
+    uint32_t* reset_importances = nullptr;
+};
+
 int trace_impl(cpm_ctx* ctx, const cpm_volume* vol, const cpm_tf* tf, const cpm_tf* tf_scattering, const float aabb[8],
                const cpm_trace_params* params, const float* light_samples8, const float* isect2, const cpm_emitter_desc* emitter,
                const uint32_t* recompute_indices, int n_recompute, uint32_t* rng_state, float* photons8,
-               cpm_stream stream) {
+               cpm_stream stream, const SelectedArgs& sel = SelectedArgs()) {
     CPM_ENTER(ctx);
     CPM_REQUIRE(ctx, vol && tf && aabb && params, "cpm_trace: null argument");
     const cpm_trace_params& p = *params;
@@ -456,6 +483,11 @@ int trace_impl(cpm_ctx* ctx, const cpm_volume* vol, const cpm_tf* tf, const cpm_
     A.isect = isect2;
     A.recompute_indices = recompute_indices;
     A.n_threads = n_threads;
+    A.n_threads_dev = sel.n_dev;
+    A.old_photons = sel.old_photons;
+    A.old_stride = (uint32_t)n_threads;
+    A.reset_importances = sel.reset_importances;
+    if (sel.old_photons) CPM_REQUIRE_ALIGNED16(ctx, sel.old_photons, "cpm_trace_selected");
     A.rng = rng_state;
     A.photons = photons8;
     A.step_counter = ctx->dbg.step_counter;
@@ -515,6 +547,19 @@ int cpm_trace(cpm_ctx* ctx, const cpm_volume* vol, const cpm_tf* tf, const cpm_t
               cpm_stream stream) {
     return trace_impl(ctx, vol, tf, tf_scattering, aabb, params, light_samples8, isect2, nullptr, recompute_indices, n_recompute,
                       rng_state, photons8, stream);
+}
+
+int cpm_trace_selected(cpm_ctx* ctx, const cpm_volume* vol, const cpm_tf* tf, const cpm_tf* tf_scattering, const float aabb[8],
+                       const cpm_trace_params* params, const float* light_samples8, const float* isect2, const uint32_t* indices,
+                       const int32_t* n_indices_dev, int max_indices, float* old_photons8, uint32_t* reset_importances,
+                       uint32_t* rng_state, float* photons8, cpm_stream stream) {
+    if (ctx && !(indices && n_indices_dev)) return set_error(ctx, CPM_ERR_INVALID_ARGUMENT, "cpm_trace_selected", "null indices / count");
+    SelectedArgs sel;
+    sel.n_dev = n_indices_dev;
+    sel.old_photons = old_photons8;
+    sel.reset_importances = reset_importances;
+    return trace_impl(ctx, vol, tf, tf_scattering, aabb, params, light_samples8, isect2, nullptr, indices, max_indices, rng_state, photons8,
+                      stream, sel);
 }
 
 int cpm_trace_emitted(cpm_ctx* ctx, const cpm_volume* vol, const cpm_tf* tf, const cpm_tf* tf_scattering, const float aabb[8],

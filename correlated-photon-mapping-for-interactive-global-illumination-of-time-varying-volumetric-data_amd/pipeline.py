@@ -510,13 +510,25 @@ class CorrelatedPhotonMapper(PhotonFrame):
         self.remaining = -1
         self.n_recomputed = -1
         self.last_path = None
+        # the update without a host round trip (cpm_selection_*, cpm_trace_selected, cpm_splat_delta): taken when every changed
+        # photon is traced in the same evaluation (budget = 100 %, the default) and the update is the reference's add-remove
+        self.selection = None
+        self.old_photons = None
+        self.fused = True
 
     def full_frame(self):
         """Light / everything changed: full trace, bin + gather, snapshot (tracercl.cpp:541-560)."""
         self.trace()
         self._full_light_volume()
         self.ctx.reset_importance(self.importance, 0, self.n)
-        self.prev_photons = self.photons.clone()
+        # the previous-photon snapshot (a whole-buffer copy per evaluation in the reference, processorcl.cpp:343-352) is only
+        # kept where the legacy add-remove reads it; the fused update's tracer keeps the records it replaces itself
+        self.have_frame = True
+        if self._fused_configured():
+            self._prev_stale = True
+        else:
+            self.prev_photons = self.photons.clone()
+            self._prev_stale = False
         self.n_recomputed = -1
         self.remaining, self.remaining_offset = 0, 0
         self.last_path = "full"
@@ -583,11 +595,61 @@ class CorrelatedPhotonMapper(PhotonFrame):
         self._vol_next = previous if previous_is_own else None
         self.minmax, self._minmax_next = self._minmax_next, self.minmax
 
+    def _fused_configured(self):
+        return self.fused and not self.exact_update and self.max_incremental_percent >= 100.0 and self.emitter is None
+
+    def _fused_available(self):
+        return self._fused_configured() and getattr(self, "have_frame", False)
+
+    def correlated_update_fused(self):
+        """The same evaluation with the count kept on the device: importance + threshold + tile lists in one launch, the lists
+        lined up by a second, the tracer and the - old / + new splat launched over the budget and bounded by the device count.
+        The host reads the count once, after everything is enqueued (from the selection's mailbox).  Returns n re-traced."""
+        ctx, torch = self.ctx, self.torch
+        n_total = self.n
+        if self.selection is None:
+            self.selection = ctx.selection_create(n_total)
+            self.old_photons = torch.empty((self.I * n_total, 8), dtype=torch.float32, device=ctx.device)
+        sel = self.selection
+        sel.begin()
+        sel.photon_importance(self.importance_grid, self.brick_dims, (float(self.region),) * 3, list(self.vol.desc.texture_to_index),
+                              self.photons, 0, self.light_samples, self.isect, n_total, self.I, n_total, self.importance,
+                              fix_exit_point=self.fix_exit_point)
+        sel.finish(self.indices)
+        self.params.flags = 0                            # correlated: RNG state is NOT written back
+        ctx.trace_selected(self.vol, self.tf, self.aabb, self.params, self.light_samples, self.isect, self.indices, sel, n_total,
+                           self.rng, self.photons, old_photons=self.old_photons, reset_importances=self.importance)
+        max_recomp = int(self.n * (self.incremental_threshold_percent / 100.0))
+        if self.touched_mask is not None:
+            self.touched_mask.zero_()
+        ctx.splat_delta(self.old_photons, n_total, self.photons, self.indices, sel, n_total, self.grid, self.radius, self.scale,
+                        self.n, self.I, self.light_volume, apply_below=max(max_recomp, 1), brick_mask=self.touched_mask)
+        n = sel.count()                                  # the one host read, behind everything enqueued
+        self.n_recomputed = n
+        self.remaining, self.remaining_offset = 0, n
+        if n == 0:
+            self.last_path = "unchanged"
+        elif n < max_recomp:
+            self.last_path = "incremental"
+        else:                                            # the delta launch stood aside: rebuild (processorcl.cpp:299-339)
+            self._full_light_volume()
+            self.last_path = "full"
+            if self.touched_mask is not None:
+                self.touched_mask.fill_(1)
+        # (no snapshot to refresh: the tracer kept the records it replaced; prev_photons stays allocated for the legacy path only)
+        self._prev_stale = True
+        return n
+
     def correlated_update(self):
         """One evaluation of the importance branch + the light-volume processor.  Returns n re-traced."""
         ctx, torch = self.ctx, self.torch
         n_total = self.n
         vd = self.vol.dims
+        if self._fused_available():
+            return self.correlated_update_fused()
+        if getattr(self, "_prev_stale", False) and getattr(self, "have_frame", False):   # the fused path does not maintain the snapshot
+            self.prev_photons = self.photons.clone()
+            self._prev_stale = False
         ctx.photon_importance(self.importance_grid, self.brick_dims, (float(self.region),) * 3,
                               list(self.vol.desc.texture_to_index), self.photons, 0, self.light_samples, self.isect,
                               n_total, self.I, n_total, self.importance, fix_exit_point=self.fix_exit_point)
@@ -648,6 +710,8 @@ class CorrelatedPhotonMapper(PhotonFrame):
             self.bin()
             ctx.gather_bricks(self.sorted, self.cell_start, self.n * self.I, self.grid, self.radius, self.scale, self.brick_mask,
                               self.light_volume)
+            if self.touched_mask is not None:   # multi-GPU delta reduce: the re-gathered bricks are the ones that changed
+                self.touched_mask.copy_(self.brick_mask)
             self.last_path = "exact incremental"
         elif self.prev_photons is not None and 0 < n < max_recomp:
             # incremental: remove the old contributions, add the new ones (processorcl.cpp:196-298)

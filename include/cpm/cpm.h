@@ -390,7 +390,7 @@ int cpm_volume_difference(cpm_ctx* ctx, const cpm_volume* cur, const cpm_volume*
 /* importance[c] = sum of the 4 channel-wise (max - min) of the piecewise-linear
  * TF-difference colour over the brick's [min, max] data range
  * (-D INCREMENTAL_TF_IMPORTANCE).  positions/colors: n_points host arrays
- * (tens of points; copied to the device by this call).
+ * (tens of points; consumed by the time the call returns: up to 48 ride in the kernel arguments, no copy is enqueued).
  * Replaces classifyMinMaxUniformGrid3DImportanceKernel
  * (ref importancesamplingcl/cl/minmaxuniformgrid3dimportance.cl:269-289).
  * prev_minmax2 / volume_diff non-NULL: the time-varying variant
@@ -444,6 +444,88 @@ int cpm_select_recompute(cpm_ctx* ctx, uint32_t* importances, size_t n, uint32_t
  * (ref cl/threshold.cl:33-40, cl/indextobuffer.cl:33-40, ...tracercl.cpp:325-356). */
 int cpm_select_changed(cpm_ctx* ctx, const uint32_t* importances, size_t n, uint32_t* indices_out,
                        int32_t* n_changed_dev, cpm_stream stream);
+
+/* ---- the correlated update without a host round trip (BASELINE configs 3 and 5)
+ *
+ * The reference's importance branch (ref processor/progressivephotontracercl.cpp:298-374) is a chain of small launches
+ * around one host wait: detector kernel per light, threshold, reduce, iota, 31-bit sort, a 4-byte read-back the host
+ * blocks on (:343-345,374), keys-only sort, tracer, and in the light-volume processor two selected splats and a
+ * 32 MiB snapshot copy (ref processor/photontolightvolumeprocessorcl.cpp:196-298,343-352).  On this GPU each small launch
+ * costs its latency and the wait drains the queue, so the chain cost more than re-tracing everything.  The entry points
+ * below are the same computation with the count kept on the device:
+ *
+ *   cpm_selection_begin
+ *   cpm_photon_importance_select   (per light)  detector kernel + threshold + per-tile count + tile-local index lists
+ *   cpm_selection_finish                        tile lists -> ascending index list, count -> device word + host mailbox
+ *   cpm_trace_selected             (per light)  -D PHOTON_RECOMPUTATION tracer over the DEVICE count; keeps the records it
+ *                                               overwrites (what prevPhotons_ is for) and resets the photons' importance
+ *   cpm_splat_delta                             - old + new atomic splat of the re-traced photons in one launch
+ *
+ * Results are those of cpm_photon_importance + cpm_select_changed + cpm_trace + cpm_reset_importance +
+ * cpm_splat_selected(-1, snapshot) + cpm_splat_selected(+1) bit for bit (the splat sums within atomic-order tolerance).
+ * It covers the case in which every changed photon is traced in this evaluation (maxIncrementalPhotonsToUpdate = 100 %,
+ * the default); a smaller budget needs the ranking by importance and takes cpm_select_recompute with its host decision. */
+
+typedef struct cpm_selection cpm_selection;
+
+/* State of one selection over at most max_photons photons: tile counts, tile-local lists, the count word and its
+ * host-visible mailbox (pinned host memory the compaction kernel writes; cpm_selection_count polls it, no stream sync). */
+int cpm_selection_create(cpm_ctx* ctx, size_t max_photons, cpm_selection** out);
+void cpm_selection_destroy(cpm_ctx* ctx, cpm_selection* sel);
+/* Start a new selection (host bookkeeping only; nothing is enqueued). */
+int cpm_selection_begin(cpm_ctx* ctx, cpm_selection* sel);
+
+/* cpm_photon_importance for one light, fused with thresholdKernel and the count: importances[photon_offset + i] is
+ * updated exactly as by cpm_photon_importance, and the photons left with a key < 0x7fffffff are listed per tile.
+ * The importance grid is walked through a one-bit-per-cell occupancy mask staged in LDS (built by a small launch from the
+ * grid handed in): cells with importance +0 are not loaded, the sums are the same floats.
+ * Replaces photonRecomputationDetectorKernel + thresholdKernel + clogs::Reduce + indexToBufferKernel
+ * (ref cl/photonrecomputationdetector.cl:92-157, cl/threshold.cl:33-40, cl/indextobuffer.cl:33-40,
+ *  processor/progressivephotontracercl.cpp:298-356). */
+int cpm_photon_importance_select(cpm_ctx* ctx, cpm_selection* sel, const float* importance_grid,
+                                 const int32_t grid_dims[3], const float cell_size[3],
+                                 const float texture_to_index[16], const float* photons8, int photon_offset,
+                                 const float* light_samples8, const float* isect2, int n_light_samples,
+                                 int max_interactions, int total_photons, int fix_exit_point,
+                                 uint32_t* importances, cpm_stream stream);
+/* The equal-importance detector (ref ...detector.cl:160-194) in the same fused form. */
+int cpm_photon_importance_equal_select(cpm_ctx* ctx, cpm_selection* sel, int photon_offset, int n_light_samples,
+                                       int percentage, int iteration, uint32_t* importances, cpm_stream stream);
+
+/* indices_out[0 .. count) = the selected photons of all lights, ascending (what cpm_select_changed leaves in the first
+ * part of its list; the rest of indices_out is not written); count -> cpm_selection_count_device and the mailbox. */
+int cpm_selection_finish(cpm_ctx* ctx, cpm_selection* sel, uint32_t* indices_out, cpm_stream stream);
+const int32_t* cpm_selection_count_device(const cpm_selection* sel);
+/* The count of the last cpm_selection_finish on the host: waits for the mailbox write of THAT launch (a poll of pinned
+ * memory; later work in the stream keeps running), not for the stream.  Replaces the blocking wait on the reduce's
+ * read-back (ref processor/progressivephotontracercl.cpp:343-345,374). */
+int cpm_selection_count(cpm_ctx* ctx, cpm_selection* sel, int32_t* n_out);
+
+/* cpm_trace's recompute variant with the number of indices read on the device: thread j < min(*n_indices_dev, max_indices)
+ * traces light sample indices[j] - photon_offset (threads whose index falls outside this light's range do nothing, as in
+ * cpm_trace).  old_photons8 (nullable): before a record is overwritten it is copied to old_photons8[k * max_indices + j]
+ * (interaction k) -- the previous-photon snapshot of exactly the re-traced photons.  reset_importances (nullable):
+ * reset_importances[indices[j]] = 0x7fffffff for every traced photon (resetPhotonImportance, ref
+ * processor/progressivephotontracercl.cpp:529,607-611).
+ * Replaces PhotonTracerCL::tracePhotons with indices (ref photontracercl.cpp:135-174; cl/photontracer.cl:97-106). */
+int cpm_trace_selected(cpm_ctx* ctx, const cpm_volume* vol, const cpm_tf* tf, const cpm_tf* tf_scattering,
+                       const float aabb[8], const cpm_trace_params* params, const float* light_samples8,
+                       const float* isect2, const uint32_t* indices, const int32_t* n_indices_dev, int max_indices,
+                       float* old_photons8, uint32_t* reset_importances, uint32_t* rng_state, float* photons8,
+                       cpm_stream stream);
+
+/* grid += splat(photons[indices[j] + k n_photons]) - splat(old_photons8[k old_stride + j]), j < *n_indices_dev,
+ * k < n_interactions, in one launch; a photon whose old and new records are the same bits adds nothing (the reference's
+ * two splats cancel for it up to rounding).  Does nothing when *n_indices_dev >= apply_below (> 0): the caller then
+ * rebuilds the volume (the incremental-or-full threshold, ref processor/photontolightvolumeprocessorcl.cpp:196,299,
+ * evaluated where the count lives).  brick_mask (nullable): the 4x4x4-voxel bricks an old or new splat box overlaps
+ * are marked as by cpm_mark_touched_bricks (multi-GPU delta reduce).
+ * Replaces splatSelectedPhotonsToLightVolumeKernel x 2 (ref cl/photonstolightvolume.cl:168-202;
+ * processor/photontolightvolumeprocessorcl.cpp:268-274). */
+int cpm_splat_delta(cpm_ctx* ctx, const float* old_photons8, int old_stride, const float* photons8,
+                    const uint32_t* indices, const int32_t* n_indices_dev, int max_indices, int apply_below,
+                    const cpm_grid_desc* grid, float radius, float relative_irradiance_scale, int n_photons,
+                    int n_interactions, uint8_t* brick_mask, float* grid_out, cpm_stream stream);
 
 /* ------------------------------------------------------------------ temporal interpolation (time-varying data) */
 
