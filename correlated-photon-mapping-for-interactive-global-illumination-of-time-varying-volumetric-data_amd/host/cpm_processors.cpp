@@ -325,6 +325,70 @@ void PhotonTracerCL::tracePhotons(const Volume* volume, const TransferFunction& 
              "cpm_trace");
 }
 
+int RecomputedPhotonIndices::resolveCount() {
+    if (countPending && selection) {
+        auto& rt = CpmRuntime::get();
+        int32_t n = 0;
+        if (rt.check(cpm_selection_count(rt.ctx(), selection, &n), "cpm_selection_count")) nRecomputedPhotons = n;
+        countPending = false;
+    }
+    return nRecomputedPhotons;
+}
+
+void PhotonTracerCL::tracePhotonsSelected(const Volume* volume, const TransferFunction& transferFunction, const float aabb[8],
+                                          const AdvancedMaterialProperty& material, float stepSize, const LightSamples* lightSamples,
+                                          const Buffer<unsigned int>* indices, const int32_t* nIndicesDevice, int maxIndices, vec4* replacedPhotons,
+                                          unsigned int* resetImportances, int photonOffset, int maxInteractions, PhotonData* photonOutData) {
+    auto& rt = CpmRuntime::get();
+    if (!rt.valid()) return;
+    if (randomState_.getSize() != photonOutData->getNumberOfPhotons()) setRandomSeedSize(photonOutData->getNumberOfPhotons());
+    cpm_volume* vol_ = volume->getDeviceRepresentation();
+    syncTF(transferFunction);
+    if (!vol_ || !tf_) return;
+    cpm_trace_params p = {};
+    const vec4 m = material.getCombinedMaterialParameters();
+    p.material[0] = m.x; p.material[1] = m.y; p.material[2] = m.z; p.material[3] = m.w;
+    p.step_size = stepSize;
+    p.photon_offset = photonOffset;
+    p.n_light_samples = (int)lightSamples->getSize();
+    p.max_interactions = maxInteractions;
+    p.total_photons = (int)photonOutData->getNumberOfPhotons();
+    p.shading_type = material.getPhaseFunctionEnum();
+    p.flags = (onlyMultipleScattering_ ? CPM_TRACE_NO_SINGLE_SCATTERING : 0) | (progressive_ ? CPM_TRACE_PROGRESSIVE : 0);
+    p.iteration = photonOutData->iteration();
+    rt.check(cpm_trace_selected(rt.ctx(), vol_, tf_, nullptr, aabb, &p, reinterpret_cast<const float*>(lightSamples->getLightSamples()->device()),
+                                reinterpret_cast<const float*>(lightSamples->getIntersectionPoints()->device()), indices->device(), nIndicesDevice,
+                                maxIndices, reinterpret_cast<float*>(replacedPhotons), resetImportances,
+                                reinterpret_cast<uint32_t*>(randomState_.device()), reinterpret_cast<float*>(photonOutData->photons_.device()), rt.stream()),
+             "cpm_trace_selected");
+}
+
+void PhotonRecomputationDetector::photonRecomputationImportanceSelect(cpm_selection* selection, const PhotonData* photonData, int photonOffset,
+                                                                      const Volume* origVolume, const ImportanceUniformGrid3D* grid,
+                                                                      const LightSamples& lightSamples, Buffer<unsigned int>& imp, bool fixExitPoint) {
+    auto& rt = CpmRuntime::get();
+    if (!rt.valid()) return;
+    if (imp.getSize() != photonData->getNumberOfPhotons()) imp.setSize(photonData->getNumberOfPhotons());
+    if (getEqualImportance()) {
+        rt.check(cpm_photon_importance_equal_select(rt.ctx(), selection, photonOffset, (int)lightSamples.getSize(), getPercentage(), getIteration(),
+                                                    imp.device(), rt.stream()), "cpm_photon_importance_equal_select");
+        return;
+    }
+    const size3_t gd = grid->getDimensions(), cd = grid->getCellDimension(), vd = origVolume->getDimensions();
+    const int32_t dims[3] = { (int32_t)gd.x, (int32_t)gd.y, (int32_t)gd.z };
+    const float cell[3] = { (float)cd.x, (float)cd.y, (float)cd.z };
+    cpm_volume_desc d;
+    const int32_t vdims[3] = { (int32_t)vd.x, (int32_t)vd.y, (int32_t)vd.z };
+    cpm_volume_desc_default(&d, vdims, origVolume->dtype());
+    rt.check(cpm_photon_importance_select(rt.ctx(), selection, grid->data.device(), dims, cell, d.texture_to_index,
+                                          reinterpret_cast<const float*>(photonData->photons_.device()), photonOffset,
+                                          reinterpret_cast<const float*>(lightSamples.getLightSamples()->device()),
+                                          reinterpret_cast<const float*>(lightSamples.getIntersectionPoints()->device()), (int)lightSamples.getSize(),
+                                          photonData->getMaxPhotonInteractions(), (int)photonData->getNumberOfPhotons(), fixExitPoint ? 1 : 0, imp.device(),
+                                          rt.stream()),
+             "cpm_photon_importance_select");
+}
+
 void PhotonRecomputationDetector::photonRecomputationImportance(const PhotonData* photonData, int photonOffset, const Volume* origVolume,
                                                                 const ImportanceUniformGrid3D* grid, const LightSamples& lightSamples,
                                                                 Buffer<unsigned int>& imp) {
@@ -517,18 +581,31 @@ void MinMaxUniformGrid3DImportanceCLProcessor::process() {  // minmaxuniformgrid
     const size3_t d = minMax->getDimensions();
     const size3_t cur = importance_->getDimensions();
     if (cur.x != d.x || cur.y != d.y || cur.z != d.z) { importance_->setDimensions(d); importance_->setCellDimension(minMax->getCellDimension()); }
+    const bool volumeChanged = minMaxUniformGrid3DInport_.changedSinceLastCheck();  // minMaxUniformGrid3DInport_.onChange (:73-74)
     if (tfChanged_) {
         if (prevTransferFunction_.size() == 0 || !incrementalImportance) updateTransferFunctionData();
         else updateTransferFunctionDifferenceData();
         prevTransferFunction_ = transferFunction_;
         tfChanged_ = false;
-    } else if (positions_.empty()) {
+    } else if (volumeChanged || positions_.empty()) {  // InvalidationReason::Volume (:134-136): importance of a range = the TF itself
         updateTransferFunctionData();
     }
     const int nElements = (int)(d.x * d.y * d.z);
-    rt.check(cpm_importance_tf(rt.ctx(), minMax->data.device(), nullptr, nullptr, nElements, positions_.data(), reinterpret_cast<const float*>(colors_.data()),
-                               (int)positions_.size(), importance_->data.device(), rt.stream()),
-             "cpm_importance_tf");
+    if (volumeDifferenceInfoInport_.isReady() && prevMinMaxUniformGrid3D_ != nullptr && prevMinMaxUniformGrid3D_.get() != minMax.get()) {
+        // time-varying data changed (:149-190): importance x mean |v_(t+1) - v_t| over the union of the old and new brick ranges
+        auto diff = std::dynamic_pointer_cast<DynamicVolumeInfoUniformGrid3D>(volumeDifferenceInfoInport_.getData());
+        if (!diff) { LogError("volumeDifferenceInfoInport_ expects DynamicVolumeInfoUniformGrid3D as input"); return; }
+        if (!diff->hasDeviceData()) diff->uploadHostData();
+        auto* prev = const_cast<MinMaxUniformGrid3D*>(prevMinMaxUniformGrid3D_.get());
+        rt.check(cpm_importance_tf(rt.ctx(), minMax->data.device(), prev->data.device(), diff->data.device(), nElements, positions_.data(),
+                                   reinterpret_cast<const float*>(colors_.data()), (int)positions_.size(), importance_->data.device(), rt.stream()),
+                 "cpm_importance_tf(time-varying)");
+    } else {
+        rt.check(cpm_importance_tf(rt.ctx(), minMax->data.device(), nullptr, nullptr, nElements, positions_.data(), reinterpret_cast<const float*>(colors_.data()),
+                                   (int)positions_.size(), importance_->data.device(), rt.stream()),
+                 "cpm_importance_tf");
+    }
+    prevMinMaxUniformGrid3D_ = minMax;  // :212-213
     importanceUniformGrid3DOutport_.setData(importance_);
 }
 
@@ -540,7 +617,7 @@ ProgressivePhotonTracerCL::ProgressivePhotonTracerCL() {
     for (PropertyBase* p : std::initializer_list<PropertyBase*>{ &samplingRate_, &radius_, &sceneRadianceScaling_, &maxIncrementalPhotonsToUpdate_,
                                                                 &equalIncrementalImportance_, &spatialSorting_, &maxScatteringEvents_, &noSingleScattering_,
                                                                 &alphaProp_, &workGroupSize_, &useGLSharing_, &enableProgressiveRefinement_,
-                                                                &enableProgressivePhotonRecomputation_, &clipX_, &clipY_, &clipZ_ })
+                                                                &enableProgressivePhotonRecomputation_, &clipX_, &clipY_, &clipZ_, &fusedImportanceBranch_ })
         addProperty(*p);
     addProperty(advancedMaterial_); addProperty(camera_); addProperty(invalidateRendering_); addProperty(transferFunctionProperty_);
     transferFunctionProperty_.onChange([this]() { setTransferFunction(transferFunctionProperty_.get()); });             // tracercl.cpp:148
@@ -553,6 +630,9 @@ ProgressivePhotonTracerCL::ProgressivePhotonTracerCL() {
     clipX_.onChange([this]() { onClipChange(); });
     clipY_.onChange([this]() { onClipChange(); });
     clipZ_.onChange([this]() { onClipChange(); });
+}
+ProgressivePhotonTracerCL::~ProgressivePhotonTracerCL() {
+    if (selection_) cpm_selection_destroy(CpmRuntime::get().ctx(), selection_);
 }
 void ProgressivePhotonTracerCL::onClipChange() {  // progressivephotontracercl.cpp:672-686
     if (!volumePort_.isReady()) return;
@@ -569,6 +649,9 @@ void ProgressivePhotonTracerCL::process() {  // progressivephotontracercl.cpp:21
     auto& rt = CpmRuntime::get();
     if (!photonTracer_.isValid() || !volumePort_.isReady()) return;
     rt.beginProfile();
+    if (volumePort_.changedSinceLastCheck()) invalidateProgressiveRendering(PhotonData::InvalidationReason::Volume);  // volumePort_.onChange (:107-108)
+    recomputedPhotonIndices_->keepsReplaced = fusedImportanceBranch_.get() && maxIncrementalPhotonsToUpdate_.get() >= 100.f &&
+                                              recomputationImportanceGrid_.isConnected();
     const auto lights = lightSamples_.getVectorData();
     size_t nPhotons = 0;
     // lightSamples_.onChange (tracercl.cpp:119-126): a light whose samples were rewritten since the last
@@ -612,6 +695,63 @@ void ProgressivePhotonTracerCL::process() {  // progressivephotontracercl.cpp:21
         }
         if (recomputedPhotonIndices_->indicesToRecomputedPhotons.getSize() != photonData_->getNumberOfPhotons())
             recomputedPhotonIndices_->indicesToRecomputedPhotons.setSize(photonData_->getNumberOfPhotons());
+        recomputedPhotonIndices_->replacedValid = false;
+        recomputedPhotonIndices_->countPending = false;
+        // The whole branch with the count kept on the device (cpm.h, "the correlated update without a host round trip"):
+        // possible when every changed photon is traced in this evaluation -- a budget below 100 % needs the ranking by
+        // importance, a host decision on the count.
+        const bool fused = fusedImportanceBranch_.get() && (flag & (tfFlag | volFlag)) && maxIncrementalPhotonsToUpdate_.get() >= 100.f;
+        if (fused) {
+            auto grid = std::dynamic_pointer_cast<ImportanceUniformGrid3D>(recomputationImportanceGrid_.getData());
+            if (!grid) { LogError("UniformGrid3DInport require ImportanceUniformGrid3D as input"); return; }
+            const size_t N = photonData_->getNumberOfPhotons();
+            if (!selection_ || selectionPhotons_ != N) {
+                if (selection_) cpm_selection_destroy(rt.ctx(), selection_);
+                selection_ = nullptr;
+                if (!rt.check(cpm_selection_create(rt.ctx(), N, &selection_), "cpm_selection_create")) return;
+                selectionPhotons_ = N;
+            }
+            auto& rec = *recomputedPhotonIndices_;
+            if (rec.replacedPhotons.getSize() != photonData_->photons_.getSize()) rec.replacedPhotons.setSize(photonData_->photons_.getSize());
+            photonRecomputationDetector_.setPercentage((int)maxIncrementalPhotonsToUpdate_.get());
+            photonRecomputationDetector_.setIteration(photonRecomputationDetector_.getIteration() + 1);
+            rt.check(cpm_selection_begin(rt.ctx(), selection_), "cpm_selection_begin");
+            int offset = 0;
+            for (auto& l : lights) {  // detector + threshold + count + index lists, per light (:298-356)
+                photonRecomputationDetector_.photonRecomputationImportanceSelect(selection_, photonData_.get(), offset, volume, grid.get(), *l,
+                                                                                 photonRecomputationImportance_, fixExitPoint);
+                offset += (int)l->getSize();
+            }
+            rt.check(cpm_selection_finish(rt.ctx(), selection_, rec.indicesToRecomputedPhotons.device(), rt.stream()), "cpm_selection_finish");
+            offset = 0;
+            for (auto& l : lights) {  // ascending indices = emission-lattice order (:467-473); importance reset in the same launch (:529)
+                photonTracer_.tracePhotonsSelected(volume, transferFunction_, aabb_, advancedMaterial_, stepSize, l.get(), &rec.indicesToRecomputedPhotons,
+                                                   cpm_selection_count_device(selection_), (int)N, rec.replacedPhotons.device(),
+                                                   photonRecomputationImportance_.device(), offset, maxInteractions, photonData_.get());
+                offset += (int)l->getSize();
+            }
+            rec.selection = selection_;
+            rec.countPending = true;
+            rec.nRecomputedPhotons = 0;  // resolved on first use (resolveCount)
+            rec.replacedStride = (int)N;
+            rec.replacedValid = true;
+            rankedByImportance_ = false;
+            remainingPhotonsOffset_ = 0;
+            remainingPhotonsToUpdate_ = 0;  // everything changed was traced
+            enableProgressiveRefinement_.set(false);
+            recomputedIndicesPort_.setData(recomputedPhotonIndices_);
+            photonData_->setInvalidationReason(invalidationFlag_);
+            invalidationFlag_ = PhotonData::InvalidationReason(0);
+            outport_.setData(photonData_);
+            if (rt.profiling()) {
+                rt.logProfile("Photon tracing");
+                const int nr = rec.resolveCount();
+                char buf[96];
+                std::snprintf(buf, sizeof buf, "Computed photons: %d = %.2f %%", nr, N ? 100.0 * (double)nr / (double)N : 0.0);
+                LogInfo(buf);
+            }
+            return;
+        }
         if (flag & (tfFlag | volFlag)) {
             auto grid = std::dynamic_pointer_cast<ImportanceUniformGrid3D>(recomputationImportanceGrid_.getData());
             if (!grid) { LogError("UniformGrid3DInport require ImportanceUniformGrid3D as input"); return; }
@@ -669,6 +809,8 @@ void ProgressivePhotonTracerCL::process() {  // progressivephotontracercl.cpp:21
             offset += (int)l->getSize();
         }
         recomputedPhotonIndices_->nRecomputedPhotons = -1;
+        recomputedPhotonIndices_->countPending = false;
+        recomputedPhotonIndices_->replacedValid = false;
         remainingPhotonsToUpdate_ = 0;
         remainingPhotonsOffset_ = 0;
         if (photonRecomputationImportance_.getSize() > 0) resetPhotonImportance(0, photonRecomputationImportance_.getSize());
@@ -740,21 +882,32 @@ void PhotonToLightVolumeProcessorCL::process() {  // photontolightvolumeprocesso
     const float scale = cpm_relative_irradiance_scale(photonData->getRadiusRelativeToSceneSize(), (double)nPhotons);
     const float* photons = reinterpret_cast<const float*>(photonData->photons_.device());
     float* out = lightVolume_->data.device();
-    // a progressive iteration (i > 1): this evaluation's estimate goes to a side buffer and is averaged in below
-    const bool progressiveIteration = progressiveAccumulation_.get() && !fresh && photonData->iteration() > 1 &&
+    const int maxRecomputationPhotons = (int)((float)nPhotons * (incrementalRecomputationThreshold_.get() / 100.f));
+    const bool haveIdx = recomputedPhotonIndicesPort_.isReady();
+    RecomputedPhotonIndices* rec = haveIdx ? recomputedPhotonIndicesPort_.getData().get() : nullptr;
+    // (a fused tracer evaluation left the count on the device: this reads its host mailbox, not the stream)
+    const int nRecomputed = haveIdx ? rec->resolveCount() : -1;
+    // the records the re-traced photons had before: kept by the tracer for exactly those photons (fused branch), else this
+    // processor's whole-buffer snapshot of the previous evaluation
+    const bool exactAddRemove = exactIncrementalUpdate_.get() && formulation_.get() == "gather";
+    const bool useReplaced = haveIdx && rec->replacedValid && !exactAddRemove && rec->replacedPhotons.getSize() == photonData->photons_.getSize();
+    const bool havePrev = useReplaced || (prevPhotonsValid_ && prevPhotons_.getSize() == photonData->photons_.getSize());
+    const bool canAddRemove = !fresh && haveIdx && havePrev && nRecomputed > 0 && nRecomputed < maxRecomputationPhotons;
+    // a progressive iteration (i > 1): this evaluation's estimate goes to a side buffer and is averaged in below.  Only when
+    // the tracer really ran a progressive iteration over all photons -- a timer-driven continuation of a correlated update
+    // (indices connected, a batch re-traced) is an add-remove on the light volume itself.
+    const bool progressiveIteration = progressiveAccumulation_.get() && !fresh && photonData->iteration() > 1 && (!haveIdx || nRecomputed < 0) &&
                                       static_cast<int>(photonData->getInvalidationReason()) == static_cast<int>(PhotonData::InvalidationReason::Progressive);
     if (progressiveIteration) {
         estimate_.setSize(cells * channels);
         out = estimate_.device();
     }
-    const int maxRecomputationPhotons = (int)((float)nPhotons * (incrementalRecomputationThreshold_.get() / 100.f));
-    const bool haveIdx = recomputedPhotonIndicesPort_.isReady();
-    const int nRecomputed = haveIdx ? recomputedPhotonIndicesPort_.getData()->nRecomputedPhotons : -1;
     bool partialUpdate = false;  // this evaluation only touched the re-traced photons
-    if (!fresh && haveIdx && prevPhotons_.getSize() == photonData->photons_.getSize() && nRecomputed > 0 && nRecomputed < maxRecomputationPhotons) {
+    bool marksDone = false;      // brickMask_ already holds the old AND new positions' bricks
+    if (canAddRemove) {
         partialUpdate = true;
-        const unsigned int* idx = recomputedPhotonIndicesPort_.getData()->indicesToRecomputedPhotons.device();
-        if (exactIncrementalUpdate_.get() && formulation_.get() == "gather") {
+        const unsigned int* idx = rec->indicesToRecomputedPhotons.device();
+        if (exactAddRemove) {
             // exact add-remove: mark the bricks an old or new position touches, re-bin, re-gather those bricks only
             const size_t nb = ((outDim.x + 3) / 4) * ((outDim.y + 3) / 4) * ((outDim.z + 3) / 4);
             brickMask_.setSize(nb);
@@ -768,7 +921,21 @@ void PhotonToLightVolumeProcessorCL::process() {  // photontolightvolumeprocesso
             ok = ok && rt.check(cpm_bin(rt.ctx(), photons, (int)m, &g, order_.device(), cellStart_.device(), sorted_.device(), rt.stream()), "cpm_bin");
             if (ok) rt.check(cpm_gather_bricks(rt.ctx(), sorted_.device(), cellStart_.device(), (int)m, &g, radius, scale, brickMask_.device(), out,
                                                rt.stream()), "cpm_gather_bricks");
+            marksDone = true;
             lastPath_ = "exact incremental";
+        } else if (useReplaced) {
+            // add-remove (:196-298) in one launch over the device count: - the records the tracer replaced, + the new ones
+            uint8_t* mask = nullptr;
+            if (comm_) {  // multi-GPU: the bricks an old or new position touches, marked by the same launch
+                const size_t nb = ((outDim.x + 3) / 4) * ((outDim.y + 3) / 4) * ((outDim.z + 3) / 4);
+                brickMask_.setSize(nb);
+                (void)hipMemsetAsync(brickMask_.device(), 0, nb, rt.stream());
+                mask = brickMask_.device();
+                marksDone = true;
+            }
+            rt.check(cpm_splat_delta(rt.ctx(), reinterpret_cast<const float*>(rec->replacedPhotons.device()), rec->replacedStride, photons, idx,
+                                     rec->countDevice(), nPhotons, 0, &g, radius, scale, nPhotons, nInter, mask, out, rt.stream()), "cpm_splat_delta");
+            lastPath_ = "incremental";
         } else {
         // add-remove (:196-298): -old, +new over the re-traced photons
         if (comm_) {  // multi-GPU: remember which bricks the OLD positions touch (the snapshot is refreshed below)
@@ -783,7 +950,7 @@ void PhotonToLightVolumeProcessorCL::process() {  // photontolightvolumeprocesso
         rt.check(cpm_splat_selected(rt.ctx(), photons, idx, nRecomputed, &g, radius, scale, 1.f, nPhotons, nInter, out, rt.stream()), "cpm_splat_selected(+)");
         lastPath_ = "incremental";
         }
-    } else if (fresh || prevPhotons_.getSize() != photonData->photons_.getSize() || nRecomputed < 0 || nRecomputed >= maxRecomputationPhotons) {
+    } else if (fresh || !havePrev || nRecomputed < 0 || nRecomputed >= maxRecomputationPhotons) {
         if (formulation_.get() == "splat") {  // the reference's formulation: clear + atomic splat (:299-339)
             (void)hipMemsetAsync(out, 0, cells * channels * sizeof(float), rt.stream());
             rt.check(cpm_splat(rt.ctx(), photons, nPhotons, &g, radius, scale, out, rt.stream()), "cpm_splat");
@@ -805,9 +972,14 @@ void PhotonToLightVolumeProcessorCL::process() {  // photontolightvolumeprocesso
     } else {
         lastPath_ = "unchanged";
     }
-    if (haveIdx && nRecomputed != 0) {  // snapshot for the next add-remove (:343-352)
-        if (partialUpdate) {  // only the re-traced photons differ from the snapshot: move those (the reference copies everything)
-            const unsigned int* idx = recomputedPhotonIndicesPort_.getData()->indicesToRecomputedPhotons.device();
+    // Snapshot for the next add-remove (:343-352).  The reference copies the whole photon buffer after every evaluation with
+    // the index port connected (64 MiB of traffic per 1 M photon frame).  Here the tracer's fused branch hands over the replaced
+    // records themselves, so the snapshot is only kept where something reads it: the exact add-remove, or a tracer that does
+    // not keep the records (budget below 100 %, fusedImportanceBranch off).
+    const bool tracerKeepsRecords = haveIdx && rec->keepsReplaced && !exactAddRemove && snapshotFree_;
+    if (haveIdx && nRecomputed != 0 && !tracerKeepsRecords) {
+        if (partialUpdate && prevPhotonsValid_) {  // only the re-traced photons differ from the snapshot: move those (the reference copies everything)
+            const unsigned int* idx = rec->indicesToRecomputedPhotons.device();
             rt.check(cpm_snapshot_selected_photons(rt.ctx(), photons, idx, nRecomputed, nPhotons, nInter,
                                                    reinterpret_cast<float*>(prevPhotons_.device()), rt.stream()),
                      "cpm_snapshot_selected_photons");
@@ -815,6 +987,9 @@ void PhotonToLightVolumeProcessorCL::process() {  // photontolightvolumeprocesso
             if (prevPhotons_.getSize() != photonData->photons_.getSize()) prevPhotons_.setSize(photonData->photons_.getSize());
             (void)hipMemcpyAsync(prevPhotons_.device(), photonData->photons_.device(), photonData->photons_.getSizeInBytes(), hipMemcpyDeviceToDevice, rt.stream());
         }
+        prevPhotonsValid_ = true;
+    } else if (haveIdx && nRecomputed != 0) {
+        prevPhotonsValid_ = false;  // the photons moved on without the snapshot
     }
     if (progressiveIteration && lastPath_[0] == 'f') {  // L_i = mix(L_(i-1), E_i, 1 / i)
         rt.check(cpm_mix_buffers(rt.ctx(), lightVolume_->data.device(), estimate_.device(), 1.0f / (float)photonData->iteration(), cells * channels,
@@ -824,7 +999,8 @@ void PhotonToLightVolumeProcessorCL::process() {  // photontolightvolumeprocesso
     if (comm_ && lastPath_[0] != 'u') {
         const unsigned int* idx = partialUpdate ? recomputedPhotonIndicesPort_.getData()->indicesToRecomputedPhotons.device() : nullptr;
         // NOTE: the snapshot above has already been refreshed; the touched bricks of the OLD positions were marked before it
-        reduceOverShards(g, cells * channels, partialUpdate, nullptr, photons, idx, nRecomputed, nPhotons, nInter, radius);
+        // (marksDone: the new positions' bricks as well -- nothing left to mark)
+        reduceOverShards(g, cells * channels, partialUpdate, marksDone ? photons : nullptr, photons, idx, nRecomputed, nPhotons, nInter, radius);
         outport_.setData(reducedVolume_);
         return;
     }
@@ -832,7 +1008,7 @@ void PhotonToLightVolumeProcessorCL::process() {  // photontolightvolumeprocesso
 }
 
 // The one exchange step of the path: sum of the shards' partial light volumes.
-void PhotonToLightVolumeProcessorCL::reduceOverShards(const cpm_grid_desc& g, size_t count, bool partialUpdate, const float*,
+void PhotonToLightVolumeProcessorCL::reduceOverShards(const cpm_grid_desc& g, size_t count, bool partialUpdate, const float* marksComplete,
                                                       const float* photons, const unsigned int* idx, int nRecomputed, int nPhotons,
                                                       int nInter, float radius) {
     auto& rt = CpmRuntime::get();
@@ -848,7 +1024,8 @@ void PhotonToLightVolumeProcessorCL::reduceOverShards(const cpm_grid_desc& g, si
         // positions were marked into brickMask_ before the snapshot moved on (see process()); add the new ones, then sum
         // the union of all shards' bricks only.
         uint32_t nUnion = 0;
-        bool ok = rt.check(cpm_mark_touched_bricks(rt.ctx(), photons, idx, nRecomputed, nPhotons, nInter, &g, radius, brickMask_.device(),
+        bool ok = marksComplete != nullptr ||
+                  rt.check(cpm_mark_touched_bricks(rt.ctx(), photons, idx, nRecomputed, nPhotons, nInter, &g, radius, brickMask_.device(),
                                                    rt.stream()), "cpm_mark_touched_bricks(new)");
         if (ok && rt.check(cpm_allreduce_grid_bricks(rt.ctx(), comm_, lightVolume_->data.device(), reducedVolume_->data.device(), &g,
                                                      brickMask_.device(), &nUnion, rt.stream()), "cpm_allreduce_grid_bricks")) {

@@ -54,6 +54,21 @@ struct RecomputedPhotonIndices {
     int nRecomputedPhotons = -1;
     bool isInitialized() const { return nRecomputedPhotons != -1; }
     void setUninitialized() { nRecomputedPhotons = -1; }
+    // The fused importance branch (cpm_selection_*, cpm_trace_selected) leaves the count on the device: nRecomputedPhotons is
+    // then resolved on first use from the selection's host mailbox (no stream synchronisation; ref tracercl.cpp:343-345,374
+    // blocks on an event here).  `selection` is owned by the tracer processor.
+    cpm_selection* selection = nullptr;
+    bool countPending = false;
+    int resolveCount();
+    const int32_t* countDevice() const { return selection ? cpm_selection_count_device(selection) : nullptr; }
+    // ... and the tracer keeps the records it overwrites: replacedPhotons[k * replacedStride + j] is what photon
+    // indicesToRecomputedPhotons[j] was at interaction k before this evaluation -- the part of the light-volume processor's
+    // prevPhotons_ snapshot (ref photontolightvolumeprocessorcl.cpp:343-352: a copy of the WHOLE buffer per evaluation) that
+    // the add-remove update reads.  replacedValid: filled by the evaluation that produced the current indices.
+    Buffer<vec4> replacedPhotons;
+    int replacedStride = 0;
+    bool replacedValid = false;
+    bool keepsReplaced = false;  // the tracer is configured to hand over replaced records on its importance branch (no snapshot needed downstream)
 };
 
 // progressivephotonmapping/photondata.h:65-156, photondata.cpp:36-98
@@ -280,6 +295,12 @@ public:
     void setNoSingleScattering(bool v) { onlyMultipleScattering_ = v; }
     void setProgressive(bool v) { progressive_ = v; }
     bool isProgressive() const { return progressive_; }
+    // the same over a device-side count (cpm_trace_selected): thread j < min(*nIndicesDevice, maxIndices); the records about to
+    // be overwritten go to replacedPhotons (stride maxIndices), the traced photons' importance keys are reset
+    void tracePhotonsSelected(const Volume* volume, const TransferFunction& transferFunction, const float aabb[8],
+                              const AdvancedMaterialProperty& material, float stepSize, const LightSamples* lightSamples,
+                              const Buffer<unsigned int>* indices, const int32_t* nIndicesDevice, int maxIndices, vec4* replacedPhotons,
+                              unsigned int* resetImportances, int photonOffset, int maxInteractions, PhotonData* photonOutData);
     void setRandomSeedSize(size_t nPhotons);   // :176-182
     Buffer<uvec2>& randomState() { return randomState_; }
 private:
@@ -297,6 +318,10 @@ public:
     void photonRecomputationImportance(const PhotonData* photonData, int photonOffset, const Volume* origVolume,
                                        const ImportanceUniformGrid3D* uniformGridVolume, const LightSamples& lightSamples,
                                        Buffer<unsigned int>& recomputationImportance);
+    // the same fused with threshold + count + index lists (cpm_photon_importance_select): appends this light to `selection`
+    void photonRecomputationImportanceSelect(cpm_selection* selection, const PhotonData* photonData, int photonOffset, const Volume* origVolume,
+                                             const ImportanceUniformGrid3D* uniformGridVolume, const LightSamples& lightSamples,
+                                             Buffer<unsigned int>& recomputationImportance, bool fixExitPoint);
     void setPercentage(int p) { percentage_ = p; }
     int getPercentage() const { return percentage_; }
     void setIteration(int i) { iteration_ = i; }
@@ -390,6 +415,7 @@ private:
     vec4 tfPointColorDiff(const vec4& p1, const vec4& p2) const;  // :503-507
     TransferFunction transferFunction_, prevTransferFunction_;
     bool tfChanged_ = false;
+    std::shared_ptr<const MinMaxUniformGrid3D> prevMinMaxUniformGrid3D_;  // .h:126: the grid of the previous evaluation (time-varying data)
     std::vector<float> positions_;
     std::vector<vec4> colors_;
     std::shared_ptr<ImportanceUniformGrid3D> importance_ = std::make_shared<ImportanceUniformGrid3D>();
@@ -438,7 +464,13 @@ public:
     TransferFunction transferFunction_;
     PhotonTracerCL photonTracer_;
     bool fixExitPoint = false;
+    // false: the importance branch launch by launch with its host read of the count in the middle (always taken when the update
+    // budget is below 100 %: ranking by importance is a host decision); true (default): the count stays on the device
+    BoolProperty fusedImportanceBranch_{ "fusedImportanceBranch", "Importance branch without host round trip", true };
+    ~ProgressivePhotonTracerCL();
 private:
+    cpm_selection* selection_ = nullptr;
+    size_t selectionPhotons_ = 0;
     void onClipChange();
     float getSceneRadius() const { return 0.5f * std::sqrt(12.f); }  // unit-model volume spanning [-1, 1]^3
     void resetPhotonImportance(size_t offset, size_t n);
@@ -509,6 +541,8 @@ private:
     const char* lastReduce_ = "none";
     std::shared_ptr<Volume> lightVolume_ = std::make_shared<Volume>(size3_t{ 1, 1, 1 }, CPM_F32);
     Buffer<vec4> prevPhotons_;
+    bool prevPhotonsValid_ = false;  // prevPhotons_ is the photon buffer as of the end of the previous evaluation
+    bool snapshotFree_ = true;       // no whole-buffer snapshot while the tracer hands over the replaced records (set false to keep the reference's copy)
     Buffer<unsigned int> order_, cellStart_;
     Buffer<float> sorted_;
     Buffer<uint8_t> brickMask_;

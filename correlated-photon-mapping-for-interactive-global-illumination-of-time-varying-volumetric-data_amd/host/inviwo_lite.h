@@ -163,14 +163,16 @@ class DataOutport {
 public:
     explicit DataOutport(std::string id) : id_(std::move(id)) {}
     const std::string& getIdentifier() const { return id_; }
-    void setData(std::shared_ptr<T> d) { data_ = std::move(d); }
+    void setData(std::shared_ptr<T> d) { data_ = std::move(d); ++stamp_; }
     std::shared_ptr<T> getData() const { return data_; }
     bool isConnected() const { return nConnections_ > 0; }
     void connectionAdded() { ++nConnections_; }
+    size_t stamp() const { return stamp_; }  // advances with every setData: what invalidates the connected inports
 private:
     std::string id_;
     std::shared_ptr<T> data_;
     int nConnections_ = 0;
+    size_t stamp_ = 0;
 };
 
 template <typename T>
@@ -191,11 +193,22 @@ public:
     }
     void setOptional(bool o) { optional_ = o; }
     void onConnect(std::function<void()> f) { onConnect_ = std::move(f); }
+    // Inport::onChange, polled: has the source port been given data since the last call?  (Inviwo fires the callback
+    // when the upstream processor sets its outport; the processors here ask at the start of process().)
+    bool changedSinceLastCheck() {
+        const size_t now = sources_.empty() ? 0 : sources_[0]->stamp();
+        const DataOutport<T>* src = sources_.empty() ? nullptr : sources_[0];
+        const bool ch = now != seenStamp_ || src != seenSource_;
+        seenStamp_ = now; seenSource_ = src;
+        return ch;
+    }
 private:
     std::string id_;
     std::vector<DataOutport<T>*> sources_;
     bool optional_ = false;
     std::function<void()> onConnect_;
+    size_t seenStamp_ = 0;
+    const DataOutport<T>* seenSource_ = nullptr;
 };
 
 class PropertyBase {

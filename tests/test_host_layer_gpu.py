@@ -61,6 +61,7 @@ def host(cpm, ctx):
 class Net:
     def __init__(self, lib, vol, n_side, light_pos, light_dir, tf_points, size_option=2, max_scattering=1, correlated=False):
         self.lib = lib
+        self.max_scattering = max_scattering
         vol = np.ascontiguousarray(vol)
         pts = np.ascontiguousarray(np.asarray(tf_points, np.float32))
         self.h = lib.cpmh_create(vol.ctypes.data, 0, vol.shape[2], vol.shape[1], vol.shape[0], n_side, n_side,
@@ -83,7 +84,7 @@ class Net:
         return out, tuple(dims), ch.value
 
     def photons(self):
-        out = np.zeros((self.lib.cpmh_n_photons(self.h), 8), np.float32)
+        out = np.zeros((self.lib.cpmh_n_photons(self.h) * self.max_scattering, 8), np.float32)   # SoA by interaction: I x N records
         assert self.lib.cpmh_download_photons(self.h, out.ctypes.data) == 0
         return out
 
@@ -288,9 +289,11 @@ def test_network_correlated_tf_edit(host, cpm):
     assert host.cpmh_set_property_string(fresh.h, b"lightvolume", b"formulation", b"gather") == 0
     fresh.evaluate()
     lv_full, _, _ = fresh.light_volume()
+    # (set before the first evaluation, as a deserialised workspace does: the processor then keeps the photon snapshot the
+    # exact add-remove reads -- switched on later, the first edit is served by a full gather, same bits)
+    assert host.cpmh_set_property_float(net3.h, b"lightvolume", b"exactIncrementalUpdate", 1.0) == 0
     net3.evaluate(first=True)
     assert host.cpmh_set_property_float(net3.h, b"lightvolume", b"incrementalRecomputationThreshold", 100.0) == 0
-    assert host.cpmh_set_property_float(net3.h, b"lightvolume", b"exactIncrementalUpdate", 1.0) == 0
     net3.set_tf(edit)
     net3.evaluate()
     assert host.cpmh_last_light_volume_path(net3.h) == b"exact incremental"
