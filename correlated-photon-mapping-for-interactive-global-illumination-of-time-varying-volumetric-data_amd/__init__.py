@@ -9,11 +9,11 @@ Importing this package does not load the shared library; ``binding.load_library(
 """
 from . import binding, synthetic  # noqa: F401
 
-__all__ = ["binding", "synthetic", "pipeline", "sharding", "build"]
+__all__ = ["binding", "synthetic", "pipeline", "sharding", "build", "hostlayer"]
 
 
 def __getattr__(name):
-    if name in ("pipeline", "build", "sharding"):
+    if name in ("pipeline", "build", "sharding", "hostlayer"):
         import importlib
         return importlib.import_module(f"{__name__}.{name}")
     raise AttributeError(name)

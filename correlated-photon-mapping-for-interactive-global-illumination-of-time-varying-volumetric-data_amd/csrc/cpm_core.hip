@@ -185,6 +185,9 @@ void cpm_destroy(cpm_ctx* ctx) {
     if (!ctx) return;
     for (int i = 0; i < 8; ++i) if (ctx->scratch[i]) (void)hipFree(ctx->scratch[i]);
     if (ctx->dir_hint) (void)hipFree(ctx->dir_hint);
+    for (int i = 0; i < cpm_ctx::kTfStageSlots; ++i)
+        if (ctx->tf_stage_done[i]) { (void)hipEventSynchronize(ctx->tf_stage_done[i]); (void)hipEventDestroy(ctx->tf_stage_done[i]); }
+    if (ctx->tf_stage) (void)hipHostFree(ctx->tf_stage);
     for (auto& r : ctx->prof_pending) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
     for (auto e : ctx->prof_pool) (void)hipEventDestroy(e);
     delete ctx;
@@ -340,15 +343,51 @@ int cpm_tf_create(cpm_ctx* ctx, const float* rgba, int width, int is_device, cpm
     return rc;
 }
 
+// LUT from a pinned host slot (read over the host link by the kernel itself) -> rgba + alpha column, one launch
+__global__ void tf_upload_kernel(const float4* __restrict__ src, int width, float4* __restrict__ rgba, float* __restrict__ alpha) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < width) {
+        const float4 c = src[i];
+        rgba[i] = c;
+        alpha[i] = c.w;
+    }
+}
+
 int cpm_tf_update(cpm_ctx* ctx, cpm_tf* tf, const float* rgba, int is_device, cpm_stream stream) {
     CPM_ENTER(ctx);
     CPM_REQUIRE(ctx, tf && rgba, "cpm_tf_update: null argument");
     hipStream_t s = (hipStream_t)stream;
-    CPM_HIP_CHECK(ctx, hipMemcpyAsync(tf->rgba, rgba, (size_t)tf->width * 4 * sizeof(float),
-                                      is_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, s));
-    CPM_LAUNCH(ctx, tf_alpha_kernel, dim3(div_up(tf->width, 256)), dim3(256), 0, s, tf->rgba, tf->width, tf->alpha);
-    CPM_LAUNCH_CHECK(ctx, "tf_alpha_kernel");
-    if (!is_device) CPM_HIP_CHECK(ctx, hipStreamSynchronize(s));
+    const size_t floats = (size_t)tf->width * 4;
+    if (is_device) {
+        CPM_HIP_CHECK(ctx, hipMemcpyAsync(tf->rgba, rgba, floats * sizeof(float), hipMemcpyDeviceToDevice, s));
+        CPM_LAUNCH(ctx, tf_alpha_kernel, dim3(div_up(tf->width, 256)), dim3(256), 0, s, tf->rgba, tf->width, tf->alpha);
+        CPM_LAUNCH_CHECK(ctx, "tf_alpha_kernel");
+        return CPM_OK;
+    }
+    // host data: consumed here (copied into a pinned slot), read by the launch -- the caller's array may go away on return
+    // and the host does not wait for the stream
+    if (ctx->tf_stage_floats < floats) {
+        for (int i = 0; i < cpm_ctx::kTfStageSlots; ++i)
+            if (ctx->tf_stage_done[i]) CPM_HIP_CHECK(ctx, hipEventSynchronize(ctx->tf_stage_done[i]));
+        if (ctx->tf_stage) (void)hipHostFree(ctx->tf_stage);
+        ctx->tf_stage = nullptr;
+        ctx->tf_stage_floats = 0;
+        CPM_HIP_CHECK(ctx, hipHostMalloc((void**)&ctx->tf_stage, cpm_ctx::kTfStageSlots * floats * sizeof(float), hipHostMallocMapped));
+        CPM_HIP_CHECK(ctx, hipHostGetDevicePointer((void**)&ctx->tf_stage_dev, ctx->tf_stage, 0));
+        ctx->tf_stage_floats = floats;
+        for (int i = 0; i < cpm_ctx::kTfStageSlots; ++i)
+            if (!ctx->tf_stage_done[i]) CPM_HIP_CHECK(ctx, hipEventCreateWithFlags(&ctx->tf_stage_done[i], hipEventDisableTiming));
+    }
+    const int slot = ctx->tf_stage_next;
+    ctx->tf_stage_next = (slot + 1) % cpm_ctx::kTfStageSlots;
+    CPM_HIP_CHECK(ctx, hipEventSynchronize(ctx->tf_stage_done[slot]));  // (an event never recorded is complete)
+    float* host = ctx->tf_stage + (size_t)slot * ctx->tf_stage_floats;
+    memcpy(host, rgba, floats * sizeof(float));
+    CPM_LAUNCH(ctx, tf_upload_kernel, dim3(div_up(tf->width, 256)), dim3(256), 0, s,
+               reinterpret_cast<const float4*>(ctx->tf_stage_dev + (size_t)slot * ctx->tf_stage_floats), tf->width,
+               reinterpret_cast<float4*>(tf->rgba), tf->alpha);
+    CPM_LAUNCH_CHECK(ctx, "tf_upload_kernel");
+    CPM_HIP_CHECK(ctx, hipEventRecord(ctx->tf_stage_done[slot], s));
     return CPM_OK;
 }
 

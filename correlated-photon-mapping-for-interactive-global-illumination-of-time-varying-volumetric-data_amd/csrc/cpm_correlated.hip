@@ -286,14 +286,29 @@ struct ImpGrid {
     const float* grid;
     int dims[3];
     float cell[3];
+    float inv_cell[3];  // exact reciprocal of a power-of-two cell size
+    int cell_pow2[3];
     Affine t2i;
 };
+
+void set_cell(ImpGrid& G, int a, float cell) {
+    G.cell[a] = cell;
+    int e = 0;
+    const float m = frexpf(cell, &e);  // cell = m * 2^e, m in [0.5, 1)
+    G.cell_pow2[a] = (m == 0.5f && e > -120 && e < 120) ? 1 : 0;
+
+    G.inv_cell[a] = G.cell_pow2[a] ? 1.0f / cell : 0.f;
+}
 
 // setupUniformGridTraversal + stepToNextCellNextHit (OPTIMIZE_STEP_FOR_SIMD) driven by
 // uniformGridImportance (ref uniformgridcl/cl/uniformgrid/uniformgrid.cl:38-69,147-167;
 // progressivephotonmapping/cl/photonrecomputationdetector.cl:55-90)
 // MASK: `mask` holds one bit per cell (set = the cell's importance is not +0.0f); a clear bit stands for the value +0.0f
 // without the load -- the same operand, so the same sum (the multiply and the add are still performed).
+// cell_pow2[a]: the cell size is a power of two and inv_cell[a] its exact reciprocal; x * inv_cell is then the correctly
+// rounded quotient x / cell (both are exact scalings) without the division sequence.
+// (Walking several cells ahead with their loads in flight together, and finishing long walks by dense waves from an LDS
+// queue, were both built, bit-identical, measured slower and removed: docs/EXPERIMENTS.md.)
 template <bool MASK>
 CPM_DEV float uniform_grid_importance(const ImpGrid& G, const uint32_t* mask, const float x1[3], const float x2[3]) {
     int cell[3], cellEnd[3], di[3];
@@ -301,9 +316,10 @@ CPM_DEV float uniform_grid_importance(const ImpGrid& G, const uint32_t* mask, co
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
         float maxc = (float)(G.dims[a] - 1);
-        float cf = min_(max_(__builtin_floorf(x1[a] / G.cell[a]), 0.f), maxc);
+        const float q1 = G.cell_pow2[a] ? x1[a] * G.inv_cell[a] : x1[a] / G.cell[a];
+        float cf = min_(max_(__builtin_floorf(q1), 0.f), maxc);
         cell[a] = (int)cf;
-        float ef = x2[a] / G.cell[a];
+        float ef = G.cell_pow2[a] ? x2[a] * G.inv_cell[a] : x2[a] / G.cell[a];
         ef = min_(max_(ef, -1.f), (float)G.dims[a]);
         int ei = (int)ef;
         cellEnd[a] = ei < 0 ? 0 : (ei > G.dims[a] - 1 ? G.dims[a] - 1 : ei);
@@ -317,10 +333,11 @@ CPM_DEV float uniform_grid_importance(const ImpGrid& G, const uint32_t* mask, co
     float importance = 0.f, dt1 = 0.f;
     bool cont = true;
     int cap = G.dims[0] + G.dims[1] + G.dims[2] + 4;  // every wave reaches its exit, NaN input included
+    const uint32_t sy = (uint32_t)G.dims[0], sz = (uint32_t)G.dims[0] * (uint32_t)G.dims[1];
     while (cont && cap-- > 0) {
-        const size_t ci = (size_t)cell[0] + (size_t)cell[1] * G.dims[0] + (size_t)cell[2] * G.dims[0] * G.dims[1];
+        const uint32_t ci = (uint32_t)cell[0] + (uint32_t)cell[1] * sy + (uint32_t)cell[2] * sz;
         float val = 0.f;
-        if (!MASK || ((mask[ci >> 5] >> (ci & 31)) & 1u)) val = G.grid[ci];
+        if (!MASK || ((mask[ci >> 5] >> (ci & 31u)) & 1u)) val = G.grid[ci];
         float dt0 = dt1;
         bool ax0 = dt[0] <= dt[1] && dt[0] <= dt[2];
         bool ax1 = !ax0 && (dt[0] > dt[1] && dt[1] <= dt[2]);
@@ -451,12 +468,12 @@ __global__ __launch_bounds__(256) void importance_select_kernel(ImpGrid G, const
     extern __shared__ uint32_t s_mask[];
     __shared__ uint32_t s_wcnt[K][4];
     const uint32_t t = threadIdx.x, lane = t & 63u, wave = t >> 6;
+    const int b0 = (int)(blockIdx.x * S.per_tile);
+    const int b1 = min(b0 + (int)S.per_tile, n_light_samples);
     if (MODE == 0 && MASK) {
         for (uint32_t i = t; i < mask_words; i += 256u) s_mask[i] = mask[i];
         __syncthreads();
     }
-    const int b0 = (int)(blockIdx.x * S.per_tile);
-    const int b1 = min(b0 + (int)S.per_tile, n_light_samples);
     unsigned long long ballots[K];
     uint32_t flags = 0;
 #pragma unroll
@@ -754,7 +771,7 @@ int cpm_photon_importance(cpm_ctx* ctx, const float* importance_grid, const int3
     for (int a = 0; a < 3; ++a) {
         CPM_REQUIRE(ctx, grid_dims[a] >= 1 && cell_size[a] > 0.f, "cpm_photon_importance: grid dims / cell size");
         G.dims[a] = grid_dims[a];
-        G.cell[a] = cell_size[a];
+        set_cell(G, a, cell_size[a]);
     }
     if (!affine_from_matrix(texture_to_index, G.t2i))
         return set_error(ctx, CPM_ERR_UNSUPPORTED, "cpm_photon_importance", "textureToIndex must be scale + translate");
@@ -857,7 +874,10 @@ int cpm_selection_create(cpm_ctx* ctx, size_t max_photons, cpm_selection** out) 
     s->max_photons = max_photons;
     // tiles of K * 256 photons, K in {1, 2, 4, 8}: about 2048 tiles at the sizes of the path (1 M photons: 512 per tile)
     uint32_t k = 1;
-    while (k < 8 && max_photons / (256ull * k) > 2048) k *= 2;
+#ifndef CPM_SEL_TILES
+#define CPM_SEL_TILES 2048   // (tuning: tools/build_variant.sh)
+#endif
+    while (k < 8 && max_photons / (256ull * k) > CPM_SEL_TILES) k *= 2;
     s->per_tile = 256u * k;
     s->max_tiles = (uint32_t)((max_photons + s->per_tile - 1) / s->per_tile) + 64u;  // + one partial tile per further light
     bool ok = hipMalloc(&s->tile, (size_t)s->max_tiles * sizeof(uint2)) == hipSuccess &&
@@ -915,16 +935,16 @@ void launch_select(cpm_ctx* ctx, cpm_selection* s, hipStream_t st, uint32_t tile
                    const float* photons8, int photon_offset, const float* ls, const float* isect, int n_light_samples, int max_interactions,
                    int total_photons, int fix_exit_point, int pct, int iter, uint32_t* importances, const SelTiles& S) {
     const dim3 grid(tiles), block(256);
+#define CPM_SEL_LAUNCH(KK)                                                                                                             \
+    CPM_LAUNCH(ctx, (importance_select_kernel<MODE, MASK, KK>), grid, block, lds, st, G, s->mask, mask_words, photons8, photon_offset, ls, isect, \
+               n_light_samples, max_interactions, total_photons, fix_exit_point, pct, iter, importances, S)
     switch (s->per_tile / 256u) {
-        case 1: CPM_LAUNCH(ctx, (importance_select_kernel<MODE, MASK, 1>), grid, block, lds, st, G, s->mask, mask_words, photons8, photon_offset, ls, isect,
-                           n_light_samples, max_interactions, total_photons, fix_exit_point, pct, iter, importances, S); break;
-        case 2: CPM_LAUNCH(ctx, (importance_select_kernel<MODE, MASK, 2>), grid, block, lds, st, G, s->mask, mask_words, photons8, photon_offset, ls, isect,
-                           n_light_samples, max_interactions, total_photons, fix_exit_point, pct, iter, importances, S); break;
-        case 4: CPM_LAUNCH(ctx, (importance_select_kernel<MODE, MASK, 4>), grid, block, lds, st, G, s->mask, mask_words, photons8, photon_offset, ls, isect,
-                           n_light_samples, max_interactions, total_photons, fix_exit_point, pct, iter, importances, S); break;
-        default: CPM_LAUNCH(ctx, (importance_select_kernel<MODE, MASK, 8>), grid, block, lds, st, G, s->mask, mask_words, photons8, photon_offset, ls, isect,
-                            n_light_samples, max_interactions, total_photons, fix_exit_point, pct, iter, importances, S); break;
+        case 1: CPM_SEL_LAUNCH(1); break;
+        case 2: CPM_SEL_LAUNCH(2); break;
+        case 4: CPM_SEL_LAUNCH(4); break;
+        default: CPM_SEL_LAUNCH(8); break;
     }
+#undef CPM_SEL_LAUNCH
 }
 }  // namespace
 
@@ -949,7 +969,7 @@ int cpm_photon_importance_select(cpm_ctx* ctx, cpm_selection* s, const float* im
     for (int a = 0; a < 3; ++a) {
         CPM_REQUIRE(ctx, grid_dims[a] >= 1 && cell_size[a] > 0.f, "cpm_photon_importance_select: grid dims / cell size");
         G.dims[a] = grid_dims[a];
-        G.cell[a] = cell_size[a];
+        set_cell(G, a, cell_size[a]);
         cells *= (unsigned long long)grid_dims[a];
     }
     CPM_REQUIRE(ctx, cells < (1ull << 31), "cpm_photon_importance_select: grid too large");

@@ -49,6 +49,14 @@ struct cpm_ctx {
     int fast_hist_parity = 0;    // which of the two (histogram, cursors) pairs the next cpm_bin_fast uses
     const void* fast_last_table = nullptr;  // the last cpm_bin_fast's table and radius: cpm_gather_fast refuses another radius for it
     float fast_last_radius = 0.f;
+    // cpm_tf_update from host memory: the LUT goes through a ring of pinned host slots the upload kernel reads directly --
+    // no staged copy ahead of the kernel, no wait for it behind (a slot is reused only after the launch that read it)
+    static constexpr int kTfStageSlots = 4;
+    float* tf_stage = nullptr;          // pinned host, kTfStageSlots x tf_stage_floats
+    float* tf_stage_dev = nullptr;      // its device address
+    size_t tf_stage_floats = 0;
+    hipEvent_t tf_stage_done[kTfStageSlots] = { nullptr, nullptr, nullptr, nullptr };
+    int tf_stage_next = 0;
 };
 
 // scratch slots

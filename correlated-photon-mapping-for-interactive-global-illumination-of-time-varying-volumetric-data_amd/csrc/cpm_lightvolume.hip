@@ -70,11 +70,12 @@ CPM_DEV float splat_weight(f3 c, f3 p, float radius) {
     return density_kernel_(dist / radius);
 }
 
-// splatPhoton (photonstolightvolume.cl:31-79) with the power already scaled
-CPM_DEV void splat_photon(float* __restrict__ out, const GridDev& G, f3 p, f3 pw, float radius) {
+// splatPhoton (photonstolightvolume.cl:31-79) with the power already scaled; z_first / z_step: the slices
+// sz + z_first, sz + z_first + z_step, ... of the box only (0 / 1 = the whole box; lanes sharing a photon split it by slice)
+CPM_DEV void splat_photon(float* __restrict__ out, const GridDev& G, f3 p, f3 pw, float radius, int z_first = 0, int z_step = 1) {
     if (p.x == kFltMax || p.y == kFltMax || p.z == kFltMax) return;
     Box3 bx = splat_box(G, p, radius);
-    for (int z = bx.sz; z < bx.ez; ++z)
+    for (int z = bx.sz + z_first; z < bx.ez; z += z_step)
         for (int y = bx.sy; y < bx.ey; ++y)
             for (int x = bx.sx; x < bx.ex; ++x) {
                 size_t voxel = (size_t)x + (size_t)y * G.dx + (size_t)z * G.dx * G.dy;
@@ -1087,8 +1088,10 @@ CPM_DEV void mark_bricks_of(const GridDev& G, f3 p, float radius, int bxn, int b
 }
 
 // splatSelectedPhotonsToLightVolumeKernel twice (photonstolightvolume.cl:168-202 as called at
-// processor/photontolightvolumeprocessorcl.cpp:268-274) in one launch over a device-side count: thread 2j removes the record
-// selected photon j had before its re-trace (old_photons[k * old_stride + j]), thread 2j + 1 adds the one it has now.
+// processor/photontolightvolumeprocessorcl.cpp:268-274) in one launch over a device-side count.  Six lanes per selected
+// photon j: (remove the record it had before its re-trace, old_photons[k * old_stride + j] | add the one it has now) x the
+// z slices sz + {0, 1, 2}, sz + 3 + ..., of the splat box -- a few thousand photons make a latency-bound launch, and a
+// lane's chain of up to 27 dependent sqrt / divide / atomic steps is what it lasts.
 __global__ __launch_bounds__(256) void splat_delta_kernel(const float* __restrict__ old_photons, uint32_t old_stride,
                                                           const float* __restrict__ photons, const uint32_t* __restrict__ indices,
                                                           const int32_t* __restrict__ n_dev, int max_n, int apply_below, GridDev G,
@@ -1096,10 +1099,12 @@ __global__ __launch_bounds__(256) void splat_delta_kernel(const float* __restric
                                                           uint8_t* __restrict__ mask, float* __restrict__ out) {
     const int n = min(*n_dev, max_n);
     if (apply_below > 0 && n >= apply_below) return;
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    const int j = t >> 1;
-    if (j >= n) return;
-    const bool add = t & 1;
+    // (the launch is sized for a few thousand photons, not for the budget: a grid over 6 x max_n lanes is thousands of
+    // workgroups that read the count and leave -- 4 us of dispatch at 1 M photons; larger counts stride)
+    for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < 6ll * n; t += (long long)gridDim.x * blockDim.x) {
+    const int j = (int)(t / 6), part = (int)(t - 6ll * j);
+    const bool add = part & 1;
+    const int zpart = part >> 1;
     const size_t id = indices[j];
     for (int it = 0; it < n_interactions; ++it) {
         const float4* qo = reinterpret_cast<const float4*>(old_photons) + 2 * ((size_t)it * old_stride + (size_t)j);
@@ -1114,8 +1119,9 @@ __global__ __launch_bounds__(256) void splat_delta_kernel(const float* __restric
         f3 p = { a.x, a.y, a.z };
         f3 pw = { a.w * k, b.x * k, b.y * k };
         pw.x *= m; pw.y *= m; pw.z *= m;
-        splat_photon(out, G, p, pw, radius);
-        if (mask) mark_bricks_of(G, p, radius, bxn, byn, mask);
+        splat_photon(out, G, p, pw, radius, zpart, 3);
+        if (mask && zpart == 0) mark_bricks_of(G, p, radius, bxn, byn, mask);
+    }
     }
 }
 
@@ -1181,13 +1187,14 @@ int cpm_splat_delta(cpm_ctx* ctx, const float* old_photons8, int old_stride, con
     int rc = make_grid_dev(ctx, grid, G);
     if (rc) return rc;
     CPM_REQUIRE(ctx, max_indices >= 0 && old_stride >= max_indices && n_photons >= 0 && n_interactions >= 1 && radius > 0.f, "cpm_splat_delta: bad size");
-    CPM_REQUIRE(ctx, max_indices < (1 << 30), "cpm_splat_delta: too many indices");
+    CPM_REQUIRE(ctx, max_indices < (1 << 28), "cpm_splat_delta: too many indices");
     if (max_indices == 0) return CPM_OK;
     CPM_REQUIRE(ctx, old_photons8 && photons8 && indices && n_indices_dev && grid_out, "cpm_splat_delta: null buffer");
     CPM_REQUIRE_ALIGNED16(ctx, photons8, "cpm_splat_delta");
     CPM_REQUIRE_ALIGNED16(ctx, old_photons8, "cpm_splat_delta");
     const float k = kInv4Pi * scale;
-    CPM_LAUNCH(ctx, splat_delta_kernel, dim3((unsigned)div_up(2ll * max_indices, 256)), dim3(256), 0, (hipStream_t)stream, old_photons8,
+    const long long wgs = div_up(6ll * max_indices, 256);
+    CPM_LAUNCH(ctx, splat_delta_kernel, dim3((unsigned)(wgs < 2048 ? wgs : 2048)), dim3(256), 0, (hipStream_t)stream, old_photons8,
                (uint32_t)old_stride, photons8, indices, n_indices_dev, max_indices, apply_below, G, radius, k, n_photons, n_interactions,
                div_up(G.dx, 4), div_up(G.dy, 4), brick_mask, grid_out);
     CPM_LAUNCH_CHECK(ctx, "splat_delta_kernel");

@@ -279,6 +279,9 @@ void LightSampleMeshIntersectionCL::meshSampleIntersection(const Mesh* mesh, Lig
 
 PhotonTracerCL::~PhotonTracerCL() {
     auto& rt = CpmRuntime::get();
+    if (tfStream_) { (void)hipStreamSynchronize(tfStream_); (void)hipStreamDestroy(tfStream_); }
+    if (tfReady_) (void)hipEventDestroy(tfReady_);
+    if (mainMark_) (void)hipEventDestroy(mainMark_);
     if (tf_) cpm_tf_destroy(rt.ctx(), tf_);
 }
 void PhotonTracerCL::setRandomSeedSize(size_t nPhotons) {
@@ -289,11 +292,45 @@ void PhotonTracerCL::setRandomSeedSize(size_t nPhotons) {
 }
 void PhotonTracerCL::syncTF(const TransferFunction& tf) {
     auto& rt = CpmRuntime::get();
+    if (!rt.valid()) return;
+    // (the points first: evaluating the 1024-texel LUT costs the host as much as the launch it decides about)
+    const auto& pts = tf.points();
+    bool same = tf_ && pts.size() == tfPoints_.size();
+    for (size_t i = 0; same && i < pts.size(); ++i)
+        same = pts[i].pos == tfPoints_[i].pos && std::memcmp(&pts[i].color, &tfPoints_[i].color, sizeof(vec4)) == 0;
+    if (same) return;
+    tfPoints_ = pts;
     std::vector<float> lut = tf.lut(1024);
     if (tf_ && lut == tfLut_) return;
-    if (!tf_) rt.check(cpm_tf_create(rt.ctx(), lut.data(), 1024, 0, rt.stream(), &tf_), "cpm_tf_create");
-    else rt.check(cpm_tf_update(rt.ctx(), tf_, lut.data(), 0, rt.stream()), "cpm_tf_update");
+    if (!tf_) {
+        rt.check(cpm_tf_create(rt.ctx(), lut.data(), 1024, 0, rt.stream(), &tf_), "cpm_tf_create");
+    } else {
+        static const bool sideStream = !(getenv("CPM_TF_SIDE_STREAM") && getenv("CPM_TF_SIDE_STREAM")[0] == '0');  // (measurement switch)
+        if (!tfStream_ && sideStream) {
+            if (hipStreamCreateWithFlags(&tfStream_, hipStreamNonBlocking) != hipSuccess) tfStream_ = nullptr;
+            if (tfStream_ && (hipEventCreateWithFlags(&tfReady_, hipEventDisableTiming) != hipSuccess ||
+                              hipEventCreateWithFlags(&mainMark_, hipEventDisableTiming) != hipSuccess)) {
+                (void)hipStreamDestroy(tfStream_);
+                tfStream_ = nullptr;
+            }
+        }
+        if (tfStream_) {
+            // the upload may start once everything enqueued so far -- the previous trace reads the old LUT -- has run ...
+            (void)hipEventRecord(mainMark_, rt.stream());
+            (void)hipStreamWaitEvent(tfStream_, mainMark_, 0);
+            rt.check(cpm_tf_update(rt.ctx(), tf_, lut.data(), 0, tfStream_), "cpm_tf_update");
+            (void)hipEventRecord(tfReady_, tfStream_);
+            tfPending_ = true;  // ... and the next trace waits for it (waitTF)
+        } else {
+            rt.check(cpm_tf_update(rt.ctx(), tf_, lut.data(), 0, rt.stream()), "cpm_tf_update");
+        }
+    }
     tfLut_ = std::move(lut);
+}
+void PhotonTracerCL::waitTF() {
+    if (!tfPending_) return;
+    (void)hipStreamWaitEvent(CpmRuntime::get().stream(), tfReady_, 0);
+    tfPending_ = false;
 }
 void PhotonTracerCL::tracePhotons(const Volume* volume, const TransferFunction& transferFunction, const float aabb[8],
                                   const AdvancedMaterialProperty& material, float stepSize, const LightSamples* lightSamples,
@@ -305,6 +342,7 @@ void PhotonTracerCL::tracePhotons(const Volume* volume, const TransferFunction& 
     cpm_volume* vol_ = volume->getDeviceRepresentation();  // volume->getRepresentation<VolumeCL>() (:111)
     syncTF(transferFunction);
     if (!vol_ || !tf_) return;
+    waitTF();
     cpm_trace_params p = {};
     const vec4 m = material.getCombinedMaterialParameters();
     p.material[0] = m.x; p.material[1] = m.y; p.material[2] = m.z; p.material[3] = m.w;
@@ -345,6 +383,7 @@ void PhotonTracerCL::tracePhotonsSelected(const Volume* volume, const TransferFu
     cpm_volume* vol_ = volume->getDeviceRepresentation();
     syncTF(transferFunction);
     if (!vol_ || !tf_) return;
+    waitTF();
     cpm_trace_params p = {};
     const vec4 m = material.getCombinedMaterialParameters();
     p.material[0] = m.x; p.material[1] = m.y; p.material[2] = m.z; p.material[3] = m.w;
@@ -617,7 +656,8 @@ ProgressivePhotonTracerCL::ProgressivePhotonTracerCL() {
     for (PropertyBase* p : std::initializer_list<PropertyBase*>{ &samplingRate_, &radius_, &sceneRadianceScaling_, &maxIncrementalPhotonsToUpdate_,
                                                                 &equalIncrementalImportance_, &spatialSorting_, &maxScatteringEvents_, &noSingleScattering_,
                                                                 &alphaProp_, &workGroupSize_, &useGLSharing_, &enableProgressiveRefinement_,
-                                                                &enableProgressivePhotonRecomputation_, &clipX_, &clipY_, &clipZ_, &fusedImportanceBranch_ })
+                                                                &enableProgressivePhotonRecomputation_, &clipX_, &clipY_, &clipZ_, &fusedImportanceBranch_,
+                                                                &equalImportancePercentage_ })
         addProperty(*p);
     addProperty(advancedMaterial_); addProperty(camera_); addProperty(invalidateRendering_); addProperty(transferFunctionProperty_);
     transferFunctionProperty_.onChange([this]() { setTransferFunction(transferFunctionProperty_.get()); });             // tracercl.cpp:148
@@ -649,6 +689,7 @@ void ProgressivePhotonTracerCL::process() {  // progressivephotontracercl.cpp:21
     auto& rt = CpmRuntime::get();
     if (!photonTracer_.isValid() || !volumePort_.isReady()) return;
     rt.beginProfile();
+    photonTracer_.syncTF(transferFunction_);  // the LUT upload runs beside whatever precedes the trace
     if (volumePort_.changedSinceLastCheck()) invalidateProgressiveRendering(PhotonData::InvalidationReason::Volume);  // volumePort_.onChange (:107-108)
     recomputedPhotonIndices_->keepsReplaced = fusedImportanceBranch_.get() && maxIncrementalPhotonsToUpdate_.get() >= 100.f &&
                                               recomputationImportanceGrid_.isConnected();
@@ -713,7 +754,7 @@ void ProgressivePhotonTracerCL::process() {  // progressivephotontracercl.cpp:21
             }
             auto& rec = *recomputedPhotonIndices_;
             if (rec.replacedPhotons.getSize() != photonData_->photons_.getSize()) rec.replacedPhotons.setSize(photonData_->photons_.getSize());
-            photonRecomputationDetector_.setPercentage((int)maxIncrementalPhotonsToUpdate_.get());
+            photonRecomputationDetector_.setPercentage(equalImportancePercentage_.get() > 0 ? equalImportancePercentage_.get() : (int)maxIncrementalPhotonsToUpdate_.get());
             photonRecomputationDetector_.setIteration(photonRecomputationDetector_.getIteration() + 1);
             rt.check(cpm_selection_begin(rt.ctx(), selection_), "cpm_selection_begin");
             int offset = 0;
@@ -755,7 +796,7 @@ void ProgressivePhotonTracerCL::process() {  // progressivephotontracercl.cpp:21
         if (flag & (tfFlag | volFlag)) {
             auto grid = std::dynamic_pointer_cast<ImportanceUniformGrid3D>(recomputationImportanceGrid_.getData());
             if (!grid) { LogError("UniformGrid3DInport require ImportanceUniformGrid3D as input"); return; }
-            photonRecomputationDetector_.setPercentage((int)maxIncrementalPhotonsToUpdate_.get());
+            photonRecomputationDetector_.setPercentage(equalImportancePercentage_.get() > 0 ? equalImportancePercentage_.get() : (int)maxIncrementalPhotonsToUpdate_.get());
             photonRecomputationDetector_.setIteration(photonRecomputationDetector_.getIteration() + 1);
             int offset = 0;
             for (auto& l : lights) {

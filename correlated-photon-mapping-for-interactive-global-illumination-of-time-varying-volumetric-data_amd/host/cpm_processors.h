@@ -303,12 +303,20 @@ public:
                               unsigned int* resetImportances, int photonOffset, int maxInteractions, PhotonData* photonOutData);
     void setRandomSeedSize(size_t nPhotons);   // :176-182
     Buffer<uvec2>& randomState() { return randomState_; }
-private:
+    // Bring the device LUT up to date with `tf` on a stream of its own (the upload reads no context scratch), so that it runs
+    // beside the importance pass instead of ahead of the tracer; tracePhotons* make the main stream wait for it.  Called at
+    // the top of the tracer processor's evaluation; tracePhotons* call it too (a no-op then).
     void syncTF(const TransferFunction& tf);
+private:
+    void waitTF();
     Buffer<uvec2> randomState_;
     bool onlyMultipleScattering_ = false, progressive_ = false;
     cpm_tf* tf_ = nullptr;
     std::vector<float> tfLut_;
+    std::vector<TFPrimitive> tfPoints_;
+    hipStream_t tfStream_ = nullptr;
+    hipEvent_t tfReady_ = nullptr, mainMark_ = nullptr;
+    bool tfPending_ = false;
 };
 
 // progressivephotonmapping/photonrecomputationdetector.{h,cpp}
@@ -467,6 +475,9 @@ public:
     // false: the importance branch launch by launch with its host read of the count in the middle (always taken when the update
     // budget is below 100 %: ranking by importance is a host decision); true (default): the count stays on the device
     BoolProperty fusedImportanceBranch_{ "fusedImportanceBranch", "Importance branch without host round trip", true };
+    // measurement aid (not a reference property): with equalImportance on, select every (100 / p)-th photon while the update
+    // budget stays what maxIncrementalPhotonsToUpdate says (the reference uses that one property for both: 0 = as the reference)
+    IntProperty equalImportancePercentage_{ "equalImportancePercentage", "Equal importance: percentage selected", 0 };
     ~ProgressivePhotonTracerCL();
 private:
     cpm_selection* selection_ = nullptr;

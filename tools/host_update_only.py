@@ -1,0 +1,34 @@
+#!/usr/bin/env python3
+"""The correlated update through the C++ processors, alone, for rocprofv3: config3 = 60 TF edits (alternating edit / revert) of
+the 256^3 / 1 M photon network; config5 = the time-varying network stepped a quarter of a sequence step at a time.
+usage: tools/host_update_only.py [config3|config5] [reps]"""
+import sys
+sys.path.insert(0, '.')
+import numpy as np, torch, cpm_amd, importlib
+S, P, B = cpm_amd.synthetic, cpm_amd.pipeline, cpm_amd.binding
+what = sys.argv[1] if len(sys.argv) > 1 else "config3"
+reps = int(sys.argv[2]) if len(sys.argv) > 2 else 60
+ctx = B.Context(0)
+H = importlib.import_module(cpm_amd.__name__ + ".hostlayer")
+hl = H.load()
+vol = S.heterogeneous_volume(256)
+base = list(S.WORKSPACE_TF_POINTS); edit = list(base); edit[3] = (0.26,) + base[3][1:]
+d = P._normalize((0.3, 0.5, -1.0)); pos = np.array([0.5] * 3, np.float32) - np.float32(2.0) * d
+if what == "config3":
+    net = H.HostNetwork(hl, vol, 1024, pos, d, base, size_option=2, correlated=True)
+    net.evaluate(first=True)
+    full = net.bench_full_frames(reps)
+    ms, n = net.bench_tf_edits(edit, base, reps)
+    print(f"config3: full frame {np.median(full[5:]):.4f} ms, update {np.median(ms[5:]):.4f} ms (p10 {np.percentile(ms[5:], 10):.4f}, p90 {np.percentile(ms[5:], 90):.4f}), "
+          f"re-traced {n[-1]} of {net.n_photons} = {n[-1] / net.n_photons:.4%}, path {net.last_path}")
+else:
+    n_steps = 8
+    seq_np = np.stack([S.heterogeneous_volume(256, S.sequence_blob_center(t, 32)) for t in range(n_steps)])
+    seq = H.HostSequence(hl, seq_np)
+    net = H.HostNetwork(hl, seq_np[0], 1024, pos, d, base, size_option=2, correlated=True)
+    seq.attach(net)
+    net.evaluate(first=True)
+    rows = [seq.step(net, 0.25 * (k % (4 * (n_steps - 1)))) for k in range(1, reps)]
+    rows = rows[3:]
+    print(f"config5: players {np.median([r[1] for r in rows]):.4f} ms, update {np.median([r[2] for r in rows]):.4f} ms, "
+          f"re-traced {np.mean([r[0] for r in rows]) / net.n_photons:.4%}, path {net.last_path}")
