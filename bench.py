@@ -495,6 +495,14 @@ def main():
             net = hostlayer.HostNetwork(hl, vol_np, nx, lpos, dnorm, base_pts, size_option=vdim // gdim, correlated=True)
             net.evaluate(first=True)
             full_ms = net.bench_full_frames(reps_c)
+            # as shipped: importanceBranchPolicy = adaptive -- the tracer serves an edit with whichever of importance branch +
+            # add-remove and full frame it has measured cheaper (the first edit probes the branch)
+            ms_auto, n_auto = net.bench_tf_edits(edit, base_pts, reps_c)
+            auto_costs = {k: round(float(v), 4) for k, v in net.path_costs().items()}
+            auto_decision = net.last_decision
+            net.set_string("tracer", "importanceBranchPolicy", "never")     # ... the same edits served by full frames only
+            ms_never, _ = net.bench_tf_edits(edit, base_pts, reps_c)
+            net.set_string("tracer", "importanceBranchPolicy", "always")    # ... and by the importance branch only (the reference's behaviour)
             ms, nre = net.bench_tf_edits(edit, base_pts, reps_c)
             net.set_float("tracer", "fusedImportanceBranch", 0.0)      # the launch-by-launch branch with its host wait, for comparison
             net.evaluate()
@@ -521,7 +529,12 @@ def main():
             cheaper = [r["fraction"] for r in sweep.values() if min(r["add_remove_ms"], r["rebuild_ms"]) < full_med]
             break_even = max(cheaper) if cheaper else 0.0
             extras["config3_tf_edit"] = {
-                "update_ms": round(float(np.median(ms[10:])), 4), "update_ms_p10_p90": [round(float(np.percentile(ms[10:], q)), 4) for q in (10, 90)],
+                "update_ms": round(float(np.median(ms_auto[10:])), 4),
+                "update_ms_p10_p90": [round(float(np.percentile(ms_auto[10:], q)), 4) for q in (10, 90)],
+                "served_by": auto_decision, "full_frames_among_updates": round(float(np.mean(n_auto[10:] < 0)), 3),
+                "measured_path_costs_ms": auto_costs,
+                "importance_branch_update_ms": round(float(np.median(ms[10:])), 4),
+                "full_frame_on_edit_ms": round(float(np.median(ms_never[10:])), 4),
                 "fraction_retraced": round(float(np.mean(nre[10:])) / max(n_host, 1), 5), "updates": int(reps_c - 10),
                 "full_frame_ms_same_network": round(float(np.median(full_ms[10:])), 4),
                 "launch_by_launch_update_ms": round(float(np.median(ms_legacy[10:])), 4),
@@ -575,7 +588,8 @@ def main():
             extras["config5_time_step"]["host_network"] = {
                 "steps": len(rows), "displayed_times": "a quarter of a sequence step apart",
                 "players_ms": round(float(np.median([r[1] for r in rows])), 4), "update_ms": round(float(np.median([r[2] for r in rows])), 4),
-                "fraction_retraced": round(float(np.mean([r[0] for r in rows])) / max(net.n_photons, 1), 5),
+                "fraction_retraced": round(float(np.mean([max(r[0], 0) for r in rows])) / max(net.n_photons, 1), 5),
+                "full_frames_among_steps": round(float(np.mean([r[0] < 0 for r in rows])), 3), "served_by": net.last_decision,
                 "measured": "libcpm_host.so: VolumeSequencePlayer + 2 UniformGrid3D players (players_ms); importance (time-varying) -> tracer -> light volume (update_ms)"}
             net.close(); seq.close()
             del seq_np

@@ -107,7 +107,7 @@ int cpmh_set_property_float(cpmh_network* net, const char* processor, const char
     return -2;
 }
 int cpmh_set_property_string(cpmh_network* net, const char* processor, const char* id, const char* value) {
-    Processor* p = !strcmp(processor, "lightvolume") ? (Processor*)&net->lightVolume : nullptr;
+    Processor* p = !strcmp(processor, "lightvolume") ? (Processor*)&net->lightVolume : !strcmp(processor, "tracer") ? (Processor*)&net->tracer : nullptr;
     if (!p) return -1;
     if (auto* s = dynamic_cast<StringOptionProperty*>(p->getPropertyByIdentifier(id))) { s->set(value); return 0; }
     return -2;
@@ -131,6 +131,12 @@ int cpmh_download_photons(cpmh_network* net, float* out) {
 int cpmh_n_recomputed(cpmh_network* net) { auto r = net->tracer.recomputedIndicesPort_.getData(); return r ? r->resolveCount() : -1; }
 int cpmh_remaining(cpmh_network* net) { return net->tracer.remainingPhotonsToUpdate(); }
 const char* cpmh_last_light_volume_path(cpmh_network* net) { return net->lightVolume.lastPath(); }
+const char* cpmh_last_tracer_decision(cpmh_network* net) { return net->tracer.lastDecision(); }
+// measured GPU-timeline cost of the two ways to serve a change: { full trace, full light volume, branch trace, branch light volume } ms (-1 = not measured yet)
+void cpmh_path_costs(cpmh_network* net, float out[4]) {
+    const auto& c = net->tracer.costs();
+    out[0] = c.fullTraceMs; out[1] = c.fullLightVolumeMs; out[2] = c.branchTraceMs; out[3] = c.branchLightVolumeMs;
+}
 // Multi-GPU call site, driven with a communicator of size 1 on this process's device (a real RCCL communicator: the
 // network's photons are then "the one shard", the outport carries the reduced volume).
 int cpmh_enable_shard_reduce(cpmh_network* net) {

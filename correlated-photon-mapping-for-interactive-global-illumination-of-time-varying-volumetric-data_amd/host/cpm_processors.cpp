@@ -56,6 +56,30 @@ bool CpmRuntime::check(int status, const char* what) const {
     return false;
 }
 
+StreamSpan::~StreamSpan() {
+    if (a_) (void)hipEventDestroy(a_);
+    if (b_) (void)hipEventDestroy(b_);
+}
+void StreamSpan::begin(hipStream_t s, float* target) {
+    poll();
+    if (pending_) { open_ = false; return; }  // the previous span has not completed yet: skip this measurement
+    if (!a_ && (hipEventCreate(&a_) != hipSuccess || hipEventCreate(&b_) != hipSuccess)) { a_ = b_ = nullptr; open_ = false; return; }
+    target_ = target;
+    open_ = hipEventRecord(a_, s) == hipSuccess;
+}
+void StreamSpan::end(hipStream_t s) {
+    if (!open_) return;
+    open_ = false;
+    pending_ = hipEventRecord(b_, s) == hipSuccess;
+}
+void StreamSpan::poll() {
+    if (!pending_ || hipEventQuery(b_) != hipSuccess) return;
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, a_, b_) == hipSuccess && target_)
+        *target_ = *target_ < -1.5f ? -1.f : (*target_ < 0.f ? ms : 0.5f * (*target_ + ms));  // first sample dropped, then a running mean
+    pending_ = false;
+}
+
 // ---- data ---------------------------------------------------------------------------------------------
 
 void TransferFunction::sort() {
@@ -279,9 +303,6 @@ void LightSampleMeshIntersectionCL::meshSampleIntersection(const Mesh* mesh, Lig
 
 PhotonTracerCL::~PhotonTracerCL() {
     auto& rt = CpmRuntime::get();
-    if (tfStream_) { (void)hipStreamSynchronize(tfStream_); (void)hipStreamDestroy(tfStream_); }
-    if (tfReady_) (void)hipEventDestroy(tfReady_);
-    if (mainMark_) (void)hipEventDestroy(mainMark_);
     if (tf_) cpm_tf_destroy(rt.ctx(), tf_);
 }
 void PhotonTracerCL::setRandomSeedSize(size_t nPhotons) {
@@ -302,35 +323,11 @@ void PhotonTracerCL::syncTF(const TransferFunction& tf) {
     tfPoints_ = pts;
     std::vector<float> lut = tf.lut(1024);
     if (tf_ && lut == tfLut_) return;
-    if (!tf_) {
-        rt.check(cpm_tf_create(rt.ctx(), lut.data(), 1024, 0, rt.stream(), &tf_), "cpm_tf_create");
-    } else {
-        static const bool sideStream = !(getenv("CPM_TF_SIDE_STREAM") && getenv("CPM_TF_SIDE_STREAM")[0] == '0');  // (measurement switch)
-        if (!tfStream_ && sideStream) {
-            if (hipStreamCreateWithFlags(&tfStream_, hipStreamNonBlocking) != hipSuccess) tfStream_ = nullptr;
-            if (tfStream_ && (hipEventCreateWithFlags(&tfReady_, hipEventDisableTiming) != hipSuccess ||
-                              hipEventCreateWithFlags(&mainMark_, hipEventDisableTiming) != hipSuccess)) {
-                (void)hipStreamDestroy(tfStream_);
-                tfStream_ = nullptr;
-            }
-        }
-        if (tfStream_) {
-            // the upload may start once everything enqueued so far -- the previous trace reads the old LUT -- has run ...
-            (void)hipEventRecord(mainMark_, rt.stream());
-            (void)hipStreamWaitEvent(tfStream_, mainMark_, 0);
-            rt.check(cpm_tf_update(rt.ctx(), tf_, lut.data(), 0, tfStream_), "cpm_tf_update");
-            (void)hipEventRecord(tfReady_, tfStream_);
-            tfPending_ = true;  // ... and the next trace waits for it (waitTF)
-        } else {
-            rt.check(cpm_tf_update(rt.ctx(), tf_, lut.data(), 0, rt.stream()), "cpm_tf_update");
-        }
-    }
+    // (cpm_tf_update consumes the host LUT on return and does not wait for the stream.  Putting the upload on a stream of its
+    // own, beside the importance pass, was measured: no gain on the branch, +10 us of cross-stream latency on a full frame.)
+    if (!tf_) rt.check(cpm_tf_create(rt.ctx(), lut.data(), 1024, 0, rt.stream(), &tf_), "cpm_tf_create");
+    else rt.check(cpm_tf_update(rt.ctx(), tf_, lut.data(), 0, rt.stream()), "cpm_tf_update");
     tfLut_ = std::move(lut);
-}
-void PhotonTracerCL::waitTF() {
-    if (!tfPending_) return;
-    (void)hipStreamWaitEvent(CpmRuntime::get().stream(), tfReady_, 0);
-    tfPending_ = false;
 }
 void PhotonTracerCL::tracePhotons(const Volume* volume, const TransferFunction& transferFunction, const float aabb[8],
                                   const AdvancedMaterialProperty& material, float stepSize, const LightSamples* lightSamples,
@@ -342,7 +339,6 @@ void PhotonTracerCL::tracePhotons(const Volume* volume, const TransferFunction& 
     cpm_volume* vol_ = volume->getDeviceRepresentation();  // volume->getRepresentation<VolumeCL>() (:111)
     syncTF(transferFunction);
     if (!vol_ || !tf_) return;
-    waitTF();
     cpm_trace_params p = {};
     const vec4 m = material.getCombinedMaterialParameters();
     p.material[0] = m.x; p.material[1] = m.y; p.material[2] = m.z; p.material[3] = m.w;
@@ -383,7 +379,6 @@ void PhotonTracerCL::tracePhotonsSelected(const Volume* volume, const TransferFu
     cpm_volume* vol_ = volume->getDeviceRepresentation();
     syncTF(transferFunction);
     if (!vol_ || !tf_) return;
-    waitTF();
     cpm_trace_params p = {};
     const vec4 m = material.getCombinedMaterialParameters();
     p.material[0] = m.x; p.material[1] = m.y; p.material[2] = m.z; p.material[3] = m.w;
@@ -657,7 +652,7 @@ ProgressivePhotonTracerCL::ProgressivePhotonTracerCL() {
                                                                 &equalIncrementalImportance_, &spatialSorting_, &maxScatteringEvents_, &noSingleScattering_,
                                                                 &alphaProp_, &workGroupSize_, &useGLSharing_, &enableProgressiveRefinement_,
                                                                 &enableProgressivePhotonRecomputation_, &clipX_, &clipY_, &clipZ_, &fusedImportanceBranch_,
-                                                                &equalImportancePercentage_ })
+                                                                &equalImportancePercentage_, &importanceBranchPolicy_ })
         addProperty(*p);
     addProperty(advancedMaterial_); addProperty(camera_); addProperty(invalidateRendering_); addProperty(transferFunctionProperty_);
     transferFunctionProperty_.onChange([this]() { setTransferFunction(transferFunctionProperty_.get()); });             // tracercl.cpp:148
@@ -689,8 +684,10 @@ void ProgressivePhotonTracerCL::process() {  // progressivephotontracercl.cpp:21
     auto& rt = CpmRuntime::get();
     if (!photonTracer_.isValid() || !volumePort_.isReady()) return;
     rt.beginProfile();
-    photonTracer_.syncTF(transferFunction_);  // the LUT upload runs beside whatever precedes the trace
+    span_.poll();
+    photonTracer_.syncTF(transferFunction_);  // the LUT upload goes first: nothing waits for it later
     if (volumePort_.changedSinceLastCheck()) invalidateProgressiveRendering(PhotonData::InvalidationReason::Volume);  // volumePort_.onChange (:107-108)
+    recomputedPhotonIndices_->costs = &costs_;
     recomputedPhotonIndices_->keepsReplaced = fusedImportanceBranch_.get() && maxIncrementalPhotonsToUpdate_.get() >= 100.f &&
                                               recomputationImportanceGrid_.isConnected();
     const auto lights = lightSamples_.getVectorData();
@@ -708,6 +705,7 @@ void ProgressivePhotonTracerCL::process() {  // progressivephotontracercl.cpp:21
     seenLights_ = std::move(now);
     if (nPhotons != photonData_->getNumberOfPhotons() || maxScatteringEvents_.get() != photonData_->getMaxPhotonInteractions()) {
         photonData_->setSize(nPhotons, maxScatteringEvents_.get());
+        costs_ = PathCosts();  // another problem size: measure again
         invalidateProgressiveRendering(PhotonData::InvalidationReason::All);
     }
     const Volume* volume = volumePort_.getData().get();
@@ -741,8 +739,49 @@ void ProgressivePhotonTracerCL::process() {  // progressivephotontracercl.cpp:21
         // The whole branch with the count kept on the device (cpm.h, "the correlated update without a host round trip"):
         // possible when every changed photon is traced in this evaluation -- a budget below 100 % needs the ranking by
         // importance, a host decision on the count.
-        const bool fused = fusedImportanceBranch_.get() && (flag & (tfFlag | volFlag)) && maxIncrementalPhotonsToUpdate_.get() >= 100.f;
+        bool fused = fusedImportanceBranch_.get() && (flag & (tfFlag | volFlag)) && maxIncrementalPhotonsToUpdate_.get() >= 100.f;
+        // The branch exists to avoid re-tracing everything; where its measured cost (importance pass over ALL photons, re-trace,
+        // add-remove) exceeds the full frame's, take the frame: the correlated RNG streams make the photons the same either way.
+        bool takeFullFrame = false;
+        if (fused && importanceBranchPolicy_.get() == "never") {
+            takeFullFrame = true;
+        } else if (fused && importanceBranchPolicy_.get() == "adaptive") {
+            auto& c = costs_;
+            if (c.known() && c.branchTraceMs + c.branchLightVolumeMs > c.fullTraceMs + c.fullLightVolumeMs && c.evaluationsSinceProbe < 32) {
+                takeFullFrame = true;
+                ++c.evaluationsSinceProbe;
+            } else {
+                c.evaluationsSinceProbe = 0;
+            }
+        }
+        if (takeFullFrame) {
+            fused = false;
+            lastDecision_ = importanceBranchPolicy_.get() == "never" ? "full frame (policy)" : "full frame (measured cheaper than the importance branch)";
+            span_.begin(rt.stream(), &costs_.fullTraceMs);
+            int offset = 0;
+            for (auto& l : lights) {
+                photonTracer_.tracePhotons(volume, transferFunction_, aabb_, advancedMaterial_, stepSize, l.get(), nullptr, 0, offset, 0, maxInteractions,
+                                           photonData_.get());
+                offset += (int)l->getSize();
+            }
+            resetPhotonImportance(0, photonRecomputationImportance_.getSize());
+            span_.end(rt.stream());
+            recomputedPhotonIndices_->nRecomputedPhotons = -1;
+            recomputedPhotonIndices_->takenInPlaceOfBranch = true;
+            remainingPhotonsToUpdate_ = 0;
+            remainingPhotonsOffset_ = 0;
+            enableProgressiveRefinement_.set(false);
+            recomputedIndicesPort_.setData(recomputedPhotonIndices_);
+            photonData_->setInvalidationReason(invalidationFlag_);
+            invalidationFlag_ = PhotonData::InvalidationReason(0);
+            outport_.setData(photonData_);
+            if (rt.profiling()) rt.logProfile("Photon tracing");
+            return;
+        }
+        recomputedPhotonIndices_->takenInPlaceOfBranch = false;
         if (fused) {
+            lastDecision_ = "importance branch";
+            span_.begin(rt.stream(), &costs_.branchTraceMs);
             auto grid = std::dynamic_pointer_cast<ImportanceUniformGrid3D>(recomputationImportanceGrid_.getData());
             if (!grid) { LogError("UniformGrid3DInport require ImportanceUniformGrid3D as input"); return; }
             const size_t N = photonData_->getNumberOfPhotons();
@@ -771,6 +810,7 @@ void ProgressivePhotonTracerCL::process() {  // progressivephotontracercl.cpp:21
                                                    photonRecomputationImportance_.device(), offset, maxInteractions, photonData_.get());
                 offset += (int)l->getSize();
             }
+            span_.end(rt.stream());
             rec.selection = selection_;
             rec.countPending = true;
             rec.nRecomputedPhotons = 0;  // resolved on first use (resolveCount)
@@ -843,12 +883,16 @@ void ProgressivePhotonTracerCL::process() {  // progressivephotontracercl.cpp:21
         remainingPhotonsToUpdate_ -= (int)nPhotonsToCompute;
         enableProgressiveRefinement_.set(remainingPhotonsToUpdate_ > 0 && enableProgressivePhotonRecomputation_.get());
     } else {
+        lastDecision_ = "full frame";
+        span_.begin(rt.stream(), &costs_.fullTraceMs);
         int offset = 0;
         for (auto& l : lights) {
             photonTracer_.tracePhotons(volume, transferFunction_, aabb_, advancedMaterial_, stepSize, l.get(), nullptr, 0, offset, 0, maxInteractions,
                                        photonData_.get());
             offset += (int)l->getSize();
         }
+        span_.end(rt.stream());
+        recomputedPhotonIndices_->takenInPlaceOfBranch = false;
         recomputedPhotonIndices_->nRecomputedPhotons = -1;
         recomputedPhotonIndices_->countPending = false;
         recomputedPhotonIndices_->replacedValid = false;
@@ -899,7 +943,9 @@ void PhotonToLightVolumeProcessorCL::process() {  // photontolightvolumeprocesso
     auto& rt = CpmRuntime::get();
     if (!rt.valid() || !photons_.isReady() || !volumeInport_.isReady()) return;
     rt.beginProfile();
+    span_.poll();
     struct LogAtExit { const CpmRuntime& r; ~LogAtExit() { r.logProfile("Photons to light volume"); } } logAtExit{ rt };
+    struct SpanAtExit { StreamSpan& s; hipStream_t st; ~SpanAtExit() { s.end(st); } } spanAtExit{ span_, rt.stream() };
     auto photonData = photons_.getData();
     if (volumeSizeOption_.get() == 0) {  // size from the photon radius (:144-163, Q15)
         const size_t n = (size_t)std::ceil(1.0 / photonData->getRadiusRelativeToSceneSize());
@@ -945,6 +991,9 @@ void PhotonToLightVolumeProcessorCL::process() {  // photontolightvolumeprocesso
     }
     bool partialUpdate = false;  // this evaluation only touched the re-traced photons
     bool marksDone = false;      // brickMask_ already holds the old AND new positions' bricks
+    // what this evaluation costs on the GPU's timeline, filed under the way the tracer served the change (PathCosts)
+    if (haveIdx && nRecomputed != 0 && rec->costs)
+        span_.begin(rt.stream(), (nRecomputed < 0) ? &rec->costs->fullLightVolumeMs : &rec->costs->branchLightVolumeMs);
     if (canAddRemove) {
         partialUpdate = true;
         const unsigned int* idx = rec->indicesToRecomputedPhotons.device();

@@ -36,6 +36,31 @@ private:
     cpm_ctx* ctx_ = nullptr;
 };
 
+// Measured cost of the two ways to serve a transfer-function / volume change, in GPU-timeline milliseconds (HIP events
+// recorded in the stream around a processor's launches, read back at a later evaluation -- never waited for):
+// tracer + light volume of a full frame against importance branch + add-remove.  Owned by the tracer processor, which decides
+// with it; the light-volume processor files its share through the indices port's payload.
+struct PathCosts {
+    // (-2: never run; -1: run once -- a kernel's first launch carries its one-off load, that sample is dropped; >= 0: running mean)
+    float fullTraceMs = -2.f, fullLightVolumeMs = -2.f;       // everything re-traced; volume rebuilt
+    float branchTraceMs = -2.f, branchLightVolumeMs = -2.f;   // importance branch; add-remove (or rebuild above its threshold)
+    int evaluationsSinceProbe = 0;                            // full frames taken in place of the branch since it was last measured
+    bool known() const { return fullTraceMs >= 0.f && fullLightVolumeMs >= 0.f && branchTraceMs >= 0.f && branchLightVolumeMs >= 0.f; }
+};
+
+// A pair of events around the launches of one evaluation; the elapsed time is picked up when a later evaluation finds it ready.
+class StreamSpan {
+public:
+    ~StreamSpan();
+    void begin(hipStream_t s, float* target);  // records the start; `target` receives the milliseconds once they are known
+    void end(hipStream_t s);
+    void poll();                               // non-blocking: stores the elapsed time if the end event has completed
+private:
+    hipEvent_t a_ = nullptr, b_ = nullptr;
+    float* target_ = nullptr;
+    bool pending_ = false, open_ = false;
+};
+
 // ---- data types (L2) ---------------------------------------------------------------------------
 
 // progressivephotonmapping/photondata.h:47-56
@@ -69,6 +94,8 @@ struct RecomputedPhotonIndices {
     int replacedStride = 0;
     bool replacedValid = false;
     bool keepsReplaced = false;  // the tracer is configured to hand over replaced records on its importance branch (no snapshot needed downstream)
+    bool takenInPlaceOfBranch = false;  // nRecomputedPhotons == -1 because the tracer chose the full frame over its importance branch
+    PathCosts* costs = nullptr;         // the tracer's measurements (the light-volume processor adds its share)
 };
 
 // progressivephotonmapping/photondata.h:65-156, photondata.cpp:36-98
@@ -303,20 +330,15 @@ public:
                               unsigned int* resetImportances, int photonOffset, int maxInteractions, PhotonData* photonOutData);
     void setRandomSeedSize(size_t nPhotons);   // :176-182
     Buffer<uvec2>& randomState() { return randomState_; }
-    // Bring the device LUT up to date with `tf` on a stream of its own (the upload reads no context scratch), so that it runs
-    // beside the importance pass instead of ahead of the tracer; tracePhotons* make the main stream wait for it.  Called at
-    // the top of the tracer processor's evaluation; tracePhotons* call it too (a no-op then).
+    // Bring the device LUT up to date with `tf` (one small launch, no host wait).  Called at the top of the tracer processor's
+    // evaluation; tracePhotons* call it too (a no-op then).
     void syncTF(const TransferFunction& tf);
 private:
-    void waitTF();
     Buffer<uvec2> randomState_;
     bool onlyMultipleScattering_ = false, progressive_ = false;
     cpm_tf* tf_ = nullptr;
     std::vector<float> tfLut_;
     std::vector<TFPrimitive> tfPoints_;
-    hipStream_t tfStream_ = nullptr;
-    hipEvent_t tfReady_ = nullptr, mainMark_ = nullptr;
-    bool tfPending_ = false;
 };
 
 // progressivephotonmapping/photonrecomputationdetector.{h,cpp}
@@ -475,6 +497,14 @@ public:
     // false: the importance branch launch by launch with its host read of the count in the middle (always taken when the update
     // budget is below 100 %: ranking by importance is a host decision); true (default): the count stays on the device
     BoolProperty fusedImportanceBranch_{ "fusedImportanceBranch", "Importance branch without host round trip", true };
+    // "adaptive": where the measured cost of importance branch + add-remove exceeds that of re-tracing and rebuilding
+    // everything (CpmRuntime::PathCosts), a TF / volume change is served by the full frame -- the same photons (correlated RNG
+    // streams), the same light volume within the add-remove tolerance; the branch is measured again every 32nd such evaluation.
+    // Applies when every changed photon would be traced in one evaluation (budget 100 %).  Not a reference property.
+    // "adaptive" (default) | "always" (the reference's behaviour: the branch on every TF / volume change) | "never" (the full frame)
+    StringOptionProperty importanceBranchPolicy_{ "importanceBranchPolicy", "Importance branch", "adaptive" };
+    const char* lastDecision() const { return lastDecision_; }
+    PathCosts& costs() { return costs_; }
     // measurement aid (not a reference property): with equalImportance on, select every (100 / p)-th photon while the update
     // budget stays what maxIncrementalPhotonsToUpdate says (the reference uses that one property for both: 0 = as the reference)
     IntProperty equalImportancePercentage_{ "equalImportancePercentage", "Equal importance: percentage selected", 0 };
@@ -482,6 +512,9 @@ public:
 private:
     cpm_selection* selection_ = nullptr;
     size_t selectionPhotons_ = 0;
+    StreamSpan span_;
+    PathCosts costs_;
+    const char* lastDecision_ = "none";
     void onClipChange();
     float getSceneRadius() const { return 0.5f * std::sqrt(12.f); }  // unit-model volume spanning [-1, 1]^3
     void resetPhotonImportance(size_t offset, size_t n);
@@ -552,6 +585,7 @@ private:
     const char* lastReduce_ = "none";
     std::shared_ptr<Volume> lightVolume_ = std::make_shared<Volume>(size3_t{ 1, 1, 1 }, CPM_F32);
     Buffer<vec4> prevPhotons_;
+    StreamSpan span_;
     bool prevPhotonsValid_ = false;  // prevPhotons_ is the photon buffer as of the end of the previous evaluation
     bool snapshotFree_ = true;       // no whole-buffer snapshot while the tracer hands over the replaced records (set false to keep the reference's copy)
     Buffer<unsigned int> order_, cellStart_;

@@ -25,6 +25,8 @@ def load():
         "cpmh_n_photons": (i32, [vp]),
         "cpmh_n_recomputed": (i32, [vp]),
         "cpmh_last_light_volume_path": (C.c_char_p, [vp]),
+        "cpmh_last_tracer_decision": (C.c_char_p, [vp]),
+        "cpmh_path_costs": (None, [vp, vp]),
         "cpmh_bench_tf_edits": (i32, [vp, vp, i32, vp, i32, i32, vp, vp]),
         "cpmh_bench_full_frames": (i32, [vp, i32, vp]),
         "cpmh_sequence_create": (vp, [vp, i32, i32, i32, i32, i32, i32]),
@@ -61,6 +63,10 @@ class HostNetwork:
         if self.lib.cpmh_set_property_float(self.h, processor.encode(), prop.encode(), float(value)) != 0:
             raise KeyError(f"{processor}.{prop}")
 
+    def set_string(self, processor: str, prop: str, value: str):
+        if self.lib.cpmh_set_property_string(self.h, processor.encode(), prop.encode(), value.encode()) != 0:
+            raise KeyError(f"{processor}.{prop}")
+
     @property
     def n_photons(self):
         return int(self.lib.cpmh_n_photons(self.h))
@@ -68,6 +74,15 @@ class HostNetwork:
     @property
     def last_path(self):
         return self.lib.cpmh_last_light_volume_path(self.h).decode()
+
+    @property
+    def last_decision(self):
+        return self.lib.cpmh_last_tracer_decision(self.h).decode()
+
+    def path_costs(self):
+        c = (C.c_float * 4)()
+        self.lib.cpmh_path_costs(self.h, C.byref(c))
+        return {"full_trace_ms": c[0], "full_light_volume_ms": c[1], "branch_trace_ms": c[2], "branch_light_volume_ms": c[3]}
 
     def bench_tf_edits(self, points_a, points_b, reps):
         a = np.ascontiguousarray(np.asarray(points_a, np.float32))

@@ -23,6 +23,8 @@ def hostx(seqlib):
     for name, res, args in [("cpmh_bench_tf_edits", C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
                             ("cpmh_bench_full_frames", C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
                             ("cpmh_attach_sequence", C.c_int, [C.c_void_p, C.c_void_p]),
+                            ("cpmh_last_tracer_decision", C.c_char_p, [C.c_void_p]),
+                            ("cpmh_path_costs", None, [C.c_void_p, C.c_void_p]),
                             ("cpmh_sequence_step", C.c_int, [C.c_void_p, C.c_void_p, C.c_float, C.c_void_p])]:
         f = getattr(lib, name)
         f.restype, f.argtypes = res, args
@@ -40,6 +42,7 @@ def test_fused_branch_equals_launch_by_launch(hostx, cpm, max_scattering):
     a = Net(host, vol, 128, pos, d, BASE, correlated=True, max_scattering=max_scattering)
     b = Net(host, vol, 128, pos, d, BASE, correlated=True, max_scattering=max_scattering)
     assert host.cpmh_set_property_float(b.h, b"tracer", b"fusedImportanceBranch", 0.0) == 0
+    assert host.cpmh_set_property_string(a.h, b"tracer", b"importanceBranchPolicy", b"always") == 0   # the branch itself is under test
     for net in (a, b):
         net.evaluate(first=True)
         assert host.cpmh_set_property_float(net.h, b"lightvolume", b"incrementalRecomputationThreshold", 100.0) == 0
@@ -129,6 +132,7 @@ def test_time_varying_network(hostx, cpm):
     pos, d = _light(cpm, (0.3, 0.5, -1.0))
     net = Net(host, vols[0], 128, pos, d, S.WORKSPACE_TF_POINTS, correlated=True)
     assert host.cpmh_attach_sequence(net.h, seq) == 0
+    assert host.cpmh_set_property_string(net.h, b"tracer", b"importanceBranchPolicy", b"always") == 0
     net.evaluate(first=True)
     assert host.cpmh_set_property_float(net.h, b"lightvolume", b"incrementalRecomputationThreshold", 100.0) == 0
     n_total = host.cpmh_n_photons(net.h)
@@ -160,6 +164,7 @@ def test_timing_harness(hostx, cpm):
     vol = S.heterogeneous_volume(64)
     pos, d = _light(cpm, (0.3, 0.5, -1.0))
     net = Net(host, vol, 128, pos, d, BASE, correlated=True)
+    assert host.cpmh_set_property_string(net.h, b"tracer", b"importanceBranchPolicy", b"always") == 0
     net.evaluate(first=True)
     a = np.ascontiguousarray(np.asarray(EDIT, np.float32))
     b = np.ascontiguousarray(np.asarray(BASE, np.float32))
@@ -170,4 +175,48 @@ def test_timing_harness(hostx, cpm):
     assert all(m > 0 for m in ms) and len(set(n)) == 1 and n[0] > 0
     assert host.cpmh_bench_full_frames(net.h, reps, C.byref(ms)) == 0
     assert all(m > 0 for m in ms) and host.cpmh_n_recomputed(net.h) == -1
+    net.close()
+
+
+def test_adaptive_branch_takes_the_measured_cheaper_path(hostx, cpm):
+    """importanceBranchPolicy = adaptive (the default): the first TF edit goes through the importance branch (nothing measured yet); from
+    then on the tracer compares the GPU-timeline cost of branch + add-remove with that of a full frame and serves the edit
+    with the cheaper one.  Whatever it takes, the photons are those of a from-scratch network."""
+    host = hostx
+    S = cpm.synthetic
+    vol = S.heterogeneous_volume(64)
+    pos, d = _light(cpm, (0.3, 0.5, -1.0))
+    net = Net(host, vol, 128, pos, d, BASE, correlated=True)
+    net.evaluate(first=True)
+    assert host.cpmh_last_tracer_decision(net.h) == b"full frame"
+    assert host.cpmh_set_property_float(net.h, b"lightvolume", b"incrementalRecomputationThreshold", 100.0) == 0
+    costs = (C.c_float * 4)()
+    decisions = []
+    net.evaluate(first=True)                              # a second full frame: the first sample of a path is dropped
+    for k in range(6):
+        pts = EDIT if k % 2 == 0 else BASE
+        host.cpmh_path_costs(net.h, C.byref(costs))
+        before = list(costs)
+        net.set_tf(pts)
+        net.evaluate()                                    # (ends with a device synchronisation: the spans are complete)
+        dec = host.cpmh_last_tracer_decision(net.h)
+        decisions.append(dec)
+        known = all(c >= 0 for c in before)
+        if not known:
+            assert dec == b"importance branch", (k, before)
+        else:
+            want_full = before[2] + before[3] > before[0] + before[1]
+            assert dec.startswith(b"full frame (measured") == want_full, (k, before, dec)
+        n = host.cpmh_n_recomputed(net.h)
+        assert (n == -1) == dec.startswith(b"full frame")
+        fresh = Net(host, vol, 128, pos, d, pts, correlated=False)
+        fresh.evaluate(first=True)
+        assert np.array_equal(bits(net.photons()), bits(fresh.photons()))
+        lv, _, _ = net.light_volume()
+        lv_full, _, _ = fresh.light_volume()
+        np.testing.assert_allclose(lv, lv_full, rtol=1e-3, atol=2e-5 * float(lv_full.max()))
+        fresh.close()
+    assert decisions[0] == decisions[1] == b"importance branch"       # the first sample of a path is a warm-up, not a measurement
+    host.cpmh_path_costs(net.h, C.byref(costs))
+    assert all(c > 0 for c in costs)
     net.close()

@@ -223,6 +223,8 @@ def test_network_shard_reduce_call_site(host, cpm):
     nets = [Net(host, vol, 128, pos, d, base, correlated=True) for _ in range(2)]
     assert host.cpmh_enable_shard_reduce(nets[0].h) == 0
     for net in nets:
+        assert host.cpmh_set_property_string(net.h, b"tracer", b"importanceBranchPolicy", b"always") == 0
+    for net in nets:
         net.evaluate(first=True)
         assert host.cpmh_set_property_float(net.h, b"lightvolume", b"incrementalRecomputationThreshold", 100.0) == 0
     assert host.cpmh_last_reduce(nets[0].h) == b"dense" and host.cpmh_last_reduce(nets[1].h) == b"none"
