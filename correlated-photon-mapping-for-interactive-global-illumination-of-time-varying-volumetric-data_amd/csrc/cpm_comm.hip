@@ -177,14 +177,23 @@ int cpm_comm_create_all(cpm_ctx* const* ctxs, int n, cpm_comm** comms_out) {
         comms_out[i] = nullptr;
     }
     CPM_NCCL_CHECK(ctx0, R, R->CommInitAll(comms.data(), n, devs.data()));
+    // on any failure below: every end created so far is destroyed (with its RCCL communicator), the RCCL communicators not
+    // yet wrapped are destroyed directly, and comms_out is all NULL again
+    auto fail = [&](int from, int rc) {
+        for (int j = 0; j < n; ++j) {
+            if (comms_out[j]) { cpm_comm_destroy(comms_out[j]); comms_out[j] = nullptr; }
+            else if (j >= from && comms[j] && R->CommDestroy) { (void)hipSetDevice(devs[j]); (void)R->CommDestroy(comms[j]); }
+        }
+        return rc;
+    };
     for (int i = 0; i < n; ++i) {
         cpm_comm* c = new (std::nothrow) cpm_comm();
-        if (!c) return set_error(ctx0, CPM_ERR_OUT_OF_MEMORY, "cpm_comm_create_all", "host allocation failed");
+        if (!c) return fail(i, set_error(ctx0, CPM_ERR_OUT_OF_MEMORY, "cpm_comm_create_all", "host allocation failed"));
         c->comm = comms[i]; c->rank = i; c->size = n; c->device = devs[i];
         comms_out[i] = c;
-        CPM_ENTER(ctxs[i]);
+        if (hipSetDevice(ctxs[i]->device) != hipSuccess) return fail(i + 1, set_error(ctx0, CPM_ERR_DEVICE, "cpm_comm_create_all", "hipSetDevice"));
         int rc = alloc_side(ctxs[i], c);
-        if (rc) return rc;
+        if (rc) return fail(i + 1, rc);
     }
     return CPM_OK;
 }
@@ -233,6 +242,8 @@ int cpm_allreduce_grids(cpm_ctx* const* ctxs, cpm_comm* const* comms, float* con
     if (!ctxs || !comms || !grids || n < 1 || !ctxs[0]) return CPM_ERR_INVALID_ARGUMENT;
     cpm_ctx* ctx0 = ctxs[0];
     if (count == 0 || n == 1) return CPM_OK;
+    for (int i = 0; i < n; ++i)
+        if (!comms[i] || !grids[i]) return set_error(ctx0, CPM_ERR_INVALID_ARGUMENT, "cpm_allreduce_grids", "null communicator or grid");
     const Rccl* R = rccl(ctx0);
     if (!R) return CPM_ERR_UNSUPPORTED;
     CPM_NCCL_CHECK(ctx0, R, R->GroupStart());

@@ -123,17 +123,22 @@ CPM_DEV bool is_sentinel(float4 a) { return a.x == kFltMax || a.y == kFltMax || 
 // The candidate voxels of a photon along one axis: the integers within r' = r * textureToIndex + 1e-3 of its index-space
 // coordinate, clipped to the grid; empty (s > e) when none.  The clamps act on floats, so that far-away photons never
 // reach an out-of-range float -> int conversion.
-CPM_DEV void axis_range(float u, float rg, int dim, int& s, int& e) {
+// At most `maxc` of them -- the host's floor(2 r') + 1, from which the record capacity and the gather's loops are sized: at
+// index coordinates of a hundred or more the rounding of u - r' / u + r' can admit one more integer when 2 r' lies within an
+// ulp(u) below an integer; that candidate sits at distance r' > r (weight zero) and is dropped here, so that the count, the
+// scatter and the gather agree on a photon's bricks by construction.
+CPM_DEV void axis_range(float u, float rg, int dim, int maxc, int& s, int& e) {
     s = (int)min_(max_(__builtin_ceilf(u - rg), 0.0f), (float)dim);
     e = (int)max_(min_(__builtin_floorf(u + rg), (float)(dim - 1)), -1.0f);
+    e = min(e, s + maxc - 1);
 }
 struct Box { int sx, ex, sy, ey, sz, ez; };
-CPM_DEV bool candidate_box(const GridDev& G, float4 a, float rgx, float rgy, float rgz, Box& b) {
+CPM_DEV bool candidate_box(const GridDev& G, float4 a, float rgx, float rgy, float rgz, int maxc, Box& b) {
     const f3 p = { a.x, a.y, a.z };
     const f3 u = transform_(G.t2i, p);
-    axis_range(u.x, rgx, G.dx, b.sx, b.ex);
-    axis_range(u.y, rgy, G.dy, b.sy, b.ey);
-    axis_range(u.z, rgz, G.dz, b.sz, b.ez);
+    axis_range(u.x, rgx, G.dx, maxc, b.sx, b.ex);
+    axis_range(u.y, rgy, G.dy, maxc, b.sy, b.ey);
+    axis_range(u.z, rgz, G.dz, maxc, b.sz, b.ez);
     return b.sx <= b.ex && b.sy <= b.ey && b.sz <= b.ez;
 }
 // f(key) for every brick the box touches (at most two per axis: a box is at most 4 voxels wide, a brick at least 8
@@ -222,13 +227,18 @@ __global__ __launch_bounds__(1024) void fast_count_kernel(const float* __restric
 #pragma unroll
     for (int k = 0; k < kCountItems; ++k) {
         if (is_sentinel(a[k])) continue;
-        mp = max_(mp, __builtin_fabsf(a[k].w));
-        if (CH == 4) mp = max_(mp, max_(__builtin_fabsf(a2[k].x), __builtin_fabsf(a2[k].y)));
+        // (finite powers only, photon by photon: one NaN / inf must not hide its neighbours' maximum)
+        const float p0 = __builtin_fabsf(a[k].w);
+        if (p0 <= kFltMax) mp = max_(mp, p0);
+        if (CH == 4) {
+            const float p1 = __builtin_fabsf(a2[k].x), p2 = __builtin_fabsf(a2[k].y);
+            if (p1 <= kFltMax) mp = max_(mp, p1);
+            if (p2 <= kFltMax) mp = max_(mp, p2);
+        }
         Box box;
-        if (candidate_box(G, a[k], rgx, rgy, rgz, box)) for_each_brick(L, box, [&](uint32_t key) { atomicAdd(&s_hist[key], 1u); });
+        if (candidate_box(G, a[k], rgx, rgy, rgz, L.maxc, box)) for_each_brick(L, box, [&](uint32_t key) { atomicAdd(&s_hist[key], 1u); });
     }
-    // max |power| of the workgroup (a finite, non-negative float orders like its bit pattern); NaN / inf are ignored
-    if (!(mp <= kFltMax)) mp = 0.f;
+    // max |power| of the workgroup (a finite, non-negative float orders like its bit pattern)
     for (int off = 32; off > 0; off >>= 1) mp = max_(mp, __shfl_xor(mp, off, 64));
     if ((t & 63) == 0) s_mp[t >> 6] = mp;
     __syncthreads();
@@ -303,7 +313,7 @@ __global__ __launch_bounds__(1024, 8) void fast_scatter_kernel(const float* __re
 #pragma unroll
         for (int k = 0; k < kScatterItems; ++k) {
             Box box;
-            if (is_sentinel(a[k]) || !candidate_box(G, a[k], rgx, rgy, rgz, box)) continue;
+            if (is_sentinel(a[k]) || !candidate_box(G, a[k], rgx, rgy, rgz, L.maxc, box)) continue;
             for_each_brick(L, box, [&](uint32_t key) {
                 const size_t pos = (size_t)atomicAdd(&s_pos[key], 1u);
                 if (CH == 1) {
@@ -331,11 +341,13 @@ template <int MAXC, int CH>
 CPM_DEV void brick_record(const GridDev& G, float4 a, float pg, float pb, int ox, int oy, int oz, int BX, int BY, int BZ, float rgx,
                           float rgy, float rgz, float r2, float inv_r2, float k, float S, long long* __restrict__ tile, int plane) {
     Box c;
-    if (!candidate_box(G, a, rgx, rgy, rgz, c)) return;
+    if (!candidate_box(G, a, rgx, rgy, rgz, MAXC, c)) return;
     const int sx = max(c.sx, ox), ex = min(c.ex, ox + BX - 1);
     const int sy = max(c.sy, oy), ey = min(c.ey, oy + BY - 1);
     const int sz = max(c.sz, oz), ez = min(c.ez, oz + BZ - 1);
-    const float pk = a.w * k, pkg = pg * k, pkb = pb * k;
+    // (a non-finite power has no fixed-point image: that channel of that photon contributes nothing, as in max |power|)
+    const float pk = __builtin_fabsf(a.w) <= kFltMax ? a.w * k : 0.f;
+    const float pkg = __builtin_fabsf(pg) <= kFltMax ? pg * k : 0.f, pkb = __builtin_fabsf(pb) <= kFltMax ? pb * k : 0.f;
     float dxv[MAXC], dyv[MAXC], dzv[MAXC];
     bool okx[MAXC], oky[MAXC], okz[MAXC];
 #pragma unroll

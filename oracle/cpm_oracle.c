@@ -842,6 +842,10 @@ void cpmo_gather_fast(const float* photons, int n, const cpmo_grid_desc* g, floa
     const float sT[3] = { T[0], T[5], T[10] }, tT[3] = { T[12], T[13], T[14] };
     const float sI[3] = { I[0], I[5], I[10] }, tI[3] = { I[12], I[13], I[14] };
     const float r2 = radius * radius, inv_r2 = 1.0f / r2;
+    /* candidates per axis: floor(2 r') + 1 with r' = r * textureToIndex + 1e-3 along the widest axis (what the record capacity
+     * and the device loops are sized from); a box is cut to that many (the extra integer rounding can admit lies at r' > r) */
+    const float rmax = fmaxf(radius * sT[0], fmaxf(radius * sT[1], radius * sT[2])) + 1e-3f;
+    const int maxc = (int)floorf(2.f * rmax) + 1;
     for (int i = 0; i < n; ++i) {
         const float* ph = photons + 8 * (size_t)i;
         if (ph[0] == FLT_MAX || ph[1] == FLT_MAX || ph[2] == FLT_MAX) continue;
@@ -853,9 +857,12 @@ void cpmo_gather_fast(const float* photons, int n, const cpmo_grid_desc* g, floa
              * must not reach an out-of-range float -> int conversion) */
             int lo = (int)om_min(om_max(ceilf(u - rg), 0.0f), (float)dims[a]);
             int hi = (int)om_max(om_min(floorf(u + rg), (float)(dims[a] - 1)), -1.0f);
+            if (hi > lo + maxc - 1) hi = lo + maxc - 1;
             s[a] = lo; e[a] = hi;
         }
-        const float pk[3] = { ph[3] * k, ph[4] * k, ph[5] * k };
+        /* a non-finite power has no fixed-point image: that channel of that photon contributes nothing */
+        const float pk[3] = { fabsf(ph[3]) <= FLT_MAX ? ph[3] * k : 0.f, fabsf(ph[4]) <= FLT_MAX ? ph[4] * k : 0.f,
+                              fabsf(ph[5]) <= FLT_MAX ? ph[5] * k : 0.f };
         for (int z = s[2]; z <= e[2]; ++z) {
             const float dz = om_fma(sI[2], (float)z, tI[2]) - ph[2];
             for (int y = s[1]; y <= e[1]; ++y) {

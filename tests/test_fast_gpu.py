@@ -74,12 +74,16 @@ def expected_filing(ph, dims, radius, grid):
     pairs = []
     stored = np.where(ph[:, 0] != FLT_MAX)[0]
     rng_axes = []
+    # at most floor(2 r') + 1 candidates per axis, r' along the widest axis (what capacity and loops are sized from)
+    rmax = max(np.float32(radius) * t2i[5 * a] for a in range(3)) + np.float32(1e-3)
+    maxc = int(np.floor(np.float32(2.0) * np.float32(rmax))) + 1
     for a in range(3):
         s, t = t2i[5 * a], t2i[12 + a]
         u = (np.float64(s) * ph[stored, a].astype(np.float64) + np.float64(t)).astype(np.float32)   # = fma(s, p, t): the product is exact in double
         rg = np.float32(radius) * s + np.float32(1e-3)
         lo = np.clip(np.ceil((u - rg).astype(np.float32)), 0, dims[a]).astype(np.int64)
         hi = np.clip(np.floor((u + rg).astype(np.float32)), -1, dims[a] - 1).astype(np.int64)
+        hi = np.minimum(hi, lo + maxc - 1)
         rng_axes.append((lo, hi))
     ok = np.ones(stored.size, bool)
     for lo, hi in rng_axes:
@@ -263,3 +267,55 @@ def test_fast_non_default_grid_matrices(ctx, oracle, cpm):
     sp = np.zeros(out.numel(), np.float32)
     oracle.splat(ph, n, og, radius, scale, sp)       # the reference formulation with the same matrices
     np.testing.assert_allclose(_n(out), sp, rtol=1e-4, atol=ATOL_OF_MAX * float(sp.max()))
+
+
+def test_candidate_box_is_cut_to_the_host_reach(ctx, oracle, cpm):
+    """with 2 r' an ulp(u) below an integer the rounding of u - r' / u + r' admits one candidate more than the
+    host's floor(2 r') + 1 -- at a brick face that would be a second record for a photon whose capacity is one.  The box is
+    cut to the host's reach (the extra candidate lies at r' > r, weight zero): HIP == oracle, one record per photon."""
+    dims = (400, 8, 16)
+    f32 = np.float32
+    rg_target = np.nextafter(f32(0.5), f32(0))                       # 2 r' just below 1 -> reach 1
+    radius = float((rg_target - f32(1e-3)) / f32(400))
+    grid = cpm.binding.default_grid_desc(dims, 1)
+    rg = f32(radius) * f32(grid.texture_to_index[0]) + f32(1e-3)
+    assert int(np.floor(f32(2) * (rg))) + 1 == 1
+    n = 5000
+    rng = np.random.default_rng(5)
+    ph = np.zeros((n, 8), f32)
+    ph[:, 0] = f32(304.0) / f32(400)                                  # index coordinate 303.5: between voxels 303 | 304 = bricks 37 | 38
+    ph[:, 1] = (rng.integers(0, 8, n).astype(f32) + f32(0.5)) / f32(8)     # voxel centres along y and z: r is a hundredth of a voxel there
+    ph[:, 2] = (rng.integers(0, 16, n).astype(f32) + f32(0.5)) / f32(16)
+    ph[:, 3:6] = 1.0
+    u = f32(f32(grid.texture_to_index[0]) * ph[0, 0] + f32(grid.texture_to_index[12]))
+    assert np.ceil(f32(u - rg)) < np.floor(f32(u + rg))               # the float box really holds two integers
+    assert ctx.fast_record_capacity(grid, n, radius) == n
+    scale = float(cpm.binding.relative_irradiance_scale(radius, float(n)))
+    got, table, srt = run_fast(ctx, cpm, ph, dims, 1, radius, scale)
+    want_fast, _ = oracle_both(oracle, ph, dims, 1, radius, scale)
+    assert np.array_equal(bits(got), bits(want_fast))
+    assert table[brick_count(dims)] == n                              # one record per photon
+
+
+def test_non_finite_powers_are_ignored_photon_by_photon(ctx, oracle, cpm):
+    """a NaN / inf power neither hides its neighbours' maximum (the fixed-point scale) nor reaches the sums: the
+    volume is the one the finite photons alone give -- bit for bit, with HIP == oracle."""
+    dims = (32, 32, 32)
+    rng = np.random.default_rng(11)
+    n = 20_000
+    ph = make_photons(rng, n, dims, sentinels=0.05, outside=0.0)
+    clean = ph.copy()
+    bad = rng.random(n) < 0.02
+    bad &= ph[:, 0] != FLT_MAX
+    ph[bad, 3] = np.where(rng.random(bad.sum()) < 0.5, np.nan, np.inf).astype(np.float32)
+    clean[bad, :3] = FLT_MAX                                          # the same frame without those photons
+    clean[bad, 4:6] = FLT_MAX
+    assert bad.sum() > 100
+    radius = float(np.float32(0.866) / np.float32(32))
+    scale = float(cpm.binding.relative_irradiance_scale(radius, float(n)))
+    got, _, _ = run_fast(ctx, cpm, ph, dims, 1, radius, scale)
+    want, _ = oracle_both(oracle, ph, dims, 1, radius, scale)
+    ref, _, _ = run_fast(ctx, cpm, clean, dims, 1, radius, scale)
+    assert np.isfinite(got).all() and got.max() > 0
+    assert np.array_equal(bits(got), bits(want))
+    assert np.array_equal(bits(got), bits(ref))
