@@ -207,7 +207,10 @@ CPM_DEV float woodcock(const VolDev& V, const float* lut, float wf, float m1, fl
     return t;
 }
 
-template <int DT, int EMIT>
+// SINGLE: max_interactions == 1 known at compile time -- the scatter branch (phase-function sample, re-encoded direction, slab
+// test) and the sentinel loop leave the instruction stream of the headline configuration; the NO_SINGLE_SCATTERING variant and
+// I > 1 take the general kernel.
+template <int DT, int EMIT, bool SINGLE = false>
 __global__ __launch_bounds__(256, 8) void trace_kernel(const TraceArgs A) {
     extern __shared__ float lds[];
     // One decoded / re-encoded direction per workgroup: a directional light gives every sample the same (theta, phi),
@@ -243,7 +246,7 @@ __global__ __launch_bounds__(256, 8) void trace_kernel(const TraceArgs A) {
         live = threadId >= 0 && threadId < A.p.n_light_samples;
     }
     const int photonOffset = A.p.photon_offset;
-    const uint32_t maxInteractions = (uint32_t)A.p.max_interactions;
+    const uint32_t maxInteractions = SINGLE ? 1u : (uint32_t)A.p.max_interactions;
     const size_t totalPhotons = (size_t)A.p.total_photons;
     uint2* rng = reinterpret_cast<uint2*>(A.rng);
     if (live && A.old_photons) {  // what the light-volume update subtracts: the records this thread is about to replace
@@ -333,7 +336,7 @@ __global__ __launch_bounds__(256, 8) void trace_kernel(const TraceArgs A) {
 
     const float wf = A.tf_wf, m1 = A.tf_m1, m2 = A.tf_m2;
 
-    if (A.p.flags & CPM_TRACE_NO_SINGLE_SCATTERING) {  // photontracer.cl:143-157
+    if (!SINGLE && (A.p.flags & CPM_TRACE_NO_SINGLE_SCATTERING)) {  // photontracer.cl:143-157
         float vs_unused, op_unused;
         float t = woodcock<DT>(A.vol, lut, wf, m1, m2, origin, direction, tStart, tEnd, rx, rc, steps, vs_unused, op_unused);
         if (scatterEvent) {
@@ -404,6 +407,7 @@ __global__ __launch_bounds__(256, 8) void trace_kernel(const TraceArgs A) {
         if ((threadIdx.x & 63) == 0) atomicAdd(A.step_counter, (unsigned long long)s);
     }
 }
+
 
 }  // namespace
 
@@ -520,7 +524,12 @@ int trace_impl(cpm_ctx* ctx, const cpm_volume* vol, const cpm_tf* tf, const cpm_
             }
         }
     }
-#define CPM_TRACE_LAUNCH_E(DT, E) CPM_LAUNCH(ctx, (trace_kernel<DT, E>), grid, block, lds, s, A)
+    const bool single = p.max_interactions == 1 && !(p.flags & CPM_TRACE_NO_SINGLE_SCATTERING);
+#define CPM_TRACE_LAUNCH_E(DT, E)                                                          \
+    do {                                                                                   \
+        if (single) CPM_LAUNCH(ctx, (trace_kernel<DT, E, true>), grid, block, lds, s, A);  \
+        else CPM_LAUNCH(ctx, (trace_kernel<DT, E, false>), grid, block, lds, s, A);        \
+    } while (0)
 #define CPM_TRACE_LAUNCH(DT)                                                  \
     do {                                                                      \
         if (emit == EMIT_NONE) CPM_TRACE_LAUNCH_E(DT, EMIT_NONE);             \
