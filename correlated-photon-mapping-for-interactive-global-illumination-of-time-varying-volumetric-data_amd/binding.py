@@ -35,7 +35,7 @@ ABI_SYMBOLS = [
     "cpm_splat", "cpm_splat_selected", "cpm_copy_indexed_photons", "cpm_snapshot_selected_photons",
     "cpm_sort_pairs", "cpm_sort_keys", "cpm_bin", "cpm_gather", "cpm_mark_touched_bricks", "cpm_gather_bricks",
     "cpm_fast_table_entries", "cpm_gather_fast_supported", "cpm_fast_record_capacity", "cpm_bin_fast", "cpm_gather_fast",
-    "cpm_volume_minmax", "cpm_volume_difference", "cpm_importance_tf",
+    "cpm_volume_minmax", "cpm_volume_difference", "cpm_volume_step", "cpm_importance_tf",
     "cpm_photon_importance", "cpm_photon_importance_equal", "cpm_reset_importance",
     "cpm_select_recompute", "cpm_select_changed",
     "cpm_selection_create", "cpm_selection_destroy", "cpm_selection_begin", "cpm_photon_importance_select",
@@ -156,6 +156,7 @@ def load_library() -> C.CDLL:
         "cpm_gather_fast": (i32, [vp, vp, vp, i32, P(GridDesc), f32, f32, i32, vp, vp]),
         "cpm_volume_minmax": (i32, [vp, vp, i32, vp, vp]),
         "cpm_volume_difference": (i32, [vp, vp, vp, i32, vp, vp]),
+        "cpm_volume_step": (i32, [vp, vp, vp, i32, vp, vp, vp]),
         "cpm_importance_tf": (i32, [vp, vp, vp, vp, i32, vp, vp, i32, vp, vp]),
         "cpm_photon_importance": (i32, [vp, vp, P(i32 * 3), P(f32 * 3), P(f32 * 16), vp, i32, vp, vp, i32, i32, i32, i32, vp, vp]),
         "cpm_photon_importance_equal": (i32, [vp, i32, i32, i32, i32, vp, vp]),
@@ -501,6 +502,10 @@ class Context:
     # -- correlated
     def volume_minmax(self, vol, region, out):
         self._check(self.lib.cpm_volume_minmax(self.h, vol.h, region, self._ptr(out), self._stream()))
+
+    def volume_step(self, cur, nxt, region, diff_out, minmax_out):
+        """mean |next - cur| bricks and the min / max bricks of `next` in one pass (cpm_volume_step)."""
+        self._check(self.lib.cpm_volume_step(self.h, cur.h, nxt.h, region, self._ptr(diff_out), self._ptr(minmax_out), self._stream()))
 
     def volume_difference(self, cur, nxt, region, out):
         self._check(self.lib.cpm_volume_difference(self.h, cur.h, nxt.h, region, self._ptr(out), self._stream()))

@@ -125,11 +125,14 @@ CPM_DEV uint32_t float_key(float f) {  // order-preserving float -> uint
 }
 CPM_DEV float key_float(uint32_t k) { return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k); }
 
-template <int DT, bool DIFF>
+// MODE 0: min / max bricks of A; 1: mean |B - A| bricks; 2: both in one pass -- the difference against A and the min / max
+// of B (a time step: the new volume's bricks and what changed, with each volume read once)
+template <int DT, int MODE>
 __global__ __launch_bounds__(256) void brick_row_kernel(BrickVol A, const void* __restrict__ bvox, double range,
                                                         uint16_t* __restrict__ mm_out, float* __restrict__ diff_out) {
-    extern __shared__ unsigned long long s_slots[];  // DIFF: ox sums; else ox (min | max << 32) pairs as two u32 arrays
-    uint32_t* s_min = reinterpret_cast<uint32_t*>(s_slots);
+    constexpr bool DIFF = MODE != 0, MINMAX = MODE != 1;
+    extern __shared__ unsigned long long s_slots[];  // DIFF: ox sums; MINMAX: ox minima and ox maxima (u32) behind them
+    uint32_t* s_min = reinterpret_cast<uint32_t*>(s_slots + (DIFF ? A.ox : 0));
     uint32_t* s_max = s_min + A.ox;
     constexpr int ES = DT == CPM_U8 ? 1 : (DT == CPM_U16 ? 2 : 4);
     constexpr int EPC = 16 / ES;  // elements per 16-byte chunk
@@ -138,7 +141,7 @@ __global__ __launch_bounds__(256) void brick_row_kernel(BrickVol A, const void* 
     const int y0 = gy * R, z0 = gz * R;
     for (int g = threadIdx.x; g < A.ox; g += blockDim.x) {
         if (DIFF) s_slots[g] = 0ull;
-        else { s_min[g] = 0xffffffffu; s_max[g] = 0u; }
+        if (MINMAX) { s_min[g] = 0xffffffffu; s_max[g] = 0u; }
     }
     __syncthreads();
     const int cpr = (A.dx + EPC - 1) / EPC;  // chunks per row
@@ -166,18 +169,18 @@ __global__ __launch_bounds__(256) void brick_row_kernel(BrickVol A, const void* 
                 else if (DT == CPM_U16) { va = (wa[e >> 1] >> (16 * (e & 1))) & 0xffffu; vb = (wb[e >> 1] >> (16 * (e & 1))) & 0xffffu; }
                 else va = float_key(__uint_as_float(wa[e]));
                 if (DIFF) sum += va > vb ? va - vb : vb - va;
-                else { mn = va < mn ? va : mn; mx = va > mx ? va : mx; }
+                if (MINMAX) { const uint32_t vm = MODE == 2 ? vb : va; mn = vm < mn ? vm : mn; mx = vm > mx ? vm : mx; }
                 any = true;
                 if (--left == 0) {  // the brick ends inside the chunk
                     if (DIFF) atomicAdd(&s_slots[g], sum);
-                    else { atomicMin(&s_min[g], mn); atomicMax(&s_max[g], mx); }
+                    if (MINMAX) { atomicMin(&s_min[g], mn); atomicMax(&s_max[g], mx); }
                     ++g; left = R; mn = 0xffffffffu; mx = 0u; sum = 0; any = false;
                 }
             }
         }
         if (any) {
             if (DIFF) atomicAdd(&s_slots[g], sum);
-            else { atomicMin(&s_min[g], mn); atomicMax(&s_max[g], mx); }
+            if (MINMAX) { atomicMin(&s_min[g], mn); atomicMax(&s_max[g], mx); }
         }
     }
     __syncthreads();
@@ -186,7 +189,8 @@ __global__ __launch_bounds__(256) void brick_row_kernel(BrickVol A, const void* 
         if (DIFF) {
             const double cnt = (double)R * R * R;
             diff_out[brick] = (float)(((double)s_slots[g] / cnt) / range);
-        } else {
+        }
+        if (MINMAX) {
             const float lo = DT == CPM_F32 ? key_float(s_min[g]) : (float)s_min[g];
             const float hi = DT == CPM_F32 ? key_float(s_max[g]) : (float)s_max[g];
             const float a = (lo * A.norm + A.offset) * A.one_minus_scaling;
@@ -684,9 +688,9 @@ int cpm_volume_minmax(cpm_ctx* ctx, const cpm_volume* vol, int region, uint16_t*
         const dim3 grid((unsigned)(V.oy * V.oz)), block(256);
         const size_t lds = (size_t)V.ox * 8;
         switch (V.dtype) {
-            case CPM_U8: CPM_LAUNCH(ctx, (brick_row_kernel<CPM_U8, false>), grid, block, lds, s, V, nullptr, 1.0, minmax2, nullptr); break;
-            case CPM_U16: CPM_LAUNCH(ctx, (brick_row_kernel<CPM_U16, false>), grid, block, lds, s, V, nullptr, 1.0, minmax2, nullptr); break;
-            default: CPM_LAUNCH(ctx, (brick_row_kernel<CPM_F32, false>), grid, block, lds, s, V, nullptr, 1.0, minmax2, nullptr); break;
+            case CPM_U8: CPM_LAUNCH(ctx, (brick_row_kernel<CPM_U8, 0>), grid, block, lds, s, V, nullptr, 1.0, minmax2, nullptr); break;
+            case CPM_U16: CPM_LAUNCH(ctx, (brick_row_kernel<CPM_U16, 0>), grid, block, lds, s, V, nullptr, 1.0, minmax2, nullptr); break;
+            default: CPM_LAUNCH(ctx, (brick_row_kernel<CPM_F32, 0>), grid, block, lds, s, V, nullptr, 1.0, minmax2, nullptr); break;
         }
         CPM_LAUNCH_CHECK(ctx, "brick_row_kernel");
         return CPM_OK;
@@ -711,14 +715,39 @@ int cpm_volume_difference(cpm_ctx* ctx, const cpm_volume* cur, const cpm_volume*
         const dim3 grid((unsigned)(V.oy * V.oz)), block(256);
         const size_t lds = (size_t)V.ox * 8;
         hipStream_t s = (hipStream_t)stream;
-        if (V.dtype == CPM_U8) CPM_LAUNCH(ctx, (brick_row_kernel<CPM_U8, true>), grid, block, lds, s, V, next->voxels, range, nullptr, out);
-        else CPM_LAUNCH(ctx, (brick_row_kernel<CPM_U16, true>), grid, block, lds, s, V, next->voxels, range, nullptr, out);
+        if (V.dtype == CPM_U8) CPM_LAUNCH(ctx, (brick_row_kernel<CPM_U8, 1>), grid, block, lds, s, V, next->voxels, range, nullptr, out);
+        else CPM_LAUNCH(ctx, (brick_row_kernel<CPM_U16, 1>), grid, block, lds, s, V, next->voxels, range, nullptr, out);
         CPM_LAUNCH_CHECK(ctx, "brick_row_kernel");
         return CPM_OK;
     }
     CPM_LAUNCH(ctx, difference_kernel, dim3(V.ox * V.oy * V.oz), dim3(64), 0, (hipStream_t)stream, V, next->voxels, range, out);
     CPM_LAUNCH_CHECK(ctx, "difference_kernel");
     return CPM_OK;
+}
+
+int cpm_volume_step(cpm_ctx* ctx, const cpm_volume* cur, const cpm_volume* next, int region, float* mean_abs_diff, uint16_t* next_minmax2,
+                    cpm_stream stream) {
+    CPM_ENTER(ctx);
+    BrickVol V;
+    int rc = make_brick_vol(ctx, cur, region, V);
+    if (rc) return rc;
+    CPM_REQUIRE(ctx, next && mean_abs_diff && next_minmax2, "cpm_volume_step: null argument");
+    CPM_REQUIRE(ctx, memcmp(cur->desc.dims, next->desc.dims, sizeof(cur->desc.dims)) == 0 && cur->desc.dtype == next->desc.dtype,
+                "cpm_volume_step: volumes differ in shape or type");
+    if (ctx->dbg.brick_streaming && V.dtype != CPM_F32 && rows_are_16_byte_aligned(V) && (size_t)V.ox * 16 <= 48 * 1024 &&
+        cur->desc.format_offset == next->desc.format_offset && cur->desc.format_scaling == next->desc.format_scaling) {
+        const double range = V.dtype == CPM_U8 ? 255.0 : 65535.0;
+        const dim3 grid((unsigned)(V.oy * V.oz)), block(256);
+        const size_t lds = (size_t)V.ox * 16;
+        hipStream_t s = (hipStream_t)stream;
+        if (V.dtype == CPM_U8) CPM_LAUNCH(ctx, (brick_row_kernel<CPM_U8, 2>), grid, block, lds, s, V, next->voxels, range, next_minmax2, mean_abs_diff);
+        else CPM_LAUNCH(ctx, (brick_row_kernel<CPM_U16, 2>), grid, block, lds, s, V, next->voxels, range, next_minmax2, mean_abs_diff);
+        CPM_LAUNCH_CHECK(ctx, "brick_row_kernel");
+        return CPM_OK;
+    }
+    rc = cpm_volume_difference(ctx, cur, next, region, mean_abs_diff, stream);
+    if (rc) return rc;
+    return cpm_volume_minmax(ctx, next, region, next_minmax2, stream);
 }
 
 int cpm_importance_tf(cpm_ctx* ctx, const uint16_t* minmax2, const uint16_t* prev_minmax2, const float* volume_diff,

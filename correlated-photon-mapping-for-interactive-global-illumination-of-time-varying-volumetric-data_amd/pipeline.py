@@ -577,8 +577,7 @@ class CorrelatedPhotonMapper(PhotonFrame):
             nxt = self._vol_next
             nxt.update(voxels)
         self._vol_next = nxt
-        ctx.volume_difference(self.vol, self._vol_next, self.region, self._diff)
-        ctx.volume_minmax(self._vol_next, self.region, self._minmax_next)
+        ctx.volume_step(self.vol, self._vol_next, self.region, self._diff, self._minmax_next)   # difference + min/max, one pass
         # TF unchanged: importance of a range = the TF itself (updateTransferFunctionData), zero-padded to [0, 1]
         pts = sorted(self.tf_points)
         pos = [p[0] for p in pts]

@@ -387,6 +387,13 @@ int cpm_volume_minmax(cpm_ctx* ctx, const cpm_volume* vol, int region, uint16_t*
 int cpm_volume_difference(cpm_ctx* ctx, const cpm_volume* cur, const cpm_volume* next, int region,
                           float* mean_abs_diff, cpm_stream stream);
 
+/* One time step of a sequence in one pass over the two volumes: mean_abs_diff as cpm_volume_difference(cur, next) and
+ * next_minmax2 as cpm_volume_minmax(next) -- the same values; each volume is read once (8 / 16-bit voxels; float volumes take
+ * the two separate launches).  What the importance processor's time-varying branch consumes per step
+ * (ref importancesamplingcl/processors/minmaxuniformgrid3dimportanceclprocessor.cpp:149-190). */
+int cpm_volume_step(cpm_ctx* ctx, const cpm_volume* cur, const cpm_volume* next, int region, float* mean_abs_diff,
+                    uint16_t* next_minmax2, cpm_stream stream);
+
 /* importance[c] = sum of the 4 channel-wise (max - min) of the piecewise-linear
  * TF-difference colour over the brick's [min, max] data range
  * (-D INCREMENTAL_TF_IMPORTANCE).  positions/colors: n_points host arrays

@@ -42,6 +42,12 @@ def _minmax_difference_case(ctx, oracle, shape, dtype, region):
     diff = ctx.torch.zeros(nb, dtype=ctx.torch.float32, device=ctx.device)
     ctx.volume_difference(va, vb, region, diff)
     assert np.array_equal(bits(_n(diff)), bits(oracle.volume_difference(oa, ob, region)))
+    # the time step in one pass (cpm_volume_step): the difference and the NEXT volume's min / max, the same values
+    diff2 = ctx.torch.full_like(diff, -1.0)
+    mm2 = ctx.torch.zeros_like(mm)
+    ctx.volume_step(va, vb, region, diff2, mm2)
+    assert np.array_equal(bits(_n(diff2)), bits(oracle.volume_difference(oa, ob, region)))
+    assert np.array_equal(_n(mm2, np.uint16), oracle.volume_minmax(ob, region))
 
 
 def _tf_diff_points():
