@@ -39,7 +39,7 @@ ABI_SYMBOLS = [
     "cpm_photon_importance", "cpm_photon_importance_equal", "cpm_reset_importance",
     "cpm_select_recompute", "cpm_select_changed",
     "cpm_selection_create", "cpm_selection_destroy", "cpm_selection_begin", "cpm_photon_importance_select",
-    "cpm_photon_importance_equal_select", "cpm_selection_finish", "cpm_selection_count_device", "cpm_selection_count",
+    "cpm_photon_importance_equal_select", "cpm_photon_importance_retrace", "cpm_selection_finish", "cpm_selection_count_device", "cpm_selection_count",
     "cpm_trace_selected", "cpm_splat_delta",
     "cpm_mix_buffers", "cpm_volume_mix",
     "cpm_comm_get_unique_id", "cpm_comm_create", "cpm_comm_create_all", "cpm_comm_destroy", "cpm_comm_rank", "cpm_comm_size",
@@ -168,6 +168,8 @@ def load_library() -> C.CDLL:
         "cpm_selection_begin": (i32, [vp, vp]),
         "cpm_photon_importance_select": (i32, [vp, vp, vp, P(i32 * 3), P(f32 * 3), P(f32 * 16), vp, i32, vp, vp, i32, i32, i32, i32, vp, vp]),
         "cpm_photon_importance_equal_select": (i32, [vp, vp, i32, i32, i32, i32, vp, vp]),
+        "cpm_photon_importance_retrace": (i32, [vp, vp, vp, P(i32 * 3), P(f32 * 3), P(f32 * 16), vp, vp, vp, P(f32 * 8), P(TraceParams), vp, vp, i32,
+                                          vp, vp, vp, vp, vp]),
         "cpm_selection_finish": (i32, [vp, vp, vp, vp]),
         "cpm_selection_count_device": (vp, [vp]),
         "cpm_selection_count": (i32, [vp, vp, P(i32)]),
@@ -580,6 +582,16 @@ class Selection:
             c.h, self.h, c._ptr(importance_grid), C.byref((C.c_int32 * 3)(*grid_dims)), C.byref((C.c_float * 3)(*cell_size)),
             C.byref((C.c_float * 16)(*texture_to_index)), c._ptr(photons), photon_offset, c._ptr(light_samples), c._ptr(isect),
             n_light_samples, max_interactions, total_photons, int(fix_exit_point), c._ptr(importances), c._stream()))
+
+    def photon_importance_retrace(self, importance_grid, grid_dims, cell_size, texture_to_index, vol, tf, aabb, params, light_samples, isect,
+                                  importances, rng_state, photons, old_photons, fix_exit_point=False, tf_scattering=None):
+        """Detector + threshold + tracer of one light in one launch (cpm_photon_importance_retrace)."""
+        c = self.ctx
+        c._check(c.lib.cpm_photon_importance_retrace(
+            c.h, self.h, c._ptr(importance_grid), C.byref((C.c_int32 * 3)(*grid_dims)), C.byref((C.c_float * 3)(*cell_size)),
+            C.byref((C.c_float * 16)(*texture_to_index)), vol.h, tf.h, tf_scattering.h if tf_scattering is not None else None,
+            C.byref((C.c_float * 8)(*aabb)), C.byref(params), c._ptr(light_samples), c._ptr(isect), int(fix_exit_point),
+            c._ptr(importances), c._ptr(rng_state), c._ptr(photons), c._ptr(old_photons), c._stream()))
 
     def photon_importance_equal(self, photon_offset, n_light_samples, percentage, iteration, importances):
         c = self.ctx

@@ -1,7 +1,7 @@
 // cpm_correlated.hip -- helpers of the correlated re-trace (C1-C6, S2-S4): min/max bricks,
 // temporal difference bricks, TF-difference importance per brick, per-photon importance by
 // DDA through the importance grid, and the fused threshold + count + iota + sort selection.
-#include "cpm_ctx.h"
+#include "cpm_trace_body.hip.h"
 
 #include <chrono>
 #include <new>
@@ -641,6 +641,96 @@ __global__ __launch_bounds__(256) void partition_write_kernel(const uint32_t* __
     }
 }
 
+// Detector + threshold + tracer in ONE launch (cpm_photon_importance_retrace): the importance branch of
+// ProgressivePhotonTracerCL::process (ref processor/progressivephotontracercl.cpp:298-374,467-529) for the case that every
+// changed photon is traced in this evaluation.  Pass 1 per tile as importance_select_kernel: importance of every sample,
+// threshold, ballot-ranked list + count (for the index list the outport carries and the light-volume update walks).  Pass 2:
+// the lanes whose photon changed re-trace it on the spot -- its records are first copied to old_sparse at the photon's own
+// index (what the reference's prevPhotons_ snapshot holds for it), then overwritten by tracer::trace_photon, the same device
+// function trace_kernel runs: same RNG stream, same operations, same bits; its importance key goes back to 0x7fffffff
+// (resetPhotonImportance).  What this saves against cpm_photon_importance_select + cpm_selection_finish + cpm_trace_selected:
+// the re-trace no longer waits for the compaction, and its launch -- a chain of dependent loads (count, index, sample, old
+// record) for a few thousand photons, 17 us at config 3 -- is gone; the divergent walks (3 steps on average) hide among the
+// importance pass's own waves.
+template <int DT, bool MASK, bool SINGLE>
+__global__ __launch_bounds__(256) void importance_retrace_kernel(ImpGrid G, const uint32_t* __restrict__ mask, uint32_t mask_words,
+                                                                 int fix_exit_point, uint32_t* __restrict__ importances, SelTiles S,
+                                                                 const tracer::TraceArgs A, float* __restrict__ old_sparse) {
+    extern __shared__ uint32_t s_dyn[];  // [occupancy bits of the importance grid][TF alpha column(s)]
+    uint32_t* s_mask = s_dyn;
+    float* lut = reinterpret_cast<float*>(s_dyn + mask_words);
+    float* luts = lut;
+    __shared__ uint32_t s_wcnt[4];
+    const uint32_t t = threadIdx.x, lane = t & 63u, wave = t >> 6;
+    const int K = (int)(S.per_tile / 256u);
+    const int n_light_samples = A.p.n_light_samples, photon_offset = A.p.photon_offset;
+    const int b0 = (int)(blockIdx.x * S.per_tile);
+    const int b1 = min(b0 + (int)S.per_tile, n_light_samples);
+    if (MASK) for (uint32_t i = t; i < mask_words; i += 256u) s_mask[i] = mask[i];
+    for (int i = (int)t; i < A.tf_width; i += 256) lut[i] = A.tf_alpha[i];
+    if (A.tfs_alpha != A.tf_alpha) {
+        luts = lut + A.tf_width;
+        for (int i = (int)t; i < A.tf_width; i += 256) luts[i] = A.tfs_alpha[i];
+    }
+    __syncthreads();
+    // pass 1: importance, threshold, the tile's ascending list
+    uint32_t flags = 0, running = 0;
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    uint32_t* list = S.local + (size_t)photon_offset + (size_t)b0;
+    for (int k = 0; k < K; ++k) {  // (uniform)
+        const int threadId = b0 + k * 256 + (int)t;
+        bool changed = false;
+        if (threadId < b1) {
+            const uint32_t u = photon_importance_value<MASK>(G, s_mask, A.photons, photon_offset, A.light_samples, A.isect, A.p.max_interactions,
+                                                             A.p.total_photons, fix_exit_point, threadId);
+            const uint32_t key = importances[photon_offset + threadId] - u;
+            changed = key < 2147483647u;
+        }
+        const unsigned long long mc = __ballot(changed);
+        if (lane == 0) s_wcnt[wave] = (uint32_t)__popcll(mc);
+        __syncthreads();
+        uint32_t before = 0, total = 0;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) { const uint32_t c = s_wcnt[w]; before += w < (int)wave ? c : 0u; total += c; }
+        if (changed) {
+            list[running + before + (uint32_t)__popcll(mc & lt)] = (uint32_t)(photon_offset + threadId);
+            flags |= 1u << k;
+        }
+        running += total;
+        __syncthreads();  // s_wcnt is rewritten by the next chunk
+    }
+    if (t == 0) S.tile[S.tile_first + blockIdx.x] = make_uint2(running, (uint32_t)(photon_offset + b0));
+    // pass 2: the changed photons, re-traced by the lanes that found them
+    unsigned steps = 0;
+    const size_t totalPhotons = (size_t)A.p.total_photons;
+    const int nInter = SINGLE ? 1 : A.p.max_interactions;
+    for (int k = 0; k < K; ++k) {
+        if (!(flags & (1u << k))) continue;
+        const int threadId = b0 + k * 256 + (int)t;
+        for (int it = 0; it < nInter; ++it) {  // the records about to be replaced
+            const size_t id = (size_t)photon_offset + (size_t)it * totalPhotons + (size_t)threadId;
+            const float4* q = reinterpret_cast<const float4*>(A.photons) + 2 * id;
+            float4* o = reinterpret_cast<float4*>(old_sparse) + 2 * id;
+            const float4 a = q[0], b = q[1];
+            o[0] = a; o[1] = b;
+        }
+        const float4* lsp = reinterpret_cast<const float4*>(A.light_samples) + 2 * (size_t)threadId;
+        const float4 l0 = lsp[0], l1 = lsp[1];
+        const float2 ip = reinterpret_cast<const float2*>(A.isect)[threadId];
+        const uint2 rs = reinterpret_cast<const uint2*>(A.rng)[photon_offset + threadId];
+        const f3 direction = decode_direction_(l1.z, l1.w);
+        float th, ph;
+        encode_direction_(direction, th, ph);
+        tracer::trace_photon<DT, SINGLE>(A, lut, luts, threadId, l0, l1, ip, rs, direction, th, ph, steps);
+        importances[photon_offset + threadId] = 2147483647u;  // resetPhotonImportance (tracercl.cpp:529)
+    }
+    if (A.step_counter) {
+        unsigned sN = steps;
+        for (int off = 32; off > 0; off >>= 1) sN += __shfl_down(sN, off, 64);
+        if (lane == 0 && sN) atomicAdd(A.step_counter, (unsigned long long)sN);
+    }
+}
+
 // The radix-pass form of cpm_select_changed (cpm_debug_set_select_partition(0)): flag = 0 for a photon whose importance
 // says "re-trace" (key < 0x7fffffff), 1 otherwise; iota.
 // One stable radix pass over the flag then partitions the indices (changed first, both parts ascending) and its
@@ -1029,6 +1119,83 @@ int cpm_photon_importance_select(cpm_ctx* ctx, cpm_selection* s, const float* im
                                 total_photons, fix_exit_point, 1, 0, importances, S);
     }
     CPM_LAUNCH_CHECK(ctx, "importance_select_kernel");
+    return CPM_OK;
+}
+
+int cpm_photon_importance_retrace(cpm_ctx* ctx, cpm_selection* s, const float* importance_grid, const int32_t grid_dims[3],
+                                  const float cell_size[3], const float texture_to_index[16], const cpm_volume* vol, const cpm_tf* tf,
+                                  const cpm_tf* tf_scattering, const float aabb[8], const cpm_trace_params* params,
+                                  const float* light_samples8, const float* isect2, int fix_exit_point, uint32_t* importances,
+                                  uint32_t* rng_state, float* photons8, float* old_photons8, cpm_stream stream) {
+    CPM_ENTER(ctx);
+    CPM_REQUIRE(ctx, s, "cpm_photon_importance_retrace: null selection");
+    CPM_REQUIRE(ctx, grid_dims && cell_size && texture_to_index && params, "cpm_photon_importance_retrace: null argument");
+    tracer::TraceArgs A;
+    size_t lut_bytes = 0;
+    int rc = cpm::make_trace_args(ctx, vol, tf, tf_scattering, aabb, params, A, lut_bytes);
+    if (rc) return rc;
+    const cpm_trace_params& p = *params;
+    CPM_REQUIRE(ctx, !(p.flags & CPM_TRACE_PROGRESSIVE), "cpm_photon_importance_retrace: a correlated re-trace does not write the RNG state back");
+    if (p.n_light_samples == 0) return CPM_OK;
+    CPM_REQUIRE(ctx, importance_grid && photons8 && light_samples8 && isect2 && importances && rng_state && old_photons8,
+                "cpm_photon_importance_retrace: null buffer");
+    CPM_REQUIRE_ALIGNED16(ctx, photons8, "cpm_photon_importance_retrace");
+    CPM_REQUIRE_ALIGNED16(ctx, old_photons8, "cpm_photon_importance_retrace");
+    CPM_REQUIRE_ALIGNED16(ctx, light_samples8, "cpm_photon_importance_retrace");
+    CPM_REQUIRE(ctx, (reinterpret_cast<uintptr_t>(rng_state) & 7u) == 0 && (reinterpret_cast<uintptr_t>(isect2) & 7u) == 0,
+                "cpm_photon_importance_retrace: rng_state / isect2 must be 8-byte aligned");
+    ImpGrid G;
+    G.grid = importance_grid;
+    unsigned long long cells = 1;
+    for (int a = 0; a < 3; ++a) {
+        CPM_REQUIRE(ctx, grid_dims[a] >= 1 && cell_size[a] > 0.f, "cpm_photon_importance_retrace: grid dims / cell size");
+        G.dims[a] = grid_dims[a];
+        set_cell(G, a, cell_size[a]);
+        cells *= (unsigned long long)grid_dims[a];
+    }
+    CPM_REQUIRE(ctx, cells < (1ull << 31), "cpm_photon_importance_retrace: grid too large");
+    if (!affine_from_matrix(texture_to_index, G.t2i))
+        return set_error(ctx, CPM_ERR_UNSUPPORTED, "cpm_photon_importance_retrace", "textureToIndex must be scale + translate");
+    uint32_t first = 0, tiles = 0;
+    rc = selection_append(ctx, s, p.photon_offset, p.n_light_samples, &first, &tiles);
+    if (rc) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    s->last_stream = st;
+    SelTiles S{ s->tile, s->local, first, s->per_tile };
+    A.light_samples = light_samples8;
+    A.isect = isect2;
+    A.rng = rng_state;
+    A.photons = photons8;
+    A.n_threads = p.n_light_samples;
+    const size_t words = (size_t)((cells + 63) / 64) * 2;
+    const bool use_mask = words * 4 <= 64 * 1024;
+    if (use_mask) {
+        if (s->mask_words < words) {
+            if (s->mask) { CPM_HIP_CHECK(ctx, hipStreamSynchronize(st)); (void)hipFree(s->mask); s->mask = nullptr; s->mask_words = 0; }
+            CPM_HIP_CHECK(ctx, hipMalloc(&s->mask, words * 4));
+            s->mask_words = words;
+        }
+        CPM_LAUNCH(ctx, importance_mask_kernel, dim3(div_up((long long)cells, 256)), dim3(256), 0, st, importance_grid, (uint32_t)cells, s->mask);
+        CPM_LAUNCH_CHECK(ctx, "importance_mask_kernel");
+    }
+    const uint32_t mw = use_mask ? (uint32_t)words : 0u;
+    const size_t lds = (size_t)mw * 4 + lut_bytes;
+    const bool single = p.max_interactions == 1 && !(p.flags & CPM_TRACE_NO_SINGLE_SCATTERING);
+    const dim3 grid(tiles), block(256);
+#define CPM_RETRACE_LAUNCH(DT)                                                                                                                   \
+    do {                                                                                                                                         \
+        if (use_mask && single) CPM_LAUNCH(ctx, (importance_retrace_kernel<DT, true, true>), grid, block, lds, st, G, s->mask, mw, fix_exit_point, importances, S, A, old_photons8);   \
+        else if (use_mask) CPM_LAUNCH(ctx, (importance_retrace_kernel<DT, true, false>), grid, block, lds, st, G, s->mask, mw, fix_exit_point, importances, S, A, old_photons8);       \
+        else if (single) CPM_LAUNCH(ctx, (importance_retrace_kernel<DT, false, true>), grid, block, lds, st, G, s->mask, mw, fix_exit_point, importances, S, A, old_photons8);        \
+        else CPM_LAUNCH(ctx, (importance_retrace_kernel<DT, false, false>), grid, block, lds, st, G, s->mask, mw, fix_exit_point, importances, S, A, old_photons8);                   \
+    } while (0)
+    switch (vol->desc.dtype) {
+        case CPM_U8: CPM_RETRACE_LAUNCH(CPM_U8); break;
+        case CPM_U16: CPM_RETRACE_LAUNCH(CPM_U16); break;
+        default: CPM_RETRACE_LAUNCH(CPM_F32); break;
+    }
+#undef CPM_RETRACE_LAUNCH
+    CPM_LAUNCH_CHECK(ctx, "importance_retrace_kernel");
     return CPM_OK;
 }
 

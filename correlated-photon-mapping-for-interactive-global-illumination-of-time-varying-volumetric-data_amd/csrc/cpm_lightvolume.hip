@@ -1107,7 +1107,8 @@ __global__ __launch_bounds__(256) void splat_delta_kernel(const float* __restric
     const int zpart = part >> 1;
     const size_t id = indices[j];
     for (int it = 0; it < n_interactions; ++it) {
-        const float4* qo = reinterpret_cast<const float4*>(old_photons) + 2 * ((size_t)it * old_stride + (size_t)j);
+        // old_stride == 0: the old records sit at the photons' own indices (cpm_photon_importance_retrace's old_photons8)
+        const float4* qo = reinterpret_cast<const float4*>(old_photons) + 2 * (old_stride ? (size_t)it * old_stride + (size_t)j : (size_t)it * n_photons + id);
         const float4* qn = reinterpret_cast<const float4*>(photons) + 2 * ((size_t)it * n_photons + id);
         const float4 oa = qo[0], ob = qo[1], na = qn[0], nb = qn[1];
         // the same record before and after: its two splats cancel term by term
@@ -1186,7 +1187,8 @@ int cpm_splat_delta(cpm_ctx* ctx, const float* old_photons8, int old_stride, con
     GridDev G;
     int rc = make_grid_dev(ctx, grid, G);
     if (rc) return rc;
-    CPM_REQUIRE(ctx, max_indices >= 0 && old_stride >= max_indices && n_photons >= 0 && n_interactions >= 1 && radius > 0.f, "cpm_splat_delta: bad size");
+    CPM_REQUIRE(ctx, max_indices >= 0 && (old_stride == 0 || old_stride >= max_indices) && n_photons >= 0 && n_interactions >= 1 && radius > 0.f,
+                "cpm_splat_delta: bad size");
     CPM_REQUIRE(ctx, max_indices < (1 << 28), "cpm_splat_delta: too many indices");
     if (max_indices == 0) return CPM_OK;
     CPM_REQUIRE(ctx, old_photons8 && photons8 && indices && n_indices_dev && grid_out, "cpm_splat_delta: null buffer");

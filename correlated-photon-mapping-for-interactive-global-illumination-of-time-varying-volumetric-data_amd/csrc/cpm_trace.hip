@@ -19,193 +19,13 @@
 //     Inviwo's 1024-texel LUT) and sampled with two ds_read + one lerp.
 //   * MWC64X state lives in two VGPRs; photons and light samples move as 2 x float4
 //     (coalesced 2 KiB per wave-instruction).
-#include "cpm_ctx.h"
-#include "cpm_emit.hip.h"
+#include "cpm_trace_body.hip.h"
 
 using namespace cpm;
 
+using namespace cpm::tracer;
+
 namespace {
-
-struct VolDev {
-    const void* voxels;      // cpm_volume::quads
-    float fx, fy, fz;        // (float)dim
-    float mx1, my1, mz1;     // dim - 1
-    float mx2, my2, mz2;     // max(dim - 2, 0)
-    uint32_t sy, sz;         // row / slice stride in elements
-    int mul24;               // strides and indices fit 24 bits: v_mul_u32_u24 (full rate) instead of v_mul_lo_u32 (quarter)
-    float norm, offset, one_minus_scaling;
-};
-
-struct TraceArgs {
-    VolDev vol;
-    const float* tf_alpha;
-    const float* tfs_alpha;   // == tf_alpha when the reference's "tf passed twice" quirk applies
-    int tf_width;
-    float tf_wf, tf_m1, tf_m2;
-    float bmin[3], bmax[3];
-    cpm_trace_params p;
-    const float* light_samples;
-    const float* isect;
-    const uint32_t* recompute_indices;
-    int n_threads;
-    // cpm_trace_selected: the number of indices lives on the device (nullable: n_threads is it); the records about to be
-    // overwritten are kept in old_photons[k * old_stride + j]; the traced photons' importance keys are reset
-    const int32_t* n_threads_dev;
-    float* old_photons;
-    uint32_t old_stride;
-    uint32_t* reset_importances;
-    uint32_t* rng;
-    float* photons;
-    unsigned long long* step_counter;  // nullable (statistics build of the launch)
-    const float* dir_hint;             // cpm_ctx::dir_hint (emitted mode: the hint of ITS light, cpm_ctx::dir_hint + 8)
-    // emitted mode (cpm_trace_emitted): light sample and entry / exit of lattice sample first_sample + thread, in registers
-    Light light;
-    float lattice_x, lattice_y;
-    int first_sample;
-};
-
-enum { EMIT_NONE = 0, EMIT_DIRECTIONAL = 1, EMIT_POINT = 2 };
-
-// One fetch = the whole 2 x 2 x 2 footprint of a trilinear sample: two neighbouring elements of cpm_volume::quads, each
-// { v(x, y, z), v(x, y + 1, z), v(x, y, z + 1), v(x, y + 1, z + 1) } (clamped at the last row / slice).  Four x-pair fetches of
-// the linear layout before: the texture-address path is the loop's second bottleneck; two fetches per sample took 10 % off the
-// config-2 trace and 24 % off a 33-step-per-photon one, one fetch a further 5 % and 13 %.
-template <int DT> struct FootprintLoad;
-template <> struct FootprintLoad<CPM_U8> {
-    static CPM_DEV void load(const void* base, uint32_t idx, float (&v)[8]) {
-        uint32_t w[2];
-        __builtin_memcpy(w, static_cast<const uint8_t*>(base) + 4 * (size_t)idx, 8);
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {  // v_cvt_f32_ubyte0..3
-            v[4 * i + 0] = (float)(w[i] & 0xffu);
-            v[4 * i + 1] = (float)((w[i] >> 8) & 0xffu);
-            v[4 * i + 2] = (float)((w[i] >> 16) & 0xffu);
-            v[4 * i + 3] = (float)(w[i] >> 24);
-        }
-    }
-};
-template <> struct FootprintLoad<CPM_U16> {
-    static CPM_DEV void load(const void* base, uint32_t idx, float (&v)[8]) {
-        uint32_t w[4];
-        __builtin_memcpy(w, static_cast<const uint16_t*>(base) + 4 * (size_t)idx, 16);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            v[2 * i + 0] = (float)(w[i] & 0xffffu);
-            v[2 * i + 1] = (float)(w[i] >> 16);
-        }
-    }
-};
-template <> struct FootprintLoad<CPM_F32> {
-    static CPM_DEV void load(const void* base, uint32_t idx, float (&v)[8]) {
-        __builtin_memcpy(v, static_cast<const float*>(base) + 4 * (size_t)idx, 32);
-    }
-};
-
-CPM_DEV void coord(float s, float dimf, float m1, float m2, float& fl, float& a) {
-    // u' = clamp(s*w - 0.5, 0, w-1), i0 = min(floor(u'), w-2) (0 <= floor(u'), 0 <= m2), a = u' - i0.
-    // v_med3_f32 is the clamp in one instruction (the operands are never NaN here); min/max pairs cost two
-    // plus a canonicalising v_max of the uniform bound each -- 16 instructions per Woodcock step.
-    const float u = __builtin_amdgcn_fmed3f(fma_(s, dimf, -0.5f), 0.0f, m1);
-    fl = __builtin_amdgcn_fmed3f(__builtin_floorf(u), 0.0f, m2);
-    a = u - fl;
-}
-
-template <int DT>
-CPM_DEV float sample_volume(const VolDev& V, float px, float py, float pz) {
-    float flx, fly, flz, ax, ay, az;
-    coord(px, V.fx, V.mx1, V.mx2, flx, ax);
-    coord(py, V.fy, V.my1, V.my2, fly, ay);
-    coord(pz, V.fz, V.mz1, V.mz2, flz, az);
-    int ix = (int)flx, iy = (int)fly, iz = (int)flz;
-    uint32_t b00 = V.mul24 ? (uint32_t)ix + __umul24(V.sy, (uint32_t)iy) + __umul24(V.sz, (uint32_t)iz)
-                           : (uint32_t)ix + V.sy * (uint32_t)iy + V.sz * (uint32_t)iz;
-    float v[8];  // [x][z][y]: 000 010 001 011 | 100 110 101 111
-    FootprintLoad<DT>::load(V.voxels, b00, v);
-    float c00 = lerp_(v[0], v[4], ax);
-    float c10 = lerp_(v[1], v[5], ax);
-    float c01 = lerp_(v[2], v[6], ax);
-    float c11 = lerp_(v[3], v[7], ax);
-    float c0 = lerp_(c00, c10, ay);
-    float c1 = lerp_(c01, c11, ay);
-    float c = lerp_(c0, c1, az);
-    float s = c * V.norm;
-    return (s + V.offset) * V.one_minus_scaling;
-}
-
-// read_imagef(tf, smpNormClampEdgeLinear, (float2)(v, 0.5f)).w from the LDS alpha column
-CPM_DEV float sample_alpha(const float* lut, float wf, float m1, float m2, float v) {
-    float fl, a;
-    coord(v, wf, m1, m2, fl, a);
-    int i = (int)fl;
-    return lerp_(lut[i], lut[i + 1], a);
-}
-
-// build-defined phase-function sampling (Inviwo sampleShadingFunction is not in the
-// reference tree): Henyey-Greenstein (g = material.x) or isotropic about `w`.
-CPM_DEV float phase_cos(int type, float g, float u1) {
-    if (type == CPM_PHASE_ISOTROPIC || __builtin_fabsf(g) < 1e-3f) return fma_(-2.0f, u1, 1.0f);
-    float g2 = g * g;
-    float sq = (1.0f - g2) / fma_(2.0f * g, u1, 1.0f - g);
-    return (1.0f + g2 - sq * sq) / (2.0f * g);
-}
-CPM_DEV float phase_pdf(int type, float g, float cosT) {
-    if (type == CPM_PHASE_ISOTROPIC || __builtin_fabsf(g) < 1e-3f) return kInv4Pi;
-    float g2 = g * g;
-    float den = fma_(-2.0f * g, cosT, 1.0f + g2);
-    return kInv4Pi * (1.0f - g2) / (den * __builtin_sqrtf(den));
-}
-CPM_DEV f3 phase_sample(int type, float g, f3 w, float u1, float u2, float* pdf) {
-    float cosT = phase_cos(type, g, u1);
-    cosT = min_(max_(cosT, -1.0f), 1.0f);
-    float sinT = __builtin_sqrtf(max_(0.0f, fma_(-cosT, cosT, 1.0f)));
-    float sp, cp;
-    sincos_(kTwoPi * u2, sp, cp);
-    f3 a;
-    if (__builtin_fabsf(w.z) < 0.999f) { a.x = 0; a.y = 0; a.z = 1; } else { a.x = 1; a.y = 0; a.z = 0; }
-    f3 u = cross3_(a, w);
-    float il = 1.0f / __builtin_sqrtf(dot3_(u, u));
-    u.x *= il; u.y *= il; u.z *= il;
-    f3 v = cross3_(w, u);
-    float ku = sinT * cp, kv = sinT * sp;
-    f3 d;
-    d.x = fma_(cosT, w.x, fma_(kv, v.x, ku * u.x));
-    d.y = fma_(cosT, w.y, fma_(kv, v.y, ku * u.y));
-    d.z = fma_(cosT, w.z, fma_(kv, v.z, ku * u.z));
-    if (pdf) *pdf = phase_pdf(type, g, cosT);
-    return d;
-}
-
-CPM_DEV void write_photon(float* photons, size_t id, f3 p, f3 pw, float th, float ph) {
-    // (plain stores: with the tile-wise chunk order below a streaming hint no longer helps this launch, and the bin's count
-    // launch reads the records 0.8 us sooner without it -- 5 us sooner at 4 M photons)
-    float4* q = reinterpret_cast<float4*>(photons) + 2 * id;
-    q[0] = make_float4(p.x, p.y, p.z, pw.x);
-    q[1] = make_float4(pw.y, pw.z, th, ph);
-}
-
-template <int DT>
-CPM_DEV float woodcock(const VolDev& V, const float* lut, float wf, float m1, float m2, f3 o, f3 d, float tStart,
-                       float tEnd, uint32_t& rx, uint32_t& rc, unsigned& steps, float& last_sample, float& last_opacity) {
-    constexpr float invTauMaxSampleBaseInterval = 1.f / (1.f * 150.f);  // tauMax = 1 (photontracer.cl:160)
-    float t = tStart;
-    float opacity, u2;
-    do {
-        float u1 = rand01_(rx, rc);
-        t = fma_(-log_(u1), invTauMaxSampleBaseInterval, t);
-        // the fetched value cannot influence the result once t > tEnd (the loop ends
-        // whatever it is), so the fetch is skipped there; the RNG draw is not.
-        opacity = 0.f;
-        if (t <= tEnd) {
-            float vs = sample_volume<DT>(V, fma_(t, d.x, o.x), fma_(t, d.y, o.y), fma_(t, d.z, o.z));
-            opacity = sample_alpha(lut, wf, m1, m2, vs);
-            last_sample = vs;
-        }
-        u2 = rand01_(rx, rc);
-        ++steps;
-    } while (u2 >= opacity && t <= tEnd);
-    last_opacity = opacity;
-    return t;
-}
 
 // SINGLE: max_interactions == 1 known at compile time -- the scatter branch (phase-function sample, re-encoded direction, slab
 // test) and the sentinel loop leave the instruction stream of the headline configuration; the NO_SINGLE_SCATTERING variant and
@@ -313,16 +133,9 @@ __global__ __launch_bounds__(256, 8) void trace_kernel(const TraceArgs A) {
         l1 = make_float4(pw.y, pw.z, t0, p0);
     }
 
-    uint32_t rx = rs.x, rc = rs.y;
-    uint32_t nInteractions = 0;
     unsigned steps = 0;
-
-    f3 origin = { l0.x, l0.y, l0.z };
-    float mi = (float)maxInteractions;
-    f3 power = { l0.w, l1.x, l1.y };
-    if (maxInteractions != 1) { power.x = power.x / mi; power.y = power.y / mi; power.z = power.z / mi; }  // x / 1.0f == x
     f3 direction;
-    float th, ph;  // encodeDirection(direction), kept current: re-evaluated only where the direction changes
+    float th, ph;  // encodeDirection(direction)
     // (a point light's samples each have their own direction: s_dir is not even written in that mode)
     if (EMIT != EMIT_POINT && __all(__float_as_uint(l1.z) == __float_as_uint(s_dir[0]) && __float_as_uint(l1.w) == __float_as_uint(s_dir[1]))) {
         direction.x = s_dir[2]; direction.y = s_dir[3]; direction.z = s_dir[4];
@@ -331,75 +144,7 @@ __global__ __launch_bounds__(256, 8) void trace_kernel(const TraceArgs A) {
         direction = decode_direction_(l1.z, l1.w);
         encode_direction_(direction, th, ph);
     }
-    float tStart = ip.x, tEnd = ip.y;
-    bool scatterEvent = tStart < tEnd;
-
-    const float wf = A.tf_wf, m1 = A.tf_m1, m2 = A.tf_m2;
-
-    if (!SINGLE && (A.p.flags & CPM_TRACE_NO_SINGLE_SCATTERING)) {  // photontracer.cl:143-157
-        float vs_unused, op_unused;
-        float t = woodcock<DT>(A.vol, lut, wf, m1, m2, origin, direction, tStart, tEnd, rx, rc, steps, vs_unused, op_unused);
-        if (scatterEvent) {
-            origin.x = fma_(t, direction.x, origin.x);
-            origin.y = fma_(t, direction.y, origin.y);
-            origin.z = fma_(t, direction.z, origin.z);
-            tStart = 0.f; tEnd = kFltMax;
-            float u1 = rand01_(rx, rc), u2 = rand01_(rx, rc);
-            float pdf;
-            direction = phase_sample(A.p.shading_type, A.p.material[0], direction, u1, u2, &pdf);
-            encode_direction_(direction, th, ph);
-            scatterEvent = ray_box_(A.bmin, A.bmax, origin, direction, tStart, tEnd);
-            power.x = power.x / pdf; power.y = power.y / pdf; power.z = power.z / pdf;
-            tStart = tStart + 0.5f * A.p.step_size;
-        }
-    }
-    while (scatterEvent) {  // photontracer.cl:158-197
-        float volumeSample = 0.f, colorW = 0.f;
-        float t = woodcock<DT>(A.vol, lut, wf, m1, m2, origin, direction, tStart, tEnd, rx, rc, steps, volumeSample, colorW);
-        scatterEvent = t <= tEnd;
-        if (scatterEvent) {
-            origin.x = fma_(t, direction.x, origin.x);
-            origin.y = fma_(t, direction.y, origin.y);
-            origin.z = fma_(t, direction.z, origin.z);
-            size_t photonId = (size_t)photonOffset + nInteractions * totalPhotons + (size_t)threadId;
-            // (th, ph) = encodeDirection(direction) (photontracer.cl:167): current, see above.
-            // The reference samples the volume and the TF again at the collision point
-            // (photontracer.cl:170-173).  The accepted Woodcock iteration sampled exactly that point --
-            // fma(t, d, o) with the same t, d, o -- so its volume sample and alpha ARE those values.
-            float dv = max_(colorW, 0.01f);
-            power.x = power.x / dv; power.y = power.y / dv; power.z = power.z / dv;
-            ++nInteractions;
-            bool scatter = false;
-            float scatteringAlbedo = 0.f;
-            if (nInteractions < maxInteractions) {  // the albedo is only read behind this test (photontracer.cl:179)
-                float scatW = (luts == lut) ? colorW : sample_alpha(luts, wf, m1, m2, volumeSample);
-                scatteringAlbedo = scatW / (scatW + colorW);
-                scatter = rand01_(rx, rc) < scatteringAlbedo;
-            }
-            if (scatter) {
-                power.x *= scatteringAlbedo; power.y *= scatteringAlbedo; power.z *= scatteringAlbedo;
-                write_photon(A.photons, photonId, origin, power, th, ph);
-                tStart = 0.f; tEnd = kFltMax;
-                float u1 = rand01_(rx, rc), u2 = rand01_(rx, rc);
-                direction = phase_sample(A.p.shading_type, A.p.material[0], direction, u1, u2, nullptr);
-                encode_direction_(direction, th, ph);
-                scatterEvent = ray_box_(A.bmin, A.bmax, origin, direction, tStart, tEnd);
-                tStart = tStart + 0.5f * A.p.step_size;
-            } else {
-                write_photon(A.photons, photonId, origin, power, th, ph);
-                power.x = power.y = power.z = kFltMax;  // read by the recomputation detector
-                scatterEvent = false;
-            }
-        }
-    }
-    for (uint32_t i = nInteractions; i < maxInteractions; ++i) {  // photontracer.cl:199-209 (th, ph: the current direction)
-        size_t photonId = (size_t)photonOffset + i * totalPhotons + (size_t)threadId;
-        f3 p = { kFltMax, kFltMax, kFltMax };
-        f3 pw = { power.x, kFltMax, kFltMax };
-        write_photon(A.photons, photonId, p, pw, th, ph);
-    }
-    if (A.p.flags & CPM_TRACE_PROGRESSIVE) rng[photonOffset + threadId] = make_uint2(rx, rc);  // :211-215
-    if (A.reset_importances) A.reset_importances[photonOffset + threadId] = 2147483647u;  // resetPhotonImportance (tracercl.cpp:529)
+    trace_photon<DT, SINGLE>(A, lut, luts, threadId, l0, l1, ip, rs, direction, th, ph, steps);
     if (A.step_counter) {
         // statistics only: wave-level sum, one atomic per wave
         unsigned s = steps;
@@ -412,7 +157,43 @@ __global__ __launch_bounds__(256, 8) void trace_kernel(const TraceArgs A) {
 }  // namespace
 
 namespace cpm {
-// exposed to cpm_correlated.hip (min/max bricks use the same normalisation)
+
+int make_trace_args(cpm_ctx* ctx, const cpm_volume* vol, const cpm_tf* tf, const cpm_tf* tf_scattering, const float aabb[8],
+                    const cpm_trace_params* params, tracer::TraceArgs& A, size_t& lds) {
+    CPM_REQUIRE(ctx, vol && tf && aabb && params, "cpm_trace: null argument");
+    const cpm_trace_params& p = *params;
+    CPM_REQUIRE(ctx, p.n_light_samples >= 0 && p.photon_offset >= 0 && p.total_photons >= 0, "cpm_trace: negative size");
+    CPM_REQUIRE(ctx, p.max_interactions >= 1 && p.max_interactions <= 64, "cpm_trace: max_interactions in [1, 64]");
+    CPM_REQUIRE(ctx, (long long)p.photon_offset + p.n_light_samples <= (long long)p.total_photons,
+                "cpm_trace: photon_offset + n_light_samples exceeds total_photons");
+    if (tf_scattering) CPM_REQUIRE(ctx, tf_scattering->width == tf->width, "cpm_trace: tf widths differ");
+    const cpm_volume_desc& d = vol->desc;
+    CPM_REQUIRE(ctx, (unsigned long long)d.dims[0] * d.dims[1] * d.dims[2] < (1ull << 32), "cpm_trace: volume too large");
+    A = tracer::TraceArgs{};
+    A.vol.voxels = vol->quads;
+    A.vol.fx = (float)d.dims[0]; A.vol.fy = (float)d.dims[1]; A.vol.fz = (float)d.dims[2];
+    A.vol.mx1 = (float)(d.dims[0] - 1); A.vol.my1 = (float)(d.dims[1] - 1); A.vol.mz1 = (float)(d.dims[2] - 1);
+    A.vol.mx2 = (float)(d.dims[0] - 2);
+    A.vol.my2 = (float)(d.dims[1] > 2 ? d.dims[1] - 2 : 0);
+    A.vol.mz2 = (float)(d.dims[2] > 2 ? d.dims[2] - 2 : 0);
+    A.vol.sy = (uint32_t)d.dims[0];
+    A.vol.sz = (uint32_t)d.dims[0] * (uint32_t)d.dims[1];
+    A.vol.mul24 = A.vol.sz < (1u << 24) && d.dims[0] < (1 << 24) && d.dims[1] < (1 << 24) && d.dims[2] < (1 << 24);
+    A.vol.norm = d.dtype == CPM_U8 ? (1.0f / 255.0f) : (d.dtype == CPM_U16 ? (1.0f / 65535.0f) : 1.0f);
+    A.vol.offset = d.format_offset;
+    A.vol.one_minus_scaling = 1.0f - d.format_scaling;
+    A.tf_alpha = tf->alpha;
+    A.tfs_alpha = tf_scattering ? tf_scattering->alpha : tf->alpha;
+    A.tf_width = tf->width;
+    A.tf_wf = (float)tf->width; A.tf_m1 = (float)(tf->width - 1); A.tf_m2 = (float)(tf->width - 2);
+    for (int a = 0; a < 3; ++a) { A.bmin[a] = aabb[a]; A.bmax[a] = aabb[4 + a]; }
+    A.p = p;
+    A.step_counter = ctx->dbg.step_counter;
+    A.dir_hint = ctx->dir_hint;
+    lds = (size_t)tf->width * sizeof(float) * (A.tfs_alpha != A.tf_alpha ? 2 : 1);
+    return CPM_OK;
+}
+
 }
 
 extern "C" {
@@ -462,27 +243,10 @@ int trace_impl(cpm_ctx* ctx, const cpm_volume* vol, const cpm_tf* tf, const cpm_
                     "cpm_trace_emitted: first_sample + n_light_samples exceeds the lattice");
     }
     const cpm_volume_desc& d = vol->desc;
-    CPM_REQUIRE(ctx, (unsigned long long)d.dims[0] * d.dims[1] * d.dims[2] < (1ull << 32), "cpm_trace: volume too large");
-
     TraceArgs A;
-    A.vol.voxels = vol->quads;
-    A.vol.fx = (float)d.dims[0]; A.vol.fy = (float)d.dims[1]; A.vol.fz = (float)d.dims[2];
-    A.vol.mx1 = (float)(d.dims[0] - 1); A.vol.my1 = (float)(d.dims[1] - 1); A.vol.mz1 = (float)(d.dims[2] - 1);
-    A.vol.mx2 = (float)(d.dims[0] - 2);
-    A.vol.my2 = (float)(d.dims[1] > 2 ? d.dims[1] - 2 : 0);
-    A.vol.mz2 = (float)(d.dims[2] > 2 ? d.dims[2] - 2 : 0);
-    A.vol.sy = (uint32_t)d.dims[0];
-    A.vol.sz = (uint32_t)d.dims[0] * (uint32_t)d.dims[1];
-    A.vol.mul24 = A.vol.sz < (1u << 24) && d.dims[0] < (1 << 24) && d.dims[1] < (1 << 24) && d.dims[2] < (1 << 24);
-    A.vol.norm = d.dtype == CPM_U8 ? (1.0f / 255.0f) : (d.dtype == CPM_U16 ? (1.0f / 65535.0f) : 1.0f);
-    A.vol.offset = d.format_offset;
-    A.vol.one_minus_scaling = 1.0f - d.format_scaling;
-    A.tf_alpha = tf->alpha;
-    A.tfs_alpha = tf_scattering ? tf_scattering->alpha : tf->alpha;
-    A.tf_width = tf->width;
-    A.tf_wf = (float)tf->width; A.tf_m1 = (float)(tf->width - 1); A.tf_m2 = (float)(tf->width - 2);
-    for (int a = 0; a < 3; ++a) { A.bmin[a] = aabb[a]; A.bmax[a] = aabb[4 + a]; }
-    A.p = p;
+    size_t lds = 0;
+    int rc_args = cpm::make_trace_args(ctx, vol, tf, tf_scattering, aabb, params, A, lds);
+    if (rc_args) return rc_args;
     A.light_samples = light_samples8;
     A.isect = isect2;
     A.recompute_indices = recompute_indices;
@@ -494,13 +258,7 @@ int trace_impl(cpm_ctx* ctx, const cpm_volume* vol, const cpm_tf* tf, const cpm_
     if (sel.old_photons) CPM_REQUIRE_ALIGNED16(ctx, sel.old_photons, "cpm_trace_selected");
     A.rng = rng_state;
     A.photons = photons8;
-    A.step_counter = ctx->dbg.step_counter;
-    A.dir_hint = ctx->dir_hint;
-    A.light = Light{};
-    A.lattice_x = A.lattice_y = 0.f;
-    A.first_sample = 0;
 
-    size_t lds = (size_t)tf->width * sizeof(float) * (A.tfs_alpha != A.tf_alpha ? 2 : 1);
     hipStream_t s = (hipStream_t)stream;
     dim3 grid(div_up(n_threads, 256)), block(256);
     int emit = EMIT_NONE;

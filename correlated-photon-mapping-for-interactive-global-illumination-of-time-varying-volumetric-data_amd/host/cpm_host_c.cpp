@@ -134,6 +134,7 @@ const char* cpmh_last_light_volume_path(cpmh_network* net) { return net->lightVo
 const char* cpmh_last_tracer_decision(cpmh_network* net) { return net->tracer.lastDecision(); }
 // measured GPU-timeline cost of the two ways to serve a change: { full trace, full light volume, branch trace, branch light volume } ms (-1 = not measured yet)
 void cpmh_path_costs(cpmh_network* net, float out[4]) {
+    net->tracer.pollCosts(); net->lightVolume.pollCosts();  // (what the next evaluation would pick up first)
     const auto& c = net->tracer.costs();
     out[0] = c.fullTraceMs; out[1] = c.fullLightVolumeMs; out[2] = c.branchTraceMs; out[3] = c.branchLightVolumeMs;
 }

@@ -397,6 +397,43 @@ void PhotonTracerCL::tracePhotonsSelected(const Volume* volume, const TransferFu
              "cpm_trace_selected");
 }
 
+void PhotonTracerCL::importanceRetrace(cpm_selection* selection, const Volume* volume, const ImportanceUniformGrid3D* grid,
+                                       const TransferFunction& transferFunction, const float aabb[8], const AdvancedMaterialProperty& material,
+                                       float stepSize, const LightSamples* lightSamples, Buffer<unsigned int>& importances, vec4* replacedPhotons,
+                                       int photonOffset, int maxInteractions, bool fixExitPoint, PhotonData* photonOutData) {
+    auto& rt = CpmRuntime::get();
+    if (!rt.valid()) return;
+    if (randomState_.getSize() != photonOutData->getNumberOfPhotons()) setRandomSeedSize(photonOutData->getNumberOfPhotons());
+    if (importances.getSize() != photonOutData->getNumberOfPhotons()) importances.setSize(photonOutData->getNumberOfPhotons());
+    cpm_volume* vol_ = volume->getDeviceRepresentation();
+    syncTF(transferFunction);
+    if (!vol_ || !tf_) return;
+    cpm_trace_params p = {};
+    const vec4 m = material.getCombinedMaterialParameters();
+    p.material[0] = m.x; p.material[1] = m.y; p.material[2] = m.z; p.material[3] = m.w;
+    p.step_size = stepSize;
+    p.photon_offset = photonOffset;
+    p.n_light_samples = (int)lightSamples->getSize();
+    p.max_interactions = maxInteractions;
+    p.total_photons = (int)photonOutData->getNumberOfPhotons();
+    p.shading_type = material.getPhaseFunctionEnum();
+    p.flags = onlyMultipleScattering_ ? CPM_TRACE_NO_SINGLE_SCATTERING : 0;  // (with an importance grid connected the tracer is never progressive)
+    p.iteration = photonOutData->iteration();
+    const size3_t gd = grid->getDimensions(), cd = grid->getCellDimension(), vd = volume->getDimensions();
+    const int32_t dims[3] = { (int32_t)gd.x, (int32_t)gd.y, (int32_t)gd.z };
+    const float cell[3] = { (float)cd.x, (float)cd.y, (float)cd.z };
+    cpm_volume_desc d;
+    const int32_t vdims[3] = { (int32_t)vd.x, (int32_t)vd.y, (int32_t)vd.z };
+    cpm_volume_desc_default(&d, vdims, volume->dtype());
+    rt.check(cpm_photon_importance_retrace(rt.ctx(), selection, grid->data.device(), dims, cell, d.texture_to_index, vol_, tf_, nullptr, aabb, &p,
+                                           reinterpret_cast<const float*>(lightSamples->getLightSamples()->device()),
+                                           reinterpret_cast<const float*>(lightSamples->getIntersectionPoints()->device()), fixExitPoint ? 1 : 0,
+                                           importances.device(), reinterpret_cast<uint32_t*>(randomState_.device()),
+                                           reinterpret_cast<float*>(photonOutData->photons_.device()), reinterpret_cast<float*>(replacedPhotons),
+                                           rt.stream()),
+             "cpm_photon_importance_retrace");
+}
+
 void PhotonRecomputationDetector::photonRecomputationImportanceSelect(cpm_selection* selection, const PhotonData* photonData, int photonOffset,
                                                                       const Volume* origVolume, const ImportanceUniformGrid3D* grid,
                                                                       const LightSamples& lightSamples, Buffer<unsigned int>& imp, bool fixExitPoint) {
@@ -652,7 +689,7 @@ ProgressivePhotonTracerCL::ProgressivePhotonTracerCL() {
                                                                 &equalIncrementalImportance_, &spatialSorting_, &maxScatteringEvents_, &noSingleScattering_,
                                                                 &alphaProp_, &workGroupSize_, &useGLSharing_, &enableProgressiveRefinement_,
                                                                 &enableProgressivePhotonRecomputation_, &clipX_, &clipY_, &clipZ_, &fusedImportanceBranch_,
-                                                                &equalImportancePercentage_, &importanceBranchPolicy_ })
+                                                                &equalImportancePercentage_, &importanceBranchPolicy_, &retraceInImportancePass_ })
         addProperty(*p);
     addProperty(advancedMaterial_); addProperty(camera_); addProperty(invalidateRendering_); addProperty(transferFunctionProperty_);
     transferFunctionProperty_.onChange([this]() { setTransferFunction(transferFunctionProperty_.get()); });             // tracercl.cpp:148
@@ -796,25 +833,37 @@ void ProgressivePhotonTracerCL::process() {  // progressivephotontracercl.cpp:21
             photonRecomputationDetector_.setPercentage(equalImportancePercentage_.get() > 0 ? equalImportancePercentage_.get() : (int)maxIncrementalPhotonsToUpdate_.get());
             photonRecomputationDetector_.setIteration(photonRecomputationDetector_.getIteration() + 1);
             rt.check(cpm_selection_begin(rt.ctx(), selection_), "cpm_selection_begin");
+            const bool oneLaunch = retraceInImportancePass_.get() && !photonRecomputationDetector_.getEqualImportance() &&
+                                   !photonTracer_.isProgressive();
             int offset = 0;
-            for (auto& l : lights) {  // detector + threshold + count + index lists, per light (:298-356)
-                photonRecomputationDetector_.photonRecomputationImportanceSelect(selection_, photonData_.get(), offset, volume, grid.get(), *l,
-                                                                                 photonRecomputationImportance_, fixExitPoint);
-                offset += (int)l->getSize();
-            }
-            rt.check(cpm_selection_finish(rt.ctx(), selection_, rec.indicesToRecomputedPhotons.device(), rt.stream()), "cpm_selection_finish");
-            offset = 0;
-            for (auto& l : lights) {  // ascending indices = emission-lattice order (:467-473); importance reset in the same launch (:529)
-                photonTracer_.tracePhotonsSelected(volume, transferFunction_, aabb_, advancedMaterial_, stepSize, l.get(), &rec.indicesToRecomputedPhotons,
-                                                   cpm_selection_count_device(selection_), (int)N, rec.replacedPhotons.device(),
-                                                   photonRecomputationImportance_.device(), offset, maxInteractions, photonData_.get());
-                offset += (int)l->getSize();
+            if (oneLaunch) {
+                for (auto& l : lights) {  // detector + threshold + tracer + importance reset of a light in one launch (:298-356,467-529)
+                    photonTracer_.importanceRetrace(selection_, volume, grid.get(), transferFunction_, aabb_, advancedMaterial_, stepSize, l.get(),
+                                                    photonRecomputationImportance_, rec.replacedPhotons.device(), offset, maxInteractions, fixExitPoint,
+                                                    photonData_.get());
+                    offset += (int)l->getSize();
+                }
+                rt.check(cpm_selection_finish(rt.ctx(), selection_, rec.indicesToRecomputedPhotons.device(), rt.stream()), "cpm_selection_finish");
+            } else {
+                for (auto& l : lights) {  // detector + threshold + count + index lists, per light (:298-356)
+                    photonRecomputationDetector_.photonRecomputationImportanceSelect(selection_, photonData_.get(), offset, volume, grid.get(), *l,
+                                                                                     photonRecomputationImportance_, fixExitPoint);
+                    offset += (int)l->getSize();
+                }
+                rt.check(cpm_selection_finish(rt.ctx(), selection_, rec.indicesToRecomputedPhotons.device(), rt.stream()), "cpm_selection_finish");
+                offset = 0;
+                for (auto& l : lights) {  // ascending indices = emission-lattice order (:467-473); importance reset in the same launch (:529)
+                    photonTracer_.tracePhotonsSelected(volume, transferFunction_, aabb_, advancedMaterial_, stepSize, l.get(), &rec.indicesToRecomputedPhotons,
+                                                       cpm_selection_count_device(selection_), (int)N, rec.replacedPhotons.device(),
+                                                       photonRecomputationImportance_.device(), offset, maxInteractions, photonData_.get());
+                    offset += (int)l->getSize();
+                }
             }
             span_.end(rt.stream());
             rec.selection = selection_;
             rec.countPending = true;
             rec.nRecomputedPhotons = 0;  // resolved on first use (resolveCount)
-            rec.replacedStride = (int)N;
+            rec.replacedStride = oneLaunch ? 0 : (int)N;  // 0: the replaced records sit at the photons' own indices
             rec.replacedValid = true;
             rankedByImportance_ = false;
             remainingPhotonsOffset_ = 0;

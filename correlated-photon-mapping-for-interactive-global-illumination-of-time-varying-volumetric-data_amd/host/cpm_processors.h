@@ -324,6 +324,12 @@ public:
     bool isProgressive() const { return progressive_; }
     // the same over a device-side count (cpm_trace_selected): thread j < min(*nIndicesDevice, maxIndices); the records about to
     // be overwritten go to replacedPhotons (stride maxIndices), the traced photons' importance keys are reset
+    // detector + threshold + tracer of one light in one launch (cpm_photon_importance_retrace); the replaced records go to
+    // replacedPhotons at the photons' own indices
+    void importanceRetrace(cpm_selection* selection, const Volume* volume, const ImportanceUniformGrid3D* grid, const TransferFunction& transferFunction,
+                           const float aabb[8], const AdvancedMaterialProperty& material, float stepSize, const LightSamples* lightSamples,
+                           Buffer<unsigned int>& importances, vec4* replacedPhotons, int photonOffset, int maxInteractions, bool fixExitPoint,
+                           PhotonData* photonOutData);
     void tracePhotonsSelected(const Volume* volume, const TransferFunction& transferFunction, const float aabb[8],
                               const AdvancedMaterialProperty& material, float stepSize, const LightSamples* lightSamples,
                               const Buffer<unsigned int>* indices, const int32_t* nIndicesDevice, int maxIndices, vec4* replacedPhotons,
@@ -494,6 +500,9 @@ public:
     TransferFunction transferFunction_;
     PhotonTracerCL photonTracer_;
     bool fixExitPoint = false;
+    // true (default): detector, threshold and tracer in ONE launch (cpm_photon_importance_retrace); false: selection, compaction
+    // and cpm_trace_selected as separate launches (still no host round trip).  The equal-importance detector takes the latter.
+    BoolProperty retraceInImportancePass_{ "retraceInImportancePass", "Re-trace inside the importance pass", true };
     // false: the importance branch launch by launch with its host read of the count in the middle (always taken when the update
     // budget is below 100 %: ranking by importance is a host decision); true (default): the count stays on the device
     BoolProperty fusedImportanceBranch_{ "fusedImportanceBranch", "Importance branch without host round trip", true };
@@ -505,6 +514,7 @@ public:
     StringOptionProperty importanceBranchPolicy_{ "importanceBranchPolicy", "Importance branch", "adaptive" };
     const char* lastDecision() const { return lastDecision_; }
     PathCosts& costs() { return costs_; }
+    void pollCosts() { span_.poll(); }  // picks up a finished evaluation's span now (process() does so by itself)
     // measurement aid (not a reference property): with equalImportance on, select every (100 / p)-th photon while the update
     // budget stays what maxIncrementalPhotonsToUpdate says (the reference uses that one property for both: 0 = as the reference)
     IntProperty equalImportancePercentage_{ "equalImportancePercentage", "Equal importance: percentage selected", 0 };
@@ -568,6 +578,7 @@ public:
     // property of the reference (it re-splats every iteration and leaves the averaging to the consumer).
     BoolProperty progressiveAccumulation_{ "progressiveAccumulation", "Average progressive iterations", true };
     const char* lastPath() const { return lastPath_; }
+    void pollCosts() { span_.poll(); }
     // Multi-GPU: this processor's photons are ONE shard of the frame's photons and lightVolume_ is the shard's
     // partial light volume; with a communicator set, the outport carries the sum over the shards -- one cpm_allreduce_grid
     // per full evaluation, cpm_allreduce_grid_bricks (touched bricks only) after an add-remove update.  The call site is

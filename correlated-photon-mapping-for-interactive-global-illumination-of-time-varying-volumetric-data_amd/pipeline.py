@@ -515,6 +515,7 @@ class CorrelatedPhotonMapper(PhotonFrame):
         self.selection = None
         self.old_photons = None
         self.fused = True
+        self.retrace_in_importance_pass = True   # cpm_photon_importance_retrace (False: select, compact, then cpm_trace_selected)
 
     def full_frame(self):
         """Light / everything changed: full trace, bin + gather, snapshot (tracercl.cpp:541-560)."""
@@ -611,17 +612,26 @@ class CorrelatedPhotonMapper(PhotonFrame):
             self.old_photons = torch.empty((self.I * n_total, 8), dtype=torch.float32, device=ctx.device)
         sel = self.selection
         sel.begin()
-        sel.photon_importance(self.importance_grid, self.brick_dims, (float(self.region),) * 3, list(self.vol.desc.texture_to_index),
-                              self.photons, 0, self.light_samples, self.isect, n_total, self.I, n_total, self.importance,
-                              fix_exit_point=self.fix_exit_point)
-        sel.finish(self.indices)
         self.params.flags = 0                            # correlated: RNG state is NOT written back
-        ctx.trace_selected(self.vol, self.tf, self.aabb, self.params, self.light_samples, self.isect, self.indices, sel, n_total,
-                           self.rng, self.photons, old_photons=self.old_photons, reset_importances=self.importance)
+        if self.retrace_in_importance_pass:
+            # detector + threshold + tracer in one launch; the replaced records stay at the photons' own indices
+            sel.photon_importance_retrace(self.importance_grid, self.brick_dims, (float(self.region),) * 3, list(self.vol.desc.texture_to_index),
+                                          self.vol, self.tf, self.aabb, self.params, self.light_samples, self.isect, self.importance,
+                                          self.rng, self.photons, self.old_photons, fix_exit_point=self.fix_exit_point)
+            sel.finish(self.indices)
+            old_stride = 0
+        else:
+            sel.photon_importance(self.importance_grid, self.brick_dims, (float(self.region),) * 3, list(self.vol.desc.texture_to_index),
+                                  self.photons, 0, self.light_samples, self.isect, n_total, self.I, n_total, self.importance,
+                                  fix_exit_point=self.fix_exit_point)
+            sel.finish(self.indices)
+            ctx.trace_selected(self.vol, self.tf, self.aabb, self.params, self.light_samples, self.isect, self.indices, sel, n_total,
+                               self.rng, self.photons, old_photons=self.old_photons, reset_importances=self.importance)
+            old_stride = n_total
         max_recomp = int(self.n * (self.incremental_threshold_percent / 100.0))
         if self.touched_mask is not None:
             self.touched_mask.zero_()
-        ctx.splat_delta(self.old_photons, n_total, self.photons, self.indices, sel, n_total, self.grid, self.radius, self.scale,
+        ctx.splat_delta(self.old_photons, old_stride, self.photons, self.indices, sel, n_total, self.grid, self.radius, self.scale,
                         self.n, self.I, self.light_volume, apply_below=max(max_recomp, 1), brick_mask=self.touched_mask)
         n = sel.count()                                  # the one host read, behind everything enqueued
         self.n_recomputed = n

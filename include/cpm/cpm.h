@@ -495,6 +495,23 @@ int cpm_photon_importance_select(cpm_ctx* ctx, cpm_selection* sel, const float* 
                                  const float* light_samples8, const float* isect2, int n_light_samples,
                                  int max_interactions, int total_photons, int fix_exit_point,
                                  uint32_t* importances, cpm_stream stream);
+/* Detector + threshold + tracer of one light in ONE launch: cpm_photon_importance_select, and the photons it selects are
+ * re-traced on the spot by the lanes that found them (the device function cpm_trace runs: same RNG streams, same bits), their
+ * importance keys reset.  params: as for cpm_trace (photon_offset, n_light_samples, max_interactions, total_photons, material,
+ * flags without CPM_TRACE_PROGRESSIVE).  old_photons8 (float8[N * I], laid out like photons8): the records a re-traced photon had
+ * before, written at the photon's OWN index -- the part of the reference's prevPhotons_ snapshot that the add-remove update
+ * reads; pass it to cpm_splat_delta with old_stride = 0.  cpm_selection_finish then delivers the index list and the count as
+ * for cpm_photon_importance_select.  Results: those of cpm_photon_importance_select + cpm_selection_finish +
+ * cpm_trace_selected, bit for bit (photons, index list, count; every selected photon's key back at 0x7fffffff).
+ * Replaces the importance branch of ProgressivePhotonTracerCL::process for a full budget
+ * (ref processor/progressivephotontracercl.cpp:298-374,467-529). */
+int cpm_photon_importance_retrace(cpm_ctx* ctx, cpm_selection* sel, const float* importance_grid,
+                                  const int32_t grid_dims[3], const float cell_size[3], const float texture_to_index[16],
+                                  const cpm_volume* vol, const cpm_tf* tf, const cpm_tf* tf_scattering, const float aabb[8],
+                                  const cpm_trace_params* params, const float* light_samples8, const float* isect2,
+                                  int fix_exit_point, uint32_t* importances, uint32_t* rng_state, float* photons8,
+                                  float* old_photons8, cpm_stream stream);
+
 /* The equal-importance detector (ref ...detector.cl:160-194) in the same fused form. */
 int cpm_photon_importance_equal_select(cpm_ctx* ctx, cpm_selection* sel, int photon_offset, int n_light_samples,
                                        int percentage, int iteration, uint32_t* importances, cpm_stream stream);
@@ -521,7 +538,9 @@ int cpm_trace_selected(cpm_ctx* ctx, const cpm_volume* vol, const cpm_tf* tf, co
                        float* old_photons8, uint32_t* reset_importances, uint32_t* rng_state, float* photons8,
                        cpm_stream stream);
 
-/* grid += splat(photons[indices[j] + k n_photons]) - splat(old_photons8[k old_stride + j]), j < *n_indices_dev,
+/* grid += splat(photons[indices[j] + k n_photons]) - splat(old_photons8[k old_stride + j]), j < *n_indices_dev
+ * (old_stride = 0: the old record of photon indices[j] sits at old_photons8[k n_photons + indices[j]], as
+ * cpm_photon_importance_retrace leaves it),
  * k < n_interactions, in one launch; a photon whose old and new records are the same bits adds nothing (the reference's
  * two splats cancel for it up to rounding).  Does nothing when *n_indices_dev >= apply_below (> 0): the caller then
  * rebuilds the volume (the incremental-or-full threshold, ref processor/photontolightvolumeprocessorcl.cpp:196,299,

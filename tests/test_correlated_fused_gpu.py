@@ -214,11 +214,18 @@ def test_fused_update_equals_legacy_update(ctx, oracle, cpm, max_inter):
     a = P.CorrelatedPhotonMapper(ctx, vol_np, S.tf_from_points(base), 160, (32, 32, 32), incremental_threshold_percent=100.0, **kw)
     b = P.CorrelatedPhotonMapper(ctx, vol_np, S.tf_from_points(base), 160, (32, 32, 32), incremental_threshold_percent=100.0, **kw)
     b.fused = False
-    a.full_frame(); b.full_frame()
+    c2 = P.CorrelatedPhotonMapper(ctx, vol_np, S.tf_from_points(base), 160, (32, 32, 32), incremental_threshold_percent=100.0, **kw)
+    c2.retrace_in_importance_pass = False            # select + compact + cpm_trace_selected instead of the one-launch form
+    a.full_frame(); b.full_frame(); c2.full_frame()
     assert a.prev_photons is None and b.prev_photons is not None     # the fused configuration keeps no 32 MiB snapshot
     for pts in (edit, base, edit):
         a.set_transfer_function(pts); b.set_transfer_function(pts)
+        c2.set_transfer_function(pts)
         na, nb = a.correlated_update(), b.correlated_update()
+        assert c2.correlated_update() == na
+        assert np.array_equal(bits(_n(c2.photons)), bits(_n(a.photons)))
+        assert np.array_equal(_n(c2.indices, np.uint32)[:na], _n(a.indices, np.uint32)[:na])
+        assert np.array_equal(_n(c2.importance, np.uint32), _n(a.importance, np.uint32))
         assert na == nb > 0
         assert a.last_path == b.last_path == "incremental"
         assert np.array_equal(bits(_n(a.photons)), bits(_n(b.photons)))
@@ -242,3 +249,77 @@ def test_fused_update_equals_legacy_update(ctx, oracle, cpm, max_inter):
     assert a.correlated_update() == b.correlated_update()
     assert np.array_equal(bits(_n(a.photons)), bits(_n(b.photons)))
     np.testing.assert_allclose(_n(a.light_volume), _n(b.light_volume), rtol=1e-3, atol=2e-5 * float(lv_full.max()))
+
+
+@pytest.mark.parametrize("max_inter,dtype", [(1, np.uint8), (3, np.uint8), (1, np.uint16), (2, np.float32)])
+def test_importance_retrace_equals_select_then_trace_selected(ctx, oracle, cpm, max_inter, dtype):
+    """cpm_photon_importance_retrace against cpm_photon_importance_select + cpm_selection_finish + cpm_trace_selected on the same
+    inputs: photons, index list, count and importance keys bit for bit; the replaced records at the photons' own indices."""
+    S, P = cpm.synthetic, cpm.pipeline
+    torch = ctx.torch
+    vdim, n_side, region = 64, 128, 8
+    base = [(0.0, 1, 1, 1, 0.0), (0.45, 1, 0.5, 0.2, 0.0), (0.55, 0.6, 0.3, 0.1, 0.05), (0.8, 0.9, 0.2, 0.3, 0.4), (1.0, 0.1, 0.6, 0.7, 0.5)]
+    edit = list(base)
+    edit[3] = (0.85,) + base[3][1:]
+    vol8 = S.heterogeneous_volume(vdim)
+    vol_np = vol8 if dtype == np.uint8 else (vol8.astype(np.uint16) * 257 if dtype == np.uint16 else (vol8.astype(np.float32) / np.float32(255)))
+    fr = P.PhotonFrame(ctx, vol_np, S.tf_from_points(base), n_side, (32, 32, 32), light_travel_direction=(0.3, 0.5, -1.0),
+                       max_interactions=max_inter, material=(0.3, 0, 0, 0))
+    fr.trace()
+    n = fr.n
+    before = fr.photons.clone()
+    fr.tf.update(S.tf_from_points(edit))
+    gd = (vdim // region,) * 3
+    rng = np.random.default_rng(21)
+    grid = rng.random(gd[0] * gd[1] * gd[2], dtype=np.float32)
+    grid[rng.random(grid.size) < 0.93] = 0
+    dgrid = _t(ctx, grid)
+    t2i = list(fr.vol.desc.texture_to_index)
+    imp0 = np.full(n, UNCHANGED, np.uint32)
+    imp0[rng.integers(0, n, 5)] -= 7                          # keys left from an earlier evaluation: re-traced and reset as well
+    # reference: the three launches
+    sel = ctx.selection_create(n)
+    imp_a = _t(ctx, imp0)
+    idx_a = torch.zeros(n, dtype=torch.int32, device=ctx.device)
+    ph_a = before.clone()
+    old_a = torch.zeros((max_inter * n, 8), dtype=torch.float32, device=ctx.device)
+    sel.begin()
+    sel.photon_importance(dgrid, gd, (float(region),) * 3, t2i, ph_a, 0, fr.light_samples, fr.isect, n, max_inter, n, imp_a)
+    sel.finish(idx_a)
+    ctx.trace_selected(fr.vol, fr.tf, fr.aabb, fr.params, fr.light_samples, fr.isect, idx_a, sel, n, fr.rng, ph_a, old_photons=old_a,
+                       reset_importances=imp_a)
+    cnt_a = sel.count()
+    assert 0 < cnt_a < n
+    # one launch
+    imp_b = _t(ctx, imp0)
+    idx_b = torch.zeros(n, dtype=torch.int32, device=ctx.device)
+    ph_b = before.clone()
+    old_b = torch.full((max_inter * n, 8), 7.0, dtype=torch.float32, device=ctx.device)
+    sel.begin()
+    sel.photon_importance_retrace(dgrid, gd, (float(region),) * 3, t2i, fr.vol, fr.tf, fr.aabb, fr.params, fr.light_samples, fr.isect, imp_b,
+                                  fr.rng, ph_b, old_b)
+    sel.finish(idx_b)
+    cnt_b = sel.count()
+    assert cnt_b == cnt_a
+    assert np.array_equal(_n(idx_b, np.uint32)[:cnt_b], _n(idx_a, np.uint32)[:cnt_a])
+    assert np.array_equal(bits(_n(ph_b)), bits(_n(ph_a)))
+    assert (bits(_n(ph_b)) != bits(_n(before))).any()
+    assert np.array_equal(_n(imp_b, np.uint32), _n(imp_a, np.uint32)) and (_n(imp_b, np.uint32) == UNCHANGED).all()
+    # the replaced records: at the photons' own indices, nothing else written
+    sel_idx = _n(idx_b, np.uint32)[:cnt_b].astype(np.int64)
+    ob = _n(old_b).reshape(max_inter, n, 8)
+    bf = _n(before).reshape(max_inter, n, 8)
+    assert np.array_equal(bits(ob[:, sel_idx]), bits(bf[:, sel_idx]))
+    untouched = np.ones(n, bool)
+    untouched[sel_idx] = False
+    assert (ob[:, untouched] == 7.0).all()
+    # light volume: the delta from the indexed old records == the delta from the compact ones
+    fr.photons.copy_(before)
+    fr.splat(all_interactions=True)
+    lv0 = fr.light_volume.clone()
+    lva, lvb = lv0.clone(), lv0.clone()
+    ctx.splat_delta(old_a, n, ph_a, idx_a, sel, n, fr.grid, fr.radius, fr.scale, n, max_inter, lva)
+    ctx.splat_delta(old_b, 0, ph_b, idx_b, sel, n, fr.grid, fr.radius, fr.scale, n, max_inter, lvb)
+    np.testing.assert_allclose(_n(lvb), _n(lva), rtol=1e-3, atol=2e-5 * float(lv0.max()))
+    assert float((lvb - lv0).abs().max()) > 0
+    sel.close()

@@ -43,16 +43,25 @@ def test_fused_branch_equals_launch_by_launch(hostx, cpm, max_scattering):
     b = Net(host, vol, 128, pos, d, BASE, correlated=True, max_scattering=max_scattering)
     assert host.cpmh_set_property_float(b.h, b"tracer", b"fusedImportanceBranch", 0.0) == 0
     assert host.cpmh_set_property_string(a.h, b"tracer", b"importanceBranchPolicy", b"always") == 0   # the branch itself is under test
+    # c: the device-count branch as separate launches (selection, compaction, cpm_trace_selected) instead of the one-launch form
+    c = Net(host, vol, 128, pos, d, BASE, correlated=True, max_scattering=max_scattering)
+    assert host.cpmh_set_property_string(c.h, b"tracer", b"importanceBranchPolicy", b"always") == 0
+    assert host.cpmh_set_property_float(c.h, b"tracer", b"retraceInImportancePass", 0.0) == 0
+    c.evaluate(first=True)
+    assert host.cpmh_set_property_float(c.h, b"lightvolume", b"incrementalRecomputationThreshold", 100.0) == 0
     for net in (a, b):
         net.evaluate(first=True)
         assert host.cpmh_set_property_float(net.h, b"lightvolume", b"incrementalRecomputationThreshold", 100.0) == 0
     # the legacy network needs one evaluation to take its first snapshot: a full frame follows its first edit
     for k, pts in enumerate((EDIT, BASE, EDIT)):
-        for net in (a, b):
+        for net in (a, b, c):
             net.set_tf(pts)
             net.evaluate()
         na, nb = host.cpmh_n_recomputed(a.h), host.cpmh_n_recomputed(b.h)
-        assert na == nb > 0
+        assert na == nb == host.cpmh_n_recomputed(c.h) > 0
+        assert host.cpmh_last_light_volume_path(c.h) == b"incremental"
+        assert np.array_equal(bits(a.photons()), bits(c.photons()))
+        lc, _, _ = c.light_volume()
         assert host.cpmh_last_light_volume_path(a.h) == b"incremental"
         assert np.array_equal(bits(a.photons()), bits(b.photons()))
         fresh = Net(host, vol, 128, pos, d, pts, correlated=False, max_scattering=max_scattering)
@@ -63,6 +72,7 @@ def test_fused_branch_equals_launch_by_launch(hostx, cpm, max_scattering):
         lb, _, _ = b.light_volume()
         np.testing.assert_allclose(la, lv_full, rtol=1e-3, atol=2e-5 * float(lv_full.max()))
         np.testing.assert_allclose(lb, lv_full, rtol=1e-3, atol=2e-5 * float(lv_full.max()))
+        np.testing.assert_allclose(lc, lv_full, rtol=1e-3, atol=2e-5 * float(lv_full.max()))
         fresh.close()
     assert host.cpmh_last_light_volume_path(b.h) == b"incremental"
     # an edit that changes nothing re-traces nothing and leaves the volume alone
@@ -76,7 +86,7 @@ def test_fused_branch_equals_launch_by_launch(hostx, cpm, max_scattering):
     a.set_tf(BASE)
     a.evaluate()
     assert host.cpmh_n_recomputed(a.h) == na and host.cpmh_last_light_volume_path(a.h) == b"full"
-    a.close(); b.close()
+    a.close(); b.close(); c.close()
 
 
 def test_timer_continuation_updates_the_light_volume_itself(hostx, cpm):

@@ -18,6 +18,9 @@ base = list(S.WORKSPACE_TF_POINTS); edit = list(base); edit[3] = (0.26,) + base[
 d = P._normalize((0.3, 0.5, -1.0)); pos = np.array([0.5] * 3, np.float32) - np.float32(2.0) * d
 if what == "config3":
     net = H.HostNetwork(hl, vol, nside, pos, d, base, size_option=2, correlated=True)
+    import os
+    if os.environ.get("CPM_RETRACE_IN_PASS") == "0":
+        net.set_float("tracer", "retraceInImportancePass", 0.0)
     net.evaluate(first=True)
     full = net.bench_full_frames(reps)
     net.set_string("tracer", "importanceBranchPolicy", "never")
