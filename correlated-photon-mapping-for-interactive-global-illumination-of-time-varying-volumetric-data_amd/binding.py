@@ -44,10 +44,31 @@ ABI_SYMBOLS = [
     "cpm_mix_buffers", "cpm_volume_mix",
     "cpm_comm_get_unique_id", "cpm_comm_create", "cpm_comm_create_all", "cpm_comm_destroy", "cpm_comm_rank", "cpm_comm_size",
     "cpm_allreduce_grid", "cpm_reduce_grid", "cpm_allreduce_grids", "cpm_allreduce_grid_bricks",
+    "cpm_light_volume_texels", "cpm_gl_available", "cpm_gl_register_buffer", "cpm_gl_acquire", "cpm_gl_release",
+    "cpm_gl_buffer_pointer", "cpm_gl_copy_to_buffer", "cpm_gl_unregister",
 ]
+CPM_GL_TEXEL_F32, CPM_GL_TEXEL_F16 = 0, 1
 
 
 CPM_MIX_F32, CPM_MIX_U16X2 = 0, 1
+
+
+class GLResource:
+    """A registered OpenGL buffer object (cpm_gl_resource)."""
+
+    def __init__(self, ctx, h):
+        self.ctx, self.h = ctx, h
+
+    def pointer(self):
+        """(device address, bytes) of an acquired buffer."""
+        p, n = C.c_void_p(), C.c_size_t(0)
+        self.ctx._check(self.ctx.lib.cpm_gl_buffer_pointer(self.ctx.h, self.h, C.byref(p), C.byref(n)))
+        return p.value, n.value
+
+    def close(self):
+        if self.h:
+            self.ctx.lib.cpm_gl_unregister(self.ctx.h, self.h)
+            self.h = None
 
 
 class VolumeDesc(C.Structure):
@@ -187,6 +208,14 @@ def load_library() -> C.CDLL:
         "cpm_reduce_grid": (i32, [vp, vp, vp, vp, sz, i32, vp]),
         "cpm_allreduce_grids": (i32, [P(vp), P(vp), P(vp), sz, P(vp), i32]),
         "cpm_allreduce_grid_bricks": (i32, [vp, vp, vp, vp, P(GridDesc), vp, P(u32), vp]),
+        "cpm_gl_available": (i32, [vp]),
+        "cpm_gl_register_buffer": (i32, [vp, u32, i32, P(vp)]),
+        "cpm_light_volume_texels": (i32, [vp, vp, sz, i32, vp, vp]),
+        "cpm_gl_acquire": (i32, [vp, P(vp), i32, vp]),
+        "cpm_gl_release": (i32, [vp, P(vp), i32, vp]),
+        "cpm_gl_buffer_pointer": (i32, [vp, vp, P(vp), P(sz)]),
+        "cpm_gl_copy_to_buffer": (i32, [vp, vp, sz, i32, vp, vp]),
+        "cpm_gl_unregister": (None, [vp, vp]),
         "cpm_volume_device_data": (vp, [vp, P(sz)]),
         "cpm_volume_download": (i32, [vp, vp, vp, vp]),
         # include/cpm/cpm_profile.h (measurement hooks)
@@ -489,6 +518,30 @@ class Context:
         self._check(self.lib.cpm_allreduce_grid_bricks(self.h, comm.h, self._ptr(partial), self._ptr(total), C.byref(grid),
                                                        self._ptr(brick_mask), C.byref(n_union), self._stream()))
         return int(n_union.value)
+
+    # -- OpenGL sharing (needs the host's GL context current on this thread; CpmError(CPM_ERR_UNSUPPORTED) without one)
+    def gl_available(self) -> bool:
+        return bool(self.lib.cpm_gl_available(self.h))
+
+    def gl_register_buffer(self, gl_buffer: int, read_only: bool = False) -> "GLResource":
+        h = C.c_void_p()
+        self._check(self.lib.cpm_gl_register_buffer(self.h, int(gl_buffer), int(read_only), C.byref(h)))
+        return GLResource(self, h)
+
+    def gl_acquire(self, resources):
+        arr = (C.c_void_p * len(resources))(*[r.h for r in resources])
+        self._check(self.lib.cpm_gl_acquire(self.h, arr, len(resources), self._stream()))
+
+    def gl_release(self, resources):
+        arr = (C.c_void_p * len(resources))(*[r.h for r in resources])
+        self._check(self.lib.cpm_gl_release(self.h, arr, len(resources), self._stream()))
+
+    def gl_copy_to_buffer(self, light_volume, buffer: "GLResource", texel: int = CPM_GL_TEXEL_F32):
+        self._check(self.lib.cpm_gl_copy_to_buffer(self.h, self._ptr(light_volume), light_volume.numel(), int(texel), buffer.h, self._stream()))
+
+    def light_volume_texels(self, light_volume, out, texel: int = CPM_GL_TEXEL_F32):
+        """The light volume as float32 / float16 texels in `out` (a device tensor of light_volume.numel() elements)."""
+        self._check(self.lib.cpm_light_volume_texels(self.h, self._ptr(light_volume), light_volume.numel(), int(texel), self._ptr(out), self._stream()))
 
     # -- temporal interpolation
     def mix_buffers(self, x, y, a, out, kind=None):

@@ -150,6 +150,9 @@ int cpmh_enable_shard_reduce(cpmh_network* net) {
     return 0;
 }
 const char* cpmh_last_reduce(cpmh_network* net) { return net->lightVolume.lastReduce(); }
+// OpenGL sharing call site: the host's pixel-unpack buffer the light volume's texels are written into (needs its GL context)
+void cpmh_share_light_volume_gl(cpmh_network* net, unsigned gl_buffer, int texel) { net->lightVolume.shareLightVolumeWithGL(gl_buffer, texel); }
+const char* cpmh_last_gl_copy(cpmh_network* net) { return net->lightVolume.lastGLCopy(); }
 // progressive refinement: switch it on (the tracer then writes its RNG state back), one timer tick + evaluation per call
 int cpmh_enable_refinement(cpmh_network* net, int on) {
     net->tracer.enableProgressiveRefinement_.set(on != 0);

@@ -1140,10 +1140,31 @@ void PhotonToLightVolumeProcessorCL::process() {  // photontolightvolumeprocesso
         // NOTE: the snapshot above has already been refreshed; the touched bricks of the OLD positions were marked before it
         // (marksDone: the new positions' bricks as well -- nothing left to mark)
         reduceOverShards(g, cells * channels, partialUpdate, marksDone ? photons : nullptr, photons, idx, nRecomputed, nPhotons, nInter, radius);
+        copyToGLBuffer(reducedVolume_->data.device(), cells * channels);
         outport_.setData(reducedVolume_);
         return;
     }
+    copyToGLBuffer(lightVolume_->data.device(), cells * channels);
     outport_.setData(lightVolume_);
+}
+
+void PhotonToLightVolumeProcessorCL::dropGLBuffer() {
+    if (glBuffer_ && CpmRuntime::get().valid()) cpm_gl_unregister(CpmRuntime::get().ctx(), glBuffer_);
+    glBuffer_ = nullptr;
+}
+
+// VolumeCLGL + SyncCLGL + enqueueCopyBufferToImage (photontolightvolumeprocessorcl.cpp:184-194,404-406): acquire the host's
+// pixel-unpack buffer, write the texels into it, release -- all on the frame's stream; the host's glTexSubImage3D follows.
+void PhotonToLightVolumeProcessorCL::copyToGLBuffer(const float* volume, size_t n) {
+    lastGLCopy_ = "none";
+    if (!useGLSharing_.get() || glBufferName_ == 0) return;
+    auto& rt = CpmRuntime::get();
+    if (!cpm_gl_available(rt.ctx())) { lastGLCopy_ = "no context"; return; }
+    lastGLCopy_ = "failed";
+    if (!glBuffer_ && cpm_gl_register_buffer(rt.ctx(), glBufferName_, 0, &glBuffer_) != CPM_OK) return;
+    if (cpm_gl_acquire(rt.ctx(), &glBuffer_, 1, rt.stream()) != CPM_OK) return;
+    const int rc = cpm_gl_copy_to_buffer(rt.ctx(), volume, n, glTexel_, glBuffer_, rt.stream());
+    if (cpm_gl_release(rt.ctx(), &glBuffer_, 1, rt.stream()) == CPM_OK && rc == CPM_OK) lastGLCopy_ = "copied";
 }
 
 // The one exchange step of the path: sum of the shards' partial light volumes.

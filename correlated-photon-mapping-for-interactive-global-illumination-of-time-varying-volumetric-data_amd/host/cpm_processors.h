@@ -555,7 +555,7 @@ public:
     StringOptionProperty volumeDataTypeOption_{ "volumeDataType", "Output data type", "float32" };
     BoolProperty alignChangedPhotons_{ "alignChangedPhotons", "Mem-align changed photons", false };
     IntProperty workGroupSize_{ "wgsize", "Work group size", 128 };      // inert
-    BoolProperty useGLSharing_{ "glsharing", "Use OpenGL sharing", true };  // inert
+    BoolProperty useGLSharing_{ "glsharing", "Use OpenGL sharing", true };  // see shareLightVolumeWithGL
     // "gather" (default: sort/bin + deterministic gather) or "splat" (the reference's atomic formulation)
     // VolumeInformationProperty "Information" of the output volume (read-only in the reference's UI)
     struct InformationProperty : CompositeProperty {
@@ -585,7 +585,22 @@ public:
     // where the reference hands the finished volume to the outport (photontolightvolumeprocessorcl.cpp:404-411).
     void setCommunicator(cpm_comm* comm) { comm_ = comm; }
     const char* lastReduce() const { return lastReduce_; }
+    // OpenGL sharing (`glsharing`, ref photontolightvolumeprocessorcl.cpp:184-194,404-406).  CDNA cannot map a GL texture (no
+    // image hardware); the finished light volume is written on the device into a GL pixel-unpack BUFFER of the host's context
+    // (VolumeCLGL + enqueueCopyBufferToImage in the reference), from which the host issues glTexSubImage3D into the raycaster's
+    // texture.  The host names its buffer once; registration happens at the next evaluation with the GL context current
+    // (Inviwo's processors run on the GL thread).  texel: CPM_GL_TEXEL_F32 / _F16.  Without a current context (or with
+    // `glsharing` off) the outport's device buffer is all there is -- as before.
+    void shareLightVolumeWithGL(unsigned glPixelUnpackBuffer, int texel) { glBufferName_ = glPixelUnpackBuffer; glTexel_ = texel; dropGLBuffer(); }
+    const char* lastGLCopy() const { return lastGLCopy_; }
+    ~PhotonToLightVolumeProcessorCL() override { dropGLBuffer(); }
 private:
+    void dropGLBuffer();
+    void copyToGLBuffer(const float* volume, size_t n);
+    unsigned glBufferName_ = 0;
+    int glTexel_ = CPM_GL_TEXEL_F32;
+    cpm_gl_resource* glBuffer_ = nullptr;
+    const char* lastGLCopy_ = "none";  // "none" | "copied" | "no context" | "failed"
     void volumeSizeOptionChanged();
     void reduceOverShards(const cpm_grid_desc& g, size_t count, bool partialUpdate, const float* prevPhotons, const float* photons,
                           const unsigned int* idx, int nRecomputed, int nPhotons, int nInter, float radius);

@@ -616,6 +616,44 @@ int cpm_allreduce_grids(cpm_ctx* const* ctxs, cpm_comm* const* comms, float* con
 int cpm_allreduce_grid_bricks(cpm_ctx* ctx, cpm_comm* comm, const float* partial, float* total,
                               const cpm_grid_desc* grid, uint8_t* brick_mask, uint32_t* n_union_out, cpm_stream stream);
 
+/* ---- OpenGL sharing: the consumer side of the light volume ---------------------------------------------------------
+ * Replaces Inviwo's CL-GL sharing on this path (property `glsharing`, ref processor/progressivephotontracercl.cpp:93,
+ * processor/photontolightvolumeprocessorcl.cpp:69): `SyncCLGL` + `BufferCLGL` for the photon buffer (ref
+ * photontolightvolumeprocessorcl.cpp:184-194) and `VolumeCLGL` for the light volume the raycaster samples, filled by
+ * `enqueueCopyBufferToImage` (ref :404-406).
+ * CDNA GPUs have no image hardware (hipMalloc3DArray: "operation not supported" on gfx950), so a GL texture cannot be
+ * mapped the way VolumeCLGL maps it; GL BUFFER objects can.  The light volume therefore reaches the raycaster's 3-D
+ * texture through a pixel-unpack buffer of the HOST's context: registered once, acquired for the frame's launches --
+ * the texels are written into it on the device -- released, and the host issues glTexSubImage3D from it (a copy inside
+ * the GL driver).  Never through host memory.  The photon buffer can be shared the same way (BufferCLGL).
+ * All calls need the host's OpenGL context current on the calling thread (as Inviwo's processors have it); without one
+ * -- a headless process -- registration returns CPM_ERR_UNSUPPORTED and the caller keeps its own upload path.  The
+ * library does not link OpenGL.  Never run against a live context in this repository's test environment (no display on
+ * the GPU boxes): the device work is tested through cpm_light_volume_texels, the rest by argument / no-context tests. */
+
+typedef struct cpm_gl_resource cpm_gl_resource;
+enum { CPM_GL_TEXEL_F32 = 0, CPM_GL_TEXEL_F16 = 1 };
+
+/* The light volume (n = cells * channels floats) as the texels of the reference's four output formats -- Float32 /
+ * Vec4Float32 as they are, Float16 / Vec4Float16 rounded to nearest even (ref photontolightvolumeprocessorcl.cpp:111-120)
+ * -- into any device buffer (texels_out may be light_volume for CPM_GL_TEXEL_F32: nothing is done). */
+int cpm_light_volume_texels(cpm_ctx* ctx, const float* light_volume, size_t n, int texel /* CPM_GL_TEXEL_* */, void* texels_out,
+                            cpm_stream stream);
+
+/* 1 when the calling thread has a current OpenGL context the library can see, else 0. */
+int cpm_gl_available(cpm_ctx* ctx);
+/* BufferCLGL: a GL buffer object (the photon buffer, or the pixel-unpack buffer behind the light-volume texture). */
+int cpm_gl_register_buffer(cpm_ctx* ctx, unsigned gl_buffer, int read_only, cpm_gl_resource** out);
+/* SyncCLGL: acquire before the first launch that touches the resources, release after the last (stream-ordered). */
+int cpm_gl_acquire(cpm_ctx* ctx, cpm_gl_resource* const* resources, int n, cpm_stream stream);
+int cpm_gl_release(cpm_ctx* ctx, cpm_gl_resource* const* resources, int n, cpm_stream stream);
+/* Device address (and size in bytes) of an acquired buffer: valid until it is released.  A float32 light volume can be
+ * gathered straight into it (pass it as grid_out). */
+int cpm_gl_buffer_pointer(cpm_ctx* ctx, cpm_gl_resource* buffer, void** dev_ptr, size_t* bytes);
+/* enqueueCopyBufferToImage's device half: cpm_light_volume_texels into the acquired buffer (size checked). */
+int cpm_gl_copy_to_buffer(cpm_ctx* ctx, const float* light_volume, size_t n, int texel, cpm_gl_resource* buffer, cpm_stream stream);
+void cpm_gl_unregister(cpm_ctx* ctx, cpm_gl_resource* resource);
+
 #ifdef __cplusplus
 }
 #endif

@@ -52,6 +52,7 @@ def host(cpm, ctx):
                             ("cpmh_tf_lut", None, [C.c_void_p, C.c_void_p]),
                             ("cpmh_enable_refinement", C.c_int, [C.c_void_p, C.c_int]), ("cpmh_refine", C.c_int, [C.c_void_p]),
                             ("cpmh_enable_shard_reduce", C.c_int, [C.c_void_p]), ("cpmh_last_reduce", C.c_char_p, [C.c_void_p]),
+                            ("cpmh_share_light_volume_gl", None, [C.c_void_p, C.c_uint, C.c_int]), ("cpmh_last_gl_copy", C.c_char_p, [C.c_void_p]),
                             ("cpmh_describe_surface", C.c_char_p, [C.c_void_p])]:
         f = getattr(lib, name)
         f.restype, f.argtypes = res, args
@@ -241,6 +242,25 @@ def test_network_shard_reduce_call_site(host, cpm):
     # the reduced volume was refreshed in the touched bricks only; elsewhere it still holds the previous sum -- which is what
     # the partial volume holds there too (atomic +- splats leave untouched voxels alone)
     np.testing.assert_allclose(a, b, rtol=1e-4, atol=2e-5 * float(b.max()))
+    for net in nets:
+        net.close()
+
+
+def test_network_gl_sharing_call_site_without_context(host, cpm):
+    """`glsharing` call site of the light-volume processor on a box without a display: a pixel-unpack buffer named by the host is
+    not registered (no current OpenGL context), the evaluation completes and the outport's device buffer is unaffected."""
+    S = cpm.synthetic
+    vol = S.heterogeneous_volume(64)
+    pos, d = _light(cpm, (0.3, 0.5, -1.0))
+    nets = [Net(host, vol, 128, pos, d, S.WORKSPACE_TF_POINTS) for _ in range(2)]
+    assert host.cpmh_last_gl_copy(nets[0].h) == b"none"
+    host.cpmh_share_light_volume_gl(nets[0].h, 5, 0)
+    for net in nets:
+        net.evaluate(first=True)
+    assert host.cpmh_last_gl_copy(nets[0].h) == b"no context" and host.cpmh_last_gl_copy(nets[1].h) == b"none"
+    a, _, _ = nets[0].light_volume()
+    b, _, _ = nets[1].light_volume()
+    assert np.array_equal(bits(a), bits(b)) and a.max() > 0
     for net in nets:
         net.close()
 
