@@ -31,6 +31,7 @@ ABI_SYMBOLS = [
     "cpm_uniform_samples_2d", "cpm_directional_light_samples", "cpm_point_light_samples",
     "cpm_light_sample_box_intersection", "cpm_light_sample_mesh_intersection",
     "cpm_trace", "cpm_trace_emitted",
+    "cpm_trace_order_create", "cpm_trace_order_destroy", "cpm_trace_set_order", "cpm_trace_order_update",
     "cpm_grid_desc_default", "cpm_relative_irradiance_scale",
     "cpm_splat", "cpm_splat_selected", "cpm_copy_indexed_photons", "cpm_snapshot_selected_photons",
     "cpm_sort_pairs", "cpm_sort_keys", "cpm_bin", "cpm_gather", "cpm_mark_touched_bricks", "cpm_gather_bricks",
@@ -51,6 +52,33 @@ CPM_GL_TEXEL_F32, CPM_GL_TEXEL_F16 = 0, 1
 
 
 CPM_MIX_F32, CPM_MIX_U16X2 = 0, 1
+
+
+class TraceOrder:
+    """The launch order of a trace over n_light_samples samples, fed by the launches' own costs (cpm_trace_order)."""
+
+    def __init__(self, ctx, n_light_samples: int):
+        self.ctx = ctx
+        h = C.c_void_p()
+        ctx._check(ctx.lib.cpm_trace_order_create(ctx.h, int(n_light_samples), C.byref(h)))
+        self.h = h
+        self.n_light_samples = int(n_light_samples)
+
+    def update(self):
+        self.ctx._check(self.ctx.lib.cpm_trace_order_update(self.ctx.h, self.h, self.ctx._stream()))
+
+    def read(self):
+        """(order table, costs gathered since the last update, launches counted) as numpy -- test hook, synchronises."""
+        import numpy as np
+        n = (self.n_light_samples + 255) // 256
+        order, cost = np.zeros(n, np.uint32), np.zeros(n + 1, np.uint32)
+        self.ctx._check(self.ctx.lib.cpm_debug_trace_order_read(self.ctx.h, self.h, order.ctypes.data, cost.ctypes.data))
+        return order, cost[:n], int(cost[n])
+
+    def close(self):
+        if self.h:
+            self.ctx.lib.cpm_trace_order_destroy(self.ctx.h, self.h)
+            self.h = None
 
 
 class GLResource:
@@ -211,6 +239,10 @@ def load_library() -> C.CDLL:
         "cpm_gl_available": (i32, [vp]),
         "cpm_gl_register_buffer": (i32, [vp, u32, i32, P(vp)]),
         "cpm_light_volume_texels": (i32, [vp, vp, sz, i32, vp, vp]),
+        "cpm_trace_order_create": (i32, [vp, i32, P(vp)]),
+        "cpm_trace_order_destroy": (None, [vp, vp]),
+        "cpm_trace_set_order": (i32, [vp, vp, i32]),
+        "cpm_trace_order_update": (i32, [vp, vp, vp]),
         "cpm_gl_acquire": (i32, [vp, P(vp), i32, vp]),
         "cpm_gl_release": (i32, [vp, P(vp), i32, vp]),
         "cpm_gl_buffer_pointer": (i32, [vp, vp, P(vp), P(sz)]),
@@ -219,6 +251,7 @@ def load_library() -> C.CDLL:
         "cpm_volume_device_data": (vp, [vp, P(sz)]),
         "cpm_volume_download": (i32, [vp, vp, vp, vp]),
         # include/cpm/cpm_profile.h (measurement hooks)
+        "cpm_debug_trace_order_read": (i32, [vp, vp, vp, vp]),
         "cpm_debug_set_step_counter": (None, [vp, vp]),
         "cpm_debug_set_gather_stamps": (None, [vp, vp]),
         "cpm_debug_force_voxel_gather": (None, [vp, i32]),
@@ -518,6 +551,13 @@ class Context:
         self._check(self.lib.cpm_allreduce_grid_bricks(self.h, comm.h, self._ptr(partial), self._ptr(total), C.byref(grid),
                                                        self._ptr(brick_mask), C.byref(n_union), self._stream()))
         return int(n_union.value)
+
+    # -- launch order of the trace
+    def trace_order_create(self, n_light_samples: int) -> "TraceOrder":
+        return TraceOrder(self, n_light_samples)
+
+    def trace_set_order(self, order, measure: bool = True):
+        self._check(self.lib.cpm_trace_set_order(self.h, order.h if order is not None else None, int(bool(measure))))
 
     # -- OpenGL sharing (needs the host's GL context current on this thread; CpmError(CPM_ERR_UNSUPPORTED) without one)
     def gl_available(self) -> bool:

@@ -45,6 +45,8 @@ struct cpm_ctx {
         int brick_streaming = 1, select_partition = 1;
         int stream_wg_per_cu = -1;
     } dbg;
+    struct cpm_trace_order* trace_order = nullptr;  // cpm_trace_set_order (not owned)
+    bool trace_order_measure = false;               // ... and whether the launches add their costs to it
     size_t fast_hist_words = 0;  // cpm_bin_fast: size of the histograms whose all-zero state is established (0 = none)
     int fast_hist_parity = 0;    // which of the two (histogram, cursors) pairs the next cpm_bin_fast uses
     const void* fast_last_table = nullptr;  // the last cpm_bin_fast's table and radius: cpm_gather_fast refuses another radius for it
@@ -85,6 +87,14 @@ struct cpm_tf {
     int width = 0;
     float* rgba = nullptr;   // device, width * 4
     float* alpha = nullptr;  // device, width (what the tracer stages into LDS)
+};
+
+// cpm_trace_order_*: the order in which a trace launch's workgroups take the 256-sample chunks, and what the chunks cost
+struct cpm_trace_order {
+    int n_light_samples = 0;
+    uint32_t n_chunks = 0;
+    uint32_t* order = nullptr;  // device, n_chunks: workgroup b takes chunk order[b]
+    uint32_t* cost = nullptr;   // device, n_chunks + 1: per chunk the sum of its waves' longest walks; [n_chunks] = launches counted
 };
 
 namespace cpm {

@@ -30,6 +30,14 @@ namespace {
 // SINGLE: max_interactions == 1 known at compile time -- the scatter branch (phase-function sample, re-encoded direction, slab
 // test) and the sentinel loop leave the instruction stream of the headline configuration; the NO_SINGLE_SCATTERING variant and
 // I > 1 take the general kernel.
+CPM_DEV int default_chunk(int b, unsigned n_chunks) {
+    if (b < (int)(n_chunks & ~127u)) {
+        const int x = b & 7, j = b >> 3;
+        b = ((((j >> 4) << 3) + x) << 4) + (j & 15);
+    }
+    return b;
+}
+
 template <int DT, int EMIT, bool SINGLE = false>
 __global__ __launch_bounds__(256, 8) void trace_kernel(const TraceArgs A) {
     extern __shared__ float lds[];
@@ -48,11 +56,11 @@ __global__ __launch_bounds__(256, 8) void trace_kernel(const TraceArgs A) {
     // the tile the bin's workgroup t (same XCD) reads back.  Measured: 38.4 -> 37.0 us at config 2, 177 -> 159 us at 4 M
     // photons / 512^3, 4-9 % on every transfer function tried (tools/trace_exp.py).  Interleaving tiles, not eighths of the
     // lattice, keeps the XCDs balanced (round 1: contiguous eighths cost 701 -> 971 us on a sparse TF).
+    // With a cpm_trace_order the same assignment of tiles to XCDs comes from its table, in which every XCD's heaviest chunks
+    // of the last launches stand first (cpm_trace_order_update).
     int chunk = blockIdx.x;
-    if (chunk < (int)(gridDim.x & ~127u)) {
-        const int x = chunk & 7, j = chunk >> 3;
-        chunk = ((((j >> 4) << 3) + x) << 4) + (j & 15);
-    }
+    if (A.chunk_order) chunk = (int)A.chunk_order[blockIdx.x];
+    else chunk = default_chunk(chunk, gridDim.x);
     const int gid = chunk * blockDim.x + threadIdx.x;
     int threadId = gid;
     int nThreads = A.n_threads;
@@ -145,6 +153,19 @@ __global__ __launch_bounds__(256, 8) void trace_kernel(const TraceArgs A) {
         encode_direction_(direction, th, ph);
     }
     trace_photon<DT, SINGLE>(A, lut, luts, threadId, l0, l1, ip, rs, direction, th, ph, steps);
+    if (A.chunk_cost) {  // what this chunk cost: the wave's longest walk (cpm_trace_order); lanes past the end have left
+        unsigned m = steps;
+        const unsigned long long alive = __ballot(true);
+        const unsigned lane = threadIdx.x & 63u;
+        for (unsigned off = 32; off > 0; off >>= 1) {
+            const unsigned o = (unsigned)__shfl_xor((int)m, (int)off, 64);
+            if ((alive >> (lane ^ off)) & 1ull) m = max(m, o);
+        }
+        if (lane == 0) {
+            atomicAdd(&A.chunk_cost[chunk], m);
+            if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&A.chunk_cost[gridDim.x], 1u);  // launches counted
+        }
+    }
     if (A.step_counter) {
         // statistics only: wave-level sum, one atomic per wave
         unsigned s = steps;
@@ -261,6 +282,12 @@ int trace_impl(cpm_ctx* ctx, const cpm_volume* vol, const cpm_tf* tf, const cpm_
 
     hipStream_t s = (hipStream_t)stream;
     dim3 grid(div_up(n_threads, 256)), block(256);
+    if (ctx->trace_order && !recompute_indices && !sel.n_dev) {  // a plain launch over all the samples: in the order's order
+        const cpm_trace_order* o = ctx->trace_order;
+        CPM_REQUIRE(ctx, o->n_light_samples == n_threads, "cpm_trace: the trace order set on this context was created for another number of samples");
+        A.chunk_order = o->order;
+        A.chunk_cost = ctx->trace_order_measure ? o->cost : nullptr;
+    }
     int emit = EMIT_NONE;
     if (emitter) {
         emit = emitter->kind == CPM_EMIT_DIRECTIONAL ? EMIT_DIRECTIONAL : EMIT_POINT;
@@ -304,7 +331,166 @@ int trace_impl(cpm_ctx* ctx, const cpm_volume* vol, const cpm_tf* tf, const cpm_
     CPM_LAUNCH_CHECK(ctx, "trace_kernel");
     return CPM_OK;
 }
+
+// cpm_trace_order_update: one workgroup per XCD.  The chunks XCD x works on are, in lattice order, default_chunk(8 j + x);
+// those whose cost is among the XCD's heaviest eighth come first, the others follow, both in lattice order (a stable
+// partition by ballots); chunks past the last full block of 128 keep their place.  Then the costs are cleared.
+constexpr int kOrderThreads = 1024, kOrderBins = 2048;  // (two bins per thread)
+__global__ __launch_bounds__(kOrderThreads) void trace_order_kernel(uint32_t* __restrict__ order, uint32_t* __restrict__ cost, uint32_t n_chunks) {
+    __shared__ uint32_t s_hist[kOrderBins];
+    __shared__ uint32_t s_wave[kOrderThreads / 64];
+    __shared__ uint32_t s_thr, s_shift, s_heavy;
+    const uint32_t t = threadIdx.x, lane = t & 63u, wave = t >> 6, x = blockIdx.x;
+    const uint32_t full = n_chunks & ~127u, mine = full / 8u;  // this XCD's chunks
+    if (cost[n_chunks] == 0u) return;  // nothing measured since the last update (uniform)
+    if (x == 0) for (uint32_t b = full + t; b < n_chunks; b += kOrderThreads) { order[b] = b; }
+    if (mine == 0u) return;
+    // the costs' range -> a shift that brings them under kOrderBins
+    uint32_t mx = 0;
+    for (uint32_t j = t; j < mine; j += kOrderThreads) mx = max(mx, cost[default_chunk((int)(8u * j + x), n_chunks)]);
+    for (int off = 32; off > 0; off >>= 1) mx = max(mx, (uint32_t)__shfl_xor((int)mx, off, 64));
+    if (lane == 0) s_wave[wave] = mx;
+    for (uint32_t i = t; i < kOrderBins; i += kOrderThreads) s_hist[i] = 0u;
+    __syncthreads();
+    if (t == 0) {
+        uint32_t m = 0;
+        for (int w = 0; w < kOrderThreads / 64; ++w) m = max(m, s_wave[w]);
+        uint32_t sh = 0;
+        while ((m >> sh) >= (uint32_t)kOrderBins) ++sh;
+        s_shift = sh;
+    }
+    __syncthreads();
+    const uint32_t sh = s_shift;
+    for (uint32_t j = t; j < mine; j += kOrderThreads) atomicAdd(&s_hist[cost[default_chunk((int)(8u * j + x), n_chunks)] >> sh], 1u);
+    __syncthreads();
+    // bins above `thr` hold at most an eighth of the chunks: those are the heavy ones.  From the top: r = kOrderBins - 1 - bin,
+    // cum(r) = chunks in the bins r' <= r; thread t owns r = 2 t and 2 t + 1; R = how many r have cum(r) <= want (cum is
+    // monotone, so these are the first R), thr = kOrderBins - 1 - R, the heavy ones number cum(R - 1).
+    {
+        const uint32_t want = mine / 8u;
+        if (t == 0) { s_thr = 0u; s_heavy = 0u; }
+        const uint32_t h0 = s_hist[kOrderBins - 1 - 2 * t], h1 = s_hist[kOrderBins - 2 - 2 * t];
+        uint32_t inc = h0 + h1;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t o = (uint32_t)__shfl_up((int)inc, off, 64);
+            if ((int)lane >= off) inc += o;
+        }
+        if (lane == 63) s_wave[wave] = inc;
+        __syncthreads();
+        uint32_t before = 0;
+        for (uint32_t w = 0; w < wave; ++w) before += s_wave[w];
+        const uint32_t c1 = before + inc, c0 = c1 - h1;  // cum(2 t), cum(2 t + 1)
+        uint32_t r_ok = (c0 <= want ? 1u : 0u) + (c1 <= want ? 1u : 0u);
+        if (r_ok) { atomicAdd(&s_thr, r_ok); atomicMax(&s_heavy, r_ok == 2u ? c1 : c0); }
+        __syncthreads();
+        if (t == 0) s_thr = (uint32_t)(kOrderBins - 1) - s_thr;
+        __syncthreads();
+    }
+    const uint32_t thr = s_thr, n_heavy = s_heavy;
+    // stable partition of the XCD's list: heavy chunks to positions [0, n_heavy), the others behind them
+    uint32_t base_h = 0, base_l = n_heavy;
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    for (uint32_t j0 = 0; j0 < mine; j0 += kOrderThreads) {  // (uniform)
+        const uint32_t j = j0 + t;
+        const bool in = j < mine;
+        const uint32_t c = in ? (uint32_t)default_chunk((int)(8u * j + x), n_chunks) : 0u;
+        const bool heavy = in && (cost[c] >> sh) > thr;
+        const unsigned long long mh = __ballot(heavy), ml = __ballot(in && !heavy);
+        __syncthreads();
+        if (lane == 0) s_wave[wave] = (uint32_t)__popcll(mh) | ((uint32_t)__popcll(ml) << 16);
+        __syncthreads();
+        uint32_t bh = 0, bl = 0, th = 0, tl = 0;
+        for (uint32_t w = 0; w < kOrderThreads / 64; ++w) {
+            const uint32_t v = s_wave[w];
+            if (w < wave) { bh += v & 0xffffu; bl += v >> 16; }
+            th += v & 0xffffu; tl += v >> 16;
+        }
+        if (in) {
+            const uint32_t pos = heavy ? base_h + bh + (uint32_t)__popcll(mh & lt) : base_l + bl + (uint32_t)__popcll(ml & lt);
+            order[8u * pos + x] = c;  // the XCD's pos-th workgroup
+        }
+        base_h += th; base_l += tl;
+    }
+}
+
+__global__ __launch_bounds__(256) void trace_order_clear_kernel(uint32_t* __restrict__ cost, uint32_t n) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i < n) cost[i] = 0u;
+}
 }  // namespace
+
+extern "C" {
+
+int cpm_trace_order_create(cpm_ctx* ctx, int n_light_samples, cpm_trace_order** out) {
+    CPM_ENTER(ctx);
+    CPM_REQUIRE(ctx, out, "cpm_trace_order_create: null out");
+    *out = nullptr;
+    CPM_REQUIRE(ctx, n_light_samples > 0, "cpm_trace_order_create: n_light_samples < 1");
+    cpm_trace_order* o = new (std::nothrow) cpm_trace_order();
+    if (!o) return set_error(ctx, CPM_ERR_OUT_OF_MEMORY, "cpm_trace_order_create", "host allocation");
+    o->n_light_samples = n_light_samples;
+    o->n_chunks = (uint32_t)div_up(n_light_samples, 256);
+    std::vector<uint32_t> init(o->n_chunks);
+    const uint32_t full = o->n_chunks & ~127u;
+    for (uint32_t b = 0; b < o->n_chunks; ++b) {
+        uint32_t c = b;
+        if (b < full) { const uint32_t x = b & 7u, j = b >> 3; c = ((((j >> 4) << 3) + x) << 4) + (j & 15u); }
+        init[b] = c;
+    }
+    bool ok = hipMalloc(&o->order, (size_t)o->n_chunks * 4) == hipSuccess && hipMalloc(&o->cost, ((size_t)o->n_chunks + 1) * 4) == hipSuccess &&
+              hipMemcpy(o->order, init.data(), (size_t)o->n_chunks * 4, hipMemcpyHostToDevice) == hipSuccess &&
+              hipMemset(o->cost, 0, ((size_t)o->n_chunks + 1) * 4) == hipSuccess;
+    if (!ok) {
+        if (o->order) (void)hipFree(o->order);
+        if (o->cost) (void)hipFree(o->cost);
+        delete o;
+        return set_error(ctx, CPM_ERR_OUT_OF_MEMORY, "cpm_trace_order_create", "device allocation");
+    }
+    *out = o;
+    return CPM_OK;
+}
+
+void cpm_trace_order_destroy(cpm_ctx* ctx, cpm_trace_order* order) {
+    if (!order) return;
+    if (ctx) {
+        (void)hipSetDevice(ctx->device);
+        if (ctx->trace_order == order) { ctx->trace_order = nullptr; ctx->trace_order_measure = false; }
+    }
+    if (order->order) (void)hipFree(order->order);
+    if (order->cost) (void)hipFree(order->cost);
+    delete order;
+}
+
+int cpm_trace_set_order(cpm_ctx* ctx, cpm_trace_order* order, int measure) {
+    CPM_ENTER(ctx);
+    ctx->trace_order = order;
+    ctx->trace_order_measure = order != nullptr && measure != 0;
+    return CPM_OK;
+}
+
+// test hook (include/cpm/cpm_profile.h): the order table and the costs gathered so far, copied to the host (synchronises)
+int cpm_debug_trace_order_read(cpm_ctx* ctx, const cpm_trace_order* order, uint32_t* order_out, uint32_t* cost_out) {
+    CPM_ENTER(ctx);
+    CPM_REQUIRE(ctx, order, "cpm_debug_trace_order_read: null order");
+    CPM_HIP_CHECK(ctx, hipDeviceSynchronize());
+    if (order_out) CPM_HIP_CHECK(ctx, hipMemcpy(order_out, order->order, (size_t)order->n_chunks * 4, hipMemcpyDeviceToHost));
+    if (cost_out) CPM_HIP_CHECK(ctx, hipMemcpy(cost_out, order->cost, ((size_t)order->n_chunks + 1) * 4, hipMemcpyDeviceToHost));
+    return CPM_OK;
+}
+
+int cpm_trace_order_update(cpm_ctx* ctx, cpm_trace_order* order, cpm_stream stream) {
+    CPM_ENTER(ctx);
+    CPM_REQUIRE(ctx, order && order->order && order->cost, "cpm_trace_order_update: null order");
+    hipStream_t s = (hipStream_t)stream;
+    CPM_LAUNCH(ctx, trace_order_kernel, dim3(8), dim3(kOrderThreads), 0, s, order->order, order->cost, order->n_chunks);
+    CPM_LAUNCH_CHECK(ctx, "trace_order_kernel");
+    CPM_LAUNCH(ctx, trace_order_clear_kernel, dim3(div_up((long long)order->n_chunks + 1, 256)), dim3(256), 0, s, order->cost, order->n_chunks + 1);
+    CPM_LAUNCH_CHECK(ctx, "trace_order_clear_kernel");
+    return CPM_OK;
+}
+
+}  // extern "C"
 
 extern "C" {
 

@@ -304,6 +304,7 @@ void LightSampleMeshIntersectionCL::meshSampleIntersection(const Mesh* mesh, Lig
 PhotonTracerCL::~PhotonTracerCL() {
     auto& rt = CpmRuntime::get();
     if (tf_) cpm_tf_destroy(rt.ctx(), tf_);
+    for (auto& lo : launchOrders_) if (lo.second.order) cpm_trace_order_destroy(rt.ctx(), lo.second.order);
 }
 void PhotonTracerCL::setRandomSeedSize(size_t nPhotons) {
     if (nPhotons > 0) {
@@ -328,6 +329,7 @@ void PhotonTracerCL::syncTF(const TransferFunction& tf) {
     if (!tf_) rt.check(cpm_tf_create(rt.ctx(), lut.data(), 1024, 0, rt.stream(), &tf_), "cpm_tf_create");
     else rt.check(cpm_tf_update(rt.ctx(), tf_, lut.data(), 0, rt.stream()), "cpm_tf_update");
     tfLut_ = std::move(lut);
+    for (auto& lo : launchOrders_) lo.second.sinceMeasured = 0;  // what the launches cost has changed: measure the next one
 }
 void PhotonTracerCL::tracePhotons(const Volume* volume, const TransferFunction& transferFunction, const float aabb[8],
                                   const AdvancedMaterialProperty& material, float stepSize, const LightSamples* lightSamples,
@@ -352,11 +354,36 @@ void PhotonTracerCL::tracePhotons(const Volume* volume, const TransferFunction& 
     p.flags = (onlyMultipleScattering_ ? CPM_TRACE_NO_SINGLE_SCATTERING : 0) | (progressive_ ? CPM_TRACE_PROGRESSIVE : 0);
     p.iteration = photonOutData->iteration();
     p.batch = batch;
+    // a full launch: in the order of this light's measured chunk costs
+    LaunchOrder* lo = nullptr;
+    bool measure = false;
+    if (adaptiveLaunchOrder_ && !photonsToRecomputeIndices && p.n_light_samples > 0) {
+        for (auto& e : launchOrders_) if (e.first == lightSamples) lo = &e.second;
+        if (!lo) { launchOrders_.push_back({ lightSamples, LaunchOrder() }); lo = &launchOrders_.back().second; }
+        if (lo->order && lo->n != p.n_light_samples) { cpm_trace_order_destroy(rt.ctx(), lo->order); lo->order = nullptr; }
+        if (!lo->order) {
+            if (!rt.check(cpm_trace_order_create(rt.ctx(), p.n_light_samples, &lo->order), "cpm_trace_order_create")) lo = nullptr;
+            else { lo->n = p.n_light_samples; lo->sinceMeasured = 0; }
+        }
+        if (lo) {
+            if (lo->volume != (const void*)vol_) { lo->volume = vol_; lo->sinceMeasured = 0; }
+            measure = lo->sinceMeasured == 0 || lo->sinceMeasured >= kMeasureEvery;
+            cpm_trace_set_order(rt.ctx(), lo->order, measure ? 1 : 0);
+        }
+    }
     rt.check(cpm_trace(rt.ctx(), vol_, tf_, nullptr, aabb, &p, reinterpret_cast<const float*>(lightSamples->getLightSamples()->device()),
                        reinterpret_cast<const float*>(lightSamples->getIntersectionPoints()->device()),
                        photonsToRecomputeIndices ? photonsToRecomputeIndices->device() : nullptr, nInvalidPhotons,
                        reinterpret_cast<uint32_t*>(randomState_.device()), reinterpret_cast<float*>(photonOutData->photons_.device()), rt.stream()),
              "cpm_trace");
+    if (lo) {
+        cpm_trace_set_order(rt.ctx(), nullptr, 0);
+        if (measure) {
+            rt.check(cpm_trace_order_update(rt.ctx(), lo->order, rt.stream()), "cpm_trace_order_update");
+            lo->sinceMeasured = 0;
+        }
+        ++lo->sinceMeasured;
+    }
 }
 
 int RecomputedPhotonIndices::resolveCount() {

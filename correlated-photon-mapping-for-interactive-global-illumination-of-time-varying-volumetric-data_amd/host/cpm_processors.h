@@ -339,7 +339,15 @@ public:
     // Bring the device LUT up to date with `tf` (one small launch, no host wait).  Called at the top of the tracer processor's
     // evaluation; tracePhotons* call it too (a no-op then).
     void syncTF(const TransferFunction& tf);
+    // Full launches take their 256-sample chunks in the order of their measured costs (cpm_trace_order_*): per light one
+    // order object; a launch is measured -- and the order re-sorted behind it -- when the light is new, when the transfer
+    // function or the volume changed since the last measured launch, and every kMeasureEvery-th launch otherwise.
+    void setAdaptiveLaunchOrder(bool v) { adaptiveLaunchOrder_ = v; }
+    static constexpr int kMeasureEvery = 256;
 private:
+    struct LaunchOrder { cpm_trace_order* order = nullptr; int n = 0; int sinceMeasured = 0; const void* volume = nullptr; };
+    std::vector<std::pair<const LightSamples*, LaunchOrder>> launchOrders_;
+    bool adaptiveLaunchOrder_ = true;
     Buffer<uvec2> randomState_;
     bool onlyMultipleScattering_ = false, progressive_ = false;
     cpm_tf* tf_ = nullptr;

@@ -257,17 +257,43 @@ class PhotonFrame:
         self.cell_start = torch.empty(self.cells + 1, dtype=torch.int32, device=dev)
         self.sorted = torch.empty((self.n * self.I, 4 if channels == 1 else 8), dtype=f32, device=dev)
         self.light_volume = torch.zeros((self.cells, channels) if channels > 1 else (self.cells,), dtype=f32, device=dev)
+        self.adaptive_order = True   # full traces take their chunks in the order of their measured costs (cpm_trace_order_*)
+        self.trace_order = None
+        self._traces_since_order = 0
         self.brick_table = None   # cpm_bin_fast's table and records (every photon in all the bricks it reaches), allocated on first use
         self.sorted_fast = None
 
     # stages
+    #: every so many full traces one is measured (what each chunk cost) and the order re-sorted from it (cpm_trace_order_update);
+    #: so is the first one, and the first after a change of what is traced (invalidate_trace_order)
+    TRACE_ORDER_EVERY = 256
+
     def trace(self, recompute_indices=None, n_recompute=0):
-        if self.emitter is not None:
-            self.ctx.trace_emitted(self.vol, self.tf, self.aabb, self.params, self.emitter, self.rng, self.photons,
-                                   recompute_indices=recompute_indices, n_recompute=n_recompute)
-        else:
-            self.ctx.trace(self.vol, self.tf, self.aabb, self.params, self.light_samples, self.isect, self.rng, self.photons,
-                           recompute_indices=recompute_indices, n_recompute=n_recompute)
+        full = recompute_indices is None and self.adaptive_order
+        measure = full and (self._traces_since_order == 0 or self._traces_since_order >= self.TRACE_ORDER_EVERY)
+        if full:
+            if self.trace_order is None:
+                self.trace_order = self.ctx.trace_order_create(self.n)
+            self.ctx.trace_set_order(self.trace_order, measure)
+        try:
+            if self.emitter is not None:
+                self.ctx.trace_emitted(self.vol, self.tf, self.aabb, self.params, self.emitter, self.rng, self.photons,
+                                       recompute_indices=recompute_indices, n_recompute=n_recompute)
+            else:
+                self.ctx.trace(self.vol, self.tf, self.aabb, self.params, self.light_samples, self.isect, self.rng, self.photons,
+                               recompute_indices=recompute_indices, n_recompute=n_recompute)
+        finally:
+            if full:
+                self.ctx.trace_set_order(None)
+        if full:
+            if measure:
+                self.trace_order.update()   # one small launch behind the measured trace
+                self._traces_since_order = 0
+            self._traces_since_order += 1
+
+    def invalidate_trace_order(self):
+        """Volume / transfer function / light changed: the next full trace is followed by a re-sort of its chunks."""
+        self._traces_since_order = 0
 
     def bin(self):
         self.ctx.bin(self.photons, self.n * self.I, self.grid, self.order, self.cell_start, self.sorted)
@@ -545,6 +571,7 @@ class CorrelatedPhotonMapper(PhotonFrame):
 
     def set_transfer_function(self, tf_points, width=1024, moved=None):
         """A TF edit: updates the LUT and the importance grid (MinMaxUniformGrid3DImportanceCLProcessor)."""
+        self.invalidate_trace_order()
         pos, col = tf_difference_points(tf_points, self.tf_points)
         self.tf_points = list(tf_points)
         self.tf.update(S.tf_from_points(tf_points, width))
@@ -562,6 +589,7 @@ class CorrelatedPhotonMapper(PhotonFrame):
         beforehand, which is adopted as it is -- the element of a sequence whose device representation already exists
         (Inviwo caches a VolumeCL per sequence element the same way), no copy and no re-layout in the step."""
         ctx, torch = self.ctx, self.torch
+        self.invalidate_trace_order()
         nb = self.importance_grid.numel()
         if getattr(self, "_minmax_next", None) is None:
             self._minmax_next = torch.zeros_like(self.minmax)

@@ -42,6 +42,10 @@ void cpm_debug_set_sort_mode(cpm_ctx* ctx, int mode);
 void cpm_debug_set_sort_items(cpm_ctx* ctx, int items);
 /* streaming kernels (temporal mix): workgroups per CU; 0 = one vector per lane, -1 = by size (default) */
 void cpm_debug_set_stream_wg_per_cu(cpm_ctx* ctx, int n);
+/* test hook: a cpm_trace_order's table (n_chunks = ceil(n_light_samples / 256) entries) and the costs gathered since its last
+ * update (n_chunks + 1 entries, the last one = launches counted); either may be NULL.  Synchronises the device. */
+struct cpm_trace_order;
+int cpm_debug_trace_order_read(cpm_ctx* ctx, const struct cpm_trace_order* order, uint32_t* order_out, uint32_t* cost_out);
 #ifdef __cplusplus
 }
 #endif
