@@ -329,7 +329,7 @@ void PhotonTracerCL::syncTF(const TransferFunction& tf) {
     if (!tf_) rt.check(cpm_tf_create(rt.ctx(), lut.data(), 1024, 0, rt.stream(), &tf_), "cpm_tf_create");
     else rt.check(cpm_tf_update(rt.ctx(), tf_, lut.data(), 0, rt.stream()), "cpm_tf_update");
     tfLut_ = std::move(lut);
-    for (auto& lo : launchOrders_) lo.second.sinceMeasured = 0;  // what the launches cost has changed: measure the next one
+    for (auto& lo : launchOrders_) lo.second.stale = true;  // what the launches cost may have changed
 }
 void PhotonTracerCL::tracePhotons(const Volume* volume, const TransferFunction& transferFunction, const float aabb[8],
                                   const AdvancedMaterialProperty& material, float stepSize, const LightSamples* lightSamples,
@@ -366,8 +366,10 @@ void PhotonTracerCL::tracePhotons(const Volume* volume, const TransferFunction& 
             else { lo->n = p.n_light_samples; lo->sinceMeasured = 0; }
         }
         if (lo) {
-            if (lo->volume != (const void*)vol_) { lo->volume = vol_; lo->sinceMeasured = 0; }
-            measure = lo->sinceMeasured == 0 || lo->sinceMeasured >= kMeasureEvery;
+            if (lo->volume != (const void*)vol_) { lo->volume = vol_; lo->stale = true; }
+            // (a stale order is still a valid order; while the transfer function is being dragged every launch is "stale", and a
+            // measured launch + re-sort costs what ten launches gain)
+            measure = lo->sinceMeasured == 0 || lo->sinceMeasured >= kMeasureEvery || (lo->stale && lo->sinceMeasured >= kMeasureAtLeastApart);
             cpm_trace_set_order(rt.ctx(), lo->order, measure ? 1 : 0);
         }
     }
@@ -381,6 +383,7 @@ void PhotonTracerCL::tracePhotons(const Volume* volume, const TransferFunction& 
         if (measure) {
             rt.check(cpm_trace_order_update(rt.ctx(), lo->order, rt.stream()), "cpm_trace_order_update");
             lo->sinceMeasured = 0;
+            lo->stale = false;
         }
         ++lo->sinceMeasured;
     }
@@ -742,7 +745,12 @@ void ProgressivePhotonTracerCL::onClipChange() {  // progressivephotontracercl.c
 }
 void ProgressivePhotonTracerCL::resetPhotonImportance(size_t offset, size_t n) {  // :607-611
     auto& rt = CpmRuntime::get();
+    const bool whole = offset == 0 && n == photonRecomputationImportance_.getSize();
+    // (a full frame resets every key: nothing to do when no importance pass has touched them since the last such reset --
+    // the case of every frame served without the branch; the reference fills the buffer each time)
+    if (whole && importancesAreReset_) return;
     rt.check(cpm_reset_importance(rt.ctx(), photonRecomputationImportance_.device(), offset, n, rt.stream()), "cpm_reset_importance");
+    if (whole) importancesAreReset_ = true;
 }
 void ProgressivePhotonTracerCL::process() {  // progressivephotontracercl.cpp:219-605
     auto& rt = CpmRuntime::get();
@@ -794,6 +802,7 @@ void ProgressivePhotonTracerCL::process() {  // progressivephotontracercl.cpp:21
     if (!(flag & lightFlag) && recomputationImportanceGrid_.isReady() && photonRecomputationDetector_.isValid()) {
         if (photonRecomputationImportance_.getSize() != photonData_->getNumberOfPhotons()) {
             photonRecomputationImportance_.setSize(photonData_->getNumberOfPhotons());
+            importancesAreReset_ = false;
             resetPhotonImportance(0, photonRecomputationImportance_.getSize());
         }
         if (recomputedPhotonIndices_->indicesToRecomputedPhotons.getSize() != photonData_->getNumberOfPhotons())
@@ -860,6 +869,7 @@ void ProgressivePhotonTracerCL::process() {  // progressivephotontracercl.cpp:21
             photonRecomputationDetector_.setPercentage(equalImportancePercentage_.get() > 0 ? equalImportancePercentage_.get() : (int)maxIncrementalPhotonsToUpdate_.get());
             photonRecomputationDetector_.setIteration(photonRecomputationDetector_.getIteration() + 1);
             rt.check(cpm_selection_begin(rt.ctx(), selection_), "cpm_selection_begin");
+            importancesAreReset_ = false;  // the importance pass below lowers the keys
             const bool oneLaunch = retraceInImportancePass_.get() && !photonRecomputationDetector_.getEqualImportance() &&
                                    !photonTracer_.isProgressive();
             int offset = 0;
@@ -915,6 +925,7 @@ void ProgressivePhotonTracerCL::process() {  // progressivephotontracercl.cpp:21
             photonRecomputationDetector_.setPercentage(equalImportancePercentage_.get() > 0 ? equalImportancePercentage_.get() : (int)maxIncrementalPhotonsToUpdate_.get());
             photonRecomputationDetector_.setIteration(photonRecomputationDetector_.getIteration() + 1);
             int offset = 0;
+            importancesAreReset_ = false;
             for (auto& l : lights) {
                 photonRecomputationDetector_.photonRecomputationImportance(photonData_.get(), offset, volume, grid.get(), *l, photonRecomputationImportance_);
                 offset += (int)l->getSize();

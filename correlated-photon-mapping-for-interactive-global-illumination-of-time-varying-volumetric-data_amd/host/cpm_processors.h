@@ -341,11 +341,12 @@ public:
     void syncTF(const TransferFunction& tf);
     // Full launches take their 256-sample chunks in the order of their measured costs (cpm_trace_order_*): per light one
     // order object; a launch is measured -- and the order re-sorted behind it -- when the light is new, when the transfer
-    // function or the volume changed since the last measured launch, and every kMeasureEvery-th launch otherwise.
+    // function or the volume changed since the last measured launch (but no more often than every kMeasureAtLeastApart-th
+    // launch), and every kMeasureEvery-th launch otherwise.
     void setAdaptiveLaunchOrder(bool v) { adaptiveLaunchOrder_ = v; }
-    static constexpr int kMeasureEvery = 256;
+    static constexpr int kMeasureEvery = 256, kMeasureAtLeastApart = 32;
 private:
-    struct LaunchOrder { cpm_trace_order* order = nullptr; int n = 0; int sinceMeasured = 0; const void* volume = nullptr; };
+    struct LaunchOrder { cpm_trace_order* order = nullptr; int n = 0; int sinceMeasured = 0; bool stale = false; const void* volume = nullptr; };
     std::vector<std::pair<const LightSamples*, LaunchOrder>> launchOrders_;
     bool adaptiveLaunchOrder_ = true;
     Buffer<uvec2> randomState_;
@@ -540,6 +541,7 @@ private:
     std::shared_ptr<RecomputedPhotonIndices> recomputedPhotonIndices_ = std::make_shared<RecomputedPhotonIndices>();
     PhotonRecomputationDetector photonRecomputationDetector_;
     Buffer<unsigned int> photonRecomputationImportance_;
+    bool importancesAreReset_ = false;  // every key is 0x7fffffff (no importance pass since the last whole-buffer reset)
     Buffer<int> nChanged_{ 1 };
     PhotonData::InvalidationReason invalidationFlag_ = PhotonData::InvalidationReason::All;
     float aabb_[8] = { 0, 0, 0, 1, 1, 1, 1, 1 };

@@ -260,6 +260,7 @@ class PhotonFrame:
         self.adaptive_order = True   # full traces take their chunks in the order of their measured costs (cpm_trace_order_*)
         self.trace_order = None
         self._traces_since_order = 0
+        self._order_stale = False
         self.brick_table = None   # cpm_bin_fast's table and records (every photon in all the bricks it reaches), allocated on first use
         self.sorted_fast = None
 
@@ -267,10 +268,12 @@ class PhotonFrame:
     #: every so many full traces one is measured (what each chunk cost) and the order re-sorted from it (cpm_trace_order_update);
     #: so is the first one, and the first after a change of what is traced (invalidate_trace_order)
     TRACE_ORDER_EVERY = 256
+    TRACE_ORDER_AT_LEAST_APART = 32
 
     def trace(self, recompute_indices=None, n_recompute=0):
         full = recompute_indices is None and self.adaptive_order
-        measure = full and (self._traces_since_order == 0 or self._traces_since_order >= self.TRACE_ORDER_EVERY)
+        measure = full and (self._traces_since_order == 0 or self._traces_since_order >= self.TRACE_ORDER_EVERY or
+                            (self._order_stale and self._traces_since_order >= self.TRACE_ORDER_AT_LEAST_APART))
         if full:
             if self.trace_order is None:
                 self.trace_order = self.ctx.trace_order_create(self.n)
@@ -287,13 +290,16 @@ class PhotonFrame:
                 self.ctx.trace_set_order(None)
         if full:
             if measure:
-                self.trace_order.update()   # one small launch behind the measured trace
+                self.trace_order.update()   # two small launches behind the measured trace
                 self._traces_since_order = 0
+                self._order_stale = False
             self._traces_since_order += 1
 
     def invalidate_trace_order(self):
-        """Volume / transfer function / light changed: the next full trace is followed by a re-sort of its chunks."""
-        self._traces_since_order = 0
+        """Volume / transfer function / light changed: a full trace soon is measured and followed by a re-sort of its chunks (a
+        stale order is still a valid order; measuring costs what ten launches gain, so not more often than every
+        TRACE_ORDER_AT_LEAST_APART-th launch)."""
+        self._order_stale = True
 
     def bin(self):
         self.ctx.bin(self.photons, self.n * self.I, self.grid, self.order, self.cell_start, self.sorted)
