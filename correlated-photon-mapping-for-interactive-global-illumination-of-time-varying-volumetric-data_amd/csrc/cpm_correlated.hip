@@ -20,6 +20,14 @@ struct cpm_selection {
     unsigned long long* mailbox = nullptr;      // pinned host memory, written by selection_compact_kernel
     unsigned long long* mailbox_dev = nullptr;  // its device address
     uint32_t n_tiles = 0;             // tiles appended since cpm_selection_begin
+    // cpm_photon_importance_retrace: per launch since cpm_selection_begin (one per light) the order in which its workgroups
+    // take the tiles -- costliest first, from the wall-clock the tiles took in the last MEASURED launch (see kRetraceTile)
+    struct LaunchOrder { uint32_t n_tiles = 0; uint32_t* order = nullptr; uint32_t* cost = nullptr; uint32_t* keys = nullptr; bool fresh = true; /* no order yet */ };
+    std::vector<LaunchOrder> orders;
+    std::vector<uint32_t> pending_orders;  // launches measured in this selection: their orders are re-sorted by cpm_selection_finish
+    uint32_t n_launches = 0;          // retrace launches since cpm_selection_begin
+    uint32_t selections = 0;          // cpm_selection_begin calls
+    bool measuring = false;           // this selection's retrace launches record what their tiles cost
     uint32_t epoch = 0;               // of the last cpm_selection_finish enqueued
     bool finished = false;            // a finish has been enqueued since begin
     hipStream_t last_stream = nullptr;
@@ -521,17 +529,24 @@ __global__ __launch_bounds__(256) void importance_select_kernel(ImpGrid G, const
 // Tile lists -> one ascending list.  Workgroup b = tile b: sums the counts of the tiles before it (<= a few thousand
 // loads, no scan launch), copies its list behind them; workgroup 0 also publishes the total -- the device word the
 // following launches read and the pinned host mailbox (epoch << 32 | count) the host polls instead of synchronising.
+// (A workgroup takes kCompactGroup tiles: with one tile each, 4096 tiles of 256 photons meant 16 M count loads -- 13 us.)
+constexpr uint32_t kCompactGroup = 16;  // tiles per workgroup of selection_compact_kernel
 __global__ __launch_bounds__(256) void selection_compact_kernel(const uint2* __restrict__ tile, uint32_t n_tiles,
                                                                 const uint32_t* __restrict__ local, uint32_t* __restrict__ indices,
                                                                 int32_t* __restrict__ count_dev, unsigned long long* mailbox, uint32_t epoch) {
     __shared__ uint32_t red[2][4];
+    __shared__ uint2 s_t[kCompactGroup];
+    __shared__ uint32_t s_off[kCompactGroup + 1];
     const uint32_t t = threadIdx.x, lane = t & 63u, wave = t >> 6;
+    const uint32_t g0 = blockIdx.x * kCompactGroup;
     uint32_t before = 0, total = 0;
-    for (uint32_t i = t; i < n_tiles; i += 256u) {
+    const uint32_t upto = blockIdx.x == 0 ? n_tiles : g0;  // (only workgroup 0 needs the total)
+    for (uint32_t i = t; i < upto; i += 256u) {
         const uint32_t c = tile[i].x;
         total += c;
-        before += i < blockIdx.x ? c : 0u;
+        before += i < g0 ? c : 0u;
     }
+    if (t < kCompactGroup) s_t[t] = g0 + t < n_tiles ? tile[g0 + t] : make_uint2(0u, 0u);
     for (int off = 32; off > 0; off >>= 1) { before += __shfl_down(before, off, 64); total += __shfl_down(total, off, 64); }
     if (lane == 0) { red[0][wave] = before; red[1][wave] = total; }
     __syncthreads();
@@ -541,8 +556,31 @@ __global__ __launch_bounds__(256) void selection_compact_kernel(const uint2* __r
         *count_dev = (int32_t)total;
         __hip_atomic_store(mailbox, ((unsigned long long)epoch << 32) | (unsigned long long)total, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
-    const uint2 me = tile[blockIdx.x];
-    for (uint32_t k = t; k < me.x; k += 256u) indices[before + k] = local[(size_t)me.y + k];
+    if (t == 0) {
+        uint32_t run = 0;
+        for (uint32_t q = 0; q < kCompactGroup; ++q) { s_off[q] = run; run += s_t[q].x; }
+        s_off[kCompactGroup] = run;
+    }
+    __syncthreads();
+    // the group's entries, flattened: entry e belongs to the tile q with s_off[q] <= e < s_off[q + 1]
+    const uint32_t entries = s_off[kCompactGroup];
+    for (uint32_t e = t; e < entries; e += 256u) {
+        uint32_t q = 0;
+#pragma unroll
+        for (uint32_t k = 1; k < kCompactGroup; ++k) q += s_off[k] <= e ? 1u : 0u;  // (empty tiles repeat an offset: counted past)
+        indices[before + e] = local[(size_t)s_t[q].y + (e - s_off[q])];
+    }
+}
+
+// what a retrace launch's tiles cost -> sort keys (costliest first under an ascending sort), identity values; costs cleared
+constexpr uint32_t kCostBits = 20;
+__global__ __launch_bounds__(256) void retrace_order_keys_kernel(uint32_t* __restrict__ cost, uint32_t* __restrict__ keys, uint32_t* __restrict__ order, uint32_t n) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t top = (1u << kCostBits) - 1u, c = cost[i];
+    keys[i] = top - (c < top ? c : top);
+    order[i] = i;
+    cost[i] = 0u;
 }
 
 // photonRecomputationDetectorEqualImportanceKernel (ref ...detector.cl:160-194)
@@ -652,20 +690,27 @@ __global__ __launch_bounds__(256) void partition_write_kernel(const uint32_t* __
 // the re-trace no longer waits for the compaction, and its launch -- a chain of dependent loads (count, index, sample, old
 // record) for a few thousand photons, 17 us at config 3 -- is gone; the divergent walks (3 steps on average) hide among the
 // importance pass's own waves.
+// Tiles of kRetraceTile = 256 photons -- one per lane -- taken in the order of `order` (costliest first; nullable = tile b
+// to workgroup b).  A tile's cost is its slowest wave's wall-clock: the rays through a transparent pocket walk 30 - 70 cells
+// and are the re-traced photons too, they are lattice neighbours, and the launch used to end with a few such tiles started
+// last (config 3: tiles of 512 in index order 46.2 us; costliest first 39.4 -- the costliest tile alone; tiles of 256 in index
+// order 51 - 52, costliest first 34.1).  The cost is recorded (one atomic per wave) only in the launches the selection measures.
+constexpr uint32_t kRetraceTile = 256;
 template <int DT, bool MASK, bool SINGLE>
 __global__ __launch_bounds__(256) void importance_retrace_kernel(ImpGrid G, const uint32_t* __restrict__ mask, uint32_t mask_words,
                                                                  int fix_exit_point, uint32_t* __restrict__ importances, SelTiles S,
-                                                                 const tracer::TraceArgs A, float* __restrict__ old_sparse) {
+                                                                 const tracer::TraceArgs A, float* __restrict__ old_sparse,
+                                                                 const uint32_t* __restrict__ order, uint32_t* __restrict__ cost) {
     extern __shared__ uint32_t s_dyn[];  // [occupancy bits of the importance grid][TF alpha column(s)]
     uint32_t* s_mask = s_dyn;
     float* lut = reinterpret_cast<float*>(s_dyn + mask_words);
     float* luts = lut;
     __shared__ uint32_t s_wcnt[4];
+    const unsigned long long w0 = cost ? wall_clock64() : 0ull;
     const uint32_t t = threadIdx.x, lane = t & 63u, wave = t >> 6;
-    const int K = (int)(S.per_tile / 256u);
     const int n_light_samples = A.p.n_light_samples, photon_offset = A.p.photon_offset;
-    const int b0 = (int)(blockIdx.x * S.per_tile);
-    const int b1 = min(b0 + (int)S.per_tile, n_light_samples);
+    const uint32_t tile = order ? order[blockIdx.x] : blockIdx.x;
+    const int b0 = (int)(tile * kRetraceTile);
     if (MASK) for (uint32_t i = t; i < mask_words; i += 256u) s_mask[i] = mask[i];
     for (int i = (int)t; i < A.tf_width; i += 256) lut[i] = A.tf_alpha[i];
     if (A.tfs_alpha != A.tf_alpha) {
@@ -674,39 +719,28 @@ __global__ __launch_bounds__(256) void importance_retrace_kernel(ImpGrid G, cons
     }
     __syncthreads();
     // pass 1: importance, threshold, the tile's ascending list
-    uint32_t flags = 0, running = 0;
     const unsigned long long lt = (1ull << lane) - 1ull;
-    uint32_t* list = S.local + (size_t)photon_offset + (size_t)b0;
-    for (int k = 0; k < K; ++k) {  // (uniform)
-        const int threadId = b0 + k * 256 + (int)t;
-        bool changed = false;
-        if (threadId < b1) {
-            const uint32_t u = photon_importance_value<MASK>(G, s_mask, A.photons, photon_offset, A.light_samples, A.isect, A.p.max_interactions,
-                                                             A.p.total_photons, fix_exit_point, threadId);
-            const uint32_t key = importances[photon_offset + threadId] - u;
-            changed = key < 2147483647u;
-        }
-        const unsigned long long mc = __ballot(changed);
-        if (lane == 0) s_wcnt[wave] = (uint32_t)__popcll(mc);
-        __syncthreads();
-        uint32_t before = 0, total = 0;
-#pragma unroll
-        for (int w = 0; w < 4; ++w) { const uint32_t c = s_wcnt[w]; before += w < (int)wave ? c : 0u; total += c; }
-        if (changed) {
-            list[running + before + (uint32_t)__popcll(mc & lt)] = (uint32_t)(photon_offset + threadId);
-            flags |= 1u << k;
-        }
-        running += total;
-        __syncthreads();  // s_wcnt is rewritten by the next chunk
+    const int threadId = b0 + (int)t;
+    bool changed = false;
+    if (threadId < n_light_samples) {
+        const uint32_t u = photon_importance_value<MASK>(G, s_mask, A.photons, photon_offset, A.light_samples, A.isect, A.p.max_interactions,
+                                                         A.p.total_photons, fix_exit_point, threadId);
+        const uint32_t key = importances[photon_offset + threadId] - u;
+        changed = key < 2147483647u;
     }
-    if (t == 0) S.tile[S.tile_first + blockIdx.x] = make_uint2(running, (uint32_t)(photon_offset + b0));
-    // pass 2: the changed photons, re-traced by the lanes that found them
+    const unsigned long long mc = __ballot(changed);
+    if (lane == 0) s_wcnt[wave] = (uint32_t)__popcll(mc);
+    __syncthreads();
+    uint32_t before = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) { const uint32_t c = s_wcnt[w]; before += w < (int)wave ? c : 0u; total += c; }
+    if (t == 0) S.tile[S.tile_first + tile] = make_uint2(total, (uint32_t)(photon_offset + b0));
+    // pass 2: a changed photon is re-traced by the lane that found it
     unsigned steps = 0;
-    const size_t totalPhotons = (size_t)A.p.total_photons;
-    const int nInter = SINGLE ? 1 : A.p.max_interactions;
-    for (int k = 0; k < K; ++k) {
-        if (!(flags & (1u << k))) continue;
-        const int threadId = b0 + k * 256 + (int)t;
+    if (changed) {
+        S.local[(size_t)photon_offset + (size_t)b0 + before + (uint32_t)__popcll(mc & lt)] = (uint32_t)(photon_offset + threadId);
+        const size_t totalPhotons = (size_t)A.p.total_photons;
+        const int nInter = SINGLE ? 1 : A.p.max_interactions;
         for (int it = 0; it < nInter; ++it) {  // the records about to be replaced
             const size_t id = (size_t)photon_offset + (size_t)it * totalPhotons + (size_t)threadId;
             const float4* q = reinterpret_cast<const float4*>(A.photons) + 2 * id;
@@ -724,6 +758,8 @@ __global__ __launch_bounds__(256) void importance_retrace_kernel(ImpGrid G, cons
         tracer::trace_photon<DT, SINGLE>(A, lut, luts, threadId, l0, l1, ip, rs, direction, th, ph, steps);
         importances[photon_offset + threadId] = 2147483647u;  // resetPhotonImportance (tracercl.cpp:529)
     }
+    // (lanes reconverge here; one lane of the wave reports for it)
+    if (cost && lane == 0) atomicMax(&cost[tile], (uint32_t)(wall_clock64() - w0));
     if (A.step_counter) {
         unsigned sN = steps;
         for (int off = 32; off > 0; off >>= 1) sN += __shfl_down(sN, off, 64);
@@ -998,7 +1034,8 @@ int cpm_selection_create(cpm_ctx* ctx, size_t max_photons, cpm_selection** out) 
 #endif
     while (k < 8 && max_photons / (256ull * k) > CPM_SEL_TILES) k *= 2;
     s->per_tile = 256u * k;
-    s->max_tiles = (uint32_t)((max_photons + s->per_tile - 1) / s->per_tile) + 64u;  // + one partial tile per further light
+    // (sized for the smallest tiles in use, cpm_photon_importance_retrace's) + one partial tile per further light
+    s->max_tiles = (uint32_t)((max_photons + kRetraceTile - 1) / kRetraceTile) + 64u;
     bool ok = hipMalloc(&s->tile, (size_t)s->max_tiles * sizeof(uint2)) == hipSuccess &&
               hipMalloc(&s->local, max_photons * sizeof(uint32_t)) == hipSuccess &&
               hipMalloc(&s->count_dev, sizeof(int32_t)) == hipSuccess &&
@@ -1022,6 +1059,11 @@ void cpm_selection_destroy(cpm_ctx* ctx, cpm_selection* s) {
     if (s->tile) (void)hipFree(s->tile);
     if (s->local) (void)hipFree(s->local);
     if (s->count_dev) (void)hipFree(s->count_dev);
+    for (auto& o : s->orders) {
+        if (o.order) (void)hipFree(o.order);
+        if (o.cost) (void)hipFree(o.cost);
+        if (o.keys) (void)hipFree(o.keys);
+    }
     if (s->mask) (void)hipFree(s->mask);
     if (s->mailbox) (void)hipHostFree(s->mailbox);
     delete s;
@@ -1031,7 +1073,13 @@ int cpm_selection_begin(cpm_ctx* ctx, cpm_selection* s) {
     CPM_ENTER(ctx);
     CPM_REQUIRE(ctx, s, "cpm_selection_begin: null selection");
     s->n_tiles = 0;
+    s->n_launches = 0;
+    s->pending_orders.clear();
     s->finished = false;
+    // every kMeasureEvery-th selection records what its retrace tiles cost (the photon paths the cost depends on change slowly)
+    constexpr uint32_t kMeasureEvery = 32;
+    s->measuring = s->selections % kMeasureEvery == 0;
+    ++s->selections;
     return CPM_OK;
 }
 
@@ -1039,10 +1087,12 @@ int cpm_selection_begin(cpm_ctx* ctx, cpm_selection* s) {
 
 namespace {
 // appends the tiles of one light's launch; *first = its first tile
-int selection_append(cpm_ctx* ctx, cpm_selection* s, int photon_offset, int n_light_samples, uint32_t* first, uint32_t* tiles) {
+int selection_append(cpm_ctx* ctx, cpm_selection* s, int photon_offset, int n_light_samples, uint32_t* first, uint32_t* tiles,
+                     uint32_t per_tile = 0) {
+    if (per_tile == 0) per_tile = s->per_tile;
     CPM_REQUIRE(ctx, !s->finished, "cpm_photon_importance_select: call cpm_selection_begin first");
     CPM_REQUIRE(ctx, (size_t)photon_offset + (size_t)n_light_samples <= s->max_photons, "cpm_photon_importance_select: photons exceed the selection's max_photons");
-    *tiles = (uint32_t)div_up(n_light_samples, s->per_tile);
+    *tiles = (uint32_t)div_up(n_light_samples, per_tile);
     CPM_REQUIRE(ctx, s->n_tiles + *tiles <= s->max_tiles, "cpm_photon_importance_select: too many lights for this selection");
     *first = s->n_tiles;
     s->n_tiles += *tiles;
@@ -1157,11 +1207,29 @@ int cpm_photon_importance_retrace(cpm_ctx* ctx, cpm_selection* s, const float* i
     if (!affine_from_matrix(texture_to_index, G.t2i))
         return set_error(ctx, CPM_ERR_UNSUPPORTED, "cpm_photon_importance_retrace", "textureToIndex must be scale + translate");
     uint32_t first = 0, tiles = 0;
-    rc = selection_append(ctx, s, p.photon_offset, p.n_light_samples, &first, &tiles);
+    rc = selection_append(ctx, s, p.photon_offset, p.n_light_samples, &first, &tiles, kRetraceTile);
     if (rc) return rc;
     hipStream_t st = (hipStream_t)stream;
     s->last_stream = st;
-    SelTiles S{ s->tile, s->local, first, s->per_tile };
+    SelTiles S{ s->tile, s->local, first, kRetraceTile };
+    // this launch's tile order (one per light: the launches of a selection come in the same order every time)
+    const uint32_t ordinal = s->n_launches++;
+    if (s->orders.size() <= ordinal) s->orders.resize(ordinal + 1);
+    cpm_selection::LaunchOrder& lo = s->orders[ordinal];
+    if (lo.n_tiles != tiles) {
+        if (lo.order) (void)hipFree(lo.order);
+        if (lo.cost) (void)hipFree(lo.cost);
+        if (lo.keys) (void)hipFree(lo.keys);
+        lo = cpm_selection::LaunchOrder();
+        CPM_HIP_CHECK(ctx, hipMalloc(&lo.order, (size_t)tiles * 4));
+        CPM_HIP_CHECK(ctx, hipMalloc(&lo.cost, (size_t)tiles * 4));
+        CPM_HIP_CHECK(ctx, hipMalloc(&lo.keys, (size_t)tiles * 4));
+        CPM_HIP_CHECK(ctx, hipMemsetAsync(lo.cost, 0, (size_t)tiles * 4, st));
+        lo.n_tiles = tiles;
+        lo.fresh = true;  // no order yet: index order, and this launch is measured whatever the selection's turn
+    }
+    const uint32_t* tile_order = lo.fresh ? nullptr : lo.order;
+    uint32_t* tile_cost = (s->measuring || lo.fresh) ? lo.cost : nullptr;
     A.light_samples = light_samples8;
     A.isect = isect2;
     A.rng = rng_state;
@@ -1184,10 +1252,10 @@ int cpm_photon_importance_retrace(cpm_ctx* ctx, cpm_selection* s, const float* i
     const dim3 grid(tiles), block(256);
 #define CPM_RETRACE_LAUNCH(DT)                                                                                                                   \
     do {                                                                                                                                         \
-        if (use_mask && single) CPM_LAUNCH(ctx, (importance_retrace_kernel<DT, true, true>), grid, block, lds, st, G, s->mask, mw, fix_exit_point, importances, S, A, old_photons8);   \
-        else if (use_mask) CPM_LAUNCH(ctx, (importance_retrace_kernel<DT, true, false>), grid, block, lds, st, G, s->mask, mw, fix_exit_point, importances, S, A, old_photons8);       \
-        else if (single) CPM_LAUNCH(ctx, (importance_retrace_kernel<DT, false, true>), grid, block, lds, st, G, s->mask, mw, fix_exit_point, importances, S, A, old_photons8);        \
-        else CPM_LAUNCH(ctx, (importance_retrace_kernel<DT, false, false>), grid, block, lds, st, G, s->mask, mw, fix_exit_point, importances, S, A, old_photons8);                   \
+        if (use_mask && single) CPM_LAUNCH(ctx, (importance_retrace_kernel<DT, true, true>), grid, block, lds, st, G, s->mask, mw, fix_exit_point, importances, S, A, old_photons8, tile_order, tile_cost);   \
+        else if (use_mask) CPM_LAUNCH(ctx, (importance_retrace_kernel<DT, true, false>), grid, block, lds, st, G, s->mask, mw, fix_exit_point, importances, S, A, old_photons8, tile_order, tile_cost);       \
+        else if (single) CPM_LAUNCH(ctx, (importance_retrace_kernel<DT, false, true>), grid, block, lds, st, G, s->mask, mw, fix_exit_point, importances, S, A, old_photons8, tile_order, tile_cost);        \
+        else CPM_LAUNCH(ctx, (importance_retrace_kernel<DT, false, false>), grid, block, lds, st, G, s->mask, mw, fix_exit_point, importances, S, A, old_photons8, tile_order, tile_cost);                   \
     } while (0)
     switch (vol->desc.dtype) {
         case CPM_U8: CPM_RETRACE_LAUNCH(CPM_U8); break;
@@ -1196,6 +1264,7 @@ int cpm_photon_importance_retrace(cpm_ctx* ctx, cpm_selection* s, const float* i
     }
 #undef CPM_RETRACE_LAUNCH
     CPM_LAUNCH_CHECK(ctx, "importance_retrace_kernel");
+    if (tile_cost) s->pending_orders.push_back(ordinal);  // re-sorted behind the compaction (cpm_selection_finish)
     return CPM_OK;
 }
 
@@ -1230,9 +1299,19 @@ int cpm_selection_finish(cpm_ctx* ctx, cpm_selection* s, uint32_t* indices_out, 
     s->finished = true;
     ++s->epoch;
     // (with no tiles the one workgroup only publishes a count of 0)
-    CPM_LAUNCH(ctx, selection_compact_kernel, dim3(s->n_tiles ? s->n_tiles : 1u), dim3(256), 0, st, s->tile, s->n_tiles, s->local, indices_out,
-               s->count_dev, s->mailbox_dev, s->epoch);
+    CPM_LAUNCH(ctx, selection_compact_kernel, dim3(s->n_tiles ? (unsigned)div_up(s->n_tiles, kCompactGroup) : 1u), dim3(256), 0, st, s->tile, s->n_tiles,
+               s->local, indices_out, s->count_dev, s->mailbox_dev, s->epoch);
     CPM_LAUNCH_CHECK(ctx, "selection_compact_kernel");
+    // the measured launches' tile orders, costliest first -- behind everything the host waits for (a key launch + the radix sort)
+    for (uint32_t ordinal : s->pending_orders) {
+        cpm_selection::LaunchOrder& lo = s->orders[ordinal];
+        CPM_LAUNCH(ctx, retrace_order_keys_kernel, dim3((unsigned)div_up(lo.n_tiles, 256)), dim3(256), 0, st, lo.cost, lo.keys, lo.order, lo.n_tiles);
+        CPM_LAUNCH_CHECK(ctx, "retrace_order_keys_kernel");
+        int rc = cpm_sort_pairs(ctx, lo.keys, lo.order, lo.n_tiles, (int)kCostBits, stream);
+        if (rc) return rc;
+        lo.fresh = false;  // from the next launch on `order` is a permutation of the tiles
+    }
+    s->pending_orders.clear();
     return CPM_OK;
 }
 

@@ -323,3 +323,31 @@ def test_importance_retrace_equals_select_then_trace_selected(ctx, oracle, cpm, 
     np.testing.assert_allclose(_n(lvb), _n(lva), rtol=1e-3, atol=2e-5 * float(lv0.max()))
     assert float((lvb - lv0).abs().max()) > 0
     sel.close()
+
+
+def test_many_updates_cross_the_measured_selections(ctx, cpm):
+    """The one-launch importance + re-trace takes its tiles in the order of their measured costs, re-measured every 32nd
+    selection (cpm_selection_begin): 70 alternating TF edits -- index order, first measured order, two re-measurements -- leave
+    the photons, importances and index lists of a mapper that runs the launch-by-launch branch, bit for bit."""
+    S, P = cpm.synthetic, cpm.pipeline
+    torch = ctx.torch
+    vol = S.heterogeneous_volume(64)
+    base = list(S.WORKSPACE_TF_POINTS)
+    edit = list(base); edit[3] = (0.26,) + base[3][1:]
+    mk = lambda: P.CorrelatedPhotonMapper(ctx, vol, S.workspace_tf(), 300, (32,) * 3, light_travel_direction=(0.3, 0.5, -1.0), tf_points=base)
+    a, b = mk(), mk()
+    b.fused = False
+    for cm in (a, b):
+        cm.incremental_threshold_percent = 100
+        cm.full_frame()
+    for rep in range(70):
+        pts = edit if rep % 2 == 0 else base
+        for cm in (a, b):
+            cm.set_transfer_function(pts)
+        ka, kb = a.correlated_update(), b.correlated_update()
+        assert ka == kb and ka > 0
+        torch.cuda.synchronize()
+        assert torch.equal(a.photons.view(torch.int32), b.photons.view(torch.int32)), f"update {rep}"
+        assert torch.equal(a.importance, b.importance)
+        assert torch.equal(a.indices[:ka], b.indices[:kb])
+    np.testing.assert_allclose(a.light_volume.cpu().numpy(), b.light_volume.cpu().numpy(), rtol=1e-3, atol=2e-5 * float(b.light_volume.max()))
