@@ -8,5 +8,5 @@ NAME=$1; shift
 mkdir -p build/variants
 hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -std=c++17 -fPIC -shared -Wall -Wno-unused-function -ldl "$@" -I include -I $P/csrc \
   -o build/variants/$NAME.so $P/csrc/cpm_core.hip $P/csrc/cpm_rng_emission.hip $P/csrc/cpm_trace.hip $P/csrc/cpm_sort.hip \
-  $P/csrc/cpm_lightvolume.hip $P/csrc/cpm_fastvolume.hip $P/csrc/cpm_correlated.hip $P/csrc/cpm_temporal.hip $P/csrc/cpm_comm.hip
+  $P/csrc/cpm_lightvolume.hip $P/csrc/cpm_fastvolume.hip $P/csrc/cpm_correlated.hip $P/csrc/cpm_temporal.hip $P/csrc/cpm_comm.hip $P/csrc/cpm_gl.hip
 echo built build/variants/$NAME.so
