@@ -359,7 +359,14 @@ void PhotonTracerCL::tracePhotons(const Volume* volume, const TransferFunction& 
     bool measure = false;
     if (adaptiveLaunchOrder_ && !photonsToRecomputeIndices && p.n_light_samples > 0) {
         for (auto& e : launchOrders_) if (e.first == lightSamples) lo = &e.second;
-        if (!lo) { launchOrders_.push_back({ lightSamples, LaunchOrder() }); lo = &launchOrders_.back().second; }
+        if (!lo) {
+            if (launchOrders_.size() >= 16) {  // lights that came and went: start over rather than grow
+                for (auto& e : launchOrders_) if (e.second.order) cpm_trace_order_destroy(rt.ctx(), e.second.order);
+                launchOrders_.clear();
+            }
+            launchOrders_.push_back({ lightSamples, LaunchOrder() });
+            lo = &launchOrders_.back().second;
+        }
         if (lo->order && lo->n != p.n_light_samples) { cpm_trace_order_destroy(rt.ctx(), lo->order); lo->order = nullptr; }
         if (!lo->order) {
             if (!rt.check(cpm_trace_order_create(rt.ctx(), p.n_light_samples, &lo->order), "cpm_trace_order_create")) lo = nullptr;
