@@ -36,11 +36,11 @@ ABI_SYMBOLS = [
     "cpm_splat", "cpm_splat_selected", "cpm_copy_indexed_photons", "cpm_snapshot_selected_photons",
     "cpm_sort_pairs", "cpm_sort_keys", "cpm_bin", "cpm_gather", "cpm_mark_touched_bricks", "cpm_gather_bricks",
     "cpm_fast_table_entries", "cpm_gather_fast_supported", "cpm_fast_record_capacity", "cpm_bin_fast", "cpm_gather_fast",
-    "cpm_volume_minmax", "cpm_volume_difference", "cpm_volume_step", "cpm_importance_tf",
+    "cpm_volume_minmax", "cpm_volume_difference", "cpm_volume_step", "cpm_importance_tf", "cpm_importance_tf_occupancy",
     "cpm_photon_importance", "cpm_photon_importance_equal", "cpm_reset_importance",
     "cpm_select_recompute", "cpm_select_changed",
     "cpm_selection_create", "cpm_selection_destroy", "cpm_selection_begin", "cpm_photon_importance_select",
-    "cpm_photon_importance_equal_select", "cpm_photon_importance_retrace", "cpm_selection_finish", "cpm_selection_count_device", "cpm_selection_count",
+    "cpm_photon_importance_equal_select", "cpm_photon_importance_retrace", "cpm_selection_finish", "cpm_selection_set_occupancy", "cpm_selection_count_device", "cpm_selection_count",
     "cpm_trace_selected", "cpm_splat_delta",
     "cpm_mix_buffers", "cpm_volume_mix",
     "cpm_comm_get_unique_id", "cpm_comm_create", "cpm_comm_create_all", "cpm_comm_destroy", "cpm_comm_rank", "cpm_comm_size",
@@ -207,6 +207,8 @@ def load_library() -> C.CDLL:
         "cpm_volume_difference": (i32, [vp, vp, vp, i32, vp, vp]),
         "cpm_volume_step": (i32, [vp, vp, vp, i32, vp, vp, vp]),
         "cpm_importance_tf": (i32, [vp, vp, vp, vp, i32, vp, vp, i32, vp, vp]),
+        "cpm_importance_tf_occupancy": (i32, [vp, vp, vp, vp, i32, vp, vp, i32, vp, vp, vp]),
+        "cpm_selection_set_occupancy": (i32, [vp, vp, vp, vp]),
         "cpm_photon_importance": (i32, [vp, vp, P(i32 * 3), P(f32 * 3), P(f32 * 16), vp, i32, vp, vp, i32, i32, i32, i32, vp, vp]),
         "cpm_photon_importance_equal": (i32, [vp, i32, i32, i32, i32, vp, vp]),
         "cpm_reset_importance": (i32, [vp, vp, sz, sz, vp]),
@@ -605,13 +607,15 @@ class Context:
     def volume_difference(self, cur, nxt, region, out):
         self._check(self.lib.cpm_volume_difference(self.h, cur.h, nxt.h, region, self._ptr(out), self._stream()))
 
-    def importance_tf(self, minmax, n_cells, positions, colors, out, prev_minmax=None, volume_diff=None):
+    def importance_tf(self, minmax, n_cells, positions, colors, out, prev_minmax=None, volume_diff=None, occupancy=None):
+        """occupancy (optional int32 tensor of 2 * ceil(n_cells / 64) words): the grid's occupancy bits from the same launch."""
         import numpy as np
         positions = np.ascontiguousarray(positions, dtype=np.float32)
         colors = np.ascontiguousarray(colors, dtype=np.float32)
-        self._check(self.lib.cpm_importance_tf(self.h, self._ptr(minmax), self._ptr(prev_minmax), self._ptr(volume_diff),
-                                               n_cells, positions.ctypes.data, colors.ctypes.data, positions.shape[0],
-                                               self._ptr(out), self._stream()))   # (the call has consumed the host arrays on return)
+        self._check(self.lib.cpm_importance_tf_occupancy(self.h, self._ptr(minmax), self._ptr(prev_minmax), self._ptr(volume_diff),
+                                                         n_cells, positions.ctypes.data, colors.ctypes.data, positions.shape[0],
+                                                         self._ptr(out), self._ptr(occupancy),
+                                                         self._stream()))   # (the call has consumed the host arrays on return)
 
     def photon_importance(self, importance_grid, grid_dims, cell_size, texture_to_index, photons, photon_offset,
                           light_samples, isect, n_light_samples, max_interactions, total_photons, importances,
@@ -667,6 +671,11 @@ class Selection:
 
     def begin(self):
         self.ctx._check(self.ctx.lib.cpm_selection_begin(self.ctx.h, self.h))
+
+    def set_occupancy(self, importance_grid, occupancy):
+        """The grid's occupancy bits from Context.importance_tf(..., occupancy=...): this selection's launches over that grid use them."""
+        c = self.ctx
+        c._check(c.lib.cpm_selection_set_occupancy(c.h, self.h, c._ptr(importance_grid), c._ptr(occupancy)))
 
     def photon_importance(self, importance_grid, grid_dims, cell_size, texture_to_index, photons, photon_offset, light_samples, isect,
                           n_light_samples, max_interactions, total_photons, importances, fix_exit_point=False):

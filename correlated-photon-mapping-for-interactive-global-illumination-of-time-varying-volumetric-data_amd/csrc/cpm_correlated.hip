@@ -17,6 +17,8 @@ struct cpm_selection {
     int32_t* count_dev = nullptr;     // device
     uint32_t* mask = nullptr;         // device, grow-only: occupancy bits of the importance grid of the last select call
     size_t mask_words = 0;
+    const uint32_t* given_mask = nullptr;  // cpm_selection_set_occupancy: the caller's bits (cpm_importance_tf_occupancy) ...
+    const float* given_mask_grid = nullptr;  // ... of this importance grid
     unsigned long long* mailbox = nullptr;      // pinned host memory, written by selection_compact_kernel
     unsigned long long* mailbox_dev = nullptr;  // its device address
     uint32_t n_tiles = 0;             // tiles appended since cpm_selection_begin
@@ -251,6 +253,16 @@ CPM_DEV float importance_for_range_tf(float rx, float ry, const float* __restric
     return mx.x + mx.y + mx.z + mx.w;
 }
 
+// One bit per importance-grid cell, set where the cell's importance is anything but +0.0f (what the selection's grid walk
+// tests before it loads a cell): every wave writes its 64 cells' two words.
+CPM_DEV void write_occupancy(uint32_t* __restrict__ bits, uint32_t i, uint32_t n_cells, bool set) {
+    const unsigned long long m = __ballot(set);
+    if ((threadIdx.x & 63u) == 0u && i < ((n_cells + 63u) & ~63u)) {
+        bits[(i >> 5)] = (uint32_t)m;
+        bits[(i >> 5) + 1] = (uint32_t)(m >> 32);
+    }
+}
+
 // The same kernel with the break points handed over as kernel arguments (<= kTfArgPoints of them: a TF has tens) and staged
 // in LDS: no host-to-device copy ahead of the launch, nothing for the caller's arrays to outlive.
 constexpr int kTfArgPoints = 48;
@@ -258,40 +270,48 @@ struct TfPointArgs { float4 col[kTfArgPoints]; float pos[kTfArgPoints]; };
 CPM_DEV float importance_for_range_tf(float rx, float ry, const float* __restrict__ pos, const float4* __restrict__ col, int nPoints);
 __global__ __launch_bounds__(256) void importance_tf_args_kernel(const uint16_t* __restrict__ mm, const uint16_t* __restrict__ prev,
                                                                  const float* __restrict__ diff, int n_cells, const TfPointArgs P,
-                                                                 int n_points, float* __restrict__ out) {
+                                                                 int n_points, float* __restrict__ out, uint32_t* __restrict__ occupancy) {
     __shared__ float4 s_col[kTfArgPoints];
     __shared__ float s_pos[kTfArgPoints];
     if ((int)threadIdx.x < n_points) { s_col[threadIdx.x] = P.col[threadIdx.x]; s_pos[threadIdx.x] = P.pos[threadIdx.x]; }
     __syncthreads();
     int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_cells) return;
-    uint16_t lo = mm[2 * i], hi = mm[2 * i + 1];
-    if (prev) {
-        uint16_t pl = prev[2 * i], ph = prev[2 * i + 1];
-        lo = pl < lo ? pl : lo;
-        hi = ph > hi ? ph : hi;
+    float v = 0.f;
+    if (i < n_cells) {
+        uint16_t lo = mm[2 * i], hi = mm[2 * i + 1];
+        if (prev) {
+            uint16_t pl = prev[2 * i], ph = prev[2 * i + 1];
+            lo = pl < lo ? pl : lo;
+            hi = ph > hi ? ph : hi;
+        }
+        float rx = (1.f / 65535.f) * (float)lo, ry = (1.f / 65535.f) * (float)hi;
+        float imp = importance_for_range_tf(rx, ry, s_pos, s_col, n_points);
+        v = prev ? diff[i] * imp : imp;
+        out[i] = v;
     }
-    float rx = (1.f / 65535.f) * (float)lo, ry = (1.f / 65535.f) * (float)hi;
-    float imp = importance_for_range_tf(rx, ry, s_pos, s_col, n_points);
-    out[i] = prev ? diff[i] * imp : imp;
+    if (occupancy) write_occupancy(occupancy, (uint32_t)i, (uint32_t)n_cells, i < n_cells && __float_as_uint(v) != 0u);
 }
 
 // classifyMinMaxUniformGrid3DImportanceKernel / classifyTimeVarying... (ref ...importance.cl:269-330)
 __global__ __launch_bounds__(256) void importance_tf_kernel(const uint16_t* __restrict__ mm, const uint16_t* __restrict__ prev,
                                                             const float* __restrict__ diff, int n_cells,
                                                             const float* __restrict__ pos, const float4* __restrict__ col,
-                                                            int n_points, float* __restrict__ out) {
+                                                            int n_points, float* __restrict__ out, uint32_t* __restrict__ occupancy) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_cells) return;
-    uint16_t lo = mm[2 * i], hi = mm[2 * i + 1];
-    if (prev) {
-        uint16_t pl = prev[2 * i], ph = prev[2 * i + 1];
-        lo = pl < lo ? pl : lo;
-        hi = ph > hi ? ph : hi;
+    float v = 0.f;
+    if (i < n_cells) {
+        uint16_t lo = mm[2 * i], hi = mm[2 * i + 1];
+        if (prev) {
+            uint16_t pl = prev[2 * i], ph = prev[2 * i + 1];
+            lo = pl < lo ? pl : lo;
+            hi = ph > hi ? ph : hi;
+        }
+        float rx = (1.f / 65535.f) * (float)lo, ry = (1.f / 65535.f) * (float)hi;
+        float imp = importance_for_range_tf(rx, ry, pos, col, n_points);
+        v = prev ? diff[i] * imp : imp;
+        out[i] = v;
     }
-    float rx = (1.f / 65535.f) * (float)lo, ry = (1.f / 65535.f) * (float)hi;
-    float imp = importance_for_range_tf(rx, ry, pos, col, n_points);
-    out[i] = prev ? diff[i] * imp : imp;
+    if (occupancy) write_occupancy(occupancy, (uint32_t)i, (uint32_t)n_cells, i < n_cells && __float_as_uint(v) != 0u);
 }
 
 struct ImpGrid {
@@ -451,12 +471,7 @@ __global__ __launch_bounds__(256) void photon_importance_kernel(ImpGrid G, const
 // one bit per importance-grid cell: set where the cell's importance is anything but +0.0f
 __global__ __launch_bounds__(256) void importance_mask_kernel(const float* __restrict__ grid, uint32_t n_cells, uint32_t* __restrict__ mask) {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-    const bool set = i < n_cells && __float_as_uint(grid[i]) != 0u;
-    const unsigned long long m = __ballot(set);
-    if ((threadIdx.x & 63u) == 0u && i < ((n_cells + 63u) & ~63u)) {
-        mask[(i >> 5)] = (uint32_t)m;
-        mask[(i >> 5) + 1] = (uint32_t)(m >> 32);
-    }
+    write_occupancy(mask, i, n_cells, i < n_cells && __float_as_uint(grid[i]) != 0u);
 }
 
 struct SelTiles {
@@ -879,6 +894,13 @@ int cpm_volume_step(cpm_ctx* ctx, const cpm_volume* cur, const cpm_volume* next,
 int cpm_importance_tf(cpm_ctx* ctx, const uint16_t* minmax2, const uint16_t* prev_minmax2, const float* volume_diff,
                       int n_cells, const float* positions_host, const float* colors4_host, int n_points,
                       float* importance, cpm_stream stream) {
+    return cpm_importance_tf_occupancy(ctx, minmax2, prev_minmax2, volume_diff, n_cells, positions_host, colors4_host, n_points, importance,
+                                       nullptr, stream);
+}
+
+int cpm_importance_tf_occupancy(cpm_ctx* ctx, const uint16_t* minmax2, const uint16_t* prev_minmax2, const float* volume_diff,
+                                int n_cells, const float* positions_host, const float* colors4_host, int n_points,
+                                float* importance, uint32_t* occupancy, cpm_stream stream) {
     CPM_ENTER(ctx);
     CPM_REQUIRE(ctx, n_cells >= 0, "cpm_importance_tf: n_cells < 0");
     CPM_REQUIRE(ctx, n_points >= 2 && n_points <= 4096, "cpm_importance_tf: n_points must be in [2, 4096]");
@@ -893,7 +915,7 @@ int cpm_importance_tf(cpm_ctx* ctx, const uint16_t* minmax2, const uint16_t* pre
         memcpy(P.col, colors4_host, (size_t)n_points * 4 * sizeof(float));
         memcpy(P.pos, positions_host, (size_t)n_points * sizeof(float));
         CPM_LAUNCH(ctx, importance_tf_args_kernel, dim3(div_up(n_cells, 256)), dim3(256), 0, s, minmax2, prev_minmax2, volume_diff, n_cells, P,
-                   n_points, importance);
+                   n_points, importance, occupancy);
         CPM_LAUNCH_CHECK(ctx, "importance_tf_args_kernel");
         return CPM_OK;
     }
@@ -903,7 +925,7 @@ int cpm_importance_tf(cpm_ctx* ctx, const uint16_t* minmax2, const uint16_t* pre
     CPM_HIP_CHECK(ctx, hipMemcpyAsync(dev, colors4_host, (size_t)n_points * 4 * sizeof(float), hipMemcpyHostToDevice, s));
     CPM_HIP_CHECK(ctx, hipMemcpyAsync(dev + (size_t)n_points * 4, positions_host, (size_t)n_points * sizeof(float), hipMemcpyHostToDevice, s));
     CPM_LAUNCH(ctx, importance_tf_kernel, dim3(div_up(n_cells, 256)), dim3(256), 0, s, minmax2, prev_minmax2, volume_diff,
-                       n_cells, dev + (size_t)n_points * 4, reinterpret_cast<const float4*>(dev), n_points, importance);
+                       n_cells, dev + (size_t)n_points * 4, reinterpret_cast<const float4*>(dev), n_points, importance, occupancy);
     CPM_LAUNCH_CHECK(ctx, "importance_tf_kernel");
     CPM_HIP_CHECK(ctx, hipStreamSynchronize(s));  // the caller's host arrays are consumed when this returns
     return CPM_OK;
@@ -1069,6 +1091,15 @@ void cpm_selection_destroy(cpm_ctx* ctx, cpm_selection* s) {
     delete s;
 }
 
+int cpm_selection_set_occupancy(cpm_ctx* ctx, cpm_selection* s, const float* importance_grid, const uint32_t* occupancy) {
+    CPM_ENTER(ctx);
+    CPM_REQUIRE(ctx, s, "cpm_selection_set_occupancy: null selection");
+    CPM_REQUIRE(ctx, (importance_grid != nullptr) == (occupancy != nullptr), "cpm_selection_set_occupancy: grid and bits go together");
+    s->given_mask = occupancy;
+    s->given_mask_grid = importance_grid;
+    return CPM_OK;
+}
+
 int cpm_selection_begin(cpm_ctx* ctx, cpm_selection* s) {
     CPM_ENTER(ctx);
     CPM_REQUIRE(ctx, s, "cpm_selection_begin: null selection");
@@ -1099,13 +1130,28 @@ int selection_append(cpm_ctx* ctx, cpm_selection* s, int photon_offset, int n_li
     return CPM_OK;
 }
 
+// the occupancy bits a select / retrace launch stages in LDS: the caller's (cpm_selection_set_occupancy: made by the launch
+// that made the grid) or, failing that, built here by one small launch
+int selection_mask(cpm_ctx* ctx, cpm_selection* s, const float* importance_grid, long long cells, size_t words, hipStream_t st, const uint32_t** mask_out) {
+    if (s->given_mask && s->given_mask_grid == importance_grid) { *mask_out = s->given_mask; return CPM_OK; }
+    if (s->mask_words < words) {
+        if (s->mask) { CPM_HIP_CHECK(ctx, hipStreamSynchronize(st)); (void)hipFree(s->mask); s->mask = nullptr; s->mask_words = 0; }
+        CPM_HIP_CHECK(ctx, hipMalloc(&s->mask, words * 4));
+        s->mask_words = words;
+    }
+    CPM_LAUNCH(ctx, importance_mask_kernel, dim3(div_up(cells, 256)), dim3(256), 0, st, importance_grid, (uint32_t)cells, s->mask);
+    CPM_LAUNCH_CHECK(ctx, "importance_mask_kernel");
+    *mask_out = s->mask;
+    return CPM_OK;
+}
+
 template <int MODE, bool MASK>
-void launch_select(cpm_ctx* ctx, cpm_selection* s, hipStream_t st, uint32_t tiles, size_t lds, const ImpGrid& G, uint32_t mask_words,
+void launch_select(cpm_ctx* ctx, cpm_selection* s, hipStream_t st, uint32_t tiles, size_t lds, const ImpGrid& G, const uint32_t* mask_bits, uint32_t mask_words,
                    const float* photons8, int photon_offset, const float* ls, const float* isect, int n_light_samples, int max_interactions,
                    int total_photons, int fix_exit_point, int pct, int iter, uint32_t* importances, const SelTiles& S) {
     const dim3 grid(tiles), block(256);
 #define CPM_SEL_LAUNCH(KK)                                                                                                             \
-    CPM_LAUNCH(ctx, (importance_select_kernel<MODE, MASK, KK>), grid, block, lds, st, G, s->mask, mask_words, photons8, photon_offset, ls, isect, \
+    CPM_LAUNCH(ctx, (importance_select_kernel<MODE, MASK, KK>), grid, block, lds, st, G, mask_bits, mask_words, photons8, photon_offset, ls, isect, \
                n_light_samples, max_interactions, total_photons, fix_exit_point, pct, iter, importances, S)
     switch (s->per_tile / 256u) {
         case 1: CPM_SEL_LAUNCH(1); break;
@@ -1155,17 +1201,13 @@ int cpm_photon_importance_select(cpm_ctx* ctx, cpm_selection* s, const float* im
     const size_t words = (size_t)((cells + 63) / 64) * 2;
     const bool use_mask = words * 4 <= 64 * 1024;
     if (use_mask) {
-        if (s->mask_words < words) {
-            if (s->mask) { CPM_HIP_CHECK(ctx, hipStreamSynchronize(st)); (void)hipFree(s->mask); s->mask = nullptr; s->mask_words = 0; }
-            CPM_HIP_CHECK(ctx, hipMalloc(&s->mask, words * 4));
-            s->mask_words = words;
-        }
-        CPM_LAUNCH(ctx, importance_mask_kernel, dim3(div_up((long long)cells, 256)), dim3(256), 0, st, importance_grid, (uint32_t)cells, s->mask);
-        CPM_LAUNCH_CHECK(ctx, "importance_mask_kernel");
-        launch_select<0, true>(ctx, s, st, tiles, words * 4, G, (uint32_t)words, photons8, photon_offset, light_samples8, isect2, n_light_samples,
+        const uint32_t* mask_bits = nullptr;
+        rc = selection_mask(ctx, s, importance_grid, (long long)cells, words, st, &mask_bits);
+        if (rc) return rc;
+        launch_select<0, true>(ctx, s, st, tiles, words * 4, G, mask_bits, (uint32_t)words, photons8, photon_offset, light_samples8, isect2, n_light_samples,
                                max_interactions, total_photons, fix_exit_point, 1, 0, importances, S);
     } else {
-        launch_select<0, false>(ctx, s, st, tiles, 0, G, 0u, photons8, photon_offset, light_samples8, isect2, n_light_samples, max_interactions,
+        launch_select<0, false>(ctx, s, st, tiles, 0, G, nullptr, 0u, photons8, photon_offset, light_samples8, isect2, n_light_samples, max_interactions,
                                 total_photons, fix_exit_point, 1, 0, importances, S);
     }
     CPM_LAUNCH_CHECK(ctx, "importance_select_kernel");
@@ -1237,14 +1279,10 @@ int cpm_photon_importance_retrace(cpm_ctx* ctx, cpm_selection* s, const float* i
     A.n_threads = p.n_light_samples;
     const size_t words = (size_t)((cells + 63) / 64) * 2;
     const bool use_mask = words * 4 <= 64 * 1024;
+    const uint32_t* mask_bits = nullptr;
     if (use_mask) {
-        if (s->mask_words < words) {
-            if (s->mask) { CPM_HIP_CHECK(ctx, hipStreamSynchronize(st)); (void)hipFree(s->mask); s->mask = nullptr; s->mask_words = 0; }
-            CPM_HIP_CHECK(ctx, hipMalloc(&s->mask, words * 4));
-            s->mask_words = words;
-        }
-        CPM_LAUNCH(ctx, importance_mask_kernel, dim3(div_up((long long)cells, 256)), dim3(256), 0, st, importance_grid, (uint32_t)cells, s->mask);
-        CPM_LAUNCH_CHECK(ctx, "importance_mask_kernel");
+        rc = selection_mask(ctx, s, importance_grid, (long long)cells, words, st, &mask_bits);
+        if (rc) return rc;
     }
     const uint32_t mw = use_mask ? (uint32_t)words : 0u;
     const size_t lds = (size_t)mw * 4 + lut_bytes;
@@ -1252,10 +1290,10 @@ int cpm_photon_importance_retrace(cpm_ctx* ctx, cpm_selection* s, const float* i
     const dim3 grid(tiles), block(256);
 #define CPM_RETRACE_LAUNCH(DT)                                                                                                                   \
     do {                                                                                                                                         \
-        if (use_mask && single) CPM_LAUNCH(ctx, (importance_retrace_kernel<DT, true, true>), grid, block, lds, st, G, s->mask, mw, fix_exit_point, importances, S, A, old_photons8, tile_order, tile_cost);   \
-        else if (use_mask) CPM_LAUNCH(ctx, (importance_retrace_kernel<DT, true, false>), grid, block, lds, st, G, s->mask, mw, fix_exit_point, importances, S, A, old_photons8, tile_order, tile_cost);       \
-        else if (single) CPM_LAUNCH(ctx, (importance_retrace_kernel<DT, false, true>), grid, block, lds, st, G, s->mask, mw, fix_exit_point, importances, S, A, old_photons8, tile_order, tile_cost);        \
-        else CPM_LAUNCH(ctx, (importance_retrace_kernel<DT, false, false>), grid, block, lds, st, G, s->mask, mw, fix_exit_point, importances, S, A, old_photons8, tile_order, tile_cost);                   \
+        if (use_mask && single) CPM_LAUNCH(ctx, (importance_retrace_kernel<DT, true, true>), grid, block, lds, st, G, mask_bits, mw, fix_exit_point, importances, S, A, old_photons8, tile_order, tile_cost);   \
+        else if (use_mask) CPM_LAUNCH(ctx, (importance_retrace_kernel<DT, true, false>), grid, block, lds, st, G, mask_bits, mw, fix_exit_point, importances, S, A, old_photons8, tile_order, tile_cost);       \
+        else if (single) CPM_LAUNCH(ctx, (importance_retrace_kernel<DT, false, true>), grid, block, lds, st, G, mask_bits, mw, fix_exit_point, importances, S, A, old_photons8, tile_order, tile_cost);        \
+        else CPM_LAUNCH(ctx, (importance_retrace_kernel<DT, false, false>), grid, block, lds, st, G, mask_bits, mw, fix_exit_point, importances, S, A, old_photons8, tile_order, tile_cost);                   \
     } while (0)
     switch (vol->desc.dtype) {
         case CPM_U8: CPM_RETRACE_LAUNCH(CPM_U8); break;
@@ -1283,7 +1321,7 @@ int cpm_photon_importance_equal_select(cpm_ctx* ctx, cpm_selection* s, int photo
     s->last_stream = st;
     SelTiles S{ s->tile, s->local, first, s->per_tile };
     ImpGrid G = {};
-    launch_select<1, false>(ctx, s, st, tiles, 0, G, 0u, nullptr, photon_offset, nullptr, nullptr, n_light_samples, 1, 0, 0, percentage, iteration,
+    launch_select<1, false>(ctx, s, st, tiles, 0, G, nullptr, 0u, nullptr, photon_offset, nullptr, nullptr, n_light_samples, 1, 0, 0, percentage, iteration,
                             importances, S);
     CPM_LAUNCH_CHECK(ctx, "importance_select_kernel");
     return CPM_OK;

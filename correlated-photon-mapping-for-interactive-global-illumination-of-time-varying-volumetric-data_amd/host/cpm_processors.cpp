@@ -462,6 +462,9 @@ void PhotonTracerCL::importanceRetrace(cpm_selection* selection, const Volume* v
     cpm_volume_desc d;
     const int32_t vdims[3] = { (int32_t)vd.x, (int32_t)vd.y, (int32_t)vd.z };
     cpm_volume_desc_default(&d, vdims, volume->dtype());
+    // (the grid's occupancy bits came with the grid: no launch of the selection's own for them)
+    cpm_selection_set_occupancy(rt.ctx(), selection, grid->occupancyValid ? grid->data.device() : nullptr,
+                                grid->occupancyValid ? grid->occupancy.device() : nullptr);
     rt.check(cpm_photon_importance_retrace(rt.ctx(), selection, grid->data.device(), dims, cell, d.texture_to_index, vol_, tf_, nullptr, aabb, &p,
                                            reinterpret_cast<const float*>(lightSamples->getLightSamples()->device()),
                                            reinterpret_cast<const float*>(lightSamples->getIntersectionPoints()->device()), fixExitPoint ? 1 : 0,
@@ -488,6 +491,8 @@ void PhotonRecomputationDetector::photonRecomputationImportanceSelect(cpm_select
     cpm_volume_desc d;
     const int32_t vdims[3] = { (int32_t)vd.x, (int32_t)vd.y, (int32_t)vd.z };
     cpm_volume_desc_default(&d, vdims, origVolume->dtype());
+    cpm_selection_set_occupancy(rt.ctx(), selection, grid->occupancyValid ? grid->data.device() : nullptr,
+                                grid->occupancyValid ? grid->occupancy.device() : nullptr);
     rt.check(cpm_photon_importance_select(rt.ctx(), selection, grid->data.device(), dims, cell, d.texture_to_index,
                                           reinterpret_cast<const float*>(photonData->photons_.device()), photonOffset,
                                           reinterpret_cast<const float*>(lightSamples.getLightSamples()->device()),
@@ -699,19 +704,25 @@ void MinMaxUniformGrid3DImportanceCLProcessor::process() {  // minmaxuniformgrid
         updateTransferFunctionData();
     }
     const int nElements = (int)(d.x * d.y * d.z);
+    importance_->occupancy.setSize(2 * (((size_t)nElements + 63) / 64));
+    importance_->occupancyValid = false;
     if (volumeDifferenceInfoInport_.isReady() && prevMinMaxUniformGrid3D_ != nullptr && prevMinMaxUniformGrid3D_.get() != minMax.get()) {
         // time-varying data changed (:149-190): importance x mean |v_(t+1) - v_t| over the union of the old and new brick ranges
         auto diff = std::dynamic_pointer_cast<DynamicVolumeInfoUniformGrid3D>(volumeDifferenceInfoInport_.getData());
         if (!diff) { LogError("volumeDifferenceInfoInport_ expects DynamicVolumeInfoUniformGrid3D as input"); return; }
         if (!diff->hasDeviceData()) diff->uploadHostData();
         auto* prev = const_cast<MinMaxUniformGrid3D*>(prevMinMaxUniformGrid3D_.get());
-        rt.check(cpm_importance_tf(rt.ctx(), minMax->data.device(), prev->data.device(), diff->data.device(), nElements, positions_.data(),
-                                   reinterpret_cast<const float*>(colors_.data()), (int)positions_.size(), importance_->data.device(), rt.stream()),
-                 "cpm_importance_tf(time-varying)");
+        importance_->occupancyValid =
+            rt.check(cpm_importance_tf_occupancy(rt.ctx(), minMax->data.device(), prev->data.device(), diff->data.device(), nElements, positions_.data(),
+                                                 reinterpret_cast<const float*>(colors_.data()), (int)positions_.size(), importance_->data.device(),
+                                                 importance_->occupancy.device(), rt.stream()),
+                     "cpm_importance_tf(time-varying)");
     } else {
-        rt.check(cpm_importance_tf(rt.ctx(), minMax->data.device(), nullptr, nullptr, nElements, positions_.data(), reinterpret_cast<const float*>(colors_.data()),
-                                   (int)positions_.size(), importance_->data.device(), rt.stream()),
-                 "cpm_importance_tf");
+        importance_->occupancyValid =
+            rt.check(cpm_importance_tf_occupancy(rt.ctx(), minMax->data.device(), nullptr, nullptr, nElements, positions_.data(),
+                                                 reinterpret_cast<const float*>(colors_.data()), (int)positions_.size(), importance_->data.device(),
+                                                 importance_->occupancy.device(), rt.stream()),
+                     "cpm_importance_tf");
     }
     prevMinMaxUniformGrid3D_ = minMax;  // :212-213
     importanceUniformGrid3DOutport_.setData(importance_);

@@ -215,6 +215,11 @@ struct MinMaxUniformGrid3D : UniformGrid3DTyped<MinMaxUniformGrid3D, uint16_t, 2
 struct ImportanceUniformGrid3D : UniformGrid3DTyped<ImportanceUniformGrid3D, float, 1> {
     const char* getDataFormatString() const override { return "FLOAT32"; }
     int mixType() const override { return CPM_MIX_F32; }
+    // one bit per cell, set where the importance is not +0: written by the launch that wrote `data`
+    // (cpm_importance_tf_occupancy) and handed to the tracer's selection, which otherwise makes the bits itself.  Only valid
+    // while occupancyFor == data.device() contents' last writer -- the importance processor sets and clears it.
+    Buffer<uint32_t> occupancy;
+    bool occupancyValid = false;
 };
 struct DynamicVolumeInfoUniformGrid3D : UniformGrid3DTyped<DynamicVolumeInfoUniformGrid3D, float, 1> {
     const char* getDataFormatString() const override { return "FLOAT32"; }

@@ -575,6 +575,13 @@ class CorrelatedPhotonMapper(PhotonFrame):
             self.bin()
             self.gather()
 
+    def _occupancy(self):
+        """The importance grid's occupancy bits, written by the launch that writes the grid and handed to the selection."""
+        if getattr(self, "_occupancy_bits", None) is None:
+            nb = self.importance_grid.numel()
+            self._occupancy_bits = self.torch.zeros(2 * ((nb + 63) // 64), dtype=self.torch.int32, device=self.ctx.device)
+        return self._occupancy_bits
+
     def set_transfer_function(self, tf_points, width=1024, moved=None):
         """A TF edit: updates the LUT and the importance grid (MinMaxUniformGrid3DImportanceCLProcessor)."""
         self.invalidate_trace_order()
@@ -582,7 +589,7 @@ class CorrelatedPhotonMapper(PhotonFrame):
         self.tf_points = list(tf_points)
         self.tf.update(S.tf_from_points(tf_points, width))
         nb = self.importance_grid.numel()
-        self.ctx.importance_tf(self.minmax, nb, pos, col, self.importance_grid)
+        self.ctx.importance_tf(self.minmax, nb, pos, col, self.importance_grid, occupancy=self._occupancy())
         return pos, col
 
     def set_volume(self, voxels):
@@ -622,7 +629,7 @@ class CorrelatedPhotonMapper(PhotonFrame):
         if pos[-1] < 1.0:
             pos.append(1.0); col.append(col[-1])
         ctx.importance_tf(self._minmax_next, nb, np.asarray(pos, np.float32), np.asarray(col, np.float32), self.importance_grid,
-                          prev_minmax=self.minmax, volume_diff=self._diff)
+                          prev_minmax=self.minmax, volume_diff=self._diff, occupancy=self._occupancy())
         # swap in; the volume swapped out is reused for the next raw-voxel step only if this mapper created it
         previous, previous_is_own = self.vol, self._vol_is_own
         self.vol, self._vol_is_own = nxt, not adopted
@@ -646,6 +653,8 @@ class CorrelatedPhotonMapper(PhotonFrame):
             self.old_photons = torch.empty((self.I * n_total, 8), dtype=torch.float32, device=ctx.device)
         sel = self.selection
         sel.begin()
+        if getattr(self, "_occupancy_bits", None) is not None:   # (the bits of the grid's last importance_tf launch)
+            sel.set_occupancy(self.importance_grid, self._occupancy_bits)
         self.params.flags = 0                            # correlated: RNG state is NOT written back
         if self.retrace_in_importance_pass:
             # detector + threshold + tracer in one launch; the replaced records stay at the photons' own indices

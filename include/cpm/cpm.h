@@ -430,6 +430,14 @@ int cpm_importance_tf(cpm_ctx* ctx, const uint16_t* minmax2, const uint16_t* pre
                       const float* volume_diff, int n_cells, const float* positions_host,
                       const float* colors4_host, int n_points, float* importance,
                       cpm_stream stream);
+/* The same, and in the same launch the grid's occupancy bits: occupancy[(c >> 5)] bit (c & 31) set where importance[c] is
+ * anything but +0.0f; 2 * ceil(n_cells / 64) u32 words (whole 64-cell groups are written).  What the selection's grid walk
+ * tests before it loads a cell (cpm_selection_set_occupancy) -- otherwise the selection builds the bits with a launch of its
+ * own.  occupancy may be NULL (= cpm_importance_tf). */
+int cpm_importance_tf_occupancy(cpm_ctx* ctx, const uint16_t* minmax2, const uint16_t* prev_minmax2,
+                                const float* volume_diff, int n_cells, const float* positions_host,
+                                const float* colors4_host, int n_points, float* importance,
+                                uint32_t* occupancy, cpm_stream stream);
 
 /* importances[photon_offset + i] -= min(0x7fffffff, sat_rtp_u32(100 * sum over the
  * stored poly-line of photon i of cellImportance * dt * |x2 - x1|)).
@@ -543,6 +551,11 @@ int cpm_photon_importance_equal_select(cpm_ctx* ctx, cpm_selection* sel, int pho
 /* indices_out[0 .. count) = the selected photons of all lights, ascending (what cpm_select_changed leaves in the first
  * part of its list; the rest of indices_out is not written); count -> cpm_selection_count_device and the mailbox. */
 int cpm_selection_finish(cpm_ctx* ctx, cpm_selection* sel, uint32_t* indices_out, cpm_stream stream);
+/* The occupancy bits of `importance_grid` as cpm_importance_tf_occupancy left them: the select / retrace launches of this
+ * selection over exactly that grid pointer use them instead of making their own (one launch less per light).  The caller
+ * keeps bits and grid in step (the bits of the grid's LAST cpm_importance_tf_occupancy); both NULL = off.  Sticks until
+ * changed. */
+int cpm_selection_set_occupancy(cpm_ctx* ctx, cpm_selection* sel, const float* importance_grid, const uint32_t* occupancy);
 const int32_t* cpm_selection_count_device(const cpm_selection* sel);
 /* The count of the last cpm_selection_finish on the host: waits for the mailbox write of THAT launch (a poll of pinned
  * memory; later work in the stream keeps running), not for the stream.  Replaces the blocking wait on the reduce's

@@ -351,3 +351,32 @@ def test_many_updates_cross_the_measured_selections(ctx, cpm):
         assert torch.equal(a.importance, b.importance)
         assert torch.equal(a.indices[:ka], b.indices[:kb])
     np.testing.assert_allclose(a.light_volume.cpu().numpy(), b.light_volume.cpu().numpy(), rtol=1e-3, atol=2e-5 * float(b.light_volume.max()))
+
+
+@pytest.mark.parametrize("n_cells", [1, 63, 64, 65, 4096, 32768 + 17])
+def test_importance_tf_occupancy_bits(ctx, cpm, n_cells):
+    """cpm_importance_tf_occupancy: the same importances as cpm_importance_tf, and bit c of the occupancy words set exactly
+    where importance[c] is not +0.0f (what the selection's own mask launch computes); whole 64-cell groups are written."""
+    torch = ctx.torch
+    S = cpm.synthetic
+    rng = np.random.default_rng(n_cells)
+    lo = rng.integers(0, 65535, n_cells).astype(np.uint16)
+    hi = np.maximum(lo, rng.integers(0, 65535, n_cells).astype(np.uint16))
+    mm = torch.from_numpy(np.stack([lo, hi], 1).copy().view(np.int16)).to(ctx.device)
+    pos = np.array([0.0, 0.2, 0.3, 0.6, 1.0], np.float32)
+    col = np.zeros((5, 4), np.float32)
+    col[2] = (0.5, 0.1, 0.0, 0.25)   # the difference TF is non-zero only around 0.3: many cells get exactly +0
+    want = torch.zeros(n_cells, dtype=torch.float32, device=ctx.device)
+    ctx.importance_tf(mm, n_cells, pos, col, want)
+    got = torch.full((n_cells,), -1.0, dtype=torch.float32, device=ctx.device)
+    words = 2 * ((n_cells + 63) // 64)
+    occ = torch.full((words,), -1, dtype=torch.int32, device=ctx.device)
+    ctx.importance_tf(mm, n_cells, pos, col, got, occupancy=occ)
+    torch.cuda.synchronize()
+    assert torch.equal(got.view(torch.int32), want.view(torch.int32))
+    w = want.cpu().numpy()
+    assert (w.view(np.uint32) == 0).any() or n_cells < 64
+    bits_ = np.unpackbits(occ.cpu().numpy().view(np.uint8), bitorder="little")
+    expect = np.zeros(words * 32, np.uint8)
+    expect[:n_cells] = (w.view(np.uint32) != 0).astype(np.uint8)
+    assert np.array_equal(bits_, expect)
