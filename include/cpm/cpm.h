@@ -671,8 +671,9 @@ int cpm_allreduce_grid_bricks(cpm_ctx* ctx, cpm_comm* comm, const float* partial
 typedef struct cpm_gl_resource cpm_gl_resource;
 enum { CPM_GL_TEXEL_F32 = 0, CPM_GL_TEXEL_F16 = 1 };
 
-/* The light volume (n = cells * channels floats) as the texels of the reference's four output formats -- Float32 /
- * Vec4Float32 as they are, Float16 / Vec4Float16 rounded to nearest even (ref photontolightvolumeprocessorcl.cpp:111-120)
+/* The light volume (n = cells * channels floats) as the texels of the four output formats the reference's processor knows
+ * (two of them offered in its UI) -- Float32 / Vec4Float32 as they are, Float16 / Vec4Float16 rounded to nearest even
+ * (ref photontolightvolumeprocessorcl.cpp:104-120)
  * -- into any device buffer (texels_out may be light_volume for CPM_GL_TEXEL_F32: nothing is done). */
 int cpm_light_volume_texels(cpm_ctx* ctx, const float* light_volume, size_t n, int texel /* CPM_GL_TEXEL_* */, void* texels_out,
                             cpm_stream stream);
