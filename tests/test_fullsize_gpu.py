@@ -163,12 +163,12 @@ def test_config3_exact_incremental_full_size(ctx, oracle, cpm):
     assert np.array_equal(bits(_n(cm.light_volume)), bits(lv_full))
 
 
-def test_config5_time_varying_full_size(ctx, oracle, cpm):
+@pytest.mark.parametrize("steps", [list(range(0, 9)), list(range(8, 17)), list(range(16, 25)), list(range(24, 32))])   # all 31 transitions of the 32-step sequence
+def test_config5_time_varying_full_size(ctx, oracle, cpm, steps):
     from oracle_binding import default_matrices
     S, P = cpm.synthetic, cpm.pipeline
     vdim, gdim, n_side, region = 256, 128, 1024, 8
     tfp = list(S.WORKSPACE_TF_POINTS)
-    steps = [0, 1, 2]                                   # three consecutive steps of the 32-step sequence
     vols = [S.heterogeneous_volume(vdim, S.sequence_blob_center(t, 32)) for t in steps]
     cm = P.CorrelatedPhotonMapper(ctx, vols[0], S.tf_from_points(tfp), n_side, (gdim,) * 3, light_travel_direction=LIGHT_DIR,
                                   tf_points=tfp, incremental_threshold_percent=100.0, region=region)
