@@ -94,7 +94,7 @@ struct cpm_trace_order {
     int n_light_samples = 0;
     uint32_t n_chunks = 0;
     uint32_t* order = nullptr;  // device, n_chunks: workgroup b takes chunk order[b]
-    uint32_t* cost = nullptr;   // device, n_chunks + 1: per chunk the sum of its waves' longest walks; [n_chunks] = launches counted
+    uint32_t* cost = nullptr;   // device, 4 n_chunks + 1: per chunk and wave the wave's longest walk in the last measured launch; [4 n_chunks] = launches measured
 };
 
 namespace cpm {

@@ -162,8 +162,8 @@ __global__ __launch_bounds__(256, 8) void trace_kernel(const TraceArgs A) {
             if ((alive >> (lane ^ off)) & 1ull) m = max(m, o);
         }
         if (lane == 0) {
-            atomicAdd(&A.chunk_cost[chunk], m);
-            if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&A.chunk_cost[gridDim.x], 1u);  // launches counted
+            A.chunk_cost[4u * (uint32_t)chunk + (threadIdx.x >> 6)] = m;  // (a plain store per wave: per-wave atomics cost a launch 2 us)
+            if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&A.chunk_cost[4u * gridDim.x], 1u);  // launches measured
         }
     }
     if (A.step_counter) {
@@ -336,18 +336,23 @@ int trace_impl(cpm_ctx* ctx, const cpm_volume* vol, const cpm_tf* tf, const cpm_
 // those whose cost is among the XCD's heaviest eighth come first, the others follow, both in lattice order (a stable
 // partition by ballots); chunks past the last full block of 128 keep their place.  Then the costs are cleared.
 constexpr int kOrderThreads = 1024, kOrderBins = 2048;  // (two bins per thread)
+// a chunk's cost: the sum of its four waves' longest walks in the last measured launch
+CPM_DEV uint32_t chunk_cost_of(const uint32_t* __restrict__ cost, uint32_t c) {
+    const uint4 w = reinterpret_cast<const uint4*>(cost)[c];
+    return w.x + w.y + w.z + w.w;
+}
 __global__ __launch_bounds__(kOrderThreads) void trace_order_kernel(uint32_t* __restrict__ order, uint32_t* __restrict__ cost, uint32_t n_chunks) {
     __shared__ uint32_t s_hist[kOrderBins];
     __shared__ uint32_t s_wave[kOrderThreads / 64];
     __shared__ uint32_t s_thr, s_shift, s_heavy;
     const uint32_t t = threadIdx.x, lane = t & 63u, wave = t >> 6, x = blockIdx.x;
     const uint32_t full = n_chunks & ~127u, mine = full / 8u;  // this XCD's chunks
-    if (cost[n_chunks] == 0u) return;  // nothing measured since the last update (uniform)
+    if (cost[4u * n_chunks] == 0u) return;  // nothing measured since the last update (uniform)
     if (x == 0) for (uint32_t b = full + t; b < n_chunks; b += kOrderThreads) { order[b] = b; }
     if (mine == 0u) return;
     // the costs' range -> a shift that brings them under kOrderBins
     uint32_t mx = 0;
-    for (uint32_t j = t; j < mine; j += kOrderThreads) mx = max(mx, cost[default_chunk((int)(8u * j + x), n_chunks)]);
+    for (uint32_t j = t; j < mine; j += kOrderThreads) mx = max(mx, chunk_cost_of(cost, (uint32_t)default_chunk((int)(8u * j + x), n_chunks)));
     for (int off = 32; off > 0; off >>= 1) mx = max(mx, (uint32_t)__shfl_xor((int)mx, off, 64));
     if (lane == 0) s_wave[wave] = mx;
     for (uint32_t i = t; i < kOrderBins; i += kOrderThreads) s_hist[i] = 0u;
@@ -361,7 +366,7 @@ __global__ __launch_bounds__(kOrderThreads) void trace_order_kernel(uint32_t* __
     }
     __syncthreads();
     const uint32_t sh = s_shift;
-    for (uint32_t j = t; j < mine; j += kOrderThreads) atomicAdd(&s_hist[cost[default_chunk((int)(8u * j + x), n_chunks)] >> sh], 1u);
+    for (uint32_t j = t; j < mine; j += kOrderThreads) atomicAdd(&s_hist[chunk_cost_of(cost, (uint32_t)default_chunk((int)(8u * j + x), n_chunks)) >> sh], 1u);
     __syncthreads();
     // bins above `thr` hold at most an eighth of the chunks: those are the heavy ones.  From the top: r = kOrderBins - 1 - bin,
     // cum(r) = chunks in the bins r' <= r; thread t owns r = 2 t and 2 t + 1; R = how many r have cum(r) <= want (cum is
@@ -395,7 +400,7 @@ __global__ __launch_bounds__(kOrderThreads) void trace_order_kernel(uint32_t* __
         const uint32_t j = j0 + t;
         const bool in = j < mine;
         const uint32_t c = in ? (uint32_t)default_chunk((int)(8u * j + x), n_chunks) : 0u;
-        const bool heavy = in && (cost[c] >> sh) > thr;
+        const bool heavy = in && (chunk_cost_of(cost, c) >> sh) > thr;
         const unsigned long long mh = __ballot(heavy), ml = __ballot(in && !heavy);
         __syncthreads();
         if (lane == 0) s_wave[wave] = (uint32_t)__popcll(mh) | ((uint32_t)__popcll(ml) << 16);
@@ -438,9 +443,9 @@ int cpm_trace_order_create(cpm_ctx* ctx, int n_light_samples, cpm_trace_order** 
         if (b < full) { const uint32_t x = b & 7u, j = b >> 3; c = ((((j >> 4) << 3) + x) << 4) + (j & 15u); }
         init[b] = c;
     }
-    bool ok = hipMalloc(&o->order, (size_t)o->n_chunks * 4) == hipSuccess && hipMalloc(&o->cost, ((size_t)o->n_chunks + 1) * 4) == hipSuccess &&
+    bool ok = hipMalloc(&o->order, (size_t)o->n_chunks * 4) == hipSuccess && hipMalloc(&o->cost, (4 * (size_t)o->n_chunks + 1) * 4) == hipSuccess &&
               hipMemcpy(o->order, init.data(), (size_t)o->n_chunks * 4, hipMemcpyHostToDevice) == hipSuccess &&
-              hipMemset(o->cost, 0, ((size_t)o->n_chunks + 1) * 4) == hipSuccess;
+              hipMemset(o->cost, 0, (4 * (size_t)o->n_chunks + 1) * 4) == hipSuccess;
     if (!ok) {
         if (o->order) (void)hipFree(o->order);
         if (o->cost) (void)hipFree(o->cost);
@@ -475,7 +480,12 @@ int cpm_debug_trace_order_read(cpm_ctx* ctx, const cpm_trace_order* order, uint3
     CPM_REQUIRE(ctx, order, "cpm_debug_trace_order_read: null order");
     CPM_HIP_CHECK(ctx, hipDeviceSynchronize());
     if (order_out) CPM_HIP_CHECK(ctx, hipMemcpy(order_out, order->order, (size_t)order->n_chunks * 4, hipMemcpyDeviceToHost));
-    if (cost_out) CPM_HIP_CHECK(ctx, hipMemcpy(cost_out, order->cost, ((size_t)order->n_chunks + 1) * 4, hipMemcpyDeviceToHost));
+    if (cost_out) {  // per chunk the sum of its waves' slots, then the launches measured
+        std::vector<uint32_t> raw(4 * (size_t)order->n_chunks + 1);
+        CPM_HIP_CHECK(ctx, hipMemcpy(raw.data(), order->cost, raw.size() * 4, hipMemcpyDeviceToHost));
+        for (uint32_t c = 0; c < order->n_chunks; ++c) cost_out[c] = raw[4 * c] + raw[4 * c + 1] + raw[4 * c + 2] + raw[4 * c + 3];
+        cost_out[order->n_chunks] = raw[4 * (size_t)order->n_chunks];
+    }
     return CPM_OK;
 }
 
@@ -485,7 +495,7 @@ int cpm_trace_order_update(cpm_ctx* ctx, cpm_trace_order* order, cpm_stream stre
     hipStream_t s = (hipStream_t)stream;
     CPM_LAUNCH(ctx, trace_order_kernel, dim3(8), dim3(kOrderThreads), 0, s, order->order, order->cost, order->n_chunks);
     CPM_LAUNCH_CHECK(ctx, "trace_order_kernel");
-    CPM_LAUNCH(ctx, trace_order_clear_kernel, dim3(div_up((long long)order->n_chunks + 1, 256)), dim3(256), 0, s, order->cost, order->n_chunks + 1);
+    CPM_LAUNCH(ctx, trace_order_clear_kernel, dim3(div_up(4ll * order->n_chunks + 1, 256)), dim3(256), 0, s, order->cost, 4u * order->n_chunks + 1u);
     CPM_LAUNCH_CHECK(ctx, "trace_order_clear_kernel");
     return CPM_OK;
 }

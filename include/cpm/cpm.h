@@ -242,7 +242,7 @@ int cpm_trace_emitted(cpm_ctx* ctx, const cpm_volume* vol, const cpm_tf* tf, con
  * workgroups.  Dealt out in lattice order, some of those start last and the launch ends with them alone (config 2:
  * 33.5 us; with every XCD's heaviest eighth started first 29.9; lightest first 35.7).  Frames repeat -- the same
  * light, a transfer function or time step that moved a little -- so the last launch's costs predict the next one's:
- * a cpm_trace_order accumulates, per chunk, the sum of its waves' longest walks over the launches it measures, and
+ * a cpm_trace_order keeps, per chunk, the sum of its waves' longest walks in the last launch it measured, and
  * cpm_trace_order_update turns that into the order of the following launches: of the chunks an XCD works on (whole
  * 4096-sample tiles, as before) the heaviest eighth first, the others in lattice order.  Photon i does not depend on the
  * order: records, RNG states and importances are bit for bit those of the default order.
@@ -252,12 +252,13 @@ typedef struct cpm_trace_order cpm_trace_order;
 int cpm_trace_order_create(cpm_ctx* ctx, int n_light_samples, cpm_trace_order** out);
 void cpm_trace_order_destroy(cpm_ctx* ctx, cpm_trace_order* order);
 /* The context's following cpm_trace / cpm_trace_emitted launches over all n_light_samples samples (no recompute
- * indices) take their chunks in `order`; with measure != 0 they also add their costs to it (one atomic per wave: 0.5 us
- * of a 33 us launch -- a caller measures a launch now and again, not every one).  Launches of another size are refused
- * (CPM_ERR_INVALID_ARGUMENT).  NULL = the default order.  Several lights: one object each, set before each launch. */
+ * indices) take their chunks in `order`; with measure != 0 they also record what every chunk cost (one store per wave;
+ * still 1 - 1.5 us of a 30 us launch -- a caller measures a launch now and again, not every one).  Launches of another size
+ * are refused (CPM_ERR_INVALID_ARGUMENT).  NULL = the default order.  Several lights: one object each, set before each
+ * launch. */
 int cpm_trace_set_order(cpm_ctx* ctx, cpm_trace_order* order, int measure);
-/* New order from the costs gathered since the last update (then cleared); one small launch.  Without costs -- no launch
- * since -- the order is left as it is. */
+/* New order from the costs of the last measured launch (then cleared); two small launches.  Without costs -- no measured
+ * launch since -- the order is left as it is. */
 int cpm_trace_order_update(cpm_ctx* ctx, cpm_trace_order* order, cpm_stream stream);
 
 /* ------------------------------------------------------------------ light volume (grid) */
