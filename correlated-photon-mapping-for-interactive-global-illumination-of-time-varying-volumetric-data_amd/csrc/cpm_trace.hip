@@ -61,7 +61,13 @@ __global__ __launch_bounds__(256, 8) void trace_kernel(const TraceArgs A) {
     int chunk = blockIdx.x;
     if (A.chunk_order) chunk = (int)A.chunk_order[blockIdx.x];
     else chunk = default_chunk(chunk, gridDim.x);
-    const int gid = chunk * blockDim.x + threadIdx.x;
+    // Which sample a lane takes inside the chunk: with a cpm_trace_order, the samples in the order of the steps they took in the
+    // last measured launch, so that a wave holds 64 samples of like cost -- a wave walks as long as its slowest lane, and in
+    // lattice order that is 7.2 iterations for 1.86 steps per sample.  (The same streams give the same steps until the transfer
+    // function or the volume changes, and then nearly the same: this is the correlated sampling the method is named after.)
+    int local = threadIdx.x;
+    if (A.lane_sample) local = (int)A.lane_sample[(size_t)chunk * 256u + threadIdx.x];
+    const int gid = chunk * blockDim.x + local;
     int threadId = gid;
     int nThreads = A.n_threads;
     if (A.n_threads_dev) {  // cpm_trace_selected: the launch covers the budget, the count says how much of it is work
@@ -153,6 +159,7 @@ __global__ __launch_bounds__(256, 8) void trace_kernel(const TraceArgs A) {
         encode_direction_(direction, th, ph);
     }
     trace_photon<DT, SINGLE>(A, lut, luts, threadId, l0, l1, ip, rs, direction, th, ph, steps);
+    if (A.sample_steps) A.sample_steps[threadId] = (uint8_t)(steps < 255u ? steps : 255u);
     if (A.chunk_cost) {  // what this chunk cost: the wave's longest walk (cpm_trace_order); lanes past the end have left
         unsigned m = steps;
         const unsigned long long alive = __ballot(true);
@@ -287,6 +294,9 @@ int trace_impl(cpm_ctx* ctx, const cpm_volume* vol, const cpm_tf* tf, const cpm_
         CPM_REQUIRE(ctx, o->n_light_samples == n_threads, "cpm_trace: the trace order set on this context was created for another number of samples");
         A.chunk_order = o->order;
         A.chunk_cost = ctx->trace_order_measure ? o->cost : nullptr;
+        // (a progressive launch draws new random numbers every time: last time's steps say nothing about this time's)
+        A.lane_sample = (p.flags & CPM_TRACE_PROGRESSIVE) ? nullptr : o->lane_sample;
+        A.sample_steps = ctx->trace_order_measure ? o->sample_steps : nullptr;
     }
     int emit = EMIT_NONE;
     if (emitter) {
@@ -419,6 +429,29 @@ __global__ __launch_bounds__(kOrderThreads) void trace_order_kernel(uint32_t* __
     }
 }
 
+// cpm_trace_order_update, the lanes: per chunk the 256 samples sorted by the steps they took (stable: ties in sample order) --
+// a bitonic sort of (steps << 8 | sample) in LDS; lane r of the workgroup that takes the chunk next time gets sample sorted[r].
+__global__ __launch_bounds__(256) void trace_lane_order_kernel(const uint8_t* __restrict__ steps, uint8_t* __restrict__ lane_sample,
+                                                               const uint32_t* __restrict__ cost, uint32_t n_chunks) {
+    __shared__ uint32_t s_key[256];
+    if (cost[4u * n_chunks] == 0u) return;  // nothing measured since the last update (uniform)
+    const uint32_t t = threadIdx.x, base = blockIdx.x * 256u;
+    s_key[t] = ((uint32_t)steps[base + t] << 8) | t;
+    __syncthreads();
+    for (uint32_t k = 2; k <= 256u; k <<= 1) {
+        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+            const uint32_t partner = t ^ j;
+            if (partner > t) {
+                const uint32_t a = s_key[t], b = s_key[partner];
+                const bool up = (t & k) == 0u;
+                if ((a > b) == up) { s_key[t] = b; s_key[partner] = a; }
+            }
+            __syncthreads();
+        }
+    }
+    lane_sample[base + t] = (uint8_t)(s_key[t] & 0xffu);
+}
+
 __global__ __launch_bounds__(256) void trace_order_clear_kernel(uint32_t* __restrict__ cost, uint32_t n) {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
     if (i < n) cost[i] = 0u;
@@ -443,12 +476,19 @@ int cpm_trace_order_create(cpm_ctx* ctx, int n_light_samples, cpm_trace_order** 
         if (b < full) { const uint32_t x = b & 7u, j = b >> 3; c = ((((j >> 4) << 3) + x) << 4) + (j & 15u); }
         init[b] = c;
     }
-    bool ok = hipMalloc(&o->order, (size_t)o->n_chunks * 4) == hipSuccess && hipMalloc(&o->cost, (4 * (size_t)o->n_chunks + 1) * 4) == hipSuccess &&
+    std::vector<uint8_t> ident((size_t)o->n_chunks * 256);
+    for (size_t i = 0; i < ident.size(); ++i) ident[i] = (uint8_t)(i & 255u);
+    bool ok = hipMalloc(&o->lane_sample, ident.size()) == hipSuccess && hipMalloc(&o->sample_steps, ident.size()) == hipSuccess &&
+              hipMemcpy(o->lane_sample, ident.data(), ident.size(), hipMemcpyHostToDevice) == hipSuccess &&
+              hipMemset(o->sample_steps, 0, ident.size()) == hipSuccess &&
+              hipMalloc(&o->order, (size_t)o->n_chunks * 4) == hipSuccess && hipMalloc(&o->cost, (4 * (size_t)o->n_chunks + 1) * 4) == hipSuccess &&
               hipMemcpy(o->order, init.data(), (size_t)o->n_chunks * 4, hipMemcpyHostToDevice) == hipSuccess &&
               hipMemset(o->cost, 0, (4 * (size_t)o->n_chunks + 1) * 4) == hipSuccess;
     if (!ok) {
         if (o->order) (void)hipFree(o->order);
         if (o->cost) (void)hipFree(o->cost);
+        if (o->lane_sample) (void)hipFree(o->lane_sample);
+        if (o->sample_steps) (void)hipFree(o->sample_steps);
         delete o;
         return set_error(ctx, CPM_ERR_OUT_OF_MEMORY, "cpm_trace_order_create", "device allocation");
     }
@@ -464,6 +504,8 @@ void cpm_trace_order_destroy(cpm_ctx* ctx, cpm_trace_order* order) {
     }
     if (order->order) (void)hipFree(order->order);
     if (order->cost) (void)hipFree(order->cost);
+    if (order->lane_sample) (void)hipFree(order->lane_sample);
+    if (order->sample_steps) (void)hipFree(order->sample_steps);
     delete order;
 }
 
@@ -489,10 +531,23 @@ int cpm_debug_trace_order_read(cpm_ctx* ctx, const cpm_trace_order* order, uint3
     return CPM_OK;
 }
 
+// test hook (include/cpm/cpm_profile.h): the lane table and the per-sample steps of the last measured launch (synchronises)
+int cpm_debug_trace_lanes_read(cpm_ctx* ctx, const cpm_trace_order* order, uint8_t* lane_sample_out, uint8_t* steps_out) {
+    CPM_ENTER(ctx);
+    CPM_REQUIRE(ctx, order, "cpm_debug_trace_lanes_read: null order");
+    CPM_HIP_CHECK(ctx, hipDeviceSynchronize());
+    const size_t n = (size_t)order->n_chunks * 256;
+    if (lane_sample_out) CPM_HIP_CHECK(ctx, hipMemcpy(lane_sample_out, order->lane_sample, n, hipMemcpyDeviceToHost));
+    if (steps_out) CPM_HIP_CHECK(ctx, hipMemcpy(steps_out, order->sample_steps, n, hipMemcpyDeviceToHost));
+    return CPM_OK;
+}
+
 int cpm_trace_order_update(cpm_ctx* ctx, cpm_trace_order* order, cpm_stream stream) {
     CPM_ENTER(ctx);
     CPM_REQUIRE(ctx, order && order->order && order->cost, "cpm_trace_order_update: null order");
     hipStream_t s = (hipStream_t)stream;
+    CPM_LAUNCH(ctx, trace_lane_order_kernel, dim3(order->n_chunks), dim3(256), 0, s, order->sample_steps, order->lane_sample, order->cost, order->n_chunks);
+    CPM_LAUNCH_CHECK(ctx, "trace_lane_order_kernel");
     CPM_LAUNCH(ctx, trace_order_kernel, dim3(8), dim3(kOrderThreads), 0, s, order->order, order->cost, order->n_chunks);
     CPM_LAUNCH_CHECK(ctx, "trace_order_kernel");
     CPM_LAUNCH(ctx, trace_order_clear_kernel, dim3(div_up(4ll * order->n_chunks + 1, 256)), dim3(256), 0, s, order->cost, 4u * order->n_chunks + 1u);

@@ -102,7 +102,15 @@ def test_the_table(ctx, cpm, n_side):
         ctx.trace_set_order(None)
     _, cost, launches = order.read()
     assert launches == 2 and cost.sum() > 0
+    lanes0, steps = order.read_lanes()
+    assert np.array_equal(lanes0, np.tile(np.arange(256, dtype=np.uint8), (n_chunks, 1)))   # lattice order until the first update
+    assert steps[: fr.n // 256].any()
     order.update()
+    lanes, _ = order.read_lanes()
+    for c in range(n_chunks):   # every chunk: a permutation of its samples, by the steps they took, ties in sample order
+        assert np.array_equal(np.sort(lanes[c]), np.arange(256))
+        key = steps[c][lanes[c]].astype(np.int64) * 256 + lanes[c]
+        assert np.all(np.diff(key) > 0)
     table, cleared, launches = order.read()
     assert sorted(table.tolist()) == list(range(n_chunks)) and not cleared.any() and launches == 0
     full = n_chunks & ~127
