@@ -459,6 +459,16 @@ def main():
         extras["reference_formulation_splat"] = {"ms_per_frame": round(timed(torch, lambda: (fr.trace(), fr.splat(tmp)), reps), 4),
                                                  "splat_only_ms": round(timed(torch, lambda: fr.splat(tmp), reps), 4),
                                                  "note": "trace + clear + atomic splat (the reference's own formulation, cpm_splat); order-dependent sums"}
+        # the same frame with the light samples evaluated inside the tracer (cpm_trace_emitted: a caller that owns its light and
+        # intersects the volume's box needs no sample / intersection buffers -- 40 of the 48 input bytes per photon not read);
+        # photons bit-identical.  Not `value`: the reference's tracer takes sample buffers, and so does the headline.
+        if fast:
+            fe = P.PhotonFrame(ctx, fr.vol, fr.tf, lattice, (gdim,) * 3, light_travel_direction=LIGHT_DIR, emit_in_tracer=True)
+            ms_e = timed(torch, fe.frame_fast, reps)
+            extras["samples_emitted_in_tracer"] = {"ms_per_frame": round(ms_e, 4), "mphotons_per_s": round(n_rank / ms_e / 1e3, 2),
+                                                   "trace_ms": round(timed(torch, fe.trace, reps), 4),
+                                                   "photons_identical": bool(torch.equal(fe.photons.view(torch.int32), fr.photons.view(torch.int32)))}
+            del fe
         # config 2 at I = 4 (multiple scattering, Henyey-Greenstein g = 0.3): N photons, up to 4 records each
         f4 = P.PhotonFrame(ctx, fr.vol, fr.tf, lattice, (gdim,) * 3, light_travel_direction=LIGHT_DIR, max_interactions=4,
                            material=(0.3, 0.0, 0.0, 0.0))

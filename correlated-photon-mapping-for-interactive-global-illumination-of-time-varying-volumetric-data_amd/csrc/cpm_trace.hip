@@ -297,6 +297,7 @@ int trace_impl(cpm_ctx* ctx, const cpm_volume* vol, const cpm_tf* tf, const cpm_
         // (a progressive launch draws new random numbers every time: last time's steps say nothing about this time's)
         A.lane_sample = (p.flags & CPM_TRACE_PROGRESSIVE) ? nullptr : o->lane_sample;
         A.sample_steps = ctx->trace_order_measure ? o->sample_steps : nullptr;
+        if (ctx->trace_order_measure) ctx->trace_order->measured_emitted = emitter != nullptr;
     }
     int emit = EMIT_NONE;
     if (emitter) {
@@ -431,12 +432,24 @@ __global__ __launch_bounds__(kOrderThreads) void trace_order_kernel(uint32_t* __
 
 // cpm_trace_order_update, the lanes: per chunk the 256 samples sorted by the steps they took (stable: ties in sample order) --
 // a bitonic sort of (steps << 8 | sample) in LDS; lane r of the workgroup that takes the chunk next time gets sample sorted[r].
+// Sorted lanes cost something too -- a wave's sample loads and record stores then spread over the chunk's whole 8 KiB instead of a
+// quarter of it (measured: four frames in flight 17.3 -> 16.0 Gphotons/s, I = 4 0.181 -> 0.191 ms with every chunk sorted) -- so a
+// chunk is sorted only where that buys at least kLaneSortMinSaved wave-iterations (config 2 saves 14 per chunk and keeps its
+// lattice order; 49 steps per sample save 150).
+// A launch that evaluates its samples itself (cpm_trace_emitted) has no sample loads to spread: there every saved iteration counts
+// (config 2: trace 30.4 -> 27.2 us).
+constexpr uint32_t kLaneSortMinSaved = 32, kLaneSortMinSavedEmitted = 1;
 __global__ __launch_bounds__(256) void trace_lane_order_kernel(const uint8_t* __restrict__ steps, uint8_t* __restrict__ lane_sample,
-                                                               const uint32_t* __restrict__ cost, uint32_t n_chunks) {
+                                                               const uint32_t* __restrict__ cost, uint32_t n_chunks, uint32_t min_saved) {
     __shared__ uint32_t s_key[256];
+    __shared__ uint32_t s_before[4];
     if (cost[4u * n_chunks] == 0u) return;  // nothing measured since the last update (uniform)
     const uint32_t t = threadIdx.x, base = blockIdx.x * 256u;
-    s_key[t] = ((uint32_t)steps[base + t] << 8) | t;
+    const uint32_t mine = (uint32_t)steps[base + t];
+    s_key[t] = (mine << 8) | t;
+    uint32_t wmax = mine;  // what the lattice order costs: every wave its slowest lane
+    for (int off = 32; off > 0; off >>= 1) wmax = max(wmax, (uint32_t)__shfl_xor((int)wmax, off, 64));
+    if ((t & 63u) == 0u) s_before[t >> 6] = wmax;
     __syncthreads();
     for (uint32_t k = 2; k <= 256u; k <<= 1) {
         for (uint32_t j = k >> 1; j > 0; j >>= 1) {
@@ -449,7 +462,9 @@ __global__ __launch_bounds__(256) void trace_lane_order_kernel(const uint8_t* __
             __syncthreads();
         }
     }
-    lane_sample[base + t] = (uint8_t)(s_key[t] & 0xffu);
+    const uint32_t before = s_before[0] + s_before[1] + s_before[2] + s_before[3];
+    const uint32_t after = (s_key[63] >> 8) + (s_key[127] >> 8) + (s_key[191] >> 8) + (s_key[255] >> 8);
+    lane_sample[base + t] = before >= after + min_saved ? (uint8_t)(s_key[t] & 0xffu) : (uint8_t)t;
 }
 
 __global__ __launch_bounds__(256) void trace_order_clear_kernel(uint32_t* __restrict__ cost, uint32_t n) {
@@ -546,7 +561,8 @@ int cpm_trace_order_update(cpm_ctx* ctx, cpm_trace_order* order, cpm_stream stre
     CPM_ENTER(ctx);
     CPM_REQUIRE(ctx, order && order->order && order->cost, "cpm_trace_order_update: null order");
     hipStream_t s = (hipStream_t)stream;
-    CPM_LAUNCH(ctx, trace_lane_order_kernel, dim3(order->n_chunks), dim3(256), 0, s, order->sample_steps, order->lane_sample, order->cost, order->n_chunks);
+    CPM_LAUNCH(ctx, trace_lane_order_kernel, dim3(order->n_chunks), dim3(256), 0, s, order->sample_steps, order->lane_sample, order->cost, order->n_chunks,
+               order->measured_emitted ? kLaneSortMinSavedEmitted : kLaneSortMinSaved);
     CPM_LAUNCH_CHECK(ctx, "trace_lane_order_kernel");
     CPM_LAUNCH(ctx, trace_order_kernel, dim3(8), dim3(kOrderThreads), 0, s, order->order, order->cost, order->n_chunks);
     CPM_LAUNCH_CHECK(ctx, "trace_order_kernel");
