@@ -75,14 +75,6 @@ class TraceOrder:
         self.ctx._check(self.ctx.lib.cpm_debug_trace_order_read(self.ctx.h, self.h, order.ctypes.data, cost.ctypes.data))
         return order, cost[:n], int(cost[n])
 
-    def read_lanes(self):
-        """(lane table, steps per sample in the last measured launch), each (n_chunks, 256) uint8 -- test hook, synchronises."""
-        import numpy as np
-        n = (self.n_light_samples + 255) // 256
-        lanes, steps = np.zeros((n, 256), np.uint8), np.zeros((n, 256), np.uint8)
-        self.ctx._check(self.ctx.lib.cpm_debug_trace_lanes_read(self.ctx.h, self.h, lanes.ctypes.data, steps.ctypes.data))
-        return lanes, steps
-
     def close(self):
         if self.h:
             self.ctx.lib.cpm_trace_order_destroy(self.ctx.h, self.h)
@@ -262,7 +254,6 @@ def load_library() -> C.CDLL:
         "cpm_volume_download": (i32, [vp, vp, vp, vp]),
         # include/cpm/cpm_profile.h (measurement hooks)
         "cpm_debug_trace_order_read": (i32, [vp, vp, vp, vp]),
-        "cpm_debug_trace_lanes_read": (i32, [vp, vp, vp, vp]),
         "cpm_debug_set_step_counter": (None, [vp, vp]),
         "cpm_debug_set_gather_stamps": (None, [vp, vp]),
         "cpm_debug_force_voxel_gather": (None, [vp, i32]),

@@ -95,9 +95,6 @@ struct cpm_trace_order {
     uint32_t n_chunks = 0;
     uint32_t* order = nullptr;  // device, n_chunks: workgroup b takes chunk order[b]
     uint32_t* cost = nullptr;   // device, 4 n_chunks + 1: per chunk and wave the wave's longest walk in the last measured launch; [4 n_chunks] = launches measured
-    uint8_t* lane_sample = nullptr;   // device, 256 n_chunks: lane t of the workgroup on chunk c takes sample 256 c + lane_sample[256 c + t]
-    uint8_t* sample_steps = nullptr;  // device, 256 n_chunks: Woodcock steps of every sample in the last measured launch (saturated)
-    bool measured_emitted = false;    // the last measured launch evaluated its samples itself (cpm_trace_emitted): no sample loads to keep coalesced
 };
 
 namespace cpm {

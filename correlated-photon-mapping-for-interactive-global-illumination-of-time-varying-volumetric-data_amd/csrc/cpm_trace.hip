@@ -61,13 +61,7 @@ __global__ __launch_bounds__(256, 8) void trace_kernel(const TraceArgs A) {
     int chunk = blockIdx.x;
     if (A.chunk_order) chunk = (int)A.chunk_order[blockIdx.x];
     else chunk = default_chunk(chunk, gridDim.x);
-    // Which sample a lane takes inside the chunk: with a cpm_trace_order, the samples in the order of the steps they took in the
-    // last measured launch, so that a wave holds 64 samples of like cost -- a wave walks as long as its slowest lane, and in
-    // lattice order that is 7.2 iterations for 1.86 steps per sample.  (The same streams give the same steps until the transfer
-    // function or the volume changes, and then nearly the same: this is the correlated sampling the method is named after.)
-    int local = threadIdx.x;
-    if (A.lane_sample) local = (int)A.lane_sample[(size_t)chunk * 256u + threadIdx.x];
-    const int gid = chunk * blockDim.x + local;
+    const int gid = chunk * blockDim.x + threadIdx.x;
     int threadId = gid;
     int nThreads = A.n_threads;
     if (A.n_threads_dev) {  // cpm_trace_selected: the launch covers the budget, the count says how much of it is work
@@ -159,7 +153,6 @@ __global__ __launch_bounds__(256, 8) void trace_kernel(const TraceArgs A) {
         encode_direction_(direction, th, ph);
     }
     trace_photon<DT, SINGLE>(A, lut, luts, threadId, l0, l1, ip, rs, direction, th, ph, steps);
-    if (A.sample_steps) A.sample_steps[threadId] = (uint8_t)(steps < 255u ? steps : 255u);
     if (A.chunk_cost) {  // what this chunk cost: the wave's longest walk (cpm_trace_order); lanes past the end have left
         unsigned m = steps;
         const unsigned long long alive = __ballot(true);
@@ -294,10 +287,6 @@ int trace_impl(cpm_ctx* ctx, const cpm_volume* vol, const cpm_tf* tf, const cpm_
         CPM_REQUIRE(ctx, o->n_light_samples == n_threads, "cpm_trace: the trace order set on this context was created for another number of samples");
         A.chunk_order = o->order;
         A.chunk_cost = ctx->trace_order_measure ? o->cost : nullptr;
-        // (a progressive launch draws new random numbers every time: last time's steps say nothing about this time's)
-        A.lane_sample = (p.flags & CPM_TRACE_PROGRESSIVE) ? nullptr : o->lane_sample;
-        A.sample_steps = ctx->trace_order_measure ? o->sample_steps : nullptr;
-        if (ctx->trace_order_measure) ctx->trace_order->measured_emitted = emitter != nullptr;
     }
     int emit = EMIT_NONE;
     if (emitter) {
@@ -430,43 +419,6 @@ __global__ __launch_bounds__(kOrderThreads) void trace_order_kernel(uint32_t* __
     }
 }
 
-// cpm_trace_order_update, the lanes: per chunk the 256 samples sorted by the steps they took (stable: ties in sample order) --
-// a bitonic sort of (steps << 8 | sample) in LDS; lane r of the workgroup that takes the chunk next time gets sample sorted[r].
-// Sorted lanes cost something too -- a wave's sample loads and record stores then spread over the chunk's whole 8 KiB instead of a
-// quarter of it (measured: four frames in flight 17.3 -> 16.0 Gphotons/s, I = 4 0.181 -> 0.191 ms with every chunk sorted) -- so a
-// chunk is sorted only where that buys at least kLaneSortMinSaved wave-iterations (config 2 saves 14 per chunk and keeps its
-// lattice order; 49 steps per sample save 150).
-// A launch that evaluates its samples itself (cpm_trace_emitted) has no sample loads to spread: there every saved iteration counts
-// (config 2: trace 30.4 -> 27.2 us).
-constexpr uint32_t kLaneSortMinSaved = 32, kLaneSortMinSavedEmitted = 1;
-__global__ __launch_bounds__(256) void trace_lane_order_kernel(const uint8_t* __restrict__ steps, uint8_t* __restrict__ lane_sample,
-                                                               const uint32_t* __restrict__ cost, uint32_t n_chunks, uint32_t min_saved) {
-    __shared__ uint32_t s_key[256];
-    __shared__ uint32_t s_before[4];
-    if (cost[4u * n_chunks] == 0u) return;  // nothing measured since the last update (uniform)
-    const uint32_t t = threadIdx.x, base = blockIdx.x * 256u;
-    const uint32_t mine = (uint32_t)steps[base + t];
-    s_key[t] = (mine << 8) | t;
-    uint32_t wmax = mine;  // what the lattice order costs: every wave its slowest lane
-    for (int off = 32; off > 0; off >>= 1) wmax = max(wmax, (uint32_t)__shfl_xor((int)wmax, off, 64));
-    if ((t & 63u) == 0u) s_before[t >> 6] = wmax;
-    __syncthreads();
-    for (uint32_t k = 2; k <= 256u; k <<= 1) {
-        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
-            const uint32_t partner = t ^ j;
-            if (partner > t) {
-                const uint32_t a = s_key[t], b = s_key[partner];
-                const bool up = (t & k) == 0u;
-                if ((a > b) == up) { s_key[t] = b; s_key[partner] = a; }
-            }
-            __syncthreads();
-        }
-    }
-    const uint32_t before = s_before[0] + s_before[1] + s_before[2] + s_before[3];
-    const uint32_t after = (s_key[63] >> 8) + (s_key[127] >> 8) + (s_key[191] >> 8) + (s_key[255] >> 8);
-    lane_sample[base + t] = before >= after + min_saved ? (uint8_t)(s_key[t] & 0xffu) : (uint8_t)t;
-}
-
 __global__ __launch_bounds__(256) void trace_order_clear_kernel(uint32_t* __restrict__ cost, uint32_t n) {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
     if (i < n) cost[i] = 0u;
@@ -491,19 +443,12 @@ int cpm_trace_order_create(cpm_ctx* ctx, int n_light_samples, cpm_trace_order** 
         if (b < full) { const uint32_t x = b & 7u, j = b >> 3; c = ((((j >> 4) << 3) + x) << 4) + (j & 15u); }
         init[b] = c;
     }
-    std::vector<uint8_t> ident((size_t)o->n_chunks * 256);
-    for (size_t i = 0; i < ident.size(); ++i) ident[i] = (uint8_t)(i & 255u);
-    bool ok = hipMalloc(&o->lane_sample, ident.size()) == hipSuccess && hipMalloc(&o->sample_steps, ident.size()) == hipSuccess &&
-              hipMemcpy(o->lane_sample, ident.data(), ident.size(), hipMemcpyHostToDevice) == hipSuccess &&
-              hipMemset(o->sample_steps, 0, ident.size()) == hipSuccess &&
-              hipMalloc(&o->order, (size_t)o->n_chunks * 4) == hipSuccess && hipMalloc(&o->cost, (4 * (size_t)o->n_chunks + 1) * 4) == hipSuccess &&
+    bool ok = hipMalloc(&o->order, (size_t)o->n_chunks * 4) == hipSuccess && hipMalloc(&o->cost, (4 * (size_t)o->n_chunks + 1) * 4) == hipSuccess &&
               hipMemcpy(o->order, init.data(), (size_t)o->n_chunks * 4, hipMemcpyHostToDevice) == hipSuccess &&
               hipMemset(o->cost, 0, (4 * (size_t)o->n_chunks + 1) * 4) == hipSuccess;
     if (!ok) {
         if (o->order) (void)hipFree(o->order);
         if (o->cost) (void)hipFree(o->cost);
-        if (o->lane_sample) (void)hipFree(o->lane_sample);
-        if (o->sample_steps) (void)hipFree(o->sample_steps);
         delete o;
         return set_error(ctx, CPM_ERR_OUT_OF_MEMORY, "cpm_trace_order_create", "device allocation");
     }
@@ -519,8 +464,6 @@ void cpm_trace_order_destroy(cpm_ctx* ctx, cpm_trace_order* order) {
     }
     if (order->order) (void)hipFree(order->order);
     if (order->cost) (void)hipFree(order->cost);
-    if (order->lane_sample) (void)hipFree(order->lane_sample);
-    if (order->sample_steps) (void)hipFree(order->sample_steps);
     delete order;
 }
 
@@ -546,24 +489,10 @@ int cpm_debug_trace_order_read(cpm_ctx* ctx, const cpm_trace_order* order, uint3
     return CPM_OK;
 }
 
-// test hook (include/cpm/cpm_profile.h): the lane table and the per-sample steps of the last measured launch (synchronises)
-int cpm_debug_trace_lanes_read(cpm_ctx* ctx, const cpm_trace_order* order, uint8_t* lane_sample_out, uint8_t* steps_out) {
-    CPM_ENTER(ctx);
-    CPM_REQUIRE(ctx, order, "cpm_debug_trace_lanes_read: null order");
-    CPM_HIP_CHECK(ctx, hipDeviceSynchronize());
-    const size_t n = (size_t)order->n_chunks * 256;
-    if (lane_sample_out) CPM_HIP_CHECK(ctx, hipMemcpy(lane_sample_out, order->lane_sample, n, hipMemcpyDeviceToHost));
-    if (steps_out) CPM_HIP_CHECK(ctx, hipMemcpy(steps_out, order->sample_steps, n, hipMemcpyDeviceToHost));
-    return CPM_OK;
-}
-
 int cpm_trace_order_update(cpm_ctx* ctx, cpm_trace_order* order, cpm_stream stream) {
     CPM_ENTER(ctx);
     CPM_REQUIRE(ctx, order && order->order && order->cost, "cpm_trace_order_update: null order");
     hipStream_t s = (hipStream_t)stream;
-    CPM_LAUNCH(ctx, trace_lane_order_kernel, dim3(order->n_chunks), dim3(256), 0, s, order->sample_steps, order->lane_sample, order->cost, order->n_chunks,
-               order->measured_emitted ? kLaneSortMinSavedEmitted : kLaneSortMinSaved);
-    CPM_LAUNCH_CHECK(ctx, "trace_lane_order_kernel");
     CPM_LAUNCH(ctx, trace_order_kernel, dim3(8), dim3(kOrderThreads), 0, s, order->order, order->cost, order->n_chunks);
     CPM_LAUNCH_CHECK(ctx, "trace_order_kernel");
     CPM_LAUNCH(ctx, trace_order_clear_kernel, dim3(div_up(4ll * order->n_chunks + 1, 256)), dim3(256), 0, s, order->cost, 4u * order->n_chunks + 1u);

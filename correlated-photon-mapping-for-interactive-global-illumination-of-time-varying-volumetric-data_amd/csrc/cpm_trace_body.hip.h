@@ -42,8 +42,6 @@ struct TraceArgs {
     unsigned long long* step_counter;  // nullable (statistics build of the launch)
     const uint32_t* chunk_order;       // cpm_trace_order (nullable): workgroup b takes chunk chunk_order[b] ...
     uint32_t* chunk_cost;              // ... and every wave adds its longest walk to chunk_cost[chunk]
-    const uint8_t* lane_sample;        // ... lane t of the workgroup takes sample 256 chunk + lane_sample[256 chunk + t] (nullable)
-    uint8_t* sample_steps;             // ... and a measured launch leaves every sample's step count (nullable)
     const float* dir_hint;             // cpm_ctx::dir_hint (emitted mode: the hint of ITS light, cpm_ctx::dir_hint + 8)
     // emitted mode (cpm_trace_emitted): light sample and entry / exit of lattice sample first_sample + thread, in registers
     Light light;

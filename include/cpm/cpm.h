@@ -245,15 +245,8 @@ int cpm_trace_emitted(cpm_ctx* ctx, const cpm_volume* vol, const cpm_tf* tf, con
  * a cpm_trace_order keeps, per chunk, the sum of its waves' longest walks in the last launch it measured, and
  * cpm_trace_order_update turns that into the order of the following launches: of the chunks an XCD works on (whole
  * 4096-sample tiles, as before) the heaviest eighth first, the others in lattice order.
- * The same object orders the lanes inside a chunk: a wave walks as long as its slowest lane (config 2: 7.2 iterations
- * for 1.86 steps per sample), so a measured launch also leaves every sample's step count and the update sorts each
- * chunk's 256 samples by it -- a wave then holds 64 samples of like cost (49 steps per sample: wave-iterations 1.73 M ->
- * 1.12 M, 269 -> 238 us) -- but only in chunks where that saves at least 32 wave-iterations: sorted lanes spread a
- * wave's sample loads over the chunk's whole 8 KiB, and config 2 (14 saved per chunk; the launch is bound by its memory
- * traffic there) is better off in lattice order.  A launch that evaluates its samples itself (cpm_trace_emitted) has no
- * such loads and sorts wherever anything is saved.  Launches that write the RNG state back (CPM_TRACE_PROGRESSIVE: new
- * random numbers next time) keep the lattice order of lanes.  Photon i does not depend on chunk or lane order: records, RNG states and
- * importances are bit for bit those of the default order.
+ * Photon i does not depend on the order: records, RNG states and importances are bit for bit those of the default
+ * order.
  * Not in the reference (OpenCL enqueues its work-groups in order, ref processor/photontracercl.cpp:192-200). */
 typedef struct cpm_trace_order cpm_trace_order;
 /* For launches over exactly n_light_samples samples; starts out as the default order. */

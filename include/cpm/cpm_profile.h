@@ -46,9 +46,6 @@ void cpm_debug_set_stream_wg_per_cu(cpm_ctx* ctx, int n);
  * update (n_chunks + 1 entries, the last one = launches counted); either may be NULL.  Synchronises the device. */
 struct cpm_trace_order;
 int cpm_debug_trace_order_read(cpm_ctx* ctx, const struct cpm_trace_order* order, uint32_t* order_out, uint32_t* cost_out);
-/* ... its lane table (256 n_chunks bytes: lane t of the workgroup on chunk c takes sample 256 c + table[256 c + t]) and the steps every
- * sample took in the last measured launch (256 n_chunks bytes, saturated at 255); either may be NULL.  Synchronises the device. */
-int cpm_debug_trace_lanes_read(cpm_ctx* ctx, const struct cpm_trace_order* order, uint8_t* lane_sample_out, uint8_t* steps_out);
 #ifdef __cplusplus
 }
 #endif

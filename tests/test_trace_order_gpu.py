@@ -37,24 +37,6 @@ def test_order_does_not_show_in_the_photons(ctx, cpm, n_side, kw):
     assert fr.trace_order is not None and fr.trace_order.n_light_samples == fr.n
 
 
-def test_long_walks_sorted_lanes(ctx, cpm):
-    """A constant, low opacity (tens of steps per sample): the chunks' lanes DO get sorted; photons and RNG states as in lattice order."""
-    torch = ctx.torch
-    S, P = cpm.synthetic, cpm.pipeline
-    mk = lambda adaptive: P.PhotonFrame(ctx, S.heterogeneous_volume(64), S.homogeneous_tf(0.02), 256, (32,) * 3, light_travel_direction=(0.3, 0.5, -1.0))
-    ref, fr = mk(False), mk(True)
-    ref.adaptive_order = False
-    fr.TRACE_ORDER_EVERY = 2
-    ref.trace()
-    for launch in range(4):
-        fr.photons.zero_()
-        fr.trace()
-        torch.cuda.synchronize()
-        assert torch.equal(fr.photons.view(torch.int32), ref.photons.view(torch.int32)) and torch.equal(fr.rng, ref.rng)
-    lanes, steps = fr.trace_order.read_lanes()
-    assert (lanes != np.arange(256, dtype=np.uint8)).any() and steps.mean() > 8
-
-
 def test_progressive_launches_and_frames(ctx, cpm):
     """RNG write-back (progressive refinement) and the frame's light volume: the same with and without the measured order."""
     torch = ctx.torch
@@ -120,25 +102,7 @@ def test_the_table(ctx, cpm, n_side):
         ctx.trace_set_order(None)
     _, cost, launches = order.read()
     assert launches == 2 and cost.sum() > 0
-    lanes0, steps = order.read_lanes()
-    assert np.array_equal(lanes0, np.tile(np.arange(256, dtype=np.uint8), (n_chunks, 1)))   # lattice order until the first update
-    assert steps[: fr.n // 256].any()
     order.update()
-    lanes, _ = order.read_lanes()
-    sorted_chunks = 0
-    for c in range(n_chunks):
-        # a chunk where sorting saves at least 32 wave-iterations: a permutation of its samples by the steps they took, ties in
-        # sample order; any other chunk: lattice order
-        st = steps[c].astype(np.int64)
-        before = st.reshape(4, 64).max(axis=1).sum()
-        after = np.sort(st).reshape(4, 64).max(axis=1).sum()
-        if before >= after + 32:
-            sorted_chunks += 1
-            assert np.array_equal(np.sort(lanes[c]), np.arange(256))
-            key = st[lanes[c]] * 256 + lanes[c]
-            assert np.all(np.diff(key) > 0)
-        else:
-            assert np.array_equal(lanes[c], np.arange(256))
     table, cleared, launches = order.read()
     assert sorted(table.tolist()) == list(range(n_chunks)) and not cleared.any() and launches == 0
     full = n_chunks & ~127
