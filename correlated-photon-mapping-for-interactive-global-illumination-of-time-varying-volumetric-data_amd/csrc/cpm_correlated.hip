@@ -1263,10 +1263,15 @@ int cpm_photon_importance_retrace(cpm_ctx* ctx, cpm_selection* s, const float* i
         if (lo.cost) (void)hipFree(lo.cost);
         if (lo.keys) (void)hipFree(lo.keys);
         lo = cpm_selection::LaunchOrder();
-        CPM_HIP_CHECK(ctx, hipMalloc(&lo.order, (size_t)tiles * 4));
-        CPM_HIP_CHECK(ctx, hipMalloc(&lo.cost, (size_t)tiles * 4));
-        CPM_HIP_CHECK(ctx, hipMalloc(&lo.keys, (size_t)tiles * 4));
-        CPM_HIP_CHECK(ctx, hipMemsetAsync(lo.cost, 0, (size_t)tiles * 4, st));
+        const bool ok = hipMalloc(&lo.order, (size_t)tiles * 4) == hipSuccess && hipMalloc(&lo.cost, (size_t)tiles * 4) == hipSuccess &&
+                        hipMalloc(&lo.keys, (size_t)tiles * 4) == hipSuccess && hipMemsetAsync(lo.cost, 0, (size_t)tiles * 4, st) == hipSuccess;
+        if (!ok) {
+            if (lo.order) (void)hipFree(lo.order);
+            if (lo.cost) (void)hipFree(lo.cost);
+            if (lo.keys) (void)hipFree(lo.keys);
+            lo = cpm_selection::LaunchOrder();
+            return set_error(ctx, CPM_ERR_OUT_OF_MEMORY, "cpm_photon_importance_retrace", "tile order buffers");
+        }
         lo.n_tiles = tiles;
         lo.fresh = true;  // no order yet: index order, and this launch is measured whatever the selection's turn
     }
