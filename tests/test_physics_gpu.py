@@ -46,3 +46,30 @@ def test_free_path_is_exponential(ctx, cpm, alpha, direction, axis):
     ls = fr.light_samples.cpu().numpy()
     want = ls[absorbed, 3] / np.float32(max(alpha, 0.01))
     assert np.allclose(ph[absorbed, 3], want, rtol=1e-6)
+
+
+@pytest.mark.parametrize("g,isotropic", [(0.6, False), (-0.4, False), (0.0, False), (0.7, True)])
+def test_phase_function_mean_cosine(ctx, cpm, g, isotropic):
+    """Multiple scattering: the direction after the first scatter event, read back from the second interaction's
+    record (its encoded direction; a sentinel carries it too), against the phase function's first moment -- E[cos] = g for
+    Henyey-Greenstein, 0 for isotropic scattering -- and the scattered fraction against the albedo (scattering TF = TF: 1/2)."""
+    S, P, B = cpm.synthetic, cpm.pipeline, cpm.binding
+    torch = ctx.torch
+    direction = (0.3, 0.5, -1.0)
+    fr = P.PhotonFrame(ctx, S.homogeneous_volume(64, 128), S.homogeneous_tf(0.05), 768, (32,) * 3, light_travel_direction=direction,
+                       max_interactions=2, material=(g, 0.0, 0.0, 0.0),
+                       shading_type=B.CPM_PHASE_ISOTROPIC if isotropic else B.CPM_PHASE_HENYEY_GREENSTEIN)
+    fr.trace()
+    torch.cuda.synchronize()
+    ph = fr.photons.cpu().numpy().reshape(2, fr.n, 8)
+    first_real = ph[0, :, 0] != FLT_MAX
+    d0 = np.asarray(P._normalize(direction), np.float64)
+    th, phi = ph[1, :, 6].astype(np.float64), ph[1, :, 7].astype(np.float64)
+    d1 = np.stack([np.sin(th) * np.cos(phi), np.sin(th) * np.sin(phi), np.cos(th)], 1)
+    cos = d1 @ d0
+    scattered = first_real & (cos < 1.0 - 1e-6)          # the record after an absorption keeps the light's direction
+    n_coll = int(first_real.sum())
+    frac = scattered.sum() / n_coll
+    assert n_coll > 100_000 and abs(frac - 0.5) < 4.0 * math.sqrt(0.25 / n_coll) + 1e-3, frac
+    want = 0.0 if isotropic else g
+    assert abs(cos[scattered].mean() - want) < 4.0 / math.sqrt(scattered.sum()) + 2e-3, (cos[scattered].mean(), want)
