@@ -685,6 +685,8 @@ def main():
                                        + f", transport {type(transport).__name__}"
                                        + (f" [{transport_note}]" if transport_note else "")) if world > 1 else "single GPU",
                        "launch": "captured HIP graph replay" if use_graph else "eager launches",
+                       "trace_workgroup_order": "costliest chunks first, from the costs a measured launch recorded (cpm_trace_order: the first "
+                                                "frame and every 256th are measured)" if getattr(fr, "adaptive_order", False) else "lattice order",
                        "shards": (f"4096-sample lattice tiles dealt round-robin (rank r: tiles t = r mod {world})" if args.shards == "tiles"
                                   else "contiguous photon ranges (slabs of the light plane)") if world > 1 else "one shard",
                        # the transport the reduce really used, and the size RCCL itself reports for the communicator
