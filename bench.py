@@ -256,6 +256,10 @@ def main():
     ap.add_argument("--collective", default="allreduce", choices=["allreduce", "reduce"],
                     help="N > 1: every rank receives the summed light volume (cpm_allreduce_grid, default) or only rank 0, the "
                          "display GPU (cpm_reduce_grid: half the wire traffic of a ring all-reduce)")
+    ap.add_argument("--reduce", default="sparse", choices=["sparse", "dense"],
+                    help="N > 1, full frames: sum only the union of the ranks' non-zero 4x4x4 bricks (cpm_allreduce_grid_sparse: "
+                         "mask max-reduce + packed payload sized on the host from the union two frames before; no stream "
+                         "synchronisation; default) or the whole grid (cpm_allreduce_grid)")
     ap.add_argument("--test-backend", default="nccl", choices=["nccl", "gloo"],
                     help="(testing) process-group backend; gloo lets the N > 1 code path run with every rank on one GPU")
     ap.add_argument("--test-one-device", action="store_true", help="(testing) every rank uses cuda:0")
@@ -355,6 +359,9 @@ def main():
         fr.touched_mask = torch.zeros(((gdim + 3) // 4) ** 3, dtype=torch.uint8, device=ctx.device)
         fractions = []
         step_no = [0]
+        delta_sr = ctx.sparse_reduce_create(transport.comm, fr.grid) if world > 1 and isinstance(transport, sharding.RcclTransport) else None
+        delta_pending = []
+        reduce_info = []
 
         def step():
             t = 1 + step_no[0] % (n_steps - 1)
@@ -363,14 +370,19 @@ def main():
             fr.touched_mask.zero_()
             n = fr.correlated_update()
             fractions.append(n / max(fr.n, 1))
-            if world > 1 and isinstance(transport, sharding.RcclTransport):
-                # the delta path: only bricks touched by a re-traced photon (old or new position) changed on any rank
-                ctx.allreduce_grid_bricks(transport.comm, fr.light_volume, total_grid, fr.grid, fr.touched_mask)
+            if delta_sr is not None:
+                # the delta path: only bricks touched by a re-traced photon (old or new position) changed on any rank; the
+                # previous step's ticket is completed here (its count has long arrived), this step's at the next one
+                while delta_pending:
+                    reduce_info.append(delta_sr.complete(delta_pending.pop()))
+                delta_pending.append(delta_sr.start(fr.light_volume, total_grid, brick_mask=fr.touched_mask))
             elif world > 1:
                 total_grid.copy_(fr.light_volume)
                 sharding.allreduce_light_volume(total_grid, transport)
 
         def barrier():
+            while delta_pending:
+                reduce_info.append(delta_sr.complete(delta_pending.pop()))
             torch.cuda.synchronize()
             if dist is not None:
                 dist.barrier()
@@ -383,7 +395,10 @@ def main():
             fr.capture()
         # the sum of the per-rank grids overlaps the next frame's trace and bin (double-buffered grids,
         # sharding.OverlappedGridReducer); everything outstanding is waited for inside the timed region
-        reducer = sharding.OverlappedGridReducer(fr.light_volume, transport)
+        sparse = None
+        if args.reduce == "sparse" and world > 1 and not use_graph:
+            sparse = fr.grid if isinstance(transport, sharding.RcclTransport) else ((gdim,) * 3, 1)
+        reducer = sharding.OverlappedGridReducer(fr.light_volume, transport, sparse=sparse)
         frame_no = [0]
 
         def step():
@@ -603,6 +618,34 @@ def main():
                 "measured": "libcpm_host.so: VolumeSequencePlayer + 2 UniformGrid3D players (players_ms); importance (time-varying) -> tracer -> light volume (update_ms)"}
             net.close(); seq.close()
             del seq_np
+        # the sparse full-frame reduce's own work on ONE GPU (a real RCCL communicator of size 1: mask, list, pack, unpack run;
+        # the two collectives are what N > 1 adds): what it costs beside a frame, and what it would put on the wire
+        if fast:
+            try:
+                tr1 = sharding.RcclTransport(ctx, 0, 1)
+                red1 = sharding.OverlappedGridReducer(fr.light_volume, tr1, sparse=fr.grid, force=True)
+                kf = [0]
+
+                def frame_with_reduce():
+                    fr.trace(); fr.bin_fast(); fr.gather_fast(out=red1.acquire(kf[0])); red1.reduce(kf[0]); kf[0] += 1
+                ms_red = timed(torch, frame_with_reduce, reps)
+                ctx.profile_reset(); ctx.profile_enable(True)
+                for _ in range(20):
+                    frame_with_reduce()
+                red1.flush(); torch.cuda.synchronize()
+                kk = ctx.profile_collect(); ctx.profile_enable(False)
+                last = red1.info[-1]
+                extras["sparse_reduce_one_gpu"] = {
+                    "ms_per_frame_with_reduce_chain": round(ms_red, 4),
+                    "kernel_us": {k: round(tot / calls * 1e3, 2) for k, (tot, calls) in kk.items() if k.startswith("brick_") or "brick_" in k.split("<")[0]},
+                    "n_bricks_4x4x4": last["n_bricks"], "n_union": last["n_union"], "capacity": last["capacity"], "mode": last["mode"],
+                    "reduce_bytes_per_frame": last["reduce_bytes"], "dense_bytes": last["dense_bytes"],
+                    "fraction_of_dense": round(last["reduce_bytes"] / last["dense_bytes"], 4),
+                    "host_waits": "none on the stream: the union count reaches the host through a pinned mailbox two frames later",
+                    "note": "communicator of size 1 on this GPU: pack / unpack / mask / list launches measured, the two collectives are no-ops"}
+                tr1.close()
+            except Exception as e:  # noqa: BLE001
+                extras["sparse_reduce_one_gpu"] = {"error": str(e)[:200]}
         # S independent frames in flight on S streams (each frame owns its context, buffers and stream)
         if args.streams > 1:
             ctxs = [B.Context(local_rank) for _ in range(args.streams)]
@@ -678,8 +721,10 @@ def main():
                        "formulation": what, "photons_per_frame": n_total, "photons_rank0": n_rank, "volume": [vdim] * 3,
                        "light_volume": [gdim] * 3,
                        "parallelism": (f"photon-sharded x{world} ({scaling} scaling), one "
-                                       + ("touched-brick reduce (cpm_allreduce_grid_bricks)" if correlated else
-                                          ("all-reduce of the grid per frame (cpm_allreduce_grid" if root is None else "reduce of the grid to rank 0 per frame (cpm_reduce_grid")
+                                       + ("touched-brick reduce (cpm_allreduce_grid_sparse with the touched-brick mask)" if correlated else
+                                          (("sparse " if reducer.sparse else "") + ("all-reduce" if root is None else "reduce to rank 0")
+                                           + " of the grid per frame (" + ("cpm_allreduce_grid_sparse" if reducer.sparse else
+                                                                            "cpm_allreduce_grid" if root is None else "cpm_reduce_grid"))
                                           + ": RCCL on a side stream), overlapped with the next "
                                           "frame's trace + bin (double-buffered grid)")
                                        + f", transport {type(transport).__name__}"
@@ -707,6 +752,24 @@ def main():
             out["frame"]["gsamples_per_s"] = round(woodcock_steps / max(stages["trace"], 1e-9) / 1e6, 3)
         if correlated:
             out["frame"]["fraction_retraced"] = round(float(np.mean(fractions[-args.steps:])), 5)
+        infos = None
+        if correlated and reduce_info:
+            infos = [{"n_union": i.n_union, "capacity": i.capacity, "mode": i.mode, "reduce_bytes": i.reduce_bytes, "dense_bytes": i.dense_bytes,
+                      "n_bricks": i.n_bricks} for i in reduce_info]
+        elif not correlated and reducer.sparse and reducer.info:
+            infos = reducer.info
+        if infos:
+            tail = infos[-args.steps:]
+            out["reduce"] = {"kind": "sparse: union of the ranks' " + ("touched" if correlated else "non-zero") + " 4x4x4 bricks (cpm_allreduce_grid_sparse)",
+                             "reduce_bytes_per_frame": int(np.median([i["reduce_bytes"] for i in tail])),
+                             "dense_bytes": int(tail[-1]["dense_bytes"]), "n_bricks": int(tail[-1]["n_bricks"]),
+                             "n_union_median": int(np.median([i["n_union"] for i in tail])),
+                             "capacity_median": int(np.median([i["capacity"] for i in tail])),
+                             "frames_sparse": int(sum(i["mode"] == 0 for i in tail)), "frames_dense_by_policy": int(sum(i["mode"] == 1 for i in tail)),
+                             "frames_dense_after_overflow": int(sum(i["mode"] == 2 for i in tail)),
+                             "stream_synchronisations_per_frame": 0}
+        elif world > 1:
+            out["reduce"] = {"kind": "dense", "reduce_bytes_per_frame": gdim ** 3 * 4, "dense_bytes": gdim ** 3 * 4}
         out.update(extras)
         if world == 1 and not args.no_cpu_baseline and not correlated:
             out["cpu_baseline"] = cpu_baseline(args.workload, vol_np, tf, lattice, gdim)

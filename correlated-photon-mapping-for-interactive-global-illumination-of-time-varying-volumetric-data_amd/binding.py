@@ -45,6 +45,8 @@ ABI_SYMBOLS = [
     "cpm_mix_buffers", "cpm_volume_mix",
     "cpm_comm_get_unique_id", "cpm_comm_create", "cpm_comm_create_all", "cpm_comm_destroy", "cpm_comm_rank", "cpm_comm_size",
     "cpm_allreduce_grid", "cpm_reduce_grid", "cpm_allreduce_grids", "cpm_allreduce_grid_bricks",
+    "cpm_sparse_reduce_create", "cpm_sparse_reduce_destroy", "cpm_sparse_reduce_bricks", "cpm_sparse_reduce_capacity_for",
+    "cpm_allreduce_grid_sparse", "cpm_sparse_reduce_complete",
     "cpm_light_volume_texels", "cpm_gl_available", "cpm_gl_register_buffer", "cpm_gl_acquire", "cpm_gl_release",
     "cpm_gl_buffer_pointer", "cpm_gl_copy_to_buffer", "cpm_gl_unregister",
 ]
@@ -79,6 +81,12 @@ class TraceOrder:
         if self.h:
             self.ctx.lib.cpm_trace_order_destroy(self.ctx.h, self.h)
             self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class GLResource:
@@ -118,6 +126,12 @@ class TraceParams(C.Structure):
 
 
 CPM_EMIT_DIRECTIONAL, CPM_EMIT_POINT = 0, 1
+
+
+class SparseReduceInfo(C.Structure):
+    """cpm_sparse_reduce_info"""
+    _fields_ = [("ticket", C.c_uint64), ("n_bricks", C.c_uint32), ("n_union", C.c_uint32), ("capacity", C.c_uint32), ("mode", C.c_int),
+                ("reduce_bytes", C.c_uint64), ("dense_bytes", C.c_uint64)]
 
 
 class EmitterDesc(C.Structure):
@@ -238,6 +252,12 @@ def load_library() -> C.CDLL:
         "cpm_reduce_grid": (i32, [vp, vp, vp, vp, sz, i32, vp]),
         "cpm_allreduce_grids": (i32, [P(vp), P(vp), P(vp), sz, P(vp), i32]),
         "cpm_allreduce_grid_bricks": (i32, [vp, vp, vp, vp, P(GridDesc), vp, P(u32), vp]),
+        "cpm_sparse_reduce_create": (i32, [vp, vp, P(GridDesc), P(vp)]),
+        "cpm_sparse_reduce_destroy": (None, [vp]),
+        "cpm_sparse_reduce_bricks": (u32, [vp]),
+        "cpm_sparse_reduce_capacity_for": (u32, [u32, C.c_longlong]),
+        "cpm_allreduce_grid_sparse": (i32, [vp, vp, vp, vp, vp, i32, u32, P(C.c_uint64), vp]),
+        "cpm_sparse_reduce_complete": (i32, [vp, vp, C.c_uint64, vp, P(SparseReduceInfo)]),
         "cpm_gl_available": (i32, [vp]),
         "cpm_gl_register_buffer": (i32, [vp, u32, i32, P(vp)]),
         "cpm_light_volume_texels": (i32, [vp, vp, sz, i32, vp, vp]),
@@ -264,6 +284,7 @@ def load_library() -> C.CDLL:
         "cpm_debug_set_sort_mode": (None, [vp, i32]),
         "cpm_debug_set_sort_items": (None, [vp, i32]),
         "cpm_debug_set_stream_wg_per_cu": (None, [vp, i32]),
+        "cpm_debug_fail_next_select": (None, [vp, i32]),
         "cpm_profile_enable": (None, [vp, i32]),
         "cpm_profile_reset": (None, [vp]),
         "cpm_profile_collect": (i32, [vp]),
@@ -554,6 +575,11 @@ class Context:
                                                        self._ptr(brick_mask), C.byref(n_union), self._stream()))
         return int(n_union.value)
 
+    def sparse_reduce_create(self, comm: "Comm", grid: GridDesc) -> "SparseReduce":
+        h = C.c_void_p()
+        self._check(self.lib.cpm_sparse_reduce_create(self.h, comm.h, C.byref(grid), C.byref(h)))
+        return SparseReduce(self, comm, h)
+
     # -- launch order of the trace
     def trace_order_create(self, n_light_samples: int) -> "TraceOrder":
         return TraceOrder(self, n_light_samples)
@@ -713,6 +739,44 @@ class Selection:
     def close(self):
         if self.h:
             self.ctx.lib.cpm_selection_destroy(self.ctx.h, self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class SparseReduce:
+    """cpm_sparse_reduce: the sum of the ranks' light volumes over the union of their non-zero 4x4x4 bricks, enqueued without
+    a host wait (cpm.h, cpm_allreduce_grid_sparse)."""
+
+    def __init__(self, ctx: "Context", comm: "Comm", h):
+        self.ctx, self.comm, self.h = ctx, comm, h
+
+    @property
+    def n_bricks(self) -> int:
+        return int(self.ctx.lib.cpm_sparse_reduce_bricks(self.h))
+
+    def start(self, partial, total=None, brick_mask=None, root: int = -1, capacity: int = 0) -> int:
+        """Enqueue on the current stream; returns the ticket."""
+        ticket = C.c_uint64(0)
+        tot = partial if total is None else total
+        self.ctx._check(self.ctx.lib.cpm_allreduce_grid_sparse(self.ctx.h, self.h, self.ctx._ptr(partial), self.ctx._ptr(tot),
+                                                               self.ctx._ptr(brick_mask) if brick_mask is not None else None,
+                                                               root, capacity, C.byref(ticket), self.ctx._stream()))
+        return int(ticket.value)
+
+    def complete(self, ticket: int) -> SparseReduceInfo:
+        """Before `total` of the ticket is read (on the current stream): the dense sum after an overflow; the ticket's figures."""
+        info = SparseReduceInfo()
+        self.ctx._check(self.ctx.lib.cpm_sparse_reduce_complete(self.ctx.h, self.h, ticket, self.ctx._stream(), C.byref(info)))
+        return info
+
+    def close(self):
+        if self.h:
+            self.ctx.lib.cpm_sparse_reduce_destroy(self.h)
             self.h = None
 
     def __del__(self):

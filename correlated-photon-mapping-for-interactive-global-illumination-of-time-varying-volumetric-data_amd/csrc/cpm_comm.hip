@@ -12,6 +12,7 @@
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 
+#include <chrono>
 #include <mutex>
 #include <new>
 
@@ -25,6 +26,33 @@ struct cpm_comm {
     // touched-brick reduce: union mask, compact payload, its size read back once per call
     uint32_t* d_count = nullptr;
     uint32_t* h_count = nullptr;
+};
+
+// cpm_allreduce_grid_sparse: everything one (communicator, grid shape) needs, allocated once
+struct cpm_sparse_reduce {
+    static constexpr int kSlots = 8;  // tickets in flight (issued, not yet completed)
+    cpm_comm* comm = nullptr;
+    int device = 0;
+    int dims[3] = { 0, 0, 0 }, channels = 1, bxn = 0, byn = 0, bzn = 0;
+    uint32_t nb = 0;
+    size_t cells = 0;
+    uint8_t* mask = nullptr;        // nb bytes (+ 16): this rank's bricks, then the union
+    uint32_t* list = nullptr;       // nb: union bricks, ascending
+    uint32_t* slot = nullptr;       // nb: brick -> position in the list
+    uint32_t* count = nullptr;      // device word: size of the union
+    float* payload = nullptr;       // nb * 64 * channels floats (the dense size: any capacity fits)
+    unsigned long long* mailbox = nullptr;      // pinned host, kSlots words: ticket << 32 | union count
+    unsigned long long* mailbox_dev = nullptr;
+    uint64_t next_ticket = 1;
+    struct Slot {
+        uint64_t ticket = 0;
+        const float* partial = nullptr; float* total = nullptr;
+        int root = -1; uint32_t capacity = 0; bool dense = false, completed = true;
+        uint32_t n_union = 0; bool known = false;
+        hipStream_t stream = nullptr;
+    } slots[kSlots];
+    uint32_t last_union[2] = { 0, 0 };  // union counts of the two most recent tickets whose mailbox has been read, [0] the older
+    uint64_t last_union_ticket = 0;
 };
 
 namespace {
@@ -126,6 +154,172 @@ __global__ __launch_bounds__(64) void brick_copy_kernel(const uint32_t* __restri
         const size_t p = ((size_t)blockIdx.x * 64 + l) * channels + c;
         if (PACK) packed[p] = in ? grid_in[v * channels + c] : 0.f;
         else if (in) grid_out[v * channels + c] = packed[p];
+    }
+}
+
+// ---- sparse, synchronisation-free reduce (cpm_allreduce_grid_sparse) ---------------------------------------------------
+// Bricks are 4 x 4 x 4 voxels, brick b = bx + ceil(dx/4) * (by + ceil(dy/4) * bz) (the numbering of
+// cpm_mark_touched_bricks).  Four short launches around two collectives, none of which the host waits for:
+//   brick_nonzero_kernel   this rank's bricks that hold a non-zero voxel -> byte mask            (or the caller's mask)
+//   [ncclAllReduce max]    the UNION of the ranks' masks: 1 byte per brick
+//   brick_slots_kernel     union mask -> ascending brick list + brick -> slot table + count; the count also goes to a pinned
+//                          host mailbox (ticket << 32 | count) -- the host reads it LATER, to size the following payloads
+//   brick_pack_kernel      the first min(count, capacity) bricks -> payload (zeros behind them); nothing when count > capacity
+//   [ncclAllReduce sum]    capacity * 64 * channels floats -- a size the host fixed BEFORE the launch
+//   brick_unpack_kernel    payload -> total (zeros or nothing elsewhere); nothing when count > capacity (the caller's
+//                          cpm_sparse_reduce_complete then enqueues the dense sum: `partial` is untouched)
+
+constexpr uint32_t kNoSlot = 0xffffffffu;
+
+// 16 lanes per brick, one row of 4 voxels each: a row = one 16-byte load (4 for 4 channels) when dx is a multiple of 4;
+// the 16 row flags of a brick are OR-ed across its lanes (4 shuffles), lane 0 of the brick writes the byte
+template <int CH, bool VEC>
+__global__ __launch_bounds__(256) void brick_nonzero_kernel(const float* __restrict__ grid, int dx, int dy, int dz, int bxn, int byn,
+                                                            uint32_t nb, uint8_t* __restrict__ mask) {
+    const uint32_t b = blockIdx.x * 16u + (threadIdx.x >> 4);
+    const int r = threadIdx.x & 15;
+    int any = 0;
+    if (b < nb) {
+        const int bx = (int)(b % (uint32_t)bxn), by = (int)((b / (uint32_t)bxn) % (uint32_t)byn), bz = (int)(b / (uint32_t)(bxn * byn));
+        const int y = by * 4 + (r & 3), z = bz * 4 + (r >> 2);
+        if (y < dy && z < dz) {
+            const size_t v = (size_t)(bx * 4) + (size_t)dx * ((size_t)y + (size_t)dy * (size_t)z);
+            if (VEC) {
+                const float4* q = reinterpret_cast<const float4*>(grid + v * CH);
+#pragma unroll
+                for (int c = 0; c < CH; ++c) { const float4 f = q[c]; any |= f.x != 0.f || f.y != 0.f || f.z != 0.f || f.w != 0.f; }
+            } else {
+                for (int x = 0; x < 4 && bx * 4 + x < dx; ++x)
+                    for (int c = 0; c < CH; ++c) any |= grid[(v + x) * CH + c] != 0.f;
+            }
+        }
+    }
+#pragma unroll
+    for (int off = 1; off < 16; off <<= 1) any |= __shfl_xor(any, off, 64);
+    if (r == 0 && b < nb) mask[b] = any ? 1 : 0;
+}
+
+// the non-zero bytes of a word as 0 / 1 bytes (a caller's mask may hold any non-zero value)
+CPM_DEV uint32_t nonzero_bytes(uint32_t w) { return ((w | ((w & 0x7f7f7f7fu) + 0x7f7f7f7fu)) & 0x80808080u) >> 7; }
+
+// union mask -> ascending list of its bricks, the inverse table slot[brick] (kNoSlot outside the union) and the count.
+// Workgroup g takes bricks [4096 g, 4096 g + 4096), 4 per lane (one word of the mask); what lies before its chunk it counts
+// itself (16-byte loads of at most nb bytes out of L2: no scan launch, no order between workgroups -- every rank derives the
+// same list from the same mask).  The last workgroup knows the total: it goes to the device word the pack / unpack launches
+// read and to the host's mailbox.  `mask` is readable (and ignored) up to the next multiple of 16 bytes.
+__global__ __launch_bounds__(1024) void brick_slots_kernel(const uint8_t* __restrict__ mask, uint32_t nb, uint32_t* __restrict__ list,
+                                                           uint32_t* __restrict__ slot, uint32_t* __restrict__ count,
+                                                           unsigned long long* mailbox, uint32_t ticket) {
+    __shared__ uint32_t s_w[16], s_p[16];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const uint32_t chunk = blockIdx.x * 4096u;
+    // my four bricks (requested first), then the bricks before the chunk
+    const uint32_t b0 = chunk + 4u * (uint32_t)t;
+    uint32_t w = b0 < nb ? *reinterpret_cast<const uint32_t*>(mask + b0) : 0u;
+    if (b0 + 4 > nb && b0 < nb) w &= 0xffffffffu >> (8u * (b0 + 4u - nb));  // bytes at and beyond nb do not exist
+    uint32_t before = 0;
+    for (uint32_t i = (uint32_t)t * 16u; i < chunk; i += 1024u * 16u) {
+        const uint4 m = *reinterpret_cast<const uint4*>(mask + i);
+        before += __popc(nonzero_bytes(m.x)) + __popc(nonzero_bytes(m.y)) + __popc(nonzero_bytes(m.z)) + __popc(nonzero_bytes(m.w));
+    }
+    const uint32_t nz = nonzero_bytes(w);
+    const uint32_t c = __popc(nz);
+    uint32_t incl = c, pre = before;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t o = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += o;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) pre += __shfl_xor(pre, off, 64);
+    if (lane == 63) s_w[wave] = incl;
+    if (lane == 0) s_p[wave] = pre;
+    __syncthreads();
+    uint32_t base = 0, total = 0;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) { base += s_p[q]; if (q < wave) base += s_w[q]; total += s_p[q] + s_w[q]; }
+    uint32_t pos = base + incl - c;
+    if (b0 < nb) {
+        uint32_t sl[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const bool in = (nz >> (8 * q)) & 1u;
+            sl[q] = in ? pos : kNoSlot;
+            if (in) list[pos++] = b0 + (uint32_t)q;
+        }
+        if (b0 + 4 <= nb) *reinterpret_cast<uint4*>(slot + b0) = make_uint4(sl[0], sl[1], sl[2], sl[3]);
+        else for (uint32_t q = 0; b0 + q < nb; ++q) slot[b0 + q] = sl[q];
+    }
+    if (blockIdx.x == gridDim.x - 1 && t == 0) {
+        *count = total;
+        if (mailbox) __hip_atomic_store(mailbox, ((unsigned long long)ticket << 32) | (unsigned long long)total, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
+// 16 lanes per brick, one row of 4 voxels each (a 16-byte piece of a grid row <-> a 16-byte piece of the payload, whose
+// bricks are 64 * CH consecutive floats in (z, y, x, channel) order)
+template <int CH, bool VEC>
+__global__ __launch_bounds__(256) void brick_pack_kernel(const uint32_t* __restrict__ list, const uint32_t* __restrict__ count, uint32_t capacity,
+                                                         int dx, int dy, int dz, int bxn, int byn, const float* __restrict__ grid,
+                                                         float* __restrict__ payload) {
+    const uint32_t n = *count;
+    if (n > capacity) return;  // overflow: the dense sum follows (cpm_sparse_reduce_complete)
+    const uint32_t s = blockIdx.x * 16u + (threadIdx.x >> 4);
+    if (s >= capacity) return;
+    const int r = threadIdx.x & 15;
+    float4 f[CH];
+#pragma unroll
+    for (int c = 0; c < CH; ++c) f[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (s < n) {
+        const uint32_t b = list[s];
+        const int bx = (int)(b % (uint32_t)bxn), by = (int)((b / (uint32_t)bxn) % (uint32_t)byn), bz = (int)(b / (uint32_t)(bxn * byn));
+        const int y = by * 4 + (r & 3), z = bz * 4 + (r >> 2);
+        if (y < dy && z < dz) {
+            const size_t v = (size_t)(bx * 4) + (size_t)dx * ((size_t)y + (size_t)dy * (size_t)z);
+            if (VEC) {
+#pragma unroll
+                for (int c = 0; c < CH; ++c) f[c] = reinterpret_cast<const float4*>(grid + v * CH)[c];
+            } else {
+                float* ff = reinterpret_cast<float*>(f);
+                for (int x = 0; x < 4 && bx * 4 + x < dx; ++x)
+                    for (int c = 0; c < CH; ++c) ff[x * CH + c] = grid[(v + x) * CH + c];
+            }
+        }
+    }
+    float4* o = reinterpret_cast<float4*>(payload) + ((size_t)s * 16 + r) * CH;
+#pragma unroll
+    for (int c = 0; c < CH; ++c) o[c] = f[c];
+}
+
+// ZERO: 16 lanes per brick of the GRID (all of them) -- `total` is a separate buffer that must become the whole sum: a union
+// brick takes its sums from the payload, any other brick is zeroed.  Otherwise 16 lanes per brick of the UNION (the list):
+// everything else of `total` is left alone
+template <int CH, bool VEC, bool ZERO>
+__global__ __launch_bounds__(256) void brick_unpack_kernel(const uint32_t* __restrict__ list, const uint32_t* __restrict__ slot,
+                                                           const uint32_t* __restrict__ count, uint32_t capacity,
+                                                           uint32_t nb, int dx, int dy, int dz, int bxn, int byn,
+                                                           const float* __restrict__ payload, float* __restrict__ total) {
+    const uint32_t n = *count;
+    if (n > capacity) return;
+    const uint32_t i = blockIdx.x * 16u + (threadIdx.x >> 4);
+    uint32_t b, s;
+    if (ZERO) { if (i >= nb) return; b = i; s = slot[b]; }
+    else { if (i >= n) return; s = i; b = list[s]; }
+    const int r = threadIdx.x & 15;
+    const int bx = (int)(b % (uint32_t)bxn), by = (int)((b / (uint32_t)bxn) % (uint32_t)byn), bz = (int)(b / (uint32_t)(bxn * byn));
+    const int y = by * 4 + (r & 3), z = bz * 4 + (r >> 2);
+    if (y >= dy || z >= dz) return;
+    float4 f[CH];
+#pragma unroll
+    for (int c = 0; c < CH; ++c) f[c] = s == kNoSlot ? make_float4(0.f, 0.f, 0.f, 0.f) : reinterpret_cast<const float4*>(payload)[((size_t)s * 16 + r) * CH + c];
+    const size_t v = (size_t)(bx * 4) + (size_t)dx * ((size_t)y + (size_t)dy * (size_t)z);
+    if (VEC) {
+#pragma unroll
+        for (int c = 0; c < CH; ++c) reinterpret_cast<float4*>(total + v * CH)[c] = f[c];
+    } else {
+        const float* ff = reinterpret_cast<const float*>(f);
+        for (int x = 0; x < 4 && bx * 4 + x < dx; ++x)
+            for (int c = 0; c < CH; ++c) total[(v + x) * CH + c] = ff[x * CH + c];
     }
 }
 
@@ -300,6 +494,229 @@ int cpm_allreduce_grid_bricks(cpm_ctx* ctx, cpm_comm* comm, const float* partial
         CPM_NCCL_CHECK(ctx, R, R->AllReduce(packed, packed, packed_count, ncclFloat32, ncclSum, comm->comm, s));
     CPM_LAUNCH(ctx, brick_copy_kernel<false>, dim3(n_union), dim3(64), 0, s, list, gd->dims[0], gd->dims[1], gd->dims[2], gd->channels, bxn, byn, partial, total, packed);
     CPM_LAUNCH_CHECK(ctx, "brick_copy_kernel");
+    return CPM_OK;
+}
+
+// ---- cpm_allreduce_grid_sparse ------------------------------------------------------------------------------------------
+
+uint32_t cpm_sparse_reduce_capacity_for(uint32_t n_bricks, long long previous_union) {
+    if (n_bricks == 0) return 0;
+    unsigned long long c;
+    if (previous_union < 0) c = ((unsigned long long)n_bricks / 4 + 63ull) & ~63ull;                     // nothing known yet: a quarter
+    else c = ((unsigned long long)previous_union + (unsigned long long)previous_union / 4 + 64ull + 63ull) & ~63ull;  // + 25 % + 64
+    if (c * 2 > n_bricks) return n_bricks;  // beyond half of the bricks pack + sum + unpack move more than the dense sum
+    return (uint32_t)c;
+}
+
+int cpm_sparse_reduce_create(cpm_ctx* ctx, cpm_comm* comm, const cpm_grid_desc* gd, cpm_sparse_reduce** out) {
+    CPM_ENTER(ctx);
+    CPM_REQUIRE(ctx, comm && gd && out, "cpm_sparse_reduce_create: null argument");
+    CPM_REQUIRE(ctx, gd->channels == 1 || gd->channels == 4, "cpm_sparse_reduce_create: channels");
+    CPM_REQUIRE(ctx, gd->dims[0] >= 1 && gd->dims[1] >= 1 && gd->dims[2] >= 1, "cpm_sparse_reduce_create: dims");
+    CPM_REQUIRE(ctx, (unsigned long long)gd->dims[0] * gd->dims[1] * gd->dims[2] < (1ull << 31), "cpm_sparse_reduce_create: more than 2^31 cells");
+    *out = nullptr;
+    cpm_sparse_reduce* sr = new (std::nothrow) cpm_sparse_reduce();
+    if (!sr) return set_error(ctx, CPM_ERR_OUT_OF_MEMORY, "cpm_sparse_reduce_create", "host allocation failed");
+    sr->comm = comm; sr->device = ctx->device;
+    for (int a = 0; a < 3; ++a) sr->dims[a] = gd->dims[a];
+    sr->channels = gd->channels;
+    sr->bxn = div_up(gd->dims[0], 4); sr->byn = div_up(gd->dims[1], 4); sr->bzn = div_up(gd->dims[2], 4);
+    sr->nb = (uint32_t)((size_t)sr->bxn * sr->byn * sr->bzn);
+    sr->cells = (size_t)gd->dims[0] * gd->dims[1] * gd->dims[2];
+    const size_t nb = sr->nb;
+    const bool ok = hipMalloc((void**)&sr->mask, nb + 16) == hipSuccess && hipMalloc((void**)&sr->list, nb * 4) == hipSuccess &&
+                    hipMalloc((void**)&sr->slot, nb * 4) == hipSuccess && hipMalloc((void**)&sr->count, 16) == hipSuccess &&
+                    hipMalloc((void**)&sr->payload, nb * 64 * sizeof(float) * (size_t)sr->channels) == hipSuccess &&
+                    hipHostMalloc((void**)&sr->mailbox, cpm_sparse_reduce::kSlots * 8, hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess &&
+                    hipHostGetDevicePointer((void**)&sr->mailbox_dev, sr->mailbox, 0) == hipSuccess;
+    if (!ok) {
+        (void)hipGetLastError();
+        cpm_sparse_reduce_destroy(sr);
+        return set_error(ctx, CPM_ERR_OUT_OF_MEMORY, "cpm_sparse_reduce_create", "device / pinned allocation failed");
+    }
+    for (int i = 0; i < cpm_sparse_reduce::kSlots; ++i) sr->mailbox[i] = 0ull;
+    *out = sr;
+    return CPM_OK;
+}
+
+void cpm_sparse_reduce_destroy(cpm_sparse_reduce* sr) {
+    if (!sr) return;
+    (void)hipSetDevice(sr->device);
+    // the mailbox must outlive the launches that write it
+    for (auto& sl : sr->slots) if (sl.ticket && !sl.known) { (void)hipStreamSynchronize(sl.stream); break; }
+    if (sr->mask) (void)hipFree(sr->mask);
+    if (sr->list) (void)hipFree(sr->list);
+    if (sr->slot) (void)hipFree(sr->slot);
+    if (sr->count) (void)hipFree(sr->count);
+    if (sr->payload) (void)hipFree(sr->payload);
+    if (sr->mailbox) (void)hipHostFree(sr->mailbox);
+    delete sr;
+}
+
+uint32_t cpm_sparse_reduce_bricks(const cpm_sparse_reduce* sr) { return sr ? sr->nb : 0; }
+
+}  // extern "C"
+
+namespace {
+
+// the union count of an issued ticket: a poll of the pinned mailbox its brick_slots_kernel writes (work enqueued behind that
+// launch keeps running); after 2 s without it, the stream itself
+int sparse_union_count(cpm_ctx* ctx, cpm_sparse_reduce* sr, cpm_sparse_reduce::Slot& sl) {
+    if (sl.known) return CPM_OK;
+    const volatile unsigned long long* mb = sr->mailbox + (sl.ticket % cpm_sparse_reduce::kSlots);
+    const auto t0 = std::chrono::steady_clock::now();
+    bool synced = false;
+    for (unsigned spin = 0;; ++spin) {
+        const unsigned long long v = __atomic_load_n(mb, __ATOMIC_ACQUIRE);
+        if ((uint32_t)(v >> 32) == (uint32_t)sl.ticket) { sl.n_union = (uint32_t)v; sl.known = true; break; }
+        if (synced) return set_error(ctx, CPM_ERR_DEVICE, "cpm_sparse_reduce", "the union count of a ticket never arrived");
+        if ((spin & 1023u) == 1023u && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(2)) {
+            CPM_HIP_CHECK(ctx, hipStreamSynchronize(sl.stream));
+            synced = true;
+        }
+        __builtin_ia32_pause();
+    }
+    if (sl.ticket > sr->last_union_ticket) {
+        sr->last_union[0] = sr->last_union[1]; sr->last_union[1] = sl.n_union; sr->last_union_ticket = sl.ticket;
+    }
+    return CPM_OK;
+}
+
+int sparse_dense_sum(cpm_ctx* ctx, cpm_sparse_reduce* sr, const float* partial, float* total, int root, hipStream_t s) {
+    const size_t count = sr->cells * (size_t)sr->channels;
+    if (sr->comm->size == 1) {
+        if (total != partial) CPM_HIP_CHECK(ctx, hipMemcpyAsync(total, partial, count * sizeof(float), hipMemcpyDeviceToDevice, s));
+        return CPM_OK;
+    }
+    const Rccl* R = rccl(ctx);
+    if (!R) return CPM_ERR_UNSUPPORTED;
+    ProfScope ps(ctx, "rccl_sparse_dense_fallback", s);
+    if (root < 0) CPM_NCCL_CHECK(ctx, R, R->AllReduce(partial, total, count, ncclFloat32, ncclSum, sr->comm->comm, s));
+    else CPM_NCCL_CHECK(ctx, R, R->Reduce(partial, total, count, ncclFloat32, ncclSum, root, sr->comm->comm, s));
+    return CPM_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int cpm_allreduce_grid_sparse(cpm_ctx* ctx, cpm_sparse_reduce* sr, const float* partial, float* total, const uint8_t* brick_mask,
+                              int root, uint32_t capacity_bricks, uint64_t* ticket_out, cpm_stream stream) {
+    CPM_ENTER(ctx);
+    CPM_REQUIRE(ctx, sr && partial && total, "cpm_allreduce_grid_sparse: null argument");
+    CPM_REQUIRE(ctx, root < sr->comm->size, "cpm_allreduce_grid_sparse: root");
+    CPM_REQUIRE_ALIGNED16(ctx, partial, "cpm_allreduce_grid_sparse");
+    CPM_REQUIRE_ALIGNED16(ctx, total, "cpm_allreduce_grid_sparse");
+    CPM_REQUIRE(ctx, capacity_bricks <= sr->nb, "cpm_allreduce_grid_sparse: capacity beyond the number of bricks");
+    hipStream_t s = (hipStream_t)stream;
+    const uint64_t ticket = sr->next_ticket;
+    cpm_sparse_reduce::Slot& sl = sr->slots[ticket % cpm_sparse_reduce::kSlots];
+    CPM_REQUIRE(ctx, sl.completed, "cpm_allreduce_grid_sparse: 8 tickets issued and not completed (cpm_sparse_reduce_complete)");
+    // the payload's size is fixed HERE, on the host, from a union count every rank has read from its own mailbox and that is
+    // the same number on every rank (the union is): the count of ticket - 2, which has long been written when ticket is
+    // issued (its reduce had to finish before the caller could reuse that ticket's grid buffer)
+    uint32_t capacity = capacity_bricks;
+    if (capacity == 0) {
+        long long prev = -1;
+        if (ticket >= 3) {
+            cpm_sparse_reduce::Slot& old = sr->slots[(ticket - 2) % cpm_sparse_reduce::kSlots];
+            if (old.ticket == ticket - 2) { int rc = sparse_union_count(ctx, sr, old); if (rc) return rc; prev = (long long)old.n_union; }
+        }
+        capacity = cpm_sparse_reduce_capacity_for(sr->nb, prev);
+    }
+    const bool dense = capacity >= sr->nb;
+    const Rccl* R = sr->comm->size > 1 ? rccl(ctx) : nullptr;
+    if (sr->comm->size > 1 && !R) return CPM_ERR_UNSUPPORTED;
+    const bool vec = (sr->dims[0] & 3) == 0;
+    const int dx = sr->dims[0], dy = sr->dims[1], dz = sr->dims[2];
+    uint8_t* mask = sr->mask;
+    // 1. this rank's bricks
+    if (brick_mask) {
+        CPM_HIP_CHECK(ctx, hipMemcpyAsync(mask, brick_mask, sr->nb, hipMemcpyDeviceToDevice, s));
+    } else {
+        const dim3 g((unsigned)div_up(sr->nb, 16));
+        if (sr->channels == 1) {
+            if (vec) CPM_LAUNCH(ctx, (brick_nonzero_kernel<1, true>), g, dim3(256), 0, s, partial, dx, dy, dz, sr->bxn, sr->byn, sr->nb, mask);
+            else CPM_LAUNCH(ctx, (brick_nonzero_kernel<1, false>), g, dim3(256), 0, s, partial, dx, dy, dz, sr->bxn, sr->byn, sr->nb, mask);
+        } else {
+            if (vec) CPM_LAUNCH(ctx, (brick_nonzero_kernel<4, true>), g, dim3(256), 0, s, partial, dx, dy, dz, sr->bxn, sr->byn, sr->nb, mask);
+            else CPM_LAUNCH(ctx, (brick_nonzero_kernel<4, false>), g, dim3(256), 0, s, partial, dx, dy, dz, sr->bxn, sr->byn, sr->nb, mask);
+        }
+        CPM_LAUNCH_CHECK(ctx, "brick_nonzero_kernel");
+    }
+    // 2. the union
+    if (sr->comm->size > 1) {
+        ProfScope ps(ctx, "rccl_sparse_mask", s);
+        CPM_NCCL_CHECK(ctx, R, R->AllReduce(mask, mask, sr->nb, ncclUint8, ncclMax, sr->comm->comm, s));
+    }
+    // 3. list, slots, count (-> mailbox)
+    CPM_LAUNCH(ctx, brick_slots_kernel, dim3((unsigned)div_up(sr->nb, 4096)), dim3(1024), 0, s, mask, sr->nb, sr->list, sr->slot, sr->count,
+               sr->mailbox_dev + (ticket % cpm_sparse_reduce::kSlots), (uint32_t)ticket);
+    CPM_LAUNCH_CHECK(ctx, "brick_slots_kernel");
+    if (dense) {
+        int rc = sparse_dense_sum(ctx, sr, partial, total, root, s);
+        if (rc) return rc;
+    } else {
+        // 4. pack -> sum -> unpack, all sized by `capacity`
+        const dim3 pg((unsigned)div_up(capacity, 16));
+#define CPM_SPARSE_PACK(CH, VEC) CPM_LAUNCH(ctx, (brick_pack_kernel<CH, VEC>), pg, dim3(256), 0, s, sr->list, sr->count, capacity, dx, dy, dz, sr->bxn, sr->byn, partial, sr->payload)
+        if (sr->channels == 1) { if (vec) CPM_SPARSE_PACK(1, true); else CPM_SPARSE_PACK(1, false); }
+        else { if (vec) CPM_SPARSE_PACK(4, true); else CPM_SPARSE_PACK(4, false); }
+#undef CPM_SPARSE_PACK
+        CPM_LAUNCH_CHECK(ctx, "brick_pack_kernel");
+        const size_t n = (size_t)capacity * 64 * (size_t)sr->channels;
+        if (sr->comm->size > 1) {
+            ProfScope ps(ctx, "rccl_sparse_payload", s);
+            if (root < 0) CPM_NCCL_CHECK(ctx, R, R->AllReduce(sr->payload, sr->payload, n, ncclFloat32, ncclSum, sr->comm->comm, s));
+            else CPM_NCCL_CHECK(ctx, R, R->Reduce(sr->payload, sr->payload, n, ncclFloat32, ncclSum, root, sr->comm->comm, s));
+        }
+        if (root < 0 || root == sr->comm->rank) {
+            // a separate `total` becomes the whole sum (zeros outside the union) unless the caller's mask says which bricks
+            // changed: then everything else of `total` still holds (the delta path)
+            const bool zero = total != partial && !brick_mask;
+            const dim3 ug((unsigned)div_up(zero ? sr->nb : capacity, 16));
+#define CPM_SPARSE_UNPACK(CH, VEC, ZERO) CPM_LAUNCH(ctx, (brick_unpack_kernel<CH, VEC, ZERO>), ug, dim3(256), 0, s, sr->list, sr->slot, sr->count, capacity, sr->nb, dx, dy, dz, sr->bxn, sr->byn, sr->payload, total)
+            if (sr->channels == 1) {
+                if (vec) { if (zero) CPM_SPARSE_UNPACK(1, true, true); else CPM_SPARSE_UNPACK(1, true, false); }
+                else { if (zero) CPM_SPARSE_UNPACK(1, false, true); else CPM_SPARSE_UNPACK(1, false, false); }
+            } else {
+                if (vec) { if (zero) CPM_SPARSE_UNPACK(4, true, true); else CPM_SPARSE_UNPACK(4, true, false); }
+                else { if (zero) CPM_SPARSE_UNPACK(4, false, true); else CPM_SPARSE_UNPACK(4, false, false); }
+            }
+#undef CPM_SPARSE_UNPACK
+            CPM_LAUNCH_CHECK(ctx, "brick_unpack_kernel");
+        }
+    }
+    sl = cpm_sparse_reduce::Slot();
+    sl.ticket = ticket; sl.partial = partial; sl.total = total; sl.root = root; sl.capacity = capacity; sl.dense = dense;
+    sl.completed = false; sl.stream = s;
+    sr->next_ticket = ticket + 1;
+    if (ticket_out) *ticket_out = ticket;
+    return CPM_OK;
+}
+
+int cpm_sparse_reduce_complete(cpm_ctx* ctx, cpm_sparse_reduce* sr, uint64_t ticket, cpm_stream stream, cpm_sparse_reduce_info* info) {
+    CPM_ENTER(ctx);
+    CPM_REQUIRE(ctx, sr && ticket >= 1 && ticket < sr->next_ticket, "cpm_sparse_reduce_complete: no such ticket");
+    cpm_sparse_reduce::Slot& sl = sr->slots[ticket % cpm_sparse_reduce::kSlots];
+    CPM_REQUIRE(ctx, sl.ticket == ticket, "cpm_sparse_reduce_complete: the ticket is more than 8 calls old");
+    int rc = sparse_union_count(ctx, sr, sl);
+    if (rc) return rc;
+    int mode = sl.dense ? 1 : 0;
+    if (!sl.completed && !sl.dense && sl.n_union > sl.capacity) {
+        // more bricks than the payload was sized for: pack and unpack did nothing (every rank took the same decision from the
+        // same count), `partial` is as it was -- the dense sum, behind the sparse chain on the caller's stream
+        rc = sparse_dense_sum(ctx, sr, sl.partial, sl.total, sl.root, (hipStream_t)stream);
+        if (rc) return rc;
+    }
+    if (!sl.dense && sl.n_union > sl.capacity) mode = 2;
+    sl.completed = true;
+    if (info) {
+        const uint64_t brick_bytes = 64ull * sizeof(float) * (uint64_t)sr->channels;
+        info->ticket = ticket; info->n_bricks = sr->nb; info->n_union = sl.n_union; info->capacity = sl.capacity; info->mode = mode;
+        info->dense_bytes = (uint64_t)sr->cells * sizeof(float) * (uint64_t)sr->channels;
+        info->reduce_bytes = (uint64_t)sr->nb + (mode != 1 ? (uint64_t)sl.capacity * brick_bytes : 0ull) + (mode != 0 ? info->dense_bytes : 0ull);
+    }
     return CPM_OK;
 }
 

@@ -372,7 +372,8 @@ int cpm_tf_update(cpm_ctx* ctx, cpm_tf* tf, const float* rgba, int is_device, cp
         if (ctx->tf_stage) (void)hipHostFree(ctx->tf_stage);
         ctx->tf_stage = nullptr;
         ctx->tf_stage_floats = 0;
-        CPM_HIP_CHECK(ctx, hipHostMalloc((void**)&ctx->tf_stage, cpm_ctx::kTfStageSlots * floats * sizeof(float), hipHostMallocMapped));
+        CPM_HIP_CHECK(ctx, hipHostMalloc((void**)&ctx->tf_stage, cpm_ctx::kTfStageSlots * floats * sizeof(float),
+                                         hipHostMallocMapped | hipHostMallocCoherent));  // the upload kernel reads a slot the CPU rewrote: never from a stale L2 line
         CPM_HIP_CHECK(ctx, hipHostGetDevicePointer((void**)&ctx->tf_stage_dev, ctx->tf_stage, 0));
         ctx->tf_stage_floats = floats;
         for (int i = 0; i < cpm_ctx::kTfStageSlots; ++i)

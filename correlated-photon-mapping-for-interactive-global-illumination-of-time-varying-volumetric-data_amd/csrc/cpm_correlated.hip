@@ -32,6 +32,7 @@ struct cpm_selection {
     bool measuring = false;           // this selection's retrace launches record what their tiles cost
     uint32_t epoch = 0;               // of the last cpm_selection_finish enqueued
     bool finished = false;            // a finish has been enqueued since begin
+    bool failed = false;              // a select / retrace call since begin failed after its tiles were appended: the finish publishes 0
     hipStream_t last_stream = nullptr;
 };
 
@@ -817,6 +818,7 @@ extern "C" {
 // test hook (include/cpm/cpm_profile.h): 1 (default) = streaming brick-row kernels where rows are 16-byte aligned
 void cpm_debug_set_brick_streaming(cpm_ctx* ctx, int on) { if (ctx) ctx->dbg.brick_streaming = on; }  // 0 = always the per-brick kernels
 void cpm_debug_set_select_partition(cpm_ctx* ctx, int on) { if (ctx) ctx->dbg.select_partition = on; }  // 0 = the radix-pass form
+void cpm_debug_fail_next_select(cpm_ctx* ctx, int on) { if (ctx) ctx->dbg.fail_next_select = on; }
 
 int cpm_volume_minmax(cpm_ctx* ctx, const cpm_volume* vol, int region, uint16_t* minmax2, cpm_stream stream) {
     CPM_ENTER(ctx);
@@ -1107,6 +1109,7 @@ int cpm_selection_begin(cpm_ctx* ctx, cpm_selection* s) {
     s->n_launches = 0;
     s->pending_orders.clear();
     s->finished = false;
+    s->failed = false;
     // every kMeasureEvery-th selection records what its retrace tiles cost (the photon paths the cost depends on change slowly)
     constexpr uint32_t kMeasureEvery = 32;
     s->measuring = s->selections % kMeasureEvery == 0;
@@ -1129,6 +1132,26 @@ int selection_append(cpm_ctx* ctx, cpm_selection* s, int photon_offset, int n_li
     s->n_tiles += *tiles;
     return CPM_OK;
 }
+
+// What a select / retrace call appended is taken back unless the call reaches its end: tiles no launch wrote must never reach
+// selection_compact_kernel (it would sum uninitialised counts and copy garbage indices).  A selection with a failed call is
+// marked: cpm_selection_finish then publishes a count of 0 and reports the failure.
+struct AppendGuard {
+    cpm_selection* s; uint32_t n_tiles0, n_launches0; bool ok = false;
+    AppendGuard(cpm_selection* sel, uint32_t first) : s(sel), n_tiles0(first), n_launches0(sel->n_launches) {}
+    ~AppendGuard() { if (!ok) { s->n_tiles = n_tiles0; s->n_launches = n_launches0; s->failed = true; } }
+};
+
+#define CPM_INJECTED_SELECT_FAILURE(ctx, who)                                                                          \
+    do {                                                                                                             \
+        if ((ctx)->dbg.fail_next_select) {                                                                           \
+            (ctx)->dbg.fail_next_select = 0;                                                                         \
+            return set_error((ctx), CPM_ERR_DEVICE, who, "injected failure (cpm_debug_fail_next_select)");           \
+        }                                                                                                            \
+    } while (0)
+
+// LDS a select / retrace workgroup may ask for without an opt-in (occupancy bits + the tracer's LUTs + the static arrays)
+constexpr size_t kSelectLdsBudget = 64 * 1024 - 2048;
 
 // the occupancy bits a select / retrace launch stages in LDS: the caller's (cpm_selection_set_occupancy: made by the launch
 // that made the grid) or, failing that, built here by one small launch
@@ -1193,13 +1216,15 @@ int cpm_photon_importance_select(cpm_ctx* ctx, cpm_selection* s, const float* im
     uint32_t first = 0, tiles = 0;
     int rc = selection_append(ctx, s, photon_offset, n_light_samples, &first, &tiles);
     if (rc) return rc;
+    AppendGuard guard(s, first);
+    CPM_INJECTED_SELECT_FAILURE(ctx, "cpm_photon_importance_select");
     hipStream_t st = (hipStream_t)stream;
     s->last_stream = st;
     SelTiles S{ s->tile, s->local, first, s->per_tile };
     // occupancy mask of the grid: 1 bit per cell, staged in LDS by every workgroup (4 KiB for the 32^3 grid of a 256^3 volume);
-    // grids beyond 64 KiB of bits are walked without it
+    // grids whose bits do not fit the LDS budget are walked without it
     const size_t words = (size_t)((cells + 63) / 64) * 2;
-    const bool use_mask = words * 4 <= 64 * 1024;
+    const bool use_mask = words * 4 <= kSelectLdsBudget;
     if (use_mask) {
         const uint32_t* mask_bits = nullptr;
         rc = selection_mask(ctx, s, importance_grid, (long long)cells, words, st, &mask_bits);
@@ -1211,6 +1236,7 @@ int cpm_photon_importance_select(cpm_ctx* ctx, cpm_selection* s, const float* im
                                 total_photons, fix_exit_point, 1, 0, importances, S);
     }
     CPM_LAUNCH_CHECK(ctx, "importance_select_kernel");
+    guard.ok = true;
     return CPM_OK;
 }
 
@@ -1251,6 +1277,8 @@ int cpm_photon_importance_retrace(cpm_ctx* ctx, cpm_selection* s, const float* i
     uint32_t first = 0, tiles = 0;
     rc = selection_append(ctx, s, p.photon_offset, p.n_light_samples, &first, &tiles, kRetraceTile);
     if (rc) return rc;
+    AppendGuard guard(s, first);
+    CPM_INJECTED_SELECT_FAILURE(ctx, "cpm_photon_importance_retrace");
     hipStream_t st = (hipStream_t)stream;
     s->last_stream = st;
     SelTiles S{ s->tile, s->local, first, kRetraceTile };
@@ -1283,7 +1311,7 @@ int cpm_photon_importance_retrace(cpm_ctx* ctx, cpm_selection* s, const float* i
     A.photons = photons8;
     A.n_threads = p.n_light_samples;
     const size_t words = (size_t)((cells + 63) / 64) * 2;
-    const bool use_mask = words * 4 <= 64 * 1024;
+    const bool use_mask = words * 4 + lut_bytes <= kSelectLdsBudget;  // (the tracer's LUTs share the dynamic LDS)
     const uint32_t* mask_bits = nullptr;
     if (use_mask) {
         rc = selection_mask(ctx, s, importance_grid, (long long)cells, words, st, &mask_bits);
@@ -1308,6 +1336,7 @@ int cpm_photon_importance_retrace(cpm_ctx* ctx, cpm_selection* s, const float* i
 #undef CPM_RETRACE_LAUNCH
     CPM_LAUNCH_CHECK(ctx, "importance_retrace_kernel");
     if (tile_cost) s->pending_orders.push_back(ordinal);  // re-sorted behind the compaction (cpm_selection_finish)
+    guard.ok = true;
     return CPM_OK;
 }
 
@@ -1322,6 +1351,8 @@ int cpm_photon_importance_equal_select(cpm_ctx* ctx, cpm_selection* s, int photo
     uint32_t first = 0, tiles = 0;
     int rc = selection_append(ctx, s, photon_offset, n_light_samples, &first, &tiles);
     if (rc) return rc;
+    AppendGuard guard(s, first);
+    CPM_INJECTED_SELECT_FAILURE(ctx, "cpm_photon_importance_equal_select");
     hipStream_t st = (hipStream_t)stream;
     s->last_stream = st;
     SelTiles S{ s->tile, s->local, first, s->per_tile };
@@ -1329,6 +1360,7 @@ int cpm_photon_importance_equal_select(cpm_ctx* ctx, cpm_selection* s, int photo
     launch_select<1, false>(ctx, s, st, tiles, 0, G, nullptr, 0u, nullptr, photon_offset, nullptr, nullptr, n_light_samples, 1, 0, 0, percentage, iteration,
                             importances, S);
     CPM_LAUNCH_CHECK(ctx, "importance_select_kernel");
+    guard.ok = true;
     return CPM_OK;
 }
 
@@ -1341,10 +1373,17 @@ int cpm_selection_finish(cpm_ctx* ctx, cpm_selection* s, uint32_t* indices_out, 
     s->last_stream = st;
     s->finished = true;
     ++s->epoch;
+    // a selection one of whose calls failed selects nothing: what follows on the stream (re-trace, delta splat) then does nothing
+    // either, and the caller learns of it here -- and falls back to a full frame
+    const uint32_t n_tiles = s->failed ? 0u : s->n_tiles;
     // (with no tiles the one workgroup only publishes a count of 0)
-    CPM_LAUNCH(ctx, selection_compact_kernel, dim3(s->n_tiles ? (unsigned)div_up(s->n_tiles, kCompactGroup) : 1u), dim3(256), 0, st, s->tile, s->n_tiles,
+    CPM_LAUNCH(ctx, selection_compact_kernel, dim3(n_tiles ? (unsigned)div_up(n_tiles, kCompactGroup) : 1u), dim3(256), 0, st, s->tile, n_tiles,
                s->local, indices_out, s->count_dev, s->mailbox_dev, s->epoch);
     CPM_LAUNCH_CHECK(ctx, "selection_compact_kernel");
+    if (s->failed) {
+        s->pending_orders.clear();
+        return set_error(ctx, CPM_ERR_DEVICE, "cpm_selection_finish", "a select / retrace call of this selection failed: nothing is selected");
+    }
     // the measured launches' tile orders, costliest first -- behind everything the host waits for (a key launch + the radix sort)
     for (uint32_t ordinal : s->pending_orders) {
         cpm_selection::LaunchOrder& lo = s->orders[ordinal];

@@ -44,6 +44,7 @@ struct cpm_ctx {
         int sort_mode = 0, sort_items = 0;
         int brick_streaming = 1, select_partition = 1;
         int stream_wg_per_cu = -1;
+        int fail_next_select = 0;
     } dbg;
     struct cpm_trace_order* trace_order = nullptr;  // cpm_trace_set_order (not owned)
     bool trace_order_measure = false;               // ... and whether the launches add their costs to it

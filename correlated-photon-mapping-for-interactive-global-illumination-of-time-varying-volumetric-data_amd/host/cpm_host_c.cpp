@@ -7,6 +7,8 @@
 #include <cstring>
 #include <sstream>
 
+#include <cpm/cpm_profile.h>
+
 #include "cpm_modules.h"
 
 using namespace inviwo;
@@ -25,6 +27,13 @@ struct cpmh_network {
     TransferFunction tf;
     bool correlated = false;
     cpm_comm* comm = nullptr;  // cpmh_enable_shard_reduce
+    // further lights of the workspace ("Directional light source 2" -> "Directional light sampler 2" -> the tracer's LightSamples
+    // multi-inport, workspaces/CorrelatedPhotonMappingSingleVolume.inv:1068-1170,1255-1270): they share the sample generator
+    struct ExtraLight {
+        DataOutport<DirectionalLight> source{ "LightSource" };
+        DirectionalLightSamplerCLProcessor sampler;
+    };
+    std::vector<std::unique_ptr<ExtraLight>> extraLights;
     ~cpmh_network() { if (comm) cpm_comm_destroy(comm); }
 };
 
@@ -76,6 +85,34 @@ cpmh_network* cpmh_create(const void* voxels, int dtype, int dx, int dy, int dz,
 
 void cpmh_destroy(cpmh_network* net) { delete net; }
 
+// One more directional light feeding the tracer's multi-inport (one tracer launch per light, photonOffset = the photons of the
+// lights before it: progressivephotontracercl.cpp:481-527,543-549).  Before the first evaluation.  Returns the light's index.
+int cpmh_add_light(cpmh_network* net, const float light_position[3], const float light_direction[3]) {
+    if (!net) return -1;
+    auto e = std::make_unique<cpmh_network::ExtraLight>();
+    auto light = std::make_shared<DirectionalLight>();
+    light->position = vec3(light_position[0], light_position[1], light_position[2]);
+    light->direction = vec3(light_direction[0], light_direction[1], light_direction[2]);
+    e->source.setData(light);
+    e->sampler.boundingVolumePort_.connectTo(&net->proxyGeometry);
+    e->sampler.samplesPort_.connectTo(&net->sampleGenerator.samplesPort_);
+    e->sampler.lightsPort_.connectTo(&e->source);
+    net->tracer.lightSamples_.connectTo(&e->sampler.lightSamplesPort_);
+    net->extraLights.push_back(std::move(e));
+    return (int)net->extraLights.size();
+}
+int cpmh_n_lights(cpmh_network* net) { return net ? 1 + (int)net->extraLights.size() : 0; }
+// the clip ranges of CubeProxyGeometry, to which the tracer's clip properties are linked (workspace :393-420,740-757: clipX
+// 73..512 etc.), in voxels: the proxy mesh the light samplers intersect AND the tracer's box
+void cpmh_set_clip(cpmh_network* net, int x0, int x1, int y0, int y1, int z0, int z1) {
+    const size3_t d = net->volume->getDimensions();
+    net->proxyGeometry.setData(Mesh::box(vec3((float)x0 / (float)d.x, (float)y0 / (float)d.y, (float)z0 / (float)d.z),
+                                         vec3((float)x1 / (float)d.x, (float)y1 / (float)d.y, (float)z1 / (float)d.z)));
+    net->tracer.clipX_.set(ivec2{ x0, x1 }); net->tracer.clipY_.set(ivec2{ y0, y1 }); net->tracer.clipZ_.set(ivec2{ z0, z1 });
+}
+// test hook (cpm_profile.h): the next select / retrace launch of the tracer's importance branch fails after appending its tiles
+void cpmh_debug_fail_next_select(cpmh_network*) { cpm_debug_fail_next_select(CpmRuntime::get().ctx(), 1); }
+
 // Evaluate the network once, upstream first (what Inviwo's evaluator does on invalidation).
 // first != 0: everything (light samples included); else only what a TF edit / timer tick invalidates.
 int cpmh_evaluate(cpmh_network* net, int first) {
@@ -83,6 +120,7 @@ int cpmh_evaluate(cpmh_network* net, int first) {
     if (first) {
         net->sampleGenerator.process();
         net->lightSampler.process();
+        for (auto& e : net->extraLights) e->sampler.process();
         if (net->correlated) net->minMax.process();
     }
     if (net->correlated) net->importance.process();
@@ -136,7 +174,7 @@ const char* cpmh_last_tracer_decision(cpmh_network* net) { return net->tracer.la
 void cpmh_path_costs(cpmh_network* net, float out[4]) {
     net->tracer.pollCosts(); net->lightVolume.pollCosts();  // (what the next evaluation would pick up first)
     const auto& c = net->tracer.costs();
-    out[0] = c.fullTraceMs; out[1] = c.fullLightVolumeMs; out[2] = c.branchTraceMs; out[3] = c.branchLightVolumeMs;
+    out[0] = c.fullTraceMs; out[1] = c.fullLightVolumeMs; out[2] = c.branchTraceMs(); out[3] = c.branchLightVolumeMs();
 }
 // Multi-GPU call site, driven with a communicator of size 1 on this process's device (a real RCCL communicator: the
 // network's photons are then "the one shard", the outport carries the reduced volume).
@@ -172,6 +210,19 @@ void cpmh_light_plane(cpmh_network* net, float out[10]) {
     std::tie(o, u, v, area) = net->lightSampler.lightSampler_.lastPlane();
     const float t[10] = { o.x, o.y, o.z, u.x, u.y, u.z, v.x, v.y, v.z, area };
     memcpy(out, t, sizeof(t));
+}
+// ... of light `light` (0 = the network's first), and the direction its sampler used
+int cpmh_light_plane_of(cpmh_network* net, int light, float out[10], float dir[3]) {
+    if (!net || light < 0 || light > (int)net->extraLights.size()) return -1;
+    DirectionalLightSamplerCLProcessor& s = light == 0 ? net->lightSampler : net->extraLights[light - 1]->sampler;
+    auto src = light == 0 ? net->lightSource.getData() : net->extraLights[light - 1]->source.getData();
+    vec3 o, u, v; float area;
+    std::tie(o, u, v, area) = s.lightSampler_.lastPlane();
+    const float t[10] = { o.x, o.y, o.z, u.x, u.y, u.z, v.x, v.y, v.z, area };
+    memcpy(out, t, sizeof(t));
+    vec3 d = normalize(src->direction);
+    dir[0] = d.x; dir[1] = d.y; dir[2] = d.z;
+    return 0;
 }
 
 // direction the sampler used (normalised as the reference does) and the tracer's 1024-texel TF LUT
@@ -241,6 +292,25 @@ int cpmh_bench_full_frames(cpmh_network* net, int reps, double* out_ms) {
         if (hipDeviceSynchronize() != hipSuccess) return -2;
         out_ms[r] = now_ms() - t0;
     }
+    return 0;
+}
+
+// `reps` full frames enqueued back to back, ONE synchronisation at the end: the network's THROUGHPUT (what bench.py's headline
+// measures through the Python driver); cpmh_bench_full_frames above is its LATENCY from an idle device.  host_ms (nullable):
+// the host time the evaluations themselves took (enqueueing).
+int cpmh_bench_frames_back_to_back(cpmh_network* net, int reps, double* total_ms, double* host_ms) {
+    if (!net) return -1;
+    if (hipDeviceSynchronize() != hipSuccess) return -2;
+    const double t0 = now_ms();
+    for (int r = 0; r < reps; ++r) {
+        net->tracer.invalidateProgressiveRendering(PhotonData::InvalidationReason::All);
+        net->tracer.process();
+        net->lightVolume.process();
+    }
+    const double t1 = now_ms();
+    if (hipDeviceSynchronize() != hipSuccess) return -2;
+    if (total_ms) *total_ms = now_ms() - t0;
+    if (host_ms) *host_ms = t1 - t0;
     return 0;
 }
 

@@ -137,9 +137,11 @@ double PhotonData::progressiveSphereRadius(double radius, int iteration, double 
 }
 double PhotonData::sphereVolume(double radius) { return std::pow(radius, 3) * (M_PI * 4. / 3.); }  // :79-81
 
-std::shared_ptr<Mesh> Mesh::unitCube() {
+std::shared_ptr<Mesh> Mesh::unitCube() { return box(vec3(0.f, 0.f, 0.f), vec3(1.f, 1.f, 1.f)); }
+// the proxy geometry CubeProxyGeometry emits for clip ranges lo..hi (data space): 8 corners, 12 triangles
+std::shared_ptr<Mesh> Mesh::box(vec3 lo, vec3 hi) {
     auto m = std::make_shared<Mesh>();
-    for (int z = 0; z < 2; ++z) for (int y = 0; y < 2; ++y) for (int x = 0; x < 2; ++x) m->vertices.push_back(vec3((float)x, (float)y, (float)z));
+    for (int z = 0; z < 2; ++z) for (int y = 0; y < 2; ++y) for (int x = 0; x < 2; ++x) m->vertices.push_back(vec3(x ? hi.x : lo.x, y ? hi.y : lo.y, z ? hi.z : lo.z));
     const int quads[6][4] = { { 0, 1, 3, 2 }, { 4, 6, 7, 5 }, { 0, 4, 5, 1 }, { 2, 3, 7, 6 }, { 0, 2, 6, 4 }, { 1, 5, 7, 3 } };
     for (auto& q : quads) { const int t[6] = { q[0], q[1], q[2], q[0], q[2], q[3] }; m->indices.insert(m->indices.end(), t, t + 6); }
     return m;
@@ -402,6 +404,8 @@ int RecomputedPhotonIndices::resolveCount() {
         int32_t n = 0;
         if (rt.check(cpm_selection_count(rt.ctx(), selection, &n), "cpm_selection_count")) nRecomputedPhotons = n;
         countPending = false;
+        const size_t total = indicesToRecomputedPhotons.getSize();
+        if (costs && total > 0 && n >= 0) costs->sawFraction((float)n / (float)total);
     }
     return nRecomputedPhotons;
 }
@@ -434,17 +438,17 @@ void PhotonTracerCL::tracePhotonsSelected(const Volume* volume, const TransferFu
              "cpm_trace_selected");
 }
 
-void PhotonTracerCL::importanceRetrace(cpm_selection* selection, const Volume* volume, const ImportanceUniformGrid3D* grid,
+bool PhotonTracerCL::importanceRetrace(cpm_selection* selection, const Volume* volume, const ImportanceUniformGrid3D* grid,
                                        const TransferFunction& transferFunction, const float aabb[8], const AdvancedMaterialProperty& material,
                                        float stepSize, const LightSamples* lightSamples, Buffer<unsigned int>& importances, vec4* replacedPhotons,
                                        int photonOffset, int maxInteractions, bool fixExitPoint, PhotonData* photonOutData) {
     auto& rt = CpmRuntime::get();
-    if (!rt.valid()) return;
+    if (!rt.valid()) return false;
     if (randomState_.getSize() != photonOutData->getNumberOfPhotons()) setRandomSeedSize(photonOutData->getNumberOfPhotons());
     if (importances.getSize() != photonOutData->getNumberOfPhotons()) importances.setSize(photonOutData->getNumberOfPhotons());
     cpm_volume* vol_ = volume->getDeviceRepresentation();
     syncTF(transferFunction);
-    if (!vol_ || !tf_) return;
+    if (!vol_ || !tf_) return false;
     cpm_trace_params p = {};
     const vec4 m = material.getCombinedMaterialParameters();
     p.material[0] = m.x; p.material[1] = m.y; p.material[2] = m.z; p.material[3] = m.w;
@@ -465,7 +469,7 @@ void PhotonTracerCL::importanceRetrace(cpm_selection* selection, const Volume* v
     // (the grid's occupancy bits came with the grid: no launch of the selection's own for them)
     cpm_selection_set_occupancy(rt.ctx(), selection, grid->occupancyValid ? grid->data.device() : nullptr,
                                 grid->occupancyValid ? grid->occupancy.device() : nullptr);
-    rt.check(cpm_photon_importance_retrace(rt.ctx(), selection, grid->data.device(), dims, cell, d.texture_to_index, vol_, tf_, nullptr, aabb, &p,
+    return rt.check(cpm_photon_importance_retrace(rt.ctx(), selection, grid->data.device(), dims, cell, d.texture_to_index, vol_, tf_, nullptr, aabb, &p,
                                            reinterpret_cast<const float*>(lightSamples->getLightSamples()->device()),
                                            reinterpret_cast<const float*>(lightSamples->getIntersectionPoints()->device()), fixExitPoint ? 1 : 0,
                                            importances.device(), reinterpret_cast<uint32_t*>(randomState_.device()),
@@ -474,16 +478,15 @@ void PhotonTracerCL::importanceRetrace(cpm_selection* selection, const Volume* v
              "cpm_photon_importance_retrace");
 }
 
-void PhotonRecomputationDetector::photonRecomputationImportanceSelect(cpm_selection* selection, const PhotonData* photonData, int photonOffset,
+bool PhotonRecomputationDetector::photonRecomputationImportanceSelect(cpm_selection* selection, const PhotonData* photonData, int photonOffset,
                                                                       const Volume* origVolume, const ImportanceUniformGrid3D* grid,
                                                                       const LightSamples& lightSamples, Buffer<unsigned int>& imp, bool fixExitPoint) {
     auto& rt = CpmRuntime::get();
-    if (!rt.valid()) return;
+    if (!rt.valid()) return false;
     if (imp.getSize() != photonData->getNumberOfPhotons()) imp.setSize(photonData->getNumberOfPhotons());
     if (getEqualImportance()) {
-        rt.check(cpm_photon_importance_equal_select(rt.ctx(), selection, photonOffset, (int)lightSamples.getSize(), getPercentage(), getIteration(),
-                                                    imp.device(), rt.stream()), "cpm_photon_importance_equal_select");
-        return;
+        return rt.check(cpm_photon_importance_equal_select(rt.ctx(), selection, photonOffset, (int)lightSamples.getSize(), getPercentage(), getIteration(),
+                                                           imp.device(), rt.stream()), "cpm_photon_importance_equal_select");
     }
     const size3_t gd = grid->getDimensions(), cd = grid->getCellDimension(), vd = origVolume->getDimensions();
     const int32_t dims[3] = { (int32_t)gd.x, (int32_t)gd.y, (int32_t)gd.z };
@@ -493,7 +496,7 @@ void PhotonRecomputationDetector::photonRecomputationImportanceSelect(cpm_select
     cpm_volume_desc_default(&d, vdims, origVolume->dtype());
     cpm_selection_set_occupancy(rt.ctx(), selection, grid->occupancyValid ? grid->data.device() : nullptr,
                                 grid->occupancyValid ? grid->occupancy.device() : nullptr);
-    rt.check(cpm_photon_importance_select(rt.ctx(), selection, grid->data.device(), dims, cell, d.texture_to_index,
+    return rt.check(cpm_photon_importance_select(rt.ctx(), selection, grid->data.device(), dims, cell, d.texture_to_index,
                                           reinterpret_cast<const float*>(photonData->photons_.device()), photonOffset,
                                           reinterpret_cast<const float*>(lightSamples.getLightSamples()->device()),
                                           reinterpret_cast<const float*>(lightSamples.getIntersectionPoints()->device()), (int)lightSamples.getSize(),
@@ -838,16 +841,16 @@ void ProgressivePhotonTracerCL::process() {  // progressivephotontracercl.cpp:21
             takeFullFrame = true;
         } else if (fused && importanceBranchPolicy_.get() == "adaptive") {
             auto& c = costs_;
-            if (c.known() && c.branchTraceMs + c.branchLightVolumeMs > c.fullTraceMs + c.fullLightVolumeMs && c.evaluationsSinceProbe < 32) {
+            if (c.known() && c.branchTraceMs() + c.branchLightVolumeMs() > c.fullTraceMs + c.fullLightVolumeMs && c.evaluationsSinceProbe < 32) {
                 takeFullFrame = true;
                 ++c.evaluationsSinceProbe;
             } else {
                 c.evaluationsSinceProbe = 0;
             }
         }
-        if (takeFullFrame) {
-            fused = false;
-            lastDecision_ = importanceBranchPolicy_.get() == "never" ? "full frame (policy)" : "full frame (measured cheaper than the importance branch)";
+        // the TF / volume change served by a full frame in place of the importance branch (the policy's choice, or the branch failed)
+        auto fullFrameInPlaceOfBranch = [&](const char* decision) {
+            lastDecision_ = decision;
             span_.begin(rt.stream(), &costs_.fullTraceMs);
             int offset = 0;
             for (auto& l : lights) {
@@ -859,6 +862,8 @@ void ProgressivePhotonTracerCL::process() {  // progressivephotontracercl.cpp:21
             span_.end(rt.stream());
             recomputedPhotonIndices_->nRecomputedPhotons = -1;
             recomputedPhotonIndices_->takenInPlaceOfBranch = true;
+            recomputedPhotonIndices_->countPending = false;
+            recomputedPhotonIndices_->replacedValid = false;
             remainingPhotonsToUpdate_ = 0;
             remainingPhotonsOffset_ = 0;
             enableProgressiveRefinement_.set(false);
@@ -867,12 +872,16 @@ void ProgressivePhotonTracerCL::process() {  // progressivephotontracercl.cpp:21
             invalidationFlag_ = PhotonData::InvalidationReason(0);
             outport_.setData(photonData_);
             if (rt.profiling()) rt.logProfile("Photon tracing");
+        };
+        if (takeFullFrame) {
+            fused = false;
+            fullFrameInPlaceOfBranch(importanceBranchPolicy_.get() == "never" ? "full frame (policy)" : "full frame (measured cheaper than the importance branch)");
             return;
         }
         recomputedPhotonIndices_->takenInPlaceOfBranch = false;
         if (fused) {
             lastDecision_ = "importance branch";
-            span_.begin(rt.stream(), &costs_.branchTraceMs);
+            span_.begin(rt.stream(), &costs_.branchTraceMs());
             auto grid = std::dynamic_pointer_cast<ImportanceUniformGrid3D>(recomputationImportanceGrid_.getData());
             if (!grid) { LogError("UniformGrid3DInport require ImportanceUniformGrid3D as input"); return; }
             const size_t N = photonData_->getNumberOfPhotons();
@@ -891,21 +900,32 @@ void ProgressivePhotonTracerCL::process() {  // progressivephotontracercl.cpp:21
             const bool oneLaunch = retraceInImportancePass_.get() && !photonRecomputationDetector_.getEqualImportance() &&
                                    !photonTracer_.isProgressive();
             int offset = 0;
+            // A selection one of whose launches failed publishes a count of 0 (cpm_selection_finish reports it): nothing behind
+            // it on the stream re-traces or splats with indices no kernel wrote, and the change is served by a full frame.
+            bool selected = true;
             if (oneLaunch) {
                 for (auto& l : lights) {  // detector + threshold + tracer + importance reset of a light in one launch (:298-356,467-529)
-                    photonTracer_.importanceRetrace(selection_, volume, grid.get(), transferFunction_, aabb_, advancedMaterial_, stepSize, l.get(),
-                                                    photonRecomputationImportance_, rec.replacedPhotons.device(), offset, maxInteractions, fixExitPoint,
-                                                    photonData_.get());
+                    selected &= photonTracer_.importanceRetrace(selection_, volume, grid.get(), transferFunction_, aabb_, advancedMaterial_, stepSize, l.get(),
+                                                                photonRecomputationImportance_, rec.replacedPhotons.device(), offset, maxInteractions, fixExitPoint,
+                                                                photonData_.get());
                     offset += (int)l->getSize();
                 }
-                rt.check(cpm_selection_finish(rt.ctx(), selection_, rec.indicesToRecomputedPhotons.device(), rt.stream()), "cpm_selection_finish");
+                selected &= rt.check(cpm_selection_finish(rt.ctx(), selection_, rec.indicesToRecomputedPhotons.device(), rt.stream()), "cpm_selection_finish");
             } else {
                 for (auto& l : lights) {  // detector + threshold + count + index lists, per light (:298-356)
-                    photonRecomputationDetector_.photonRecomputationImportanceSelect(selection_, photonData_.get(), offset, volume, grid.get(), *l,
-                                                                                     photonRecomputationImportance_, fixExitPoint);
+                    selected &= photonRecomputationDetector_.photonRecomputationImportanceSelect(selection_, photonData_.get(), offset, volume, grid.get(), *l,
+                                                                                                 photonRecomputationImportance_, fixExitPoint);
                     offset += (int)l->getSize();
                 }
-                rt.check(cpm_selection_finish(rt.ctx(), selection_, rec.indicesToRecomputedPhotons.device(), rt.stream()), "cpm_selection_finish");
+                selected &= rt.check(cpm_selection_finish(rt.ctx(), selection_, rec.indicesToRecomputedPhotons.device(), rt.stream()), "cpm_selection_finish");
+            }
+            if (!selected) {
+                span_.end(rt.stream());
+                costs_ = PathCosts();  // (that span measured a failure)
+                fullFrameInPlaceOfBranch("full frame (the importance branch failed)");
+                return;
+            }
+            if (!oneLaunch) {
                 offset = 0;
                 for (auto& l : lights) {  // ascending indices = emission-lattice order (:467-473); importance reset in the same launch (:529)
                     photonTracer_.tracePhotonsSelected(volume, transferFunction_, aabb_, advancedMaterial_, stepSize, l.get(), &rec.indicesToRecomputedPhotons,
@@ -1098,7 +1118,7 @@ void PhotonToLightVolumeProcessorCL::process() {  // photontolightvolumeprocesso
     bool marksDone = false;      // brickMask_ already holds the old AND new positions' bricks
     // what this evaluation costs on the GPU's timeline, filed under the way the tracer served the change (PathCosts)
     if (haveIdx && nRecomputed != 0 && rec->costs)
-        span_.begin(rt.stream(), (nRecomputed < 0) ? &rec->costs->fullLightVolumeMs : &rec->costs->branchLightVolumeMs);
+        span_.begin(rt.stream(), (nRecomputed < 0) ? &rec->costs->fullLightVolumeMs : &rec->costs->branchLightVolumeMs());
     if (canAddRemove) {
         partialUpdate = true;
         const unsigned int* idx = rec->indicesToRecomputedPhotons.device();
@@ -1223,7 +1243,20 @@ void PhotonToLightVolumeProcessorCL::copyToGLBuffer(const float* volume, size_t 
     if (cpm_gl_release(rt.ctx(), &glBuffer_, 1, rt.stream()) == CPM_OK && rc == CPM_OK) lastGLCopy_ = "copied";
 }
 
-// The one exchange step of the path: sum of the shards' partial light volumes.
+void PhotonToLightVolumeProcessorCL::dropSparseReduce() {
+    if (sparseReduce_) cpm_sparse_reduce_destroy(sparseReduce_);
+    sparseReduce_ = nullptr;
+}
+void PhotonToLightVolumeProcessorCL::setCommunicator(cpm_comm* comm) {
+    if (comm != comm_) dropSparseReduce();
+    comm_ = comm;
+}
+
+// The one exchange step of the path: sum of the shards' partial light volumes -- over the union of the shards' non-zero
+// (full evaluation) or touched (add-remove) 4x4x4 bricks only, enqueued without a stream synchronisation
+// (cpm_allreduce_grid_sparse).  The ticket is completed here, before the outport hands the volume on: a consumer on this
+// stream must find the sum, also after an overflow (the dense sum is then enqueued behind the sparse chain); that reads one
+// word of pinned memory the frame's own launches write.
 void PhotonToLightVolumeProcessorCL::reduceOverShards(const cpm_grid_desc& g, size_t count, bool partialUpdate, const float* marksComplete,
                                                       const float* photons, const unsigned int* idx, int nRecomputed, int nPhotons,
                                                       int nInter, float radius) {
@@ -1235,17 +1268,31 @@ void PhotonToLightVolumeProcessorCL::reduceOverShards(const cpm_grid_desc& g, si
         reducedVolume_->data.setSize(count);
         partialUpdate = false;  // nothing to update incrementally yet
     }
+    if (sparseReduce_ && (sparseReduceDims_.x != outDim.x || sparseReduceDims_.y != outDim.y || sparseReduceDims_.z != outDim.z ||
+                          sparseReduceChannels_ != lightVolume_->channels))
+        dropSparseReduce();
+    if (!sparseReduce_) {
+        if (!rt.check(cpm_sparse_reduce_create(rt.ctx(), comm_, &g, &sparseReduce_), "cpm_sparse_reduce_create")) sparseReduce_ = nullptr;
+        sparseReduceDims_ = outDim;
+        sparseReduceChannels_ = lightVolume_->channels;
+    }
+    const uint8_t* mask = nullptr;
     if (partialUpdate && brickMask_.getSize() != 0 && idx) {
         // add-remove: only bricks touched by an old or a new position of a re-traced photon changed on this shard.  The old
         // positions were marked into brickMask_ before the snapshot moved on (see process()); add the new ones, then sum
         // the union of all shards' bricks only.
-        uint32_t nUnion = 0;
-        bool ok = marksComplete != nullptr ||
-                  rt.check(cpm_mark_touched_bricks(rt.ctx(), photons, idx, nRecomputed, nPhotons, nInter, &g, radius, brickMask_.device(),
-                                                   rt.stream()), "cpm_mark_touched_bricks(new)");
-        if (ok && rt.check(cpm_allreduce_grid_bricks(rt.ctx(), comm_, lightVolume_->data.device(), reducedVolume_->data.device(), &g,
-                                                     brickMask_.device(), &nUnion, rt.stream()), "cpm_allreduce_grid_bricks")) {
-            lastReduce_ = "touched bricks";
+        if (marksComplete != nullptr ||
+            rt.check(cpm_mark_touched_bricks(rt.ctx(), photons, idx, nRecomputed, nPhotons, nInter, &g, radius, brickMask_.device(), rt.stream()),
+                     "cpm_mark_touched_bricks(new)"))
+            mask = brickMask_.device();
+    }
+    if (sparseReduce_) {
+        uint64_t ticket = 0;
+        cpm_sparse_reduce_info info = {};
+        if (rt.check(cpm_allreduce_grid_sparse(rt.ctx(), sparseReduce_, lightVolume_->data.device(), reducedVolume_->data.device(), mask, -1, 0,
+                                               &ticket, rt.stream()), "cpm_allreduce_grid_sparse") &&
+            rt.check(cpm_sparse_reduce_complete(rt.ctx(), sparseReduce_, ticket, rt.stream(), &info), "cpm_sparse_reduce_complete")) {
+            lastReduce_ = info.mode == 0 ? (mask ? "touched bricks" : "non-zero bricks") : (info.mode == 1 ? "dense" : "dense (overflow)");
             return;
         }
     }

@@ -43,9 +43,20 @@ private:
 struct PathCosts {
     // (-2: never run; -1: run once -- a kernel's first launch carries its one-off load, that sample is dropped; >= 0: running mean)
     float fullTraceMs = -2.f, fullLightVolumeMs = -2.f;       // everything re-traced; volume rebuilt
-    float branchTraceMs = -2.f, branchLightVolumeMs = -2.f;   // importance branch; add-remove (or rebuild above its threshold)
+    // importance branch; add-remove (or rebuild above its threshold).  The branch's cost grows with the fraction re-traced
+    // (1 % -> 100 %: 0.067 -> 0.12 ms at config 3), so it is kept per coarse bucket of that fraction -- < 1 %, < 5 %, < 25 %, the
+    // rest -- and looked up / filed under the bucket of the LAST fraction seen: consecutive edits of one interaction are alike.
+    static constexpr int kBuckets = 4;
+    float branchTraceMsBy[kBuckets] = { -2.f, -2.f, -2.f, -2.f }, branchLightVolumeMsBy[kBuckets] = { -2.f, -2.f, -2.f, -2.f };
+    int bucket = 0;
     int evaluationsSinceProbe = 0;                            // full frames taken in place of the branch since it was last measured
-    bool known() const { return fullTraceMs >= 0.f && fullLightVolumeMs >= 0.f && branchTraceMs >= 0.f && branchLightVolumeMs >= 0.f; }
+    static int bucketOf(float fraction) { return fraction < 0.01f ? 0 : fraction < 0.05f ? 1 : fraction < 0.25f ? 2 : 3; }
+    void sawFraction(float fraction) { const int b = bucketOf(fraction); if (b != bucket) { bucket = b; evaluationsSinceProbe = 0; } }
+    float& branchTraceMs() { return branchTraceMsBy[bucket]; }
+    float& branchLightVolumeMs() { return branchLightVolumeMsBy[bucket]; }
+    float branchTraceMs() const { return branchTraceMsBy[bucket]; }
+    float branchLightVolumeMs() const { return branchLightVolumeMsBy[bucket]; }
+    bool known() const { return fullTraceMs >= 0.f && fullLightVolumeMs >= 0.f && branchTraceMs() >= 0.f && branchLightVolumeMs() >= 0.f; }
 };
 
 // A pair of events around the launches of one evaluation; the elapsed time is picked up when a later evaluation finds it ready.
@@ -235,6 +246,7 @@ struct Mesh {  // proxy geometry: vertex positions (data space) + triangle indic
     std::vector<vec3> vertices;
     std::vector<int> indices;
     static std::shared_ptr<Mesh> unitCube();
+    static std::shared_ptr<Mesh> box(vec3 lo, vec3 hi);
 };
 
 // ---- host geometry (lightcl/*.cpp) ---------------------------------------------------------------
@@ -331,7 +343,7 @@ public:
     // be overwritten go to replacedPhotons (stride maxIndices), the traced photons' importance keys are reset
     // detector + threshold + tracer of one light in one launch (cpm_photon_importance_retrace); the replaced records go to
     // replacedPhotons at the photons' own indices
-    void importanceRetrace(cpm_selection* selection, const Volume* volume, const ImportanceUniformGrid3D* grid, const TransferFunction& transferFunction,
+    bool importanceRetrace(cpm_selection* selection, const Volume* volume, const ImportanceUniformGrid3D* grid, const TransferFunction& transferFunction,
                            const float aabb[8], const AdvancedMaterialProperty& material, float stepSize, const LightSamples* lightSamples,
                            Buffer<unsigned int>& importances, vec4* replacedPhotons, int photonOffset, int maxInteractions, bool fixExitPoint,
                            PhotonData* photonOutData);
@@ -369,7 +381,7 @@ public:
                                        const ImportanceUniformGrid3D* uniformGridVolume, const LightSamples& lightSamples,
                                        Buffer<unsigned int>& recomputationImportance);
     // the same fused with threshold + count + index lists (cpm_photon_importance_select): appends this light to `selection`
-    void photonRecomputationImportanceSelect(cpm_selection* selection, const PhotonData* photonData, int photonOffset, const Volume* origVolume,
+    bool photonRecomputationImportanceSelect(cpm_selection* selection, const PhotonData* photonData, int photonOffset, const Volume* origVolume,
                                              const ImportanceUniformGrid3D* uniformGridVolume, const LightSamples& lightSamples,
                                              Buffer<unsigned int>& recomputationImportance, bool fixExitPoint);
     void setPercentage(int p) { percentage_ = p; }
@@ -598,7 +610,7 @@ public:
     // partial light volume; with a communicator set, the outport carries the sum over the shards -- one cpm_allreduce_grid
     // per full evaluation, cpm_allreduce_grid_bricks (touched bricks only) after an add-remove update.  The call site is
     // where the reference hands the finished volume to the outport (photontolightvolumeprocessorcl.cpp:404-411).
-    void setCommunicator(cpm_comm* comm) { comm_ = comm; }
+    void setCommunicator(cpm_comm* comm);
     const char* lastReduce() const { return lastReduce_; }
     // OpenGL sharing (`glsharing`, ref photontolightvolumeprocessorcl.cpp:184-194,404-406).  CDNA cannot map a GL texture (no
     // image hardware); the finished light volume is written on the device into a GL pixel-unpack BUFFER of the host's context
@@ -608,7 +620,7 @@ public:
     // `glsharing` off) the outport's device buffer is all there is -- as before.
     void shareLightVolumeWithGL(unsigned glPixelUnpackBuffer, int texel) { glBufferName_ = glPixelUnpackBuffer; glTexel_ = texel; dropGLBuffer(); }
     const char* lastGLCopy() const { return lastGLCopy_; }
-    ~PhotonToLightVolumeProcessorCL() override { dropGLBuffer(); }
+    ~PhotonToLightVolumeProcessorCL() override { dropGLBuffer(); dropSparseReduce(); }
 private:
     void dropGLBuffer();
     void copyToGLBuffer(const float* volume, size_t n);
@@ -620,6 +632,10 @@ private:
     void reduceOverShards(const cpm_grid_desc& g, size_t count, bool partialUpdate, const float* prevPhotons, const float* photons,
                           const unsigned int* idx, int nRecomputed, int nPhotons, int nInter, float radius);
     cpm_comm* comm_ = nullptr;
+    cpm_sparse_reduce* sparseReduce_ = nullptr;  // cpm_allreduce_grid_sparse state of (comm_, the light volume's shape)
+    size3_t sparseReduceDims_{ 0, 0, 0 };
+    int sparseReduceChannels_ = 0;
+    void dropSparseReduce();
     std::shared_ptr<Volume> reducedVolume_;
     Buffer<uint32_t> brickTable_;
     Buffer<float> estimate_;  // E_i of a progressive iteration

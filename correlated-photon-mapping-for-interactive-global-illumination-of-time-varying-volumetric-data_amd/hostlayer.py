@@ -29,6 +29,10 @@ def load():
         "cpmh_path_costs": (None, [vp, vp]),
         "cpmh_bench_tf_edits": (i32, [vp, vp, i32, vp, i32, i32, vp, vp]),
         "cpmh_bench_full_frames": (i32, [vp, i32, vp]),
+        "cpmh_bench_frames_back_to_back": (i32, [vp, i32, vp, vp]),
+        "cpmh_add_light": (i32, [vp, C.POINTER(C.c_float * 3), C.POINTER(C.c_float * 3)]),
+        "cpmh_n_lights": (i32, [vp]),
+        "cpmh_set_clip": (None, [vp, i32, i32, i32, i32, i32, i32]),
         "cpmh_sequence_create": (vp, [vp, i32, i32, i32, i32, i32, i32]),
         "cpmh_sequence_destroy": (None, [vp]),
         "cpmh_attach_sequence": (i32, [vp, vp]),
@@ -93,10 +97,24 @@ class HostNetwork:
         return np.array(list(ms)), np.array(list(n))
 
     def bench_full_frames(self, reps):
+        """Latency: every frame timed from an idle device until it is idle again."""
         ms = (C.c_double * reps)()
         if self.lib.cpmh_bench_full_frames(self.h, reps, C.byref(ms)) != 0:
             raise RuntimeError("cpmh_bench_full_frames failed")
         return np.array(list(ms))
+
+    def bench_frames_back_to_back(self, reps):
+        """Throughput: `reps` full frames enqueued back to back, one synchronisation; (ms per frame, host enqueue ms per frame)."""
+        total, host = C.c_double(0), C.c_double(0)
+        if self.lib.cpmh_bench_frames_back_to_back(self.h, reps, C.byref(total), C.byref(host)) != 0:
+            raise RuntimeError("cpmh_bench_frames_back_to_back failed")
+        return total.value / reps, host.value / reps
+
+    def add_light(self, light_position, light_direction):
+        return int(self.lib.cpmh_add_light(self.h, C.byref((C.c_float * 3)(*light_position)), C.byref((C.c_float * 3)(*light_direction))))
+
+    def set_clip(self, x0, x1, y0, y1, z0, z1):
+        self.lib.cpmh_set_clip(self.h, x0, x1, y0, y1, z0, z1)
 
     def close(self):
         if self.h:

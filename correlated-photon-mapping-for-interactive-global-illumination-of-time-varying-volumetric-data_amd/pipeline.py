@@ -271,7 +271,7 @@ class PhotonFrame:
     TRACE_ORDER_AT_LEAST_APART = 32
 
     def trace(self, recompute_indices=None, n_recompute=0):
-        full = recompute_indices is None and self.adaptive_order
+        full = recompute_indices is None and self.adaptive_order and self.n > 0   # (an empty shard traces nothing and needs no order)
         measure = full and (self._traces_since_order == 0 or self._traces_since_order >= self.TRACE_ORDER_EVERY or
                             (self._order_stale and self._traces_since_order >= self.TRACE_ORDER_AT_LEAST_APART))
         if full:

@@ -13,6 +13,11 @@ density and the one-workgroup-per-brick gather stays balanced.  `shard_range` (a
 slab of the light plane: a rank's photons pile into 1/N of the lit bricks, N times denser; measured
 12.9 -> 32 us for the brick gather at N = 8) is kept for comparison.
 
+Full frames sum only the UNION of the ranks' non-zero 4x4x4-voxel bricks (``cpm_allreduce_grid_sparse``: a byte-mask
+max-reduce, then a packed payload whose size the host fixed beforehand from the union of two frames ago -- no stream
+synchronisation, no read-back on the frame's path; dense after an overflow).  ``sparse_capacity`` is that policy, the same
+function the library exports; ``TorchTransport`` carries out the same steps with torch ops for the CPU tests.
+
 The collective goes through the C-ABI: ``cpm_allreduce_grid`` (RCCL over xGMI on the caller's stream,
 ``include/cpm/cpm.h``), the call a C++ host makes.  ``torch.distributed`` only carries the 128-byte
 communicator id to the ranks (and the benchmark's barriers).  For the CPU tests (gloo, no GPU, no
@@ -51,6 +56,32 @@ def shard_tiles(n_total: int, rank: int, world: int, tile: int = SHARD_TILE):
     return idx[idx < n_total]
 
 
+def sparse_capacity(n_bricks: int, previous_union: int) -> int:
+    """Bricks of payload for a union that had `previous_union` bricks two frames ago (< 0: unknown): + 25 % + 64, rounded up to
+    64; a quarter of the bricks while unknown; `n_bricks` (= dense) beyond half of them.  Mirrors
+    cpm_sparse_reduce_capacity_for (include/cpm/cpm.h) -- tests/test_abi.py holds the two together."""
+    if n_bricks <= 0:
+        return 0
+    if previous_union < 0:
+        c = (n_bricks // 4 + 63) & ~63
+    else:
+        c = (previous_union + previous_union // 4 + 64 + 63) & ~63
+    return n_bricks if c * 2 > n_bricks else c
+
+
+def brick_view(grid, dims, channels=1):
+    """The grid (x fastest, `channels` interleaved) as [bz, by, bx, 4, 4, 4 * channels] after zero-padding every axis to a
+    multiple of 4: brick b = bx + nbx * (by + nby * bz), a brick's values in (z, y, x, channel) order."""
+    import torch
+    dx, dy, dz = dims
+    px, py, pz = -dx % 4, -dy % 4, -dz % 4
+    g = grid.reshape(dz, dy, dx * channels)
+    if px or py or pz:
+        g = torch.nn.functional.pad(g, (0, px * channels, 0, py, 0, pz))
+    nz, ny, nx = (dz + pz) // 4, (dy + py) // 4, (dx + px) // 4
+    return g.reshape(nz, 4, ny, 4, nx, 4 * channels).permute(0, 2, 4, 1, 3, 5)
+
+
 # --------------------------------------------------------------------------- transports
 
 class TorchTransport:
@@ -73,6 +104,57 @@ class TorchTransport:
     def wait(handle):
         if handle is not None:
             handle.wait()
+
+    # -- the sparse full-frame sum with torch ops: the steps of cpm_allreduce_grid_sparse, one after the other
+    def sparse_setup(self, dims, channels=1):
+        self._sp = {"dims": tuple(dims), "channels": channels, "unions": [], "log": []}
+        self._sp["nb"] = ((dims[0] + 3) // 4) * ((dims[1] + 3) // 4) * ((dims[2] + 3) // 4)
+
+    def sparse_start(self, grid, capacity: int = 0):
+        """grid (in place) = sum over the ranks, over the union of their non-zero bricks; returns the ticket's figures."""
+        import torch
+        sp, dist = self._sp, self._dist
+        dims, ch, nb = sp["dims"], sp["channels"], sp["nb"]
+        k = len(sp["unions"])
+        cap = capacity or sparse_capacity(nb, sp["unions"][k - 2] if k >= 2 else -1)
+        bricks = brick_view(grid, dims, ch).reshape(nb, 64 * ch).clone()
+        mask = (bricks != 0).any(dim=1).to(torch.uint8)
+        if self.world > 1:
+            dist.all_reduce(mask, op=dist.ReduceOp.MAX, group=self.group)
+        union = torch.nonzero(mask, as_tuple=False).reshape(-1)
+        n_union = int(union.numel())
+        sp["unions"].append(n_union)
+        dense_bytes = grid.numel() * 4
+        if cap >= nb or n_union > cap:  # dense by policy, or the union outgrew the payload
+            mode = 1 if cap >= nb else 2
+            if self.world > 1:
+                if self.root is not None:
+                    dist.reduce(grid, dst=self.root, op=dist.ReduceOp.SUM, group=self.group)
+                else:
+                    dist.all_reduce(grid, op=dist.ReduceOp.SUM, group=self.group)
+            moved = nb + dense_bytes + (cap * 256 * ch if mode == 2 else 0)
+        else:
+            mode = 0
+            payload = torch.zeros(cap, 64 * ch, dtype=grid.dtype, device=grid.device)
+            payload[:n_union] = bricks[union]
+            if self.world > 1:
+                if self.root is not None:
+                    dist.reduce(payload, dst=self.root, op=dist.ReduceOp.SUM, group=self.group)
+                else:
+                    dist.all_reduce(payload, op=dist.ReduceOp.SUM, group=self.group)
+            if self.root is None or self._rank() == self.root:
+                dx, dy, dz = dims
+                bricks[union] = payload[:n_union]  # (`bricks` is a copy: permuted and reshaped)
+                nz, ny, nx = (dz + 3) // 4, (dy + 3) // 4, (dx + 3) // 4
+                back = bricks.reshape(nz, ny, nx, 4, 4, 4 * ch).permute(0, 3, 1, 4, 2, 5).reshape(nz * 4, ny * 4, nx * 4 * ch)
+                grid.reshape(dz, dy, dx * ch).copy_(back[:dz, :dy, :dx * ch])
+            moved = nb + cap * 256 * ch
+        info = {"n_bricks": nb, "n_union": n_union, "capacity": cap, "mode": mode, "reduce_bytes": moved, "dense_bytes": dense_bytes}
+        sp["log"].append(info)
+        return info
+
+    def _rank(self):
+        return self._dist.get_rank(self.group) if self.world > 1 else 0
 
 
 class RcclTransport:
@@ -114,7 +196,34 @@ class RcclTransport:
         if handle is not None:
             self.torch.cuda.current_stream(self.ctx.device).wait_event(handle)
 
+    # -- the sparse full-frame sum (cpm_allreduce_grid_sparse): same stream discipline as start / wait
+    def sparse_setup(self, grid_desc):
+        self.sparse = self.ctx.sparse_reduce_create(self.comm, grid_desc)
+        self.sparse_log = []
+
+    def sparse_start(self, grid, capacity: int = 0):
+        torch = self.torch
+        ready = torch.cuda.Event()
+        ready.record(torch.cuda.current_stream(self.ctx.device))
+        with torch.cuda.stream(self.stream):
+            self.stream.wait_event(ready)
+            ticket = self.sparse.start(grid, root=-1 if self.root is None else self.root, capacity=capacity)
+        return ticket
+
+    def sparse_wait(self, ticket):
+        """The CURRENT stream waits for the ticket's sum (the dense one after an overflow); the host reads one mailbox word."""
+        torch = self.torch
+        with torch.cuda.stream(self.stream):
+            info = self.sparse.complete(ticket)
+            done = torch.cuda.Event()
+            done.record(self.stream)
+        torch.cuda.current_stream(self.ctx.device).wait_event(done)
+        self.sparse_log.append(info)
+        return info
+
     def close(self):
+        if getattr(self, "sparse", None) is not None:
+            self.sparse.close()
         self.comm.close()
 
 
@@ -145,30 +254,54 @@ class OverlappedGridReducer:
         grid = red.result(K - 1)
     """
 
-    def __init__(self, like, transport=None, group=None):
+    def __init__(self, like, transport=None, group=None, sparse=None, force=False):
+        """sparse: None = dense all-reduce; a cpm GridDesc (RcclTransport) or (dims, channels) (TorchTransport) = the sum
+        over the union of the ranks' non-zero bricks (cpm_allreduce_grid_sparse).  force: run the reduce with one rank too
+        (measuring pack / unpack on one GPU)."""
         import torch
         self.transport = transport if transport is not None else TorchTransport(group)
-        self.active = self.transport.world > 1
+        self.active = self.transport.world > 1 or force
         self.buffers = [like, torch.empty_like(like)]
         self._pending = [None, None]
+        self.sparse = sparse is not None
+        self.info = []  # per completed sparse ticket: union, capacity, mode, bytes
+        if self.sparse and self.active:
+            if isinstance(self.transport, TorchTransport):
+                dims, channels = sparse
+                self.transport.sparse_setup(dims, channels)
+            else:
+                self.transport.sparse_setup(sparse)
+
+    def _wait(self, b):
+        h = self._pending[b]
+        if h is None:
+            return
+        self._pending[b] = None
+        if not self.sparse:
+            self.transport.wait(h)
+        elif isinstance(self.transport, TorchTransport):
+            self.info.append(h)  # carried out at start
+        else:
+            i = self.transport.sparse_wait(h)
+            self.info.append({"n_bricks": i.n_bricks, "n_union": i.n_union, "capacity": i.capacity, "mode": i.mode,
+                              "reduce_bytes": i.reduce_bytes, "dense_bytes": i.dense_bytes})
 
     def acquire(self, k: int):
         b = k & 1
-        if self._pending[b] is not None:
-            self.transport.wait(self._pending[b])
-            self._pending[b] = None
+        self._wait(b)
         return self.buffers[b]
 
     def reduce(self, k: int):
         if self.active:
             b = k & 1
-            self._pending[b] = self.transport.start(self.buffers[b])
+            if self.sparse:
+                self._pending[b] = self.transport.sparse_start(self.buffers[b])
+            else:
+                self._pending[b] = self.transport.start(self.buffers[b])
 
     def flush(self):
         for b in (0, 1):
-            if self._pending[b] is not None:
-                self.transport.wait(self._pending[b])
-                self._pending[b] = None
+            self._wait(b)
 
     def result(self, k: int):
         return self.buffers[k & 1]

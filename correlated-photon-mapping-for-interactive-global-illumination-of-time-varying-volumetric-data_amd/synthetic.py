@@ -54,18 +54,20 @@ def homogeneous_volume(dim: int = 64, value: int = 128) -> np.ndarray:
     return np.full((dim, dim, dim), value, dtype=np.uint8)
 
 
-def heterogeneous_volume(dim: int = 256, blob_center=(0.5, 0.5, 0.5)) -> np.ndarray:
+def heterogeneous_volume(dim=256, blob_center=(0.5, 0.5, 0.5)) -> np.ndarray:
     """Config 2/4/5: v = clamp(0.5 + 0.25 sin(8 pi x) sin(6 pi y) sin(4 pi z)
-    + 0.25 exp(-|p - c|^2 / 0.02), 0, 1) at voxel centres, quantised to u8."""
-    c = (np.arange(dim, dtype=np.float64) + 0.5) / dim
-    sx = np.sin(8 * math.pi * c)
-    sy = np.sin(6 * math.pi * c)
-    sz = np.sin(4 * math.pi * c)
-    gx = (c - blob_center[0]) ** 2
-    gy = (c - blob_center[1]) ** 2
-    gz = (c - blob_center[2]) ** 2
-    out = np.empty((dim, dim, dim), dtype=np.uint8)
-    for z in range(dim):
+    + 0.25 exp(-|p - c|^2 / 0.02), 0, 1) at voxel centres, quantised to u8.
+    dim: an int (a cube) or (dx, dy, dz) -- the workspace's own volume is 512 x 512 x 96; the array is [z, y, x]."""
+    dx, dy, dz = (dim, dim, dim) if np.isscalar(dim) else (int(dim[0]), int(dim[1]), int(dim[2]))
+    cx, cy, cz = [(np.arange(d, dtype=np.float64) + 0.5) / d for d in (dx, dy, dz)]
+    sx = np.sin(8 * math.pi * cx)
+    sy = np.sin(6 * math.pi * cy)
+    sz = np.sin(4 * math.pi * cz)
+    gx = (cx - blob_center[0]) ** 2
+    gy = (cy - blob_center[1]) ** 2
+    gz = (cz - blob_center[2]) ** 2
+    out = np.empty((dz, dy, dx), dtype=np.uint8)
+    for z in range(dz):
         wave = 0.25 * sz[z] * sy[:, None] * sx[None, :]
         blob = 0.25 * np.exp(-(gz[z] + gy[:, None] + gx[None, :]) / 0.02)
         v = np.clip(0.5 + wave + blob, 0.0, 1.0)

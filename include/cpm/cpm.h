@@ -660,6 +660,48 @@ int cpm_allreduce_grids(cpm_ctx* const* ctxs, cpm_comm* const* comms, float* con
 int cpm_allreduce_grid_bricks(cpm_ctx* ctx, cpm_comm* comm, const float* partial, float* total,
                               const cpm_grid_desc* grid, uint8_t* brick_mask, uint32_t* n_union_out, cpm_stream stream);
 
+/* Full frames: the sum over the ranks of the per-rank light volumes WITHOUT moving the empty space and WITHOUT a host wait.
+ * A rank's photons reach a fraction of the grid (config 2: 1 in 8 of the 4x4x4-voxel bricks holds a non-zero voxel), every
+ * rank reaches nearly the same bricks (lattice tiles are dealt round-robin), and the dense sum -- 64 MiB per frame at
+ * config 4 against ~40 us of per-rank compute -- would be the frame.  One call enqueues, on the caller's stream:
+ *   this rank's non-zero bricks -> byte mask (or `brick_mask`, nb bytes as cpm_mark_touched_bricks fills it: the delta path)
+ *   -> ncclAllReduce(max) of the mask = the UNION, identical on every rank -> ascending brick list + count
+ *   -> pack the union's bricks of `partial` -> ncclAllReduce / ncclReduce (sum) of capacity * 64 * channels floats -> unpack.
+ * total[brick] = sum over ranks of partial[brick] for every brick of the union.  Elsewhere: total == partial (in place) is left
+ * as it is (zero on every rank, or unchanged: delta path); a separate `total` is zero-filled there unless `brick_mask` was
+ * given (then its other bricks still hold the previous sum).  root < 0: every rank receives; else only `root` writes `total`.
+ *
+ * No stream synchronisation, no read-back in the call: the collective's size is `capacity_bricks`, fixed by the host before
+ * the launch.  capacity_bricks = 0 (the normal use) takes cpm_sparse_reduce_capacity_for(n_bricks, union count of the
+ * call before the previous one): that count reaches the host through a pinned mailbox (a poll, no stream wait) and is the
+ * same number on every rank, so all ranks size the collective alike as long as they make the same sequence of calls.
+ * Should a union outgrow its capacity (the scene changed), pack / unpack do nothing and cpm_sparse_reduce_complete --
+ * which the caller makes before reading `total` -- enqueues the dense sum instead; capacity == n_bricks means dense from the
+ * start (a union beyond half of the bricks).  At most 8 tickets may be issued and not completed.  All calls of one
+ * cpm_sparse_reduce go to one stream (or streams ordered by events): they share the mask, list and payload buffers.
+ * Call site: where PhotonToLightVolumeProcessorCL::process hands the volume on
+ * (ref processor/photontolightvolumeprocessorcl.cpp:356-412). */
+typedef struct cpm_sparse_reduce cpm_sparse_reduce;
+typedef struct cpm_sparse_reduce_info {
+    uint64_t ticket;
+    uint32_t n_bricks, n_union, capacity;
+    int mode;               /* 0 sparse, 1 dense from the start (capacity policy), 2 dense after an overflow */
+    uint64_t reduce_bytes;  /* elements handed to the collectives of this ticket, in bytes: mask + payload (+ dense) */
+    uint64_t dense_bytes;   /* cells * channels * 4: what cpm_allreduce_grid hands over */
+} cpm_sparse_reduce_info;
+int cpm_sparse_reduce_create(cpm_ctx* ctx, cpm_comm* comm, const cpm_grid_desc* grid, cpm_sparse_reduce** out);
+void cpm_sparse_reduce_destroy(cpm_sparse_reduce* sr);
+uint32_t cpm_sparse_reduce_bricks(const cpm_sparse_reduce* sr);
+/* Bricks of payload for a grid of n_bricks whose union two calls ago had previous_union bricks (< 0: not known yet):
+ * previous_union * 1.25 + 64 rounded up to 64, a quarter of the bricks while unknown; n_bricks (= dense) beyond half of them.
+ * A pure function: hosts that mirror the policy (sharding.py) call it. */
+uint32_t cpm_sparse_reduce_capacity_for(uint32_t n_bricks, long long previous_union);
+int cpm_allreduce_grid_sparse(cpm_ctx* ctx, cpm_sparse_reduce* sr, const float* partial, float* total, const uint8_t* brick_mask,
+                              int root, uint32_t capacity_bricks, uint64_t* ticket_out, cpm_stream stream);
+/* Before `total` of `ticket` is read (enqueue-wise: on `stream`, behind the call that issued the ticket): reads the ticket's
+ * union count from the mailbox (waits for THAT launch only) and, after an overflow, enqueues the dense sum. */
+int cpm_sparse_reduce_complete(cpm_ctx* ctx, cpm_sparse_reduce* sr, uint64_t ticket, cpm_stream stream, cpm_sparse_reduce_info* info_out);
+
 /* ---- OpenGL sharing: the consumer side of the light volume ---------------------------------------------------------
  * Replaces Inviwo's CL-GL sharing on this path (property `glsharing`, ref processor/progressivephotontracercl.cpp:93,
  * processor/photontolightvolumeprocessorcl.cpp:69): `SyncCLGL` + `BufferCLGL` for the photon buffer (ref

@@ -42,6 +42,9 @@ void cpm_debug_set_sort_mode(cpm_ctx* ctx, int mode);
 void cpm_debug_set_sort_items(cpm_ctx* ctx, int items);
 /* streaming kernels (temporal mix): workgroups per CU; 0 = one vector per lane, -1 = by size (default) */
 void cpm_debug_set_stream_wg_per_cu(cpm_ctx* ctx, int n);
+/* test hook: the next cpm_photon_importance_select / _equal_select / _retrace call fails AFTER it has appended its tiles (what a
+ * refused launch or a failed allocation does): the selection must then publish a count of 0 */
+void cpm_debug_fail_next_select(cpm_ctx* ctx, int on);
 /* test hook: a cpm_trace_order's table (n_chunks = ceil(n_light_samples / 256) entries) and the costs gathered since its last
  * update (n_chunks + 1 entries, the last one = launches counted); either may be NULL.  Synchronises the device. */
 struct cpm_trace_order;

@@ -49,6 +49,19 @@ def test_default_descriptors_and_host_helpers(cpm, oracle):
     assert abs(B.relative_irradiance_scale(3 ** 0.5 / 256, 1048576) - 0.2340) < 2e-4
 
 
+def test_sparse_reduce_capacity_policy_is_the_same_on_both_sides(cpm):
+    """sharding.sparse_capacity (the CPU mirror of the sparse reduce) and cpm_sparse_reduce_capacity_for (what the library
+    sizes its payload with) are one function: pure host arithmetic, no device."""
+    import importlib
+    sh = importlib.import_module(cpm.__name__ + ".sharding")
+    lib = cpm.binding.load_library()
+    for nb in (0, 1, 27, 512, 4096, 32768, 262144):
+        for prev in (-1, 0, 1, 63, 64, 100, nb // 8, nb // 4, nb // 3, nb // 2, nb):
+            assert lib.cpm_sparse_reduce_capacity_for(nb, prev) == sh.sparse_capacity(nb, prev), (nb, prev)
+    assert sh.sparse_capacity(32768, 4000) == 5120 and sh.sparse_capacity(32768, -1) == 8192
+    assert sh.sparse_capacity(32768, 14000) == 32768  # beyond half of the bricks: dense
+
+
 def test_no_cpu_fallback(cpm):
     """Without a GPU the product path must fail loudly (never compute on the CPU)."""
     import torch

@@ -33,6 +33,9 @@ def test_bench_single_gpu_line():
     assert set(d["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic"}
     assert set(d["cpu_baseline"]) >= {"value", "unit", "cores", "kind", "sample"} and d["cpu_baseline"]["kind"] == "port"
     assert d["pipelined"]["light_volumes_identical_to_single_stream"] is True
+    sp = d["sparse_reduce_one_gpu"]
+    assert "error" not in sp, sp
+    assert sp["n_union"] <= sp["n_bricks_4x4x4"] and sp["reduce_bytes_per_frame"] > 0 and sp["dense_bytes"] == 32 ** 3 * 4
 
 
 def test_bench_two_ranks_code_path():
@@ -48,6 +51,9 @@ def test_bench_two_ranks_code_path():
     assert "cpu_baseline" not in d                      # rank 0 at N = 1 only
     assert "all-reduce" in d["config"]["parallelism"] and d["scaling"] == "weak"
     assert d["config"]["photons_rank0"] == 65536 and d["config"]["photons_per_frame"] == 131072   # weak: the per-rank work is fixed
+    # the default reduce is the sparse one (here carried out by torch ops over gloo): no stream synchronisation on the frame's path
+    assert "sparse" in d["config"]["parallelism"] and d["reduce"]["stream_synchronisations_per_frame"] == 0
+    assert d["reduce"]["frames_sparse"] + d["reduce"]["frames_dense_by_policy"] + d["reduce"]["frames_dense_after_overflow"] == 6
 
 
 def test_bench_plain_command_starts_its_own_ranks():

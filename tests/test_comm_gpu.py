@@ -100,3 +100,135 @@ def test_rccl_transport_of_the_sharding_layer(ctx, cpm):
     red = sh.OverlappedGridReducer(g, tr)
     assert not red.active and red.acquire(0) is g
     tr.close()
+
+
+def _bricks_of(dims):
+    bxn, byn, bzn = [(d + 3) // 4 for d in dims]
+    z, y, x = np.meshgrid(np.arange(dims[2]), np.arange(dims[1]), np.arange(dims[0]), indexing="ij")
+    return (x // 4) + bxn * ((y // 4) + byn * (z // 4)), bxn * byn * bzn
+
+
+@pytest.mark.parametrize("dims,ch", [((128, 128, 128), 1), ((64, 32, 48), 4), ((30, 18, 9), 1), ((21, 7, 5), 4), ((256, 256, 48), 1)])
+def test_sparse_grid_reduce_one_rank(ctx, cpm, dims, ch):
+    """cpm_allreduce_grid_sparse with a real RCCL communicator of size 1: mask -> union -> list -> pack -> (sum) -> unpack, no
+    host wait in the call; the union count arrives through the mailbox; in place the grid is unchanged bit for bit, a
+    separate total is the grid on the union and zero elsewhere; a payload too small for the union falls back to the dense
+    sum in cpm_sparse_reduce_complete; the automatic capacity follows the policy with the union of two calls before."""
+    torch = ctx.torch
+    B = cpm.binding
+    sh = importlib.import_module(cpm.__name__ + ".sharding")
+    comm = ctx.comm_create(ctx.comm_unique_id(), 0, 1)
+    gd = B.default_grid_desc(dims, ch)
+    sr = ctx.sparse_reduce_create(comm, gd)
+    cells = dims[0] * dims[1] * dims[2]
+    b, nb = _bricks_of(dims)
+    assert sr.n_bricks == nb
+    rng = np.random.default_rng(nb + ch)
+    lit_bricks = rng.random(nb) < 0.12
+    vox = lit_bricks[b.reshape(-1)] & (rng.random(cells) < 0.4)
+    g_np = np.zeros((cells, ch), np.float32)
+    g_np[vox] = rng.random((int(vox.sum()), ch), dtype=np.float32) + 0.01
+    g_np[vox, ch - 1] *= rng.random(int(vox.sum())) < 0.5   # zeros inside lit voxels too
+    want_union = int(np.unique(b.reshape(-1)[(g_np != 0).any(axis=1)]).size)
+    g = torch.from_numpy(g_np.reshape(-1)).to(ctx.device)
+    keep = g.clone()
+    # in place
+    t1 = sr.start(g)
+    i1 = sr.complete(t1)
+    torch.cuda.synchronize()
+    assert i1.n_union == want_union and i1.n_bricks == nb
+    assert i1.capacity == sh.sparse_capacity(nb, -1)
+    assert i1.mode == (1 if i1.capacity >= nb else 2 if want_union > i1.capacity else 0)
+    assert torch.equal(g.view(torch.int32), keep.view(torch.int32))
+    # a separate total: the grid on the union, zeros elsewhere (it held garbage)
+    total = torch.full_like(g, 7.0)
+    t2 = sr.start(g, total)
+    i2 = sr.complete(t2)
+    torch.cuda.synchronize()
+    assert torch.equal(total.view(torch.int32), keep.view(torch.int32)) and i2.n_union == want_union
+    # payload too small: overflow -> dense sum in complete()
+    if want_union > 1:
+        total.fill_(-3.0)
+        t3 = sr.start(g, total, capacity=max(1, want_union // 2))
+        i3 = sr.complete(t3)
+        torch.cuda.synchronize()
+        assert i3.mode == 2 and torch.equal(total.view(torch.int32), keep.view(torch.int32))
+        assert i3.reduce_bytes == nb + i3.capacity * 256 * ch + cells * ch * 4 == nb + i3.capacity * 256 * ch + i3.dense_bytes
+    else:
+        sr.complete(sr.start(g, total))
+    # the automatic capacity of call k comes from the union of call k - 2
+    t4 = sr.start(g)
+    i4 = sr.complete(t4)
+    assert i4.capacity == sh.sparse_capacity(nb, want_union)
+    if i4.mode == 0:
+        assert i4.reduce_bytes == nb + i4.capacity * 256 * ch and i4.reduce_bytes < i4.dense_bytes
+    # the caller's mask (delta path): exactly the marked bricks are replaced, the rest of a separate total is kept
+    mask_np = (rng.random(nb) < 0.07).astype(np.uint8)
+    mask = torch.from_numpy(mask_np).to(ctx.device)
+    total.fill_(-1.0)
+    i5 = sr.complete(sr.start(g, total, brick_mask=mask, capacity=nb // 2 if nb >= 4 else 0))
+    torch.cuda.synchronize()
+    if i5.mode == 0:
+        sel = np.repeat(mask_np[b.reshape(-1)].astype(bool), ch)
+        got = total.cpu().numpy()
+        assert i5.n_union == int(mask_np.sum())
+        assert np.array_equal(got[sel], g_np.reshape(-1)[sel]) and (got[~sel] == -1.0).all()
+    torch.cuda.synchronize()
+    assert torch.equal(g.view(torch.int32), keep.view(torch.int32))
+    sr.close()
+    comm.close()
+
+
+def test_sparse_reduce_ticket_discipline(ctx, cpm):
+    torch = ctx.torch
+    B = cpm.binding
+    comm = ctx.comm_create(ctx.comm_unique_id(), 0, 1)
+    sr = ctx.sparse_reduce_create(comm, B.default_grid_desc((16, 16, 16), 1))
+    g = torch.zeros(4096, device=ctx.device)
+    g[5] = 1.0
+    tickets = [sr.start(g) for _ in range(8)]
+    with pytest.raises(B.CpmError):
+        sr.start(g)                       # 8 issued and not completed
+    for t in tickets:
+        assert sr.complete(t).n_union == 1
+    assert sr.complete(tickets[-1]).n_union == 1   # completing twice is harmless
+    with pytest.raises(B.CpmError):
+        sr.complete(tickets[-1] + 1)      # never issued
+    t = sr.start(g)
+    assert t == tickets[-1] + 1
+    sr.complete(t)
+    with pytest.raises(B.CpmError):
+        sr.start(g, capacity=4096)        # beyond the number of bricks
+    # an empty grid: union 0, nothing moves, the grid stays zero
+    g.zero_()
+    assert sr.complete(sr.start(g)).n_union == 0
+    torch.cuda.synchronize()
+    assert not g.any()
+    sr.close()
+    comm.close()
+
+
+def test_overlapped_reducer_sparse_on_one_gpu(ctx, cpm):
+    """The frame loop of bench.py with the sparse reduce forced on at one rank: every frame's grid comes back unchanged,
+    and the figures of every ticket are recorded."""
+    torch = ctx.torch
+    B = cpm.binding
+    sh = importlib.import_module(cpm.__name__ + ".sharding")
+    tr = sh.RcclTransport(ctx, 0, 1)
+    gd = B.default_grid_desc((64, 64, 64), 1)
+    first = torch.zeros(64 ** 3, device=ctx.device)
+    red = sh.OverlappedGridReducer(first, tr, sparse=gd, force=True)
+    assert red.active
+    frames = []
+    for k in range(6):
+        out = red.acquire(k)
+        out.zero_()
+        out[: 64 * 64 * (2 + k)] = float(k + 1)
+        frames.append(out.clone())
+        red.reduce(k)
+    red.flush()
+    torch.cuda.synchronize()
+    assert torch.equal(red.result(5), frames[5]) and torch.equal(red.result(4), frames[4])
+    assert len(red.info) == 6
+    assert [i["n_union"] for i in red.info] == [256 * ((2 + k + 3) // 4) for k in range(6)]
+    tr.close()

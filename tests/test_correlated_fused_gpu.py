@@ -380,3 +380,101 @@ def test_importance_tf_occupancy_bits(ctx, cpm, n_cells):
     expect = np.zeros(words * 32, np.uint8)
     expect[:n_cells] = (w.view(np.uint32) != 0).astype(np.uint8)
     assert np.array_equal(bits_, expect)
+
+
+def test_failed_select_call_publishes_an_empty_selection(ctx, oracle, cpm):
+    """tiles appended by a call that then fails must be taken back -- the compaction would otherwise sum counts no
+    kernel wrote.  With the failure injected after the append (what a refused launch does), the selection's finish reports it
+    and publishes a count of 0, a later light of the same selection included; the next selection is unaffected."""
+    from oracle_binding import default_matrices
+    B = cpm.binding
+    vdim, region, n_side = 64, 8, 90
+    n = n_side * n_side
+    _, _, ls, isect, _, ph = _traced_setup(cpm, oracle, n_side, vdim)
+    gd = (vdim // region,) * 3
+    rng = np.random.default_rng(5)
+    grid = rng.random(gd[0] * gd[1] * gd[2], dtype=np.float32)
+    grid[rng.random(grid.size) < 0.7] = 0
+    t2i, _ = default_matrices((vdim,) * 3)
+    sel = ctx.selection_create(2 * n)
+    idx_d = ctx.torch.full((2 * n,), -1, dtype=ctx.torch.int32, device=ctx.device)
+    dgrid, dph2 = _t(ctx, grid), _t(ctx, np.concatenate([ph, ph]))
+    dls, dis = _t(ctx, ls), _t(ctx, isect)
+    args = (dgrid, gd, (float(region),) * 3, t2i.tolist(), dph2)
+
+    def fresh_keys():
+        return _t(ctx, np.full(2 * n, UNCHANGED, np.uint32))
+    # reference: both lights selected
+    imp = fresh_keys()
+    sel.begin()
+    sel.photon_importance(*args, 0, dls, dis, n, 1, 2 * n, imp)
+    sel.photon_importance(*args, n, dls, dis, n, 1, 2 * n, imp)
+    sel.finish(idx_d)
+    want = sel.count()
+    want_idx = _n(idx_d, np.uint32)[:want].copy()
+    assert want > 0
+    for failing in (0, 1):          # the first or the second light's call fails
+        imp = fresh_keys()
+        sel.begin()
+        for k in range(2):
+            if k == failing:
+                ctx.lib.cpm_debug_fail_next_select(ctx.h, 1)
+                with pytest.raises(B.CpmError):
+                    sel.photon_importance(*args, k * n, dls, dis, n, 1, 2 * n, imp)
+            else:
+                sel.photon_importance(*args, k * n, dls, dis, n, 1, 2 * n, imp)
+        with pytest.raises(B.CpmError):
+            sel.finish(idx_d)
+        assert sel.count() == 0
+    # the selection object is as good as new
+    imp = fresh_keys()
+    sel.begin()
+    sel.photon_importance(*args, 0, dls, dis, n, 1, 2 * n, imp)
+    sel.photon_importance(*args, n, dls, dis, n, 1, 2 * n, imp)
+    sel.finish(idx_d)
+    assert sel.count() == want and np.array_equal(_n(idx_d, np.uint32)[:want], want_idx)
+    sel.close()
+
+
+def test_importance_grid_beyond_the_lds_budget(ctx, oracle, cpm):
+    """An importance grid whose occupancy bits (1 per cell) do not fit beside the tracer's LUTs in the workgroup's LDS (80^3 cells =
+    64 000 bytes of bits): select and the one-launch retrace walk the grid without the bits -- same importances, same list."""
+    from oracle_binding import default_matrices
+    vdim, region, n_side = 80, 1, 64
+    n = n_side * n_side
+    vol_np, tf, ls, isect, st, ph = _traced_setup(cpm, oracle, n_side, vdim)
+    gd = (vdim // region,) * 3
+    rng = np.random.default_rng(11)
+    grid = (rng.random(gd[0] * gd[1] * gd[2], dtype=np.float32) * np.float32(0.02)).astype(np.float32)
+    grid[rng.random(grid.size) < 0.9] = 0
+    t2i, _ = default_matrices((vdim,) * 3)
+    imp_o = np.full(n, UNCHANGED, np.uint32)
+    oracle.photon_importance(grid, gd, (region,) * 3, t2i, ph, 0, ls, isect, n, 1, n, imp_o)
+    want_idx, want_cnt = oracle.select_changed(imp_o)
+    assert 0 < want_cnt < n
+    sel = ctx.selection_create(n)
+    imp_d = _t(ctx, np.full(n, UNCHANGED, np.uint32))
+    idx_d = ctx.torch.zeros(n, dtype=ctx.torch.int32, device=ctx.device)
+    sel.begin()
+    sel.photon_importance(_t(ctx, grid), gd, (float(region),) * 3, t2i.tolist(), _t(ctx, ph), 0, _t(ctx, ls), _t(ctx, isect), n, 1, n, imp_d)
+    sel.finish(idx_d)
+    assert sel.count() == want_cnt
+    assert np.array_equal(_n(imp_d, np.uint32), imp_o) and np.array_equal(_n(idx_d, np.uint32)[:want_cnt], want_idx[:want_cnt])
+    # the one-launch form over the same grid: same list; the selected photons are re-traced (same TF: the same photons again)
+    B = cpm.binding
+    p = B.TraceParams()
+    p.material[0] = 0.3
+    p.step_size = 1 / vdim
+    p.n_light_samples = n
+    p.max_interactions = 1
+    p.total_photons = n
+    dvol, dtf = ctx.volume_create(vol_np), ctx.tf_create(tf)
+    imp_d = _t(ctx, np.full(n, UNCHANGED, np.uint32))
+    dph, old = _t(ctx, ph), ctx.torch.zeros((n, 8), dtype=ctx.torch.float32, device=ctx.device)
+    sel.begin()
+    sel.photon_importance_retrace(_t(ctx, grid), gd, (float(region),) * 3, t2i.tolist(), dvol, dtf, cpm.synthetic.UNIT_CUBE_AABB, p, _t(ctx, ls),
+                                  _t(ctx, isect), imp_d, _t(ctx, st), dph, old)
+    sel.finish(idx_d)
+    assert sel.count() == want_cnt and np.array_equal(_n(idx_d, np.uint32)[:want_cnt], want_idx[:want_cnt])
+    assert np.array_equal(bits(_n(dph)), bits(ph))
+    sel.close()

@@ -249,3 +249,80 @@ def test_reduce_to_the_display_rank(tmp_path, cpm):
         port = s.getsockname()[1]
     mp.spawn(_root_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
     assert (tmp_path / "ok_0").read_text() == "1" and (tmp_path / "ok_1").read_text() == "1"
+
+
+def _sparse_worker(rank, world, port, out_dir, dims, channels, root):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    sys.path.insert(0, str(REPO))
+    import importlib
+    import torch
+    import torch.distributed as dist
+    import cpm_amd
+    sh = importlib.import_module(cpm_amd.__name__ + ".sharding")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dx, dy, dz = dims
+    n = dx * dy * dz * channels
+    nb = ((dx + 3) // 4) * ((dy + 3) // 4) * ((dz + 3) // 4)
+    gen = torch.Generator().manual_seed(1234 + rank)
+
+    def partial_grid(k):
+        """A rank's light volume of frame k: a lit slab whose depth grows with k (so the union outgrows a capacity sized two
+        frames earlier), every rank lighting slightly different voxels of it; exactly representable values (sums are exact)."""
+        g = torch.zeros(dz, dy, dx, channels)
+        depth = min(dz, 2 + 7 * k if k < 5 else 4)
+        lit = torch.rand(depth, dy, dx, generator=gen) < 0.3
+        vals = torch.randint(1, 1000, (depth, dy, dx, channels), generator=gen).float() / 8.0
+        g[:depth] = vals * lit[..., None]
+        return g.reshape(-1)
+
+    red = sh.OverlappedGridReducer(torch.zeros(n), sh.TorchTransport(root=root), sparse=(dims, channels))
+    K = 8
+    mine = []
+    for k in range(K):
+        out = red.acquire(k)
+        mine.append(partial_grid(k))
+        out.copy_(mine[-1])
+        red.reduce(k)
+        # dense reference of the same frame, computed with the plain collective
+        want = mine[-1].clone()
+        dist.all_reduce(want)
+        if root is None or rank == root:
+            got = red.result(k)
+            assert torch.equal(got, want), f"frame {k}: sparse sum != dense sum"
+    red.flush()
+    infos = red.info
+    assert len(infos) == K
+    # the capacity of frame k is the policy applied to the union of frame k - 2; the union is the same on every rank
+    for k, i in enumerate(infos):
+        assert i["n_bricks"] == nb
+        assert i["capacity"] == sh.sparse_capacity(nb, infos[k - 2]["n_union"] if k >= 2 else -1)
+        assert i["mode"] == (1 if i["capacity"] >= nb else 2 if i["n_union"] > i["capacity"] else 0)
+    unions = torch.tensor([i["n_union"] for i in infos])
+    gathered = [torch.zeros_like(unions) for _ in range(world)]
+    dist.all_gather(gathered, unions)
+    assert all(torch.equal(g, unions) for g in gathered)
+    with open(os.path.join(out_dir, f"modes_{rank}"), "w") as f:
+        f.write(",".join(str(i["mode"]) for i in infos) + ";" + ",".join(str(i["reduce_bytes"]) for i in infos) + ";" + str(infos[0]["dense_bytes"]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("dims,channels,root", [((32, 32, 32), 1, None), ((20, 13, 9), 1, None), ((16, 16, 24), 4, None), ((32, 32, 32), 1, 0)])
+def test_sparse_grid_reduce_equals_dense_sum(tmp_path, cpm, dims, channels, root):
+    """cpm_allreduce_grid_sparse's steps over gloo (TorchTransport carries them out with torch ops): the sum over the union
+    of the ranks' non-zero 4x4x4 bricks equals the dense sum bit for bit -- on the union and (zeros) elsewhere --, ragged
+    grids and 4 channels included; the payload is sized by the policy from the union two frames before; a union that
+    outgrows it falls back to the dense sum on every rank alike; steady frames move a fraction of the dense bytes."""
+    import socket
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_sparse_worker, args=(2, port, str(tmp_path), dims, channels, root), nprocs=2, join=True)
+    m0, m1 = (tmp_path / "modes_0").read_text(), (tmp_path / "modes_1").read_text()
+    assert m0 == m1
+    modes, moved, dense = m0.split(";")
+    modes, moved, dense = [int(x) for x in modes.split(",")], [int(x) for x in moved.split(",")], int(dense)
+    if dims == (32, 32, 32):
+        assert 2 in modes[:5]      # the growing slab overflowed a payload sized for an earlier frame
+        assert modes[-1] == 0 and moved[-1] * 2 < dense  # the steady thin slab: sparse, a fraction of the dense bytes

@@ -230,3 +230,36 @@ def test_adaptive_branch_takes_the_measured_cheaper_path(hostx, cpm):
     host.cpmh_path_costs(net.h, C.byref(costs))
     assert all(c > 0 for c in costs)
     net.close()
+
+
+def test_failed_importance_launch_falls_back_to_a_full_frame(hostx, cpm):
+    """A select / retrace call that fails after appending its tiles (injected: cpm_debug_fail_next_select) must not leave tiles no
+    kernel wrote in the selection: the finish publishes a count of 0 and reports the failure, the tracer serves the edit with a
+    full frame -- the photons of a from-scratch evaluation -- and the next edit takes the branch again."""
+    host = hostx
+    host.cpmh_debug_fail_next_select.argtypes = [C.c_void_p]
+    host.cpmh_debug_fail_next_select.restype = None
+    S = cpm.synthetic
+    vol = S.heterogeneous_volume(64)
+    pos, d = _light(cpm, (0.3, 0.5, -1.0))
+    for one_launch in (1.0, 0.0):
+        net = Net(host, vol, 128, pos, d, BASE, correlated=True)
+        assert host.cpmh_set_property_string(net.h, b"tracer", b"importanceBranchPolicy", b"always") == 0
+        assert host.cpmh_set_property_float(net.h, b"tracer", b"retraceInImportancePass", one_launch) == 0
+        net.evaluate(first=True)
+        assert host.cpmh_set_property_float(net.h, b"lightvolume", b"incrementalRecomputationThreshold", 100.0) == 0
+        host.cpmh_debug_fail_next_select(net.h)
+        net.set_tf(EDIT)
+        net.evaluate()
+        assert host.cpmh_last_tracer_decision(net.h) == b"full frame (the importance branch failed)"
+        assert host.cpmh_n_recomputed(net.h) == -1 and host.cpmh_last_light_volume_path(net.h) == b"full"
+        fresh = Net(host, vol, 128, pos, d, EDIT, correlated=False)
+        fresh.evaluate(first=True)
+        assert np.array_equal(bits(net.photons()), bits(fresh.photons()))
+        a, _, _ = net.light_volume()
+        b, _, _ = fresh.light_volume()
+        assert np.array_equal(bits(a), bits(b))
+        net.set_tf(BASE)                                   # the branch works again
+        net.evaluate()
+        assert host.cpmh_last_tracer_decision(net.h) == b"importance branch" and host.cpmh_n_recomputed(net.h) > 0
+        net.close(); fresh.close()
