@@ -63,7 +63,9 @@ struct BrickLayout {
     int lx, ly, lz;         // log2 brick size (voxels)
     int nbx, nby, nbz, nb;  // bricks
     int bvox;               // voxels per brick
-    int maxc;               // candidate voxels per axis (gather side; 0 until brick_reach)
+    int maxc;               // candidate voxels per axis, the widest axis' (0 until brick_reach)
+    int mcx, mcy, mcz;      // ... and per axis: an anisotropic grid (the workspace's 256 x 256 x 48 light volume: r = 2.8 / 2.8 / 0.5
+                            // voxels) has a box of 6 x 6 x 2 candidates
 };
 CPM_DEV uint32_t off_meta(const BrickLayout& L) { return (uint32_t)L.nb + 1u; }
 CPM_DEV uint32_t off_items(const BrickLayout& L) { return (uint32_t)L.nb + 5u; }
@@ -103,16 +105,27 @@ __host__ void brick_shape(const int dims[3], BrickLayout& L) {
     L.nbx = count(0); L.nby = count(1); L.nbz = count(2);
     L.nb = L.nbx * L.nby * L.nbz;
     L.bvox = 1 << (lg[0] + lg[1] + lg[2]);
-    L.maxc = 0;
+    L.maxc = L.mcx = L.mcy = L.mcz = 0;
 }
 
-// candidates per axis from the radius; false when the kernels do not cover it (a candidate box must not span more than
-// two bricks per axis, and the tuned record loops go up to 4 candidates per axis)
+// candidates per axis from the radius; false when the kernels do not cover it: a candidate box must not span more than
+// two bricks per axis (it is at most as wide as a brick, or the brick spans the axis).  Up to 4 candidates per axis the
+// record loops are unrolled (fast_brick_kernel<2 / 3 / 4>); wider boxes take run-time loops (<0>).
+constexpr int kMaxCandidates = 8;
 __host__ bool brick_reach(const GridDev& G, float radius, BrickLayout& L) {
-    const float rx = radius * G.t2i.sx, ry = radius * G.t2i.sy, rz = radius * G.t2i.sz;  // radius in voxels per axis
-    const float rmax = fmaxf(rx, fmaxf(ry, rz)) + 1e-3f;
-    L.maxc = (int)floorf(2.f * rmax) + 1;
-    return radius > 0.f && L.maxc <= 4;
+    const float r[3] = { radius * G.t2i.sx, radius * G.t2i.sy, radius * G.t2i.sz };  // radius in voxels per axis
+    int mc[3];
+    for (int a = 0; a < 3; ++a) {
+        const float c = floorf(2.f * (r[a] + 1e-3f)) + 1.f;
+        mc[a] = c < 1.f ? 1 : (c > 1e6f ? 1000000 : (int)c);
+    }
+    L.mcx = mc[0]; L.mcy = mc[1]; L.mcz = mc[2];
+    L.maxc = mc[0] > mc[1] ? (mc[0] > mc[2] ? mc[0] : mc[2]) : (mc[1] > mc[2] ? mc[1] : mc[2]);
+    if (!(radius > 0.f) || L.maxc > kMaxCandidates) return false;
+    const int lg[3] = { L.lx, L.ly, L.lz }, nbr[3] = { L.nbx, L.nby, L.nbz };
+    for (int a = 0; a < 3; ++a)
+        if (mc[a] > (1 << lg[a]) && nbr[a] > 1) return false;
+    return true;
 }
 __host__ size_t tile_bytes_for(const GridDev& G, const BrickLayout& L) { return (size_t)(G.channels == 4 ? 3 : 1) * (size_t)L.bvox * 8; }
 
@@ -133,12 +146,12 @@ CPM_DEV void axis_range(float u, float rg, int dim, int maxc, int& s, int& e) {
     e = min(e, s + maxc - 1);
 }
 struct Box { int sx, ex, sy, ey, sz, ez; };
-CPM_DEV bool candidate_box(const GridDev& G, float4 a, float rgx, float rgy, float rgz, int maxc, Box& b) {
+CPM_DEV bool candidate_box(const GridDev& G, float4 a, float rgx, float rgy, float rgz, int mcx, int mcy, int mcz, Box& b) {
     const f3 p = { a.x, a.y, a.z };
     const f3 u = transform_(G.t2i, p);
-    axis_range(u.x, rgx, G.dx, maxc, b.sx, b.ex);
-    axis_range(u.y, rgy, G.dy, maxc, b.sy, b.ey);
-    axis_range(u.z, rgz, G.dz, maxc, b.sz, b.ez);
+    axis_range(u.x, rgx, G.dx, mcx, b.sx, b.ex);
+    axis_range(u.y, rgy, G.dy, mcy, b.sy, b.ey);
+    axis_range(u.z, rgz, G.dz, mcz, b.sz, b.ez);
     return b.sx <= b.ex && b.sy <= b.ey && b.sz <= b.ez;
 }
 // f(key) for every brick the box touches (at most two per axis: a box is at most 4 voxels wide, a brick at least 8
@@ -236,7 +249,7 @@ __global__ __launch_bounds__(1024) void fast_count_kernel(const float* __restric
             if (p2 <= kFltMax) mp = max_(mp, p2);
         }
         Box box;
-        if (candidate_box(G, a[k], rgx, rgy, rgz, L.maxc, box)) for_each_brick(L, box, [&](uint32_t key) { atomicAdd(&s_hist[key], 1u); });
+        if (candidate_box(G, a[k], rgx, rgy, rgz, L.mcx, L.mcy, L.mcz, box)) for_each_brick(L, box, [&](uint32_t key) { atomicAdd(&s_hist[key], 1u); });
     }
     // max |power| of the workgroup (a finite, non-negative float orders like its bit pattern)
     for (int off = 32; off > 0; off >>= 1) mp = max_(mp, __shfl_xor(mp, off, 64));
@@ -313,7 +326,7 @@ __global__ __launch_bounds__(1024, 8) void fast_scatter_kernel(const float* __re
 #pragma unroll
         for (int k = 0; k < kScatterItems; ++k) {
             Box box;
-            if (is_sentinel(a[k]) || !candidate_box(G, a[k], rgx, rgy, rgz, L.maxc, box)) continue;
+            if (is_sentinel(a[k]) || !candidate_box(G, a[k], rgx, rgy, rgz, L.mcx, L.mcy, L.mcz, box)) continue;
             for_each_brick(L, box, [&](uint32_t key) {
                 const size_t pos = (size_t)atomicAdd(&s_pos[key], 1u);
                 if (CH == 1) {
@@ -337,11 +350,46 @@ __global__ __launch_bounds__(1024, 8) void fast_scatter_kernel(const float* __re
 // for the candidates beyond the face; d^2 in texture space with the contract's operands (c = indexToTexture * v,
 // d = c - p, d^2 = fma(dz, dz, fma(dy, dy, dx * dx))); weight 0.75 * (1 - d^2 / r^2) for d^2 <= r^2; value -> fixed point
 // by truncation.
+// The same record for a box of any width (MAXC = 0 of fast_brick_kernel: more than 4 candidates along some axis): run-time loops
+// over the candidates inside this brick, a row left as soon as dz^2 + dy^2 alone exceeds r^2.
+template <int CH>
+CPM_DEV void brick_record_wide(const GridDev& G, const BrickLayout& L, float4 a, float pg, float pb, int ox, int oy, int oz, int BX, int BY, int BZ,
+                               float rgx, float rgy, float rgz, float r2, float inv_r2, float k, float S, long long* __restrict__ tile, int plane) {
+    Box c;
+    if (!candidate_box(G, a, rgx, rgy, rgz, L.mcx, L.mcy, L.mcz, c)) return;
+    const int sx = max(c.sx, ox), ex = min(c.ex, ox + BX - 1);
+    const int sy = max(c.sy, oy), ey = min(c.ey, oy + BY - 1);
+    const int sz = max(c.sz, oz), ez = min(c.ez, oz + BZ - 1);
+    const float pk = __builtin_fabsf(a.w) <= kFltMax ? a.w * k : 0.f;
+    const float pkg = __builtin_fabsf(pg) <= kFltMax ? pg * k : 0.f, pkb = __builtin_fabsf(pb) <= kFltMax ? pb * k : 0.f;
+    float dx2[kMaxCandidates];
+#pragma unroll
+    for (int q = 0; q < kMaxCandidates; ++q) { const float d = fma_(G.i2t.sx, (float)(sx + q), G.i2t.tx) - a.x; dx2[q] = d * d; }
+    for (int vz = sz; vz <= ez; ++vz) {
+        const float dz = fma_(G.i2t.sz, (float)vz, G.i2t.tz) - a.z;
+        for (int vy = sy; vy <= ey; ++vy) {
+            const float dy = fma_(G.i2t.sy, (float)vy, G.i2t.ty) - a.y;
+            const int row = (sx - ox) + BX * ((vy - oy) + BY * (vz - oz));
+#pragma unroll
+            for (int q = 0; q < kMaxCandidates; ++q) {
+                const float d2 = fma_(dz, dz, fma_(dy, dy, dx2[q]));   // the contract's operands: dx * dx, then the two fmas
+                if (sx + q > ex || !(d2 <= r2)) continue;
+                const float w = 0.75f * (1.0f - d2 * inv_r2);
+                atomicAdd(reinterpret_cast<unsigned long long*>(tile + row + q), to_fixed(pk * w, S));
+                if (CH == 4) {
+                    atomicAdd(reinterpret_cast<unsigned long long*>(tile + plane + row + q), to_fixed(pkg * w, S));
+                    atomicAdd(reinterpret_cast<unsigned long long*>(tile + 2 * plane + row + q), to_fixed(pkb * w, S));
+                }
+            }
+        }
+    }
+}
+
 template <int MAXC, int CH>
 CPM_DEV void brick_record(const GridDev& G, float4 a, float pg, float pb, int ox, int oy, int oz, int BX, int BY, int BZ, float rgx,
                           float rgy, float rgz, float r2, float inv_r2, float k, float S, long long* __restrict__ tile, int plane) {
     Box c;
-    if (!candidate_box(G, a, rgx, rgy, rgz, MAXC, c)) return;
+    if (!candidate_box(G, a, rgx, rgy, rgz, MAXC, MAXC, MAXC, c)) return;
     const int sx = max(c.sx, ox), ex = min(c.ex, ox + BX - 1);
     const int sy = max(c.sy, oy), ey = min(c.ey, oy + BY - 1);
     const int sz = max(c.sz, oz), ez = min(c.ez, oz + BZ - 1);
@@ -447,7 +495,10 @@ __global__ __launch_bounds__(kBrickThreads, (CH == 4 ? 4 : CPM_BRICK_WAVES)) voi
 #pragma unroll
             for (int q = 0; q < kBrickPer; ++q) {
                 const uint32_t j = first + (uint32_t)(q * kBrickThreads + t);
-                if (j < j1) brick_record<MAXC, CH>(G, a[q], a2[q].x, a2[q].y, ox, oy, oz, BX, BY, BZ, rgx, rgy, rgz, r2, inv_r2, k, S, s_tile, L.bvox);
+                if (j < j1) {
+                    if (MAXC == 0) brick_record_wide<CH>(G, L, a[q], a2[q].x, a2[q].y, ox, oy, oz, BX, BY, BZ, rgx, rgy, rgz, r2, inv_r2, k, S, s_tile, L.bvox);
+                    else brick_record<(MAXC == 0 ? 1 : MAXC), CH>(G, a[q], a2[q].x, a2[q].y, ox, oy, oz, BX, BY, BZ, rgx, rgy, rgz, r2, inv_r2, k, S, s_tile, L.bvox);
+                }
             }
 #pragma unroll
             for (int q = 0; q < kBrickPer; ++q) { a[q] = an[q]; a2[q] = an2[q]; }
@@ -532,7 +583,7 @@ int cpm_bin_fast(cpm_ctx* ctx, const float* photons8, int n, const cpm_grid_desc
     BrickLayout L;
     brick_shape(grid->dims, L);
     if (!brick_reach(G, radius, L) || tile_bytes_for(G, L) > 160 * 1024 - 1024)
-        return set_error(ctx, CPM_ERR_UNSUPPORTED, "cpm_bin_fast", "radius beyond 2 voxels (or not positive): use cpm_bin + cpm_gather");
+        return set_error(ctx, CPM_ERR_UNSUPPORTED, "cpm_bin_fast", "radius beyond 3.5 voxels along some axis (or not positive): use cpm_bin + cpm_gather");
     CPM_REQUIRE(ctx, (long long)n * copies_per_photon(L) < (1ll << 32), "cpm_bin_fast: record positions are 32-bit (n * 8 must stay below 2^32)");
     // scratch: two histograms (nb brick counts + 4 accumulators), used in turn -- a call's scatter launch zeroes the one the
     // NEXT call counts into -- then run_base: one row of nb offsets per tile of 4096 photons (written only where a tile has
@@ -596,7 +647,7 @@ int cpm_gather_fast(cpm_ctx* ctx, const float* sorted_pos_power, const uint32_t*
     BrickLayout L;
     brick_shape(grid->dims, L);
     if (!brick_reach(G, radius, L))
-        return set_error(ctx, CPM_ERR_UNSUPPORTED, "cpm_gather_fast", "radius beyond 2 voxels: use cpm_bin + cpm_gather");
+        return set_error(ctx, CPM_ERR_UNSUPPORTED, "cpm_gather_fast", "radius beyond 3.5 voxels along some axis: use cpm_bin + cpm_gather");
     const size_t tile_bytes = tile_bytes_for(G, L);
     if (tile_bytes > 160 * 1024 - 1024)
         return set_error(ctx, CPM_ERR_UNSUPPORTED, "cpm_gather_fast", "brick does not fit the LDS: use cpm_bin + cpm_gather");
@@ -616,9 +667,9 @@ int cpm_gather_fast(cpm_ctx* ctx, const float* sorted_pos_power, const uint32_t*
                    radius, k, accumulate, grid_out);                                                                     \
     } while (0)
     if (G.channels == 1) {
-        if (L.maxc <= 2) CPM_BRICK_LAUNCH(2, 1); else if (L.maxc == 3) CPM_BRICK_LAUNCH(3, 1); else CPM_BRICK_LAUNCH(4, 1);
+        if (L.maxc <= 2) CPM_BRICK_LAUNCH(2, 1); else if (L.maxc == 3) CPM_BRICK_LAUNCH(3, 1); else if (L.maxc == 4) CPM_BRICK_LAUNCH(4, 1); else CPM_BRICK_LAUNCH(0, 1);
     } else {
-        if (L.maxc <= 2) CPM_BRICK_LAUNCH(2, 4); else if (L.maxc == 3) CPM_BRICK_LAUNCH(3, 4); else CPM_BRICK_LAUNCH(4, 4);
+        if (L.maxc <= 2) CPM_BRICK_LAUNCH(2, 4); else if (L.maxc == 3) CPM_BRICK_LAUNCH(3, 4); else if (L.maxc == 4) CPM_BRICK_LAUNCH(4, 4); else CPM_BRICK_LAUNCH(0, 4);
     }
 #undef CPM_BRICK_LAUNCH
     CPM_LAUNCH_CHECK(ctx, "fast_brick_kernel");

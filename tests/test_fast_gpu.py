@@ -74,11 +74,10 @@ def expected_filing(ph, dims, radius, grid):
     pairs = []
     stored = np.where(ph[:, 0] != FLT_MAX)[0]
     rng_axes = []
-    # at most floor(2 r') + 1 candidates per axis, r' along the widest axis (what capacity and loops are sized from)
-    rmax = max(np.float32(radius) * t2i[5 * a] for a in range(3)) + np.float32(1e-3)
-    maxc = int(np.floor(np.float32(2.0) * np.float32(rmax))) + 1
+    # at most floor(2 r') + 1 candidates along an axis, r' = r * textureToIndex + 1e-3 of that axis
     for a in range(3):
         s, t = t2i[5 * a], t2i[12 + a]
+        maxc = int(np.floor(np.float32(2.0) * np.float32(np.float32(radius) * s + np.float32(1e-3)))) + 1
         u = (np.float64(s) * ph[stored, a].astype(np.float64) + np.float64(t)).astype(np.float32)   # = fma(s, p, t): the product is exact in double
         rg = np.float32(radius) * s + np.float32(1e-3)
         lo = np.clip(np.ceil((u - rg).astype(np.float32)), 0, dims[a]).astype(np.int64)
@@ -145,6 +144,13 @@ CASES = [
     ((16, 16, 16), 1, 1, 0.866, dict(sentinels=0.0, outside=0.0)),
     ((16, 16, 16), 1, 63, 0.866, {}),
     ((16, 16, 16), 1, 4097, 0.866, {}),
+    # boxes wider than 4 candidates: the run-time record loops (fast_brick_kernel<0>)
+    ((64, 64, 64), 1, 40_000, 2.3, {}),
+    ((64, 64, 64), 4, 20_000, 3.4, dict(negative=True)),
+    ((40, 24, 56), 1, 30_000, 3.1, dict(cluster=0.0)),
+    ((256, 256, 48), 1, 200_000, 2.76, dict(cluster=0.9)),   # the workspace's light volume: 6 x 6 x 2 candidates
+    ((96, 96, 18), 4, 30_000, 2.76, {}),
+    ((256, 256, 192), 1, 60_000, 3.3, {}),                   # bigger bricks and wide boxes
 ]
 
 
@@ -218,19 +224,23 @@ def test_fast_unsupported_radius_is_refused(ctx, cpm):
     B = cpm.binding
     grid = B.default_grid_desc((32, 32, 32), 1)
     assert ctx.gather_fast_supported(grid, 0.866 / 32)
-    assert not ctx.gather_fast_supported(grid, 2.2 / 32)
+    # up to 8 candidate voxels per axis (r < 3.5 voxels: unrolled loops up to 4, run-time loops beyond); 4.2 voxels is refused
+    assert ctx.gather_fast_supported(grid, 2.2 / 32) and ctx.gather_fast_supported(grid, 3.4 / 32)
+    assert not ctx.gather_fast_supported(grid, 4.2 / 32)
+    # an anisotropic grid: the box is as wide as EACH axis' radius asks (the workspace's 256 x 256 x 48 light volume: 6 x 6 x 2)
+    assert ctx.gather_fast_supported(B.default_grid_desc((256, 256, 48), 1), 0.010779)
     table = ctx.torch.zeros(ctx.fast_table_entries(grid, 16), dtype=ctx.torch.int32, device=ctx.device)
-    assert ctx.fast_record_capacity(grid, 16, 0.866 / 32) == 8 * 16 and ctx.fast_record_capacity(grid, 16, 2.2 / 32) == 0
+    assert ctx.fast_record_capacity(grid, 16, 0.866 / 32) == 8 * 16 and ctx.fast_record_capacity(grid, 16, 4.2 / 32) == 0
     assert ctx.fast_record_capacity(grid, 16, 0.2 / 32) == 16      # a candidate box one voxel wide: one brick per photon
     srt = ctx.torch.zeros((8 * 16, 4), dtype=ctx.torch.float32, device=ctx.device)
     out = ctx.torch.zeros(32 ** 3, dtype=ctx.torch.float32, device=ctx.device)
     photons = ctx.torch.zeros((16, 8), dtype=ctx.torch.float32, device=ctx.device)
     with pytest.raises(B.CpmError) as e:
-        ctx.bin_fast(photons, 16, grid, 2.2 / 32, table, srt)
+        ctx.bin_fast(photons, 16, grid, 4.2 / 32, table, srt)
     assert e.value.status == -4  # CPM_ERR_UNSUPPORTED: callers fall back to cpm_bin + cpm_gather
     ctx.bin_fast(photons, 16, grid, 0.866 / 32, table, srt)
     with pytest.raises(B.CpmError) as e:
-        ctx.gather_fast(srt, table, 16, grid, 2.2 / 32, 1.0, out)
+        ctx.gather_fast(srt, table, 16, grid, 4.2 / 32, 1.0, out)
     assert e.value.status == -4
     with pytest.raises(B.CpmError):                                  # the records were filed for another radius
         ctx.gather_fast(srt, table, 16, grid, 1.2 / 32, 1.0, out)
