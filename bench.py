@@ -520,6 +520,16 @@ def main():
             net = hostlayer.HostNetwork(hl, vol_np, nx, lpos, dnorm, base_pts, size_option=vdim // gdim, correlated=True)
             net.evaluate(first=True)
             full_ms = net.bench_full_frames(reps_c)
+            # the headline's frame through the product's boundary -- the C++ Processor/Port layer: frames enqueued back to back
+            # with one synchronisation (throughput: what `value` measures through the Python driver) and every frame from an idle
+            # device until it is idle again (latency: what one Inviwo evaluation costs)
+            net.bench_frames_back_to_back(20)
+            thr_ms, enq_ms = net.bench_frames_back_to_back(max(100, args.steps))
+            extras["host_network"] = {
+                "throughput_ms_per_frame": round(thr_ms, 4), "mphotons_per_s": round(n_rank / thr_ms / 1e3, 2),
+                "latency_ms_from_idle": round(float(np.median(full_ms[10:])), 4), "host_enqueue_ms_per_frame": round(enq_ms, 4),
+                "measured": "libcpm_host.so: ProgressivePhotonTracerCL + PhotonToLightVolumeProcessorCL of the workspace's network (config 2, importance grid "
+                            "connected), full frames: invalidate -> tracer.process() -> lightVolume.process()"}
             # as shipped: importanceBranchPolicy = adaptive -- the tracer serves an edit with whichever of importance branch +
             # add-remove and full frame it has measured cheaper (the first edit probes the branch)
             ms_auto, n_auto = net.bench_tf_edits(edit, base_pts, reps_c)
@@ -646,6 +656,45 @@ def main():
                 tr1.close()
             except Exception as e:  # noqa: BLE001
                 extras["sparse_reduce_one_gpu"] = {"error": str(e)[:200]}
+        # the workspace's own operating point through the C++ processors (workspaces/CorrelatedPhotonMappingSingleVolume.inv: two
+        # directional lights on the tracer's multi-inport, 2 x 1024^2 samples, a 512 x 512 x 96 volume clipped as its proxy
+        # geometry is, a light volume of half the size): full frames and BASELINE config 3's TF edit on it
+        if args.workload == "config2" and fast:
+            try:
+                hostlayer = importlib.import_module(cpm_amd.__name__ + ".hostlayer")
+                hl = hostlayer.load()
+                wl = []
+                for w in ((-90.045471, 104.828, 312.07489), (94.269867, 148.44716, 302.45557)):   # the lights' world positions (:214,1089)
+                    dd = P._normalize(tuple(-x for x in w))
+                    wl.append((np.array([0.5, 0.5, 0.5], np.float32) - np.float32(2.0) * dd, dd))
+                vol_w = S.heterogeneous_volume((512, 512, 96))
+                base_pts = list(S.WORKSPACE_TF_POINTS)
+                edit = list(base_pts)
+                edit[3] = (0.26,) + base_pts[3][1:]
+                net = hostlayer.HostNetwork(hl, vol_w, 1024, wl[0][0], wl[0][1], base_pts, size_option=2, correlated=True)
+                net.add_light(*wl[1])
+                net.set_clip(73, 512, 7, 512, 0, 96)
+                net.evaluate(first=True)
+                net.bench_frames_back_to_back(10)
+                thr_w, _ = net.bench_frames_back_to_back(60)
+                lat_w = float(np.median(net.bench_full_frames(40)[10:]))
+                kern_w = net.profile_full_frames(30)
+                ms_e, n_e = net.bench_tf_edits(edit, base_pts, 40)
+                extras["workspace_point"] = {
+                    "ms_per_frame": round(thr_w, 4), "mphotons_per_s": round(2 * 1024 * 1024 / thr_w / 1e3, 2),
+                    "latency_ms_from_idle": round(lat_w, 4), "photons_per_frame": 2 * 1024 * 1024, "lights": 2,
+                    "volume": [512, 512, 96], "light_volume": [256, 256, 48], "clip": [73, 512, 7, 512, 0, 96],
+                    "candidate_box": "6 x 6 x 2 voxels (r = 2.8 / 2.8 / 0.5 light-volume voxels: |indexToTexture (1, 1, 1)| of a 4 : 4 : 0.75 volume)",
+                    "kernel_ms_per_frame": {k: round(v, 5) for k, v in sorted(kern_w.items(), key=lambda kv: -kv[1])},
+                    "tf_edit_update_ms": round(float(np.median(ms_e[10:])), 4),
+                    "tf_edit_fraction_retraced": round(float(np.mean(np.maximum(n_e[10:], 0))) / (2 * 1024 * 1024), 5),
+                    "tf_edit_served_by": net.last_decision,
+                    "measured": "libcpm_host.so: the workspace's network (two light samplers -> tracer multi-inport -> light volume), frames back to "
+                                "back with one synchronisation; tests/test_workspace_point_gpu.py holds the same network to the oracle"}
+                net.close()
+                del vol_w
+            except Exception as e:  # noqa: BLE001
+                extras["workspace_point"] = {"error": str(e)[:300]}
         # S independent frames in flight on S streams (each frame owns its context, buffers and stream)
         if args.streams > 1:
             ctxs = [B.Context(local_rank) for _ in range(args.streams)]
@@ -744,6 +793,8 @@ def main():
                          "launches_per_frame": round(per_frame[dom][1], 2)},
             "frame": {"kernel_ms_per_frame": {k: round(v[0], 5) for k, v in sorted(per_frame.items(), key=lambda kv: -kv[1][0])},
                       "stage_ms": stages, "sum_kernel_ms": round(sum(v[0] for v in per_frame.values()), 4),
+                      "kernel_times_from": "a second pass of the same frames with a HIP-event pair around every launch (about 1 us more per launch "
+                                           "than in the timed region: sum_kernel_ms exceeds ms_per_step by that)",
                       "algorithmic_bytes_per_frame": frame_bytes,
                       "frame_hbm_frac": round(frame_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)},
         }

@@ -712,6 +712,10 @@ __global__ __launch_bounds__(256) void partition_write_kernel(const uint32_t* __
 // last (config 3: tiles of 512 in index order 46.2 us; costliest first 39.4 -- the costliest tile alone; tiles of 256 in index
 // order 51 - 52, costliest first 34.1).  The cost is recorded (one atomic per wave) only in the launches the selection measures.
 constexpr uint32_t kRetraceTile = 256;
+#ifndef CPM_RETRACE_AHEAD
+#define CPM_RETRACE_AHEAD 2
+#endif
+constexpr int kRetraceAhead = CPM_RETRACE_AHEAD;
 template <int DT, bool MASK, bool SINGLE>
 __global__ __launch_bounds__(256) void importance_retrace_kernel(ImpGrid G, const uint32_t* __restrict__ mask, uint32_t mask_words,
                                                                  int fix_exit_point, uint32_t* __restrict__ importances, SelTiles S,
@@ -771,7 +775,9 @@ __global__ __launch_bounds__(256) void importance_retrace_kernel(ImpGrid G, cons
         const f3 direction = decode_direction_(l1.z, l1.w);
         float th, ph;
         encode_direction_(direction, th, ph);
-        tracer::trace_photon<DT, SINGLE>(A, lut, luts, threadId, l0, l1, ip, rs, direction, th, ph, steps);
+        // (kRetraceAhead fetches of the walk in flight, as in trace_kernel; this launch is the importance pass, not its few walks:
+        // 1 / 2 / 4 in flight 34.3 / 32.4 / 32.8 us, 8 -- registers -- 50.6)
+        tracer::trace_photon<DT, SINGLE, kRetraceAhead>(A, lut, luts, threadId, l0, l1, ip, rs, direction, th, ph, steps);
         importances[photon_offset + threadId] = 2147483647u;  // resetPhotonImportance (tracercl.cpp:529)
     }
     // (lanes reconverge here; one lane of the wave reports for it)

@@ -192,11 +192,52 @@ CPM_DEV float woodcock(const VolDev& V, const float* lut, float wf, float m1, fl
     return t;
 }
 
+// The same walk with the next AHEAD steps' volume fetches in flight together.  A Woodcock step's POSITION depends on the
+// random numbers only -- t += -log(u1) / 150 -- never on what was fetched; only whether the walk ends there does.  So the
+// positions of steps j + 1 .. j + AHEAD are known before step j's sample arrives: their fetches are issued back to back, then
+// the steps are decided in order; at the accepted step the RNG state is put back to what it was right behind that step's
+// second draw.  Same draws in the same order, same operations on the same operands: the same t, sample, opacity, state and
+// step count as woodcock() -- at the price of up to AHEAD - 1 fetches (and logs) past the end.  Two in flight pay everywhere
+// (the second fetch hides behind the first's latency: -6 % on the config-2 trace); more cost registers and bandwidth.
+template <int DT, int AHEAD>
+CPM_DEV float woodcock_ahead(const VolDev& V, const float* lut, float wf, float m1, float m2, f3 o, f3 d, float tStart,
+                             float tEnd, uint32_t& rx, uint32_t& rc, unsigned& steps, float& last_sample, float& last_opacity) {
+    constexpr float invTauMaxSampleBaseInterval = 1.f / (1.f * 150.f);
+    float t = tStart;
+    for (;;) {
+        float tj[AHEAD], u2j[AHEAD], vs[AHEAD];
+        uint32_t sx[AHEAD], sc[AHEAD];
+#pragma unroll
+        for (int j = 0; j < AHEAD; ++j) {
+            const float u1 = rand01_(rx, rc);
+            t = fma_(-log_(u1), invTauMaxSampleBaseInterval, t);
+            tj[j] = t;
+            u2j[j] = rand01_(rx, rc);
+            sx[j] = rx; sc[j] = rc;
+            // beyond tEnd (or t = inf / NaN) nothing is read from the fetch: a safe address instead of the walk's
+            const bool in = t <= tEnd;
+            vs[j] = sample_volume<DT>(V, in ? fma_(t, d.x, o.x) : 0.f, in ? fma_(t, d.y, o.y) : 0.f, in ? fma_(t, d.z, o.z) : 0.f);
+        }
+#pragma unroll
+        for (int j = 0; j < AHEAD; ++j) {
+            const bool in = tj[j] <= tEnd;
+            float opacity = 0.f;
+            if (in) { opacity = sample_alpha(lut, wf, m1, m2, vs[j]); last_sample = vs[j]; }
+            ++steps;
+            if (!(u2j[j] >= opacity && in)) {
+                rx = sx[j]; rc = sc[j];
+                last_opacity = opacity;
+                return tj[j];
+            }
+        }
+    }
+}
+
 // One light sample's walk: photontracer.cl:129-215 from the loaded sample on.  `direction` = decodeDirection(l1.z, l1.w) and
 // (th, ph) = encodeDirection(direction), evaluated by the caller (once per workgroup for a directional light, per lane
 // otherwise: the same operations on the same inputs either way).  Writes the photon records (and sentinels) of sample
 // `threadId`, its RNG state when progressive, its importance key when A.reset_importances is set.
-template <int DT, bool SINGLE>
+template <int DT, bool SINGLE, int AHEAD = 1>
 CPM_DEV void trace_photon(const TraceArgs& A, const float* lut, const float* luts, int threadId, float4 l0, float4 l1, float2 ip, uint2 rs,
                           f3 direction, float th, float ph, unsigned& steps) {
     const int photonOffset = A.p.photon_offset;
@@ -217,7 +258,8 @@ CPM_DEV void trace_photon(const TraceArgs& A, const float* lut, const float* lut
 
     if (!SINGLE && (A.p.flags & CPM_TRACE_NO_SINGLE_SCATTERING)) {  // photontracer.cl:143-157
         float vs_unused, op_unused;
-        float t = woodcock<DT>(A.vol, lut, wf, m1, m2, origin, direction, tStart, tEnd, rx, rc, steps, vs_unused, op_unused);
+        float t = AHEAD > 1 ? woodcock_ahead<DT, (AHEAD > 1 ? AHEAD : 2)>(A.vol, lut, wf, m1, m2, origin, direction, tStart, tEnd, rx, rc, steps, vs_unused, op_unused)
+                            : woodcock<DT>(A.vol, lut, wf, m1, m2, origin, direction, tStart, tEnd, rx, rc, steps, vs_unused, op_unused);
         if (scatterEvent) {
             origin.x = fma_(t, direction.x, origin.x);
             origin.y = fma_(t, direction.y, origin.y);
@@ -234,7 +276,8 @@ CPM_DEV void trace_photon(const TraceArgs& A, const float* lut, const float* lut
     }
     while (scatterEvent) {  // photontracer.cl:158-197
         float volumeSample = 0.f, colorW = 0.f;
-        float t = woodcock<DT>(A.vol, lut, wf, m1, m2, origin, direction, tStart, tEnd, rx, rc, steps, volumeSample, colorW);
+        float t = AHEAD > 1 ? woodcock_ahead<DT, (AHEAD > 1 ? AHEAD : 2)>(A.vol, lut, wf, m1, m2, origin, direction, tStart, tEnd, rx, rc, steps, volumeSample, colorW)
+                            : woodcock<DT>(A.vol, lut, wf, m1, m2, origin, direction, tStart, tEnd, rx, rc, steps, volumeSample, colorW);
         scatterEvent = t <= tEnd;
         if (scatterEvent) {
             origin.x = fma_(t, direction.x, origin.x);

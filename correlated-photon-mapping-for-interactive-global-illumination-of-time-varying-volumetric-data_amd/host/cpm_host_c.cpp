@@ -314,6 +314,30 @@ int cpmh_bench_frames_back_to_back(cpmh_network* net, int reps, double* total_ms
     return 0;
 }
 
+// Per-kernel GPU time of `reps` full frames of the network (the library's HIP-event hook on the runtime's context):
+// "kernel name=ms per frame;..." -- what bench.py reports for the workspace point.
+const char* cpmh_profile_full_frames(cpmh_network* net, int reps) {
+    static std::string out;
+    out.clear();
+    if (!net || reps < 1) return out.c_str();
+    cpm_ctx* ctx = CpmRuntime::get().ctx();
+    if (hipDeviceSynchronize() != hipSuccess) return out.c_str();
+    cpm_profile_reset(ctx);
+    cpm_profile_enable(ctx, 1);
+    for (int r = 0; r < reps; ++r) {
+        net->tracer.invalidateProgressiveRendering(PhotonData::InvalidationReason::All);
+        net->tracer.process();
+        net->lightVolume.process();
+    }
+    const int n = cpm_profile_collect(ctx);
+    std::ostringstream os;
+    for (int i = 0; i < n; ++i) os << cpm_profile_name(ctx, i) << "=" << cpm_profile_total_ms(ctx, i) / reps << ";";
+    if (!CpmRuntime::get().profiling()) cpm_profile_enable(ctx, 0);
+    cpm_profile_reset(ctx);
+    out = os.str();
+    return out.c_str();
+}
+
 // ---- time-varying data: .u3d files and the sequence processors ------------------------------------------
 
 struct cpmh_sequence;

@@ -63,6 +63,8 @@ StreamSpan::~StreamSpan() {
 void StreamSpan::begin(hipStream_t s, float* target) {
     poll();
     if (pending_) { open_ = false; return; }  // the previous span has not completed yet: skip this measurement
+    if (target && *target >= 0.f && ++skipped_ < kEvery) { open_ = false; return; }  // known: sampled every kEvery-th time
+    skipped_ = 0;
     if (!a_ && (hipEventCreate(&a_) != hipSuccess || hipEventCreate(&b_) != hipSuccess)) { a_ = b_ = nullptr; open_ = false; return; }
     target_ = target;
     open_ = hipEventRecord(a_, s) == hipSuccess;
@@ -1097,12 +1099,30 @@ void PhotonToLightVolumeProcessorCL::process() {  // photontolightvolumeprocesso
     const int maxRecomputationPhotons = (int)((float)nPhotons * (incrementalRecomputationThreshold_.get() / 100.f));
     const bool haveIdx = recomputedPhotonIndicesPort_.isReady();
     RecomputedPhotonIndices* rec = haveIdx ? recomputedPhotonIndicesPort_.getData().get() : nullptr;
-    // (a fused tracer evaluation left the count on the device: this reads its host mailbox, not the stream)
-    const int nRecomputed = haveIdx ? rec->resolveCount() : -1;
     // the records the re-traced photons had before: kept by the tracer for exactly those photons (fused branch), else this
     // processor's whole-buffer snapshot of the previous evaluation
     const bool exactAddRemove = exactIncrementalUpdate_.get() && formulation_.get() == "gather";
     const bool useReplaced = haveIdx && rec->replacedValid && !exactAddRemove && rec->replacedPhotons.getSize() == photonData->photons_.getSize();
+    // A fused tracer evaluation left the count on the device and it may still be on its way.  The add-remove launch does not need
+    // it on the host -- it reads the device word and stands aside by itself when the count reaches the rebuild threshold
+    // (apply_below) -- so it is enqueued FIRST, and only then does the host read the count (its pinned mailbox, not the
+    // stream): the launch is already queued behind the tracer's when the count arrives, instead of being launched into an idle
+    // GPU after it (8 - 10 us of every update).
+    bool deltaEnqueued = false;
+    if (haveIdx && rec->countPending && useReplaced && !fresh && maxRecomputationPhotons > 0) {
+        if (rec->costs) span_.begin(rt.stream(), &rec->costs->branchLightVolumeMs());
+        uint8_t* mask = nullptr;
+        if (comm_) {  // multi-GPU: the bricks an old or new position touches, marked by the same launch
+            const size_t nb = ((outDim.x + 3) / 4) * ((outDim.y + 3) / 4) * ((outDim.z + 3) / 4);
+            brickMask_.setSize(nb);
+            (void)hipMemsetAsync(brickMask_.device(), 0, nb, rt.stream());
+            mask = brickMask_.device();
+        }
+        deltaEnqueued = rt.check(cpm_splat_delta(rt.ctx(), reinterpret_cast<const float*>(rec->replacedPhotons.device()), rec->replacedStride, photons,
+                                                 rec->indicesToRecomputedPhotons.device(), rec->countDevice(), nPhotons, maxRecomputationPhotons, &g, radius,
+                                                 scale, nPhotons, nInter, mask, out, rt.stream()), "cpm_splat_delta");
+    }
+    const int nRecomputed = haveIdx ? rec->resolveCount() : -1;
     const bool havePrev = useReplaced || (prevPhotonsValid_ && prevPhotons_.getSize() == photonData->photons_.getSize());
     const bool canAddRemove = !fresh && haveIdx && havePrev && nRecomputed > 0 && nRecomputed < maxRecomputationPhotons;
     // a progressive iteration (i > 1): this evaluation's estimate goes to a side buffer and is averaged in below.  Only when
@@ -1117,7 +1137,7 @@ void PhotonToLightVolumeProcessorCL::process() {  // photontolightvolumeprocesso
     bool partialUpdate = false;  // this evaluation only touched the re-traced photons
     bool marksDone = false;      // brickMask_ already holds the old AND new positions' bricks
     // what this evaluation costs on the GPU's timeline, filed under the way the tracer served the change (PathCosts)
-    if (haveIdx && nRecomputed != 0 && rec->costs)
+    if (haveIdx && nRecomputed != 0 && rec->costs && !deltaEnqueued)  // (with the add-remove enqueued ahead, its span is already open)
         span_.begin(rt.stream(), (nRecomputed < 0) ? &rec->costs->fullLightVolumeMs : &rec->costs->branchLightVolumeMs());
     if (canAddRemove) {
         partialUpdate = true;
@@ -1138,6 +1158,10 @@ void PhotonToLightVolumeProcessorCL::process() {  // photontolightvolumeprocesso
                                                rt.stream()), "cpm_gather_bricks");
             marksDone = true;
             lastPath_ = "exact incremental";
+        } else if (useReplaced && deltaEnqueued) {
+            // add-remove (:196-298) in one launch over the device count: enqueued above, ahead of the count's arrival
+            marksDone = comm_ != nullptr;
+            lastPath_ = "incremental";
         } else if (useReplaced) {
             // add-remove (:196-298) in one launch over the device count: - the records the tracer replaced, + the new ones
             uint8_t* mask = nullptr;

@@ -63,13 +63,17 @@ struct PathCosts {
 class StreamSpan {
 public:
     ~StreamSpan();
-    void begin(hipStream_t s, float* target);  // records the start; `target` receives the milliseconds once they are known
+    // records the start; `target` receives the milliseconds once they are known.  A cost that is known is sampled again only
+    // every kEvery-th time: an event pair costs the frame ~3 us of its 70 on the GPU's timeline
+    void begin(hipStream_t s, float* target);
+    static constexpr int kEvery = 16;
     void end(hipStream_t s);
     void poll();                               // non-blocking: stores the elapsed time if the end event has completed
 private:
     hipEvent_t a_ = nullptr, b_ = nullptr;
     float* target_ = nullptr;
     bool pending_ = false, open_ = false;
+    int skipped_ = 0;
 };
 
 // ---- data types (L2) ---------------------------------------------------------------------------

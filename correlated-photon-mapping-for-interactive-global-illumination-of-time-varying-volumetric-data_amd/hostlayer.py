@@ -30,6 +30,7 @@ def load():
         "cpmh_bench_tf_edits": (i32, [vp, vp, i32, vp, i32, i32, vp, vp]),
         "cpmh_bench_full_frames": (i32, [vp, i32, vp]),
         "cpmh_bench_frames_back_to_back": (i32, [vp, i32, vp, vp]),
+        "cpmh_profile_full_frames": (C.c_char_p, [vp, i32]),
         "cpmh_add_light": (i32, [vp, C.POINTER(C.c_float * 3), C.POINTER(C.c_float * 3)]),
         "cpmh_n_lights": (i32, [vp]),
         "cpmh_set_clip": (None, [vp, i32, i32, i32, i32, i32, i32]),
@@ -109,6 +110,11 @@ class HostNetwork:
         if self.lib.cpmh_bench_frames_back_to_back(self.h, reps, C.byref(total), C.byref(host)) != 0:
             raise RuntimeError("cpmh_bench_frames_back_to_back failed")
         return total.value / reps, host.value / reps
+
+    def profile_full_frames(self, reps):
+        """{kernel name: ms per frame} over `reps` full frames (HIP events around every launch)."""
+        text = self.lib.cpmh_profile_full_frames(self.h, reps).decode()
+        return {k: float(v) for k, v in (item.split("=") for item in text.split(";") if item)}
 
     def add_light(self, light_position, light_direction):
         return int(self.lib.cpmh_add_light(self.h, C.byref((C.c_float * 3)(*light_position)), C.byref((C.c_float * 3)(*light_direction))))

@@ -29,6 +29,7 @@ def report(name, net, n_photons):
     thr, host = net.bench_frames_back_to_back(reps)
     lat = float(np.median(net.bench_full_frames(60)[10:]))
     print(f"{name}: throughput {thr:.4f} ms/frame ({n_photons / thr / 1e3:.0f} Mphotons/s), host enqueue {host:.4f} ms/frame, latency from idle {lat:.4f} ms")
+    print("    kernels (us per frame):", {k: round(v * 1e3, 1) for k, v in sorted(net.profile_full_frames(50).items(), key=lambda kv: -kv[1])})
 
 
 vol = S.heterogeneous_volume(256)
