@@ -39,14 +39,17 @@ def build_library(force: bool = False, verbose: bool = True) -> Path:
 HOST_SOURCES = ["cpm_processors.cpp", "cpm_timevarying.cpp", "cpm_modules.cpp", "cpm_host_c.cpp"]
 
 
-def build_host_library(force: bool = False, verbose: bool = True) -> Path:
-    """libcpm_host.so: the C++ Processor/Port layer over the C-ABI (host code only, links libcpm_hip.so)."""
-    out = PKG_DIR / "libcpm_host.so"
+def build_host_library(force: bool = False, verbose: bool = True, extras: bool = False) -> Path:
+    """libcpm_host.so: the C++ Processor/Port layer over the C-ABI (host code only, links libcpm_hip.so).
+    extras: also the processors outside the workspace's path (RadixSortCL node, UniformGrid3D export / selector / vector source:
+    -DCPM_HOST_EXTRAS) -> libcpm_host_extras.so; the default library does not carry them."""
+    out = PKG_DIR / ("libcpm_host_extras.so" if extras else "libcpm_host.so")
     srcs = [PKG_DIR / "host" / s for s in HOST_SOURCES]
     deps = srcs + list((PKG_DIR / "host").glob("*.h")) + [REPO / "include" / "cpm" / "cpm.h", PKG_DIR / "libcpm_hip.so"]
     if not force and out.exists() and all(out.stat().st_mtime >= d.stat().st_mtime for d in deps):
         return out
-    cmd = [hipcc(), "-x", "c++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-D__HIP_PLATFORM_AMD__", "-I", str(REPO / "include"),
+    cmd = [hipcc(), "-x", "c++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-D__HIP_PLATFORM_AMD__", *(["-DCPM_HOST_EXTRAS"] if extras else []),
+           "-I", str(REPO / "include"),
            "-I", str(PKG_DIR / "host"), "-I", "/opt/rocm/include", "-o", str(out), *map(str, srcs),
            "-L", str(PKG_DIR), "-lcpm_hip", "-L", "/opt/rocm/lib", "-lamdhip64", "-Wl,-rpath,$ORIGIN", "-Wl,-rpath,/opt/rocm/lib"]
     if verbose:

@@ -413,8 +413,10 @@ struct cpmh_sequence {
     VolumeMinMaxCLProcessor minMax;
     DynamicVolumeDifferenceAnalysis difference;
     UniformGrid3DPlayerProcessor minMaxPlayer, differencePlayer;
+#ifdef CPM_HOST_EXTRAS
     UniformGrid3DVectorSource gridSource;
     UniformGrid3DPlayerProcessor gridSourcePlayer;
+#endif
     bool analysed = false;
 };
 
@@ -435,7 +437,9 @@ cpmh_sequence* cpmh_sequence_create(const void* voxels, int dtype, int dx, int d
     s->difference.inport_.connectTo(&s->source);
     s->minMaxPlayer.inport_.connectTo(&s->minMax.vectorOutport_);
     s->differencePlayer.inport_.connectTo(&s->difference.outport_);
+#ifdef CPM_HOST_EXTRAS
     s->gridSourcePlayer.inport_.connectTo(&s->gridSource.port_);
+#endif
     return s;
 }
 void cpmh_sequence_destroy(cpmh_sequence* s) { delete s; }
@@ -475,7 +479,10 @@ int cpmh_sequence_step(cpmh_network* net, cpmh_sequence* s, float time, double* 
 }
 
 static void for_each_clock(cpmh_sequence* s, const std::function<void(SequenceClock&)>& f) {
-    f(s->volumePlayer.clock_); f(s->minMaxPlayer.clock_); f(s->differencePlayer.clock_); f(s->gridSourcePlayer.clock_);
+    f(s->volumePlayer.clock_); f(s->minMaxPlayer.clock_); f(s->differencePlayer.clock_);
+#ifdef CPM_HOST_EXTRAS
+    f(s->gridSourcePlayer.clock_);
+#endif
 }
 int cpmh_sequence_evaluate(cpmh_sequence* s) {
     if (!s->analysed) {  // per-sequence analysis runs once (the sequence does not change)
@@ -486,8 +493,10 @@ int cpmh_sequence_evaluate(cpmh_sequence* s) {
     s->volumePlayer.process();
     s->minMaxPlayer.process();
     s->differencePlayer.process();
+#ifdef CPM_HOST_EXTRAS
     s->gridSource.process();
     s->gridSourcePlayer.process();
+#endif
     return (s->volumePlayer.outport_.getData() && s->minMaxPlayer.outport_.getData() && s->differencePlayer.outport_.getData()) ? 0 : -1;
 }
 void cpmh_sequence_set_time_per_element(cpmh_sequence* s, float seconds) {
@@ -512,11 +521,17 @@ int cpmh_sequence_download(cpmh_sequence* s, int what, void* out) {
         std::memcpy(out, v->ramBytes.data(), v->ramBytes.size());
         return 0;
     }
+#ifdef CPM_HOST_EXTRAS
     auto g = what == 1 ? s->minMaxPlayer.outport_.getData() : (what == 2 ? s->differencePlayer.outport_.getData() : s->gridSourcePlayer.outport_.getData());
+#else
+    if (what != 1 && what != 2) return -1;
+    auto g = what == 1 ? s->minMaxPlayer.outport_.getData() : s->differencePlayer.outport_.getData();
+#endif
     if (!g) return -1;
     std::memcpy(out, g->hostData(), g->getSizeInBytes());
     return 0;
 }
+#ifdef CPM_HOST_EXTRAS
 // what: 1 = the min/max grids of all time steps, 2 = the difference grids
 int cpmh_sequence_export(cpmh_sequence* s, int what, const char* path) {
     UniformGrid3DExport exp;
@@ -529,12 +544,17 @@ int cpmh_sequence_export(cpmh_sequence* s, int what, const char* path) {
     return 0;
 }
 void cpmh_sequence_load_grids(cpmh_sequence* s, const char* path) { s->gridSource.filePath.set(path); }
+#endif
 const char* cpmh_sequence_describe_surface(cpmh_sequence* s) {
     static std::string str;
     std::ostringstream os;
+#ifdef CPM_HOST_EXTRAS
     UniformGrid3DExport exp;
     UniformGrid3DSequenceSelector sel;
     Processor* ps[] = { &s->volumePlayer, &s->minMax, &s->difference, &s->minMaxPlayer, &s->gridSource, &exp, &sel };
+#else
+    Processor* ps[] = { &s->volumePlayer, &s->minMax, &s->difference, &s->minMaxPlayer };
+#endif
     for (Processor* p : ps) {
         os << p->getProcessorInfo().classIdentifier << "|in:";
         for (auto& i : p->getInportIds()) os << i << ",";
@@ -583,6 +603,7 @@ const char* cpmh_factory_create(const char* class_identifier) {
     str = os.str();
     return str.c_str();
 }
+#ifdef CPM_HOST_EXTRAS
 // RadixSortCL processor: sorts n (key, data) u32 pairs on the device through the processor's ports
 int cpmh_radixsort_processor(uint32_t* keys, uint32_t* data, int n) {
     if (!CpmRuntime::get().valid()) return -1;
@@ -605,5 +626,6 @@ int cpmh_radixsort_processor(uint32_t* keys, uint32_t* data, int n) {
     std::memcpy(data, out->hostData(), (size_t)n * 4);
     return 0;
 }
+#endif
 
 }  // extern "C"

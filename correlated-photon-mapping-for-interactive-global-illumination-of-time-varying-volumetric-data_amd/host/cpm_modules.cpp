@@ -17,6 +17,7 @@ std::vector<std::string> ProcessorFactory::getKeys() const {
     return k;
 }
 
+#ifdef CPM_HOST_EXTRAS
 RadixSortCL::RadixSortCL() { addPortId("unsortedKeys", true); addPortId("unsortedData", true); addPortId("sortedData", false); }
 void RadixSortCL::process() {
     auto& rt = CpmRuntime::get();
@@ -30,6 +31,7 @@ void RadixSortCL::process() {
     rt.check(cpm_sort_pairs(rt.ctx(), keys->device(), data->device(), keys->getSize(), 0, rt.stream()), "cpm_sort_pairs");
     outputPort_.setData(data);  // pass-through, as the reference does (:255-258)
 }
+#endif
 
 ProgressivePhotonMappingModule::ProgressivePhotonMappingModule() : InviwoModule("ProgressivePhotonMapping") {
     registerProcessor<PhotonToLightVolumeProcessorCL>();
@@ -48,10 +50,12 @@ LightCLModule::LightCLModule() : InviwoModule("LightCL") {
 RndGenMWC64XModule::RndGenMWC64XModule() : InviwoModule("RndGenMWC64X") {}
 UniformGridCLModule::UniformGridCLModule() : InviwoModule("UniformGridCL") {
     registerProcessor<DynamicVolumeDifferenceAnalysis>();
-    registerProcessor<UniformGrid3DExport>();
     registerProcessor<UniformGrid3DPlayerProcessor>();
+#ifdef CPM_HOST_EXTRAS
+    registerProcessor<UniformGrid3DExport>();
     registerProcessor<UniformGrid3DSequenceSelector>();
     registerProcessor<UniformGrid3DVectorSource>();  // stands for UniformGrid3DSourceProcessor (reads a .u3d sequence)
+#endif
     registerProcessor<VolumeMinMaxCLProcessor>();
     registerProcessor<VolumeSequencePlayer>();
     registerDataReaderWriter("u3d");
@@ -62,7 +66,11 @@ ImportanceSamplingCLModule::ImportanceSamplingCLModule() : InviwoModule("Importa
     registerProcessor<MinMaxUniformGrid3DImportanceCLProcessor>();
     registerProcessor<UniformSampleGenerator2DProcessorCL>();
 }
-RadixSortCLModule::RadixSortCLModule() : InviwoModule("RadixSortCL") { registerProcessor<RadixSortCL>(); }
+RadixSortCLModule::RadixSortCLModule() : InviwoModule("RadixSortCL") {
+#ifdef CPM_HOST_EXTRAS
+    registerProcessor<RadixSortCL>();  // (the path sorts through cpm_sort_* / cpm_bin, not through this node)
+#endif
+}
 
 std::vector<std::unique_ptr<InviwoModule>> registerCorrelatedPhotonMappingModules() {
     std::vector<std::unique_ptr<InviwoModule>> m;

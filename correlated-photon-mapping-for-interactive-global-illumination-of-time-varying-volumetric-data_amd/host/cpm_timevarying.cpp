@@ -169,6 +169,7 @@ std::shared_ptr<UniformGrid3DVector> UniformGrid3DReader::readData(const std::st
     return dataVector;
 }
 
+#ifdef CPM_HOST_EXTRAS
 UniformGrid3DVectorSource::UniformGrid3DVectorSource() { addPortId("data", false); addProperty(filePath); }
 void UniformGrid3DVectorSource::process() {
     if (filePath.get().empty() || filePath.get() == loaded_) return;
@@ -190,6 +191,7 @@ void UniformGrid3DExport::exportData() {
         LogError(e.what());
     }
 }
+#endif
 
 // ---- difference analysis ----------------------------------------------------------------------------------
 
@@ -328,6 +330,7 @@ void VolumeSequencePlayer::process() {
     }
 }
 
+#ifdef CPM_HOST_EXTRAS
 UniformGrid3DSequenceSelector::UniformGrid3DSequenceSelector() {
     addPortId("inport", true); addPortId("outport", false);
     addProperty(index_);
@@ -339,5 +342,6 @@ void UniformGrid3DSequenceSelector::process() {
     size_t i = (size_t)std::max(1, index_.get()) - 1;
     outport_.setData(v->at(std::min(i, v->size() - 1)));
 }
+#endif
 
 }  // namespace inviwo

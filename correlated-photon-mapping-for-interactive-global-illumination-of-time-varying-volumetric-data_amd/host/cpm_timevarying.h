@@ -23,6 +23,7 @@ public:
     std::shared_ptr<UniformGrid3DVector> readData(const std::string& filePath);  // :59-183
 };
 
+#ifdef CPM_HOST_EXTRAS  // (out of SURVEY section 8's scope: see cpm_modules.h)
 // uniformgridcl/processors/uniformgrid3dvectorsource.{h,cpp} (DataSource<UniformGrid3DVector, ...>)
 class UniformGrid3DVectorSource : public Processor {
 public:
@@ -45,6 +46,7 @@ public:
     StringOptionProperty file_{ "file", "File name", "newvolume.u3d" };
     BoolProperty overwrite_{ "overwrite", "Overwrite", false };
 };
+#endif
 
 // uniformgridcl/processors/dynamicvolumedifferenceanalysis.{h,cpp}: per brick mean |next - cur| for every time step
 // (a CPU loop in the reference, :96-151; cpm_volume_difference here)
@@ -108,6 +110,7 @@ private:
     std::shared_ptr<Volume> outVolume_;
 };
 
+#ifdef CPM_HOST_EXTRAS
 // uniformgridcl/processors/uniformgrid3dsequenceselector.{h,cpp}: VectorElementSelectorProcessor<UniformGrid3DBase>
 // (port / property ids of Inviwo's VectorElementSelectorProcessor, assumed: "inport", "outport", "timeStep")
 class UniformGrid3DSequenceSelector : public Processor {
@@ -119,5 +122,6 @@ public:
     DataOutport<UniformGrid3DBase> outport_{ "outport" };
     IntProperty index_{ "selectedSequenceIndex", "Sequence index", 1 };
 };
+#endif
 
 }  // namespace inviwo

@@ -59,6 +59,14 @@ def host(cpm, ctx):
     return lib
 
 
+@pytest.fixture(scope="module")
+def host_extras(cpm, ctx):
+    """libcpm_host_extras.so: the same layer built with -DCPM_HOST_EXTRAS -- the processors outside the workspace's path
+    (RadixSortCL node, UniformGrid3D export / selector / vector source); the product library does not carry them."""
+    cpm.build.build_host_library(extras=True)
+    return C.CDLL(str(cpm.binding.LIB_PATH.parent / "libcpm_host_extras.so"))
+
+
 class Net:
     def __init__(self, lib, vol, n_side, light_pos, light_dir, tf_points, size_option=2, max_scattering=1, correlated=False):
         self.lib = lib
@@ -360,9 +368,11 @@ assert h and lib.cpmh_evaluate(h, 1) == 0
     assert "Photons to light volume: " in log and "fast_scatter_kernel" in log and "fast_brick_kernel" in log
 
 
-def test_radixsort_processor(host, ctx):
-    """org.inviwo.RadixSortCL created through the module factory: keys sorted ascending, data permuted with them
+def test_radixsort_processor(host, host_extras, ctx):
+    """(extras build) org.inviwo.RadixSortCL created through the module factory: keys sorted ascending, data permuted with them
     (stable), pass-through of the data buffer (radixsortcl.cpp:208-259)."""
+    assert not hasattr(host, "cpmh_radixsort_processor")      # not in the product library
+    host = host_extras
     host.cpmh_radixsort_processor.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
     rng = np.random.default_rng(4)
     n = 100_003

@@ -14,12 +14,14 @@ MODULES = {  # ref <name>module.cpp: identifier, getVersion(), registerProcessor
     "ProgressivePhotonMapping": (0, {"org.inviwo.PhotonToLightVolumeProcessorCL", "org.inviwo.ProgressivePhotonTracerCL"}),
     "LightCL": (1, {"org.inviwo.DirectionalLightSamplerCL"}),
     "RndGenMWC64X": (0, set()),
-    "UniformGridCL": (1, {"org.inviwo.DynamicVolumeDifferenceAnalysis", "org.inviwo.UniformGrid3DExport",
-                          "org.inviwo.UniformGrid3DPlayerProcessor", "org.inviwo.UniformGrid3DSequenceSelector",
+    "UniformGridCL": (1, {"org.inviwo.DynamicVolumeDifferenceAnalysis", "org.inviwo.UniformGrid3DPlayerProcessor",
                           "org.inviwo.VolumeMinMaxCLProcessor", "org.inviwo.VolumeSequencePlayer"}),
     "ImportanceSamplingCL": (1, {"org.inviwo.MinMaxUniformGrid3DImportanceCLProcessor", "org.inviwo.UniformSampleGenerator2DCL"}),
-    "RadixSortCL": (0, {"org.inviwo.RadixSortCL"}),
+    "RadixSortCL": (0, set()),   # the module registers; its sort NODE is outside the path (the path sorts through cpm_bin / cpm_sort_*)
 }
+# processors of the reference's modules outside SURVEY section 8's scope: only in the -DCPM_HOST_EXTRAS build
+EXTRAS = {"UniformGridCL": {"org.inviwo.UniformGrid3DExport", "org.inviwo.UniformGrid3DSequenceSelector", "org.inviwo.UniformGrid3DVectorSource"},
+          "RadixSortCL": {"org.inviwo.RadixSortCL"}}
 # port class identifiers the workspace spells out (.inv:465-469, 547-548, 618-619)
 WORKSPACE_PORT_TYPES = {"UniformGrid3DBaseInport", "UniformGrid3DBaseOutport", "PhotonDataInport", "RecomputedPhotonIndicesInport",
                         "LightSamplesMultiInport"}
@@ -29,6 +31,16 @@ WORKSPACE_PORT_TYPES = {"UniformGrid3DBaseInport", "UniformGrid3DBaseOutport", "
 def host(cpm):
     cpm.build.build_host_library()
     lib = C.CDLL(str(cpm.binding.LIB_PATH.parent / "libcpm_host.so"))
+    lib.cpmh_modules_describe.restype = C.c_char_p
+    lib.cpmh_factory_create.restype = C.c_char_p
+    lib.cpmh_factory_create.argtypes = [C.c_char_p]
+    return lib
+
+
+@pytest.fixture(scope="module")
+def host_extras(cpm):
+    cpm.build.build_host_library(extras=True)
+    lib = C.CDLL(str(cpm.binding.LIB_PATH.parent / "libcpm_host_extras.so"))
     lib.cpmh_modules_describe.restype = C.c_char_p
     lib.cpmh_factory_create.restype = C.c_char_p
     lib.cpmh_factory_create.argtypes = [C.c_char_p]
@@ -53,6 +65,19 @@ def test_modules_register_the_reference_surface(host):
         assert procs <= seen[name][1], (name, procs - seen[name][1])
     assert "u3d" in seen["UniformGridCL"][2]
     assert WORKSPACE_PORT_TYPES <= ports
+    for name, procs in EXTRAS.items():                 # the product library does not register what the path does not use
+        assert not (procs & seen[name][1]), (name, procs & seen[name][1])
+
+
+def test_extras_build_registers_the_out_of_scope_processors(host_extras):
+    seen = {}
+    for line in host_extras.cpmh_modules_describe().decode().strip().splitlines():
+        name, _, procs, _, _ = line.split("|")
+        seen[name] = set(filter(None, procs.split(",")))
+    for name, procs in EXTRAS.items():
+        assert procs <= seen[name], (name, procs - seen[name])
+    cid, ins, outs, _ = _parse(host_extras.cpmh_factory_create(b"org.inviwo.RadixSortCL").decode())
+    assert ins == {"unsortedKeys", "unsortedData"} and outs == {"sortedData"}          # radixsortcl.cpp:194-202
 
 
 def test_factory_creates_processors_by_class_identifier(host):
@@ -61,8 +86,7 @@ def test_factory_creates_processors_by_class_identifier(host):
     assert cid == "org.inviwo.ProgressivePhotonTracerCL"
     assert {"volume", "recomputationImportance", "LightSamples"} <= ins and {"photons", "recomputedIndices"} <= outs
     assert {"maxIncrementalPhotonsToUpdate", "maxScatteringEvents", "radius"} <= props
-    cid, ins, outs, _ = _parse(host.cpmh_factory_create(b"org.inviwo.RadixSortCL").decode())
-    assert ins == {"unsortedKeys", "unsortedData"} and outs == {"sortedData"}          # radixsortcl.cpp:194-202
+    assert host.cpmh_factory_create(b"org.inviwo.RadixSortCL") == b""     # outside the path: extras build only
     assert host.cpmh_factory_create(b"org.inviwo.NoSuchProcessor") == b""
 
 

@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 
 from test_parity_gpu import _n, bits
-from test_host_layer_gpu import host  # noqa: F401  (fixture: builds and loads libcpm_host after torch's HIP runtime)
+from test_host_layer_gpu import host, host_extras  # noqa: F401  (fixtures: build and load libcpm_host after torch's HIP runtime)
 
 pytestmark = pytest.mark.gpu
 
@@ -18,27 +18,37 @@ SURFACE = {  # ref uniformgridcl/processors/*.cpp constructors
                                                 {"time", "selectedSequenceIndex", "timePerElement", "frameRate", "playSequence"}),
     "org.inviwo.VolumeMinMaxCLProcessor": ({"volume", "VolumeSequenceInput"}, {"output", "UniformGrid3DVectorOut"}, {"region"}),
     "org.inviwo.DynamicVolumeDifferenceAnalysis": ({"data"}, {"DynamicDataInfo"}, {"region"}),
+}
+SURFACE_EXTRAS = {  # outside the workspace's path: -DCPM_HOST_EXTRAS build only
     "org.inviwo.UniformGrid3DVectorSource": (set(), {"data"}, set()),
     "org.inviwo.UniformGrid3DExport": ({"data"}, set(), set()),
     "org.inviwo.UniformGrid3DSequenceSelector": (set(), set(), set()),
 }
+SEQ_SIGNATURES = [("cpmh_sequence_create", C.c_void_p, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
+                  ("cpmh_sequence_destroy", None, [C.c_void_p]), ("cpmh_sequence_evaluate", C.c_int, [C.c_void_p]),
+                  ("cpmh_sequence_set_time_per_element", None, [C.c_void_p, C.c_float]),
+                  ("cpmh_sequence_set_time", C.c_int, [C.c_void_p, C.c_float]), ("cpmh_sequence_tick", C.c_int, [C.c_void_p]),
+                  ("cpmh_sequence_time", C.c_float, [C.c_void_p]), ("cpmh_sequence_max_time", C.c_float, [C.c_void_p]),
+                  ("cpmh_sequence_weight", C.c_float, [C.c_void_p]),
+                  ("cpmh_sequence_download", C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
+                  ("cpmh_sequence_describe_surface", C.c_char_p, [C.c_void_p])]
 
 
 @pytest.fixture(scope="module")
 def seqlib(host):
-    for name, res, args in [("cpmh_sequence_create", C.c_void_p, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
-                            ("cpmh_sequence_destroy", None, [C.c_void_p]), ("cpmh_sequence_evaluate", C.c_int, [C.c_void_p]),
-                            ("cpmh_sequence_set_time_per_element", None, [C.c_void_p, C.c_float]),
-                            ("cpmh_sequence_set_time", C.c_int, [C.c_void_p, C.c_float]), ("cpmh_sequence_tick", C.c_int, [C.c_void_p]),
-                            ("cpmh_sequence_time", C.c_float, [C.c_void_p]), ("cpmh_sequence_max_time", C.c_float, [C.c_void_p]),
-                            ("cpmh_sequence_weight", C.c_float, [C.c_void_p]),
-                            ("cpmh_sequence_download", C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
-                            ("cpmh_sequence_export", C.c_int, [C.c_void_p, C.c_int, C.c_char_p]),
-                            ("cpmh_sequence_load_grids", None, [C.c_void_p, C.c_char_p]),
-                            ("cpmh_sequence_describe_surface", C.c_char_p, [C.c_void_p])]:
+    for name, res, args in SEQ_SIGNATURES:
         f = getattr(host, name)
         f.restype, f.argtypes = res, args
     return host
+
+
+@pytest.fixture(scope="module")
+def seqlib_extras(host_extras):
+    for name, res, args in SEQ_SIGNATURES + [("cpmh_sequence_export", C.c_int, [C.c_void_p, C.c_int, C.c_char_p]),
+                                             ("cpmh_sequence_load_grids", None, [C.c_void_p, C.c_char_p])]:
+        f = getattr(host_extras, name)
+        f.restype, f.argtypes = res, args
+    return host_extras
 
 
 def _sequence(cpm, dim=32, steps=4):
@@ -57,6 +67,20 @@ def test_sequence_surface(seqlib, cpm):
         assert cid in seen, cid
         assert ins <= seen[cid][0] and outs <= seen[cid][1] and props <= seen[cid][2], (cid, seen[cid])
     seqlib.cpmh_sequence_destroy(h)
+
+
+def test_sequence_surface_of_the_extras_build(seqlib_extras, seqlib, cpm):
+    vols = _sequence(cpm, 16, 2)
+    h = seqlib_extras.cpmh_sequence_create(vols.ctypes.data, 0, 16, 16, 16, 2, 8)
+    seen = {}
+    for line in seqlib_extras.cpmh_sequence_describe_surface(h).decode().strip().splitlines():
+        cid, i, o, p = line.split("|")
+        seen[cid] = (set(filter(None, i[3:].split(","))), set(filter(None, o[4:].split(","))), set(filter(None, p[5:].split(","))))
+    for cid, (ins, outs, props) in {**SURFACE, **SURFACE_EXTRAS}.items():
+        assert cid in seen, cid
+        assert ins <= seen[cid][0] and outs <= seen[cid][1] and props <= seen[cid][2], (cid, seen[cid])
+    seqlib_extras.cpmh_sequence_destroy(h)
+    assert not hasattr(seqlib, "cpmh_sequence_export")      # the product library: players and analyses only
 
 
 def test_players_match_the_abi(seqlib, ctx, oracle, cpm, tmp_path):
@@ -101,7 +125,23 @@ def test_players_match_the_abi(seqlib, ctx, oracle, cpm, tmp_path):
         ctx.mix_buffers(diffs[i0], diffs[i1], w, od)
         assert np.array_equal(bits(gd), bits(_n(od)))
 
-    # export the analysed grids, read them back through the vector source, play them: same interpolated grid
+    seqlib.cpmh_sequence_destroy(h)
+
+
+def test_export_and_vector_source_of_the_extras_build(seqlib_extras, ctx, cpm, tmp_path):
+    """(extras build) export the analysed grids, read them back through the vector source, play them: same interpolated grid."""
+    seqlib = seqlib_extras
+    dim, steps, region = 32, 4, 8
+    vols = _sequence(cpm, dim, steps)
+    h = seqlib.cpmh_sequence_create(vols.ctypes.data, 0, dim, dim, dim, steps, region)
+    nb = (dim // region) ** 3
+    dvols = [ctx.volume_create(v) for v in vols]
+    mms = []
+    for t in range(steps):
+        mm = ctx.torch.zeros((nb, 2), dtype=ctx.torch.int16, device=ctx.device)
+        ctx.volume_minmax(dvols[t], region, mm)
+        mms.append(mm)
+    seqlib.cpmh_sequence_evaluate(h)
     path = str(tmp_path / "minmax.u3d").encode()
     assert seqlib.cpmh_sequence_export(h, 1, path) == 0
     seqlib.cpmh_sequence_load_grids(h, path)

@@ -17,7 +17,8 @@ rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write --
 python3 tools/pmc_traffic.py $O/pmc_fetch $O/pmc_write $O/pmc_traffic.json $WL
 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU --output-format csv -d $O/sq_a -- python3 tools/stage_only.py frame_fast 10 $WL > $O/sq_a.log 2>&1
 rocprofv3 --kernel-trace --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_SCA SQ_INST_CYCLES_VMEM --output-format csv -d $O/sq_b -- python3 tools/stage_only.py frame_fast 10 $WL > $O/sq_b.log 2>&1
-mkdir -p $O/sq; cp -r $O/sq_a $O/sq/a; cp -r $O/sq_b $O/sq/b
+rocprofv3 --kernel-trace --pmc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum --output-format csv -d $O/sq_c -- python3 tools/stage_only.py frame_fast 10 $WL > $O/sq_c.log 2>&1
+mkdir -p $O/sq; cp -r $O/sq_a $O/sq/a; cp -r $O/sq_b $O/sq/b; cp -r $O/sq_c $O/sq/c
 python3 tools/pmc_summary.py $O/sq > $O/sq_counters_summary.txt
 python3 bench.py --workload $WL --steps 200 --warmup 20 > $O/bench.log 2>&1; grep '"metric"' $O/bench.log > $O/bench.json; cut -c1-600 $O/bench.json
-rm -rf $O/stats $O/pmc_fetch $O/pmc_write $O/sq_a $O/sq_b $O/sq
+rm -rf $O/stats $O/pmc_fetch $O/pmc_write $O/sq_a $O/sq_b $O/sq_c $O/sq
