@@ -412,10 +412,12 @@ def main():
                 fr.trace()
                 if fast:
                     fr.bin_fast()
-                    fr.gather_fast(out=reducer.acquire(k))
-                else:
-                    fr.bin()
-                    fr.gather(out=reducer.acquire(k))
+                    marks = reducer.marks_for(k) if reducer.sparse else None   # (the gather also marks the volume's non-zero bricks)
+                    fr.gather_fast(out=reducer.acquire(k), nonzero_bricks=marks)
+                    reducer.reduce(k, marked=marks is not None)
+                    return
+                fr.bin()
+                fr.gather(out=reducer.acquire(k))
             reducer.reduce(k)
 
         def barrier():
@@ -637,7 +639,9 @@ def main():
                 kf = [0]
 
                 def frame_with_reduce():
-                    fr.trace(); fr.bin_fast(); fr.gather_fast(out=red1.acquire(kf[0])); red1.reduce(kf[0]); kf[0] += 1
+                    fr.trace(); fr.bin_fast()
+                    fr.gather_fast(out=red1.acquire(kf[0]), nonzero_bricks=red1.marks_for(kf[0]))
+                    red1.reduce(kf[0], marked=True); kf[0] += 1
                 ms_red = timed(torch, frame_with_reduce, reps)
                 ctx.profile_reset(); ctx.profile_enable(True)
                 for _ in range(20):

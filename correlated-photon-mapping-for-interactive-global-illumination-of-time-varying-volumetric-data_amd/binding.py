@@ -35,7 +35,7 @@ ABI_SYMBOLS = [
     "cpm_grid_desc_default", "cpm_relative_irradiance_scale",
     "cpm_splat", "cpm_splat_selected", "cpm_copy_indexed_photons", "cpm_snapshot_selected_photons",
     "cpm_sort_pairs", "cpm_sort_keys", "cpm_bin", "cpm_gather", "cpm_mark_touched_bricks", "cpm_gather_bricks",
-    "cpm_fast_table_entries", "cpm_gather_fast_supported", "cpm_fast_record_capacity", "cpm_bin_fast", "cpm_gather_fast",
+    "cpm_fast_table_entries", "cpm_gather_fast_supported", "cpm_fast_record_capacity", "cpm_bin_fast", "cpm_gather_fast", "cpm_gather_fast_marked",
     "cpm_volume_minmax", "cpm_volume_difference", "cpm_volume_step", "cpm_importance_tf", "cpm_importance_tf_occupancy",
     "cpm_photon_importance", "cpm_photon_importance_equal", "cpm_reset_importance",
     "cpm_select_recompute", "cpm_select_changed",
@@ -217,6 +217,7 @@ def load_library() -> C.CDLL:
         "cpm_fast_record_capacity": (sz, [P(GridDesc), i32, f32]),
         "cpm_bin_fast": (i32, [vp, vp, i32, P(GridDesc), f32, vp, vp, vp]),
         "cpm_gather_fast": (i32, [vp, vp, vp, i32, P(GridDesc), f32, f32, i32, vp, vp]),
+        "cpm_gather_fast_marked": (i32, [vp, vp, vp, i32, P(GridDesc), f32, f32, i32, vp, vp, vp]),
         "cpm_volume_minmax": (i32, [vp, vp, i32, vp, vp]),
         "cpm_volume_difference": (i32, [vp, vp, vp, i32, vp, vp]),
         "cpm_volume_step": (i32, [vp, vp, vp, i32, vp, vp, vp]),
@@ -256,7 +257,7 @@ def load_library() -> C.CDLL:
         "cpm_sparse_reduce_destroy": (None, [vp]),
         "cpm_sparse_reduce_bricks": (u32, [vp]),
         "cpm_sparse_reduce_capacity_for": (u32, [u32, C.c_longlong]),
-        "cpm_allreduce_grid_sparse": (i32, [vp, vp, vp, vp, vp, i32, u32, P(C.c_uint64), vp]),
+        "cpm_allreduce_grid_sparse": (i32, [vp, vp, vp, vp, vp, i32, i32, u32, P(C.c_uint64), vp]),
         "cpm_sparse_reduce_complete": (i32, [vp, vp, C.c_uint64, vp, P(SparseReduceInfo)]),
         "cpm_gl_available": (i32, [vp]),
         "cpm_gl_register_buffer": (i32, [vp, u32, i32, P(vp)]),
@@ -536,9 +537,14 @@ class Context:
         self._check(self.lib.cpm_bin_fast(self.h, self._ptr(photons), n, C.byref(grid), radius, self._ptr(brick_table),
                                           self._ptr(sorted_pos_power), self._stream()))
 
-    def gather_fast(self, sorted_pos_power, brick_table, n, grid, radius, scale, out, accumulate=False):
-        self._check(self.lib.cpm_gather_fast(self.h, self._ptr(sorted_pos_power), self._ptr(brick_table), n, C.byref(grid), radius,
-                                             scale, int(accumulate), self._ptr(out), self._stream()))
+    def gather_fast(self, sorted_pos_power, brick_table, n, grid, radius, scale, out, accumulate=False, nonzero_bricks=None):
+        """nonzero_bricks (uint8, one per 4x4x4 brick): also written -- 1 where the volume is not zero (cpm_gather_fast_marked)."""
+        if nonzero_bricks is None:
+            self._check(self.lib.cpm_gather_fast(self.h, self._ptr(sorted_pos_power), self._ptr(brick_table), n, C.byref(grid), radius, scale,
+                                                 int(accumulate), self._ptr(out), self._stream()))
+        else:
+            self._check(self.lib.cpm_gather_fast_marked(self.h, self._ptr(sorted_pos_power), self._ptr(brick_table), n, C.byref(grid), radius, scale,
+                                                        int(accumulate), self._ptr(out), self._ptr(nonzero_bricks), self._stream()))
 
     def mark_touched_bricks(self, photons, indices, n_indices, n_photons, n_interactions, grid, radius, brick_mask):
         self._check(self.lib.cpm_mark_touched_bricks(self.h, self._ptr(photons), self._ptr(indices), n_indices, n_photons,
@@ -759,13 +765,14 @@ class SparseReduce:
     def n_bricks(self) -> int:
         return int(self.ctx.lib.cpm_sparse_reduce_bricks(self.h))
 
-    def start(self, partial, total=None, brick_mask=None, root: int = -1, capacity: int = 0) -> int:
-        """Enqueue on the current stream; returns the ticket."""
+    def start(self, partial, total=None, brick_mask=None, root: int = -1, capacity: int = 0, mask_is_nonzero: bool = False) -> int:
+        """Enqueue on the current stream; returns the ticket.  brick_mask: the bricks an update touched (default) or, with
+        mask_is_nonzero, the non-zero bricks of `partial` as cpm_gather_fast_marked wrote them."""
         ticket = C.c_uint64(0)
         tot = partial if total is None else total
         self.ctx._check(self.ctx.lib.cpm_allreduce_grid_sparse(self.ctx.h, self.h, self.ctx._ptr(partial), self.ctx._ptr(tot),
                                                                self.ctx._ptr(brick_mask) if brick_mask is not None else None,
-                                                               root, capacity, C.byref(ticket), self.ctx._stream()))
+                                                               1 if mask_is_nonzero else 0, root, capacity, C.byref(ticket), self.ctx._stream()))
         return int(ticket.value)
 
     def complete(self, ticket: int) -> SparseReduceInfo:

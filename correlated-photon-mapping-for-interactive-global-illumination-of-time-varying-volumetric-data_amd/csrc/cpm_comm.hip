@@ -601,9 +601,10 @@ int sparse_dense_sum(cpm_ctx* ctx, cpm_sparse_reduce* sr, const float* partial, 
 extern "C" {
 
 int cpm_allreduce_grid_sparse(cpm_ctx* ctx, cpm_sparse_reduce* sr, const float* partial, float* total, const uint8_t* brick_mask,
-                              int root, uint32_t capacity_bricks, uint64_t* ticket_out, cpm_stream stream) {
+                              int mask_kind, int root, uint32_t capacity_bricks, uint64_t* ticket_out, cpm_stream stream) {
     CPM_ENTER(ctx);
     CPM_REQUIRE(ctx, sr && partial && total, "cpm_allreduce_grid_sparse: null argument");
+    CPM_REQUIRE(ctx, mask_kind == CPM_SPARSE_MASK_TOUCHED || mask_kind == CPM_SPARSE_MASK_NONZERO, "cpm_allreduce_grid_sparse: mask_kind");
     CPM_REQUIRE(ctx, root < sr->comm->size, "cpm_allreduce_grid_sparse: root");
     CPM_REQUIRE_ALIGNED16(ctx, partial, "cpm_allreduce_grid_sparse");
     CPM_REQUIRE_ALIGNED16(ctx, total, "cpm_allreduce_grid_sparse");
@@ -673,7 +674,7 @@ int cpm_allreduce_grid_sparse(cpm_ctx* ctx, cpm_sparse_reduce* sr, const float* 
         if (root < 0 || root == sr->comm->rank) {
             // a separate `total` becomes the whole sum (zeros outside the union) unless the caller's mask says which bricks
             // changed: then everything else of `total` still holds (the delta path)
-            const bool zero = total != partial && !brick_mask;
+            const bool zero = total != partial && (!brick_mask || mask_kind == CPM_SPARSE_MASK_NONZERO);
             const dim3 ug((unsigned)div_up(zero ? sr->nb : capacity, 16));
 #define CPM_SPARSE_UNPACK(CH, VEC, ZERO) CPM_LAUNCH(ctx, (brick_unpack_kernel<CH, VEC, ZERO>), ug, dim3(256), 0, s, sr->list, sr->slot, sr->count, capacity, sr->nb, dx, dy, dz, sr->bxn, sr->byn, sr->payload, total)
             if (sr->channels == 1) {

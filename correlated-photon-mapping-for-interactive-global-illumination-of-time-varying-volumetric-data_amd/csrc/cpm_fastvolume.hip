@@ -68,6 +68,8 @@ struct BrickLayout {
                             // voxels) has a box of 6 x 6 x 2 candidates
 };
 CPM_DEV uint32_t off_meta(const BrickLayout& L) { return (uint32_t)L.nb + 1u; }
+// a tile's list of (brick, run offset) pairs in run_base: a head (the count) + at most one pair per brick
+__host__ __device__ inline size_t pair_stride(const BrickLayout& L) { return (size_t)L.nb + 1u; }
 CPM_DEV uint32_t off_items(const BrickLayout& L) { return (uint32_t)L.nb + 5u; }
 
 __host__ int make_grid_dev_fast(cpm_ctx* ctx, const cpm_grid_desc* g, GridDev& G) {
@@ -216,16 +218,19 @@ CPM_DEV void fast_scan(const uint32_t* __restrict__ counts, const BrickLayout& L
 
 // bin, launch 1 of 2.  Per workgroup (1024 threads) = per TILE of 4096 photons: the bricks every photon's candidate box
 // touches, counted in an LDS histogram; ONE returning global atomic per non-empty brick reserves the tile's run inside that
-// brick -- its offset goes to run_base[tile][brick] (a dense row per tile, written only where the tile has copies) for
-// the scatter launch; max |power| of the stored photons on the way.
+// brick -- (brick, offset) goes to the tile's list in run_base (as many pairs as the tile has bricks: a tile's 4 lattice rows
+// reach 100 - 200 of config 4's 8192 bricks; a dense row per tile made the scatter launch read 34 MB of them there), the
+// list's length to its head, for the scatter launch; max |power| of the stored photons on the way.
 template <int CH>
 __global__ __launch_bounds__(1024) void fast_count_kernel(const float* __restrict__ photons, int n, GridDev G, BrickLayout L, float radius,
                                                           uint32_t* __restrict__ hist, uint32_t* __restrict__ acc,
                                                           uint32_t* __restrict__ run_base) {
     extern __shared__ uint32_t s_hist[];
     __shared__ float s_mp[16];
+    __shared__ uint32_t s_pairs;
     const int t = threadIdx.x;
     for (int b = t; b < L.nb; b += 1024) s_hist[b] = 0u;
+    if (t == 0) s_pairs = 0u;
     const float rgx = radius * G.t2i.sx + 1e-3f, rgy = radius * G.t2i.sy + 1e-3f, rgz = radius * G.t2i.sz + 1e-3f;
     const float4* __restrict__ ph = reinterpret_cast<const float4*>(photons);
     float mp = 0.f;
@@ -256,7 +261,7 @@ __global__ __launch_bounds__(1024) void fast_count_kernel(const float* __restric
     if ((t & 63) == 0) s_mp[t >> 6] = mp;
     __syncthreads();
     // the runs' places: four bins at a time, the atomics of a group issued together
-    uint32_t* __restrict__ row = run_base + (size_t)blockIdx.x * (size_t)L.nb;
+    uint2* __restrict__ pairs = reinterpret_cast<uint2*>(run_base) + (size_t)blockIdx.x * (size_t)pair_stride(L);
     for (int b = t; b < L.nb; b += 4 * 1024) {
         uint32_t c[4], base[4];
 #pragma unroll
@@ -264,8 +269,10 @@ __global__ __launch_bounds__(1024) void fast_count_kernel(const float* __restric
 #pragma unroll
         for (int q = 0; q < 4; ++q) { base[q] = 0u; if (c[q]) base[q] = atomicAdd(&hist[b + q * 1024], c[q]); }
 #pragma unroll
-        for (int q = 0; q < 4; ++q) if (c[q]) row[b + q * 1024] = base[q];
+        for (int q = 0; q < 4; ++q) if (c[q]) pairs[1u + atomicAdd(&s_pairs, 1u)] = make_uint2((uint32_t)(b + q * 1024), base[q]);
     }
+    __syncthreads();
+    if (t == 0) pairs[0] = make_uint2(s_pairs, 0u);
     // one atomic per workgroup at most, and none once the running maximum has reached this workgroup's
     if (t == 0) {
         float m = s_mp[0];
@@ -298,7 +305,10 @@ __global__ __launch_bounds__(1024, 8) void fast_scatter_kernel(const float* __re
     const float4* __restrict__ ph = reinterpret_cast<const float4*>(photons);
     const int n_tiles = (int)(((long long)n + kScatterTile - 1) / kScatterTile);
     float4 a[kScatterItems], b2[kScatterItems];
-    // a tile's photons and its row of run offsets (straight into LDS: s_pos holds the offsets until the starts are added)
+    // a tile's photons and its list of (brick, run offset) pairs (the first few per lane requested with the photons)
+    constexpr int kPairsAhead = 2;
+    uint2 pr[kPairsAhead];
+    uint32_t n_pairs = 0;
     auto load = [&](int tile) {
 #pragma unroll
         for (int k = 0; k < kScatterItems; ++k) {
@@ -306,10 +316,21 @@ __global__ __launch_bounds__(1024, 8) void fast_scatter_kernel(const float* __re
             a[k] = make_float4(kFltMax, kFltMax, kFltMax, 0.f); b2[k] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (i < n) { a[k] = ph[2 * i]; if (CH == 4) b2[k] = ph[2 * i + 1]; }
         }
+        n_pairs = 0;
         if (tile < n_tiles) {
-            const uint32_t* __restrict__ row = run_base + (size_t)tile * (size_t)L.nb;
-            for (int b = t; b < L.nb; b += 1024) s_pos[b] = row[b];
+            const uint2* __restrict__ pairs = reinterpret_cast<const uint2*>(run_base) + (size_t)tile * (size_t)pair_stride(L);
+            n_pairs = pairs[0].x;
+#pragma unroll
+            for (int q = 0; q < kPairsAhead; ++q) { const uint32_t j = (uint32_t)(q * 1024 + t); pr[q] = j < n_pairs ? pairs[1u + j] : make_uint2(0u, 0u); }
         }
+    };
+    // next free position of the tile's run in every brick it has copies in = brick start + run offset (s_pos of other bricks
+    // is never read)
+    auto place = [&](int tile) {
+        const uint2* __restrict__ pairs = reinterpret_cast<const uint2*>(run_base) + (size_t)tile * (size_t)pair_stride(L);
+#pragma unroll
+        for (int q = 0; q < kPairsAhead; ++q) { const uint32_t j = (uint32_t)(q * 1024 + t); if (j < n_pairs) s_pos[pr[q].x] = s_start[pr[q].x] + pr[q].y; }
+        for (uint32_t j = (uint32_t)(kPairsAhead * 1024 + t); j < n_pairs; j += 1024u) { const uint2 p = pairs[1u + j]; s_pos[p.x] = s_start[p.x] + p.y; }
     };
     load(blockIdx.x);
     for (int w = blockIdx.x * 1024 + t; w < zero_words; w += gridDim.x * 1024) zero_next[w] = 0u;
@@ -321,7 +342,7 @@ __global__ __launch_bounds__(1024, 8) void fast_scatter_kernel(const float* __re
     __syncthreads();
     for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         if (tile != (int)blockIdx.x) load(tile);
-        for (int b = t; b < L.nb; b += 1024) s_pos[b] += s_start[b];  // (each thread its own entries: no barrier in between)
+        place(tile);
         __syncthreads();
 #pragma unroll
         for (int k = 0; k < kScatterItems; ++k) {
@@ -436,10 +457,17 @@ CPM_DEV void brick_record(const GridDev& G, float4 a, float pg, float pb, int ox
 #ifndef CPM_BRICK_WAVES
 #define CPM_BRICK_WAVES 8
 #endif
+constexpr int kMaxSubBricks = 512;  // 4x4x4 sub-bricks of a brick (a tile of <= 159 KiB holds <= 320)
 template <int MAXC, int CH>
 __global__ __launch_bounds__(kBrickThreads, (CH == 4 ? 4 : CPM_BRICK_WAVES)) void fast_brick_kernel(const float* __restrict__ sorted, const uint32_t* __restrict__ table, GridDev G,
-                                                                  BrickLayout L, float radius, float k, int accumulate, float* __restrict__ out) {
+                                                                  BrickLayout L, float radius, float k, int accumulate, float* __restrict__ out,
+                                                                  uint8_t* __restrict__ marks) {
     extern __shared__ long long s_tile[];
+    // marks (nullable): one byte per 4x4x4-voxel brick of the grid (cpm_mark_touched_bricks' numbering), 1 where this launch
+    // leaves a non-zero value, 0 elsewhere -- every byte written: what cpm_allreduce_grid_sparse would otherwise read the whole
+    // volume again for
+    __shared__ uint8_t s_flag[kMaxSubBricks];
+    const int nbx4 = (G.dx + 3) >> 2, nby4 = (G.dy + 3) >> 2;
     constexpr int CH3 = CH == 4 ? 3 : 1, STRIDE = CH == 4 ? 2 : 1;
     const int t = threadIdx.x;
     const int BX = 1 << L.lx, BY = 1 << L.ly, BZ = 1 << L.lz;
@@ -457,7 +485,10 @@ __global__ __launch_bounds__(kBrickThreads, (CH == 4 ? 4 : CPM_BRICK_WAVES)) voi
             for (size_t i = ((size_t)blockIdx.x * kBrickThreads + t) * 4; i < cells; i += (size_t)gridDim.x * kBrickThreads * 4) {
                 const int x = (int)(i % (size_t)G.dx), y = (int)((i / (size_t)G.dx) % (size_t)G.dy), z = (int)(i / ((size_t)G.dx * G.dy));
                 const uint32_t b = (uint32_t)(x >> L.lx) + (uint32_t)L.nbx * ((uint32_t)(y >> L.ly) + (uint32_t)L.nby * (uint32_t)(z >> L.lz));
-                if (table[b + 1] == table[b]) *reinterpret_cast<float4*>(out + i) = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (table[b + 1] == table[b]) {
+                    *reinterpret_cast<float4*>(out + i) = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (marks && ((y | z) & 3) == 0) marks[(uint32_t)(x >> 2) + (uint32_t)nbx4 * ((uint32_t)(y >> 2) + (uint32_t)nby4 * (uint32_t)(z >> 2))] = 0;
+                }
             }
         } else {
             for (size_t i = (size_t)blockIdx.x * kBrickThreads + t; i < cells; i += (size_t)gridDim.x * kBrickThreads) {
@@ -465,6 +496,7 @@ __global__ __launch_bounds__(kBrickThreads, (CH == 4 ? 4 : CPM_BRICK_WAVES)) voi
                 const uint32_t b = (uint32_t)(x >> L.lx) + (uint32_t)L.nbx * ((uint32_t)(y >> L.ly) + (uint32_t)L.nby * (uint32_t)(z >> L.lz));
                 if (table[b + 1] != table[b]) continue;
                 if (CH == 1) out[i] = 0.f; else reinterpret_cast<float4*>(out)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (marks && ((x | y | z) & 3) == 0) marks[(uint32_t)(x >> 2) + (uint32_t)nbx4 * ((uint32_t)(y >> 2) + (uint32_t)nby4 * (uint32_t)(z >> 2))] = 0;
             }
         }
     }
@@ -489,6 +521,8 @@ __global__ __launch_bounds__(kBrickThreads, (CH == 4 ? 4 : CPM_BRICK_WAVES)) voi
         };
         fetch(j0, a, a2);
         for (int w = t; w < words; w += kBrickThreads) s_tile[w] = 0ll;
+        const int nsub = L.bvox >> 6;
+        if (marks) for (int w = t; w < nsub; w += kBrickThreads) s_flag[w] = 0;  // (the lane that read flag w for the brick before)
         __syncthreads();
         for (uint32_t first = j0; first < j1; first += (uint32_t)(kBrickPer * kBrickThreads)) {  // uniform
             fetch(first + (uint32_t)(kBrickPer * kBrickThreads), an, an2);
@@ -510,16 +544,25 @@ __global__ __launch_bounds__(kBrickThreads, (CH == 4 ? 4 : CPM_BRICK_WAVES)) voi
             if (gx >= G.dx || gy >= G.dy || gz >= G.dz) continue;
             const size_t o = (size_t)gx + (size_t)G.dx * ((size_t)gy + (size_t)G.dy * (size_t)gz);
             const float fr = (float)s_tile[v] * invS;
+            bool nonzero = fr != 0.f;
             if (CH == 1) {
                 out[o] = accumulate ? out[o] + fr : fr;
             } else {
                 const float fg = (float)s_tile[L.bvox + v] * invS, fb = (float)s_tile[2 * L.bvox + v] * invS;
+                nonzero = nonzero || fg != 0.f || fb != 0.f;
                 float4* q = reinterpret_cast<float4*>(out) + o;
                 if (accumulate) { const float4 tt = *q; *q = make_float4(tt.x + fr, tt.y + fg, tt.z + fb, tt.w); }
                 else *q = make_float4(fr, fg, fb, 0.f);
             }
+            if (marks && nonzero) s_flag[(lx >> 2) + (BX >> 2) * ((ly >> 2) + (BY >> 2) * (lz >> 2))] = 1;  // (same value from every writer)
         }
         __syncthreads();  // the tile is cleared again for the next brick
+        if (marks)
+            for (int w = t; w < nsub; w += kBrickThreads) {
+                const int sx = w % (BX >> 2), sy = (w / (BX >> 2)) % (BY >> 2), sz = w / ((BX >> 2) * (BY >> 2));
+                const int gx4 = (ox >> 2) + sx, gy4 = (oy >> 2) + sy, gz4 = (oz >> 2) + sz;
+                if (4 * gx4 < G.dx && 4 * gy4 < G.dy && 4 * gz4 < G.dz) marks[(uint32_t)gx4 + (uint32_t)nbx4 * ((uint32_t)gy4 + (uint32_t)nby4 * (uint32_t)gz4)] = s_flag[w];
+            }
     }
 }
 
@@ -586,12 +629,12 @@ int cpm_bin_fast(cpm_ctx* ctx, const float* photons8, int n, const cpm_grid_desc
         return set_error(ctx, CPM_ERR_UNSUPPORTED, "cpm_bin_fast", "radius beyond 3.5 voxels along some axis (or not positive): use cpm_bin + cpm_gather");
     CPM_REQUIRE(ctx, (long long)n * copies_per_photon(L) < (1ll << 32), "cpm_bin_fast: record positions are 32-bit (n * 8 must stay below 2^32)");
     // scratch: two histograms (nb brick counts + 4 accumulators), used in turn -- a call's scatter launch zeroes the one the
-    // NEXT call counts into -- then run_base: one row of nb offsets per tile of 4096 photons (written only where a tile has
-    // copies, read as whole rows)
+    // NEXT call counts into -- then run_base: per tile of 4096 photons a list of (brick, run offset) pairs behind its length
+    // (room for every brick; as many written and read as the tile touches)
     static_assert(kCountTile == kScatterTile, "count and scatter launches share the tile decomposition");
     const size_t hist_words = (size_t)L.nb + kAccWords;
     const size_t tiles = n > 0 ? (size_t)div_up(n, kCountTile) : 1;
-    const size_t arena = (2 * hist_words + tiles * (size_t)L.nb) * 4;
+    const size_t arena = (2 * hist_words + 2 * tiles * pair_stride(L)) * 4;  // (a pair = 2 words)
     const bool had = ctx->scratch_bytes[CPM_SCR_FAST_BIN] >= arena;
     uint32_t* base = (uint32_t*)scratch(ctx, CPM_SCR_FAST_BIN, arena);
     if (!base) return CPM_ERR_OUT_OF_MEMORY;
@@ -636,7 +679,13 @@ int cpm_bin_fast(cpm_ctx* ctx, const float* photons8, int n, const cpm_grid_desc
 
 int cpm_gather_fast(cpm_ctx* ctx, const float* sorted_pos_power, const uint32_t* brick_table, int n, const cpm_grid_desc* grid,
                     float radius, float scale, int accumulate, float* grid_out, cpm_stream stream) {
+    return cpm_gather_fast_marked(ctx, sorted_pos_power, brick_table, n, grid, radius, scale, accumulate, grid_out, nullptr, stream);
+}
+
+int cpm_gather_fast_marked(cpm_ctx* ctx, const float* sorted_pos_power, const uint32_t* brick_table, int n, const cpm_grid_desc* grid,
+                           float radius, float scale, int accumulate, float* grid_out, uint8_t* nonzero_bricks, cpm_stream stream) {
     CPM_ENTER(ctx);
+    CPM_REQUIRE(ctx, !(nonzero_bricks && accumulate), "cpm_gather_fast_marked: the marks describe a volume this launch wrote whole (not with accumulate)");
     GridDev G;
     int rc = make_grid_dev_fast(ctx, grid, G);
     if (rc) return rc;
@@ -649,7 +698,7 @@ int cpm_gather_fast(cpm_ctx* ctx, const float* sorted_pos_power, const uint32_t*
     if (!brick_reach(G, radius, L))
         return set_error(ctx, CPM_ERR_UNSUPPORTED, "cpm_gather_fast", "radius beyond 3.5 voxels along some axis: use cpm_bin + cpm_gather");
     const size_t tile_bytes = tile_bytes_for(G, L);
-    if (tile_bytes > 160 * 1024 - 1024)
+    if (tile_bytes > 160 * 1024 - 1024 || (L.bvox >> 6) > kMaxSubBricks)
         return set_error(ctx, CPM_ERR_UNSUPPORTED, "cpm_gather_fast", "brick does not fit the LDS: use cpm_bin + cpm_gather");
     // the records were filed for ONE radius (a wider one would need copies the bin did not make)
     if (ctx->fast_last_table == brick_table && ctx->fast_last_radius != radius)
@@ -664,7 +713,7 @@ int cpm_gather_fast(cpm_ctx* ctx, const float* sorted_pos_power, const uint32_t*
         rc = allow_lds(ctx, fast_brick_kernel<MAXC, CH>, tile_bytes);                                                    \
         if (rc) return rc;                                                                                               \
         CPM_LAUNCH(ctx, (fast_brick_kernel<MAXC, CH>), bgrid, dim3(kBrickThreads), tile_bytes, s, sorted_pos_power, brick_table, G, L,  \
-                   radius, k, accumulate, grid_out);                                                                     \
+                   radius, k, accumulate, grid_out, nonzero_bricks);                                                     \
     } while (0)
     if (G.channels == 1) {
         if (L.maxc <= 2) CPM_BRICK_LAUNCH(2, 1); else if (L.maxc == 3) CPM_BRICK_LAUNCH(3, 1); else if (L.maxc == 4) CPM_BRICK_LAUNCH(4, 1); else CPM_BRICK_LAUNCH(0, 1);

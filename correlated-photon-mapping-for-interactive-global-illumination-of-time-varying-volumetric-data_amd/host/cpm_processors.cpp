@@ -1134,6 +1134,7 @@ void PhotonToLightVolumeProcessorCL::process() {  // photontolightvolumeprocesso
         estimate_.setSize(cells * channels);
         out = estimate_.device();
     }
+    marksAreNonzero_ = false;
     bool partialUpdate = false;  // this evaluation only touched the re-traced photons
     bool marksDone = false;      // brickMask_ already holds the old AND new positions' bricks
     // what this evaluation costs on the GPU's timeline, filed under the way the tracer served the change (PathCosts)
@@ -1199,8 +1200,16 @@ void PhotonToLightVolumeProcessorCL::process() {  // photontolightvolumeprocesso
             // (a record per (photon, brick it reaches): cpm_fast_record_capacity)
             brickTable_.setSize(cpm_fast_table_entries(&g, (int)m));
             sorted_.setSize(cpm_fast_record_capacity(&g, (int)m, radius) * (channels == 1 ? 4 : 8));
-            if (rt.check(cpm_bin_fast(rt.ctx(), photons, (int)m, &g, radius, brickTable_.device(), sorted_.device(), rt.stream()), "cpm_bin_fast"))
-                rt.check(cpm_gather_fast(rt.ctx(), sorted_.device(), brickTable_.device(), (int)m, &g, radius, scale, 0, out, rt.stream()), "cpm_gather_fast");
+            // (multi-GPU: the gather also marks the non-zero 4x4x4 bricks of the volume it writes -- what the sparse reduce sums over)
+            uint8_t* marks = nullptr;
+            if (comm_ && !progressiveIteration) {
+                nonzeroMarks_.setSize(((outDim.x + 3) / 4) * ((outDim.y + 3) / 4) * ((outDim.z + 3) / 4) + 16);
+                marks = nonzeroMarks_.device();
+            }
+            if (rt.check(cpm_bin_fast(rt.ctx(), photons, (int)m, &g, radius, brickTable_.device(), sorted_.device(), rt.stream()), "cpm_bin_fast") &&
+                rt.check(cpm_gather_fast_marked(rt.ctx(), sorted_.device(), brickTable_.device(), (int)m, &g, radius, scale, 0, out, marks, rt.stream()),
+                         "cpm_gather_fast"))
+                marksAreNonzero_ = marks != nullptr;
         } else {  // sort/bin + deterministic per-cell gather
             const size_t m = (size_t)nPhotons * nInter;
             order_.setSize(m); cellStart_.setSize(cells + 1); sorted_.setSize(m * (channels == 1 ? 4 : 8));
@@ -1301,6 +1310,11 @@ void PhotonToLightVolumeProcessorCL::reduceOverShards(const cpm_grid_desc& g, si
         sparseReduceChannels_ = lightVolume_->channels;
     }
     const uint8_t* mask = nullptr;
+    int maskKind = CPM_SPARSE_MASK_TOUCHED;
+    if (!partialUpdate && marksAreNonzero_) {  // a full evaluation whose gather marked the volume's non-zero bricks
+        mask = nonzeroMarks_.device();
+        maskKind = CPM_SPARSE_MASK_NONZERO;
+    }
     if (partialUpdate && brickMask_.getSize() != 0 && idx) {
         // add-remove: only bricks touched by an old or a new position of a re-traced photon changed on this shard.  The old
         // positions were marked into brickMask_ before the snapshot moved on (see process()); add the new ones, then sum
@@ -1313,10 +1327,10 @@ void PhotonToLightVolumeProcessorCL::reduceOverShards(const cpm_grid_desc& g, si
     if (sparseReduce_) {
         uint64_t ticket = 0;
         cpm_sparse_reduce_info info = {};
-        if (rt.check(cpm_allreduce_grid_sparse(rt.ctx(), sparseReduce_, lightVolume_->data.device(), reducedVolume_->data.device(), mask, -1, 0,
+        if (rt.check(cpm_allreduce_grid_sparse(rt.ctx(), sparseReduce_, lightVolume_->data.device(), reducedVolume_->data.device(), mask, maskKind, -1, 0,
                                                &ticket, rt.stream()), "cpm_allreduce_grid_sparse") &&
             rt.check(cpm_sparse_reduce_complete(rt.ctx(), sparseReduce_, ticket, rt.stream(), &info), "cpm_sparse_reduce_complete")) {
-            lastReduce_ = info.mode == 0 ? (mask ? "touched bricks" : "non-zero bricks") : (info.mode == 1 ? "dense" : "dense (overflow)");
+            lastReduce_ = info.mode == 0 ? (mask && maskKind == CPM_SPARSE_MASK_TOUCHED ? "touched bricks" : "non-zero bricks") : (info.mode == 1 ? "dense" : "dense (overflow)");
             return;
         }
     }

@@ -637,6 +637,8 @@ private:
                           const unsigned int* idx, int nRecomputed, int nPhotons, int nInter, float radius);
     cpm_comm* comm_ = nullptr;
     cpm_sparse_reduce* sparseReduce_ = nullptr;  // cpm_allreduce_grid_sparse state of (comm_, the light volume's shape)
+    Buffer<uint8_t> nonzeroMarks_;               // cpm_gather_fast_marked: the non-zero 4x4x4 bricks of the volume just written
+    bool marksAreNonzero_ = false;               // ... valid for this evaluation's lightVolume_
     size3_t sparseReduceDims_{ 0, 0, 0 };
     int sparseReduceChannels_ = 0;
     void dropSparseReduce();

@@ -318,9 +318,9 @@ class PhotonFrame:
             self.sorted_fast = self.torch.empty((cap, 4 if self.grid.channels == 1 else 8), dtype=self.torch.float32, device=self.ctx.device)
         self.ctx.bin_fast(self.photons, self.n * self.I, self.grid, self.radius, self.brick_table, self.sorted_fast)
 
-    def gather_fast(self, accumulate=False, out=None):
+    def gather_fast(self, accumulate=False, out=None, nonzero_bricks=None):
         self.ctx.gather_fast(self.sorted_fast, self.brick_table, self.n * self.I, self.grid, self.radius, self.scale,
-                             self.light_volume if out is None else out, accumulate=accumulate)
+                             self.light_volume if out is None else out, accumulate=accumulate, nonzero_bricks=nonzero_bricks)
 
     def frame_fast(self):
         """The hot path in tolerance mode: trace -> brick bin -> tile gather."""

@@ -110,8 +110,9 @@ class TorchTransport:
         self._sp = {"dims": tuple(dims), "channels": channels, "unions": [], "log": []}
         self._sp["nb"] = ((dims[0] + 3) // 4) * ((dims[1] + 3) // 4) * ((dims[2] + 3) // 4)
 
-    def sparse_start(self, grid, capacity: int = 0):
-        """grid (in place) = sum over the ranks, over the union of their non-zero bricks; returns the ticket's figures."""
+    def sparse_start(self, grid, capacity: int = 0, nonzero_bricks=None):
+        """grid (in place) = sum over the ranks, over the union of their non-zero bricks; returns the ticket's figures.
+        (nonzero_bricks: accepted for symmetry with RcclTransport; the mask is taken from the grid here.)"""
         import torch
         sp, dist = self._sp, self._dist
         dims, ch, nb = sp["dims"], sp["channels"], sp["nb"]
@@ -201,13 +202,15 @@ class RcclTransport:
         self.sparse = self.ctx.sparse_reduce_create(self.comm, grid_desc)
         self.sparse_log = []
 
-    def sparse_start(self, grid, capacity: int = 0):
+    def sparse_start(self, grid, capacity: int = 0, nonzero_bricks=None):
+        """nonzero_bricks: the marks cpm_gather_fast_marked left for this grid (the reduce then needs no pass over it)."""
         torch = self.torch
         ready = torch.cuda.Event()
         ready.record(torch.cuda.current_stream(self.ctx.device))
         with torch.cuda.stream(self.stream):
             self.stream.wait_event(ready)
-            ticket = self.sparse.start(grid, root=-1 if self.root is None else self.root, capacity=capacity)
+            ticket = self.sparse.start(grid, root=-1 if self.root is None else self.root, capacity=capacity, brick_mask=nonzero_bricks,
+                                       mask_is_nonzero=nonzero_bricks is not None)
         return ticket
 
     def sparse_wait(self, ticket):
@@ -265,12 +268,15 @@ class OverlappedGridReducer:
         self._pending = [None, None]
         self.sparse = sparse is not None
         self.info = []  # per completed sparse ticket: union, capacity, mode, bytes
+        self.marks = [None, None]  # per buffer: the non-zero 4x4x4 bricks, written by the gather (marks_for)
         if self.sparse and self.active:
             if isinstance(self.transport, TorchTransport):
                 dims, channels = sparse
                 self.transport.sparse_setup(dims, channels)
             else:
                 self.transport.sparse_setup(sparse)
+                nb = self.transport.sparse.n_bricks
+                self.marks = [torch.zeros(nb + 16, dtype=torch.uint8, device=like.device) for _ in range(2)]
 
     def _wait(self, b):
         h = self._pending[b]
@@ -291,11 +297,16 @@ class OverlappedGridReducer:
         self._wait(b)
         return self.buffers[b]
 
-    def reduce(self, k: int):
+    def marks_for(self, k: int):
+        """Where the gather of frame k leaves the non-zero bricks of its volume (cpm_gather_fast_marked), or None: pass it as the
+        gather's `nonzero_bricks` and say so to reduce(k, marked=True) -- the reduce then skips its own pass over the volume."""
+        return self.marks[k & 1] if self.active else None
+
+    def reduce(self, k: int, marked: bool = False):
         if self.active:
             b = k & 1
             if self.sparse:
-                self._pending[b] = self.transport.sparse_start(self.buffers[b])
+                self._pending[b] = self.transport.sparse_start(self.buffers[b], nonzero_bricks=self.marks[b] if marked else None)
             else:
                 self._pending[b] = self.transport.start(self.buffers[b])
 

@@ -384,8 +384,10 @@ int cpm_gather_bricks(cpm_ctx* ctx, const float* sorted_pos_power, const uint32_
 
 /* u32 entries of the brick table cpm_bin_fast fills on this grid (0 = bad arguments): brick starts, max |power|, radius. */
 size_t cpm_fast_table_entries(const cpm_grid_desc* grid, int n);
-/* 1 when the pair covers this grid / radius (radius < 2 voxels per axis, positive axis-aligned textureToIndex);
- * otherwise use cpm_bin + cpm_gather. */
+/* 1 when the pair covers this grid / radius: at most 8 candidate voxels along every axis (floor(2 (r * textureToIndex + 1e-3)) + 1
+ * <= 8: radius < 3.5 voxels of THAT axis -- the box follows an anisotropic grid: 6 x 6 x 2 on the workspace's 256 x 256 x 48
+ * light volume; up to 4 per axis the record loops are unrolled, wider boxes take run-time loops), positive axis-aligned
+ * textureToIndex; otherwise use cpm_bin + cpm_gather. */
 int cpm_gather_fast_supported(const cpm_grid_desc* grid, float radius);
 /* Records sorted_pos_power must hold for n photons at this radius (every photon in all its bricks: 8 n, or n when a
  * candidate box is a single voxel wide); 0 when unsupported. */
@@ -403,6 +405,13 @@ int cpm_bin_fast(cpm_ctx* ctx, const float* photons8, int n, const cpm_grid_desc
 int cpm_gather_fast(cpm_ctx* ctx, const float* sorted_pos_power, const uint32_t* brick_table, int n,
                     const cpm_grid_desc* grid, float radius, float relative_irradiance_scale, int accumulate,
                     float* grid_out, cpm_stream stream);
+/* The same launch also says where the volume it wrote is not zero: nonzero_bricks[b] = 1 when the 4x4x4-voxel brick b
+ * (b = bx + ceil(dx / 4) * (by + ceil(dy / 4) * bz): cpm_mark_touched_bricks' numbering) holds a non-zero value, else 0 --
+ * every byte written.  What cpm_allreduce_grid_sparse(..., CPM_SPARSE_MASK_NONZERO) takes instead of reading the volume again
+ * (multi-GPU full frames).  Not with accumulate (the marks would describe this launch's share only). */
+int cpm_gather_fast_marked(cpm_ctx* ctx, const float* sorted_pos_power, const uint32_t* brick_table, int n,
+                           const cpm_grid_desc* grid, float radius, float relative_irradiance_scale, int accumulate,
+                           float* grid_out, uint8_t* nonzero_bricks, cpm_stream stream);
 
 /* ------------------------------------------------------------------ correlated re-trace (C1-C7, S2-S4) */
 
@@ -664,11 +673,11 @@ int cpm_allreduce_grid_bricks(cpm_ctx* ctx, cpm_comm* comm, const float* partial
  * A rank's photons reach a fraction of the grid (config 2: 1 in 8 of the 4x4x4-voxel bricks holds a non-zero voxel), every
  * rank reaches nearly the same bricks (lattice tiles are dealt round-robin), and the dense sum -- 64 MiB per frame at
  * config 4 against ~40 us of per-rank compute -- would be the frame.  One call enqueues, on the caller's stream:
- *   this rank's non-zero bricks -> byte mask (or `brick_mask`, nb bytes as cpm_mark_touched_bricks fills it: the delta path)
+ *   this rank's non-zero bricks -> byte mask (or the caller's `brick_mask`: see below)
  *   -> ncclAllReduce(max) of the mask = the UNION, identical on every rank -> ascending brick list + count
  *   -> pack the union's bricks of `partial` -> ncclAllReduce / ncclReduce (sum) of capacity * 64 * channels floats -> unpack.
  * total[brick] = sum over ranks of partial[brick] for every brick of the union.  Elsewhere: total == partial (in place) is left
- * as it is (zero on every rank, or unchanged: delta path); a separate `total` is zero-filled there unless `brick_mask` was
+ * as it is (zero on every rank, or unchanged: delta path); a separate `total` is zero-filled there unless a TOUCHED mask was
  * given (then its other bricks still hold the previous sum).  root < 0: every rank receives; else only `root` writes `total`.
  *
  * No stream synchronisation, no read-back in the call: the collective's size is `capacity_bricks`, fixed by the host before
@@ -696,8 +705,14 @@ uint32_t cpm_sparse_reduce_bricks(const cpm_sparse_reduce* sr);
  * previous_union * 1.25 + 64 rounded up to 64, a quarter of the bricks while unknown; n_bricks (= dense) beyond half of them.
  * A pure function: hosts that mirror the policy (sharding.py) call it. */
 uint32_t cpm_sparse_reduce_capacity_for(uint32_t n_bricks, long long previous_union);
+/* brick_mask (nullable = the library finds this rank's non-zero bricks with a pass over `partial`): n_bricks bytes, non-zero =
+ * the brick takes part.  mask_kind says what it is: CPM_SPARSE_MASK_NONZERO -- every brick of `partial` holding a non-zero
+ * voxel is marked (cpm_gather_fast_marked writes exactly that): same result as NULL without the pass;
+ * CPM_SPARSE_MASK_TOUCHED -- the bricks an update changed (cpm_mark_touched_bricks / cpm_splat_delta): everything else of a
+ * separate `total` keeps its value. */
+enum { CPM_SPARSE_MASK_TOUCHED = 0, CPM_SPARSE_MASK_NONZERO = 1 };
 int cpm_allreduce_grid_sparse(cpm_ctx* ctx, cpm_sparse_reduce* sr, const float* partial, float* total, const uint8_t* brick_mask,
-                              int root, uint32_t capacity_bricks, uint64_t* ticket_out, cpm_stream stream);
+                              int mask_kind, int root, uint32_t capacity_bricks, uint64_t* ticket_out, cpm_stream stream);
 /* Before `total` of `ticket` is read (enqueue-wise: on `stream`, behind the call that issued the ticket): reads the ticket's
  * union count from the mailbox (waits for THAT launch only) and, after an overflow, enqueues the dense sum. */
 int cpm_sparse_reduce_complete(cpm_ctx* ctx, cpm_sparse_reduce* sr, uint64_t ticket, cpm_stream stream, cpm_sparse_reduce_info* info_out);

@@ -175,6 +175,13 @@ def test_sparse_grid_reduce_one_rank(ctx, cpm, dims, ch):
         assert np.array_equal(got[sel], g_np.reshape(-1)[sel]) and (got[~sel] == -1.0).all()
     torch.cuda.synchronize()
     assert torch.equal(g.view(torch.int32), keep.view(torch.int32))
+    # the caller's NON-ZERO mask (cpm_gather_fast_marked's): as without a mask, a separate total is zero-filled elsewhere
+    nzmask = np.zeros(nb, np.uint8)
+    nzmask[np.unique(b.reshape(-1)[(g_np != 0).any(axis=1)])] = 1
+    total.fill_(-5.0)
+    i6 = sr.complete(sr.start(g, total, brick_mask=torch.from_numpy(nzmask).to(ctx.device), mask_is_nonzero=True, capacity=nb // 2 if nb >= 4 else 0))
+    torch.cuda.synchronize()
+    assert i6.n_union == want_union and torch.equal(total.view(torch.int32), keep.view(torch.int32))
     sr.close()
     comm.close()
 
@@ -225,7 +232,11 @@ def test_overlapped_reducer_sparse_on_one_gpu(ctx, cpm):
         out.zero_()
         out[: 64 * 64 * (2 + k)] = float(k + 1)
         frames.append(out.clone())
-        red.reduce(k)
+        if k % 2:      # odd frames hand over the non-zero marks a gather would have written
+            m = red.marks_for(k)
+            m.zero_()
+            m[: 256 * ((2 + k + 3) // 4)] = 1
+        red.reduce(k, marked=bool(k % 2))
     red.flush()
     torch.cuda.synchronize()
     assert torch.equal(red.result(5), frames[5]) and torch.equal(red.result(4), frames[4])

@@ -329,3 +329,39 @@ def test_non_finite_powers_are_ignored_photon_by_photon(ctx, oracle, cpm):
     assert np.isfinite(got).all() and got.max() > 0
     assert np.array_equal(bits(got), bits(want))
     assert np.array_equal(bits(got), bits(ref))
+
+
+@pytest.mark.parametrize("dims,channels,rvox", [((128, 128, 128), 1, 0.866), ((40, 24, 56), 4, 1.2), ((21, 7, 5), 1, 0.9), ((256, 256, 48), 1, 2.76),
+                                                ((256, 256, 192), 1, 1.0)])
+def test_gather_fast_marks_the_nonzero_bricks(ctx, oracle, cpm, dims, channels, rvox):
+    """cpm_gather_fast_marked: the same light volume, plus one byte per 4x4x4-voxel brick saying whether it holds a non-zero value --
+    every byte written (the buffer starts as garbage), ragged grids, 4 channels, bigger bricks and wide boxes included."""
+    rng = np.random.default_rng(dims[0] + channels)
+    n = 30_000
+    ph = make_photons(rng, n, dims, cluster=0.9)
+    radius = float(np.float32(rvox) / np.float32(max(dims)))
+    scale = float(cpm.binding.relative_irradiance_scale(radius, float(n)))
+    B = cpm.binding
+    grid = B.default_grid_desc(dims, channels)
+    cells = dims[0] * dims[1] * dims[2]
+    table = ctx.torch.zeros(max(ctx.fast_table_entries(grid, n), 1), dtype=ctx.torch.int32, device=ctx.device)
+    srt = ctx.torch.zeros((max(ctx.fast_record_capacity(grid, n, radius), 1), 4 if channels == 1 else 8), dtype=ctx.torch.float32, device=ctx.device)
+    ctx.bin_fast(_t(ctx, ph), n, grid, radius, table, srt)
+    shape = (cells,) if channels == 1 else (cells, 4)
+    plain = ctx.torch.full(shape, 7.0, dtype=ctx.torch.float32, device=ctx.device)
+    ctx.gather_fast(srt, table, n, grid, radius, scale, plain)
+    bxn, byn, bzn = [(d + 3) // 4 for d in dims]
+    nb = bxn * byn * bzn
+    marks = ctx.torch.full((nb + 16,), 77, dtype=ctx.torch.uint8, device=ctx.device)
+    out = ctx.torch.full(shape, 7.0, dtype=ctx.torch.float32, device=ctx.device)
+    ctx.gather_fast(srt, table, n, grid, radius, scale, out, nonzero_bricks=marks)
+    assert np.array_equal(bits(_n(out)), bits(_n(plain)))
+    z, y, x = np.meshgrid(np.arange(dims[2]), np.arange(dims[1]), np.arange(dims[0]), indexing="ij")
+    b = ((x // 4) + bxn * ((y // 4) + byn * (z // 4))).reshape(-1)
+    nz = (_n(out).reshape(cells, -1) != 0).any(axis=1)
+    want = np.zeros(nb, np.uint8)
+    want[np.unique(b[nz])] = 1
+    got = _n(marks)
+    assert np.array_equal(got[:nb], want) and (got[nb:] == 77).all() and want.sum() > 0
+    with pytest.raises(B.CpmError):     # with accumulate the marks would describe this launch's share only
+        ctx.gather_fast(srt, table, n, grid, radius, scale, out, accumulate=True, nonzero_bricks=marks)
