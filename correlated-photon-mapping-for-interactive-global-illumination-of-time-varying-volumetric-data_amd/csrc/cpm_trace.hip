@@ -30,6 +30,11 @@ namespace {
 // SINGLE: max_interactions == 1 known at compile time -- the scatter branch (phase-function sample, re-encoded direction, slab
 // test) and the sentinel loop leave the instruction stream of the headline configuration; the NO_SINGLE_SCATTERING variant and
 // I > 1 take the general kernel.
+// (two steps of the walk in flight, tracer::woodcock_ahead: measured 32.1 -> 30.2 us at config 2, 124.6 -> 118.0 at 4 M photons /
+// 512^3, 105.7 -> 101.4 at 8 steps per photon; 3 and 4 in flight cost registers and lose)
+#ifndef CPM_TRACE_AHEAD
+#define CPM_TRACE_AHEAD 2
+#endif
 CPM_DEV int default_chunk(int b, unsigned n_chunks) {
     if (b < (int)(n_chunks & ~127u)) {
         const int x = b & 7, j = b >> 3;
@@ -152,12 +157,8 @@ __global__ __launch_bounds__(256, 8) void trace_kernel(const TraceArgs A) {
         direction = decode_direction_(l1.z, l1.w);
         encode_direction_(direction, th, ph);
     }
-    // (two steps of the walk in flight, tracer::woodcock_ahead: measured 32.1 -> 30.2 us at config 2, 124.6 -> 118.0 at 4 M photons /
-    // 512^3, 105.7 -> 101.4 at 8 steps per photon; 3 and 4 in flight cost registers and lose)
-#ifndef CPM_TRACE_AHEAD
-#define CPM_TRACE_AHEAD 2
-#endif
-    trace_photon<DT, SINGLE, CPM_TRACE_AHEAD>(A, lut, luts, threadId, l0, l1, ip, rs, direction, th, ph, steps);
+    // (SINGLE: two steps of the walk in flight; the general kernel's registers are full without them: I = 4 97.3 us with two, 93.6 with one)
+    trace_photon<DT, SINGLE, (SINGLE ? CPM_TRACE_AHEAD : 1)>(A, lut, luts, threadId, l0, l1, ip, rs, direction, th, ph, steps);
     if (A.chunk_cost) {  // what this chunk cost: the wave's longest walk (cpm_trace_order); lanes past the end have left
         unsigned m = steps;
         const unsigned long long alive = __ballot(true);
@@ -178,7 +179,6 @@ __global__ __launch_bounds__(256, 8) void trace_kernel(const TraceArgs A) {
         if ((threadIdx.x & 63) == 0) atomicAdd(A.step_counter, (unsigned long long)s);
     }
 }
-
 
 }  // namespace
 

@@ -233,95 +233,126 @@ CPM_DEV float woodcock_ahead(const VolDev& V, const float* lut, float wf, float 
     }
 }
 
-// One light sample's walk: photontracer.cl:129-215 from the loaded sample on.  `direction` = decodeDirection(l1.z, l1.w) and
-// (th, ph) = encodeDirection(direction), evaluated by the caller (once per workgroup for a directional light, per lane
-// otherwise: the same operations on the same inputs either way).  Writes the photon records (and sentinels) of sample
-// `threadId`, its RNG state when progressive, its importance key when A.reset_importances is set.
-template <int DT, bool SINGLE, int AHEAD = 1>
-CPM_DEV void trace_photon(const TraceArgs& A, const float* lut, const float* luts, int threadId, float4 l0, float4 l1, float2 ip, uint2 rs,
-                          f3 direction, float th, float ph, unsigned& steps) {
+// One light sample's walk: photontracer.cl:129-215 from the loaded sample on, in three pieces: walk_init -- everything before the
+// loop; walk_segment -- ONE turn of the loop `while (scatterEvent)` (a Woodcock walk, the record of the interaction it ends in,
+// the decision to scatter on); walk_finish -- the sentinel records, the RNG write-back, the importance reset.  trace_photon runs
+// them back to back.  (The pieces exist because a tracer with one launch per interaction was built on them -- walks parked in a
+// queue between launches -- and measured slower: docs/EXPERIMENTS.md, round 4.)
+struct WalkState {
+    f3 origin, direction, power;
+    float tStart, tEnd, th, ph;   // (th, ph) = encodeDirection(direction)
+    uint32_t rx, rc, nInteractions;
+    bool scatterEvent;
+};
+
+// `direction` = decodeDirection(l1.z, l1.w) and (th, ph) = encodeDirection(direction), evaluated by the caller (once per workgroup
+// for a directional light, per lane otherwise: the same operations on the same inputs either way).
+template <int DT, bool SINGLE, int AHEAD>
+CPM_DEV void walk_init(const TraceArgs& A, const float* lut, float4 l0, float4 l1, float2 ip, uint2 rs, f3 direction, float th, float ph,
+                       unsigned& steps, WalkState& S) {
+    const uint32_t maxInteractions = SINGLE ? 1u : (uint32_t)A.p.max_interactions;
+    S.rx = rs.x; S.rc = rs.y;
+    S.nInteractions = 0;
+    S.origin = { l0.x, l0.y, l0.z };
+    S.direction = direction;
+    S.th = th; S.ph = ph;
+    float mi = (float)maxInteractions;
+    S.power = { l0.w, l1.x, l1.y };
+    if (maxInteractions != 1) { S.power.x = S.power.x / mi; S.power.y = S.power.y / mi; S.power.z = S.power.z / mi; }  // x / 1.0f == x
+    S.tStart = ip.x; S.tEnd = ip.y;
+    S.scatterEvent = S.tStart < S.tEnd;
+    const float wf = A.tf_wf, m1 = A.tf_m1, m2 = A.tf_m2;
+    if (!SINGLE && (A.p.flags & CPM_TRACE_NO_SINGLE_SCATTERING)) {  // photontracer.cl:143-157
+        float vs_unused, op_unused;
+        float t = AHEAD > 1 ? woodcock_ahead<DT, (AHEAD > 1 ? AHEAD : 2)>(A.vol, lut, wf, m1, m2, S.origin, S.direction, S.tStart, S.tEnd, S.rx, S.rc, steps, vs_unused, op_unused)
+                            : woodcock<DT>(A.vol, lut, wf, m1, m2, S.origin, S.direction, S.tStart, S.tEnd, S.rx, S.rc, steps, vs_unused, op_unused);
+        if (S.scatterEvent) {
+            S.origin.x = fma_(t, S.direction.x, S.origin.x);
+            S.origin.y = fma_(t, S.direction.y, S.origin.y);
+            S.origin.z = fma_(t, S.direction.z, S.origin.z);
+            S.tStart = 0.f; S.tEnd = kFltMax;
+            float u1 = rand01_(S.rx, S.rc), u2 = rand01_(S.rx, S.rc);
+            float pdf;
+            S.direction = phase_sample(A.p.shading_type, A.p.material[0], S.direction, u1, u2, &pdf);
+            encode_direction_(S.direction, S.th, S.ph);
+            S.scatterEvent = ray_box_(A.bmin, A.bmax, S.origin, S.direction, S.tStart, S.tEnd);
+            S.power.x = S.power.x / pdf; S.power.y = S.power.y / pdf; S.power.z = S.power.z / pdf;
+            S.tStart = S.tStart + 0.5f * A.p.step_size;
+        }
+    }
+}
+
+// one turn of photontracer.cl:158-197; call while S.scatterEvent
+template <int DT, bool SINGLE, int AHEAD>
+CPM_DEV void walk_segment(const TraceArgs& A, const float* lut, const float* luts, int threadId, unsigned& steps, WalkState& S) {
     const int photonOffset = A.p.photon_offset;
     const uint32_t maxInteractions = SINGLE ? 1u : (uint32_t)A.p.max_interactions;
     const size_t totalPhotons = (size_t)A.p.total_photons;
-    uint2* rng = reinterpret_cast<uint2*>(A.rng);
-    uint32_t rx = rs.x, rc = rs.y;
-    uint32_t nInteractions = 0;
-
-    f3 origin = { l0.x, l0.y, l0.z };
-    float mi = (float)maxInteractions;
-    f3 power = { l0.w, l1.x, l1.y };
-    if (maxInteractions != 1) { power.x = power.x / mi; power.y = power.y / mi; power.z = power.z / mi; }  // x / 1.0f == x
-    float tStart = ip.x, tEnd = ip.y;
-    bool scatterEvent = tStart < tEnd;
-
     const float wf = A.tf_wf, m1 = A.tf_m1, m2 = A.tf_m2;
+    float volumeSample = 0.f, colorW = 0.f;
+    float t = AHEAD > 1 ? woodcock_ahead<DT, (AHEAD > 1 ? AHEAD : 2)>(A.vol, lut, wf, m1, m2, S.origin, S.direction, S.tStart, S.tEnd, S.rx, S.rc, steps, volumeSample, colorW)
+                        : woodcock<DT>(A.vol, lut, wf, m1, m2, S.origin, S.direction, S.tStart, S.tEnd, S.rx, S.rc, steps, volumeSample, colorW);
+    S.scatterEvent = t <= S.tEnd;
+    if (S.scatterEvent) {
+        S.origin.x = fma_(t, S.direction.x, S.origin.x);
+        S.origin.y = fma_(t, S.direction.y, S.origin.y);
+        S.origin.z = fma_(t, S.direction.z, S.origin.z);
+        size_t photonId = (size_t)photonOffset + S.nInteractions * totalPhotons + (size_t)threadId;
+        // (th, ph) = encodeDirection(direction) (photontracer.cl:167): current, see above.
+        // The reference samples the volume and the TF again at the collision point
+        // (photontracer.cl:170-173).  The accepted Woodcock iteration sampled exactly that point --
+        // fma(t, d, o) with the same t, d, o -- so its volume sample and alpha ARE those values.
+        float dv = max_(colorW, 0.01f);
+        S.power.x = S.power.x / dv; S.power.y = S.power.y / dv; S.power.z = S.power.z / dv;
+        ++S.nInteractions;
+        bool scatter = false;
+        float scatteringAlbedo = 0.f;
+        if (S.nInteractions < maxInteractions) {  // the albedo is only read behind this test (photontracer.cl:179)
+            float scatW = (luts == lut) ? colorW : sample_alpha(luts, wf, m1, m2, volumeSample);
+            scatteringAlbedo = scatW / (scatW + colorW);
+            scatter = rand01_(S.rx, S.rc) < scatteringAlbedo;
+        }
+        if (scatter) {
+            S.power.x *= scatteringAlbedo; S.power.y *= scatteringAlbedo; S.power.z *= scatteringAlbedo;
+            write_photon(A.photons, photonId, S.origin, S.power, S.th, S.ph);
+            S.tStart = 0.f; S.tEnd = kFltMax;
+            float u1 = rand01_(S.rx, S.rc), u2 = rand01_(S.rx, S.rc);
+            S.direction = phase_sample(A.p.shading_type, A.p.material[0], S.direction, u1, u2, nullptr);
+            encode_direction_(S.direction, S.th, S.ph);
+            S.scatterEvent = ray_box_(A.bmin, A.bmax, S.origin, S.direction, S.tStart, S.tEnd);
+            S.tStart = S.tStart + 0.5f * A.p.step_size;
+        } else {
+            write_photon(A.photons, photonId, S.origin, S.power, S.th, S.ph);
+            S.power.x = S.power.y = S.power.z = kFltMax;  // read by the recomputation detector
+            S.scatterEvent = false;
+        }
+    }
+}
 
-    if (!SINGLE && (A.p.flags & CPM_TRACE_NO_SINGLE_SCATTERING)) {  // photontracer.cl:143-157
-        float vs_unused, op_unused;
-        float t = AHEAD > 1 ? woodcock_ahead<DT, (AHEAD > 1 ? AHEAD : 2)>(A.vol, lut, wf, m1, m2, origin, direction, tStart, tEnd, rx, rc, steps, vs_unused, op_unused)
-                            : woodcock<DT>(A.vol, lut, wf, m1, m2, origin, direction, tStart, tEnd, rx, rc, steps, vs_unused, op_unused);
-        if (scatterEvent) {
-            origin.x = fma_(t, direction.x, origin.x);
-            origin.y = fma_(t, direction.y, origin.y);
-            origin.z = fma_(t, direction.z, origin.z);
-            tStart = 0.f; tEnd = kFltMax;
-            float u1 = rand01_(rx, rc), u2 = rand01_(rx, rc);
-            float pdf;
-            direction = phase_sample(A.p.shading_type, A.p.material[0], direction, u1, u2, &pdf);
-            encode_direction_(direction, th, ph);
-            scatterEvent = ray_box_(A.bmin, A.bmax, origin, direction, tStart, tEnd);
-            power.x = power.x / pdf; power.y = power.y / pdf; power.z = power.z / pdf;
-            tStart = tStart + 0.5f * A.p.step_size;
-        }
-    }
-    while (scatterEvent) {  // photontracer.cl:158-197
-        float volumeSample = 0.f, colorW = 0.f;
-        float t = AHEAD > 1 ? woodcock_ahead<DT, (AHEAD > 1 ? AHEAD : 2)>(A.vol, lut, wf, m1, m2, origin, direction, tStart, tEnd, rx, rc, steps, volumeSample, colorW)
-                            : woodcock<DT>(A.vol, lut, wf, m1, m2, origin, direction, tStart, tEnd, rx, rc, steps, volumeSample, colorW);
-        scatterEvent = t <= tEnd;
-        if (scatterEvent) {
-            origin.x = fma_(t, direction.x, origin.x);
-            origin.y = fma_(t, direction.y, origin.y);
-            origin.z = fma_(t, direction.z, origin.z);
-            size_t photonId = (size_t)photonOffset + nInteractions * totalPhotons + (size_t)threadId;
-            // (th, ph) = encodeDirection(direction) (photontracer.cl:167): current, see above.
-            // The reference samples the volume and the TF again at the collision point
-            // (photontracer.cl:170-173).  The accepted Woodcock iteration sampled exactly that point --
-            // fma(t, d, o) with the same t, d, o -- so its volume sample and alpha ARE those values.
-            float dv = max_(colorW, 0.01f);
-            power.x = power.x / dv; power.y = power.y / dv; power.z = power.z / dv;
-            ++nInteractions;
-            bool scatter = false;
-            float scatteringAlbedo = 0.f;
-            if (nInteractions < maxInteractions) {  // the albedo is only read behind this test (photontracer.cl:179)
-                float scatW = (luts == lut) ? colorW : sample_alpha(luts, wf, m1, m2, volumeSample);
-                scatteringAlbedo = scatW / (scatW + colorW);
-                scatter = rand01_(rx, rc) < scatteringAlbedo;
-            }
-            if (scatter) {
-                power.x *= scatteringAlbedo; power.y *= scatteringAlbedo; power.z *= scatteringAlbedo;
-                write_photon(A.photons, photonId, origin, power, th, ph);
-                tStart = 0.f; tEnd = kFltMax;
-                float u1 = rand01_(rx, rc), u2 = rand01_(rx, rc);
-                direction = phase_sample(A.p.shading_type, A.p.material[0], direction, u1, u2, nullptr);
-                encode_direction_(direction, th, ph);
-                scatterEvent = ray_box_(A.bmin, A.bmax, origin, direction, tStart, tEnd);
-                tStart = tStart + 0.5f * A.p.step_size;
-            } else {
-                write_photon(A.photons, photonId, origin, power, th, ph);
-                power.x = power.y = power.z = kFltMax;  // read by the recomputation detector
-                scatterEvent = false;
-            }
-        }
-    }
-    for (uint32_t i = nInteractions; i < maxInteractions; ++i) {  // photontracer.cl:199-209 (th, ph: the current direction)
+template <bool SINGLE>
+CPM_DEV void walk_finish(const TraceArgs& A, int threadId, const WalkState& S) {
+    const int photonOffset = A.p.photon_offset;
+    const uint32_t maxInteractions = SINGLE ? 1u : (uint32_t)A.p.max_interactions;
+    const size_t totalPhotons = (size_t)A.p.total_photons;
+    for (uint32_t i = S.nInteractions; i < maxInteractions; ++i) {  // photontracer.cl:199-209 (th, ph: the current direction)
         size_t photonId = (size_t)photonOffset + i * totalPhotons + (size_t)threadId;
         f3 p = { kFltMax, kFltMax, kFltMax };
-        f3 pw = { power.x, kFltMax, kFltMax };
-        write_photon(A.photons, photonId, p, pw, th, ph);
+        f3 pw = { S.power.x, kFltMax, kFltMax };
+        write_photon(A.photons, photonId, p, pw, S.th, S.ph);
     }
-    if (A.p.flags & CPM_TRACE_PROGRESSIVE) rng[photonOffset + threadId] = make_uint2(rx, rc);  // :211-215
+    if (A.p.flags & CPM_TRACE_PROGRESSIVE) reinterpret_cast<uint2*>(A.rng)[photonOffset + threadId] = make_uint2(S.rx, S.rc);  // :211-215
     if (A.reset_importances) A.reset_importances[photonOffset + threadId] = 2147483647u;  // resetPhotonImportance (tracercl.cpp:529)
+}
+
+// Writes the photon records (and sentinels) of sample `threadId`, its RNG state when progressive, its importance key when
+// A.reset_importances is set.
+template <int DT, bool SINGLE, int AHEAD = 1>
+CPM_DEV void trace_photon(const TraceArgs& A, const float* lut, const float* luts, int threadId, float4 l0, float4 l1, float2 ip, uint2 rs,
+                          f3 direction, float th, float ph, unsigned& steps) {
+    WalkState S;
+    walk_init<DT, SINGLE, AHEAD>(A, lut, l0, l1, ip, rs, direction, th, ph, steps, S);
+    while (S.scatterEvent) walk_segment<DT, SINGLE, AHEAD>(A, lut, luts, threadId, steps, S);
+    walk_finish<SINGLE>(A, threadId, S);
 }
 
 }  // namespace tracer
