@@ -112,7 +112,7 @@ __host__ void brick_shape(const int dims[3], BrickLayout& L) {
 
 // candidates per axis from the radius; false when the kernels do not cover it: a candidate box must not span more than
 // two bricks per axis (it is at most as wide as a brick, or the brick spans the axis).  Up to 4 candidates per axis the
-// record loops are unrolled (fast_brick_kernel<2 / 3 / 4>); wider boxes take run-time loops (<0>).
+// record loops are unrolled (fast_brick_kernel<2 / 3 / 4>); wider boxes take run-time loops over y and z (<6 / 8 / 14>).
 constexpr int kMaxCandidates = 8;
 __host__ bool brick_reach(const GridDev& G, float radius, BrickLayout& L) {
     const float r[3] = { radius * G.t2i.sx, radius * G.t2i.sy, radius * G.t2i.sz };  // radius in voxels per axis
@@ -371,9 +371,9 @@ __global__ __launch_bounds__(1024, 8) void fast_scatter_kernel(const float* __re
 // for the candidates beyond the face; d^2 in texture space with the contract's operands (c = indexToTexture * v,
 // d = c - p, d^2 = fma(dz, dz, fma(dy, dy, dx * dx))); weight 0.75 * (1 - d^2 / r^2) for d^2 <= r^2; value -> fixed point
 // by truncation.
-// The same record for a box of any width (MAXC = 0 of fast_brick_kernel: more than 4 candidates along some axis): run-time loops
+// The same record for a box of any width (MAXC > 4 of fast_brick_kernel: more than 4 candidates along some axis): run-time loops
 // over the candidates inside this brick, a row left as soon as dz^2 + dy^2 alone exceeds r^2.
-template <int CH>
+template <int CH, int WX /* candidates along x the loop is unrolled for: >= L.mcx */>
 CPM_DEV void brick_record_wide(const GridDev& G, const BrickLayout& L, float4 a, float pg, float pb, int ox, int oy, int oz, int BX, int BY, int BZ,
                                float rgx, float rgy, float rgz, float r2, float inv_r2, float k, float S, long long* __restrict__ tile, int plane) {
     Box c;
@@ -383,16 +383,16 @@ CPM_DEV void brick_record_wide(const GridDev& G, const BrickLayout& L, float4 a,
     const int sz = max(c.sz, oz), ez = min(c.ez, oz + BZ - 1);
     const float pk = __builtin_fabsf(a.w) <= kFltMax ? a.w * k : 0.f;
     const float pkg = __builtin_fabsf(pg) <= kFltMax ? pg * k : 0.f, pkb = __builtin_fabsf(pb) <= kFltMax ? pb * k : 0.f;
-    float dx2[kMaxCandidates];
+    float dx2[WX];
 #pragma unroll
-    for (int q = 0; q < kMaxCandidates; ++q) { const float d = fma_(G.i2t.sx, (float)(sx + q), G.i2t.tx) - a.x; dx2[q] = d * d; }
+    for (int q = 0; q < WX; ++q) { const float d = fma_(G.i2t.sx, (float)(sx + q), G.i2t.tx) - a.x; dx2[q] = d * d; }
     for (int vz = sz; vz <= ez; ++vz) {
         const float dz = fma_(G.i2t.sz, (float)vz, G.i2t.tz) - a.z;
         for (int vy = sy; vy <= ey; ++vy) {
             const float dy = fma_(G.i2t.sy, (float)vy, G.i2t.ty) - a.y;
             const int row = (sx - ox) + BX * ((vy - oy) + BY * (vz - oz));
 #pragma unroll
-            for (int q = 0; q < kMaxCandidates; ++q) {
+            for (int q = 0; q < WX; ++q) {
                 const float d2 = fma_(dz, dz, fma_(dy, dy, dx2[q]));   // the contract's operands: dx * dx, then the two fmas
                 if (sx + q > ex || !(d2 <= r2)) continue;
                 const float w = 0.75f * (1.0f - d2 * inv_r2);
@@ -530,8 +530,10 @@ __global__ __launch_bounds__(kBrickThreads, (CH == 4 ? 4 : CPM_BRICK_WAVES)) voi
             for (int q = 0; q < kBrickPer; ++q) {
                 const uint32_t j = first + (uint32_t)(q * kBrickThreads + t);
                 if (j < j1) {
-                    if (MAXC == 0) brick_record_wide<CH>(G, L, a[q], a2[q].x, a2[q].y, ox, oy, oz, BX, BY, BZ, rgx, rgy, rgz, r2, inv_r2, k, S, s_tile, L.bvox);
-                    else brick_record<(MAXC == 0 ? 1 : MAXC), CH>(G, a[q], a2[q].x, a2[q].y, ox, oy, oz, BX, BY, BZ, rgx, rgy, rgz, r2, inv_r2, k, S, s_tile, L.bvox);
+                    // MAXC <= 4: a box of at most MAXC^3 candidates, all loops unrolled; MAXC = 6 / 8 / 14 (= x width 4): wide or anisotropic
+                    // boxes -- y and z at run time, x unrolled for 6 / 8 / 4 candidates
+                    if (MAXC > 4) brick_record_wide<CH, (MAXC == 14 ? 4 : MAXC)>(G, L, a[q], a2[q].x, a2[q].y, ox, oy, oz, BX, BY, BZ, rgx, rgy, rgz, r2, inv_r2, k, S, s_tile, L.bvox);
+                    else brick_record<(MAXC > 4 ? 1 : MAXC), CH>(G, a[q], a2[q].x, a2[q].y, ox, oy, oz, BX, BY, BZ, rgx, rgy, rgz, r2, inv_r2, k, S, s_tile, L.bvox);
                 }
             }
 #pragma unroll
@@ -715,10 +717,14 @@ int cpm_gather_fast_marked(cpm_ctx* ctx, const float* sorted_pos_power, const ui
         CPM_LAUNCH(ctx, (fast_brick_kernel<MAXC, CH>), bgrid, dim3(kBrickThreads), tile_bytes, s, sorted_pos_power, brick_table, G, L,  \
                    radius, k, accumulate, grid_out, nonzero_bricks);                                                     \
     } while (0)
+    // the wide variants by the box's width along x (what their inner loop is unrolled for): 14 = 4, 6, 8
+    const int wide = L.mcx <= 4 ? 14 : (L.mcx <= 6 ? 6 : 8);
     if (G.channels == 1) {
-        if (L.maxc <= 2) CPM_BRICK_LAUNCH(2, 1); else if (L.maxc == 3) CPM_BRICK_LAUNCH(3, 1); else if (L.maxc == 4) CPM_BRICK_LAUNCH(4, 1); else CPM_BRICK_LAUNCH(0, 1);
+        if (L.maxc <= 2) CPM_BRICK_LAUNCH(2, 1); else if (L.maxc == 3) CPM_BRICK_LAUNCH(3, 1); else if (L.maxc == 4) CPM_BRICK_LAUNCH(4, 1);
+        else if (wide == 14) CPM_BRICK_LAUNCH(14, 1); else if (wide == 6) CPM_BRICK_LAUNCH(6, 1); else CPM_BRICK_LAUNCH(8, 1);
     } else {
-        if (L.maxc <= 2) CPM_BRICK_LAUNCH(2, 4); else if (L.maxc == 3) CPM_BRICK_LAUNCH(3, 4); else if (L.maxc == 4) CPM_BRICK_LAUNCH(4, 4); else CPM_BRICK_LAUNCH(0, 4);
+        if (L.maxc <= 2) CPM_BRICK_LAUNCH(2, 4); else if (L.maxc == 3) CPM_BRICK_LAUNCH(3, 4); else if (L.maxc == 4) CPM_BRICK_LAUNCH(4, 4);
+        else if (wide == 14) CPM_BRICK_LAUNCH(14, 4); else if (wide == 6) CPM_BRICK_LAUNCH(6, 4); else CPM_BRICK_LAUNCH(8, 4);
     }
 #undef CPM_BRICK_LAUNCH
     CPM_LAUNCH_CHECK(ctx, "fast_brick_kernel");

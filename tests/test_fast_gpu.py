@@ -151,6 +151,8 @@ CASES = [
     ((256, 256, 48), 1, 200_000, 2.76, dict(cluster=0.9)),   # the workspace's light volume: 6 x 6 x 2 candidates
     ((96, 96, 18), 4, 30_000, 2.76, {}),
     ((256, 256, 192), 1, 60_000, 3.3, {}),                   # bigger bricks and wide boxes
+    ((24, 64, 64), 1, 20_000, 3.0, {}),                      # narrow along x (3 candidates), wide along y and z (7)
+    ((24, 64, 64), 4, 10_000, 3.0, dict(negative=True)),
 ]
 
 
