@@ -311,7 +311,10 @@ def main():
     # the one exchange step: RCCL through the C-ABI (one-process-per-GPU form); torch.distributed only carries the id
     transport_note = None
     root = 0 if args.collective == "reduce" else None
-    if world > 1 and args.transport == "rccl" and args.test_backend == "nccl" and not args.test_one_device:
+    # (testing: with CPM_RCCL_LIBRARY naming the tests' RCCL double -- shared memory between ranks on ONE GPU -- the C-ABI's multi-rank
+    # path runs over gloo-launched ranks too)
+    fake_rccl = bool(os.environ.get("CPM_RCCL_LIBRARY"))
+    if world > 1 and args.transport == "rccl" and ((args.test_backend == "nccl" and not args.test_one_device) or fake_rccl):
         # Every rank first checks locally that RCCL can be bound (no communication), the ranks agree, and only then
         # enter the collective communicator setup; a probe all-reduce follows.  Should any of it fail, ALL ranks fall
         # back to torch.distributed's all-reduce (the same RCCL wire) and the JSON line says so -- a scaling run is

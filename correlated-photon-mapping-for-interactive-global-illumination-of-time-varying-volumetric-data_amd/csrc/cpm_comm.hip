@@ -10,6 +10,7 @@
 // RCCL is bound at run time (dlopen of librccl.so.1 on the first cpm_comm_* call), so a single-GPU host needs no RCCL
 // and libcpm_hip.so carries no link-time dependency on it.
 #include <dlfcn.h>
+#include <stdlib.h>
 #include <rccl/rccl.h>
 
 #include <chrono>
@@ -75,8 +76,14 @@ std::once_flag g_rccl_once;
 
 void load_rccl() {
     Rccl& R = g_rccl;
+    // CPM_RCCL_LIBRARY: another build of RCCL -- or the tests' double (tests/fake_rccl: shared memory between ranks that share one GPU)
+    const char* override_path = getenv("CPM_RCCL_LIBRARY");
+    if (override_path && override_path[0]) {
+        R.lib = dlopen(override_path, RTLD_NOW | RTLD_LOCAL);
+        if (!R.lib) { R.error = std::string("CPM_RCCL_LIBRARY: cannot load ") + override_path; return; }
+    }
     const char* names[] = { "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1" };
-    for (const char* n : names) { R.lib = dlopen(n, RTLD_NOW | RTLD_LOCAL); if (R.lib) break; }
+    for (const char* n : names) { if (R.lib) break; R.lib = dlopen(n, RTLD_NOW | RTLD_LOCAL); }
     if (!R.lib) { R.error = "librccl.so.1 not found (dlopen)"; return; }
     auto sym = [&](const char* s) -> void* {
         void* p = dlsym(R.lib, s);

@@ -97,3 +97,24 @@ def test_bench_single_process_rccl_world1():
     assert r.returncode == 0, (r.stdout + r.stderr)[-4000:]
     d = _last_json(r.stdout)
     assert d["n_gpus"] == 1 and d["value"] > 0
+
+
+def test_bench_two_ranks_through_the_c_abi_reduce():
+    """bench.py --gpus 2 with the C-ABI's own transport (RcclTransport -> cpm_comm_create(rank, 2), cpm_allreduce_grid_sparse with the
+    gather's marks) -- over the RCCL test double (tests/fake_rccl: librccl refuses two ranks on the box's one GPU), ranks started by
+    gloo.  The communicator reports two ranks, every frame's reduce went through the sparse path or its dense fall-back."""
+    sys.path.insert(0, str(REPO / "tests" / "fake_rccl"))
+    import build as fake_build
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", CPM_RCCL_LIBRARY=str(fake_build.build()))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29536", str(REPO / "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "3", "--workload", "config1",
+           "--test-backend", "gloo", "--test-one-device", "--transport", "rccl"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=str(REPO), env=env)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-4000:]
+    d = _last_json(r.stdout)
+    assert d["n_gpus"] == 2 and d["value"] > 0
+    assert d["config"]["transport"] == "RcclTransport" and d["config"]["rccl_ranks"] == 2
+    red = d["reduce"]
+    assert red["stream_synchronisations_per_frame"] == 0 and "cpm_allreduce_grid_sparse" in red["kind"]
+    assert red["frames_sparse"] + red["frames_dense_by_policy"] + red["frames_dense_after_overflow"] == 6
+    assert red["n_union_median"] > 0 and red["reduce_bytes_per_frame"] > 0

@@ -1,0 +1,110 @@
+"""The C-ABI's multi-rank path with TWO ranks, on the one GPU of the test box: libcpm_hip binds the RCCL test double
+(tests/fake_rccl: the eight RCCL entry points over shared memory; CPM_RCCL_LIBRARY) instead of librccl, which refuses two ranks on
+one device.  What runs is the product's code -- cpm_comm_create with rank / size, cpm_allreduce_grid / cpm_reduce_grid,
+cpm_allreduce_grid_sparse (union of two DIFFERENT masks, slot tables, the capacity policy on both ranks, overflow -> dense on both,
+root reduce, the delta path), sharding.RcclTransport + OverlappedGridReducer -- and the sums are compared with numpy's.  Not a
+substitute for a run over xGMI: RCCL itself has still never executed with more than one rank."""
+import importlib
+import os
+import subprocess
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+REPO = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(REPO / "tests" / "fake_rccl"))
+
+
+def _partial(dims, ch, k, who):
+    dx, dy, dz = dims
+    g = np.zeros((dz, dy, dx, ch), np.float32)
+    rng = np.random.default_rng(1000 * k + 17 * who + dx)
+    depth = min(dz, (2 + 7 * k) if k < 5 else 4)
+    lit = rng.random((depth, dy, dx)) < 0.3
+    vals = rng.integers(1, 1000, (depth, dy, dx, ch)).astype(np.float32) / np.float32(8.0)
+    g[:depth] = vals * lit[..., None]
+    return g.reshape(-1)
+
+
+def _bricks(dims):
+    bxn, byn, bzn = [(d + 3) // 4 for d in dims]
+    z, y, x = np.meshgrid(np.arange(dims[2]), np.arange(dims[1]), np.arange(dims[0]), indexing="ij")
+    return ((x // 4) + bxn * ((y // 4) + byn * (z // 4))).reshape(-1), bxn * byn * bzn
+
+
+@pytest.fixture(scope="module")
+def two_ranks(tmp_path_factory, cpm):
+    import build as fake_build
+    lib = fake_build.build()
+    out = tmp_path_factory.mktemp("fake_rccl")
+    env = dict(os.environ, CPM_RCCL_LIBRARY=str(lib))
+    procs = [subprocess.Popen([sys.executable, str(REPO / "tests" / "fake_rccl" / "worker.py"), str(r), "2", str(out)],
+                              env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    logs = []
+    for p in procs:
+        try:
+            o, _ = p.communicate(timeout=300)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            pytest.fail("the two-rank workers did not finish in 300 s")
+        logs.append(o)
+    assert all(p.returncode == 0 for p in procs), "\n".join(l[-3000:] for l in logs)
+    return [np.load(out / f"rank{r}.npz") for r in range(2)]
+
+
+def test_dense_collectives_with_two_ranks(two_ranks):
+    r0, r1 = two_ranks
+    want = _partial((16, 16, 16), 1, 0, 0) + _partial((16, 16, 16), 1, 0, 1)
+    assert np.array_equal(r0["dense_allreduce"], want) and np.array_equal(r1["dense_allreduce"], want)
+    want = _partial((16, 16, 16), 1, 1, 0) + _partial((16, 16, 16), 1, 1, 1)
+    assert np.array_equal(r0["dense_reduce_root0"], want) and (r1["dense_reduce_root0"] == -1.0).all()
+
+
+@pytest.mark.parametrize("dims,ch", [((32, 32, 32), 1), ((20, 13, 9), 4)])
+def test_sparse_reduce_with_two_ranks(two_ranks, cpm, dims, ch):
+    sh = importlib.import_module(cpm.__name__ + ".sharding")
+    r0, r1 = two_ranks
+    b, nb = _bricks(dims)
+    key = f"sparse_{dims[0]}_{ch}"
+    i0, i1 = r0[key + "_info"], r1[key + "_info"]
+    assert np.array_equal(i0, i1)                                   # union, capacity, mode and bytes: the same numbers on both ranks
+    for k in range(8):
+        a, c = _partial(dims, ch, k, 0), _partial(dims, ch, k, 1)
+        want = a + c
+        assert np.array_equal(r0[f"{key}_{k}"], want), k            # in place (even k) and separate total (odd k): the dense sum, bit for bit
+        assert np.array_equal(r1[f"{key}_{k}"], want), k
+        union = np.unique(b[np.repeat(((a != 0) | (c != 0)).reshape(-1, ch).any(axis=1), 1)]).size
+        assert i0[k, 0] == union
+        assert i0[k, 1] == sh.sparse_capacity(nb, int(i0[k - 2, 0]) if k >= 2 else -1)
+        assert i0[k, 2] == (1 if i0[k, 1] >= nb else 2 if union > i0[k, 1] else 0)
+    if dims == (32, 32, 32):
+        modes = list(i0[:, 2])
+        assert 2 in modes and 1 in modes and modes[-1] == 0         # overflow -> dense, dense by policy, and back to sparse
+    # root reduce: rank 1 has the sum, rank 0 its own partial
+    a, c = _partial(dims, ch, 2, 0), _partial(dims, ch, 2, 1)
+    assert np.array_equal(r1[key + "_root1"], a + c) and np.array_equal(r0[key + "_root1"], a)
+    # delta path: the union of the two ranks' touched bricks carries the sum, the rest of the separate total is untouched
+    m = (r0[key + "_delta_mask"] | r1[key + "_delta_mask"]).astype(bool)
+    sel = np.repeat(m[b], ch)
+    want = _partial(dims, ch, 3, 0) + _partial(dims, ch, 3, 1)
+    for r in (r0, r1):
+        got = r[key + "_delta"]
+        assert r[key + "_delta_union"][0] == m.sum()
+        if r[key + "_delta_union"][1] == 0:
+            assert np.array_equal(got[sel], want[sel]) and (got[~sel] == -2.0).all()
+
+
+def test_overlapped_reducer_over_two_ranks(two_ranks):
+    """bench.py's frame loop: every frame's buffer holds the two ranks' sum once its reduce has been waited for, with and without the
+    gather's marks; the figures of every ticket agree between the ranks."""
+    r0, r1 = two_ranks
+    dims = (32, 32, 32)
+    for k in range(7):
+        want = _partial(dims, 1, k, 0) + _partial(dims, 1, k, 1)
+        assert np.array_equal(r0[f"reducer_{k}"], want), k
+        assert np.array_equal(r1[f"reducer_{k}"], want), k
+    assert np.array_equal(r0["reducer_info"], r1["reducer_info"]) and r0["reducer_info"].shape == (7, 3)
