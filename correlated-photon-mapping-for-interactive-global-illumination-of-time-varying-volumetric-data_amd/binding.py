@@ -77,6 +77,12 @@ class TraceOrder:
         self.ctx._check(self.ctx.lib.cpm_debug_trace_order_read(self.ctx.h, self.h, order.ctypes.data, cost.ctypes.data))
         return order, cost[:n], int(cost[n])
 
+    def write(self, table):
+        """Replace the table (a permutation of the chunks) -- measurement hook, synchronises."""
+        import numpy as np
+        t = np.ascontiguousarray(table, np.uint32)
+        self.ctx._check(self.ctx.lib.cpm_debug_trace_order_write(self.ctx.h, self.h, t.ctypes.data))
+
     def close(self):
         if self.h:
             self.ctx.lib.cpm_trace_order_destroy(self.ctx.h, self.h)
@@ -275,6 +281,7 @@ def load_library() -> C.CDLL:
         "cpm_volume_download": (i32, [vp, vp, vp, vp]),
         # include/cpm/cpm_profile.h (measurement hooks)
         "cpm_debug_trace_order_read": (i32, [vp, vp, vp, vp]),
+        "cpm_debug_trace_order_write": (i32, [vp, vp, vp]),
         "cpm_debug_set_step_counter": (None, [vp, vp]),
         "cpm_debug_set_gather_stamps": (None, [vp, vp]),
         "cpm_debug_force_voxel_gather": (None, [vp, i32]),

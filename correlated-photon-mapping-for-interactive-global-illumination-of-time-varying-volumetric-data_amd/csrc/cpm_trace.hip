@@ -494,6 +494,20 @@ int cpm_debug_trace_order_read(cpm_ctx* ctx, const cpm_trace_order* order, uint3
     return CPM_OK;
 }
 
+// measurement hook (include/cpm/cpm_profile.h): another table for the order object -- any permutation of its chunks (checked)
+int cpm_debug_trace_order_write(cpm_ctx* ctx, cpm_trace_order* order, const uint32_t* table) {
+    CPM_ENTER(ctx);
+    CPM_REQUIRE(ctx, order && table, "cpm_debug_trace_order_write: null argument");
+    std::vector<uint8_t> seen(order->n_chunks, 0);
+    for (uint32_t b = 0; b < order->n_chunks; ++b) {
+        CPM_REQUIRE(ctx, table[b] < order->n_chunks && !seen[table[b]], "cpm_debug_trace_order_write: not a permutation of the chunks");
+        seen[table[b]] = 1;
+    }
+    CPM_HIP_CHECK(ctx, hipDeviceSynchronize());
+    CPM_HIP_CHECK(ctx, hipMemcpy(order->order, table, (size_t)order->n_chunks * 4, hipMemcpyHostToDevice));
+    return CPM_OK;
+}
+
 int cpm_trace_order_update(cpm_ctx* ctx, cpm_trace_order* order, cpm_stream stream) {
     CPM_ENTER(ctx);
     CPM_REQUIRE(ctx, order && order->order && order->cost, "cpm_trace_order_update: null order");

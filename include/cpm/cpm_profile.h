@@ -49,6 +49,8 @@ void cpm_debug_fail_next_select(cpm_ctx* ctx, int on);
  * update (n_chunks + 1 entries, the last one = launches counted); either may be NULL.  Synchronises the device. */
 struct cpm_trace_order;
 int cpm_debug_trace_order_read(cpm_ctx* ctx, const struct cpm_trace_order* order, uint32_t* order_out, uint32_t* cost_out);
+/* measurement hook: replace the order's table by `table` (n_chunks entries, a permutation of the chunks: checked).  Synchronises. */
+int cpm_debug_trace_order_write(cpm_ctx* ctx, struct cpm_trace_order* order, const uint32_t* table);
 #ifdef __cplusplus
 }
 #endif
