@@ -124,3 +124,27 @@ def test_the_table(ctx, cpm, n_side):
         if k:
             assert c[:k].min() > c[k:].max()
     order.close()
+
+
+def test_any_permutation_of_the_chunks_gives_the_same_photons(ctx, cpm):
+    """The measurement hook behind tools/xcd_order_exp.py (cpm_debug_trace_order_write): under an arbitrary permutation of the chunks the
+    photons are still the default order's; a table that is not a permutation is refused."""
+    torch = ctx.torch
+    B = cpm.binding
+    ref = make(ctx, cpm, 300, False)
+    ref.trace()
+    fr = make(ctx, cpm, 300, True)
+    fr.trace()                                   # creates the order object (and measures)
+    n_chunks = (fr.n + 255) // 256
+    rng = np.random.default_rng(5)
+    for _ in range(3):
+        fr.trace_order.write(rng.permutation(n_chunks).astype(np.uint32))
+        fr._traces_since_order = 1               # no re-measure, no re-sort: the written table is what the launch takes
+        fr.photons.zero_()
+        fr.trace()
+        torch.cuda.synchronize()
+        assert torch.equal(fr.photons.view(torch.int32), ref.photons.view(torch.int32))
+    bad = np.arange(n_chunks, dtype=np.uint32)
+    bad[0] = bad[1]
+    with pytest.raises(B.CpmError):
+        fr.trace_order.write(bad)
