@@ -625,6 +625,8 @@ def main():
             for k in range(1, 4 * (n_steps - 1)):
                 rows.append(seq.step(net, 0.25 * k))
             rows = rows[3:]
+            totals = [seq.step_total(net, 0.25 * (4 * (n_steps - 1) - k))[1] for k in range(1, 4 * (n_steps - 1))][5:]   # (back down the sequence)
+            extras["config5_time_step"]["host_network_step_ms"] = round(float(np.median(totals)), 4)
             extras["config5_time_step"]["host_network"] = {
                 "steps": len(rows), "displayed_times": "a quarter of a sequence step apart",
                 "players_ms": round(float(np.median([r[1] for r in rows])), 4), "update_ms": round(float(np.median([r[2] for r in rows])), 4),

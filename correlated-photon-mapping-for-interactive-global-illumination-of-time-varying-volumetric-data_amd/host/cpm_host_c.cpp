@@ -478,6 +478,23 @@ int cpmh_sequence_step(cpmh_network* net, cpmh_sequence* s, float time, double* 
     return cpmh_n_recomputed(net);
 }
 
+// The same displayed time as ONE measurement: players + importance + tracer + light volume enqueued back to back, one
+// synchronisation at the end (cpmh_sequence_step waits in the middle to report its two parts, which costs the second part an
+// idle device).  Returns the photons re-traced (-1: everything), *total_ms the wall clock.
+int cpmh_sequence_step_total(cpmh_network* net, cpmh_sequence* s, float time, double* total_ms) {
+    if (!net || !s) return -1;
+    if (hipDeviceSynchronize() != hipSuccess) return -2;
+    const double t0 = now_ms();
+    cpmh_sequence_set_time(s, time);
+    if (cpmh_sequence_evaluate(s) != 0) return -3;
+    net->importance.process();
+    net->tracer.process();
+    net->lightVolume.process();
+    if (hipDeviceSynchronize() != hipSuccess) return -2;
+    if (total_ms) *total_ms = now_ms() - t0;
+    return cpmh_n_recomputed(net);
+}
+
 static void for_each_clock(cpmh_sequence* s, const std::function<void(SequenceClock&)>& f) {
     f(s->volumePlayer.clock_); f(s->minMaxPlayer.clock_); f(s->differencePlayer.clock_);
 #ifdef CPM_HOST_EXTRAS

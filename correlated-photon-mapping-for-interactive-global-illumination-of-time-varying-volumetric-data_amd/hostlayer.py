@@ -38,6 +38,7 @@ def load():
         "cpmh_sequence_destroy": (None, [vp]),
         "cpmh_attach_sequence": (i32, [vp, vp]),
         "cpmh_sequence_step": (i32, [vp, vp, C.c_float, vp]),
+        "cpmh_sequence_step_total": (i32, [vp, vp, C.c_float, vp]),
     }
     for name, (res, args) in sigs.items():
         f = getattr(lib, name)
@@ -146,6 +147,14 @@ class HostSequence:
         if n < -1:
             raise RuntimeError("cpmh_sequence_step failed")
         return n, t[0], t[1]
+
+    def step_total(self, net: HostNetwork, time: float):
+        """One displayed time, everything enqueued back to back, one synchronisation: (photons re-traced, ms)."""
+        t = C.c_double(0)
+        n = self.lib.cpmh_sequence_step_total(net.h, self.h, float(time), C.byref(t))
+        if n < -1:
+            raise RuntimeError("cpmh_sequence_step_total failed")
+        return n, t.value
 
     def close(self):
         if self.h:

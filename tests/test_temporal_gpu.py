@@ -91,3 +91,28 @@ def test_mix_errors(ctx, cpm):
     b = ctx.volume_create(np.zeros((4, 4, 8), np.uint8))
     with pytest.raises(cpm.binding.CpmError):
         ctx.volume_mix(a, b, 0.5, a)
+
+
+@pytest.mark.parametrize("shape,dtype", [((32, 32, 32), np.uint8), ((24, 20, 16), np.uint16), ((12, 16, 20), np.float32), ((9, 7, 11), np.uint8)])
+def test_volume_mix_leaves_the_tracers_copy_in_step(ctx, oracle, cpm, shape, dtype):
+    """cpm_volume_mix also rebuilds the footprint-ordered copy the tracer reads (one launch with the mix where a row is a whole number
+    of 4-byte words, mix + re-layout otherwise): a trace through the mixed volume gives the photons of a trace through a volume
+    created from the mixed voxels."""
+    S, P = cpm.synthetic, cpm.pipeline
+    rng = np.random.default_rng(sum(shape) + 1)
+    if dtype == np.float32:
+        a, b = rng.random(shape, dtype=np.float32), rng.random(shape, dtype=np.float32)
+    else:
+        hi = np.iinfo(dtype).max + 1
+        a, b = rng.integers(0, hi, shape).astype(dtype), rng.integers(0, hi, shape).astype(dtype)
+    va, vb, vo = ctx.volume_create(a), ctx.volume_create(b), ctx.volume_create(np.zeros_like(a))
+    ctx.volume_mix(va, vb, 0.3125, vo)
+    mixed = vo.download()
+    fresh = ctx.volume_create(mixed)
+    tf = S.homogeneous_tf(0.1)
+    f1 = P.PhotonFrame(ctx, vo, tf, 96, (16, 16, 16), light_travel_direction=(0.3, 0.5, -1.0))
+    f2 = P.PhotonFrame(ctx, fresh, tf, 96, (16, 16, 16), light_travel_direction=(0.3, 0.5, -1.0))
+    f1.trace(); f2.trace()
+    ctx.torch.cuda.synchronize()
+    assert ctx.torch.equal(f1.photons.view(ctx.torch.int32), f2.photons.view(ctx.torch.int32))
+    assert (f1.photons[:, 0] < 1e30).any()
