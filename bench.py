@@ -489,6 +489,22 @@ def main():
                                                    "trace_ms": round(timed(torch, fe.trace, reps), 4),
                                                    "photons_identical": bool(torch.equal(fe.photons.view(torch.int32), fr.photons.view(torch.int32)))}
             del fe
+        # the launch order's gain when the order is STALE: costs measured under the base TF, the trace timed under the edited
+        # TF (config 3's edit) without re-measuring -- what the first frames after an edit see -- then with a fresh order, and in lattice order
+        if fast and args.workload == "config2":
+            fo = P.PhotonFrame(ctx, fr.vol, tf, lattice, (gdim,) * 3, light_travel_direction=LIGHT_DIR)
+            fo.trace(); fo.trace()
+            fo.tf.update(S.workspace_tf(moved_point4=0.26))
+            fo._traces_since_order = 1                       # (no re-measure: the order stays the base TF's)
+            t_stale = timed(torch, fo.trace, reps)
+            fo._traces_since_order = 0                       # measure + re-sort under the edited TF
+            fo.trace()
+            t_fresh = timed(torch, fo.trace, reps)
+            fo.adaptive_order = False
+            t_lattice = timed(torch, fo.trace, reps)
+            extras["trace_order_after_tf_edit"] = {"stale_order_ms": round(t_stale, 4), "fresh_order_ms": round(t_fresh, 4), "lattice_order_ms": round(t_lattice, 4),
+                                                   "note": "trace alone under config 3's edited TF: order measured under the base TF / re-measured / none"}
+            del fo
         # config 2 at I = 4 (multiple scattering, Henyey-Greenstein g = 0.3): N photons, up to 4 records each
         f4 = P.PhotonFrame(ctx, fr.vol, fr.tf, lattice, (gdim,) * 3, light_travel_direction=LIGHT_DIR, max_interactions=4,
                            material=(0.3, 0.0, 0.0, 0.0))
