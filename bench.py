@@ -363,6 +363,7 @@ def main():
         fractions = []
         step_no = [0]
         delta_sr = ctx.sparse_reduce_create(transport.comm, fr.grid) if world > 1 and isinstance(transport, sharding.RcclTransport) else None
+        full_sr = ctx.sparse_reduce_create(transport.comm, fr.grid) if delta_sr is not None else None   # (its own payload policy: the unions differ a hundredfold)
         delta_pending = []
         reduce_info = []
 
@@ -377,15 +378,20 @@ def main():
                 # the delta path: only bricks touched by a re-traced photon (old or new position) changed on any rank; the
                 # previous step's ticket is completed here (its count has long arrived), this step's at the next one
                 while delta_pending:
-                    reduce_info.append(delta_sr.complete(delta_pending.pop()))
-                delta_pending.append(delta_sr.start(fr.light_volume, total_grid, brick_mask=fr.touched_mask))
+                    sr_, t_ = delta_pending.pop()
+                    reduce_info.append(sr_.complete(t_))
+                if fr.last_path == "full":   # the update rebuilt the rank's volume: the union of the non-zero bricks, zeros elsewhere
+                    delta_pending.append((full_sr, full_sr.start(fr.light_volume, total_grid)))
+                else:
+                    delta_pending.append((delta_sr, delta_sr.start(fr.light_volume, total_grid, brick_mask=fr.touched_mask)))
             elif world > 1:
                 total_grid.copy_(fr.light_volume)
                 sharding.allreduce_light_volume(total_grid, transport)
 
         def barrier():
             while delta_pending:
-                reduce_info.append(delta_sr.complete(delta_pending.pop()))
+                sr_, t_ = delta_pending.pop()
+                reduce_info.append(sr_.complete(t_))
             torch.cuda.synchronize()
             if dist is not None:
                 dist.barrier()
