@@ -108,6 +108,7 @@ static int launch_quads(cpm_ctx* ctx, cpm_volume* vol, const void* src, hipStrea
 
 namespace cpm {
 int build_quads(cpm_ctx* ctx, cpm_volume* vol, const void* src, bool copy_linear, hipStream_t s) {
+    vol->quads_stale = false;
     switch (vol->desc.dtype) {
         case CPM_U8: return copy_linear ? launch_quads<uint8_t, true>(ctx, vol, src, s) : launch_quads<uint8_t, false>(ctx, vol, src, s);
         case CPM_U16: return copy_linear ? launch_quads<uint16_t, true>(ctx, vol, src, s) : launch_quads<uint16_t, false>(ctx, vol, src, s);

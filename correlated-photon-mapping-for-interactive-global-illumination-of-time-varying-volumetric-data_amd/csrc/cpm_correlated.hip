@@ -716,7 +716,8 @@ constexpr uint32_t kRetraceTile = 256;
 #define CPM_RETRACE_AHEAD 2
 #endif
 constexpr int kRetraceAhead = CPM_RETRACE_AHEAD;
-template <int DT, bool MASK, bool SINGLE>
+// LINEAR: the volume's footprint copy is stale (a mixed time step): the re-traces fetch from the linear block (cpm::trace_volume_source)
+template <int DT, bool MASK, bool SINGLE, bool LINEAR = false>
 __global__ __launch_bounds__(256) void importance_retrace_kernel(ImpGrid G, const uint32_t* __restrict__ mask, uint32_t mask_words,
                                                                  int fix_exit_point, uint32_t* __restrict__ importances, SelTiles S,
                                                                  const tracer::TraceArgs A, float* __restrict__ old_sparse,
@@ -777,7 +778,7 @@ __global__ __launch_bounds__(256) void importance_retrace_kernel(ImpGrid G, cons
         encode_direction_(direction, th, ph);
         // (kRetraceAhead fetches of the walk in flight, as in trace_kernel; this launch is the importance pass, not its few walks:
         // 1 / 2 / 4 in flight 34.3 / 32.4 / 32.8 us, 8 -- registers -- 50.6)
-        tracer::trace_photon<DT, SINGLE, kRetraceAhead>(A, lut, luts, threadId, l0, l1, ip, rs, direction, th, ph, steps);
+        tracer::trace_photon<DT, SINGLE, kRetraceAhead, LINEAR>(A, lut, luts, threadId, l0, l1, ip, rs, direction, th, ph, steps);
         importances[photon_offset + threadId] = 2147483647u;  // resetPhotonImportance (tracercl.cpp:529)
     }
     // (lanes reconverge here; one lane of the wave reports for it)
@@ -1327,18 +1328,27 @@ int cpm_photon_importance_retrace(cpm_ctx* ctx, cpm_selection* s, const float* i
     const size_t lds = (size_t)mw * 4 + lut_bytes;
     const bool single = p.max_interactions == 1 && !(p.flags & CPM_TRACE_NO_SINGLE_SCATTERING);
     const dim3 grid(tiles), block(256);
-#define CPM_RETRACE_LAUNCH(DT)                                                                                                                   \
+    bool linear = false;  // a stale footprint copy (mixed time step): the re-traces read the volume's linear block
+    rc = cpm::trace_volume_source(ctx, vol, true, st, A, &linear);
+    if (rc) return rc;
+#define CPM_RETRACE_LAUNCH_L(DT, L)                                                                                                              \
     do {                                                                                                                                         \
-        if (use_mask && single) CPM_LAUNCH(ctx, (importance_retrace_kernel<DT, true, true>), grid, block, lds, st, G, mask_bits, mw, fix_exit_point, importances, S, A, old_photons8, tile_order, tile_cost);   \
-        else if (use_mask) CPM_LAUNCH(ctx, (importance_retrace_kernel<DT, true, false>), grid, block, lds, st, G, mask_bits, mw, fix_exit_point, importances, S, A, old_photons8, tile_order, tile_cost);       \
-        else if (single) CPM_LAUNCH(ctx, (importance_retrace_kernel<DT, false, true>), grid, block, lds, st, G, mask_bits, mw, fix_exit_point, importances, S, A, old_photons8, tile_order, tile_cost);        \
-        else CPM_LAUNCH(ctx, (importance_retrace_kernel<DT, false, false>), grid, block, lds, st, G, mask_bits, mw, fix_exit_point, importances, S, A, old_photons8, tile_order, tile_cost);                   \
+        if (use_mask && single) CPM_LAUNCH(ctx, (importance_retrace_kernel<DT, true, true, L>), grid, block, lds, st, G, mask_bits, mw, fix_exit_point, importances, S, A, old_photons8, tile_order, tile_cost);   \
+        else if (use_mask) CPM_LAUNCH(ctx, (importance_retrace_kernel<DT, true, false, L>), grid, block, lds, st, G, mask_bits, mw, fix_exit_point, importances, S, A, old_photons8, tile_order, tile_cost);       \
+        else if (single) CPM_LAUNCH(ctx, (importance_retrace_kernel<DT, false, true, L>), grid, block, lds, st, G, mask_bits, mw, fix_exit_point, importances, S, A, old_photons8, tile_order, tile_cost);        \
+        else CPM_LAUNCH(ctx, (importance_retrace_kernel<DT, false, false, L>), grid, block, lds, st, G, mask_bits, mw, fix_exit_point, importances, S, A, old_photons8, tile_order, tile_cost);                   \
+    } while (0)
+#define CPM_RETRACE_LAUNCH(DT)                                  \
+    do {                                                        \
+        if (linear) CPM_RETRACE_LAUNCH_L(DT, true);             \
+        else CPM_RETRACE_LAUNCH_L(DT, false);                   \
     } while (0)
     switch (vol->desc.dtype) {
         case CPM_U8: CPM_RETRACE_LAUNCH(CPM_U8); break;
         case CPM_U16: CPM_RETRACE_LAUNCH(CPM_U16); break;
         default: CPM_RETRACE_LAUNCH(CPM_F32); break;
     }
+#undef CPM_RETRACE_LAUNCH_L
 #undef CPM_RETRACE_LAUNCH
     CPM_LAUNCH_CHECK(ctx, "importance_retrace_kernel");
     if (tile_cost) s->pending_orders.push_back(ordinal);  // re-sorted behind the compaction (cpm_selection_finish)

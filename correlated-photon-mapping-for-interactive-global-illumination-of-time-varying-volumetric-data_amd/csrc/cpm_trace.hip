@@ -43,7 +43,9 @@ CPM_DEV int default_chunk(int b, unsigned n_chunks) {
     return b;
 }
 
-template <int DT, int EMIT, bool SINGLE = false>
+// LINEAR: the volume's footprint copy is stale (cpm_volume_mix) and this launch re-traces selected photons: four x-pair fetches of
+// the linear block per sample instead of one (cpm::trace_volume_source); same voxels, same lerps, same bits.
+template <int DT, int EMIT, bool SINGLE = false, bool LINEAR = false>
 __global__ __launch_bounds__(256, 8) void trace_kernel(const TraceArgs A) {
     extern __shared__ float lds[];
     // One decoded / re-encoded direction per workgroup: a directional light gives every sample the same (theta, phi),
@@ -158,7 +160,7 @@ __global__ __launch_bounds__(256, 8) void trace_kernel(const TraceArgs A) {
         encode_direction_(direction, th, ph);
     }
     // (SINGLE: two steps of the walk in flight; the general kernel's registers are full without them: I = 4 97.3 us with two, 93.6 with one)
-    trace_photon<DT, SINGLE, (SINGLE ? CPM_TRACE_AHEAD : 1)>(A, lut, luts, threadId, l0, l1, ip, rs, direction, th, ph, steps);
+    trace_photon<DT, SINGLE, (SINGLE ? CPM_TRACE_AHEAD : 1), LINEAR>(A, lut, luts, threadId, l0, l1, ip, rs, direction, th, ph, steps);
     if (A.chunk_cost) {  // what this chunk cost: the wave's longest walk (cpm_trace_order); lanes past the end have left
         unsigned m = steps;
         const unsigned long long alive = __ballot(true);
@@ -218,6 +220,18 @@ int make_trace_args(cpm_ctx* ctx, const cpm_volume* vol, const cpm_tf* tf, const
     A.dir_hint = ctx->dir_hint;
     lds = (size_t)tf->width * sizeof(float) * (A.tfs_alpha != A.tf_alpha ? 2 : 1);
     return CPM_OK;
+}
+
+int trace_volume_source(cpm_ctx* ctx, const cpm_volume* vol, bool sparse_launch, hipStream_t s, tracer::TraceArgs& A, bool* linear) {
+    *linear = false;
+    if (!vol->quads_stale) return CPM_OK;  // (make_trace_args left A.vol.voxels = vol->quads)
+    if (sparse_launch) {
+        A.vol.voxels = vol->voxels;
+        *linear = true;
+        return CPM_OK;
+    }
+    // (the copy is derived data of the volume the caller handed over as const: re-deriving it does not change what the volume holds)
+    return build_quads(ctx, const_cast<cpm_volume*>(vol), vol->voxels, false, s);
 }
 
 }
@@ -286,6 +300,12 @@ int trace_impl(cpm_ctx* ctx, const cpm_volume* vol, const cpm_tf* tf, const cpm_
     A.photons = photons8;
 
     hipStream_t s = (hipStream_t)stream;
+    // a stale footprint copy (the volume is cpm_volume_mix's output): a launch over selected photons whose number is on the device,
+    // or at most a quarter of the samples, reads the linear block; any other launch re-derives the copy first
+    bool linear = false;
+    const bool sparse = recompute_indices && !emitter && (sel.n_dev || (long long)n_recompute * 4 <= (long long)p.n_light_samples);
+    int rc_src = cpm::trace_volume_source(ctx, vol, sparse, s, A, &linear);
+    if (rc_src) return rc_src;
     dim3 grid(div_up(n_threads, 256)), block(256);
     if (ctx->trace_order && !recompute_indices && !sel.n_dev) {  // a plain launch over all the samples: in the order's order
         const cpm_trace_order* o = ctx->trace_order;
@@ -322,7 +342,9 @@ int trace_impl(cpm_ctx* ctx, const cpm_volume* vol, const cpm_tf* tf, const cpm_
     } while (0)
 #define CPM_TRACE_LAUNCH(DT)                                                  \
     do {                                                                      \
-        if (emit == EMIT_NONE) CPM_TRACE_LAUNCH_E(DT, EMIT_NONE);             \
+        if (linear && single) CPM_LAUNCH(ctx, (trace_kernel<DT, EMIT_NONE, true, true>), grid, block, lds, s, A);   \
+        else if (linear) CPM_LAUNCH(ctx, (trace_kernel<DT, EMIT_NONE, false, true>), grid, block, lds, s, A);       \
+        else if (emit == EMIT_NONE) CPM_TRACE_LAUNCH_E(DT, EMIT_NONE);        \
         else if (emit == EMIT_DIRECTIONAL) CPM_TRACE_LAUNCH_E(DT, EMIT_DIRECTIONAL); \
         else CPM_TRACE_LAUNCH_E(DT, EMIT_POINT);                              \
     } while (0)

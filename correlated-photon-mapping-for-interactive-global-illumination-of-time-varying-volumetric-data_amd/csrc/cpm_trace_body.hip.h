@@ -3,6 +3,7 @@
 // (importance_retrace_kernel: detector + threshold + tracer in one launch).  Replaces photonTracerKernel
 // (ref progressivephotonmapping/cl/photontracer.cl:69-216) and woodcockTracking (ref cl/transmittance.cl:126-144).
 #pragma once
+#include <type_traits>
 #include "cpm_ctx.h"
 #include "cpm_emit.hip.h"
 
@@ -10,7 +11,7 @@ namespace cpm {
 namespace tracer {
 
 struct VolDev {
-    const void* voxels;      // cpm_volume::quads
+    const void* voxels;      // cpm_volume::quads -- or cpm_volume::voxels for the LINEAR instantiations (the copy is stale)
     float fx, fy, fz;        // (float)dim
     float mx1, my1, mz1;     // dim - 1
     float mx2, my2, mz2;     // max(dim - 2, 0)
@@ -95,7 +96,24 @@ CPM_DEV void coord(float s, float dimf, float m1, float m2, float& fl, float& a)
     a = u - fl;
 }
 
-template <int DT>
+// The same eight voxels from the volume's linear block (x fastest): four fetches of an x-pair, rows (y, z), (y', z), (y, z'), (y', z')
+// with y' = min(y + 1, dim.y - 1), z' likewise -- exactly what a footprint element holds -- into the same order.
+template <int DT> struct LinearLoad {
+    typedef typename std::conditional<DT == CPM_U8, uint8_t, typename std::conditional<DT == CPM_U16, uint16_t, float>::type>::type T;
+    static CPM_DEV void load(const VolDev& V, uint32_t b00, int iy, int iz, float (&v)[8]) {
+        const T* base = static_cast<const T*>(V.voxels) + b00;
+        const uint32_t up = (float)iy < V.my1 ? V.sy : 0u, back = (float)iz < V.mz1 ? V.sz : 0u;
+        const uint32_t off[4] = { 0u, up, back, up + back };   // [z][y] = 00 01(y') 10(z') 11
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            T pr[2];
+            __builtin_memcpy(pr, base + off[k], sizeof(pr));
+            v[k] = (float)pr[0]; v[4 + k] = (float)pr[1];
+        }
+    }
+};
+
+template <int DT, bool LINEAR = false>
 CPM_DEV float sample_volume(const VolDev& V, float px, float py, float pz) {
     float flx, fly, flz, ax, ay, az;
     coord(px, V.fx, V.mx1, V.mx2, flx, ax);
@@ -105,7 +123,8 @@ CPM_DEV float sample_volume(const VolDev& V, float px, float py, float pz) {
     uint32_t b00 = V.mul24 ? (uint32_t)ix + __umul24(V.sy, (uint32_t)iy) + __umul24(V.sz, (uint32_t)iz)
                            : (uint32_t)ix + V.sy * (uint32_t)iy + V.sz * (uint32_t)iz;
     float v[8];  // [x][z][y]: 000 010 001 011 | 100 110 101 111
-    FootprintLoad<DT>::load(V.voxels, b00, v);
+    if (LINEAR) LinearLoad<DT>::load(V, b00, iy, iz, v);
+    else FootprintLoad<DT>::load(V.voxels, b00, v);
     float c00 = lerp_(v[0], v[4], ax);
     float c10 = lerp_(v[1], v[5], ax);
     float c01 = lerp_(v[2], v[6], ax);
@@ -168,7 +187,7 @@ CPM_DEV void write_photon(float* photons, size_t id, f3 p, f3 pw, float th, floa
     q[1] = make_float4(pw.y, pw.z, th, ph);
 }
 
-template <int DT>
+template <int DT, bool LINEAR = false>
 CPM_DEV float woodcock(const VolDev& V, const float* lut, float wf, float m1, float m2, f3 o, f3 d, float tStart,
                        float tEnd, uint32_t& rx, uint32_t& rc, unsigned& steps, float& last_sample, float& last_opacity) {
     constexpr float invTauMaxSampleBaseInterval = 1.f / (1.f * 150.f);  // tauMax = 1 (photontracer.cl:160)
@@ -181,7 +200,7 @@ CPM_DEV float woodcock(const VolDev& V, const float* lut, float wf, float m1, fl
         // whatever it is), so the fetch is skipped there; the RNG draw is not.
         opacity = 0.f;
         if (t <= tEnd) {
-            float vs = sample_volume<DT>(V, fma_(t, d.x, o.x), fma_(t, d.y, o.y), fma_(t, d.z, o.z));
+            float vs = sample_volume<DT, LINEAR>(V, fma_(t, d.x, o.x), fma_(t, d.y, o.y), fma_(t, d.z, o.z));
             opacity = sample_alpha(lut, wf, m1, m2, vs);
             last_sample = vs;
         }
@@ -199,7 +218,7 @@ CPM_DEV float woodcock(const VolDev& V, const float* lut, float wf, float m1, fl
 // second draw.  Same draws in the same order, same operations on the same operands: the same t, sample, opacity, state and
 // step count as woodcock() -- at the price of up to AHEAD - 1 fetches (and logs) past the end.  Two in flight pay everywhere
 // (the second fetch hides behind the first's latency: -6 % on the config-2 trace); more cost registers and bandwidth.
-template <int DT, int AHEAD>
+template <int DT, int AHEAD, bool LINEAR = false>
 CPM_DEV float woodcock_ahead(const VolDev& V, const float* lut, float wf, float m1, float m2, f3 o, f3 d, float tStart,
                              float tEnd, uint32_t& rx, uint32_t& rc, unsigned& steps, float& last_sample, float& last_opacity) {
     constexpr float invTauMaxSampleBaseInterval = 1.f / (1.f * 150.f);
@@ -216,7 +235,7 @@ CPM_DEV float woodcock_ahead(const VolDev& V, const float* lut, float wf, float 
             sx[j] = rx; sc[j] = rc;
             // beyond tEnd (or t = inf / NaN) nothing is read from the fetch: a safe address instead of the walk's
             const bool in = t <= tEnd;
-            vs[j] = sample_volume<DT>(V, in ? fma_(t, d.x, o.x) : 0.f, in ? fma_(t, d.y, o.y) : 0.f, in ? fma_(t, d.z, o.z) : 0.f);
+            vs[j] = sample_volume<DT, LINEAR>(V, in ? fma_(t, d.x, o.x) : 0.f, in ? fma_(t, d.y, o.y) : 0.f, in ? fma_(t, d.z, o.z) : 0.f);
         }
 #pragma unroll
         for (int j = 0; j < AHEAD; ++j) {
@@ -247,7 +266,7 @@ struct WalkState {
 
 // `direction` = decodeDirection(l1.z, l1.w) and (th, ph) = encodeDirection(direction), evaluated by the caller (once per workgroup
 // for a directional light, per lane otherwise: the same operations on the same inputs either way).
-template <int DT, bool SINGLE, int AHEAD>
+template <int DT, bool SINGLE, int AHEAD, bool LINEAR = false>
 CPM_DEV void walk_init(const TraceArgs& A, const float* lut, float4 l0, float4 l1, float2 ip, uint2 rs, f3 direction, float th, float ph,
                        unsigned& steps, WalkState& S) {
     const uint32_t maxInteractions = SINGLE ? 1u : (uint32_t)A.p.max_interactions;
@@ -264,8 +283,8 @@ CPM_DEV void walk_init(const TraceArgs& A, const float* lut, float4 l0, float4 l
     const float wf = A.tf_wf, m1 = A.tf_m1, m2 = A.tf_m2;
     if (!SINGLE && (A.p.flags & CPM_TRACE_NO_SINGLE_SCATTERING)) {  // photontracer.cl:143-157
         float vs_unused, op_unused;
-        float t = AHEAD > 1 ? woodcock_ahead<DT, (AHEAD > 1 ? AHEAD : 2)>(A.vol, lut, wf, m1, m2, S.origin, S.direction, S.tStart, S.tEnd, S.rx, S.rc, steps, vs_unused, op_unused)
-                            : woodcock<DT>(A.vol, lut, wf, m1, m2, S.origin, S.direction, S.tStart, S.tEnd, S.rx, S.rc, steps, vs_unused, op_unused);
+        float t = AHEAD > 1 ? woodcock_ahead<DT, (AHEAD > 1 ? AHEAD : 2), LINEAR>(A.vol, lut, wf, m1, m2, S.origin, S.direction, S.tStart, S.tEnd, S.rx, S.rc, steps, vs_unused, op_unused)
+                            : woodcock<DT, LINEAR>(A.vol, lut, wf, m1, m2, S.origin, S.direction, S.tStart, S.tEnd, S.rx, S.rc, steps, vs_unused, op_unused);
         if (S.scatterEvent) {
             S.origin.x = fma_(t, S.direction.x, S.origin.x);
             S.origin.y = fma_(t, S.direction.y, S.origin.y);
@@ -283,15 +302,15 @@ CPM_DEV void walk_init(const TraceArgs& A, const float* lut, float4 l0, float4 l
 }
 
 // one turn of photontracer.cl:158-197; call while S.scatterEvent
-template <int DT, bool SINGLE, int AHEAD>
+template <int DT, bool SINGLE, int AHEAD, bool LINEAR = false>
 CPM_DEV void walk_segment(const TraceArgs& A, const float* lut, const float* luts, int threadId, unsigned& steps, WalkState& S) {
     const int photonOffset = A.p.photon_offset;
     const uint32_t maxInteractions = SINGLE ? 1u : (uint32_t)A.p.max_interactions;
     const size_t totalPhotons = (size_t)A.p.total_photons;
     const float wf = A.tf_wf, m1 = A.tf_m1, m2 = A.tf_m2;
     float volumeSample = 0.f, colorW = 0.f;
-    float t = AHEAD > 1 ? woodcock_ahead<DT, (AHEAD > 1 ? AHEAD : 2)>(A.vol, lut, wf, m1, m2, S.origin, S.direction, S.tStart, S.tEnd, S.rx, S.rc, steps, volumeSample, colorW)
-                        : woodcock<DT>(A.vol, lut, wf, m1, m2, S.origin, S.direction, S.tStart, S.tEnd, S.rx, S.rc, steps, volumeSample, colorW);
+    float t = AHEAD > 1 ? woodcock_ahead<DT, (AHEAD > 1 ? AHEAD : 2), LINEAR>(A.vol, lut, wf, m1, m2, S.origin, S.direction, S.tStart, S.tEnd, S.rx, S.rc, steps, volumeSample, colorW)
+                        : woodcock<DT, LINEAR>(A.vol, lut, wf, m1, m2, S.origin, S.direction, S.tStart, S.tEnd, S.rx, S.rc, steps, volumeSample, colorW);
     S.scatterEvent = t <= S.tEnd;
     if (S.scatterEvent) {
         S.origin.x = fma_(t, S.direction.x, S.origin.x);
@@ -346,12 +365,12 @@ CPM_DEV void walk_finish(const TraceArgs& A, int threadId, const WalkState& S) {
 
 // Writes the photon records (and sentinels) of sample `threadId`, its RNG state when progressive, its importance key when
 // A.reset_importances is set.
-template <int DT, bool SINGLE, int AHEAD = 1>
+template <int DT, bool SINGLE, int AHEAD = 1, bool LINEAR = false>
 CPM_DEV void trace_photon(const TraceArgs& A, const float* lut, const float* luts, int threadId, float4 l0, float4 l1, float2 ip, uint2 rs,
                           f3 direction, float th, float ph, unsigned& steps) {
     WalkState S;
-    walk_init<DT, SINGLE, AHEAD>(A, lut, l0, l1, ip, rs, direction, th, ph, steps, S);
-    while (S.scatterEvent) walk_segment<DT, SINGLE, AHEAD>(A, lut, luts, threadId, steps, S);
+    walk_init<DT, SINGLE, AHEAD, LINEAR>(A, lut, l0, l1, ip, rs, direction, th, ph, steps, S);
+    while (S.scatterEvent) walk_segment<DT, SINGLE, AHEAD, LINEAR>(A, lut, luts, threadId, steps, S);
     walk_finish<SINGLE>(A, threadId, S);
 }
 
@@ -360,5 +379,8 @@ CPM_DEV void trace_photon(const TraceArgs& A, const float* lut, const float* lut
 // kernel arguments of a trace from the ABI's arguments (validated); lds = dynamic LDS bytes of the LUT(s)
 int make_trace_args(cpm_ctx* ctx, const cpm_volume* vol, const cpm_tf* tf, const cpm_tf* tf_scattering, const float aabb[8],
                     const cpm_trace_params* params, tracer::TraceArgs& A, size_t& lds);
+// A.vol.voxels of a launch: the footprint copy -- rebuilt first when it is stale and the launch covers all the samples -- or, for a
+// re-trace of a few photons through a stale copy, the linear block (*linear = true: the LINEAR kernels)
+int trace_volume_source(cpm_ctx* ctx, const cpm_volume* vol, bool sparse_launch, hipStream_t s, tracer::TraceArgs& A, bool* linear);
 
 }  // namespace cpm

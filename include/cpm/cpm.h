@@ -128,8 +128,8 @@ int cpm_volume_update(cpm_ctx* ctx, cpm_volume* vol, const void* voxels, int vox
 void cpm_volume_destroy(cpm_ctx* ctx, cpm_volume* vol);
 /* Device address and byte size of the voxel block, READ-ONLY (for consumers that read a volume produced on
  * the device, e.g. cpm_volume_mix's output): the tracer samples a second copy of the voxels laid out
- * by trilinear footprint (4 x the volume's bytes; one fetch per sample) that cpm_volume_create / _update / _mix keep in
- * step -- data written through this pointer does not reach it until cpm_volume_update(vol, that same pointer, 1)
+ * by trilinear footprint (4 x the volume's bytes; one fetch per sample) that cpm_volume_create / _update keep in
+ * step (cpm_volume_mix leaves it to the next trace that needs it) -- data written through this pointer does not reach it until cpm_volume_update(vol, that same pointer, 1)
  * re-derives it (no copy in that case); and a blocking device->host copy of the block
  * (Volume::getRepresentation<VolumeRAM>() of a volume whose valid representation is the device one). */
 void* cpm_volume_device_data(const cpm_volume* vol, size_t* bytes);
@@ -624,6 +624,9 @@ int cpm_mix_buffers(cpm_ctx* ctx, const void* x, const void* y, float a, size_t 
  * normalised values (v / 255, v / 65535, or the float itself) mixed as x * (1 - w) + y * w,
  * stored back in the same format (normalised integers: clamp, scale, round to nearest).
  * `out` is a volume of the same desc (it may alias neither input).
+ * The tracer's footprint copy of `out` is NOT rebuilt here: the next trace over all the samples re-derives it first,
+ * re-traces of selected photons (cpm_trace with indices, cpm_trace_selected, cpm_photon_importance_retrace) sample the
+ * linear block meanwhile -- a time step served by a correlated update never pays the re-layout.
  * Replaces VolumeSequencePlayer::process + glsl/volume_mix.frag
  * (ref uniformgridcl/processors/volumesequenceplayer.cpp:87-140; uniformgridcl/glsl/volume_mix.frag:42-52). */
 int cpm_volume_mix(cpm_ctx* ctx, const cpm_volume* v0, const cpm_volume* v1, float weight,

@@ -116,3 +116,58 @@ def test_volume_mix_leaves_the_tracers_copy_in_step(ctx, oracle, cpm, shape, dty
     ctx.torch.cuda.synchronize()
     assert ctx.torch.equal(f1.photons.view(ctx.torch.int32), f2.photons.view(ctx.torch.int32))
     assert (f1.photons[:, 0] < 1e30).any()
+
+
+@pytest.mark.parametrize("path", ["one launch", "selected", "launch by launch"])
+@pytest.mark.parametrize("dtype", [np.uint8, np.uint16, np.float32])
+def test_updates_through_a_mixed_volume_read_the_linear_block(ctx, cpm, path, dtype):
+    """cpm_volume_mix leaves the tracer's footprint copy stale: the correlated update's re-traces (one-launch importance + re-trace,
+    cpm_trace_selected over the device count, cpm_trace over a host-counted index list) then sample the volume's linear block --
+    four x-pair fetches instead of one footprint fetch, the same eight voxels and lerps -- and a trace over all the samples
+    re-derives the copy first.  Photons, selections and importance grids are those of a mapper stepping through volumes
+    created from the mixed voxels (copies in step from the start), bit for bit."""
+    S, P = cpm.synthetic, cpm.pipeline
+    tfp = [(0.0, 1, 1, 1, 0.0), (0.55, 1, 0.5, 0.2, 0.0), (0.7, 0.6, 0.3, 0.1, 0.3), (1.0, 0.1, 0.6, 0.7, 0.6)]
+
+    def as_type(v):
+        if dtype == np.uint8:
+            return v
+        if dtype == np.uint16:
+            return (v.astype(np.uint16) * 257).astype(np.uint16)
+        return (v.astype(np.float32) / np.float32(255.0)).astype(np.float32)
+
+    keys = [as_type(S.heterogeneous_volume(64, S.sequence_blob_center(t * 10, 32))) for t in range(3)]
+    kw = dict(light_travel_direction=(0.3, 0.5, -1.0), tf_points=tfp, incremental_threshold_percent=100.0)
+    if path == "launch by launch":
+        kw["fused"] = False
+    key_vols = [ctx.volume_create(v) for v in keys]
+    mixed_out = [ctx.volume_create(np.zeros_like(keys[0])) for _ in range(2)]   # the player's two output volumes, used in turn
+
+    def make(first):
+        m = P.CorrelatedPhotonMapper(ctx, first, S.tf_from_points(tfp), 128, (32, 32, 32), **{k: v for k, v in kw.items() if k != "fused"})
+        m.fused = kw.get("fused", True)
+        m.retrace_in_importance_pass = path == "one launch"
+        return m
+
+    lazy, eager = make(key_vols[0]), make(ctx.volume_create(keys[0]))
+    lazy.full_frame(); eager.full_frame()
+    assert np.array_equal(bits(_n(lazy.photons)), bits(_n(eager.photons)))
+    retraced = []
+    for k, (i, w) in enumerate([(0, 0.5), (1, 0.0), (1, 0.75), (1, 1.0)]):
+        out = mixed_out[k % 2]
+        ctx.volume_mix(key_vols[i], key_vols[i + 1], w, out)
+        fresh = ctx.volume_create(out.download())            # the same voxels, its copy in step
+        lazy.set_volume(out); eager.set_volume(fresh)
+        assert np.array_equal(bits(_n(lazy.importance_grid)), bits(_n(eager.importance_grid)))
+        n = lazy.correlated_update()
+        assert n == eager.correlated_update()
+        retraced.append(n)
+        assert np.array_equal(bits(_n(lazy.photons)), bits(_n(eager.photons)))
+        assert np.array_equal(_n(lazy.indices)[:n], _n(eager.indices)[:n])
+        a, b = _n(lazy.light_volume), _n(eager.light_volume)   # +- atomic splats: order-dependent sums
+        assert np.allclose(a, b, rtol=1e-4, atol=1e-5 * float(np.abs(a).max()))
+    assert any(0 < n < lazy.n for n in retraced), retraced
+    # a trace over all the samples through the stale copy re-derives it
+    lazy.full_frame(); eager.full_frame()
+    assert np.array_equal(bits(_n(lazy.photons)), bits(_n(eager.photons)))
+    assert np.array_equal(bits(_n(lazy.light_volume)), bits(_n(eager.light_volume)))
