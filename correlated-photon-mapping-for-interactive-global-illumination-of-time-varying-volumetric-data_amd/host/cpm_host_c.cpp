@@ -280,6 +280,29 @@ int cpmh_bench_tf_edits(cpmh_network* net, const float* tf_a5, int na, const flo
     return 0;
 }
 
+// The same edits with the host's clock read between the stages: stage_ms[5 r + k] = time since the edit when (0) the property is set,
+// (1) the importance processor, (2) the tracer, (3) the light-volume processor have returned, (4) the device is idle.
+int cpmh_bench_tf_edits_timeline(cpmh_network* net, const float* tf_a5, int na, const float* tf_b5, int nb, int reps, double* stage_ms) {
+    if (!net || !net->correlated || !stage_ms) return -1;
+    if (hipDeviceSynchronize() != hipSuccess) return -2;
+    for (int r = 0; r < reps; ++r) {
+        double* o = stage_ms + 5 * (size_t)r;
+        const double t0 = now_ms();
+        if (r % 2 == 0) cpmh_set_transfer_function(net, tf_a5, na);
+        else cpmh_set_transfer_function(net, tf_b5, nb);
+        o[0] = now_ms() - t0;
+        net->importance.process();
+        o[1] = now_ms() - t0;
+        net->tracer.process();
+        o[2] = now_ms() - t0;
+        net->lightVolume.process();
+        o[3] = now_ms() - t0;
+        if (hipDeviceSynchronize() != hipSuccess) return -2;
+        o[4] = now_ms() - t0;
+    }
+    return 0;
+}
+
 // `reps` full frames of the same network: everything invalidated (tracer: all photons; light volume: bin + gather).
 int cpmh_bench_full_frames(cpmh_network* net, int reps, double* out_ms) {
     if (!net) return -1;

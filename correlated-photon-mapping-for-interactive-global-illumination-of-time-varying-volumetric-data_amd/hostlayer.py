@@ -28,6 +28,7 @@ def load():
         "cpmh_last_tracer_decision": (C.c_char_p, [vp]),
         "cpmh_path_costs": (None, [vp, vp]),
         "cpmh_bench_tf_edits": (i32, [vp, vp, i32, vp, i32, i32, vp, vp]),
+        "cpmh_bench_tf_edits_timeline": (i32, [vp, vp, i32, vp, i32, i32, vp]),
         "cpmh_bench_full_frames": (i32, [vp, i32, vp]),
         "cpmh_bench_frames_back_to_back": (i32, [vp, i32, vp, vp]),
         "cpmh_profile_full_frames": (C.c_char_p, [vp, i32]),
@@ -97,6 +98,15 @@ class HostNetwork:
         if self.lib.cpmh_bench_tf_edits(self.h, a.ctypes.data, a.shape[0], b.ctypes.data, b.shape[0], reps, C.byref(ms), C.byref(n)) != 0:
             raise RuntimeError("cpmh_bench_tf_edits failed")
         return np.array(list(ms)), np.array(list(n))
+
+    def bench_tf_edits_timeline(self, points_a, points_b, reps):
+        """Host clock since the edit after: property set, importance, tracer, light volume returned, device idle -> (reps, 5) ms."""
+        a = np.ascontiguousarray(np.asarray(points_a, np.float32))
+        b = np.ascontiguousarray(np.asarray(points_b, np.float32))
+        ms = (C.c_double * (5 * reps))()
+        if self.lib.cpmh_bench_tf_edits_timeline(self.h, a.ctypes.data, a.shape[0], b.ctypes.data, b.shape[0], reps, C.byref(ms)) != 0:
+            raise RuntimeError("cpmh_bench_tf_edits_timeline failed")
+        return np.array(list(ms)).reshape(reps, 5)
 
     def bench_full_frames(self, reps):
         """Latency: every frame timed from an idle device until it is idle again."""
