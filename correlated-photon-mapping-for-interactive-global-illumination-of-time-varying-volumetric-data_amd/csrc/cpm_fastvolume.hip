@@ -86,16 +86,35 @@ __host__ int make_grid_dev_fast(cpm_ctx* ctx, const cpm_grid_desc* g, GridDev& G
     return CPM_OK;
 }
 
-// brick shape from the grid alone: 8 x 8 x 16 voxels; while there are more than 8 Ki bricks, doubled along the axis with the
-// most bricks (ties: x, then y, then z).
+// candidate voxels per axis for a radius (in texture units): floor(2 r') + 1 with r' = r * textureToIndex + 1e-3
+__host__ void candidates_per_axis(const GridDev& G, float radius, int mc[3]) {
+    const float r[3] = { radius * G.t2i.sx, radius * G.t2i.sy, radius * G.t2i.sz };  // radius in voxels per axis
+    for (int a = 0; a < 3; ++a) {
+        const float c = floorf(2.f * (r[a] + 1e-3f)) + 1.f;
+        mc[a] = c < 1.f ? 1 : (c > 1e6f ? 1000000 : (int)c);
+    }
+}
+
+// brick shape: 8 x 8 x 16 voxels; while there are more than 8 Ki bricks, doubled along the axis with the most bricks (ties: x,
+// then y, then z).
 // (Measured at config 2, 128^3: 4096 bricks of 8^3 -> 80.1 us per frame, 2048 of 16x8x8 -> 76.1, 2048 of 8x8x16 -> 74.9,
 // 1024 of 16x16x8 -> 81.0, 8192 of 8x4x8 -> 93.6: fewer bricks make the scans, the per-tile rows and the empty bricks
 // cheaper until the heaviest brick -- a serial chain of 1024-record batches in one workgroup -- takes over.)
-__host__ void brick_shape(const int dims[3], BrickLayout& L) {
+// A WIDE candidate box (more than 4 candidates along some axis, `mc` given) shapes the brick after itself: a photon is filed under
+// every brick its box touches, and a box 6 wide lies across the faces of an 8-wide brick most of the time -- the workspace's
+// 256 x 256 x 48 light volume (box 6 x 6 x 2) put 2.6 copies of every photon into 8 x 8 x 16 bricks.  Per axis 16 voxels where the
+// box has 5 or more candidates, 8 otherwise, and never more than 2048 voxels (a box wide along all three axes: 16 x 16 x 8):
+// 16 x 16 x 8 there (1.7 copies; frame 0.233 -> 0.193 ms; 16 x 16 x 4: 0.197, 16 x 8 x 8: 0.208, 32 x 16 x 4: 0.228, 32 x 32 x 4:
+// 0.293 -- larger bricks are heavier work items).
+__host__ void brick_shape(const int dims[3], BrickLayout& L, const int* mc = nullptr) {
 #ifndef CPM_BRICK_LG
 #define CPM_BRICK_LG 3, 3, 4
 #endif
     int lg[3] = { CPM_BRICK_LG };
+    if (mc && (mc[0] > 4 || mc[1] > 4 || mc[2] > 4)) {
+        for (int a = 0; a < 3; ++a) lg[a] = mc[a] >= 5 ? 4 : 3;
+        if (lg[0] + lg[1] + lg[2] > 11) lg[2] = 3;
+    }
     auto count = [&](int a) { return (dims[a] + (1 << lg[a]) - 1) >> lg[a]; };
     while ((long long)count(0) * count(1) * count(2) > kMaxBricks) {
         int axis = 0;
@@ -109,18 +128,21 @@ __host__ void brick_shape(const int dims[3], BrickLayout& L) {
     L.bvox = 1 << (lg[0] + lg[1] + lg[2]);
     L.maxc = L.mcx = L.mcy = L.mcz = 0;
 }
+// ... for a grid and a radius (what every entry point that knows the radius uses: count, scatter and gather agree by construction)
+__host__ void brick_shape_for(const GridDev& G, float radius, BrickLayout& L) {
+    const int dims[3] = { G.dx, G.dy, G.dz };
+    int mc[3];
+    candidates_per_axis(G, radius, mc);
+    brick_shape(dims, L, mc);
+}
 
 // candidates per axis from the radius; false when the kernels do not cover it: a candidate box must not span more than
 // two bricks per axis (it is at most as wide as a brick, or the brick spans the axis).  Up to 4 candidates per axis the
 // record loops are unrolled (fast_brick_kernel<2 / 3 / 4>); wider boxes take run-time loops over y and z (<6 / 8 / 14>).
 constexpr int kMaxCandidates = 8;
 __host__ bool brick_reach(const GridDev& G, float radius, BrickLayout& L) {
-    const float r[3] = { radius * G.t2i.sx, radius * G.t2i.sy, radius * G.t2i.sz };  // radius in voxels per axis
     int mc[3];
-    for (int a = 0; a < 3; ++a) {
-        const float c = floorf(2.f * (r[a] + 1e-3f)) + 1.f;
-        mc[a] = c < 1.f ? 1 : (c > 1e6f ? 1000000 : (int)c);
-    }
+    candidates_per_axis(G, radius, mc);
     L.mcx = mc[0]; L.mcy = mc[1]; L.mcz = mc[2];
     L.maxc = mc[0] > mc[1] ? (mc[0] > mc[2] ? mc[0] : mc[2]) : (mc[1] > mc[2] ? mc[1] : mc[2]);
     if (!(radius > 0.f) || L.maxc > kMaxCandidates) return false;
@@ -381,8 +403,10 @@ CPM_DEV void brick_record_wide(const GridDev& G, const BrickLayout& L, float4 a,
     const int sx = max(c.sx, ox), ex = min(c.ex, ox + BX - 1);
     const int sy = max(c.sy, oy), ey = min(c.ey, oy + BY - 1);
     const int sz = max(c.sz, oz), ez = min(c.ez, oz + BZ - 1);
-    const float pk = __builtin_fabsf(a.w) <= kFltMax ? a.w * k : 0.f;
-    const float pkg = __builtin_fabsf(pg) <= kFltMax ? pg * k : 0.f, pkb = __builtin_fabsf(pb) <= kFltMax ? pb * k : 0.f;
+    // value * S with S a power of two: (p k w) S and (p k S) w round the same real number scaled by 2^sh -- the same bits (a product
+    // small enough to be denormal truncates to 0 either way: S <= 2^100)
+    const float pk = __builtin_fabsf(a.w) <= kFltMax ? (a.w * k) * S : 0.f;
+    const float pkg = __builtin_fabsf(pg) <= kFltMax ? (pg * k) * S : 0.f, pkb = __builtin_fabsf(pb) <= kFltMax ? (pb * k) * S : 0.f;
     float dx2[WX];
 #pragma unroll
     for (int q = 0; q < WX; ++q) { const float d = fma_(G.i2t.sx, (float)(sx + q), G.i2t.tx) - a.x; dx2[q] = d * d; }
@@ -396,10 +420,10 @@ CPM_DEV void brick_record_wide(const GridDev& G, const BrickLayout& L, float4 a,
                 const float d2 = fma_(dz, dz, fma_(dy, dy, dx2[q]));   // the contract's operands: dx * dx, then the two fmas
                 if (sx + q > ex || !(d2 <= r2)) continue;
                 const float w = 0.75f * (1.0f - d2 * inv_r2);
-                atomicAdd(reinterpret_cast<unsigned long long*>(tile + row + q), to_fixed(pk * w, S));
+                atomicAdd(reinterpret_cast<unsigned long long*>(tile + row + q), (unsigned long long)(long long)(int)(pk * w));
                 if (CH == 4) {
-                    atomicAdd(reinterpret_cast<unsigned long long*>(tile + plane + row + q), to_fixed(pkg * w, S));
-                    atomicAdd(reinterpret_cast<unsigned long long*>(tile + 2 * plane + row + q), to_fixed(pkb * w, S));
+                    atomicAdd(reinterpret_cast<unsigned long long*>(tile + plane + row + q), (unsigned long long)(long long)(int)(pkg * w));
+                    atomicAdd(reinterpret_cast<unsigned long long*>(tile + 2 * plane + row + q), (unsigned long long)(long long)(int)(pkb * w));
                 }
             }
         }
@@ -584,9 +608,15 @@ extern "C" {
 
 size_t cpm_fast_table_entries(const cpm_grid_desc* grid, int n) {
     if (!grid || n < 0 || grid->dims[0] < 1 || grid->dims[1] < 1 || grid->dims[2] < 1) return 0;
-    BrickLayout L;
-    brick_shape(grid->dims, L);
-    return table_entries(L);
+    // (the radius is not known here: room for the brick shape of a narrow box and for those of wide ones)
+    size_t most = 0;
+    for (int w = 0; w < 8; ++w) {
+        const int mc[3] = { (w & 1) ? 5 : 1, (w & 2) ? 5 : 1, (w & 4) ? 5 : 1 };
+        BrickLayout L;
+        brick_shape(grid->dims, L, mc);
+        most = table_entries(L) > most ? table_entries(L) : most;
+    }
+    return most;
 }
 
 int cpm_gather_fast_supported(const cpm_grid_desc* grid, float radius) {
@@ -597,7 +627,7 @@ int cpm_gather_fast_supported(const cpm_grid_desc* grid, float radius) {
     if (!affine_from_matrix(grid->texture_to_index, G.t2i) || !affine_from_matrix(grid->index_to_texture, G.i2t)) return 0;
     if (!(G.t2i.sx > 0.f && G.t2i.sy > 0.f && G.t2i.sz > 0.f)) return 0;
     BrickLayout L;
-    brick_shape(grid->dims, L);
+    brick_shape_for(G, radius, L);
     if (!brick_reach(G, radius, L)) return 0;
     return tile_bytes_for(G, L) <= 160 * 1024 - 1024;
 }
@@ -608,7 +638,7 @@ size_t cpm_fast_record_capacity(const cpm_grid_desc* grid, int n, float radius) 
     G.dx = grid->dims[0]; G.dy = grid->dims[1]; G.dz = grid->dims[2]; G.channels = grid->channels;
     (void)affine_from_matrix(grid->texture_to_index, G.t2i); (void)affine_from_matrix(grid->index_to_texture, G.i2t);
     BrickLayout L;
-    brick_shape(grid->dims, L);
+    brick_shape_for(G, radius, L);
     (void)brick_reach(G, radius, L);
     return (size_t)n * (size_t)copies_per_photon(L);
 }
@@ -626,7 +656,7 @@ int cpm_bin_fast(cpm_ctx* ctx, const float* photons8, int n, const cpm_grid_desc
     CPM_REQUIRE_ALIGNED16(ctx, sorted_pos_power, "cpm_bin_fast");
     hipStream_t s = (hipStream_t)stream;
     BrickLayout L;
-    brick_shape(grid->dims, L);
+    brick_shape_for(G, radius, L);
     if (!brick_reach(G, radius, L) || tile_bytes_for(G, L) > 160 * 1024 - 1024)
         return set_error(ctx, CPM_ERR_UNSUPPORTED, "cpm_bin_fast", "radius beyond 3.5 voxels along some axis (or not positive): use cpm_bin + cpm_gather");
     CPM_REQUIRE(ctx, (long long)n * copies_per_photon(L) < (1ll << 32), "cpm_bin_fast: record positions are 32-bit (n * 8 must stay below 2^32)");
@@ -696,7 +726,7 @@ int cpm_gather_fast_marked(cpm_ctx* ctx, const float* sorted_pos_power, const ui
     CPM_REQUIRE_ALIGNED16(ctx, sorted_pos_power, "cpm_gather_fast");
     if (G.channels == 4) CPM_REQUIRE_ALIGNED16(ctx, grid_out, "cpm_gather_fast");
     BrickLayout L;
-    brick_shape(grid->dims, L);
+    brick_shape_for(G, radius, L);
     if (!brick_reach(G, radius, L))
         return set_error(ctx, CPM_ERR_UNSUPPORTED, "cpm_gather_fast", "radius beyond 3.5 voxels along some axis: use cpm_bin + cpm_gather");
     const size_t tile_bytes = tile_bytes_for(G, L);

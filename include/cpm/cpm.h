@@ -374,7 +374,8 @@ int cpm_gather_bricks(cpm_ctx* ctx, const float* sorted_pos_power, const uint32_
  * 0.75 * (1 - d^2 / r^2) for d^2 <= r^2 (no sqrt, no division -- ref cl/densityestimationkernel.cl:43-60 takes
  * x = d / r), and per-voxel sums are accumulated as 64-bit fixed-point integers, so they do not depend on any
  * order: the result is bitwise reproducible run to run although nothing is sorted inside a brick.
- * Photons are filed by BRICK (8x8x16 voxels; bigger for grids beyond 8 Ki bricks) with an unstable counting sort -- the
+ * Photons are filed by BRICK (8x8x16 voxels; 16 voxels along the axes where the candidate box has 5 or more voxels once it has more
+ * than 4 along some axis, at most 16x16x8; bigger for grids beyond 8 Ki bricks) with an unstable counting sort -- the
  * order of the records inside a brick is unspecified.  A photon whose candidate voxels (the integers within
  * r * textureToIndex + 1e-3 of its index-space coordinate, per axis, clipped to the grid) straddle a brick face is filed
  * under EVERY brick they lie in (at most 8; 0.3 % of the photons are filed twice at BASELINE config 2), so a brick's

@@ -52,9 +52,21 @@ def make_photons(rng, n, dims, *, sentinels=0.1, outside=0.02, cluster=None, neg
     return ph
 
 
-def brick_layout(dims):
-    """Bricks of 8 x 8 x 16 voxels; beyond 8 Ki of them doubled along the axis with the most bricks (cpm.h): (log2 sizes, counts)."""
+def candidates_per_axis(radius, grid):
+    """floor(2 r') + 1 with r' = r * textureToIndex + 1e-3, per axis."""
+    t2i = np.array(grid.texture_to_index, np.float32)
+    return [int(np.floor(np.float32(2.0) * np.float32(np.float32(radius) * t2i[5 * a] + np.float32(1e-3)))) + 1 for a in range(3)]
+
+
+def brick_layout(dims, mc=None):
+    """Bricks of 8 x 8 x 16 voxels -- for a candidate box wider than 4 along some axis (mc: candidates per axis) 16 voxels along the
+    axes with 5 or more candidates and 8 along the others, at most 2048 voxels; beyond 8 Ki of them doubled along the axis with the
+    most bricks (cpm.h): (log2 sizes, counts)."""
     lg = [3, 3, 4]
+    if mc is not None and max(mc) > 4:
+        lg = [4 if c >= 5 else 3 for c in mc]
+        if sum(lg) > 11:
+            lg[2] = 3
     cnt = lambda: [(d + (1 << l) - 1) >> l for d, l in zip(dims, lg)]
     while np.prod(cnt()) > 8192:
         c = cnt()
@@ -62,14 +74,14 @@ def brick_layout(dims):
     return lg, cnt()
 
 
-def brick_count(dims):
-    return int(np.prod(brick_layout(dims)[1]))
+def brick_count(dims, mc=None):
+    return int(np.prod(brick_layout(dims, mc)[1]))
 
 
 def expected_filing(ph, dims, radius, grid):
     """(photon index, brick) pairs cpm_bin_fast must file: every stored photon under every brick its candidate voxels
     (integers within r * textureToIndex + 1e-3 of the index-space coordinate, clipped to the grid) lie in."""
-    lg, nbk = brick_layout(dims)
+    lg, nbk = brick_layout(dims, candidates_per_axis(radius, grid))
     t2i = np.array(grid.texture_to_index, np.float32)
     pairs = []
     stored = np.where(ph[:, 0] != FLT_MAX)[0]
@@ -170,7 +182,7 @@ def test_fast_equals_restatement_and_reference_semantics(ctx, oracle, cpm, dims,
     # of a brick are exactly the photons filed under it (in no particular order)
     grid = cpm.binding.default_grid_desc(dims, channels)
     pairs = expected_filing(ph, dims, radius, grid)
-    nb = brick_count(dims)
+    nb = brick_count(dims, candidates_per_axis(radius, grid))
     total = len(pairs)
     assert table[0] == 0 and table[nb] == total and (np.diff(table[: nb + 1].astype(np.int64)) >= 0).all()
     assert total <= ctx.fast_record_capacity(grid, n, radius)
