@@ -99,3 +99,38 @@ def test_headers_are_plain_c_and_cxx(tmp_path):
         r = subprocess.run([cc, std, "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", str(repo / "include"), "-fsyntax-only", *extra, str(src)],
                            capture_output=True, text=True)
         assert r.returncode == 0, r.stderr
+
+
+def test_fast_formulation_sizing_is_host_arithmetic(cpm):
+    """cpm_fast_table_entries / cpm_gather_fast_supported / cpm_fast_record_capacity are pure host functions (what a caller sizes
+    its buffers with before any launch): the table has room for the brick shape of a narrow candidate box (8 x 8 x 16 voxels) and
+    for those a wide box chooses (16 voxels along axes with 5 or more candidates, at most 16 x 16 x 8); radii beyond 8 candidates
+    along an axis are refused; a photon is filed under at most 8 bricks."""
+    B = cpm.binding
+    lib = B.load_library()
+    import ctypes as C
+    lib.cpm_fast_table_entries.restype = C.c_size_t
+    lib.cpm_fast_record_capacity.restype = C.c_size_t
+
+    def bricks(dims, lg):
+        n = [(d + (1 << l) - 1) >> l for d, l in zip(dims, lg)]
+        while n[0] * n[1] * n[2] > 8192:
+            a = n.index(max(n))
+            lg = list(lg); lg[a] += 1
+            n = [(d + (1 << l) - 1) >> l for d, l in zip(dims, lg)]
+        return n[0] * n[1] * n[2]
+
+    for dims in ((128, 128, 128), (256, 256, 48), (256, 256, 256), (32, 32, 32), (24, 64, 64)):
+        g = B.default_grid_desc(dims, 1)
+        shapes = [(3, 3, 4)] + [tuple(4 if (w >> a) & 1 else 3 for a in range(3)) for w in range(1, 7)] + [(4, 4, 3)]
+        most = max(bricks(dims, s) for s in shapes)
+        assert lib.cpm_fast_table_entries(C.byref(g), 1000) == 2 * most + 5, dims
+        r1 = 1.0 / max(dims)                       # one voxel along the longest axis
+        assert lib.cpm_gather_fast_supported(C.byref(g), C.c_float(0.5 * r1)) == 1
+        assert lib.cpm_gather_fast_supported(C.byref(g), C.c_float(2.8 * r1)) == 1     # 6 candidates: the wide kernels
+        assert lib.cpm_gather_fast_supported(C.byref(g), C.c_float(4.6 * r1)) == 0     # 10 candidates: cpm_bin + cpm_gather
+        assert lib.cpm_gather_fast_supported(C.byref(g), C.c_float(0.0)) == 0
+        assert lib.cpm_fast_record_capacity(C.byref(g), 1000, C.c_float(2.8 * r1)) == 8000
+        assert lib.cpm_fast_record_capacity(C.byref(g), 1000, C.c_float(4.6 * r1)) == 0
+    g = B.default_grid_desc((400, 8, 16), 1)       # reach 1 along every axis: one record per photon
+    assert lib.cpm_fast_record_capacity(C.byref(g), 1000, C.c_float(0.4 / 400)) == 1000
