@@ -331,15 +331,26 @@ def main():
             ok, err = False, str(e)
         transport = None
         if agree(ok):
-            try:
-                transport = sharding.RcclTransport(ctx, rank, world, root=root)
-                probe = torch.ones(8, dtype=torch.float32, device=ctx.device)
-                transport.wait(transport.start(probe))
-                torch.cuda.synchronize()
-                ok = bool((probe == float(world)).all().item()) if (root is None or rank == root) else True
-                err = "" if ok else "probe all-reduce returned a wrong sum"
-            except Exception as e:  # noqa: BLE001
-                ok, err = False, str(e)
+            # (in a thread that is given two minutes: a communicator setup that never returns on some rank must not take the run with
+            # it -- that rank reports failure, every rank falls back; RCCL with more than one rank has never run on this build's boxes)
+            import threading
+            box = {}
+
+            def setup():
+                try:
+                    tr = sharding.RcclTransport(ctx, rank, world, root=root)
+                    probe = torch.ones(8, dtype=torch.float32, device=ctx.device)
+                    tr.wait(tr.start(probe))
+                    torch.cuda.synchronize()
+                    good = bool((probe == float(world)).all().item()) if (root is None or rank == root) else True
+                    box["result"] = (tr if good else None, "" if good else "probe all-reduce returned a wrong sum")
+                except Exception as e:  # noqa: BLE001
+                    box["result"] = (None, str(e))
+            th = threading.Thread(target=setup, daemon=True)
+            th.start()
+            th.join(float(os.environ.get("CPM_BENCH_RCCL_SETUP_TIMEOUT", "120")))
+            transport, err = box.get("result", (None, "communicator setup did not return in time"))
+            ok = transport is not None
             if not agree(ok):
                 transport = None
         if transport is None:
