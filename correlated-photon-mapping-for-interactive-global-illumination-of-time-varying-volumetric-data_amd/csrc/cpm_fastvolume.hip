@@ -485,8 +485,11 @@ constexpr int kMaxSubBricks = 512;  // 4x4x4 sub-bricks of a brick (a tile of <=
 template <int MAXC, int CH>
 __global__ __launch_bounds__(kBrickThreads, (CH == 4 ? 4 : CPM_BRICK_WAVES)) void fast_brick_kernel(const float* __restrict__ sorted, const uint32_t* __restrict__ table, GridDev G,
                                                                   BrickLayout L, float radius, float k, int accumulate, float* __restrict__ out,
-                                                                  uint8_t* __restrict__ marks) {
+                                                                  uint8_t* __restrict__ marks, int repl_arg) {
     extern __shared__ long long s_tile[];
+    // REPL copies of the brick's tile, lane l adds into copy l mod REPL: neighbouring lanes hold neighbouring photons, whose adds meet in
+    // the same voxels -- same-address LDS atomics of one instruction are served one after the other
+    const int repl = repl_arg;
     // marks (nullable): one byte per 4x4x4-voxel brick of the grid (cpm_mark_touched_bricks' numbering), 1 where this launch
     // leaves a non-zero value, 0 elsewhere -- every byte written: what cpm_allreduce_grid_sparse would otherwise read the whole
     // volume again for
@@ -544,7 +547,8 @@ __global__ __launch_bounds__(kBrickThreads, (CH == 4 ? 4 : CPM_BRICK_WAVES)) voi
             }
         };
         fetch(j0, a, a2);
-        for (int w = t; w < words; w += kBrickThreads) s_tile[w] = 0ll;
+        for (int w = t; w < words * repl; w += kBrickThreads) s_tile[w] = 0ll;
+        long long* my_tile = s_tile + (size_t)(t & (repl - 1)) * (size_t)words;
         const int nsub = L.bvox >> 6;
         if (marks) for (int w = t; w < nsub; w += kBrickThreads) s_flag[w] = 0;  // (the lane that read flag w for the brick before)
         __syncthreads();
@@ -556,8 +560,8 @@ __global__ __launch_bounds__(kBrickThreads, (CH == 4 ? 4 : CPM_BRICK_WAVES)) voi
                 if (j < j1) {
                     // MAXC <= 4: a box of at most MAXC^3 candidates, all loops unrolled; MAXC = 6 / 8 / 14 (= x width 4): wide or anisotropic
                     // boxes -- y and z at run time, x unrolled for 6 / 8 / 4 candidates
-                    if (MAXC > 4) brick_record_wide<CH, (MAXC == 14 ? 4 : MAXC)>(G, L, a[q], a2[q].x, a2[q].y, ox, oy, oz, BX, BY, BZ, rgx, rgy, rgz, r2, inv_r2, k, S, s_tile, L.bvox);
-                    else brick_record<(MAXC > 4 ? 1 : MAXC), CH>(G, a[q], a2[q].x, a2[q].y, ox, oy, oz, BX, BY, BZ, rgx, rgy, rgz, r2, inv_r2, k, S, s_tile, L.bvox);
+                    if (MAXC > 4) brick_record_wide<CH, (MAXC == 14 ? 4 : MAXC)>(G, L, a[q], a2[q].x, a2[q].y, ox, oy, oz, BX, BY, BZ, rgx, rgy, rgz, r2, inv_r2, k, S, my_tile, L.bvox);
+                    else brick_record<(MAXC > 4 ? 1 : MAXC), CH>(G, a[q], a2[q].x, a2[q].y, ox, oy, oz, BX, BY, BZ, rgx, rgy, rgz, r2, inv_r2, k, S, my_tile, L.bvox);
                 }
             }
 #pragma unroll
@@ -569,12 +573,16 @@ __global__ __launch_bounds__(kBrickThreads, (CH == 4 ? 4 : CPM_BRICK_WAVES)) voi
             const int gx = ox + lx, gy = oy + ly, gz = oz + lz;
             if (gx >= G.dx || gy >= G.dy || gz >= G.dz) continue;
             const size_t o = (size_t)gx + (size_t)G.dx * ((size_t)gy + (size_t)G.dy * (size_t)gz);
-            const float fr = (float)s_tile[v] * invS;
+            long long sum_r = s_tile[v];
+            for (int c = 1; c < repl; ++c) sum_r += s_tile[(size_t)c * words + v];
+            const float fr = (float)sum_r * invS;
             bool nonzero = fr != 0.f;
             if (CH == 1) {
                 out[o] = accumulate ? out[o] + fr : fr;
             } else {
-                const float fg = (float)s_tile[L.bvox + v] * invS, fb = (float)s_tile[2 * L.bvox + v] * invS;
+                long long sum_g = s_tile[L.bvox + v], sum_b = s_tile[2 * L.bvox + v];
+                for (int c = 1; c < repl; ++c) { sum_g += s_tile[(size_t)c * words + L.bvox + v]; sum_b += s_tile[(size_t)c * words + 2 * L.bvox + v]; }
+                const float fg = (float)sum_g * invS, fb = (float)sum_b * invS;
                 nonzero = nonzero || fg != 0.f || fb != 0.f;
                 float4* q = reinterpret_cast<float4*>(out) + o;
                 if (accumulate) { const float4 tt = *q; *q = make_float4(tt.x + fr, tt.y + fg, tt.z + fb, tt.w); }
@@ -729,12 +737,22 @@ int cpm_gather_fast_marked(cpm_ctx* ctx, const float* sorted_pos_power, const ui
     brick_shape_for(G, radius, L);
     if (!brick_reach(G, radius, L))
         return set_error(ctx, CPM_ERR_UNSUPPORTED, "cpm_gather_fast", "radius beyond 3.5 voxels along some axis: use cpm_bin + cpm_gather");
-    const size_t tile_bytes = tile_bytes_for(G, L);
+    size_t tile_bytes = tile_bytes_for(G, L);
     if (tile_bytes > 160 * 1024 - 1024 || (L.bvox >> 6) > kMaxSubBricks)
         return set_error(ctx, CPM_ERR_UNSUPPORTED, "cpm_gather_fast", "brick does not fit the LDS: use cpm_bin + cpm_gather");
     // the records were filed for ONE radius (a wider one would need copies the bin did not make)
     if (ctx->fast_last_table == brick_table && ctx->fast_last_radius != radius)
         return set_error(ctx, CPM_ERR_INVALID_ARGUMENT, "cpm_gather_fast", "radius differs from the one given to cpm_bin_fast for this table");
+    // copies of the tile (see the kernel) for the wide boxes, whose records add 16 values each into a brick that many of them share: as
+    // many (a power of two, at most CPM_BRICK_REPL) as leave two workgroups per CU their LDS.  Measured at the workspace point: frame
+    // 0.191 ms with one copy, 0.1815 with two, 0.180 with four; the narrow boxes' launches are not bound by these conflicts (config 4's
+    // size: 56.9 / 57.5 / 58.5 us with 1 / 2 / 4 copies -- the extra tiles to clear and sum cost more) and keep one.
+#ifndef CPM_BRICK_REPL
+#define CPM_BRICK_REPL 4
+#endif
+    int repl = 1;
+    while (L.maxc > 4 && repl * 2 <= CPM_BRICK_REPL && tile_bytes * (size_t)(repl * 2) <= 72 * 1024) repl *= 2;
+    tile_bytes *= (size_t)repl;
     const float k = kInv4Pi * scale;
     hipStream_t s = (hipStream_t)stream;
     // resident workgroups: two of 1024 threads per CU, fewer when there are fewer bricks
@@ -745,7 +763,7 @@ int cpm_gather_fast_marked(cpm_ctx* ctx, const float* sorted_pos_power, const ui
         rc = allow_lds(ctx, fast_brick_kernel<MAXC, CH>, tile_bytes);                                                    \
         if (rc) return rc;                                                                                               \
         CPM_LAUNCH(ctx, (fast_brick_kernel<MAXC, CH>), bgrid, dim3(kBrickThreads), tile_bytes, s, sorted_pos_power, brick_table, G, L,  \
-                   radius, k, accumulate, grid_out, nonzero_bricks);                                                     \
+                   radius, k, accumulate, grid_out, nonzero_bricks, repl);                                               \
     } while (0)
     // the wide variants by the box's width along x (what their inner loop is unrolled for): 14 = 4, 6, 8
     const int wide = L.mcx <= 4 ? 14 : (L.mcx <= 6 ? 6 : 8);

@@ -1,0 +1,5 @@
+# usage: tools/ws_variants.sh variant...  -- the workspace point (tools/workspace_only.py) under builds of build/variants/ (LD_PRELOAD: the host layer links libcpm_hip.so)
+for v in "" "$@"; do
+  echo "== ${v:-product}"
+  if [ -n "$v" ]; then LD_PRELOAD=$PWD/build/variants/$v.so python tools/workspace_only.py 100 2>&1 | grep -v amdgpu.ids; else python tools/workspace_only.py 100 2>&1 | grep -v amdgpu.ids; fi
+done
