@@ -81,7 +81,7 @@ struct cpm_volume {
     // z' likewise, x fastest -- the 2 x 2 x 2 footprint of a trilinear fetch is ONE load of two neighbouring elements
     // (cpm_trace.hip); 4 * bytes + 64, rebuilt by everything that writes `voxels` (cpm_volume_update, cpm_volume_mix)
     void* quads = nullptr;
-    // cpm_volume_mix leaves the copy to whoever needs it: a trace over all the samples rebuilds it first (build_quads_if_stale),
+    // cpm_volume_mix leaves the copy to whoever needs it: a trace over all the samples rebuilds it first (cpm::trace_volume_source),
     // re-traces of selected photons read the linear block instead (four fetches per sample instead of one, for a few thousand
     // photons) -- a time step of a played sequence that is served by a correlated update never pays the 17 us re-layout
     mutable bool quads_stale = false;

@@ -331,7 +331,7 @@ def test_emitted_trace_refusals(ctx, cpm):
 def test_trace_reads_what_every_volume_writer_left(ctx, oracle, cpm, shape, how):
     """The tracer samples the volume's footprint copy (one fetch = the 2 x 2 x 2 neighbourhood); every writer of a volume --
     create, update from the host or from the device (one fused launch, or copy + re-layout for a source that is not
-    4-byte aligned), volume_mix -- rebuilds it, for row lengths on and off the 16-byte path and for one-row / one-slice
+    4-byte aligned) -- rebuilds it, volume_mix leaves that to the trace that follows, for row lengths on and off the 16-byte path and for one-row / one-slice
     volumes (the y + 1 / z + 1 clamps)."""
     torch = ctx.torch
     rng = np.random.default_rng(sum(shape) + len(how))

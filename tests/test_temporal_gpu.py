@@ -95,8 +95,8 @@ def test_mix_errors(ctx, cpm):
 
 @pytest.mark.parametrize("shape,dtype", [((32, 32, 32), np.uint8), ((24, 20, 16), np.uint16), ((12, 16, 20), np.float32), ((9, 7, 11), np.uint8)])
 def test_volume_mix_leaves_the_tracers_copy_in_step(ctx, oracle, cpm, shape, dtype):
-    """cpm_volume_mix also rebuilds the footprint-ordered copy the tracer reads (one launch with the mix where a row is a whole number
-    of 4-byte words, mix + re-layout otherwise): a trace through the mixed volume gives the photons of a trace through a volume
+    """cpm_volume_mix marks the footprint-ordered copy the tracer reads as stale and the next trace over all the samples re-derives it
+    (row lengths on and off the 4-byte grid): a trace through the mixed volume gives the photons of a trace through a volume
     created from the mixed voxels."""
     S, P = cpm.synthetic, cpm.pipeline
     rng = np.random.default_rng(sum(shape) + 1)
