@@ -30,7 +30,7 @@ ABI_SYMBOLS = [
     "cpm_tf_create", "cpm_tf_update", "cpm_tf_destroy",
     "cpm_uniform_samples_2d", "cpm_directional_light_samples", "cpm_point_light_samples",
     "cpm_light_sample_box_intersection", "cpm_light_sample_mesh_intersection",
-    "cpm_trace", "cpm_trace_emitted",
+    "cpm_trace", "cpm_trace_lights", "cpm_trace_lights_order_samples", "cpm_trace_emitted",
     "cpm_trace_order_create", "cpm_trace_order_destroy", "cpm_trace_set_order", "cpm_trace_order_update",
     "cpm_grid_desc_default", "cpm_relative_irradiance_scale",
     "cpm_splat", "cpm_splat_selected", "cpm_copy_indexed_photons", "cpm_snapshot_selected_photons",
@@ -131,6 +131,11 @@ class TraceParams(C.Structure):
                 ("iteration", C.c_int32), ("batch", C.c_int32)]
 
 
+class LightSpan(C.Structure):
+    """cpm_light_span: one light of a cpm_trace_lights launch."""
+    _fields_ = [("light_samples8", C.c_void_p), ("isect2", C.c_void_p), ("n_light_samples", C.c_int32), ("photon_offset", C.c_int32)]
+
+
 CPM_EMIT_DIRECTIONAL, CPM_EMIT_POINT = 0, 1
 
 
@@ -205,6 +210,8 @@ def load_library() -> C.CDLL:
         "cpm_light_sample_box_intersection": (i32, [vp, vp, i32, P(f32 * 8), vp, vp]),
         "cpm_light_sample_mesh_intersection": (i32, [vp, vp, vp, i32, vp, i32, vp, vp]),
         "cpm_trace": (i32, [vp, vp, vp, vp, P(f32 * 8), P(TraceParams), vp, vp, vp, i32, vp, vp, vp]),
+        "cpm_trace_lights": (i32, [vp, vp, vp, vp, P(f32 * 8), P(TraceParams), vp, i32, vp, vp, vp]),
+        "cpm_trace_lights_order_samples": (i32, [vp, i32]),
         "cpm_trace_emitted": (i32, [vp, vp, vp, vp, P(f32 * 8), P(TraceParams), P(EmitterDesc), vp, i32, vp, vp, vp]),
         "cpm_grid_desc_default": (None, [P(GridDesc), P(i32 * 3), i32]),
         "cpm_relative_irradiance_scale": (f32, [C.c_double, C.c_double]),
@@ -490,6 +497,24 @@ class Context:
             self.h, vol.h, tf.h, tf_scattering.h if tf_scattering is not None else None,
             C.byref((C.c_float * 8)(*aabb)), C.byref(params), self._ptr(light_samples), self._ptr(isect),
             self._ptr(recompute_indices), n_recompute, self._ptr(rng_state), self._ptr(photons), self._stream()))
+
+    def light_spans(self, lights):
+        """lights: [(light_samples, isect, n_light_samples, photon_offset), ...] -> a cpm_light_span array."""
+        arr = (LightSpan * len(lights))()
+        for a, (ls, isect, n, off) in zip(arr, lights):
+            a.light_samples8, a.isect2, a.n_light_samples, a.photon_offset = self._ptr(ls), self._ptr(isect), n, off
+        return arr
+
+    def trace_lights_order_samples(self, spans) -> int:
+        """The number of samples a cpm_trace_order for a cpm_trace_lights launch over `spans` is created for."""
+        return int(self.lib.cpm_trace_lights_order_samples(C.cast(spans, C.c_void_p), len(spans)))
+
+    def trace_lights(self, vol, tf, aabb, params: TraceParams, spans, rng_state, photons, tf_scattering=None):
+        """cpm_trace for several lights in one launch (spans: light_spans(...))."""
+        self._check(self.lib.cpm_trace_lights(
+            self.h, vol.h, tf.h, tf_scattering.h if tf_scattering is not None else None,
+            C.byref((C.c_float * 8)(*aabb)), C.byref(params), C.cast(spans, C.c_void_p), len(spans), self._ptr(rng_state), self._ptr(photons),
+            self._stream()))
 
     def trace_emitted(self, vol, tf, aabb, params: TraceParams, emitter: EmitterDesc, rng_state, photons,
                       recompute_indices=None, n_recompute=0, tf_scattering=None):

@@ -45,8 +45,11 @@ CPM_DEV int default_chunk(int b, unsigned n_chunks) {
 
 // LINEAR: the volume's footprint copy is stale (cpm_volume_mix) and this launch re-traces selected photons: four x-pair fetches of
 // the linear block per sample instead of one (cpm::trace_volume_source); same voxels, same lerps, same bits.
-template <int DT, int EMIT, bool SINGLE = false, bool LINEAR = false>
-__global__ __launch_bounds__(256, 8) void trace_kernel(const TraceArgs A) {
+// MULTI: the samples of several lights (cpm_trace_lights): the workgroup's chunk says whose -- that light's buffers, count and photon
+// offset stand in for the launch's.
+template <int DT, int EMIT, bool SINGLE = false, bool LINEAR = false, bool MULTI = false>
+__global__ __launch_bounds__(256, 8) void trace_kernel(const TraceArgs A0) {
+    TraceArgs A = A0;
     extern __shared__ float lds[];
     // One decoded / re-encoded direction per workgroup: a directional light gives every sample the same (theta, phi),
     // and decodeDirection + encodeDirection (two sincos, acos, atan2, a division: ~200 instructions) is a pure function of
@@ -68,7 +71,18 @@ __global__ __launch_bounds__(256, 8) void trace_kernel(const TraceArgs A) {
     int chunk = blockIdx.x;
     if (A.chunk_order) chunk = (int)A.chunk_order[blockIdx.x];
     else chunk = default_chunk(chunk, gridDim.x);
-    const int gid = chunk * blockDim.x + threadIdx.x;
+    int local_chunk = chunk;  // ... within its light
+    if (MULTI) {  // (uniform)
+        int sp = 0;
+        while (sp + 1 < A0.n_spans && chunk >= A0.span[sp + 1].chunk_base) ++sp;
+        local_chunk = chunk - A0.span[sp].chunk_base;
+        A.light_samples = A0.span[sp].light_samples;
+        A.isect = A0.span[sp].isect;
+        A.n_threads = A0.span[sp].n;
+        A.p.n_light_samples = A0.span[sp].n;
+        A.p.photon_offset = A0.span[sp].photon_offset;
+    }
+    const int gid = local_chunk * (int)blockDim.x + (int)threadIdx.x;
     int threadId = gid;
     int nThreads = A.n_threads;
     if (A.n_threads_dev) {  // cpm_trace_selected: the launch covers the budget, the count says how much of it is work
@@ -251,6 +265,9 @@ struct SelectedArgs {  // cpm_trace_selected's extras
     const int32_t* n_dev = nullptr;
     float* old_photons = nullptr;
     uint32_t* reset_importances = nullptr;
+    // cpm_trace_lights' extras: the lights of the launch (light_samples8 / isect2 / params' offset and count are then unused)
+    const cpm_light_span* lights = nullptr;
+    int n_lights = 0;
 };
 
 int trace_impl(cpm_ctx* ctx, const cpm_volume* vol, const cpm_tf* tf, const cpm_tf* tf_scattering, const float aabb[8],
@@ -267,11 +284,26 @@ int trace_impl(cpm_ctx* ctx, const cpm_volume* vol, const cpm_tf* tf, const cpm_
     CPM_REQUIRE(ctx, n_recompute >= 0, "cpm_trace: n_recompute < 0");
     if (tf_scattering) CPM_REQUIRE(ctx, tf_scattering->width == tf->width, "cpm_trace: tf widths differ");
     int n_threads = recompute_indices ? n_recompute : p.n_light_samples;
+    if (sel.lights) {  // the launch's chunks: every light's samples rounded up to whole chunks
+        long long chunks = 0;
+        for (int l = 0; l < sel.n_lights; ++l) chunks += div_up(sel.lights[l].n_light_samples, 256);
+        CPM_REQUIRE(ctx, chunks * 256 < (1ll << 31), "cpm_trace_lights: too many samples");
+        n_threads = (int)(chunks * 256);
+    }
     if (n_threads == 0) return CPM_OK;
     CPM_REQUIRE(ctx, rng_state && photons8, "cpm_trace: null buffer");
     CPM_REQUIRE_ALIGNED16(ctx, photons8, "cpm_trace");
     CPM_REQUIRE(ctx, (reinterpret_cast<uintptr_t>(rng_state) & 7u) == 0, "cpm_trace: rng_state must be 8-byte aligned");
-    if (!emitter) {
+    if (sel.lights) {
+        for (int l = 0; l < sel.n_lights; ++l) {
+            const cpm_light_span& L = sel.lights[l];
+            CPM_REQUIRE(ctx, L.n_light_samples >= 0 && L.photon_offset >= 0 && (long long)L.photon_offset + L.n_light_samples <= (long long)p.total_photons,
+                        "cpm_trace_lights: a light's photon_offset + n_light_samples exceeds total_photons");
+            CPM_REQUIRE(ctx, L.n_light_samples == 0 || (L.light_samples8 && L.isect2), "cpm_trace_lights: null buffer");
+            CPM_REQUIRE_ALIGNED16(ctx, L.light_samples8, "cpm_trace_lights");
+            CPM_REQUIRE(ctx, (reinterpret_cast<uintptr_t>(L.isect2) & 7u) == 0, "cpm_trace_lights: isect2 must be 8-byte aligned");
+        }
+    } else if (!emitter) {
         CPM_REQUIRE(ctx, light_samples8 && isect2, "cpm_trace: null buffer");
         CPM_REQUIRE_ALIGNED16(ctx, light_samples8, "cpm_trace");
         CPM_REQUIRE(ctx, (reinterpret_cast<uintptr_t>(isect2) & 7u) == 0, "cpm_trace: isect2 must be 8-byte aligned");
@@ -298,6 +330,14 @@ int trace_impl(cpm_ctx* ctx, const cpm_volume* vol, const cpm_tf* tf, const cpm_
     if (sel.old_photons) CPM_REQUIRE_ALIGNED16(ctx, sel.old_photons, "cpm_trace_selected");
     A.rng = rng_state;
     A.photons = photons8;
+    if (sel.lights) {
+        A.n_spans = sel.n_lights;
+        int base = 0;
+        for (int l = 0; l < sel.n_lights; ++l) {
+            A.span[l] = { sel.lights[l].light_samples8, sel.lights[l].isect2, sel.lights[l].n_light_samples, sel.lights[l].photon_offset, base };
+            base += div_up(sel.lights[l].n_light_samples, 256);
+        }
+    }
 
     hipStream_t s = (hipStream_t)stream;
     // a stale footprint copy (the volume is cpm_volume_mix's output): a launch over selected photons whose number is on the device,
@@ -348,11 +388,24 @@ int trace_impl(cpm_ctx* ctx, const cpm_volume* vol, const cpm_tf* tf, const cpm_
         else if (emit == EMIT_DIRECTIONAL) CPM_TRACE_LAUNCH_E(DT, EMIT_DIRECTIONAL); \
         else CPM_TRACE_LAUNCH_E(DT, EMIT_POINT);                              \
     } while (0)
+#define CPM_TRACE_LAUNCH_MULTI(DT)                                                                                         \
+    do {                                                                                                                   \
+        if (single) CPM_LAUNCH(ctx, (trace_kernel<DT, EMIT_NONE, true, false, true>), grid, block, lds, s, A);            \
+        else CPM_LAUNCH(ctx, (trace_kernel<DT, EMIT_NONE, false, false, true>), grid, block, lds, s, A);                  \
+    } while (0)
+    if (sel.lights) {
+        switch (d.dtype) {
+            case CPM_U8: CPM_TRACE_LAUNCH_MULTI(CPM_U8); break;
+            case CPM_U16: CPM_TRACE_LAUNCH_MULTI(CPM_U16); break;
+            default: CPM_TRACE_LAUNCH_MULTI(CPM_F32); break;
+        }
+    } else
     switch (d.dtype) {
         case CPM_U8: CPM_TRACE_LAUNCH(CPM_U8); break;
         case CPM_U16: CPM_TRACE_LAUNCH(CPM_U16); break;
         default: CPM_TRACE_LAUNCH(CPM_F32); break;
     }
+#undef CPM_TRACE_LAUNCH_MULTI
 #undef CPM_TRACE_LAUNCH
 #undef CPM_TRACE_LAUNCH_E
     CPM_LAUNCH_CHECK(ctx, "trace_kernel");
@@ -551,6 +604,27 @@ int cpm_trace(cpm_ctx* ctx, const cpm_volume* vol, const cpm_tf* tf, const cpm_t
               cpm_stream stream) {
     return trace_impl(ctx, vol, tf, tf_scattering, aabb, params, light_samples8, isect2, nullptr, recompute_indices, n_recompute,
                       rng_state, photons8, stream);
+}
+
+int cpm_trace_lights_order_samples(const cpm_light_span* lights, int n_lights) {
+    long long chunks = 0;
+    for (int l = 0; lights && l < n_lights; ++l) chunks += lights[l].n_light_samples > 0 ? div_up(lights[l].n_light_samples, 256) : 0;
+    return chunks * 256 < (1ll << 31) ? (int)(chunks * 256) : 0;
+}
+
+int cpm_trace_lights(cpm_ctx* ctx, const cpm_volume* vol, const cpm_tf* tf, const cpm_tf* tf_scattering, const float aabb[8],
+                     const cpm_trace_params* params, const cpm_light_span* lights, int n_lights, uint32_t* rng_state, float* photons8,
+                     cpm_stream stream) {
+    if (ctx && !(lights && n_lights >= 1 && n_lights <= CPM_MAX_TRACE_LIGHTS))
+        return set_error(ctx, CPM_ERR_INVALID_ARGUMENT, "cpm_trace_lights", "1 .. CPM_MAX_TRACE_LIGHTS lights");
+    if (ctx && !params) return set_error(ctx, CPM_ERR_INVALID_ARGUMENT, "cpm_trace_lights", "null params");
+    cpm_trace_params p = *params;   // (the per-light fields come from the spans)
+    p.photon_offset = 0;
+    p.n_light_samples = 0;
+    SelectedArgs sel;
+    sel.lights = lights;
+    sel.n_lights = n_lights;
+    return trace_impl(ctx, vol, tf, tf_scattering, aabb, &p, nullptr, nullptr, nullptr, nullptr, 0, rng_state, photons8, stream, sel);
 }
 
 int cpm_trace_selected(cpm_ctx* ctx, const cpm_volume* vol, const cpm_tf* tf, const cpm_tf* tf_scattering, const float aabb[8],

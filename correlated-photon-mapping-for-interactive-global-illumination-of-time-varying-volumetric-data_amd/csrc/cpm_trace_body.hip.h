@@ -48,6 +48,10 @@ struct TraceArgs {
     Light light;
     float lattice_x, lattice_y;
     int first_sample;
+    // cpm_trace_lights: several lights' samples in one launch -- chunk c belongs to the span with chunk_base <= c < the next one's
+    struct Span { const float* light_samples; const float* isect; int n, photon_offset, chunk_base; };
+    int n_spans;
+    Span span[CPM_MAX_TRACE_LIGHTS];
 };
 
 enum { EMIT_NONE = 0, EMIT_DIRECTIONAL = 1, EMIT_POINT = 2 };

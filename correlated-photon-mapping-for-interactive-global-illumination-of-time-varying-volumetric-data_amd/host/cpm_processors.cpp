@@ -309,6 +309,7 @@ PhotonTracerCL::~PhotonTracerCL() {
     auto& rt = CpmRuntime::get();
     if (tf_) cpm_tf_destroy(rt.ctx(), tf_);
     for (auto& lo : launchOrders_) if (lo.second.order) cpm_trace_order_destroy(rt.ctx(), lo.second.order);
+    if (allLightsOrder_.order) cpm_trace_order_destroy(rt.ctx(), allLightsOrder_.order);
 }
 void PhotonTracerCL::setRandomSeedSize(size_t nPhotons) {
     if (nPhotons > 0) {
@@ -334,6 +335,7 @@ void PhotonTracerCL::syncTF(const TransferFunction& tf) {
     else rt.check(cpm_tf_update(rt.ctx(), tf_, lut.data(), 0, rt.stream()), "cpm_tf_update");
     tfLut_ = std::move(lut);
     for (auto& lo : launchOrders_) lo.second.stale = true;  // what the launches cost may have changed
+    allLightsOrder_.stale = true;
 }
 void PhotonTracerCL::tracePhotons(const Volume* volume, const TransferFunction& transferFunction, const float aabb[8],
                                   const AdvancedMaterialProperty& material, float stepSize, const LightSamples* lightSamples,
@@ -398,6 +400,64 @@ void PhotonTracerCL::tracePhotons(const Volume* volume, const TransferFunction& 
         }
         ++lo->sinceMeasured;
     }
+}
+
+bool PhotonTracerCL::tracePhotonsAllLights(const Volume* volume, const TransferFunction& transferFunction, const float aabb[8],
+                                           const AdvancedMaterialProperty& material, float stepSize, const std::vector<const LightSamples*>& lights,
+                                           int maxInteractions, PhotonData* photonOutData) {
+    auto& rt = CpmRuntime::get();
+    if (!rt.valid() || lights.size() < 2 || lights.size() > (size_t)CPM_MAX_TRACE_LIGHTS) return false;
+    if (randomState_.getSize() != photonOutData->getNumberOfPhotons()) setRandomSeedSize(photonOutData->getNumberOfPhotons());
+    cpm_volume* vol_ = volume->getDeviceRepresentation();
+    syncTF(transferFunction);
+    if (!vol_ || !tf_) return false;
+    cpm_trace_params p = {};
+    const vec4 m = material.getCombinedMaterialParameters();
+    p.material[0] = m.x; p.material[1] = m.y; p.material[2] = m.z; p.material[3] = m.w;
+    p.step_size = stepSize;
+    p.max_interactions = maxInteractions;
+    p.total_photons = (int)photonOutData->getNumberOfPhotons();
+    p.shading_type = material.getPhaseFunctionEnum();
+    p.flags = (onlyMultipleScattering_ ? CPM_TRACE_NO_SINGLE_SCATTERING : 0) | (progressive_ ? CPM_TRACE_PROGRESSIVE : 0);
+    p.iteration = photonOutData->iteration();
+    cpm_light_span spans[CPM_MAX_TRACE_LIGHTS];
+    int offset = 0;
+    for (size_t l = 0; l < lights.size(); ++l) {
+        spans[l].light_samples8 = reinterpret_cast<const float*>(lights[l]->getLightSamples()->device());
+        spans[l].isect2 = reinterpret_cast<const float*>(lights[l]->getIntersectionPoints()->device());
+        spans[l].n_light_samples = (int)lights[l]->getSize();
+        spans[l].photon_offset = offset;
+        offset += (int)lights[l]->getSize();
+    }
+    // the launch's chunks in the order of their measured costs, as for a light's own launch (tracePhotons)
+    LaunchOrder* lo = nullptr;
+    bool measure = false;
+    const int orderSamples = cpm_trace_lights_order_samples(spans, (int)lights.size());
+    if (adaptiveLaunchOrder_ && orderSamples > 0) {
+        lo = &allLightsOrder_;
+        if (lo->order && (lo->n != orderSamples || allLightsOrderFor_ != lights)) { cpm_trace_order_destroy(rt.ctx(), lo->order); *lo = LaunchOrder(); }
+        if (!lo->order) {
+            if (!rt.check(cpm_trace_order_create(rt.ctx(), orderSamples, &lo->order), "cpm_trace_order_create")) lo = nullptr;
+            else { lo->n = orderSamples; lo->sinceMeasured = 0; allLightsOrderFor_ = lights; }
+        }
+        if (lo) {
+            if (lo->volume != (const void*)vol_) { lo->volume = vol_; lo->stale = true; }
+            measure = lo->sinceMeasured == 0 || lo->sinceMeasured >= kMeasureEvery || (lo->stale && lo->sinceMeasured >= kMeasureAtLeastApart);
+            cpm_trace_set_order(rt.ctx(), lo->order, measure ? 1 : 0);
+        }
+    }
+    const bool ok = rt.check(cpm_trace_lights(rt.ctx(), vol_, tf_, nullptr, aabb, &p, spans, (int)lights.size(), reinterpret_cast<uint32_t*>(randomState_.device()),
+                                              reinterpret_cast<float*>(photonOutData->photons_.device()), rt.stream()), "cpm_trace_lights");
+    if (lo) {
+        cpm_trace_set_order(rt.ctx(), nullptr, 0);
+        if (measure && ok) {
+            rt.check(cpm_trace_order_update(rt.ctx(), lo->order, rt.stream()), "cpm_trace_order_update");
+            lo->sinceMeasured = 0;
+            lo->stale = false;
+        }
+        ++lo->sinceMeasured;
+    }
+    return ok;
 }
 
 int RecomputedPhotonIndices::resolveCount() {
@@ -742,7 +802,7 @@ ProgressivePhotonTracerCL::ProgressivePhotonTracerCL() {
                                                                 &equalIncrementalImportance_, &spatialSorting_, &maxScatteringEvents_, &noSingleScattering_,
                                                                 &alphaProp_, &workGroupSize_, &useGLSharing_, &enableProgressiveRefinement_,
                                                                 &enableProgressivePhotonRecomputation_, &clipX_, &clipY_, &clipZ_, &fusedImportanceBranch_,
-                                                                &equalImportancePercentage_, &importanceBranchPolicy_, &retraceInImportancePass_ })
+                                                                &equalImportancePercentage_, &importanceBranchPolicy_, &retraceInImportancePass_, &traceLightsInOneLaunch_ })
         addProperty(*p);
     addProperty(advancedMaterial_); addProperty(camera_); addProperty(invalidateRendering_); addProperty(transferFunctionProperty_);
     transferFunctionProperty_.onChange([this]() { setTransferFunction(transferFunctionProperty_.get()); });             // tracercl.cpp:148
@@ -821,6 +881,21 @@ void ProgressivePhotonTracerCL::process() {  // progressivephotontracercl.cpp:21
     } else {
         photonData_->advanceToNextIteration(alphaProp_.get());
     }
+    // a full frame: every light's samples traced -- in one launch where there are several lights, else (or should that launch be
+    // refused) light by light as the reference does (:543-549)
+    auto traceAllLights = [&]() {
+        if (lights.size() > 1 && traceLightsInOneLaunch_.get()) {
+            std::vector<const LightSamples*> all;
+            for (auto& l : lights) all.push_back(l.get());
+            if (photonTracer_.tracePhotonsAllLights(volume, transferFunction_, aabb_, advancedMaterial_, stepSize, all, maxInteractions, photonData_.get())) return;
+        }
+        int offset = 0;
+        for (auto& l : lights) {
+            photonTracer_.tracePhotons(volume, transferFunction_, aabb_, advancedMaterial_, stepSize, l.get(), nullptr, 0, offset, 0, maxInteractions,
+                                       photonData_.get());
+            offset += (int)l->getSize();
+        }
+    };
     size_t nPhotonsToCompute = photonData_->getNumberOfPhotons();
     if (!(flag & lightFlag) && recomputationImportanceGrid_.isReady() && photonRecomputationDetector_.isValid()) {
         if (photonRecomputationImportance_.getSize() != photonData_->getNumberOfPhotons()) {
@@ -854,12 +929,7 @@ void ProgressivePhotonTracerCL::process() {  // progressivephotontracercl.cpp:21
         auto fullFrameInPlaceOfBranch = [&](const char* decision) {
             lastDecision_ = decision;
             span_.begin(rt.stream(), &costs_.fullTraceMs);
-            int offset = 0;
-            for (auto& l : lights) {
-                photonTracer_.tracePhotons(volume, transferFunction_, aabb_, advancedMaterial_, stepSize, l.get(), nullptr, 0, offset, 0, maxInteractions,
-                                           photonData_.get());
-                offset += (int)l->getSize();
-            }
+            traceAllLights();
             resetPhotonImportance(0, photonRecomputationImportance_.getSize());
             span_.end(rt.stream());
             recomputedPhotonIndices_->nRecomputedPhotons = -1;
@@ -1012,12 +1082,7 @@ void ProgressivePhotonTracerCL::process() {  // progressivephotontracercl.cpp:21
     } else {
         lastDecision_ = "full frame";
         span_.begin(rt.stream(), &costs_.fullTraceMs);
-        int offset = 0;
-        for (auto& l : lights) {
-            photonTracer_.tracePhotons(volume, transferFunction_, aabb_, advancedMaterial_, stepSize, l.get(), nullptr, 0, offset, 0, maxInteractions,
-                                       photonData_.get());
-            offset += (int)l->getSize();
-        }
+        traceAllLights();
         span_.end(rt.stream());
         recomputedPhotonIndices_->takenInPlaceOfBranch = false;
         recomputedPhotonIndices_->nRecomputedPhotons = -1;

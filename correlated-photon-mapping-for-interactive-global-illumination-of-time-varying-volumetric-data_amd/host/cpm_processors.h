@@ -340,6 +340,12 @@ public:
                       const AdvancedMaterialProperty& material, float stepSize, const LightSamples* lightSamples,
                       const Buffer<unsigned int>* photonsToRecomputeIndices, int nInvalidPhotons, int photonOffset,
                       int batch, int maxInteractions, PhotonData* photonOutData);
+    // every light of a full frame in ONE launch (cpm_trace_lights: light l at photon offset sum of the sizes before it) instead of the
+    // reference's launch per light (processor/progressivephotontracercl.cpp:543-549): same photons, the launch's fixed part paid
+    // once.  false = does not apply (one light, more than CPM_MAX_TRACE_LIGHTS): the caller loops.
+    bool tracePhotonsAllLights(const Volume* volume, const TransferFunction& transferFunction, const float aabb[8],
+                               const AdvancedMaterialProperty& material, float stepSize, const std::vector<const LightSamples*>& lights,
+                               int maxInteractions, PhotonData* photonOutData);
     void setNoSingleScattering(bool v) { onlyMultipleScattering_ = v; }
     void setProgressive(bool v) { progressive_ = v; }
     bool isProgressive() const { return progressive_; }
@@ -369,6 +375,8 @@ public:
 private:
     struct LaunchOrder { cpm_trace_order* order = nullptr; int n = 0; int sinceMeasured = 0; bool stale = false; const void* volume = nullptr; };
     std::vector<std::pair<const LightSamples*, LaunchOrder>> launchOrders_;
+    LaunchOrder allLightsOrder_;                         // ... of the launch over all lights
+    std::vector<const LightSamples*> allLightsOrderFor_;
     bool adaptiveLaunchOrder_ = true;
     Buffer<uvec2> randomState_;
     bool onlyMultipleScattering_ = false, progressive_ = false;
@@ -533,6 +541,7 @@ public:
     // true (default): detector, threshold and tracer in ONE launch (cpm_photon_importance_retrace); false: selection, compaction
     // and cpm_trace_selected as separate launches (still no host round trip).  The equal-importance detector takes the latter.
     BoolProperty retraceInImportancePass_{ "retraceInImportancePass", "Re-trace inside the importance pass", true };
+    BoolProperty traceLightsInOneLaunch_{ "traceLightsInOneLaunch", "Full frames trace all lights in one launch", true };
     // false: the importance branch launch by launch with its host read of the count in the middle (always taken when the update
     // budget is below 100 %: ranking by importance is a host decision); true (default): the count stays on the device
     BoolProperty fusedImportanceBranch_{ "fusedImportanceBranch", "Importance branch without host round trip", true };

@@ -214,6 +214,26 @@ int cpm_trace(cpm_ctx* ctx, const cpm_volume* vol, const cpm_tf* tf, const cpm_t
               const float* isect2, const uint32_t* recompute_indices, int n_recompute,
               uint32_t* rng_state, float* photons8, cpm_stream stream);
 
+/* cpm_trace for SEVERAL lights in one launch: light l's samples go to photons photon_offset[l] .. + n_light_samples[l] exactly as
+ * n_lights cpm_trace calls with those offsets leave them (same streams, same bits) -- one launch instead of one per light, whose
+ * fixed part (a workgroup's chain of round trips, the ramp and the tail: about 10 us at any size) is paid once.
+ * params->photon_offset / n_light_samples are ignored; at most CPM_MAX_TRACE_LIGHTS lights (more: call per light).
+ * With a cpm_trace_order set it must have been created for the launch's chunks: sum over the lights of
+ * 256 * ceil(n_light_samples / 256) samples (cpm_trace_lights_order_samples).
+ * Replaces the loop over the light-sample inport's lights around PhotonTracerCL::tracePhotons
+ * (ref processor/progressivephotontracercl.cpp:543-549). */
+#define CPM_MAX_TRACE_LIGHTS 4
+typedef struct cpm_light_span {
+    const float* light_samples8;  /* device, float8[n_light_samples] */
+    const float* isect2;          /* device, float2[n_light_samples] */
+    int32_t n_light_samples;
+    int32_t photon_offset;        /* first photon of this light in the photon / RNG arrays */
+} cpm_light_span;
+int cpm_trace_lights_order_samples(const cpm_light_span* lights, int n_lights);
+int cpm_trace_lights(cpm_ctx* ctx, const cpm_volume* vol, const cpm_tf* tf, const cpm_tf* tf_scattering,
+                     const float aabb[8], const cpm_trace_params* params, const cpm_light_span* lights, int n_lights,
+                     uint32_t* rng_state, float* photons8, cpm_stream stream);
+
 /* The same trace with the emission chain evaluated in the tracer's registers instead of read from buffers: thread i
  * takes lattice sample first_sample + i of cpm_uniform_samples_2d(nx, ny), turns it into the light sample of
  * cpm_directional_light_samples / cpm_point_light_samples and into the entry / exit of cpm_light_sample_box_intersection
