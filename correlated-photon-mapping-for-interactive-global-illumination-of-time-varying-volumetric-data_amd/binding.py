@@ -40,7 +40,7 @@ ABI_SYMBOLS = [
     "cpm_photon_importance", "cpm_photon_importance_equal", "cpm_reset_importance",
     "cpm_select_recompute", "cpm_select_changed",
     "cpm_selection_create", "cpm_selection_destroy", "cpm_selection_begin", "cpm_photon_importance_select",
-    "cpm_photon_importance_equal_select", "cpm_photon_importance_retrace", "cpm_selection_finish", "cpm_selection_set_occupancy", "cpm_selection_count_device", "cpm_selection_count",
+    "cpm_photon_importance_equal_select", "cpm_photon_importance_retrace", "cpm_photon_importance_retrace_lights", "cpm_selection_finish", "cpm_selection_set_occupancy", "cpm_selection_count_device", "cpm_selection_count",
     "cpm_trace_selected", "cpm_splat_delta",
     "cpm_mix_buffers", "cpm_volume_mix",
     "cpm_comm_get_unique_id", "cpm_comm_create", "cpm_comm_create_all", "cpm_comm_destroy", "cpm_comm_rank", "cpm_comm_size",
@@ -249,6 +249,8 @@ def load_library() -> C.CDLL:
         "cpm_photon_importance_equal_select": (i32, [vp, vp, i32, i32, i32, i32, vp, vp]),
         "cpm_photon_importance_retrace": (i32, [vp, vp, vp, P(i32 * 3), P(f32 * 3), P(f32 * 16), vp, vp, vp, P(f32 * 8), P(TraceParams), vp, vp, i32,
                                           vp, vp, vp, vp, vp]),
+        "cpm_photon_importance_retrace_lights": (i32, [vp, vp, vp, P(i32 * 3), P(f32 * 3), P(f32 * 16), vp, vp, vp, P(f32 * 8), P(TraceParams), vp, i32, i32,
+                                                 vp, vp, vp, vp, vp]),
         "cpm_selection_finish": (i32, [vp, vp, vp, vp]),
         "cpm_selection_count_device": (vp, [vp]),
         "cpm_selection_count": (i32, [vp, vp, P(i32)]),
@@ -690,6 +692,16 @@ class Context:
             self._ptr(isect), n_light_samples, max_interactions, total_photons, int(fix_exit_point),
             self._ptr(importances), self._stream()))
 
+    def photon_importance_retrace_lights(self, importance_grid, grid_dims, cell_size, texture_to_index, vol, tf, aabb, params, spans,
+                                         importances, rng_state, photons, old_photons, fix_exit_point=False, tf_scattering=None):
+        """photon_importance_retrace for several lights in one launch (spans: Context.light_spans(...))."""
+        c = self.ctx
+        c._check(c.lib.cpm_photon_importance_retrace_lights(
+            c.h, self.h, c._ptr(importance_grid), C.byref((C.c_int32 * 3)(*grid_dims)), C.byref((C.c_float * 3)(*cell_size)),
+            C.byref((C.c_float * 16)(*texture_to_index)), vol.h, tf.h, tf_scattering.h if tf_scattering is not None else None,
+            C.byref((C.c_float * 8)(*aabb)), C.byref(params), C.cast(spans, C.c_void_p), len(spans), int(fix_exit_point),
+            c._ptr(importances), c._ptr(rng_state), c._ptr(photons), c._ptr(old_photons), c._stream()))
+
     def photon_importance_equal(self, photon_offset, n_light_samples, percentage, iteration, importances):
         self._check(self.lib.cpm_photon_importance_equal(self.h, photon_offset, n_light_samples, percentage, iteration,
                                                          self._ptr(importances), self._stream()))
@@ -757,6 +769,16 @@ class Selection:
             c.h, self.h, c._ptr(importance_grid), C.byref((C.c_int32 * 3)(*grid_dims)), C.byref((C.c_float * 3)(*cell_size)),
             C.byref((C.c_float * 16)(*texture_to_index)), vol.h, tf.h, tf_scattering.h if tf_scattering is not None else None,
             C.byref((C.c_float * 8)(*aabb)), C.byref(params), c._ptr(light_samples), c._ptr(isect), int(fix_exit_point),
+            c._ptr(importances), c._ptr(rng_state), c._ptr(photons), c._ptr(old_photons), c._stream()))
+
+    def photon_importance_retrace_lights(self, importance_grid, grid_dims, cell_size, texture_to_index, vol, tf, aabb, params, spans,
+                                         importances, rng_state, photons, old_photons, fix_exit_point=False, tf_scattering=None):
+        """photon_importance_retrace for several lights in one launch (spans: Context.light_spans(...))."""
+        c = self.ctx
+        c._check(c.lib.cpm_photon_importance_retrace_lights(
+            c.h, self.h, c._ptr(importance_grid), C.byref((C.c_int32 * 3)(*grid_dims)), C.byref((C.c_float * 3)(*cell_size)),
+            C.byref((C.c_float * 16)(*texture_to_index)), vol.h, tf.h, tf_scattering.h if tf_scattering is not None else None,
+            C.byref((C.c_float * 8)(*aabb)), C.byref(params), C.cast(spans, C.c_void_p), len(spans), int(fix_exit_point),
             c._ptr(importances), c._ptr(rng_state), c._ptr(photons), c._ptr(old_photons), c._stream()))
 
     def photon_importance_equal(self, photon_offset, n_light_samples, percentage, iteration, importances):

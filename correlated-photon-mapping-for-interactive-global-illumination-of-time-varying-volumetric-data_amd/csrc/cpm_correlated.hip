@@ -717,11 +717,14 @@ constexpr uint32_t kRetraceTile = 256;
 #endif
 constexpr int kRetraceAhead = CPM_RETRACE_AHEAD;
 // LINEAR: the volume's footprint copy is stale (a mixed time step): the re-traces fetch from the linear block (cpm::trace_volume_source)
-template <int DT, bool MASK, bool SINGLE, bool LINEAR = false>
+// MULTI: the tiles of several lights in one launch (cpm_photon_importance_retrace_lights): a tile's place among the spans' tile ranges
+// (TraceArgs::span, chunk_base = first tile) says whose samples it holds.
+template <int DT, bool MASK, bool SINGLE, bool LINEAR = false, bool MULTI = false>
 __global__ __launch_bounds__(256) void importance_retrace_kernel(ImpGrid G, const uint32_t* __restrict__ mask, uint32_t mask_words,
                                                                  int fix_exit_point, uint32_t* __restrict__ importances, SelTiles S,
-                                                                 const tracer::TraceArgs A, float* __restrict__ old_sparse,
+                                                                 const tracer::TraceArgs A0, float* __restrict__ old_sparse,
                                                                  const uint32_t* __restrict__ order, uint32_t* __restrict__ cost) {
+    tracer::TraceArgs A = A0;
     extern __shared__ uint32_t s_dyn[];  // [occupancy bits of the importance grid][TF alpha column(s)]
     uint32_t* s_mask = s_dyn;
     float* lut = reinterpret_cast<float*>(s_dyn + mask_words);
@@ -729,9 +732,20 @@ __global__ __launch_bounds__(256) void importance_retrace_kernel(ImpGrid G, cons
     __shared__ uint32_t s_wcnt[4];
     const unsigned long long w0 = cost ? wall_clock64() : 0ull;
     const uint32_t t = threadIdx.x, lane = t & 63u, wave = t >> 6;
-    const int n_light_samples = A.p.n_light_samples, photon_offset = A.p.photon_offset;
     const uint32_t tile = order ? order[blockIdx.x] : blockIdx.x;
-    const int b0 = (int)(tile * kRetraceTile);
+    uint32_t local_tile = tile;  // ... within its light
+    if (MULTI) {  // (uniform)
+        int sp = 0;
+        while (sp + 1 < A0.n_spans && (int)tile >= A0.span[sp + 1].chunk_base) ++sp;
+        local_tile = tile - (uint32_t)A0.span[sp].chunk_base;
+        A.light_samples = A0.span[sp].light_samples;
+        A.isect = A0.span[sp].isect;
+        A.n_threads = A0.span[sp].n;
+        A.p.n_light_samples = A0.span[sp].n;
+        A.p.photon_offset = A0.span[sp].photon_offset;
+    }
+    const int n_light_samples = A.p.n_light_samples, photon_offset = A.p.photon_offset;
+    const int b0 = (int)(local_tile * kRetraceTile);
     if (MASK) for (uint32_t i = t; i < mask_words; i += 256u) s_mask[i] = mask[i];
     for (int i = (int)t; i < A.tf_width; i += 256) lut[i] = A.tf_alpha[i];
     if (A.tfs_alpha != A.tf_alpha) {
@@ -1247,28 +1261,57 @@ int cpm_photon_importance_select(cpm_ctx* ctx, cpm_selection* s, const float* im
     return CPM_OK;
 }
 
-int cpm_photon_importance_retrace(cpm_ctx* ctx, cpm_selection* s, const float* importance_grid, const int32_t grid_dims[3],
-                                  const float cell_size[3], const float texture_to_index[16], const cpm_volume* vol, const cpm_tf* tf,
-                                  const cpm_tf* tf_scattering, const float aabb[8], const cpm_trace_params* params,
-                                  const float* light_samples8, const float* isect2, int fix_exit_point, uint32_t* importances,
-                                  uint32_t* rng_state, float* photons8, float* old_photons8, cpm_stream stream) {
+}  // extern "C"
+
+namespace {
+// cpm_photon_importance_retrace (one light: the span made of its arguments) and cpm_photon_importance_retrace_lights (several: one launch
+// over all their tiles, the MULTI kernels)
+int retrace_impl(cpm_ctx* ctx, cpm_selection* s, const float* importance_grid, const int32_t grid_dims[3], const float cell_size[3],
+                 const float texture_to_index[16], const cpm_volume* vol, const cpm_tf* tf, const cpm_tf* tf_scattering, const float aabb[8],
+                 const cpm_trace_params* params, const cpm_light_span* lights, int n_lights, int fix_exit_point, uint32_t* importances,
+                 uint32_t* rng_state, float* photons8, float* old_photons8, cpm_stream stream) {
     CPM_ENTER(ctx);
     CPM_REQUIRE(ctx, s, "cpm_photon_importance_retrace: null selection");
     CPM_REQUIRE(ctx, grid_dims && cell_size && texture_to_index && params, "cpm_photon_importance_retrace: null argument");
+    CPM_REQUIRE(ctx, lights && n_lights >= 1 && n_lights <= CPM_MAX_TRACE_LIGHTS, "cpm_photon_importance_retrace_lights: 1 .. CPM_MAX_TRACE_LIGHTS lights");
+    cpm_trace_params p = *params;
+    long long n_all = 0;
+    for (int l = 0; l < n_lights; ++l) {
+        CPM_REQUIRE(ctx, lights[l].n_light_samples >= 0 && lights[l].photon_offset >= 0, "cpm_photon_importance_retrace: negative size");
+        n_all += lights[l].n_light_samples;
+    }
+    if (n_lights > 1) { p.photon_offset = 0; p.n_light_samples = 0; }  // (the per-light fields come from the spans)
     tracer::TraceArgs A;
     size_t lut_bytes = 0;
-    int rc = cpm::make_trace_args(ctx, vol, tf, tf_scattering, aabb, params, A, lut_bytes);
+    int rc = cpm::make_trace_args(ctx, vol, tf, tf_scattering, aabb, &p, A, lut_bytes);
     if (rc) return rc;
-    const cpm_trace_params& p = *params;
     CPM_REQUIRE(ctx, !(p.flags & CPM_TRACE_PROGRESSIVE), "cpm_photon_importance_retrace: a correlated re-trace does not write the RNG state back");
-    if (p.n_light_samples == 0) return CPM_OK;
-    CPM_REQUIRE(ctx, importance_grid && photons8 && light_samples8 && isect2 && importances && rng_state && old_photons8,
-                "cpm_photon_importance_retrace: null buffer");
+    if (n_all == 0) return CPM_OK;
+    CPM_REQUIRE(ctx, importance_grid && photons8 && importances && rng_state && old_photons8, "cpm_photon_importance_retrace: null buffer");
     CPM_REQUIRE_ALIGNED16(ctx, photons8, "cpm_photon_importance_retrace");
     CPM_REQUIRE_ALIGNED16(ctx, old_photons8, "cpm_photon_importance_retrace");
-    CPM_REQUIRE_ALIGNED16(ctx, light_samples8, "cpm_photon_importance_retrace");
-    CPM_REQUIRE(ctx, (reinterpret_cast<uintptr_t>(rng_state) & 7u) == 0 && (reinterpret_cast<uintptr_t>(isect2) & 7u) == 0,
-                "cpm_photon_importance_retrace: rng_state / isect2 must be 8-byte aligned");
+    CPM_REQUIRE(ctx, (reinterpret_cast<uintptr_t>(rng_state) & 7u) == 0, "cpm_photon_importance_retrace: rng_state must be 8-byte aligned");
+    for (int l = 0; l < n_lights; ++l) {
+        const cpm_light_span& L = lights[l];
+        if (L.n_light_samples == 0) continue;
+        CPM_REQUIRE(ctx, L.light_samples8 && L.isect2, "cpm_photon_importance_retrace: null buffer");
+        CPM_REQUIRE(ctx, (long long)L.photon_offset + L.n_light_samples <= (long long)p.total_photons,
+                    "cpm_photon_importance_retrace: photon_offset + n_light_samples exceeds total_photons");
+        CPM_REQUIRE_ALIGNED16(ctx, L.light_samples8, "cpm_photon_importance_retrace");
+        CPM_REQUIRE(ctx, (reinterpret_cast<uintptr_t>(L.isect2) & 7u) == 0, "cpm_photon_importance_retrace: isect2 must be 8-byte aligned");
+    }
+    // a stale footprint copy (a mixed time step) has linear-block kernels for one light only: several lights go one by one
+    if (n_lights > 1 && vol->quads_stale) {
+        for (int l = 0; l < n_lights; ++l) {
+            cpm_trace_params pl = *params;
+            pl.photon_offset = lights[l].photon_offset;
+            pl.n_light_samples = lights[l].n_light_samples;
+            rc = retrace_impl(ctx, s, importance_grid, grid_dims, cell_size, texture_to_index, vol, tf, tf_scattering, aabb, &pl, lights + l, 1, fix_exit_point,
+                              importances, rng_state, photons8, old_photons8, stream);
+            if (rc) return rc;
+        }
+        return CPM_OK;
+    }
     ImpGrid G;
     G.grid = importance_grid;
     unsigned long long cells = 1;
@@ -1281,9 +1324,18 @@ int cpm_photon_importance_retrace(cpm_ctx* ctx, cpm_selection* s, const float* i
     CPM_REQUIRE(ctx, cells < (1ull << 31), "cpm_photon_importance_retrace: grid too large");
     if (!affine_from_matrix(texture_to_index, G.t2i))
         return set_error(ctx, CPM_ERR_UNSUPPORTED, "cpm_photon_importance_retrace", "textureToIndex must be scale + translate");
+    // the lights' tiles, one light after the other (what a call per light appends)
+    const uint32_t tiles_before = s->n_tiles;
     uint32_t first = 0, tiles = 0;
-    rc = selection_append(ctx, s, p.photon_offset, p.n_light_samples, &first, &tiles, kRetraceTile);
-    if (rc) return rc;
+    for (int l = 0; l < n_lights; ++l) {
+        uint32_t f = 0, tl = 0;
+        rc = selection_append(ctx, s, lights[l].photon_offset, lights[l].n_light_samples, &f, &tl, kRetraceTile);
+        if (rc) { s->n_tiles = tiles_before; return rc; }
+        if (l == 0) first = f;
+        A.span[l] = { lights[l].light_samples8, lights[l].isect2, lights[l].n_light_samples, lights[l].photon_offset, (int)tiles };
+        tiles += tl;
+    }
+    A.n_spans = n_lights;
     AppendGuard guard(s, first);
     CPM_INJECTED_SELECT_FAILURE(ctx, "cpm_photon_importance_retrace");
     hipStream_t st = (hipStream_t)stream;
@@ -1312,11 +1364,13 @@ int cpm_photon_importance_retrace(cpm_ctx* ctx, cpm_selection* s, const float* i
     }
     const uint32_t* tile_order = lo.fresh ? nullptr : lo.order;
     uint32_t* tile_cost = (s->measuring || lo.fresh) ? lo.cost : nullptr;
-    A.light_samples = light_samples8;
-    A.isect = isect2;
+    A.light_samples = lights[0].light_samples8;
+    A.isect = lights[0].isect2;
     A.rng = rng_state;
     A.photons = photons8;
-    A.n_threads = p.n_light_samples;
+    A.n_threads = lights[0].n_light_samples;
+    A.p.n_light_samples = lights[0].n_light_samples;
+    A.p.photon_offset = lights[0].photon_offset;
     const size_t words = (size_t)((cells + 63) / 64) * 2;
     const bool use_mask = words * 4 + lut_bytes <= kSelectLdsBudget;  // (the tracer's LUTs share the dynamic LDS)
     const uint32_t* mask_bits = nullptr;
@@ -1338,9 +1392,17 @@ int cpm_photon_importance_retrace(cpm_ctx* ctx, cpm_selection* s, const float* i
         else if (single) CPM_LAUNCH(ctx, (importance_retrace_kernel<DT, false, true, L>), grid, block, lds, st, G, mask_bits, mw, fix_exit_point, importances, S, A, old_photons8, tile_order, tile_cost);        \
         else CPM_LAUNCH(ctx, (importance_retrace_kernel<DT, false, false, L>), grid, block, lds, st, G, mask_bits, mw, fix_exit_point, importances, S, A, old_photons8, tile_order, tile_cost);                   \
     } while (0)
+#define CPM_RETRACE_LAUNCH_M(DT)                                                                                                                 \
+    do {                                                                                                                                         \
+        if (use_mask && single) CPM_LAUNCH(ctx, (importance_retrace_kernel<DT, true, true, false, true>), grid, block, lds, st, G, mask_bits, mw, fix_exit_point, importances, S, A, old_photons8, tile_order, tile_cost);   \
+        else if (use_mask) CPM_LAUNCH(ctx, (importance_retrace_kernel<DT, true, false, false, true>), grid, block, lds, st, G, mask_bits, mw, fix_exit_point, importances, S, A, old_photons8, tile_order, tile_cost);       \
+        else if (single) CPM_LAUNCH(ctx, (importance_retrace_kernel<DT, false, true, false, true>), grid, block, lds, st, G, mask_bits, mw, fix_exit_point, importances, S, A, old_photons8, tile_order, tile_cost);        \
+        else CPM_LAUNCH(ctx, (importance_retrace_kernel<DT, false, false, false, true>), grid, block, lds, st, G, mask_bits, mw, fix_exit_point, importances, S, A, old_photons8, tile_order, tile_cost);                   \
+    } while (0)
 #define CPM_RETRACE_LAUNCH(DT)                                  \
     do {                                                        \
-        if (linear) CPM_RETRACE_LAUNCH_L(DT, true);             \
+        if (n_lights > 1) CPM_RETRACE_LAUNCH_M(DT);             \
+        else if (linear) CPM_RETRACE_LAUNCH_L(DT, true);        \
         else CPM_RETRACE_LAUNCH_L(DT, false);                   \
     } while (0)
     switch (vol->desc.dtype) {
@@ -1349,11 +1411,35 @@ int cpm_photon_importance_retrace(cpm_ctx* ctx, cpm_selection* s, const float* i
         default: CPM_RETRACE_LAUNCH(CPM_F32); break;
     }
 #undef CPM_RETRACE_LAUNCH_L
+#undef CPM_RETRACE_LAUNCH_M
 #undef CPM_RETRACE_LAUNCH
     CPM_LAUNCH_CHECK(ctx, "importance_retrace_kernel");
     if (tile_cost) s->pending_orders.push_back(ordinal);  // re-sorted behind the compaction (cpm_selection_finish)
     guard.ok = true;
     return CPM_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int cpm_photon_importance_retrace(cpm_ctx* ctx, cpm_selection* s, const float* importance_grid, const int32_t grid_dims[3],
+                                  const float cell_size[3], const float texture_to_index[16], const cpm_volume* vol, const cpm_tf* tf,
+                                  const cpm_tf* tf_scattering, const float aabb[8], const cpm_trace_params* params,
+                                  const float* light_samples8, const float* isect2, int fix_exit_point, uint32_t* importances,
+                                  uint32_t* rng_state, float* photons8, float* old_photons8, cpm_stream stream) {
+    if (ctx && !params) return set_error(ctx, CPM_ERR_INVALID_ARGUMENT, "cpm_photon_importance_retrace", "null params");
+    const cpm_light_span one = { light_samples8, isect2, params ? params->n_light_samples : 0, params ? params->photon_offset : 0 };
+    return retrace_impl(ctx, s, importance_grid, grid_dims, cell_size, texture_to_index, vol, tf, tf_scattering, aabb, params, &one, 1, fix_exit_point,
+                        importances, rng_state, photons8, old_photons8, stream);
+}
+
+int cpm_photon_importance_retrace_lights(cpm_ctx* ctx, cpm_selection* s, const float* importance_grid, const int32_t grid_dims[3],
+                                         const float cell_size[3], const float texture_to_index[16], const cpm_volume* vol, const cpm_tf* tf,
+                                         const cpm_tf* tf_scattering, const float aabb[8], const cpm_trace_params* params,
+                                         const cpm_light_span* lights, int n_lights, int fix_exit_point, uint32_t* importances,
+                                         uint32_t* rng_state, float* photons8, float* old_photons8, cpm_stream stream) {
+    return retrace_impl(ctx, s, importance_grid, grid_dims, cell_size, texture_to_index, vol, tf, tf_scattering, aabb, params, lights, n_lights, fix_exit_point,
+                        importances, rng_state, photons8, old_photons8, stream);
 }
 
 int cpm_photon_importance_equal_select(cpm_ctx* ctx, cpm_selection* s, int photon_offset, int n_light_samples, int percentage,

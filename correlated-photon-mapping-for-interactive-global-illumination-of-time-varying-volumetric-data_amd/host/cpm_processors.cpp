@@ -540,6 +540,51 @@ bool PhotonTracerCL::importanceRetrace(cpm_selection* selection, const Volume* v
              "cpm_photon_importance_retrace");
 }
 
+int PhotonTracerCL::importanceRetraceAllLights(cpm_selection* selection, const Volume* volume, const ImportanceUniformGrid3D* grid,
+                                               const TransferFunction& transferFunction, const float aabb[8], const AdvancedMaterialProperty& material,
+                                               float stepSize, const std::vector<const LightSamples*>& lights, Buffer<unsigned int>& importances,
+                                               vec4* replacedPhotons, int maxInteractions, bool fixExitPoint, PhotonData* photonOutData) {
+    auto& rt = CpmRuntime::get();
+    if (!rt.valid() || lights.size() < 2 || lights.size() > (size_t)CPM_MAX_TRACE_LIGHTS) return -1;
+    if (randomState_.getSize() != photonOutData->getNumberOfPhotons()) setRandomSeedSize(photonOutData->getNumberOfPhotons());
+    if (importances.getSize() != photonOutData->getNumberOfPhotons()) importances.setSize(photonOutData->getNumberOfPhotons());
+    cpm_volume* vol_ = volume->getDeviceRepresentation();
+    syncTF(transferFunction);
+    if (!vol_ || !tf_) return 0;
+    cpm_trace_params p = {};
+    const vec4 m = material.getCombinedMaterialParameters();
+    p.material[0] = m.x; p.material[1] = m.y; p.material[2] = m.z; p.material[3] = m.w;
+    p.step_size = stepSize;
+    p.max_interactions = maxInteractions;
+    p.total_photons = (int)photonOutData->getNumberOfPhotons();
+    p.shading_type = material.getPhaseFunctionEnum();
+    p.flags = onlyMultipleScattering_ ? CPM_TRACE_NO_SINGLE_SCATTERING : 0;  // (with an importance grid connected the tracer is never progressive)
+    p.iteration = photonOutData->iteration();
+    cpm_light_span spans[CPM_MAX_TRACE_LIGHTS];
+    int offset = 0;
+    for (size_t l = 0; l < lights.size(); ++l) {
+        spans[l].light_samples8 = reinterpret_cast<const float*>(lights[l]->getLightSamples()->device());
+        spans[l].isect2 = reinterpret_cast<const float*>(lights[l]->getIntersectionPoints()->device());
+        spans[l].n_light_samples = (int)lights[l]->getSize();
+        spans[l].photon_offset = offset;
+        offset += (int)lights[l]->getSize();
+    }
+    const size3_t gd = grid->getDimensions(), cd = grid->getCellDimension(), vd = volume->getDimensions();
+    const int32_t dims[3] = { (int32_t)gd.x, (int32_t)gd.y, (int32_t)gd.z };
+    const float cell[3] = { (float)cd.x, (float)cd.y, (float)cd.z };
+    cpm_volume_desc d;
+    const int32_t vdims[3] = { (int32_t)vd.x, (int32_t)vd.y, (int32_t)vd.z };
+    cpm_volume_desc_default(&d, vdims, volume->dtype());
+    cpm_selection_set_occupancy(rt.ctx(), selection, grid->occupancyValid ? grid->data.device() : nullptr,
+                                grid->occupancyValid ? grid->occupancy.device() : nullptr);
+    return rt.check(cpm_photon_importance_retrace_lights(rt.ctx(), selection, grid->data.device(), dims, cell, d.texture_to_index, vol_, tf_, nullptr, aabb, &p,
+                                                         spans, (int)lights.size(), fixExitPoint ? 1 : 0, importances.device(),
+                                                         reinterpret_cast<uint32_t*>(randomState_.device()),
+                                                         reinterpret_cast<float*>(photonOutData->photons_.device()), reinterpret_cast<float*>(replacedPhotons),
+                                                         rt.stream()),
+                    "cpm_photon_importance_retrace_lights") ? 1 : 0;
+}
+
 bool PhotonRecomputationDetector::photonRecomputationImportanceSelect(cpm_selection* selection, const PhotonData* photonData, int photonOffset,
                                                                       const Volume* origVolume, const ImportanceUniformGrid3D* grid,
                                                                       const LightSamples& lightSamples, Buffer<unsigned int>& imp, bool fixExitPoint) {
@@ -975,8 +1020,18 @@ void ProgressivePhotonTracerCL::process() {  // progressivephotontracercl.cpp:21
             // A selection one of whose launches failed publishes a count of 0 (cpm_selection_finish reports it): nothing behind
             // it on the stream re-traces or splats with indices no kernel wrote, and the change is served by a full frame.
             bool selected = true;
+            int allLights = -1;  // every light's importance pass + re-trace in ONE launch where there are several lights
+            if (oneLaunch && lights.size() > 1 && traceLightsInOneLaunch_.get()) {
+                std::vector<const LightSamples*> all;
+                for (auto& l : lights) all.push_back(l.get());
+                allLights = photonTracer_.importanceRetraceAllLights(selection_, volume, grid.get(), transferFunction_, aabb_, advancedMaterial_, stepSize, all,
+                                                                     photonRecomputationImportance_, rec.replacedPhotons.device(), maxInteractions, fixExitPoint,
+                                                                     photonData_.get());
+                if (allLights == 0) selected = false;
+            }
             if (oneLaunch) {
                 for (auto& l : lights) {  // detector + threshold + tracer + importance reset of a light in one launch (:298-356,467-529)
+                    if (allLights >= 0) break;
                     selected &= photonTracer_.importanceRetrace(selection_, volume, grid.get(), transferFunction_, aabb_, advancedMaterial_, stepSize, l.get(),
                                                                 photonRecomputationImportance_, rec.replacedPhotons.device(), offset, maxInteractions, fixExitPoint,
                                                                 photonData_.get());

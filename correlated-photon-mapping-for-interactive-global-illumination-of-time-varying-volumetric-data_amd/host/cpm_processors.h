@@ -357,6 +357,12 @@ public:
                            const float aabb[8], const AdvancedMaterialProperty& material, float stepSize, const LightSamples* lightSamples,
                            Buffer<unsigned int>& importances, vec4* replacedPhotons, int photonOffset, int maxInteractions, bool fixExitPoint,
                            PhotonData* photonOutData);
+    // ... for every light of the evaluation in ONE launch (cpm_photon_importance_retrace_lights; light l at photon offset sum of the sizes
+    // before it): -1 = does not apply (one light, more than CPM_MAX_TRACE_LIGHTS: the caller loops), 0 = failed, 1 = enqueued
+    int importanceRetraceAllLights(cpm_selection* selection, const Volume* volume, const ImportanceUniformGrid3D* grid,
+                                   const TransferFunction& transferFunction, const float aabb[8], const AdvancedMaterialProperty& material,
+                                   float stepSize, const std::vector<const LightSamples*>& lights, Buffer<unsigned int>& importances, vec4* replacedPhotons,
+                                   int maxInteractions, bool fixExitPoint, PhotonData* photonOutData);
     void tracePhotonsSelected(const Volume* volume, const TransferFunction& transferFunction, const float aabb[8],
                               const AdvancedMaterialProperty& material, float stepSize, const LightSamples* lightSamples,
                               const Buffer<unsigned int>* indices, const int32_t* nIndicesDevice, int maxIndices, vec4* replacedPhotons,

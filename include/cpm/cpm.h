@@ -581,6 +581,18 @@ int cpm_photon_importance_retrace(cpm_ctx* ctx, cpm_selection* sel, const float*
                                   int fix_exit_point, uint32_t* importances, uint32_t* rng_state, float* photons8,
                                   float* old_photons8, cpm_stream stream);
 
+/* cpm_photon_importance_retrace for SEVERAL lights in one launch (cpm_light_span: a light's buffers, count and photon offset;
+ * params->photon_offset / n_light_samples are ignored): the tiles of the lights are appended to the selection one light after
+ * the other and results are those of one call per light in that order, bit for bit -- the launch's fixed part is paid once.
+ * At most CPM_MAX_TRACE_LIGHTS lights; through a mixed volume (cpm_volume_mix: stale footprint copy) the lights are launched one
+ * by one.  Replaces the loop over the lights around the importance branch (ref processor/progressivephotontracercl.cpp:481-527). */
+int cpm_photon_importance_retrace_lights(cpm_ctx* ctx, cpm_selection* sel, const float* importance_grid,
+                                         const int32_t grid_dims[3], const float cell_size[3], const float texture_to_index[16],
+                                         const cpm_volume* vol, const cpm_tf* tf, const cpm_tf* tf_scattering, const float aabb[8],
+                                         const cpm_trace_params* params, const cpm_light_span* lights, int n_lights,
+                                         int fix_exit_point, uint32_t* importances, uint32_t* rng_state, float* photons8,
+                                         float* old_photons8, cpm_stream stream);
+
 /* The equal-importance detector (ref ...detector.cl:160-194) in the same fused form. */
 int cpm_photon_importance_equal_select(cpm_ctx* ctx, cpm_selection* sel, int photon_offset, int n_light_samples,
                                        int percentage, int iteration, uint32_t* importances, cpm_stream stream);
