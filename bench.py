@@ -731,6 +731,8 @@ def main():
                     "tf_edit_update_ms": round(float(np.median(ms_e[10:])), 4),
                     "tf_edit_fraction_retraced": round(float(np.mean(np.maximum(n_e[10:], 0))) / (2 * 1024 * 1024), 5),
                     "tf_edit_served_by": net.last_decision,
+                    "launches": "both lights' samples traced by one launch (cpm_trace_lights; the TF edit's importance pass + re-trace likewise: "
+                                "cpm_photon_importance_retrace_lights); bricks of 16 x 16 x 8 voxels for the wide box, four copies of a brick's LDS tile",
                     "measured": "libcpm_host.so: the workspace's network (two light samplers -> tracer multi-inport -> light volume), frames back to "
                                 "back with one synchronisation; tests/test_workspace_point_gpu.py holds the same network to the oracle"}
                 net.close()
