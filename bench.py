@@ -338,6 +338,7 @@ def main():
 
             def setup():
                 try:
+                    torch.cuda.set_device(local_rank)   # (a new thread starts on device 0: streams and tensors must be this rank's)
                     tr = sharding.RcclTransport(ctx, rank, world, root=root)
                     probe = torch.ones(8, dtype=torch.float32, device=ctx.device)
                     tr.wait(tr.start(probe))
