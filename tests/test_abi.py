@@ -134,3 +134,19 @@ def test_fast_formulation_sizing_is_host_arithmetic(cpm):
         assert lib.cpm_fast_record_capacity(C.byref(g), 1000, C.c_float(4.6 * r1)) == 0
     g = B.default_grid_desc((400, 8, 16), 1)       # reach 1 along every axis: one record per photon
     assert lib.cpm_fast_record_capacity(C.byref(g), 1000, C.c_float(0.4 / 400)) == 1000
+
+
+def test_trace_lights_order_samples_is_host_arithmetic(cpm):
+    """cpm_trace_lights_order_samples: the samples a cpm_trace_order for a launch over several lights is created for -- every light's
+    count rounded up to whole 256-sample chunks (no device needed)."""
+    import ctypes as C
+    B = cpm.binding
+    lib = B.load_library()
+    lib.cpm_trace_lights_order_samples.restype = C.c_int
+    lib.cpm_trace_lights_order_samples.argtypes = [C.c_void_p, C.c_int]
+    for counts in ([1048576, 1048576], [1], [255, 257, 0, 256], [10000, 1369, 4096]):
+        arr = (B.LightSpan * len(counts))()
+        for a, n in zip(arr, counts):
+            a.n_light_samples = n
+        assert lib.cpm_trace_lights_order_samples(C.cast(arr, C.c_void_p), len(counts)) == 256 * sum((n + 255) // 256 for n in counts)
+    assert lib.cpm_trace_lights_order_samples(None, 3) == 0
