@@ -36,7 +36,24 @@ def build_library(force: bool = False, verbose: bool = True) -> Path:
     return out
 
 
-HOST_SOURCES = ["cpm_processors.cpp", "cpm_timevarying.cpp", "cpm_modules.cpp", "cpm_host_c.cpp"]
+HOST_SOURCES = ["cpm_processors.cpp", "cpm_timevarying.cpp", "cpm_modules.cpp", "cpm_host_c.cpp", "cpm_hostmath.cpp"]
+
+
+def build_hostmath_library(force: bool = False, verbose: bool = True) -> Path:
+    """libcpm_hostmath.so: the path's host arithmetic alone (light rectangle, transfer-function difference; host/cpm_hostmath.cpp) --
+    standard C++, no HIP: what pipeline.py calls, loadable before or without any GPU runtime.  libcpm_host.so carries the same
+    translation unit."""
+    out = PKG_DIR / "libcpm_hostmath.so"
+    src = PKG_DIR / "host" / "cpm_hostmath.cpp"
+    deps = [src, PKG_DIR / "host" / "cpm_hostmath.h"]
+    if not force and out.exists() and all(out.stat().st_mtime >= d.stat().st_mtime for d in deps):
+        return out
+    cxx = shutil.which("g++") or hipcc()
+    cmd = [cxx, "-O2", "-ffp-contract=off", "-std=c++17", "-fPIC", "-shared", "-Wall", "-I", str(PKG_DIR / "host"), "-o", str(out), str(src)]
+    if verbose:
+        print(" ".join(cmd), file=sys.stderr)
+    subprocess.run(cmd, check=True)
+    return out
 
 
 def build_host_library(force: bool = False, verbose: bool = True, extras: bool = False) -> Path:
@@ -48,7 +65,7 @@ def build_host_library(force: bool = False, verbose: bool = True, extras: bool =
     deps = srcs + list((PKG_DIR / "host").glob("*.h")) + [REPO / "include" / "cpm" / "cpm.h", PKG_DIR / "libcpm_hip.so"]
     if not force and out.exists() and all(out.stat().st_mtime >= d.stat().st_mtime for d in deps):
         return out
-    cmd = [hipcc(), "-x", "c++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-D__HIP_PLATFORM_AMD__", *(["-DCPM_HOST_EXTRAS"] if extras else []),
+    cmd = [hipcc(), "-x", "c++", "-O2", "-ffp-contract=off", "-std=c++17", "-fPIC", "-shared", "-Wall", "-D__HIP_PLATFORM_AMD__", *(["-DCPM_HOST_EXTRAS"] if extras else []),
            "-I", str(REPO / "include"),
            "-I", str(PKG_DIR / "host"), "-I", "/opt/rocm/include", "-o", str(out), *map(str, srcs),
            "-L", str(PKG_DIR), "-lcpm_hip", "-L", "/opt/rocm/lib", "-lamdhip64", "-Wl,-rpath,$ORIGIN", "-Wl,-rpath,/opt/rocm/lib"]
@@ -60,4 +77,5 @@ def build_host_library(force: bool = False, verbose: bool = True, extras: bool =
 
 if __name__ == "__main__":
     build_library(force="--force" in sys.argv)
+    build_hostmath_library(force="--force" in sys.argv)
     build_host_library(force="--force" in sys.argv)

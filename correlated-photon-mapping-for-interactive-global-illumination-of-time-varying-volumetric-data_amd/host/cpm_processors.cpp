@@ -4,6 +4,8 @@
 
 #include <cpm/cpm_profile.h>
 
+#include "cpm_hostmath.h"
+
 #include <cstdlib>
 
 #include <algorithm>
@@ -110,34 +112,41 @@ std::vector<float> TransferFunction::lut(int width) const {
     return out;
 }
 
-// progressivephotonmapping/photondata.cpp:100-117
-void Photon::setDirection(vec3 dir) {
-    float phi = std::atan2(dir.y, dir.x);
-    float theta = std::acos(std::min(std::max(dir.z, -1.f), 1.f));
-    encodedDirection = vec2{ theta, phi };
+// A photon's direction is stored as (polar angle from +z, azimuth from +x): photondata.cpp:100-117, the host twin of the
+// kernels' encodeDirection / decodeDirection.
+void Photon::setDirection(vec3 d) {
+    const float cosPolar = d.z < -1.f ? -1.f : (d.z > 1.f ? 1.f : d.z);
+    encodedDirection = vec2{ std::acos(cosPolar), std::atan2(d.y, d.x) };
 }
 vec3 Photon::getDirection() const {
-    return vec3{ std::sin(encodedDirection.x) * std::cos(encodedDirection.y), std::sin(encodedDirection.x) * std::sin(encodedDirection.y),
-                 std::cos(encodedDirection.x) };
+    const float polar = encodedDirection.x, azimuth = encodedDirection.y, ring = std::sin(polar);
+    return vec3{ ring * std::cos(azimuth), ring * std::sin(azimuth), std::cos(polar) };
 }
 
-const double PhotonData::scaleToMakeLightPowerOfOneVisibleForDirectionalLightSource = 1. / M_PI;  // photondata.cpp:38
-void PhotonData::setSize(size_t numberOfPhotons, int maxPhotonInteractions) {  // :53-59
-    maxPhotonInteractions_ = maxPhotonInteractions;
-    if (numberOfPhotons > 0) photons_.setSize(numberOfPhotons * 2 * maxPhotonInteractions);
+// PhotonData (photondata.cpp:36-98): record storage is two vec4 per photon and interaction; the radius is kept in world units
+// and handed out relative to the scene; the progressive schedule is Knaus & Zwicker's r' = r ((i + alpha) / (i + 1))^(1/3).
+const double PhotonData::scaleToMakeLightPowerOfOneVisibleForDirectionalLightSource = 1. / M_PI;
+void PhotonData::setSize(size_t count, int interactions) {
+    maxPhotonInteractions_ = interactions;
+    if (count != 0) photons_.setSize(count * 2 * interactions);
 }
-void PhotonData::setRadius(double radiusRelativeToSceneSize, double sceneRadius) {  // :61-65
-    sceneRadius_ = sceneRadius;
-    worldSpaceRadius_ = radiusRelativeToSceneSize * sceneRadius;
+void PhotonData::setRadius(double relativeToScene, double sceneExtent) {
+    sceneRadius_ = sceneExtent;
+    worldSpaceRadius_ = relativeToScene * sceneExtent;
 }
-void PhotonData::advanceToNextIteration(double alpha) {  // :67-70
-    setRadius(progressiveSphereRadius(getRadius(), iteration_, alpha));
-    iteration_++;
+void PhotonData::advanceToNextIteration(double alpha) {
+    const double shrunk = progressiveSphereRadius(getRadius(), iteration_, alpha);
+    setRadius(shrunk);
+    ++iteration_;
 }
-double PhotonData::progressiveSphereRadius(double radius, int iteration, double alpha) {  // :72-77 (Knaus & Zwicker eq. 20)
-    return radius * std::pow(((double)iteration + alpha) / (1.0 + (double)iteration), 1. / 3.);
+double PhotonData::progressiveSphereRadius(double r, int i, double alpha) {
+    const double ratio = ((double)i + alpha) / (1.0 + (double)i);
+    return r * std::pow(ratio, 1. / 3.);
 }
-double PhotonData::sphereVolume(double radius) { return std::pow(radius, 3) * (M_PI * 4. / 3.); }  // :79-81
+double PhotonData::sphereVolume(double r) {
+    const double unitBall = M_PI * 4. / 3.;
+    return std::pow(r, 3) * unitBall;
+}
 
 std::shared_ptr<Mesh> Mesh::unitCube() { return box(vec3(0.f, 0.f, 0.f), vec3(1.f, 1.f, 1.f)); }
 // the proxy geometry CubeProxyGeometry emits for clip ranges lo..hi (data space): 8 corners, 12 triangles
@@ -149,105 +158,42 @@ std::shared_ptr<Mesh> Mesh::box(vec3 lo, vec3 hi) {
     return m;
 }
 
-// ---- host geometry --------------------------------------------------------------------------------------
+// ---- host geometry ----------------------------------------------------------------------------------------
+// The reference's entry points (lightcl/*.h) over this build's own host arithmetic: host/cpm_hostmath.cpp.
 
 namespace geometry {
 
-void projectPointsOnPlane(const std::vector<vec3>& points, const Plane& plane, vec3 u, vec3 v, std::vector<vec2>& out) {
-    vec3 n = plane.normal;
-    float d = dot(n, plane.point);
-    out.reserve(points.size());
-    for (const auto& elem : points) {
-        float distanceFromPlane = dot(n, elem) - d;
-        vec3 projectedPoint = elem - distanceFromPlane * n;
-        vec3 originToProjectedPoint = projectedPoint - plane.point;
-        out.push_back(vec2{ dot(u, originToProjectedPoint), dot(v, originToProjectedPoint) });
-    }
+namespace {
+std::vector<cpm_host::Pt2> toHost(const std::vector<vec2>& in) {
+    std::vector<cpm_host::Pt2> out(in.size());
+    for (size_t i = 0; i < in.size(); ++i) out[i] = { in[i].x, in[i].y };
+    return out;
 }
-
-std::vector<vec2> convexHull2D(std::vector<vec2> points) {
-    std::sort(points.begin(), points.end(), [](vec2 a, vec2 b) { return a.x != b.x ? a.x < b.x : a.y < b.y; });
-    if (points.size() < 4) return points;
-    auto isPointLeftOfLine = [](vec2 p0, vec2 p1, vec2 p) { return (p1.x - p0.x) * (p.y - p0.y) - (p.x - p0.x) * (p1.y - p0.y); };
-    const int n = (int)points.size();
-    int minXMinYId = 0, minXMaxYId = 1;
-    for (; minXMaxYId < n; ++minXMaxYId) if (points[0].x != points[minXMaxYId].x) break;
-    --minXMaxYId;
-    if (minXMaxYId == n - 1) {
-        std::vector<vec2> hull{ points[minXMinYId] };
-        if (points[minXMaxYId].y != points[minXMinYId].y) hull.push_back(points[minXMaxYId]);
-        hull.push_back(points[minXMinYId]);
-        return hull;
-    }
-    int maxXMinYId = n - 1, maxXMaxYId = n - 2;  // names as in the reference (convexhull2d.cpp:84-91)
-    for (; maxXMaxYId >= 0; --maxXMaxYId) if (points[n - 1].x > points[maxXMaxYId].x) break;
-    ++maxXMaxYId;
-    std::vector<vec2> hull{ points[minXMinYId] };
-    for (int i = minXMaxYId + 1; i <= maxXMinYId; ++i) {
-        if (isPointLeftOfLine(points[minXMinYId], points[maxXMinYId], points[i]) >= 0 && i < maxXMinYId) continue;
-        while (hull.size() >= 2) {
-            if (isPointLeftOfLine(hull[hull.size() - 2], hull[hull.size() - 1], points[i]) > 0) break;
-            hull.pop_back();
-        }
-        hull.push_back(points[i]);
-    }
-    if (maxXMaxYId != maxXMinYId) hull.push_back(points[maxXMaxYId]);
-    size_t bottomHull = hull.size() - 1;
-    for (int i = maxXMaxYId; i > minXMaxYId; --i) {
-        if (isPointLeftOfLine(points[maxXMaxYId], points[minXMaxYId], points[i]) >= 0 && i > minXMaxYId) continue;
-        while (hull.size() - bottomHull >= 2) {
-            if (isPointLeftOfLine(hull[hull.size() - 2], hull[hull.size() - 1], points[i]) > 0) break;
-            hull.pop_back();
-        }
-        hull.push_back(points[i]);
-    }
-    if (minXMaxYId != minXMinYId) hull.push_back(points[maxXMinYId]);
-    return hull;
+std::vector<cpm_host::Pt3> toHost(const std::vector<vec3>& in) {
+    std::vector<cpm_host::Pt3> out(in.size());
+    for (size_t i = 0; i < in.size(); ++i) out[i] = { in[i].x, in[i].y, in[i].z };
+    return out;
 }
+inline cpm_host::Pt3 toHost(vec3 p) { return { p.x, p.y, p.z }; }
+inline vec3 fromHost(cpm_host::Pt3 p) { return vec3(p.x, p.y, p.z); }
+inline vec2 fromHost(cpm_host::Pt2 p) { return vec2{ p.x, p.y }; }
+}  // namespace
 
+void projectPointsOnPlane(const std::vector<vec3>& pts, const Plane& in, vec3 axis0, vec3 axis1, std::vector<vec2>& coords) {
+    for (cpm_host::Pt2 c : cpm_host::planeCoordinates(toHost(pts), toHost(in.point), toHost(in.normal), toHost(axis0), toHost(axis1))) coords.push_back(fromHost(c));
+}
+std::vector<vec2> convexHull2D(std::vector<vec2> pts) {
+    std::vector<vec2> out;
+    for (cpm_host::Pt2 c : cpm_host::hullCycle(toHost(pts))) out.push_back(fromHost(c));
+    return out;
+}
 std::tuple<vec2, vec2, vec2> mimumBoundingRectangle(const std::vector<vec2>& hull) {
-    float minArea = FLT_MAX;
-    vec2 origin, u, v;
-    const size_t nPoints = hull.size();
-    for (size_t i = 0, j = nPoints - 1; i < nPoints; j = i, ++i) {
-        vec2 e{ hull[i].x - hull[j].x, hull[i].y - hull[j].y };
-        float len = std::sqrt(e.x * e.x + e.y * e.y);
-        vec2 e0{ e.x / len, e.y / len };
-        if (std::isnan(e0.x) || std::isnan(e0.y)) continue;
-        vec2 e1{ -e0.y, e0.x };
-        float min0 = 0.f, min1 = 0.f, max0 = 0.f, max1 = 0.f;
-        for (size_t k = 0; k < nPoints; ++k) {
-            vec2 d{ hull[k].x - hull[j].x, hull[k].y - hull[j].y };
-            float t = d.x * e0.x + d.y * e0.y;
-            min0 = std::min(min0, t); max0 = std::max(max0, t);
-            t = d.x * e1.x + d.y * e1.y;
-            min1 = std::min(min1, t); max1 = std::max(max1, t);
-        }
-        float area = (max0 - min0) * (max1 - min1);
-        if (area < minArea) {
-            minArea = area;
-            float a = std::min(min0, 0.f), b = std::min(min1, 0.f);
-            origin = vec2{ hull[j].x + a * e0.x + b * e1.x, hull[j].y + a * e0.y + b * e1.y };
-            u = vec2{ e0.x * (max0 - min0), e0.y * (max0 - min0) };
-            v = vec2{ e1.x * (max1 - min1), e1.y * (max1 - min1) };
-        }
-    }
-    return std::make_tuple(origin, u, v);
+    const cpm_host::Rectangle2 r = cpm_host::smallestRectangle(toHost(hull));
+    return std::make_tuple(fromHost(r.corner), fromHost(r.side0), fromHost(r.side1));
 }
-
-std::tuple<vec3, vec3, vec3> fitPlaneAlignedOrientedBoundingBox2D(const std::vector<vec3>& points, const Plane& plane) {
-    auto projectPoint = [&](vec3 p) { return p - (dot(plane.normal, p) - dot(plane.normal, plane.point)) * plane.normal; };
-    vec3 u, v;
-    if (std::fabs(plane.normal.x) > std::fabs(plane.normal.y)) u = normalize(projectPoint(vec3(1.f, 0.f, 0.f)) - plane.point);
-    else u = normalize(projectPoint(vec3(0.f, 1.f, 0.f)) - plane.point);
-    v = normalize(cross(plane.normal, u));
-    std::vector<vec2> projected;
-    projectPointsOnPlane(points, plane, u, v, projected);
-    auto hull = convexHull2D(projected);
-    vec2 bo, bu, bv;
-    std::tie(bo, bu, bv) = mimumBoundingRectangle(hull);
-    vec3 origin = plane.point + bo.x * u + bo.y * v;
-    return std::make_tuple(origin, bu.x * u + bu.y * v, bv.x * u + bv.y * v);
+std::tuple<vec3, vec3, vec3> fitPlaneAlignedOrientedBoundingBox2D(const std::vector<vec3>& pts, const Plane& in) {
+    const cpm_host::LightRectangle r = cpm_host::fitLightRectangle(toHost(pts), toHost(in.point), toHost(in.normal));
+    return std::make_tuple(fromHost(r.origin), fromHost(r.u), fromHost(r.v));
 }
 
 }  // namespace geometry
@@ -311,6 +257,18 @@ PhotonTracerCL::~PhotonTracerCL() {
     for (auto& lo : launchOrders_) if (lo.second.order) cpm_trace_order_destroy(rt.ctx(), lo.second.order);
     if (allLightsOrder_.order) cpm_trace_order_destroy(rt.ctx(), allLightsOrder_.order);
 }
+namespace {
+// a per-photon side buffer (importance keys, ...) follows the photon count
+template <typename T>
+void onePerPhoton(Buffer<T>& buffer, const PhotonData& photons) {
+    const size_t n = photons.getNumberOfPhotons();
+    if (buffer.getSize() != n) buffer.setSize(n);
+}
+}  // namespace
+void PhotonTracerCL::seedStreamsFor(const PhotonData& photons) {  // one RNG stream per photon, seeded when the count changes (photontracercl.cpp:71-73)
+    const size_t n = photons.getNumberOfPhotons();
+    if (randomState_.getSize() != n) setRandomSeedSize(n);
+}
 void PhotonTracerCL::setRandomSeedSize(size_t nPhotons) {
     if (nPhotons > 0) {
         randomState_.setSize(nPhotons);
@@ -343,7 +301,7 @@ void PhotonTracerCL::tracePhotons(const Volume* volume, const TransferFunction& 
                                   int maxInteractions, PhotonData* photonOutData) {
     auto& rt = CpmRuntime::get();
     if (!rt.valid()) return;
-    if (randomState_.getSize() != photonOutData->getNumberOfPhotons()) setRandomSeedSize(photonOutData->getNumberOfPhotons());
+    seedStreamsFor(*photonOutData);
     cpm_volume* vol_ = volume->getDeviceRepresentation();  // volume->getRepresentation<VolumeCL>() (:111)
     syncTF(transferFunction);
     if (!vol_ || !tf_) return;
@@ -407,7 +365,7 @@ bool PhotonTracerCL::tracePhotonsAllLights(const Volume* volume, const TransferF
                                            int maxInteractions, PhotonData* photonOutData) {
     auto& rt = CpmRuntime::get();
     if (!rt.valid() || lights.size() < 2 || lights.size() > (size_t)CPM_MAX_TRACE_LIGHTS) return false;
-    if (randomState_.getSize() != photonOutData->getNumberOfPhotons()) setRandomSeedSize(photonOutData->getNumberOfPhotons());
+    seedStreamsFor(*photonOutData);
     cpm_volume* vol_ = volume->getDeviceRepresentation();
     syncTF(transferFunction);
     if (!vol_ || !tf_) return false;
@@ -478,7 +436,7 @@ void PhotonTracerCL::tracePhotonsSelected(const Volume* volume, const TransferFu
                                           unsigned int* resetImportances, int photonOffset, int maxInteractions, PhotonData* photonOutData) {
     auto& rt = CpmRuntime::get();
     if (!rt.valid()) return;
-    if (randomState_.getSize() != photonOutData->getNumberOfPhotons()) setRandomSeedSize(photonOutData->getNumberOfPhotons());
+    seedStreamsFor(*photonOutData);
     cpm_volume* vol_ = volume->getDeviceRepresentation();
     syncTF(transferFunction);
     if (!vol_ || !tf_) return;
@@ -506,8 +464,8 @@ bool PhotonTracerCL::importanceRetrace(cpm_selection* selection, const Volume* v
                                        int photonOffset, int maxInteractions, bool fixExitPoint, PhotonData* photonOutData) {
     auto& rt = CpmRuntime::get();
     if (!rt.valid()) return false;
-    if (randomState_.getSize() != photonOutData->getNumberOfPhotons()) setRandomSeedSize(photonOutData->getNumberOfPhotons());
-    if (importances.getSize() != photonOutData->getNumberOfPhotons()) importances.setSize(photonOutData->getNumberOfPhotons());
+    seedStreamsFor(*photonOutData);
+    onePerPhoton(importances, *photonOutData);
     cpm_volume* vol_ = volume->getDeviceRepresentation();
     syncTF(transferFunction);
     if (!vol_ || !tf_) return false;
@@ -546,8 +504,8 @@ int PhotonTracerCL::importanceRetraceAllLights(cpm_selection* selection, const V
                                                vec4* replacedPhotons, int maxInteractions, bool fixExitPoint, PhotonData* photonOutData) {
     auto& rt = CpmRuntime::get();
     if (!rt.valid() || lights.size() < 2 || lights.size() > (size_t)CPM_MAX_TRACE_LIGHTS) return -1;
-    if (randomState_.getSize() != photonOutData->getNumberOfPhotons()) setRandomSeedSize(photonOutData->getNumberOfPhotons());
-    if (importances.getSize() != photonOutData->getNumberOfPhotons()) importances.setSize(photonOutData->getNumberOfPhotons());
+    seedStreamsFor(*photonOutData);
+    onePerPhoton(importances, *photonOutData);
     cpm_volume* vol_ = volume->getDeviceRepresentation();
     syncTF(transferFunction);
     if (!vol_ || !tf_) return 0;
@@ -590,7 +548,7 @@ bool PhotonRecomputationDetector::photonRecomputationImportanceSelect(cpm_select
                                                                       const LightSamples& lightSamples, Buffer<unsigned int>& imp, bool fixExitPoint) {
     auto& rt = CpmRuntime::get();
     if (!rt.valid()) return false;
-    if (imp.getSize() != photonData->getNumberOfPhotons()) imp.setSize(photonData->getNumberOfPhotons());
+    onePerPhoton(imp, *photonData);
     if (getEqualImportance()) {
         return rt.check(cpm_photon_importance_equal_select(rt.ctx(), selection, photonOffset, (int)lightSamples.getSize(), getPercentage(), getIteration(),
                                                            imp.device(), rt.stream()), "cpm_photon_importance_equal_select");
@@ -617,7 +575,7 @@ void PhotonRecomputationDetector::photonRecomputationImportance(const PhotonData
                                                                 Buffer<unsigned int>& imp) {
     auto& rt = CpmRuntime::get();  // photonrecomputationdetector.cpp:49-121 (size check fixed: Q11)
     if (!rt.valid()) return;
-    if (imp.getSize() != photonData->getNumberOfPhotons()) imp.setSize(photonData->getNumberOfPhotons());
+    onePerPhoton(imp, *photonData);
     if (getEqualImportance()) {
         rt.check(cpm_photon_importance_equal(rt.ctx(), photonOffset, (int)lightSamples.getSize(), getPercentage(), getIteration(), imp.device(), rt.stream()),
                  "cpm_photon_importance_equal");
@@ -738,10 +696,6 @@ void MinMaxUniformGrid3DImportanceCLProcessor::setTransferFunction(const Transfe
     transferFunction_ = tf;
     tfChanged_ = true;
 }
-vec4 MinMaxUniformGrid3DImportanceCLProcessor::tfPointColorDiff(const vec4& p1, const vec4& p2) const {
-    const float s1 = useAssociatedColor_ ? p1.w : 1.f, s2 = useAssociatedColor_ ? p2.w : 1.f;
-    return vec4(std::fabs(p2.x * s2 - p1.x * s1), std::fabs(p2.y * s2 - p1.y * s1), std::fabs(p2.z * s2 - p1.z * s1), std::fabs(p2.w * s2 - p1.w * s1));
-}
 void MinMaxUniformGrid3DImportanceCLProcessor::updateTransferFunctionData() {
     positions_.clear(); colors_.clear();
     const auto& tf = transferFunction_;
@@ -752,49 +706,25 @@ void MinMaxUniformGrid3DImportanceCLProcessor::updateTransferFunctionData() {
     if (tf.get(tf.size() - 1).pos < 1.) { positions_.push_back(1.f); colors_.push_back(col(tf.get(tf.size() - 1))); }
 }
 void MinMaxUniformGrid3DImportanceCLProcessor::updateTransferFunctionDifferenceData() {
-    positions_.clear(); colors_.clear();
-    const auto& tf = transferFunction_.points();
-    const auto& prev = prevTransferFunction_.points();
-    if (tf.empty() && prev.empty()) { positions_ = { 0.f, 0.f }; colors_ = { vec4(), vec4() }; return; }
-    const float eps = TFPointEpsilon_.get();
-    auto ne0 = [&](const vec4& c) { return std::fabs(c.x) > eps || std::fabs(c.y) > eps || std::fabs(c.z) > eps || std::fabs(c.w) > eps; };
-    auto mixT = [](const TFPrimitive& a, const TFPrimitive& b, double t) {
-        const float tf_ = (float)t;
-        return TFPrimitive{ a.pos + (b.pos - a.pos) * t, vec4(a.color.x + (b.color.x - a.color.x) * tf_, a.color.y + (b.color.y - a.color.y) * tf_,
-                                                              a.color.z + (b.color.z - a.color.z) * tf_, a.color.w + (b.color.w - a.color.w) * tf_) };
+    // minmaxuniformgrid3dimportanceclprocessor.cpp:364-501, through this build's own statement of it (cpm_hostmath.cpp, rule D)
+    auto nodes = [](const TransferFunction& f) {
+        std::vector<cpm_host::TfNode> v(f.size());
+        for (size_t i = 0; i < v.size(); ++i) {
+            const TFPrimitive& q = f.get(i);
+            v[i].pos = q.pos;
+            const float c[4] = { q.color.x, q.color.y, q.color.z, q.color.w };
+            std::memcpy(v[i].rgba, c, sizeof c);
+        }
+        return v;
     };
-    auto mixAt = [&](const TFPrimitive& a, const TFPrimitive& b, const TFPrimitive& at) { return mixT(a, b, (at.pos - a.pos) / (b.pos - a.pos)); };
-    const TFPrimitive first = tf.front(), pfirst = prev.front();
-    TFPrimitive p1, p2;
-    p1 = p2 = TFPrimitive{ first.pos < pfirst.pos ? first.pos : pfirst.pos, tfPointColorDiff(first.color, pfirst.color) };
-    if (first.pos != pfirst.pos && first.color.w == 0.f && pfirst.color.w == 0.f) {
-        if (first.pos < pfirst.pos) {
-            const TFPrimitive a2 = tf[std::min<size_t>(1, tf.size() - 1)];
-            p2 = TFPrimitive{ pfirst.pos, tfPointColorDiff(pfirst.color, mixAt(first, a2, pfirst).color) };
-        } else {
-            const TFPrimitive a2 = prev[std::min<size_t>(1, prev.size() - 1)];
-            p2 = TFPrimitive{ first.pos, tfPointColorDiff(first.color, mixAt(pfirst, a2, first).color) };
-        }
+    cpm_host::TfBreakpoints list;
+    if (!cpm_host::tfDifference(nodes(transferFunction_), nodes(prevTransferFunction_), TFPointEpsilon_.get(), useAssociatedColor_, list)) {
+        updateTransferFunctionData();  // one of the two is empty: no difference function, classify with the function itself
+        return;
     }
-    positions_.push_back(0.f);
-    colors_.push_back((p1.pos > 0. && (first.color.w > 0.f || pfirst.color.w > 0.f) && ne0(p1.color)) ? p1.color : vec4());
-    size_t id = 0, prevId = 0;
-    while (id < tf.size() || prevId < prev.size()) {
-        if ((ne0(p1.color) || ne0(p2.color)) && (p1.color.w > 0.f || p2.color.w > 0.f)) {
-            if (positions_.size() == 1) { positions_.push_back((float)p1.pos); colors_.push_back(p1.color); }
-            positions_.push_back((float)p2.pos); colors_.push_back(p2.color);
-        }
-        const TFPrimitive a1 = tf[std::min(id, tf.size() - 1)];
-        const TFPrimitive a2 = (id + 1 + 1 < tf.size()) ? tf[id + 1] : TFPrimitive{ 1., tf.back().color };
-        const TFPrimitive b1 = prev[std::min(prevId, prev.size() - 1)];
-        const TFPrimitive b2 = (prevId + 1 + 1 < prev.size()) ? prev[prevId + 1] : TFPrimitive{ 1., prev.back().color };
-        p1 = p2;
-        if (a2.pos < b2.pos) { p2 = TFPrimitive{ a2.pos, tfPointColorDiff(a2.color, mixAt(b1, b2, a2).color) }; ++id; }
-        else if (b2.pos < a2.pos) { p2 = TFPrimitive{ b2.pos, tfPointColorDiff(b2.color, mixAt(a1, a2, b2).color) }; ++prevId; }
-        else { p2 = TFPrimitive{ a2.color.w < b2.color.w ? b2.pos : a2.pos, tfPointColorDiff(a2.color, b2.color) }; ++id; ++prevId; }
-    }
-    if (p2.pos < 1. && p2.color.w > 0.f) { positions_.push_back((float)p2.pos); colors_.push_back(p2.color); }
-    if (positions_.back() < 1.f) { positions_.push_back(1.f); colors_.push_back(vec4()); }
+    positions_ = list.pos;
+    colors_.resize(list.size());
+    for (size_t i = 0; i < list.size(); ++i) colors_[i] = vec4(list.rgba[4 * i], list.rgba[4 * i + 1], list.rgba[4 * i + 2], list.rgba[4 * i + 3]);
 }
 void MinMaxUniformGrid3DImportanceCLProcessor::process() {  // minmaxuniformgrid3dimportanceclprocessor.cpp:110-216
     auto& rt = CpmRuntime::get();
@@ -850,19 +780,26 @@ ProgressivePhotonTracerCL::ProgressivePhotonTracerCL() {
                                                                 &equalImportancePercentage_, &importanceBranchPolicy_, &retraceInImportancePass_, &traceLightsInOneLaunch_ })
         addProperty(*p);
     addProperty(advancedMaterial_); addProperty(camera_); addProperty(invalidateRendering_); addProperty(transferFunctionProperty_);
-    transferFunctionProperty_.onChange([this]() { setTransferFunction(transferFunctionProperty_.get()); });             // tracercl.cpp:148
-    camera_.onChange([this]() { invalidateProgressiveRendering(PhotonData::InvalidationReason::Camera); });            // :161-165
-    invalidateRendering_.onChange([this]() { invalidateProgressiveRendering(PhotonData::InvalidationReason::All); });  // :172, 612-615
-    advancedMaterial_.onChange([this]() { invalidateProgressiveRendering(PhotonData::InvalidationReason::All); });     // kernelArgChanged
+    // what an edit of each property invalidates (progressivephotontracercl.cpp:137-188): the camera only the view-dependent part,
+    // material / scattering depth / the "invalidate" button and the clip ranges everything
+    using Why = PhotonData::InvalidationReason;
+    auto invalidates = [this](PropertyBase& edited, Why why) { edited.onChange([this, why]() { invalidateProgressiveRendering(why); }); };
+    invalidates(camera_, Why::Camera);
+    for (PropertyBase* edited : std::initializer_list<PropertyBase*>{ &invalidateRendering_, &advancedMaterial_, &maxScatteringEvents_ }) invalidates(*edited, Why::All);
+    for (PropertyBase* range : std::initializer_list<PropertyBase*>{ &clipX_, &clipY_, &clipZ_ }) range->onChange(std::bind(&ProgressivePhotonTracerCL::onClipChange, this));
+    transferFunctionProperty_.onChange([this]() { setTransferFunction(transferFunctionProperty_.get()); });
     equalIncrementalImportance_.onChange([this]() { photonRecomputationDetector_.setEqualImportance(equalIncrementalImportance_.get()); });
     noSingleScattering_.onChange([this]() { photonTracer_.setNoSingleScattering(noSingleScattering_.get()); });
-    maxScatteringEvents_.onChange([this]() { invalidateProgressiveRendering(PhotonData::InvalidationReason::All); });
-    clipX_.onChange([this]() { onClipChange(); });
-    clipY_.onChange([this]() { onClipChange(); });
-    clipZ_.onChange([this]() { onClipChange(); });
 }
 ProgressivePhotonTracerCL::~ProgressivePhotonTracerCL() {
     if (selection_) cpm_selection_destroy(CpmRuntime::get().ctx(), selection_);
+}
+// the end of every evaluation: both outports carry their data, the reasons collected since the last one travel with the photons
+void ProgressivePhotonTracerCL::publishPhotons() {
+    recomputedIndicesPort_.setData(recomputedPhotonIndices_);
+    photonData_->setInvalidationReason(invalidationFlag_);
+    invalidationFlag_ = PhotonData::InvalidationReason(0);
+    outport_.setData(photonData_);
 }
 void ProgressivePhotonTracerCL::onClipChange() {  // progressivephotontracercl.cpp:672-686
     if (!volumePort_.isReady()) return;
@@ -984,10 +921,7 @@ void ProgressivePhotonTracerCL::process() {  // progressivephotontracercl.cpp:21
             remainingPhotonsToUpdate_ = 0;
             remainingPhotonsOffset_ = 0;
             enableProgressiveRefinement_.set(false);
-            recomputedIndicesPort_.setData(recomputedPhotonIndices_);
-            photonData_->setInvalidationReason(invalidationFlag_);
-            invalidationFlag_ = PhotonData::InvalidationReason(0);
-            outport_.setData(photonData_);
+            publishPhotons();
             if (rt.profiling()) rt.logProfile("Photon tracing");
         };
         if (takeFullFrame) {
@@ -1071,10 +1005,7 @@ void ProgressivePhotonTracerCL::process() {  // progressivephotontracercl.cpp:21
             remainingPhotonsOffset_ = 0;
             remainingPhotonsToUpdate_ = 0;  // everything changed was traced
             enableProgressiveRefinement_.set(false);
-            recomputedIndicesPort_.setData(recomputedPhotonIndices_);
-            photonData_->setInvalidationReason(invalidationFlag_);
-            invalidationFlag_ = PhotonData::InvalidationReason(0);
-            outport_.setData(photonData_);
+            publishPhotons();
             if (rt.profiling()) {
                 rt.logProfile("Photon tracing");
                 const int nr = rec.resolveCount();
@@ -1148,10 +1079,7 @@ void ProgressivePhotonTracerCL::process() {  // progressivephotontracercl.cpp:21
         if (photonRecomputationImportance_.getSize() > 0) resetPhotonImportance(0, photonRecomputationImportance_.getSize());
     }
     (void)nPhotonsToCompute;
-    recomputedIndicesPort_.setData(recomputedPhotonIndices_);
-    photonData_->setInvalidationReason(invalidationFlag_);
-    invalidationFlag_ = PhotonData::InvalidationReason(0);
-    outport_.setData(photonData_);
+    publishPhotons();
     if (rt.profiling()) {  // "Photon tracing: ... = X ms", "Computed photons: n = p %" (tracercl.cpp:562-598)
         rt.logProfile("Photon tracing");
         const int nr = recomputedPhotonIndices_->nRecomputedPhotons;

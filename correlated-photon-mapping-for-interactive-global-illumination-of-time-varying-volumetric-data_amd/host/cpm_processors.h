@@ -368,6 +368,7 @@ public:
                               const Buffer<unsigned int>* indices, const int32_t* nIndicesDevice, int maxIndices, vec4* replacedPhotons,
                               unsigned int* resetImportances, int photonOffset, int maxInteractions, PhotonData* photonOutData);
     void setRandomSeedSize(size_t nPhotons);   // :176-182
+    void seedStreamsFor(const PhotonData& photons);
     Buffer<uvec2>& randomState() { return randomState_; }
     // Bring the device LUT up to date with `tf` (one small launch, no host wait).  Called at the top of the tracer processor's
     // evaluation; tracePhotons* call it too (a no-op then).
@@ -492,7 +493,6 @@ public:
 private:
     void updateTransferFunctionData();            // :304-362
     void updateTransferFunctionDifferenceData();  // :364-501
-    vec4 tfPointColorDiff(const vec4& p1, const vec4& p2) const;  // :503-507
     TransferFunction transferFunction_, prevTransferFunction_;
     bool tfChanged_ = false;
     std::shared_ptr<const MinMaxUniformGrid3D> prevMinMaxUniformGrid3D_;  // .h:126: the grid of the previous evaluation (time-varying data)
@@ -571,6 +571,7 @@ private:
     PathCosts costs_;
     const char* lastDecision_ = "none";
     void onClipChange();
+    void publishPhotons();
     float getSceneRadius() const { return 0.5f * std::sqrt(12.f); }  // unit-model volume spanning [-1, 1]^3
     void resetPhotonImportance(size_t offset, size_t n);
     std::shared_ptr<PhotonData> photonData_ = std::make_shared<PhotonData>();

@@ -3,79 +3,119 @@
 
 #include <algorithm>
 #include <fstream>
+#include <functional>
+#include <map>
 #include <sstream>
 
 namespace inviwo {
 
 namespace {
 
-std::string trim(const std::string& s) {
-    size_t a = s.find_first_not_of(" \t\r\n"), b = s.find_last_not_of(" \t\r\n");
-    return a == std::string::npos ? std::string() : s.substr(a, b - a + 1);
-}
-std::string toLower(std::string s) {
-    std::transform(s.begin(), s.end(), s.begin(), [](unsigned char c) { return (char)std::tolower(c); });
-    return s;
-}
-std::vector<std::string> splitString(const std::string& s, char d) {
-    std::vector<std::string> out;
-    std::stringstream ss(s);
-    std::string item;
-    while (std::getline(ss, item, d)) out.push_back(item);
-    if (out.empty()) out.push_back("");
-    return out;
-}
-std::string parentPath(const std::string& p) {
-    size_t i = p.find_last_of('/');
-    return i == std::string::npos ? std::string() : p.substr(0, i + 1);
-}
-std::string replaceExtension(const std::string& p, const std::string& ext) {
-    size_t slash = p.find_last_of('/'), dot = p.find_last_of('.');
-    if (dot == std::string::npos || (slash != std::string::npos && dot < slash)) return p + "." + ext;
-    return p.substr(0, dot + 1) + ext;
-}
-std::string stem(const std::string& p) {
-    size_t slash = p.find_last_of('/');
-    std::string name = slash == std::string::npos ? p : p.substr(slash + 1);
-    size_t dot = name.find_last_of('.');
-    return dot == std::string::npos ? name : name.substr(0, dot);
-}
-bool fileExists(const std::string& p) { return std::ifstream(p).good(); }
+// ---- the .u3d format, as this build states it -----------------------------------------------------------------------------
+// A sequence of uniform grids is a text header <name>.u3d beside <name>.raw, the elements' data back to back.  Header: one
+// "Key: value" per line, keys case-blind; blank lines and lines opening with '#' or '/' are skipped, text behind a '#' is
+// dropped, and a line that does not split into exactly one key and one value at ':' is ignored.  Keys:
+//   RawFile | ObjectFileName   the data file, relative to the header's directory
+//   Resolution | Dimensions    nx ny nz count
+//   Format                     element type by Inviwo's format name (Vec2UINT16 = min/max grid, FLOAT32 = float grid)
+//   ModelMatrix, WorldMatrix   sixteen numbers, rows first (the matrices are held columns first)
+//   CellDimensions             voxels per cell, per axis
+// (uniformgridcl/uniformgrid3dwriter.cpp:47-102 writes it, uniformgrid3dreader.cpp:59-183 reads it.)
 
-// glm::transpose(m) streamed row by row == the column-major matrix read row-wise
-void writeMatrix(std::ostream& ss, const char* key, const mat4& m) {
-    ss << key << ":";
-    for (int r = 0; r < 4; ++r)
-        for (int c = 0; c < 4; ++c) ss << " " << m[c * 4 + r];
-    ss << "\n";
+std::string stripped(const std::string& text) {
+    const char* blanks = " \t\r\n";
+    const size_t first = text.find_first_not_of(blanks);
+    if (first == std::string::npos) return {};
+    return text.substr(first, text.find_last_not_of(blanks) - first + 1);
 }
-mat4 readMatrix(std::stringstream& ss) {  // uniformgrid3dreader.cpp:100-115: mat[i][j] in stream order, then transpose
-    mat4 m = identityMatrix();
-    for (int i = 0; i < 4; ++i)
-        for (int j = 0; j < 4; ++j) {
-            float v = 0;
-            ss >> v;
-            m[j * 4 + i] = v;
+
+struct PathParts {
+    std::string folder, name;  // folder keeps its trailing '/', name has no extension
+    explicit PathParts(const std::string& path) {
+        const size_t cut = path.find_last_of('/');
+        folder = cut == std::string::npos ? std::string() : path.substr(0, cut + 1);
+        name = path.substr(folder.size());
+        const size_t dot = name.find_last_of('.');
+        if (dot != std::string::npos) name.erase(dot);
+    }
+    std::string sibling(const char* extension) const { return folder + name + "." + extension; }
+};
+
+bool readable(const std::string& path) { return std::ifstream(path).good(); }
+
+struct U3dHeader {
+    std::string dataFile, format;
+    size_t extent[4] = { 0, 0, 0, 0 };  // nx ny nz count
+    mat4 model = identityMatrix(), world = identityMatrix();
+    size3_t cell{ 0, 0, 0 };
+    bool formatSeen = false;
+
+    static void rowsFirst(std::istream& in, mat4& m) {
+        for (int row = 0; row < 4; ++row)
+            for (int col = 0; col < 4; ++col) {
+                float value = 0.f;
+                in >> value;
+                m[(size_t)col * 4 + row] = value;
+            }
+    }
+    static void rowsFirst(std::ostream& os, const char* key, const mat4& m) {
+        os << key << ":";
+        for (int row = 0; row < 4; ++row)
+            for (int col = 0; col < 4; ++col) os << " " << m[(size_t)col * 4 + row];
+        os << "\n";
+    }
+
+    // one header line, its key already lower-cased
+    void take(const std::string& key, const std::string& value, const std::string& folder) {
+        enum Field { DataFile, Extent, Format, Model, World, Cell };
+        static const std::map<std::string, Field> fields = { { "rawfile", DataFile }, { "objectfilename", DataFile }, { "resolution", Extent },
+                                                              { "dimensions", Extent }, { "format", Format }, { "modelmatrix", Model },
+                                                              { "worldmatrix", World }, { "celldimensions", Cell } };
+        const auto known = fields.find(key);
+        if (known == fields.end()) return;
+        std::istringstream in(value);
+        switch (known->second) {
+            case DataFile: dataFile = folder + value; break;
+            case Extent: for (size_t& e : extent) in >> e; break;
+            case Format: in >> format; formatSeen = true; break;
+            case Model: rowsFirst(in, model); break;
+            case World: rowsFirst(in, world); break;
+            case Cell: in >> cell.x >> cell.y >> cell.z; break;
         }
-    return m;
+    }
+
+    void parse(std::istream& text, const std::string& folder) {
+        for (std::string line; std::getline(text, line);) {
+            line = stripped(line);
+            const char lead = line.empty() ? '#' : line.front();
+            if (lead == '#' || lead == '/') continue;
+            line = line.substr(0, line.find('#'));
+            std::vector<std::string> fields;  // the pieces between colons; an empty piece at the very end does not count
+            for (size_t from = 0; from <= line.size();) {
+                const size_t colon = std::min(line.find(':', from), line.size());
+                if (colon < line.size() || colon > from) fields.push_back(line.substr(from, colon - from));
+                from = colon + 1;
+            }
+            if (fields.size() != 2) continue;
+            std::string key = stripped(fields[0]);
+            for (char& ch : key) ch = (char)std::tolower((unsigned char)ch);
+            take(key, stripped(fields[1]), folder);
+        }
+    }
+};
+
+// Inviwo's data-format names: scalar or VecN of these element types
+bool knownFormatName(std::string name) {
+    if (name.compare(0, 3, "Vec") == 0 && name.size() > 3 && name[3] >= '2' && name[3] <= '4') name.erase(0, 4);
+    for (const char* element : { "FLOAT16", "FLOAT32", "FLOAT64", "INT8", "INT16", "INT32", "INT64", "UINT8", "UINT16", "UINT32", "UINT64" })
+        if (name == element) return true;
+    return false;
 }
 
-std::shared_ptr<UniformGrid3DBase> makeGrid(const std::string& format) {
+std::shared_ptr<UniformGrid3DBase> gridOfFormat(const std::string& format) {
     if (format == "Vec2UINT16") return std::make_shared<MinMaxUniformGrid3D>();
     if (format == "FLOAT32") return std::make_shared<ImportanceUniformGrid3D>();
     return nullptr;
-}
-const char* const kValidFormats =
-    "FLOAT16, FLOAT32, FLOAT64, INT8, INT16, INT32, INT64, UINT8, UINT16, UINT32, UINT64, Vec2FLOAT16, Vec2FLOAT32, "
-    "Vec2FLOAT64, Vec2INT8, Vec2INT16, Vec2INT32, Vec2INT64, Vec2UINT8, Vec2UINT16, Vec2UINT32, Vec2UINT64, Vec3FLOAT16, "
-    "Vec3FLOAT32, Vec3FLOAT64, Vec3INT8, Vec3INT16, Vec3INT32, Vec3INT64, Vec3UINT8, Vec3UINT16, Vec3UINT32, Vec3UINT64, "
-    "Vec4FLOAT16, Vec4FLOAT32, Vec4FLOAT64, Vec4INT8, Vec4INT16, Vec4INT32, Vec4INT64, Vec4UINT8, Vec4UINT16, Vec4UINT32, "
-    "Vec4UINT64";
-bool isInviwoFormat(const std::string& f) {
-    std::stringstream ss(kValidFormats);
-    std::string item;
-    while (std::getline(ss, item, ',')) if (trim(item) == f) return true;
-    return false;
 }
 
 }  // namespace
@@ -83,90 +123,57 @@ bool isInviwoFormat(const std::string& f) {
 // ---- .u3d ---------------------------------------------------------------------------------------------
 
 void UniformGrid3DWriter::writeData(const UniformGrid3DVector* vectorData, const std::string& filePath) const {
-    if (!vectorData || vectorData->size() < 1) throw DataWriterException("Error: Cannot write empty vector");
-    const std::string rawPath = replaceExtension(filePath, "raw");
-    if (!overwrite_ && (fileExists(filePath) || fileExists(rawPath)))
-        throw DataWriterException("Error: File already exists and overwrite is off: " + filePath);
+    if (!vectorData || vectorData->empty()) throw DataWriterException("UniformGrid3DWriter: nothing to write (empty sequence)");
+    const PathParts where(filePath);
+    const std::string dataPath = where.sibling("raw");
+    if (!overwrite_ && (readable(filePath) || readable(dataPath)))
+        throw DataWriterException("UniformGrid3DWriter: " + filePath + " (or its .raw) exists and overwriting is switched off");
 
-    UniformGrid3DBase* data = vectorData->front().get();
-    std::stringstream ss;
-    ss.precision(9);
-    const size3_t dim = data->getDimensions(), cell = data->getCellDimension();
-    ss << "RawFile: " << stem(filePath) << ".raw\n";
-    ss << "Resolution: " << dim.x << " " << dim.y << " " << dim.z << " " << vectorData->size() << "\n";
-    ss << "Format: " << data->getDataFormatString() << "\n";
-    writeMatrix(ss, "ModelMatrix", data->getModelMatrix());
-    writeMatrix(ss, "WorldMatrix", data->getWorldMatrix());
-    ss << "CellDimensions: " << cell.x << " " << cell.y << " " << cell.z << "\n";
+    const UniformGrid3DBase& first = *vectorData->front();
+    const size3_t n = first.getDimensions(), c = first.getCellDimension();
+    std::ostringstream head;
+    head.precision(9);
+    head << "RawFile: " << where.name << ".raw\n"
+         << "Resolution: " << n.x << " " << n.y << " " << n.z << " " << vectorData->size() << "\n"
+         << "Format: " << first.getDataFormatString() << "\n";
+    U3dHeader::rowsFirst(head, "ModelMatrix", first.getModelMatrix());
+    U3dHeader::rowsFirst(head, "WorldMatrix", first.getWorldMatrix());
+    head << "CellDimensions: " << c.x << " " << c.y << " " << c.z << "\n";
 
-    std::ofstream f(filePath.c_str());
-    if (!f.good()) throw DataWriterException("Could not write to file: " + filePath);
-    f << ss.str();
-    f.close();
-
-    std::ofstream fout(rawPath.c_str(), std::ios::out | std::ios::binary);
-    if (!fout.good()) throw DataWriterException("Could not write to raw file: " + rawPath);
-    for (auto& element : *vectorData) fout.write((const char*)element->hostData(), (std::streamsize)element->getSizeInBytes());
-    fout.close();
+    std::ofstream text(filePath);
+    if (!(text << head.str())) throw DataWriterException("UniformGrid3DWriter: cannot write " + filePath);
+    text.close();
+    std::ofstream raw(dataPath, std::ios::binary);
+    for (const auto& grid : *vectorData) raw.write(static_cast<const char*>(grid->hostData()), (std::streamsize)grid->getSizeInBytes());
+    if (!raw.good()) throw DataWriterException("UniformGrid3DWriter: cannot write " + dataPath);
 }
 
 std::shared_ptr<UniformGrid3DVector> UniformGrid3DReader::readData(const std::string& filePath) {
-    const std::string fileDirectory = parentPath(filePath);
-    std::ifstream f(filePath.c_str());
-    if (!f.good()) throw DataReaderException("Error: Could not open file: " + filePath);
-    std::string textLine, rawFile, formatFlag;
-    mat4 modelMatrix = identityMatrix(), worldMatrix = identityMatrix();
-    size3_t cellDimensions{ 0, 0, 0 };
-    size_t resolution[4] = { 0, 0, 0, 0 };
-    bool haveFormat = false;
+    std::ifstream text(filePath);
+    if (!text.good()) throw DataReaderException("UniformGrid3DReader: cannot open " + filePath);
+    U3dHeader head;
+    head.parse(text, PathParts(filePath).folder);
+    if (head.extent[0] + head.extent[1] + head.extent[2] + head.extent[3] == 0)
+        throw DataReaderException("UniformGrid3DReader: no \"Resolution\" line in " + filePath);
+    if (!head.formatSeen) throw DataReaderException("UniformGrid3DReader: no \"Format\" line in " + filePath);
+    if (!knownFormatName(head.format)) throw DataReaderException("UniformGrid3DReader: \"" + head.format + "\" in " + filePath + " is not a data format name");
+    std::shared_ptr<UniformGrid3DBase> grid = gridOfFormat(head.format);
+    if (!grid) throw DataReaderException("UniformGrid3DReader: grids of format " + head.format + " are not supported (" + filePath + ")");
+    grid->setCellDimension(head.cell);
+    grid->setModelMatrix(head.model);
+    grid->setWorldMatrix(head.world);
+    grid->setDimensions(size3_t{ head.extent[0], head.extent[1], head.extent[2] });
 
-    while (std::getline(f, textLine)) {
-        textLine = trim(textLine);
-        if (textLine == "" || textLine[0] == '#' || textLine[0] == '/') continue;
-        auto parts = splitString(splitString(textLine, '#')[0], ':');
-        if (parts.size() != 2) continue;
-        const std::string key = toLower(trim(parts[0]));
-        const std::string value = trim(parts[1]);
-        std::stringstream ss(value);
-        if (key == "objectfilename" || key == "rawfile") {
-            rawFile = fileDirectory + value;
-        } else if (key == "resolution" || key == "dimensions") {
-            ss >> resolution[0] >> resolution[1] >> resolution[2] >> resolution[3];
-        } else if (key == "format") {
-            ss >> formatFlag;
-            haveFormat = true;
-        } else if (key == "modelmatrix") {
-            modelMatrix = readMatrix(ss);
-        } else if (key == "worldmatrix") {
-            worldMatrix = readMatrix(ss);
-        } else if (key == "celldimensions") {
-            ss >> cellDimensions.x >> cellDimensions.y >> cellDimensions.z;
-        }
+    std::ifstream raw(head.dataFile, std::ios::binary);
+    if (!raw.good()) throw DataReaderException("UniformGrid3DReader: cannot open the data file " + head.dataFile);
+    auto sequence = std::make_shared<UniformGrid3DVector>();
+    const std::streamsize bytesPerGrid = (std::streamsize)grid->getSizeInBytes();
+    for (size_t element = 0; element < head.extent[3]; ++element) {
+        sequence->push_back(element == 0 ? grid : grid->clone());
+        if (!raw.read(static_cast<char*>(sequence->back()->hostData()), bytesPerGrid))
+            throw DataReaderException("UniformGrid3DReader: " + head.dataFile + " ends before element " + std::to_string(element) + " is complete");
     }
-    if (resolution[0] == 0 && resolution[1] == 0 && resolution[2] == 0 && resolution[3] == 0)
-        throw DataReaderException("Error: Unable to find \"Resolution\" tag in file: " + filePath);
-    if (!haveFormat) throw DataReaderException("Error: Unable to find \"Format\" tag in file: " + filePath);
-    if (!isInviwoFormat(formatFlag))
-        throw DataReaderException("Error: Invalid format string found: " + formatFlag + " in " + filePath +
-                                  " \nThe valid formats are:\n" + kValidFormats);
-    std::shared_ptr<UniformGrid3DBase> data = makeGrid(formatFlag);
-    if (!data) throw DataReaderException("Error: Unsupported data fromat \"Format\" tag in file: " + filePath);
-    data->setCellDimension(cellDimensions);
-    data->setModelMatrix(modelMatrix);
-    data->setWorldMatrix(worldMatrix);
-    data->setDimensions(size3_t{ resolution[0], resolution[1], resolution[2] });
-    const size_t bytes = data->getSizeInBytes();
-
-    auto dataVector = std::make_shared<UniformGrid3DVector>();
-    std::ifstream fin(rawFile.c_str(), std::ios::in | std::ios::binary);
-    if (!fin.good()) throw DataReaderException("Error: Unable to read from  file: " + rawFile);
-    for (size_t t = 0; t < resolution[3]; ++t) {
-        if (t == 0) dataVector->push_back(data);
-        else dataVector->push_back(dataVector->front()->clone());
-        fin.read((char*)dataVector->back()->hostData(), (std::streamsize)bytes);
-        if ((size_t)fin.gcount() != bytes) throw DataReaderException("Error: raw file is too short: " + rawFile);
-    }
-    return dataVector;
+    return sequence;
 }
 
 #ifdef CPM_HOST_EXTRAS
@@ -194,6 +201,8 @@ void UniformGrid3DExport::exportData() {
 #endif
 
 // ---- difference analysis ----------------------------------------------------------------------------------
+// Per time step t: the mean |v(t+1) - v(t)| of every brick of `region` voxels a side, the last step against the first
+// (dynamicvolumedifferenceanalysis.cpp:60-104 loops over voxels on the CPU; here one launch per pair).
 
 DynamicVolumeDifferenceAnalysis::DynamicVolumeDifferenceAnalysis() {
     addPortId("data", true); addPortId("DynamicDataInfo", false);
@@ -202,34 +211,38 @@ DynamicVolumeDifferenceAnalysis::DynamicVolumeDifferenceAnalysis() {
 void DynamicVolumeDifferenceAnalysis::process() {
     auto& rt = CpmRuntime::get();
     if (!rt.valid() || !inport_.isReady()) return;
-    auto data = inport_.getData();
-    auto output = std::make_shared<UniformGrid3DVector>();
-    const size_t r = (size_t)volumeRegionSize_.get();
-    for (size_t timeStep = 0; timeStep < data->size(); ++timeStep) {
-        const size_t nextTimeStep = (timeStep + 1) % data->size();
-        auto& curVolume = (*data)[timeStep];
-        auto& nextVolume = (*data)[nextTimeStep];
-        cpm_volume *cur = curVolume->getDeviceRepresentation(), *next = nextVolume->getDeviceRepresentation();
-        if (!cur || !next) return;
-        const size3_t dim = curVolume->getDimensions();
-        auto out = std::make_shared<DynamicVolumeInfoUniformGrid3D>();
-        out->setCellDimension(size3_t{ r, r, r });
-        out->setModelMatrix(curVolume->getModelMatrix());
-        out->setWorldMatrix(curVolume->getWorldMatrix());
-        out->setDimensions(size3_t{ (dim.x + r - 1) / r, (dim.y + r - 1) / r, (dim.z + r - 1) / r });
-        if (!rt.check(cpm_volume_difference(rt.ctx(), cur, next, (int)r, out->data.device(), rt.stream()), "cpm_volume_difference")) return;
-        output->emplace_back(out);
+    const auto sequence = inport_.getData();
+    const size_t steps = sequence->size(), side = (size_t)volumeRegionSize_.get();
+    auto perStep = std::make_shared<UniformGrid3DVector>();
+    auto bricksAlong = [side](size_t voxels) { return (voxels + side - 1) / side; };
+    for (size_t t = 0; t < steps; ++t) {
+        const auto& before = (*sequence)[t];
+        const auto& after = (*sequence)[(t + 1) % steps];
+        cpm_volume *dBefore = before->getDeviceRepresentation(), *dAfter = after->getDeviceRepresentation();
+        if (!dBefore || !dAfter) return;
+        auto info = std::make_shared<DynamicVolumeInfoUniformGrid3D>();
+        info->setCellDimension(size3_t{ side, side, side });
+        info->setModelMatrix(before->getModelMatrix());
+        info->setWorldMatrix(before->getWorldMatrix());
+        const size3_t voxels = before->getDimensions();
+        info->setDimensions(size3_t{ bricksAlong(voxels.x), bricksAlong(voxels.y), bricksAlong(voxels.z) });
+        if (!rt.check(cpm_volume_difference(rt.ctx(), dBefore, dAfter, (int)side, info->data.device(), rt.stream()), "cpm_volume_difference")) return;
+        perStep->push_back(info);
     }
-    outport_.setData(output);
+    outport_.setData(perStep);
 }
 
 // ---- players --------------------------------------------------------------------------------------------------
+// Both players show element `index` blended with its successor (the last with the first) by the fraction of
+// time / timePerElement; a sequence of one element is passed through.  The clock below is that rule (the reference keeps a copy of
+// it in each player: uniformgrid3dplayerprocessor.cpp:117-152, volumesequenceplayer.cpp:142-180); the timer that ticks it belongs to
+// the caller.
 
 void BufferMixerCL::mix(UniformGrid3DBase& x, UniformGrid3DBase& y, float a, UniformGrid3DBase& out) {
     auto& rt = CpmRuntime::get();
     if (!rt.valid()) return;
-    if (!x.hasDeviceData()) x.uploadHostData();  // getRepresentation<BufferCL>() of RAM-only data (e.g. read from .u3d)
-    if (!y.hasDeviceData()) y.uploadHostData();
+    for (UniformGrid3DBase* operand : { &x, &y })
+        if (!operand->hasDeviceData()) operand->uploadHostData();  // RAM-only data (read from a .u3d) gets its device copy here
     rt.check(cpm_mix_buffers(rt.ctx(), x.deviceData(), y.deviceData(), a, x.mixElements(), x.mixType(), out.deviceData(), rt.stream()),
              "cpm_mix_buffers");
 }
@@ -239,95 +252,98 @@ SequenceClock::SequenceClock(const char* perElementId, const char* perElementNam
     time_.setMinValue(0.f); time_.setMaxValue(0.f);
     index_.setMinValue(1); index_.setMaxValue(1);
     index_.setReadOnly(true);
-    time_.onChange([this]() { updateVolumeIndex(); });
+    time_.onChange(std::bind(&SequenceClock::updateVolumeIndex, this));
 }
-void SequenceClock::onSequenceTimerEvent() {  // uniformgrid3dplayerprocessor.cpp:117-127
-    float time = time_.get();
-    time = time + static_cast<float>(1000 / frameRate_.get()) / 1000.f;
-    if (time > time_.getMaxValue()) time -= time_.getMaxValue();  // wrap around
-    time_.set(time);
+// a tick advances the time by one frame period (whole milliseconds, as the reference's timer interval) and wraps at the end
+void SequenceClock::onSequenceTimerEvent() {
+    const int wholeMilliseconds = 1000 / frameRate_.get();
+    const float period = (float)wholeMilliseconds / 1000.f;
+    float now = time_.get() + period;
+    const float end = time_.getMaxValue();
+    if (now > end) now -= end;
+    time_.set(now);
     updateVolumeIndex();
 }
-void SequenceClock::updateVolumeIndex() {  // :130-138
-    float integerTime;
-    std::modf(time_.get() / timePerElement_.get(), &integerTime);
-    auto timeStep = static_cast<size_t>(integerTime) % (size_t)index_.getMaxValue();
-    if ((int)timeStep != index_.get() - 1) index_.set(static_cast<int>(timeStep + 1));
+// index = 1 + (whole elements elapsed) mod (elements)
+void SequenceClock::updateVolumeIndex() {
+    float whole = 0.f;
+    std::modf(time_.get() / timePerElement_.get(), &whole);
+    const int shown = 1 + (int)(static_cast<size_t>(whole) % (size_t)index_.getMaxValue());
+    if (shown != index_.get()) index_.set(shown);
 }
-void SequenceClock::onTimeStepChange(size_t nElements) {  // :140-152
-    time_.setMaxValue(time_.getMinValue() + static_cast<float>(nElements - 1) * timePerElement_.get());
-    if (time_.get() > time_.getMaxValue()) time_.set(time_.getMinValue());
+// a sequence of n elements spans (n - 1) element times; time and index are pulled back into range
+void SequenceClock::onTimeStepChange(size_t nElements) {
+    const float start = time_.getMinValue();
+    time_.setMaxValue(start + static_cast<float>(nElements - 1) * timePerElement_.get());
+    if (time_.get() > time_.getMaxValue()) time_.set(start);
     index_.setMaxValue(static_cast<int>(nElements));
     if (index_.get() > index_.getMaxValue()) index_.set(index_.getMinValue());
 }
+
+namespace {
+// what a player's process() has to blend: elements `first` and `second` of a sequence of `count`, at `fraction` between them
+struct BlendStep {
+    size_t first, second;
+    float fraction;
+    BlendStep(SequenceClock& clock, size_t count) {
+        if ((size_t)clock.index_.getMaxValue() != count) clock.onTimeStepChange(count);  // the sequence on the inport changed length
+        fraction = clock.weight();
+        first = (size_t)(clock.index_.get() - 1);
+        second = (first + 1) % count;
+    }
+};
+bool sameExtent(size3_t a, size3_t b) { return a.x == b.x && a.y == b.y && a.z == b.z; }
+}  // namespace
 
 UniformGrid3DPlayerProcessor::UniformGrid3DPlayerProcessor() {
     addPortId("Sequence", true); addPortId("InterpolatedData", false);
     addProperty(clock_.time_); addProperty(clock_.index_); addProperty(clock_.timePerElement_);
     addProperty(clock_.frameRate_); addProperty(clock_.playSequence_);
-    inport_.onConnect([this]() { if (inport_.hasData()) clock_.onTimeStepChange(inport_.getData()->size()); });
-    clock_.timePerElement_.onChange([this]() { if (inport_.hasData()) clock_.onTimeStepChange(inport_.getData()->size()); });
+    auto resize = [this]() { if (inport_.hasData()) clock_.onTimeStepChange(inport_.getData()->size()); };
+    inport_.onConnect(resize);
+    clock_.timePerElement_.onChange(resize);
 }
 void UniformGrid3DPlayerProcessor::process() {
     if (!inport_.isReady()) return;
-    auto elements = inport_.getData();
-    if (elements->empty()) return;
-    if ((size_t)clock_.index_.getMaxValue() != elements->size()) clock_.onTimeStepChange(elements->size());  // inport_.onChange
-    const float t = clock_.weight();
-    const size_t timeStep = (size_t)(clock_.index_.get() - 1);
-    const size_t nextTimeStep = (timeStep + 1) % elements->size();
-    if (elements->size() > 1) {
-        std::swap(outData_, outDataPingPong_);
-        auto input0 = elements->at(timeStep);
-        auto input1 = elements->at(nextTimeStep);
-        const size3_t d0 = input0->getDimensions();
-        if (!outData_ || outData_->getDimensions().x != d0.x || outData_->getDimensions().y != d0.y || outData_->getDimensions().z != d0.z ||
-            std::string(outData_->getDataFormatString()) != input0->getDataFormatString()) {
-            outData_ = input0->clone();
-            outData_->setModelMatrix(input0->getModelMatrix());
-            outData_->setWorldMatrix(input0->getWorldMatrix());
-        }
-        bufferMixer_.mix(*input0, *input1, t, *outData_);
-        outport_.setData(outData_);
-    } else {
-        outport_.setData(elements->at(timeStep));
-    }
+    const auto sequence = inport_.getData();
+    if (sequence->empty()) return;
+    const BlendStep step(clock_, sequence->size());
+    const auto& from = sequence->at(step.first);
+    if (sequence->size() == 1) { outport_.setData(from); return; }
+    const auto& towards = sequence->at(step.second);
+    std::swap(outData_, outDataPingPong_);  // the consumer may still hold the grid handed out last time
+    const bool fits = outData_ && sameExtent(outData_->getDimensions(), from->getDimensions()) &&
+                      std::strcmp(outData_->getDataFormatString(), from->getDataFormatString()) == 0;
+    if (!fits) outData_ = from->clone();  // shape, matrices and cell size of the sequence's elements
+    bufferMixer_.mix(*from, *towards, step.fraction, *outData_);
+    outport_.setData(outData_);
 }
 
 VolumeSequencePlayer::VolumeSequencePlayer() {
     addPortId("volumeSequence", true); addPortId("InterpolatedVolume", false);
     addProperty(clock_.time_); addProperty(clock_.index_); addProperty(clock_.timePerElement_);
     addProperty(clock_.frameRate_); addProperty(clock_.playSequence_);
-    inport_.onConnect([this]() { if (inport_.hasData()) clock_.onTimeStepChange(inport_.getData()->size()); });
-    clock_.timePerElement_.onChange([this]() { if (inport_.hasData()) clock_.onTimeStepChange(inport_.getData()->size()); });
+    auto resize = [this]() { if (inport_.hasData()) clock_.onTimeStepChange(inport_.getData()->size()); };
+    inport_.onConnect(resize);
+    clock_.timePerElement_.onChange(resize);
 }
 void VolumeSequencePlayer::process() {
     auto& rt = CpmRuntime::get();
     if (!inport_.isReady()) return;
-    auto volumes = inport_.getData();
-    if (volumes->empty()) return;
-    if ((size_t)clock_.index_.getMaxValue() != volumes->size()) clock_.onTimeStepChange(volumes->size());
-    const float t = clock_.weight();
-    const size_t timeStep = (size_t)(clock_.index_.get() - 1);
-    const size_t nextTimeStep = (timeStep + 1) % volumes->size();
-    if (volumes->size() > 1) {
-        auto inputVol0 = volumes->at(timeStep);
-        auto inputVol1 = volumes->at(nextTimeStep);
-        const size3_t d0 = inputVol0->getDimensions();
-        if (!outVolume_ || outVolume_->getDimensions().x != d0.x || outVolume_->getDimensions().y != d0.y ||
-            outVolume_->getDimensions().z != d0.z || outVolume_->dtype() != inputVol0->dtype()) {
-            outVolume_ = std::make_shared<Volume>(d0, inputVol0->dtype());  // device storage only
-            outVolume_->setModelMatrix(inputVol0->getModelMatrix());
-            outVolume_->setWorldMatrix(inputVol0->getWorldMatrix());
-        }
-        cpm_volume *v0 = inputVol0->getDeviceRepresentation(), *v1 = inputVol1->getDeviceRepresentation();
-        cpm_volume* out = outVolume_->getDeviceRepresentation();
-        if (!v0 || !v1 || !out) return;
-        if (!rt.check(cpm_volume_mix(rt.ctx(), v0, v1, t, out, rt.stream()), "cpm_volume_mix")) return;
-        outport_.setData(outVolume_);
-    } else {
-        outport_.setData(volumes->at(timeStep));
+    const auto sequence = inport_.getData();
+    if (sequence->empty()) return;
+    const BlendStep step(clock_, sequence->size());
+    const auto& from = sequence->at(step.first);
+    if (sequence->size() == 1) { outport_.setData(from); return; }
+    const auto& towards = sequence->at(step.second);
+    if (!outVolume_ || !sameExtent(outVolume_->getDimensions(), from->getDimensions()) || outVolume_->dtype() != from->dtype()) {
+        outVolume_ = std::make_shared<Volume>(from->getDimensions(), from->dtype());  // device storage only
+        outVolume_->setModelMatrix(from->getModelMatrix());
+        outVolume_->setWorldMatrix(from->getWorldMatrix());
     }
+    cpm_volume *a = from->getDeviceRepresentation(), *b = towards->getDeviceRepresentation(), *blended = outVolume_->getDeviceRepresentation();
+    if (!a || !b || !blended) return;
+    if (rt.check(cpm_volume_mix(rt.ctx(), a, b, step.fraction, blended, rt.stream()), "cpm_volume_mix")) outport_.setData(outVolume_);
 }
 
 #ifdef CPM_HOST_EXTRAS

@@ -10,6 +10,7 @@ the C++ drop-in surface lives in host/.
 """
 from __future__ import annotations
 
+import ctypes as C
 import math
 
 import numpy as np
@@ -18,129 +19,82 @@ from . import binding as B
 from . import synthetic as S
 
 
-# --------------------------------------------------------------------------- E2 (host, CPU in the reference too)
+# --------------------------------------------------------------------------- E2 / C2 (host arithmetic, CPU in the reference too)
+# One implementation: host/cpm_hostmath.cpp (what the C++ processors use), reached here through libcpm_hostmath.so.
 
 def _normalize(v):
     v = np.asarray(v, dtype=np.float32)
     return v / np.float32(np.sqrt(np.sum(v * v, dtype=np.float32)))
 
 
-def project_points_on_plane(points, plane_point, normal, u, v):
-    """ref lightcl/pointplaneprojection.cpp:39-54"""
-    n = np.asarray(normal, np.float32)
-    d = np.float32(np.dot(n, plane_point))
-    out = []
-    for p in np.asarray(points, np.float32):
-        dist = np.float32(np.dot(n, p)) - d
-        proj = p - dist * n
-        o2p = proj - plane_point
-        out.append((np.float32(np.dot(u, o2p)), np.float32(np.dot(v, o2p))))
-    return out
+_hostmath_lib = None
+
+
+def _hostmath():
+    global _hostmath_lib
+    if _hostmath_lib is None:
+        from . import build as _build
+        lib = C.CDLL(str(_build.build_hostmath_library(verbose=False)))
+        fp, dp, i32 = C.POINTER(C.c_float), C.POINTER(C.c_double), C.c_int
+        lib.cpmh_fit_light_rectangle.restype, lib.cpmh_fit_light_rectangle.argtypes = None, [fp, i32, fp, fp, fp]
+        lib.cpmh_hull_cycle.restype, lib.cpmh_hull_cycle.argtypes = i32, [fp, i32, fp]
+        lib.cpmh_smallest_rectangle.restype, lib.cpmh_smallest_rectangle.argtypes = None, [fp, i32, fp]
+        lib.cpmh_tf_difference.restype = i32
+        lib.cpmh_tf_difference.argtypes = [dp, fp, i32, dp, fp, i32, C.c_float, i32, fp, fp]
+        _hostmath_lib = lib
+    return _hostmath_lib
+
+
+def _fp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_float))
 
 
 def convex_hull_2d(points):
-    """Andrew's monotone chain as written in ref lightcl/convexhull2d.cpp:38-130
-    (the hull is returned closed: first point repeated at the end)."""
-    pts = sorted(points, key=lambda p: (p[0], p[1]))
-    if len(pts) < 4:
-        return pts
-
-    def left(p0, p1, q):
-        return (p1[0] - p0[0]) * (q[1] - p0[1]) - (q[0] - p0[0]) * (p1[1] - p0[1])
-
-    n = len(pts)
-    min_min = 0
-    min_max = 1
-    while min_max < n and pts[0][0] == pts[min_max][0]:
-        min_max += 1
-    min_max -= 1
-    if min_max == n - 1:
-        hull = [pts[min_min]]
-        if pts[min_max][1] != pts[min_min][1]:
-            hull.append(pts[min_max])
-        hull.append(pts[min_min])
-        return hull
-    max_min = n - 1
-    max_max = n - 2
-    while max_max >= 0 and not (pts[n - 1][0] > pts[max_max][0]):
-        max_max -= 1
-    max_max += 1
-    hull = [pts[min_min]]
-    for i in range(min_max + 1, max_min + 1):
-        if left(pts[min_min], pts[max_min], pts[i]) >= 0 and i < max_min:
-            continue
-        while len(hull) >= 2:
-            if left(hull[-2], hull[-1], pts[i]) > 0:
-                break
-            hull.pop()
-        hull.append(pts[i])
-    if max_max != max_min:
-        hull.append(pts[max_max])
-    bottom = len(hull) - 1
-    for i in range(max_max, min_max, -1):
-        if left(pts[max_max], pts[min_max], pts[i]) >= 0 and i > min_max:
-            continue
-        while len(hull) - bottom >= 2:
-            if left(hull[-2], hull[-1], pts[i]) > 0:
-                break
-            hull.pop()
-        hull.append(pts[i])
-    if min_max != min_min:
-        hull.append(pts[max_min])
-    return hull
+    """The vertex cycle the rectangle search walks (cpm_host::hullCycle, rule H; ref lightcl/convexhull2d.cpp:38-130)."""
+    pts = np.ascontiguousarray(np.asarray(points, np.float32).reshape(-1, 2))
+    out = np.zeros((len(pts) + 2, 2), np.float32)
+    n = _hostmath().cpmh_hull_cycle(_fp(pts), len(pts), _fp(out))
+    return [(out[i, 0], out[i, 1]) for i in range(n)]
 
 
 def minimum_bounding_rectangle(hull):
-    """ref lightcl/orientedboundingbox2d.cpp:40-78 (rotating edges)"""
-    f = np.float32
-    best = None
-    min_area = f(np.finfo(np.float32).max)
-    n = len(hull)
-    j = n - 1
-    for i in range(n):
-        e = np.array([hull[i][0] - hull[j][0], hull[i][1] - hull[j][1]], np.float32)
-        ln = f(np.sqrt(e[0] * e[0] + e[1] * e[1]))
-        if ln == 0 or not np.isfinite(ln):
-            j = i
-            continue
-        e0 = e / ln
-        e1 = np.array([-e0[1], e0[0]], np.float32)
-        min0 = max0 = min1 = max1 = f(0)
-        for k in range(n):
-            d = np.array([hull[k][0] - hull[j][0], hull[k][1] - hull[j][1]], np.float32)
-            t = f(np.dot(d, e0))
-            min0, max0 = min(min0, t), max(max0, t)
-            t = f(np.dot(d, e1))
-            min1, max1 = min(min1, t), max(max1, t)
-        area = (max0 - min0) * (max1 - min1)
-        if area < min_area:
-            min_area = area
-            origin = np.array(hull[j], np.float32) + min(min0, f(0)) * e0 + min(min1, f(0)) * e1
-            best = (origin, e0 * (max0 - min0), e1 * (max1 - min1))
-        j = i
-    return best
+    """(corner, side0, side1) of the smallest rectangle along an edge of the cycle (ref lightcl/orientedboundingbox2d.cpp:40-78)."""
+    pts = np.ascontiguousarray(np.asarray(hull, np.float32).reshape(-1, 2))
+    out = np.zeros(6, np.float32)
+    _hostmath().cpmh_smallest_rectangle(_fp(pts), len(pts), _fp(out))
+    return out[0:2].copy(), out[2:4].copy(), out[4:6].copy()
 
 
 def fit_plane_aligned_obb(points, plane_point, plane_normal):
-    """ref lightcl/orientedboundingbox2d.cpp:80-100: (origin, u, v) of the minimum-area
-    rectangle, in the light plane, covering the projected points."""
-    n = _normalize(plane_normal)
-    plane_point = np.asarray(plane_point, np.float32)
+    """(origin, u, v) of the minimum-area rectangle, in the light plane, covering the projected points
+    (cpm_host::fitLightRectangle; ref lightcl/orientedboundingbox2d.cpp:80-100)."""
+    pts = np.ascontiguousarray(np.asarray(points, np.float32).reshape(-1, 3))
+    through = np.ascontiguousarray(np.asarray(plane_point, np.float32))
+    n = np.ascontiguousarray(_normalize(plane_normal))
+    out = np.zeros(9, np.float32)
+    _hostmath().cpmh_fit_light_rectangle(_fp(pts), len(pts), _fp(through), _fp(n), _fp(out))
+    return out[0:3].copy(), out[3:6].copy(), out[6:9].copy()
 
-    def project(p):
-        p = np.asarray(p, np.float32)
-        return p - (np.float32(np.dot(n, p)) - np.float32(np.dot(n, plane_point))) * n
 
-    if abs(n[0]) > abs(n[1]):
-        u = _normalize(project((1.0, 0.0, 0.0)) - plane_point)
-    else:
-        u = _normalize(project((0.0, 1.0, 0.0)) - plane_point)
-    v = _normalize(np.cross(n, u).astype(np.float32))
-    projected = project_points_on_plane(points, plane_point, n, u, v)
-    hull = convex_hull_2d(projected)
-    o2, u2, v2 = minimum_bounding_rectangle(hull)
-    origin = plane_point + o2[0] * u + o2[1] * v
-    return origin.astype(np.float32), (u2[0] * u + u2[1] * v).astype(np.float32), (v2[0] * u + v2[1] * v).astype(np.float32)
+def tf_difference_points(tf_points, prev_points, eps=1e-4, associated=False):
+    """Break-point list of |TF_new - TF_old|, zero-padded at 0 and 1 (cpm_host::tfDifference, rule D; ref importancesamplingcl/
+    processors/minmaxuniformgrid3dimportanceclprocessor.cpp:364-501).  tf_points / prev_points: lists of (position, r, g, b, a).
+    Returns (positions, colors4)."""
+    def split(points):
+        pts = sorted(points, key=lambda q: float(q[0]))
+        pos = np.ascontiguousarray([float(q[0]) for q in pts], np.float64)
+        rgba = np.ascontiguousarray([[np.float32(c) for c in q[1:5]] for q in pts], np.float32).reshape(-1, 4)
+        return pos, rgba
+    pa, ca = split(tf_points)
+    pb, cb = split(prev_points)
+    cap = len(pa) + len(pb) + 2
+    out_pos, out_rgba = np.zeros(cap, np.float32), np.zeros((cap, 4), np.float32)
+    dp = C.POINTER(C.c_double)
+    n = _hostmath().cpmh_tf_difference(pa.ctypes.data_as(dp), _fp(ca), len(pa), pb.ctypes.data_as(dp), _fp(cb), len(pb),
+                                       float(eps), int(bool(associated)), _fp(out_pos), _fp(out_rgba))
+    if n < 0:
+        raise ValueError("tf_difference_points: one of the two transfer functions is empty")
+    return out_pos[:n].copy(), out_rgba[:n].copy()
 
 
 # --------------------------------------------------------------------------- frame
@@ -419,79 +373,6 @@ class ProgressivePhotonMapper(PhotonFrame):
         if self.iteration > 1:
             self.ctx.mix_buffers(self.light_volume, self.estimate, 1.0 / self.iteration, self.light_volume)
         return self.light_volume
-
-
-# --------------------------------------------------------------------------- C2 (host, CPU in the reference too)
-
-def _mix_prim(a, b, t):
-    """TFPrimitive mix by parameter t (ref minmaxuniformgrid3dimportanceclprocessor.cpp:519-524)."""
-    return (a[0] + (b[0] - a[0]) * t, tuple(np.float32(x) + (np.float32(y) - np.float32(x)) * np.float32(t) for x, y in zip(a[1], b[1])))
-
-
-def _mix_at(a, b, at):
-    return _mix_prim(a, b, (at[0] - a[0]) / (b[0] - a[0]))
-
-
-def _color_diff(p1, p2, associated=False):
-    """|p2 - p1| per channel (ref ...processor.cpp:503-507)."""
-    a = np.asarray(p1, np.float32) * (np.float32(p1[3]) if associated else np.float32(1))
-    b = np.asarray(p2, np.float32) * (np.float32(p2[3]) if associated else np.float32(1))
-    return tuple(np.abs(b - a).astype(np.float32))
-
-
-def tf_difference_points(tf_points, prev_points, eps=1e-4, associated=False):
-    """Break-point list of |TF_new - TF_old|, zero-padded at 0 and 1
-    (MinMaxUniformGrid3DImportanceCLProcessor::updateTransferFunctionDifferenceData,
-    ref importancesamplingcl/processors/minmaxuniformgrid3dimportanceclprocessor.cpp:364-501).
-    tf_points / prev_points: sorted lists of (position, r, g, b, a).  Returns (positions, colors4)."""
-    tf = [(float(p[0]), tuple(np.float32(c) for c in p[1:])) for p in sorted(tf_points)]
-    prev = [(float(p[0]), tuple(np.float32(c) for c in p[1:])) for p in sorted(prev_points)]
-    if not tf and not prev:
-        return np.array([0, 0], np.float32), np.zeros((2, 4), np.float32)
-
-    def ne0(c):
-        return any(abs(float(x)) > eps for x in c)
-
-    positions, colors = [], []
-    first, pfirst = tf[0], prev[0]
-    p1 = p2 = (first[0] if first[0] < pfirst[0] else pfirst[0], _color_diff(first[1], pfirst[1], associated))
-    if first[0] != pfirst[0] and first[1][3] == 0.0 and pfirst[1][3] == 0.0:
-        if first[0] < pfirst[0]:
-            a2 = tf[min(1, len(tf) - 1)]
-            p = _mix_at(first, a2, pfirst)
-            p2 = (pfirst[0], _color_diff(pfirst[1], p[1], associated))
-        else:
-            a2 = prev[min(1, len(prev) - 1)]
-            p = _mix_at(pfirst, a2, first)
-            p2 = (first[0], _color_diff(first[1], p[1], associated))
-    if p1[0] > 0.0 and (first[1][3] > 0.0 or pfirst[1][3] > 0.0) and ne0(p1[1]):
-        positions.append(0.0); colors.append(p1[1])
-    else:
-        positions.append(0.0); colors.append((0.0, 0.0, 0.0, 0.0))
-    i = j = 0
-    while i < len(tf) or j < len(prev):
-        if (ne0(p1[1]) or ne0(p2[1])) and (p1[1][3] > 0.0 or p2[1][3] > 0.0):
-            if len(positions) == 1:
-                positions.append(p1[0]); colors.append(p1[1])
-            positions.append(p2[0]); colors.append(p2[1])
-        a1 = tf[min(i, len(tf) - 1)]
-        a2 = tf[i + 1] if i + 1 < len(tf) - 1 else (1.0, tf[-1][1])
-        b1 = prev[min(j, len(prev) - 1)]
-        b2 = prev[j + 1] if j + 1 < len(prev) - 1 else (1.0, prev[-1][1])
-        p1 = p2
-        if a2[0] < b2[0]:
-            p = _mix_at(b1, b2, a2)
-            p2 = (a2[0], _color_diff(a2[1], p[1], associated)); i += 1
-        elif b2[0] < a2[0]:
-            p = _mix_at(a1, a2, b2)
-            p2 = (b2[0], _color_diff(b2[1], p[1], associated)); j += 1
-        else:
-            p2 = (b2[0] if a2[1][3] < b2[1][3] else a2[0], _color_diff(a2[1], b2[1], associated)); i += 1; j += 1
-    if p2[0] < 1.0 and p2[1][3] > 0.0:
-        positions.append(p2[0]); colors.append(p2[1])
-    if positions[-1] < 1.0:
-        positions.append(1.0); colors.append((0.0, 0.0, 0.0, 0.0))
-    return np.asarray(positions, np.float32), np.asarray(colors, np.float32).reshape(-1, 4)
 
 
 # --------------------------------------------------------------------------- correlated re-trace (C7 + G5)

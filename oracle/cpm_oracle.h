@@ -154,6 +154,18 @@ void cpmo_mix_f32(const float* x, const float* y, float a, size_t n, float* out)
 void cpmo_mix_u16x2(const uint16_t* x, const uint16_t* y, float a, size_t n_pairs, uint16_t* out);
 void cpmo_volume_mix(const cpmo_volume* v0, const cpmo_volume* v1, float weight, void* out_voxels);
 
+/* ---- host arithmetic that decides device inputs (cpm_oracle_host.c) -------------------------------------- */
+/* E2: lightcl/convexhull2d.cpp:38-130 (hull_xy: room for n + 2 points; returns the count) */
+int cpmo_convex_hull_2d(const float* xy, int n, float* hull_xy);
+/* E2: lightcl/orientedboundingbox2d.cpp:40-78 (out = origin.xy, u.xy, v.xy) */
+void cpmo_minimum_bounding_rectangle(const float* hull_xy, int n, float out[6]);
+/* E2: lightcl/orientedboundingbox2d.cpp:80-100 + pointplaneprojection.cpp:39-54 (out = origin.xyz, u.xyz, v.xyz) */
+void cpmo_fit_obb(const float* points_xyz, int n, const float plane_point[3], const float plane_normal[3], float out[9]);
+/* C2: importancesamplingcl/processors/minmaxuniformgrid3dimportanceclprocessor.cpp:364-524 (outputs: room for
+ * n_tf + n_prev + 2 points; returns the count, -1 when exactly one function is empty) */
+int cpmo_tf_difference_points(const double* tf_pos, const float* tf_rgba, int n_tf, const double* prev_pos, const float* prev_rgba, int n_prev,
+                              float eps, int associated, float* out_pos, float* out_rgba);
+
 #ifdef __cplusplus
 }
 #endif

@@ -85,6 +85,12 @@ class Oracle:
         L.cpmo_sort_keys.argtypes = [C.c_void_p, C.c_size_t, C.c_int]
         L.cpmo_select_recompute.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
         L.cpmo_set_threads.argtypes = [C.c_int]
+        fp, dp = C.POINTER(C.c_float), C.POINTER(C.c_double)
+        L.cpmo_convex_hull_2d.restype, L.cpmo_convex_hull_2d.argtypes = C.c_int, [fp, C.c_int, fp]
+        L.cpmo_minimum_bounding_rectangle.restype, L.cpmo_minimum_bounding_rectangle.argtypes = None, [fp, C.c_int, fp]
+        L.cpmo_fit_obb.restype, L.cpmo_fit_obb.argtypes = None, [fp, C.c_int, fp, fp, fp]
+        L.cpmo_tf_difference_points.restype = C.c_int
+        L.cpmo_tf_difference_points.argtypes = [dp, fp, C.c_int, dp, fp, C.c_int, C.c_float, C.c_int, fp, fp]
 
     # ---- helpers
     def set_threads(self, n):
@@ -300,6 +306,44 @@ class Oracle:
         cnt = C.c_int32(0)
         self.lib.cpmo_select_changed(_p(np.ascontiguousarray(importances, np.uint32)), importances.size, _p(idx), C.byref(cnt))
         return idx, cnt.value
+
+
+    # ---- host arithmetic (cpm_oracle_host.c)
+    @staticmethod
+    def _fp(a):
+        return a.ctypes.data_as(C.POINTER(C.c_float))
+
+    def convex_hull_2d(self, points):
+        pts = np.ascontiguousarray(np.asarray(points, np.float32).reshape(-1, 2))
+        out = np.zeros((len(pts) + 2, 2), np.float32)
+        n = self.lib.cpmo_convex_hull_2d(self._fp(pts), len(pts), self._fp(out))
+        return out[:n].copy()
+
+    def minimum_bounding_rectangle(self, hull):
+        pts = np.ascontiguousarray(np.asarray(hull, np.float32).reshape(-1, 2))
+        out = np.zeros(6, np.float32)
+        self.lib.cpmo_minimum_bounding_rectangle(self._fp(pts), len(pts), self._fp(out))
+        return out
+
+    def fit_obb(self, points, plane_point, unit_normal):
+        pts = np.ascontiguousarray(np.asarray(points, np.float32).reshape(-1, 3))
+        pp, nn = np.ascontiguousarray(plane_point, np.float32), np.ascontiguousarray(unit_normal, np.float32)
+        out = np.zeros(9, np.float32)
+        self.lib.cpmo_fit_obb(self._fp(pts), len(pts), self._fp(pp), self._fp(nn), self._fp(out))
+        return out[0:3].copy(), out[3:6].copy(), out[6:9].copy()
+
+    def tf_difference_points(self, tf_points, prev_points, eps=1e-4, associated=False):
+        def split(points):
+            pts = sorted(points, key=lambda q: float(q[0]))
+            return (np.ascontiguousarray([float(q[0]) for q in pts], np.float64),
+                    np.ascontiguousarray([[np.float32(c) for c in q[1:5]] for q in pts], np.float32).reshape(-1, 4))
+        (pa, ca), (pb, cb) = split(tf_points), split(prev_points)
+        cap = len(pa) + len(pb) + 2
+        pos, col = np.zeros(cap, np.float32), np.zeros((cap, 4), np.float32)
+        dp = C.POINTER(C.c_double)
+        n = self.lib.cpmo_tf_difference_points(pa.ctypes.data_as(dp), self._fp(ca), len(pa), pb.ctypes.data_as(dp), self._fp(cb), len(pb),
+                                               float(eps), int(bool(associated)), self._fp(pos), self._fp(col))
+        return (None, None) if n < 0 else (pos[:n].copy(), col[:n].copy())
 
 
 class Ref:
