@@ -235,6 +235,9 @@ def launch_ranks(n_ranks):
     return rc
 
 
+TIMED_BATCHES = 7   # the timed region is repeated; the median batch is reported
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -246,6 +249,9 @@ def main():
     ap.add_argument("--shards", default="tiles", choices=["tiles", "range"],
                     help="N > 1: a rank takes the lattice's 4096-sample tiles t = rank (mod N) (default: every rank sees every lit "
                          "brick at 1/N of the density) or a contiguous range (a slab of the light plane)")
+    ap.add_argument("--records", default="planar", choices=["planar", "float8"],
+                    help="fast formulation: photon records in the two-plane layout the tracer can write and the brick bin reads half of "
+                         "(default), or the reference's float8 records")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the labelled extra figures (other formulations, I = 4, sparse TF, configs 3 / 5, pipelined)")
@@ -411,6 +417,10 @@ def main():
         use_graph = False
     else:
         fr = P.PhotonFrame(ctx, vol_np, tf, lattice, (gdim,) * 3, light_travel_direction=LIGHT_DIR, photon_indices=shard)
+        # the frame's records in the two-plane layout (CPM_TRACE_PHOTONS_PLANAR: the same records at other addresses; the brick bin
+        # then reads 16 instead of 32 bytes per photon).  --records float8 times the reference's interleaved layout instead.
+        planar = fast and args.records == "planar"
+        fr.set_planar_records(planar)
         use_graph = args.graph and not fast
         if use_graph:
             fr.capture()
@@ -448,18 +458,25 @@ def main():
                 dist.barrier()
             torch.cuda.synchronize()
 
+    # W untimed steps, then TIMED_BATCHES batches of exactly K steps, each between two barrier + synchronize pairs and taken as the
+    # MAX over the ranks; ms_per_step / value are the MEDIAN batch's (K = 20 frames of config 2 last 1.4 ms: one batch is one sample of
+    # the box's clocks; every batch's figure is in the line)
     for _ in range(args.warmup):
         step()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    batch_elapsed = []
+    for _ in range(TIMED_BATCHES):
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        barrier()
+        dt = time.perf_counter() - t0
+        if dist is not None:
+            t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        batch_elapsed.append(dt)
+    elapsed = sorted(batch_elapsed)[len(batch_elapsed) // 2]
 
     # ---- second pass with per-kernel HIP events (library hook) on the same stream
     prof_steps = min(args.steps, 100)
@@ -487,6 +504,8 @@ def main():
         ctx.set_step_counter(None)
         woodcock_steps = int(counter.item())
 
+    if not correlated:
+        fr.set_planar_records(False)   # (the extras below read fr.photons as float8 records: other formulations, the identity checks)
     # ---- labelled extras (never `value`), rank 0 of a single-GPU run only
     if world == 1 and not args.no_extras and not correlated:
         reps = max(10, min(args.steps, 50))
@@ -807,6 +826,9 @@ def main():
             "value": round(value, 2), "unit": "Mphotons/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
+            "timing": {"what": f"median of {TIMED_BATCHES} timed batches of {args.steps} steps each (every batch between barrier + synchronize pairs, "
+                               "MAX over ranks); value and ms_per_step are that batch's",
+                       "batch_ms_per_step": [round(e / args.steps * 1e3, 4) for e in batch_elapsed]},
             "config": {"workload": (f"BASELINE {args.workload}: {vdim}^3 u8 heterogeneous volume, {n_total} photons per frame in all "
                                     f"({lattice[0]}x{lattice[1]} lattice, one directional light; {n_rank} on rank 0), {gdim}^3 x1 f32 light volume, "
                                     f"I=1, r=1 voxel, MWC64X streams from glibc srand(0)"
@@ -824,6 +846,9 @@ def main():
                                        + f", transport {type(transport).__name__}"
                                        + (f" [{transport_note}]" if transport_note else "")) if world > 1 else "single GPU",
                        "launch": "captured HIP graph replay" if use_graph else "eager launches",
+                       "photon_records": ("two-plane layout (CPM_TRACE_PHOTONS_PLANAR: the same records, position + first power channel in one plane; "
+                                          "the brick bin reads 16 of a record's 32 bytes)" if (not correlated and planar) else
+                                          "float8 records (the reference's layout, cl/photon.cl:49-63)"),
                        "trace_workgroup_order": "costliest chunks first, from the costs a measured launch recorded (cpm_trace_order: the first "
                                                 "frame and every 256th are measured)" if getattr(fr, "adaptive_order", False) else "lattice order",
                        "shards": (f"4096-sample lattice tiles dealt round-robin (rank r: tiles t = r mod {world})" if args.shards == "tiles"

@@ -1286,6 +1286,7 @@ int retrace_impl(cpm_ctx* ctx, cpm_selection* s, const float* importance_grid, c
     int rc = cpm::make_trace_args(ctx, vol, tf, tf_scattering, aabb, &p, A, lut_bytes);
     if (rc) return rc;
     CPM_REQUIRE(ctx, !(p.flags & CPM_TRACE_PROGRESSIVE), "cpm_photon_importance_retrace: a correlated re-trace does not write the RNG state back");
+    CPM_REQUIRE(ctx, !(p.flags & CPM_TRACE_PHOTONS_PLANAR), "cpm_photon_importance_retrace: the importance pass reads float8 records (CPM_PHOTONS_INTERLEAVED)");
     if (n_all == 0) return CPM_OK;
     CPM_REQUIRE(ctx, importance_grid && photons8 && importances && rng_state && old_photons8, "cpm_photon_importance_retrace: null buffer");
     CPM_REQUIRE_ALIGNED16(ctx, photons8, "cpm_photon_importance_retrace");
@@ -1368,6 +1369,7 @@ int retrace_impl(cpm_ctx* ctx, cpm_selection* s, const float* importance_grid, c
     A.isect = lights[0].isect2;
     A.rng = rng_state;
     A.photons = photons8;
+    A.rec_stride = 2u; A.rec_b = 1u;  // (the importance pass reads float8 records)
     A.n_threads = lights[0].n_light_samples;
     A.p.n_light_samples = lights[0].n_light_samples;
     A.p.photon_offset = lights[0].photon_offset;

@@ -244,8 +244,8 @@ CPM_DEV void fast_scan(const uint32_t* __restrict__ counts, const BrickLayout& L
 // reach 100 - 200 of config 4's 8192 bricks; a dense row per tile made the scatter launch read 34 MB of them there), the
 // list's length to its head, for the scatter launch; max |power| of the stored photons on the way.
 template <int CH>
-__global__ __launch_bounds__(1024) void fast_count_kernel(const float* __restrict__ photons, int n, GridDev G, BrickLayout L, float radius,
-                                                          uint32_t* __restrict__ hist, uint32_t* __restrict__ acc,
+__global__ __launch_bounds__(1024) void fast_count_kernel(const float* __restrict__ photons, uint32_t rec_stride, uint32_t rec_b, int n, GridDev G,
+                                                          BrickLayout L, float radius, uint32_t* __restrict__ hist, uint32_t* __restrict__ acc,
                                                           uint32_t* __restrict__ run_base) {
     extern __shared__ uint32_t s_hist[];
     __shared__ float s_mp[16];
@@ -261,7 +261,7 @@ __global__ __launch_bounds__(1024) void fast_count_kernel(const float* __restric
     for (int k = 0; k < kCountItems; ++k) {  // the loads first, all in flight together
         const long long i = (long long)blockIdx.x * kCountTile + k * 1024 + t;
         a[k] = make_float4(kFltMax, kFltMax, kFltMax, 0.f); a2[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (i < n) { a[k] = ph[2 * i]; if (CH == 4) a2[k] = ph[2 * i + 1]; }
+        if (i < n) { a[k] = ph[(size_t)rec_stride * i]; if (CH == 4) a2[k] = ph[(size_t)rec_stride * i + rec_b]; }
     }
     __syncthreads();
 #pragma unroll
@@ -314,7 +314,7 @@ __global__ __launch_bounds__(1024) void fast_count_kernel(const float* __restric
 // used in turn: this launch zeroes the OTHER one (idle until the next call), so no memset is needed in steady state and
 // no workgroup has to know when the others have read.  Big inputs: a workgroup walks several tiles, the scan is paid once.
 template <int CH>
-__global__ __launch_bounds__(1024, 8) void fast_scatter_kernel(const float* __restrict__ photons, int n, GridDev G, BrickLayout L, float radius,
+__global__ __launch_bounds__(1024, 8) void fast_scatter_kernel(const float* __restrict__ photons, uint32_t rec_stride, uint32_t rec_b, int n, GridDev G, BrickLayout L, float radius,
                                                             const uint32_t* __restrict__ hist, const uint32_t* __restrict__ run_base,
                                                             uint32_t* __restrict__ zero_next, int zero_words,
                                                             uint32_t* __restrict__ table, float* __restrict__ sorted) {
@@ -336,7 +336,7 @@ __global__ __launch_bounds__(1024, 8) void fast_scatter_kernel(const float* __re
         for (int k = 0; k < kScatterItems; ++k) {
             const long long i = (long long)tile * kScatterTile + k * 1024 + t;
             a[k] = make_float4(kFltMax, kFltMax, kFltMax, 0.f); b2[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (i < n) { a[k] = ph[2 * i]; if (CH == 4) b2[k] = ph[2 * i + 1]; }
+            if (i < n) { a[k] = ph[(size_t)rec_stride * i]; if (CH == 4) b2[k] = ph[(size_t)rec_stride * i + rec_b]; }
         }
         n_pairs = 0;
         if (tile < n_tiles) {
@@ -600,6 +600,17 @@ __global__ __launch_bounds__(kBrickThreads, (CH == 4 ? 4 : CPM_BRICK_WAVES)) voi
     }
 }
 
+// records from one layout to the other: a lane moves one record (two 16-byte loads, two 16-byte stores; one side of each pair is
+// contiguous across the wave whatever the direction)
+__global__ __launch_bounds__(256) void photons_convert_kernel(const float4* __restrict__ src, uint32_t ss, uint32_t sb, float4* __restrict__ dst,
+                                                              uint32_t ds, uint32_t db, size_t n) {
+    const size_t j = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (j >= n) return;
+    const float4 a = src[(size_t)ss * j], b = src[(size_t)ss * j + sb];
+    dst[(size_t)ds * j] = a;
+    dst[(size_t)ds * j + db] = b;
+}
+
 template <typename K>
 __host__ int allow_lds(cpm_ctx* ctx, K kernel, size_t bytes) {
     if (bytes <= 48 * 1024) return CPM_OK;
@@ -653,7 +664,15 @@ size_t cpm_fast_record_capacity(const cpm_grid_desc* grid, int n, float radius) 
 
 int cpm_bin_fast(cpm_ctx* ctx, const float* photons8, int n, const cpm_grid_desc* grid, float radius, uint32_t* brick_table,
                  float* sorted_pos_power, cpm_stream stream) {
+    return cpm_bin_fast_layout(ctx, photons8, CPM_PHOTONS_INTERLEAVED, n, grid, radius, brick_table, sorted_pos_power, stream);
+}
+
+int cpm_bin_fast_layout(cpm_ctx* ctx, const float* photons8, int layout, int n, const cpm_grid_desc* grid, float radius, uint32_t* brick_table,
+                        float* sorted_pos_power, cpm_stream stream) {
     CPM_ENTER(ctx);
+    CPM_REQUIRE(ctx, layout == CPM_PHOTONS_INTERLEAVED || layout == CPM_PHOTONS_PLANAR, "cpm_bin_fast: photon layout");
+    // half A of record j at float4 j * rs, half B rb behind it (the tracer's rec_stride / rec_b: n here is its N * I)
+    const uint32_t rs = layout == CPM_PHOTONS_PLANAR ? 1u : 2u, rb = layout == CPM_PHOTONS_PLANAR ? (uint32_t)(n > 0 ? n : 0) : 1u;
     GridDev G;
     int rc = make_grid_dev_fast(ctx, grid, G);
     if (rc) return rc;
@@ -692,10 +711,10 @@ int cpm_bin_fast(cpm_ctx* ctx, const float* photons8, int n, const cpm_grid_desc
         const dim3 cgrid((unsigned)tiles);
         if (G.channels == 1) {
             rc = allow_lds(ctx, fast_count_kernel<1>, lds); if (rc) return rc;
-            CPM_LAUNCH(ctx, fast_count_kernel<1>, cgrid, dim3(1024), lds, s, photons8, n, G, L, radius, hist, acc, run_base);
+            CPM_LAUNCH(ctx, fast_count_kernel<1>, cgrid, dim3(1024), lds, s, photons8, rs, rb, n, G, L, radius, hist, acc, run_base);
         } else {
             rc = allow_lds(ctx, fast_count_kernel<4>, lds); if (rc) return rc;
-            CPM_LAUNCH(ctx, fast_count_kernel<4>, cgrid, dim3(1024), lds, s, photons8, n, G, L, radius, hist, acc, run_base);
+            CPM_LAUNCH(ctx, fast_count_kernel<4>, cgrid, dim3(1024), lds, s, photons8, rs, rb, n, G, L, radius, hist, acc, run_base);
         }
         CPM_LAUNCH_CHECK(ctx, "fast_count_kernel");
     }
@@ -704,16 +723,34 @@ int cpm_bin_fast(cpm_ctx* ctx, const float* photons8, int n, const cpm_grid_desc
     const dim3 sgrid((unsigned)(stiles < smax ? stiles : smax));
     if (G.channels == 1) {
         rc = allow_lds(ctx, fast_scatter_kernel<1>, 2 * lds); if (rc) return rc;
-        CPM_LAUNCH(ctx, fast_scatter_kernel<1>, sgrid, dim3(1024), 2 * lds, s, photons8, n, G, L, radius, hist, run_base, zero_next, (int)hist_words, brick_table, sorted_pos_power);
+        CPM_LAUNCH(ctx, fast_scatter_kernel<1>, sgrid, dim3(1024), 2 * lds, s, photons8, rs, rb, n, G, L, radius, hist, run_base, zero_next, (int)hist_words, brick_table, sorted_pos_power);
     } else {
         rc = allow_lds(ctx, fast_scatter_kernel<4>, 2 * lds); if (rc) return rc;
-        CPM_LAUNCH(ctx, fast_scatter_kernel<4>, sgrid, dim3(1024), 2 * lds, s, photons8, n, G, L, radius, hist, run_base, zero_next, (int)hist_words, brick_table, sorted_pos_power);
+        CPM_LAUNCH(ctx, fast_scatter_kernel<4>, sgrid, dim3(1024), 2 * lds, s, photons8, rs, rb, n, G, L, radius, hist, run_base, zero_next, (int)hist_words, brick_table, sorted_pos_power);
     }
     CPM_LAUNCH_CHECK(ctx, "fast_scatter_kernel");
     ctx->fast_hist_parity ^= 1;
     ctx->fast_hist_words = hist_words;
     ctx->fast_last_table = brick_table;
     ctx->fast_last_radius = radius;
+    return CPM_OK;
+}
+
+int cpm_photons_convert(cpm_ctx* ctx, const float* src, int src_layout, float* dst, int dst_layout, size_t n_records, cpm_stream stream) {
+    CPM_ENTER(ctx);
+    CPM_REQUIRE(ctx, (src_layout == CPM_PHOTONS_INTERLEAVED || src_layout == CPM_PHOTONS_PLANAR) &&
+                         (dst_layout == CPM_PHOTONS_INTERLEAVED || dst_layout == CPM_PHOTONS_PLANAR), "cpm_photons_convert: layout");
+    if (n_records == 0) return CPM_OK;
+    CPM_REQUIRE(ctx, src && dst && src != dst, "cpm_photons_convert: null or aliased buffers");
+    CPM_REQUIRE(ctx, n_records < (1ull << 31), "cpm_photons_convert: more than 2^31 records");
+    CPM_REQUIRE_ALIGNED16(ctx, src, "cpm_photons_convert");
+    CPM_REQUIRE_ALIGNED16(ctx, dst, "cpm_photons_convert");
+    const uint32_t n = (uint32_t)n_records;
+    const uint32_t ss = src_layout == CPM_PHOTONS_PLANAR ? 1u : 2u, sb = src_layout == CPM_PHOTONS_PLANAR ? n : 1u;
+    const uint32_t ds = dst_layout == CPM_PHOTONS_PLANAR ? 1u : 2u, db = dst_layout == CPM_PHOTONS_PLANAR ? n : 1u;
+    CPM_LAUNCH(ctx, photons_convert_kernel, dim3((unsigned)div_up((long long)n_records, 256)), dim3(256), 0, (hipStream_t)stream,
+               reinterpret_cast<const float4*>(src), ss, sb, reinterpret_cast<float4*>(dst), ds, db, n_records);
+    CPM_LAUNCH_CHECK(ctx, "photons_convert_kernel");
     return CPM_OK;
 }
 

@@ -100,9 +100,9 @@ __global__ __launch_bounds__(256, 8) void trace_kernel(const TraceArgs A0) {
     uint2* rng = reinterpret_cast<uint2*>(A.rng);
     if (live && A.old_photons) {  // what the light-volume update subtracts: the records this thread is about to replace
         for (uint32_t k = 0; k < maxInteractions; ++k) {
-            const float4* q = reinterpret_cast<const float4*>(A.photons) + 2 * ((size_t)photonOffset + k * totalPhotons + (size_t)threadId);
-            float4* o = reinterpret_cast<float4*>(A.old_photons) + 2 * ((size_t)k * A.old_stride + (size_t)gid);
-            const float4 a = q[0], b = q[1];
+            const float4* q = reinterpret_cast<const float4*>(A.photons) + (size_t)A.rec_stride * ((size_t)photonOffset + k * totalPhotons + (size_t)threadId);
+            float4* o = reinterpret_cast<float4*>(A.old_photons) + 2 * ((size_t)k * A.old_stride + (size_t)gid);  // (kept as float8 records)
+            const float4 a = q[0], b = q[A.rec_b];
             o[0] = a; o[1] = b;
         }
     }
@@ -330,6 +330,9 @@ int trace_impl(cpm_ctx* ctx, const cpm_volume* vol, const cpm_tf* tf, const cpm_
     if (sel.old_photons) CPM_REQUIRE_ALIGNED16(ctx, sel.old_photons, "cpm_trace_selected");
     A.rng = rng_state;
     A.photons = photons8;
+    const bool planar = (p.flags & CPM_TRACE_PHOTONS_PLANAR) != 0;
+    A.rec_stride = planar ? 1u : 2u;
+    A.rec_b = planar ? (uint32_t)((long long)p.total_photons * p.max_interactions) : 1u;
     if (sel.lights) {
         A.n_spans = sel.n_lights;
         int base = 0;

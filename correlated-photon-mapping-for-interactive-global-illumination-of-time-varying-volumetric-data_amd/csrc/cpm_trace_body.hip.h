@@ -40,6 +40,10 @@ struct TraceArgs {
     uint32_t* reset_importances;
     uint32_t* rng;
     float* photons;
+    // where record j's two 16-byte halves lie, in float4 units: half A = (position, power.r) at j * rec_stride, half B =
+    // (power.g, power.b, theta, phi) rec_b behind it.  (2, 1): the reference's float8 record (cl/photon.cl:49-63); (1, N * I): the
+    // two-plane layout of CPM_TRACE_PHOTONS_PLANAR -- what the bin reads lies in one plane.
+    uint32_t rec_stride, rec_b;
     unsigned long long* step_counter;  // nullable (statistics build of the launch)
     const uint32_t* chunk_order;       // cpm_trace_order (nullable): workgroup b takes chunk chunk_order[b] ...
     uint32_t* chunk_cost;              // ... and every wave adds its longest walk to chunk_cost[chunk]
@@ -183,12 +187,12 @@ CPM_DEV f3 phase_sample(int type, float g, f3 w, float u1, float u2, float* pdf)
     return d;
 }
 
-CPM_DEV void write_photon(float* photons, size_t id, f3 p, f3 pw, float th, float ph) {
+CPM_DEV void write_photon(const TraceArgs& A, size_t id, f3 p, f3 pw, float th, float ph) {
     // (plain stores: with the tile-wise chunk order below a streaming hint no longer helps this launch, and the bin's count
     // launch reads the records 0.8 us sooner without it -- 5 us sooner at 4 M photons)
-    float4* q = reinterpret_cast<float4*>(photons) + 2 * id;
+    float4* q = reinterpret_cast<float4*>(A.photons) + (size_t)A.rec_stride * id;
     q[0] = make_float4(p.x, p.y, p.z, pw.x);
-    q[1] = make_float4(pw.y, pw.z, th, ph);
+    q[A.rec_b] = make_float4(pw.y, pw.z, th, ph);
 }
 
 template <int DT, bool LINEAR = false>
@@ -337,7 +341,7 @@ CPM_DEV void walk_segment(const TraceArgs& A, const float* lut, const float* lut
         }
         if (scatter) {
             S.power.x *= scatteringAlbedo; S.power.y *= scatteringAlbedo; S.power.z *= scatteringAlbedo;
-            write_photon(A.photons, photonId, S.origin, S.power, S.th, S.ph);
+            write_photon(A, photonId, S.origin, S.power, S.th, S.ph);
             S.tStart = 0.f; S.tEnd = kFltMax;
             float u1 = rand01_(S.rx, S.rc), u2 = rand01_(S.rx, S.rc);
             S.direction = phase_sample(A.p.shading_type, A.p.material[0], S.direction, u1, u2, nullptr);
@@ -345,7 +349,7 @@ CPM_DEV void walk_segment(const TraceArgs& A, const float* lut, const float* lut
             S.scatterEvent = ray_box_(A.bmin, A.bmax, S.origin, S.direction, S.tStart, S.tEnd);
             S.tStart = S.tStart + 0.5f * A.p.step_size;
         } else {
-            write_photon(A.photons, photonId, S.origin, S.power, S.th, S.ph);
+            write_photon(A, photonId, S.origin, S.power, S.th, S.ph);
             S.power.x = S.power.y = S.power.z = kFltMax;  // read by the recomputation detector
             S.scatterEvent = false;
         }
@@ -361,7 +365,7 @@ CPM_DEV void walk_finish(const TraceArgs& A, int threadId, const WalkState& S) {
         size_t photonId = (size_t)photonOffset + i * totalPhotons + (size_t)threadId;
         f3 p = { kFltMax, kFltMax, kFltMax };
         f3 pw = { S.power.x, kFltMax, kFltMax };
-        write_photon(A.photons, photonId, p, pw, S.th, S.ph);
+        write_photon(A, photonId, p, pw, S.th, S.ph);
     }
     if (A.p.flags & CPM_TRACE_PROGRESSIVE) reinterpret_cast<uint2*>(A.rng)[photonOffset + threadId] = make_uint2(S.rx, S.rc);  // :211-215
     if (A.reset_importances) A.reset_importances[photonOffset + threadId] = 2147483647u;  // resetPhotonImportance (tracercl.cpp:529)

@@ -217,6 +217,27 @@ class PhotonFrame:
         self._order_stale = False
         self.brick_table = None   # cpm_bin_fast's table and records (every photon in all the bricks it reaches), allocated on first use
         self.sorted_fast = None
+        self.photon_layout = B.CPM_PHOTONS_INTERLEAVED   # how self.photons is laid out (set_planar_records)
+        self._records8 = None
+
+    def set_planar_records(self, on=True):
+        """The tracer writes -- and the brick bin reads -- the two-plane record layout (CPM_TRACE_PHOTONS_PLANAR / cpm_bin_fast_layout):
+        the same records, position + first power channel in one plane; self.photons then holds that layout and `records()` gives
+        the float8 form.  For frames of trace -> bin_fast -> gather_fast; everything else on this class reads float8 records."""
+        self.photon_layout = B.CPM_PHOTONS_PLANAR if on else B.CPM_PHOTONS_INTERLEAVED
+        if on:
+            self.params.flags |= B.CPM_TRACE_PHOTONS_PLANAR
+        else:
+            self.params.flags &= ~B.CPM_TRACE_PHOTONS_PLANAR
+
+    def records(self):
+        """The photon records as float8 rows (what the `photons` port carries), converted when self.photons is planar."""
+        if self.photon_layout == B.CPM_PHOTONS_INTERLEAVED:
+            return self.photons
+        if self._records8 is None:
+            self._records8 = self.torch.empty_like(self.photons)
+        self.ctx.photons_convert(self.photons, B.CPM_PHOTONS_PLANAR, self._records8, B.CPM_PHOTONS_INTERLEAVED, self.n * self.I)
+        return self._records8
 
     # stages
     #: every so many full traces one is measured (what each chunk cost) and the order re-sorted from it (cpm_trace_order_update);
@@ -270,7 +291,7 @@ class PhotonFrame:
         cap = max(self.ctx.fast_record_capacity(self.grid, self.n * self.I, self.radius), 1)
         if self.sorted_fast is None or self.sorted_fast.shape[0] < cap:   # (a progressive radius schedule only ever shrinks it)
             self.sorted_fast = self.torch.empty((cap, 4 if self.grid.channels == 1 else 8), dtype=self.torch.float32, device=self.ctx.device)
-        self.ctx.bin_fast(self.photons, self.n * self.I, self.grid, self.radius, self.brick_table, self.sorted_fast)
+        self.ctx.bin_fast(self.photons, self.n * self.I, self.grid, self.radius, self.brick_table, self.sorted_fast, layout=self.photon_layout)
 
     def gather_fast(self, accumulate=False, out=None, nonzero_bricks=None):
         self.ctx.gather_fast(self.sorted_fast, self.brick_table, self.n * self.I, self.grid, self.radius, self.scale,

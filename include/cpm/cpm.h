@@ -180,8 +180,20 @@ int cpm_light_sample_mesh_intersection(cpm_ctx* ctx, const float* vertices3, con
 
 enum {
     CPM_TRACE_PROGRESSIVE = 1,          /* -D PROGRESSIVE_PHOTON_MAPPING: write RNG state back */
-    CPM_TRACE_NO_SINGLE_SCATTERING = 2  /* -D NO_SINGLE_SCATTERING */
+    CPM_TRACE_NO_SINGLE_SCATTERING = 2, /* -D NO_SINGLE_SCATTERING */
+    CPM_TRACE_PHOTONS_PLANAR = 4        /* write the records in the two-plane layout (CPM_PHOTONS_PLANAR below) */
 };
+/* How the N * I photon records lie in their buffer of 8 * N * I floats.
+ * INTERLEAVED: the reference's float8 record (ref progressivephotonmapping/cl/photon.cl:49-63): record j at floats [8 j, 8 j + 8) =
+ *   (x, y, z, powerR | powerG, powerB, theta, phi).  What every entry point takes unless it says otherwise, and what the
+ *   `photons` port carries.
+ * PLANAR: plane A = float4[N * I] of (x, y, z, powerR) at the start of the buffer, plane B = float4[N * I] of
+ *   (powerG, powerB, theta, phi) behind it (record j = A[j], B[j]; the same bytes, the same records, `id = offset + k N + i` as
+ *   in cl/photontracer.cl:166).  The tracer writes the same two 16-byte stores per record either way; what reads only position and
+ *   the first power channel -- the brick bin of a one-channel light volume -- then streams 16 bytes per record instead of 32.
+ *   Written by cpm_trace / cpm_trace_emitted / cpm_trace_lights with CPM_TRACE_PHOTONS_PLANAR, read by cpm_bin_fast_layout,
+ *   converted by cpm_photons_convert for every other consumer. */
+enum { CPM_PHOTONS_INTERLEAVED = 0, CPM_PHOTONS_PLANAR = 1 };
 enum { CPM_PHASE_HENYEY_GREENSTEIN = 0, CPM_PHASE_ISOTROPIC = 1 };
 
 /* Scalar arguments of photonTracerKernel
@@ -420,6 +432,13 @@ size_t cpm_fast_record_capacity(const cpm_grid_desc* grid, int n, float radius);
  * radius: the photon radius (texture units) the gather will use -- it decides which bricks a photon is filed under. */
 int cpm_bin_fast(cpm_ctx* ctx, const float* photons8, int n, const cpm_grid_desc* grid, float radius, uint32_t* brick_table,
                  float* sorted_pos_power, cpm_stream stream);
+/* The same for records in either layout (CPM_PHOTONS_*; n = N * I records, for PLANAR also the distance between the planes):
+ * the same table and the same records filed, bit for bit -- the planar form reads 16 instead of 32 bytes per photon when
+ * channels == 1. */
+int cpm_bin_fast_layout(cpm_ctx* ctx, const float* photons, int layout, int n, const cpm_grid_desc* grid, float radius,
+                        uint32_t* brick_table, float* sorted_pos_power, cpm_stream stream);
+/* dst (layout dst_layout) = the n records of src (layout src_layout); src != dst.  A pure copy: 64 bytes moved per record. */
+int cpm_photons_convert(cpm_ctx* ctx, const float* src, int src_layout, float* dst, int dst_layout, size_t n_records, cpm_stream stream);
 
 /* grid_out[v] = (accumulate ? grid_out[v] : 0) + float(sum over photons of fixed(power * k * w(v, photon))) with
  * k = relative_irradiance_scale / (4 pi) as in cpm_splat.  n, grid, radius: as given to cpm_bin_fast. */

@@ -13,6 +13,9 @@ ctx = B.Context(0)
 tf_alpha = os.environ.get("CPM_TF_ALPHA")  # constant-alpha transfer function instead of the workspace's (1.0 = one Woodcock step per photon)
 fr = P.PhotonFrame(ctx, S.heterogeneous_volume(vdim), (S.homogeneous_tf(float(tf_alpha)) if tf_alpha else S.workspace_tf()), nside, (gdim,) * 3, light_travel_direction=(0.3, 0.5, -1.0))
 fr.frame(); fr.frame_fast()
+if stage == "frame_fast" and os.environ.get("CPM_RECORDS", "planar") == "planar":   # the bench's default: two-plane records
+    fr.set_planar_records(True)
+    fr.frame_fast()
 torch.cuda.synchronize()
 fn = {"trace": fr.trace, "bin_fast": fr.bin_fast, "gather_fast": fr.gather_fast, "frame_fast": fr.frame_fast, "frame": fr.frame,
       "bin": fr.bin, "gather": fr.gather}[stage]
