@@ -49,6 +49,8 @@ ABI_SYMBOLS = [
     "cpm_allreduce_grid", "cpm_reduce_grid", "cpm_allreduce_grids", "cpm_allreduce_grid_bricks",
     "cpm_sparse_reduce_create", "cpm_sparse_reduce_destroy", "cpm_sparse_reduce_bricks", "cpm_sparse_reduce_capacity_for",
     "cpm_allreduce_grid_sparse", "cpm_sparse_reduce_complete",
+    "cpm_bricklist_reduce_create", "cpm_bricklist_reduce_destroy", "cpm_bricklist_reduce_bricks", "cpm_bricklist_capacity_for",
+    "cpm_bricklist_segment_bytes", "cpm_reduce_grid_bricklists", "cpm_bricklist_reduce_complete",
     "cpm_light_volume_texels", "cpm_gl_available", "cpm_gl_register_buffer", "cpm_gl_acquire", "cpm_gl_release",
     "cpm_gl_buffer_pointer", "cpm_gl_copy_to_buffer", "cpm_gl_unregister",
 ]
@@ -145,6 +147,12 @@ class SparseReduceInfo(C.Structure):
     """cpm_sparse_reduce_info"""
     _fields_ = [("ticket", C.c_uint64), ("n_bricks", C.c_uint32), ("n_union", C.c_uint32), ("capacity", C.c_uint32), ("mode", C.c_int),
                 ("reduce_bytes", C.c_uint64), ("dense_bytes", C.c_uint64)]
+
+
+class BricklistInfo(C.Structure):
+    """cpm_bricklist_info"""
+    _fields_ = [("ticket", C.c_uint64), ("n_bricks", C.c_uint32), ("n_own", C.c_uint32), ("capacity", C.c_uint32), ("resent", C.c_int32),
+                ("sent_bytes", C.c_uint64), ("received_bytes", C.c_uint64), ("dense_bytes", C.c_uint64), ("listed_bricks", C.c_uint32)]
 
 
 class EmitterDesc(C.Structure):
@@ -278,6 +286,13 @@ def load_library() -> C.CDLL:
         "cpm_sparse_reduce_capacity_for": (u32, [u32, C.c_longlong]),
         "cpm_allreduce_grid_sparse": (i32, [vp, vp, vp, vp, vp, i32, i32, u32, P(C.c_uint64), vp]),
         "cpm_sparse_reduce_complete": (i32, [vp, vp, C.c_uint64, vp, P(SparseReduceInfo)]),
+        "cpm_bricklist_reduce_create": (i32, [vp, vp, P(GridDesc), i32, P(vp)]),
+        "cpm_bricklist_reduce_destroy": (None, [vp]),
+        "cpm_bricklist_reduce_bricks": (u32, [vp]),
+        "cpm_bricklist_capacity_for": (u32, [u32, C.c_longlong]),
+        "cpm_bricklist_segment_bytes": (C.c_uint64, [u32, i32]),
+        "cpm_reduce_grid_bricklists": (i32, [vp, vp, vp, vp, P(C.c_uint64), vp]),
+        "cpm_bricklist_reduce_complete": (i32, [vp, vp, C.c_uint64, vp, P(BricklistInfo)]),
         "cpm_gl_available": (i32, [vp]),
         "cpm_gl_register_buffer": (i32, [vp, u32, i32, P(vp)]),
         "cpm_light_volume_texels": (i32, [vp, vp, sz, i32, vp, vp]),
@@ -627,6 +642,11 @@ class Context:
                                                        self._ptr(brick_mask), C.byref(n_union), self._stream()))
         return int(n_union.value)
 
+    def bricklist_reduce_create(self, comm, grid: "GridDesc", root: int = 0) -> "BricklistReduce":
+        h = C.c_void_p()
+        self._check(self.lib.cpm_bricklist_reduce_create(self.h, comm.h, C.byref(grid), root, C.byref(h)))
+        return BricklistReduce(self, comm, h, root)
+
     def sparse_reduce_create(self, comm: "Comm", grid: GridDesc) -> "SparseReduce":
         h = C.c_void_p()
         self._check(self.lib.cpm_sparse_reduce_create(self.h, comm.h, C.byref(grid), C.byref(h)))
@@ -850,6 +870,44 @@ class SparseReduce:
     def close(self):
         if self.h:
             self.ctx.lib.cpm_sparse_reduce_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class BricklistReduce:
+    """cpm_bricklist_reduce: the frame's reduce to the display GPU as per-rank lists of non-zero 4x4x4 bricks (cpm.h,
+    cpm_reduce_grid_bricklists): for shards whose bricks are (nearly) disjoint -- contiguous photon ranges."""
+
+    def __init__(self, ctx: "Context", comm: "Comm", h, root: int):
+        self.ctx, self.comm, self.h, self.root = ctx, comm, h, root
+
+    @property
+    def n_bricks(self) -> int:
+        return int(self.ctx.lib.cpm_bricklist_reduce_bricks(self.h))
+
+    def start(self, grid, nonzero_bricks=None) -> int:
+        """Enqueue on the current stream (in place: the root's grid becomes the sum, the others' are read); returns the ticket."""
+        ticket = C.c_uint64(0)
+        self.ctx._check(self.ctx.lib.cpm_reduce_grid_bricklists(self.ctx.h, self.h, self.ctx._ptr(grid),
+                                                                self.ctx._ptr(nonzero_bricks) if nonzero_bricks is not None else None,
+                                                                C.byref(ticket), self.ctx._stream()))
+        return int(ticket.value)
+
+    def complete(self, ticket: int) -> BricklistInfo:
+        """Before the ticket's grid is read (root) or gathered into again (every rank): the exchange repeated at exact size where a
+        rank's list had outgrown its segment; the ticket's figures."""
+        info = BricklistInfo()
+        self.ctx._check(self.ctx.lib.cpm_bricklist_reduce_complete(self.ctx.h, self.h, ticket, self.ctx._stream(), C.byref(info)))
+        return info
+
+    def close(self):
+        if self.h:
+            self.ctx.lib.cpm_bricklist_reduce_destroy(self.h)
             self.h = None
 
     def __del__(self):

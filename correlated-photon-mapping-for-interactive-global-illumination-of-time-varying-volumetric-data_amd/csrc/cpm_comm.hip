@@ -56,6 +56,42 @@ struct cpm_sparse_reduce {
     uint64_t last_union_ticket = 0;
 };
 
+// cpm_reduce_grid_bricklists: everything one (communicator, grid shape, root) needs
+constexpr int kBricklistMaxRanks = 16;
+struct cpm_bricklist_reduce {
+    static constexpr int kSlots = 4;  // tickets in flight (issued, not yet completed)
+    cpm_comm* comm = nullptr;
+    int device = 0, root = 0;
+    int dims[3] = { 0, 0, 0 }, channels = 1, bxn = 0, byn = 0, bzn = 0;
+    uint32_t nb = 0;
+    size_t cells = 0;
+    // a sender's own bricks (the root needs none of these)
+    uint8_t* mask = nullptr;     // nb bytes (+ 16)
+    uint32_t* list = nullptr;    // nb: its non-zero bricks, ascending
+    uint32_t* slot = nullptr;    // nb: scratch of brick_slots_kernel
+    uint32_t* count = nullptr;   // device word: their number
+    // pinned host words [kSlots][kBricklistMaxRanks]: ticket << 32 | the brick count of rank r's segment -- written by the sender's list
+    // launch (its own word) and by the root's add launches (every sender's word, from the segment's header)
+    unsigned long long* mailbox = nullptr;
+    unsigned long long* mailbox_dev = nullptr;
+    // a sender's segment / the root's received segments, per slot; and the buffer of an exchange repeated at exact size
+    void* seg[kSlots] = { nullptr, nullptr, nullptr, nullptr };
+    size_t seg_bytes[kSlots] = { 0, 0, 0, 0 };
+    void* again = nullptr;
+    size_t again_bytes = 0;
+    uint64_t next_ticket = 1;
+    struct Slot {
+        uint64_t ticket = 0;
+        float* grid = nullptr;
+        uint32_t cap[kBricklistMaxRanks] = {};      // per sender (a sender fills its own entry only)
+        uint32_t counts[kBricklistMaxRanks] = {};
+        bool known[kBricklistMaxRanks] = {};
+        bool completed = true;
+        int resent = 0;
+        hipStream_t stream = nullptr;
+    } slots[kSlots];
+};
+
 namespace {
 
 struct Rccl {
@@ -68,6 +104,8 @@ struct Rccl {
     ncclResult_t (*Reduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, int, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*GroupStart)() = nullptr;
     ncclResult_t (*GroupEnd)() = nullptr;
+    ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
     std::string error;
 };
@@ -98,6 +136,8 @@ void load_rccl() {
     R.Reduce = reinterpret_cast<decltype(R.Reduce)>(sym("ncclReduce"));
     R.GroupStart = reinterpret_cast<decltype(R.GroupStart)>(sym("ncclGroupStart"));
     R.GroupEnd = reinterpret_cast<decltype(R.GroupEnd)>(sym("ncclGroupEnd"));
+    R.Send = reinterpret_cast<decltype(R.Send)>(sym("ncclSend"));
+    R.Recv = reinterpret_cast<decltype(R.Recv)>(sym("ncclRecv"));
     R.GetErrorString = reinterpret_cast<decltype(R.GetErrorString)>(sym("ncclGetErrorString"));
 }
 
@@ -724,6 +764,360 @@ int cpm_sparse_reduce_complete(cpm_ctx* ctx, cpm_sparse_reduce* sr, uint64_t tic
         info->ticket = ticket; info->n_bricks = sr->nb; info->n_union = sl.n_union; info->capacity = sl.capacity; info->mode = mode;
         info->dense_bytes = (uint64_t)sr->cells * sizeof(float) * (uint64_t)sr->channels;
         info->reduce_bytes = (uint64_t)sr->nb + (mode != 1 ? (uint64_t)sl.capacity * brick_bytes : 0ull) + (mode != 0 ? info->dense_bytes : 0ull);
+    }
+    return CPM_OK;
+}
+
+}  // extern "C"
+
+// ---- cpm_reduce_grid_bricklists ----------------------------------------------------------------------------------------------
+// A segment = [ header: count, capacity, ticket, magic ][ capacity bricks of 64 * CH floats ][ capacity brick ids ].
+
+namespace {
+
+constexpr uint32_t kSegMagic = 0x62726b6cu;  // "brkl"
+struct SegHeader { uint32_t count, capacity, ticket, magic; };
+
+__host__ __device__ inline size_t seg_payload_offset() { return sizeof(SegHeader); }
+__host__ __device__ inline size_t seg_ids_offset(uint32_t capacity, int channels) { return sizeof(SegHeader) + (size_t)capacity * 256u * (size_t)channels; }
+__host__ inline size_t seg_size(uint32_t capacity, int channels) { return seg_ids_offset(capacity, channels) + (size_t)capacity * 4u; }
+
+// sender: its first min(count, capacity) bricks -> the segment; the header alone when they do not fit.  16 lanes per brick, a
+// 16-byte piece of a grid row each (as brick_pack_kernel)
+template <int CH, bool VEC>
+__global__ __launch_bounds__(256) void bricklist_pack_kernel(const uint32_t* __restrict__ list, const uint32_t* __restrict__ count, uint32_t capacity,
+                                                             uint32_t ticket, int dx, int dy, int dz, int bxn, int byn, const float* __restrict__ grid,
+                                                             unsigned char* __restrict__ seg) {
+    const uint32_t n = *count;
+    if (blockIdx.x == 0 && threadIdx.x == 0) *reinterpret_cast<SegHeader*>(seg) = SegHeader{ n, capacity, ticket, kSegMagic };
+    if (n > capacity) return;
+    const uint32_t s = blockIdx.x * 16u + (threadIdx.x >> 4);
+    if (s >= n) return;
+    const int r = threadIdx.x & 15;
+    const uint32_t b = list[s];
+    if (r == 0) reinterpret_cast<uint32_t*>(seg + seg_ids_offset(capacity, CH))[s] = b;
+    const int bx = (int)(b % (uint32_t)bxn), by = (int)((b / (uint32_t)bxn) % (uint32_t)byn), bz = (int)(b / (uint32_t)(bxn * byn));
+    const int y = by * 4 + (r & 3), z = bz * 4 + (r >> 2);
+    float4 f[CH];
+#pragma unroll
+    for (int c = 0; c < CH; ++c) f[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (y < dy && z < dz) {
+        const size_t v = (size_t)(bx * 4) + (size_t)dx * ((size_t)y + (size_t)dy * (size_t)z);
+        if (VEC) {
+#pragma unroll
+            for (int c = 0; c < CH; ++c) f[c] = reinterpret_cast<const float4*>(grid + v * CH)[c];
+        } else {
+            float* ff = reinterpret_cast<float*>(f);
+            for (int x = 0; x < 4 && bx * 4 + x < dx; ++x)
+                for (int c = 0; c < CH; ++c) ff[x * CH + c] = grid[(v + x) * CH + c];
+        }
+    }
+    float4* o = reinterpret_cast<float4*>(seg + seg_payload_offset()) + ((size_t)s * 16 + r) * CH;
+#pragma unroll
+    for (int c = 0; c < CH; ++c) o[c] = f[c];
+}
+
+// root: one received segment added into the grid (its bricks are distinct: no two lanes meet); the segment's brick count goes to
+// the host's mailbox word of that sender.  A segment that carries only its header (count > capacity) adds nothing -- the exchange is
+// repeated at cpm_bricklist_reduce_complete.  A header that is not this ticket's (a transport fault) counts as empty and says so.
+template <int CH, bool VEC>
+__global__ __launch_bounds__(256) void bricklist_add_kernel(const unsigned char* __restrict__ seg, uint32_t capacity, uint32_t ticket, uint32_t nb,
+                                                            int dx, int dy, int dz, int bxn, int byn, float* __restrict__ grid,
+                                                            unsigned long long* mailbox) {
+    const SegHeader h = *reinterpret_cast<const SegHeader*>(seg);
+    const bool sane = h.magic == kSegMagic && h.ticket == ticket && h.capacity == capacity;
+    const uint32_t n = sane ? h.count : 0xffffffffu;
+    if (mailbox && blockIdx.x == 0 && threadIdx.x == 0)
+        __hip_atomic_store(mailbox, ((unsigned long long)ticket << 32) | (unsigned long long)n, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (n > capacity) return;
+    const uint32_t s = blockIdx.x * 16u + (threadIdx.x >> 4);
+    if (s >= n) return;
+    const int r = threadIdx.x & 15;
+    const uint32_t b = reinterpret_cast<const uint32_t*>(seg + seg_ids_offset(capacity, CH))[s];
+    if (b >= nb) return;
+    const int bx = (int)(b % (uint32_t)bxn), by = (int)((b / (uint32_t)bxn) % (uint32_t)byn), bz = (int)(b / (uint32_t)(bxn * byn));
+    const int y = by * 4 + (r & 3), z = bz * 4 + (r >> 2);
+    if (y >= dy || z >= dz) return;
+    const float4* p = reinterpret_cast<const float4*>(seg + seg_payload_offset()) + ((size_t)s * 16 + r) * CH;
+    const size_t v = (size_t)(bx * 4) + (size_t)dx * ((size_t)y + (size_t)dy * (size_t)z);
+    if (VEC) {
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+            float4* q = reinterpret_cast<float4*>(grid + v * CH) + c;
+            const float4 a = *q, d = p[c];
+            *q = make_float4(a.x + d.x, a.y + d.y, a.z + d.z, a.w + d.w);
+        }
+    } else {
+        const float* ff = reinterpret_cast<const float*>(p);
+        for (int x = 0; x < 4 && bx * 4 + x < dx; ++x)
+            for (int c = 0; c < CH; ++c) grid[(v + x) * CH + c] += ff[x * CH + c];
+    }
+}
+
+int bricklist_grow(cpm_ctx* ctx, void** buf, size_t* have, size_t need, hipStream_t s) {
+    if (*have >= need) return CPM_OK;
+    if (*buf) {  // (launches that read the old block may still be queued)
+        CPM_HIP_CHECK(ctx, hipStreamSynchronize(s));
+        (void)hipFree(*buf);
+        *buf = nullptr; *have = 0;
+    }
+    const size_t bytes = need + need / 4 + 4096;
+    if (hipMalloc(buf, bytes) != hipSuccess) { (void)hipGetLastError(); *buf = nullptr; return set_error(ctx, CPM_ERR_OUT_OF_MEMORY, "cpm_reduce_grid_bricklists", "segment buffer"); }
+    *have = bytes;
+    return CPM_OK;
+}
+
+// rank r's brick count of an issued ticket: a poll of the pinned word its list launch (a sender's own) or the root's add launch wrote
+int bricklist_count(cpm_ctx* ctx, cpm_bricklist_reduce* br, cpm_bricklist_reduce::Slot& sl, int r) {
+    if (sl.known[r]) return CPM_OK;
+    const volatile unsigned long long* mb = br->mailbox + (sl.ticket % cpm_bricklist_reduce::kSlots) * kBricklistMaxRanks + r;
+    const auto t0 = std::chrono::steady_clock::now();
+    bool synced = false;
+    for (unsigned spin = 0;; ++spin) {
+        const unsigned long long v = __atomic_load_n(mb, __ATOMIC_ACQUIRE);
+        if ((uint32_t)(v >> 32) == (uint32_t)sl.ticket) { sl.counts[r] = (uint32_t)v; sl.known[r] = true; return CPM_OK; }
+        if (synced) return set_error(ctx, CPM_ERR_DEVICE, "cpm_bricklist_reduce", "the brick count of a ticket never arrived");
+        if ((spin & 1023u) == 1023u && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(2)) {
+            CPM_HIP_CHECK(ctx, hipStreamSynchronize(sl.stream));
+            synced = true;
+        }
+        __builtin_ia32_pause();
+    }
+}
+
+int bricklist_pack(cpm_ctx* ctx, cpm_bricklist_reduce* br, uint32_t capacity, uint32_t ticket, const float* grid, void* seg, hipStream_t s) {
+    const bool vec = (br->dims[0] & 3) == 0;
+    const dim3 g((unsigned)div_up(capacity, 16));
+    unsigned char* sg = static_cast<unsigned char*>(seg);
+#define CPM_BL_PACK(CH, VEC) CPM_LAUNCH(ctx, (bricklist_pack_kernel<CH, VEC>), g, dim3(256), 0, s, br->list, br->count, capacity, ticket, br->dims[0], br->dims[1], br->dims[2], br->bxn, br->byn, grid, sg)
+    if (br->channels == 1) { if (vec) CPM_BL_PACK(1, true); else CPM_BL_PACK(1, false); }
+    else { if (vec) CPM_BL_PACK(4, true); else CPM_BL_PACK(4, false); }
+#undef CPM_BL_PACK
+    CPM_LAUNCH_CHECK(ctx, "bricklist_pack_kernel");
+    return CPM_OK;
+}
+
+int bricklist_add(cpm_ctx* ctx, cpm_bricklist_reduce* br, uint32_t capacity, uint32_t ticket, const void* seg, float* grid, unsigned long long* mailbox,
+                  hipStream_t s) {
+    const bool vec = (br->dims[0] & 3) == 0;
+    const dim3 g((unsigned)div_up(capacity, 16));
+    const unsigned char* sg = static_cast<const unsigned char*>(seg);
+#define CPM_BL_ADD(CH, VEC) CPM_LAUNCH(ctx, (bricklist_add_kernel<CH, VEC>), g, dim3(256), 0, s, sg, capacity, ticket, br->nb, br->dims[0], br->dims[1], br->dims[2], br->bxn, br->byn, grid, mailbox)
+    if (br->channels == 1) { if (vec) CPM_BL_ADD(1, true); else CPM_BL_ADD(1, false); }
+    else { if (vec) CPM_BL_ADD(4, true); else CPM_BL_ADD(4, false); }
+#undef CPM_BL_ADD
+    CPM_LAUNCH_CHECK(ctx, "bricklist_add_kernel");
+    return CPM_OK;
+}
+
+uint32_t round_up_64(uint64_t v) { return (uint32_t)((v + 63ull) & ~63ull); }
+
+// a sender's non-zero bricks of `grid` -> br->list (ascending) and br->count; the count also to `mailbox` when given.  marks: what
+// cpm_gather_fast_marked left for this grid (else a pass over the grid)
+int bricklist_own_list(cpm_ctx* ctx, cpm_bricklist_reduce* br, const float* grid, const uint8_t* marks, unsigned long long* mailbox, uint32_t ticket,
+                       hipStream_t s) {
+    if (marks) {
+        CPM_HIP_CHECK(ctx, hipMemcpyAsync(br->mask, marks, br->nb, hipMemcpyDeviceToDevice, s));
+    } else {
+        const bool vec = (br->dims[0] & 3) == 0;
+        const dim3 g((unsigned)div_up(br->nb, 16));
+        const int dx = br->dims[0], dy = br->dims[1], dz = br->dims[2];
+        if (br->channels == 1) {
+            if (vec) CPM_LAUNCH(ctx, (brick_nonzero_kernel<1, true>), g, dim3(256), 0, s, grid, dx, dy, dz, br->bxn, br->byn, br->nb, br->mask);
+            else CPM_LAUNCH(ctx, (brick_nonzero_kernel<1, false>), g, dim3(256), 0, s, grid, dx, dy, dz, br->bxn, br->byn, br->nb, br->mask);
+        } else {
+            if (vec) CPM_LAUNCH(ctx, (brick_nonzero_kernel<4, true>), g, dim3(256), 0, s, grid, dx, dy, dz, br->bxn, br->byn, br->nb, br->mask);
+            else CPM_LAUNCH(ctx, (brick_nonzero_kernel<4, false>), g, dim3(256), 0, s, grid, dx, dy, dz, br->bxn, br->byn, br->nb, br->mask);
+        }
+        CPM_LAUNCH_CHECK(ctx, "brick_nonzero_kernel");
+    }
+    CPM_LAUNCH(ctx, brick_slots_kernel, dim3((unsigned)div_up(br->nb, 4096)), dim3(1024), 0, s, br->mask, br->nb, br->list, br->slot, br->count, mailbox, ticket);
+    CPM_LAUNCH_CHECK(ctx, "brick_slots_kernel");
+    return CPM_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+uint32_t cpm_bricklist_capacity_for(uint32_t n_bricks, long long previous_count) {
+    if (n_bricks == 0) return 0;
+    const uint32_t all = round_up_64(n_bricks);
+    const uint64_t c = previous_count < 0 ? (uint64_t)n_bricks / 4 : (uint64_t)previous_count + (uint64_t)previous_count / 4 + 64ull;
+    const uint32_t cap = round_up_64(c);
+    return cap == 0 ? 64u : (cap > all ? all : cap);
+}
+
+uint64_t cpm_bricklist_segment_bytes(uint32_t capacity, int channels) { return (uint64_t)seg_size(capacity, channels); }
+
+int cpm_bricklist_reduce_create(cpm_ctx* ctx, cpm_comm* comm, const cpm_grid_desc* gd, int root, cpm_bricklist_reduce** out) {
+    CPM_ENTER(ctx);
+    CPM_REQUIRE(ctx, comm && gd && out, "cpm_bricklist_reduce_create: null argument");
+    CPM_REQUIRE(ctx, gd->channels == 1 || gd->channels == 4, "cpm_bricklist_reduce_create: channels");
+    CPM_REQUIRE(ctx, gd->dims[0] >= 1 && gd->dims[1] >= 1 && gd->dims[2] >= 1, "cpm_bricklist_reduce_create: dims");
+    CPM_REQUIRE(ctx, (unsigned long long)gd->dims[0] * gd->dims[1] * gd->dims[2] < (1ull << 31), "cpm_bricklist_reduce_create: more than 2^31 cells");
+    CPM_REQUIRE(ctx, root >= 0 && root < comm->size, "cpm_bricklist_reduce_create: root");
+    CPM_REQUIRE(ctx, comm->size <= kBricklistMaxRanks, "cpm_bricklist_reduce_create: more than 16 ranks");
+    *out = nullptr;
+    cpm_bricklist_reduce* br = new (std::nothrow) cpm_bricklist_reduce();
+    if (!br) return set_error(ctx, CPM_ERR_OUT_OF_MEMORY, "cpm_bricklist_reduce_create", "host allocation failed");
+    br->comm = comm; br->device = ctx->device; br->root = root;
+    for (int a = 0; a < 3; ++a) br->dims[a] = gd->dims[a];
+    br->channels = gd->channels;
+    br->bxn = div_up(gd->dims[0], 4); br->byn = div_up(gd->dims[1], 4); br->bzn = div_up(gd->dims[2], 4);
+    br->nb = (uint32_t)((size_t)br->bxn * br->byn * br->bzn);
+    br->cells = (size_t)gd->dims[0] * gd->dims[1] * gd->dims[2];
+    const size_t nb = br->nb, words = (size_t)cpm_bricklist_reduce::kSlots * kBricklistMaxRanks;
+    bool ok = hipHostMalloc((void**)&br->mailbox, words * 8, hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess &&
+              hipHostGetDevicePointer((void**)&br->mailbox_dev, br->mailbox, 0) == hipSuccess;
+    if (ok && comm->rank != root)
+        ok = hipMalloc((void**)&br->mask, nb + 16) == hipSuccess && hipMalloc((void**)&br->list, nb * 4) == hipSuccess &&
+             hipMalloc((void**)&br->slot, nb * 4) == hipSuccess && hipMalloc((void**)&br->count, 16) == hipSuccess;
+    if (!ok) {
+        (void)hipGetLastError();
+        cpm_bricklist_reduce_destroy(br);
+        return set_error(ctx, CPM_ERR_OUT_OF_MEMORY, "cpm_bricklist_reduce_create", "device / pinned allocation failed");
+    }
+    for (size_t i = 0; i < words; ++i) br->mailbox[i] = 0ull;
+    *out = br;
+    return CPM_OK;
+}
+
+void cpm_bricklist_reduce_destroy(cpm_bricklist_reduce* br) {
+    if (!br) return;
+    (void)hipSetDevice(br->device);
+    for (auto& sl : br->slots) if (sl.ticket && !sl.completed) { (void)hipStreamSynchronize(sl.stream); break; }  // the mailbox outlives its writers
+    for (void* p : { (void*)br->mask, (void*)br->list, (void*)br->slot, (void*)br->count, br->again }) if (p) (void)hipFree(p);
+    for (void* p : br->seg) if (p) (void)hipFree(p);
+    if (br->mailbox) (void)hipHostFree(br->mailbox);
+    delete br;
+}
+
+uint32_t cpm_bricklist_reduce_bricks(const cpm_bricklist_reduce* br) { return br ? br->nb : 0; }
+
+int cpm_reduce_grid_bricklists(cpm_ctx* ctx, cpm_bricklist_reduce* br, float* grid, const uint8_t* nonzero_bricks, uint64_t* ticket_out, cpm_stream stream) {
+    CPM_ENTER(ctx);
+    CPM_REQUIRE(ctx, br && grid, "cpm_reduce_grid_bricklists: null argument");
+    CPM_REQUIRE_ALIGNED16(ctx, grid, "cpm_reduce_grid_bricklists");
+    hipStream_t s = (hipStream_t)stream;
+    constexpr int kSlots = cpm_bricklist_reduce::kSlots;
+    const uint64_t ticket = br->next_ticket;
+    cpm_bricklist_reduce::Slot& sl = br->slots[ticket % kSlots];
+    CPM_REQUIRE(ctx, sl.completed, "cpm_reduce_grid_bricklists: 4 tickets issued and not completed (cpm_bricklist_reduce_complete)");
+    const int rank = br->comm->rank, size = br->comm->size, root = br->root;
+    cpm_bricklist_reduce::Slot fresh;
+    fresh.ticket = ticket; fresh.grid = grid; fresh.completed = false; fresh.stream = s;
+    if (size > 1) {
+        const Rccl* R = rccl(ctx);
+        if (!R) return CPM_ERR_UNSUPPORTED;
+        // capacities: from the counts of ticket - 2 (every rank's at the root, its own at a sender), long written when this ticket is issued
+        cpm_bricklist_reduce::Slot* old = nullptr;
+        if (ticket >= 3 && br->slots[(ticket - 2) % kSlots].ticket == ticket - 2) old = &br->slots[(ticket - 2) % kSlots];
+        for (int r = 0; r < size; ++r) {
+            if (r == root || (rank != root && r != rank)) continue;
+            long long prev = -1;
+            if (old) { int rc = bricklist_count(ctx, br, *old, r); if (rc) return rc; prev = old->counts[r] == 0xffffffffu ? -1 : (long long)old->counts[r]; }
+            fresh.cap[r] = cpm_bricklist_capacity_for(br->nb, prev);
+        }
+        const int slot_i = (int)(ticket % kSlots);
+        unsigned long long* mb = br->mailbox_dev + (size_t)slot_i * kBricklistMaxRanks;
+        if (rank != root) {
+            // this rank's bricks -> list + count (-> its mailbox word) -> segment -> the root
+            int rc = bricklist_own_list(ctx, br, grid, nonzero_bricks, mb + rank, (uint32_t)ticket, s);
+            if (rc) return rc;
+            const size_t bytes = seg_size(fresh.cap[rank], br->channels);
+            rc = bricklist_grow(ctx, &br->seg[slot_i], &br->seg_bytes[slot_i], bytes, s);
+            if (rc) return rc;
+            rc = bricklist_pack(ctx, br, fresh.cap[rank], (uint32_t)ticket, grid, br->seg[slot_i], s);
+            if (rc) return rc;
+            ProfScope ps(ctx, "rccl_bricklist_send", s);
+            CPM_NCCL_CHECK(ctx, R, R->Send(br->seg[slot_i], bytes, ncclInt8, root, br->comm->comm, s));
+        } else {
+            size_t total = 0;
+            for (int r = 0; r < size; ++r) if (r != root) total += (seg_size(fresh.cap[r], br->channels) + 255) & ~(size_t)255;
+            int rc = bricklist_grow(ctx, &br->seg[slot_i], &br->seg_bytes[slot_i], total, s);
+            if (rc) return rc;
+            unsigned char* base = static_cast<unsigned char*>(br->seg[slot_i]);
+            {
+                ProfScope ps(ctx, "rccl_bricklist_recv", s);
+                CPM_NCCL_CHECK(ctx, R, R->GroupStart());
+                size_t off = 0;
+                for (int r = 0; r < size; ++r) {
+                    if (r == root) continue;
+                    const size_t bytes = seg_size(fresh.cap[r], br->channels);
+                    ncclResult_t e = R->Recv(base + off, bytes, ncclInt8, r, br->comm->comm, s);
+                    if (e != ncclSuccess) { (void)R->GroupEnd(); return set_error(ctx, CPM_ERR_DEVICE, "ncclRecv", R->GetErrorString(e)); }
+                    off += (bytes + 255) & ~(size_t)255;
+                }
+                CPM_NCCL_CHECK(ctx, R, R->GroupEnd());
+            }
+            size_t off = 0;
+            for (int r = 0; r < size; ++r) {  // in rank order: a brick two ranks list is summed in that order
+                if (r == root) continue;
+                rc = bricklist_add(ctx, br, fresh.cap[r], (uint32_t)ticket, base + off, grid, mb + r, s);
+                if (rc) return rc;
+                off += (seg_size(fresh.cap[r], br->channels) + 255) & ~(size_t)255;
+            }
+        }
+    }
+    sl = fresh;
+    br->next_ticket = ticket + 1;
+    if (ticket_out) *ticket_out = ticket;
+    return CPM_OK;
+}
+
+int cpm_bricklist_reduce_complete(cpm_ctx* ctx, cpm_bricklist_reduce* br, uint64_t ticket, cpm_stream stream, cpm_bricklist_info* info) {
+    CPM_ENTER(ctx);
+    CPM_REQUIRE(ctx, br && ticket >= 1 && ticket < br->next_ticket, "cpm_bricklist_reduce_complete: no such ticket");
+    cpm_bricklist_reduce::Slot& sl = br->slots[ticket % cpm_bricklist_reduce::kSlots];
+    CPM_REQUIRE(ctx, sl.ticket == ticket, "cpm_bricklist_reduce_complete: the ticket is more than 4 calls old");
+    hipStream_t s = (hipStream_t)stream;
+    const int rank = br->comm->rank, size = br->comm->size, root = br->root;
+    uint64_t sent = 0, received = 0;
+    uint32_t listed = 0;
+    if (size > 1) {
+        const Rccl* R = rccl(ctx);
+        if (!R) return CPM_ERR_UNSUPPORTED;
+        for (int r = 0; r < size; ++r) {
+            if (r == root || (rank != root && r != rank)) continue;
+            int rc = bricklist_count(ctx, br, sl, r);
+            if (rc) return rc;
+            const uint32_t n = sl.counts[r];
+            if (n == 0xffffffffu) return set_error(ctx, CPM_ERR_DEVICE, "cpm_bricklist_reduce_complete", "a received segment did not carry this ticket's header");
+            const size_t first_bytes = seg_size(sl.cap[r], br->channels);
+            if (rank == root) { received += first_bytes; listed += n; } else sent += first_bytes;
+            if (sl.completed || n <= sl.cap[r]) continue;
+            // the segment carried its header alone: this pair exchanges again, at the exact size both now know
+            const uint32_t exact = round_up_64(n);
+            const size_t bytes = seg_size(exact, br->channels);
+            rc = bricklist_grow(ctx, &br->again, &br->again_bytes, bytes, s);
+            if (rc) return rc;
+            if (rank != root) {
+                // (list and count have served later tickets since: made again from the ticket's grid, which the caller has left alone)
+                rc = bricklist_own_list(ctx, br, sl.grid, nullptr, nullptr, (uint32_t)ticket, s);
+                if (rc) return rc;
+                rc = bricklist_pack(ctx, br, exact, (uint32_t)ticket, sl.grid, br->again, s);
+                if (rc) return rc;
+                CPM_NCCL_CHECK(ctx, R, R->Send(br->again, bytes, ncclInt8, root, br->comm->comm, s));
+                sent += bytes;
+            } else {
+                CPM_NCCL_CHECK(ctx, R, R->Recv(br->again, bytes, ncclInt8, r, br->comm->comm, s));
+                rc = bricklist_add(ctx, br, exact, (uint32_t)ticket, br->again, sl.grid, nullptr, s);
+                if (rc) return rc;
+                received += bytes;
+            }
+            ++sl.resent;
+        }
+    }
+    sl.completed = true;
+    if (info) {
+        info->ticket = ticket; info->n_bricks = br->nb;
+        info->n_own = (size > 1 && rank != root) ? sl.counts[rank] : 0u;
+        info->capacity = (size > 1 && rank != root) ? sl.cap[rank] : 0u;
+        info->resent = sl.resent;
+        info->sent_bytes = sent; info->received_bytes = received;
+        info->dense_bytes = (uint64_t)br->cells * sizeof(float) * (uint64_t)br->channels;
+        info->listed_bricks = listed;
     }
     return CPM_OK;
 }

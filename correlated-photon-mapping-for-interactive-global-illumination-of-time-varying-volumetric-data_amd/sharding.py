@@ -69,6 +69,48 @@ def sparse_capacity(n_bricks: int, previous_union: int) -> int:
     return n_bricks if c * 2 > n_bricks else c
 
 
+def bricklist_capacity(n_bricks: int, previous_count: int) -> int:
+    """Bricks a rank's segment has room for when it listed `previous_count` bricks two frames ago (< 0: unknown): + 25 % + 64 rounded
+    up to 64, a quarter of the bricks while unknown, never more than all (rounded up to 64).  Mirrors cpm_bricklist_capacity_for."""
+    if n_bricks <= 0:
+        return 0
+    everything = (n_bricks + 63) & ~63
+    c = n_bricks // 4 if previous_count < 0 else previous_count + previous_count // 4 + 64
+    c = (c + 63) & ~63
+    return 64 if c == 0 else min(c, everything)
+
+
+def bricklist_segment_bytes(capacity: int, channels: int = 1) -> int:
+    """16-byte header + capacity bricks of 64 * channels floats + capacity brick ids (cpm_bricklist_segment_bytes)."""
+    return 16 + capacity * (256 * channels + 4)
+
+
+# What a frame's exchange puts on a rank's busiest xGMI link, and a time for it (arithmetic; DESIGN section 6): the three forms the
+# build has, from the brick counts a probe frame measured.  Constants: one link ~153 GB/s peak of which a collective's steady state
+# gets about 2/3; a small collective's latency on 8 GPUs ~30 us (SURVEY 5, "Distributed communication backend").
+XGMI_LINK_GBS = 100.0
+COLLECTIVE_LATENCY_US = 30.0
+
+
+def exchange_model(n_bricks: int, channels: int, world: int, union_bricks: int, own_bricks_max: int, cells: int):
+    """Bytes per link and a modelled time per frame of (a) the dense ring reduce, (b) the union-of-bricks reduce
+    (cpm_allreduce_grid_sparse with a root: mask max-reduce + packed payload reduce), (c) per-rank brick lists sent to the root
+    (cpm_reduce_grid_bricklists: one segment per sender, every sender on its own link into the root).
+    union_bricks: bricks non-zero on ANY rank; own_bricks_max: the most any single rank lists."""
+    brick_bytes = 256 * channels
+    ring = (world - 1) / world if world > 1 else 0.0
+    dense = cells * channels * 4 * ring
+    cap_u = sparse_capacity(n_bricks, union_bricks)
+    union = (n_bricks + (cells * channels * 4 if cap_u >= n_bricks else cap_u * brick_bytes)) * ring
+    lists = bricklist_segment_bytes(bricklist_capacity(n_bricks, own_bricks_max), channels) if world > 1 else 0
+
+    def us(nbytes, collectives):
+        return collectives * COLLECTIVE_LATENCY_US + nbytes / (XGMI_LINK_GBS * 1e3)
+    return {"dense_reduce": {"bytes_per_link": int(dense), "model_us": round(us(dense, 1), 1)},
+            "union_reduce": {"bytes_per_link": int(union), "model_us": round(us(union, 2), 1)},
+            "brick_lists": {"bytes_per_link": int(lists), "model_us": round(us(lists, 1), 1)}}
+
+
 def brick_view(grid, dims, channels=1):
     """The grid (x fastest, `channels` interleaved) as [bz, by, bx, 4, 4, 4 * channels] after zero-padding every axis to a
     multiple of 4: brick b = bx + nbx * (by + nby * bz), a brick's values in (z, y, x, channel) order."""
@@ -157,6 +199,75 @@ class TorchTransport:
     def _rank(self):
         return self._dist.get_rank(self.group) if self.world > 1 else 0
 
+    # -- per-rank brick lists to the root with torch ops: the steps of cpm_reduce_grid_bricklists (send / recv pairs; capacities from
+    # the counts of two frames before -- a sender's own, at the root every sender's as its headers reported them)
+    def lists_setup(self, dims, channels=1, root=0):
+        nb = ((dims[0] + 3) // 4) * ((dims[1] + 3) // 4) * ((dims[2] + 3) // 4)
+        self._bl = {"dims": tuple(dims), "channels": channels, "nb": nb, "root": root, "counts": [], "log": []}
+
+    def lists_start(self, grid, nonzero_bricks=None):
+        """grid at the root (in place) = sum over the ranks; other ranks' grids are read.  Returns the frame's figures (carried out here)."""
+        import torch
+        bl, dist = self._bl, self._dist
+        dims, ch, nb, root = bl["dims"], bl["channels"], bl["nb"], bl["root"]
+        rank, k = self._rank(), len(bl["counts"])
+        prev = bl["counts"][k - 2] if k >= 2 else None     # per rank (root) / {rank: own} (sender)
+        info = {"n_bricks": nb, "n_own": 0, "capacity": 0, "resent": 0, "sent_bytes": 0, "received_bytes": 0, "dense_bytes": grid.numel() * 4, "listed_bricks": 0}
+        if self.world == 1:
+            bl["counts"].append({})
+            bl["log"].append(info)
+            return info
+        bricks = brick_view(grid, dims, ch).reshape(nb, 64 * ch)
+
+        def segment(values, ids, count, cap):
+            seg = torch.zeros(2 + cap + cap * 64 * ch, dtype=torch.float32)
+            seg[0], seg[1] = float(count), float(cap)      # (counts stay far below 2^24: exact in float32)
+            if count <= cap:
+                seg[2:2 + count] = ids.to(torch.float32)
+                seg[2 + cap:2 + cap + count * 64 * ch] = values.reshape(-1)
+            return seg
+        if rank != root:
+            mine = torch.nonzero((bricks != 0).any(dim=1), as_tuple=False).reshape(-1)
+            count = int(mine.numel())
+            cap = bricklist_capacity(nb, prev[rank] if prev is not None else -1)
+            vals = bricks[mine].cpu()
+            dist.send(segment(vals, mine.cpu(), count, cap), dst=root, group=self.group)
+            info.update(n_own=count, capacity=cap, sent_bytes=bricklist_segment_bytes(cap, ch))
+            if count > cap:
+                exact = (count + 63) & ~63
+                dist.send(segment(vals, mine.cpu(), count, exact), dst=root, group=self.group)
+                info["resent"] = 1
+                info["sent_bytes"] += bricklist_segment_bytes(exact, ch)
+            bl["counts"].append({rank: count})
+        else:
+            total = bricks.clone()
+            counts = {}
+            for r in range(self.world):     # rank order: a brick two ranks list is summed in that order
+                if r == root:
+                    continue
+                cap = bricklist_capacity(nb, prev[r] if prev is not None else -1)
+                seg = torch.zeros(2 + cap + cap * 64 * ch, dtype=torch.float32)
+                dist.recv(seg, src=r, group=self.group)
+                info["received_bytes"] += bricklist_segment_bytes(cap, ch)
+                count = int(seg[0].item())
+                counts[r] = count
+                if count > cap:
+                    cap = (count + 63) & ~63
+                    seg = torch.zeros(2 + cap + cap * 64 * ch, dtype=torch.float32)
+                    dist.recv(seg, src=r, group=self.group)
+                    info["resent"] += 1
+                    info["received_bytes"] += bricklist_segment_bytes(cap, ch)
+                ids = seg[2:2 + count].to(torch.int64).to(grid.device)
+                total[ids] += seg[2 + cap:2 + cap + count * 64 * ch].reshape(count, 64 * ch).to(grid.device)
+                info["listed_bricks"] += count
+            bl["counts"].append(counts)
+            dx, dy, dz = dims
+            nz, ny, nx = (dz + 3) // 4, (dy + 3) // 4, (dx + 3) // 4
+            back = total.reshape(nz, ny, nx, 4, 4, 4 * ch).permute(0, 3, 1, 4, 2, 5).reshape(nz * 4, ny * 4, nx * 4 * ch)
+            grid.reshape(dz, dy, dx * ch).copy_(back[:dz, :dy, :dx * ch])
+        bl["log"].append(info)
+        return info
+
 
 class RcclTransport:
     """all-reduce through the C-ABI (cpm_allreduce_grid) on a side stream of the rank's GPU.
@@ -224,9 +335,36 @@ class RcclTransport:
         self.sparse_log.append(info)
         return info
 
+    # -- per-rank brick lists to the root (cpm_reduce_grid_bricklists): same stream discipline
+    def lists_setup(self, grid_desc, root=0):
+        self.lists = self.ctx.bricklist_reduce_create(self.comm, grid_desc, root)
+        self.lists_log = []
+
+    def lists_start(self, grid, nonzero_bricks=None):
+        torch = self.torch
+        ready = torch.cuda.Event()
+        ready.record(torch.cuda.current_stream(self.ctx.device))
+        with torch.cuda.stream(self.stream):
+            self.stream.wait_event(ready)
+            ticket = self.lists.start(grid, nonzero_bricks=nonzero_bricks)
+        return ticket
+
+    def lists_wait(self, ticket):
+        """The CURRENT stream waits for the ticket's exchange (repeated at exact size where a list had outgrown its segment)."""
+        torch = self.torch
+        with torch.cuda.stream(self.stream):
+            info = self.lists.complete(ticket)
+            done = torch.cuda.Event()
+            done.record(self.stream)
+        torch.cuda.current_stream(self.ctx.device).wait_event(done)
+        self.lists_log.append(info)
+        return info
+
     def close(self):
         if getattr(self, "sparse", None) is not None:
             self.sparse.close()
+        if getattr(self, "lists", None) is not None:
+            self.lists.close()
         self.comm.close()
 
 

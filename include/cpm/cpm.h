@@ -772,6 +772,48 @@ int cpm_allreduce_grid_sparse(cpm_ctx* ctx, cpm_sparse_reduce* sr, const float* 
  * union count from the mailbox (waits for THAT launch only) and, after an overflow, enqueues the dense sum. */
 int cpm_sparse_reduce_complete(cpm_ctx* ctx, cpm_sparse_reduce* sr, uint64_t ticket, cpm_stream stream, cpm_sparse_reduce_info* info_out);
 
+/* Full frames whose shards light (nearly) DISJOINT parts of the volume: the north-star's "single RCCL reduce" to the display GPU,
+ * carried as per-rank brick LISTS.  With contiguous photon ranges a rank's photons enter through a slab of the light plane and
+ * its non-zero 4x4x4 bricks are its own; the union-of-bricks reduce above would still move the whole union over every link
+ * (config 4 at 8 ranks: 13.8 MB per link and frame against ~55 us of compute per rank).  Here every rank other than `root` packs
+ * ITS non-zero bricks -- (brick id, 64 * channels values) records behind a 16-byte header carrying their number -- and sends that one
+ * segment to the root (ncclSend / ncclRecv: a rank's bytes cross one xGMI link once); the root adds the segments into its own
+ * grid in rank order (a brick two ranks report is summed, in that fixed order: the result is reproducible).
+ *     grid at the root    = sum over the ranks of their grids (in place)
+ *     grid at other ranks = unchanged (read only)
+ * A segment's size must be known on both sides when the send and the receive are enqueued: capacity = the sender's brick count of
+ * the call before the previous one * 1.25 + 64 (rounded up to 64; a quarter of the bricks while unknown, never more than all) --
+ * a number the sender has from its own pinned mailbox and the root from the header it received then (no host wait, no
+ * collective for it: cpm_bricklist_capacity_for).  A rank whose count outgrows its capacity sends the header alone; at
+ * cpm_bricklist_reduce_complete -- which every rank calls before the grid is read or gathered into again -- that rank and the root
+ * alone repeat the exchange at the exact size (both know the count by then).  No rank waits for a rank it does not exchange with.
+ * Every rank makes the same sequence of calls; all calls of one cpm_bricklist_reduce go to one stream (or streams ordered by
+ * events); at most 4 tickets issued and not completed.  nonzero_bricks (nullable): the marks cpm_gather_fast_marked left for `grid`
+ * (else a pass over the grid finds them).  Communicators of size 1: nothing to do.
+ * Call site: where PhotonToLightVolumeProcessorCL::process hands the volume on (ref processor/photontolightvolumeprocessorcl.cpp:356-412). */
+typedef struct cpm_bricklist_reduce cpm_bricklist_reduce;
+typedef struct cpm_bricklist_info {
+    uint64_t ticket;
+    uint32_t n_bricks;        /* 4x4x4 bricks of the grid */
+    uint32_t n_own;           /* this rank's non-zero bricks */
+    uint32_t capacity;        /* bricks its segment had room for (0 at the root) */
+    int32_t resent;           /* segments exchanged again at exact size: 0 / 1 at a sender, their number at the root */
+    uint64_t sent_bytes;      /* bytes this rank handed to ncclSend for the ticket (0 at the root) */
+    uint64_t received_bytes;  /* bytes the root posted receives for (0 elsewhere) */
+    uint64_t dense_bytes;     /* cells * channels * 4: what cpm_reduce_grid sends per rank */
+    uint32_t listed_bricks;   /* root: bricks in all received lists together (their overlap with each other and the root's is summed) */
+} cpm_bricklist_info;
+int cpm_bricklist_reduce_create(cpm_ctx* ctx, cpm_comm* comm, const cpm_grid_desc* grid, int root, cpm_bricklist_reduce** out);
+void cpm_bricklist_reduce_destroy(cpm_bricklist_reduce* br);
+uint32_t cpm_bricklist_reduce_bricks(const cpm_bricklist_reduce* br);
+/* Bricks a segment has room for when its sender listed previous_count bricks two calls ago (< 0: not known yet). */
+uint32_t cpm_bricklist_capacity_for(uint32_t n_bricks, long long previous_count);
+/* Bytes of a segment with room for `capacity` bricks: 16 + capacity * (256 * channels + 4). */
+uint64_t cpm_bricklist_segment_bytes(uint32_t capacity, int channels);
+int cpm_reduce_grid_bricklists(cpm_ctx* ctx, cpm_bricklist_reduce* br, float* grid, const uint8_t* nonzero_bricks, uint64_t* ticket_out,
+                               cpm_stream stream);
+int cpm_bricklist_reduce_complete(cpm_ctx* ctx, cpm_bricklist_reduce* br, uint64_t ticket, cpm_stream stream, cpm_bricklist_info* info_out);
+
 /* ---- OpenGL sharing: the consumer side of the light volume ---------------------------------------------------------
  * Replaces Inviwo's CL-GL sharing on this path (property `glsharing`, ref processor/progressivephotontracercl.cpp:93,
  * processor/photontolightvolumeprocessorcl.cpp:69): `SyncCLGL` + `BufferCLGL` for the photon buffer (ref

@@ -3,7 +3,7 @@
  * The GPU boxes of this build have ONE GPU and RCCL refuses two ranks on one device, so the multi-rank logic of
  * libcpm_hip.so (cpm_comm_*, cpm_allreduce_grid_sparse: union masks, slot tables, capacity policy, overflow fall-back,
  * root reduce) could only ever run with a communicator of size 1.  This library implements the eight RCCL entry points
- * libcpm_hip binds (csrc/cpm_comm.hip, load_rccl) over POSIX shared memory between processes that share one GPU:
+ * libcpm_hip binds (csrc/cpm_comm.hip, load_rccl; ncclSend / ncclRecv since round 5) over POSIX shared memory between processes that share one GPU:
  * a collective synchronises the caller's stream, stages the operands through host memory, meets the other ranks at a
  * process-shared barrier, reduces, and copies the result back.  Stream order is kept (the call blocks the host instead of
  * enqueueing, which a caller cannot tell from a very slow RCCL).  Selected with CPM_RCCL_LIBRARY=<path to this .so>.
@@ -29,6 +29,16 @@ typedef struct { char internal[128]; } ncclUniqueId;
 
 #define FAKE_MAX_RANKS 8
 #define FAKE_SLOT_BYTES ((size_t)40 << 20) /* per rank: the biggest operand a test hands over (config 2's 8 MiB grid and then some) */
+#define FAKE_CHANNEL_BYTES ((size_t)24 << 20) /* per ordered pair of ranks: one ncclSend in flight (pages are only touched when used) */
+
+/* point-to-point: one single-message channel per ordered pair (src -> dst).  ncclSend copies the operand in and returns (it waits
+ * only while the pair's previous message has not been taken); ncclRecv waits for the message and copies it out.  Only the two ranks
+ * of a pair ever meet -- unlike the collectives below there is no barrier over the communicator. */
+typedef struct {
+    volatile unsigned long sent, taken; /* messages put in / taken out */
+    volatile size_t bytes;
+    char pad[40];
+} fake_channel;
 
 typedef struct {
     volatile int ready;
@@ -41,6 +51,7 @@ typedef struct fake_comm {
     char name[64];
     fake_header* hdr;
     unsigned char* slots;  /* nranks x FAKE_SLOT_BYTES */
+    unsigned char* channels; /* nranks x nranks x (64-byte control block + FAKE_CHANNEL_BYTES), [src][dst] */
     size_t map_bytes;
     unsigned char* host;   /* staging for the result */
 } fake_comm;
@@ -70,7 +81,7 @@ ncclResult_t ncclCommInitRank(ncclComm_t* out, int nranks, ncclUniqueId id, int 
     if (!c) return ncclSystemError;
     c->rank = rank; c->nranks = nranks;
     memcpy(c->name, id.internal, sizeof c->name - 1);
-    c->map_bytes = 4096 + (size_t)nranks * FAKE_SLOT_BYTES;
+    c->map_bytes = 4096 + (size_t)nranks * FAKE_SLOT_BYTES + (size_t)nranks * nranks * (64 + FAKE_CHANNEL_BYTES);
     int fd = -1;
     if (rank == 0) {
         fd = shm_open(c->name, O_CREAT | O_RDWR, 0600);
@@ -89,6 +100,7 @@ ncclResult_t ncclCommInitRank(ncclComm_t* out, int nranks, ncclUniqueId id, int 
     if (m == MAP_FAILED) { free(c); return ncclSystemError; }
     c->hdr = (fake_header*)m;
     c->slots = (unsigned char*)m + 4096;
+    c->channels = c->slots + (size_t)nranks * FAKE_SLOT_BYTES;   /* (a fresh shm object reads as zeros: sent == taken == 0) */
     if (rank == 0) {
         pthread_barrierattr_t a;
         pthread_barrierattr_init(&a);
@@ -158,6 +170,45 @@ static ncclResult_t collective(const void* send, void* recv, size_t count, ncclD
     pthread_barrier_wait(&c->hdr->barrier);  /* the slots may be overwritten by the next collective only now */
     if (root < 0 || root == c->rank)
         if (hipMemcpy(recv, c->host, bytes, hipMemcpyHostToDevice) != hipSuccess) return ncclUnhandledCudaError;
+    return ncclSuccess;
+}
+
+static unsigned char* channel_of(ncclComm_t c, int src, int dst) { return c->channels + ((size_t)src * c->nranks + dst) * (64 + FAKE_CHANNEL_BYTES); }
+
+static int wait_until(volatile unsigned long* word, unsigned long at_least, int seconds) {
+    for (long spins = 0; *word < at_least; ++spins) {
+        if (spins > (long)seconds * 20000) return 0;
+        usleep(50);
+    }
+    __sync_synchronize();
+    return 1;
+}
+
+ncclResult_t ncclSend(const void* send, size_t count, ncclDataType_t dt, int peer, ncclComm_t c, hipStream_t s) {
+    const size_t bytes = count * elem_size(dt);
+    if (!c || elem_size(dt) == 0 || peer < 0 || peer >= c->nranks || peer == c->rank || bytes > FAKE_CHANNEL_BYTES) return ncclInvalidArgument;
+    if (hipStreamSynchronize(s) != hipSuccess) return ncclUnhandledCudaError;
+    unsigned char* ch = channel_of(c, c->rank, peer);
+    fake_channel* k = (fake_channel*)ch;
+    if (!wait_until(&k->taken, k->sent, 60)) return ncclSystemError;   /* the pair's previous message is still in the channel */
+    if (hipMemcpy(ch + 64, send, bytes, hipMemcpyDeviceToHost) != hipSuccess) return ncclUnhandledCudaError;
+    k->bytes = bytes;
+    __sync_synchronize();
+    k->sent = k->sent + 1;
+    return ncclSuccess;
+}
+
+ncclResult_t ncclRecv(void* recv, size_t count, ncclDataType_t dt, int peer, ncclComm_t c, hipStream_t s) {
+    const size_t bytes = count * elem_size(dt);
+    if (!c || elem_size(dt) == 0 || peer < 0 || peer >= c->nranks || peer == c->rank || bytes > FAKE_CHANNEL_BYTES) return ncclInvalidArgument;
+    if (hipStreamSynchronize(s) != hipSuccess) return ncclUnhandledCudaError;
+    unsigned char* ch = channel_of(c, peer, c->rank);
+    fake_channel* k = (fake_channel*)ch;
+    if (!wait_until(&k->sent, k->taken + 1, 60)) return ncclSystemError;
+    if (k->bytes != bytes) return ncclInvalidArgument;   /* (RCCL would hang or corrupt: sizes of a send and its receive must agree) */
+    if (hipMemcpy(recv, ch + 64, bytes, hipMemcpyHostToDevice) != hipSuccess) return ncclUnhandledCudaError;
+    __sync_synchronize();
+    k->taken = k->taken + 1;
     return ncclSuccess;
 }
 
