@@ -395,25 +395,37 @@ class OverlappedGridReducer:
         grid = red.result(K - 1)
     """
 
-    def __init__(self, like, transport=None, group=None, sparse=None, force=False):
+    def __init__(self, like, transport=None, group=None, sparse=None, force=False, lists=None, root=0):
         """sparse: None = dense all-reduce; a cpm GridDesc (RcclTransport) or (dims, channels) (TorchTransport) = the sum
-        over the union of the ranks' non-zero bricks (cpm_allreduce_grid_sparse).  force: run the reduce with one rank too
-        (measuring pack / unpack on one GPU)."""
+        over the union of the ranks' non-zero bricks (cpm_allreduce_grid_sparse).  lists (same forms; not with sparse): every rank's
+        own non-zero bricks as a list to `root`, whose grid becomes the sum (cpm_reduce_grid_bricklists: for shards with disjoint
+        brick sets -- contiguous photon ranges).  force: run the reduce with one rank too (measuring pack / unpack on one GPU)."""
         import torch
+        if sparse is not None and lists is not None:
+            raise ValueError("OverlappedGridReducer: sparse (union of bricks) or lists (per-rank brick lists), not both")
         self.transport = transport if transport is not None else TorchTransport(group)
         self.active = self.transport.world > 1 or force
         self.buffers = [like, torch.empty_like(like)]
         self._pending = [None, None]
         self.sparse = sparse is not None
-        self.info = []  # per completed sparse ticket: union, capacity, mode, bytes
+        self.lists = lists is not None
+        self.info = []  # per completed sparse ticket: union, capacity, mode, bytes; per completed list exchange: its cpm_bricklist_info
         self.marks = [None, None]  # per buffer: the non-zero 4x4x4 bricks, written by the gather (marks_for)
-        if self.sparse and self.active:
+        if (self.sparse or self.lists) and self.active:
+            desc = sparse if self.sparse else lists
             if isinstance(self.transport, TorchTransport):
-                dims, channels = sparse
-                self.transport.sparse_setup(dims, channels)
+                dims, channels = desc
+                if self.sparse:
+                    self.transport.sparse_setup(dims, channels)
+                else:
+                    self.transport.lists_setup(dims, channels, root)
             else:
-                self.transport.sparse_setup(sparse)
-                nb = self.transport.sparse.n_bricks
+                if self.sparse:
+                    self.transport.sparse_setup(desc)
+                    nb = self.transport.sparse.n_bricks
+                else:
+                    self.transport.lists_setup(desc, root)
+                    nb = self.transport.lists.n_bricks
                 self.marks = [torch.zeros(nb + 16, dtype=torch.uint8, device=like.device) for _ in range(2)]
 
     def _wait(self, b):
@@ -421,10 +433,14 @@ class OverlappedGridReducer:
         if h is None:
             return
         self._pending[b] = None
-        if not self.sparse:
+        if not (self.sparse or self.lists):
             self.transport.wait(h)
         elif isinstance(self.transport, TorchTransport):
             self.info.append(h)  # carried out at start
+        elif self.lists:
+            i = self.transport.lists_wait(h)
+            self.info.append({f: int(getattr(i, f)) for f in ("n_bricks", "n_own", "capacity", "resent", "sent_bytes", "received_bytes",
+                                                              "dense_bytes", "listed_bricks")})
         else:
             i = self.transport.sparse_wait(h)
             self.info.append({"n_bricks": i.n_bricks, "n_union": i.n_union, "capacity": i.capacity, "mode": i.mode,
@@ -445,6 +461,8 @@ class OverlappedGridReducer:
             b = k & 1
             if self.sparse:
                 self._pending[b] = self.transport.sparse_start(self.buffers[b], nonzero_bricks=self.marks[b] if marked else None)
+            elif self.lists:
+                self._pending[b] = self.transport.lists_start(self.buffers[b], nonzero_bricks=self.marks[b] if marked else None)
             else:
                 self._pending[b] = self.transport.start(self.buffers[b])
 

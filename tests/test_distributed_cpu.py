@@ -326,3 +326,94 @@ def test_sparse_grid_reduce_equals_dense_sum(tmp_path, cpm, dims, channels, root
     if dims == (32, 32, 32):
         assert 2 in modes[:5]      # the growing slab overflowed a payload sized for an earlier frame
         assert modes[-1] == 0 and moved[-1] * 2 < dense  # the steady thin slab: sparse, a fraction of the dense bytes
+
+
+def _lists_worker(rank, world, port, out_dir, dims, channels, root, slabs):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    sys.path.insert(0, str(REPO))
+    import importlib
+    import torch
+    import torch.distributed as dist
+    import cpm_amd
+    sh = importlib.import_module(cpm_amd.__name__ + ".sharding")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dx, dy, dz = dims
+    n = dx * dy * dz * channels
+    nb = ((dx + 3) // 4) * ((dy + 3) // 4) * ((dz + 3) // 4)
+    gen = torch.Generator().manual_seed(99 + rank)
+
+    def partial_grid(k):
+        """A rank's light volume of frame k.  slabs: the rank lights ITS slab of y rows (a contiguous photon range: a slab of the light
+        plane) and a border row of the next rank's -- brick sets nearly disjoint; else every rank lights the same region (tile shards).
+        The lit depth grows with k and comes back, so a list outgrows the segment sized two frames earlier.  Values are multiples of
+        1/8 below 2^10: sums are exact in any order."""
+        g = torch.zeros(dz, dy, dx, channels)
+        depth = min(dz, 2 + 10 * k if k < 4 else 4)
+        lit = torch.rand(depth, dy, dx, generator=gen) < 0.35
+        if slabs:
+            rows = torch.zeros(dy, dtype=torch.bool)
+            lo, hi = rank * dy // world, (rank + 1) * dy // world
+            rows[lo:min(dy, hi + 1)] = True
+            lit &= rows[None, :, None]
+        vals = torch.randint(1, 1000, (depth, dy, dx, channels), generator=gen).float() / 8.0
+        g[:depth] = vals * lit[..., None]
+        return g.reshape(-1)
+
+    red = sh.OverlappedGridReducer(torch.zeros(n), sh.TorchTransport(), lists=(dims, channels), root=root)
+    K = 8
+    for k in range(K):
+        out = red.acquire(k)
+        mine = partial_grid(k)
+        out.copy_(mine)
+        red.reduce(k)
+        want = mine.clone()
+        dist.all_reduce(want)     # the dense sum of the same frame (exact values: any order gives these bits)
+        got = red.result(k)
+        if rank == root:
+            assert torch.equal(got, want), f"frame {k}: sum of the lists != dense sum"
+        else:
+            assert torch.equal(got, mine), f"frame {k}: a sender's grid was written"
+    red.flush()
+    infos = red.info
+    assert len(infos) == K
+    for k, i in enumerate(infos):
+        assert i["n_bricks"] == nb
+        if rank != root:   # a sender's capacity is the policy applied to ITS count of two frames before; a list that outgrew it went again
+            assert i["capacity"] == sh.bricklist_capacity(nb, infos[k - 2]["n_own"] if k >= 2 else -1)
+            assert i["resent"] == (1 if i["n_own"] > i["capacity"] else 0)
+            assert i["sent_bytes"] >= sh.bricklist_segment_bytes(i["capacity"], channels) and i["received_bytes"] == 0
+    own = torch.tensor([[i["n_own"], i["resent"], i["sent_bytes"], i["received_bytes"], i["listed_bricks"]] for i in infos])
+    everyone = [torch.zeros_like(own) for _ in range(world)]
+    dist.all_gather(everyone, own)
+    if rank == root:
+        for k in range(K):   # the root received what the others sent, and listed what they listed
+            assert int(own[k, 3]) == sum(int(everyone[r][k, 2]) for r in range(world) if r != root)
+            assert int(own[k, 4]) == sum(int(everyone[r][k, 0]) for r in range(world) if r != root)
+            assert int(own[k, 1]) == sum(int(everyone[r][k, 1]) for r in range(world) if r != root)
+        with open(os.path.join(out_dir, "root"), "w") as f:
+            f.write(";".join(",".join(str(int(v)) for v in own[:, c]) for c in range(5)) + ";" + str(infos[0]["dense_bytes"]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,dims,channels,root,slabs", [(2, (32, 32, 32), 1, 0, True), (2, (20, 13, 9), 4, 1, False), (4, (32, 32, 32), 1, 0, True),
+                                                           (4, (16, 24, 16), 4, 2, True), (8, (32, 64, 16), 1, 0, True)])
+def test_brick_lists_to_the_root_equal_the_dense_sum(tmp_path, cpm, world, dims, channels, root, slabs):
+    """cpm_reduce_grid_bricklists's protocol over gloo (TorchTransport carries it out with send / recv), 2, 4 and 8 ranks: the root's grid
+    becomes the dense sum bit for bit, the senders' grids are left alone; a segment is sized from the sender's count two frames before
+    (sender and root derive the same number on their own), a list that outgrew it goes again at exact size between that pair alone; with
+    slab shards the root receives a fraction of what the dense reduce moves."""
+    import socket
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_lists_worker, args=(world, port, str(tmp_path), dims, channels, root, slabs), nprocs=world, join=True)
+    cols = (tmp_path / "root").read_text().split(";")
+    resent, received, dense = [int(x) for x in cols[1].split(",")], [int(x) for x in cols[3].split(",")], int(cols[5])
+    nb = ((dims[0] + 3) // 4) * ((dims[1] + 3) // 4) * ((dims[2] + 3) // 4)
+    if nb >= 512 and world <= 4:         # (a grid of a few dozen bricks, or an eighth of one, fits its first segment whatever happens)
+        assert sum(resent[:5]) >= 1      # the growing slab outgrew a segment sized for an earlier frame
+    assert resent[-1] == 0               # the steady thin slab fits
+    if slabs and nb >= 512:            # (the + 64 bricks of head-room dominate a grid of a hundred bricks: the byte model sends that one densely)
+        assert received[-1] * 2 < dense * (world - 1)   # ... and is a fraction of N - 1 dense grids

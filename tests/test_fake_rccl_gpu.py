@@ -108,3 +108,89 @@ def test_overlapped_reducer_over_two_ranks(two_ranks):
         assert np.array_equal(r0[f"reducer_{k}"], want), k
         assert np.array_equal(r1[f"reducer_{k}"], want), k
     assert np.array_equal(r0["reducer_info"], r1["reducer_info"]) and r0["reducer_info"].shape == (7, 3)
+
+
+# ---- the brick-list exchange (cpm_reduce_grid_bricklists): 2 and 4 ranks on the one GPU -------------------------------------------------
+
+def _slab_partial(dims, ch, k, who, n_ranks):
+    dx, dy, dz = dims
+    g = np.zeros((dz, dy, dx, ch), np.float32)
+    rng = np.random.default_rng(4000 * k + 31 * who + dx)
+    depth = min(dz, (2 + 10 * k) if k < 4 else 4)
+    lit = rng.random((depth, dy, dx)) < 0.35
+    rows = np.zeros(dy, bool)
+    rows[who * dy // n_ranks:min(dy, (who + 1) * dy // n_ranks + 1)] = True
+    lit &= rows[None, :, None]
+    vals = rng.integers(1, 1000, (depth, dy, dx, ch)).astype(np.float32) / np.float32(8.0)
+    g[:depth] = vals * lit[..., None]
+    return g.reshape(-1)
+
+
+def _run_lists(tmp_path_factory, world, root):
+    import build as fake_build
+    lib = fake_build.build()
+    out = tmp_path_factory.mktemp(f"fake_rccl_lists_{world}")
+    env = dict(os.environ, CPM_RCCL_LIBRARY=str(lib))
+    procs = [subprocess.Popen([sys.executable, str(REPO / "tests" / "fake_rccl" / "worker_lists.py"), str(r), str(world), str(out), str(root)],
+                              env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
+    logs = []
+    for p in procs:
+        try:
+            o, _ = p.communicate(timeout=420)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            pytest.fail(f"the {world}-rank brick-list workers did not finish in 420 s")
+        logs.append(o)
+    assert all(p.returncode == 0 for p in procs), "\n".join(l[-3000:] for l in logs)
+    return [np.load(out / f"rank{r}.npz") for r in range(world)]
+
+
+@pytest.mark.parametrize("world,root", [(2, 0), (4, 1)])
+def test_brick_lists_to_the_root(tmp_path_factory, cpm, world, root):
+    """Every rank but the root packs ITS non-zero 4x4x4 bricks and sends that one segment to the root, which adds the segments in rank
+    order: the root's grid is the dense sum bit for bit (numpy's), the senders' grids are untouched; a segment is sized from the sender's
+    count two tickets before -- sender and root each derive it on their own --, a list that outgrew it goes again at exact size between
+    that pair alone; the root's byte counts are the senders'; slab shards move a fraction of the dense grids.  At most 4 + this process
+    use the GPU at once (the box allows 6)."""
+    sh = importlib.import_module(cpm.__name__ + ".sharding")
+    ranks = _run_lists(tmp_path_factory, world, root)
+    for dims, ch in (((32, 32, 32), 1), ((20, 13, 9), 4)):
+        key = f"lists_{dims[0]}_{ch}"
+        nb = _bricks(dims)[1]
+        infos = [r[key + "_info"] for r in ranks]
+        for k in range(8):
+            parts = [_slab_partial(dims, ch, k, w, world) for w in range(world)]
+            want = parts[root].copy()
+            for w in range(world):      # the root adds in rank order (exact values: any order gives these bits, but this IS the order)
+                if w != root:
+                    want = want + parts[w]
+            assert np.array_equal(ranks[root][f"{key}_{k}"], want), (dims, k)
+            for w in range(world):
+                if w != root:
+                    assert np.array_equal(ranks[w][f"{key}_{k}"], parts[w]), (dims, k, w)
+                    n_own, cap, resent, sent = (int(v) for v in infos[w][k, :4])
+                    b, _ = _bricks(dims)
+                    assert n_own == np.unique(b[(parts[w] != 0).reshape(-1, ch).any(axis=1)]).size
+                    assert cap == sh.bricklist_capacity(nb, int(infos[w][k - 2, 0]) if k >= 2 else -1)
+                    assert resent == (1 if n_own > cap else 0)
+                    exact = (n_own + 63) & ~63
+                    assert sent == sh.bricklist_segment_bytes(cap, ch) + (sh.bricklist_segment_bytes(exact, ch) if resent else 0)
+            assert int(infos[root][k, 4]) == sum(int(infos[w][k, 3]) for w in range(world) if w != root)   # received == sent
+            assert int(infos[root][k, 5]) == sum(int(infos[w][k, 0]) for w in range(world) if w != root)   # listed == the lists
+            assert int(infos[root][k, 2]) == sum(int(infos[w][k, 2]) for w in range(world) if w != root)   # repeated exchanges
+        if dims == (32, 32, 32):
+            assert sum(int(infos[w][:, 2].sum()) for w in range(world) if w != root) >= 1   # a list outgrew its segment at least once ...
+            assert int(infos[root][-1, 2]) == 0                                                # ... and the steady frame fits
+            assert int(infos[root][-1, 4]) * 2 < int(infos[root][-1, 7]) * (world - 1)         # a fraction of N - 1 dense grids
+    # the frame loop (two tickets in flight, reduce stream beside the frame's)
+    for k in range(7):
+        parts = [_slab_partial((32, 32, 32), 1, k, w, world) for w in range(world)]
+        want = parts[root].copy()
+        for w in range(world):
+            if w != root:
+                want = want + parts[w]
+        assert np.array_equal(ranks[root][f"reducer_{k}"], want), k
+        for w in range(world):
+            if w != root:
+                assert np.array_equal(ranks[w][f"reducer_{k}"], parts[w]), (k, w)
