@@ -246,9 +246,10 @@ def main():
     ap.add_argument("--workload", default="config2", choices=sorted(WORKLOADS))
     ap.add_argument("--formulation", default="fast", choices=["fast", "exact"])
     ap.add_argument("--scaling", default=None, choices=["weak", "strong"])
-    ap.add_argument("--shards", default="tiles", choices=["tiles", "range"],
-                    help="N > 1: a rank takes the lattice's 4096-sample tiles t = rank (mod N) (default: every rank sees every lit "
-                         "brick at 1/N of the density) or a contiguous range (a slab of the light plane)")
+    ap.add_argument("--shards", default="auto", choices=["auto", "tiles", "range"],
+                    help="N > 1: a rank takes the lattice's 4096-sample tiles t = rank (mod N) (every rank sees every lit brick at 1/N of "
+                         "the density: the gather stays balanced, every rank's brick set is the union) or a contiguous range (a slab of the "
+                         "light plane: brick sets nearly disjoint).  auto: range with --exchange lists, else tiles")
     ap.add_argument("--records", default="planar", choices=["planar", "float8"],
                     help="fast formulation: photon records in the two-plane layout the tracer can write and the brick bin reads half of "
                          "(default), or the reference's float8 records")
@@ -259,13 +260,16 @@ def main():
                     help="frames in flight for the extra 'pipelined' figure (0 = skip it); 'value' is always one stream")
     ap.add_argument("--transport", default="rccl", choices=["rccl", "torch"],
                     help="the grid reduce: cpm_allreduce_grid through the C-ABI (default) or torch.distributed")
-    ap.add_argument("--collective", default="allreduce", choices=["allreduce", "reduce"],
-                    help="N > 1: every rank receives the summed light volume (cpm_allreduce_grid, default) or only rank 0, the "
-                         "display GPU (cpm_reduce_grid: half the wire traffic of a ring all-reduce)")
-    ap.add_argument("--reduce", default="sparse", choices=["sparse", "dense"],
-                    help="N > 1, full frames: sum only the union of the ranks' non-zero 4x4x4 bricks (cpm_allreduce_grid_sparse: "
-                         "mask max-reduce + packed payload sized on the host from the union two frames before; no stream "
-                         "synchronisation; default) or the whole grid (cpm_allreduce_grid)")
+    ap.add_argument("--collective", default="reduce", choices=["allreduce", "reduce"],
+                    help="N > 1: only rank 0, the display GPU, receives the summed light volume (the north-star's single RCCL reduce; "
+                         "default) or every rank does (all-reduce: twice the wire traffic of a ring reduce)")
+    ap.add_argument("--exchange", default="auto", choices=["auto", "union", "lists", "dense"],
+                    help="N > 1, full frames -- what crosses xGMI: the union of the ranks' non-zero 4x4x4 bricks (cpm_allreduce_grid_sparse: mask "
+                         "max-reduce + packed payload sized on the host from the union two frames before), every rank's OWN bricks as a list "
+                         "to the root (cpm_reduce_grid_bricklists: one send per rank; for shards with disjoint brick sets) or the whole grid.  "
+                         "No form synchronises the stream.  auto: lists where the photon count is fixed (strong scaling: the per-rank compute "
+                         "shrinks, the union does not), union where it grows with the ranks (weak)")
+    ap.add_argument("--reduce", default=None, choices=["sparse", "dense"], help="(older spelling of --exchange union / dense)")
     ap.add_argument("--test-backend", default="nccl", choices=["nccl", "gloo"],
                     help="(testing) process-group backend; gloo lets the N > 1 code path run with every rank on one GPU")
     ap.add_argument("--test-one-device", action="store_true", help="(testing) every rank uses cuda:0")
@@ -290,81 +294,103 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: libcpm_hip has no CPU fallback")
     torch.cuda.set_device(local_rank)
+    # Control plane: a gloo group (communicator id, agreement flags, max-over-ranks time).  The DATA path's exchange is RCCL through the
+    # C-ABI; its communicator is set up BEFORE anything else touches RCCL on the devices -- torch's own NCCL group is only created
+    # when that set-up failed on some rank and every rank falls back (so a fall-back never shares a device with a half-built
+    # communicator; a set-up that never returns is the launcher's timeout to end).
     dist = None
     if world > 1 or "TORCHELASTIC_RUN_ID" in os.environ:  # launched by torch.distributed.run (also at N = 1)
         import torch.distributed as dist
-        if args.test_backend == "gloo":
-            dist.init_process_group("gloo")
-        else:
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))  # backend nccl = RCCL on ROCm
+        dist.init_process_group("gloo")
 
     vdim, (nx, ny), gdim, default_scaling = WORKLOADS[args.workload]
     scaling = args.scaling or default_scaling
     fast = args.formulation == "fast"
+    correlated = args.workload == "config5"
     vol_np = S.heterogeneous_volume(vdim) if args.workload != "config1" else S.homogeneous_volume(vdim)
     tf = S.workspace_tf() if args.workload != "config1" else S.homogeneous_tf(0.25)
     if scaling == "weak":
         lattice, n_total = (nx, ny * world), nx * ny * world
     else:
         lattice, n_total = (nx, ny), nx * ny
-    if args.shards == "tiles":
+    # what crosses xGMI per frame, and which photons a rank owns (static rules: every rank takes the same decision from the same flags)
+    exchange = args.exchange
+    if args.reduce is not None:
+        exchange = {"sparse": "union", "dense": "dense"}[args.reduce]
+    root = 0 if args.collective == "reduce" else None
+    if exchange == "auto":
+        exchange = "lists" if (scaling == "strong" and fast and not correlated and root is not None and not args.graph) else "union"
+    if exchange == "lists" and (root is None or correlated or args.graph):
+        raise SystemExit("bench.py: --exchange lists is the full frames' reduce to the display GPU (needs --collective reduce, not config5 / --graph)")
+    shards_kind = args.shards if args.shards != "auto" else ("range" if exchange == "lists" else "tiles")
+    if shards_kind == "tiles":
         shard = sharding.shard_tiles(n_total, rank, world)
     else:
         lo, hi = sharding.shard_range(n_total, rank, world)
         shard = np.arange(lo, hi, dtype=np.int64)
     n_rank = int(shard.size)
     ctx = B.Context(local_rank)
-    # the one exchange step: RCCL through the C-ABI (one-process-per-GPU form); torch.distributed only carries the id
     transport_note = None
-    root = 0 if args.collective == "reduce" else None
     # (testing: with CPM_RCCL_LIBRARY naming the tests' RCCL double -- shared memory between ranks on ONE GPU -- the C-ABI's multi-rank
-    # path runs over gloo-launched ranks too)
+    # path runs over ranks that share a device)
     fake_rccl = bool(os.environ.get("CPM_RCCL_LIBRARY"))
+
+    def agree(ok):
+        flag = torch.tensor([1 if ok else 0], dtype=torch.int32)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        return bool(flag.item())
+
+    def torch_transport():
+        """torch.distributed carries the sums: over its own NCCL (= RCCL) group on real multi-GPU runs, over gloo in the tests."""
+        if world > 1 and args.test_backend == "nccl" and not args.test_one_device:
+            return sharding.TorchTransport(group=dist.new_group(backend="nccl"), root=root)
+        return sharding.TorchTransport(root=root)
+
+    transport = None
     if world > 1 and args.transport == "rccl" and ((args.test_backend == "nccl" and not args.test_one_device) or fake_rccl):
-        # Every rank first checks locally that RCCL can be bound (no communication), the ranks agree, and only then
-        # enter the collective communicator setup; a probe all-reduce follows.  Should any of it fail, ALL ranks fall
-        # back to torch.distributed's all-reduce (the same RCCL wire) and the JSON line says so -- a scaling run is
-        # never lost to the transport.
-        def agree(ok):
-            flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=ctx.device)
-            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-            return bool(flag.item())
+        # every rank first checks locally that RCCL can be bound (no communication); the ranks agree; then the collective communicator
+        # set-up and a probe of the collectives the frames will use.  Should a rank fail, ALL ranks fall back to torch.distributed
+        # (the same wire) and the JSON line says so.
         err = ""
         try:
             ctx.comm_unique_id()
             ok = True
         except Exception as e:  # noqa: BLE001
             ok, err = False, str(e)
-        transport = None
         if agree(ok):
-            # (in a thread that is given two minutes: a communicator setup that never returns on some rank must not take the run with
-            # it -- that rank reports failure, every rank falls back; RCCL with more than one rank has never run on this build's boxes)
-            import threading
-            box = {}
-
-            def setup():
-                try:
-                    torch.cuda.set_device(local_rank)   # (a new thread starts on device 0: streams and tensors must be this rank's)
-                    tr = sharding.RcclTransport(ctx, rank, world, root=root)
-                    probe = torch.ones(8, dtype=torch.float32, device=ctx.device)
-                    tr.wait(tr.start(probe))
-                    torch.cuda.synchronize()
-                    good = bool((probe == float(world)).all().item()) if (root is None or rank == root) else True
-                    box["result"] = (tr if good else None, "" if good else "probe all-reduce returned a wrong sum")
-                except Exception as e:  # noqa: BLE001
-                    box["result"] = (None, str(e))
-            th = threading.Thread(target=setup, daemon=True)
-            th.start()
-            th.join(float(os.environ.get("CPM_BENCH_RCCL_SETUP_TIMEOUT", "120")))
-            transport, err = box.get("result", (None, "communicator setup did not return in time"))
-            ok = transport is not None
+            try:
+                transport = sharding.RcclTransport(ctx, rank, world, root=root)
+                probe = torch.ones(8, dtype=torch.float32, device=ctx.device)
+                transport.wait(transport.start(probe))
+                torch.cuda.synchronize()
+                ok = bool((probe == float(world)).all().item()) if (root is None or rank == root) else True
+                if not ok:
+                    err = "probe reduce returned a wrong sum"
+            except Exception as e:  # noqa: BLE001
+                ok, err = False, str(e)
             if not agree(ok):
+                if transport is not None:
+                    try:
+                        transport.close()
+                    except Exception:  # noqa: BLE001
+                        pass
                 transport = None
         if transport is None:
-            transport = sharding.TorchTransport(root=root)
-            transport_note = "torch.distributed all_reduce (RCCL through the C-ABI was not usable on some rank" + (f": {err}" if err else "") + ")"
-    else:
-        transport = sharding.TorchTransport(root=root)
+            transport = torch_transport()
+            transport_note = "torch.distributed (RCCL through the C-ABI was not usable on some rank" + (f": {err}" if err else "") + ")"
+    if transport is None:
+        transport = torch_transport() if dist is not None else sharding.TorchTransport(root=root)
+    rccl = isinstance(transport, sharding.RcclTransport)
+
+    def ranks_barrier():
+        """Every rank's device work is done and every rank is here: the timed region's brackets."""
+        torch.cuda.synchronize()
+        if dist is not None and world > 1:
+            if rccl:
+                transport.barrier()
+            else:
+                dist.barrier(group=transport.group)
+        torch.cuda.synchronize()
 
     correlated = args.workload == "config5"
     if correlated:
@@ -380,8 +406,7 @@ def main():
         fr.touched_mask = torch.zeros(((gdim + 3) // 4) ** 3, dtype=torch.uint8, device=ctx.device)
         fractions = []
         step_no = [0]
-        delta_sr = ctx.sparse_reduce_create(transport.comm, fr.grid) if world > 1 and isinstance(transport, sharding.RcclTransport) else None
-        full_sr = ctx.sparse_reduce_create(transport.comm, fr.grid) if delta_sr is not None else None   # (its own payload policy: the unions differ a hundredfold)
+        delta_sr = ctx.sparse_reduce_create(transport.comm, fr.grid) if world > 1 and rccl else None
         delta_pending = []
         reduce_info = []
 
@@ -394,14 +419,17 @@ def main():
             fractions.append(n / max(fr.n, 1))
             if delta_sr is not None:
                 # the delta path: only bricks touched by a re-traced photon (old or new position) changed on any rank; the
-                # previous step's ticket is completed here (its count has long arrived), this step's at the next one
+                # previous step's ticket is completed here (its count has long arrived), this step's at the next one.
+                # A rank whose update REBUILT its volume (a rank-local decision: its own re-trace count against its own threshold)
+                # hands in every brick as touched -- ONE reduce object, ONE kind of mask on every rank whatever path each took: the union
+                # then covers everything and the frame's sum is the dense one, on all ranks alike (two objects with
+                # separate histories let ranks issue collectives of different sizes).
                 while delta_pending:
                     sr_, t_ = delta_pending.pop()
                     reduce_info.append(sr_.complete(t_))
-                if fr.last_path == "full":   # the update rebuilt the rank's volume: the union of the non-zero bricks, zeros elsewhere
-                    delta_pending.append((full_sr, full_sr.start(fr.light_volume, total_grid)))
-                else:
-                    delta_pending.append((delta_sr, delta_sr.start(fr.light_volume, total_grid, brick_mask=fr.touched_mask)))
+                if fr.last_path == "full":
+                    fr.touched_mask.fill_(1)
+                delta_pending.append((delta_sr, delta_sr.start(fr.light_volume, total_grid, brick_mask=fr.touched_mask)))
             elif world > 1:
                 total_grid.copy_(fr.light_volume)
                 sharding.allreduce_light_volume(total_grid, transport)
@@ -410,10 +438,7 @@ def main():
             while delta_pending:
                 sr_, t_ = delta_pending.pop()
                 reduce_info.append(sr_.complete(t_))
-            torch.cuda.synchronize()
-            if dist is not None:
-                dist.barrier()
-            torch.cuda.synchronize()
+            ranks_barrier()
         use_graph = False
     else:
         fr = P.PhotonFrame(ctx, vol_np, tf, lattice, (gdim,) * 3, light_travel_direction=LIGHT_DIR, photon_indices=shard)
@@ -426,10 +451,11 @@ def main():
             fr.capture()
         # the sum of the per-rank grids overlaps the next frame's trace and bin (double-buffered grids,
         # sharding.OverlappedGridReducer); everything outstanding is waited for inside the timed region
-        sparse = None
-        if args.reduce == "sparse" and world > 1 and not use_graph:
-            sparse = fr.grid if isinstance(transport, sharding.RcclTransport) else ((gdim,) * 3, 1)
-        reducer = sharding.OverlappedGridReducer(fr.light_volume, transport, sparse=sparse)
+        desc = fr.grid if rccl else ((gdim,) * 3, 1)
+        if use_graph or world == 1:
+            exchange = "dense"
+        reducer = sharding.OverlappedGridReducer(fr.light_volume, transport, sparse=desc if exchange == "union" else None,
+                                                 lists=desc if exchange == "lists" else None, root=0 if root is None else root)
         frame_no = [0]
 
         def step():
@@ -443,7 +469,7 @@ def main():
                 fr.trace()
                 if fast:
                     fr.bin_fast()
-                    marks = reducer.marks_for(k) if reducer.sparse else None   # (the gather also marks the volume's non-zero bricks)
+                    marks = reducer.marks_for(k) if (reducer.sparse or reducer.lists) else None   # (the gather also marks the volume's non-zero bricks)
                     fr.gather_fast(out=reducer.acquire(k), nonzero_bricks=marks)
                     reducer.reduce(k, marked=marks is not None)
                     return
@@ -453,10 +479,7 @@ def main():
 
         def barrier():
             reducer.flush()
-            torch.cuda.synchronize()
-            if dist is not None:
-                dist.barrier()
-            torch.cuda.synchronize()
+            ranks_barrier()
 
     # W untimed steps, then TIMED_BATCHES batches of exactly K steps, each between two barrier + synchronize pairs and taken as the
     # MAX over the ranks; ms_per_step / value are the MEDIAN batch's (K = 20 frames of config 2 last 1.4 ms: one batch is one sample of
@@ -472,7 +495,7 @@ def main():
         barrier()
         dt = time.perf_counter() - t0
         if dist is not None:
-            t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+            t = torch.tensor([dt], dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
         batch_elapsed.append(dt)
@@ -789,6 +812,23 @@ def main():
                                    "light_volumes_identical_to_single_stream": same}
             del frames, ctxs
 
+    # what every rank's light volume lights, for the exchange's byte model (all ranks: the counts are gathered)
+    exchange_rows = None
+    if not correlated and world > 1 and fast:
+        tmp = torch.empty_like(fr.light_volume)
+        fr.trace(); fr.bin_fast(); fr.gather_fast(out=tmp)
+        lit = (sharding.brick_view(tmp, (gdim,) * 3, 1).reshape(-1, 64) != 0).any(dim=1)
+        tail = reducer.info[-args.steps:] if reducer.info else []
+        mine = torch.tensor([float(lit.sum().item()),
+                             float(np.median([i.get("sent_bytes", 0) for i in tail])) if tail else 0.0,
+                             float(np.median([i.get("received_bytes", 0) for i in tail])) if tail else 0.0,
+                             float(sum(i.get("resent", 0) for i in tail))], dtype=torch.float64)
+        rows = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(rows, mine)
+        union = lit.to(torch.uint8).cpu()
+        dist.all_reduce(union, op=dist.ReduceOp.MAX)
+        exchange_rows = {"per_rank": [r.tolist() for r in rows], "union": int(union.sum().item()), "n_bricks": int(lit.numel())}
+        del tmp
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         value = n_total * args.steps / elapsed / 1e6
@@ -838,9 +878,9 @@ def main():
                        "light_volume": [gdim] * 3,
                        "parallelism": (f"photon-sharded x{world} ({scaling} scaling), one "
                                        + ("touched-brick reduce (cpm_allreduce_grid_sparse with the touched-brick mask)" if correlated else
-                                          (("sparse " if reducer.sparse else "") + ("all-reduce" if root is None else "reduce to rank 0")
-                                           + " of the grid per frame (" + ("cpm_allreduce_grid_sparse" if reducer.sparse else
-                                                                            "cpm_allreduce_grid" if root is None else "cpm_reduce_grid"))
+                                          ({"union": "sparse ", "lists": "brick-list ", "dense": ""}[exchange] + ("all-reduce" if root is None else "reduce to rank 0")
+                                           + " of the grid per frame (" + {"union": "cpm_allreduce_grid_sparse", "lists": "cpm_reduce_grid_bricklists: every rank's own non-zero bricks, one send per rank",
+                                                                           "dense": "cpm_allreduce_grid" if root is None else "cpm_reduce_grid"}[exchange])
                                           + ": RCCL on a side stream), overlapped with the next "
                                           "frame's trace + bin (double-buffered grid)")
                                        + f", transport {type(transport).__name__}"
@@ -851,12 +891,13 @@ def main():
                                           "float8 records (the reference's layout, cl/photon.cl:49-63)"),
                        "trace_workgroup_order": "costliest chunks first, from the costs a measured launch recorded (cpm_trace_order: the first "
                                                 "frame and every 256th are measured)" if getattr(fr, "adaptive_order", False) else "lattice order",
-                       "shards": (f"4096-sample lattice tiles dealt round-robin (rank r: tiles t = r mod {world})" if args.shards == "tiles"
+                       "shards": (f"4096-sample lattice tiles dealt round-robin (rank r: tiles t = r mod {world})" if shards_kind == "tiles"
                                   else "contiguous photon ranges (slabs of the light plane)") if world > 1 else "one shard",
+                       "exchange": exchange if world > 1 else "none",
                        # the transport the reduce really used, and the size RCCL itself reports for the communicator
                        # (cpm_comm_size; 0 = the reduce did not go through the C-ABI's RCCL communicator)
                        "transport": type(transport).__name__,
-                       "rccl_ranks": transport.comm.size if isinstance(transport, sharding.RcclTransport) else 0},
+                       "rccl_ranks": transport.comm.size if rccl else 0},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": ab.get(dom_base, 0), "avg_launch_ms": round(dom_avg_ms, 5),
@@ -889,8 +930,21 @@ def main():
                              "frames_sparse": int(sum(i["mode"] == 0 for i in tail)), "frames_dense_by_policy": int(sum(i["mode"] == 1 for i in tail)),
                              "frames_dense_after_overflow": int(sum(i["mode"] == 2 for i in tail)),
                              "stream_synchronisations_per_frame": 0}
+        elif world > 1 and not correlated and reducer.lists and exchange_rows:
+            pr = exchange_rows["per_rank"]
+            out["reduce"] = {"kind": "brick lists: every rank's own non-zero 4x4x4 bricks to rank 0 (cpm_reduce_grid_bricklists)",
+                             "sent_bytes_per_rank_per_frame": [int(r[1]) for r in pr], "received_bytes_at_root_per_frame": int(pr[0][2]),
+                             "reduce_bytes_per_frame": int(max(r[1] for r in pr)),   # the busiest link: a sender's one segment
+                             "exchanges_repeated_at_exact_size": int(sum(r[3] for r in pr[1:])),
+                             "dense_bytes": gdim ** 3 * 4, "n_bricks": exchange_rows["n_bricks"], "stream_synchronisations_per_frame": 0}
         elif world > 1:
             out["reduce"] = {"kind": "dense", "reduce_bytes_per_frame": gdim ** 3 * 4, "dense_bytes": gdim ** 3 * 4}
+        if exchange_rows:
+            counts = [int(r[0]) for r in exchange_rows["per_rank"]]
+            out.setdefault("reduce", {})["bricks"] = {"lit_per_rank": counts, "union": exchange_rows["union"], "of": exchange_rows["n_bricks"]}
+            out["reduce"]["model"] = dict(sharding.exchange_model(exchange_rows["n_bricks"], 1, world, exchange_rows["union"], max(counts), gdim ** 3),
+                                          note="bytes on a rank's busiest xGMI link per frame and a modelled time (latency 30 us per collective, 100 GB/s per "
+                                               "link) for the three forms, from this run's brick counts; arithmetic, not a measurement")
         out.update(extras)
         if world == 1 and not args.no_cpu_baseline and not correlated:
             out["cpu_baseline"] = cpu_baseline(args.workload, vol_np, tf, lattice, gdim)

@@ -48,7 +48,7 @@ ABI_SYMBOLS = [
     "cpm_comm_get_unique_id", "cpm_comm_create", "cpm_comm_create_all", "cpm_comm_destroy", "cpm_comm_rank", "cpm_comm_size",
     "cpm_allreduce_grid", "cpm_reduce_grid", "cpm_allreduce_grids", "cpm_allreduce_grid_bricks",
     "cpm_sparse_reduce_create", "cpm_sparse_reduce_destroy", "cpm_sparse_reduce_bricks", "cpm_sparse_reduce_capacity_for",
-    "cpm_allreduce_grid_sparse", "cpm_sparse_reduce_complete",
+    "cpm_allreduce_grid_sparse", "cpm_sparse_reduce_complete", "cpm_brick_mask_or",
     "cpm_bricklist_reduce_create", "cpm_bricklist_reduce_destroy", "cpm_bricklist_reduce_bricks", "cpm_bricklist_capacity_for",
     "cpm_bricklist_segment_bytes", "cpm_reduce_grid_bricklists", "cpm_bricklist_reduce_complete",
     "cpm_light_volume_texels", "cpm_gl_available", "cpm_gl_register_buffer", "cpm_gl_acquire", "cpm_gl_release",
@@ -286,6 +286,7 @@ def load_library() -> C.CDLL:
         "cpm_sparse_reduce_capacity_for": (u32, [u32, C.c_longlong]),
         "cpm_allreduce_grid_sparse": (i32, [vp, vp, vp, vp, vp, i32, i32, u32, P(C.c_uint64), vp]),
         "cpm_sparse_reduce_complete": (i32, [vp, vp, C.c_uint64, vp, P(SparseReduceInfo)]),
+        "cpm_brick_mask_or": (i32, [vp, vp, vp, sz, vp]),
         "cpm_bricklist_reduce_create": (i32, [vp, vp, P(GridDesc), i32, P(vp)]),
         "cpm_bricklist_reduce_destroy": (None, [vp]),
         "cpm_bricklist_reduce_bricks": (u32, [vp]),
@@ -641,6 +642,9 @@ class Context:
         self._check(self.lib.cpm_allreduce_grid_bricks(self.h, comm.h, self._ptr(partial), self._ptr(total), C.byref(grid),
                                                        self._ptr(brick_mask), C.byref(n_union), self._stream()))
         return int(n_union.value)
+
+    def brick_mask_or(self, dst, src, n=None):
+        self._check(self.lib.cpm_brick_mask_or(self.h, self._ptr(dst), self._ptr(src), int(dst.numel() if n is None else n), self._stream()))
 
     def bricklist_reduce_create(self, comm, grid: "GridDesc", root: int = 0) -> "BricklistReduce":
         h = C.c_void_p()

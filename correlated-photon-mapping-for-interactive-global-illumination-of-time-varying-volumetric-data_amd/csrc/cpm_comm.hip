@@ -770,6 +770,22 @@ int cpm_sparse_reduce_complete(cpm_ctx* ctx, cpm_sparse_reduce* sr, uint64_t tic
 
 }  // extern "C"
 
+namespace {
+__global__ __launch_bounds__(256) void brick_mask_or_kernel(uint8_t* __restrict__ dst, const uint8_t* __restrict__ src, size_t n) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) dst[i] = (dst[i] | src[i]) ? 1 : 0;
+}
+}  // namespace
+
+extern "C" int cpm_brick_mask_or(cpm_ctx* ctx, uint8_t* dst, const uint8_t* src, size_t n, cpm_stream stream) {
+    CPM_ENTER(ctx);
+    if (n == 0) return CPM_OK;
+    CPM_REQUIRE(ctx, dst && src, "cpm_brick_mask_or: null mask");
+    CPM_LAUNCH(ctx, brick_mask_or_kernel, dim3((unsigned)div_up((long long)n, 256)), dim3(256), 0, (hipStream_t)stream, dst, src, n);
+    CPM_LAUNCH_CHECK(ctx, "brick_mask_or_kernel");
+    return CPM_OK;
+}
+
 // ---- cpm_reduce_grid_bricklists ----------------------------------------------------------------------------------------------
 // A segment = [ header: count, capacity, ticket, magic ][ capacity bricks of 64 * CH floats ][ capacity brick ids ].
 

@@ -1348,6 +1348,7 @@ void PhotonToLightVolumeProcessorCL::reduceOverShards(const cpm_grid_desc& g, si
         reducedVolume_->channels = lightVolume_->channels;
         reducedVolume_->data.setSize(count);
         partialUpdate = false;  // nothing to update incrementally yet
+        firstSumIntoReduced_ = true;
     }
     if (sparseReduce_ && (sparseReduceDims_.x != outDim.x || sparseReduceDims_.y != outDim.y || sparseReduceDims_.z != outDim.z ||
                           sparseReduceChannels_ != lightVolume_->channels))
@@ -1357,20 +1358,44 @@ void PhotonToLightVolumeProcessorCL::reduceOverShards(const cpm_grid_desc& g, si
         sparseReduceDims_ = outDim;
         sparseReduceChannels_ = lightVolume_->channels;
     }
+    // Which bricks this shard hands in, and as what.  Shards decide between rebuild and add-remove on their own counts, so in one frame
+    // one shard may rebuild while another updates: the kind of mask must not depend on that decision.  Rule: the first sum into a new
+    // `reducedVolume_` (every shard alike: same evaluation) is NONZERO -- the whole volume is defined, zeros outside the union; every
+    // later one is TOUCHED -- the bricks where THIS shard's contribution changed: an update's old and new positions, or, for a rebuild,
+    // everything the shard had lit (its marks of the last rebuild and what its updates touched since: litBefore_) or lights now.
+    const size_t nb4 = (size_t)((outDim.x + 3) / 4) * ((outDim.y + 3) / 4) * ((outDim.z + 3) / 4);
+    const bool firstSum = firstSumIntoReduced_;
+    firstSumIntoReduced_ = false;
     const uint8_t* mask = nullptr;
     int maskKind = CPM_SPARSE_MASK_TOUCHED;
-    if (!partialUpdate && marksAreNonzero_) {  // a full evaluation whose gather marked the volume's non-zero bricks
-        mask = nonzeroMarks_.device();
-        maskKind = CPM_SPARSE_MASK_NONZERO;
-    }
+    if (litBefore_.getSize() != nb4 + 16) { litBefore_.setSize(nb4 + 16); litBeforeValid_ = false; }
     if (partialUpdate && brickMask_.getSize() != 0 && idx) {
         // add-remove: only bricks touched by an old or a new position of a re-traced photon changed on this shard.  The old
         // positions were marked into brickMask_ before the snapshot moved on (see process()); add the new ones, then sum
         // the union of all shards' bricks only.
         if (marksComplete != nullptr ||
             rt.check(cpm_mark_touched_bricks(rt.ctx(), photons, idx, nRecomputed, nPhotons, nInter, &g, radius, brickMask_.device(), rt.stream()),
-                     "cpm_mark_touched_bricks(new)"))
+                     "cpm_mark_touched_bricks(new)")) {
             mask = brickMask_.device();
+            if (litBeforeValid_) litBeforeValid_ = rt.check(cpm_brick_mask_or(rt.ctx(), litBefore_.device(), brickMask_.device(), nb4, rt.stream()), "cpm_brick_mask_or");
+        }
+    } else if (firstSum) {
+        if (marksAreNonzero_) { mask = nonzeroMarks_.device(); maskKind = CPM_SPARSE_MASK_NONZERO; }   // (no marks: the reduce finds the non-zero bricks itself)
+    } else {
+        // a rebuild while a previous sum stands
+        allBricks_.setSize(nb4 + 16);
+        if (marksAreNonzero_ && litBeforeValid_ &&
+            hipMemcpyAsync(allBricks_.device(), nonzeroMarks_.device(), nb4, hipMemcpyDeviceToDevice, rt.stream()) == hipSuccess &&
+            rt.check(cpm_brick_mask_or(rt.ctx(), allBricks_.device(), litBefore_.device(), nb4, rt.stream()), "cpm_brick_mask_or")) {
+            mask = allBricks_.device();
+        } else {  // what it had lit is not known (a formulation without marks): every brick counts as touched -- the dense sum
+            (void)hipMemsetAsync(allBricks_.device(), 1, nb4, rt.stream());
+            mask = allBricks_.device();
+        }
+    }
+    if (!partialUpdate) {  // what this shard lights from here on
+        litBeforeValid_ = marksAreNonzero_ &&
+                          hipMemcpyAsync(litBefore_.device(), nonzeroMarks_.device(), nb4, hipMemcpyDeviceToDevice, rt.stream()) == hipSuccess;
     }
     if (sparseReduce_) {
         uint64_t ticket = 0;

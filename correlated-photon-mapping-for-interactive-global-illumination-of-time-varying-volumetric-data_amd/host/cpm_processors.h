@@ -655,6 +655,8 @@ private:
     cpm_sparse_reduce* sparseReduce_ = nullptr;  // cpm_allreduce_grid_sparse state of (comm_, the light volume's shape)
     Buffer<uint8_t> nonzeroMarks_;               // cpm_gather_fast_marked: the non-zero 4x4x4 bricks of the volume just written
     bool marksAreNonzero_ = false;               // ... valid for this evaluation's lightVolume_
+    Buffer<uint8_t> litBefore_, allBricks_;      // multi-GPU: the bricks this shard has lit since its last rebuild / the mask a rebuild hands in
+    bool litBeforeValid_ = false, firstSumIntoReduced_ = false;
     size3_t sparseReduceDims_{ 0, 0, 0 };
     int sparseReduceChannels_ = 0;
     void dropSparseReduce();

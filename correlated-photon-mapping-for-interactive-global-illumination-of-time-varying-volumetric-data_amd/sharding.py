@@ -130,9 +130,11 @@ class TorchTransport:
     """all-reduce over torch.distributed (gloo in the CPU tests; any backend).  No-op for one rank.
     root: None = every rank receives the sum (all-reduce); an int = only that rank does (reduce: the display GPU)."""
 
-    def __init__(self, group=None, root=None):
+    def __init__(self, group=None, root=None, p2p_group=None):
+        """group: where the collectives run (any backend); p2p_group: where the brick lists' send / recv pairs of host tensors run
+        (default: the default group -- gloo in this build's runs)."""
         import torch.distributed as dist
-        self._dist, self.group, self.root = dist, group, root
+        self._dist, self.group, self.root, self.p2p_group = dist, group, root, p2p_group
         self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
 
     def start(self, grid):
@@ -231,11 +233,11 @@ class TorchTransport:
             count = int(mine.numel())
             cap = bricklist_capacity(nb, prev[rank] if prev is not None else -1)
             vals = bricks[mine].cpu()
-            dist.send(segment(vals, mine.cpu(), count, cap), dst=root, group=self.group)
+            dist.send(segment(vals, mine.cpu(), count, cap), dst=root, group=self.p2p_group)
             info.update(n_own=count, capacity=cap, sent_bytes=bricklist_segment_bytes(cap, ch))
             if count > cap:
                 exact = (count + 63) & ~63
-                dist.send(segment(vals, mine.cpu(), count, exact), dst=root, group=self.group)
+                dist.send(segment(vals, mine.cpu(), count, exact), dst=root, group=self.p2p_group)
                 info["resent"] = 1
                 info["sent_bytes"] += bricklist_segment_bytes(exact, ch)
             bl["counts"].append({rank: count})
@@ -247,14 +249,14 @@ class TorchTransport:
                     continue
                 cap = bricklist_capacity(nb, prev[r] if prev is not None else -1)
                 seg = torch.zeros(2 + cap + cap * 64 * ch, dtype=torch.float32)
-                dist.recv(seg, src=r, group=self.group)
+                dist.recv(seg, src=r, group=self.p2p_group)
                 info["received_bytes"] += bricklist_segment_bytes(cap, ch)
                 count = int(seg[0].item())
                 counts[r] = count
                 if count > cap:
                     cap = (count + 63) & ~63
                     seg = torch.zeros(2 + cap + cap * 64 * ch, dtype=torch.float32)
-                    dist.recv(seg, src=r, group=self.group)
+                    dist.recv(seg, src=r, group=self.p2p_group)
                     info["resent"] += 1
                     info["received_bytes"] += bricklist_segment_bytes(cap, ch)
                 ids = seg[2:2 + count].to(torch.int64).to(grid.device)
@@ -307,6 +309,17 @@ class RcclTransport:
         """The CURRENT stream waits for the reduce (no host wait)."""
         if handle is not None:
             self.torch.cuda.current_stream(self.ctx.device).wait_event(handle)
+
+    def barrier(self):
+        """Every rank has reached this call (an 8-float all-reduce on the transport's stream, waited for on the host): the brackets of a
+        timed region, without a second communication library on the devices."""
+        torch = self.torch
+        if self.world > 1:
+            if getattr(self, "_token", None) is None:
+                self._token = torch.zeros(8, dtype=torch.float32, device=self.ctx.device)
+            with torch.cuda.stream(self.stream):
+                self.ctx.allreduce_grid(self.comm, self._token)
+            self.stream.synchronize()
 
     # -- the sparse full-frame sum (cpm_allreduce_grid_sparse): same stream discipline as start / wait
     def sparse_setup(self, grid_desc):

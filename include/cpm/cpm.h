@@ -724,6 +724,11 @@ int cpm_allreduce_grids(cpm_ctx* const* ctxs, cpm_comm* const* comms, float* con
 int cpm_allreduce_grid_bricks(cpm_ctx* ctx, cpm_comm* comm, const float* partial, float* total,
                               const cpm_grid_desc* grid, uint8_t* brick_mask, uint32_t* n_union_out, cpm_stream stream);
 
+/* dst[b] |= src[b] (non-zero -> 1) over n bricks: the union of two brick masks.  What a shard that REBUILDS its light volume passes to
+ * cpm_allreduce_grid_sparse as its touched bricks -- the bricks it had lit before (old non-zero marks, plus everything its add-remove
+ * updates touched since) or lights now -- so that shards may rebuild and update in the same frame and still agree on the sum. */
+int cpm_brick_mask_or(cpm_ctx* ctx, uint8_t* dst, const uint8_t* src, size_t n, cpm_stream stream);
+
 /* Full frames: the sum over the ranks of the per-rank light volumes WITHOUT moving the empty space and WITHOUT a host wait.
  * A rank's photons reach a fraction of the grid (config 2: 1 in 8 of the 4x4x4-voxel bricks holds a non-zero voxel), every
  * rank reaches nearly the same bricks (lattice tiles are dealt round-robin), and the dense sum -- 64 MiB per frame at

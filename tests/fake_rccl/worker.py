@@ -95,6 +95,34 @@ for dims, ch in (((32, 32, 32), 1), ((20, 13, 9), 4)):
     results[f"sparse_{dims[0]}_{ch}_delta"] = total.cpu().numpy()
     results[f"sparse_{dims[0]}_{ch}_delta_mask"] = mask
     results[f"sparse_{dims[0]}_{ch}_delta_union"] = np.array([i.n_union, i.mode], np.int64)
+    # a MIXED frame: rank 0 rebuilds its volume and hands in every brick it had lit or lights now (two masks OR-ed on the
+    # device: cpm_brick_mask_or), rank 1 updates a few bricks and hands in those -- both as TOUCHED masks, into the standing sum
+    dx, dy, dz = dims
+    bxn, byn = (dx + 3) // 4, (dy + 3) // 4
+    zz, yy, xx = np.meshgrid(np.arange(dz), np.arange(dy), np.arange(dx), indexing="ij")
+    brick_of = np.repeat(((xx // 4) + bxn * ((yy // 4) + byn * (zz // 4))).reshape(-1), ch)
+
+    def nz_mask(g):
+        m = np.zeros(nb, np.uint8)
+        m[np.unique(brick_of[g != 0])] = 1
+        return m
+    standing = [partial(dims, ch, 4, w) for w in (0, 1)]
+    total = torch.from_numpy(standing[0] + standing[1]).to(ctx.device)
+    if rank == 0:
+        new = partial(dims, ch, 6, 0)
+        m_dev = torch.from_numpy(nz_mask(standing[0])).to(ctx.device)
+        ctx.brick_mask_or(m_dev, torch.from_numpy(nz_mask(new)).to(ctx.device))
+    else:
+        t1 = (np.random.default_rng(77).random(nb) < 0.04).astype(np.uint8)
+        new = standing[1].copy()
+        sel = t1[brick_of].astype(bool)
+        new[sel] = partial(dims, ch, 7, 1)[sel]
+        m_dev = torch.from_numpy(t1).to(ctx.device)
+    p = torch.from_numpy(new).to(ctx.device)
+    i = sr.complete(sr.start(p, total, brick_mask=m_dev))
+    torch.cuda.synchronize()
+    results[f"sparse_{dims[0]}_{ch}_mixed"] = total.cpu().numpy()
+    results[f"sparse_{dims[0]}_{ch}_mixed_new"] = new
     sr.close()
 comm.close()
 

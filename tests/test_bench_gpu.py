@@ -49,7 +49,10 @@ def test_bench_two_ranks_code_path():
     assert KEYS <= set(d)
     assert d["n_gpus"] == 2 and d["steps"] == 6 and d["value"] > 0
     assert "cpu_baseline" not in d                      # rank 0 at N = 1 only
-    assert "all-reduce" in d["config"]["parallelism"] and d["scaling"] == "weak"
+    assert "reduce to rank 0" in d["config"]["parallelism"] and d["scaling"] == "weak"      # the north-star's reduce to the display GPU
+    assert d["config"]["exchange"] == "union" and "tiles" in d["config"]["shards"]             # weak scaling: tile shards, union of bricks
+    assert len(d["timing"]["batch_ms_per_step"]) == 7 and d["reduce"]["bricks"]["union"] >= max(d["reduce"]["bricks"]["lit_per_rank"])
+    assert set(d["reduce"]["model"]) >= {"dense_reduce", "union_reduce", "brick_lists"}
     assert d["config"]["photons_rank0"] == 65536 and d["config"]["photons_per_frame"] == 131072   # weak: the per-rank work is fixed
     # the default reduce is the sparse one (here carried out by torch ops over gloo): no stream synchronisation on the frame's path
     assert "sparse" in d["config"]["parallelism"] and d["reduce"]["stream_synchronisations_per_frame"] == 0
@@ -118,3 +121,38 @@ def test_bench_two_ranks_through_the_c_abi_reduce():
     assert red["stream_synchronisations_per_frame"] == 0 and "cpm_allreduce_grid_sparse" in red["kind"]
     assert red["frames_sparse"] + red["frames_dense_by_policy"] + red["frames_dense_after_overflow"] == 6
     assert red["n_union_median"] > 0 and red["reduce_bytes_per_frame"] > 0
+
+
+def test_bench_two_ranks_brick_lists_through_the_c_abi():
+    """A fixed photon count sharded over two ranks (--scaling strong): contiguous ranges + cpm_reduce_grid_bricklists by default -- every
+    rank's own bricks as one segment to rank 0, over the RCCL test double on the box's one GPU."""
+    sys.path.insert(0, str(REPO / "tests" / "fake_rccl"))
+    import build as fake_build
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", CPM_RCCL_LIBRARY=str(fake_build.build()))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29537", str(REPO / "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "3", "--workload", "config1",
+           "--scaling", "strong", "--test-backend", "gloo", "--test-one-device", "--transport", "rccl"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=str(REPO), env=env)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-4000:]
+    d = _last_json(r.stdout)
+    assert d["n_gpus"] == 2 and d["value"] > 0 and d["scaling"] == "strong"
+    assert d["config"]["transport"] == "RcclTransport" and d["config"]["rccl_ranks"] == 2
+    assert d["config"]["exchange"] == "lists" and "contiguous" in d["config"]["shards"]
+    red = d["reduce"]
+    assert "cpm_reduce_grid_bricklists" in red["kind"] and red["stream_synchronisations_per_frame"] == 0
+    assert red["sent_bytes_per_rank_per_frame"][0] == 0 and red["sent_bytes_per_rank_per_frame"][1] > 0    # the root sends nothing
+    assert red["received_bytes_at_root_per_frame"] == sum(red["sent_bytes_per_rank_per_frame"])
+    assert red["bricks"]["union"] <= sum(red["bricks"]["lit_per_rank"])
+
+
+def test_bench_two_ranks_brick_lists_over_gloo():
+    """The same exchange carried out by torch ops (TorchTransport's twin of the protocol) when the C-ABI's transport is not in use."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29538", str(REPO / "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "3", "--workload", "config1",
+           "--scaling", "strong", "--test-backend", "gloo", "--test-one-device"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=str(REPO), env=env)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-4000:]
+    d = _last_json(r.stdout)
+    assert d["config"]["exchange"] == "lists" and d["config"]["transport"] == "TorchTransport"
+    assert "cpm_reduce_grid_bricklists" in d["reduce"]["kind"] and d["reduce"]["received_bytes_at_root_per_frame"] > 0

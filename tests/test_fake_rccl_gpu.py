@@ -98,6 +98,19 @@ def test_sparse_reduce_with_two_ranks(two_ranks, cpm, dims, ch):
             assert np.array_equal(got[sel], want[sel]) and (got[~sel] == -2.0).all()
 
 
+@pytest.mark.parametrize("dims,ch", [((32, 32, 32), 1), ((20, 13, 9), 4)])
+def test_one_rank_rebuilds_while_the_other_updates(two_ranks, dims, ch):
+    """The frame in which the shards take different paths (a rank-local decision: ADVICE r04): the rebuilding rank hands in every brick
+    it had lit or lights now, the updating rank its touched bricks, both as TOUCHED masks -- the standing sum becomes the sum of the
+    two CURRENT partial volumes everywhere, on both ranks (what PhotonToLightVolumeProcessorCL::reduceOverShards now does)."""
+    r0, r1 = two_ranks
+    key = f"sparse_{dims[0]}_{ch}"
+    want = r0[key + "_mixed_new"] + r1[key + "_mixed_new"]
+    assert np.array_equal(r0[key + "_mixed"], want) and np.array_equal(r1[key + "_mixed"], want)
+    assert not np.array_equal(r0[key + "_mixed_new"], _partial(dims, ch, 4, 0))   # rank 0 really rebuilt ...
+    assert not np.array_equal(r1[key + "_mixed_new"], _partial(dims, ch, 4, 1))   # ... and rank 1 really changed something
+
+
 def test_overlapped_reducer_over_two_ranks(two_ranks):
     """bench.py's frame loop: every frame's buffer holds the two ranks' sum once its reduce has been waited for, with and without the
     gather's marks; the figures of every ticket agree between the ranks."""
