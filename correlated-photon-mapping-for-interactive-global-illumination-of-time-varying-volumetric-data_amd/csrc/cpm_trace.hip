@@ -284,9 +284,13 @@ int trace_impl(cpm_ctx* ctx, const cpm_volume* vol, const cpm_tf* tf, const cpm_
     CPM_REQUIRE(ctx, n_recompute >= 0, "cpm_trace: n_recompute < 0");
     if (tf_scattering) CPM_REQUIRE(ctx, tf_scattering->width == tf->width, "cpm_trace: tf widths differ");
     int n_threads = recompute_indices ? n_recompute : p.n_light_samples;
-    if (sel.lights) {  // the launch's chunks: every light's samples rounded up to whole chunks
+    if (sel.lights) {  // the launch's chunks: every light's samples rounded up to whole chunks (sizes checked first: a negative count
+                       // must not cancel another light's chunks and pass for an empty launch)
         long long chunks = 0;
-        for (int l = 0; l < sel.n_lights; ++l) chunks += div_up(sel.lights[l].n_light_samples, 256);
+        for (int l = 0; l < sel.n_lights; ++l) {
+            CPM_REQUIRE(ctx, sel.lights[l].n_light_samples >= 0 && sel.lights[l].photon_offset >= 0, "cpm_trace_lights: negative size");
+            chunks += div_up(sel.lights[l].n_light_samples, 256);
+        }
         CPM_REQUIRE(ctx, chunks * 256 < (1ll << 31), "cpm_trace_lights: too many samples");
         n_threads = (int)(chunks * 256);
     }
@@ -618,9 +622,10 @@ int cpm_trace_lights_order_samples(const cpm_light_span* lights, int n_lights) {
 int cpm_trace_lights(cpm_ctx* ctx, const cpm_volume* vol, const cpm_tf* tf, const cpm_tf* tf_scattering, const float aabb[8],
                      const cpm_trace_params* params, const cpm_light_span* lights, int n_lights, uint32_t* rng_state, float* photons8,
                      cpm_stream stream) {
-    if (ctx && !(lights && n_lights >= 1 && n_lights <= CPM_MAX_TRACE_LIGHTS))
+    if (!ctx) return CPM_ERR_INVALID_ARGUMENT;   // (as every entry point: no context, nothing to report through)
+    if (!(lights && n_lights >= 1 && n_lights <= CPM_MAX_TRACE_LIGHTS))
         return set_error(ctx, CPM_ERR_INVALID_ARGUMENT, "cpm_trace_lights", "1 .. CPM_MAX_TRACE_LIGHTS lights");
-    if (ctx && !params) return set_error(ctx, CPM_ERR_INVALID_ARGUMENT, "cpm_trace_lights", "null params");
+    if (!params) return set_error(ctx, CPM_ERR_INVALID_ARGUMENT, "cpm_trace_lights", "null params");
     cpm_trace_params p = *params;   // (the per-light fields come from the spans)
     p.photon_offset = 0;
     p.n_light_samples = 0;

@@ -9,7 +9,19 @@ ProcessorFactory& ProcessorFactory::get() {
 }
 std::unique_ptr<Processor> ProcessorFactory::create(const std::string& id) const {
     auto it = creators_.find(id);
-    return it == creators_.end() ? nullptr : it->second();
+    if (it != creators_.end()) return it->second();
+#ifndef CPM_HOST_EXTRAS
+    // the four processors of the reference's modules that are not on the workspace's path exist only in the -DCPM_HOST_EXTRAS build
+    // (libcpm_host_extras.so): say so instead of "unknown processor"
+    for (const char* extra : { "org.inviwo.RadixSortCL", "org.inviwo.UniformGrid3DExport", "org.inviwo.UniformGrid3DSequenceSelector",
+                               "org.inviwo.UniformGrid3DSourceProcessor", "org.inviwo.UniformGrid3DVectorSource" })
+        if (id == extra) {
+            LogError("processor " + id + " is not in this library: it is built with -DCPM_HOST_EXTRAS (libcpm_host_extras.so)");
+            return nullptr;
+        }
+#endif
+    LogError("unknown processor class identifier: " + id);
+    return nullptr;
 }
 std::vector<std::string> ProcessorFactory::getKeys() const {
     std::vector<std::string> k;

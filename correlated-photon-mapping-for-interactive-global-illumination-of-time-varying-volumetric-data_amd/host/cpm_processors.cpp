@@ -62,11 +62,11 @@ StreamSpan::~StreamSpan() {
     if (a_) (void)hipEventDestroy(a_);
     if (b_) (void)hipEventDestroy(b_);
 }
-void StreamSpan::begin(hipStream_t s, float* target) {
+void StreamSpan::begin(hipStream_t s, float* target, bool force) {
     poll();
     if (pending_) { open_ = false; return; }  // the previous span has not completed yet: skip this measurement
-    if (target && *target >= 0.f && ++skipped_ < kEvery) { open_ = false; return; }  // known: sampled every kEvery-th time
-    skipped_ = 0;
+    if (target && *target >= 0.f && !force && ++skipped_[target] < kEvery) { open_ = false; return; }  // known: sampled every kEvery-th time
+    if (target) skipped_[target] = 0;
     if (!a_ && (hipEventCreate(&a_) != hipSuccess || hipEventCreate(&b_) != hipSuccess)) { a_ = b_ = nullptr; open_ = false; return; }
     target_ = target;
     open_ = hipEventRecord(a_, s) == hipSuccess;
@@ -900,10 +900,13 @@ void ProgressivePhotonTracerCL::process() {  // progressivephotontracercl.cpp:21
             takeFullFrame = true;
         } else if (fused && importanceBranchPolicy_.get() == "adaptive") {
             auto& c = costs_;
-            if (c.known() && c.branchTraceMs() + c.branchLightVolumeMs() > c.fullTraceMs + c.fullLightVolumeMs && c.evaluationsSinceProbe < 32) {
+            const bool fullFrameCheaper = c.known() && c.branchTraceMs() + c.branchLightVolumeMs() > c.fullTraceMs + c.fullLightVolumeMs;
+            c.probing = false;
+            if (fullFrameCheaper && c.evaluationsSinceProbe < 32) {
                 takeFullFrame = true;
                 ++c.evaluationsSinceProbe;
             } else {
+                c.probing = fullFrameCheaper;   // the 33rd such evaluation: the branch is taken to see what it costs now
                 c.evaluationsSinceProbe = 0;
             }
         }
@@ -932,7 +935,7 @@ void ProgressivePhotonTracerCL::process() {  // progressivephotontracercl.cpp:21
         recomputedPhotonIndices_->takenInPlaceOfBranch = false;
         if (fused) {
             lastDecision_ = "importance branch";
-            span_.begin(rt.stream(), &costs_.branchTraceMs());
+            span_.begin(rt.stream(), &costs_.branchTraceMs(), costs_.probing);
             auto grid = std::dynamic_pointer_cast<ImportanceUniformGrid3D>(recomputationImportanceGrid_.getData());
             if (!grid) { LogError("UniformGrid3DInport require ImportanceUniformGrid3D as input"); return; }
             const size_t N = photonData_->getNumberOfPhotons();
@@ -1158,7 +1161,7 @@ void PhotonToLightVolumeProcessorCL::process() {  // photontolightvolumeprocesso
     // GPU after it (8 - 10 us of every update).
     bool deltaEnqueued = false;
     if (haveIdx && rec->countPending && useReplaced && !fresh && maxRecomputationPhotons > 0) {
-        if (rec->costs) span_.begin(rt.stream(), &rec->costs->branchLightVolumeMs());
+        if (rec->costs) span_.begin(rt.stream(), &rec->costs->branchLightVolumeMs(), rec->costs->probing);
         uint8_t* mask = nullptr;
         if (comm_) {  // multi-GPU: the bricks an old or new position touches, marked by the same launch
             const size_t nb = ((outDim.x + 3) / 4) * ((outDim.y + 3) / 4) * ((outDim.z + 3) / 4);
@@ -1187,7 +1190,7 @@ void PhotonToLightVolumeProcessorCL::process() {  // photontolightvolumeprocesso
     bool marksDone = false;      // brickMask_ already holds the old AND new positions' bricks
     // what this evaluation costs on the GPU's timeline, filed under the way the tracer served the change (PathCosts)
     if (haveIdx && nRecomputed != 0 && rec->costs && !deltaEnqueued)  // (with the add-remove enqueued ahead, its span is already open)
-        span_.begin(rt.stream(), (nRecomputed < 0) ? &rec->costs->fullLightVolumeMs : &rec->costs->branchLightVolumeMs());
+        span_.begin(rt.stream(), (nRecomputed < 0) ? &rec->costs->fullLightVolumeMs : &rec->costs->branchLightVolumeMs(), nRecomputed >= 0 && rec->costs->probing);
     if (canAddRemove) {
         partialUpdate = true;
         const unsigned int* idx = rec->indicesToRecomputedPhotons.device();

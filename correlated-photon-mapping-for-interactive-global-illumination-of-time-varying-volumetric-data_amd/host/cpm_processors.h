@@ -50,6 +50,7 @@ struct PathCosts {
     float branchTraceMsBy[kBuckets] = { -2.f, -2.f, -2.f, -2.f }, branchLightVolumeMsBy[kBuckets] = { -2.f, -2.f, -2.f, -2.f };
     int bucket = 0;
     int evaluationsSinceProbe = 0;                            // full frames taken in place of the branch since it was last measured
+    bool probing = false;                                     // this evaluation takes the branch only to re-measure it: its spans are always sampled
     static int bucketOf(float fraction) { return fraction < 0.01f ? 0 : fraction < 0.05f ? 1 : fraction < 0.25f ? 2 : 3; }
     void sawFraction(float fraction) { const int b = bucketOf(fraction); if (b != bucket) { bucket = b; evaluationsSinceProbe = 0; } }
     float& branchTraceMs() { return branchTraceMsBy[bucket]; }
@@ -65,7 +66,10 @@ public:
     ~StreamSpan();
     // records the start; `target` receives the milliseconds once they are known.  A cost that is known is sampled again only
     // every kEvery-th time: an event pair costs the frame ~3 us of its 70 on the GPU's timeline
-    void begin(hipStream_t s, float* target);
+    // (the count of skipped samples is kept PER TARGET -- a span serves several costs, and the rarely taken path's probes, every 33rd
+    // evaluation under the adaptive policy, must not be thinned by the common path's samples: ADVICE r04 -- and `force` takes the sample
+    // whatever the count: a probe is always measured)
+    void begin(hipStream_t s, float* target, bool force = false);
     static constexpr int kEvery = 16;
     void end(hipStream_t s);
     void poll();                               // non-blocking: stores the elapsed time if the end event has completed
@@ -73,7 +77,7 @@ private:
     hipEvent_t a_ = nullptr, b_ = nullptr;
     float* target_ = nullptr;
     bool pending_ = false, open_ = false;
-    int skipped_ = 0;
+    std::map<const float*, int> skipped_;
 };
 
 // ---- data types (L2) ---------------------------------------------------------------------------
