@@ -318,11 +318,13 @@ def main():
     if args.reduce is not None:
         exchange = {"sparse": "union", "dense": "dense"}[args.reduce]
     root = 0 if args.collective == "reduce" else None
-    if exchange == "auto":
-        exchange = "lists" if (scaling == "strong" and fast and not correlated and root is not None and not args.graph) else "union"
-    if exchange == "lists" and (root is None or correlated or args.graph):
-        raise SystemExit("bench.py: --exchange lists is the full frames' reduce to the display GPU (needs --collective reduce, not config5 / --graph)")
-    shards_kind = args.shards if args.shards != "auto" else ("range" if exchange == "lists" else "tiles")
+    lists_possible = fast and not correlated and root is not None and not args.graph
+    if exchange == "lists" and not lists_possible:
+        raise SystemExit("bench.py: --exchange lists is the full frames' reduce to the display GPU (fast formulation, --collective reduce, not config5 / --graph)")
+    # shards: a fixed photon count (strong) shrinks a rank's compute with N while tile shards keep every rank's brick set the union --
+    # contiguous ranges there (brick sets nearly disjoint: profiles/r05_shard_exchange_bytes_config4.json); a photon count that grows
+    # with N (weak) keeps the balanced tile shards.  exchange = auto: decided below, once a probe frame has counted the bricks.
+    shards_kind = args.shards if args.shards != "auto" else ("range" if (scaling == "strong" and lists_possible and exchange in ("auto", "lists")) else "tiles")
     if shards_kind == "tiles":
         shard = sharding.shard_tiles(n_total, rank, world)
     else:
@@ -452,8 +454,45 @@ def main():
         # the sum of the per-rank grids overlaps the next frame's trace and bin (double-buffered grids,
         # sharding.OverlappedGridReducer); everything outstanding is waited for inside the timed region
         desc = fr.grid if rccl else ((gdim,) * 3, 1)
+        exchange_choice = None
         if use_graph or world == 1:
             exchange = "dense"
+        elif exchange == "auto":
+            # the byte model at set-up (sharding.exchange_model): one probe frame, its lit 4x4x4 bricks counted on every rank and OR-ed over
+            # the ranks (gloo: every rank ends with the same numbers and takes the same decision)
+            exchange = "union"
+            if lists_possible:
+                probe_out = torch.empty_like(fr.light_volume)
+                fr.trace(); fr.bin_fast(); fr.gather_fast(out=probe_out)
+                lit = (sharding.brick_view(probe_out, (gdim,) * 3, 1).reshape(-1, 64) != 0).any(dim=1)
+                own = torch.tensor([int(lit.sum().item())], dtype=torch.int64)
+                dist.all_reduce(own, op=dist.ReduceOp.MAX)
+                um = lit.to(torch.uint8).cpu()
+                dist.all_reduce(um, op=dist.ReduceOp.MAX)
+                model = sharding.exchange_model(int(lit.numel()), 1, world, int(um.sum().item()), int(own.item()), gdim ** 3)
+                exchange = "lists" if model["brick_lists"]["model_us"] < model["union_reduce"]["model_us"] else "union"
+                exchange_choice = {"chosen": exchange, "from": model, "lit_bricks_max_per_rank": int(own.item()), "union_bricks": int(um.sum().item())}
+                del probe_out
+        if exchange == "lists" and rccl:
+            # (send / receive pairs have not run over this communicator yet: a small exchange now, so that a transport that cannot do them
+            # is found here -- every rank then takes the union form -- and not in the middle of the frames)
+            ok = True
+            try:
+                pd = B.default_grid_desc((16, 16, 16), 1)
+                pbr = ctx.bricklist_reduce_create(transport.comm, pd, 0 if root is None else root)
+                pg = torch.full((16 ** 3,), 1.0, dtype=torch.float32, device=ctx.device)
+                with torch.cuda.stream(transport.stream):
+                    pbr.complete(pbr.start(pg))
+                transport.stream.synchronize()
+                ok = bool((pg == float(world)).all().item()) if rank == (0 if root is None else root) else True
+                pbr.close()
+            except Exception as e:  # noqa: BLE001
+                ok = False
+                transport_note = f"brick lists not usable over this transport ({e}): union of bricks instead"
+            if not agree(ok):
+                exchange = "union"
+                if exchange_choice:
+                    exchange_choice["chosen"] = "union (the list exchange's probe failed on some rank)"
         reducer = sharding.OverlappedGridReducer(fr.light_volume, transport, sparse=desc if exchange == "union" else None,
                                                  lists=desc if exchange == "lists" else None, root=0 if root is None else root)
         frame_no = [0]
@@ -894,6 +933,7 @@ def main():
                        "shards": (f"4096-sample lattice tiles dealt round-robin (rank r: tiles t = r mod {world})" if shards_kind == "tiles"
                                   else "contiguous photon ranges (slabs of the light plane)") if world > 1 else "one shard",
                        "exchange": exchange if world > 1 else "none",
+                       "exchange_chosen_by": (exchange_choice if (world > 1 and not correlated and exchange_choice) else "flag / not applicable"),
                        # the transport the reduce really used, and the size RCCL itself reports for the communicator
                        # (cpm_comm_size; 0 = the reduce did not go through the C-ABI's RCCL communicator)
                        "transport": type(transport).__name__,

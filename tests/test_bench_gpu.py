@@ -42,7 +42,7 @@ def test_bench_two_ranks_code_path():
     env = dict(os.environ, MASTER_ADDR="127.0.0.1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", "29533", str(REPO / "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2", "--workload", "config1",
-           "--test-backend", "gloo", "--test-one-device"]
+           "--test-backend", "gloo", "--test-one-device", "--exchange", "union"]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=str(REPO), env=env)
     assert r.returncode == 0, (r.stdout + r.stderr)[-4000:]
     d = _last_json(r.stdout)
@@ -74,6 +74,10 @@ def test_bench_plain_command_starts_its_own_ranks():
     assert KEYS <= set(d) and d["n_gpus"] == 2 and d["value"] > 0
     assert d["config"]["photons_per_frame"] == 131072 and d["config"]["photons_rank0"] == 65536
     assert "tiles" in d["config"]["shards"] and d["config"]["transport"] == "TorchTransport" and d["config"]["rccl_ranks"] == 0
+    # --exchange auto: the byte model decided from a probe frame's brick counts, the same decision on both ranks
+    chosen = d["config"]["exchange_chosen_by"]
+    assert d["config"]["exchange"] in ("union", "lists") and chosen["chosen"] == d["config"]["exchange"]
+    assert set(chosen["from"]) >= {"dense_reduce", "union_reduce", "brick_lists"} and chosen["union_bricks"] >= chosen["lit_bricks_max_per_rank"] > 0
 
 
 def test_bench_strong_scaling_and_exact_formulation():
@@ -111,7 +115,7 @@ def test_bench_two_ranks_through_the_c_abi_reduce():
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", CPM_RCCL_LIBRARY=str(fake_build.build()))
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", "29536", str(REPO / "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "3", "--workload", "config1",
-           "--test-backend", "gloo", "--test-one-device", "--transport", "rccl"]
+           "--test-backend", "gloo", "--test-one-device", "--transport", "rccl", "--exchange", "union"]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=str(REPO), env=env)
     assert r.returncode == 0, (r.stdout + r.stderr)[-4000:]
     d = _last_json(r.stdout)
