@@ -55,17 +55,7 @@ constexpr int kMaxBricks = 8192;              // two LDS words per brick in fast
 // table layout (u32 entries): [0, nb] brick starts (table[nb] = records written) | 4 meta | nb: the non-empty bricks in
 // brick order (the gather's work items: handed to the workgroups round-robin, so that the bricks of a lit face -- every
 // 16th brick of a 128^3 grid -- do not all land on the same few workgroups)
-constexpr int kMetaMaxPow = 0, kMetaRadius = 1, kMetaItems = 2, kMetaParts = 3;
-// A brick's records are summed by ONE workgroup at a time, and a lit volume has few bricks (the workspace's 256 x 256 x 48 light volume:
-// 418 non-empty bricks of 16 x 16 x 8 voxels holding 2.8 M records, up to 12 925 in one): the launch lasted as long as the CU with the
-// two heaviest bricks (69 of the frame's 170 us there; without ANY LDS add 66: tools/ws_variants.sh noadd).  So a brick's records
-// are dealt to `parts` workgroups in equal shares of at most kPartRecords; each sums its share in its LDS tile, parts > 1 store their
-// 64-bit partial tiles, and the one that arrives last adds the others' and rounds.  Integer sums: the result is the unsplit one, bit for bit.
-#ifndef CPM_BRICK_PART
-#define CPM_BRICK_PART 2048
-#endif
-constexpr uint32_t kPartRecords = CPM_BRICK_PART;
-__host__ __device__ inline uint32_t parts_of(uint32_t records) { return records == 0u ? 0u : (records + kPartRecords - 1u) / kPartRecords; }
+constexpr int kMetaMaxPow = 0, kMetaRadius = 1, kMetaItems = 2;
 // accumulators behind every scratch histogram (zero between calls, like the histogram): max |power| bits
 constexpr int kAccMaxPow = 0, kAccWords = 4;
 
@@ -81,8 +71,6 @@ CPM_DEV uint32_t off_meta(const BrickLayout& L) { return (uint32_t)L.nb + 1u; }
 // a tile's list of (brick, run offset) pairs in run_base: a head (the count) + at most one pair per brick
 __host__ __device__ inline size_t pair_stride(const BrickLayout& L) { return (size_t)L.nb + 1u; }
 CPM_DEV uint32_t off_items(const BrickLayout& L) { return (uint32_t)L.nb + 5u; }
-// ... then the launch's work items, one (brick, part) pair per workgroup turn, a brick's parts next to each other (8-byte aligned)
-__host__ __device__ inline uint32_t off_parts(const BrickLayout& L) { return (2u * (uint32_t)L.nb + 5u + 1u) & ~1u; }
 
 __host__ int make_grid_dev_fast(cpm_ctx* ctx, const cpm_grid_desc* g, GridDev& G) {
     if (!g) return set_error(ctx, CPM_ERR_INVALID_ARGUMENT, "grid", "null grid desc");
@@ -165,9 +153,7 @@ __host__ bool brick_reach(const GridDev& G, float radius, BrickLayout& L) {
 }
 __host__ size_t tile_bytes_for(const GridDev& G, const BrickLayout& L) { return (size_t)(G.channels == 4 ? 3 : 1) * (size_t)L.bvox * 8; }
 
-// n_records: the most records a call can file (cpm_fast_record_capacity): every brick has at least one part when it has records
-__host__ size_t max_parts(const BrickLayout& L, size_t n_records) { return (size_t)L.nb + n_records / kPartRecords + 1; }
-__host__ size_t table_entries(const BrickLayout& L, size_t n_records) { return (size_t)off_parts(L) + 2 * max_parts(L, n_records); }
+__host__ size_t table_entries(const BrickLayout& L) { return 2 * (size_t)L.nb + 5; }
 
 CPM_DEV bool is_sentinel(float4 a) { return a.x == kFltMax || a.y == kFltMax || a.z == kFltMax; }
 
@@ -225,38 +211,31 @@ CPM_DEV unsigned long long to_fixed(float v, float S) {
 // workgroup; with `table` (workgroup 0 only) the starts and the total also go to the table.  `counts` is the finished
 // global histogram (every workgroup reads it: nb * 4 bytes of L2 traffic each).
 CPM_DEV void fast_scan(const uint32_t* __restrict__ counts, const BrickLayout& L, uint32_t* __restrict__ s_start,
-                       uint32_t* __restrict__ table, uint32_t* s_c, uint32_t* s_i, uint32_t* s_p) {
+                       uint32_t* __restrict__ table, uint32_t* s_c, uint32_t* s_i) {
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int per = (L.nb + 1023) / 1024;
     const int b0 = min(t * per, L.nb), b1 = min(b0 + per, L.nb);
-    uint32_t c = 0, it = 0, pt = 0;
-    for (int b = b0; b < b1; ++b) { const uint32_t h = counts[b]; s_start[b] = h; c += h; it += h != 0u; pt += parts_of(h); }
-    uint32_t ci = c, ii = it, pi = pt;
+    uint32_t c = 0, it = 0;
+    for (int b = b0; b < b1; ++b) { const uint32_t h = counts[b]; s_start[b] = h; c += h; it += h != 0u; }
+    uint32_t ci = c, ii = it;
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) {
-        const uint32_t oc = __shfl_up(ci, off, 64), oi = __shfl_up(ii, off, 64), op = __shfl_up(pi, off, 64);
-        if (lane >= off) { ci += oc; ii += oi; pi += op; }
+        const uint32_t oc = __shfl_up(ci, off, 64), oi = __shfl_up(ii, off, 64);
+        if (lane >= off) { ci += oc; ii += oi; }
     }
-    if (lane == 63) { s_c[wave] = ci; s_i[wave] = ii; s_p[wave] = pi; }
+    if (lane == 63) { s_c[wave] = ci; s_i[wave] = ii; }
     __syncthreads();
-    uint32_t bc = 0, bi = 0, bp = 0, tc = 0, ti = 0, tp = 0;
+    uint32_t bc = 0, bi = 0, tc = 0, ti = 0;
 #pragma unroll
-    for (int w = 0; w < 16; ++w) { if (w < wave) { bc += s_c[w]; bi += s_i[w]; bp += s_p[w]; } tc += s_c[w]; ti += s_i[w]; tp += s_p[w]; }
-    uint32_t ac = bc + ci - c, ai = bi + ii - it, ap = bp + pi - pt;  // exclusive prefixes of this thread's first brick
+    for (int w = 0; w < 16; ++w) { if (w < wave) { bc += s_c[w]; bi += s_i[w]; } tc += s_c[w]; ti += s_i[w]; }
+    uint32_t ac = bc + ci - c, ai = bi + ii - it;  // exclusive prefixes of this thread's first brick
     for (int b = b0; b < b1; ++b) {
         const uint32_t h = s_start[b];
         s_start[b] = ac;
-        if (table) {
-            table[b] = ac;
-            if (h) {
-                table[off_items(L) + ai++] = (uint32_t)b;
-                uint2* parts = reinterpret_cast<uint2*>(table + off_parts(L));
-                for (uint32_t q = 0, n = parts_of(h); q < n; ++q) parts[ap++] = make_uint2((uint32_t)b, q);
-            }
-        }
+        if (table) { table[b] = ac; if (h) table[off_items(L) + ai++] = (uint32_t)b; }
         ac += h;
     }
-    if (table && t == 0) { table[L.nb] = tc; table[off_meta(L) + kMetaItems] = ti; table[off_meta(L) + kMetaParts] = tp; }
+    if (table && t == 0) { table[L.nb] = tc; table[off_meta(L) + kMetaItems] = ti; }
 }
 
 // bin, launch 1 of 2.  Per workgroup (1024 threads) = per TILE of 4096 photons: the bricks every photon's candidate box
@@ -342,7 +321,7 @@ __global__ __launch_bounds__(1024, 8) void fast_scatter_kernel(const float* __re
     extern __shared__ uint32_t s_lds[];
     uint32_t* s_start = s_lds;         // nb: brick starts
     uint32_t* s_pos = s_lds + L.nb;    // nb: next free position of this tile's run in the brick
-    __shared__ uint32_t s_c[16], s_i[16], s_p[16];
+    __shared__ uint32_t s_c[16], s_i[16];
     const int t = threadIdx.x;
     const float rgx = radius * G.t2i.sx + 1e-3f, rgy = radius * G.t2i.sy + 1e-3f, rgz = radius * G.t2i.sz + 1e-3f;
     const float4* __restrict__ ph = reinterpret_cast<const float4*>(photons);
@@ -381,7 +360,7 @@ __global__ __launch_bounds__(1024, 8) void fast_scatter_kernel(const float* __re
         table[off_meta(L) + kMetaMaxPow] = hist[L.nb + kAccMaxPow];
         table[off_meta(L) + kMetaRadius] = __float_as_uint(radius);
     }
-    fast_scan(hist, L, s_start, blockIdx.x == 0 ? table : nullptr, s_c, s_i, s_p);
+    fast_scan(hist, L, s_start, blockIdx.x == 0 ? table : nullptr, s_c, s_i);
     __syncthreads();
     for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         if (tile != (int)blockIdx.x) load(tile);
@@ -441,16 +420,7 @@ CPM_DEV void brick_record_wide(const GridDev& G, const BrickLayout& L, float4 a,
                 const float d2 = fma_(dz, dz, fma_(dy, dy, dx2[q]));   // the contract's operands: dx * dx, then the two fmas
                 if (sx + q > ex || !(d2 <= r2)) continue;
                 const float w = 0.75f * (1.0f - d2 * inv_r2);
-#ifdef CPM_EXP_NOCONFLICT   // (experiment only: WRONG sums -- every lane of a 16-lane group adds into its own bank pair: what the launch
-                            // would take if the adds met no bank conflict; tools/ws_variants.sh)
-                atomicAdd(reinterpret_cast<unsigned long long*>(tile + (((row + q) & ~15) | (int)(threadIdx.x & 15))), (unsigned long long)(long long)(int)(pk * w));
-#elif defined(CPM_EXP_STORE)      // (experiment only: a plain 8-byte store in place of the atomic)
-                tile[row + q] = (long long)(int)(pk * w);
-#elif defined(CPM_EXP_NOADD)      // (experiment only: the value is formed, nothing goes to the LDS)
-                { const int vq = (int)(pk * w); if (vq == 0x7fffff01) atomicAdd(reinterpret_cast<unsigned long long*>(tile + row + q), 1ull); }
-#else
                 atomicAdd(reinterpret_cast<unsigned long long*>(tile + row + q), (unsigned long long)(long long)(int)(pk * w));
-#endif
                 if (CH == 4) {
                     atomicAdd(reinterpret_cast<unsigned long long*>(tile + plane + row + q), (unsigned long long)(long long)(int)(pkg * w));
                     atomicAdd(reinterpret_cast<unsigned long long*>(tile + 2 * plane + row + q), (unsigned long long)(long long)(int)(pkb * w));
@@ -515,8 +485,7 @@ constexpr int kMaxSubBricks = 512;  // 4x4x4 sub-bricks of a brick (a tile of <=
 template <int MAXC, int CH>
 __global__ __launch_bounds__(kBrickThreads, (CH == 4 ? 4 : CPM_BRICK_WAVES)) void fast_brick_kernel(const float* __restrict__ sorted, const uint32_t* __restrict__ table, GridDev G,
                                                                   BrickLayout L, float radius, float k, int accumulate, float* __restrict__ out,
-                                                                  uint8_t* __restrict__ marks, int repl_arg, uint32_t* __restrict__ arrive,
-                                                                  long long* __restrict__ partials) {
+                                                                  uint8_t* __restrict__ marks, int repl_arg) {
     extern __shared__ long long s_tile[];
     // REPL copies of the brick's tile, lane l adds into copy l mod REPL: neighbouring lanes hold neighbouring photons, whose adds meet in
     // the same voxels -- same-address LDS atomics of one instruction are served one after the other
@@ -525,7 +494,6 @@ __global__ __launch_bounds__(kBrickThreads, (CH == 4 ? 4 : CPM_BRICK_WAVES)) voi
     // leaves a non-zero value, 0 elsewhere -- every byte written: what cpm_allreduce_grid_sparse would otherwise read the whole
     // volume again for
     __shared__ uint8_t s_flag[kMaxSubBricks];
-    __shared__ uint32_t s_arrived;
     const int nbx4 = (G.dx + 3) >> 2, nby4 = (G.dy + 3) >> 2;
     constexpr int CH3 = CH == 4 ? 3 : 1, STRIDE = CH == 4 ? 2 : 1;
     const int t = threadIdx.x;
@@ -559,15 +527,12 @@ __global__ __launch_bounds__(kBrickThreads, (CH == 4 ? 4 : CPM_BRICK_WAVES)) voi
             }
         }
     }
-    // the work items: (brick, part) pairs -- a brick's records dealt in equal shares to its parts -- round-robin over the workgroups
-    const uint32_t n_parts = table[off_meta(L) + kMetaParts];
-    const uint2* __restrict__ work = reinterpret_cast<const uint2*>(table + off_parts(L));
-    for (uint32_t item = blockIdx.x; item < n_parts; item += gridDim.x) {
-        const uint2 bp = work[item];
-        const uint32_t b = bp.x, part = bp.y;
-        const uint32_t jb0 = table[b], jb1 = table[b + 1];
-        const uint32_t parts = parts_of(jb1 - jb0), share = (jb1 - jb0 + parts - 1u) / parts;
-        const uint32_t j0 = jb0 + part * share, j1 = min(jb1, j0 + share);
+    // the bricks with records: the table's list, round-robin over the workgroups
+    const uint32_t n_items = table[off_meta(L) + kMetaItems];
+    const uint32_t* __restrict__ items = table + off_items(L);
+    for (uint32_t item = blockIdx.x; item < n_items; item += gridDim.x) {
+        const uint32_t b = items[item];
+        const uint32_t j0 = table[b], j1 = table[b + 1];
         const int bx = (int)(b % (uint32_t)L.nbx), by = (int)((b / (uint32_t)L.nbx) % (uint32_t)L.nby), bz = (int)(b / (uint32_t)(L.nbx * L.nby));
         const int ox = bx << L.lx, oy = by << L.ly, oz = bz << L.lz;
         // batches of kBrickPer x 1024 records, kBrickPer independent loads per lane; the first batch is requested before the
@@ -603,46 +568,20 @@ __global__ __launch_bounds__(kBrickThreads, (CH == 4 ? 4 : CPM_BRICK_WAVES)) voi
             for (int q = 0; q < kBrickPer; ++q) { a[q] = an[q]; a2[q] = an2[q]; }
         }
         __syncthreads();
-        if (parts > 1u) {
-            // this part's sums (its tile copies added up) -> copy 0 and the part's slot of `partials`; the part that arrives last adds
-            // the others' slots (a brick's parts are consecutive work items: slot = item - part + q) and carries on to the rounding
-            long long* mine = partials + (size_t)item * (size_t)words;
-            for (int w = t; w < words; w += kBrickThreads) {
-                long long sum = s_tile[w];
-                for (int c = 1; c < repl; ++c) sum += s_tile[(size_t)c * words + w];
-                s_tile[w] = sum;
-                mine[w] = sum;
-            }
-            __threadfence();   // (release: the slot before the arrival)
-            __syncthreads();
-            if (t == 0) s_arrived = atomicAdd(&arrive[b], 1u);
-            __syncthreads();
-            if (s_arrived != parts - 1u) continue;   // uniform; the tile is cleared again at the top of the next item
-            if (t == 0) arrive[b] = 0u;              // the counters are all zero again when the launch ends
-            __threadfence();   // (acquire: the other parts' slots)
-            const long long* first = partials + (size_t)(item - part) * (size_t)words;
-            for (uint32_t q = 0; q < parts; ++q) {
-                if (q == part) continue;
-                const long long* other = first + (size_t)q * (size_t)words;
-                for (int w = t; w < words; w += kBrickThreads) s_tile[w] += other[w];
-            }
-            // (every lane reads back only the words it wrote: no barrier needed before the rounding below)
-        }
-        const int copies = parts > 1u ? 1 : repl;
         for (int v = t; v < L.bvox; v += kBrickThreads) {
             const int lx = v & (BX - 1), ly = (v >> L.lx) & (BY - 1), lz = v >> (L.lx + L.ly);
             const int gx = ox + lx, gy = oy + ly, gz = oz + lz;
             if (gx >= G.dx || gy >= G.dy || gz >= G.dz) continue;
             const size_t o = (size_t)gx + (size_t)G.dx * ((size_t)gy + (size_t)G.dy * (size_t)gz);
             long long sum_r = s_tile[v];
-            for (int c = 1; c < copies; ++c) sum_r += s_tile[(size_t)c * words + v];
+            for (int c = 1; c < repl; ++c) sum_r += s_tile[(size_t)c * words + v];
             const float fr = (float)sum_r * invS;
             bool nonzero = fr != 0.f;
             if (CH == 1) {
                 out[o] = accumulate ? out[o] + fr : fr;
             } else {
                 long long sum_g = s_tile[L.bvox + v], sum_b = s_tile[2 * L.bvox + v];
-                for (int c = 1; c < copies; ++c) { sum_g += s_tile[(size_t)c * words + L.bvox + v]; sum_b += s_tile[(size_t)c * words + 2 * L.bvox + v]; }
+                for (int c = 1; c < repl; ++c) { sum_g += s_tile[(size_t)c * words + L.bvox + v]; sum_b += s_tile[(size_t)c * words + 2 * L.bvox + v]; }
                 const float fg = (float)sum_g * invS, fb = (float)sum_b * invS;
                 nonzero = nonzero || fg != 0.f || fb != 0.f;
                 float4* q = reinterpret_cast<float4*>(out) + o;
@@ -694,8 +633,7 @@ size_t cpm_fast_table_entries(const cpm_grid_desc* grid, int n) {
         const int mc[3] = { (w & 1) ? 5 : 1, (w & 2) ? 5 : 1, (w & 4) ? 5 : 1 };
         BrickLayout L;
         brick_shape(grid->dims, L, mc);
-        const size_t e = table_entries(L, (size_t)n * 8u);   // (8: the most bricks a photon is filed under)
-        most = e > most ? e : most;
+        most = table_entries(L) > most ? table_entries(L) : most;
     }
     return most;
 }
@@ -854,30 +792,15 @@ int cpm_gather_fast_marked(cpm_ctx* ctx, const float* sorted_pos_power, const ui
     tile_bytes *= (size_t)repl;
     const float k = kInv4Pi * scale;
     hipStream_t s = (hipStream_t)stream;
-    // the split bricks' scratch: an arrival counter per brick (all zero between launches: the part that arrives last resets its brick's)
-    // and a slot of 64-bit partial sums per work item (room for the most parts the table can hold)
-    const size_t counters_bytes = ((size_t)L.nb * 4 + 255) & ~(size_t)255;
-    const size_t slot_words = (size_t)(G.channels == 4 ? 3 : 1) * (size_t)L.bvox;
-    const size_t parts_room = max_parts(L, (size_t)n * (size_t)copies_per_photon(L));
-    const size_t need = counters_bytes + parts_room * slot_words * 8;
-    const bool had = ctx->scratch_bytes[CPM_SCR_FAST_SLABS] >= need;
-    unsigned char* sc = (unsigned char*)scratch(ctx, CPM_SCR_FAST_SLABS, need);
-    if (!sc) return CPM_ERR_OUT_OF_MEMORY;
-    if (!had || ctx->fast_parts_counters != counters_bytes) {
-        CPM_HIP_CHECK(ctx, hipMemsetAsync(sc, 0, counters_bytes, s));
-        ctx->fast_parts_counters = counters_bytes;
-    }
-    uint32_t* arrive = reinterpret_cast<uint32_t*>(sc);
-    long long* partials = reinterpret_cast<long long*>(sc + counters_bytes);
-    // resident workgroups: two of 1024 threads per CU
+    // resident workgroups: two of 1024 threads per CU, fewer when there are fewer bricks
     const size_t resident = (size_t)CPM_BRICK_WG_PER_CU * (size_t)ctx->num_cus;
-    const dim3 bgrid((unsigned)resident);
+    const dim3 bgrid((unsigned)((size_t)L.nb < resident ? (size_t)L.nb : resident));
 #define CPM_BRICK_LAUNCH(MAXC, CH)                                                                                       \
     do {                                                                                                                 \
         rc = allow_lds(ctx, fast_brick_kernel<MAXC, CH>, tile_bytes);                                                    \
         if (rc) return rc;                                                                                               \
         CPM_LAUNCH(ctx, (fast_brick_kernel<MAXC, CH>), bgrid, dim3(kBrickThreads), tile_bytes, s, sorted_pos_power, brick_table, G, L,  \
-                   radius, k, accumulate, grid_out, nonzero_bricks, repl, arrive, partials);                             \
+                   radius, k, accumulate, grid_out, nonzero_bricks, repl);                                               \
     } while (0)
     // the wide variants by the box's width along x (what their inner loop is unrolled for): 14 = 4, 6, 8
     const int wide = L.mcx <= 4 ? 14 : (L.mcx <= 6 ? 6 : 8);
