@@ -309,16 +309,15 @@ CPM_DEV void walk_init(const TraceArgs& A, const float* lut, float4 l0, float4 l
     }
 }
 
-// one turn of photontracer.cl:158-197; call while S.scatterEvent
-template <int DT, bool SINGLE, int AHEAD, bool LINEAR = false>
-CPM_DEV void walk_segment(const TraceArgs& A, const float* lut, const float* luts, int threadId, unsigned& steps, WalkState& S) {
+// What follows a Woodcock walk that ended at t with the accepted step's sample and alpha (photontracer.cl:161-196): the collision
+// point, the power division, the decision to scatter on, the record, and -- when scattering -- the new direction, its encoding and
+// the slab test.  S.scatterEvent says whether another walk follows.
+template <bool SINGLE>
+CPM_DEV void walk_interact(const TraceArgs& A, const float* lut, const float* luts, int threadId, float t, float volumeSample, float colorW, WalkState& S) {
     const int photonOffset = A.p.photon_offset;
     const uint32_t maxInteractions = SINGLE ? 1u : (uint32_t)A.p.max_interactions;
     const size_t totalPhotons = (size_t)A.p.total_photons;
     const float wf = A.tf_wf, m1 = A.tf_m1, m2 = A.tf_m2;
-    float volumeSample = 0.f, colorW = 0.f;
-    float t = AHEAD > 1 ? woodcock_ahead<DT, (AHEAD > 1 ? AHEAD : 2), LINEAR>(A.vol, lut, wf, m1, m2, S.origin, S.direction, S.tStart, S.tEnd, S.rx, S.rc, steps, volumeSample, colorW)
-                        : woodcock<DT, LINEAR>(A.vol, lut, wf, m1, m2, S.origin, S.direction, S.tStart, S.tEnd, S.rx, S.rc, steps, volumeSample, colorW);
     S.scatterEvent = t <= S.tEnd;
     if (S.scatterEvent) {
         S.origin.x = fma_(t, S.direction.x, S.origin.x);
@@ -354,6 +353,16 @@ CPM_DEV void walk_segment(const TraceArgs& A, const float* lut, const float* lut
             S.scatterEvent = false;
         }
     }
+}
+
+// one turn of photontracer.cl:158-197; call while S.scatterEvent
+template <int DT, bool SINGLE, int AHEAD, bool LINEAR = false>
+CPM_DEV void walk_segment(const TraceArgs& A, const float* lut, const float* luts, int threadId, unsigned& steps, WalkState& S) {
+    const float wf = A.tf_wf, m1 = A.tf_m1, m2 = A.tf_m2;
+    float volumeSample = 0.f, colorW = 0.f;
+    float t = AHEAD > 1 ? woodcock_ahead<DT, (AHEAD > 1 ? AHEAD : 2), LINEAR>(A.vol, lut, wf, m1, m2, S.origin, S.direction, S.tStart, S.tEnd, S.rx, S.rc, steps, volumeSample, colorW)
+                        : woodcock<DT, LINEAR>(A.vol, lut, wf, m1, m2, S.origin, S.direction, S.tStart, S.tEnd, S.rx, S.rc, steps, volumeSample, colorW);
+    walk_interact<SINGLE>(A, lut, luts, threadId, t, volumeSample, colorW, S);
 }
 
 template <bool SINGLE>
