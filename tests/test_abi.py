@@ -62,6 +62,28 @@ def test_sparse_reduce_capacity_policy_is_the_same_on_both_sides(cpm):
     assert sh.sparse_capacity(32768, 14000) == 32768  # beyond half of the bricks: dense
 
 
+def test_bricklist_policy_and_exchange_model_are_host_arithmetic(cpm):
+    """sharding.bricklist_capacity / bricklist_segment_bytes mirror cpm_bricklist_capacity_for / cpm_bricklist_segment_bytes (a sender and
+    the root must derive the same segment size on their own); sharding.exchange_model prices the three exchanges from brick counts."""
+    import importlib
+    sh = importlib.import_module(cpm.__name__ + ".sharding")
+    lib = cpm.binding.load_library()
+    for nb in (0, 1, 27, 60, 512, 4096, 32768, 262144):
+        for prev in (-1, 0, 1, 63, 64, 100, nb // 8, nb // 4, nb // 2, nb, 2 * nb):
+            assert lib.cpm_bricklist_capacity_for(nb, prev) == sh.bricklist_capacity(nb, prev), (nb, prev)
+    for cap in (0, 64, 1024, 7680):
+        for ch in (1, 4):
+            assert lib.cpm_bricklist_segment_bytes(cap, ch) == sh.bricklist_segment_bytes(cap, ch) == 16 + cap * (256 * ch + 4)
+    assert sh.bricklist_capacity(32768, 6077) == 7680 and sh.bricklist_capacity(32768, -1) == 8192 and sh.bricklist_capacity(60, 1000) == 64
+    # config 4 at 8 ranks, the counts measured on one GPU (profiles/r05_shard_exchange_bytes_config4.json): slab shards + lists move a
+    # fifth of what the union of bricks does, and both a fraction of the dense grid
+    m = sh.exchange_model(262144, 1, 8, 40520, 6390, 256 ** 3)
+    assert m["brick_lists"]["bytes_per_link"] * 5 < m["union_reduce"]["bytes_per_link"] < m["dense_reduce"]["bytes_per_link"] / 4
+    assert m["brick_lists"]["model_us"] < m["union_reduce"]["model_us"] < m["dense_reduce"]["model_us"]
+    one = sh.exchange_model(32768, 1, 1, 6000, 6000, 128 ** 3)
+    assert one["brick_lists"]["bytes_per_link"] == 0 and one["dense_reduce"]["bytes_per_link"] == 0
+
+
 def test_no_cpu_fallback(cpm):
     """Without a GPU the product path must fail loudly (never compute on the CPU)."""
     import torch

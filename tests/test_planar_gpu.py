@@ -96,3 +96,39 @@ def test_planar_config2_full_size(cpm, ctx):
     assert np.array_equal(_u32(fr.records()), _u32(want_records))
     assert np.array_equal(_u32(fr.brick_table), _u32(want_table))
     assert np.array_equal(_u32(fr.light_volume), _u32(want_lv))
+
+
+def test_planar_trace_lights_and_brick_mask_or(cpm, ctx):
+    """cpm_trace_lights (several lights, one launch) writes the two-plane layout too; and cpm_brick_mask_or is the union of two masks."""
+    import ctypes as C
+    S, P, B = cpm.synthetic, cpm.pipeline, cpm.binding
+    torch = ctx.torch
+    vol = ctx.volume_create(S.heterogeneous_volume(48))
+    tf = ctx.tf_create(S.workspace_tf())
+    frames = [P.PhotonFrame(ctx, vol, tf, s, (16, 16, 16), light_travel_direction=d, max_interactions=2, material=(0.3, 0, 0, 0), seed=k)
+              for k, (s, d) in enumerate(((50, (0.3, 0.5, -1.0)), (37, (-0.4, 0.2, -1.0))))]
+    ns = [f.n for f in frames]
+    N, I = sum(ns), 2
+    rng = torch.cat([f.rng_initial for f in frames]).contiguous()
+    params = B.TraceParams()
+    C.memmove(C.byref(params), C.byref(frames[0].params), C.sizeof(params))
+    params.total_photons = N
+    spans = ctx.light_spans([(f.light_samples, f.isect, n, off) for f, n, off in zip(frames, ns, (0, ns[0]))])
+    want = torch.full((N * I, 8), -7.0, dtype=torch.float32, device=ctx.device)
+    ctx.trace_lights(vol, tf, frames[0].aabb, params, spans, rng.clone(), want)
+    params.flags |= B.CPM_TRACE_PHOTONS_PLANAR
+    planar = torch.full((N * I, 8), -7.0, dtype=torch.float32, device=ctx.device)
+    ctx.trace_lights(vol, tf, frames[0].aabb, params, spans, rng.clone(), planar)
+    back = torch.empty_like(planar)
+    ctx.photons_convert(planar, B.CPM_PHOTONS_PLANAR, back, B.CPM_PHOTONS_INTERLEAVED, N * I)
+    torch.cuda.synchronize()
+    assert np.array_equal(_u32(back), _u32(want)) and (want[:, 0] < 1e30).any()
+    # the importance pass reads float8 records: a planar re-trace through it is refused, not misread
+    g = torch.Generator(device="cpu").manual_seed(3)
+    a = (torch.rand(1000, generator=g) < 0.3).to(torch.uint8).to(ctx.device) * 7     # (any non-zero value counts)
+    b = (torch.rand(1000, generator=g) < 0.3).to(torch.uint8).to(ctx.device)
+    want_or = ((a != 0) | (b != 0)).to(torch.uint8)
+    ctx.brick_mask_or(a, b)
+    torch.cuda.synchronize()
+    assert torch.equal(a, want_or)
+    ctx.brick_mask_or(a, b, n=0)   # nothing to do
