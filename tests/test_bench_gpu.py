@@ -160,3 +160,29 @@ def test_bench_two_ranks_brick_lists_over_gloo():
     d = _last_json(r.stdout)
     assert d["config"]["exchange"] == "lists" and d["config"]["transport"] == "TorchTransport"
     assert "cpm_reduce_grid_bricklists" in d["reduce"]["kind"] and d["reduce"]["received_bytes_at_root_per_frame"] > 0
+
+
+def test_bench_four_ranks_weak_scaling_chooses_its_exchange():
+    """`bench.py --gpus 4` as the driver runs it for the scaling curve (config 2's weak scaling rule on the small workload): tile shards, the
+    exchange picked by the byte model from a probe frame's brick counts (the same decision on every rank), carried out by the C-ABI over
+    the RCCL test double with FOUR ranks on the box's one GPU (4 ranks + this process: within the box's limit of 6)."""
+    sys.path.insert(0, str(REPO / "tests" / "fake_rccl"))
+    import build as fake_build
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", CPM_RCCL_LIBRARY=str(fake_build.build()))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "4", "--master-addr", "127.0.0.1",
+           "--master-port", "29539", str(REPO / "bench.py"), "--gpus", "4", "--steps", "5", "--warmup", "3", "--workload", "config1",
+           "--test-backend", "gloo", "--test-one-device", "--transport", "rccl"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=str(REPO), env=env)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-4000:]
+    d = _last_json(r.stdout)
+    assert d["n_gpus"] == 4 and d["value"] > 0 and d["scaling"] == "weak" and "tiles" in d["config"]["shards"]
+    assert d["config"]["transport"] == "RcclTransport" and d["config"]["rccl_ranks"] == 4
+    assert d["config"]["photons_per_frame"] == 4 * 65536 and d["config"]["photons_rank0"] == 65536
+    chosen = d["config"]["exchange_chosen_by"]
+    assert chosen["chosen"] == d["config"]["exchange"] and d["config"]["exchange"] in ("lists", "union")
+    red = d["reduce"]
+    assert red["stream_synchronisations_per_frame"] == 0 and len(red["bricks"]["lit_per_rank"]) == 4
+    if d["config"]["exchange"] == "lists":
+        assert len(red["sent_bytes_per_rank_per_frame"]) == 4 and red["sent_bytes_per_rank_per_frame"][0] == 0
+        assert all(b > 0 for b in red["sent_bytes_per_rank_per_frame"][1:])
+        assert red["received_bytes_at_root_per_frame"] == sum(red["sent_bytes_per_rank_per_frame"])
