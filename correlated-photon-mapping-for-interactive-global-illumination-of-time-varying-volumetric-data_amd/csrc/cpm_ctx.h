@@ -48,7 +48,8 @@ struct cpm_ctx {
     } dbg;
     struct cpm_trace_order* trace_order = nullptr;  // cpm_trace_set_order (not owned)
     bool trace_order_measure = false;               // ... and whether the launches add their costs to it
-    size_t fast_hist_words = 0;  // cpm_bin_fast: size of the counters whose all-zero state is established (0 = none)
+    size_t fast_hist_words = 0;  // cpm_bin_fast: size of the histograms whose all-zero state is established (0 = none)
+    int fast_hist_parity = 0;    // which of the two (histogram, cursors) pairs the next cpm_bin_fast uses
     const void* fast_last_table = nullptr;  // the last cpm_bin_fast's table and radius: cpm_gather_fast refuses another radius for it
     float fast_last_radius = 0.f;
     // cpm_tf_update from host memory: the LUT goes through a ring of pinned host slots the upload kernel reads directly --
@@ -69,7 +70,7 @@ enum {
     CPM_SCR_BIN_KEYS = 3,    // cell keys of cpm_bin
     CPM_SCR_SMALL = 4,       // TF points etc.
     CPM_SCR_MISC = 5,
-    CPM_SCR_FAST_BIN = 6,    // cpm_bin_fast: per brick a 64-bit (runs, records) counter + accumulators, zero between calls
+    CPM_SCR_FAST_BIN = 6,    // cpm_bin_fast: two (brick histogram, cursors) pairs, used in turn, zeroed by the call before
     CPM_SCR_FAST_SLABS = 7   // (unused since the one-launch gather)
 };
 

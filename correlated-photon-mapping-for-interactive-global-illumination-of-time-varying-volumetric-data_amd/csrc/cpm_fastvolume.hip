@@ -7,17 +7,16 @@
 // reference's own sum order is undefined -- CAS float atomics, :15-29 -- so only a tolerance is defined anyway).
 // The bit-exact per-voxel sequential contract stays in cpm_bin / cpm_gather (cpm_lightvolume.hip).
 //
-// How (two short launches):
-//   bin    fast_bin_kernel      ONE pass (round 5; count + scatter launches before).  Per workgroup = per TILE of 4096 photons, kept in
-//                               registers: photon -> the bricks (8x8x16 voxels; bigger for grids beyond 8 Ki bricks) its candidate
-//                               voxels lie in: its own brick, and a neighbour's when the candidate box straddles a face (0.3 % of
-//                               the photons at config 2; at most 8 bricks); histogram in LDS; the tile's copies form one RUN per
-//                               brick, laid out one after the other inside the tile's own block of the record buffer (an LDS scan:
-//                               no global prefix is needed, so no second launch); ONE returning global atomic per non-empty
-//                               (tile, brick) hands the run its slot in that brick's run list -- (position, length) -- and counts
-//                               the brick's records; then an LDS cursor per brick places the compact 16-byte (pos, power) records.
-//                               The workgroup that finishes last copies the counters into the table (records and runs per brick, the
-//                               list of non-empty bricks, max |power|, the radius) and leaves them zero for the next call.
+// How (three short launches):
+//   bin    fast_count_kernel    photon -> the bricks (8x8x16 voxels; bigger for grids beyond 8 Ki bricks) its candidate
+//                               voxels lie in: its own brick, and a neighbour's when the candidate box straddles a
+//                               face (0.3 % of the photons at config 2, where r is half a cell; at most 8 bricks).
+//                               Per tile of 4096 photons: histogram in LDS, ONE returning global atomic per non-empty
+//                               brick = the offset of the tile's run inside that brick (run_base[tile][brick]).
+//          fast_scatter_kernel  every workgroup scans the finished histogram into brick starts (LDS, while its photon
+//                               loads are in flight); position of a copy = start + run offset + an LDS counter; a
+//                               compact 16-byte (pos, power) record per (photon, brick) copy.  Workgroup 0 also writes
+//                               the table: brick starts, the list of non-empty bricks, max |power|, the radius.
 //   gather fast_brick_kernel    a brick's voxels receive from exactly the records filed under that brick, so a
 //                               workgroup sums a brick on its own: lanes own records, the brick is an LDS tile of
 //                               64-bit FIXED-POINT sums (ds_add_u64) -- integer addition is associative, so the result
@@ -25,8 +24,6 @@
 //                               ordering protocol at all -- then ONE rounding to float and a coalesced store of the
 //                               brick (zeros for a brick nothing reaches).  No halos, no slabs, no second launch:
 //                               what the records' duplication buys.
-//                               (a brick's records lie in its runs: the gather maps a record number to (run, offset) by a search in
-//                               the brick's run lengths, scanned in LDS.)
 // No global float atomics, no sort passes, no per-voxel ordering.
 #include "cpm_ctx.h"
 
@@ -49,19 +46,18 @@ namespace {
 #endif
 constexpr int kBrickThreads = CPM_BRICK_THREADS;
 constexpr int kBrickPer = CPM_BRICK_PER;      // records per lane and batch of fast_brick_kernel
-constexpr int kBinItems = CPM_COUNT_ITEMS;    // photons per thread of fast_bin_kernel (1024 threads)
-constexpr int kBinTile = 1024 * kBinItems;    // ... = a tile: 4096 photons (the tracer's XCD tile)
-constexpr int kMaxBricks = 8192;              // two LDS words per brick in fast_bin_kernel: 64 KiB
-constexpr int kRunChunk = 1024;               // runs of a brick the gather takes at a time (one per lane; their lengths scanned in LDS)
+constexpr int kCountItems = CPM_COUNT_ITEMS;  // photons per thread of fast_count_kernel (1024 threads)
+constexpr int kCountTile = 1024 * kCountItems;
+constexpr int kScatterItems = kCountItems;    // the two launches share the tile decomposition (run_base rows)
+constexpr int kScatterTile = 1024 * kScatterItems;
+constexpr int kMaxBricks = 8192;              // two LDS words per brick in fast_scatter_kernel: 64 KiB
 
-// table layout (u32 entries): [0, nb) records per brick, [nb] records in all | 4 meta | nb: the non-empty bricks in
+// table layout (u32 entries): [0, nb] brick starts (table[nb] = records written) | 4 meta | nb: the non-empty bricks in
 // brick order (the gather's work items: handed to the workgroups round-robin, so that the bricks of a lit face -- every
-// 16th brick of a 128^3 grid -- do not all land on the same few workgroups) | nb: runs per brick | runs: per brick room for one
-// (position, length) pair per tile of the call (a tile files at most one run under a brick)
-constexpr int kMetaMaxPow = 0, kMetaRadius = 1, kMetaItems = 2, kMetaTiles = 3;
-// scratch of the bin (zero between calls: the workgroup that finishes last resets it): per brick a 64-bit counter (runs << 32 |
-// records), then these words
-constexpr int kAccMaxPow = 0, kAccDone = 1, kAccWords = 4;
+// 16th brick of a 128^3 grid -- do not all land on the same few workgroups)
+constexpr int kMetaMaxPow = 0, kMetaRadius = 1, kMetaItems = 2;
+// accumulators behind every scratch histogram (zero between calls, like the histogram): max |power| bits
+constexpr int kAccMaxPow = 0, kAccWords = 4;
 
 struct BrickLayout {
     int lx, ly, lz;         // log2 brick size (voxels)
@@ -72,9 +68,9 @@ struct BrickLayout {
                             // voxels) has a box of 6 x 6 x 2 candidates
 };
 CPM_DEV uint32_t off_meta(const BrickLayout& L) { return (uint32_t)L.nb + 1u; }
+// a tile's list of (brick, run offset) pairs in run_base: a head (the count) + at most one pair per brick
+__host__ __device__ inline size_t pair_stride(const BrickLayout& L) { return (size_t)L.nb + 1u; }
 CPM_DEV uint32_t off_items(const BrickLayout& L) { return (uint32_t)L.nb + 5u; }
-CPM_DEV uint32_t off_nruns(const BrickLayout& L) { return 2u * (uint32_t)L.nb + 5u; }
-__host__ __device__ inline size_t off_runs(const BrickLayout& L) { return (3 * (size_t)L.nb + 5 + 1) & ~(size_t)1; }   // (8-byte aligned pairs)
 
 __host__ int make_grid_dev_fast(cpm_ctx* ctx, const cpm_grid_desc* g, GridDev& G) {
     if (!g) return set_error(ctx, CPM_ERR_INVALID_ARGUMENT, "grid", "null grid desc");
@@ -157,8 +153,7 @@ __host__ bool brick_reach(const GridDev& G, float radius, BrickLayout& L) {
 }
 __host__ size_t tile_bytes_for(const GridDev& G, const BrickLayout& L) { return (size_t)(G.channels == 4 ? 3 : 1) * (size_t)L.bvox * 8; }
 
-__host__ size_t tiles_of(size_t n) { return n > 0 ? (n + kBinTile - 1) / kBinTile : 1; }
-__host__ size_t table_entries(const BrickLayout& L, size_t n) { return off_runs(L) + 2 * (size_t)L.nb * tiles_of(n); }
+__host__ size_t table_entries(const BrickLayout& L) { return 2 * (size_t)L.nb + 5; }
 
 CPM_DEV bool is_sentinel(float4 a) { return a.x == kFltMax || a.y == kFltMax || a.z == kFltMax; }
 
@@ -212,70 +207,65 @@ CPM_DEV unsigned long long to_fixed(float v, float S) {
     return (unsigned long long)(long long)q;
 }
 
-// An exclusive scan over the workgroup's 1024 threads of up to three per-thread sums at once (wave shuffles + 16 wave totals in
-// LDS); `total` receives the workgroup's sums.  Contains a barrier.
-struct Scan3 { uint32_t a, b, c; };
-CPM_DEV Scan3 block_exclusive_scan3(Scan3 mine, uint32_t* s_w /* 48 words */, Scan3& total) {
+// Exclusive scan of the brick counts (-> brick starts, left in LDS for the caller's scatter) by one 1024-thread
+// workgroup; with `table` (workgroup 0 only) the starts and the total also go to the table.  `counts` is the finished
+// global histogram (every workgroup reads it: nb * 4 bytes of L2 traffic each).
+CPM_DEV void fast_scan(const uint32_t* __restrict__ counts, const BrickLayout& L, uint32_t* __restrict__ s_start,
+                       uint32_t* __restrict__ table, uint32_t* s_c, uint32_t* s_i) {
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    Scan3 inc = mine;
+    const int per = (L.nb + 1023) / 1024;
+    const int b0 = min(t * per, L.nb), b1 = min(b0 + per, L.nb);
+    uint32_t c = 0, it = 0;
+    for (int b = b0; b < b1; ++b) { const uint32_t h = counts[b]; s_start[b] = h; c += h; it += h != 0u; }
+    uint32_t ci = c, ii = it;
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) {
-        const uint32_t oa = __shfl_up(inc.a, off, 64), ob = __shfl_up(inc.b, off, 64), oc = __shfl_up(inc.c, off, 64);
-        if (lane >= off) { inc.a += oa; inc.b += ob; inc.c += oc; }
+        const uint32_t oc = __shfl_up(ci, off, 64), oi = __shfl_up(ii, off, 64);
+        if (lane >= off) { ci += oc; ii += oi; }
     }
-    if (lane == 63) { s_w[wave] = inc.a; s_w[16 + wave] = inc.b; s_w[32 + wave] = inc.c; }
+    if (lane == 63) { s_c[wave] = ci; s_i[wave] = ii; }
     __syncthreads();
-    Scan3 before = { 0u, 0u, 0u };
-    total = { 0u, 0u, 0u };
+    uint32_t bc = 0, bi = 0, tc = 0, ti = 0;
 #pragma unroll
-    for (int w = 0; w < 16; ++w) {
-        const uint32_t wa = s_w[w], wb = s_w[16 + w], wc = s_w[32 + w];
-        if (w < wave) { before.a += wa; before.b += wb; before.c += wc; }
-        total.a += wa; total.b += wb; total.c += wc;
+    for (int w = 0; w < 16; ++w) { if (w < wave) { bc += s_c[w]; bi += s_i[w]; } tc += s_c[w]; ti += s_i[w]; }
+    uint32_t ac = bc + ci - c, ai = bi + ii - it;  // exclusive prefixes of this thread's first brick
+    for (int b = b0; b < b1; ++b) {
+        const uint32_t h = s_start[b];
+        s_start[b] = ac;
+        if (table) { table[b] = ac; if (h) table[off_items(L) + ai++] = (uint32_t)b; }
+        ac += h;
     }
-    return { before.a + inc.a - mine.a, before.b + inc.b - mine.b, before.c + inc.c - mine.c };
+    if (table && t == 0) { table[L.nb] = tc; table[off_meta(L) + kMetaItems] = ti; }
 }
 
-// The bin: ONE launch.  A workgroup (1024 threads) = a TILE of 4096 photons, 4 per thread, loaded once and kept in registers.
-//   1. the bricks every photon's candidate box touches, counted in an LDS histogram (max |power| of the stored photons on the way);
-//   2. the tile's copies form one RUN per brick it touches; the runs lie one after the other, in brick order, inside the tile's own
-//      block of the record buffer (block = tile * 4096 * copies-per-photon slots: no global prefix, so nothing to wait for) -- an
-//      exclusive scan of the histogram; ONE returning 64-bit global atomic per non-empty (tile, brick) -- (1 << 32) + count -- gives the
-//      run its slot in the brick's run list and adds the brick's records; the (position, length) pair goes to that slot;
-//   3. an LDS cursor per brick hands out the positions inside the run (an unstable counting sort: the order of the records inside a
-//      brick is irrelevant to integer sums); compact 16-byte records, streaming stores;
-//   4. the workgroup whose ticket is the last one finishes the table from the counters (they are final: every workgroup's atomics
-//      returned before its ticket): records and runs per brick, the list of non-empty bricks, the totals, max |power|, the radius --
-//      and zeroes the counters for the next call.  Other launches never read the counters: what the gather needs is in the table.
+// bin, launch 1 of 2.  Per workgroup (1024 threads) = per TILE of 4096 photons: the bricks every photon's candidate box
+// touches, counted in an LDS histogram; ONE returning global atomic per non-empty brick reserves the tile's run inside that
+// brick -- (brick, offset) goes to the tile's list in run_base (as many pairs as the tile has bricks: a tile's 4 lattice rows
+// reach 100 - 200 of config 4's 8192 bricks; a dense row per tile made the scatter launch read 34 MB of them there), the
+// list's length to its head, for the scatter launch; max |power| of the stored photons on the way.
 template <int CH>
-__global__ __launch_bounds__(1024) void fast_bin_kernel(const float* __restrict__ photons, uint32_t rec_stride, uint32_t rec_b, int n, GridDev G,
-                                                        BrickLayout L, float radius, unsigned long long* __restrict__ counters,
-                                                        uint32_t* __restrict__ acc, uint32_t* __restrict__ table, float* __restrict__ sorted,
-                                                        uint32_t n_tiles, uint32_t copies) {
-    extern __shared__ uint32_t s_lds[];
-    uint32_t* s_hist = s_lds;          // nb: the tile's copies per brick, then (step 2) the run's start inside the tile's block
-    uint32_t* s_pos = s_lds + L.nb;    // nb: next free position of the run
-    __shared__ uint32_t s_w[48];
+__global__ __launch_bounds__(1024) void fast_count_kernel(const float* __restrict__ photons, uint32_t rec_stride, uint32_t rec_b, int n, GridDev G,
+                                                          BrickLayout L, float radius, uint32_t* __restrict__ hist, uint32_t* __restrict__ acc,
+                                                          uint32_t* __restrict__ run_base) {
+    extern __shared__ uint32_t s_hist[];
     __shared__ float s_mp[16];
-    __shared__ uint32_t s_ticket;
+    __shared__ uint32_t s_pairs;
     const int t = threadIdx.x;
     for (int b = t; b < L.nb; b += 1024) s_hist[b] = 0u;
+    if (t == 0) s_pairs = 0u;
     const float rgx = radius * G.t2i.sx + 1e-3f, rgy = radius * G.t2i.sy + 1e-3f, rgz = radius * G.t2i.sz + 1e-3f;
     const float4* __restrict__ ph = reinterpret_cast<const float4*>(photons);
     float mp = 0.f;
-    float4 a[kBinItems], a2[kBinItems];
+    float4 a[kCountItems], a2[kCountItems];
 #pragma unroll
-    for (int k = 0; k < kBinItems; ++k) {  // the loads first, all in flight together
-        const long long i = (long long)blockIdx.x * kBinTile + k * 1024 + t;
+    for (int k = 0; k < kCountItems; ++k) {  // the loads first, all in flight together
+        const long long i = (long long)blockIdx.x * kCountTile + k * 1024 + t;
         a[k] = make_float4(kFltMax, kFltMax, kFltMax, 0.f); a2[k] = make_float4(0.f, 0.f, 0.f, 0.f);
         if (i < n) { a[k] = ph[(size_t)rec_stride * i]; if (CH == 4) a2[k] = ph[(size_t)rec_stride * i + rec_b]; }
     }
     __syncthreads();
-    Box box[kBinItems];
-    bool in[kBinItems];
 #pragma unroll
-    for (int k = 0; k < kBinItems; ++k) {
-        in[k] = false;
+    for (int k = 0; k < kCountItems; ++k) {
         if (is_sentinel(a[k])) continue;
         // (finite powers only, photon by photon: one NaN / inf must not hide its neighbours' maximum)
         const float p0 = __builtin_fabsf(a[k].w);
@@ -285,92 +275,116 @@ __global__ __launch_bounds__(1024) void fast_bin_kernel(const float* __restrict_
             if (p1 <= kFltMax) mp = max_(mp, p1);
             if (p2 <= kFltMax) mp = max_(mp, p2);
         }
-        in[k] = candidate_box(G, a[k], rgx, rgy, rgz, L.mcx, L.mcy, L.mcz, box[k]);
-        if (in[k]) for_each_brick(L, box[k], [&](uint32_t key) { atomicAdd(&s_hist[key], 1u); });
+        Box box;
+        if (candidate_box(G, a[k], rgx, rgy, rgz, L.mcx, L.mcy, L.mcz, box)) for_each_brick(L, box, [&](uint32_t key) { atomicAdd(&s_hist[key], 1u); });
     }
     // max |power| of the workgroup (a finite, non-negative float orders like its bit pattern)
     for (int off = 32; off > 0; off >>= 1) mp = max_(mp, __shfl_xor(mp, off, 64));
     if ((t & 63) == 0) s_mp[t >> 6] = mp;
     __syncthreads();
-    // the runs: every thread owns `per` consecutive bricks
-    const int per = (L.nb + 1023) / 1024;
-    const int b0 = min(t * per, L.nb), b1 = min(b0 + per, L.nb);
-    Scan3 mine = { 0u, 0u, 0u }, total;
-    for (int b = b0; b < b1; ++b) mine.a += s_hist[b];
-    Scan3 ex = block_exclusive_scan3(mine, s_w, total);
-    const uint32_t block_base = blockIdx.x * (uint32_t)kBinTile * copies;   // (n * copies < 2^32: checked by the host)
-    uint2* __restrict__ runs = reinterpret_cast<uint2*>(table + off_runs(L));
-    {
-        uint32_t at = ex.a;
-        for (int b = b0; b < b1; ++b) {
-            const uint32_t c = s_hist[b];
-            s_hist[b] = at; s_pos[b] = at;
-            if (c) {
-                const unsigned long long old = atomicAdd(&counters[b], (1ull << 32) + (unsigned long long)c);
-                const uint32_t slot = (uint32_t)(old >> 32);
-                if (slot < n_tiles) runs[(size_t)b * n_tiles + slot] = make_uint2(block_base + at, c);   // (always: one run per tile and brick)
-            }
-            at += c;
-        }
+    // the runs' places: four bins at a time, the atomics of a group issued together
+    uint2* __restrict__ pairs = reinterpret_cast<uint2*>(run_base) + (size_t)blockIdx.x * (size_t)pair_stride(L);
+    for (int b = t; b < L.nb; b += 4 * 1024) {
+        uint32_t c[4], base[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { const int bb = b + q * 1024; c[q] = bb < L.nb ? s_hist[bb] : 0u; }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { base[q] = 0u; if (c[q]) base[q] = atomicAdd(&hist[b + q * 1024], c[q]); }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) if (c[q]) pairs[1u + atomicAdd(&s_pairs, 1u)] = make_uint2((uint32_t)(b + q * 1024), base[q]);
     }
     __syncthreads();
-    // the records
-#pragma unroll
-    for (int k = 0; k < kBinItems; ++k) {
-        if (!in[k]) continue;
-        for_each_brick(L, box[k], [&](uint32_t key) {
-            const size_t pos = (size_t)block_base + (size_t)atomicAdd(&s_pos[key], 1u);
-            if (CH == 1) {
-                // scattered 16-byte records, read next by another launch: streaming stores
-                typedef float v4 __attribute__((ext_vector_type(4)));
-                const v4 q = { a[k].x, a[k].y, a[k].z, a[k].w };
-                __builtin_nontemporal_store(q, reinterpret_cast<v4*>(sorted) + pos);
-            } else {
-                float4* o = reinterpret_cast<float4*>(sorted) + 2 * pos;
-                o[0] = a[k];
-                o[1] = make_float4(a2[k].x, a2[k].y, 0.f, 0.f);
-            }
-        });
-    }
-    // the ticket: behind this workgroup's atomics (their results were consumed above; the maximum's is consumed here)
+    if (t == 0) pairs[0] = make_uint2(s_pairs, 0u);
+    // one atomic per workgroup at most, and none once the running maximum has reached this workgroup's
     if (t == 0) {
         float m = s_mp[0];
 #pragma unroll
         for (int w = 1; w < 16; ++w) m = max_(m, s_mp[w]);
         const uint32_t mb = __float_as_uint(m);
-        uint32_t seen = 0u;
-        if (m > 0.f) seen = atomicMax(&acc[kAccMaxPow], mb);
-        s_ticket = atomicAdd(&acc[kAccDone], 1u + (seen >> 31));   // (seen >> 31 == 0: a non-negative float's bits; keeps the order)
+        if (m > 0.f && __hip_atomic_load(&acc[kAccMaxPow], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < mb) atomicMax(&acc[kAccMaxPow], mb);
     }
-    __syncthreads();
-    if (s_ticket != gridDim.x - 1u) return;
-    // ---- the last workgroup: counters -> table, counters zeroed
-    Scan3 fin = { 0u, 0u, 0u };
-    for (int b = b0; b < b1; ++b) {
-        const unsigned long long v = __hip_atomic_load(&counters[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const uint32_t recs = (uint32_t)v, nr = (uint32_t)(v >> 32);
-        s_hist[b] = recs; s_pos[b] = nr;
-        fin.a += recs; fin.b += recs != 0u;
-    }
-    Scan3 fex = block_exclusive_scan3(fin, s_w, total);
-    {
-        uint32_t ai = fex.b;
-        for (int b = b0; b < b1; ++b) {
-            const uint32_t recs = s_hist[b];
-            table[b] = recs;
-            table[off_nruns(L) + b] = min(s_pos[b], n_tiles);
-            if (recs) table[off_items(L) + ai++] = (uint32_t)b;
-            counters[b] = 0ull;
+}
+
+// bin, launch 2 of 2.  Every workgroup (1024 threads) first turns the finished histogram into the brick starts -- an
+// exclusive scan of nb <= 8 Ki counts in LDS, while its first photon loads are in flight (the one-workgroup scan launch
+// this replaces took 5.6 us of pure latency) -- then, per tile of 4096 photons: next free position of the tile's run in
+// every brick = brick start + run_base[tile][brick] (a coalesced row read; entries of bricks the tile does not touch are
+// never used), and one LDS atomic per (photon, brick) copy hands out the positions: an unstable counting sort (the order
+// inside a brick is irrelevant to integer sums).  Workgroup 0 also writes the table.  The histogram exists twice and is
+// used in turn: this launch zeroes the OTHER one (idle until the next call), so no memset is needed in steady state and
+// no workgroup has to know when the others have read.  Big inputs: a workgroup walks several tiles, the scan is paid once.
+template <int CH>
+__global__ __launch_bounds__(1024, 8) void fast_scatter_kernel(const float* __restrict__ photons, uint32_t rec_stride, uint32_t rec_b, int n, GridDev G, BrickLayout L, float radius,
+                                                            const uint32_t* __restrict__ hist, const uint32_t* __restrict__ run_base,
+                                                            uint32_t* __restrict__ zero_next, int zero_words,
+                                                            uint32_t* __restrict__ table, float* __restrict__ sorted) {
+    extern __shared__ uint32_t s_lds[];
+    uint32_t* s_start = s_lds;         // nb: brick starts
+    uint32_t* s_pos = s_lds + L.nb;    // nb: next free position of this tile's run in the brick
+    __shared__ uint32_t s_c[16], s_i[16];
+    const int t = threadIdx.x;
+    const float rgx = radius * G.t2i.sx + 1e-3f, rgy = radius * G.t2i.sy + 1e-3f, rgz = radius * G.t2i.sz + 1e-3f;
+    const float4* __restrict__ ph = reinterpret_cast<const float4*>(photons);
+    const int n_tiles = (int)(((long long)n + kScatterTile - 1) / kScatterTile);
+    float4 a[kScatterItems], b2[kScatterItems];
+    // a tile's photons and its list of (brick, run offset) pairs (the first few per lane requested with the photons)
+    constexpr int kPairsAhead = 2;
+    uint2 pr[kPairsAhead];
+    uint32_t n_pairs = 0;
+    auto load = [&](int tile) {
+#pragma unroll
+        for (int k = 0; k < kScatterItems; ++k) {
+            const long long i = (long long)tile * kScatterTile + k * 1024 + t;
+            a[k] = make_float4(kFltMax, kFltMax, kFltMax, 0.f); b2[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (i < n) { a[k] = ph[(size_t)rec_stride * i]; if (CH == 4) b2[k] = ph[(size_t)rec_stride * i + rec_b]; }
         }
-    }
-    if (t == 0) {
-        table[L.nb] = total.a;
-        table[off_meta(L) + kMetaItems] = total.b;
-        table[off_meta(L) + kMetaTiles] = n_tiles;
-        table[off_meta(L) + kMetaMaxPow] = __hip_atomic_load(&acc[kAccMaxPow], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        n_pairs = 0;
+        if (tile < n_tiles) {
+            const uint2* __restrict__ pairs = reinterpret_cast<const uint2*>(run_base) + (size_t)tile * (size_t)pair_stride(L);
+            n_pairs = pairs[0].x;
+#pragma unroll
+            for (int q = 0; q < kPairsAhead; ++q) { const uint32_t j = (uint32_t)(q * 1024 + t); pr[q] = j < n_pairs ? pairs[1u + j] : make_uint2(0u, 0u); }
+        }
+    };
+    // next free position of the tile's run in every brick it has copies in = brick start + run offset (s_pos of other bricks
+    // is never read)
+    auto place = [&](int tile) {
+        const uint2* __restrict__ pairs = reinterpret_cast<const uint2*>(run_base) + (size_t)tile * (size_t)pair_stride(L);
+#pragma unroll
+        for (int q = 0; q < kPairsAhead; ++q) { const uint32_t j = (uint32_t)(q * 1024 + t); if (j < n_pairs) s_pos[pr[q].x] = s_start[pr[q].x] + pr[q].y; }
+        for (uint32_t j = (uint32_t)(kPairsAhead * 1024 + t); j < n_pairs; j += 1024u) { const uint2 p = pairs[1u + j]; s_pos[p.x] = s_start[p.x] + p.y; }
+    };
+    load(blockIdx.x);
+    for (int w = blockIdx.x * 1024 + t; w < zero_words; w += gridDim.x * 1024) zero_next[w] = 0u;
+    if (blockIdx.x == 0 && t == 0) {
+        table[off_meta(L) + kMetaMaxPow] = hist[L.nb + kAccMaxPow];
         table[off_meta(L) + kMetaRadius] = __float_as_uint(radius);
-        acc[kAccMaxPow] = 0u;
-        acc[kAccDone] = 0u;
+    }
+    fast_scan(hist, L, s_start, blockIdx.x == 0 ? table : nullptr, s_c, s_i);
+    __syncthreads();
+    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        if (tile != (int)blockIdx.x) load(tile);
+        place(tile);
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < kScatterItems; ++k) {
+            Box box;
+            if (is_sentinel(a[k]) || !candidate_box(G, a[k], rgx, rgy, rgz, L.mcx, L.mcy, L.mcz, box)) continue;
+            for_each_brick(L, box, [&](uint32_t key) {
+                const size_t pos = (size_t)atomicAdd(&s_pos[key], 1u);
+                if (CH == 1) {
+                    // scattered 16-byte records, read next by another launch: streaming stores
+                    typedef float v4 __attribute__((ext_vector_type(4)));
+                    const v4 q = { a[k].x, a[k].y, a[k].z, a[k].w };
+                    __builtin_nontemporal_store(q, reinterpret_cast<v4*>(sorted) + pos);
+                } else {
+                    float4* o = reinterpret_cast<float4*>(sorted) + 2 * pos;
+                    o[0] = a[k];
+                    o[1] = make_float4(b2[k].x, b2[k].y, 0.f, 0.f);
+                }
+            });
+        }
+        __syncthreads();  // s_pos is rewritten for the next tile
     }
 }
 
@@ -480,8 +494,6 @@ __global__ __launch_bounds__(kBrickThreads, (CH == 4 ? 4 : CPM_BRICK_WAVES)) voi
     // leaves a non-zero value, 0 elsewhere -- every byte written: what cpm_allreduce_grid_sparse would otherwise read the whole
     // volume again for
     __shared__ uint8_t s_flag[kMaxSubBricks];
-    __shared__ uint32_t s_rend[kRunChunk], s_rpos[kRunChunk], s_wtot[16];   // a chunk of the brick's runs: scanned lengths, positions
-    static_assert(kRunChunk == kBrickThreads, "one run per lane");
     const int nbx4 = (G.dx + 3) >> 2, nby4 = (G.dy + 3) >> 2;
     constexpr int CH3 = CH == 4 ? 3 : 1, STRIDE = CH == 4 ? 2 : 1;
     const int t = threadIdx.x;
@@ -500,7 +512,7 @@ __global__ __launch_bounds__(kBrickThreads, (CH == 4 ? 4 : CPM_BRICK_WAVES)) voi
             for (size_t i = ((size_t)blockIdx.x * kBrickThreads + t) * 4; i < cells; i += (size_t)gridDim.x * kBrickThreads * 4) {
                 const int x = (int)(i % (size_t)G.dx), y = (int)((i / (size_t)G.dx) % (size_t)G.dy), z = (int)(i / ((size_t)G.dx * G.dy));
                 const uint32_t b = (uint32_t)(x >> L.lx) + (uint32_t)L.nbx * ((uint32_t)(y >> L.ly) + (uint32_t)L.nby * (uint32_t)(z >> L.lz));
-                if (table[b] == 0u) {
+                if (table[b + 1] == table[b]) {
                     *reinterpret_cast<float4*>(out + i) = make_float4(0.f, 0.f, 0.f, 0.f);
                     if (marks && ((y | z) & 3) == 0) marks[(uint32_t)(x >> 2) + (uint32_t)nbx4 * ((uint32_t)(y >> 2) + (uint32_t)nby4 * (uint32_t)(z >> 2))] = 0;
                 }
@@ -509,7 +521,7 @@ __global__ __launch_bounds__(kBrickThreads, (CH == 4 ? 4 : CPM_BRICK_WAVES)) voi
             for (size_t i = (size_t)blockIdx.x * kBrickThreads + t; i < cells; i += (size_t)gridDim.x * kBrickThreads) {
                 const int x = (int)(i % (size_t)G.dx), y = (int)((i / (size_t)G.dx) % (size_t)G.dy), z = (int)(i / ((size_t)G.dx * G.dy));
                 const uint32_t b = (uint32_t)(x >> L.lx) + (uint32_t)L.nbx * ((uint32_t)(y >> L.ly) + (uint32_t)L.nby * (uint32_t)(z >> L.lz));
-                if (table[b] != 0u) continue;
+                if (table[b + 1] != table[b]) continue;
                 if (CH == 1) out[i] = 0.f; else reinterpret_cast<float4*>(out)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (marks && ((x | y | z) & 3) == 0) marks[(uint32_t)(x >> 2) + (uint32_t)nbx4 * ((uint32_t)(y >> 2) + (uint32_t)nby4 * (uint32_t)(z >> 2))] = 0;
             }
@@ -518,79 +530,42 @@ __global__ __launch_bounds__(kBrickThreads, (CH == 4 ? 4 : CPM_BRICK_WAVES)) voi
     // the bricks with records: the table's list, round-robin over the workgroups
     const uint32_t n_items = table[off_meta(L) + kMetaItems];
     const uint32_t* __restrict__ items = table + off_items(L);
-    const uint32_t n_tiles = table[off_meta(L) + kMetaTiles];
-    const uint2* __restrict__ runs = reinterpret_cast<const uint2*>(table + off_runs(L));
     for (uint32_t item = blockIdx.x; item < n_items; item += gridDim.x) {
         const uint32_t b = items[item];
-        const uint32_t n_runs = table[off_nruns(L) + b];
+        const uint32_t j0 = table[b], j1 = table[b + 1];
         const int bx = (int)(b % (uint32_t)L.nbx), by = (int)((b / (uint32_t)L.nbx) % (uint32_t)L.nby), bz = (int)(b / (uint32_t)(L.nbx * L.nby));
         const int ox = bx << L.lx, oy = by << L.ly, oz = bz << L.lz;
-        // the brick's records lie in its runs (one per tile that reached it), kRunChunk runs at a time: a lane loads one (position,
-        // length) pair, the lengths are scanned in LDS, record number j of the chunk is found by a search in the scanned lengths
-        uint2 my_run = make_uint2(0u, 0u);
-        if ((uint32_t)t < min(n_runs, (uint32_t)kRunChunk)) my_run = runs[(size_t)b * n_tiles + t];
+        // batches of kBrickPer x 1024 records, kBrickPer independent loads per lane; the first batch is requested before the
+        // tile is cleared, every next one while the current one is added
+        float4 a[kBrickPer], a2[kBrickPer], an[kBrickPer], an2[kBrickPer];
+        auto fetch = [&](uint32_t first, float4* x, float4* x2) {
+#pragma unroll
+            for (int q = 0; q < kBrickPer; ++q) {
+                const uint32_t j = first + (uint32_t)(q * kBrickThreads + t);
+                x[q] = make_float4(0.f, 0.f, 0.f, 0.f); x2[q] = x[q];
+                if (j < j1) { x[q] = rec[STRIDE * (size_t)j]; if (CH == 4) x2[q] = rec[2 * (size_t)j + 1]; }
+            }
+        };
+        fetch(j0, a, a2);
         for (int w = t; w < words * repl; w += kBrickThreads) s_tile[w] = 0ll;
         long long* my_tile = s_tile + (size_t)(t & (repl - 1)) * (size_t)words;
         const int nsub = L.bvox >> 6;
         if (marks) for (int w = t; w < nsub; w += kBrickThreads) s_flag[w] = 0;  // (the lane that read flag w for the brick before)
-        for (uint32_t r0 = 0; r0 < n_runs; r0 += (uint32_t)kRunChunk) {  // uniform
-            const uint32_t cnt = min(n_runs - r0, (uint32_t)kRunChunk);
-            if (r0 != 0u) my_run = (uint32_t)t < cnt ? runs[(size_t)b * n_tiles + r0 + t] : make_uint2(0u, 0u);
-            // inclusive scan of the lengths (one per lane): wave shuffles + the 16 wave totals
-            uint32_t inc = my_run.y;
+        __syncthreads();
+        for (uint32_t first = j0; first < j1; first += (uint32_t)(kBrickPer * kBrickThreads)) {  // uniform
+            fetch(first + (uint32_t)(kBrickPer * kBrickThreads), an, an2);
 #pragma unroll
-            for (int off = 1; off < 64; off <<= 1) { const uint32_t o = __shfl_up(inc, off, 64); if ((t & 63) >= off) inc += o; }
-            __syncthreads();   // (the chunk before has been read; also orders the tile's clearing before the first adds)
-            if ((t & 63) == 63) s_wtot[t >> 6] = inc;
-            __syncthreads();
-            uint32_t before = 0u, total = 0u;
-#pragma unroll
-            for (int w = 0; w < 16; ++w) { const uint32_t v = s_wtot[w]; if (w < (t >> 6)) before += v; total += v; }
-            s_rend[t] = before + inc;
-            s_rpos[t] = my_run.x;
-            __syncthreads();
-            int steps = 0;
-            while ((1u << steps) <= cnt) ++steps;   // ceil(log2(cnt + 1)) turns of the search
-            // record j of the chunk -> its position in the record buffer
-            auto locate = [&](uint32_t j) -> size_t {
-                uint32_t lo = 0u, hi = cnt;   // the first run whose scanned end lies beyond j
-                for (int it = 0; it < steps; ++it) {
-                    const uint32_t mid = (lo + hi) >> 1;
-                    const bool right = lo < hi && s_rend[min(mid, cnt - 1u)] <= j;
-                    lo = right ? mid + 1u : lo;
-                    hi = (lo < hi && !right) ? mid : hi;
+            for (int q = 0; q < kBrickPer; ++q) {
+                const uint32_t j = first + (uint32_t)(q * kBrickThreads + t);
+                if (j < j1) {
+                    // MAXC <= 4: a box of at most MAXC^3 candidates, all loops unrolled; MAXC = 6 / 8 / 14 (= x width 4): wide or anisotropic
+                    // boxes -- y and z at run time, x unrolled for 6 / 8 / 4 candidates
+                    if (MAXC > 4) brick_record_wide<CH, (MAXC == 14 ? 4 : MAXC)>(G, L, a[q], a2[q].x, a2[q].y, ox, oy, oz, BX, BY, BZ, rgx, rgy, rgz, r2, inv_r2, k, S, my_tile, L.bvox);
+                    else brick_record<(MAXC > 4 ? 1 : MAXC), CH>(G, a[q], a2[q].x, a2[q].y, ox, oy, oz, BX, BY, BZ, rgx, rgy, rgz, r2, inv_r2, k, S, my_tile, L.bvox);
                 }
-                lo = min(lo, cnt - 1u);
-                const uint32_t start = lo ? s_rend[lo - 1u] : 0u;
-                return (size_t)s_rpos[lo] + (size_t)(j - start);
-            };
-            // batches of kBrickPer x 1024 records, kBrickPer independent loads per lane, the next batch requested while the current
-            // one is added
-            float4 a[kBrickPer], a2[kBrickPer], an[kBrickPer], an2[kBrickPer];
-            auto fetch = [&](uint32_t first, float4* x, float4* x2) {
-#pragma unroll
-                for (int q = 0; q < kBrickPer; ++q) {
-                    const uint32_t j = first + (uint32_t)(q * kBrickThreads + t);
-                    x[q] = make_float4(0.f, 0.f, 0.f, 0.f); x2[q] = x[q];
-                    if (j < total) { const size_t at = locate(j); x[q] = rec[STRIDE * at]; if (CH == 4) x2[q] = rec[2 * at + 1]; }
-                }
-            };
-            fetch(0u, a, a2);
-            for (uint32_t first = 0u; first < total; first += (uint32_t)(kBrickPer * kBrickThreads)) {  // uniform
-                fetch(first + (uint32_t)(kBrickPer * kBrickThreads), an, an2);
-#pragma unroll
-                for (int q = 0; q < kBrickPer; ++q) {
-                    const uint32_t j = first + (uint32_t)(q * kBrickThreads + t);
-                    if (j < total) {
-                        // MAXC <= 4: a box of at most MAXC^3 candidates, all loops unrolled; MAXC = 6 / 8 / 14 (= x width 4): wide or anisotropic
-                        // boxes -- y and z at run time, x unrolled for 6 / 8 / 4 candidates
-                        if (MAXC > 4) brick_record_wide<CH, (MAXC == 14 ? 4 : MAXC)>(G, L, a[q], a2[q].x, a2[q].y, ox, oy, oz, BX, BY, BZ, rgx, rgy, rgz, r2, inv_r2, k, S, my_tile, L.bvox);
-                        else brick_record<(MAXC > 4 ? 1 : MAXC), CH>(G, a[q], a2[q].x, a2[q].y, ox, oy, oz, BX, BY, BZ, rgx, rgy, rgz, r2, inv_r2, k, S, my_tile, L.bvox);
-                    }
-                }
-#pragma unroll
-                for (int q = 0; q < kBrickPer; ++q) { a[q] = an[q]; a2[q] = an2[q]; }
             }
+#pragma unroll
+            for (int q = 0; q < kBrickPer; ++q) { a[q] = an[q]; a2[q] = an2[q]; }
         }
         __syncthreads();
         for (int v = t; v < L.bvox; v += kBrickThreads) {
@@ -658,8 +633,7 @@ size_t cpm_fast_table_entries(const cpm_grid_desc* grid, int n) {
         const int mc[3] = { (w & 1) ? 5 : 1, (w & 2) ? 5 : 1, (w & 4) ? 5 : 1 };
         BrickLayout L;
         brick_shape(grid->dims, L, mc);
-        const size_t e = table_entries(L, (size_t)n);
-        most = e > most ? e : most;
+        most = table_entries(L) > most ? table_entries(L) : most;
     }
     return most;
 }
@@ -685,8 +659,7 @@ size_t cpm_fast_record_capacity(const cpm_grid_desc* grid, int n, float radius) 
     BrickLayout L;
     brick_shape_for(G, radius, L);
     (void)brick_reach(G, radius, L);
-    // (every tile of 4096 photons files its records into its own block of the buffer: whole tiles)
-    return tiles_of((size_t)n) * (size_t)kBinTile * (size_t)copies_per_photon(L);
+    return (size_t)n * (size_t)copies_per_photon(L);
 }
 
 int cpm_bin_fast(cpm_ctx* ctx, const float* photons8, int n, const cpm_grid_desc* grid, float radius, uint32_t* brick_table,
@@ -713,32 +686,51 @@ int cpm_bin_fast_layout(cpm_ctx* ctx, const float* photons8, int layout, int n, 
     brick_shape_for(G, radius, L);
     if (!brick_reach(G, radius, L) || tile_bytes_for(G, L) > 160 * 1024 - 1024)
         return set_error(ctx, CPM_ERR_UNSUPPORTED, "cpm_bin_fast", "radius beyond 3.5 voxels along some axis (or not positive): use cpm_bin + cpm_gather");
-    const size_t tiles = tiles_of((size_t)n);
-    const uint32_t copies = (uint32_t)copies_per_photon(L);
-    CPM_REQUIRE(ctx, tiles * (size_t)kBinTile * copies < (1ull << 32), "cpm_bin_fast: record positions are 32-bit (n * 8 must stay below 2^32)");
-    CPM_REQUIRE(ctx, (reinterpret_cast<uintptr_t>(brick_table) & 7u) == 0, "cpm_bin_fast: brick_table must be 8-byte aligned");
-    // scratch: a 64-bit counter per brick (runs << 32 | records) + the accumulator words -- all zero between calls: the workgroup of a
-    // launch that finishes last resets them (a new arena or another brick count: cleared here)
-    const size_t words = 2 * (size_t)L.nb + kAccWords;
-    const bool had = ctx->scratch_bytes[CPM_SCR_FAST_BIN] >= words * 4;
-    uint32_t* base = (uint32_t*)scratch(ctx, CPM_SCR_FAST_BIN, words * 4);
+    CPM_REQUIRE(ctx, (long long)n * copies_per_photon(L) < (1ll << 32), "cpm_bin_fast: record positions are 32-bit (n * 8 must stay below 2^32)");
+    // scratch: two histograms (nb brick counts + 4 accumulators), used in turn -- a call's scatter launch zeroes the one the
+    // NEXT call counts into -- then run_base: per tile of 4096 photons a list of (brick, run offset) pairs behind its length
+    // (room for every brick; as many written and read as the tile touches)
+    static_assert(kCountTile == kScatterTile, "count and scatter launches share the tile decomposition");
+    const size_t hist_words = (size_t)L.nb + kAccWords;
+    const size_t tiles = n > 0 ? (size_t)div_up(n, kCountTile) : 1;
+    const size_t arena = (2 * hist_words + 2 * tiles * pair_stride(L)) * 4;  // (a pair = 2 words)
+    const bool had = ctx->scratch_bytes[CPM_SCR_FAST_BIN] >= arena;
+    uint32_t* base = (uint32_t*)scratch(ctx, CPM_SCR_FAST_BIN, arena);
     if (!base) return CPM_ERR_OUT_OF_MEMORY;
-    if (!had || ctx->fast_hist_words != words) CPM_HIP_CHECK(ctx, hipMemsetAsync(base, 0, words * 4, s));
-    ctx->fast_hist_words = 0;  // re-established below once the launch that restores the zero state is enqueued
-    unsigned long long* counters = reinterpret_cast<unsigned long long*>(base);
-    uint32_t* acc = base + 2 * (size_t)L.nb;
-    // (n == 0 still runs one workgroup: the table -- no records anywhere -- is part of the result)
-    const size_t lds = 2 * (size_t)L.nb * 4;
-    const dim3 bgrid((unsigned)tiles);
-    if (G.channels == 1) {
-        rc = allow_lds(ctx, fast_bin_kernel<1>, lds); if (rc) return rc;
-        CPM_LAUNCH(ctx, fast_bin_kernel<1>, bgrid, dim3(1024), lds, s, photons8, rs, rb, n, G, L, radius, counters, acc, brick_table, sorted_pos_power, (uint32_t)tiles, copies);
-    } else {
-        rc = allow_lds(ctx, fast_bin_kernel<4>, lds); if (rc) return rc;
-        CPM_LAUNCH(ctx, fast_bin_kernel<4>, bgrid, dim3(1024), lds, s, photons8, rs, rb, n, G, L, radius, counters, acc, brick_table, sorted_pos_power, (uint32_t)tiles, copies);
+    if (!had || ctx->fast_hist_words != hist_words) {  // new arena or another brick count: the zero state is not established
+        CPM_HIP_CHECK(ctx, hipMemsetAsync(base, 0, 2 * hist_words * 4, s));
+        ctx->fast_hist_parity = 0;
     }
-    CPM_LAUNCH_CHECK(ctx, "fast_bin_kernel");
-    ctx->fast_hist_words = words;
+    uint32_t* hist = base + (size_t)ctx->fast_hist_parity * hist_words;
+    uint32_t* zero_next = base + (size_t)(ctx->fast_hist_parity ^ 1) * hist_words;
+    uint32_t* acc = hist + L.nb;
+    uint32_t* run_base = base + 2 * hist_words;
+    ctx->fast_hist_words = 0;  // re-established below once the kernel that restores the zero state is enqueued
+    const size_t lds = (size_t)L.nb * 4;
+    if (n > 0) {
+        const dim3 cgrid((unsigned)tiles);
+        if (G.channels == 1) {
+            rc = allow_lds(ctx, fast_count_kernel<1>, lds); if (rc) return rc;
+            CPM_LAUNCH(ctx, fast_count_kernel<1>, cgrid, dim3(1024), lds, s, photons8, rs, rb, n, G, L, radius, hist, acc, run_base);
+        } else {
+            rc = allow_lds(ctx, fast_count_kernel<4>, lds); if (rc) return rc;
+            CPM_LAUNCH(ctx, fast_count_kernel<4>, cgrid, dim3(1024), lds, s, photons8, rs, rb, n, G, L, radius, hist, acc, run_base);
+        }
+        CPM_LAUNCH_CHECK(ctx, "fast_count_kernel");
+    }
+    // n == 0 still runs one workgroup: the table (all starts 0) is part of the result
+    const int stiles = n > 0 ? div_up(n, kScatterTile) : 1, smax = 2 * ctx->num_cus;
+    const dim3 sgrid((unsigned)(stiles < smax ? stiles : smax));
+    if (G.channels == 1) {
+        rc = allow_lds(ctx, fast_scatter_kernel<1>, 2 * lds); if (rc) return rc;
+        CPM_LAUNCH(ctx, fast_scatter_kernel<1>, sgrid, dim3(1024), 2 * lds, s, photons8, rs, rb, n, G, L, radius, hist, run_base, zero_next, (int)hist_words, brick_table, sorted_pos_power);
+    } else {
+        rc = allow_lds(ctx, fast_scatter_kernel<4>, 2 * lds); if (rc) return rc;
+        CPM_LAUNCH(ctx, fast_scatter_kernel<4>, sgrid, dim3(1024), 2 * lds, s, photons8, rs, rb, n, G, L, radius, hist, run_base, zero_next, (int)hist_words, brick_table, sorted_pos_power);
+    }
+    CPM_LAUNCH_CHECK(ctx, "fast_scatter_kernel");
+    ctx->fast_hist_parity ^= 1;
+    ctx->fast_hist_words = hist_words;
     ctx->fast_last_table = brick_table;
     ctx->fast_last_radius = radius;
     return CPM_OK;

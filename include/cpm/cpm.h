@@ -415,23 +415,19 @@ int cpm_gather_bricks(cpm_ctx* ctx, const float* sorted_pos_power, const uint32_
  * reach no voxel are dropped.
  * The reference adds with CAS float atomics in arrival order (ref cl/photonstolightvolume.cl:15-29,62-75). */
 
-/* u32 entries of the brick table cpm_bin_fast fills on this grid for n photons (0 = bad arguments): records per brick, the list of
- * non-empty bricks, max |power|, the radius, and per brick its runs -- (position, length) pairs, room for one per tile of 4096 photons. */
+/* u32 entries of the brick table cpm_bin_fast fills on this grid (0 = bad arguments): brick starts, max |power|, radius. */
 size_t cpm_fast_table_entries(const cpm_grid_desc* grid, int n);
 /* 1 when the pair covers this grid / radius: at most 8 candidate voxels along every axis (floor(2 (r * textureToIndex + 1e-3)) + 1
  * <= 8: radius < 3.5 voxels of THAT axis -- the box follows an anisotropic grid: 6 x 6 x 2 on the workspace's 256 x 256 x 48
  * light volume; up to 4 per axis the record loops are unrolled, wider boxes take run-time loops), positive axis-aligned
  * textureToIndex; otherwise use cpm_bin + cpm_gather. */
 int cpm_gather_fast_supported(const cpm_grid_desc* grid, float radius);
-/* Records sorted_pos_power must hold for n photons at this radius (every photon in all its bricks: 8 per photon, or 1 when a
- * candidate box is a single voxel wide -- for whole tiles of 4096 photons: a tile files into its own block of the buffer); 0 when
- * unsupported. */
+/* Records sorted_pos_power must hold for n photons at this radius (every photon in all its bricks: 8 n, or n when a
+ * candidate box is a single voxel wide); 0 when unsupported. */
 size_t cpm_fast_record_capacity(const cpm_grid_desc* grid, int n, float radius);
 
-/* brick_table (device, 8-byte aligned, cpm_fast_table_entries(grid, n) u32): [0, bricks) records per brick, [bricks] records in all,
- * 4 words (max |power| bits, radius bits, non-empty bricks, tiles), the non-empty bricks, runs per brick, the runs.  A brick's records
- * are the records of its runs: the bin is ONE launch (a tile of 4096 photons lays its copies out inside its own block of
- * sorted_pos_power, so no global prefix has to exist before the records are placed).  sorted_pos_power: cpm_fast_record_capacity(grid, n, radius) compact records, float4
+/* brick_table (device, cpm_fast_table_entries(grid, n) u32): brick starts (brick_table[bricks] = records written), max
+ * |power|, the radius.  sorted_pos_power: cpm_fast_record_capacity(grid, n, radius) compact records, float4
  * (x, y, z, powerR) when channels == 1, 2 x float4 (x, y, z, powerR | powerG, powerB, 0, 0) when == 4.
  * radius: the photon radius (texture units) the gather will use -- it decides which bricks a photon is filed under. */
 int cpm_bin_fast(cpm_ctx* ctx, const float* photons8, int n, const cpm_grid_desc* grid, float radius, uint32_t* brick_table,

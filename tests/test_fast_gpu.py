@@ -108,15 +108,6 @@ def expected_filing(ph, dims, radius, grid):
     return pairs
 
 
-def table_runs(table, nb, tiles):
-    """cpm_bin_fast's table (include/cpm/cpm.h): records per brick, runs per brick, the runs' (position, length) pairs [nb, tiles, 2]."""
-    counts = table[:nb]
-    n_runs = table[2 * nb + 5:3 * nb + 5]
-    off = (3 * nb + 5 + 1) & ~1
-    runs = table[off:off + 2 * nb * tiles].reshape(nb, tiles, 2)
-    return counts, n_runs, runs
-
-
 def run_fast(ctx, cpm, ph, dims, channels, radius, scale, accumulate_into=None):
     B = cpm.binding
     n = ph.shape[0]
@@ -187,31 +178,23 @@ def test_fast_equals_restatement_and_reference_semantics(ctx, oracle, cpm, dims,
     want_fast, want_exact = oracle_both(oracle, ph, dims, channels, radius, scale)
     assert np.array_equal(bits(got), bits(want_fast))
     np.testing.assert_allclose(got, want_exact, rtol=RTOL, atol=ATOL_OF_MAX * float(np.abs(want_exact).max()))
-    # the table: a photon is filed under every brick its candidate voxels lie in; the table holds those counts, and the records of a
-    # brick -- the records of its runs, one run per tile of 4096 photons that reached it -- are exactly the photons filed under it (in
-    # no particular order)
+    # the table: a photon is filed under every brick its candidate voxels lie in; brick starts are those counts, the records
+    # of a brick are exactly the photons filed under it (in no particular order)
     grid = cpm.binding.default_grid_desc(dims, channels)
     pairs = expected_filing(ph, dims, radius, grid)
     nb = brick_count(dims, candidates_per_axis(radius, grid))
     total = len(pairs)
-    tiles = max(1, -(-n // 4096))
-    counts_got, n_runs, runs = table_runs(table, nb, tiles)
-    assert table[nb] == total and total <= ctx.fast_record_capacity(grid, n, radius)
+    assert table[0] == 0 and table[nb] == total and (np.diff(table[: nb + 1].astype(np.int64)) >= 0).all()
+    assert total <= ctx.fast_record_capacity(grid, n, radius)
     counts = np.bincount(np.array([b for _, b in pairs], np.int64), minlength=nb) if pairs else np.zeros(nb, np.int64)
-    assert np.array_equal(counts_got.astype(np.int64), counts)
-    assert table[nb + 1 + 2] == (counts > 0).sum() and table[nb + 1 + 3] == tiles       # meta: non-empty bricks, tiles
-    assert np.array_equal(np.sort(table[nb + 5:nb + 5 + (counts > 0).sum()]), np.nonzero(counts)[0])
-    assert ((n_runs > 0) == (counts > 0)).all() and (n_runs <= tiles).all()
+    assert np.array_equal(np.diff(table[: nb + 1].astype(np.int64)), counts)
     rec_of = (lambda i: ph[i, :4]) if channels == 1 else (lambda i: np.concatenate([ph[i, :6], np.zeros(2, np.float32)]))
     width = 4 if channels == 1 else 8
     by_brick = {}
     for i, b in pairs:
         by_brick.setdefault(b, []).append(rec_of(i))
     for b, recs in list(by_brick.items())[:400]:  # (every brick for the small cases, a sample for the big ones)
-        mine = runs[b, :n_runs[b]]
-        assert mine[:, 1].sum() == counts[b] and (mine[:, 1] > 0).all()
-        got_b = np.concatenate([srt[int(p0):int(p0) + int(ln)] for p0, ln in mine])
-        got_b = np.ascontiguousarray(got_b).view([("", np.uint32)] * width).reshape(-1)
+        got_b = np.ascontiguousarray(srt[table[b]:table[b + 1]]).view([("", np.uint32)] * width).reshape(-1)
         want_b = np.ascontiguousarray(np.stack(recs).astype(np.float32)).view([("", np.uint32)] * width).reshape(-1)
         assert np.array_equal(np.sort(got_b), np.sort(want_b)), b
     # bitwise reproducible although nothing orders the records inside a brick
@@ -330,7 +313,7 @@ def test_candidate_box_is_cut_to_the_host_reach(ctx, oracle, cpm):
     ph[:, 3:6] = 1.0
     u = f32(f32(grid.texture_to_index[0]) * ph[0, 0] + f32(grid.texture_to_index[12]))
     assert np.ceil(f32(u - rg)) < np.floor(f32(u + rg))               # the float box really holds two integers
-    assert ctx.fast_record_capacity(grid, n, radius) == 2 * 4096        # one slot per photon (whole tiles of 4096): no room for a second record
+    assert ctx.fast_record_capacity(grid, n, radius) == n
     scale = float(cpm.binding.relative_irradiance_scale(radius, float(n)))
     got, table, srt = run_fast(ctx, cpm, ph, dims, 1, radius, scale)
     want_fast, _ = oracle_both(oracle, ph, dims, 1, radius, scale)

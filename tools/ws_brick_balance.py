@@ -14,11 +14,12 @@ torch.cuda.synchronize()
 t = fr.brick_table.cpu().numpy().view(np.uint32)
 # table: [0, nb] starts | 4 meta | items; nb from the layout: 16 x 16 x 8 bricks -> 16 * 16 * 6
 nb = 16 * 16 * 6
-counts = t[:nb].astype(np.int64)
+starts = t[:nb + 1].astype(np.int64)
+counts = np.diff(starts)
 n_items = int(t[nb + 1 + 2])
 items = t[nb + 5:nb + 5 + n_items]
 c = counts[items]
-print(f"records {int(t[nb])}  bricks {nb}  non-empty {n_items}  records per non-empty brick: mean {c.mean():.0f} median {np.median(c):.0f} max {c.max()}  p90 {np.percentile(c, 90):.0f}")
+print(f"records {starts[-1]}  bricks {nb}  non-empty {n_items}  records per non-empty brick: mean {c.mean():.0f} median {np.median(c):.0f} max {c.max()}  p90 {np.percentile(c, 90):.0f}")
 G = 512
 cost = 3.0 + c / 2048.0 * 2.2      # a brick: ~3 us of fixed latency chain + ~2.2 us per pass of 2048 records (rough)
 for name, order in (("brick order (the launch's)", np.arange(n_items)), ("largest first", np.argsort(-c))):
