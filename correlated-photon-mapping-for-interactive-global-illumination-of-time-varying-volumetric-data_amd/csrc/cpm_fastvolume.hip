@@ -414,6 +414,9 @@ CPM_DEV void brick_record_wide(const GridDev& G, const BrickLayout& L, float4 a,
         const float dz = fma_(G.i2t.sz, (float)vz, G.i2t.tz) - a.z;
         for (int vy = sy; vy <= ey; ++vy) {
             const float dy = fma_(G.i2t.sy, (float)vy, G.i2t.ty) - a.y;
+            // no slot of this row can hit: d^2 >= fma(dz, dz, dy * dy) for every dx (rounding is monotone in the addend) -- the far slice
+            // of a photon midway between two slices, the outer rows of one well off its slice
+            if (!(fma_(dz, dz, dy * dy) <= r2)) continue;
             const int row = (sx - ox) + BX * ((vy - oy) + BY * (vz - oz));
 #pragma unroll
             for (int q = 0; q < WX; ++q) {
