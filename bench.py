@@ -814,7 +814,8 @@ def main():
                     "tf_edit_fraction_retraced": round(float(np.mean(np.maximum(n_e[10:], 0))) / (2 * 1024 * 1024), 5),
                     "tf_edit_served_by": net.last_decision,
                     "launches": "both lights' samples traced by one launch (cpm_trace_lights; the TF edit's importance pass + re-trace likewise: "
-                                "cpm_photon_importance_retrace_lights); bricks of 16 x 16 x 8 voxels for the wide box, four copies of a brick's LDS tile",
+                                "cpm_photon_importance_retrace_lights); the wide box's gather: a photon filed under one brick of 16 x 16 x 8 voxels, 64-bit LDS tiles with "
+                                "a halo (two copies), staged per brick and merged by a second launch",
                     "measured": "libcpm_host.so: the workspace's network (two light samplers -> tracer multi-inport -> light volume), frames back to "
                                 "back with one synchronisation; tests/test_workspace_point_gpu.py holds the same network to the oracle"}
                 net.close()
@@ -878,7 +879,7 @@ def main():
 
         stages = {"trace": stage(["trace_kernel"]),
                   "bin": stage(["bin_", "radix_", "cell_start", "fast_count", "fast_scan", "fast_scatter"]),
-                  "gather": stage(["gather", "fast_brick"]),
+                  "gather": stage(["gather", "fast_brick", "fast_halo"]),
                   "reduce": stage(["rccl_"])}
         tile = 256 * (4 if n_rank <= (1 << 15) else 8 if n_rank <= (1 << 23) else 16)
         tiles = -(-n_rank // tile)

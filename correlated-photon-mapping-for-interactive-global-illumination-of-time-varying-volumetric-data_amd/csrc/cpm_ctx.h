@@ -71,7 +71,7 @@ enum {
     CPM_SCR_SMALL = 4,       // TF points etc.
     CPM_SCR_MISC = 5,
     CPM_SCR_FAST_BIN = 6,    // cpm_bin_fast: two (brick histogram, cursors) pairs, used in turn, zeroed by the call before
-    CPM_SCR_FAST_SLABS = 7   // (unused since the one-launch gather)
+    CPM_SCR_FAST_STAGE = 7   // cpm_gather_fast, wide boxes: one 64-bit tile with its halo per brick
 };
 
 struct cpm_volume {

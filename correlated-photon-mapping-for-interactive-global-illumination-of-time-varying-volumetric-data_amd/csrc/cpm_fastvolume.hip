@@ -23,7 +23,12 @@
 //                               does not depend on the order lanes, waves or runs add in: bitwise reproducible with no
 //                               ordering protocol at all -- then ONE rounding to float and a coalesced store of the
 //                               brick (zeros for a brick nothing reaches).  No halos, no slabs, no second launch:
-//                               what the records' duplication buys.
+//                               what the records' duplication buys -- for boxes of up to 4 candidates per axis.
+//          fast_halo_kernel +   WIDE boxes (5 - 8 candidates along some axis; the workspace's 6 x 6 x 2): duplication stops paying
+//          fast_halo_merge_...  (1.7 copies per photon, each as dear to a wave as a whole box), so a photon is filed once, under the
+//                               brick of its box's low corner; that brick's tile has a halo on its high sides, tiles go to a
+//                               staging slot per brick as 64-bit sums, and a second launch adds the <= 8 tiles that cover a
+//                               voxel -- still integers, still one rounding, the same bits.
 // No global float atomics, no sort passes, no per-voxel ordering.
 #include "cpm_ctx.h"
 
@@ -66,6 +71,8 @@ struct BrickLayout {
     int maxc;               // candidate voxels per axis, the widest axis' (0 until brick_reach)
     int mcx, mcy, mcz;      // ... and per axis: an anisotropic grid (the workspace's 256 x 256 x 48 light volume: r = 2.8 / 2.8 / 0.5
                             // voxels) has a box of 6 x 6 x 2 candidates
+    int halo;               // wide boxes (maxc > 4): a photon is filed under ONE brick, the one of its box's low corner, and that brick's
+                            // workgroup sums into a tile with mc - 1 more voxels on the high side of every axis (see fast_halo_kernel)
 };
 CPM_DEV uint32_t off_meta(const BrickLayout& L) { return (uint32_t)L.nb + 1u; }
 // a tile's list of (brick, run offset) pairs in run_base: a head (the count) + at most one pair per brick
@@ -100,12 +107,13 @@ __host__ void candidates_per_axis(const GridDev& G, float radius, int mc[3]) {
 // (Measured at config 2, 128^3: 4096 bricks of 8^3 -> 80.1 us per frame, 2048 of 16x8x8 -> 76.1, 2048 of 8x8x16 -> 74.9,
 // 1024 of 16x16x8 -> 81.0, 8192 of 8x4x8 -> 93.6: fewer bricks make the scans, the per-tile rows and the empty bricks
 // cheaper until the heaviest brick -- a serial chain of 1024-record batches in one workgroup -- takes over.)
-// A WIDE candidate box (more than 4 candidates along some axis, `mc` given) shapes the brick after itself: a photon is filed under
-// every brick its box touches, and a box 6 wide lies across the faces of an 8-wide brick most of the time -- the workspace's
-// 256 x 256 x 48 light volume (box 6 x 6 x 2) put 2.6 copies of every photon into 8 x 8 x 16 bricks.  Per axis 16 voxels where the
-// box has 5 or more candidates, 8 otherwise, and never more than 2048 voxels (a box wide along all three axes: 16 x 16 x 8):
-// 16 x 16 x 8 there (1.7 copies; frame 0.233 -> 0.193 ms; 16 x 16 x 4: 0.197, 16 x 8 x 8: 0.208, 32 x 16 x 4: 0.228, 32 x 32 x 4:
-// 0.293 -- larger bricks are heavier work items).
+// A WIDE candidate box (more than 4 candidates along some axis, `mc` given) shapes the brick after itself: per axis 16 voxels where the
+// box has 5 or more candidates, 8 otherwise, and never more than 2048 voxels (a box wide along all three axes: 16 x 16 x 8).  Measured at
+// the workspace's 256 x 256 x 48 light volume (box 6 x 6 x 2) when a photon was still filed under every brick its box touches: 8 x 8 x 16
+// 0.233 ms per frame (2.6 copies per photon), 16 x 16 x 8 0.193 (1.7 copies), 16 x 16 x 4 0.197, 16 x 8 x 8 0.208, 32 x 16 x 4 0.228; and with
+// one filing per photon and tiles with a halo (fast_halo_kernel): 16 x 16 x 8 0.154, 16 x 16 x 4 0.157, 8 x 16 x 8 0.160, 16 x 8 x 8 0.164,
+// 8 x 8 x 8 0.171 (smaller bricks: more halo to stage and merge, and the gather launch is no faster -- it is not bound by the balance
+// of its work items).
 __host__ void brick_shape(const int dims[3], BrickLayout& L, const int* mc = nullptr) {
 #ifndef CPM_BRICK_LG
 #define CPM_BRICK_LG 3, 3, 4
@@ -127,6 +135,7 @@ __host__ void brick_shape(const int dims[3], BrickLayout& L, const int* mc = nul
     L.nb = L.nbx * L.nby * L.nbz;
     L.bvox = 1 << (lg[0] + lg[1] + lg[2]);
     L.maxc = L.mcx = L.mcy = L.mcz = 0;
+    L.halo = 0;
 }
 // ... for a grid and a radius (what every entry point that knows the radius uses: count, scatter and gather agree by construction)
 __host__ void brick_shape_for(const GridDev& G, float radius, BrickLayout& L) {
@@ -145,13 +154,18 @@ __host__ bool brick_reach(const GridDev& G, float radius, BrickLayout& L) {
     candidates_per_axis(G, radius, mc);
     L.mcx = mc[0]; L.mcy = mc[1]; L.mcz = mc[2];
     L.maxc = mc[0] > mc[1] ? (mc[0] > mc[2] ? mc[0] : mc[2]) : (mc[1] > mc[2] ? mc[1] : mc[2]);
+    L.halo = L.maxc > 4 ? 1 : 0;
     if (!(radius > 0.f) || L.maxc > kMaxCandidates) return false;
     const int lg[3] = { L.lx, L.ly, L.lz }, nbr[3] = { L.nbx, L.nby, L.nbz };
     for (int a = 0; a < 3; ++a)
         if (mc[a] > (1 << lg[a]) && nbr[a] > 1) return false;
     return true;
 }
-__host__ size_t tile_bytes_for(const GridDev& G, const BrickLayout& L) { return (size_t)(G.channels == 4 ? 3 : 1) * (size_t)L.bvox * 8; }
+// voxels of a brick's LDS tile: the brick, with its halo where photons are filed once
+__host__ __device__ inline int tile_voxels(const BrickLayout& L) {
+    return L.halo ? ((1 << L.lx) + L.mcx - 1) * ((1 << L.ly) + L.mcy - 1) * ((1 << L.lz) + L.mcz - 1) : L.bvox;
+}
+__host__ size_t tile_bytes_for(const GridDev& G, const BrickLayout& L) { return (size_t)(G.channels == 4 ? 3 : 1) * (size_t)tile_voxels(L) * 8; }
 
 __host__ size_t table_entries(const BrickLayout& L) { return 2 * (size_t)L.nb + 5; }
 
@@ -182,7 +196,12 @@ CPM_DEV bool candidate_box(const GridDev& G, float4 a, float rgx, float rgy, flo
 // unless it spans its whole axis)
 template <typename F>
 CPM_DEV void for_each_brick(const BrickLayout& L, const Box& b, F f) {
-    const int bx0 = b.sx >> L.lx, bx1 = b.ex >> L.lx, by0 = b.sy >> L.ly, by1 = b.ey >> L.ly, bz0 = b.sz >> L.lz, bz1 = b.ez >> L.lz;
+    const int bx0 = b.sx >> L.lx, by0 = b.sy >> L.ly, bz0 = b.sz >> L.lz;
+    if (L.halo) {  // filed once, under the brick of the box's low corner
+        f((uint32_t)bx0 + (uint32_t)L.nbx * ((uint32_t)by0 + (uint32_t)L.nby * (uint32_t)bz0));
+        return;
+    }
+    const int bx1 = b.ex >> L.lx, by1 = b.ey >> L.ly, bz1 = b.ez >> L.lz;
     for (int bz = bz0; bz <= bz1; ++bz)
         for (int by = by0; by <= by1; ++by)
             for (int bx = bx0; bx <= bx1; ++bx)
@@ -393,35 +412,33 @@ __global__ __launch_bounds__(1024, 8) void fast_scatter_kernel(const float* __re
 // for the candidates beyond the face; d^2 in texture space with the contract's operands (c = indexToTexture * v,
 // d = c - p, d^2 = fma(dz, dz, fma(dy, dy, dx * dx))); weight 0.75 * (1 - d^2 / r^2) for d^2 <= r^2; value -> fixed point
 // by truncation.
-// The same record for a box of any width (MAXC > 4 of fast_brick_kernel: more than 4 candidates along some axis): run-time loops
-// over the candidates inside this brick, a row left as soon as dz^2 + dy^2 alone exceeds r^2.
+// The same record for a WIDE box (more than 4 candidates along some axis; fast_halo_kernel): the whole box -- the photon is filed under the
+// brick of the box's low corner only, and the tile reaches mc - 1 voxels beyond the brick's high faces -- with run-time loops over z and y
+// and the x candidates unrolled.  TX / TY: the tile's row and slice pitch.
 template <int CH, int WX /* candidates along x the loop is unrolled for: >= L.mcx */>
-CPM_DEV void brick_record_wide(const GridDev& G, const BrickLayout& L, float4 a, float pg, float pb, int ox, int oy, int oz, int BX, int BY, int BZ,
-                               float rgx, float rgy, float rgz, float r2, float inv_r2, float k, float S, long long* __restrict__ tile, int plane) {
+CPM_DEV void halo_record(const GridDev& G, const BrickLayout& L, float4 a, float pg, float pb, int ox, int oy, int oz, int TX, int TY,
+                         float rgx, float rgy, float rgz, float r2, float inv_r2, float k, float S, long long* __restrict__ tile, int plane) {
     Box c;
     if (!candidate_box(G, a, rgx, rgy, rgz, L.mcx, L.mcy, L.mcz, c)) return;
-    const int sx = max(c.sx, ox), ex = min(c.ex, ox + BX - 1);
-    const int sy = max(c.sy, oy), ey = min(c.ey, oy + BY - 1);
-    const int sz = max(c.sz, oz), ez = min(c.ez, oz + BZ - 1);
     // value * S with S a power of two: (p k w) S and (p k S) w round the same real number scaled by 2^sh -- the same bits (a product
     // small enough to be denormal truncates to 0 either way: S <= 2^100)
     const float pk = __builtin_fabsf(a.w) <= kFltMax ? (a.w * k) * S : 0.f;
     const float pkg = __builtin_fabsf(pg) <= kFltMax ? (pg * k) * S : 0.f, pkb = __builtin_fabsf(pb) <= kFltMax ? (pb * k) * S : 0.f;
     float dx2[WX];
 #pragma unroll
-    for (int q = 0; q < WX; ++q) { const float d = fma_(G.i2t.sx, (float)(sx + q), G.i2t.tx) - a.x; dx2[q] = d * d; }
-    for (int vz = sz; vz <= ez; ++vz) {
+    for (int q = 0; q < WX; ++q) { const float d = fma_(G.i2t.sx, (float)(c.sx + q), G.i2t.tx) - a.x; dx2[q] = d * d; }
+    for (int vz = c.sz; vz <= c.ez; ++vz) {
         const float dz = fma_(G.i2t.sz, (float)vz, G.i2t.tz) - a.z;
-        for (int vy = sy; vy <= ey; ++vy) {
+        for (int vy = c.sy; vy <= c.ey; ++vy) {
             const float dy = fma_(G.i2t.sy, (float)vy, G.i2t.ty) - a.y;
             // no slot of this row can hit: d^2 >= fma(dz, dz, dy * dy) for every dx (rounding is monotone in the addend) -- the far slice
             // of a photon midway between two slices, the outer rows of one well off its slice
             if (!(fma_(dz, dz, dy * dy) <= r2)) continue;
-            const int row = (sx - ox) + BX * ((vy - oy) + BY * (vz - oz));
+            const int row = (c.sx - ox) + TX * ((vy - oy) + TY * (vz - oz));
 #pragma unroll
             for (int q = 0; q < WX; ++q) {
                 const float d2 = fma_(dz, dz, fma_(dy, dy, dx2[q]));   // the contract's operands: dx * dx, then the two fmas
-                if (sx + q > ex || !(d2 <= r2)) continue;
+                if (c.sx + q > c.ex || !(d2 <= r2)) continue;
                 const float w = 0.75f * (1.0f - d2 * inv_r2);
                 atomicAdd(reinterpret_cast<unsigned long long*>(tile + row + q), (unsigned long long)(long long)(int)(pk * w));
                 if (CH == 4) {
@@ -488,11 +505,8 @@ constexpr int kMaxSubBricks = 512;  // 4x4x4 sub-bricks of a brick (a tile of <=
 template <int MAXC, int CH>
 __global__ __launch_bounds__(kBrickThreads, (CH == 4 ? 4 : CPM_BRICK_WAVES)) void fast_brick_kernel(const float* __restrict__ sorted, const uint32_t* __restrict__ table, GridDev G,
                                                                   BrickLayout L, float radius, float k, int accumulate, float* __restrict__ out,
-                                                                  uint8_t* __restrict__ marks, int repl_arg) {
+                                                                  uint8_t* __restrict__ marks) {
     extern __shared__ long long s_tile[];
-    // REPL copies of the brick's tile, lane l adds into copy l mod REPL: neighbouring lanes hold neighbouring photons, whose adds meet in
-    // the same voxels -- same-address LDS atomics of one instruction are served one after the other
-    const int repl = repl_arg;
     // marks (nullable): one byte per 4x4x4-voxel brick of the grid (cpm_mark_touched_bricks' numbering), 1 where this launch
     // leaves a non-zero value, 0 elsewhere -- every byte written: what cpm_allreduce_grid_sparse would otherwise read the whole
     // volume again for
@@ -550,8 +564,8 @@ __global__ __launch_bounds__(kBrickThreads, (CH == 4 ? 4 : CPM_BRICK_WAVES)) voi
             }
         };
         fetch(j0, a, a2);
-        for (int w = t; w < words * repl; w += kBrickThreads) s_tile[w] = 0ll;
-        long long* my_tile = s_tile + (size_t)(t & (repl - 1)) * (size_t)words;
+        for (int w = t; w < words; w += kBrickThreads) s_tile[w] = 0ll;
+        long long* my_tile = s_tile;
         const int nsub = L.bvox >> 6;
         if (marks) for (int w = t; w < nsub; w += kBrickThreads) s_flag[w] = 0;  // (the lane that read flag w for the brick before)
         __syncthreads();
@@ -561,10 +575,8 @@ __global__ __launch_bounds__(kBrickThreads, (CH == 4 ? 4 : CPM_BRICK_WAVES)) voi
             for (int q = 0; q < kBrickPer; ++q) {
                 const uint32_t j = first + (uint32_t)(q * kBrickThreads + t);
                 if (j < j1) {
-                    // MAXC <= 4: a box of at most MAXC^3 candidates, all loops unrolled; MAXC = 6 / 8 / 14 (= x width 4): wide or anisotropic
-                    // boxes -- y and z at run time, x unrolled for 6 / 8 / 4 candidates
-                    if (MAXC > 4) brick_record_wide<CH, (MAXC == 14 ? 4 : MAXC)>(G, L, a[q], a2[q].x, a2[q].y, ox, oy, oz, BX, BY, BZ, rgx, rgy, rgz, r2, inv_r2, k, S, my_tile, L.bvox);
-                    else brick_record<(MAXC > 4 ? 1 : MAXC), CH>(G, a[q], a2[q].x, a2[q].y, ox, oy, oz, BX, BY, BZ, rgx, rgy, rgz, r2, inv_r2, k, S, my_tile, L.bvox);
+                    // a box of at most MAXC^3 candidates (MAXC <= 4), all loops unrolled
+                    brick_record<MAXC, CH>(G, a[q], a2[q].x, a2[q].y, ox, oy, oz, BX, BY, BZ, rgx, rgy, rgz, r2, inv_r2, k, S, my_tile, L.bvox);
                 }
             }
 #pragma unroll
@@ -576,15 +588,13 @@ __global__ __launch_bounds__(kBrickThreads, (CH == 4 ? 4 : CPM_BRICK_WAVES)) voi
             const int gx = ox + lx, gy = oy + ly, gz = oz + lz;
             if (gx >= G.dx || gy >= G.dy || gz >= G.dz) continue;
             const size_t o = (size_t)gx + (size_t)G.dx * ((size_t)gy + (size_t)G.dy * (size_t)gz);
-            long long sum_r = s_tile[v];
-            for (int c = 1; c < repl; ++c) sum_r += s_tile[(size_t)c * words + v];
+            const long long sum_r = s_tile[v];
             const float fr = (float)sum_r * invS;
             bool nonzero = fr != 0.f;
             if (CH == 1) {
                 out[o] = accumulate ? out[o] + fr : fr;
             } else {
-                long long sum_g = s_tile[L.bvox + v], sum_b = s_tile[2 * L.bvox + v];
-                for (int c = 1; c < repl; ++c) { sum_g += s_tile[(size_t)c * words + L.bvox + v]; sum_b += s_tile[(size_t)c * words + 2 * L.bvox + v]; }
+                const long long sum_g = s_tile[L.bvox + v], sum_b = s_tile[2 * L.bvox + v];
                 const float fg = (float)sum_g * invS, fb = (float)sum_b * invS;
                 nonzero = nonzero || fg != 0.f || fb != 0.f;
                 float4* q = reinterpret_cast<float4*>(out) + o;
@@ -600,6 +610,195 @@ __global__ __launch_bounds__(kBrickThreads, (CH == 4 ? 4 : CPM_BRICK_WAVES)) voi
                 const int gx4 = (ox >> 2) + sx, gy4 = (oy >> 2) + sy, gz4 = (oz >> 2) + sz;
                 if (4 * gx4 < G.dx && 4 * gy4 < G.dy && 4 * gz4 < G.dz) marks[(uint32_t)gx4 + (uint32_t)nbx4 * ((uint32_t)gy4 + (uint32_t)nby4 * (uint32_t)gz4)] = s_flag[w];
             }
+    }
+}
+
+// ---- wide boxes (more than 4 candidates along some axis): tiles with a halo, no copies ------------------------------------------------
+// With a box 6 wide, 43 % of the records of a 16 x 16 x 8 brick were copies of neighbouring bricks' photons (1.7 copies per photon), and a
+// copy costs a wave as much as a whole box: lanes hold unrelated records, the wave runs every row and slot any lane needs
+// (docs/EXPERIMENTS.md, round 5).  So a wide-box photon is filed ONCE, under the brick of its box's low corner; that brick's workgroup sums
+// whole boxes into a tile that reaches mc - 1 voxels beyond the brick's high faces and leaves the tile's 64-bit sums in `stage` (one
+// slot per brick, written by the bricks with records only).  fast_halo_merge_kernel then forms every voxel's sum over the <= 8 tiles
+// that cover it -- its own brick's and the halos of the bricks below / left / in front -- as integers, rounds once and stores: the same
+// bits as one sum over all photons.  It also writes the zeros of the bricks no tile covers and the non-zero marks.
+template <int CH, int WX>
+__global__ __launch_bounds__(kBrickThreads, (CH == 4 ? 4 : CPM_BRICK_WAVES)) void fast_halo_kernel(const float* __restrict__ sorted, const uint32_t* __restrict__ table,
+                                                                                                    GridDev G, BrickLayout L, float radius, float k,
+                                                                                                    long long* __restrict__ stage, int repl) {
+    extern __shared__ long long s_tile[];
+    constexpr int CH3 = CH == 4 ? 3 : 1, STRIDE = CH == 4 ? 2 : 1;
+    const int t = threadIdx.x;
+    const int TX = (1 << L.lx) + L.mcx - 1, TY = (1 << L.ly) + L.mcy - 1;
+    const int tvox = tile_voxels(L), words = CH3 * tvox;
+    const float rgx = radius * G.t2i.sx + 1e-3f, rgy = radius * G.t2i.sy + 1e-3f, rgz = radius * G.t2i.sz + 1e-3f;
+    const float r2 = radius * radius, inv_r2 = 1.0f / r2;
+    const float S = fixed_scale(__uint_as_float(table[off_meta(L) + kMetaMaxPow]), k);
+    const float4* __restrict__ rec = reinterpret_cast<const float4*>(sorted);
+    const uint32_t n_items = table[off_meta(L) + kMetaItems];
+    const uint32_t* __restrict__ items = table + off_items(L);
+    for (uint32_t item = blockIdx.x; item < n_items; item += gridDim.x) {
+        const uint32_t b = items[item];
+        const uint32_t j0 = table[b], j1 = table[b + 1];
+        const int bx = (int)(b % (uint32_t)L.nbx), by = (int)((b / (uint32_t)L.nbx) % (uint32_t)L.nby), bz = (int)(b / (uint32_t)(L.nbx * L.nby));
+        const int ox = bx << L.lx, oy = by << L.ly, oz = bz << L.lz;
+        float4 a[kBrickPer], a2[kBrickPer], an[kBrickPer], an2[kBrickPer];
+        auto fetch = [&](uint32_t first, float4* x, float4* x2) {
+#pragma unroll
+            for (int q = 0; q < kBrickPer; ++q) {
+                const uint32_t j = first + (uint32_t)(q * kBrickThreads + t);
+                x[q] = make_float4(0.f, 0.f, 0.f, 0.f); x2[q] = x[q];
+                if (j < j1) { x[q] = rec[STRIDE * (size_t)j]; if (CH == 4) x2[q] = rec[2 * (size_t)j + 1]; }
+            }
+        };
+        fetch(j0, a, a2);
+        // `repl` copies of the tile, lane l adds into copy l mod repl: neighbouring lanes hold neighbouring photons, whose adds meet in
+        // the same voxels -- same-address LDS atomics of one instruction are served one after the other
+        for (int w = t; w < words * repl; w += kBrickThreads) s_tile[w] = 0ll;
+        long long* my_tile = s_tile + (size_t)(t & (repl - 1)) * (size_t)words;
+        __syncthreads();
+        for (uint32_t first = j0; first < j1; first += (uint32_t)(kBrickPer * kBrickThreads)) {  // uniform
+            fetch(first + (uint32_t)(kBrickPer * kBrickThreads), an, an2);
+#pragma unroll
+            for (int q = 0; q < kBrickPer; ++q) {
+                const uint32_t j = first + (uint32_t)(q * kBrickThreads + t);
+                if (j < j1) halo_record<CH, WX>(G, L, a[q], a2[q].x, a2[q].y, ox, oy, oz, TX, TY, rgx, rgy, rgz, r2, inv_r2, k, S, my_tile, tvox);
+            }
+#pragma unroll
+            for (int q = 0; q < kBrickPer; ++q) { a[q] = an[q]; a2[q] = an2[q]; }
+        }
+        __syncthreads();
+        long long* __restrict__ dst = stage + (size_t)b * (size_t)words;
+        for (int w = t; w < words; w += kBrickThreads) {
+            long long sum = s_tile[w];
+            for (int c = 1; c < repl; ++c) sum += s_tile[(size_t)c * words + w];
+            dst[w] = sum;
+        }
+        __syncthreads();  // the tile is cleared again for the next brick
+    }
+}
+
+// One workgroup per brick of the grid (see fast_halo_kernel).
+template <int CH>
+__global__ __launch_bounds__(256) void fast_halo_merge_kernel(const long long* __restrict__ stage, const uint32_t* __restrict__ table, GridDev G, BrickLayout L,
+                                                              float k, int accumulate, float* __restrict__ out, uint8_t* __restrict__ marks) {
+    __shared__ uint8_t s_flag[kMaxSubBricks];
+    constexpr int CH3 = CH == 4 ? 3 : 1;
+    const int t = threadIdx.x;
+    const int BX = 1 << L.lx, BY = 1 << L.ly, BZ = 1 << L.lz;
+    const int hx = L.mcx - 1, hy = L.mcy - 1, hz = L.mcz - 1;
+    const int TX = BX + hx, TY = BY + hy;
+    const int tvox = tile_voxels(L), words = CH3 * tvox;
+    const int nbx4 = (G.dx + 3) >> 2, nby4 = (G.dy + 3) >> 2, nsub = L.bvox >> 6;
+    const float S = fixed_scale(__uint_as_float(table[off_meta(L) + kMetaMaxPow]), k);
+    const float invS = 1.0f / S;  // a power of two: exact
+    for (uint32_t b = blockIdx.x; b < (uint32_t)L.nb; b += gridDim.x) {
+        const int bx = (int)(b % (uint32_t)L.nbx), by = (int)((b / (uint32_t)L.nbx) % (uint32_t)L.nby), bz = (int)(b / (uint32_t)(L.nbx * L.nby));
+        const int ox = bx << L.lx, oy = by << L.ly, oz = bz << L.lz;
+        // the tiles that cover this brick: its own and those of the 7 bricks one step down along x / y / z (uniform; the 16 table words are
+        // requested together -- a brick that is not there stands in as itself)
+        const long long* src[8];
+        uint32_t lo[8], hi[8], sbv[8];
+        int n_src = 0;
+#pragma unroll
+        for (int d = 0; d < 8; ++d) {
+            const int dx = d & 1, dy = (d >> 1) & 1, dz = d >> 2;
+            const bool there = !((dx && (bx == 0 || hx == 0)) || (dy && (by == 0 || hy == 0)) || (dz && (bz == 0 || hz == 0)));
+            sbv[d] = there ? (uint32_t)(bx - dx) + (uint32_t)L.nbx * ((uint32_t)(by - dy) + (uint32_t)L.nby * (uint32_t)(bz - dz)) : 0xffffffffu;
+            const uint32_t sb = there ? sbv[d] : b;
+            lo[d] = table[sb]; hi[d] = table[sb + 1];
+        }
+#pragma unroll
+        for (int d = 0; d < 8; ++d) {
+            const bool lit = sbv[d] != 0xffffffffu && lo[d] != hi[d];
+            src[d] = lit ? stage + (size_t)sbv[d] * (size_t)words : nullptr;
+            n_src += lit ? 1 : 0;
+        }
+        if (marks) for (int w = t; w < nsub; w += 256) s_flag[w] = 0;
+        __syncthreads();
+        if (n_src == 0) {
+            // no tile covers this brick: its zeros (nothing in accumulate mode), four voxels of an x row per lane where rows allow it
+            if (!accumulate) {
+                if (CH == 1 && (G.dx & 3) == 0) {
+                    for (int v = 4 * t; v < L.bvox; v += 4 * 256) {
+                        const int lx = v & (BX - 1), ly = (v >> L.lx) & (BY - 1), lz = v >> (L.lx + L.ly);
+                        const int gx = ox + lx, gy = oy + ly, gz = oz + lz;
+                        if (gx < G.dx && gy < G.dy && gz < G.dz)
+                            *reinterpret_cast<float4*>(out + ((size_t)gx + (size_t)G.dx * ((size_t)gy + (size_t)G.dy * (size_t)gz))) = make_float4(0.f, 0.f, 0.f, 0.f);
+                    }
+                } else {
+                    for (int v = t; v < L.bvox; v += 256) {
+                        const int lx = v & (BX - 1), ly = (v >> L.lx) & (BY - 1), lz = v >> (L.lx + L.ly);
+                        const int gx = ox + lx, gy = oy + ly, gz = oz + lz;
+                        if (gx >= G.dx || gy >= G.dy || gz >= G.dz) continue;
+                        const size_t o = (size_t)gx + (size_t)G.dx * ((size_t)gy + (size_t)G.dy * (size_t)gz);
+                        if (CH == 1) out[o] = 0.f; else reinterpret_cast<float4*>(out)[o] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    }
+                }
+            }
+        } else {
+            // kMergePer voxels per lane and turn; every load of a turn is requested before the first is used: one per covering tile that
+            // is there (uniform) and reaches the voxel
+            constexpr int kMergePer = CH == 4 ? 1 : 2;
+            for (int v0 = t; v0 < L.bvox; v0 += 256 * kMergePer) {
+                long long val[kMergePer][8][CH3];
+                size_t o[kMergePer];
+                bool in[kMergePer];
+                int sub[kMergePer];
+#pragma unroll
+                for (int u = 0; u < kMergePer; ++u) {
+                    const int v = v0 + 256 * u;
+                    const int lx = v & (BX - 1), ly = (v >> L.lx) & (BY - 1), lz = v >> (L.lx + L.ly);
+                    const int gx = ox + lx, gy = oy + ly, gz = oz + lz;
+                    in[u] = v < L.bvox && gx < G.dx && gy < G.dy && gz < G.dz;
+                    o[u] = (size_t)gx + (size_t)G.dx * ((size_t)gy + (size_t)G.dy * (size_t)gz);
+                    sub[u] = (lx >> 2) + (BX >> 2) * ((ly >> 2) + (BY >> 2) * (lz >> 2));
+#pragma unroll
+                    for (int d = 0; d < 8; ++d) {
+                        const int dx = d & 1, dy = (d >> 1) & 1, dz = d >> 2;
+#pragma unroll
+                        for (int c = 0; c < CH3; ++c) val[u][d][c] = 0ll;
+                        const bool reach = src[d] && in[u] && !((dx && lx >= hx) || (dy && ly >= hy) || (dz && lz >= hz));
+                        if (reach) {
+                            // (the voxel's place in a tile one brick down along an axis: that many voxels further up)
+                            const int idx = (lx + TX * (ly + TY * lz)) + (dx * BX + TX * (dy * BY + TY * (dz * BZ)));
+#pragma unroll
+                            for (int c = 0; c < CH3; ++c) val[u][d][c] = src[d][c * tvox + idx];
+                        }
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < kMergePer; ++u) {
+                    if (!in[u]) continue;
+                    long long sum[CH3];
+#pragma unroll
+                    for (int c = 0; c < CH3; ++c) sum[c] = 0ll;
+#pragma unroll
+                    for (int d = 0; d < 8; ++d)
+#pragma unroll
+                        for (int c = 0; c < CH3; ++c) sum[c] += val[u][d][c];
+                    const float fr = (float)sum[0] * invS;
+                    bool nonzero = fr != 0.f;
+                    if (CH == 1) {
+                        out[o[u]] = accumulate ? out[o[u]] + fr : fr;
+                    } else {
+                        const float fg = (float)sum[CH == 4 ? 1 : 0] * invS, fb = (float)sum[CH == 4 ? 2 : 0] * invS;
+                        nonzero = nonzero || fg != 0.f || fb != 0.f;
+                        float4* q = reinterpret_cast<float4*>(out) + o[u];
+                        if (accumulate) { const float4 tt = *q; *q = make_float4(tt.x + fr, tt.y + fg, tt.z + fb, tt.w); }
+                        else *q = make_float4(fr, fg, fb, 0.f);
+                    }
+                    if (marks && nonzero) s_flag[sub[u]] = 1;  // (same value from every writer)
+                }
+            }
+        }
+        __syncthreads();
+        if (marks)
+            for (int w = t; w < nsub; w += 256) {
+                const int sx = w % (BX >> 2), sy = (w / (BX >> 2)) % (BY >> 2), sz = w / ((BX >> 2) * (BY >> 2));
+                const int gx4 = (ox >> 2) + sx, gy4 = (oy >> 2) + sy, gz4 = (oz >> 2) + sz;
+                if (4 * gx4 < G.dx && 4 * gy4 < G.dy && 4 * gz4 < G.dz) marks[(uint32_t)gx4 + (uint32_t)nbx4 * ((uint32_t)gy4 + (uint32_t)nby4 * (uint32_t)gz4)] = s_flag[w];
+            }
+        __syncthreads();  // s_flag is cleared again for the next brick
     }
 }
 
@@ -783,36 +982,52 @@ int cpm_gather_fast_marked(cpm_ctx* ctx, const float* sorted_pos_power, const ui
     // the records were filed for ONE radius (a wider one would need copies the bin did not make)
     if (ctx->fast_last_table == brick_table && ctx->fast_last_radius != radius)
         return set_error(ctx, CPM_ERR_INVALID_ARGUMENT, "cpm_gather_fast", "radius differs from the one given to cpm_bin_fast for this table");
-    // copies of the tile (see the kernel) for the wide boxes, whose records add 16 values each into a brick that many of them share: as
-    // many (a power of two, at most CPM_BRICK_REPL) as leave two workgroups per CU their LDS.  Measured at the workspace point: frame
-    // 0.191 ms with one copy, 0.1815 with two, 0.180 with four; the narrow boxes' launches are not bound by these conflicts (config 4's
-    // size: 56.9 / 57.5 / 58.5 us with 1 / 2 / 4 copies -- the extra tiles to clear and sum cost more) and keep one.
-#ifndef CPM_BRICK_REPL
-#define CPM_BRICK_REPL 4
-#endif
-    int repl = 1;
-    while (L.maxc > 4 && repl * 2 <= CPM_BRICK_REPL && tile_bytes * (size_t)(repl * 2) <= 72 * 1024) repl *= 2;
-    tile_bytes *= (size_t)repl;
     const float k = kInv4Pi * scale;
     hipStream_t s = (hipStream_t)stream;
     // resident workgroups: two of 1024 threads per CU, fewer when there are fewer bricks
     const size_t resident = (size_t)CPM_BRICK_WG_PER_CU * (size_t)ctx->num_cus;
     const dim3 bgrid((unsigned)((size_t)L.nb < resident ? (size_t)L.nb : resident));
+    if (L.halo) {
+        // wide boxes: tiles with a halo into the staging slots, then the merge (see fast_halo_kernel).  Copies of the tile for the same-address
+        // adds of neighbouring photons: as many (a power of two, at most CPM_BRICK_REPL) as leave two workgroups per CU their LDS.
+#ifndef CPM_BRICK_REPL
+#define CPM_BRICK_REPL 4
+#endif
+        int repl = 1;
+        while (repl * 2 <= CPM_BRICK_REPL && tile_bytes * (size_t)(repl * 2) <= 72 * 1024) repl *= 2;
+        const size_t stage_bytes = (size_t)L.nb * tile_bytes;
+        long long* stage = (long long*)scratch(ctx, CPM_SCR_FAST_STAGE, stage_bytes);
+        if (!stage) return CPM_ERR_OUT_OF_MEMORY;
+        const size_t lds = tile_bytes * (size_t)repl;
+        const int wide = L.mcx <= 4 ? 4 : (L.mcx <= 6 ? 6 : 8);  // what the x loop is unrolled for
+#define CPM_HALO_LAUNCH(CH, WX)                                                                                                          \
+    do {                                                                                                                                 \
+        rc = allow_lds(ctx, fast_halo_kernel<CH, WX>, lds);                                                                              \
+        if (rc) return rc;                                                                                                               \
+        CPM_LAUNCH(ctx, (fast_halo_kernel<CH, WX>), bgrid, dim3(kBrickThreads), lds, s, sorted_pos_power, brick_table, G, L, radius, k,   \
+                   stage, repl);                                                                                                         \
+    } while (0)
+        if (G.channels == 1) { if (wide == 4) CPM_HALO_LAUNCH(1, 4); else if (wide == 6) CPM_HALO_LAUNCH(1, 6); else CPM_HALO_LAUNCH(1, 8); }
+        else { if (wide == 4) CPM_HALO_LAUNCH(4, 4); else if (wide == 6) CPM_HALO_LAUNCH(4, 6); else CPM_HALO_LAUNCH(4, 8); }
+#undef CPM_HALO_LAUNCH
+        CPM_LAUNCH_CHECK(ctx, "fast_halo_kernel");
+        const dim3 mgrid((unsigned)L.nb);
+        if (G.channels == 1) CPM_LAUNCH(ctx, fast_halo_merge_kernel<1>, mgrid, dim3(256), 0, s, stage, brick_table, G, L, k, accumulate, grid_out, nonzero_bricks);
+        else CPM_LAUNCH(ctx, fast_halo_merge_kernel<4>, mgrid, dim3(256), 0, s, stage, brick_table, G, L, k, accumulate, grid_out, nonzero_bricks);
+        CPM_LAUNCH_CHECK(ctx, "fast_halo_merge_kernel");
+        return CPM_OK;
+    }
 #define CPM_BRICK_LAUNCH(MAXC, CH)                                                                                       \
     do {                                                                                                                 \
         rc = allow_lds(ctx, fast_brick_kernel<MAXC, CH>, tile_bytes);                                                    \
         if (rc) return rc;                                                                                               \
         CPM_LAUNCH(ctx, (fast_brick_kernel<MAXC, CH>), bgrid, dim3(kBrickThreads), tile_bytes, s, sorted_pos_power, brick_table, G, L,  \
-                   radius, k, accumulate, grid_out, nonzero_bricks, repl);                                               \
+                   radius, k, accumulate, grid_out, nonzero_bricks);                                                     \
     } while (0)
-    // the wide variants by the box's width along x (what their inner loop is unrolled for): 14 = 4, 6, 8
-    const int wide = L.mcx <= 4 ? 14 : (L.mcx <= 6 ? 6 : 8);
     if (G.channels == 1) {
-        if (L.maxc <= 2) CPM_BRICK_LAUNCH(2, 1); else if (L.maxc == 3) CPM_BRICK_LAUNCH(3, 1); else if (L.maxc == 4) CPM_BRICK_LAUNCH(4, 1);
-        else if (wide == 14) CPM_BRICK_LAUNCH(14, 1); else if (wide == 6) CPM_BRICK_LAUNCH(6, 1); else CPM_BRICK_LAUNCH(8, 1);
+        if (L.maxc <= 2) CPM_BRICK_LAUNCH(2, 1); else if (L.maxc == 3) CPM_BRICK_LAUNCH(3, 1); else CPM_BRICK_LAUNCH(4, 1);
     } else {
-        if (L.maxc <= 2) CPM_BRICK_LAUNCH(2, 4); else if (L.maxc == 3) CPM_BRICK_LAUNCH(3, 4); else if (L.maxc == 4) CPM_BRICK_LAUNCH(4, 4);
-        else if (wide == 14) CPM_BRICK_LAUNCH(14, 4); else if (wide == 6) CPM_BRICK_LAUNCH(6, 4); else CPM_BRICK_LAUNCH(8, 4);
+        if (L.maxc <= 2) CPM_BRICK_LAUNCH(2, 4); else if (L.maxc == 3) CPM_BRICK_LAUNCH(3, 4); else CPM_BRICK_LAUNCH(4, 4);
     }
 #undef CPM_BRICK_LAUNCH
     CPM_LAUNCH_CHECK(ctx, "fast_brick_kernel");

@@ -80,8 +80,11 @@ def brick_count(dims, mc=None):
 
 def expected_filing(ph, dims, radius, grid):
     """(photon index, brick) pairs cpm_bin_fast must file: every stored photon under every brick its candidate voxels
-    (integers within r * textureToIndex + 1e-3 of the index-space coordinate, clipped to the grid) lie in."""
-    lg, nbk = brick_layout(dims, candidates_per_axis(radius, grid))
+    (integers within r * textureToIndex + 1e-3 of the index-space coordinate, clipped to the grid) lie in -- narrow boxes; a photon with a
+    WIDE box (more than 4 candidates along some axis) once, under the brick of the box's low corner (that brick's tile has a halo)."""
+    mc = candidates_per_axis(radius, grid)
+    lg, nbk = brick_layout(dims, mc)
+    once = max(mc) > 4
     t2i = np.array(grid.texture_to_index, np.float32)
     pairs = []
     stored = np.where(ph[:, 0] != FLT_MAX)[0]
@@ -100,7 +103,7 @@ def expected_filing(ph, dims, radius, grid):
     for lo, hi in rng_axes:
         ok &= lo <= hi
     for j in np.where(ok)[0]:
-        (lx, hx), (ly, hy), (lz, hz) = [(int(lo[j]) >> lg[a], int(hi[j]) >> lg[a]) for a, (lo, hi) in enumerate(rng_axes)]
+        (lx, hx), (ly, hy), (lz, hz) = [(int(lo[j]) >> lg[a], int(lo[j] if once else hi[j]) >> lg[a]) for a, (lo, hi) in enumerate(rng_axes)]
         for bz in range(lz, hz + 1):
             for by in range(ly, hy + 1):
                 for bx in range(lx, hx + 1):
@@ -156,7 +159,7 @@ CASES = [
     ((16, 16, 16), 1, 1, 0.866, dict(sentinels=0.0, outside=0.0)),
     ((16, 16, 16), 1, 63, 0.866, {}),
     ((16, 16, 16), 1, 4097, 0.866, {}),
-    # boxes wider than 4 candidates: the run-time record loops (fast_brick_kernel<0>)
+    # boxes wider than 4 candidates: one filing per photon, tiles with a halo, staged and merged (fast_halo_kernel + fast_halo_merge_kernel)
     ((64, 64, 64), 1, 40_000, 2.3, {}),
     ((64, 64, 64), 4, 20_000, 3.4, dict(negative=True)),
     ((40, 24, 56), 1, 30_000, 3.1, dict(cluster=0.0)),
@@ -221,6 +224,25 @@ def test_fast_accumulate_empty_and_all_sentinels(ctx, oracle, cpm):
     assert not got.any() and table[brick_count(dims)] == 0
     got, _, _ = run_fast(ctx, cpm, sent, dims, 1, radius, scale, accumulate_into=base)
     assert np.array_equal(bits(got), bits(base))
+
+
+@pytest.mark.parametrize("dims,channels,rvox", [((64, 64, 64), 1, 2.6), ((40, 24, 56), 4, 3.1), ((96, 96, 18), 1, 2.76), ((16, 16, 8), 1, 2.76)])
+def test_fast_accumulate_wide_boxes(ctx, oracle, cpm, dims, channels, rvox):
+    """Wide boxes (tiles with a halo, staged and merged): accumulate mode adds to what is there -- also in the bricks no tile covers --
+    ragged grids, 4 channels, a halo along z, a grid of one brick."""
+    rng = np.random.default_rng(dims[0] * 7 + channels)
+    n = 15_000
+    ph = make_photons(rng, n, dims, negative=channels == 4)
+    radius = float(np.float32(rvox) / np.float32(max(dims)))
+    scale = float(cpm.binding.relative_irradiance_scale(radius, float(n)))
+    cells = dims[0] * dims[1] * dims[2]
+    base = rng.random(cells if channels == 1 else (cells, 4), dtype=np.float32)
+    got, _, _ = run_fast(ctx, cpm, ph, dims, channels, radius, scale, accumulate_into=base)
+    want_fast, _ = oracle_both(oracle, ph, dims, channels, radius, scale, accumulate_into=base)
+    assert np.array_equal(bits(got), bits(want_fast))
+    # twice in a row from the same staging slots: the same bits
+    again, _, _ = run_fast(ctx, cpm, ph, dims, channels, radius, scale, accumulate_into=base)
+    assert np.array_equal(bits(again), bits(got))
 
 
 def test_fast_after_bigger_call_and_other_grid(ctx, oracle, cpm):
@@ -346,7 +368,7 @@ def test_non_finite_powers_are_ignored_photon_by_photon(ctx, oracle, cpm):
 
 
 @pytest.mark.parametrize("dims,channels,rvox", [((128, 128, 128), 1, 0.866), ((40, 24, 56), 4, 1.2), ((21, 7, 5), 1, 0.9), ((256, 256, 48), 1, 2.76),
-                                                ((256, 256, 192), 1, 1.0)])
+                                                ((256, 256, 192), 1, 1.0), ((40, 24, 56), 4, 3.1), ((64, 64, 64), 1, 2.6), ((21, 37, 5), 1, 2.4)])
 def test_gather_fast_marks_the_nonzero_bricks(ctx, oracle, cpm, dims, channels, rvox):
     """cpm_gather_fast_marked: the same light volume, plus one byte per 4x4x4-voxel brick saying whether it holds a non-zero value --
     every byte written (the buffer starts as garbage), ragged grids, 4 channels, bigger bricks and wide boxes included."""
