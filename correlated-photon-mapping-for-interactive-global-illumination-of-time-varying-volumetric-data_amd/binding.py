@@ -37,7 +37,7 @@ ABI_SYMBOLS = [
     "cpm_grid_desc_default", "cpm_relative_irradiance_scale",
     "cpm_splat", "cpm_splat_selected", "cpm_copy_indexed_photons", "cpm_snapshot_selected_photons",
     "cpm_sort_pairs", "cpm_sort_keys", "cpm_bin", "cpm_gather", "cpm_mark_touched_bricks", "cpm_gather_bricks",
-    "cpm_fast_table_entries", "cpm_gather_fast_supported", "cpm_fast_record_capacity", "cpm_bin_fast", "cpm_bin_fast_layout", "cpm_photons_convert", "cpm_gather_fast", "cpm_gather_fast_marked",
+    "cpm_fast_table_entries", "cpm_gather_fast_supported", "cpm_fast_record_capacity", "cpm_bin_fast", "cpm_bin_fast_layout", "cpm_photons_convert", "cpm_set_photon_layout", "cpm_get_photon_layout", "cpm_splat_records", "cpm_gather_fast", "cpm_gather_fast_marked",
     "cpm_volume_minmax", "cpm_volume_difference", "cpm_volume_step", "cpm_importance_tf", "cpm_importance_tf_occupancy",
     "cpm_photon_importance", "cpm_photon_importance_equal", "cpm_reset_importance",
     "cpm_select_recompute", "cpm_select_changed",
@@ -241,6 +241,9 @@ def load_library() -> C.CDLL:
         "cpm_bin_fast": (i32, [vp, vp, i32, P(GridDesc), f32, vp, vp, vp]),
         "cpm_bin_fast_layout": (i32, [vp, vp, i32, i32, P(GridDesc), f32, vp, vp, vp]),
         "cpm_photons_convert": (i32, [vp, vp, i32, vp, i32, C.c_size_t, vp]),
+        "cpm_set_photon_layout": (i32, [vp, i32]),
+        "cpm_get_photon_layout": (i32, [vp]),
+        "cpm_splat_records": (i32, [vp, vp, i32, i32, P(GridDesc), f32, f32, vp, vp]),
         "cpm_gather_fast": (i32, [vp, vp, vp, i32, P(GridDesc), f32, f32, i32, vp, vp]),
         "cpm_gather_fast_marked": (i32, [vp, vp, vp, i32, P(GridDesc), f32, f32, i32, vp, vp, vp]),
         "cpm_volume_minmax": (i32, [vp, vp, i32, vp, vp]),
@@ -587,14 +590,26 @@ class Context:
     def fast_record_capacity(self, grid: GridDesc, n: int, radius: float) -> int:
         return int(self.lib.cpm_fast_record_capacity(C.byref(grid), n, radius))
 
-    def bin_fast(self, photons, n, grid: GridDesc, radius, brick_table, sorted_pos_power, layout=0):
-        """layout: CPM_PHOTONS_INTERLEAVED (float8 records) or CPM_PHOTONS_PLANAR (what a CPM_TRACE_PHOTONS_PLANAR trace wrote)."""
-        if layout == CPM_PHOTONS_INTERLEAVED:
+    def bin_fast(self, photons, n, grid: GridDesc, radius, brick_table, sorted_pos_power, layout=None):
+        """layout: None (cpm_bin_fast: the context's layout), CPM_PHOTONS_INTERLEAVED (float8 records) or CPM_PHOTONS_PLANAR (what a
+        CPM_TRACE_PHOTONS_PLANAR trace wrote)."""
+        if layout is None:
             self._check(self.lib.cpm_bin_fast(self.h, self._ptr(photons), n, C.byref(grid), radius, self._ptr(brick_table),
                                               self._ptr(sorted_pos_power), self._stream()))
         else:
             self._check(self.lib.cpm_bin_fast_layout(self.h, self._ptr(photons), layout, n, C.byref(grid), radius, self._ptr(brick_table),
                                                      self._ptr(sorted_pos_power), self._stream()))
+
+    def set_photon_layout(self, layout):
+        """CPM_PHOTONS_INTERLEAVED / CPM_PHOTONS_PLANAR for every N * I record buffer handed to this context (cpm_set_photon_layout)."""
+        self._check(self.lib.cpm_set_photon_layout(self.h, int(layout)))
+
+    def photon_layout(self):
+        return int(self.lib.cpm_get_photon_layout(self.h))
+
+    def splat_records(self, photons, n_records, total_photons, grid: GridDesc, radius, scale, out):
+        self._check(self.lib.cpm_splat_records(self.h, self._ptr(photons), n_records, total_photons, C.byref(grid), radius, scale,
+                                               self._ptr(out), self._stream()))
 
     def photons_convert(self, src, src_layout, dst, dst_layout, n_records):
         self._check(self.lib.cpm_photons_convert(self.h, self._ptr(src), src_layout, self._ptr(dst), dst_layout, n_records, self._stream()))

@@ -123,6 +123,15 @@ int cpm_abi_version(void) { return CPM_ABI_VERSION; }
 
 // ---- measurement hooks (include/cpm/cpm_profile.h)
 void cpm_profile_enable(cpm_ctx* ctx, int on) { if (ctx) ctx->profiling = on != 0; }
+
+int cpm_set_photon_layout(cpm_ctx* ctx, int layout) {
+    if (!ctx) return CPM_ERR_INVALID_ARGUMENT;
+    if (layout != CPM_PHOTONS_INTERLEAVED && layout != CPM_PHOTONS_PLANAR)
+        return cpm::set_error(ctx, CPM_ERR_INVALID_ARGUMENT, "cpm_set_photon_layout", "layout must be CPM_PHOTONS_INTERLEAVED or CPM_PHOTONS_PLANAR");
+    ctx->photon_layout = layout;
+    return CPM_OK;
+}
+int cpm_get_photon_layout(const cpm_ctx* ctx) { return ctx ? ctx->photon_layout : CPM_PHOTONS_INTERLEAVED; }
 void cpm_profile_reset(cpm_ctx* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);  // one host thread may drive several contexts / GPUs

@@ -322,6 +322,7 @@ struct ImpGrid {
     float inv_cell[3];  // exact reciprocal of a power-of-two cell size
     int cell_pow2[3];
     Affine t2i;
+    RecLayout rec;      // where the halves of the photon records lie (the context's layout: cpm_set_photon_layout)
 };
 
 void set_cell(ImpGrid& G, int a, float cell) {
@@ -420,8 +421,8 @@ CPM_DEV uint32_t photon_importance_value(const ImpGrid& G, const uint32_t* mask,
         f3 entry = { fma_(tStart, direction.x, origin.x), fma_(tStart, direction.y, origin.y), fma_(tStart, direction.z, origin.z) };
         for (int interaction = 0; interaction < max_interactions; ++interaction) {
             size_t photonId = (size_t)photon_offset + (size_t)interaction * total_photons + threadId;
-            const float4* q = reinterpret_cast<const float4*>(photons) + 2 * photonId;
-            float4 a = q[0], b = q[1];
+            const float4* q = rec_at(photons, G.rec, photonId);
+            float4 a = q[0], b = q[G.rec.b];
             f3 exitp = { a.x, a.y, a.z };
             if (a.x == kFltMax || a.y == kFltMax || a.z == kFltMax) {
                 if (interaction == 0) {
@@ -778,10 +779,10 @@ __global__ __launch_bounds__(256) void importance_retrace_kernel(ImpGrid G, cons
         const int nInter = SINGLE ? 1 : A.p.max_interactions;
         for (int it = 0; it < nInter; ++it) {  // the records about to be replaced
             const size_t id = (size_t)photon_offset + (size_t)it * totalPhotons + (size_t)threadId;
-            const float4* q = reinterpret_cast<const float4*>(A.photons) + 2 * id;
-            float4* o = reinterpret_cast<float4*>(old_sparse) + 2 * id;
-            const float4 a = q[0], b = q[1];
-            o[0] = a; o[1] = b;
+            const float4* q = rec_at(A.photons, G.rec, id);   // (old_photons8 is laid out like photons8)
+            float4* o = rec_at(old_sparse, G.rec, id);
+            const float4 a = q[0], b = q[G.rec.b];
+            o[0] = a; o[G.rec.b] = b;
         }
         const float4* lsp = reinterpret_cast<const float4*>(A.light_samples) + 2 * (size_t)threadId;
         const float4 l0 = lsp[0], l1 = lsp[1];
@@ -968,6 +969,7 @@ int cpm_photon_importance(cpm_ctx* ctx, const float* importance_grid, const int3
     CPM_REQUIRE_ALIGNED16(ctx, light_samples8, "cpm_photon_importance");
     ImpGrid G;
     G.grid = importance_grid;
+    G.rec = rec_layout(ctx, (size_t)total_photons * (size_t)max_interactions);
     for (int a = 0; a < 3; ++a) {
         CPM_REQUIRE(ctx, grid_dims[a] >= 1 && cell_size[a] > 0.f, "cpm_photon_importance: grid dims / cell size");
         G.dims[a] = grid_dims[a];
@@ -1224,6 +1226,7 @@ int cpm_photon_importance_select(cpm_ctx* ctx, cpm_selection* s, const float* im
     CPM_REQUIRE_ALIGNED16(ctx, light_samples8, "cpm_photon_importance_select");
     ImpGrid G;
     G.grid = importance_grid;
+    G.rec = rec_layout(ctx, (size_t)total_photons * (size_t)max_interactions);
     unsigned long long cells = 1;
     for (int a = 0; a < 3; ++a) {
         CPM_REQUIRE(ctx, grid_dims[a] >= 1 && cell_size[a] > 0.f, "cpm_photon_importance_select: grid dims / cell size");
@@ -1286,7 +1289,8 @@ int retrace_impl(cpm_ctx* ctx, cpm_selection* s, const float* importance_grid, c
     int rc = cpm::make_trace_args(ctx, vol, tf, tf_scattering, aabb, &p, A, lut_bytes);
     if (rc) return rc;
     CPM_REQUIRE(ctx, !(p.flags & CPM_TRACE_PROGRESSIVE), "cpm_photon_importance_retrace: a correlated re-trace does not write the RNG state back");
-    CPM_REQUIRE(ctx, !(p.flags & CPM_TRACE_PHOTONS_PLANAR), "cpm_photon_importance_retrace: the importance pass reads float8 records (CPM_PHOTONS_INTERLEAVED)");
+    CPM_REQUIRE(ctx, !(p.flags & CPM_TRACE_PHOTONS_PLANAR) || ctx->photon_layout == CPM_PHOTONS_PLANAR,
+                "cpm_photon_importance_retrace: the importance pass reads the records in the context's layout (cpm_set_photon_layout), not a call's");
     if (n_all == 0) return CPM_OK;
     CPM_REQUIRE(ctx, importance_grid && photons8 && importances && rng_state && old_photons8, "cpm_photon_importance_retrace: null buffer");
     CPM_REQUIRE_ALIGNED16(ctx, photons8, "cpm_photon_importance_retrace");
@@ -1315,6 +1319,7 @@ int retrace_impl(cpm_ctx* ctx, cpm_selection* s, const float* importance_grid, c
     }
     ImpGrid G;
     G.grid = importance_grid;
+    G.rec = rec_layout(ctx, (size_t)p.total_photons * (size_t)p.max_interactions);
     unsigned long long cells = 1;
     for (int a = 0; a < 3; ++a) {
         CPM_REQUIRE(ctx, grid_dims[a] >= 1 && cell_size[a] > 0.f, "cpm_photon_importance_retrace: grid dims / cell size");
@@ -1369,7 +1374,7 @@ int retrace_impl(cpm_ctx* ctx, cpm_selection* s, const float* importance_grid, c
     A.isect = lights[0].isect2;
     A.rng = rng_state;
     A.photons = photons8;
-    A.rec_stride = 2u; A.rec_b = 1u;  // (the importance pass reads float8 records)
+    A.rec_stride = G.rec.stride; A.rec_b = G.rec.b;  // (the context's layout: what the importance pass reads, the re-trace writes)
     A.n_threads = lights[0].n_light_samples;
     A.p.n_light_samples = lights[0].n_light_samples;
     A.p.photon_offset = lights[0].photon_offset;

@@ -52,6 +52,8 @@ struct cpm_ctx {
     int fast_hist_parity = 0;    // which of the two (histogram, cursors) pairs the next cpm_bin_fast uses
     const void* fast_last_table = nullptr;  // the last cpm_bin_fast's table and radius: cpm_gather_fast refuses another radius for it
     float fast_last_radius = 0.f;
+    // cpm_set_photon_layout: how the photon-record buffers of N * I records handed to this context are laid out (CPM_PHOTONS_*)
+    int photon_layout = 0;
     // cpm_tf_update from host memory: the LUT goes through a ring of pinned host slots the upload kernel reads directly --
     // no staged copy ahead of the kernel, no wait for it behind (a slot is reused only after the launch that read it)
     static constexpr int kTfStageSlots = 4;
@@ -159,9 +161,21 @@ struct ProfScope {
 
 inline int div_up(long long a, long long b) { return (int)((a + b - 1) / b); }
 
+// Where the halves of photon record j lie in a record buffer (include/cpm/cpm.h, CPM_PHOTONS_*): half A = (x, y, z, powerR) at float4
+// index stride * j, half B = (powerG, powerB, theta, phi) `b` float4s behind it.  float8 records: {2, 1}; two planes of n records: {1, n}.
+struct RecLayout { uint32_t stride, b; };
+inline RecLayout rec_interleaved() { return RecLayout{ 2u, 1u }; }
+// ... of a buffer of n_records records in the context's layout (cpm_set_photon_layout)
+inline RecLayout rec_layout(const cpm_ctx* ctx, size_t n_records) {
+    return ctx->photon_layout == 1 /* CPM_PHOTONS_PLANAR */ ? RecLayout{ 1u, (uint32_t)n_records } : rec_interleaved();
+}
+__host__ __device__ inline const float4* rec_at(const float* base, RecLayout R, size_t j) { return reinterpret_cast<const float4*>(base) + (size_t)R.stride * j; }
+__host__ __device__ inline float4* rec_at(float* base, RecLayout R, size_t j) { return reinterpret_cast<float4*>(base) + (size_t)R.stride * j; }
+
 // what the last scatter pass of cpm_bin's sort also produces (cpm_sort.hip, radix_scatter_kernel<..., BINSINK>)
 struct BinSink {
-    const float* photons = nullptr;   // float8 photon records
+    const float* photons = nullptr;   // photon records ...
+    RecLayout rec = { 2u, 1u };       // ... and where their halves lie
     int channels = 1;
     uint32_t* order = nullptr;        // sorted photon indices
     float* sorted = nullptr;          // compact (pos, power) records in cell order

@@ -866,7 +866,8 @@ size_t cpm_fast_record_capacity(const cpm_grid_desc* grid, int n, float radius) 
 
 int cpm_bin_fast(cpm_ctx* ctx, const float* photons8, int n, const cpm_grid_desc* grid, float radius, uint32_t* brick_table,
                  float* sorted_pos_power, cpm_stream stream) {
-    return cpm_bin_fast_layout(ctx, photons8, CPM_PHOTONS_INTERLEAVED, n, grid, radius, brick_table, sorted_pos_power, stream);
+    if (!ctx) return CPM_ERR_INVALID_ARGUMENT;
+    return cpm_bin_fast_layout(ctx, photons8, ctx->photon_layout, n, grid, radius, brick_table, sorted_pos_power, stream);
 }
 
 int cpm_bin_fast_layout(cpm_ctx* ctx, const float* photons8, int layout, int n, const cpm_grid_desc* grid, float radius, uint32_t* brick_table,

@@ -95,19 +95,19 @@ CPM_DEV void splat_photon(float* __restrict__ out, const GridDev& G, f3 p, f3 pw
 }
 
 // splatPhotonsToLightVolumeKernel (photonstolightvolume.cl:139-166)
-__global__ __launch_bounds__(256) void splat_kernel(const float* __restrict__ photons, int n, GridDev G, float radius,
+__global__ __launch_bounds__(256) void splat_kernel(const float* __restrict__ photons, RecLayout R, int n, GridDev G, float radius,
                                                     float k, float* __restrict__ out) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const float4* q = reinterpret_cast<const float4*>(photons) + 2 * (size_t)i;
-    float4 a = q[0], b = q[1];
+    const float4* q = rec_at(photons, R, (size_t)i);
+    float4 a = q[0], b = q[R.b];
     f3 p = { a.x, a.y, a.z };
     f3 pw = { a.w * k, b.x * k, b.y * k };
     splat_photon(out, G, p, pw, radius);
 }
 
 // splatSelectedPhotonsToLightVolumeKernel (photonstolightvolume.cl:168-202)
-__global__ __launch_bounds__(256) void splat_selected_kernel(const float* __restrict__ photons,
+__global__ __launch_bounds__(256) void splat_selected_kernel(const float* __restrict__ photons, RecLayout R,
                                                              const uint32_t* __restrict__ indices, int n_indices,
                                                              GridDev G, float radius, float k, float multiplier,
                                                              int n_photons, int n_interactions,
@@ -116,8 +116,8 @@ __global__ __launch_bounds__(256) void splat_selected_kernel(const float* __rest
     if (j >= n_indices) return;
     size_t id = indices[j];
     for (int it = 0; it < n_interactions; ++it) {
-        const float4* q = reinterpret_cast<const float4*>(photons) + 2 * ((size_t)it * n_photons + id);
-        float4 a = q[0], b = q[1];
+        const float4* q = rec_at(photons, R, (size_t)it * n_photons + id);
+        float4 a = q[0], b = q[R.b];
         f3 p = { a.x, a.y, a.z };
         f3 pw = { a.w * k, b.x * k, b.y * k };
         pw.x *= multiplier; pw.y *= multiplier; pw.z *= multiplier;
@@ -126,7 +126,7 @@ __global__ __launch_bounds__(256) void splat_selected_kernel(const float* __rest
 }
 
 // copyIndexPhotonsKernel (photonstolightvolume.cl:225-248)
-__global__ __launch_bounds__(256) void copy_indexed_kernel(const float* __restrict__ photons,
+__global__ __launch_bounds__(256) void copy_indexed_kernel(const float* __restrict__ photons, RecLayout R,
                                                            const uint32_t* __restrict__ indices, int n_indices,
                                                            float multiplier, int n_photons, int n_interactions,
                                                            float* __restrict__ aligned, int out_offset) {
@@ -134,8 +134,8 @@ __global__ __launch_bounds__(256) void copy_indexed_kernel(const float* __restri
     if (j >= n_indices) return;
     size_t id = indices[j];
     for (int it = 0; it < n_interactions; ++it) {
-        const float4* q = reinterpret_cast<const float4*>(photons) + 2 * ((size_t)it * n_photons + id);
-        float4 a = q[0], b = q[1];
+        const float4* q = rec_at(photons, R, (size_t)it * n_photons + id);
+        float4 a = q[0], b = q[R.b];
         float4* o = reinterpret_cast<float4*>(aligned) + 2 * ((size_t)out_offset + j + (size_t)it * n_indices);
         o[0] = make_float4(a.x, a.y, a.z, a.w * multiplier);
         o[1] = make_float4(b.x * multiplier, b.y * multiplier, b.z, b.w);
@@ -143,7 +143,7 @@ __global__ __launch_bounds__(256) void copy_indexed_kernel(const float* __restri
 }
 
 // previous-photon snapshot refresh: only the re-traced photons move (two 16-byte accesses each way)
-__global__ __launch_bounds__(256) void snapshot_selected_kernel(const float* __restrict__ photons, const uint32_t* __restrict__ indices,
+__global__ __launch_bounds__(256) void snapshot_selected_kernel(const float* __restrict__ photons, RecLayout R, const uint32_t* __restrict__ indices,
                                                                 int n_indices, int n_photons, int n_interactions,
                                                                 float* __restrict__ snapshot) {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
@@ -151,11 +151,11 @@ __global__ __launch_bounds__(256) void snapshot_selected_kernel(const float* __r
     const uint32_t idx = indices[j % n_indices];
     if (idx >= (uint32_t)n_photons) return;
     const size_t id = (size_t)idx + (size_t)(j / n_indices) * (size_t)n_photons;
-    const float4* q = reinterpret_cast<const float4*>(photons) + 2 * id;
-    float4* o = reinterpret_cast<float4*>(snapshot) + 2 * id;
-    const float4 a = q[0], b = q[1];
+    const float4* q = rec_at(photons, R, id);
+    float4* o = rec_at(snapshot, R, id);
+    const float4 a = q[0], b = q[R.b];
     o[0] = a;
-    o[1] = b;
+    o[R.b] = b;
 }
 
 // ---- bin
@@ -166,7 +166,7 @@ __global__ __launch_bounds__(256) void snapshot_selected_kernel(const float* __r
 // tile's histogram of the first digit is counted in LDS and written where the sort's first pass expects it
 // (digit-major hist[256][tiles]), which saves that pass's histogram launch.
 template <int ITEMS>
-__global__ __launch_bounds__(256) void bin_keys_kernel(const float* __restrict__ photons, int n, GridDev G,
+__global__ __launch_bounds__(256) void bin_keys_kernel(const float* __restrict__ photons, RecLayout R, int n, GridDev G,
                                                        uint32_t cells, uint32_t* __restrict__ keys,
                                                        uint32_t* __restrict__ vals, uint32_t* __restrict__ cell_start,
                                                        uint32_t* __restrict__ hist, uint32_t num_tiles) {
@@ -184,7 +184,7 @@ __global__ __launch_bounds__(256) void bin_keys_kernel(const float* __restrict__
     for (int k = 0; k < ITEMS; ++k) {
         const int i = (int)blockIdx.x * (256 * ITEMS) + k * 256 + (int)threadIdx.x;
         if (i < n) {
-            float4 a = reinterpret_cast<const float4*>(photons)[2 * (size_t)i];
+            float4 a = *rec_at(photons, R, (size_t)i);
             uint32_t key = cells;
             if (!(a.x == kFltMax || a.y == kFltMax || a.z == kFltMax)) {
                 float fx = min_(max_(__builtin_floorf(a.x * (float)G.dx), 0.0f), (float)(G.dx - 1));
@@ -206,7 +206,7 @@ __global__ __launch_bounds__(256) void bin_keys_kernel(const float* __restrict__
 // order[j] = sorted photon index; compact (pos, power) records in cell order; and the start of
 // every run of equal keys is dropped into cell_start[key] (the table was preset to 0xffffffff).
 // Work is partitioned by photon, so clustered photons do not unbalance it.
-__global__ __launch_bounds__(256) void bin_finalize_kernel(const float* __restrict__ photons,
+__global__ __launch_bounds__(256) void bin_finalize_kernel(const float* __restrict__ photons, RecLayout R,
                                                            const uint32_t* __restrict__ sorted_keys,
                                                            const uint32_t* __restrict__ sorted_vals, int n,
                                                            int channels, uint32_t* __restrict__ order,
@@ -217,12 +217,12 @@ __global__ __launch_bounds__(256) void bin_finalize_kernel(const float* __restri
     uint32_t key = sorted_keys[j];
     if (j == 0 || sorted_keys[j - 1] != key) cell_start[key] = (uint32_t)j;  // key <= cells: inside the table
     order[j] = id;
-    const float4* q = reinterpret_cast<const float4*>(photons) + 2 * (size_t)id;
+    const float4* q = rec_at(photons, R, (size_t)id);
     float4 a = q[0];
     if (channels == 1) {
         reinterpret_cast<float4*>(sorted)[j] = a;
     } else {
-        float4 b = q[1];
+        float4 b = q[R.b];
         float4* o = reinterpret_cast<float4*>(sorted) + 2 * (size_t)j;
         o[0] = a;
         o[1] = make_float4(b.x, b.y, 0.f, 0.f);
@@ -1060,13 +1060,13 @@ __global__ __launch_bounds__(64 * NB) void gather_coop_kernel(const float* __res
 }
 
 // splat boxes of the selected photons (all interactions) -> the 4x4x4 voxel bricks they overlap
-__global__ __launch_bounds__(256) void mark_bricks_kernel(const float* __restrict__ photons, const uint32_t* __restrict__ indices,
+__global__ __launch_bounds__(256) void mark_bricks_kernel(const float* __restrict__ photons, RecLayout R, const uint32_t* __restrict__ indices,
                                                           int n_indices, int n_photons, int n_interactions, GridDev G,
                                                           float radius, int bxn, int byn, uint8_t* __restrict__ mask) {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= n_indices * n_interactions) return;
     const size_t id = (size_t)indices[j % n_indices] + (size_t)(j / n_indices) * (size_t)n_photons;
-    const float4 a = reinterpret_cast<const float4*>(photons)[2 * id];
+    const float4 a = *rec_at(photons, R, id);
     if (a.x == kFltMax || a.y == kFltMax || a.z == kFltMax) return;
     const f3 p = { a.x, a.y, a.z };
     const Box3 bb = splat_box(G, p, radius);
@@ -1092,8 +1092,8 @@ CPM_DEV void mark_bricks_of(const GridDev& G, f3 p, float radius, int bxn, int b
 // photon j: (remove the record it had before its re-trace, old_photons[k * old_stride + j] | add the one it has now) x the
 // z slices sz + {0, 1, 2}, sz + 3 + ..., of the splat box -- a few thousand photons make a latency-bound launch, and a
 // lane's chain of up to 27 dependent sqrt / divide / atomic steps is what it lasts.
-__global__ __launch_bounds__(256) void splat_delta_kernel(const float* __restrict__ old_photons, uint32_t old_stride,
-                                                          const float* __restrict__ photons, const uint32_t* __restrict__ indices,
+__global__ __launch_bounds__(256) void splat_delta_kernel(const float* __restrict__ old_photons, uint32_t old_stride, RecLayout RO,
+                                                          const float* __restrict__ photons, RecLayout R, const uint32_t* __restrict__ indices,
                                                           const int32_t* __restrict__ n_dev, int max_n, int apply_below, GridDev G,
                                                           float radius, float k, int n_photons, int n_interactions, int bxn, int byn,
                                                           uint8_t* __restrict__ mask, float* __restrict__ out) {
@@ -1108,9 +1108,10 @@ __global__ __launch_bounds__(256) void splat_delta_kernel(const float* __restric
     const size_t id = indices[j];
     for (int it = 0; it < n_interactions; ++it) {
         // old_stride == 0: the old records sit at the photons' own indices (cpm_photon_importance_retrace's old_photons8)
-        const float4* qo = reinterpret_cast<const float4*>(old_photons) + 2 * (old_stride ? (size_t)it * old_stride + (size_t)j : (size_t)it * n_photons + id);
-        const float4* qn = reinterpret_cast<const float4*>(photons) + 2 * ((size_t)it * n_photons + id);
-        const float4 oa = qo[0], ob = qo[1], na = qn[0], nb = qn[1];
+        // (RO: the compact copy of cpm_trace_selected keeps float8 records; the old records at the photons' own indices lie as the photons do)
+        const float4* qo = rec_at(old_photons, RO, old_stride ? (size_t)it * old_stride + (size_t)j : (size_t)it * n_photons + id);
+        const float4* qn = rec_at(photons, R, (size_t)it * n_photons + id);
+        const float4 oa = qo[0], ob = qo[RO.b], na = qn[0], nb = qn[R.b];
         // the same record before and after: its two splats cancel term by term
         if (__float_as_uint(oa.x) == __float_as_uint(na.x) && __float_as_uint(oa.y) == __float_as_uint(na.y) && __float_as_uint(oa.z) == __float_as_uint(na.z) &&
             __float_as_uint(oa.w) == __float_as_uint(na.w) && __float_as_uint(ob.x) == __float_as_uint(nb.x) && __float_as_uint(ob.y) == __float_as_uint(nb.y))
@@ -1147,7 +1148,13 @@ void cpm_debug_force_voxel_gather(cpm_ctx* ctx, int on) { if (ctx) ctx->dbg.gath
 
 int cpm_splat(cpm_ctx* ctx, const float* photons8, int total_photons, const cpm_grid_desc* grid, float radius,
               float scale, float* grid_out, cpm_stream stream) {
+    return cpm_splat_records(ctx, photons8, total_photons, total_photons, grid, radius, scale, grid_out, stream);
+}
+
+int cpm_splat_records(cpm_ctx* ctx, const float* photons8, int n_records, int total_photons, const cpm_grid_desc* grid, float radius,
+                      float scale, float* grid_out, cpm_stream stream) {
     CPM_ENTER(ctx);
+    CPM_REQUIRE(ctx, n_records >= total_photons, "cpm_splat_records: fewer records than photons");
     GridDev G;
     int rc = make_grid_dev(ctx, grid, G);
     if (rc) return rc;
@@ -1156,7 +1163,7 @@ int cpm_splat(cpm_ctx* ctx, const float* photons8, int total_photons, const cpm_
     CPM_REQUIRE(ctx, photons8 && grid_out, "cpm_splat: null buffer");
     CPM_REQUIRE_ALIGNED16(ctx, photons8, "cpm_splat");
     float k = kInv4Pi * scale;
-    CPM_LAUNCH(ctx, splat_kernel, dim3(div_up(total_photons, 256)), dim3(256), 0, (hipStream_t)stream, photons8,
+    CPM_LAUNCH(ctx, splat_kernel, dim3(div_up(total_photons, 256)), dim3(256), 0, (hipStream_t)stream, photons8, rec_layout(ctx, (size_t)n_records),
                        total_photons, G, radius, k, grid_out);
     CPM_LAUNCH_CHECK(ctx, "splat_kernel");
     return CPM_OK;
@@ -1175,7 +1182,7 @@ int cpm_splat_selected(cpm_ctx* ctx, const float* photons8, const uint32_t* indi
     CPM_REQUIRE_ALIGNED16(ctx, photons8, "cpm_splat_selected");
     float k = kInv4Pi * scale;
     CPM_LAUNCH(ctx, splat_selected_kernel, dim3(div_up(n_indices, 256)), dim3(256), 0, (hipStream_t)stream, photons8,
-                       indices, n_indices, G, radius, k, multiplier, n_photons, n_interactions, grid_out);
+                       rec_layout(ctx, (size_t)n_photons * n_interactions), indices, n_indices, G, radius, k, multiplier, n_photons, n_interactions, grid_out);
     CPM_LAUNCH_CHECK(ctx, "splat_selected_kernel");
     return CPM_OK;
 }
@@ -1196,8 +1203,9 @@ int cpm_splat_delta(cpm_ctx* ctx, const float* old_photons8, int old_stride, con
     CPM_REQUIRE_ALIGNED16(ctx, old_photons8, "cpm_splat_delta");
     const float k = kInv4Pi * scale;
     const long long wgs = div_up(6ll * max_indices, 256);
+    const RecLayout R = rec_layout(ctx, (size_t)n_photons * n_interactions);
     CPM_LAUNCH(ctx, splat_delta_kernel, dim3((unsigned)(wgs < 2048 ? wgs : 2048)), dim3(256), 0, (hipStream_t)stream, old_photons8,
-               (uint32_t)old_stride, photons8, indices, n_indices_dev, max_indices, apply_below, G, radius, k, n_photons, n_interactions,
+               (uint32_t)old_stride, old_stride ? rec_interleaved() : R, photons8, R, indices, n_indices_dev, max_indices, apply_below, G, radius, k, n_photons, n_interactions,
                div_up(G.dx, 4), div_up(G.dy, 4), brick_mask, grid_out);
     CPM_LAUNCH_CHECK(ctx, "splat_delta_kernel");
     return CPM_OK;
@@ -1213,7 +1221,7 @@ int cpm_copy_indexed_photons(cpm_ctx* ctx, const float* photons8, const uint32_t
     CPM_REQUIRE_ALIGNED16(ctx, photons8, "cpm_copy_indexed_photons");
     CPM_REQUIRE_ALIGNED16(ctx, aligned8, "cpm_copy_indexed_photons");
     CPM_LAUNCH(ctx, copy_indexed_kernel, dim3(div_up(n_indices, 256)), dim3(256), 0, (hipStream_t)stream, photons8,
-                       indices, n_indices, multiplier, n_photons, n_interactions, aligned8, out_offset);
+                       rec_layout(ctx, (size_t)n_photons * n_interactions), indices, n_indices, multiplier, n_photons, n_interactions, aligned8, out_offset);
     CPM_LAUNCH_CHECK(ctx, "copy_indexed_kernel");
     return CPM_OK;
 }
@@ -1228,7 +1236,8 @@ int cpm_snapshot_selected_photons(cpm_ctx* ctx, const float* photons8, const uin
     CPM_REQUIRE_ALIGNED16(ctx, photons8, "cpm_snapshot_selected_photons");
     CPM_REQUIRE_ALIGNED16(ctx, snapshot8, "cpm_snapshot_selected_photons");
     const int threads = n_indices * n_interactions;
-    CPM_LAUNCH(ctx, snapshot_selected_kernel, dim3((unsigned)div_up(threads, 256)), dim3(256), 0, (hipStream_t)stream, photons8, indices,
+    CPM_LAUNCH(ctx, snapshot_selected_kernel, dim3((unsigned)div_up(threads, 256)), dim3(256), 0, (hipStream_t)stream, photons8,
+               rec_layout(ctx, (size_t)n_photons * n_interactions), indices,
                n_indices, n_photons, n_interactions, snapshot8);
     CPM_LAUNCH_CHECK(ctx, "snapshot_selected_kernel");
     return CPM_OK;
@@ -1259,15 +1268,15 @@ int cpm_bin(cpm_ctx* ctx, const float* photons8, int n, const cpm_grid_desc* gri
         uint32_t* hist = ctx->dbg.bin_fused ? cpm::sort_first_hist(ctx, (size_t)n, kb, &num_tiles) : nullptr;
         const dim3 kgrid((unsigned)div_up(n, 256 * items));
         switch (items) {
-            case 4: CPM_LAUNCH(ctx, bin_keys_kernel<4>, kgrid, dim3(256), 0, s, photons8, n, G, cells, keys, vals, cell_start, hist, num_tiles); break;
-            case 8: CPM_LAUNCH(ctx, bin_keys_kernel<8>, kgrid, dim3(256), 0, s, photons8, n, G, cells, keys, vals, cell_start, hist, num_tiles); break;
-            default: CPM_LAUNCH(ctx, bin_keys_kernel<16>, kgrid, dim3(256), 0, s, photons8, n, G, cells, keys, vals, cell_start, hist, num_tiles); break;
+            case 4: CPM_LAUNCH(ctx, bin_keys_kernel<4>, kgrid, dim3(256), 0, s, photons8, rec_layout(ctx, (size_t)n), n, G, cells, keys, vals, cell_start, hist, num_tiles); break;
+            case 8: CPM_LAUNCH(ctx, bin_keys_kernel<8>, kgrid, dim3(256), 0, s, photons8, rec_layout(ctx, (size_t)n), n, G, cells, keys, vals, cell_start, hist, num_tiles); break;
+            default: CPM_LAUNCH(ctx, bin_keys_kernel<16>, kgrid, dim3(256), 0, s, photons8, rec_layout(ctx, (size_t)n), n, G, cells, keys, vals, cell_start, hist, num_tiles); break;
         }
         CPM_LAUNCH_CHECK(ctx, "bin_keys_kernel");
         // no copy-back after an odd number of passes: the cell-start kernel reads the keys wherever the
         // ping-pong left them; the last scatter pass writes order / records / run starts itself (BinSink)
         BinSink sink;
-        sink.photons = photons8; sink.channels = G.channels; sink.order = order; sink.sorted = sorted_pos_power;
+        sink.photons = photons8; sink.rec = rec_layout(ctx, (size_t)n); sink.channels = G.channels; sink.order = order; sink.sorted = sorted_pos_power;
         sink.cell_start = cell_start;
         rc = cpm::radix_sort(ctx, keys, vals, (size_t)n, kb, s, &keys, &vals, ctx->dbg.bin_fused ? &sink : nullptr, &finalized, hist != nullptr);
         if (rc) return rc;
@@ -1275,7 +1284,7 @@ int cpm_bin(cpm_ctx* ctx, const float* photons8, int n, const cpm_grid_desc* gri
     // run starts -> table (preset to "none" by bin_keys_kernel), then the suffix-min scan turns it into cell starts
     if (n == 0) CPM_HIP_CHECK(ctx, hipMemsetAsync(cell_start, 0xff, ((size_t)cells + 1) * sizeof(uint32_t), s));
     if (n > 0 && !finalized) {  // n == 1, the onesweep test mode, or cpm_debug_set_bin_fused(0)
-        CPM_LAUNCH(ctx, bin_finalize_kernel, dim3(div_up(n, 256)), dim3(256), 0, s, photons8, keys, vals, n, G.channels,
+        CPM_LAUNCH(ctx, bin_finalize_kernel, dim3(div_up(n, 256)), dim3(256), 0, s, photons8, rec_layout(ctx, (size_t)n), keys, vals, n, G.channels,
                            order, sorted_pos_power, cell_start);
         CPM_LAUNCH_CHECK(ctx, "bin_finalize_kernel");
     }
@@ -1315,7 +1324,8 @@ int cpm_mark_touched_bricks(cpm_ctx* ctx, const float* photons8, const uint32_t*
     CPM_REQUIRE_ALIGNED16(ctx, photons8, "cpm_mark_touched_bricks");
     const int bxn = div_up(G.dx, 4), byn = div_up(G.dy, 4);
     const long long threads = (long long)n_indices * n_interactions;
-    CPM_LAUNCH(ctx, mark_bricks_kernel, dim3((unsigned)div_up(threads, 256)), dim3(256), 0, (hipStream_t)stream, photons8, indices,
+    CPM_LAUNCH(ctx, mark_bricks_kernel, dim3((unsigned)div_up(threads, 256)), dim3(256), 0, (hipStream_t)stream, photons8,
+               rec_layout(ctx, (size_t)n_photons * n_interactions), indices,
                n_indices, n_photons, n_interactions, G, radius, bxn, byn, brick_mask);
     CPM_LAUNCH_CHECK(ctx, "mark_bricks_kernel");
     return CPM_OK;

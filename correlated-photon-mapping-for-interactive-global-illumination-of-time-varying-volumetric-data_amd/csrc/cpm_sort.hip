@@ -259,12 +259,12 @@ __global__ __launch_bounds__(kSortThreads) void radix_scatter_kernel(const uint3
             if (BINSINK) {
                 const uint32_t id = svals[i];
                 sink.order[pos] = id;
-                const float4* q = reinterpret_cast<const float4*>(sink.photons) + 2 * (size_t)id;
+                const float4* q = rec_at(sink.photons, sink.rec, (size_t)id);
                 const float4 a = q[0];
                 if (sink.channels == 1) {
                     reinterpret_cast<float4*>(sink.sorted)[pos] = a;
                 } else {
-                    const float4 b = q[1];
+                    const float4 b = q[sink.rec.b];
                     float4* o = reinterpret_cast<float4*>(sink.sorted) + 2 * (size_t)pos;
                     o[0] = a;
                     o[1] = make_float4(b.x, b.y, 0.f, 0.f);

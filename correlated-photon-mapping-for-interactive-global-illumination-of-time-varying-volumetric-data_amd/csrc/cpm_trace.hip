@@ -334,7 +334,7 @@ int trace_impl(cpm_ctx* ctx, const cpm_volume* vol, const cpm_tf* tf, const cpm_
     if (sel.old_photons) CPM_REQUIRE_ALIGNED16(ctx, sel.old_photons, "cpm_trace_selected");
     A.rng = rng_state;
     A.photons = photons8;
-    const bool planar = (p.flags & CPM_TRACE_PHOTONS_PLANAR) != 0;
+    const bool planar = (p.flags & CPM_TRACE_PHOTONS_PLANAR) != 0 || ctx->photon_layout == CPM_PHOTONS_PLANAR;
     A.rec_stride = planar ? 1u : 2u;
     A.rec_b = planar ? (uint32_t)((long long)p.total_photons * p.max_interactions) : 1u;
     if (sel.lights) {

@@ -3,6 +3,7 @@
 // photon tracer -> photon-to-light-volume, plus min/max -> importance -> tracer) and evaluates it,
 // so that tests can drive the C++ surface through ctypes.  Connections follow
 // workspaces/CorrelatedPhotonMappingSingleVolume.inv:1178-1271.
+#include <vector>
 #include <chrono>
 #include <cstring>
 #include <sstream>
@@ -162,9 +163,17 @@ int cpmh_download_light_volume(cpmh_network* net, float* out) {
     return hipMemcpy(out, lv->data.device(), lv->data.getSizeInBytes(), hipMemcpyDeviceToHost) == hipSuccess ? 0 : -1;
 }
 int cpmh_n_photons(cpmh_network* net) { auto p = net->tracer.outport_.getData(); return p ? (int)p->getNumberOfPhotons() : 0; }
+// out: float8 records (the reference's), whatever layout the library keeps them in on the device
 int cpmh_download_photons(cpmh_network* net, float* out) {
     auto p = net->tracer.outport_.getData();
-    return hipMemcpy(out, p->photons_.device(), p->photons_.getSizeInBytes(), hipMemcpyDeviceToHost) == hipSuccess ? 0 : -1;
+    if (hipMemcpy(out, p->photons_.device(), p->photons_.getSizeInBytes(), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    if (cpm_get_photon_layout(CpmRuntime::get().ctx()) == CPM_PHOTONS_PLANAR) {
+        const size_t n = p->photons_.getSizeInBytes() / 32;  // records
+        std::vector<float> planes(out, out + 8 * n);
+        for (size_t j = 0; j < n; ++j)
+            for (int c = 0; c < 4; ++c) { out[8 * j + c] = planes[4 * j + c]; out[8 * j + 4 + c] = planes[4 * (n + j) + c]; }
+    }
+    return 0;
 }
 int cpmh_n_recomputed(cpmh_network* net) { auto r = net->tracer.recomputedIndicesPort_.getData(); return r ? r->resolveCount() : -1; }
 int cpmh_remaining(cpmh_network* net) { return net->tracer.remainingPhotonsToUpdate(); }

@@ -32,6 +32,11 @@ CpmRuntime::CpmRuntime() {
     const char* e = std::getenv("CPM_PROFILING");
     profiling_ = ctx_ && e && e[0] && e[0] != '0';
     if (profiling_) cpm_profile_enable(ctx_, 1);
+    // The records travel from processor to processor inside this library only, so they lie the way the device reads them fastest: two
+    // planes (the brick bin of a one-channel light volume then streams 16 of a record's 32 bytes).  CPM_HOST_PHOTON_LAYOUT=interleaved keeps
+    // the reference's float8 record in the buffers (what a processor outside this library reading the `photons` port would expect).
+    const char* lay = std::getenv("CPM_HOST_PHOTON_LAYOUT");
+    if (ctx_ && !(lay && std::string(lay) == "interleaved")) cpm_set_photon_layout(ctx_, CPM_PHOTONS_PLANAR);
 }
 void CpmRuntime::beginProfile() const {
     if (profiling_) cpm_profile_reset(ctx_);
@@ -1244,7 +1249,7 @@ void PhotonToLightVolumeProcessorCL::process() {  // photontolightvolumeprocesso
     } else if (fresh || !havePrev || nRecomputed < 0 || nRecomputed >= maxRecomputationPhotons) {
         if (formulation_.get() == "splat") {  // the reference's formulation: clear + atomic splat (:299-339)
             (void)hipMemsetAsync(out, 0, cells * channels * sizeof(float), rt.stream());
-            rt.check(cpm_splat(rt.ctx(), photons, nPhotons, &g, radius, scale, out, rt.stream()), "cpm_splat");
+            rt.check(cpm_splat_records(rt.ctx(), photons, nPhotons * nInter, nPhotons, &g, radius, scale, out, rt.stream()), "cpm_splat");
         } else if (formulation_.get() == "fast" && cpm_gather_fast_supported(&g, radius)) {
             // brick bin + LDS-tile gather, fixed-point sums: the reference's terms within the stated fp32 tolerance
             const size_t m = (size_t)nPhotons * nInter;

@@ -217,7 +217,7 @@ class PhotonFrame:
         self._order_stale = False
         self.brick_table = None   # cpm_bin_fast's table and records (every photon in all the bricks it reaches), allocated on first use
         self.sorted_fast = None
-        self.photon_layout = B.CPM_PHOTONS_INTERLEAVED   # how self.photons is laid out (set_planar_records)
+        self.photon_layout = ctx.photon_layout()   # how self.photons is laid out: the context's layout (cpm_set_photon_layout), or set_planar_records
         self._records8 = None
 
     def set_planar_records(self, on=True):

@@ -192,8 +192,18 @@ enum {
  *   in cl/photontracer.cl:166).  The tracer writes the same two 16-byte stores per record either way; what reads only position and
  *   the first power channel -- the brick bin of a one-channel light volume -- then streams 16 bytes per record instead of 32.
  *   Written by cpm_trace / cpm_trace_emitted / cpm_trace_lights with CPM_TRACE_PHOTONS_PLANAR, read by cpm_bin_fast_layout,
- *   converted by cpm_photons_convert for every other consumer. */
+ *   converted by cpm_photons_convert -- call by call; or, for a whole context, cpm_set_photon_layout. */
 enum { CPM_PHOTONS_INTERLEAVED = 0, CPM_PHOTONS_PLANAR = 1 };
+/* The layout of this context's photon-record buffers (default CPM_PHOTONS_INTERLEAVED).  With CPM_PHOTONS_PLANAR every buffer of
+ * N * I records -- `photons8` of every entry point, the snapshot of cpm_snapshot_selected_photons, `old_photons8` of
+ * cpm_photon_importance_retrace[_lights] and of cpm_splat_delta with old_stride = 0 (all "laid out like photons8") -- is read and
+ * written as two planes of N * I float4 (the tracers as if CPM_TRACE_PHOTONS_PLANAR were given, cpm_bin_fast as
+ * cpm_bin_fast_layout(.., CPM_PHOTONS_PLANAR, ..)); results are the same bits, records sit at other addresses.  The compact,
+ * index-ordered copies keep the float8 record whatever the context says: `aligned8` of cpm_copy_indexed_photons, `old_photons8` of
+ * cpm_trace_selected and of cpm_splat_delta with old_stride > 0.  What the reference's host code never sees (it hands the buffers
+ * from processor to processor); libcpm_host.so runs its network this way. */
+int cpm_set_photon_layout(cpm_ctx* ctx, int layout);
+int cpm_get_photon_layout(const cpm_ctx* ctx);
 enum { CPM_PHASE_HENYEY_GREENSTEIN = 0, CPM_PHASE_ISOTROPIC = 1 };
 
 /* Scalar arguments of photonTracerKernel
@@ -320,6 +330,10 @@ float cpm_relative_irradiance_scale(double radius_relative_to_scene, double n_ph
  * Replaces splatPhotonsToLightVolumeKernel (ref cl/photonstolightvolume.cl:139-166). */
 int cpm_splat(cpm_ctx* ctx, const float* photons8, int total_photons, const cpm_grid_desc* grid,
               float radius, float relative_irradiance_scale, float* grid_out, cpm_stream stream);
+/* ... from a buffer of n_records >= total_photons records (N * I of them, of which the first N are splatted): what a planar context
+ * (cpm_set_photon_layout) needs to find plane B; cpm_splat takes n_records = total_photons. */
+int cpm_splat_records(cpm_ctx* ctx, const float* photons8, int n_records, int total_photons, const cpm_grid_desc* grid,
+                      float radius, float relative_irradiance_scale, float* grid_out, cpm_stream stream);
 
 /* grid += multiplier * splat of photons[indices[j] + k * n_photons], k < n_interactions.
  * Replaces splatSelectedPhotonsToLightVolumeKernel (ref cl/photonstolightvolume.cl:168-202). */
