@@ -422,7 +422,7 @@ CPM_DEV uint32_t photon_importance_value(const ImpGrid& G, const uint32_t* mask,
         for (int interaction = 0; interaction < max_interactions; ++interaction) {
             size_t photonId = (size_t)photon_offset + (size_t)interaction * total_photons + threadId;
             const float4* q = rec_at(photons, G.rec, photonId);
-            float4 a = q[0], b = q[G.rec.b];
+            const float4 a = q[0];   // (half B -- the direction -- only where a later interaction left the volume: in two planes it is another line)
             f3 exitp = { a.x, a.y, a.z };
             if (a.x == kFltMax || a.y == kFltMax || a.z == kFltMax) {
                 if (interaction == 0) {
@@ -437,6 +437,7 @@ CPM_DEV uint32_t photon_importance_value(const ImpGrid& G, const uint32_t* mask,
                     break;
                 } else {
                     float t0 = 0.f, t1 = kFltMax;
+                    const float4 b = q[G.rec.b];
                     f3 pd = decode_direction_(b.z, b.w);
                     if (a.w != kFltMax && ray_box_(bmin, bmax, entry, pd, t0, t1)) {
                         exitp.x = fma_(t1, pd.x, entry.x);

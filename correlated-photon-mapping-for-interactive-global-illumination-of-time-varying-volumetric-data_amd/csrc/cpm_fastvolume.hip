@@ -161,9 +161,12 @@ __host__ bool brick_reach(const GridDev& G, float radius, BrickLayout& L) {
         if (mc[a] > (1 << lg[a]) && nbr[a] > 1) return false;
     return true;
 }
+// a tile with a halo: voxels per x row -- the brick's, the halo's, and one more where that makes the count even (the merge reads
+// voxels in pairs, 16 bytes; the odd column stays zero)
+__host__ __device__ inline int halo_pitch_x(const BrickLayout& L) { return ((1 << L.lx) + L.mcx) & ~1; }
 // voxels of a brick's LDS tile: the brick, with its halo where photons are filed once
 __host__ __device__ inline int tile_voxels(const BrickLayout& L) {
-    return L.halo ? ((1 << L.lx) + L.mcx - 1) * ((1 << L.ly) + L.mcy - 1) * ((1 << L.lz) + L.mcz - 1) : L.bvox;
+    return L.halo ? halo_pitch_x(L) * ((1 << L.ly) + L.mcy - 1) * ((1 << L.lz) + L.mcz - 1) : L.bvox;
 }
 __host__ size_t tile_bytes_for(const GridDev& G, const BrickLayout& L) { return (size_t)(G.channels == 4 ? 3 : 1) * (size_t)tile_voxels(L) * 8; }
 
@@ -628,7 +631,7 @@ __global__ __launch_bounds__(kBrickThreads, (CH == 4 ? 4 : CPM_BRICK_WAVES)) voi
     extern __shared__ long long s_tile[];
     constexpr int CH3 = CH == 4 ? 3 : 1, STRIDE = CH == 4 ? 2 : 1;
     const int t = threadIdx.x;
-    const int TX = (1 << L.lx) + L.mcx - 1, TY = (1 << L.ly) + L.mcy - 1;
+    const int TX = halo_pitch_x(L), TY = (1 << L.ly) + L.mcy - 1;
     const int tvox = tile_voxels(L), words = CH3 * tvox;
     const float rgx = radius * G.t2i.sx + 1e-3f, rgy = radius * G.t2i.sy + 1e-3f, rgz = radius * G.t2i.sz + 1e-3f;
     const float r2 = radius * radius, inv_r2 = 1.0f / r2;
@@ -686,7 +689,7 @@ __global__ __launch_bounds__(256) void fast_halo_merge_kernel(const long long* _
     const int t = threadIdx.x;
     const int BX = 1 << L.lx, BY = 1 << L.ly, BZ = 1 << L.lz;
     const int hx = L.mcx - 1, hy = L.mcy - 1, hz = L.mcz - 1;
-    const int TX = BX + hx, TY = BY + hy;
+    const int TX = halo_pitch_x(L), TY = BY + hy;
     const int tvox = tile_voxels(L), words = CH3 * tvox;
     const int nbx4 = (G.dx + 3) >> 2, nby4 = (G.dy + 3) >> 2, nsub = L.bvox >> 6;
     const float S = fixed_scale(__uint_as_float(table[off_meta(L) + kMetaMaxPow]), k);
@@ -736,58 +739,79 @@ __global__ __launch_bounds__(256) void fast_halo_merge_kernel(const long long* _
                 }
             }
         } else {
-            // kMergePer voxels per lane and turn; every load of a turn is requested before the first is used: one per covering tile that
-            // is there (uniform) and reaches the voxel
+            // a lane takes PAIRS of voxels along x (16-byte loads: the tile's rows hold an even number of voxels, a pair never straddles the
+            // brick's edge or a tile's), kMergePer pairs per turn; every load of a turn is requested before the first is used: one per
+            // covering tile that is there (uniform) and reaches the pair's first voxel; the second voxel's value is dropped where that
+            // tile does not reach it
+            typedef long long ll2 __attribute__((ext_vector_type(2)));
             constexpr int kMergePer = CH == 4 ? 1 : 2;
-            for (int v0 = t; v0 < L.bvox; v0 += 256 * kMergePer) {
-                long long val[kMergePer][8][CH3];
+            const int pairs = L.bvox >> 1, hbx = BX >> 1;
+            for (int w0 = t; w0 < pairs; w0 += 256 * kMergePer) {
+                ll2 val[kMergePer][8][CH3];
+                uint32_t second[kMergePer];   // bit d: tile d reaches the pair's second voxel too
                 size_t o[kMergePer];
                 bool in[kMergePer];
-                int sub[kMergePer];
+                int sub[kMergePer], gxs[kMergePer];
 #pragma unroll
                 for (int u = 0; u < kMergePer; ++u) {
-                    const int v = v0 + 256 * u;
-                    const int lx = v & (BX - 1), ly = (v >> L.lx) & (BY - 1), lz = v >> (L.lx + L.ly);
+                    const int w = w0 + 256 * u;
+                    const int lx = 2 * (w & (hbx - 1)), ly = (w >> (L.lx - 1)) & (BY - 1), lz = w >> (L.lx - 1 + L.ly);
                     const int gx = ox + lx, gy = oy + ly, gz = oz + lz;
-                    in[u] = v < L.bvox && gx < G.dx && gy < G.dy && gz < G.dz;
+                    in[u] = w < pairs && gx < G.dx && gy < G.dy && gz < G.dz;
+                    gxs[u] = gx;
                     o[u] = (size_t)gx + (size_t)G.dx * ((size_t)gy + (size_t)G.dy * (size_t)gz);
                     sub[u] = (lx >> 2) + (BX >> 2) * ((ly >> 2) + (BY >> 2) * (lz >> 2));
+                    second[u] = 0u;
 #pragma unroll
                     for (int d = 0; d < 8; ++d) {
                         const int dx = d & 1, dy = (d >> 1) & 1, dz = d >> 2;
 #pragma unroll
-                        for (int c = 0; c < CH3; ++c) val[u][d][c] = 0ll;
+                        for (int c = 0; c < CH3; ++c) val[u][d][c] = ll2{ 0ll, 0ll };
                         const bool reach = src[d] && in[u] && !((dx && lx >= hx) || (dy && ly >= hy) || (dz && lz >= hz));
                         if (reach) {
                             // (the voxel's place in a tile one brick down along an axis: that many voxels further up)
                             const int idx = (lx + TX * (ly + TY * lz)) + (dx * BX + TX * (dy * BY + TY * (dz * BZ)));
+                            second[u] |= (!dx || lx + 1 < hx) ? (1u << d) : 0u;
 #pragma unroll
-                            for (int c = 0; c < CH3; ++c) val[u][d][c] = src[d][c * tvox + idx];
+                            for (int c = 0; c < CH3; ++c) val[u][d][c] = *reinterpret_cast<const ll2*>(src[d] + c * tvox + idx);
                         }
                     }
                 }
 #pragma unroll
                 for (int u = 0; u < kMergePer; ++u) {
                     if (!in[u]) continue;
-                    long long sum[CH3];
+                    long long sum0[CH3], sum1[CH3];
 #pragma unroll
-                    for (int c = 0; c < CH3; ++c) sum[c] = 0ll;
+                    for (int c = 0; c < CH3; ++c) { sum0[c] = 0ll; sum1[c] = 0ll; }
 #pragma unroll
                     for (int d = 0; d < 8; ++d)
 #pragma unroll
-                        for (int c = 0; c < CH3; ++c) sum[c] += val[u][d][c];
-                    const float fr = (float)sum[0] * invS;
-                    bool nonzero = fr != 0.f;
+                        for (int c = 0; c < CH3; ++c) { sum0[c] += val[u][d][c].x; sum1[c] += ((second[u] >> d) & 1u) ? val[u][d][c].y : 0ll; }
+                    const bool two = gxs[u] + 1 < G.dx;
+                    const float f0 = (float)sum0[0] * invS, f1 = (float)sum1[0] * invS;
+                    bool nonzero = f0 != 0.f || (two && f1 != 0.f);
                     if (CH == 1) {
-                        out[o[u]] = accumulate ? out[o[u]] + fr : fr;
+                        if (two && (o[u] & 1) == 0) {
+                            float2* q = reinterpret_cast<float2*>(out + o[u]);
+                            if (accumulate) { const float2 tt = *q; *q = make_float2(tt.x + f0, tt.y + f1); } else *q = make_float2(f0, f1);
+                        } else {
+                            out[o[u]] = accumulate ? out[o[u]] + f0 : f0;
+                            if (two) out[o[u] + 1] = accumulate ? out[o[u] + 1] + f1 : f1;
+                        }
                     } else {
-                        const float fg = (float)sum[CH == 4 ? 1 : 0] * invS, fb = (float)sum[CH == 4 ? 2 : 0] * invS;
-                        nonzero = nonzero || fg != 0.f || fb != 0.f;
+                        const float g0 = (float)sum0[CH == 4 ? 1 : 0] * invS, b0 = (float)sum0[CH == 4 ? 2 : 0] * invS;
+                        const float g1 = (float)sum1[CH == 4 ? 1 : 0] * invS, b1 = (float)sum1[CH == 4 ? 2 : 0] * invS;
+                        nonzero = nonzero || g0 != 0.f || b0 != 0.f || (two && (g1 != 0.f || b1 != 0.f));
                         float4* q = reinterpret_cast<float4*>(out) + o[u];
-                        if (accumulate) { const float4 tt = *q; *q = make_float4(tt.x + fr, tt.y + fg, tt.z + fb, tt.w); }
-                        else *q = make_float4(fr, fg, fb, 0.f);
+                        if (accumulate) {
+                            const float4 tt = q[0]; q[0] = make_float4(tt.x + f0, tt.y + g0, tt.z + b0, tt.w);
+                            if (two) { const float4 t1 = q[1]; q[1] = make_float4(t1.x + f1, t1.y + g1, t1.z + b1, t1.w); }
+                        } else {
+                            q[0] = make_float4(f0, g0, b0, 0.f);
+                            if (two) q[1] = make_float4(f1, g1, b1, 0.f);
+                        }
                     }
-                    if (marks && nonzero) s_flag[sub[u]] = 1;  // (same value from every writer)
+                    if (marks && nonzero) s_flag[sub[u]] = 1;  // (same value from every writer; a pair lies in one 4 x 4 x 4 sub-brick)
                 }
             }
         }
