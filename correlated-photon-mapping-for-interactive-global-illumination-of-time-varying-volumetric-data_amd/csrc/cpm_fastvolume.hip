@@ -845,7 +845,8 @@ __host__ int allow_lds(cpm_ctx* ctx, K kernel, size_t bytes) {
     return CPM_OK;
 }
 
-__host__ int copies_per_photon(const BrickLayout& L) { return L.maxc > 1 ? 8 : 1; }
+// records a photon can be filed as: one per brick its box touches (two per axis at most); a wide box is filed once (tiles with a halo)
+__host__ int copies_per_photon(const BrickLayout& L) { return L.halo ? 1 : (L.maxc > 1 ? 8 : 1); }
 
 }  // namespace
 

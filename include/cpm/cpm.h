@@ -425,8 +425,10 @@ int cpm_gather_bricks(cpm_ctx* ctx, const float* sorted_pos_power, const uint32_
  * order of the records inside a brick is unspecified.  A photon whose candidate voxels (the integers within
  * r * textureToIndex + 1e-3 of its index-space coordinate, per axis, clipped to the grid) straddle a brick face is filed
  * under EVERY brick they lie in (at most 8; 0.3 % of the photons are filed twice at BASELINE config 2), so a brick's
- * voxels receive from that brick's records alone and the gather is one launch.  Sentinel photons and photons that
- * reach no voxel are dropped.
+ * voxels receive from that brick's records alone and the gather is one launch.  A photon with a WIDE box (5 - 8 candidates
+ * along some axis) is filed ONCE, under the brick of its box's low corner: that brick's tile carries a halo, tiles are staged as
+ * 64-bit sums and a second launch of cpm_gather_fast adds the tiles that cover a voxel before the one rounding (context scratch:
+ * one tile per brick of the grid) -- the same bits.  Sentinel photons and photons that reach no voxel are dropped.
  * The reference adds with CAS float atomics in arrival order (ref cl/photonstolightvolume.cl:15-29,62-75). */
 
 /* u32 entries of the brick table cpm_bin_fast fills on this grid (0 = bad arguments): brick starts, max |power|, radius. */
@@ -436,8 +438,8 @@ size_t cpm_fast_table_entries(const cpm_grid_desc* grid, int n);
  * light volume; up to 4 per axis the record loops are unrolled, wider boxes take run-time loops), positive axis-aligned
  * textureToIndex; otherwise use cpm_bin + cpm_gather. */
 int cpm_gather_fast_supported(const cpm_grid_desc* grid, float radius);
-/* Records sorted_pos_power must hold for n photons at this radius (every photon in all its bricks: 8 n, or n when a
- * candidate box is a single voxel wide); 0 when unsupported. */
+/* Records sorted_pos_power must hold for n photons at this radius (every photon in all its bricks: 8 n; n when a
+ * candidate box is a single voxel wide, or wide -- filed once); 0 when unsupported. */
 size_t cpm_fast_record_capacity(const cpm_grid_desc* grid, int n, float radius);
 
 /* brick_table (device, cpm_fast_table_entries(grid, n) u32): brick starts (brick_table[bricks] = records written), max

@@ -152,7 +152,8 @@ def test_fast_formulation_sizing_is_host_arithmetic(cpm):
         assert lib.cpm_gather_fast_supported(C.byref(g), C.c_float(2.8 * r1)) == 1     # 6 candidates: the wide kernels
         assert lib.cpm_gather_fast_supported(C.byref(g), C.c_float(4.6 * r1)) == 0     # 10 candidates: cpm_bin + cpm_gather
         assert lib.cpm_gather_fast_supported(C.byref(g), C.c_float(0.0)) == 0
-        assert lib.cpm_fast_record_capacity(C.byref(g), 1000, C.c_float(2.8 * r1)) == 8000
+        assert lib.cpm_fast_record_capacity(C.byref(g), 1000, C.c_float(2.8 * r1)) == 1000     # a wide box is filed once
+        assert lib.cpm_fast_record_capacity(C.byref(g), 1000, C.c_float(1.2 * r1)) == 8000
         assert lib.cpm_fast_record_capacity(C.byref(g), 1000, C.c_float(4.6 * r1)) == 0
     g = B.default_grid_desc((400, 8, 16), 1)       # reach 1 along every axis: one record per photon
     assert lib.cpm_fast_record_capacity(C.byref(g), 1000, C.c_float(0.4 / 400)) == 1000
