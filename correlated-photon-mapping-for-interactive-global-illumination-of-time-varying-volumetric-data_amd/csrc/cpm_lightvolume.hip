@@ -71,12 +71,14 @@ CPM_DEV float splat_weight(f3 c, f3 p, float radius) {
 }
 
 // splatPhoton (photonstolightvolume.cl:31-79) with the power already scaled; z_first / z_step: the slices
-// sz + z_first, sz + z_first + z_step, ... of the box only (0 / 1 = the whole box; lanes sharing a photon split it by slice)
-CPM_DEV void splat_photon(float* __restrict__ out, const GridDev& G, f3 p, f3 pw, float radius, int z_first = 0, int z_step = 1) {
+// sz + z_first, sz + z_first + z_step, ... of the box only (0 / 1 = the whole box; lanes sharing a photon split it by slice),
+// y_first / y_step: likewise its rows
+CPM_DEV void splat_photon(float* __restrict__ out, const GridDev& G, f3 p, f3 pw, float radius, int z_first = 0, int z_step = 1,
+                          int y_first = 0, int y_step = 1) {
     if (p.x == kFltMax || p.y == kFltMax || p.z == kFltMax) return;
     Box3 bx = splat_box(G, p, radius);
     for (int z = bx.sz + z_first; z < bx.ez; z += z_step)
-        for (int y = bx.sy; y < bx.ey; ++y)
+        for (int y = bx.sy + y_first; y < bx.ey; y += y_step)
             for (int x = bx.sx; x < bx.ex; ++x) {
                 size_t voxel = (size_t)x + (size_t)y * G.dx + (size_t)z * G.dx * G.dy;
                 f3 vi = { (float)x, (float)y, (float)z };
@@ -1090,21 +1092,23 @@ CPM_DEV void mark_bricks_of(const GridDev& G, f3 p, float radius, int bxn, int b
 // splatSelectedPhotonsToLightVolumeKernel twice (photonstolightvolume.cl:168-202 as called at
 // processor/photontolightvolumeprocessorcl.cpp:268-274) in one launch over a device-side count.  Six lanes per selected
 // photon j: (remove the record it had before its re-trace, old_photons[k * old_stride + j] | add the one it has now) x the
-// z slices sz + {0, 1, 2}, sz + 3 + ..., of the splat box -- a few thousand photons make a latency-bound launch, and a
-// lane's chain of up to 27 dependent sqrt / divide / atomic steps is what it lasts.
+// z slices sz + {0, 1, 2}, sz + 3 + ..., of the splat box (x `yparts` groups of its rows where the box is wide: the workspace's
+// 7 x 7 x 3 voxels) -- a few thousand photons make a latency-bound launch, and a lane's chain of dependent sqrt / divide / atomic
+// steps (up to 27; 49 for a wide box before its rows were split) is what it lasts.
 __global__ __launch_bounds__(256) void splat_delta_kernel(const float* __restrict__ old_photons, uint32_t old_stride, RecLayout RO,
                                                           const float* __restrict__ photons, RecLayout R, const uint32_t* __restrict__ indices,
                                                           const int32_t* __restrict__ n_dev, int max_n, int apply_below, GridDev G,
                                                           float radius, float k, int n_photons, int n_interactions, int bxn, int byn,
-                                                          uint8_t* __restrict__ mask, float* __restrict__ out) {
+                                                          uint8_t* __restrict__ mask, float* __restrict__ out, int yparts) {
     const int n = min(*n_dev, max_n);
     if (apply_below > 0 && n >= apply_below) return;
+    const int parts = 6 * yparts;
     // (the launch is sized for a few thousand photons, not for the budget: a grid over 6 x max_n lanes is thousands of
     // workgroups that read the count and leave -- 4 us of dispatch at 1 M photons; larger counts stride)
-    for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < 6ll * n; t += (long long)gridDim.x * blockDim.x) {
-    const int j = (int)(t / 6), part = (int)(t - 6ll * j);
+    for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < (long long)parts * n; t += (long long)gridDim.x * blockDim.x) {
+    const int j = (int)(t / parts), part = (int)(t - (long long)parts * j);
     const bool add = part & 1;
-    const int zpart = part >> 1;
+    const int zpart = (part >> 1) % 3, ypart = (part >> 1) / 3;
     const size_t id = indices[j];
     for (int it = 0; it < n_interactions; ++it) {
         // old_stride == 0: the old records sit at the photons' own indices (cpm_photon_importance_retrace's old_photons8)
@@ -1121,8 +1125,8 @@ __global__ __launch_bounds__(256) void splat_delta_kernel(const float* __restric
         f3 p = { a.x, a.y, a.z };
         f3 pw = { a.w * k, b.x * k, b.y * k };
         pw.x *= m; pw.y *= m; pw.z *= m;
-        splat_photon(out, G, p, pw, radius, zpart, 3);
-        if (mask && zpart == 0) mark_bricks_of(G, p, radius, bxn, byn, mask);
+        splat_photon(out, G, p, pw, radius, zpart, 3, ypart, yparts);
+        if (mask && zpart == 0 && ypart == 0) mark_bricks_of(G, p, radius, bxn, byn, mask);
     }
     }
 }
@@ -1202,11 +1206,13 @@ int cpm_splat_delta(cpm_ctx* ctx, const float* old_photons8, int old_stride, con
     CPM_REQUIRE_ALIGNED16(ctx, photons8, "cpm_splat_delta");
     CPM_REQUIRE_ALIGNED16(ctx, old_photons8, "cpm_splat_delta");
     const float k = kInv4Pi * scale;
-    const long long wgs = div_up(6ll * max_indices, 256);
+    // a box more than 4 rows high: its rows in 4 groups (a lane's chain of dependent splat steps is what the launch lasts)
+    const int yparts = 2.f * radius * G.t2i.sy + 1.f > 4.f ? 4 : 1;
+    const long long wgs = div_up(6ll * yparts * max_indices, 256);
     const RecLayout R = rec_layout(ctx, (size_t)n_photons * n_interactions);
     CPM_LAUNCH(ctx, splat_delta_kernel, dim3((unsigned)(wgs < 2048 ? wgs : 2048)), dim3(256), 0, (hipStream_t)stream, old_photons8,
                (uint32_t)old_stride, old_stride ? rec_interleaved() : R, photons8, R, indices, n_indices_dev, max_indices, apply_below, G, radius, k, n_photons, n_interactions,
-               div_up(G.dx, 4), div_up(G.dy, 4), brick_mask, grid_out);
+               div_up(G.dx, 4), div_up(G.dy, 4), brick_mask, grid_out, yparts);
     CPM_LAUNCH_CHECK(ctx, "splat_delta_kernel");
     return CPM_OK;
 }
