@@ -23,9 +23,9 @@
 //                               does not depend on the order lanes, waves or runs add in: bitwise reproducible with no
 //                               ordering protocol at all -- then ONE rounding to float and a coalesced store of the
 //                               brick (zeros for a brick nothing reaches).  No halos, no slabs, no second launch:
-//                               what the records' duplication buys -- for boxes of up to 4 candidates per axis.
-//          fast_halo_kernel +   WIDE boxes (5 - 8 candidates along some axis; the workspace's 6 x 6 x 2): duplication stops paying
-//          fast_halo_merge_...  (1.7 copies per photon, each as dear to a wave as a whole box), so a photon is filed once, under the
+//                               what the records' duplication buys -- for boxes of up to 3 candidates per axis.
+//          fast_halo_kernel +   boxes of 4 - 8 candidates along some axis (the workspace's 6 x 6 x 2): duplication stops paying (1.7
+//          fast_halo_merge_...  to 2.2 copies per photon, each as dear to a wave as a whole box), so a photon is filed once, under the
 //                               brick of its box's low corner; that brick's tile has a halo on its high sides, tiles go to a
 //                               staging slot per brick as 64-bit sums, and a second launch adds the <= 8 tiles that cover a
 //                               voxel -- still integers, still one rounding, the same bits.
@@ -71,7 +71,7 @@ struct BrickLayout {
     int maxc;               // candidate voxels per axis, the widest axis' (0 until brick_reach)
     int mcx, mcy, mcz;      // ... and per axis: an anisotropic grid (the workspace's 256 x 256 x 48 light volume: r = 2.8 / 2.8 / 0.5
                             // voxels) has a box of 6 x 6 x 2 candidates
-    int halo;               // wide boxes (maxc > 4): a photon is filed under ONE brick, the one of its box's low corner, and that brick's
+    int halo;               // boxes of 4 or more candidates along some axis: a photon is filed under ONE brick, the one of its box's low corner, and that brick's
                             // workgroup sums into a tile with mc - 1 more voxels on the high side of every axis (see fast_halo_kernel)
 };
 CPM_DEV uint32_t off_meta(const BrickLayout& L) { return (uint32_t)L.nb + 1u; }
@@ -120,8 +120,26 @@ __host__ void brick_shape(const int dims[3], BrickLayout& L, const int* mc = nul
 #endif
     int lg[3] = { CPM_BRICK_LG };
     if (mc && (mc[0] > 4 || mc[1] > 4 || mc[2] > 4)) {
+#ifdef CPM_WIDE_LG
+        const int wl[3] = { CPM_WIDE_LG };
+        for (int a = 0; a < 3; ++a) lg[a] = wl[a];
+#else
         for (int a = 0; a < 3; ++a) lg[a] = mc[a] >= 5 ? 4 : 3;
         if (lg[0] + lg[1] + lg[2] > 11) lg[2] = 3;
+        // a record costs what its box has candidates -- of an axis' floor(2 r') + 1 all but one lie within reach of a photon --: a brick's
+        // voxels x that count stay under 56 Ki, the brick halved along its longest axis (x, then y, then z), not below 8 voxels -- or a few
+        // heavy bricks are the whole launch (128^3, 1 M photons under the lit face, box 6 x 6 x 6: 16 x 16 x 8 bricks 161 us, 8 x 8 x 8 70;
+        // the workspace's 6 x 6 x 2 keeps 16 x 16 x 8: smaller bricks there only add halo to stage and merge)
+        long long box = 1;
+        for (int a = 0; a < 3; ++a) box *= mc[a] > 8 ? 7 : (mc[a] > 1 ? mc[a] - 1 : 1);
+        while ((1ll << (lg[0] + lg[1] + lg[2])) * box > 56 * 1024) {
+            int axis = 0;
+            if (lg[1] > lg[axis]) axis = 1;
+            if (lg[2] > lg[axis]) axis = 2;
+            if (lg[axis] <= 3) break;
+            --lg[axis];
+        }
+#endif
     }
     auto count = [&](int a) { return (dims[a] + (1 << lg[a]) - 1) >> lg[a]; };
     while ((long long)count(0) * count(1) * count(2) > kMaxBricks) {
@@ -154,7 +172,10 @@ __host__ bool brick_reach(const GridDev& G, float radius, BrickLayout& L) {
     candidates_per_axis(G, radius, mc);
     L.mcx = mc[0]; L.mcy = mc[1]; L.mcz = mc[2];
     L.maxc = mc[0] > mc[1] ? (mc[0] > mc[2] ? mc[0] : mc[2]) : (mc[1] > mc[2] ? mc[1] : mc[2]);
-    L.halo = L.maxc > 4 ? 1 : 0;
+#ifndef CPM_HALO_FROM
+#define CPM_HALO_FROM 3
+#endif
+    L.halo = L.maxc > CPM_HALO_FROM ? 1 : 0;
     if (!(radius > 0.f) || L.maxc > kMaxCandidates) return false;
     const int lg[3] = { L.lx, L.ly, L.lz }, nbr[3] = { L.nbx, L.nby, L.nbz };
     for (int a = 0; a < 3; ++a)
@@ -616,7 +637,9 @@ __global__ __launch_bounds__(kBrickThreads, (CH == 4 ? 4 : CPM_BRICK_WAVES)) voi
     }
 }
 
-// ---- wide boxes (more than 4 candidates along some axis): tiles with a halo, no copies ------------------------------------------------
+// ---- boxes of 4 or more candidates along some axis: tiles with a halo, no copies ------------------------------------------------------
+// (from which width: config 2's photons, 128^3, bin + gather in us with copies | filed once: 3 candidates (r = 1.45 voxels) 53.3 | 54.9,
+// 4 (r = 1.9) 86.1 | 71.3, 2 (r = 0.87) 36.4 | 47.4 -- tools/fast_radius_sweep.py)
 // With a box 6 wide, 43 % of the records of a 16 x 16 x 8 brick were copies of neighbouring bricks' photons (1.7 copies per photon), and a
 // copy costs a wave as much as a whole box: lanes hold unrelated records, the wave runs every row and slot any lane needs
 // (docs/EXPERIMENTS.md, round 5).  So a wide-box photon is filed ONCE, under the brick of its box's low corner; that brick's workgroup sums
@@ -856,8 +879,8 @@ size_t cpm_fast_table_entries(const cpm_grid_desc* grid, int n) {
     if (!grid || n < 0 || grid->dims[0] < 1 || grid->dims[1] < 1 || grid->dims[2] < 1) return 0;
     // (the radius is not known here: room for the brick shape of a narrow box and for those of wide ones)
     size_t most = 0;
-    for (int w = 0; w < 8; ++w) {
-        const int mc[3] = { (w & 1) ? 5 : 1, (w & 2) ? 5 : 1, (w & 4) ? 5 : 1 };
+    for (int w = 0; w < 512; ++w) {  // every box of 1 ... 8 candidates per axis
+        const int mc[3] = { 1 + (w & 7), 1 + ((w >> 3) & 7), 1 + (w >> 6) };
         BrickLayout L;
         brick_shape(grid->dims, L, mc);
         most = table_entries(L) > most ? table_entries(L) : most;
@@ -1051,9 +1074,9 @@ int cpm_gather_fast_marked(cpm_ctx* ctx, const float* sorted_pos_power, const ui
                    radius, k, accumulate, grid_out, nonzero_bricks);                                                     \
     } while (0)
     if (G.channels == 1) {
-        if (L.maxc <= 2) CPM_BRICK_LAUNCH(2, 1); else if (L.maxc == 3) CPM_BRICK_LAUNCH(3, 1); else CPM_BRICK_LAUNCH(4, 1);
+        if (L.maxc <= 2) CPM_BRICK_LAUNCH(2, 1); else CPM_BRICK_LAUNCH(3, 1);
     } else {
-        if (L.maxc <= 2) CPM_BRICK_LAUNCH(2, 4); else if (L.maxc == 3) CPM_BRICK_LAUNCH(3, 4); else CPM_BRICK_LAUNCH(4, 4);
+        if (L.maxc <= 2) CPM_BRICK_LAUNCH(2, 4); else CPM_BRICK_LAUNCH(3, 4);
     }
 #undef CPM_BRICK_LAUNCH
     CPM_LAUNCH_CHECK(ctx, "fast_brick_kernel");

@@ -425,7 +425,7 @@ int cpm_gather_bricks(cpm_ctx* ctx, const float* sorted_pos_power, const uint32_
  * order of the records inside a brick is unspecified.  A photon whose candidate voxels (the integers within
  * r * textureToIndex + 1e-3 of its index-space coordinate, per axis, clipped to the grid) straddle a brick face is filed
  * under EVERY brick they lie in (at most 8; 0.3 % of the photons are filed twice at BASELINE config 2), so a brick's
- * voxels receive from that brick's records alone and the gather is one launch.  A photon with a WIDE box (5 - 8 candidates
+ * voxels receive from that brick's records alone and the gather is one launch.  A photon with a WIDE box (4 - 8 candidates
  * along some axis) is filed ONCE, under the brick of its box's low corner: that brick's tile carries a halo, tiles are staged as
  * 64-bit sums and a second launch of cpm_gather_fast adds the tiles that cover a voxel before the one rounding (context scratch:
  * one tile per brick of the grid) -- the same bits.  Sentinel photons and photons that reach no voxel are dropped.

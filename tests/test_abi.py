@@ -144,7 +144,7 @@ def test_fast_formulation_sizing_is_host_arithmetic(cpm):
 
     for dims in ((128, 128, 128), (256, 256, 48), (256, 256, 256), (32, 32, 32), (24, 64, 64)):
         g = B.default_grid_desc(dims, 1)
-        shapes = [(3, 3, 4)] + [tuple(4 if (w >> a) & 1 else 3 for a in range(3)) for w in range(1, 7)] + [(4, 4, 3)]
+        shapes = [(3, 3, 4)] + [tuple(4 if (w >> a) & 1 else 3 for a in range(3)) for w in range(0, 7)] + [(4, 4, 3)]   # (what brick_shape can give)
         most = max(bricks(dims, s) for s in shapes)
         assert lib.cpm_fast_table_entries(C.byref(g), 1000) == 2 * most + 5, dims
         r1 = 1.0 / max(dims)                       # one voxel along the longest axis
@@ -153,7 +153,8 @@ def test_fast_formulation_sizing_is_host_arithmetic(cpm):
         assert lib.cpm_gather_fast_supported(C.byref(g), C.c_float(4.6 * r1)) == 0     # 10 candidates: cpm_bin + cpm_gather
         assert lib.cpm_gather_fast_supported(C.byref(g), C.c_float(0.0)) == 0
         assert lib.cpm_fast_record_capacity(C.byref(g), 1000, C.c_float(2.8 * r1)) == 1000     # a wide box is filed once
-        assert lib.cpm_fast_record_capacity(C.byref(g), 1000, C.c_float(1.2 * r1)) == 8000
+        assert lib.cpm_fast_record_capacity(C.byref(g), 1000, C.c_float(1.2 * r1)) == 8000     # 3 candidates: a record per brick touched
+        assert lib.cpm_fast_record_capacity(C.byref(g), 1000, C.c_float(1.8 * r1)) == 1000     # 4: filed once
         assert lib.cpm_fast_record_capacity(C.byref(g), 1000, C.c_float(4.6 * r1)) == 0
     g = B.default_grid_desc((400, 8, 16), 1)       # reach 1 along every axis: one record per photon
     assert lib.cpm_fast_record_capacity(C.byref(g), 1000, C.c_float(0.4 / 400)) == 1000

@@ -67,6 +67,14 @@ def brick_layout(dims, mc=None):
         lg = [4 if c >= 5 else 3 for c in mc]
         if sum(lg) > 11:
             lg[2] = 3
+        # ... and a brick's voxels x the box's candidates within reach ((mc - 1) per axis) stay under 56 Ki: halved along the longest axis,
+        # not below 8 voxels
+        box = int(np.prod([7 if c > 8 else max(c - 1, 1) for c in mc]))
+        while (1 << sum(lg)) * box > 56 * 1024:
+            a = int(np.argmax(lg))
+            if lg[a] <= 3:
+                break
+            lg[a] -= 1
     cnt = lambda: [(d + (1 << l) - 1) >> l for d, l in zip(dims, lg)]
     while np.prod(cnt()) > 8192:
         c = cnt()
@@ -81,10 +89,10 @@ def brick_count(dims, mc=None):
 def expected_filing(ph, dims, radius, grid):
     """(photon index, brick) pairs cpm_bin_fast must file: every stored photon under every brick its candidate voxels
     (integers within r * textureToIndex + 1e-3 of the index-space coordinate, clipped to the grid) lie in -- narrow boxes; a photon with a
-    WIDE box (more than 4 candidates along some axis) once, under the brick of the box's low corner (that brick's tile has a halo)."""
+    box of 4 or more candidates along some axis once, under the brick of the box's low corner (that brick's tile has a halo)."""
     mc = candidates_per_axis(radius, grid)
     lg, nbk = brick_layout(dims, mc)
-    once = max(mc) > 4
+    once = max(mc) > 3
     t2i = np.array(grid.texture_to_index, np.float32)
     pairs = []
     stored = np.where(ph[:, 0] != FLT_MAX)[0]
