@@ -1,7 +1,7 @@
 """How evenly the brick gather's work items fall on its workgroups at the workspace's operating point (one light standing in for two:
 2 x 1024^2 photons through the 512 x 512 x 96 volume, 256 x 256 x 48 light volume, boxes of 6 x 6 x 2 candidates).
-Reads the brick table the bin wrote (records per brick) and replays the launch's static hand-out -- item i to workgroup i mod G -- and
-alternatives.  usage (GPU box): python tools/ws_brick_balance.py"""
+Reads the brick table the bin wrote (records per brick: since the halo form a photon is filed once, under the brick of its box's low corner)
+and replays the launch's static hand-out -- item i to workgroup i mod G -- and alternatives.  usage (GPU box): python tools/ws_brick_balance.py"""
 import sys
 sys.path.insert(0, '.')
 import numpy as np, torch, cpm_amd
