@@ -236,6 +236,7 @@ def launch_ranks(n_ranks):
 
 
 TIMED_BATCHES = 7   # the timed region is repeated; the median batch is reported
+MIN_WARM_STEPS = 200 # untimed frames before the first timed batch, whatever --warmup says (see main)
 
 
 def main():
@@ -291,6 +292,14 @@ def main():
     local_rank = 0 if args.test_one_device else int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus and rank == 0:
         print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
+    if os.environ.get("CPM_BENCH_SPIN", "1") != "0":
+        # the timed region ends in a synchronize: a host thread that sleeps in it wakes tens of microseconds after the device is done --
+        # 2 - 3 % of a 20-frame batch.  Spin instead (set before the device's context exists)
+        try:
+            import ctypes
+            ctypes.CDLL("libamdhip64.so").hipSetDeviceFlags(ctypes.c_uint(0x1))  # hipDeviceScheduleSpin
+        except OSError:
+            pass
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: libcpm_hip has no CPU fallback")
     torch.cuda.set_device(local_rank)
@@ -524,6 +533,10 @@ def main():
     # MAX over the ranks; ms_per_step / value are the MEDIAN batch's (K = 20 frames of config 2 last 1.4 ms: one batch is one sample of
     # the box's clocks; every batch's figure is in the line)
     for _ in range(args.warmup):
+        step()
+    # (a fresh box's clocks are still rising after W = 5 frames -- 0.3 ms of work: the first batches of a short run read 2 - 3 % slow.
+    # Untimed frames up to MIN_WARM_STEPS in all; the K timed steps of every batch are untouched)
+    for _ in range(max(0, MIN_WARM_STEPS - args.warmup)):
         step()
     batch_elapsed = []
     for _ in range(TIMED_BATCHES):
@@ -907,7 +920,8 @@ def main():
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "timing": {"what": f"median of {TIMED_BATCHES} timed batches of {args.steps} steps each (every batch between barrier + synchronize pairs, "
-                               "MAX over ranks); value and ms_per_step are that batch's",
+                               "MAX over ranks); value and ms_per_step are that batch's; untimed frames before the first batch: "
+                               f"{max(args.warmup, MIN_WARM_STEPS)} (--warmup {args.warmup}, at least {MIN_WARM_STEPS}: a fresh box's clocks are still rising after 5)",
                        "batch_ms_per_step": [round(e / args.steps * 1e3, 4) for e in batch_elapsed]},
             "config": {"workload": (f"BASELINE {args.workload}: {vdim}^3 u8 heterogeneous volume, {n_total} photons per frame in all "
                                     f"({lattice[0]}x{lattice[1]} lattice, one directional light; {n_rank} on rank 0), {gdim}^3 x1 f32 light volume, "
