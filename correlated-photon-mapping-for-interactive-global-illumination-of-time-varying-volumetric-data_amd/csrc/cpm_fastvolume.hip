@@ -164,8 +164,9 @@ __host__ void brick_shape_for(const GridDev& G, float radius, BrickLayout& L) {
 }
 
 // candidates per axis from the radius; false when the kernels do not cover it: a candidate box must not span more than
-// two bricks per axis (it is at most as wide as a brick, or the brick spans the axis).  Up to 4 candidates per axis the
-// record loops are unrolled (fast_brick_kernel<2 / 3 / 4>); wider boxes take run-time loops over y and z (<6 / 8 / 14>).
+// two bricks per axis (it is at most as wide as a brick, or the brick spans the axis).  Up to 3 candidates per axis a photon is
+// filed under every brick its box touches and the record loops are unrolled (fast_brick_kernel<2 / 3>); from 4 it is filed once and
+// summed into a tile with a halo, with run-time loops over y and z (fast_halo_kernel<., 4 / 6 / 8>).
 constexpr int kMaxCandidates = 8;
 __host__ bool brick_reach(const GridDev& G, float radius, BrickLayout& L) {
     int mc[3];

@@ -435,7 +435,7 @@ int cpm_gather_bricks(cpm_ctx* ctx, const float* sorted_pos_power, const uint32_
 size_t cpm_fast_table_entries(const cpm_grid_desc* grid, int n);
 /* 1 when the pair covers this grid / radius: at most 8 candidate voxels along every axis (floor(2 (r * textureToIndex + 1e-3)) + 1
  * <= 8: radius < 3.5 voxels of THAT axis -- the box follows an anisotropic grid: 6 x 6 x 2 on the workspace's 256 x 256 x 48
- * light volume; up to 4 per axis the record loops are unrolled, wider boxes take run-time loops), positive axis-aligned
+ * light volume; up to 3 per axis the record loops are unrolled, wider boxes take run-time loops and tiles with a halo), positive axis-aligned
  * textureToIndex; otherwise use cpm_bin + cpm_gather. */
 int cpm_gather_fast_supported(const cpm_grid_desc* grid, float radius);
 /* Records sorted_pos_power must hold for n photons at this radius (every photon in all its bricks: 8 n; n when a
