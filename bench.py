@@ -297,7 +297,9 @@ def main():
         # 2 - 3 % of a 20-frame batch.  Spin instead (set before the device's context exists)
         try:
             import ctypes
-            ctypes.CDLL("libamdhip64.so").hipSetDeviceFlags(ctypes.c_uint(0x1))  # hipDeviceScheduleSpin
+            hip = ctypes.CDLL("libamdhip64.so")
+            if hip.hipSetDevice(ctypes.c_int(local_rank)) == 0:       # (the flags are the current device's)
+                hip.hipSetDeviceFlags(ctypes.c_uint(0x1))             # hipDeviceScheduleSpin
         except OSError:
             pass
     if not torch.cuda.is_available():
