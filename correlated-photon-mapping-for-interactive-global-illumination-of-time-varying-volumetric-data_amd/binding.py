@@ -51,6 +51,8 @@ ABI_SYMBOLS = [
     "cpm_allreduce_grid_sparse", "cpm_sparse_reduce_complete", "cpm_brick_mask_or",
     "cpm_bricklist_reduce_create", "cpm_bricklist_reduce_destroy", "cpm_bricklist_reduce_bricks", "cpm_bricklist_capacity_for",
     "cpm_bricklist_segment_bytes", "cpm_reduce_grid_bricklists", "cpm_bricklist_reduce_complete",
+    "cpm_bricklist_reduce_open", "cpm_bricklist_pack_grid", "cpm_bricklist_reduce_exchange", "cpm_gather_fast_segment",
+    "cpm_bricklist_segment_to_grid", "cpm_comm_send", "cpm_comm_recv", "cpm_gather_fast_supported_on",
     "cpm_light_volume_texels", "cpm_gl_available", "cpm_gl_register_buffer", "cpm_gl_acquire", "cpm_gl_release",
     "cpm_gl_buffer_pointer", "cpm_gl_copy_to_buffer", "cpm_gl_unregister",
 ]
@@ -153,6 +155,12 @@ class BricklistInfo(C.Structure):
     """cpm_bricklist_info"""
     _fields_ = [("ticket", C.c_uint64), ("n_bricks", C.c_uint32), ("n_own", C.c_uint32), ("capacity", C.c_uint32), ("resent", C.c_int32),
                 ("sent_bytes", C.c_uint64), ("received_bytes", C.c_uint64), ("dense_bytes", C.c_uint64), ("listed_bricks", C.c_uint32)]
+
+
+class BricklistSegment(C.Structure):
+    """cpm_bricklist_segment: where a ticket's brick list lies on a sender (segment == NULL at the root: it gathers into its grid)."""
+    _fields_ = [("segment", C.c_void_p), ("capacity", C.c_uint32), ("room", C.c_uint32), ("ticket", C.c_uint32), ("channels", C.c_uint32),
+                ("control", C.c_void_p), ("mailbox", C.c_void_p)]
 
 
 class EmitterDesc(C.Structure):
@@ -297,6 +305,14 @@ def load_library() -> C.CDLL:
         "cpm_bricklist_segment_bytes": (C.c_uint64, [u32, i32]),
         "cpm_reduce_grid_bricklists": (i32, [vp, vp, vp, vp, P(C.c_uint64), vp]),
         "cpm_bricklist_reduce_complete": (i32, [vp, vp, C.c_uint64, vp, P(BricklistInfo)]),
+        "cpm_bricklist_reduce_open": (i32, [vp, vp, P(C.c_uint64), P(BricklistSegment)]),
+        "cpm_bricklist_pack_grid": (i32, [vp, vp, C.c_uint64, vp, vp, vp]),
+        "cpm_bricklist_reduce_exchange": (i32, [vp, vp, C.c_uint64, vp, vp]),
+        "cpm_gather_fast_segment": (i32, [vp, vp, vp, i32, P(GridDesc), f32, f32, P(BricklistSegment), vp]),
+        "cpm_bricklist_segment_to_grid": (i32, [vp, P(BricklistSegment), P(GridDesc), vp, vp]),
+        "cpm_comm_send": (i32, [vp, vp, vp, C.c_size_t, i32, vp]),
+        "cpm_comm_recv": (i32, [vp, vp, vp, C.c_size_t, i32, vp]),
+        "cpm_gather_fast_supported_on": (i32, [vp, P(GridDesc), f32]),
         "cpm_gl_available": (i32, [vp]),
         "cpm_gl_register_buffer": (i32, [vp, u32, i32, P(vp)]),
         "cpm_light_volume_texels": (i32, [vp, vp, sz, i32, vp, vp]),
@@ -623,6 +639,24 @@ class Context:
             self._check(self.lib.cpm_gather_fast_marked(self.h, self._ptr(sorted_pos_power), self._ptr(brick_table), n, C.byref(grid), radius, scale,
                                                         int(accumulate), self._ptr(out), self._ptr(nonzero_bricks), self._stream()))
 
+    def gather_fast_segment(self, sorted_pos_power, brick_table, n, grid, radius, scale, segment: "BricklistSegment"):
+        """cpm_gather_fast whose output is a brick-list segment (BricklistReduce.open): the non-zero 4x4x4 bricks alone, no grid."""
+        self._check(self.lib.cpm_gather_fast_segment(self.h, self._ptr(sorted_pos_power), self._ptr(brick_table), n, C.byref(grid), radius, scale,
+                                                     C.byref(segment), self._stream()))
+
+    def bricklist_segment_to_grid(self, segment: "BricklistSegment", grid, out):
+        """out += the segment's bricks (same device)."""
+        self._check(self.lib.cpm_bricklist_segment_to_grid(self.h, C.byref(segment), C.byref(grid), self._ptr(out), self._stream()))
+
+    def gather_fast_supported_on(self, grid, radius) -> bool:
+        return bool(self.lib.cpm_gather_fast_supported_on(self.h, C.byref(grid), radius))
+
+    def comm_send(self, comm: "Comm", buf, nbytes: int, peer: int):
+        self._check(self.lib.cpm_comm_send(self.h, comm.h, self._ptr(buf), nbytes, peer, self._stream()))
+
+    def comm_recv(self, comm: "Comm", buf, nbytes: int, peer: int):
+        self._check(self.lib.cpm_comm_recv(self.h, comm.h, self._ptr(buf), nbytes, peer, self._stream()))
+
     def mark_touched_bricks(self, photons, indices, n_indices, n_photons, n_interactions, grid, radius, brick_mask):
         self._check(self.lib.cpm_mark_touched_bricks(self.h, self._ptr(photons), self._ptr(indices), n_indices, n_photons,
                                                      n_interactions, C.byref(grid), radius, self._ptr(brick_mask), self._stream()))
@@ -916,6 +950,24 @@ class BricklistReduce:
                                                                 self.ctx._ptr(nonzero_bricks) if nonzero_bricks is not None else None,
                                                                 C.byref(ticket), self.ctx._stream()))
         return int(ticket.value)
+
+    # -- the same exchange step by step (no dense grid on a sender): open -> fill the segment -> exchange -> complete
+    def open(self):
+        """A ticket and -- on a rank other than the root -- where its segment lies: (ticket, BricklistSegment); segment.segment is None at
+        the root and with one rank (gather into the grid there).  Host only: nothing is enqueued."""
+        ticket, seg = C.c_uint64(0), BricklistSegment()
+        self.ctx._check(self.ctx.lib.cpm_bricklist_reduce_open(self.ctx.h, self.h, C.byref(ticket), C.byref(seg)))
+        return int(ticket.value), seg
+
+    def pack_grid(self, ticket: int, grid, nonzero_bricks=None):
+        """Sender: the non-zero 4x4x4 bricks of a dense grid -> the ticket's segment (one launch on the current stream; nothing at the root)."""
+        self.ctx._check(self.ctx.lib.cpm_bricklist_pack_grid(self.ctx.h, self.h, ticket, self.ctx._ptr(grid),
+                                                             self.ctx._ptr(nonzero_bricks) if nonzero_bricks is not None else None, self.ctx._stream()))
+
+    def exchange(self, ticket: int, root_grid=None):
+        """Sender: one send of the segment; root: the receives and the two launches that add them into root_grid (current stream)."""
+        self.ctx._check(self.ctx.lib.cpm_bricklist_reduce_exchange(self.ctx.h, self.h, ticket,
+                                                                   self.ctx._ptr(root_grid) if root_grid is not None else None, self.ctx._stream()))
 
     def complete(self, ticket: int) -> BricklistInfo:
         """Before the ticket's grid is read (root) or gathered into again (every rank): the exchange repeated at exact size where a

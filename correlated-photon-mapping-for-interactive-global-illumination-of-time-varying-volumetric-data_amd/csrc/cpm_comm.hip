@@ -18,6 +18,7 @@
 #include <new>
 
 #include "cpm_ctx.h"
+#include "cpm/cpm_profile.h"
 
 using namespace cpm;
 
@@ -59,36 +60,36 @@ struct cpm_sparse_reduce {
 // cpm_reduce_grid_bricklists: everything one (communicator, grid shape, root) needs
 constexpr int kBricklistMaxRanks = 16;
 struct cpm_bricklist_reduce {
-    static constexpr int kSlots = 4;  // tickets in flight (issued, not yet completed)
+    static constexpr int kSlots = 4;  // tickets in flight (opened, not yet completed)
     cpm_comm* comm = nullptr;
     int device = 0, root = 0;
     int dims[3] = { 0, 0, 0 }, channels = 1, bxn = 0, byn = 0, bzn = 0;
-    uint32_t nb = 0;
+    uint32_t nb = 0, room = 0;   // 4x4x4 bricks of the grid; slots a sender's buffer holds (nb rounded up to 64)
     size_t cells = 0;
-    // a sender's own bricks (the root needs none of these)
-    uint8_t* mask = nullptr;     // nb bytes (+ 16)
-    uint32_t* list = nullptr;    // nb: its non-zero bricks, ascending
-    uint32_t* slot = nullptr;    // nb: scratch of brick_slots_kernel
-    uint32_t* count = nullptr;   // device word: their number
-    // pinned host words [kSlots][kBricklistMaxRanks]: ticket << 32 | the brick count of rank r's segment -- written by the sender's list
-    // launch (its own word) and by the root's add launches (every sender's word, from the segment's header)
+    uint32_t* ctl = nullptr;      // sender, device: per slot 2 words (slots handed out, workgroups done), zero between launches
+    uint32_t* slot_of = nullptr;  // root, device: per sender (rank order, the root left out) nb words: brick -> slot in that sender's
+                                  // segment; never cleared -- an entry counts only if the slot it names carries the brick's id
+    // pinned host words: [kSlots][kBricklistMaxRanks] ticket << 32 | the brick count of rank r's segment -- written by the last workgroup of
+    // the sender's fill launch (its own word) and by the root's add launch (every sender's word, from the segment's header); behind them
+    // the same again for the exchanges repeated at exact size (the root's acknowledgement of the header it then found)
     unsigned long long* mailbox = nullptr;
     unsigned long long* mailbox_dev = nullptr;
-    // a sender's segment / the root's received segments, per slot; and the buffer of an exchange repeated at exact size
+    // per slot: a sender's segment (room for every brick) / the root's received segments; the root's buffer of a repeated exchange
     void* seg[kSlots] = { nullptr, nullptr, nullptr, nullptr };
     size_t seg_bytes[kSlots] = { 0, 0, 0, 0 };
     void* again = nullptr;
     size_t again_bytes = 0;
     uint64_t next_ticket = 1;
+    bool poisoned = false;  // a header that was not its ticket's: the ranks' capacities may have diverged -- every later call fails
     struct Slot {
         uint64_t ticket = 0;
-        float* grid = nullptr;
+        float* grid = nullptr;                      // the root's
         uint32_t cap[kBricklistMaxRanks] = {};      // per sender (a sender fills its own entry only)
         uint32_t counts[kBricklistMaxRanks] = {};
         bool known[kBricklistMaxRanks] = {};
-        bool completed = true;
+        bool completed = true, exchanged = false;
         int resent = 0;
-        hipStream_t stream = nullptr;
+        hipStream_t stream = nullptr;               // the exchange's
     } slots[kSlots];
 };
 
@@ -787,93 +788,204 @@ extern "C" int cpm_brick_mask_or(cpm_ctx* ctx, uint8_t* dst, const uint8_t* src,
 }
 
 // ---- cpm_reduce_grid_bricklists ----------------------------------------------------------------------------------------------
-// A segment = [ header: count, capacity, ticket, magic ][ capacity bricks of 64 * CH floats ][ capacity brick ids ].
+// Segment layout, slot counter and header: cpm_ctx.h (shared with cpm_gather_fast_segment, which fills a segment straight from the
+// brick gather).  A sender's buffer has room for every brick of the grid; the first `capacity` slots travel.
 
 namespace {
 
-constexpr uint32_t kSegMagic = 0x62726b6cu;  // "brkl"
-struct SegHeader { uint32_t count, capacity, ticket, magic; };
+__host__ __device__ inline unsigned char* seg_slot(unsigned char* seg, uint32_t s, int ch) { return seg + sizeof(SegHeader) + (size_t)s * seg_slot_bytes(ch); }
+__host__ __device__ inline const unsigned char* seg_slot(const unsigned char* seg, uint32_t s, int ch) { return seg + sizeof(SegHeader) + (size_t)s * seg_slot_bytes(ch); }
+inline uint32_t round_up_64(uint64_t v) { return (uint32_t)((v + 63ull) & ~63ull); }
 
-__host__ __device__ inline size_t seg_payload_offset() { return sizeof(SegHeader); }
-__host__ __device__ inline size_t seg_ids_offset(uint32_t capacity, int channels) { return sizeof(SegHeader) + (size_t)capacity * 256u * (size_t)channels; }
-__host__ inline size_t seg_size(uint32_t capacity, int channels) { return seg_ids_offset(capacity, channels) + (size_t)capacity * 4u; }
-
-// sender: its first min(count, capacity) bricks -> the segment; the header alone when they do not fit.  16 lanes per brick, a
-// 16-byte piece of a grid row each (as brick_pack_kernel)
+// sender, from a dense grid: every non-zero 4x4x4 brick (of the marked ones, when the gather left marks) -> a slot of the segment.
+// 16 lanes per brick, a 16-byte piece of a grid row each; ONE atomic on the segment's counter per workgroup of 16 bricks.
 template <int CH, bool VEC>
-__global__ __launch_bounds__(256) void bricklist_pack_kernel(const uint32_t* __restrict__ list, const uint32_t* __restrict__ count, uint32_t capacity,
-                                                             uint32_t ticket, int dx, int dy, int dz, int bxn, int byn, const float* __restrict__ grid,
-                                                             unsigned char* __restrict__ seg) {
-    const uint32_t n = *count;
-    if (blockIdx.x == 0 && threadIdx.x == 0) *reinterpret_cast<SegHeader*>(seg) = SegHeader{ n, capacity, ticket, kSegMagic };
-    if (n > capacity) return;
-    const uint32_t s = blockIdx.x * 16u + (threadIdx.x >> 4);
-    if (s >= n) return;
-    const int r = threadIdx.x & 15;
-    const uint32_t b = list[s];
-    if (r == 0) reinterpret_cast<uint32_t*>(seg + seg_ids_offset(capacity, CH))[s] = b;
-    const int bx = (int)(b % (uint32_t)bxn), by = (int)((b / (uint32_t)bxn) % (uint32_t)byn), bz = (int)(b / (uint32_t)(bxn * byn));
-    const int y = by * 4 + (r & 3), z = bz * 4 + (r >> 2);
+__global__ __launch_bounds__(256) void bricklist_pack_grid_kernel(const float* __restrict__ grid, const uint8_t* __restrict__ marks, uint32_t nb, int dx, int dy,
+                                                                  int dz, int bxn, int byn, SegTarget st) {
+    __shared__ uint32_t s_cnt, s_base;
+    const int t = threadIdx.x, lane = t & 63, r = t & 15;
+    const uint32_t b = blockIdx.x * 16u + (uint32_t)(t >> 4);
+    if (t == 0) s_cnt = 0u;
+    __syncthreads();
     float4 f[CH];
 #pragma unroll
     for (int c = 0; c < CH; ++c) f[c] = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (y < dy && z < dz) {
-        const size_t v = (size_t)(bx * 4) + (size_t)dx * ((size_t)y + (size_t)dy * (size_t)z);
-        if (VEC) {
+    if (b < nb && (!marks || marks[b])) {
+        const int bx = (int)(b % (uint32_t)bxn), by = (int)((b / (uint32_t)bxn) % (uint32_t)byn), bz = (int)(b / (uint32_t)(bxn * byn));
+        const int y = by * 4 + (r & 3), z = bz * 4 + (r >> 2);
+        if (y < dy && z < dz) {
+            const size_t v = (size_t)(bx * 4) + (size_t)dx * ((size_t)y + (size_t)dy * (size_t)z);
+            if (VEC) {
 #pragma unroll
-            for (int c = 0; c < CH; ++c) f[c] = reinterpret_cast<const float4*>(grid + v * CH)[c];
-        } else {
-            float* ff = reinterpret_cast<float*>(f);
-            for (int x = 0; x < 4 && bx * 4 + x < dx; ++x)
-                for (int c = 0; c < CH; ++c) ff[x * CH + c] = grid[(v + x) * CH + c];
+                for (int c = 0; c < CH; ++c) f[c] = reinterpret_cast<const float4*>(grid + v * CH)[c];
+            } else {
+                float* ff = reinterpret_cast<float*>(f);
+                for (int x = 0; x < 4 && bx * 4 + x < dx; ++x)
+                    for (int c = 0; c < CH; ++c) ff[x * CH + c] = grid[(v + x) * CH + c];
+            }
         }
     }
-    float4* o = reinterpret_cast<float4*>(seg + seg_payload_offset()) + ((size_t)s * 16 + r) * CH;
+    bool nz = false;
 #pragma unroll
-    for (int c = 0; c < CH; ++c) o[c] = f[c];
+    for (int c = 0; c < CH; ++c) nz = nz || f[c].x != 0.f || f[c].y != 0.f || f[c].z != 0.f || f[c].w != 0.f;
+    const unsigned long long m = __ballot(nz);
+    const bool brick_nz = ((m >> (lane & 48)) & 0xffffull) != 0ull;   // any of the brick's 16 lanes
+    uint32_t rel = 0u;
+    if (brick_nz && r == 0) rel = atomicAdd(&s_cnt, 1u);
+    rel = __shfl(rel, lane & 48, 64);
+    __syncthreads();
+    if (t == 0) s_base = s_cnt ? atomicAdd(&st.ctl[0], s_cnt) : 0u;
+    __syncthreads();
+    const uint32_t slot = s_base + rel;
+    if (brick_nz && slot < st.room) {
+        unsigned char* p = seg_slot(st.seg, slot, CH);
+        if (r == 0) *reinterpret_cast<uint4*>(p) = make_uint4(b, 0u, 0u, 0u);
+        float4* o = reinterpret_cast<float4*>(p + 16) + (size_t)r * CH;
+#pragma unroll
+        for (int c = 0; c < CH; ++c) o[c] = f[c];
+    }
+    if (t == 0) seg_finish(st, gridDim.x);
 }
 
-// root: one received segment added into the grid (its bricks are distinct: no two lanes meet); the segment's brick count goes to
-// the host's mailbox word of that sender.  A segment that carries only its header (count > capacity) adds nothing -- the exchange is
-// repeated at cpm_bricklist_reduce_complete.  A header that is not this ticket's (a transport fault) counts as empty and says so.
-template <int CH, bool VEC>
-__global__ __launch_bounds__(256) void bricklist_add_kernel(const unsigned char* __restrict__ seg, uint32_t capacity, uint32_t ticket, uint32_t nb,
-                                                            int dx, int dy, int dz, int bxn, int byn, float* __restrict__ grid,
-                                                            unsigned long long* mailbox) {
+// root: the received segments of one ticket (or one segment of an exchange repeated at exact size)
+struct RootSegs {
+    int n;                                         // senders in this pass
+    uint32_t slots[kBricklistMaxRanks];            // slots received from sender i
+    uint32_t hdr_cap[kBricklistMaxRanks];          // the capacity its header must carry
+    uint32_t table[kBricklistMaxRanks];            // which brick -> slot table is sender i's (its place among the senders)
+    int rank[kBricklistMaxRanks];                  // its rank: the mailbox word its count goes to
+    unsigned long long off[kBricklistMaxRanks];    // where its segment starts in the receive buffer
+};
+// bricks of a received segment that this pass adds: none from a header that is not the ticket's, none from a list that outgrew its
+// segment (that sender goes again at exact size and is added last)
+__device__ inline uint32_t seg_usable(const unsigned char* seg, uint32_t slots, uint32_t hdr_cap, uint32_t ticket, uint32_t* raw) {
     const SegHeader h = *reinterpret_cast<const SegHeader*>(seg);
-    const bool sane = h.magic == kSegMagic && h.ticket == ticket && h.capacity == capacity;
-    const uint32_t n = sane ? h.count : 0xffffffffu;
-    if (mailbox && blockIdx.x == 0 && threadIdx.x == 0)
-        __hip_atomic_store(mailbox, ((unsigned long long)ticket << 32) | (unsigned long long)n, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-    if (n > capacity) return;
-    const uint32_t s = blockIdx.x * 16u + (threadIdx.x >> 4);
+    const bool sane = h.magic == kSegMagic && h.ticket == ticket && h.capacity == hdr_cap;
+    if (raw) *raw = sane ? h.count : 0xffffffffu;
+    return sane && h.count <= slots ? h.count : 0u;
+}
+__device__ inline int sender_of(const RootSegs& S, uint32_t wg, uint32_t per, uint32_t& local) {
+    uint32_t first = 0;
+    for (int i = 0; i < S.n; ++i) {
+        const uint32_t w = (S.slots[i] + per - 1u) / per;
+        if (wg < first + w) { local = wg - first; return i; }
+        first += w;
+    }
+    local = 0;
+    return -1;
+}
+
+// root, launch 1 of 2: every received brick's slot -> its sender's brick -> slot table
+__global__ __launch_bounds__(256) void bricklist_index_kernel(const unsigned char* __restrict__ base, RootSegs S, uint32_t ticket, uint32_t nb, int ch,
+                                                              uint32_t* __restrict__ slot_of) {
+    uint32_t local;
+    const int i = sender_of(S, blockIdx.x, 256u, local);
+    if (i < 0) return;
+    const unsigned char* seg = base + S.off[i];
+    const uint32_t n = seg_usable(seg, S.slots[i], S.hdr_cap[i], ticket, nullptr);
+    const uint32_t s = local * 256u + threadIdx.x;
     if (s >= n) return;
+    const uint32_t b = *reinterpret_cast<const uint32_t*>(seg_slot(seg, s, ch));
+    if (b < nb) slot_of[(size_t)S.table[i] * nb + b] = s;
+}
+
+// root, launch 2 of 2: the sum.  16 lanes per received brick; the LOWEST-ranked sender that lists a brick adds its own values and then
+// every higher-ranked sender's for the same brick (found through the tables: an entry counts only when the slot it names carries the
+// brick's id), in rank order -- one read-modify-write of the grid per listed brick, no two groups on the same brick.  The first
+// workgroup of a sender also hands its header's count to the host (mailbox word; 0xffffffff = not this ticket's header).
+template <int CH, bool VEC>
+__global__ __launch_bounds__(256) void bricklist_add_kernel(const unsigned char* __restrict__ base, RootSegs S, uint32_t ticket, uint32_t nb,
+                                                            const uint32_t* __restrict__ slot_of, int dx, int dy, int dz, int bxn, int byn,
+                                                            float* __restrict__ grid, unsigned long long* mailbox) {
+    __shared__ uint32_t s_n[kBricklistMaxRanks];
+    uint32_t local;
+    const int i = sender_of(S, blockIdx.x, 16u, local);
+    if (i < 0) return;
+    if ((int)threadIdx.x < S.n) {
+        uint32_t raw;
+        s_n[threadIdx.x] = seg_usable(base + S.off[threadIdx.x], S.slots[threadIdx.x], S.hdr_cap[threadIdx.x], ticket, &raw);
+        if ((int)threadIdx.x == i && local == 0u && mailbox)
+            __hip_atomic_store(mailbox + S.rank[i], ((unsigned long long)ticket << 32) | (unsigned long long)raw, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    __syncthreads();
+    const uint32_t s = local * 16u + (threadIdx.x >> 4);
+    if (s >= s_n[i]) return;
     const int r = threadIdx.x & 15;
-    const uint32_t b = reinterpret_cast<const uint32_t*>(seg + seg_ids_offset(capacity, CH))[s];
-    if (b >= nb) return;
+    const unsigned char* mine = seg_slot(base + S.off[i], s, CH);
+    const uint32_t b = *reinterpret_cast<const uint32_t*>(mine);
+    if (b >= nb || slot_of[(size_t)S.table[i] * nb + b] != s) return;   // (a brick listed twice: the slot its table kept)
+    auto listed = [&](int q, uint32_t& at) {
+        at = slot_of[(size_t)S.table[q] * nb + b];
+        return at < s_n[q] && *reinterpret_cast<const uint32_t*>(seg_slot(base + S.off[q], at, CH)) == b;
+    };
+    uint32_t at;
+    for (int q = 0; q < i; ++q) if (listed(q, at)) return;   // a lower rank lists it: that group sums the brick
     const int bx = (int)(b % (uint32_t)bxn), by = (int)((b / (uint32_t)bxn) % (uint32_t)byn), bz = (int)(b / (uint32_t)(bxn * byn));
     const int y = by * 4 + (r & 3), z = bz * 4 + (r >> 2);
     if (y >= dy || z >= dz) return;
-    const float4* p = reinterpret_cast<const float4*>(seg + seg_payload_offset()) + ((size_t)s * 16 + r) * CH;
     const size_t v = (size_t)(bx * 4) + (size_t)dx * ((size_t)y + (size_t)dy * (size_t)z);
+    float4 acc[CH];
     if (VEC) {
 #pragma unroll
-        for (int c = 0; c < CH; ++c) {
-            float4* q = reinterpret_cast<float4*>(grid + v * CH) + c;
-            const float4 a = *q, d = p[c];
-            *q = make_float4(a.x + d.x, a.y + d.y, a.z + d.z, a.w + d.w);
-        }
+        for (int c = 0; c < CH; ++c) acc[c] = reinterpret_cast<const float4*>(grid + v * CH)[c];
     } else {
-        const float* ff = reinterpret_cast<const float*>(p);
+        float* ff = reinterpret_cast<float*>(acc);
+        for (int k = 0; k < 4 * CH; ++k) ff[k] = 0.f;
         for (int x = 0; x < 4 && bx * 4 + x < dx; ++x)
-            for (int c = 0; c < CH; ++c) grid[(v + x) * CH + c] += ff[x * CH + c];
+            for (int c = 0; c < CH; ++c) ff[x * CH + c] = grid[(v + x) * CH + c];
+    }
+    for (int q = i; q < S.n; ++q) {
+        const unsigned char* sl = mine;
+        if (q != i) { if (!listed(q, at)) continue; sl = seg_slot(base + S.off[q], at, CH); }
+        const float4* p = reinterpret_cast<const float4*>(sl + 16) + (size_t)r * CH;
+#pragma unroll
+        for (int c = 0; c < CH; ++c) { const float4 d = p[c]; acc[c] = make_float4(acc[c].x + d.x, acc[c].y + d.y, acc[c].z + d.z, acc[c].w + d.w); }
+    }
+    if (VEC) {
+#pragma unroll
+        for (int c = 0; c < CH; ++c) reinterpret_cast<float4*>(grid + v * CH)[c] = acc[c];
+    } else {
+        const float* ff = reinterpret_cast<const float*>(acc);
+        for (int x = 0; x < 4 && bx * 4 + x < dx; ++x)
+            for (int c = 0; c < CH; ++c) grid[(v + x) * CH + c] = ff[x * CH + c];
     }
 }
 
-int bricklist_grow(cpm_ctx* ctx, void** buf, size_t* have, size_t need, hipStream_t s) {
+// one segment on this device added into a dense grid (cpm_bricklist_segment_to_grid): its first min(count, room) slots
+template <int CH, bool VEC>
+__global__ __launch_bounds__(256) void segment_to_grid_kernel(const unsigned char* __restrict__ seg, uint32_t room, uint32_t nb, int dx, int dy, int dz, int bxn,
+                                                              int byn, float* __restrict__ grid) {
+    const SegHeader h = *reinterpret_cast<const SegHeader*>(seg);
+    const uint32_t n = h.magic == kSegMagic ? (h.count < room ? h.count : room) : 0u;
+    for (uint32_t s = blockIdx.x * 16u + (threadIdx.x >> 4); s < n; s += gridDim.x * 16u) {
+        const int r = threadIdx.x & 15;
+        const unsigned char* p = seg_slot(seg, s, CH);
+        const uint32_t b = *reinterpret_cast<const uint32_t*>(p);
+        if (b >= nb) continue;
+        const int bx = (int)(b % (uint32_t)bxn), by = (int)((b / (uint32_t)bxn) % (uint32_t)byn), bz = (int)(b / (uint32_t)(bxn * byn));
+        const int y = by * 4 + (r & 3), z = bz * 4 + (r >> 2);
+        if (y >= dy || z >= dz) continue;
+        const size_t v = (size_t)(bx * 4) + (size_t)dx * ((size_t)y + (size_t)dy * (size_t)z);
+        const float4* q = reinterpret_cast<const float4*>(p + 16) + (size_t)r * CH;
+        if (VEC) {
+#pragma unroll
+            for (int c = 0; c < CH; ++c) {
+                float4* g = reinterpret_cast<float4*>(grid + v * CH) + c;
+                const float4 a = *g, d = q[c];
+                *g = make_float4(a.x + d.x, a.y + d.y, a.z + d.z, a.w + d.w);
+            }
+        } else {
+            const float* ff = reinterpret_cast<const float*>(q);
+            for (int x = 0; x < 4 && bx * 4 + x < dx; ++x)
+                for (int c = 0; c < CH; ++c) grid[(v + x) * CH + c] += ff[x * CH + c];
+        }
+    }
+}
+
+int bricklist_grow(cpm_ctx* ctx, void** buf, size_t* have, size_t need, hipStream_t busy) {
     if (*have >= need) return CPM_OK;
     if (*buf) {  // (launches that read the old block may still be queued)
-        CPM_HIP_CHECK(ctx, hipStreamSynchronize(s));
+        CPM_HIP_CHECK(ctx, hipStreamSynchronize(busy));
         (void)hipFree(*buf);
         *buf = nullptr; *have = 0;
     }
@@ -883,7 +995,7 @@ int bricklist_grow(cpm_ctx* ctx, void** buf, size_t* have, size_t need, hipStrea
     return CPM_OK;
 }
 
-// rank r's brick count of an issued ticket: a poll of the pinned word its list launch (a sender's own) or the root's add launch wrote
+// rank r's brick count of an opened ticket: a poll of the pinned word its fill launch (a sender's own) or the root's add launch wrote
 int bricklist_count(cpm_ctx* ctx, cpm_bricklist_reduce* br, cpm_bricklist_reduce::Slot& sl, int r) {
     if (sl.known[r]) return CPM_OK;
     const volatile unsigned long long* mb = br->mailbox + (sl.ticket % cpm_bricklist_reduce::kSlots) * kBricklistMaxRanks + r;
@@ -892,63 +1004,66 @@ int bricklist_count(cpm_ctx* ctx, cpm_bricklist_reduce* br, cpm_bricklist_reduce
     for (unsigned spin = 0;; ++spin) {
         const unsigned long long v = __atomic_load_n(mb, __ATOMIC_ACQUIRE);
         if ((uint32_t)(v >> 32) == (uint32_t)sl.ticket) { sl.counts[r] = (uint32_t)v; sl.known[r] = true; return CPM_OK; }
-        if (synced) return set_error(ctx, CPM_ERR_DEVICE, "cpm_bricklist_reduce", "the brick count of a ticket never arrived");
+        if (synced) return set_error(ctx, CPM_ERR_DEVICE, "cpm_bricklist_reduce", "the brick count of a ticket never arrived (was its segment filled and exchanged?)");
         if ((spin & 1023u) == 1023u && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(2)) {
-            CPM_HIP_CHECK(ctx, hipStreamSynchronize(sl.stream));
+            CPM_HIP_CHECK(ctx, hipDeviceSynchronize());   // (fill and exchange may have gone to different streams)
             synced = true;
         }
         __builtin_ia32_pause();
     }
 }
 
-int bricklist_pack(cpm_ctx* ctx, cpm_bricklist_reduce* br, uint32_t capacity, uint32_t ticket, const float* grid, void* seg, hipStream_t s) {
-    const bool vec = (br->dims[0] & 3) == 0;
-    const dim3 g((unsigned)div_up(capacity, 16));
-    unsigned char* sg = static_cast<unsigned char*>(seg);
-#define CPM_BL_PACK(CH, VEC) CPM_LAUNCH(ctx, (bricklist_pack_kernel<CH, VEC>), g, dim3(256), 0, s, br->list, br->count, capacity, ticket, br->dims[0], br->dims[1], br->dims[2], br->bxn, br->byn, grid, sg)
-    if (br->channels == 1) { if (vec) CPM_BL_PACK(1, true); else CPM_BL_PACK(1, false); }
-    else { if (vec) CPM_BL_PACK(4, true); else CPM_BL_PACK(4, false); }
-#undef CPM_BL_PACK
-    CPM_LAUNCH_CHECK(ctx, "bricklist_pack_kernel");
-    return CPM_OK;
+int bricklist_poisoned(cpm_ctx* ctx, const cpm_bricklist_reduce* br) {
+    return br->poisoned ? set_error(ctx, CPM_ERR_DEVICE, "cpm_bricklist_reduce", "an earlier ticket's segment did not carry its header: the ranks' capacities may differ; make a new one") : CPM_OK;
 }
 
-int bricklist_add(cpm_ctx* ctx, cpm_bricklist_reduce* br, uint32_t capacity, uint32_t ticket, const void* seg, float* grid, unsigned long long* mailbox,
-                  hipStream_t s) {
-    const bool vec = (br->dims[0] & 3) == 0;
-    const dim3 g((unsigned)div_up(capacity, 16));
-    const unsigned char* sg = static_cast<const unsigned char*>(seg);
-#define CPM_BL_ADD(CH, VEC) CPM_LAUNCH(ctx, (bricklist_add_kernel<CH, VEC>), g, dim3(256), 0, s, sg, capacity, ticket, br->nb, br->dims[0], br->dims[1], br->dims[2], br->bxn, br->byn, grid, mailbox)
-    if (br->channels == 1) { if (vec) CPM_BL_ADD(1, true); else CPM_BL_ADD(1, false); }
+SegTarget sender_target(cpm_bricklist_reduce* br, const cpm_bricklist_reduce::Slot& sl) {
+    const int slot_i = (int)(sl.ticket % cpm_bricklist_reduce::kSlots);
+    SegTarget st;
+    st.seg = static_cast<unsigned char*>(br->seg[slot_i]);
+    st.capacity = sl.cap[br->comm->rank]; st.room = br->room; st.ticket = (uint32_t)sl.ticket;
+    st.ctl = br->ctl + 2 * slot_i;
+    st.mailbox = br->mailbox_dev + (size_t)slot_i * kBricklistMaxRanks + br->comm->rank;
+    return st;
+}
+
+// the root's two launches over the segments `S` names in `base`
+struct RootGrid { int dims[3]; int channels, bxn, byn; uint32_t nb; uint32_t* slot_of; };
+RootGrid root_grid_of(const cpm_bricklist_reduce* br) {
+    RootGrid g;
+    for (int a = 0; a < 3; ++a) g.dims[a] = br->dims[a];
+    g.channels = br->channels; g.bxn = br->bxn; g.byn = br->byn; g.nb = br->nb; g.slot_of = br->slot_of;
+    return g;
+}
+int bricklist_root_add(cpm_ctx* ctx, const RootGrid& rg, const RootSegs& S, const void* base, uint32_t ticket, float* grid, unsigned long long* mailbox,
+                       hipStream_t s) {
+    uint32_t w_index = 0, w_add = 0;
+    for (int i = 0; i < S.n; ++i) { w_index += (S.slots[i] + 255u) / 256u; w_add += (S.slots[i] + 15u) / 16u; }
+    if (w_add == 0) return CPM_OK;
+    const unsigned char* b = static_cast<const unsigned char*>(base);
+    CPM_LAUNCH(ctx, bricklist_index_kernel, dim3(w_index), dim3(256), 0, s, b, S, ticket, rg.nb, rg.channels, rg.slot_of);
+    CPM_LAUNCH_CHECK(ctx, "bricklist_index_kernel");
+    const bool vec = (rg.dims[0] & 3) == 0;
+#define CPM_BL_ADD(CH, VEC) CPM_LAUNCH(ctx, (bricklist_add_kernel<CH, VEC>), dim3(w_add), dim3(256), 0, s, b, S, ticket, rg.nb, rg.slot_of, rg.dims[0], rg.dims[1], rg.dims[2], rg.bxn, rg.byn, grid, mailbox)
+    if (rg.channels == 1) { if (vec) CPM_BL_ADD(1, true); else CPM_BL_ADD(1, false); }
     else { if (vec) CPM_BL_ADD(4, true); else CPM_BL_ADD(4, false); }
 #undef CPM_BL_ADD
     CPM_LAUNCH_CHECK(ctx, "bricklist_add_kernel");
     return CPM_OK;
 }
 
-uint32_t round_up_64(uint64_t v) { return (uint32_t)((v + 63ull) & ~63ull); }
+inline uint32_t table_of(const cpm_bricklist_reduce* br, int r) { return (uint32_t)(r < br->root ? r : r - 1); }
 
-// a sender's non-zero bricks of `grid` -> br->list (ascending) and br->count; the count also to `mailbox` when given.  marks: what
-// cpm_gather_fast_marked left for this grid (else a pass over the grid)
-int bricklist_own_list(cpm_ctx* ctx, cpm_bricklist_reduce* br, const float* grid, const uint8_t* marks, unsigned long long* mailbox, uint32_t ticket,
-                       hipStream_t s) {
-    if (marks) {
-        CPM_HIP_CHECK(ctx, hipMemcpyAsync(br->mask, marks, br->nb, hipMemcpyDeviceToDevice, s));
-    } else {
-        const bool vec = (br->dims[0] & 3) == 0;
-        const dim3 g((unsigned)div_up(br->nb, 16));
-        const int dx = br->dims[0], dy = br->dims[1], dz = br->dims[2];
-        if (br->channels == 1) {
-            if (vec) CPM_LAUNCH(ctx, (brick_nonzero_kernel<1, true>), g, dim3(256), 0, s, grid, dx, dy, dz, br->bxn, br->byn, br->nb, br->mask);
-            else CPM_LAUNCH(ctx, (brick_nonzero_kernel<1, false>), g, dim3(256), 0, s, grid, dx, dy, dz, br->bxn, br->byn, br->nb, br->mask);
-        } else {
-            if (vec) CPM_LAUNCH(ctx, (brick_nonzero_kernel<4, true>), g, dim3(256), 0, s, grid, dx, dy, dz, br->bxn, br->byn, br->nb, br->mask);
-            else CPM_LAUNCH(ctx, (brick_nonzero_kernel<4, false>), g, dim3(256), 0, s, grid, dx, dy, dz, br->bxn, br->byn, br->nb, br->mask);
-        }
-        CPM_LAUNCH_CHECK(ctx, "brick_nonzero_kernel");
-    }
-    CPM_LAUNCH(ctx, brick_slots_kernel, dim3((unsigned)div_up(br->nb, 4096)), dim3(1024), 0, s, br->mask, br->nb, br->list, br->slot, br->count, mailbox, ticket);
-    CPM_LAUNCH_CHECK(ctx, "brick_slots_kernel");
+int pack_grid_launch(cpm_ctx* ctx, const SegTarget& st, const int dims[3], int channels, const float* grid, const uint8_t* marks, hipStream_t s) {
+    const int bxn = div_up(dims[0], 4), byn = div_up(dims[1], 4), bzn = div_up(dims[2], 4);
+    const uint32_t nb = (uint32_t)((size_t)bxn * byn * bzn);
+    const bool vec = (dims[0] & 3) == 0;
+    const dim3 g((unsigned)div_up(nb, 16));
+#define CPM_BL_PACK(CH, VEC) CPM_LAUNCH(ctx, (bricklist_pack_grid_kernel<CH, VEC>), g, dim3(256), 0, s, grid, marks, nb, dims[0], dims[1], dims[2], bxn, byn, st)
+    if (channels == 1) { if (vec) CPM_BL_PACK(1, true); else CPM_BL_PACK(1, false); }
+    else { if (vec) CPM_BL_PACK(4, true); else CPM_BL_PACK(4, false); }
+#undef CPM_BL_PACK
+    CPM_LAUNCH_CHECK(ctx, "bricklist_pack_grid_kernel");
     return CPM_OK;
 }
 
@@ -982,13 +1097,20 @@ int cpm_bricklist_reduce_create(cpm_ctx* ctx, cpm_comm* comm, const cpm_grid_des
     br->channels = gd->channels;
     br->bxn = div_up(gd->dims[0], 4); br->byn = div_up(gd->dims[1], 4); br->bzn = div_up(gd->dims[2], 4);
     br->nb = (uint32_t)((size_t)br->bxn * br->byn * br->bzn);
+    br->room = round_up_64(br->nb);
     br->cells = (size_t)gd->dims[0] * gd->dims[1] * gd->dims[2];
-    const size_t nb = br->nb, words = (size_t)cpm_bricklist_reduce::kSlots * kBricklistMaxRanks;
+    const size_t nb = br->nb, words = 2 * (size_t)cpm_bricklist_reduce::kSlots * kBricklistMaxRanks;
     bool ok = hipHostMalloc((void**)&br->mailbox, words * 8, hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess &&
               hipHostGetDevicePointer((void**)&br->mailbox_dev, br->mailbox, 0) == hipSuccess;
-    if (ok && comm->rank != root)
-        ok = hipMalloc((void**)&br->mask, nb + 16) == hipSuccess && hipMalloc((void**)&br->list, nb * 4) == hipSuccess &&
-             hipMalloc((void**)&br->slot, nb * 4) == hipSuccess && hipMalloc((void**)&br->count, 16) == hipSuccess;
+    if (ok && comm->size > 1) {
+        if (comm->rank != root) {
+            ok = hipMalloc((void**)&br->ctl, 2 * cpm_bricklist_reduce::kSlots * 4) == hipSuccess &&
+                 hipMemset(br->ctl, 0, 2 * cpm_bricklist_reduce::kSlots * 4) == hipSuccess;
+        } else {
+            const size_t bytes = (size_t)(comm->size - 1) * nb * 4;
+            ok = hipMalloc((void**)&br->slot_of, bytes) == hipSuccess && hipMemset(br->slot_of, 0xff, bytes) == hipSuccess;
+        }
+    }
     if (!ok) {
         (void)hipGetLastError();
         cpm_bricklist_reduce_destroy(br);
@@ -1002,8 +1124,8 @@ int cpm_bricklist_reduce_create(cpm_ctx* ctx, cpm_comm* comm, const cpm_grid_des
 void cpm_bricklist_reduce_destroy(cpm_bricklist_reduce* br) {
     if (!br) return;
     (void)hipSetDevice(br->device);
-    for (auto& sl : br->slots) if (sl.ticket && !sl.completed) { (void)hipStreamSynchronize(sl.stream); break; }  // the mailbox outlives its writers
-    for (void* p : { (void*)br->mask, (void*)br->list, (void*)br->slot, (void*)br->count, br->again }) if (p) (void)hipFree(p);
+    for (auto& sl : br->slots) if (sl.ticket && !sl.completed) { (void)hipDeviceSynchronize(); break; }  // the mailbox outlives its writers
+    for (void* p : { (void*)br->ctl, (void*)br->slot_of, br->again }) if (p) (void)hipFree(p);
     for (void* p : br->seg) if (p) (void)hipFree(p);
     if (br->mailbox) (void)hipHostFree(br->mailbox);
     delete br;
@@ -1011,73 +1133,161 @@ void cpm_bricklist_reduce_destroy(cpm_bricklist_reduce* br) {
 
 uint32_t cpm_bricklist_reduce_bricks(const cpm_bricklist_reduce* br) { return br ? br->nb : 0; }
 
-int cpm_reduce_grid_bricklists(cpm_ctx* ctx, cpm_bricklist_reduce* br, float* grid, const uint8_t* nonzero_bricks, uint64_t* ticket_out, cpm_stream stream) {
+int cpm_bricklist_reduce_open(cpm_ctx* ctx, cpm_bricklist_reduce* br, uint64_t* ticket_out, cpm_bricklist_segment* seg_out) {
     CPM_ENTER(ctx);
-    CPM_REQUIRE(ctx, br && grid, "cpm_reduce_grid_bricklists: null argument");
-    CPM_REQUIRE_ALIGNED16(ctx, grid, "cpm_reduce_grid_bricklists");
-    hipStream_t s = (hipStream_t)stream;
+    CPM_REQUIRE(ctx, br, "cpm_bricklist_reduce_open: null argument");
+    int rc = bricklist_poisoned(ctx, br);
+    if (rc) return rc;
     constexpr int kSlots = cpm_bricklist_reduce::kSlots;
     const uint64_t ticket = br->next_ticket;
-    cpm_bricklist_reduce::Slot& sl = br->slots[ticket % kSlots];
-    CPM_REQUIRE(ctx, sl.completed, "cpm_reduce_grid_bricklists: 4 tickets issued and not completed (cpm_bricklist_reduce_complete)");
+    const int slot_i = (int)(ticket % kSlots);
+    cpm_bricklist_reduce::Slot& sl = br->slots[slot_i];
+    CPM_REQUIRE(ctx, sl.completed, "cpm_bricklist_reduce_open: 4 tickets opened and not completed (cpm_bricklist_reduce_complete)");
     const int rank = br->comm->rank, size = br->comm->size, root = br->root;
     cpm_bricklist_reduce::Slot fresh;
-    fresh.ticket = ticket; fresh.grid = grid; fresh.completed = false; fresh.stream = s;
+    fresh.ticket = ticket; fresh.completed = false; fresh.stream = sl.stream;
     if (size > 1) {
-        const Rccl* R = rccl(ctx);
-        if (!R) return CPM_ERR_UNSUPPORTED;
-        // capacities: from the counts of ticket - 2 (every rank's at the root, its own at a sender), long written when this ticket is issued
+        // capacities: from the counts of ticket - 2 (every rank's at the root, its own at a sender), long written when this ticket is opened
         cpm_bricklist_reduce::Slot* old = nullptr;
         if (ticket >= 3 && br->slots[(ticket - 2) % kSlots].ticket == ticket - 2) old = &br->slots[(ticket - 2) % kSlots];
         for (int r = 0; r < size; ++r) {
             if (r == root || (rank != root && r != rank)) continue;
             long long prev = -1;
-            if (old) { int rc = bricklist_count(ctx, br, *old, r); if (rc) return rc; prev = old->counts[r] == 0xffffffffu ? -1 : (long long)old->counts[r]; }
+            if (old) {
+                rc = bricklist_count(ctx, br, *old, r);
+                if (rc) return rc;
+                if (old->counts[r] == 0xffffffffu) { br->poisoned = true; return bricklist_poisoned(ctx, br); }
+                prev = (long long)old->counts[r];
+            }
             fresh.cap[r] = cpm_bricklist_capacity_for(br->nb, prev);
         }
-        const int slot_i = (int)(ticket % kSlots);
-        unsigned long long* mb = br->mailbox_dev + (size_t)slot_i * kBricklistMaxRanks;
+        size_t need = 0;
+        if (rank != root) need = seg_size(br->room, br->channels);
+        else for (int r = 0; r < size; ++r) if (r != root) need += (seg_size(fresh.cap[r], br->channels) + 255) & ~(size_t)255;
+        rc = bricklist_grow(ctx, &br->seg[slot_i], &br->seg_bytes[slot_i], need, sl.stream);
+        if (rc) return rc;
+    }
+    sl = fresh;
+    br->next_ticket = ticket + 1;
+    if (ticket_out) *ticket_out = ticket;
+    if (seg_out) {
+        memset(seg_out, 0, sizeof *seg_out);
+        seg_out->ticket = (uint32_t)ticket; seg_out->channels = (uint32_t)br->channels; seg_out->room = br->room;
+        if (size > 1 && rank != root) {
+            const SegTarget st = sender_target(br, sl);
+            seg_out->segment = st.seg; seg_out->capacity = st.capacity; seg_out->control = st.ctl; seg_out->mailbox = st.mailbox;
+        }
+    }
+    return CPM_OK;
+}
+
+int cpm_bricklist_pack_grid(cpm_ctx* ctx, cpm_bricklist_reduce* br, uint64_t ticket, const float* grid, const uint8_t* nonzero_bricks, cpm_stream stream) {
+    CPM_ENTER(ctx);
+    CPM_REQUIRE(ctx, br && ticket >= 1 && ticket < br->next_ticket, "cpm_bricklist_pack_grid: no such ticket");
+    cpm_bricklist_reduce::Slot& sl = br->slots[ticket % cpm_bricklist_reduce::kSlots];
+    CPM_REQUIRE(ctx, sl.ticket == ticket && !sl.completed && !sl.exchanged, "cpm_bricklist_pack_grid: the ticket is not open");
+    if (br->comm->size == 1 || br->comm->rank == br->root) return CPM_OK;
+    CPM_REQUIRE(ctx, grid, "cpm_bricklist_pack_grid: null grid");
+    CPM_REQUIRE_ALIGNED16(ctx, grid, "cpm_bricklist_pack_grid");
+    return pack_grid_launch(ctx, sender_target(br, sl), br->dims, br->channels, grid, nonzero_bricks, (hipStream_t)stream);
+}
+
+int cpm_debug_root_add_segments(cpm_ctx* ctx, const cpm_bricklist_segment* segs, int n, const cpm_grid_desc* gd, float* grid, uint32_t* slot_of,
+                                cpm_stream stream) {
+    CPM_ENTER(ctx);
+    CPM_REQUIRE(ctx, segs && n >= 1 && n < kBricklistMaxRanks && gd && grid && slot_of, "cpm_debug_root_add_segments: bad argument");
+    CPM_REQUIRE(ctx, gd->channels == 1 || gd->channels == 4, "cpm_debug_root_add_segments: channels");
+    CPM_REQUIRE_ALIGNED16(ctx, grid, "cpm_debug_root_add_segments");
+    RootGrid rg;
+    for (int a = 0; a < 3; ++a) rg.dims[a] = gd->dims[a];
+    rg.channels = gd->channels; rg.bxn = div_up(gd->dims[0], 4); rg.byn = div_up(gd->dims[1], 4);
+    rg.nb = (uint32_t)((size_t)rg.bxn * rg.byn * div_up(gd->dims[2], 4));
+    rg.slot_of = slot_of;
+    RootSegs S;
+    memset(&S, 0, sizeof S);
+    S.n = n;
+    for (int i = 0; i < n; ++i) {   // (segments anywhere on the device: offsets from address 0)
+        CPM_REQUIRE(ctx, segs[i].segment && segs[i].ticket == segs[0].ticket && (int)segs[i].channels == gd->channels, "cpm_debug_root_add_segments: segment");
+        S.slots[i] = segs[i].capacity; S.hdr_cap[i] = segs[i].capacity; S.table[i] = (uint32_t)i; S.rank[i] = i;
+        S.off[i] = (unsigned long long)reinterpret_cast<uintptr_t>(segs[i].segment);
+    }
+    return bricklist_root_add(ctx, rg, S, nullptr, segs[0].ticket, grid, nullptr, (hipStream_t)stream);
+}
+
+int cpm_debug_pack_grid_segment(cpm_ctx* ctx, const cpm_bricklist_segment* seg, const cpm_grid_desc* gd, const float* grid, const uint8_t* nonzero_bricks,
+                                cpm_stream stream) {
+    CPM_ENTER(ctx);
+    CPM_REQUIRE(ctx, seg && seg->segment && seg->control && gd && grid, "cpm_debug_pack_grid_segment: null argument");
+    CPM_REQUIRE(ctx, (gd->channels == 1 || gd->channels == 4) && (uint32_t)gd->channels == seg->channels, "cpm_debug_pack_grid_segment: channels");
+    CPM_REQUIRE_ALIGNED16(ctx, grid, "cpm_debug_pack_grid_segment");
+    SegTarget st;
+    st.seg = static_cast<unsigned char*>(seg->segment);
+    st.capacity = seg->capacity; st.room = seg->room; st.ticket = seg->ticket; st.ctl = seg->control; st.mailbox = seg->mailbox;
+    return pack_grid_launch(ctx, st, gd->dims, gd->channels, grid, nonzero_bricks, (hipStream_t)stream);
+}
+
+int cpm_bricklist_reduce_exchange(cpm_ctx* ctx, cpm_bricklist_reduce* br, uint64_t ticket, float* root_grid, cpm_stream stream) {
+    CPM_ENTER(ctx);
+    CPM_REQUIRE(ctx, br && ticket >= 1 && ticket < br->next_ticket, "cpm_bricklist_reduce_exchange: no such ticket");
+    int rc = bricklist_poisoned(ctx, br);
+    if (rc) return rc;
+    constexpr int kSlots = cpm_bricklist_reduce::kSlots;
+    const int slot_i = (int)(ticket % kSlots);
+    cpm_bricklist_reduce::Slot& sl = br->slots[slot_i];
+    CPM_REQUIRE(ctx, sl.ticket == ticket && !sl.completed && !sl.exchanged, "cpm_bricklist_reduce_exchange: the ticket is not open (or was exchanged already)");
+    hipStream_t s = (hipStream_t)stream;
+    const int rank = br->comm->rank, size = br->comm->size, root = br->root;
+    sl.stream = s;
+    if (size > 1) {
+        const Rccl* R = rccl(ctx);
+        if (!R) return CPM_ERR_UNSUPPORTED;
         if (rank != root) {
-            // this rank's bricks -> list + count (-> its mailbox word) -> segment -> the root
-            int rc = bricklist_own_list(ctx, br, grid, nonzero_bricks, mb + rank, (uint32_t)ticket, s);
-            if (rc) return rc;
-            const size_t bytes = seg_size(fresh.cap[rank], br->channels);
-            rc = bricklist_grow(ctx, &br->seg[slot_i], &br->seg_bytes[slot_i], bytes, s);
-            if (rc) return rc;
-            rc = bricklist_pack(ctx, br, fresh.cap[rank], (uint32_t)ticket, grid, br->seg[slot_i], s);
-            if (rc) return rc;
+            const size_t bytes = seg_size(sl.cap[rank], br->channels);
             ProfScope ps(ctx, "rccl_bricklist_send", s);
             CPM_NCCL_CHECK(ctx, R, R->Send(br->seg[slot_i], bytes, ncclInt8, root, br->comm->comm, s));
         } else {
-            size_t total = 0;
-            for (int r = 0; r < size; ++r) if (r != root) total += (seg_size(fresh.cap[r], br->channels) + 255) & ~(size_t)255;
-            int rc = bricklist_grow(ctx, &br->seg[slot_i], &br->seg_bytes[slot_i], total, s);
-            if (rc) return rc;
+            CPM_REQUIRE(ctx, root_grid, "cpm_bricklist_reduce_exchange: the root needs its grid");
+            CPM_REQUIRE_ALIGNED16(ctx, root_grid, "cpm_bricklist_reduce_exchange");
+            sl.grid = root_grid;
             unsigned char* base = static_cast<unsigned char*>(br->seg[slot_i]);
+            RootSegs S;
+            memset(&S, 0, sizeof S);
             {
                 ProfScope ps(ctx, "rccl_bricklist_recv", s);
                 CPM_NCCL_CHECK(ctx, R, R->GroupStart());
                 size_t off = 0;
-                for (int r = 0; r < size; ++r) {
+                for (int r = 0; r < size; ++r) {  // in rank order: a brick several ranks list is summed in that order
                     if (r == root) continue;
-                    const size_t bytes = seg_size(fresh.cap[r], br->channels);
+                    const size_t bytes = seg_size(sl.cap[r], br->channels);
                     ncclResult_t e = R->Recv(base + off, bytes, ncclInt8, r, br->comm->comm, s);
                     if (e != ncclSuccess) { (void)R->GroupEnd(); return set_error(ctx, CPM_ERR_DEVICE, "ncclRecv", R->GetErrorString(e)); }
+                    S.slots[S.n] = sl.cap[r]; S.hdr_cap[S.n] = sl.cap[r]; S.table[S.n] = table_of(br, r); S.rank[S.n] = r; S.off[S.n] = off;
+                    ++S.n;
                     off += (bytes + 255) & ~(size_t)255;
                 }
                 CPM_NCCL_CHECK(ctx, R, R->GroupEnd());
             }
-            size_t off = 0;
-            for (int r = 0; r < size; ++r) {  // in rank order: a brick two ranks list is summed in that order
-                if (r == root) continue;
-                rc = bricklist_add(ctx, br, fresh.cap[r], (uint32_t)ticket, base + off, grid, mb + r, s);
-                if (rc) return rc;
-                off += (seg_size(fresh.cap[r], br->channels) + 255) & ~(size_t)255;
-            }
+            rc = bricklist_root_add(ctx, root_grid_of(br), S, base, (uint32_t)ticket, root_grid, br->mailbox_dev + (size_t)slot_i * kBricklistMaxRanks, s);
+            if (rc) return rc;
         }
     }
-    sl = fresh;
-    br->next_ticket = ticket + 1;
+    sl.exchanged = true;
+    return CPM_OK;
+}
+
+int cpm_reduce_grid_bricklists(cpm_ctx* ctx, cpm_bricklist_reduce* br, float* grid, const uint8_t* nonzero_bricks, uint64_t* ticket_out, cpm_stream stream) {
+    CPM_ENTER(ctx);
+    CPM_REQUIRE(ctx, br && grid, "cpm_reduce_grid_bricklists: null argument");
+    CPM_REQUIRE_ALIGNED16(ctx, grid, "cpm_reduce_grid_bricklists");
+    uint64_t ticket = 0;
+    int rc = cpm_bricklist_reduce_open(ctx, br, &ticket, nullptr);
+    if (rc) return rc;
+    rc = cpm_bricklist_pack_grid(ctx, br, ticket, grid, nonzero_bricks, stream);
+    if (!rc) rc = cpm_bricklist_reduce_exchange(ctx, br, ticket, grid, stream);
+    if (rc) {  // (nothing of this ticket reached the wire, or the transport failed: the slot is given back either way)
+        br->slots[ticket % cpm_bricklist_reduce::kSlots].completed = true;
+        return rc;
+    }
     if (ticket_out) *ticket_out = ticket;
     return CPM_OK;
 }
@@ -1085,41 +1295,57 @@ int cpm_reduce_grid_bricklists(cpm_ctx* ctx, cpm_bricklist_reduce* br, float* gr
 int cpm_bricklist_reduce_complete(cpm_ctx* ctx, cpm_bricklist_reduce* br, uint64_t ticket, cpm_stream stream, cpm_bricklist_info* info) {
     CPM_ENTER(ctx);
     CPM_REQUIRE(ctx, br && ticket >= 1 && ticket < br->next_ticket, "cpm_bricklist_reduce_complete: no such ticket");
-    cpm_bricklist_reduce::Slot& sl = br->slots[ticket % cpm_bricklist_reduce::kSlots];
+    constexpr int kSlots = cpm_bricklist_reduce::kSlots;
+    const int slot_i = (int)(ticket % kSlots);
+    cpm_bricklist_reduce::Slot& sl = br->slots[slot_i];
     CPM_REQUIRE(ctx, sl.ticket == ticket, "cpm_bricklist_reduce_complete: the ticket is more than 4 calls old");
+    int rc = bricklist_poisoned(ctx, br);
+    if (rc) return rc;
     hipStream_t s = (hipStream_t)stream;
     const int rank = br->comm->rank, size = br->comm->size, root = br->root;
     uint64_t sent = 0, received = 0;
     uint32_t listed = 0;
     if (size > 1) {
+        CPM_REQUIRE(ctx, sl.completed || sl.exchanged, "cpm_bricklist_reduce_complete: the ticket was opened but never exchanged");
         const Rccl* R = rccl(ctx);
         if (!R) return CPM_ERR_UNSUPPORTED;
         for (int r = 0; r < size; ++r) {
             if (r == root || (rank != root && r != rank)) continue;
-            int rc = bricklist_count(ctx, br, sl, r);
+            rc = bricklist_count(ctx, br, sl, r);
             if (rc) return rc;
             const uint32_t n = sl.counts[r];
-            if (n == 0xffffffffu) return set_error(ctx, CPM_ERR_DEVICE, "cpm_bricklist_reduce_complete", "a received segment did not carry this ticket's header");
+            if (n == 0xffffffffu) {
+                br->poisoned = true;
+                return set_error(ctx, CPM_ERR_DEVICE, "cpm_bricklist_reduce_complete", "a received segment did not carry this ticket's header");
+            }
             const size_t first_bytes = seg_size(sl.cap[r], br->channels);
             if (rank == root) { received += first_bytes; listed += n; } else sent += first_bytes;
             if (sl.completed || n <= sl.cap[r]) continue;
-            // the segment carried its header alone: this pair exchanges again, at the exact size both now know
+            // the list had outgrown its segment: this pair exchanges again, at the exact size both now know -- from the sender's same
+            // buffer (it has room for every brick: nothing is rebuilt), added at the root after everything else
             const uint32_t exact = round_up_64(n);
             const size_t bytes = seg_size(exact, br->channels);
-            rc = bricklist_grow(ctx, &br->again, &br->again_bytes, bytes, s);
-            if (rc) return rc;
             if (rank != root) {
-                // (list and count have served later tickets since: made again from the ticket's grid, which the caller has left alone)
-                rc = bricklist_own_list(ctx, br, sl.grid, nullptr, nullptr, (uint32_t)ticket, s);
-                if (rc) return rc;
-                rc = bricklist_pack(ctx, br, exact, (uint32_t)ticket, sl.grid, br->again, s);
-                if (rc) return rc;
-                CPM_NCCL_CHECK(ctx, R, R->Send(br->again, bytes, ncclInt8, root, br->comm->comm, s));
+                CPM_NCCL_CHECK(ctx, R, R->Send(br->seg[slot_i], bytes, ncclInt8, root, br->comm->comm, s));
                 sent += bytes;
             } else {
-                CPM_NCCL_CHECK(ctx, R, R->Recv(br->again, bytes, ncclInt8, r, br->comm->comm, s));
-                rc = bricklist_add(ctx, br, exact, (uint32_t)ticket, br->again, sl.grid, nullptr, s);
+                rc = bricklist_grow(ctx, &br->again, &br->again_bytes, bytes, s);
                 if (rc) return rc;
+                CPM_NCCL_CHECK(ctx, R, R->Recv(br->again, bytes, ncclInt8, r, br->comm->comm, s));
+                RootSegs S;
+                memset(&S, 0, sizeof S);
+                S.n = 1; S.slots[0] = exact; S.hdr_cap[0] = sl.cap[r]; S.table[0] = table_of(br, r); S.rank[0] = r; S.off[0] = 0;
+                unsigned long long* ack_dev = br->mailbox_dev + (size_t)(kSlots + slot_i) * kBricklistMaxRanks;
+                volatile unsigned long long* ack = br->mailbox + (size_t)(kSlots + slot_i) * kBricklistMaxRanks + r;
+                rc = bricklist_root_add(ctx, root_grid_of(br), S, br->again, (uint32_t)ticket, sl.grid, ack_dev, s);
+                if (rc) return rc;
+                // (a rare path: wait for it and see that the segment that came was this ticket's and carried the count both sides sized it for)
+                CPM_HIP_CHECK(ctx, hipStreamSynchronize(s));
+                const unsigned long long v = __atomic_load_n(ack, __ATOMIC_ACQUIRE);
+                if ((uint32_t)(v >> 32) != (uint32_t)ticket || (uint32_t)v != n) {
+                    br->poisoned = true;
+                    return set_error(ctx, CPM_ERR_DEVICE, "cpm_bricklist_reduce_complete", "the segment of a repeated exchange did not carry the expected header: bricks were not added");
+                }
                 received += bytes;
             }
             ++sl.resent;
@@ -1135,6 +1361,50 @@ int cpm_bricklist_reduce_complete(cpm_ctx* ctx, cpm_bricklist_reduce* br, uint64
         info->dense_bytes = (uint64_t)br->cells * sizeof(float) * (uint64_t)br->channels;
         info->listed_bricks = listed;
     }
+    return CPM_OK;
+}
+
+int cpm_bricklist_segment_to_grid(cpm_ctx* ctx, const cpm_bricklist_segment* seg, const cpm_grid_desc* gd, float* grid_out, cpm_stream stream) {
+    CPM_ENTER(ctx);
+    CPM_REQUIRE(ctx, seg && seg->segment && gd && grid_out, "cpm_bricklist_segment_to_grid: null argument");
+    CPM_REQUIRE(ctx, (gd->channels == 1 || gd->channels == 4) && (uint32_t)gd->channels == seg->channels, "cpm_bricklist_segment_to_grid: channels");
+    CPM_REQUIRE(ctx, gd->dims[0] >= 1 && gd->dims[1] >= 1 && gd->dims[2] >= 1, "cpm_bricklist_segment_to_grid: dims");
+    CPM_REQUIRE_ALIGNED16(ctx, grid_out, "cpm_bricklist_segment_to_grid");
+    const int bxn = div_up(gd->dims[0], 4), byn = div_up(gd->dims[1], 4), bzn = div_up(gd->dims[2], 4);
+    const uint32_t nb = (uint32_t)((size_t)bxn * byn * bzn);
+    const bool vec = (gd->dims[0] & 3) == 0;
+    const unsigned char* sg = static_cast<const unsigned char*>(seg->segment);
+    const dim3 g((unsigned)(seg->room / 16u < 4096u ? (seg->room + 15u) / 16u : 4096u));
+    hipStream_t s = (hipStream_t)stream;
+#define CPM_SEG2GRID(CH, VEC) CPM_LAUNCH(ctx, (segment_to_grid_kernel<CH, VEC>), g, dim3(256), 0, s, sg, seg->room, nb, gd->dims[0], gd->dims[1], gd->dims[2], bxn, byn, grid_out)
+    if (gd->channels == 1) { if (vec) CPM_SEG2GRID(1, true); else CPM_SEG2GRID(1, false); }
+    else { if (vec) CPM_SEG2GRID(4, true); else CPM_SEG2GRID(4, false); }
+#undef CPM_SEG2GRID
+    CPM_LAUNCH_CHECK(ctx, "segment_to_grid_kernel");
+    return CPM_OK;
+}
+
+int cpm_comm_send(cpm_ctx* ctx, cpm_comm* comm, const void* buf, size_t bytes, int peer, cpm_stream stream) {
+    CPM_ENTER(ctx);
+    CPM_REQUIRE(ctx, comm && (buf || bytes == 0), "cpm_comm_send: null argument");
+    CPM_REQUIRE(ctx, peer >= 0 && peer < comm->size && peer != comm->rank, "cpm_comm_send: peer");
+    if (bytes == 0) return CPM_OK;
+    const Rccl* R = rccl(ctx);
+    if (!R) return CPM_ERR_UNSUPPORTED;
+    ProfScope ps(ctx, "rccl_send", (hipStream_t)stream);
+    CPM_NCCL_CHECK(ctx, R, R->Send(buf, bytes, ncclInt8, peer, comm->comm, (hipStream_t)stream));
+    return CPM_OK;
+}
+
+int cpm_comm_recv(cpm_ctx* ctx, cpm_comm* comm, void* buf, size_t bytes, int peer, cpm_stream stream) {
+    CPM_ENTER(ctx);
+    CPM_REQUIRE(ctx, comm && (buf || bytes == 0), "cpm_comm_recv: null argument");
+    CPM_REQUIRE(ctx, peer >= 0 && peer < comm->size && peer != comm->rank, "cpm_comm_recv: peer");
+    if (bytes == 0) return CPM_OK;
+    const Rccl* R = rccl(ctx);
+    if (!R) return CPM_ERR_UNSUPPORTED;
+    ProfScope ps(ctx, "rccl_recv", (hipStream_t)stream);
+    CPM_NCCL_CHECK(ctx, R, R->Recv(buf, bytes, ncclInt8, peer, comm->comm, (hipStream_t)stream));
     return CPM_OK;
 }
 

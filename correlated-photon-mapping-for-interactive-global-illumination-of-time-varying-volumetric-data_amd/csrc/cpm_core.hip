@@ -182,7 +182,17 @@ int cpm_create(int device, cpm_ctx** out) {
     if (!ctx) return set_error(nullptr, CPM_ERR_OUT_OF_MEMORY, "cpm_create", "host allocation failed");
     ctx->device = device;
     hipDeviceProp_t prop;
-    if (hipGetDeviceProperties(&prop, device) == hipSuccess) ctx->num_cus = prop.multiProcessorCount;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess) {
+        ctx->num_cus = prop.multiProcessorCount;
+        // the LDS a workgroup may take once hipFuncSetAttribute has allowed it (gfx950: 160 KiB; the attributes' largest -- ROCm releases
+        // differ in which of them carries the opt-in limit)
+        size_t lds = prop.sharedMemPerBlock;
+        if (prop.maxSharedMemoryPerMultiProcessor > lds) lds = prop.maxSharedMemoryPerMultiProcessor;
+        int optin = 0;
+        if (hipDeviceGetAttribute(&optin, hipDeviceAttributeSharedMemPerBlockOptin, device) == hipSuccess && (size_t)optin > lds) lds = (size_t)optin;
+        (void)hipGetLastError();
+        if (lds >= 16 * 1024) ctx->lds_per_block = lds;
+    }
     if (hipMalloc((void**)&ctx->dir_hint, 16 * sizeof(float)) != hipSuccess || hipMemset(ctx->dir_hint, 0, 16 * sizeof(float)) != hipSuccess) {
         delete ctx;
         return set_error(nullptr, CPM_ERR_OUT_OF_MEMORY, "cpm_create", "device allocation failed");

@@ -23,6 +23,7 @@ struct cpm_ctx {
     std::vector<cpm_prof_entry> prof_entries;
     int device = 0;
     int num_cus = 256;
+    size_t lds_per_block = 160 * 1024;  // LDS a workgroup may use on this device (cpm_create asks the device)
     std::string last_error;
     // grow-only scratch arenas (no allocation in steady state)
     void* scratch[8] = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };
@@ -196,5 +197,34 @@ struct GridDev {
     int dx, dy, dz, channels;
     Affine t2i, i2t;
 };
+
+
+// ---- brick-list segments (cpm_reduce_grid_bricklists; written by cpm_comm.hip's pack launch and by cpm_gather_fast_segment) -------------
+// A segment = [ SegHeader, 16 bytes ][ slot 0 ][ slot 1 ] ... ; a slot = [ brick id, 0, 0, 0 ][ 64 * channels floats ]: one non-zero
+// 4 x 4 x 4-voxel brick of a rank's light volume, values in (z, y, x, channel) order.  Slots are handed out by ONE device counter per
+// launch (any order: the root adds by brick id, a sender lists a brick once); the launch's last workgroup writes the header and the
+// sender's pinned mailbox word and leaves the counter words zero for the next launch.  The first `capacity` slots travel.
+constexpr uint32_t kSegMagic = 0x62726b32u;  // "brk2"
+struct SegHeader { uint32_t count, capacity, ticket, magic; };
+__host__ __device__ inline size_t seg_slot_bytes(int channels) { return 16u + 256u * (size_t)channels; }
+__host__ __device__ inline size_t seg_size(uint32_t capacity, int channels) { return sizeof(SegHeader) + (size_t)capacity * seg_slot_bytes(channels); }
+struct SegTarget {
+    unsigned char* seg = nullptr;          // device: header + `room` slots
+    uint32_t capacity = 0, room = 0, ticket = 0;
+    uint32_t* ctl = nullptr;               // device, 2 words: slots handed out, workgroups done (zero between launches)
+    unsigned long long* mailbox = nullptr; // device address of the pinned word: ticket << 32 | count
+};
+// the end of a launch that fills a segment: every workgroup's thread 0 calls this after its last slot; the last one publishes the count
+__device__ inline void seg_finish(const SegTarget& st, uint32_t n_workgroups) {
+    __threadfence();
+    const uint32_t d = atomicAdd(&st.ctl[1], 1u);
+    if (d + 1u != n_workgroups) return;
+    __threadfence();
+    const uint32_t n = atomicExch(&st.ctl[0], 0u);
+    atomicExch(&st.ctl[1], 0u);
+    *reinterpret_cast<SegHeader*>(st.seg) = SegHeader{ n, st.capacity, st.ticket, kSegMagic };
+    if (st.mailbox)
+        __hip_atomic_store(st.mailbox, ((unsigned long long)st.ticket << 32) | (unsigned long long)n, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
 
 }  // namespace cpm

@@ -527,11 +527,16 @@ CPM_DEV void brick_record(const GridDev& G, float4 a, float pg, float pb, int ox
 #define CPM_BRICK_WAVES 8
 #endif
 constexpr int kMaxSubBricks = 512;  // 4x4x4 sub-bricks of a brick (a tile of <= 159 KiB holds <= 320)
-template <int MAXC, int CH>
+// SEG (cpm_gather_fast_segment): nothing is stored to a grid; a gather brick's non-zero 4x4x4 sub-bricks go to slots of a brick-list segment
+// (cpm_ctx.h) taken from its device counter -- one atomic per gather brick --, a wave writing one sub-brick's 64 values (256 contiguous
+// bytes per channel plane of the slot); no zeros, no marks; the launch's last workgroup writes the segment's header and mailbox word.
+template <int MAXC, int CH, bool SEG>
 __global__ __launch_bounds__(kBrickThreads, (CH == 4 ? 4 : CPM_BRICK_WAVES)) void fast_brick_kernel(const float* __restrict__ sorted, const uint32_t* __restrict__ table, GridDev G,
                                                                   BrickLayout L, float radius, float k, int accumulate, float* __restrict__ out,
-                                                                  uint8_t* __restrict__ marks) {
+                                                                  uint8_t* __restrict__ marks, SegTarget st) {
     extern __shared__ long long s_tile[];
+    __shared__ uint32_t s_slot[SEG ? kMaxSubBricks : 1];   // SEG: a sub-brick's rank among the brick's non-zero ones (0xffffffff: all zero)
+    __shared__ uint32_t s_base;
     // marks (nullable): one byte per 4x4x4-voxel brick of the grid (cpm_mark_touched_bricks' numbering), 1 where this launch
     // leaves a non-zero value, 0 elsewhere -- every byte written: what cpm_allreduce_grid_sparse would otherwise read the whole
     // volume again for
@@ -548,7 +553,7 @@ __global__ __launch_bounds__(kBrickThreads, (CH == 4 ? 4 : CPM_BRICK_WAVES)) voi
     const float4* __restrict__ rec = reinterpret_cast<const float4*>(sorted);
     // the zeros of the bricks nothing reaches (not in accumulate mode): one streaming pass over the volume, every lane
     // looks its voxels' brick up itself (two cached loads) -- no per-brick chain of dependent table reads in a workgroup
-    if (!accumulate) {
+    if (!SEG && !accumulate) {
         const size_t cells = (size_t)G.dx * G.dy * G.dz;
         if (CH == 1 && (G.dx & 3) == 0) {  // 4 voxels of one x-row (and one brick: bricks are >= 8 wide) per lane and turn
             for (size_t i = ((size_t)blockIdx.x * kBrickThreads + t) * 4; i < cells; i += (size_t)gridDim.x * kBrickThreads * 4) {
@@ -592,7 +597,7 @@ __global__ __launch_bounds__(kBrickThreads, (CH == 4 ? 4 : CPM_BRICK_WAVES)) voi
         for (int w = t; w < words; w += kBrickThreads) s_tile[w] = 0ll;
         long long* my_tile = s_tile;
         const int nsub = L.bvox >> 6;
-        if (marks) for (int w = t; w < nsub; w += kBrickThreads) s_flag[w] = 0;  // (the lane that read flag w for the brick before)
+        if (marks || SEG) for (int w = t; w < nsub; w += kBrickThreads) s_flag[w] = 0;  // (the lane that read flag w for the brick before)
         __syncthreads();
         for (uint32_t first = j0; first < j1; first += (uint32_t)(kBrickPer * kBrickThreads)) {  // uniform
             fetch(first + (uint32_t)(kBrickPer * kBrickThreads), an, an2);
@@ -608,6 +613,56 @@ __global__ __launch_bounds__(kBrickThreads, (CH == 4 ? 4 : CPM_BRICK_WAVES)) voi
             for (int q = 0; q < kBrickPer; ++q) { a[q] = an[q]; a2[q] = an2[q]; }
         }
         __syncthreads();
+        if (SEG) {
+            // which sub-bricks hold a non-zero value (what the dense launch would store: the rounded sums)
+            for (int v = t; v < L.bvox; v += kBrickThreads) {
+                const int lx = v & (BX - 1), ly = (v >> L.lx) & (BY - 1), lz = v >> (L.lx + L.ly);
+                if (ox + lx >= G.dx || oy + ly >= G.dy || oz + lz >= G.dz) continue;
+                bool nonzero = (float)s_tile[v] * invS != 0.f;
+                if (CH == 4) nonzero = nonzero || (float)s_tile[L.bvox + v] * invS != 0.f || (float)s_tile[2 * L.bvox + v] * invS != 0.f;
+                if (nonzero) s_flag[(lx >> 2) + (BX >> 2) * ((ly >> 2) + (BY >> 2) * (lz >> 2))] = 1;
+            }
+            __syncthreads();
+            // their slots: ranks inside the brick by ballot (wave 0), one atomic on the segment's counter for the brick
+            if (t < 64) {
+                uint32_t running = 0;
+                for (int w0 = 0; w0 < nsub; w0 += 64) {
+                    const int w = w0 + t;
+                    const bool f = w < nsub && s_flag[w] != 0;
+                    const unsigned long long m = __ballot(f);
+                    if (w < nsub) s_slot[w] = f ? running + (uint32_t)__popcll(m & ((1ull << t) - 1ull)) : 0xffffffffu;
+                    running += (uint32_t)__popcll(m);
+                }
+                if (t == 0) s_base = running ? atomicAdd(&st.ctl[0], running) : 0u;
+            }
+            __syncthreads();
+            const size_t slot_bytes = seg_slot_bytes(CH);
+            for (int idx = t; idx < nsub * 64; idx += kBrickThreads) {
+                const int w = idx >> 6, j = idx & 63;
+                const uint32_t rel = s_slot[w];
+                if (rel == 0xffffffffu) continue;   // (uniform per wave: a wave writes one sub-brick)
+                const uint32_t slot = s_base + rel;
+                if (slot >= st.room) continue;
+                const int sx = w % (BX >> 2), sy = (w / (BX >> 2)) % (BY >> 2), sz = w / ((BX >> 2) * (BY >> 2));
+                const int lx = 4 * sx + (j & 3), ly = 4 * sy + ((j >> 2) & 3), lz = 4 * sz + (j >> 4);
+                const int v = lx + BX * (ly + BY * lz);
+                const bool inside = ox + lx < G.dx && oy + ly < G.dy && oz + lz < G.dz;
+                unsigned char* p = st.seg + sizeof(SegHeader) + (size_t)slot * slot_bytes;
+                if (j == 0) {
+                    const uint32_t id = (uint32_t)((ox >> 2) + sx) + (uint32_t)nbx4 * ((uint32_t)((oy >> 2) + sy) + (uint32_t)nby4 * (uint32_t)((oz >> 2) + sz));
+                    *reinterpret_cast<uint4*>(p) = make_uint4(id, 0u, 0u, 0u);
+                }
+                const float fr = inside ? (float)s_tile[v] * invS : 0.f;
+                if (CH == 1) {
+                    reinterpret_cast<float*>(p + 16)[j] = fr;
+                } else {
+                    const float fg = inside ? (float)s_tile[L.bvox + v] * invS : 0.f, fb = inside ? (float)s_tile[2 * L.bvox + v] * invS : 0.f;
+                    reinterpret_cast<float4*>(p + 16)[j] = make_float4(fr, fg, fb, 0.f);
+                }
+            }
+            __syncthreads();  // the tile is cleared again for the next brick
+            continue;
+        }
         for (int v = t; v < L.bvox; v += kBrickThreads) {
             const int lx = v & (BX - 1), ly = (v >> L.lx) & (BY - 1), lz = v >> (L.lx + L.ly);
             const int gx = ox + lx, gy = oy + ly, gz = oz + lz;
@@ -636,6 +691,7 @@ __global__ __launch_bounds__(kBrickThreads, (CH == 4 ? 4 : CPM_BRICK_WAVES)) voi
                 if (4 * gx4 < G.dx && 4 * gy4 < G.dy && 4 * gz4 < G.dz) marks[(uint32_t)gx4 + (uint32_t)nbx4 * ((uint32_t)gy4 + (uint32_t)nby4 * (uint32_t)gz4)] = s_flag[w];
             }
     }
+    if (SEG && t == 0) seg_finish(st, gridDim.x);
 }
 
 // ---- boxes of 4 or more candidates along some axis: tiles with a halo, no copies ------------------------------------------------------
@@ -705,10 +761,16 @@ __global__ __launch_bounds__(kBrickThreads, (CH == 4 ? 4 : CPM_BRICK_WAVES)) voi
 }
 
 // One workgroup per brick of the grid (see fast_halo_kernel).
-template <int CH>
+// SEG (cpm_gather_fast_segment): a brick's sums go to an LDS copy instead of the grid, its non-zero 4x4x4 sub-bricks from there to slots of a
+// brick-list segment (as fast_brick_kernel<., ., true>); bricks no tile covers write nothing.
+constexpr int kSegMergeVoxels = 2048;  // the bricks of wide boxes (brick_shape: at most 2^11 voxels)
+template <int CH, bool SEG>
 __global__ __launch_bounds__(256) void fast_halo_merge_kernel(const long long* __restrict__ stage, const uint32_t* __restrict__ table, GridDev G, BrickLayout L,
-                                                              float k, int accumulate, float* __restrict__ out, uint8_t* __restrict__ marks) {
+                                                              float k, int accumulate, float* __restrict__ out, uint8_t* __restrict__ marks, SegTarget st) {
     __shared__ uint8_t s_flag[kMaxSubBricks];
+    __shared__ float s_val[SEG ? kSegMergeVoxels * (CH == 4 ? 3 : 1) : 1];
+    __shared__ uint32_t s_slot[SEG ? kSegMergeVoxels / 64 : 1];
+    __shared__ uint32_t s_base;
     constexpr int CH3 = CH == 4 ? 3 : 1;
     const int t = threadIdx.x;
     const int BX = 1 << L.lx, BY = 1 << L.ly, BZ = 1 << L.lz;
@@ -740,11 +802,11 @@ __global__ __launch_bounds__(256) void fast_halo_merge_kernel(const long long* _
             src[d] = lit ? stage + (size_t)sbv[d] * (size_t)words : nullptr;
             n_src += lit ? 1 : 0;
         }
-        if (marks) for (int w = t; w < nsub; w += 256) s_flag[w] = 0;
+        if (marks || SEG) for (int w = t; w < nsub; w += 256) s_flag[w] = 0;
         __syncthreads();
         if (n_src == 0) {
-            // no tile covers this brick: its zeros (nothing in accumulate mode), four voxels of an x row per lane where rows allow it
-            if (!accumulate) {
+            // no tile covers this brick: its zeros (nothing in accumulate mode or for a segment), four voxels of an x row per lane where rows allow it
+            if (!SEG && !accumulate) {
                 if (CH == 1 && (G.dx & 3) == 0) {
                     for (int v = 4 * t; v < L.bvox; v += 4 * 256) {
                         const int lx = v & (BX - 1), ly = (v >> L.lx) & (BY - 1), lz = v >> (L.lx + L.ly);
@@ -814,6 +876,20 @@ __global__ __launch_bounds__(256) void fast_halo_merge_kernel(const long long* _
                     const bool two = gxs[u] + 1 < G.dx;
                     const float f0 = (float)sum0[0] * invS, f1 = (float)sum1[0] * invS;
                     bool nonzero = f0 != 0.f || (two && f1 != 0.f);
+                    if (SEG) {
+                        const int w = w0 + 256 * u;
+                        const int v0 = 2 * (w & (hbx - 1)) + BX * (((w >> (L.lx - 1)) & (BY - 1)) + BY * (w >> (L.lx - 1 + L.ly)));
+                        s_val[v0] = f0; s_val[v0 + 1] = two ? f1 : 0.f;
+                        if (CH == 4) {
+                            const float g0 = (float)sum0[CH == 4 ? 1 : 0] * invS, b0 = (float)sum0[CH == 4 ? 2 : 0] * invS;
+                            const float g1 = (float)sum1[CH == 4 ? 1 : 0] * invS, b1 = (float)sum1[CH == 4 ? 2 : 0] * invS;
+                            nonzero = nonzero || g0 != 0.f || b0 != 0.f || (two && (g1 != 0.f || b1 != 0.f));
+                            s_val[L.bvox + v0] = g0; s_val[L.bvox + v0 + 1] = two ? g1 : 0.f;
+                            s_val[2 * L.bvox + v0] = b0; s_val[2 * L.bvox + v0 + 1] = two ? b1 : 0.f;
+                        }
+                        if (nonzero) s_flag[sub[u]] = 1;
+                        continue;
+                    }
                     if (CH == 1) {
                         if (two && (o[u] & 1) == 0) {
                             float2* q = reinterpret_cast<float2*>(out + o[u]);
@@ -840,6 +916,39 @@ __global__ __launch_bounds__(256) void fast_halo_merge_kernel(const long long* _
             }
         }
         __syncthreads();
+        if (SEG && n_src != 0) {   // (uniform)
+            if (t < 64) {
+                uint32_t running = 0;
+                for (int w0 = 0; w0 < nsub; w0 += 64) {
+                    const int w = w0 + t;
+                    const bool f = w < nsub && s_flag[w] != 0;
+                    const unsigned long long m = __ballot(f);
+                    if (w < nsub) s_slot[w] = f ? running + (uint32_t)__popcll(m & ((1ull << t) - 1ull)) : 0xffffffffu;
+                    running += (uint32_t)__popcll(m);
+                }
+                if (t == 0) s_base = running ? atomicAdd(&st.ctl[0], running) : 0u;
+            }
+            __syncthreads();
+            const size_t slot_bytes = seg_slot_bytes(CH);
+            for (int idx = t; idx < nsub * 64; idx += 256) {
+                const int w = idx >> 6, j = idx & 63;
+                const uint32_t rel = s_slot[w];
+                if (rel == 0xffffffffu) continue;
+                const uint32_t slot = s_base + rel;
+                if (slot >= st.room) continue;
+                const int sx = w % (BX >> 2), sy = (w / (BX >> 2)) % (BY >> 2), sz = w / ((BX >> 2) * (BY >> 2));
+                const int lx = 4 * sx + (j & 3), ly = 4 * sy + ((j >> 2) & 3), lz = 4 * sz + (j >> 4);
+                const int v = lx + BX * (ly + BY * lz);
+                const bool inside = ox + lx < G.dx && oy + ly < G.dy && oz + lz < G.dz;   // (voxels beyond the grid were never written to s_val)
+                unsigned char* p = st.seg + sizeof(SegHeader) + (size_t)slot * slot_bytes;
+                if (j == 0) {
+                    const uint32_t id = (uint32_t)((ox >> 2) + sx) + (uint32_t)nbx4 * ((uint32_t)((oy >> 2) + sy) + (uint32_t)nby4 * (uint32_t)((oz >> 2) + sz));
+                    *reinterpret_cast<uint4*>(p) = make_uint4(id, 0u, 0u, 0u);
+                }
+                if (CH == 1) reinterpret_cast<float*>(p + 16)[j] = inside ? s_val[v] : 0.f;
+                else reinterpret_cast<float4*>(p + 16)[j] = inside ? make_float4(s_val[v], s_val[L.bvox + v], s_val[2 * L.bvox + v], 0.f) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
         if (marks)
             for (int w = t; w < nsub; w += 256) {
                 const int sx = w % (BX >> 2), sy = (w / (BX >> 2)) % (BY >> 2), sz = w / ((BX >> 2) * (BY >> 2));
@@ -848,6 +957,7 @@ __global__ __launch_bounds__(256) void fast_halo_merge_kernel(const long long* _
             }
         __syncthreads();  // s_flag is cleared again for the next brick
     }
+    if (SEG && t == 0) seg_finish(st, gridDim.x);
 }
 
 // records from one layout to the other: a lane moves one record (two 16-byte loads, two 16-byte stores; one side of each pair is
@@ -860,6 +970,10 @@ __global__ __launch_bounds__(256) void photons_convert_kernel(const float4* __re
     dst[(size_t)ds * j] = a;
     dst[(size_t)ds * j + db] = b;
 }
+
+// what a workgroup may take of the LDS: the device's limit less 1 KiB for the kernels' static arrays (gfx950: 160 KiB; queried once per
+// context -- a part with 64 KiB refuses the wide boxes here instead of failing at the launch)
+__host__ size_t lds_limit(const cpm_ctx* ctx) { return (size_t)(ctx && ctx->lds_per_block > 1024 ? ctx->lds_per_block : 64 * 1024) - 1024; }
 
 template <typename K>
 __host__ int allow_lds(cpm_ctx* ctx, K kernel, size_t bytes) {
@@ -889,7 +1003,9 @@ size_t cpm_fast_table_entries(const cpm_grid_desc* grid, int n) {
     return most;
 }
 
-int cpm_gather_fast_supported(const cpm_grid_desc* grid, float radius) {
+int cpm_gather_fast_supported(const cpm_grid_desc* grid, float radius) { return cpm_gather_fast_supported_on(nullptr, grid, radius); }
+
+int cpm_gather_fast_supported_on(const cpm_ctx* ctx, const cpm_grid_desc* grid, float radius) {
     if (!grid || grid->dims[0] < 1 || grid->dims[1] < 1 || grid->dims[2] < 1) return 0;
     if (grid->channels != 1 && grid->channels != 4) return 0;
     GridDev G;
@@ -899,7 +1015,7 @@ int cpm_gather_fast_supported(const cpm_grid_desc* grid, float radius) {
     BrickLayout L;
     brick_shape_for(G, radius, L);
     if (!brick_reach(G, radius, L)) return 0;
-    return tile_bytes_for(G, L) <= 160 * 1024 - 1024;
+    return tile_bytes_for(G, L) <= (ctx ? lds_limit(ctx) : (size_t)160 * 1024 - 1024);   // (no context: gfx950's 160 KiB)
 }
 
 size_t cpm_fast_record_capacity(const cpm_grid_desc* grid, int n, float radius) {
@@ -936,7 +1052,7 @@ int cpm_bin_fast_layout(cpm_ctx* ctx, const float* photons8, int layout, int n, 
     hipStream_t s = (hipStream_t)stream;
     BrickLayout L;
     brick_shape_for(G, radius, L);
-    if (!brick_reach(G, radius, L) || tile_bytes_for(G, L) > 160 * 1024 - 1024)
+    if (!brick_reach(G, radius, L) || tile_bytes_for(G, L) > lds_limit(ctx))
         return set_error(ctx, CPM_ERR_UNSUPPORTED, "cpm_bin_fast", "radius beyond 3.5 voxels along some axis (or not positive): use cpm_bin + cpm_gather");
     CPM_REQUIRE(ctx, (long long)n * copies_per_photon(L) < (1ll << 32), "cpm_bin_fast: record positions are 32-bit (n * 8 must stay below 2^32)");
     // scratch: two histograms (nb brick counts + 4 accumulators), used in turn -- a call's scatter launch zeroes the one the
@@ -1006,34 +1122,37 @@ int cpm_photons_convert(cpm_ctx* ctx, const float* src, int src_layout, float* d
     return CPM_OK;
 }
 
-int cpm_gather_fast(cpm_ctx* ctx, const float* sorted_pos_power, const uint32_t* brick_table, int n, const cpm_grid_desc* grid,
-                    float radius, float scale, int accumulate, float* grid_out, cpm_stream stream) {
-    return cpm_gather_fast_marked(ctx, sorted_pos_power, brick_table, n, grid, radius, scale, accumulate, grid_out, nullptr, stream);
-}
+}  // extern "C"
 
-int cpm_gather_fast_marked(cpm_ctx* ctx, const float* sorted_pos_power, const uint32_t* brick_table, int n, const cpm_grid_desc* grid,
-                           float radius, float scale, int accumulate, float* grid_out, uint8_t* nonzero_bricks, cpm_stream stream) {
-    CPM_ENTER(ctx);
-    CPM_REQUIRE(ctx, !(nonzero_bricks && accumulate), "cpm_gather_fast_marked: the marks describe a volume this launch wrote whole (not with accumulate)");
+namespace {
+
+// cpm_gather_fast / _marked (seg == nullptr) and cpm_gather_fast_segment (seg: the brick-list segment the non-zero 4x4x4 bricks go to)
+int gather_fast_impl(cpm_ctx* ctx, const float* sorted_pos_power, const uint32_t* brick_table, int n, const cpm_grid_desc* grid, float radius, float scale,
+                     int accumulate, float* grid_out, uint8_t* nonzero_bricks, const SegTarget* seg, cpm_stream stream) {
     GridDev G;
     int rc = make_grid_dev_fast(ctx, grid, G);
     if (rc) return rc;
     CPM_REQUIRE(ctx, n >= 0 && radius > 0.f, "cpm_gather_fast: bad size or radius");
-    CPM_REQUIRE(ctx, brick_table && grid_out && (sorted_pos_power || n == 0), "cpm_gather_fast: null buffer");
+    CPM_REQUIRE(ctx, brick_table && (grid_out || seg) && (sorted_pos_power || n == 0), "cpm_gather_fast: null buffer");
     CPM_REQUIRE_ALIGNED16(ctx, sorted_pos_power, "cpm_gather_fast");
-    if (G.channels == 4) CPM_REQUIRE_ALIGNED16(ctx, grid_out, "cpm_gather_fast");
+    // (the wide boxes' merge launch stores pairs and quads of voxels, the 4-channel launches float4s)
+    if (!seg && G.channels == 4) CPM_REQUIRE_ALIGNED16(ctx, grid_out, "cpm_gather_fast");
     BrickLayout L;
     brick_shape_for(G, radius, L);
     if (!brick_reach(G, radius, L))
         return set_error(ctx, CPM_ERR_UNSUPPORTED, "cpm_gather_fast", "radius beyond 3.5 voxels along some axis: use cpm_bin + cpm_gather");
+    if (!seg && L.halo) CPM_REQUIRE_ALIGNED16(ctx, grid_out, "cpm_gather_fast (boxes of 4 or more candidates)");
     size_t tile_bytes = tile_bytes_for(G, L);
-    if (tile_bytes > 160 * 1024 - 1024 || (L.bvox >> 6) > kMaxSubBricks)
+    if (tile_bytes > lds_limit(ctx) || (L.bvox >> 6) > kMaxSubBricks)
         return set_error(ctx, CPM_ERR_UNSUPPORTED, "cpm_gather_fast", "brick does not fit the LDS: use cpm_bin + cpm_gather");
+    if (seg && L.halo && L.bvox > kSegMergeVoxels)
+        return set_error(ctx, CPM_ERR_UNSUPPORTED, "cpm_gather_fast_segment", "bricks of more than 2048 voxels: gather into a grid and use cpm_bricklist_pack_grid");
     // the records were filed for ONE radius (a wider one would need copies the bin did not make)
     if (ctx->fast_last_table == brick_table && ctx->fast_last_radius != radius)
         return set_error(ctx, CPM_ERR_INVALID_ARGUMENT, "cpm_gather_fast", "radius differs from the one given to cpm_bin_fast for this table");
     const float k = kInv4Pi * scale;
     hipStream_t s = (hipStream_t)stream;
+    const SegTarget st = seg ? *seg : SegTarget();
     // resident workgroups: two of 1024 threads per CU, fewer when there are fewer bricks
     const size_t resident = (size_t)CPM_BRICK_WG_PER_CU * (size_t)ctx->num_cus;
     const dim3 bgrid((unsigned)((size_t)L.nb < resident ? (size_t)L.nb : resident));
@@ -1044,7 +1163,7 @@ int cpm_gather_fast_marked(cpm_ctx* ctx, const float* sorted_pos_power, const ui
 #define CPM_BRICK_REPL 4
 #endif
         int repl = 1;
-        while (repl * 2 <= CPM_BRICK_REPL && tile_bytes * (size_t)(repl * 2) <= 72 * 1024) repl *= 2;
+        while (repl * 2 <= CPM_BRICK_REPL && tile_bytes * (size_t)(repl * 2) <= lds_limit(ctx) * 9 / 20) repl *= 2;
         const size_t stage_bytes = (size_t)L.nb * tile_bytes;
         long long* stage = (long long*)scratch(ctx, CPM_SCR_FAST_STAGE, stage_bytes);
         if (!stage) return CPM_ERR_OUT_OF_MEMORY;
@@ -1062,26 +1181,65 @@ int cpm_gather_fast_marked(cpm_ctx* ctx, const float* sorted_pos_power, const ui
 #undef CPM_HALO_LAUNCH
         CPM_LAUNCH_CHECK(ctx, "fast_halo_kernel");
         const dim3 mgrid((unsigned)L.nb);
-        if (G.channels == 1) CPM_LAUNCH(ctx, fast_halo_merge_kernel<1>, mgrid, dim3(256), 0, s, stage, brick_table, G, L, k, accumulate, grid_out, nonzero_bricks);
-        else CPM_LAUNCH(ctx, fast_halo_merge_kernel<4>, mgrid, dim3(256), 0, s, stage, brick_table, G, L, k, accumulate, grid_out, nonzero_bricks);
+        if (seg) {
+            if (G.channels == 1) CPM_LAUNCH(ctx, (fast_halo_merge_kernel<1, true>), mgrid, dim3(256), 0, s, stage, brick_table, G, L, k, 0, grid_out, nullptr, st);
+            else CPM_LAUNCH(ctx, (fast_halo_merge_kernel<4, true>), mgrid, dim3(256), 0, s, stage, brick_table, G, L, k, 0, grid_out, nullptr, st);
+        } else {
+            if (G.channels == 1) CPM_LAUNCH(ctx, (fast_halo_merge_kernel<1, false>), mgrid, dim3(256), 0, s, stage, brick_table, G, L, k, accumulate, grid_out, nonzero_bricks, st);
+            else CPM_LAUNCH(ctx, (fast_halo_merge_kernel<4, false>), mgrid, dim3(256), 0, s, stage, brick_table, G, L, k, accumulate, grid_out, nonzero_bricks, st);
+        }
         CPM_LAUNCH_CHECK(ctx, "fast_halo_merge_kernel");
         return CPM_OK;
     }
-#define CPM_BRICK_LAUNCH(MAXC, CH)                                                                                       \
+#define CPM_BRICK_LAUNCH(MAXC, CH, SEG)                                                                                  \
     do {                                                                                                                 \
-        rc = allow_lds(ctx, fast_brick_kernel<MAXC, CH>, tile_bytes);                                                    \
+        rc = allow_lds(ctx, fast_brick_kernel<MAXC, CH, SEG>, tile_bytes);                                               \
         if (rc) return rc;                                                                                               \
-        CPM_LAUNCH(ctx, (fast_brick_kernel<MAXC, CH>), bgrid, dim3(kBrickThreads), tile_bytes, s, sorted_pos_power, brick_table, G, L,  \
-                   radius, k, accumulate, grid_out, nonzero_bricks);                                                     \
+        CPM_LAUNCH(ctx, (fast_brick_kernel<MAXC, CH, SEG>), bgrid, dim3(kBrickThreads), tile_bytes, s, sorted_pos_power, brick_table, G, L,  \
+                   radius, k, accumulate, grid_out, nonzero_bricks, st);                                                 \
     } while (0)
-    if (G.channels == 1) {
-        if (L.maxc <= 2) CPM_BRICK_LAUNCH(2, 1); else CPM_BRICK_LAUNCH(3, 1);
+    if (seg) {
+        if (G.channels == 1) { if (L.maxc <= 2) CPM_BRICK_LAUNCH(2, 1, true); else CPM_BRICK_LAUNCH(3, 1, true); }
+        else { if (L.maxc <= 2) CPM_BRICK_LAUNCH(2, 4, true); else CPM_BRICK_LAUNCH(3, 4, true); }
+    } else if (G.channels == 1) {
+        if (L.maxc <= 2) CPM_BRICK_LAUNCH(2, 1, false); else CPM_BRICK_LAUNCH(3, 1, false);
     } else {
-        if (L.maxc <= 2) CPM_BRICK_LAUNCH(2, 4); else CPM_BRICK_LAUNCH(3, 4);
+        if (L.maxc <= 2) CPM_BRICK_LAUNCH(2, 4, false); else CPM_BRICK_LAUNCH(3, 4, false);
     }
 #undef CPM_BRICK_LAUNCH
     CPM_LAUNCH_CHECK(ctx, "fast_brick_kernel");
     return CPM_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int cpm_gather_fast(cpm_ctx* ctx, const float* sorted_pos_power, const uint32_t* brick_table, int n, const cpm_grid_desc* grid,
+                    float radius, float scale, int accumulate, float* grid_out, cpm_stream stream) {
+    return cpm_gather_fast_marked(ctx, sorted_pos_power, brick_table, n, grid, radius, scale, accumulate, grid_out, nullptr, stream);
+}
+
+int cpm_gather_fast_marked(cpm_ctx* ctx, const float* sorted_pos_power, const uint32_t* brick_table, int n, const cpm_grid_desc* grid,
+                           float radius, float scale, int accumulate, float* grid_out, uint8_t* nonzero_bricks, cpm_stream stream) {
+    CPM_ENTER(ctx);
+    CPM_REQUIRE(ctx, !(nonzero_bricks && accumulate), "cpm_gather_fast_marked: the marks describe a volume this launch wrote whole (not with accumulate)");
+    CPM_REQUIRE(ctx, grid_out, "cpm_gather_fast: null buffer");
+    return gather_fast_impl(ctx, sorted_pos_power, brick_table, n, grid, radius, scale, accumulate, grid_out, nonzero_bricks, nullptr, stream);
+}
+
+int cpm_gather_fast_segment(cpm_ctx* ctx, const float* sorted_pos_power, const uint32_t* brick_table, int n, const cpm_grid_desc* grid,
+                            float radius, float scale, const cpm_bricklist_segment* segment, cpm_stream stream) {
+    CPM_ENTER(ctx);
+    CPM_REQUIRE(ctx, segment && segment->segment && segment->control && grid, "cpm_gather_fast_segment: null segment (the root, or a communicator of one rank, gathers into its grid)");
+    CPM_REQUIRE(ctx, (int)segment->channels == grid->channels, "cpm_gather_fast_segment: the segment was opened for another channel count");
+    const unsigned long long nb4 = (unsigned long long)((grid->dims[0] + 3) / 4) * ((grid->dims[1] + 3) / 4) * ((grid->dims[2] + 3) / 4);
+    CPM_REQUIRE(ctx, grid->dims[0] >= 1 && grid->dims[1] >= 1 && grid->dims[2] >= 1 && nb4 <= segment->room, "cpm_gather_fast_segment: the segment has no room for every brick of this grid");
+    SegTarget st;
+    st.seg = static_cast<unsigned char*>(segment->segment);
+    st.capacity = segment->capacity; st.room = segment->room; st.ticket = segment->ticket;
+    st.ctl = segment->control; st.mailbox = segment->mailbox;
+    return gather_fast_impl(ctx, sorted_pos_power, brick_table, n, grid, radius, scale, 0, nullptr, nullptr, &st, stream);
 }
 
 }  // extern "C"

@@ -297,6 +297,11 @@ class PhotonFrame:
         self.ctx.gather_fast(self.sorted_fast, self.brick_table, self.n * self.I, self.grid, self.radius, self.scale,
                              self.light_volume if out is None else out, accumulate=accumulate, nonzero_bricks=nonzero_bricks)
 
+    def gather_fast_segment(self, segment):
+        """The gather of a shard that is not the display GPU: its non-zero 4x4x4 bricks straight into the brick-list segment of an opened
+        ticket (binding.BricklistReduce.open) -- no dense light volume, no zeros (cpm_gather_fast_segment)."""
+        self.ctx.gather_fast_segment(self.sorted_fast, self.brick_table, self.n * self.I, self.grid, self.radius, self.scale, segment)
+
     def frame_fast(self):
         """The hot path in tolerance mode: trace -> brick bin -> tile gather."""
         self.trace()

@@ -81,8 +81,8 @@ def bricklist_capacity(n_bricks: int, previous_count: int) -> int:
 
 
 def bricklist_segment_bytes(capacity: int, channels: int = 1) -> int:
-    """16-byte header + capacity bricks of 64 * channels floats + capacity brick ids (cpm_bricklist_segment_bytes)."""
-    return 16 + capacity * (256 * channels + 4)
+    """16-byte header + capacity slots of a 16-byte head (the brick's id) and 64 * channels floats (cpm_bricklist_segment_bytes)."""
+    return 16 + capacity * (256 * channels + 16)
 
 
 # What a frame's exchange puts on a rank's busiest xGMI link, and a time for it (arithmetic; DESIGN section 6): the three forms the
@@ -92,23 +92,68 @@ XGMI_LINK_GBS = 100.0
 COLLECTIVE_LATENCY_US = 30.0
 
 
-def exchange_model(n_bricks: int, channels: int, world: int, union_bricks: int, own_bricks_max: int, cells: int):
+def exchange_model(n_bricks: int, channels: int, world: int, union_bricks: int, own_bricks_max: int, cells: int,
+                   link_gbs: float = None, latency_us: float = None):
     """Bytes per link and a modelled time per frame of (a) the dense ring reduce, (b) the union-of-bricks reduce
     (cpm_allreduce_grid_sparse with a root: mask max-reduce + packed payload reduce), (c) per-rank brick lists sent to the root
     (cpm_reduce_grid_bricklists: one segment per sender, every sender on its own link into the root).
-    union_bricks: bricks non-zero on ANY rank; own_bricks_max: the most any single rank lists."""
+    union_bricks: bricks non-zero on ANY rank; own_bricks_max: the most any single rank lists.
+    link_gbs / latency_us: what one message costs -- the ASSUMED constants above unless the caller measured them (bench.py times a 1 KB
+    and a 2 MB send / receive pair over the communicator at set-up: measure_p2p); the figures used are part of the result."""
     brick_bytes = 256 * channels
     ring = (world - 1) / world if world > 1 else 0.0
     dense = cells * channels * 4 * ring
     cap_u = sparse_capacity(n_bricks, union_bricks)
     union = (n_bricks + (cells * channels * 4 if cap_u >= n_bricks else cap_u * brick_bytes)) * ring
     lists = bricklist_segment_bytes(bricklist_capacity(n_bricks, own_bricks_max), channels) if world > 1 else 0
+    gbs = float(link_gbs) if link_gbs else XGMI_LINK_GBS
+    lat = float(latency_us) if latency_us else COLLECTIVE_LATENCY_US
 
     def us(nbytes, collectives):
-        return collectives * COLLECTIVE_LATENCY_US + nbytes / (XGMI_LINK_GBS * 1e3)
+        return collectives * lat + nbytes / (gbs * 1e3)
     return {"dense_reduce": {"bytes_per_link": int(dense), "model_us": round(us(dense, 1), 1)},
             "union_reduce": {"bytes_per_link": int(union), "model_us": round(us(union, 2), 1)},
-            "brick_lists": {"bytes_per_link": int(lists), "model_us": round(us(lists, 1), 1)}}
+            "brick_lists": {"bytes_per_link": int(lists), "model_us": round(us(lists, 1), 1)},
+            "constants": {"link_gbs": round(gbs, 2), "latency_us": round(lat, 2),
+                          "assumed": {"link_gbs": XGMI_LINK_GBS, "latency_us": COLLECTIVE_LATENCY_US},
+                          "source": "measured at set-up (measure_p2p)" if (link_gbs or latency_us) else "assumed"}}
+
+
+def measure_p2p(transport, reps: int = 20):
+    """One message's latency and a link's rate over the C-ABI communicator, measured: rank 1 and the root play ping-pong with 1 KB and with
+    2 MB messages (cpm_comm_send / cpm_comm_recv on the transport's stream, HIP events around `reps` round trips); every other rank
+    stands by.  Returns {"latency_us", "link_gbs", ...} on the two ranks that measured (the caller shares it), None elsewhere or with
+    one rank.  A measurement of THIS node's links, not a constant."""
+    torch = transport.torch
+    if transport.world < 2:
+        return None
+    root = transport.root if transport.root is not None else 0
+    other = 1 if root != 1 else 0
+    if transport.rank not in (root, other):
+        return None
+    peer = other if transport.rank == root else root
+    ctx, comm = transport.ctx, transport.comm
+    out = {}
+    with torch.cuda.stream(transport.stream):
+        for name, nbytes in (("small", 1024), ("large", 2 << 20)):
+            buf = torch.zeros(nbytes, dtype=torch.uint8, device=ctx.device)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            for it in range(reps + 3):
+                if it == 3:
+                    e0.record(transport.stream)
+                if transport.rank == root:
+                    ctx.comm_send(comm, buf, nbytes, peer)
+                    ctx.comm_recv(comm, buf, nbytes, peer)
+                else:
+                    ctx.comm_recv(comm, buf, nbytes, peer)
+                    ctx.comm_send(comm, buf, nbytes, peer)
+            e1.record(transport.stream)
+            transport.stream.synchronize()
+            out[name] = e0.elapsed_time(e1) * 1e3 / reps / 2.0   # us per one-way message
+    lat = out["small"]
+    gbs = (2 << 20) / max(out["large"] - lat, 1e-3) / 1e3
+    return {"latency_us": round(lat, 2), "link_gbs": round(gbs, 2), "one_way_us": {"1KiB": round(out["small"], 2), "2MiB": round(out["large"], 2)},
+            "method": f"ping-pong between ranks {root} and {other}, {reps} round trips per size, HIP events on the reduce stream"}
 
 
 def brick_view(grid, dims, channels=1):
@@ -205,6 +250,8 @@ class TorchTransport:
     # the counts of two frames before -- a sender's own, at the root every sender's as its headers reported them)
     def lists_setup(self, dims, channels=1, root=0):
         nb = ((dims[0] + 3) // 4) * ((dims[1] + 3) // 4) * ((dims[2] + 3) // 4)
+        if nb >= 1 << 24:
+            raise ValueError("TorchTransport.lists_setup: this twin carries brick ids as float32 (exact below 2^24 bricks)")
         self._bl = {"dims": tuple(dims), "channels": channels, "nb": nb, "root": root, "counts": [], "log": []}
 
     def lists_start(self, grid, nonzero_bricks=None):
@@ -230,6 +277,8 @@ class TorchTransport:
             return seg
         if rank != root:
             mine = torch.nonzero((bricks != 0).any(dim=1), as_tuple=False).reshape(-1)
+            # (slots are handed out by a device counter in the library: any order -- here a fixed shuffle)
+            mine = mine[torch.randperm(int(mine.numel()), generator=torch.Generator().manual_seed(977 * k + rank)).to(mine.device)]
             count = int(mine.numel())
             cap = bricklist_capacity(nb, prev[rank] if prev is not None else -1)
             vals = bricks[mine].cpu()
@@ -244,7 +293,12 @@ class TorchTransport:
         else:
             total = bricks.clone()
             counts = {}
-            for r in range(self.world):     # rank order: a brick two ranks list is summed in that order
+            again = []
+
+            def add(seg, cap, count):
+                ids = seg[2:2 + count].to(torch.int64).to(grid.device)
+                total[ids] += seg[2 + cap:2 + cap + count * 64 * ch].reshape(count, 64 * ch).to(grid.device)
+            for r in range(self.world):     # rank order: a brick several ranks list is summed in that order
                 if r == root:
                     continue
                 cap = bricklist_capacity(nb, prev[r] if prev is not None else -1)
@@ -253,15 +307,18 @@ class TorchTransport:
                 info["received_bytes"] += bricklist_segment_bytes(cap, ch)
                 count = int(seg[0].item())
                 counts[r] = count
-                if count > cap:
-                    cap = (count + 63) & ~63
-                    seg = torch.zeros(2 + cap + cap * 64 * ch, dtype=torch.float32)
-                    dist.recv(seg, src=r, group=self.p2p_group)
-                    info["resent"] += 1
-                    info["received_bytes"] += bricklist_segment_bytes(cap, ch)
-                ids = seg[2:2 + count].to(torch.int64).to(grid.device)
-                total[ids] += seg[2 + cap:2 + cap + count * 64 * ch].reshape(count, 64 * ch).to(grid.device)
                 info["listed_bricks"] += count
+                if count > cap:
+                    again.append((r, count))
+                else:
+                    add(seg, cap, count)
+            for r, count in again:          # a list that had outgrown its segment: again at exact size, added after the others
+                cap = (count + 63) & ~63
+                seg = torch.zeros(2 + cap + cap * 64 * ch, dtype=torch.float32)
+                dist.recv(seg, src=r, group=self.p2p_group)
+                info["resent"] += 1
+                info["received_bytes"] += bricklist_segment_bytes(cap, ch)
+                add(seg, cap, count)
             bl["counts"].append(counts)
             dx, dy, dz = dims
             nz, ny, nx = (dz + 3) // 4, (dy + 3) // 4, (dx + 3) // 4
@@ -362,6 +419,25 @@ class RcclTransport:
             ticket = self.lists.start(grid, nonzero_bricks=nonzero_bricks)
         return ticket
 
+    def lists_open(self):
+        """(ticket, segment): the next exchange's ticket and, on a rank other than the root, the segment its gather fills
+        (PhotonFrame.gather_fast_segment); segment is None at the root -- it gathers into its grid.  Host only."""
+        ticket, seg = self.lists.open()
+        return ticket, (seg if seg.segment else None)
+
+    def lists_exchange(self, ticket, root_grid=None, pack_from=None, nonzero_bricks=None):
+        """The opened ticket's exchange on the transport's stream, behind everything enqueued on the current one (the gather that filled
+        the segment / the root's grid).  pack_from: a sender's dense grid to take the bricks from when its gather did not fill the segment."""
+        torch = self.torch
+        ready = torch.cuda.Event()
+        ready.record(torch.cuda.current_stream(self.ctx.device))
+        with torch.cuda.stream(self.stream):
+            self.stream.wait_event(ready)
+            if pack_from is not None:
+                self.lists.pack_grid(ticket, pack_from, nonzero_bricks)
+            self.lists.exchange(ticket, root_grid)
+        return ticket
+
     def lists_wait(self, ticket):
         """The CURRENT stream waits for the ticket's exchange (repeated at exact size where a list had outgrown its segment)."""
         torch = self.torch
@@ -424,6 +500,7 @@ class OverlappedGridReducer:
         self.lists = lists is not None
         self.info = []  # per completed sparse ticket: union, capacity, mode, bytes; per completed list exchange: its cpm_bricklist_info
         self.marks = [None, None]  # per buffer: the non-zero 4x4x4 bricks, written by the gather (marks_for)
+        self._opened = {}          # frame -> (ticket, segment) of a brick-list exchange opened by segment_for and not yet enqueued
         if (self.sparse or self.lists) and self.active:
             desc = sparse if self.sparse else lists
             if isinstance(self.transport, TorchTransport):
@@ -464,6 +541,16 @@ class OverlappedGridReducer:
         self._wait(b)
         return self.buffers[b]
 
+    def segment_for(self, k: int):
+        """Brick lists over the C-ABI, on a rank that is not the root: the segment frame k's gather writes its non-zero bricks into
+        (PhotonFrame.gather_fast_segment) -- then no dense buffer, no zeros and no pass over one on this rank; None where the frame
+        gathers into acquire(k) as ever (the root, other exchanges, the torch twin).  Call after acquire(k)."""
+        if not (self.lists and self.active) or isinstance(self.transport, TorchTransport):
+            return None
+        if k not in self._opened:
+            self._opened[k] = self.transport.lists_open()
+        return self._opened[k][1]
+
     def marks_for(self, k: int):
         """Where the gather of frame k leaves the non-zero bricks of its volume (cpm_gather_fast_marked), or None: pass it as the
         gather's `nonzero_bricks` and say so to reduce(k, marked=True) -- the reduce then skips its own pass over the volume."""
@@ -474,6 +561,10 @@ class OverlappedGridReducer:
             b = k & 1
             if self.sparse:
                 self._pending[b] = self.transport.sparse_start(self.buffers[b], nonzero_bricks=self.marks[b] if marked else None)
+            elif self.lists and k in self._opened:
+                # (the ticket was opened by segment_for: a sender's gather has filled its segment, the root's its grid)
+                ticket, seg = self._opened.pop(k)
+                self._pending[b] = self.transport.lists_exchange(ticket, self.buffers[b] if seg is None else None)
             elif self.lists:
                 self._pending[b] = self.transport.lists_start(self.buffers[b], nonzero_bricks=self.marks[b] if marked else None)
             else:

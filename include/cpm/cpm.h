@@ -438,6 +438,9 @@ size_t cpm_fast_table_entries(const cpm_grid_desc* grid, int n);
  * light volume; up to 3 per axis the record loops are unrolled, wider boxes take run-time loops and tiles with a halo), positive axis-aligned
  * textureToIndex; otherwise use cpm_bin + cpm_gather. */
 int cpm_gather_fast_supported(const cpm_grid_desc* grid, float radius);
+/* ... on the context's device: also that a brick's LDS tile fits what a workgroup may use THERE (the form above assumes gfx950's
+ * 160 KiB; a wide box's tile with its halo needs 33 - 100 KiB).  What a host layer asks before it takes the fast pair. */
+int cpm_gather_fast_supported_on(const cpm_ctx* ctx, const cpm_grid_desc* grid, float radius);
 /* Records sorted_pos_power must hold for n photons at this radius (every photon in all its bricks: 8 n; n when a
  * candidate box is a single voxel wide, or wide -- filed once); 0 when unsupported. */
 size_t cpm_fast_record_capacity(const cpm_grid_desc* grid, int n, float radius);
@@ -799,13 +802,14 @@ int cpm_sparse_reduce_complete(cpm_ctx* ctx, cpm_sparse_reduce* sr, uint64_t tic
  * (config 4 at 8 ranks: 13.8 MB per link and frame against ~55 us of compute per rank).  Here every rank other than `root` packs
  * ITS non-zero bricks -- (brick id, 64 * channels values) records behind a 16-byte header carrying their number -- and sends that one
  * segment to the root (ncclSend / ncclRecv: a rank's bytes cross one xGMI link once); the root adds the segments into its own
- * grid in rank order (a brick two ranks report is summed, in that fixed order: the result is reproducible).
+ * grid in rank order (a brick two ranks report is summed, in that fixed order: the result is reproducible; a rank whose list had
+ * outgrown its segment is added last, at cpm_bricklist_reduce_complete).
  *     grid at the root    = sum over the ranks of their grids (in place)
  *     grid at other ranks = unchanged (read only)
  * A segment's size must be known on both sides when the send and the receive are enqueued: capacity = the sender's brick count of
  * the call before the previous one * 1.25 + 64 (rounded up to 64; a quarter of the bricks while unknown, never more than all) --
  * a number the sender has from its own pinned mailbox and the root from the header it received then (no host wait, no
- * collective for it: cpm_bricklist_capacity_for).  A rank whose count outgrows its capacity sends the header alone; at
+ * collective for it: cpm_bricklist_capacity_for).  A rank whose count outgrows its capacity is not added from that segment; at
  * cpm_bricklist_reduce_complete -- which every rank calls before the grid is read or gathered into again -- that rank and the root
  * alone repeat the exchange at the exact size (both know the count by then).  No rank waits for a rank it does not exchange with.
  * Every rank makes the same sequence of calls; all calls of one cpm_bricklist_reduce go to one stream (or streams ordered by
@@ -829,11 +833,57 @@ void cpm_bricklist_reduce_destroy(cpm_bricklist_reduce* br);
 uint32_t cpm_bricklist_reduce_bricks(const cpm_bricklist_reduce* br);
 /* Bricks a segment has room for when its sender listed previous_count bricks two calls ago (< 0: not known yet). */
 uint32_t cpm_bricklist_capacity_for(uint32_t n_bricks, long long previous_count);
-/* Bytes of a segment with room for `capacity` bricks: 16 + capacity * (256 * channels + 4). */
+/* Bytes of a segment with room for `capacity` bricks: 16 + capacity * (16 + 256 * channels) -- a 16-byte header (count, capacity,
+ * ticket, magic), then per brick a 16-byte head (its id) and its 64 * channels values. */
 uint64_t cpm_bricklist_segment_bytes(uint32_t capacity, int channels);
 int cpm_reduce_grid_bricklists(cpm_ctx* ctx, cpm_bricklist_reduce* br, float* grid, const uint8_t* nonzero_bricks, uint64_t* ticket_out,
                                cpm_stream stream);
 int cpm_bricklist_reduce_complete(cpm_ctx* ctx, cpm_bricklist_reduce* br, uint64_t ticket, cpm_stream stream, cpm_bricklist_info* info_out);
+
+/* The same exchange WITHOUT a dense grid on the senders (round 6).  cpm_reduce_grid_bricklists above is, step by step:
+ *     cpm_bricklist_reduce_open      a ticket, its capacities (host only: no launch), and -- on a rank other than the root -- where that
+ *                                    ticket's segment lies: `segment`
+ *     [sender] the segment's slots   cpm_bricklist_pack_grid (from a dense grid: one launch over its bricks), or -- no dense grid, no
+ *                                    zeros, no pass over it -- cpm_gather_fast_segment: the brick gather writes the non-zero 4x4x4
+ *                                    bricks of every gather brick straight into slots taken from the segment's device counter; the
+ *                                    launch's last workgroup writes the header and the count's mailbox word
+ *     [root] its own light volume    cpm_gather_fast into `root_grid` as ever
+ *     cpm_bricklist_reduce_exchange  sender: ONE ncclSend of the segment's first `capacity` slots; root: the N - 1 receives as one
+ *                                    group, then TWO launches whatever N is: every received brick's slot goes into a per-sender
+ *                                    brick -> slot table, then the lowest-ranked sender that lists a brick adds it and every higher
+ *                                    rank's values for it, in rank order, into root_grid (a brick several ranks list is summed in
+ *                                    that fixed order: reproducible)
+ *     cpm_bricklist_reduce_complete  as above; a list that outgrew its segment goes again at exact size FROM THE SAME BUFFER (a
+ *                                    sender's buffer has room for every brick of the grid: nothing is rebuilt) and is added after the
+ *                                    others.
+ * open / fill / exchange of one ticket may go to different streams ordered by events (fill on the frame's stream, exchange on the
+ * reduce's); a ticket's segment is written again four tickets later -- by then its exchange and completion have long been enqueued,
+ * and the stream that fills it must have waited for the stream they went to (as it does for a dense grid it gathers into again). */
+typedef struct cpm_bricklist_segment {
+    void* segment;                /* device; NULL at the root (and with one rank): gather into the dense grid there */
+    uint32_t capacity;            /* bricks this ticket's exchange carries */
+    uint32_t room;                /* bricks the buffer holds: all of the grid's, rounded up to 64 */
+    uint32_t ticket;              /* (low 32 bits: what the header carries) */
+    uint32_t channels;
+    uint32_t* control;            /* device, 2 words, zero between launches: slots handed out, workgroups done */
+    unsigned long long* mailbox;  /* device address of the pinned word the count goes to */
+} cpm_bricklist_segment;
+int cpm_bricklist_reduce_open(cpm_ctx* ctx, cpm_bricklist_reduce* br, uint64_t* ticket_out, cpm_bricklist_segment* segment_out);
+int cpm_bricklist_pack_grid(cpm_ctx* ctx, cpm_bricklist_reduce* br, uint64_t ticket, const float* grid, const uint8_t* nonzero_bricks,
+                            cpm_stream stream);
+int cpm_bricklist_reduce_exchange(cpm_ctx* ctx, cpm_bricklist_reduce* br, uint64_t ticket, float* root_grid, cpm_stream stream);
+/* cpm_gather_fast whose output is a segment (fast formulation, any box the brick gather covers -- wide boxes included): what the
+ * dense launch would store, as the non-zero 4x4x4 bricks alone.  No grid is read or written.  Replaces, on a shard that is not the
+ * display GPU, the light volume PhotonToLightVolumeProcessorCL::process hands on (ref processor/photontolightvolumeprocessorcl.cpp:404-412). */
+int cpm_gather_fast_segment(cpm_ctx* ctx, const float* sorted_pos_power, const uint32_t* brick_table, int n, const cpm_grid_desc* grid,
+                            float radius, float scale, const cpm_bricklist_segment* segment, cpm_stream stream);
+/* A segment's bricks added into a dense grid on the same device (tests, and a shard that wants its own light volume back):
+ * grid[brick] += values for the first min(count, room) slots. */
+int cpm_bricklist_segment_to_grid(cpm_ctx* ctx, const cpm_bricklist_segment* segment, const cpm_grid_desc* grid, float* grid_out, cpm_stream stream);
+/* Point-to-point bytes over the communicator (ncclSend / ncclRecv on the caller's stream): what bench.py times at set-up to put measured
+ * latency and link figures beside the exchange model's assumed ones. */
+int cpm_comm_send(cpm_ctx* ctx, cpm_comm* comm, const void* buf, size_t bytes, int peer, cpm_stream stream);
+int cpm_comm_recv(cpm_ctx* ctx, cpm_comm* comm, void* buf, size_t bytes, int peer, cpm_stream stream);
 
 /* ---- OpenGL sharing: the consumer side of the light volume ---------------------------------------------------------
  * Replaces Inviwo's CL-GL sharing on this path (property `glsharing`, ref processor/progressivephotontracercl.cpp:93,

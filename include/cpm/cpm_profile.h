@@ -51,6 +51,15 @@ struct cpm_trace_order;
 int cpm_debug_trace_order_read(cpm_ctx* ctx, const struct cpm_trace_order* order, uint32_t* order_out, uint32_t* cost_out);
 /* measurement hook: replace the order's table by `table` (n_chunks entries, a permutation of the chunks: checked).  Synchronises. */
 int cpm_debug_trace_order_write(cpm_ctx* ctx, struct cpm_trace_order* order, const uint32_t* table);
+/* test hook: the sender's launch of cpm_bricklist_pack_grid into a caller-made segment (a communicator of one rank has no segment to
+ * pack into): the non-zero 4x4x4 bricks of `grid` (of the marked ones when `nonzero_bricks` is given) -> `segment`. */
+int cpm_debug_pack_grid_segment(cpm_ctx* ctx, const cpm_bricklist_segment* segment, const cpm_grid_desc* grid_desc, const float* grid,
+                                const uint8_t* nonzero_bricks, cpm_stream stream);
+/* test / measurement hook: the ROOT's two launches of cpm_bricklist_reduce_exchange (brick -> slot tables, then the sum in the segments'
+ * order) over n caller-made segments on this device (all of one ticket; a segment's `capacity` = the slots "received"; a segment whose
+ * count exceeds it adds nothing, as at the root): grid += the segments.  slot_of: n * (4x4x4 bricks of the grid) words of scratch. */
+int cpm_debug_root_add_segments(cpm_ctx* ctx, const cpm_bricklist_segment* segments, int n, const cpm_grid_desc* grid_desc, float* grid,
+                                uint32_t* slot_of, cpm_stream stream);
 #ifdef __cplusplus
 }
 #endif

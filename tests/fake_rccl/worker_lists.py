@@ -81,10 +81,10 @@ comm.close()
 
 # 2. as bench.py drives it: the double-buffered reducer over the transport, two tickets in flight
 class FileIdTransport(sh.RcclTransport):
-    def __init__(self, ctx, rank, world):
+    def __init__(self, ctx, rank, world, uid_name="uid_lists2.bin"):
         import torch as _t
         self.ctx, self.torch, self.world, self.rank, self.root = ctx, _t, world, rank, root
-        self.comm = ctx.comm_create(exchange_id("uid_lists2.bin"), rank, world)
+        self.comm = ctx.comm_create(exchange_id(uid_name), rank, world)
         self.stream = _t.cuda.Stream(device=ctx.device)
 
 
@@ -104,6 +104,73 @@ torch.cuda.synchronize()
 results["reducer_5"] = red.result(5).cpu().numpy().copy()
 results["reducer_6"] = red.result(6).cpu().numpy().copy()
 results["reducer_info"] = np.array([(i["n_own"], i["capacity"], i["resent"], i["sent_bytes"], i["received_bytes"]) for i in red.info], np.int64)
+tr.close()
+
+# 3. frames whose senders have NO dense light volume: open -> cpm_gather_fast_segment -> exchange -> complete.  Real photons (64^3 volume,
+#    128 x 128 lattice, 32^3 light volume) under both shardings -- tile shards make every rank light every brick: bricks listed by ALL
+#    senders, summed at the root in rank order from inexact values.  The dense gather of the same records is kept for the test's sum.
+S, P = cpm_amd.synthetic, cpm_amd.pipeline
+vol_np, tf = S.heterogeneous_volume(64), S.workspace_tf()
+n_total = 128 * 128
+for kind in ("tiles", "range"):
+    if kind == "tiles":
+        shard = sh.shard_tiles(n_total, rank, world, tile=1024)
+    else:
+        lo, hi = sh.shard_range(n_total, rank, world)
+        shard = np.arange(lo, hi, dtype=np.int64)
+    fr = P.PhotonFrame(ctx, vol_np, tf, (128, 128), (32, 32, 32), light_travel_direction=(0.3, 0.5, -1.0), photon_indices=shard)
+    fr.set_planar_records(True)
+    comm3 = ctx.comm_create(exchange_id(f"uid_seg_{kind}.bin"), rank, world)
+    br = ctx.bricklist_reduce_create(comm3, fr.grid, root)
+    dense = torch.empty_like(fr.light_volume)
+    infos = []
+    for k in range(5):
+        fr.trace(); fr.bin_fast()
+        fr.gather_fast(out=dense)
+        ticket, seg = br.open()
+        assert bool(seg.segment) == (rank != root)
+        if seg.segment:
+            fr.gather_fast_segment(seg)
+        total = dense.clone()
+        br.exchange(ticket, total if rank == root else None)
+        i = br.complete(ticket)
+        torch.cuda.synchronize()
+        results[f"seg_{kind}_{k}"] = total.cpu().numpy()
+        results[f"seg_{kind}_{k}_dense"] = dense.cpu().numpy()
+        infos.append((i.n_own, i.capacity, i.resent, i.sent_bytes, i.received_bytes, i.listed_bricks, i.n_bricks, i.dense_bytes))
+    results[f"seg_{kind}_info"] = np.array(infos, np.int64)
+    br.close()
+    comm3.close()
+    del fr
+
+# 4. bench.py's loop in that form: segment_for / gather / reduce with two tickets in flight
+tr = FileIdTransport(ctx, rank, world, "uid_lists3.bin")
+shard = sh.shard_tiles(n_total, rank, world, tile=1024)
+fr = P.PhotonFrame(ctx, vol_np, tf, (128, 128), (32, 32, 32), light_travel_direction=(0.3, 0.5, -1.0), photon_indices=shard)
+fr.set_planar_records(True)
+red = sh.OverlappedGridReducer(fr.light_volume, tr, lists=fr.grid, root=root)
+dense = torch.empty_like(fr.light_volume)
+for k in range(6):
+    fr.trace(); fr.bin_fast()
+    if k == 0:
+        fr.gather_fast(out=dense)
+        results["loop_dense"] = dense.cpu().numpy()
+    buf = red.acquire(k)
+    if k >= 2 and rank == root:
+        results[f"loop_{k - 2}"] = buf.cpu().numpy().copy()
+    seg = red.segment_for(k)
+    assert (seg is None) == (rank == root)
+    if seg is not None:
+        fr.gather_fast_segment(seg)
+    else:
+        fr.gather_fast(out=buf)
+    red.reduce(k)
+red.flush()
+torch.cuda.synchronize()
+if rank == root:
+    results["loop_4"] = red.result(4).cpu().numpy().copy()
+    results["loop_5"] = red.result(5).cpu().numpy().copy()
+results["loop_info"] = np.array([(i["n_own"], i["capacity"], i["resent"], i["sent_bytes"], i["received_bytes"]) for i in red.info], np.int64)
 tr.close()
 np.savez(out / f"rank{rank}.npz", **results)
 print("worker", rank, "done")

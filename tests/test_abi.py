@@ -73,7 +73,7 @@ def test_bricklist_policy_and_exchange_model_are_host_arithmetic(cpm):
             assert lib.cpm_bricklist_capacity_for(nb, prev) == sh.bricklist_capacity(nb, prev), (nb, prev)
     for cap in (0, 64, 1024, 7680):
         for ch in (1, 4):
-            assert lib.cpm_bricklist_segment_bytes(cap, ch) == sh.bricklist_segment_bytes(cap, ch) == 16 + cap * (256 * ch + 4)
+            assert lib.cpm_bricklist_segment_bytes(cap, ch) == sh.bricklist_segment_bytes(cap, ch) == 16 + cap * (256 * ch + 16)
     assert sh.bricklist_capacity(32768, 6077) == 7680 and sh.bricklist_capacity(32768, -1) == 8192 and sh.bricklist_capacity(60, 1000) == 64
     # config 4 at 8 ranks, the counts measured on one GPU (profiles/r05_shard_exchange_bytes_config4.json): slab shards + lists move a
     # fifth of what the union of bricks does, and both a fraction of the dense grid

@@ -139,7 +139,17 @@ def _slab_partial(dims, ch, k, who, n_ranks):
     return g.reshape(-1)
 
 
+_LISTS_RUNS = {}
+
+
 def _run_lists(tmp_path_factory, world, root):
+    """The workers' results for (world, root): started once per session, shared by the tests that read them."""
+    if (world, root) not in _LISTS_RUNS:
+        _LISTS_RUNS[(world, root)] = _start_lists(tmp_path_factory, world, root)
+    return _LISTS_RUNS[(world, root)]
+
+
+def _start_lists(tmp_path_factory, world, root):
     import build as fake_build
     lib = fake_build.build()
     out = tmp_path_factory.mktemp(f"fake_rccl_lists_{world}")
@@ -207,3 +217,51 @@ def test_brick_lists_to_the_root(tmp_path_factory, cpm, world, root):
         for w in range(world):
             if w != root:
                 assert np.array_equal(ranks[w][f"reducer_{k}"], parts[w]), (k, w)
+
+
+@pytest.mark.parametrize("world,root", [(2, 0), (4, 1)])
+def test_senders_gather_straight_into_their_segments(tmp_path_factory, cpm, world, root):
+    """Round 6: a rank that is not the display GPU has no dense light volume -- cpm_gather_fast_segment writes the non-zero 4x4x4 bricks of
+    its gather into the ticket's segment, ONE send carries it, the root adds all received segments with two launches.  The root's volume is
+    numpy's sum of the ranks' dense volumes (the same records gathered densely on every rank) in the library's order, bit for bit, from
+    inexact values: the root's own, then the senders in rank order -- under tile shards EVERY sender lists every brick --, a sender whose list
+    had outgrown its segment (the first tickets: capacity = a quarter of the bricks) after the others.  Same workers as above."""
+    sh = importlib.import_module(cpm.__name__ + ".sharding")
+    ranks = _run_lists(tmp_path_factory, world, root)
+    nb = 8 * 8 * 8
+    overflowed = 0
+    for kind in ("tiles", "range"):
+        infos = [r[f"seg_{kind}_info"] for r in ranks]
+        for k in range(5):
+            parts = [ranks[w][f"seg_{kind}_{k}_dense"] for w in range(world)]
+            late = [w for w in range(world) if w != root and int(infos[w][k, 2])]
+            want = parts[root].copy()
+            for w in [w for w in range(world) if w != root and w not in late] + late:
+                want = want + parts[w]
+            assert np.array_equal(ranks[root][f"seg_{kind}_{k}"].view(np.uint32), want.view(np.uint32)), (kind, k)
+            b, _ = _bricks((32, 32, 32))
+            for w in range(world):
+                if w == root:
+                    continue
+                n_own, cap, resent, sent = (int(v) for v in infos[w][k, :4])
+                assert n_own == np.unique(b[parts[w] != 0]).size
+                assert cap == sh.bricklist_capacity(nb, int(infos[w][k - 2, 0]) if k >= 2 else -1)
+                assert resent == (1 if n_own > cap else 0)
+                assert sent == sh.bricklist_segment_bytes(cap, 1) + (sh.bricklist_segment_bytes((n_own + 63) & ~63, 1) if resent else 0)
+                overflowed += resent
+            assert int(infos[root][k, 4]) == sum(int(infos[w][k, 3]) for w in range(world) if w != root)
+            assert int(infos[root][k, 5]) == sum(int(infos[w][k, 0]) for w in range(world) if w != root)
+        assert int(infos[root][-1, 2]) == 0                       # the steady frame fits
+    assert overflowed >= 1                                        # ... and some early list did not
+    if world > 2:   # bricks with three and more contributors were really there (else rank order would not have been exercised)
+        lit = [np.unique(_bricks((32, 32, 32))[0][ranks[w]["seg_tiles_4_dense"] != 0]) for w in range(world)]
+        assert np.intersect1d(np.intersect1d(lit[0], lit[1]), lit[2]).size > 50
+    # the frame loop: every frame's volume at the root is the same sum (the photons do not change from frame to frame)
+    parts = [ranks[w]["loop_dense"] for w in range(world)]
+    li = [ranks[w]["loop_info"] for w in range(world)]
+    for k in range(6):
+        late = [w for w in range(world) if w != root and int(li[w][k, 2])]
+        want = parts[root].copy()
+        for w in [w for w in range(world) if w != root and w not in late] + late:
+            want = want + parts[w]
+        assert np.array_equal(ranks[root][f"loop_{k}"].view(np.uint32), want.view(np.uint32)), k
