@@ -583,7 +583,17 @@ def main():
                     exchange_choice["chosen"] = "union (the list exchange's probe failed on some rank)"
         reducer = sharding.OverlappedGridReducer(fr.light_volume, transport, sparse=desc if exchange == "union" else None,
                                                  lists=desc if exchange == "lists" else None, root=0 if root is None else root)
-        segments = exchange == "lists" and rccl   # senders gather straight into their segments
+        segments = exchange == "lists" and rccl   # the step-by-step form: a sender may gather straight into its segment
+        reducer_root = 0 if root is None else root
+        sender_gather = None
+        if segments:
+            # which form this rank's frame takes is measured here, on this rank, with its shard (both fill the same segment: a rank-local choice)
+            mine = sharding.choose_sender_gather(fr, reducer.transport.lists.n_bricks) if rank != reducer_root else {"chosen": "root: dense volume"}
+            reducer.use_segments = mine["chosen"] != "pack"
+            rows = [None] * world
+            dist.all_gather_object(rows, mine)
+            sender_gather = {"per_rank": rows, "note": "frame time (trace + bin + gather [+ pack launch]) in us, measured on each rank at set-up: cpm_gather_fast_segment "
+                                                       "against cpm_gather_fast_marked + the pack launch; the faster form is what the rank's frames run"}
         frame_no = [0]
 
         def step():
@@ -603,8 +613,9 @@ def main():
                         fr.gather_fast_segment(seg)
                         reducer.reduce(k)
                         return
-                    # (the union reduce takes the gather's marks; so does a brick-list exchange that starts from a dense volume: the torch twin)
-                    marks = reducer.marks_for(k) if (reducer.sparse or (reducer.lists and not segments)) else None
+                    # (the union reduce takes the gather's marks; so does a brick-list exchange that starts from a dense volume: the torch twin,
+                    # or a sender whose set-up measurement chose the pack launch)
+                    marks = reducer.marks_for(k) if (reducer.sparse or (reducer.lists and not (segments and rank == reducer_root))) else None
                     fr.gather_fast(out=out, nonzero_bricks=marks)
                     reducer.reduce(k, marked=marks is not None)
                     return
@@ -1037,6 +1048,7 @@ def main():
                        "shards": (f"4096-sample lattice tiles dealt round-robin (rank r: tiles t = r mod {world})" if shards_kind == "tiles"
                                   else "contiguous photon ranges (slabs of the light plane)") if world > 1 else "one shard",
                        "exchange": exchange if world > 1 else "none",
+                       "sender_gather": sender_gather if (world > 1 and not correlated) else None,
                        "exchange_chosen_by": (exchange_choice if (world > 1 and not correlated and exchange_choice) else "flag / not applicable"),
                        # the transport the reduce really used, and the size RCCL itself reports for the communicator
                        # (cpm_comm_size; 0 = the reduce did not go through the C-ABI's RCCL communicator)

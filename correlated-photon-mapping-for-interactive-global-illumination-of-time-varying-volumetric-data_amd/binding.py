@@ -341,6 +341,8 @@ def load_library() -> C.CDLL:
         "cpm_debug_set_sort_items": (None, [vp, i32]),
         "cpm_debug_set_stream_wg_per_cu": (None, [vp, i32]),
         "cpm_debug_fail_next_select": (None, [vp, i32]),
+        "cpm_debug_pack_grid_segment": (i32, [vp, P(BricklistSegment), P(GridDesc), vp, vp, vp]),
+        "cpm_debug_root_add_segments": (i32, [vp, P(BricklistSegment), i32, P(GridDesc), vp, vp, vp]),
         "cpm_profile_enable": (None, [vp, i32]),
         "cpm_profile_reset": (None, [vp]),
         "cpm_profile_collect": (i32, [vp]),
@@ -656,6 +658,16 @@ class Context:
 
     def comm_recv(self, comm: "Comm", buf, nbytes: int, peer: int):
         self._check(self.lib.cpm_comm_recv(self.h, comm.h, self._ptr(buf), nbytes, peer, self._stream()))
+
+    def debug_pack_grid_segment(self, segment: "BricklistSegment", grid_desc, grid, nonzero_bricks=None):
+        """(measurement hook, cpm_profile.h) the sender's pack launch of cpm_bricklist_pack_grid into a caller-made segment."""
+        self._check(self.lib.cpm_debug_pack_grid_segment(self.h, C.byref(segment), C.byref(grid_desc), self._ptr(grid),
+                                                         self._ptr(nonzero_bricks) if nonzero_bricks is not None else None, self._stream()))
+
+    def debug_root_add_segments(self, segments, grid_desc, grid, slot_of):
+        """(measurement hook) the root's two launches of cpm_bricklist_reduce_exchange over caller-made segments: grid += segments."""
+        arr = (BricklistSegment * len(segments))(*segments)
+        self._check(self.lib.cpm_debug_root_add_segments(self.h, arr, len(segments), C.byref(grid_desc), self._ptr(grid), self._ptr(slot_of), self._stream()))
 
     def mark_touched_bricks(self, photons, indices, n_indices, n_photons, n_interactions, grid, radius, brick_mask):
         self._check(self.lib.cpm_mark_touched_bricks(self.h, self._ptr(photons), self._ptr(indices), n_indices, n_photons,

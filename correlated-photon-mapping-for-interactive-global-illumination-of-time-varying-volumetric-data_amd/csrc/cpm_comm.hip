@@ -69,6 +69,7 @@ struct cpm_bricklist_reduce {
     uint32_t* ctl = nullptr;      // sender, device: per slot 2 words (slots handed out, workgroups done), zero between launches
     uint32_t* slot_of = nullptr;  // root, device: per sender (rank order, the root left out) nb words: brick -> slot in that sender's
                                   // segment; never cleared -- an entry counts only if the slot it names carries the brick's id
+    uint32_t* who = nullptr;      // root, device: nb words, bit i = sender i lists the brick in the pass under way; zero between passes
     // pinned host words: [kSlots][kBricklistMaxRanks] ticket << 32 | the brick count of rank r's segment -- written by the last workgroup of
     // the sender's fill launch (its own word) and by the root's add launch (every sender's word, from the segment's header); behind them
     // the same again for the exchanges repeated at exact size (the root's acknowledgement of the header it then found)
@@ -875,9 +876,19 @@ __device__ inline int sender_of(const RootSegs& S, uint32_t wg, uint32_t per, ui
     return -1;
 }
 
-// root, launch 1 of 2: every received brick's slot -> its sender's brick -> slot table
+// at[q] for a run-time q (the array lives in registers: a select chain instead of scratch memory)
+template <int N>
+__device__ inline uint32_t at_of(const uint32_t (&at)[N], int q) {
+    uint32_t v = 0xffffffffu;
+#pragma unroll
+    for (int k = 0; k < N; ++k) v = k == q ? at[k] : v;
+    return v;
+}
+
+// root, launch 1 of 2: every received brick's slot -> its sender's brick -> slot table, and the sender's bit -> the brick's word of `who`
+// (which senders list it; all zero between passes: the group that sums a brick clears its word)
 __global__ __launch_bounds__(256) void bricklist_index_kernel(const unsigned char* __restrict__ base, RootSegs S, uint32_t ticket, uint32_t nb, int ch,
-                                                              uint32_t* __restrict__ slot_of) {
+                                                              uint32_t* __restrict__ slot_of, uint32_t* __restrict__ who) {
     uint32_t local;
     const int i = sender_of(S, blockIdx.x, 256u, local);
     if (i < 0) return;
@@ -886,21 +897,34 @@ __global__ __launch_bounds__(256) void bricklist_index_kernel(const unsigned cha
     const uint32_t s = local * 256u + threadIdx.x;
     if (s >= n) return;
     const uint32_t b = *reinterpret_cast<const uint32_t*>(seg_slot(seg, s, ch));
-    if (b < nb) slot_of[(size_t)S.table[i] * nb + b] = s;
+    if (b >= nb) return;
+    slot_of[(size_t)S.table[i] * nb + b] = s;
+    atomicOr(&who[b], 1u << i);
 }
 
-// root, launch 2 of 2: the sum.  16 lanes per received brick; the LOWEST-ranked sender that lists a brick adds its own values and then
-// every higher-ranked sender's for the same brick (found through the tables: an entry counts only when the slot it names carries the
-// brick's id), in rank order -- one read-modify-write of the grid per listed brick, no two groups on the same brick.  The first
-// workgroup of a sender also hands its header's count to the host (mailbox word; 0xffffffff = not this ticket's header).
+// root, launch 2 of 2: the sum.  16 lanes per received brick.  who[brick] says which senders list it: the LOWEST-ranked one's group sums the
+// brick -- the grid's piece, its own values, then every higher-ranked lister's (their slots from the tables; a slot counts only when it
+// carries the brick's id) in rank order -- one read-modify-write of the grid per listed brick, no two groups on the same brick; every other
+// group leaves after one look-up.  That group also clears the brick's word for the next pass.  The first workgroup of a sender hands its
+// header's count to the host (mailbox word; 0xffffffff = not this ticket's header).
 template <int CH, bool VEC>
 __global__ __launch_bounds__(256) void bricklist_add_kernel(const unsigned char* __restrict__ base, RootSegs S, uint32_t ticket, uint32_t nb,
-                                                            const uint32_t* __restrict__ slot_of, int dx, int dy, int dz, int bxn, int byn,
-                                                            float* __restrict__ grid, unsigned long long* mailbox) {
+                                                            const uint32_t* __restrict__ slot_of, uint32_t* __restrict__ who, int dx, int dy, int dz, int bxn,
+                                                            int byn, float* __restrict__ grid, unsigned long long* mailbox) {
+    constexpr int kMax = kBricklistMaxRanks - 1;   // senders
     __shared__ uint32_t s_n[kBricklistMaxRanks];
     uint32_t local;
     const int i = sender_of(S, blockIdx.x, 16u, local);
     if (i < 0) return;
+    // round trip 1: the headers, this group's brick id and its values (the slot exists whatever the header says: s < slots received)
+    const uint32_t s = local * 16u + (threadIdx.x >> 4);
+    const int r = threadIdx.x & 15;
+    const bool have = s < S.slots[i];
+    const unsigned char* mine = seg_slot(base + S.off[i], have ? s : 0u, CH);
+    const uint32_t b = have ? *reinterpret_cast<const uint32_t*>(mine) : 0xffffffffu;
+    float4 own[CH];
+#pragma unroll
+    for (int c = 0; c < CH; ++c) own[c] = have ? (reinterpret_cast<const float4*>(mine + 16) + (size_t)r * CH)[c] : make_float4(0.f, 0.f, 0.f, 0.f);
     if ((int)threadIdx.x < S.n) {
         uint32_t raw;
         s_n[threadIdx.x] = seg_usable(base + S.off[threadIdx.x], S.slots[threadIdx.x], S.hdr_cap[threadIdx.x], ticket, &raw);
@@ -908,22 +932,20 @@ __global__ __launch_bounds__(256) void bricklist_add_kernel(const unsigned char*
             __hip_atomic_store(mailbox + S.rank[i], ((unsigned long long)ticket << 32) | (unsigned long long)raw, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
     __syncthreads();
-    const uint32_t s = local * 16u + (threadIdx.x >> 4);
-    if (s >= s_n[i]) return;
-    const int r = threadIdx.x & 15;
-    const unsigned char* mine = seg_slot(base + S.off[i], s, CH);
-    const uint32_t b = *reinterpret_cast<const uint32_t*>(mine);
-    if (b >= nb || slot_of[(size_t)S.table[i] * nb + b] != s) return;   // (a brick listed twice: the slot its table kept)
-    auto listed = [&](int q, uint32_t& at) {
-        at = slot_of[(size_t)S.table[q] * nb + b];
-        return at < s_n[q] && *reinterpret_cast<const uint32_t*>(seg_slot(base + S.off[q], at, CH)) == b;
-    };
-    uint32_t at;
-    for (int q = 0; q < i; ++q) if (listed(q, at)) return;   // a lower rank lists it: that group sums the brick
+    if (s >= s_n[i] || b >= nb) return;
+    // round trip 2: who lists the brick; is this the slot its sender's table kept (a brick listed twice by one sender: one slot counts)
+    const uint32_t lists = who[b] & ((1u << S.n) - 1u);
+    const uint32_t at_own = slot_of[(size_t)S.table[i] * nb + b];
+    if (!((lists >> i) & 1u) || at_own != s) return;
+    if (lists & ((1u << i) - 1u)) return;             // a lower rank lists it: that group sums the brick
+    // round trip 3: the grid's piece and the other listers' slots
     const int bx = (int)(b % (uint32_t)bxn), by = (int)((b / (uint32_t)bxn) % (uint32_t)byn), bz = (int)(b / (uint32_t)(bxn * byn));
     const int y = by * 4 + (r & 3), z = bz * 4 + (r >> 2);
-    if (y >= dy || z >= dz) return;
-    const size_t v = (size_t)(bx * 4) + (size_t)dx * ((size_t)y + (size_t)dy * (size_t)z);
+    const bool inside = y < dy && z < dz;
+    const size_t v = (size_t)(bx * 4) + (size_t)dx * ((size_t)(inside ? y : 0) + (size_t)dy * (size_t)(inside ? z : 0));
+    uint32_t at[kMax];
+#pragma unroll
+    for (int q = 0; q < kMax; ++q) at[q] = (q > i && ((lists >> q) & 1u)) ? slot_of[(size_t)S.table[q] * nb + b] : 0xffffffffu;
     float4 acc[CH];
     if (VEC) {
 #pragma unroll
@@ -931,16 +953,43 @@ __global__ __launch_bounds__(256) void bricklist_add_kernel(const unsigned char*
     } else {
         float* ff = reinterpret_cast<float*>(acc);
         for (int k = 0; k < 4 * CH; ++k) ff[k] = 0.f;
-        for (int x = 0; x < 4 && bx * 4 + x < dx; ++x)
-            for (int c = 0; c < CH; ++c) ff[x * CH + c] = grid[(v + x) * CH + c];
+        if (inside)
+            for (int x = 0; x < 4 && bx * 4 + x < dx; ++x)
+                for (int c = 0; c < CH; ++c) ff[x * CH + c] = grid[(v + x) * CH + c];
     }
-    for (int q = i; q < S.n; ++q) {
-        const unsigned char* sl = mine;
-        if (q != i) { if (!listed(q, at)) continue; sl = seg_slot(base + S.off[q], at, CH); }
-        const float4* p = reinterpret_cast<const float4*>(sl + 16) + (size_t)r * CH;
+    if (r == 0) who[b] = 0u;   // (every other group of this brick leaves whatever it reads here: none of them has the lowest bit)
 #pragma unroll
-        for (int c = 0; c < CH; ++c) { const float4 d = p[c]; acc[c] = make_float4(acc[c].x + d.x, acc[c].y + d.y, acc[c].z + d.z, acc[c].w + d.w); }
+    for (int c = 0; c < CH; ++c) acc[c] = make_float4(acc[c].x + own[c].x, acc[c].y + own[c].y, acc[c].z + own[c].z, acc[c].w + own[c].w);
+    // round trip 4, only for bricks other senders list too: their values (and their slots' heads: the brick's id, or the slot does not count), in rank order
+    constexpr int kAhead = CH == 1 ? 4 : 2;   // senders' values in flight
+    for (int q0 = i + 1; q0 < S.n && (lists >> q0) != 0u; q0 += kAhead) {   // (uniform per group of 16 lanes)
+        float4 d[kAhead][CH];
+        uint32_t head[kAhead];
+#pragma unroll
+        for (int u = 0; u < kAhead; ++u) {
+            const int q = q0 + u;
+            const uint32_t a = at_of(at, q);
+            const bool on = q < S.n && ((lists >> q) & 1u) && a < s_n[q < S.n ? q : 0];
+            head[u] = 0xffffffffu;
+#pragma unroll
+            for (int c = 0; c < CH; ++c) d[u][c] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (on) {
+                const unsigned char* sl = seg_slot(base + S.off[q], a, CH);
+                head[u] = *reinterpret_cast<const uint32_t*>(sl);
+                const float4* p = reinterpret_cast<const float4*>(sl + 16) + (size_t)r * CH;
+#pragma unroll
+                for (int c = 0; c < CH; ++c) d[u][c] = p[c];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < kAhead; ++u) {
+            if (head[u] == b) {   // (a sender that does not list the brick adds nothing)
+#pragma unroll
+                for (int c = 0; c < CH; ++c) acc[c] = make_float4(acc[c].x + d[u][c].x, acc[c].y + d[u][c].y, acc[c].z + d[u][c].z, acc[c].w + d[u][c].w);
+            }
+        }
     }
+    if (!inside) return;
     if (VEC) {
 #pragma unroll
         for (int c = 0; c < CH; ++c) reinterpret_cast<float4*>(grid + v * CH)[c] = acc[c];
@@ -1028,11 +1077,11 @@ SegTarget sender_target(cpm_bricklist_reduce* br, const cpm_bricklist_reduce::Sl
 }
 
 // the root's two launches over the segments `S` names in `base`
-struct RootGrid { int dims[3]; int channels, bxn, byn; uint32_t nb; uint32_t* slot_of; };
+struct RootGrid { int dims[3]; int channels, bxn, byn; uint32_t nb; uint32_t* slot_of; uint32_t* who; };
 RootGrid root_grid_of(const cpm_bricklist_reduce* br) {
     RootGrid g;
     for (int a = 0; a < 3; ++a) g.dims[a] = br->dims[a];
-    g.channels = br->channels; g.bxn = br->bxn; g.byn = br->byn; g.nb = br->nb; g.slot_of = br->slot_of;
+    g.channels = br->channels; g.bxn = br->bxn; g.byn = br->byn; g.nb = br->nb; g.slot_of = br->slot_of; g.who = br->who;
     return g;
 }
 int bricklist_root_add(cpm_ctx* ctx, const RootGrid& rg, const RootSegs& S, const void* base, uint32_t ticket, float* grid, unsigned long long* mailbox,
@@ -1041,10 +1090,10 @@ int bricklist_root_add(cpm_ctx* ctx, const RootGrid& rg, const RootSegs& S, cons
     for (int i = 0; i < S.n; ++i) { w_index += (S.slots[i] + 255u) / 256u; w_add += (S.slots[i] + 15u) / 16u; }
     if (w_add == 0) return CPM_OK;
     const unsigned char* b = static_cast<const unsigned char*>(base);
-    CPM_LAUNCH(ctx, bricklist_index_kernel, dim3(w_index), dim3(256), 0, s, b, S, ticket, rg.nb, rg.channels, rg.slot_of);
+    CPM_LAUNCH(ctx, bricklist_index_kernel, dim3(w_index), dim3(256), 0, s, b, S, ticket, rg.nb, rg.channels, rg.slot_of, rg.who);
     CPM_LAUNCH_CHECK(ctx, "bricklist_index_kernel");
     const bool vec = (rg.dims[0] & 3) == 0;
-#define CPM_BL_ADD(CH, VEC) CPM_LAUNCH(ctx, (bricklist_add_kernel<CH, VEC>), dim3(w_add), dim3(256), 0, s, b, S, ticket, rg.nb, rg.slot_of, rg.dims[0], rg.dims[1], rg.dims[2], rg.bxn, rg.byn, grid, mailbox)
+#define CPM_BL_ADD(CH, VEC) CPM_LAUNCH(ctx, (bricklist_add_kernel<CH, VEC>), dim3(w_add), dim3(256), 0, s, b, S, ticket, rg.nb, rg.slot_of, rg.who, rg.dims[0], rg.dims[1], rg.dims[2], rg.bxn, rg.byn, grid, mailbox)
     if (rg.channels == 1) { if (vec) CPM_BL_ADD(1, true); else CPM_BL_ADD(1, false); }
     else { if (vec) CPM_BL_ADD(4, true); else CPM_BL_ADD(4, false); }
 #undef CPM_BL_ADD
@@ -1108,7 +1157,8 @@ int cpm_bricklist_reduce_create(cpm_ctx* ctx, cpm_comm* comm, const cpm_grid_des
                  hipMemset(br->ctl, 0, 2 * cpm_bricklist_reduce::kSlots * 4) == hipSuccess;
         } else {
             const size_t bytes = (size_t)(comm->size - 1) * nb * 4;
-            ok = hipMalloc((void**)&br->slot_of, bytes) == hipSuccess && hipMemset(br->slot_of, 0xff, bytes) == hipSuccess;
+            ok = hipMalloc((void**)&br->slot_of, bytes) == hipSuccess && hipMemset(br->slot_of, 0xff, bytes) == hipSuccess &&
+                 hipMalloc((void**)&br->who, nb * 4) == hipSuccess && hipMemset(br->who, 0, nb * 4) == hipSuccess;
         }
     }
     if (!ok) {
@@ -1125,7 +1175,7 @@ void cpm_bricklist_reduce_destroy(cpm_bricklist_reduce* br) {
     if (!br) return;
     (void)hipSetDevice(br->device);
     for (auto& sl : br->slots) if (sl.ticket && !sl.completed) { (void)hipDeviceSynchronize(); break; }  // the mailbox outlives its writers
-    for (void* p : { (void*)br->ctl, (void*)br->slot_of, br->again }) if (p) (void)hipFree(p);
+    for (void* p : { (void*)br->ctl, (void*)br->slot_of, (void*)br->who, br->again }) if (p) (void)hipFree(p);
     for (void* p : br->seg) if (p) (void)hipFree(p);
     if (br->mailbox) (void)hipHostFree(br->mailbox);
     delete br;
@@ -1202,7 +1252,7 @@ int cpm_debug_root_add_segments(cpm_ctx* ctx, const cpm_bricklist_segment* segs,
     for (int a = 0; a < 3; ++a) rg.dims[a] = gd->dims[a];
     rg.channels = gd->channels; rg.bxn = div_up(gd->dims[0], 4); rg.byn = div_up(gd->dims[1], 4);
     rg.nb = (uint32_t)((size_t)rg.bxn * rg.byn * div_up(gd->dims[2], 4));
-    rg.slot_of = slot_of;
+    rg.slot_of = slot_of; rg.who = slot_of + (size_t)n * rg.nb;
     RootSegs S;
     memset(&S, 0, sizeof S);
     S.n = n;
@@ -1268,7 +1318,7 @@ int cpm_bricklist_reduce_exchange(cpm_ctx* ctx, cpm_bricklist_reduce* br, uint64
                 CPM_NCCL_CHECK(ctx, R, R->GroupEnd());
             }
             rc = bricklist_root_add(ctx, root_grid_of(br), S, base, (uint32_t)ticket, root_grid, br->mailbox_dev + (size_t)slot_i * kBricklistMaxRanks, s);
-            if (rc) return rc;
+            if (rc) { br->poisoned = true; return rc; }   // (the senders' sends are under way and `who` may hold bits nobody clears: no later ticket)
         }
     }
     sl.exchanged = true;
@@ -1338,7 +1388,7 @@ int cpm_bricklist_reduce_complete(cpm_ctx* ctx, cpm_bricklist_reduce* br, uint64
                 unsigned long long* ack_dev = br->mailbox_dev + (size_t)(kSlots + slot_i) * kBricklistMaxRanks;
                 volatile unsigned long long* ack = br->mailbox + (size_t)(kSlots + slot_i) * kBricklistMaxRanks + r;
                 rc = bricklist_root_add(ctx, root_grid_of(br), S, br->again, (uint32_t)ticket, sl.grid, ack_dev, s);
-                if (rc) return rc;
+                if (rc) { br->poisoned = true; return rc; }
                 // (a rare path: wait for it and see that the segment that came was this ticket's and carried the count both sides sized it for)
                 CPM_HIP_CHECK(ctx, hipStreamSynchronize(s));
                 const unsigned long long v = __atomic_load_n(ack, __ATOMIC_ACQUIRE);

@@ -156,6 +156,48 @@ def measure_p2p(transport, reps: int = 20):
             "method": f"ping-pong between ranks {root} and {other}, {reps} round trips per size, HIP events on the reduce stream"}
 
 
+def scratch_segment(torch, device, n_bricks: int, channels: int = 1, capacity: int = None, ticket: int = 1):
+    """A brick-list segment made from plain device buffers (binding.BricklistSegment is the public POD cpm_bricklist_segment): room for
+    every brick, `capacity` (default: all) as the exchange's size.  Returns (segment, the tensors that keep it alive).  What tools, tests
+    and bench.py's set-up measurement fill without a communicator."""
+    from . import binding as B
+    room = (n_bricks + 63) & ~63
+    buf = torch.empty(16 + room * (16 + 256 * channels), dtype=torch.uint8, device=device)
+    ctl = torch.zeros(2, dtype=torch.int32, device=device)
+    mail = torch.zeros(1, dtype=torch.int64, device=device)
+    seg = B.BricklistSegment(buf.data_ptr(), room if capacity is None else capacity, room, ticket, channels, ctl.data_ptr(), mail.data_ptr())
+    return seg, (buf, ctl, mail)
+
+
+def choose_sender_gather(frame, n_bricks: int, reps: int = 12):
+    """How a rank that is NOT the display GPU should produce its brick list -- measured on this rank, with its shard, at set-up (a rank-local
+    choice: both forms fill the same segment): "segment" = cpm_gather_fast_segment (the non-zero bricks straight from the gather: no dense
+    volume; wins where a rank lights few bricks -- contiguous photon ranges), "pack" = cpm_gather_fast_marked + one pack launch over the marked
+    bricks (wins where every rank lights every brick -- tile shards: the segment form pays its slot bookkeeping per gather brick).
+    Returns {"chosen", "segment_us", "pack_us"}: the frame's time (trace + bin + gather [+ pack]) in each form."""
+    torch, ctx = frame.torch, frame.ctx
+    seg, keep = scratch_segment(torch, ctx.device, n_bricks, frame.grid.channels)
+    marks = torch.zeros(n_bricks + 16, dtype=torch.uint8, device=ctx.device)
+    dense = torch.empty_like(frame.light_volume)
+
+    def timed(fn):
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / reps * 1e3
+    t_seg = timed(lambda: (frame.trace(), frame.bin_fast(), frame.gather_fast_segment(seg)))
+    t_pack = timed(lambda: (frame.trace(), frame.bin_fast(), frame.gather_fast(out=dense, nonzero_bricks=marks),
+                            ctx.debug_pack_grid_segment(seg, frame.grid, dense, marks)))
+    del keep
+    return {"chosen": "segment" if t_seg < t_pack else "pack", "segment_us": round(t_seg, 1), "pack_us": round(t_pack, 1)}
+
+
 def brick_view(grid, dims, channels=1):
     """The grid (x fastest, `channels` interleaved) as [bz, by, bx, 4, 4, 4 * channels] after zero-padding every axis to a
     multiple of 4: brick b = bx + nbx * (by + nby * bz), a brick's values in (z, y, x, channel) order."""
@@ -501,6 +543,7 @@ class OverlappedGridReducer:
         self.info = []  # per completed sparse ticket: union, capacity, mode, bytes; per completed list exchange: its cpm_bricklist_info
         self.marks = [None, None]  # per buffer: the non-zero 4x4x4 bricks, written by the gather (marks_for)
         self._opened = {}          # frame -> (ticket, segment) of a brick-list exchange opened by segment_for and not yet enqueued
+        self.use_segments = True   # brick lists over the C-ABI: senders gather straight into their segments (False: dense volume + pack launch)
         if (self.sparse or self.lists) and self.active:
             desc = sparse if self.sparse else lists
             if isinstance(self.transport, TorchTransport):
@@ -545,7 +588,7 @@ class OverlappedGridReducer:
         """Brick lists over the C-ABI, on a rank that is not the root: the segment frame k's gather writes its non-zero bricks into
         (PhotonFrame.gather_fast_segment) -- then no dense buffer, no zeros and no pass over one on this rank; None where the frame
         gathers into acquire(k) as ever (the root, other exchanges, the torch twin).  Call after acquire(k)."""
-        if not (self.lists and self.active) or isinstance(self.transport, TorchTransport):
+        if not (self.lists and self.active and self.use_segments) or isinstance(self.transport, TorchTransport):
             return None
         if k not in self._opened:
             self._opened[k] = self.transport.lists_open()

@@ -57,7 +57,8 @@ int cpm_debug_pack_grid_segment(cpm_ctx* ctx, const cpm_bricklist_segment* segme
                                 const uint8_t* nonzero_bricks, cpm_stream stream);
 /* test / measurement hook: the ROOT's two launches of cpm_bricklist_reduce_exchange (brick -> slot tables, then the sum in the segments'
  * order) over n caller-made segments on this device (all of one ticket; a segment's `capacity` = the slots "received"; a segment whose
- * count exceeds it adds nothing, as at the root): grid += the segments.  slot_of: n * (4x4x4 bricks of the grid) words of scratch. */
+ * count exceeds it adds nothing, as at the root): grid += the segments.  slot_of: (n + 1) * (4x4x4 bricks of the grid) words of scratch,
+ * zero-filled before the first call (the last block is the launches' who-lists-what words: zero again when the call's work is done). */
 int cpm_debug_root_add_segments(cpm_ctx* ctx, const cpm_bricklist_segment* segments, int n, const cpm_grid_desc* grid_desc, float* grid,
                                 uint32_t* slot_of, cpm_stream stream);
 #ifdef __cplusplus

@@ -125,6 +125,8 @@ for kind in ("tiles", "range"):
     dense = torch.empty_like(fr.light_volume)
     infos = []
     for k in range(5):
+        if k == 2:   # a thin medium from here on: the photons reach deep into the volume, every rank's list grows past the capacity its last counts gave it
+            fr.tf.update(S.homogeneous_tf(0.02))
         fr.trace(); fr.bin_fast()
         fr.gather_fast(out=dense)
         ticket, seg = br.open()

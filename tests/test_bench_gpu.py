@@ -27,7 +27,7 @@ def test_bench_single_gpu_line():
     d = _last_json(r.stdout)
     assert KEYS <= set(d) and {"cpu_baseline", "pipelined", "frame", "other_formulation", "reference_formulation_splat", "i4",
                                "sparse_tf_trace"} <= set(d)
-    assert d["n_gpus"] == 1 and d["steps"] == 10 and d["warmup"] == 2 and d["value"] > 0 and d["scaling"] == "weak"
+    assert d["n_gpus"] == 1 and d["steps"] == 10 and d["warmup"] == 200 and d["warmup_requested"] == 2 and d["value"] > 0 and d["scaling"] == "weak"
     assert "cpm_bin_fast" in d["config"]["formulation"] and d["other_formulation"]["name"] == "exact"
     assert any(k.startswith("fast_brick_kernel") for k in d["frame"]["kernel_ms_per_frame"])
     assert set(d["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic"}

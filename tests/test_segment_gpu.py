@@ -78,7 +78,7 @@ def test_gather_into_a_segment_is_the_dense_gather(ctx, cpm, dims, ch, radius, n
     nb = ((dims[0] + 3) // 4) * ((dims[1] + 3) // 4) * ((dims[2] + 3) // 4)
     want = _n(dense).reshape(-1, ch)
     lit = np.unique(_brick_ids(dims)[(want != 0).any(axis=1)])
-    assert 0 < lit.size < nb
+    assert 0 < lit.size <= nb
     sets = []
     for launch in range(2):
         seg, buf, ctl, mail = _segment(ctx, B, nb, ch, capacity=64, ticket=41 + launch)   # (a capacity far below the count: the gather still writes everything)
@@ -170,7 +170,7 @@ def test_root_adds_all_segments_in_rank_order(ctx, cpm):
     for l in lit[1:]:
         shared = np.intersect1d(shared, l)
     assert shared.size > 200                                   # bricks every rank lights
-    slot_of = torch.full((4 * nb,), 0x7fffffff, dtype=torch.int32, device=ctx.device)
+    slot_of = torch.zeros(5 * nb, dtype=torch.int32, device=ctx.device)   # (4 tables + the who-lists-what words; zeros in a table name slot 0: believed only where that slot carries the brick)
     arr = (B.BricklistSegment * 4)(*segs)
     for attempt in range(2):                                   # (the second pass finds the first one's table entries: all still true)
         total = _t(ctx, dense[0])
@@ -180,6 +180,7 @@ def test_root_adds_all_segments_in_rank_order(ctx, cpm):
         for r in range(1, world):
             want = want + dense[r]
         assert np.array_equal(_n(total).view(np.uint32), want.view(np.uint32))
+        assert not _n(slot_of[4 * nb:]).any()                   # the pass cleared its who-lists-what words
     # sender 2's segment "arrives" with a capacity its list outgrew: it adds nothing, the others add as before -- and the table entries it
     # left in the passes above are not believed
     segs2 = list(segs)

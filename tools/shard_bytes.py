@@ -79,6 +79,8 @@ for world in (2, 4, 8):
             union |= marks[:nb]
             t_dense.append(round(timed_us(lambda: (fr.trace(), fr.bin_fast(), fr.gather_fast(nonzero_bricks=marks))), 1))
             seg, bufs = make_segment(7)
+            # (the capacity the exchange would have settled on: this rank's count * 1.25 + 64 -- what the root's launches are sized by)
+            seg.capacity = sh.bricklist_capacity(nb, counts[-1])
             t_seg.append(round(timed_us(lambda: (fr.trace(), fr.bin_fast(), fr.gather_fast_segment(seg))), 1))
             if r > 0:
                 segs.append(seg); keep.append(bufs)
@@ -86,7 +88,7 @@ for world in (2, 4, 8):
         n_union = int(union.sum().item())
         # the root's work behind the receive: N - 1 real segments into a dense volume (any: the adds' cost does not depend on its values)
         total = torch.zeros(gdim ** 3, dtype=torch.float32, device=ctx.device)
-        slot_of = torch.full(((world - 1) * nb,), 0x7fffffff, dtype=torch.int32, device=ctx.device)
+        slot_of = torch.zeros(world * nb, dtype=torch.int32, device=ctx.device)   # (N - 1 brick -> slot tables + the who-lists-what words)
         arr = (B.BricklistSegment * (world - 1))(*segs)
 
         def root_add():
