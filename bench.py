@@ -334,6 +334,10 @@ def main():
                          "No form synchronises the stream.  auto: lists where the photon count is fixed (strong scaling: the per-rank compute "
                          "shrinks, the union does not), union where it grows with the ranks (weak)")
     ap.add_argument("--reduce", default=None, choices=["sparse", "dense"], help="(older spelling of --exchange union / dense)")
+    ap.add_argument("--sequence", default="resident", choices=["resident", "streamed"],
+                    help="--workload config5: the 32 time steps live on the device as volumes (default: what Inviwo's representations are after the "
+                         "first loop) or in pinned host memory, every rank uploading step t + 1 on the library's copy stream while it updates step t "
+                         "(cpm_volume_stream: SURVEY 8d's step with the upload in it)")
     ap.add_argument("--test-backend", default="nccl", choices=["nccl", "gloo"],
                     help="(testing) process-group backend; gloo lets the N > 1 code path run with every rank on one GPU")
     ap.add_argument("--test-one-device", action="store_true", help="(testing) every rank uses cuda:0")
@@ -486,7 +490,13 @@ def main():
     if correlated:
         n_steps = 32
         vols = [S.heterogeneous_volume(vdim, S.sequence_blob_center(t, n_steps)) for t in range(n_steps)]
-        dvols = [ctx.volume_create(v) for v in vols]  # resident as volumes (as a sequence's VolumeCL representations are): no upload in the step
+        streamed = args.sequence == "streamed"
+        if streamed:   # the sequence stays in (pinned) host memory: three device slots, uploads on the library's copy stream
+            pinned_seq = B.PinnedSequence(ctx, vols)
+            vstream = B.VolumeStream(ctx, vols[0], n_slots=3)
+            vstream.prefetch(1, pinned_seq.steps[1])
+        else:
+            dvols = [ctx.volume_create(v) for v in vols]  # resident as volumes (as a sequence's VolumeCL representations are): no upload in the step
         fr = P.CorrelatedPhotonMapper(ctx, vols[0], tf, lattice, (gdim,) * 3, light_travel_direction=LIGHT_DIR,
                                       tf_points=list(S.WORKSPACE_TF_POINTS), photon_indices=shard)
         fr.full_frame()
@@ -503,7 +513,12 @@ def main():
         def step():
             t = 1 + step_no[0] % (n_steps - 1)
             step_no[0] += 1
-            fr.set_volume(dvols[t])
+            if streamed:
+                t_next = 1 + step_no[0] % (n_steps - 1)
+                vstream.prefetch(t_next, pinned_seq.steps[t_next])   # crosses PCIe while this step is computed
+                fr.set_volume(vstream.acquire(t, pinned_seq.steps[t]))
+            else:
+                fr.set_volume(dvols[t])
             fr.touched_mask.zero_()
             n = fr.correlated_update()
             fractions.append(n / max(fr.n, 1))
@@ -841,8 +856,57 @@ def main():
             extras["config5_time_step"] = {"steps": len(res), "volume_step_ms": round(float(np.median([r[0] for r in res])), 4),
                                            "update_ms": round(float(np.median([r[1] for r in res])), 4),
                                            "fraction_retraced": round(float(np.mean([r[2] for r in res])), 5),
-                                           "note": "Python driver; time steps resident on the device as volumes (no upload, copy or re-layout in the step)"}
-            del cm, vols
+                                           "note": "Python driver; RESIDENT: time steps on the device as volumes (no upload, copy or re-layout in the step); "
+                                                   "volume_step_ms and update_ms each from an idle device"}
+            # SURVEY 8(d)'s step: "upload volume, min/max, mean-abs-diff, ...".  The same walk through the sequence (a) RESIDENT, steps enqueued
+            # back to back with one synchronisation at the end (the figure the streamed one compares with), (b) STREAMED from pinned host memory:
+            # cpm_volume_stream, three device slots, step t + 1 put on the library's copy stream before step t's update is enqueued
+            # (round and round through the steps, so that EVERY step needs an upload -- forth and back would find two of them resident at each end)
+            walk = [k % n_steps for k in range(1, 6 * n_steps + 1)]
+
+            def run_walk(volume_of, before=None):
+                torch.cuda.synchronize(); ta = time.perf_counter()
+                for j, t in enumerate(walk):
+                    if before is not None:
+                        before(j)
+                    cm.set_volume(volume_of(j, t))
+                    cm.correlated_update()
+                torch.cuda.synchronize()
+                return (time.perf_counter() - ta) * 1e3 / len(walk)
+            run_walk(lambda j, t: vols[t])
+            resident_ms = min(run_walk(lambda j, t: vols[t]) for _ in range(3))
+            pinned = B.PinnedSequence(ctx, seq_np)
+            vstream = B.VolumeStream(ctx, seq_np[0], n_slots=3)
+
+            def ahead(j):   # the step after this one starts crossing PCIe now
+                if j + 1 < len(walk):
+                    vstream.prefetch(walk[j + 1], pinned.steps[walk[j + 1]])
+            vstream.prefetch(walk[0], pinned.steps[walk[0]])
+            run_walk(lambda j, t: vstream.acquire(t, pinned.steps[t]), ahead)
+            vstream.prefetch(walk[0], pinned.steps[walk[0]])
+            streamed_ms = min(run_walk(lambda j, t: vstream.acquire(t, pinned.steps[t]), ahead) for _ in range(3))
+            torch.cuda.synchronize()
+            si = vstream.stats()
+            h2d_ms = si.upload_ms_total / max(si.uploads_timed, 1)
+            # ... and with the upload IN the step's own stream, not ahead of it (what cpm_volume_update from host memory does): the sum
+            own = [ctx.volume_create(seq_np[0]), ctx.volume_create(seq_np[0])]   # (two, used in turn: the mapper still reads the step before)
+            inline_ms = run_walk(lambda j, t: (own[j & 1].update(pinned.steps[t]), own[j & 1])[1])
+            extras["config5_time_step"].update({
+                "resident_step_ms_back_to_back": round(resident_ms, 4),
+                "streamed_step_ms": round(streamed_ms, 4),
+                "upload_ms": round(h2d_ms, 4), "h2d_gbps": round(si.bytes_per_step / max(h2d_ms, 1e-9) / 1e6, 2),
+                "bytes_per_step": int(si.bytes_per_step),
+                "upload_hidden_fraction": round(min(1.0, max(0.0, 1.0 - (streamed_ms - resident_ms) / max(h2d_ms, 1e-9))), 3),
+                "bound_ms": round(max(h2d_ms, resident_ms), 4),   # max(upload, update): what the streamed step is held to (+ 10 %)
+                "upload_in_the_step_unhidden_ms": round(inline_ms, 4),
+                "uploads_started_at_the_acquire": int(si.uploads_at_acquire),
+                "walk": f"round and round through {n_steps} steps ({len(walk)} steps timed, one synchronisation at the end): every step uploads; the wrap from the last "
+                        "step to the first is one large change per round, in the resident and the streamed walk alike",
+                "streamed": "cpm_volume_stream: sequence in pinned host memory, 3 device slots (linear block + footprint copy each), H2D + re-layout on the "
+                            "library's copy stream while the step before runs; upload_ms = the H2D copy alone (HIP events on the copy stream, mean); "
+                            "upload_hidden_fraction = 1 - (streamed - resident) / upload"})
+            vstream.close(); pinned.close()
+            del cm, vols, own
             seq = hostlayer.HostSequence(hl, np.stack(seq_np))
             net = hostlayer.HostNetwork(hl, seq_np[0], nx, lpos, dnorm, base_pts, size_option=vdim // gdim, correlated=True)
             seq.attach(net)
@@ -853,6 +917,22 @@ def main():
             rows = rows[3:]
             totals = [seq.step_total(net, 0.25 * (4 * (n_steps - 1) - k))[1] for k in range(1, 4 * (n_steps - 1))][5:]   # (back down the sequence)
             extras["config5_time_step"]["host_network_step_ms"] = round(float(np.median(totals)), 4)
+            # the same network with the sequence KEPT IN HOST MEMORY (VolumeSequencePlayer.keepSequenceOnDevice = false: its ring of three device
+            # volumes, the next element prefetched on the library's copy stream): whole elements apart, so that every step needs a new upload
+            seq.keep_on_device(False)
+            for k in range(1, n_steps):
+                seq.step_total(net, float(k))
+            tot_s = [seq.step_total(net, float(k % n_steps))[1] for k in range(n_steps, 3 * n_steps)]
+            st = seq.stream_stats() or {}
+            seq.keep_on_device(True)
+            for k in range(0, n_steps):
+                seq.step_total(net, float(k))
+            tot_r = [seq.step_total(net, float(k % n_steps))[1] for k in range(n_steps, 3 * n_steps)]
+            extras["config5_time_step"]["host_network_streamed"] = {
+                "step_ms_streamed": round(float(np.median(tot_s)), 4), "step_ms_resident_same_walk": round(float(np.median(tot_r)), 4),
+                "upload_ms": round(st.get("upload_ms", 0.0) / max(st.get("uploads", 0), 1), 4), "uploads_at_acquire": st.get("uploads_at_acquire"),
+                "note": "each step from an idle device to an idle device (cpmh_sequence_step_total synchronises on both sides): the prefetch of the NEXT "
+                        "element is what overlaps here -- it was started during the step before"}
             extras["config5_time_step"]["host_network"] = {
                 "steps": len(rows), "displayed_times": "a quarter of a sequence step apart",
                 "players_ms": round(float(np.median([r[1] for r in rows])), 4), "update_ms": round(float(np.median([r[2] for r in rows])), 4),
@@ -1026,8 +1106,9 @@ def main():
             "config": {"workload": (f"BASELINE {args.workload}: {vdim}^3 u8 heterogeneous volume, {n_total} photons per frame in all "
                                     f"({lattice[0]}x{lattice[1]} lattice, one directional light; {n_rank} on rank 0), {gdim}^3 x1 f32 light volume, "
                                     f"I=1, r=1 voxel, MWC64X streams from glibc srand(0)"
-                                    + ("; a step = one time step of the 32-step sequence: volume difference / min-max / importance, "
-                                       "correlated re-trace, delta light-volume update" if correlated else "")),
+                                    + ("; a step = one time step of the 32-step sequence: " + ("UPLOAD of the step from pinned host memory (cpm_volume_stream, "
+                                       "ahead on the copy stream), " if (correlated and args.sequence == "streamed") else "(sequence resident on the device) ")
+                                       + "volume difference / min-max / importance, correlated re-trace, delta light-volume update" if correlated else "")),
                        "formulation": what, "photons_per_frame": n_total, "photons_rank0": n_rank, "volume": [vdim] * 3,
                        "light_volume": [gdim] * 3,
                        "parallelism": (f"photon-sharded x{world} ({scaling} scaling), one "

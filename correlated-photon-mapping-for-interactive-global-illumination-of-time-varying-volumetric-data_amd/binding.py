@@ -53,6 +53,8 @@ ABI_SYMBOLS = [
     "cpm_bricklist_segment_bytes", "cpm_reduce_grid_bricklists", "cpm_bricklist_reduce_complete",
     "cpm_bricklist_reduce_open", "cpm_bricklist_pack_grid", "cpm_bricklist_reduce_exchange", "cpm_gather_fast_segment",
     "cpm_bricklist_segment_to_grid", "cpm_comm_send", "cpm_comm_recv", "cpm_gather_fast_supported_on",
+    "cpm_pinned_alloc", "cpm_pinned_free", "cpm_volume_stream_create", "cpm_volume_stream_destroy", "cpm_volume_stream_prefetch",
+    "cpm_volume_stream_acquire", "cpm_volume_stream_stats",
     "cpm_light_volume_texels", "cpm_gl_available", "cpm_gl_register_buffer", "cpm_gl_acquire", "cpm_gl_release",
     "cpm_gl_buffer_pointer", "cpm_gl_copy_to_buffer", "cpm_gl_unregister",
 ]
@@ -155,6 +157,12 @@ class BricklistInfo(C.Structure):
     """cpm_bricklist_info"""
     _fields_ = [("ticket", C.c_uint64), ("n_bricks", C.c_uint32), ("n_own", C.c_uint32), ("capacity", C.c_uint32), ("resent", C.c_int32),
                 ("sent_bytes", C.c_uint64), ("received_bytes", C.c_uint64), ("dense_bytes", C.c_uint64), ("listed_bricks", C.c_uint32)]
+
+
+class VolumeStreamInfo(C.Structure):
+    """cpm_volume_stream_info"""
+    _fields_ = [("uploads", C.c_uint64), ("hits", C.c_uint64), ("uploads_at_acquire", C.c_uint64), ("bytes_uploaded", C.c_uint64),
+                ("bytes_per_step", C.c_uint64), ("uploads_timed", C.c_uint64), ("upload_ms_total", C.c_double)]
 
 
 class BricklistSegment(C.Structure):
@@ -313,6 +321,13 @@ def load_library() -> C.CDLL:
         "cpm_comm_send": (i32, [vp, vp, vp, C.c_size_t, i32, vp]),
         "cpm_comm_recv": (i32, [vp, vp, vp, C.c_size_t, i32, vp]),
         "cpm_gather_fast_supported_on": (i32, [vp, P(GridDesc), f32]),
+        "cpm_pinned_alloc": (i32, [vp, C.c_size_t, P(vp)]),
+        "cpm_pinned_free": (None, [vp, vp]),
+        "cpm_volume_stream_create": (i32, [vp, P(VolumeDesc), i32, P(vp)]),
+        "cpm_volume_stream_destroy": (None, [vp, vp]),
+        "cpm_volume_stream_prefetch": (i32, [vp, vp, C.c_uint64, vp, vp]),
+        "cpm_volume_stream_acquire": (i32, [vp, vp, C.c_uint64, vp, vp, P(vp)]),
+        "cpm_volume_stream_stats": (i32, [vp, vp, P(VolumeStreamInfo)]),
         "cpm_gl_available": (i32, [vp]),
         "cpm_gl_register_buffer": (i32, [vp, u32, i32, P(vp)]),
         "cpm_light_volume_texels": (i32, [vp, vp, sz, i32, vp, vp]),
@@ -1027,8 +1042,9 @@ class Comm:
 
 
 class Volume:
-    def __init__(self, ctx: Context, h, desc: VolumeDesc):
-        self.ctx, self.h, self.desc = ctx, h, desc
+    def __init__(self, ctx: Context, h, desc: VolumeDesc, owned: bool = True):
+        """owned=False: a volume something else destroys (a cpm_volume_stream's slot)."""
+        self.ctx, self.h, self.desc, self.owned = ctx, h, desc, owned
 
     @property
     def dims(self):
@@ -1053,8 +1069,94 @@ class Volume:
 
     def __del__(self):
         try:
-            if self.h and self.ctx.h:
+            if self.h and self.ctx.h and self.owned:
                 self.ctx.lib.cpm_volume_destroy(self.ctx.h, self.h)
+        except Exception:
+            pass
+
+
+class PinnedSequence:
+    """The steps of a time-varying sequence in pinned host memory (cpm_pinned_alloc): what cpm_volume_stream copies from without holding the
+    calling thread.  steps[t] is a numpy view [z, y, x] of step t."""
+
+    def __init__(self, ctx: Context, volumes):
+        import numpy as np
+        self.ctx, self.steps, self._ptrs = ctx, [], []
+        for v in volumes:
+            v = np.ascontiguousarray(v)
+            p = C.c_void_p()
+            ctx._check(ctx.lib.cpm_pinned_alloc(ctx.h, v.nbytes, C.byref(p)))
+            self._ptrs.append(p)
+            a = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), shape=(v.nbytes,)).view(v.dtype).reshape(v.shape)
+            a[...] = v
+            self.steps.append(a)
+
+    def __len__(self):
+        return len(self.steps)
+
+    def pointer(self, t: int):
+        return self._ptrs[t]
+
+    def close(self):
+        self.steps = []
+        for p in self._ptrs:
+            self.ctx.lib.cpm_pinned_free(self.ctx.h, p)
+        self._ptrs = []
+
+    def __del__(self):
+        try:
+            if self.ctx.h:
+                self.close()
+        except Exception:
+            pass
+
+
+class VolumeStream:
+    """cpm_volume_stream: a ring of device volumes over a host-resident sequence, uploads on the library's copy stream (cpm.h)."""
+
+    def __init__(self, ctx: Context, like, n_slots: int = 3):
+        """like: a numpy array [z, y, x] of the steps' shape and type (or a VolumeDesc)."""
+        import numpy as np
+        self.ctx = ctx
+        if isinstance(like, VolumeDesc):
+            self.desc = like
+        else:
+            code = {np.dtype(np.uint8): CPM_U8, np.dtype(np.uint16): CPM_U16, np.dtype(np.float32): CPM_F32}[np.dtype(like.dtype)]
+            self.desc = default_volume_desc(like.shape[::-1], code)
+        self.h = C.c_void_p()
+        ctx._check(ctx.lib.cpm_volume_stream_create(ctx.h, C.byref(self.desc), n_slots, C.byref(self.h)))
+
+    @staticmethod
+    def _host(voxels):
+        if voxels is None:
+            return None
+        if isinstance(voxels, C.c_void_p):
+            return voxels
+        return C.c_void_p(voxels.ctypes.data)
+
+    def prefetch(self, tag: int, voxels):
+        """voxels: a numpy array (pinned: PinnedSequence.steps[t]) or a raw pointer; the consumer is the current stream."""
+        self.ctx._check(self.ctx.lib.cpm_volume_stream_prefetch(self.ctx.h, self.h, tag, self._host(voxels), self.ctx._stream()))
+
+    def acquire(self, tag: int, voxels=None) -> "Volume":
+        h = C.c_void_p()
+        self.ctx._check(self.ctx.lib.cpm_volume_stream_acquire(self.ctx.h, self.h, tag, self._host(voxels), self.ctx._stream(), C.byref(h)))
+        return Volume(self.ctx, h, self.desc, owned=False)
+
+    def stats(self) -> VolumeStreamInfo:
+        info = VolumeStreamInfo()
+        self.ctx._check(self.ctx.lib.cpm_volume_stream_stats(self.ctx.h, self.h, C.byref(info)))
+        return info
+
+    def close(self):
+        if self.h:
+            self.ctx.lib.cpm_volume_stream_destroy(self.ctx.h, self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            if self.ctx.h:
+                self.close()
         except Exception:
             pass
 

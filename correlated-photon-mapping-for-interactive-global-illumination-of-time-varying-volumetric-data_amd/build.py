@@ -10,7 +10,7 @@ from pathlib import Path
 PKG_DIR = Path(__file__).resolve().parent
 REPO = PKG_DIR.parent
 SOURCES = ["cpm_core.hip", "cpm_rng_emission.hip", "cpm_trace.hip", "cpm_sort.hip", "cpm_lightvolume.hip", "cpm_fastvolume.hip",
-           "cpm_correlated.hip", "cpm_temporal.hip", "cpm_comm.hip", "cpm_gl.hip"]
+           "cpm_correlated.hip", "cpm_temporal.hip", "cpm_stream.hip", "cpm_comm.hip", "cpm_gl.hip"]
 # -ffp-contract=off: the arithmetic contract spells out every fma
 FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-std=c++17", "-fPIC", "-shared",
          "-Wall", "-Wno-unused-function", "-ldl"]

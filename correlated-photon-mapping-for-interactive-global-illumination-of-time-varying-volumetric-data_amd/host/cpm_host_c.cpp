@@ -539,6 +539,8 @@ int cpmh_sequence_evaluate(cpmh_sequence* s) {
         s->difference.process();
         s->analysed = true;
     }
+    if (!s->volumePlayer.keepSequenceOnDevice_.get())   // a sequence that stays in host memory: the analyses' device copies of its elements go again
+        for (const auto& v : *s->volumes) v->invalidateDeviceRepresentation();
     s->volumePlayer.process();
     s->minMaxPlayer.process();
     s->differencePlayer.process();
@@ -547,6 +549,20 @@ int cpmh_sequence_evaluate(cpmh_sequence* s) {
     s->gridSourcePlayer.process();
 #endif
     return (s->volumePlayer.outport_.getData() && s->minMaxPlayer.outport_.getData() && s->differencePlayer.outport_.getData()) ? 0 : -1;
+}
+// keep != 0 (default): the elements become resident on first use and stay (Inviwo's VolumeCL representations); 0: they stay in host memory and
+// reach the device through the player's ring of three volumes, the next element prefetched on the library's copy stream (cpm_volume_stream)
+void cpmh_sequence_keep_on_device(cpmh_sequence* s, int keep) {
+    if (s) s->volumePlayer.keepSequenceOnDevice_.set(keep != 0);
+}
+// out[0] = finished uploads whose time has been read, out[1] = their H2D time in ms, out[2] = bytes per element, out[3] = elements a frame had to
+// wait for (uploaded at the acquire, not ahead of it); 0 when the player streams, -1 when it does not
+int cpmh_sequence_stream_stats(cpmh_sequence* s, double* out) {
+    unsigned long long n = 0, late = 0, bytes = 0;
+    double ms = 0.0;
+    if (!s || !out || !s->volumePlayer.streamStats(&n, &late, &ms, &bytes)) return -1;
+    out[0] = (double)n; out[1] = ms; out[2] = (double)bytes; out[3] = (double)late;
+    return 0;
 }
 void cpmh_sequence_set_time_per_element(cpmh_sequence* s, float seconds) {
     for_each_clock(s, [&](SequenceClock& c) { c.timePerElement_.set(seconds); });

@@ -1,6 +1,8 @@
 // cpm_timevarying.cpp -- see cpm_timevarying.h
 #include "cpm_timevarying.h"
 
+#include <hip/hip_runtime_api.h>
+
 #include <algorithm>
 #include <fstream>
 #include <functional>
@@ -323,6 +325,7 @@ VolumeSequencePlayer::VolumeSequencePlayer() {
     addPortId("volumeSequence", true); addPortId("InterpolatedVolume", false);
     addProperty(clock_.time_); addProperty(clock_.index_); addProperty(clock_.timePerElement_);
     addProperty(clock_.frameRate_); addProperty(clock_.playSequence_);
+    addProperty(keepSequenceOnDevice_);
     auto resize = [this]() { if (inport_.hasData()) clock_.onTimeStepChange(inport_.getData()->size()); };
     inport_.onConnect(resize);
     clock_.timePerElement_.onChange(resize);
@@ -341,9 +344,64 @@ void VolumeSequencePlayer::process() {
         outVolume_->setModelMatrix(from->getModelMatrix());
         outVolume_->setWorldMatrix(from->getWorldMatrix());
     }
-    cpm_volume *a = from->getDeviceRepresentation(), *b = towards->getDeviceRepresentation(), *blended = outVolume_->getDeviceRepresentation();
+    cpm_volume *a = nullptr, *b = nullptr, *blended = outVolume_->getDeviceRepresentation();
+    if (keepSequenceOnDevice_.get()) {
+        if (stream_) dropStream();
+        a = from->getDeviceRepresentation(); b = towards->getDeviceRepresentation();
+    } else {
+        // the elements stay in host memory (ref volumesequenceplayer.cpp:94-124 hands them to OpenGL, which uploads what is not resident): the two
+        // this frame blends are acquired from the ring, the one after them is put on the copy stream now -- it crosses PCIe behind this frame's work
+        const size_t bytes = from->getDimensions().x * from->getDimensions().y * from->getDimensions().z * from->elementSize();
+        if (stream_ && streamedSequence_ != sequence.get()) dropStream();
+        if (!stream_) {
+            cpm_volume_desc d;
+            const int32_t dims[3] = { (int32_t)from->getDimensions().x, (int32_t)from->getDimensions().y, (int32_t)from->getDimensions().z };
+            cpm_volume_desc_default(&d, dims, from->dtype());
+            if (!rt.check(cpm_volume_stream_create(rt.ctx(), &d, 3, &stream_), "cpm_volume_stream_create")) { stream_ = nullptr; return; }
+            streamedSequence_ = sequence.get();
+            for (const auto& v : *sequence)   // page-lock the elements' RAM once: a copy from pageable memory is staged and holds this thread
+                if (v->ramBytes.size() == bytes && hipHostRegister(const_cast<uint8_t*>(v->ramBytes.data()), bytes, hipHostRegisterDefault) == hipSuccess)
+                    pinned_.push_back(v->ramBytes.data());
+            (void)hipGetLastError();
+        }
+        // (the element the walk reaches next: one further along when the clock moved on by one element since the last frame, one back when it
+        // moved back by one, as before otherwise)
+        const size_t count = sequence->size();
+        if (step.first == (lastFirst_ + 1) % count) direction_ = +1;
+        else if (step.first == (lastFirst_ + count - 1) % count) direction_ = -1;
+        lastFirst_ = step.first;
+        const size_t next = direction_ > 0 ? (step.second + 1) % count : (step.first + count - 1) % count;
+        for (size_t e : { step.first, step.second, next }) {
+            const auto& v = sequence->at(e);
+            if (v->ramBytes.size() != bytes) { rt.check(CPM_ERR_INVALID_ARGUMENT, "VolumeSequencePlayer: an element without RAM data (or of another size) cannot be streamed"); return; }
+        }
+        if (!rt.check(cpm_volume_stream_acquire(rt.ctx(), stream_, step.first, from->ramBytes.data(), rt.stream(), &a), "cpm_volume_stream_acquire") ||
+            !rt.check(cpm_volume_stream_acquire(rt.ctx(), stream_, step.second, towards->ramBytes.data(), rt.stream(), &b), "cpm_volume_stream_acquire"))
+            return;
+        if (next != step.first && next != step.second)
+            rt.check(cpm_volume_stream_prefetch(rt.ctx(), stream_, next, sequence->at(next)->ramBytes.data(), rt.stream()), "cpm_volume_stream_prefetch");
+    }
     if (!a || !b || !blended) return;
     if (rt.check(cpm_volume_mix(rt.ctx(), a, b, step.fraction, blended, rt.stream()), "cpm_volume_mix")) outport_.setData(outVolume_);
+}
+void VolumeSequencePlayer::dropStream() {
+    auto& rt = CpmRuntime::get();
+    if (stream_) cpm_volume_stream_destroy(rt.ctx(), stream_);   // (waits for its copy stream)
+    stream_ = nullptr; streamedSequence_ = nullptr;
+    for (const void* p : pinned_) (void)hipHostUnregister(const_cast<void*>(p));
+    (void)hipGetLastError();
+    pinned_.clear();
+}
+VolumeSequencePlayer::~VolumeSequencePlayer() { dropStream(); }
+bool VolumeSequencePlayer::streamStats(unsigned long long* uploads, unsigned long long* uploadsAtAcquire, double* uploadMs, unsigned long long* bytesPerStep) {
+    if (!stream_) return false;
+    cpm_volume_stream_info i;
+    if (cpm_volume_stream_stats(CpmRuntime::get().ctx(), stream_, &i) != CPM_OK) return false;
+    if (uploads) *uploads = i.uploads_timed;
+    if (uploadsAtAcquire) *uploadsAtAcquire = i.uploads_at_acquire;
+    if (uploadMs) *uploadMs = i.upload_ms_total;
+    if (bytesPerStep) *bytesPerStep = i.bytes_per_step;
+    return true;
 }
 
 #ifdef CPM_HOST_EXTRAS

@@ -103,11 +103,25 @@ public:
     const ProcessorInfo getProcessorInfo() const override { return { "org.inviwo.VolumeSequencePlayer", "Volume Sequence Player", "Volume Operation" }; }
     void process() override;  // :87-140
     void onSequenceTimerEvent() { clock_.onSequenceTimerEvent(); }
+    ~VolumeSequencePlayer();
     DataInport<VolumeSequence> inport_{ "volumeSequence" };
     DataOutport<Volume> outport_{ "InterpolatedVolume" };
     SequenceClock clock_{ "timePerVolume", "Time Per Volume (s)", "volumesPerSecond" };
+    // (not in the reference, whose elements become resident on first use and stay: this build's default too) false: the sequence STAYS IN HOST
+    // MEMORY -- the two elements a frame blends come through a ring of three device volumes filled by the library's copy stream
+    // (cpm_volume_stream: the element after them is already crossing PCIe while this frame's blend, analyses and update run); for
+    // sequences that do not fit on the device, and what SURVEY 8(d) counts as a time step: "upload volume, ..."
+    BoolProperty keepSequenceOnDevice_{ "keepSequenceOnDevice", "Keep Sequence On Device", true };
+    // uploads the copy stream has carried so far / elements a frame had to wait for (not prefetched): cpmh_sequence_stream_stats
+    bool streamStats(unsigned long long* uploads, unsigned long long* uploadsAtAcquire, double* uploadMs, unsigned long long* bytesPerStep);
 private:
     std::shared_ptr<Volume> outVolume_;
+    ::cpm_volume_stream* stream_ = nullptr;       // keepSequenceOnDevice == false
+    const VolumeSequence* streamedSequence_ = nullptr;
+    std::vector<const void*> pinned_;             // elements' RAM blocks registered with the driver for the asynchronous copies
+    size_t lastFirst_ = 0;                        // the element the last frame started from, and which way the walk has been going
+    int direction_ = +1;
+    void dropStream();
 };
 
 #ifdef CPM_HOST_EXTRAS

@@ -37,6 +37,8 @@ def load():
         "cpmh_set_clip": (None, [vp, i32, i32, i32, i32, i32, i32]),
         "cpmh_sequence_create": (vp, [vp, i32, i32, i32, i32, i32, i32]),
         "cpmh_sequence_destroy": (None, [vp]),
+        "cpmh_sequence_keep_on_device": (None, [vp, i32]),
+        "cpmh_sequence_stream_stats": (i32, [vp, vp]),
         "cpmh_attach_sequence": (i32, [vp, vp]),
         "cpmh_sequence_step": (i32, [vp, vp, C.c_float, vp]),
         "cpmh_sequence_step_total": (i32, [vp, vp, C.c_float, vp]),
@@ -165,6 +167,17 @@ class HostSequence:
         if n < -1:
             raise RuntimeError("cpmh_sequence_step_total failed")
         return n, t.value
+
+    def keep_on_device(self, keep: bool):
+        """False: the elements stay in host memory and are streamed through the player's ring of device volumes (cpm_volume_stream)."""
+        self.lib.cpmh_sequence_keep_on_device(self.h, int(bool(keep)))
+
+    def stream_stats(self):
+        """{"uploads", "upload_ms", "bytes_per_step", "uploads_at_acquire"} of the streaming player, or None when it keeps the sequence resident."""
+        out = (C.c_double * 4)()
+        if self.lib.cpmh_sequence_stream_stats(self.h, out) != 0:
+            return None
+        return {"uploads": int(out[0]), "upload_ms": float(out[1]), "bytes_per_step": int(out[2]), "uploads_at_acquire": int(out[3])}
 
     def close(self):
         if self.h:

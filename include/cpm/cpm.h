@@ -703,6 +703,38 @@ int cpm_mix_buffers(cpm_ctx* ctx, const void* x, const void* y, float a, size_t 
 int cpm_volume_mix(cpm_ctx* ctx, const cpm_volume* v0, const cpm_volume* v1, float weight,
                    cpm_volume* out, cpm_stream stream);
 
+/* ---- a sequence whose steps live in HOST memory: the upload inside the step, behind the step before it -------------------
+ * The reference's players step a host-side sequence and upload whichever element is not resident (ref uniformgridcl/processors/
+ * volumesequenceplayer.cpp:94-124; the difference analysis reads the same host elements, ref dynamicvolumedifferenceanalysis.h:96-151):
+ * 16 MiB of PCIe per 256^3 step -- ~0.33 ms against a 0.07 ms correlated update.  A cpm_volume_stream is a ring of n_slots device volumes
+ * (linear block + the tracer's footprint copy each) over such a sequence, filled by a copy stream the library owns:
+ *   cpm_volume_stream_prefetch(tag, host voxels, consumer)   enqueues on the copy stream: wait for what `consumer` has enqueued so far (the
+ *       slot it overwrites -- the one prefetched / handed out longest ago -- was last read there), H2D, footprint re-layout, an event.
+ *       Returns at once; a step that is resident or under way is only marked as about to be used.
+ *   cpm_volume_stream_acquire(tag, host voxels or NULL, consumer, &volume)   `consumer` waits for that event (uploading first when the
+ *       step is absent) and the slot's volume is handed out: valid until n_slots - 1 OTHER steps have been prefetched / acquired after it.
+ * A caller that prefetches step t + 1, then acquires step t and enqueues its update (difference against step t - 1, importance, re-trace,
+ * delta splat) needs 3 slots and pays max(upload, update) per step instead of their sum.  Host buffers should be pinned
+ * (cpm_pinned_alloc): a copy from pageable memory is staged by the runtime and holds the calling thread.  `tag` names a step (its
+ * index); the library never reads host memory after the copy it enqueued has run -- keep a buffer alive until its step was acquired. */
+typedef struct cpm_volume_stream cpm_volume_stream;
+typedef struct cpm_volume_stream_info {
+    uint64_t uploads;             /* H2D copies enqueued */
+    uint64_t hits;                /* acquires that found their step resident or under way */
+    uint64_t uploads_at_acquire;  /* acquires that had to start the upload themselves (not hidden) */
+    uint64_t bytes_uploaded;
+    uint64_t bytes_per_step;
+    uint64_t uploads_timed;       /* finished uploads whose event pair has been read ... */
+    double upload_ms_total;       /* ... and their H2D time in all (the copy alone, on the copy stream) */
+} cpm_volume_stream_info;
+int cpm_pinned_alloc(cpm_ctx* ctx, size_t bytes, void** out);
+void cpm_pinned_free(cpm_ctx* ctx, void* p);
+int cpm_volume_stream_create(cpm_ctx* ctx, const cpm_volume_desc* desc, int n_slots /* 2 .. 8 */, cpm_volume_stream** out);
+void cpm_volume_stream_destroy(cpm_ctx* ctx, cpm_volume_stream* vs);
+int cpm_volume_stream_prefetch(cpm_ctx* ctx, cpm_volume_stream* vs, uint64_t tag, const void* host_voxels, cpm_stream consumer);
+int cpm_volume_stream_acquire(cpm_ctx* ctx, cpm_volume_stream* vs, uint64_t tag, const void* host_voxels, cpm_stream consumer, cpm_volume** out);
+int cpm_volume_stream_stats(cpm_ctx* ctx, cpm_volume_stream* vs, cpm_volume_stream_info* info);
+
 /* ------------------------------------------------------------------ multi-GPU: photon shards + one reduce
  *
  * Photon i depends only on light sample i, RNG stream i and read-only data, so GPU g of D traces photons

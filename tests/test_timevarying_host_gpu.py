@@ -175,3 +175,40 @@ def test_play_timer_wraps_around(seqlib, cpm):
         seen.append(idx)
     assert set(seen) == {1, 2, 3}
     seqlib.cpmh_sequence_destroy(h)
+
+
+def test_a_sequence_kept_in_host_memory_plays_the_same_volumes(seqlib, ctx, cpm):
+    """keepSequenceOnDevice = false (this build's property; the reference's elements become resident on first use): the player's two elements
+    come through its ring of three device volumes, filled ahead on the library's copy stream (cpm_volume_stream) -- every displayed time,
+    forth and back through the sequence and across the wrap, is the volume the resident player shows, bit for bit; every upload but the
+    first frame's was started ahead of the frame that needs it."""
+    dim, steps, region = 32, 6, 8
+    vols = _sequence(cpm, dim, steps)
+    for name, res, args in [("cpmh_sequence_keep_on_device", None, [C.c_void_p, C.c_int]), ("cpmh_sequence_stream_stats", C.c_int, [C.c_void_p, C.c_void_p])]:
+        f = getattr(seqlib, name)
+        f.restype, f.argtypes = res, args
+    a = seqlib.cpmh_sequence_create(vols.ctypes.data, 0, dim, dim, dim, steps, region)
+    b = seqlib.cpmh_sequence_create(vols.ctypes.data, 0, dim, dim, dim, steps, region)
+    seqlib.cpmh_sequence_keep_on_device(b, 0)
+    stats = (C.c_double * 4)()
+    assert seqlib.cpmh_sequence_stream_stats(a, stats) == -1            # the resident player does not stream
+    times = [0.0, 0.25, 0.5, 1.0, 1.75, 2.0, 2.5, 3.0, 3.5, 4.0, 4.9, 5.0, 4.5, 3.25, 2.0, 1.0, 0.0]
+    for time in times:
+        for h in (a, b):
+            seqlib.cpmh_sequence_evaluate(h)
+            seqlib.cpmh_sequence_set_time(h, time)
+            assert seqlib.cpmh_sequence_evaluate(h) == 0
+        got_a, got_b = np.empty_like(vols[0]), np.empty_like(vols[0])
+        assert seqlib.cpmh_sequence_download(a, 0, got_a.ctypes.data) == 0 and seqlib.cpmh_sequence_download(b, 0, got_b.ctypes.data) == 0
+        assert np.array_equal(got_a, got_b), time
+        for kind, dt, shape in ((1, np.uint16, ((dim // region) ** 3, 2)), (2, np.float32, ((dim // region) ** 3,))):
+            ga, gb = np.empty(shape, dt), np.empty(shape, dt)
+            assert seqlib.cpmh_sequence_download(a, kind, ga.ctypes.data) == 0 and seqlib.cpmh_sequence_download(b, kind, gb.ctypes.data) == 0
+            assert np.array_equal(ga.view(np.uint8), gb.view(np.uint8)), (time, kind)
+    ctx.torch.cuda.synchronize()
+    assert seqlib.cpmh_sequence_stream_stats(b, stats) == 0
+    uploads, upload_ms, bytes_per_step, late = int(stats[0]), float(stats[1]), int(stats[2]), int(stats[3])
+    assert bytes_per_step == dim ** 3 and uploads >= steps and upload_ms > 0
+    assert late <= 4          # the very first frame's two elements, and the turn-around (the walk back is not what the player prefetches for)
+    seqlib.cpmh_sequence_destroy(a)
+    seqlib.cpmh_sequence_destroy(b)
