@@ -23,41 +23,38 @@ CPM_TRACE_PHOTONS_PLANAR = 4
 CPM_PHOTONS_INTERLEAVED, CPM_PHOTONS_PLANAR = 0, 1
 CPM_PHASE_HENYEY_GREENSTEIN, CPM_PHASE_ISOTROPIC = 0, 1
 
-#: every symbol include/cpm/cpm.h declares (checked by tests/test_abi.py against the header)
-ABI_SYMBOLS = [
-    "cpm_create", "cpm_destroy", "cpm_last_error_string", "cpm_abi_version",
-    "cpm_glibc_rand_sequence", "cpm_seed_streams", "cpm_random_fill",
-    "cpm_volume_desc_default", "cpm_volume_create", "cpm_volume_update", "cpm_volume_destroy",
-    "cpm_volume_device_data", "cpm_volume_download",
-    "cpm_tf_create", "cpm_tf_update", "cpm_tf_destroy",
-    "cpm_uniform_samples_2d", "cpm_directional_light_samples", "cpm_point_light_samples",
-    "cpm_light_sample_box_intersection", "cpm_light_sample_mesh_intersection",
-    "cpm_trace", "cpm_trace_lights", "cpm_trace_lights_order_samples", "cpm_trace_emitted",
-    "cpm_trace_order_create", "cpm_trace_order_destroy", "cpm_trace_set_order", "cpm_trace_order_update",
-    "cpm_grid_desc_default", "cpm_relative_irradiance_scale",
-    "cpm_splat", "cpm_splat_selected", "cpm_copy_indexed_photons", "cpm_snapshot_selected_photons",
-    "cpm_sort_pairs", "cpm_sort_keys", "cpm_bin", "cpm_gather", "cpm_mark_touched_bricks", "cpm_gather_bricks",
-    "cpm_fast_table_entries", "cpm_gather_fast_supported", "cpm_fast_record_capacity", "cpm_bin_fast", "cpm_bin_fast_layout", "cpm_photons_convert", "cpm_set_photon_layout", "cpm_get_photon_layout", "cpm_splat_records", "cpm_gather_fast", "cpm_gather_fast_marked",
-    "cpm_volume_minmax", "cpm_volume_difference", "cpm_volume_step", "cpm_importance_tf", "cpm_importance_tf_occupancy",
-    "cpm_photon_importance", "cpm_photon_importance_equal", "cpm_reset_importance",
-    "cpm_select_recompute", "cpm_select_changed",
-    "cpm_selection_create", "cpm_selection_destroy", "cpm_selection_begin", "cpm_photon_importance_select",
-    "cpm_photon_importance_equal_select", "cpm_photon_importance_retrace", "cpm_photon_importance_retrace_lights", "cpm_selection_finish", "cpm_selection_set_occupancy", "cpm_selection_count_device", "cpm_selection_count",
-    "cpm_trace_selected", "cpm_splat_delta",
-    "cpm_mix_buffers", "cpm_volume_mix",
-    "cpm_comm_get_unique_id", "cpm_comm_create", "cpm_comm_create_all", "cpm_comm_destroy", "cpm_comm_rank", "cpm_comm_size",
-    "cpm_allreduce_grid", "cpm_reduce_grid", "cpm_allreduce_grids", "cpm_allreduce_grid_bricks",
-    "cpm_sparse_reduce_create", "cpm_sparse_reduce_destroy", "cpm_sparse_reduce_bricks", "cpm_sparse_reduce_capacity_for",
-    "cpm_allreduce_grid_sparse", "cpm_sparse_reduce_complete", "cpm_brick_mask_or",
-    "cpm_bricklist_reduce_create", "cpm_bricklist_reduce_destroy", "cpm_bricklist_reduce_bricks", "cpm_bricklist_capacity_for",
-    "cpm_bricklist_segment_bytes", "cpm_reduce_grid_bricklists", "cpm_bricklist_reduce_complete",
-    "cpm_bricklist_reduce_open", "cpm_bricklist_pack_grid", "cpm_bricklist_reduce_exchange", "cpm_gather_fast_segment",
-    "cpm_bricklist_segment_to_grid", "cpm_comm_send", "cpm_comm_recv", "cpm_gather_fast_supported_on",
-    "cpm_pinned_alloc", "cpm_pinned_free", "cpm_volume_stream_create", "cpm_volume_stream_destroy", "cpm_volume_stream_prefetch",
-    "cpm_volume_stream_acquire", "cpm_volume_stream_stats",
-    "cpm_light_volume_texels", "cpm_gl_available", "cpm_gl_register_buffer", "cpm_gl_acquire", "cpm_gl_release",
-    "cpm_gl_buffer_pointer", "cpm_gl_copy_to_buffer", "cpm_gl_unregister",
+#: every symbol include/cpm/cpm.h declares -- the core: one entry point per call site of the reference's host code (checked by tests/test_abi.py
+#: against the header)
+CORE_SYMBOLS = [
+    "cpm_create", "cpm_destroy", "cpm_last_error_string", "cpm_abi_version", "cpm_glibc_rand_sequence", "cpm_seed_streams", "cpm_random_fill",
+    "cpm_volume_desc_default", "cpm_volume_create", "cpm_volume_update", "cpm_volume_destroy", "cpm_volume_device_data", "cpm_volume_download",
+    "cpm_tf_create", "cpm_tf_update", "cpm_tf_destroy", "cpm_uniform_samples_2d", "cpm_directional_light_samples", "cpm_point_light_samples",
+    "cpm_light_sample_box_intersection", "cpm_light_sample_mesh_intersection", "cpm_trace", "cpm_grid_desc_default", "cpm_relative_irradiance_scale",
+    "cpm_splat", "cpm_splat_selected", "cpm_copy_indexed_photons", "cpm_snapshot_selected_photons", "cpm_sort_pairs", "cpm_sort_keys", "cpm_bin",
+    "cpm_gather", "cpm_volume_minmax", "cpm_volume_difference", "cpm_importance_tf", "cpm_photon_importance", "cpm_photon_importance_equal",
+    "cpm_reset_importance", "cpm_select_recompute", "cpm_select_changed", "cpm_mix_buffers", "cpm_volume_mix", "cpm_comm_get_unique_id",
+    "cpm_comm_create", "cpm_comm_create_all", "cpm_comm_destroy", "cpm_comm_rank", "cpm_comm_size", "cpm_allreduce_grid", "cpm_reduce_grid",
+    "cpm_allreduce_grids"
 ]
+#: ... and include/cpm/cpm_ext.h: what this build adds beyond those call sites
+EXT_SYMBOLS = [
+    "cpm_set_photon_layout", "cpm_get_photon_layout", "cpm_records_describe", "cpm_records_forget", "cpm_trace_lights_order_samples", "cpm_trace_lights",
+    "cpm_trace_emitted", "cpm_trace_order_create", "cpm_trace_order_destroy", "cpm_trace_set_order", "cpm_trace_order_update", "cpm_splat_records",
+    "cpm_mark_touched_bricks", "cpm_gather_bricks", "cpm_fast_table_entries", "cpm_gather_fast_supported", "cpm_gather_fast_supported_on",
+    "cpm_fast_record_capacity", "cpm_bin_fast", "cpm_bin_fast_layout", "cpm_photons_convert", "cpm_gather_fast", "cpm_gather_fast_marked",
+    "cpm_volume_step", "cpm_importance_tf_occupancy", "cpm_selection_create", "cpm_selection_destroy", "cpm_selection_begin",
+    "cpm_photon_importance_select", "cpm_photon_importance_retrace", "cpm_photon_importance_retrace_lights", "cpm_photon_importance_equal_select",
+    "cpm_selection_finish", "cpm_selection_set_occupancy", "cpm_selection_count_device", "cpm_selection_count", "cpm_trace_selected", "cpm_splat_delta",
+    "cpm_pinned_alloc", "cpm_pinned_free", "cpm_volume_stream_create", "cpm_volume_stream_destroy", "cpm_volume_stream_prefetch",
+    "cpm_volume_stream_acquire", "cpm_volume_stream_stats", "cpm_allreduce_grid_bricks", "cpm_brick_mask_or", "cpm_sparse_reduce_create",
+    "cpm_sparse_reduce_destroy", "cpm_sparse_reduce_bricks", "cpm_sparse_reduce_capacity_for", "cpm_allreduce_grid_sparse", "cpm_sparse_reduce_complete",
+    "cpm_bricklist_reduce_create", "cpm_bricklist_reduce_destroy", "cpm_bricklist_reduce_bricks", "cpm_bricklist_capacity_for",
+    "cpm_bricklist_segment_bytes", "cpm_reduce_grid_bricklists", "cpm_bricklist_reduce_complete", "cpm_bricklist_reduce_open", "cpm_bricklist_pack_grid",
+    "cpm_bricklist_reduce_exchange", "cpm_gather_fast_segment", "cpm_bricklist_segment_to_grid", "cpm_comm_send", "cpm_comm_recv",
+    "cpm_light_volume_texels", "cpm_gl_available", "cpm_gl_register_buffer", "cpm_gl_acquire", "cpm_gl_release", "cpm_gl_buffer_pointer",
+    "cpm_gl_copy_to_buffer", "cpm_gl_unregister"
+]
+ABI_SYMBOLS = CORE_SYMBOLS + EXT_SYMBOLS
 CPM_GL_TEXEL_F32, CPM_GL_TEXEL_F16 = 0, 1
 
 
@@ -258,6 +255,8 @@ def load_library() -> C.CDLL:
         "cpm_bin_fast_layout": (i32, [vp, vp, i32, i32, P(GridDesc), f32, vp, vp, vp]),
         "cpm_photons_convert": (i32, [vp, vp, i32, vp, i32, C.c_size_t, vp]),
         "cpm_set_photon_layout": (i32, [vp, i32]),
+        "cpm_records_describe": (i32, [vp, vp, i32, C.c_size_t]),
+        "cpm_records_forget": (i32, [vp, vp]),
         "cpm_get_photon_layout": (i32, [vp]),
         "cpm_splat_records": (i32, [vp, vp, i32, i32, P(GridDesc), f32, f32, vp, vp]),
         "cpm_gather_fast": (i32, [vp, vp, vp, i32, P(GridDesc), f32, f32, i32, vp, vp]),
@@ -639,6 +638,14 @@ class Context:
 
     def photon_layout(self):
         return int(self.lib.cpm_get_photon_layout(self.h))
+
+    def records_describe(self, photons, layout, n_records=None):
+        """This buffer holds n_records (default: its rows) records in `layout`, whatever the context's default (cpm_records_describe)."""
+        n = int(photons.shape[0] if n_records is None else n_records)
+        self._check(self.lib.cpm_records_describe(self.h, self._ptr(photons), int(layout), n))
+
+    def records_forget(self, photons):
+        self._check(self.lib.cpm_records_forget(self.h, self._ptr(photons)))
 
     def splat_records(self, photons, n_records, total_photons, grid: GridDesc, radius, scale, out):
         self._check(self.lib.cpm_splat_records(self.h, self._ptr(photons), n_records, total_photons, C.byref(grid), radius, scale,

@@ -26,7 +26,7 @@ def hipcc() -> str:
 def build_library(force: bool = False, verbose: bool = True) -> Path:
     out = PKG_DIR / "libcpm_hip.so"
     srcs = [PKG_DIR / "csrc" / s for s in SOURCES]
-    deps = srcs + list((PKG_DIR / "csrc").glob("*.h")) + [REPO / "include" / "cpm" / "cpm.h"]
+    deps = srcs + list((PKG_DIR / "csrc").glob("*.h")) + list((REPO / "include" / "cpm").glob("*.h"))
     if not force and out.exists() and all(out.stat().st_mtime >= d.stat().st_mtime for d in deps):
         return out
     cmd = [hipcc(), *FLAGS, "-I", str(REPO / "include"), "-I", str(PKG_DIR / "csrc"), "-o", str(out), *map(str, srcs)]
@@ -62,7 +62,7 @@ def build_host_library(force: bool = False, verbose: bool = True, extras: bool =
     -DCPM_HOST_EXTRAS) -> libcpm_host_extras.so; the default library does not carry them."""
     out = PKG_DIR / ("libcpm_host_extras.so" if extras else "libcpm_host.so")
     srcs = [PKG_DIR / "host" / s for s in HOST_SOURCES]
-    deps = srcs + list((PKG_DIR / "host").glob("*.h")) + [REPO / "include" / "cpm" / "cpm.h", PKG_DIR / "libcpm_hip.so"]
+    deps = srcs + list((PKG_DIR / "host").glob("*.h")) + list((REPO / "include" / "cpm").glob("*.h")) + [PKG_DIR / "libcpm_hip.so"]
     if not force and out.exists() and all(out.stat().st_mtime >= d.stat().st_mtime for d in deps):
         return out
     cmd = [hipcc(), "-x", "c++", "-O2", "-ffp-contract=off", "-std=c++17", "-fPIC", "-shared", "-Wall", "-D__HIP_PLATFORM_AMD__", *(["-DCPM_HOST_EXTRAS"] if extras else []),

@@ -132,6 +132,22 @@ int cpm_set_photon_layout(cpm_ctx* ctx, int layout) {
     return CPM_OK;
 }
 int cpm_get_photon_layout(const cpm_ctx* ctx) { return ctx ? ctx->photon_layout : CPM_PHOTONS_INTERLEAVED; }
+int cpm_records_describe(cpm_ctx* ctx, const float* base, int layout, size_t n_records) {
+    if (!ctx) return CPM_ERR_INVALID_ARGUMENT;
+    if (!base || (layout != CPM_PHOTONS_INTERLEAVED && layout != CPM_PHOTONS_PLANAR) || n_records >= (1ull << 31))
+        return cpm::set_error(ctx, CPM_ERR_INVALID_ARGUMENT, "cpm_records_describe", "null buffer, unknown layout or more than 2^31 records");
+    for (auto& b : ctx->record_buffers)
+        if (b.base == base) { b.layout = layout; b.n_records = n_records; return CPM_OK; }
+    if (ctx->record_buffers.size() >= 16) return cpm::set_error(ctx, CPM_ERR_INVALID_ARGUMENT, "cpm_records_describe", "16 buffers described already (cpm_records_forget)");
+    ctx->record_buffers.push_back({ base, layout, n_records });
+    return CPM_OK;
+}
+int cpm_records_forget(cpm_ctx* ctx, const float* base) {
+    if (!ctx) return CPM_ERR_INVALID_ARGUMENT;
+    for (size_t i = 0; i < ctx->record_buffers.size(); ++i)
+        if (ctx->record_buffers[i].base == base) { ctx->record_buffers.erase(ctx->record_buffers.begin() + (long)i); return CPM_OK; }
+    return CPM_OK;
+}
 void cpm_profile_reset(cpm_ctx* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);  // one host thread may drive several contexts / GPUs

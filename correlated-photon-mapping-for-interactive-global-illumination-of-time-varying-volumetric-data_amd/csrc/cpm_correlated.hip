@@ -970,7 +970,7 @@ int cpm_photon_importance(cpm_ctx* ctx, const float* importance_grid, const int3
     CPM_REQUIRE_ALIGNED16(ctx, light_samples8, "cpm_photon_importance");
     ImpGrid G;
     G.grid = importance_grid;
-    G.rec = rec_layout(ctx, (size_t)total_photons * (size_t)max_interactions);
+    G.rec = rec_layout(ctx, photons8, (size_t)total_photons * (size_t)max_interactions);
     for (int a = 0; a < 3; ++a) {
         CPM_REQUIRE(ctx, grid_dims[a] >= 1 && cell_size[a] > 0.f, "cpm_photon_importance: grid dims / cell size");
         G.dims[a] = grid_dims[a];
@@ -1227,7 +1227,7 @@ int cpm_photon_importance_select(cpm_ctx* ctx, cpm_selection* s, const float* im
     CPM_REQUIRE_ALIGNED16(ctx, light_samples8, "cpm_photon_importance_select");
     ImpGrid G;
     G.grid = importance_grid;
-    G.rec = rec_layout(ctx, (size_t)total_photons * (size_t)max_interactions);
+    G.rec = rec_layout(ctx, photons8, (size_t)total_photons * (size_t)max_interactions);
     unsigned long long cells = 1;
     for (int a = 0; a < 3; ++a) {
         CPM_REQUIRE(ctx, grid_dims[a] >= 1 && cell_size[a] > 0.f, "cpm_photon_importance_select: grid dims / cell size");
@@ -1290,8 +1290,8 @@ int retrace_impl(cpm_ctx* ctx, cpm_selection* s, const float* importance_grid, c
     int rc = cpm::make_trace_args(ctx, vol, tf, tf_scattering, aabb, &p, A, lut_bytes);
     if (rc) return rc;
     CPM_REQUIRE(ctx, !(p.flags & CPM_TRACE_PROGRESSIVE), "cpm_photon_importance_retrace: a correlated re-trace does not write the RNG state back");
-    CPM_REQUIRE(ctx, !(p.flags & CPM_TRACE_PHOTONS_PLANAR) || ctx->photon_layout == CPM_PHOTONS_PLANAR,
-                "cpm_photon_importance_retrace: the importance pass reads the records in the context's layout (cpm_set_photon_layout), not a call's");
+    CPM_REQUIRE(ctx, !(p.flags & CPM_TRACE_PHOTONS_PLANAR) || rec_layout(ctx, photons8, 1).stride == 1u,
+                "cpm_photon_importance_retrace: the importance pass reads the records as the buffer was described (cpm_records_describe) or in the context's layout, not in a call's");
     if (n_all == 0) return CPM_OK;
     CPM_REQUIRE(ctx, importance_grid && photons8 && importances && rng_state && old_photons8, "cpm_photon_importance_retrace: null buffer");
     CPM_REQUIRE_ALIGNED16(ctx, photons8, "cpm_photon_importance_retrace");
@@ -1320,7 +1320,7 @@ int retrace_impl(cpm_ctx* ctx, cpm_selection* s, const float* importance_grid, c
     }
     ImpGrid G;
     G.grid = importance_grid;
-    G.rec = rec_layout(ctx, (size_t)p.total_photons * (size_t)p.max_interactions);
+    G.rec = rec_layout(ctx, photons8, (size_t)p.total_photons * (size_t)p.max_interactions);
     unsigned long long cells = 1;
     for (int a = 0; a < 3; ++a) {
         CPM_REQUIRE(ctx, grid_dims[a] >= 1 && cell_size[a] > 0.f, "cpm_photon_importance_retrace: grid dims / cell size");

@@ -9,7 +9,7 @@
 #include <string>
 #include <vector>
 
-#include "cpm/cpm.h"
+#include "cpm/cpm_ext.h"
 #include "cpm_math.hip.h"
 
 struct cpm_prof_record { const char* name; hipEvent_t a, b; };
@@ -53,8 +53,11 @@ struct cpm_ctx {
     int fast_hist_parity = 0;    // which of the two (histogram, cursors) pairs the next cpm_bin_fast uses
     const void* fast_last_table = nullptr;  // the last cpm_bin_fast's table and radius: cpm_gather_fast refuses another radius for it
     float fast_last_radius = 0.f;
-    // cpm_set_photon_layout: how the photon-record buffers of N * I records handed to this context are laid out (CPM_PHOTONS_*)
+    // cpm_set_photon_layout: how the photon-record buffers of N * I records handed to this context are laid out (CPM_PHOTONS_*) ...
     int photon_layout = 0;
+    // ... unless the buffer has been described itself (cpm_records_describe): base -> layout and its N * I
+    struct RecordBuffer { const void* base; int layout; size_t n_records; };
+    std::vector<RecordBuffer> record_buffers;
     // cpm_tf_update from host memory: the LUT goes through a ring of pinned host slots the upload kernel reads directly --
     // no staged copy ahead of the kernel, no wait for it behind (a slot is reused only after the launch that read it)
     static constexpr int kTfStageSlots = 4;
@@ -169,6 +172,19 @@ inline RecLayout rec_interleaved() { return RecLayout{ 2u, 1u }; }
 // ... of a buffer of n_records records in the context's layout (cpm_set_photon_layout)
 inline RecLayout rec_layout(const cpm_ctx* ctx, size_t n_records) {
     return ctx->photon_layout == 1 /* CPM_PHOTONS_PLANAR */ ? RecLayout{ 1u, (uint32_t)n_records } : rec_interleaved();
+}
+// ... of the buffer starting at `base`: as it was described (cpm_records_describe: its own N * I is the distance between the planes), else the
+// context's layout with the call's count
+inline RecLayout rec_layout(const cpm_ctx* ctx, const void* base, size_t n_records) {
+    for (const auto& b : ctx->record_buffers)
+        if (b.base == base) return b.layout == 1 ? RecLayout{ 1u, (uint32_t)b.n_records } : rec_interleaved();
+    return rec_layout(ctx, n_records);
+}
+// the described layout of `base` (CPM_PHOTONS_*), or -1 when the buffer was not described
+inline int described_layout(const cpm_ctx* ctx, const void* base, size_t* n_records) {
+    for (const auto& b : ctx->record_buffers)
+        if (b.base == base) { if (n_records) *n_records = b.n_records; return b.layout; }
+    return -1;
 }
 __host__ __device__ inline const float4* rec_at(const float* base, RecLayout R, size_t j) { return reinterpret_cast<const float4*>(base) + (size_t)R.stride * j; }
 __host__ __device__ inline float4* rec_at(float* base, RecLayout R, size_t j) { return reinterpret_cast<float4*>(base) + (size_t)R.stride * j; }

@@ -1032,7 +1032,8 @@ size_t cpm_fast_record_capacity(const cpm_grid_desc* grid, int n, float radius) 
 int cpm_bin_fast(cpm_ctx* ctx, const float* photons8, int n, const cpm_grid_desc* grid, float radius, uint32_t* brick_table,
                  float* sorted_pos_power, cpm_stream stream) {
     if (!ctx) return CPM_ERR_INVALID_ARGUMENT;
-    return cpm_bin_fast_layout(ctx, photons8, ctx->photon_layout, n, grid, radius, brick_table, sorted_pos_power, stream);
+    const int described = described_layout(ctx, photons8, nullptr);   // (cpm_records_describe wins over the context's default)
+    return cpm_bin_fast_layout(ctx, photons8, described >= 0 ? described : ctx->photon_layout, n, grid, radius, brick_table, sorted_pos_power, stream);
 }
 
 int cpm_bin_fast_layout(cpm_ctx* ctx, const float* photons8, int layout, int n, const cpm_grid_desc* grid, float radius, uint32_t* brick_table,
@@ -1040,7 +1041,12 @@ int cpm_bin_fast_layout(cpm_ctx* ctx, const float* photons8, int layout, int n, 
     CPM_ENTER(ctx);
     CPM_REQUIRE(ctx, layout == CPM_PHOTONS_INTERLEAVED || layout == CPM_PHOTONS_PLANAR, "cpm_bin_fast: photon layout");
     // half A of record j at float4 j * rs, half B rb behind it (the tracer's rec_stride / rec_b: n here is its N * I)
-    const uint32_t rs = layout == CPM_PHOTONS_PLANAR ? 1u : 2u, rb = layout == CPM_PHOTONS_PLANAR ? (uint32_t)(n > 0 ? n : 0) : 1u;
+    // (a described buffer's planes lie its own N * I apart whatever `n` this call bins: cpm_records_describe)
+    size_t described_n = 0;
+    const bool described_planar = described_layout(ctx, photons8, &described_n) == CPM_PHOTONS_PLANAR;
+    CPM_REQUIRE(ctx, !(layout == CPM_PHOTONS_PLANAR && described_planar) || (size_t)(n > 0 ? n : 0) <= described_n, "cpm_bin_fast: more records than the buffer was described with");
+    const uint32_t rs = layout == CPM_PHOTONS_PLANAR ? 1u : 2u,
+                   rb = layout == CPM_PHOTONS_PLANAR ? (described_planar ? (uint32_t)described_n : (uint32_t)(n > 0 ? n : 0)) : 1u;
     GridDev G;
     int rc = make_grid_dev_fast(ctx, grid, G);
     if (rc) return rc;

@@ -1167,7 +1167,7 @@ int cpm_splat_records(cpm_ctx* ctx, const float* photons8, int n_records, int to
     CPM_REQUIRE(ctx, photons8 && grid_out, "cpm_splat: null buffer");
     CPM_REQUIRE_ALIGNED16(ctx, photons8, "cpm_splat");
     float k = kInv4Pi * scale;
-    CPM_LAUNCH(ctx, splat_kernel, dim3(div_up(total_photons, 256)), dim3(256), 0, (hipStream_t)stream, photons8, rec_layout(ctx, (size_t)n_records),
+    CPM_LAUNCH(ctx, splat_kernel, dim3(div_up(total_photons, 256)), dim3(256), 0, (hipStream_t)stream, photons8, rec_layout(ctx, photons8, (size_t)n_records),
                        total_photons, G, radius, k, grid_out);
     CPM_LAUNCH_CHECK(ctx, "splat_kernel");
     return CPM_OK;
@@ -1186,7 +1186,7 @@ int cpm_splat_selected(cpm_ctx* ctx, const float* photons8, const uint32_t* indi
     CPM_REQUIRE_ALIGNED16(ctx, photons8, "cpm_splat_selected");
     float k = kInv4Pi * scale;
     CPM_LAUNCH(ctx, splat_selected_kernel, dim3(div_up(n_indices, 256)), dim3(256), 0, (hipStream_t)stream, photons8,
-                       rec_layout(ctx, (size_t)n_photons * n_interactions), indices, n_indices, G, radius, k, multiplier, n_photons, n_interactions, grid_out);
+                       rec_layout(ctx, photons8, (size_t)n_photons * n_interactions), indices, n_indices, G, radius, k, multiplier, n_photons, n_interactions, grid_out);
     CPM_LAUNCH_CHECK(ctx, "splat_selected_kernel");
     return CPM_OK;
 }
@@ -1209,7 +1209,7 @@ int cpm_splat_delta(cpm_ctx* ctx, const float* old_photons8, int old_stride, con
     // a box more than 4 rows high: its rows in 4 groups (a lane's chain of dependent splat steps is what the launch lasts)
     const int yparts = 2.f * radius * G.t2i.sy + 1.f > 4.f ? 4 : 1;
     const long long wgs = div_up(6ll * yparts * max_indices, 256);
-    const RecLayout R = rec_layout(ctx, (size_t)n_photons * n_interactions);
+    const RecLayout R = rec_layout(ctx, photons8, (size_t)n_photons * n_interactions);
     CPM_LAUNCH(ctx, splat_delta_kernel, dim3((unsigned)(wgs < 2048 ? wgs : 2048)), dim3(256), 0, (hipStream_t)stream, old_photons8,
                (uint32_t)old_stride, old_stride ? rec_interleaved() : R, photons8, R, indices, n_indices_dev, max_indices, apply_below, G, radius, k, n_photons, n_interactions,
                div_up(G.dx, 4), div_up(G.dy, 4), brick_mask, grid_out, yparts);
@@ -1227,7 +1227,7 @@ int cpm_copy_indexed_photons(cpm_ctx* ctx, const float* photons8, const uint32_t
     CPM_REQUIRE_ALIGNED16(ctx, photons8, "cpm_copy_indexed_photons");
     CPM_REQUIRE_ALIGNED16(ctx, aligned8, "cpm_copy_indexed_photons");
     CPM_LAUNCH(ctx, copy_indexed_kernel, dim3(div_up(n_indices, 256)), dim3(256), 0, (hipStream_t)stream, photons8,
-                       rec_layout(ctx, (size_t)n_photons * n_interactions), indices, n_indices, multiplier, n_photons, n_interactions, aligned8, out_offset);
+                       rec_layout(ctx, photons8, (size_t)n_photons * n_interactions), indices, n_indices, multiplier, n_photons, n_interactions, aligned8, out_offset);
     CPM_LAUNCH_CHECK(ctx, "copy_indexed_kernel");
     return CPM_OK;
 }
@@ -1243,7 +1243,7 @@ int cpm_snapshot_selected_photons(cpm_ctx* ctx, const float* photons8, const uin
     CPM_REQUIRE_ALIGNED16(ctx, snapshot8, "cpm_snapshot_selected_photons");
     const int threads = n_indices * n_interactions;
     CPM_LAUNCH(ctx, snapshot_selected_kernel, dim3((unsigned)div_up(threads, 256)), dim3(256), 0, (hipStream_t)stream, photons8,
-               rec_layout(ctx, (size_t)n_photons * n_interactions), indices,
+               rec_layout(ctx, photons8, (size_t)n_photons * n_interactions), indices,
                n_indices, n_photons, n_interactions, snapshot8);
     CPM_LAUNCH_CHECK(ctx, "snapshot_selected_kernel");
     return CPM_OK;
@@ -1274,15 +1274,15 @@ int cpm_bin(cpm_ctx* ctx, const float* photons8, int n, const cpm_grid_desc* gri
         uint32_t* hist = ctx->dbg.bin_fused ? cpm::sort_first_hist(ctx, (size_t)n, kb, &num_tiles) : nullptr;
         const dim3 kgrid((unsigned)div_up(n, 256 * items));
         switch (items) {
-            case 4: CPM_LAUNCH(ctx, bin_keys_kernel<4>, kgrid, dim3(256), 0, s, photons8, rec_layout(ctx, (size_t)n), n, G, cells, keys, vals, cell_start, hist, num_tiles); break;
-            case 8: CPM_LAUNCH(ctx, bin_keys_kernel<8>, kgrid, dim3(256), 0, s, photons8, rec_layout(ctx, (size_t)n), n, G, cells, keys, vals, cell_start, hist, num_tiles); break;
-            default: CPM_LAUNCH(ctx, bin_keys_kernel<16>, kgrid, dim3(256), 0, s, photons8, rec_layout(ctx, (size_t)n), n, G, cells, keys, vals, cell_start, hist, num_tiles); break;
+            case 4: CPM_LAUNCH(ctx, bin_keys_kernel<4>, kgrid, dim3(256), 0, s, photons8, rec_layout(ctx, photons8, (size_t)n), n, G, cells, keys, vals, cell_start, hist, num_tiles); break;
+            case 8: CPM_LAUNCH(ctx, bin_keys_kernel<8>, kgrid, dim3(256), 0, s, photons8, rec_layout(ctx, photons8, (size_t)n), n, G, cells, keys, vals, cell_start, hist, num_tiles); break;
+            default: CPM_LAUNCH(ctx, bin_keys_kernel<16>, kgrid, dim3(256), 0, s, photons8, rec_layout(ctx, photons8, (size_t)n), n, G, cells, keys, vals, cell_start, hist, num_tiles); break;
         }
         CPM_LAUNCH_CHECK(ctx, "bin_keys_kernel");
         // no copy-back after an odd number of passes: the cell-start kernel reads the keys wherever the
         // ping-pong left them; the last scatter pass writes order / records / run starts itself (BinSink)
         BinSink sink;
-        sink.photons = photons8; sink.rec = rec_layout(ctx, (size_t)n); sink.channels = G.channels; sink.order = order; sink.sorted = sorted_pos_power;
+        sink.photons = photons8; sink.rec = rec_layout(ctx, photons8, (size_t)n); sink.channels = G.channels; sink.order = order; sink.sorted = sorted_pos_power;
         sink.cell_start = cell_start;
         rc = cpm::radix_sort(ctx, keys, vals, (size_t)n, kb, s, &keys, &vals, ctx->dbg.bin_fused ? &sink : nullptr, &finalized, hist != nullptr);
         if (rc) return rc;
@@ -1290,7 +1290,7 @@ int cpm_bin(cpm_ctx* ctx, const float* photons8, int n, const cpm_grid_desc* gri
     // run starts -> table (preset to "none" by bin_keys_kernel), then the suffix-min scan turns it into cell starts
     if (n == 0) CPM_HIP_CHECK(ctx, hipMemsetAsync(cell_start, 0xff, ((size_t)cells + 1) * sizeof(uint32_t), s));
     if (n > 0 && !finalized) {  // n == 1, the onesweep test mode, or cpm_debug_set_bin_fused(0)
-        CPM_LAUNCH(ctx, bin_finalize_kernel, dim3(div_up(n, 256)), dim3(256), 0, s, photons8, rec_layout(ctx, (size_t)n), keys, vals, n, G.channels,
+        CPM_LAUNCH(ctx, bin_finalize_kernel, dim3(div_up(n, 256)), dim3(256), 0, s, photons8, rec_layout(ctx, photons8, (size_t)n), keys, vals, n, G.channels,
                            order, sorted_pos_power, cell_start);
         CPM_LAUNCH_CHECK(ctx, "bin_finalize_kernel");
     }
@@ -1331,7 +1331,7 @@ int cpm_mark_touched_bricks(cpm_ctx* ctx, const float* photons8, const uint32_t*
     const int bxn = div_up(G.dx, 4), byn = div_up(G.dy, 4);
     const long long threads = (long long)n_indices * n_interactions;
     CPM_LAUNCH(ctx, mark_bricks_kernel, dim3((unsigned)div_up(threads, 256)), dim3(256), 0, (hipStream_t)stream, photons8,
-               rec_layout(ctx, (size_t)n_photons * n_interactions), indices,
+               rec_layout(ctx, photons8, (size_t)n_photons * n_interactions), indices,
                n_indices, n_photons, n_interactions, G, radius, bxn, byn, brick_mask);
     CPM_LAUNCH_CHECK(ctx, "mark_bricks_kernel");
     return CPM_OK;

@@ -334,9 +334,12 @@ int trace_impl(cpm_ctx* ctx, const cpm_volume* vol, const cpm_tf* tf, const cpm_
     if (sel.old_photons) CPM_REQUIRE_ALIGNED16(ctx, sel.old_photons, "cpm_trace_selected");
     A.rng = rng_state;
     A.photons = photons8;
-    const bool planar = (p.flags & CPM_TRACE_PHOTONS_PLANAR) != 0 || ctx->photon_layout == CPM_PHOTONS_PLANAR;
+    // the call's flag, else how the buffer was described (cpm_records_describe: its own N * I is the distance between the planes), else the context's
+    size_t described_n = 0;
+    const int described = described_layout(ctx, photons8, &described_n);
+    const bool planar = (p.flags & CPM_TRACE_PHOTONS_PLANAR) != 0 || (described >= 0 ? described == CPM_PHOTONS_PLANAR : ctx->photon_layout == CPM_PHOTONS_PLANAR);
     A.rec_stride = planar ? 1u : 2u;
-    A.rec_b = planar ? (uint32_t)((long long)p.total_photons * p.max_interactions) : 1u;
+    A.rec_b = planar ? (described == CPM_PHOTONS_PLANAR ? (uint32_t)described_n : (uint32_t)((long long)p.total_photons * p.max_interactions)) : 1u;
     if (sel.lights) {
         A.n_spans = sel.n_lights;
         int base = 0;

@@ -9,7 +9,7 @@
 #include <tuple>
 #include <vector>
 
-#include "cpm/cpm.h"
+#include "cpm/cpm_ext.h"
 #include "inviwo_lite.h"
 
 namespace inviwo {

@@ -115,9 +115,10 @@ class PhotonFrame:
                  radiance=(1.0, 1.0, 1.0), radius_voxels: float = 1.0, max_interactions: int = 1,
                  channels: int = 1, photon_range=None, point_light_position=None, seed: int = 0,
                  shading_type: int = B.CPM_PHASE_HENYEY_GREENSTEIN, material=(0.0, 0.0, 0.0, 0.0), light_plane=None,
-                 mesh_intersection=None, emit_in_tracer: bool = False, photon_indices=None):
+                 mesh_intersection=None, emit_in_tracer: bool = False, photon_indices=None, records_layout=None):
         torch = ctx.torch
         self.ctx = ctx
+        self.records_layout = records_layout
         self.torch = torch
         dev = ctx.device
         self._vol_is_own = not isinstance(volume, B.Volume)   # created here (set_volume may recycle it) or the caller's
@@ -219,6 +220,30 @@ class PhotonFrame:
         self.sorted_fast = None
         self.photon_layout = ctx.photon_layout()   # how self.photons is laid out: the context's layout (cpm_set_photon_layout), or set_planar_records
         self._records8 = None
+        # records_layout="planar": THIS frame's record buffers are two planes whatever the context's default -- described to the library
+        # buffer by buffer (cpm_records_describe), not through a context-wide mode
+        self._described = []
+        if records_layout == "planar":
+            self.photon_layout = B.CPM_PHOTONS_PLANAR
+            self._describe(self.photons)
+        elif records_layout not in (None, "context"):
+            raise ValueError("records_layout: None (the context's) or 'planar'")
+
+    def _describe(self, buf, replaces=None):
+        """buf holds this frame's N * I records in the frame's layout: say so to the library when the layout is this frame's own
+        (replaces: the buffer it takes the place of, whose description goes)."""
+        if getattr(self, "records_layout", None) == "planar":
+            if replaces is not None:
+                self.ctx.records_forget(replaces)
+                self._described = [b for b in self._described if b is not replaces]
+            self.ctx.records_describe(buf, B.CPM_PHOTONS_PLANAR, self.n * self.I)
+            self._described.append(buf)
+        return buf
+
+    def forget_described(self):
+        for b in self._described:
+            self.ctx.records_forget(b)
+        self._described = []
 
     def set_planar_records(self, on=True):
         """The tracer writes -- and the brick bin reads -- the two-plane record layout (CPM_TRACE_PHOTONS_PLANAR / cpm_bin_fast_layout):
@@ -467,7 +492,7 @@ class CorrelatedPhotonMapper(PhotonFrame):
         if self._fused_configured():
             self._prev_stale = True
         else:
-            self.prev_photons = self.photons.clone()
+            self.prev_photons = self._describe(self.photons.clone(), replaces=self.prev_photons)
             self._prev_stale = False
         self.n_recomputed = -1
         self.remaining, self.remaining_offset = 0, 0
@@ -607,7 +632,7 @@ class CorrelatedPhotonMapper(PhotonFrame):
         if self._fused_available():
             return self.correlated_update_fused()
         if getattr(self, "_prev_stale", False) and getattr(self, "have_frame", False):   # the fused path does not maintain the snapshot
-            self.prev_photons = self.photons.clone()
+            self.prev_photons = self._describe(self.photons.clone(), replaces=self.prev_photons)
             self._prev_stale = False
         ctx.photon_importance(self.importance_grid, self.brick_dims, (float(self.region),) * 3,
                               list(self.vol.desc.texture_to_index), self.photons, 0, self.light_samples, self.isect,
@@ -689,6 +714,6 @@ class CorrelatedPhotonMapper(PhotonFrame):
         # snapshot for the next add-remove (a whole-buffer copy in the reference, :343-352): after a partial re-trace
         # only the re-traced photons differ from the snapshot, so only they move
         if self.last_path == "full" or self.prev_photons is None:
-            self.prev_photons = self.photons.clone()
+            self.prev_photons = self._describe(self.photons.clone(), replaces=self.prev_photons)
         else:
             ctx.snapshot_selected_photons(self.photons, idx, n, self.n, self.I, self.prev_photons)

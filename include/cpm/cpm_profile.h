@@ -9,7 +9,7 @@
  */
 #ifndef CPM_CPM_PROFILE_H
 #define CPM_CPM_PROFILE_H
-#include "cpm/cpm.h"
+#include "cpm/cpm_ext.h"
 #ifdef __cplusplus
 extern "C" {
 #endif

@@ -1,6 +1,7 @@
-"""cpm_set_photon_layout: a context whose N * I record buffers are two planes gives the same bits as one with float8 records -- every
-entry point that reads or writes such a buffer, driven directly and through the pipeline's correlated mapper (full frame, TF edit,
-the three forms of the update)."""
+"""Photon records in two planes give the same bits as float8 records -- every entry point that reads or writes an N * I record buffer,
+driven directly and through the pipeline's correlated mapper (full frame, TF edit, the three forms of the update) -- in both ways of
+saying so: PER BUFFER (cpm_records_describe: the buffer's layout and its own N * I, on a context whose default stays float8; no
+context-wide mode anywhere) and as a context's default (cpm_set_photon_layout, the convenience a described buffer overrides)."""
 import numpy as np
 import pytest
 
@@ -65,8 +66,10 @@ def test_record_readers_agree_between_layouts(ctx, planar_ctx, cpm, channels):
     radius = float(np.float32(1.4) / np.float32(max(dims)))
     scale = float(B.relative_irradiance_scale(radius, float(n)))
     res = {}
-    for name, c, buf in (("float8", ctx, ph), ("planes", planar_ctx, to_planes(ph))):
+    for name, c, buf in (("float8", ctx, ph), ("planes", planar_ctx, to_planes(ph)), ("described", ctx, to_planes(ph))):
         d_ph, d_idx = _t(c, buf), _t(c, idx)
+        if name == "described":       # the default context, the buffer itself described as two planes of n * inter records
+            c.records_describe(d_ph, B.CPM_PHOTONS_PLANAR, n * inter)
         r = {}
         out = torch.zeros(cells * channels, dtype=torch.float32, device=c.device)
         c.splat_records(d_ph, n * inter, n, grid, radius, scale, out)
@@ -78,7 +81,7 @@ def test_record_readers_agree_between_layouts(ctx, planar_ctx, cpm, channels):
         c.copy_indexed_photons(d_ph, d_idx, idx.size, 0.5, n, inter, aligned, out_offset=3)
         r["aligned"] = _n(aligned)                                   # compact copies keep the float8 record in either context
         snap = torch.full((n * inter, 8), 5.0, dtype=torch.float32, device=c.device)
-        c.snapshot_selected_photons(d_ph, d_idx, idx.size, n, inter, snap)
+        c.snapshot_selected_photons(d_ph, d_idx, idx.size, n, inter, snap)     # (the snapshot is laid out like the buffer it is taken from)
         r["snapshot"] = _n(snap) if name == "float8" else from_planes(_n(snap))
         mask = torch.zeros(((dims[0] + 3) // 4) * ((dims[1] + 3) // 4) * ((dims[2] + 3) // 4), dtype=torch.uint8, device=c.device)
         c.mark_touched_bricks(d_ph, d_idx, idx.size, n, inter, grid, radius, mask)
@@ -97,17 +100,37 @@ def test_record_readers_agree_between_layouts(ctx, planar_ctx, cpm, channels):
         out = torch.zeros(cells * channels, dtype=torch.float32, device=c.device)
         c.gather_fast(srt2, table, m, grid, radius, scale, out)
         r["gather_fast"] = _n(out)
+        # a call over the FIRST n records of the n * inter in the buffer (interaction 0 alone): a described buffer's plane B stays n * inter
+        # float4 behind plane A; a context's default takes the call's own count for that distance, so only float8 and described can do this
+        if name != "planes":
+            c.bin_fast(d_ph, n, grid, radius, table, srt2)
+            out = torch.zeros(cells * channels, dtype=torch.float32, device=c.device)
+            c.gather_fast(srt2, table, n, grid, radius, scale, out)
+            r["gather_fast_prefix"] = _n(out)
+            c.bin(d_ph, n, grid, order, cell_start, srt)
+            out = torch.zeros(cells * channels, dtype=torch.float32, device=c.device)
+            c.gather(srt, cell_start, n, grid, radius, scale, out)
+            r["gather_prefix"] = _n(out)
+        if name == "described":
+            c.records_forget(d_ph)
+            with pytest.raises(B.CpmError):
+                c.records_describe(d_ph, 9, n * inter)
         res[name] = r
-    a, b = res["float8"], res["planes"]
-    for k in ("aligned", "snapshot", "mask", "order", "cell_start", "sorted", "gather", "gather_fast"):
-        assert np.array_equal(bits(a[k]), bits(b[k])), k
-    for k in ("splat", "splat_selected"):                             # float atomics: the order of the adds is not defined
-        np.testing.assert_allclose(b[k], a[k], rtol=1e-4, atol=1e-6 * float(np.abs(a[k]).max()))
+    a = res["float8"]
+    for b in (res["planes"], res["described"]):
+        for k in ("aligned", "snapshot", "mask", "order", "cell_start", "sorted", "gather", "gather_fast"):
+            assert np.array_equal(bits(a[k]), bits(b[k])), k
+        for k in ("splat", "splat_selected"):                             # float atomics: the order of the adds is not defined
+            np.testing.assert_allclose(b[k], a[k], rtol=1e-4, atol=1e-6 * float(np.abs(a[k]).max()))
+    for k in ("gather_fast_prefix", "gather_prefix"):
+        assert np.array_equal(bits(a[k]), bits(res["described"][k])), k
+    assert channels == 4 or not np.array_equal(bits(a["gather_fast_prefix"]), bits(a["gather_fast"]))   # (the second interaction's records do count)
     assert a["gather"].any() and a["mask"].any() and (a["snapshot"] != 5.0).any()
 
 
+@pytest.mark.parametrize("way", ["buffers", "context"])
 @pytest.mark.parametrize("max_inter,form", [(1, "retrace_in_pass"), (2, "retrace_in_pass"), (1, "select_then_trace"), (2, "legacy")])
-def test_correlated_mapper_in_a_planar_context(ctx, planar_ctx, cpm, max_inter, form):
+def test_correlated_mapper_in_a_planar_context(ctx, planar_ctx, cpm, max_inter, form, way):
     """Full frame, TF edits and updates with the records in two planes: the same records (converted back), index lists and importance
     keys bit for bit, the light volume bit for bit after a full frame and within the splat tolerance after a delta update."""
     S, P = cpm.synthetic, cpm.pipeline
@@ -118,8 +141,9 @@ def test_correlated_mapper_in_a_planar_context(ctx, planar_ctx, cpm, max_inter, 
     kw = dict(light_travel_direction=(0.3, 0.5, -1.0), tf_points=base, max_interactions=max_inter, material=(0.3, 0, 0, 0),
               incremental_threshold_percent=100.0)
     pair = []
-    for c in (ctx, planar_ctx):
-        m = P.CorrelatedPhotonMapper(c, vol_np, S.tf_from_points(base), 160, (32, 32, 32), **kw)
+    for c, how in ((ctx, None), (planar_ctx, None) if way == "context" else (ctx, "planar")):
+        # (way == "buffers": the SAME default context as the float8 mapper; its record buffers are described one by one)
+        m = P.CorrelatedPhotonMapper(c, vol_np, S.tf_from_points(base), 160, (32, 32, 32), records_layout=how, **kw)
         if form == "select_then_trace":
             m.retrace_in_importance_pass = False
         if form == "legacy":
@@ -127,6 +151,7 @@ def test_correlated_mapper_in_a_planar_context(ctx, planar_ctx, cpm, max_inter, 
         pair.append(m)
     a, b = pair
     assert b.photon_layout == cpm.binding.CPM_PHOTONS_PLANAR and a.photon_layout == cpm.binding.CPM_PHOTONS_INTERLEAVED
+    assert way == "context" or b.ctx.photon_layout() == cpm.binding.CPM_PHOTONS_INTERLEAVED
     la, lb = _n(a.full_frame()), _n(b.full_frame())
     assert np.array_equal(bits(la), bits(lb)) and la.any()
     assert np.array_equal(bits(_n(a.photons)), bits(_n(b.records())))
@@ -143,6 +168,7 @@ def test_correlated_mapper_in_a_planar_context(ctx, planar_ctx, cpm, max_inter, 
     # a rebuild after the edits: bit for bit again
     a._full_light_volume(); b._full_light_volume()
     assert np.array_equal(bits(_n(a.light_volume)), bits(_n(b.light_volume)))
+    b.forget_described()
 
 
 def test_call_flag_against_context_layout_is_refused(ctx, cpm):
