@@ -865,6 +865,8 @@ def main():
             walk = [k % n_steps for k in range(1, 6 * n_steps + 1)]
 
             def run_walk(volume_of, before=None):
+                if before is not None:
+                    before(-1)          # (the first step's upload is under way when the clock starts, as every later step's is)
                 torch.cuda.synchronize(); ta = time.perf_counter()
                 for j, t in enumerate(walk):
                     if before is not None:
@@ -881,9 +883,7 @@ def main():
             def ahead(j):   # the step after this one starts crossing PCIe now
                 if j + 1 < len(walk):
                     vstream.prefetch(walk[j + 1], pinned.steps[walk[j + 1]])
-            vstream.prefetch(walk[0], pinned.steps[walk[0]])
             run_walk(lambda j, t: vstream.acquire(t, pinned.steps[t]), ahead)
-            vstream.prefetch(walk[0], pinned.steps[walk[0]])
             streamed_ms = min(run_walk(lambda j, t: vstream.acquire(t, pinned.steps[t]), ahead) for _ in range(3))
             torch.cuda.synchronize()
             si = vstream.stats()
