@@ -208,33 +208,52 @@ def timed(torch, fn, reps, warm=3):
     return (time.perf_counter() - t) / reps * 1e3
 
 
-LAUNCH_BUDGET_S = 240.0   # wall clock one set of ranks gets (of the driver's 600 s): set-up + frames + extras of a default run take < 60 s
+LAUNCH_BUDGET_S = 200.0   # wall clock one set of ranks gets from the moment they are UP (torch imported, process group formed): set-up + frames + extras of a
+                          # default run take < 60 s; what comes before -- the first `import torch` on a fresh box -- can take minutes and is not RCCL's fault
+LAUNCH_TOTAL_S = (400.0, 170.0)   # ... and from their start at most this, first and second set (together inside the driver's 600 s)
+RANKS_UP_MARKER = "bench.py: ranks up"
 
 
-def _run_children(cmd, env, budget_s):
-    """Start `cmd` in its own process group, relay its stderr, collect its stdout; after budget_s seconds kill the group.
-    -> (return code or None when killed, rank 0's JSON line or None, the last lines the children wrote)."""
+def _run_children(cmd, env, budget_s, total_s=None):
+    """Start `cmd` in its own process group, relay its stderr, collect its stdout; kill the group budget_s seconds after the ranks reported
+    that they are up (RANKS_UP_MARKER on stderr) or total_s seconds after the start, whichever comes first.
+    -> (return code or None when killed, rank 0's JSON line or None, the last lines the children wrote, what the clock that ran out was)."""
     import signal
     import subprocess
     import threading
     from collections import deque
+    t0 = time.monotonic()
     proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, start_new_session=True)
-    tail, found = deque(maxlen=60), []
+    tail, found, up_at = deque(maxlen=60), [], []
 
     def pump(stream, is_stdout):
         for line in stream:
             if is_stdout and line.startswith("{") and '"metric"' in line:
                 found.append(line)
             else:
+                if RANKS_UP_MARKER in line and not up_at:
+                    up_at.append(time.monotonic())
                 tail.append(line)
                 sys.stderr.write(line)
     threads = [threading.Thread(target=pump, args=(proc.stdout, True), daemon=True), threading.Thread(target=pump, args=(proc.stderr, False), daemon=True)]
     for t in threads:
         t.start()
-    try:
-        rc = proc.wait(timeout=budget_s)
-    except subprocess.TimeoutExpired:
-        rc = None
+    rc, why = None, None
+    while True:
+        try:
+            rc = proc.wait(timeout=0.25)
+            break
+        except subprocess.TimeoutExpired:
+            now = time.monotonic()
+            if up_at and now - up_at[0] > budget_s:
+                why = f"{budget_s:.0f} s after they were up"
+            elif total_s is not None and now - t0 > total_s:
+                why = f"{total_s:.0f} s after their start" + ("" if up_at else " (they never reported being up)")
+            elif not up_at and total_s is None and now - t0 > budget_s:
+                why = f"{budget_s:.0f} s after their start"
+            if why:
+                break
+    if why:
         # (children of a parent that never touched a GPU; the whole group: the launcher and every rank it started)
         for sig, grace in ((signal.SIGTERM, 10), (signal.SIGKILL, 10)):
             try:
@@ -248,14 +267,15 @@ def _run_children(cmd, env, budget_s):
                 continue
     for t in threads:
         t.join(timeout=5)
-    return rc, (found[-1] if found else None), list(tail)
+    return rc, (found[-1] if found else None), list(tail), why
 
 
 def launch_ranks(n_ranks, argv=None, budget_s=None, make_cmd=None):
     """`python bench.py --gpus N` run plainly (no WORLD_SIZE): start the N ranks -- one process per GPU, torch.distributed.run
     on 127.0.0.1 -- as CHILD processes of this one, which has not touched a GPU and never does; relay rank 0's JSON line and exit
-    with the children's return code.  The run always ends with a line or an error: the ranks get `budget_s` seconds of wall clock
-    (CPM_BENCH_LAUNCH_BUDGET_S; a set-up that hangs inside RCCL never returns by itself); when they overrun it or die without a
+    with the children's return code.  The run always ends with a line or an error: the ranks get `budget_s` seconds of wall clock from the
+    moment they report being up (CPM_BENCH_LAUNCH_BUDGET_S; a set-up that hangs inside RCCL never returns by itself) and LAUNCH_TOTAL_S from
+    their start (importing torch on a fresh box takes minutes: not charged to the first clock); when they overrun either or die without a
     line they are killed and a FRESH set is started ONCE with `--transport torch --exchange union` (torch.distributed's own NCCL
     group, the exchange whose collectives have run before) -- that line says so in config.launcher_note; a second failure exits
     non-zero with the ranks' last lines.  make_cmd (testing): argv -> the command to run instead of torch.distributed.run."""
@@ -276,7 +296,8 @@ def launch_ranks(n_ranks, argv=None, budget_s=None, make_cmd=None):
     for attempt, args in enumerate((argv, argv + ["--transport", "torch", "--exchange", "union"])):
         cmd, env = command(args)
         t0 = time.perf_counter()
-        rc, line, tail = _run_children(cmd, env, budget)
+        total = None if budget_s is not None else (float(os.environ["CPM_BENCH_LAUNCH_TOTAL_S"]) if "CPM_BENCH_LAUNCH_TOTAL_S" in os.environ else LAUNCH_TOTAL_S[attempt])
+        rc, line, tail, expired = _run_children(cmd, env, budget, total)
         took = time.perf_counter() - t0
         if rc == 0 and line:
             if notes:   # the line of the second set of ranks says why it is not the first's
@@ -289,7 +310,7 @@ def launch_ranks(n_ranks, argv=None, budget_s=None, make_cmd=None):
             sys.stdout.write(line)
             sys.stdout.flush()
             return 0
-        why = (f"the ranks did not finish in {budget:.0f} s and were killed" if rc is None else
+        why = (f"the ranks did not finish ({expired}) and were killed" if expired else
                f"the ranks exited with code {rc} after {took:.0f} s" if rc else "the ranks exited cleanly but rank 0 printed no JSON line")
         notes.append(f"attempt {attempt + 1} ({' '.join(args[-4:])}): {why}")
         print(f"bench.py: {notes[-1]}" + ("; starting a fresh set of ranks with --transport torch --exchange union" if attempt == 0 else ""), file=sys.stderr)
@@ -380,6 +401,8 @@ def main():
     if world > 1 or "TORCHELASTIC_RUN_ID" in os.environ:  # launched by torch.distributed.run (also at N = 1)
         import torch.distributed as dist
         dist.init_process_group("gloo")
+        if rank == 0:
+            print(f"{RANKS_UP_MARKER} ({world})", file=sys.stderr, flush=True)   # (launch_ranks starts its set-up clock here)
 
     vdim, (nx, ny), gdim, default_scaling = WORKLOADS[args.workload]
     scaling = args.scaling or default_scaling

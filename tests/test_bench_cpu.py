@@ -72,8 +72,44 @@ def test_a_set_up_that_hangs_is_killed_and_replaced_once(tmp_path):
     assert len(lines) == 1                                     # the JSON line alone on stdout (the chatter went to stderr)
     d = json.loads(lines[0])
     assert d["config"]["transport"] == "TorchTransport"
-    assert "did not finish in 3 s and were killed" in d["config"]["launcher_note"] and "--transport torch --exchange union" in d["config"]["launcher_note"]
+    assert "did not finish (3 s after their start) and were killed" in d["config"]["launcher_note"] and "--transport torch --exchange union" in d["config"]["launcher_note"]
     assert "fake child hang_then_ok first" in err and "fake child hang_then_ok second" in err
+
+
+def test_the_set_up_clock_starts_when_the_ranks_are_up(tmp_path):
+    """Importing torch on a fresh box takes minutes and is nobody's hang: the budget runs from the ranks' "up" line, a separate (longer) clock from
+    their start.  A child that is slow to come up and then quick is left alone; one that comes up and then hangs is killed `budget` later."""
+    import importlib
+    import io
+    import contextlib
+    import time
+    sys.path.insert(0, str(REPO))
+    bench = importlib.import_module("bench")
+    child = tmp_path / "slow_child.py"
+    child.write_text(r"""
+import json, sys, time
+mode = sys.argv[1]
+second = "--transport" in sys.argv
+time.sleep(3.0)                                         # "importing torch"
+print("bench.py: ranks up (2)", file=sys.stderr, flush=True)
+if mode == "up_then_hang" and not second:
+    time.sleep(600)
+print(json.dumps({"metric": "Mphotons/s traced+binned+gathered", "value": 1.0, "config": {"second": second}}), flush=True)
+""")
+    for mode, second in (("up_then_quick", False), ("up_then_hang", True)):
+        out, err = io.StringIO(), io.StringIO()
+        os.environ["CPM_BENCH_LAUNCH_BUDGET_S"], os.environ["CPM_BENCH_LAUNCH_TOTAL_S"] = "2", "60"
+        try:
+            t0 = time.time()
+            with contextlib.redirect_stdout(out), contextlib.redirect_stderr(err):
+                rc = bench.launch_ranks(2, argv=["--gpus", "2"], make_cmd=lambda args: [sys.executable, str(child), mode] + args)
+        finally:
+            del os.environ["CPM_BENCH_LAUNCH_BUDGET_S"], os.environ["CPM_BENCH_LAUNCH_TOTAL_S"]
+        import json
+        d = json.loads(out.getvalue().strip())
+        assert rc == 0 and d["config"]["second"] is second, (mode, err.getvalue())
+        if second:
+            assert "2 s after they were up" in d["config"]["launcher_note"] and time.time() - t0 < 40
 
 
 def test_ranks_that_die_are_replaced_once(tmp_path):
@@ -87,7 +123,7 @@ def test_ranks_that_die_are_replaced_once(tmp_path):
 def test_a_second_failure_ends_the_run_with_the_ranks_last_lines(tmp_path):
     rc, out, err = _launch(tmp_path, "hang_always", 2.0)
     assert rc == 1 and out.strip() == ""
-    assert err.count("did not finish in 2 s and were killed") >= 2 and "no JSON line from either set of ranks" in err
+    assert err.count("did not finish (2 s after their start) and were killed") >= 2 and "no JSON line from either set of ranks" in err
     rc, out, err = _launch(tmp_path, "silent", 30.0)
     assert rc == 1 and "printed no JSON line" in err
 
