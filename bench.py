@@ -688,6 +688,10 @@ def main():
             dt = float(t.item())
         batch_elapsed.append(dt)
     elapsed = sorted(batch_elapsed)[len(batch_elapsed) // 2]
+    # (N > 1: the last timed frame's sum, as the exchange left it at the display GPU -- held against an independent dense sum below)
+    final_sum = None
+    if world > 1 and not correlated and rank == (0 if root is None else root):
+        final_sum = reducer.result(frame_no[0] - 1).detach().clone()
 
     # ---- second pass with per-kernel HIP events (library hook) on the same stream
     prof_steps = min(args.steps, 100)
@@ -1082,6 +1086,17 @@ def main():
         union = lit.to(torch.uint8).cpu()
         dist.all_reduce(union, op=dist.ReduceOp.MAX)
         exchange_rows = {"per_rank": [r.tolist() for r in rows], "union": int(union.sum().item()), "n_bricks": int(lit.numel())}
+        # self-check of the exchange that was timed: the display GPU's last summed volume against the sum of every rank's own dense volume carried by
+        # gloo over host memory (nothing of RCCL or of the brick bookkeeping in it); the photons do not change from frame to frame
+        ref = tmp.detach().cpu()
+        dist.reduce(ref, dst=0 if root is None else root)
+        if final_sum is not None:
+            got = final_sum.cpu()
+            peak = float(ref.abs().max())
+            worst = float((got - ref).abs().max())
+            exchange_rows["self_check"] = {"max_abs_difference": worst, "volume_max": peak, "relative": worst / max(peak, 1e-30),
+                                           "ok": bool(worst <= 2e-5 * peak), "nonzero_voxels": int((got != 0).sum().item()),
+                                           "against": "the ranks' own dense volumes summed by gloo over host memory (float sums in another order: tolerance 2e-5 of the maximum)"}
         del tmp
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
@@ -1202,6 +1217,10 @@ def main():
                              "dense_bytes": gdim ** 3 * 4, "n_bricks": exchange_rows["n_bricks"], "stream_synchronisations_per_frame": 0}
         elif world > 1:
             out["reduce"] = {"kind": "dense", "reduce_bytes_per_frame": gdim ** 3 * 4, "dense_bytes": gdim ** 3 * 4}
+        if exchange_rows and "self_check" in exchange_rows:
+            out.setdefault("reduce", {})["self_check"] = exchange_rows["self_check"]
+            if not exchange_rows["self_check"]["ok"]:
+                print("bench.py: the summed light volume differs from the dense reference sum: " + json.dumps(exchange_rows["self_check"]), file=sys.stderr)
         if exchange_rows:
             counts = [int(r[0]) for r in exchange_rows["per_rank"]]
             out.setdefault("reduce", {})["bricks"] = {"lit_per_rank": counts, "union": exchange_rows["union"], "of": exchange_rows["n_bricks"]}

@@ -147,6 +147,12 @@ def test_bench_two_ranks_brick_lists_through_the_c_abi():
     assert red["sent_bytes_per_rank_per_frame"][0] == 0 and red["sent_bytes_per_rank_per_frame"][1] > 0    # the root sends nothing
     assert red["received_bytes_at_root_per_frame"] == sum(red["sent_bytes_per_rank_per_frame"])
     assert red["bricks"]["union"] <= sum(red["bricks"]["lit_per_rank"])
+    # round 6: the exchange that was timed is checked against an independent dense sum; the model's constants were measured over the communicator;
+    # every sender's gather form was chosen by measurement on that rank
+    assert red["self_check"]["ok"] and red["self_check"]["nonzero_voxels"] > 0 and red["self_check"]["relative"] < 2e-5
+    assert red["model"]["measured"]["latency_us"] > 0 and red["model"]["constants"]["source"].startswith("measured")
+    sg = d["config"]["sender_gather"]["per_rank"]
+    assert sg[0]["chosen"].startswith("root") and sg[1]["chosen"] in ("segment", "pack") and sg[1]["segment_us"] > 0 and sg[1]["pack_us"] > 0
 
 
 def test_bench_two_ranks_brick_lists_over_gloo():
@@ -160,6 +166,7 @@ def test_bench_two_ranks_brick_lists_over_gloo():
     d = _last_json(r.stdout)
     assert d["config"]["exchange"] == "lists" and d["config"]["transport"] == "TorchTransport"
     assert "cpm_reduce_grid_bricklists" in d["reduce"]["kind"] and d["reduce"]["received_bytes_at_root_per_frame"] > 0
+    assert d["reduce"]["self_check"]["ok"] and d["reduce"]["model"]["constants"]["source"] == "assumed"
 
 
 def test_bench_four_ranks_weak_scaling_chooses_its_exchange():
