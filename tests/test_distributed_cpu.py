@@ -272,8 +272,6 @@ def _sparse_worker(rank, world, port, out_dir, dims, channels, root):
         depth = min(dz, 2 + 7 * k if k < 5 else 4)
         lit = torch.rand(depth, dy, dx, generator=gen) < 0.3
         vals = torch.randint(1, 1000, (depth, dy, dx, channels), generator=gen).float() / 8.0
-        if inexact:   # values whose sums DO depend on the order: the root's sum is then held to the protocol's order, not to any all-reduce's
-            vals = torch.rand(depth, dy, dx, channels, generator=gen) + 0.01
         g[:depth] = vals * lit[..., None]
         return g.reshape(-1)
 
