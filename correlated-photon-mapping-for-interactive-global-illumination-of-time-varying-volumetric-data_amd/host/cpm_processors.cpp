@@ -1250,7 +1250,8 @@ void PhotonToLightVolumeProcessorCL::process() {  // photontolightvolumeprocesso
         if (formulation_.get() == "splat") {  // the reference's formulation: clear + atomic splat (:299-339)
             (void)hipMemsetAsync(out, 0, cells * channels * sizeof(float), rt.stream());
             rt.check(cpm_splat_records(rt.ctx(), photons, nPhotons * nInter, nPhotons, &g, radius, scale, out, rt.stream()), "cpm_splat");
-        } else if (formulation_.get() == "fast" && cpm_gather_fast_supported(&g, radius)) {
+        } else if (formulation_.get() == "fast" && cpm_gather_fast_supported_on(rt.ctx(), &g, radius)) {
+            // (asked of THIS device: a brick's LDS tile must fit what a workgroup may use here, else the bit-exact pair below serves the frame)
             // brick bin + LDS-tile gather, fixed-point sums: the reference's terms within the stated fp32 tolerance
             const size_t m = (size_t)nPhotons * nInter;
             // (a record per (photon, brick it reaches): cpm_fast_record_capacity)

@@ -618,7 +618,7 @@ public:
         StringOptionProperty valueUnit{ "valueUnit", "Value unit", "arb. unit." };
     } information_;
     // "fast" (default): brick bin + LDS-tile gather with fixed-point sums (tolerance mode, bitwise reproducible; falls back
-    // to "gather" where cpm_gather_fast_supported says no); "gather": cell sort + per-voxel sequential gather (bit-exact
+    // to "gather" where cpm_gather_fast_supported_on says no for the context's device); "gather": cell sort + per-voxel sequential gather (bit-exact
     // contract, what exactIncrementalUpdate needs); "splat": the reference's atomic formulation
     StringOptionProperty formulation_{ "formulation", "Density estimation", "fast" };
     // add-remove of the re-traced photons: false (default) = the reference's -old / +new atomic splats; true = re-bin and
