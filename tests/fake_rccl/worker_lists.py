@@ -174,5 +174,42 @@ if rank == root:
     results["loop_5"] = red.result(5).cpu().numpy().copy()
 results["loop_info"] = np.array([(i["n_own"], i["capacity"], i["resent"], i["sent_bytes"], i["received_bytes"]) for i in red.info], np.int64)
 tr.close()
+
+# 5. a seeded walk: ragged grids, both channel counts, lit sets that grow, shrink and jump from ticket to ticket (capacities follow two tickets
+#    behind: lists outgrow their segments again and again), INEXACT values, three tickets in flight before the first is completed
+def fuzz_partial(dims, ch, k, who):
+    dx, dy, dz = dims
+    rng = np.random.default_rng(90000 + 1000 * k + 37 * who + dx * dy)
+    density = (0.01, 0.3, 0.02, 0.6, 0.6, 0.05, 0.9, 0.001, 0.4, 0.0)[k % 10]
+    g = np.zeros((dz, dy, dx, ch), np.float32)
+    lit = rng.random((dz, dy, dx)) < density
+    if who % 2 == 1:
+        lit[: dz // 2] = False                      # (odd ranks light the far half only: bricks with few and with many listers)
+    g[lit] = rng.random((int(lit.sum()), ch), dtype=np.float32) + np.float32(0.01)
+    return g.reshape(-1)
+
+
+comm5 = ctx.comm_create(exchange_id("uid_fuzz.bin"), rank, world)
+for fi, (dims, ch) in enumerate((((36, 20, 28), 1), ((17, 33, 12), 4), ((64, 16, 16), 1))):
+    gd = B.default_grid_desc(dims, ch)
+    br = ctx.bricklist_reduce_create(comm5, gd, root)
+    infos, pending = [], []
+    for k in range(10):
+        g = torch.from_numpy(fuzz_partial(dims, ch, k, rank)).to(ctx.device)
+        pending.append((k, g, br.start(g)))
+        if len(pending) == 3:
+            kk, gg, tt = pending.pop(0)
+            i = br.complete(tt)
+            torch.cuda.synchronize()
+            results[f"fuzz_{fi}_{kk}"] = gg.cpu().numpy()
+            infos.append((i.n_own, i.capacity, i.resent))
+    for kk, gg, tt in pending:
+        i = br.complete(tt)
+        torch.cuda.synchronize()
+        results[f"fuzz_{fi}_{kk}"] = gg.cpu().numpy()
+        infos.append((i.n_own, i.capacity, i.resent))
+    results[f"fuzz_{fi}_info"] = np.array(infos, np.int64)
+    br.close()
+comm5.close()
 np.savez(out / f"rank{rank}.npz", **results)
 print("worker", rank, "done")

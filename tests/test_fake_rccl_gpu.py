@@ -265,3 +265,40 @@ def test_senders_gather_straight_into_their_segments(tmp_path_factory, cpm, worl
         for w in [w for w in range(world) if w != root and w not in late] + late:
             want = want + parts[w]
         assert np.array_equal(ranks[root][f"loop_{k}"].view(np.uint32), want.view(np.uint32)), k
+
+
+@pytest.mark.parametrize("world,root", [(2, 0), (4, 1)])
+def test_brick_lists_seeded_walk(tmp_path_factory, cpm, world, root):
+    """Ragged grids, 1 and 4 channels, lit sets that jump between a thousandth and nine tenths of the voxels from ticket to ticket (so lists
+    outgrow the capacity their count of two tickets before gave them, repeatedly), inexact values, three tickets in flight: after every ticket
+    the root's grid is numpy's sum in the library's order -- the root's own, the senders in rank order, the ones that had to send again last
+    --, bit for bit; the senders' grids are untouched.  Same workers as above."""
+    ranks = _run_lists(tmp_path_factory, world, root)
+    sys.path.insert(0, str(REPO / "tests" / "fake_rccl"))
+    resent_total = 0
+    for fi, (dims, ch) in enumerate((((36, 20, 28), 1), ((17, 33, 12), 4), ((64, 16, 16), 1))):
+        infos = [r[f"fuzz_{fi}_info"] for r in ranks]
+        for k in range(10):
+            parts = [_fuzz_partial(dims, ch, k, w) for w in range(world)]
+            late = [w for w in range(world) if w != root and int(infos[w][k, 2])]
+            want = parts[root].copy()
+            for w in [w for w in range(world) if w != root and w not in late] + late:
+                want = want + parts[w]
+            assert np.array_equal(ranks[root][f"fuzz_{fi}_{k}"].view(np.uint32), want.view(np.uint32)), (dims, ch, k, late)
+            for w in range(world):
+                if w != root:
+                    assert np.array_equal(ranks[w][f"fuzz_{fi}_{k}"].view(np.uint32), parts[w].view(np.uint32)), (dims, k, w)
+                    resent_total += int(infos[w][k, 2])
+    assert resent_total >= 3
+
+
+def _fuzz_partial(dims, ch, k, who):
+    dx, dy, dz = dims
+    rng = np.random.default_rng(90000 + 1000 * k + 37 * who + dx * dy)
+    density = (0.01, 0.3, 0.02, 0.6, 0.6, 0.05, 0.9, 0.001, 0.4, 0.0)[k % 10]
+    g = np.zeros((dz, dy, dx, ch), np.float32)
+    lit = rng.random((dz, dy, dx)) < density
+    if who % 2 == 1:
+        lit[: dz // 2] = False
+    g[lit] = rng.random((int(lit.sum()), ch), dtype=np.float32) + np.float32(0.01)
+    return g.reshape(-1)
