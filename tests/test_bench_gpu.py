@@ -193,3 +193,24 @@ def test_bench_four_ranks_weak_scaling_chooses_its_exchange():
         assert len(red["sent_bytes_per_rank_per_frame"]) == 4 and red["sent_bytes_per_rank_per_frame"][0] == 0
         assert all(b > 0 for b in red["sent_bytes_per_rank_per_frame"][1:])
         assert red["received_bytes_at_root_per_frame"] == sum(red["sent_bytes_per_rank_per_frame"])
+
+
+def test_bench_two_frames_in_flight():
+    """--frames-in-flight 2: every other frame on a second stream with its own context and buffers -- the lever for shards whose frames are
+    launch-latency chains.  One GPU: a line, labelled; two ranks over the RCCL double with the brick-list exchange: the summed volume still
+    passes its self-check (each of the reducer's two buffers, and each ticket, stays with one of the two streams)."""
+    r = subprocess.run([sys.executable, str(REPO / "bench.py"), "--steps", "10", "--warmup", "2", "--workload", "config1", "--no-extras", "--no-cpu-baseline",
+                        "--frames-in-flight", "2"], capture_output=True, text=True, timeout=900, cwd=str(REPO))
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = _last_json(r.stdout)
+    assert d["config"]["frames_in_flight"] == 2 and d["value"] > 0
+    sys.path.insert(0, str(REPO / "tests" / "fake_rccl"))
+    import build as fake_build
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", CPM_RCCL_LIBRARY=str(fake_build.build()))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29541", str(REPO / "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "3", "--workload", "config1",
+           "--scaling", "strong", "--test-backend", "gloo", "--test-one-device", "--transport", "rccl", "--frames-in-flight", "2"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=str(REPO), env=env)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-4000:]
+    d = _last_json(r.stdout)
+    assert d["config"]["frames_in_flight"] == 2 and d["config"]["exchange"] == "lists" and d["reduce"]["self_check"]["ok"]
