@@ -509,6 +509,9 @@ int cpm_bricklist_reduce_complete(cpm_ctx* ctx, cpm_bricklist_reduce* br, uint64
  *     cpm_bricklist_reduce_complete  as above; a list that outgrew its segment goes again at exact size FROM THE SAME BUFFER (a
  *                                    sender's buffer has room for every brick of the grid: nothing is rebuilt) and is added after the
  *                                    others.
+ * ONE PROCESS PER GPU (cpm_comm_create): a sender's ncclSend meets the root's ncclRecv only when both are enqueued, so a single host thread that
+ * drives several communicators (cpm_comm_create_all: Inviwo's one process) must not use this exchange -- its sums go through the grouped
+ * cpm_allreduce_grids / the union form, whose calls the library groups across the communicators itself.
  * open / fill / exchange of one ticket may go to different streams ordered by events (fill on the frame's stream, exchange on the
  * reduce's); a ticket's segment is written again four tickets later -- by then its exchange and completion have long been enqueued,
  * and the stream that fills it must have waited for the stream they went to (as it does for a dense grid it gathers into again). */
