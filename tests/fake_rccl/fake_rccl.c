@@ -77,6 +77,8 @@ ncclResult_t ncclGetUniqueId(ncclUniqueId* id) {
 
 ncclResult_t ncclCommInitRank(ncclComm_t* out, int nranks, ncclUniqueId id, int rank) {
     if (!out || nranks < 1 || nranks > FAKE_MAX_RANKS || rank < 0 || rank >= nranks) return ncclInvalidArgument;
+    /* (tests of the launcher's wall-clock budget: a communicator set-up that never returns, as a wedged xGMI link would make it) */
+    if (getenv("FAKE_RCCL_BLOCK_INIT") && nranks > 1) for (;;) sleep(1);
     fake_comm* c = (fake_comm*)calloc(1, sizeof *c);
     if (!c) return ncclSystemError;
     c->rank = rank; c->nranks = nranks;

@@ -214,3 +214,25 @@ def test_bench_two_frames_in_flight():
     assert r.returncode == 0, (r.stdout + r.stderr)[-4000:]
     d = _last_json(r.stdout)
     assert d["config"]["frames_in_flight"] == 2 and d["config"]["exchange"] == "lists" and d["reduce"]["self_check"]["ok"]
+
+
+def test_bench_survives_a_communicator_set_up_that_never_returns():
+    """the first contact with N GPUs must end with a line.  `python bench.py --gpus 2` -- the driver's form -- over an RCCL whose
+    ncclCommInitRank blocks for ever (the test double, FAKE_RCCL_BLOCK_INIT): the ranks hang inside the C-ABI's communicator set-up, the parent
+    (which never touched a GPU) kills their process group when the set-up budget runs out and starts a FRESH set with --transport torch
+    --exchange union; ONE JSON line comes out and says what happened."""
+    sys.path.insert(0, str(REPO / "tests" / "fake_rccl"))
+    import build as fake_build
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "TORCHELASTIC_RUN_ID")}
+    env.update(CPM_RCCL_LIBRARY=str(fake_build.build()), FAKE_RCCL_BLOCK_INIT="1", CPM_BENCH_LAUNCH_BUDGET_S="20", CPM_BENCH_LAUNCH_TOTAL_S="240")
+    cmd = [sys.executable, str(REPO / "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2", "--workload", "config1",
+           "--test-backend", "gloo", "--test-one-device", "--transport", "rccl"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=str(REPO), env=env)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-4000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["value"] > 0 and d["config"]["transport"] == "TorchTransport" and d["config"]["rccl_ranks"] == 0
+    note = d["config"]["launcher_note"]
+    assert "20 s after they were up" in note and "were killed" in note and "--transport torch --exchange union" in note
+    assert "starting a fresh set of ranks" in r.stderr
