@@ -798,53 +798,105 @@ __host__ __device__ inline unsigned char* seg_slot(unsigned char* seg, uint32_t 
 __host__ __device__ inline const unsigned char* seg_slot(const unsigned char* seg, uint32_t s, int ch) { return seg + sizeof(SegHeader) + (size_t)s * seg_slot_bytes(ch); }
 inline uint32_t round_up_64(uint64_t v) { return (uint32_t)((v + 63ull) & ~63ull); }
 
-// sender, from a dense grid: every non-zero 4x4x4 brick (of the marked ones, when the gather left marks) -> a slot of the segment.
-// 16 lanes per brick, a 16-byte piece of a grid row each; ONE atomic on the segment's counter per workgroup of 16 bricks.
+// sender, from a dense grid: every listed 4x4x4 brick -> a slot of the segment.  Listed = marked, when the gather left marks (exact there; a
+// marked brick of zeros is listed as zeros: harmless), else holding a non-zero value.  A fixed grid of workgroups; every WAVE takes 4-brick quads
+// at a stride of all the waves (lit bricks come in clusters: neighbouring quads go to different waves), 16 lanes per brick, a 16-byte piece of a
+// grid row each.  Lane k of a wave holds the marks of the wave's k-th quad (one 4-byte load each, all in flight together); the wave counts its
+// listed bricks, the workgroup takes its slots with ONE atomic on the segment's counter, and the waves write their bricks at wave-local ranks
+// (shuffles; no barrier and no dependent load in the loop: the rows of several quads are in flight together).
+// (The first form took a slot per workgroup of 16 bricks and ended every workgroup with the done atomic: 2 x 16 Ki returning atomics on two
+// addresses of one cache line at config 4's size, served one after the other -- 390 us for a launch that moves 12 MB; the second walked
+// contiguous runs of quads with a marks load per iteration: 32 dependent round trips per wave, and the lit clusters on a few waves: 34 - 52 us.)
+constexpr uint32_t kPackQuadsPerWave = 64;   // at most: lane k holds quad k's marks
+constexpr int kPackThreads = 1024;            // 16 waves per workgroup: few workgroups (one slot atomic and one done atomic each), many waves
 template <int CH, bool VEC>
-__global__ __launch_bounds__(256) void bricklist_pack_grid_kernel(const float* __restrict__ grid, const uint8_t* __restrict__ marks, uint32_t nb, int dx, int dy,
-                                                                  int dz, int bxn, int byn, SegTarget st) {
-    __shared__ uint32_t s_cnt, s_base;
-    const int t = threadIdx.x, lane = t & 63, r = t & 15;
-    const uint32_t b = blockIdx.x * 16u + (uint32_t)(t >> 4);
-    if (t == 0) s_cnt = 0u;
-    __syncthreads();
-    float4 f[CH];
-#pragma unroll
-    for (int c = 0; c < CH; ++c) f[c] = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (b < nb && (!marks || marks[b])) {
+__global__ __launch_bounds__(kPackThreads) void bricklist_pack_grid_kernel(const float* __restrict__ grid, const uint8_t* __restrict__ marks, uint32_t nb, int dx, int dy,
+                                                                  int dz, int bxn, int byn, uint32_t quads_per_wave, SegTarget st) {
+    constexpr uint32_t kWaves = kPackThreads / 64;
+    __shared__ uint32_t s_cnt[kWaves], s_base;
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6, r = t & 15;
+    const uint32_t quads = (nb + 3u) / 4u, waves = gridDim.x * kWaves, first = blockIdx.x * kWaves + (uint32_t)wv;
+    auto load_row = [&](uint32_t b, float4* f) {
         const int bx = (int)(b % (uint32_t)bxn), by = (int)((b / (uint32_t)bxn) % (uint32_t)byn), bz = (int)(b / (uint32_t)(bxn * byn));
         const int y = by * 4 + (r & 3), z = bz * 4 + (r >> 2);
-        if (y < dy && z < dz) {
-            const size_t v = (size_t)(bx * 4) + (size_t)dx * ((size_t)y + (size_t)dy * (size_t)z);
-            if (VEC) {
 #pragma unroll
-                for (int c = 0; c < CH; ++c) f[c] = reinterpret_cast<const float4*>(grid + v * CH)[c];
-            } else {
-                float* ff = reinterpret_cast<float*>(f);
-                for (int x = 0; x < 4 && bx * 4 + x < dx; ++x)
-                    for (int c = 0; c < CH; ++c) ff[x * CH + c] = grid[(v + x) * CH + c];
+        for (int c = 0; c < CH; ++c) f[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (b >= nb || y >= dy || z >= dz) return;
+        const size_t v = (size_t)(bx * 4) + (size_t)dx * ((size_t)y + (size_t)dy * (size_t)z);
+        if (VEC) {
+#pragma unroll
+            for (int c = 0; c < CH; ++c) f[c] = reinterpret_cast<const float4*>(grid + v * CH)[c];
+        } else {
+            float* ff = reinterpret_cast<float*>(f);
+            for (int x = 0; x < 4 && bx * 4 + x < dx; ++x)
+                for (int c = 0; c < CH; ++c) ff[x * CH + c] = grid[(v + x) * CH + c];
+        }
+    };
+    // lane k: which bricks of the wave's k-th quad (first + k * waves) are listed, one bit each
+    uint32_t l4_mine = 0u;
+    if (marks) {
+        const uint32_t q = first + (uint32_t)lane * waves;
+        if ((uint32_t)lane < quads_per_wave && q < quads) {
+#pragma unroll
+            for (uint32_t g = 0; g < 4u; ++g) { const uint32_t b = q * 4u + g; l4_mine |= (b < nb && marks[b] != 0) ? (1u << g) : 0u; }
+        }
+    } else {
+        for (uint32_t k = 0; k < quads_per_wave; ++k) {   // (uniform per wave; quads beyond the grid load nothing)
+            const uint32_t b = (first + k * waves) * 4u + (uint32_t)(lane >> 4);
+            float4 f[CH];
+            load_row(first + k * waves < quads ? b : nb, f);
+            bool nz = false;
+#pragma unroll
+            for (int c = 0; c < CH; ++c) nz = nz || f[c].x != 0.f || f[c].y != 0.f || f[c].z != 0.f || f[c].w != 0.f;
+            const unsigned long long m = __ballot(nz);
+            uint32_t bits = 0u;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) bits |= ((m >> (16 * g)) & 0xffffull) != 0ull ? (1u << g) : 0u;
+            if ((uint32_t)lane == k) l4_mine = bits;
+        }
+    }
+    uint32_t cnt = (uint32_t)__popc(l4_mine);
+    for (int off = 32; off > 0; off >>= 1) cnt += __shfl_xor(cnt, off, 64);
+    if (lane == 0) s_cnt[wv] = cnt;
+    __syncthreads();
+    if (t == 0) {
+        uint32_t total = 0;
+        for (uint32_t w = 0; w < kWaves; ++w) total += s_cnt[w];
+        s_base = total ? atomicAdd(&st.ctl[0], total) : 0u;
+    }
+    __syncthreads();
+    uint32_t running = s_base;
+    for (int w = 0; w < wv; ++w) running += s_cnt[w];
+    if (cnt) {   // (uniform per wave)
+        constexpr int kAhead = CH == 1 ? 4 : 2;   // quads whose rows are in flight together
+        const uint32_t g = (uint32_t)(lane >> 4);
+        for (uint32_t k0 = 0; k0 < quads_per_wave; k0 += kAhead) {
+            uint32_t slot[kAhead], brick[kAhead];
+            bool on[kAhead];
+            float4 f[kAhead][CH];
+#pragma unroll
+            for (int u = 0; u < kAhead; ++u) {
+                const uint32_t k = k0 + (uint32_t)u;
+                const uint32_t l4 = k < quads_per_wave ? (uint32_t)__shfl(l4_mine, (int)(k & 63u), 64) : 0u;
+                brick[u] = (first + k * waves) * 4u + g;
+                slot[u] = running + (uint32_t)__popc(l4 & ((1u << g) - 1u));
+                on[u] = ((l4 >> g) & 1u) != 0u && slot[u] < st.room;
+                running += (uint32_t)__popc(l4);
+            }
+#pragma unroll
+            for (int u = 0; u < kAhead; ++u) load_row(on[u] ? brick[u] : nb, f[u]);   // (a brick index of nb loads nothing)
+#pragma unroll
+            for (int u = 0; u < kAhead; ++u) {
+                if (!on[u]) continue;
+                unsigned char* p = seg_slot(st.seg, slot[u], CH);
+                if (r == 0) *reinterpret_cast<uint4*>(p) = make_uint4(brick[u], 0u, 0u, 0u);
+                float4* o = reinterpret_cast<float4*>(p + 16) + (size_t)r * CH;
+#pragma unroll
+                for (int c = 0; c < CH; ++c) o[c] = f[u][c];
             }
         }
     }
-    bool nz = false;
-#pragma unroll
-    for (int c = 0; c < CH; ++c) nz = nz || f[c].x != 0.f || f[c].y != 0.f || f[c].z != 0.f || f[c].w != 0.f;
-    const unsigned long long m = __ballot(nz);
-    const bool brick_nz = ((m >> (lane & 48)) & 0xffffull) != 0ull;   // any of the brick's 16 lanes
-    uint32_t rel = 0u;
-    if (brick_nz && r == 0) rel = atomicAdd(&s_cnt, 1u);
-    rel = __shfl(rel, lane & 48, 64);
     __syncthreads();
-    if (t == 0) s_base = s_cnt ? atomicAdd(&st.ctl[0], s_cnt) : 0u;
-    __syncthreads();
-    const uint32_t slot = s_base + rel;
-    if (brick_nz && slot < st.room) {
-        unsigned char* p = seg_slot(st.seg, slot, CH);
-        if (r == 0) *reinterpret_cast<uint4*>(p) = make_uint4(b, 0u, 0u, 0u);
-        float4* o = reinterpret_cast<float4*>(p + 16) + (size_t)r * CH;
-#pragma unroll
-        for (int c = 0; c < CH; ++c) o[c] = f[c];
-    }
     if (t == 0) seg_finish(st, gridDim.x);
 }
 
@@ -1107,8 +1159,15 @@ int pack_grid_launch(cpm_ctx* ctx, const SegTarget& st, const int dims[3], int c
     const int bxn = div_up(dims[0], 4), byn = div_up(dims[1], 4), bzn = div_up(dims[2], 4);
     const uint32_t nb = (uint32_t)((size_t)bxn * byn * bzn);
     const bool vec = (dims[0] & 3) == 0;
-    const dim3 g((unsigned)div_up(nb, 16));
-#define CPM_BL_PACK(CH, VEC) CPM_LAUNCH(ctx, (bricklist_pack_grid_kernel<CH, VEC>), g, dim3(256), 0, s, grid, marks, nb, dims[0], dims[1], dims[2], bxn, byn, st)
+    // a fixed grid: two workgroups of 16 waves per CU (fewer for small grids), every wave 4-brick quads at a stride of all the waves
+    const uint32_t quads = (nb + 3u) / 4u, wpw = (uint32_t)kPackThreads / 64u;
+    uint32_t wgs = (uint32_t)(2 * ctx->num_cus);
+    if ((quads + wpw - 1u) / wpw < wgs) wgs = (quads + wpw - 1u) / wpw;
+    if (wgs == 0) wgs = 1;
+    if ((quads + wgs * wpw - 1u) / (wgs * wpw) > kPackQuadsPerWave) wgs = (quads + wpw * kPackQuadsPerWave - 1u) / (wpw * kPackQuadsPerWave);   // (lane k holds quad k's marks)
+    const uint32_t per_wave = (quads + wgs * wpw - 1u) / (wgs * wpw);
+    const dim3 g(wgs);
+#define CPM_BL_PACK(CH, VEC) CPM_LAUNCH(ctx, (bricklist_pack_grid_kernel<CH, VEC>), g, dim3(kPackThreads), 0, s, grid, marks, nb, dims[0], dims[1], dims[2], bxn, byn, per_wave, st)
     if (channels == 1) { if (vec) CPM_BL_PACK(1, true); else CPM_BL_PACK(1, false); }
     else { if (vec) CPM_BL_PACK(4, true); else CPM_BL_PACK(4, false); }
 #undef CPM_BL_PACK

@@ -1186,7 +1186,10 @@ int gather_fast_impl(cpm_ctx* ctx, const float* sorted_pos_power, const uint32_t
         else { if (wide == 4) CPM_HALO_LAUNCH(4, 4); else if (wide == 6) CPM_HALO_LAUNCH(4, 6); else CPM_HALO_LAUNCH(4, 8); }
 #undef CPM_HALO_LAUNCH
         CPM_LAUNCH_CHECK(ctx, "fast_halo_kernel");
-        const dim3 mgrid((unsigned)L.nb);
+        // (a segment: fewer workgroups, each over several bricks -- every workgroup ends with an atomic on the segment's done counter, and returning
+        // atomics on one address are served one after the other)
+        const size_t mres = (size_t)4 * (size_t)ctx->num_cus;
+        const dim3 mgrid((unsigned)(seg && (size_t)L.nb > mres ? mres : (size_t)L.nb));
         if (seg) {
             if (G.channels == 1) CPM_LAUNCH(ctx, (fast_halo_merge_kernel<1, true>), mgrid, dim3(256), 0, s, stage, brick_table, G, L, k, 0, grid_out, nullptr, st);
             else CPM_LAUNCH(ctx, (fast_halo_merge_kernel<4, true>), mgrid, dim3(256), 0, s, stage, brick_table, G, L, k, 0, grid_out, nullptr, st);
