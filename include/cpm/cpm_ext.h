@@ -467,7 +467,8 @@ int cpm_sparse_reduce_complete(cpm_ctx* ctx, cpm_sparse_reduce* sr, uint64_t tic
  * alone repeat the exchange at the exact size (both know the count by then).  No rank waits for a rank it does not exchange with.
  * Every rank makes the same sequence of calls; all calls of one cpm_bricklist_reduce go to one stream (or streams ordered by
  * events); at most 4 tickets issued and not completed.  nonzero_bricks (nullable): the marks cpm_gather_fast_marked left for `grid`
- * (else a pass over the grid finds them).  Communicators of size 1: nothing to do.
+ * (else a pass over the grid finds them); every MARKED brick is listed -- a marked brick of zeros travels as zeros, an unmarked one not at
+ * all: marks must cover every non-zero brick.  Communicators of size 1: nothing to do.
  * Call site: where PhotonToLightVolumeProcessorCL::process hands the volume on (ref processor/photontolightvolumeprocessorcl.cpp:356-412). */
 typedef struct cpm_bricklist_reduce cpm_bricklist_reduce;
 typedef struct cpm_bricklist_info {
