@@ -21,8 +21,12 @@ vol = ctx.volume_create(S.heterogeneous_volume(vdim))
 tf = S.workspace_tf()
 nb = ((gdim + 3) // 4) ** 3
 segs, keep, root, listed = [], [], None, 0
+# --root-share f: the display GPU traces f of an equal share, the others split the rest (its adds are part of ITS frame period: a lighter shard evens the ranks out)
+root_share = float(sys.argv[sys.argv.index("--root-share") + 1]) if "--root-share" in sys.argv else 1.0
+n_root = int(round(n_total / world * root_share))
+bounds = [0, n_root] + [n_root + (n_total - n_root) * (r + 1) // (world - 1) for r in range(world - 1)]
 for r in range(world):
-    lo, hi = sh.shard_range(n_total, r, world)
+    lo, hi = bounds[r], bounds[r + 1]
     fr = P.PhotonFrame(ctx, vol, tf, (nx, ny), (gdim,) * 3, light_travel_direction=(0.3, 0.5, -1.0), photon_indices=np.arange(lo, hi, dtype=np.int64))
     fr.set_planar_records(True)
     if r == 0:
@@ -34,9 +38,20 @@ for r in range(world):
     listed += count
     seg, bufs = sh.scratch_segment(torch, ctx.device, nb, 1, capacity=sh.bricklist_capacity(nb, count), ticket=3)
     fr.gather_fast_segment(seg)
+    if "--time" in sys.argv and r in (1, world // 2, world - 1):   # a sender's frame with this shard (segment form), back to back
+        for _ in range(10):
+            fr.trace(); fr.bin_fast(); fr.gather_fast_segment(seg)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(40):
+            fr.trace(); fr.bin_fast(); fr.gather_fast_segment(seg)
+        e1.record(); torch.cuda.synchronize()
+        print(f"sender rank {r}: {hi - lo} photons, frame {e0.elapsed_time(e1) / 40 * 1e3:.1f} us (segment form)", flush=True)
     segs.append(seg); keep.append(bufs)
     del fr
 torch.cuda.synchronize()
+print("photons: root", bounds[1], "others", [bounds[r + 1] - bounds[r] for r in range(1, world)])
 slot_of = torch.zeros(world * nb, dtype=torch.int32, device=ctx.device)
 sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
 totals = [root.light_volume, torch.empty_like(root.light_volume)]
