@@ -962,34 +962,37 @@ __global__ __launch_bounds__(256) void bricklist_index_kernel(const unsigned cha
 template <int CH, bool VEC>
 __global__ __launch_bounds__(256) void bricklist_add_kernel(const unsigned char* __restrict__ base, RootSegs S, uint32_t ticket, uint32_t nb,
                                                             const uint32_t* __restrict__ slot_of, uint32_t* __restrict__ who, int dx, int dy, int dz, int bxn,
-                                                            int byn, float* __restrict__ grid, unsigned long long* mailbox) {
+                                                            int byn, float* __restrict__ grid, unsigned long long* mailbox, uint32_t n_groups) {
     constexpr int kMax = kBricklistMaxRanks - 1;   // senders
     __shared__ uint32_t s_n[kBricklistMaxRanks];
-    uint32_t local;
-    const int i = sender_of(S, blockIdx.x, 16u, local);
-    if (i < 0) return;
-    // round trip 1: the headers, this group's brick id and its values (the slot exists whatever the header says: s < slots received)
-    const uint32_t s = local * 16u + (threadIdx.x >> 4);
-    const int r = threadIdx.x & 15;
-    const bool have = s < S.slots[i];
-    const unsigned char* mine = seg_slot(base + S.off[i], have ? s : 0u, CH);
-    const uint32_t b = have ? *reinterpret_cast<const uint32_t*>(mine) : 0xffffffffu;
-    float4 own[CH];
-#pragma unroll
-    for (int c = 0; c < CH; ++c) own[c] = have ? (reinterpret_cast<const float4*>(mine + 16) + (size_t)r * CH)[c] : make_float4(0.f, 0.f, 0.f, 0.f);
     if ((int)threadIdx.x < S.n) {
         uint32_t raw;
         s_n[threadIdx.x] = seg_usable(base + S.off[threadIdx.x], S.slots[threadIdx.x], S.hdr_cap[threadIdx.x], ticket, &raw);
-        if ((int)threadIdx.x == i && local == 0u && mailbox)
-            __hip_atomic_store(mailbox + S.rank[i], ((unsigned long long)ticket << 32) | (unsigned long long)raw, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (blockIdx.x == 0 && mailbox)   // (every sender's count -> the host)
+            __hip_atomic_store(mailbox + S.rank[threadIdx.x], ((unsigned long long)ticket << 32) | (unsigned long long)raw, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
     __syncthreads();
-    if (s >= s_n[i] || b >= nb) return;
+    // a fixed grid of workgroups strides over the groups of 16 received bricks (the launch runs beside the display GPU's own frame: it should
+    // not take the whole device for a latency chain)
+    for (uint32_t vb = blockIdx.x; vb < n_groups; vb += gridDim.x) {
+    uint32_t local;
+    const int i = sender_of(S, vb, 16u, local);
+    if (i < 0) continue;
+    // round trip 1: this group's brick id and its values
+    const uint32_t s = local * 16u + (threadIdx.x >> 4);
+    const int r = threadIdx.x & 15;
+    if (s >= s_n[i]) continue;
+    const unsigned char* mine = seg_slot(base + S.off[i], s, CH);
+    const uint32_t b = *reinterpret_cast<const uint32_t*>(mine);
+    float4 own[CH];
+#pragma unroll
+    for (int c = 0; c < CH; ++c) own[c] = (reinterpret_cast<const float4*>(mine + 16) + (size_t)r * CH)[c];
+    if (b >= nb) continue;
     // round trip 2: who lists the brick; is this the slot its sender's table kept (a brick listed twice by one sender: one slot counts)
     const uint32_t lists = who[b] & ((1u << S.n) - 1u);
     const uint32_t at_own = slot_of[(size_t)S.table[i] * nb + b];
-    if (!((lists >> i) & 1u) || at_own != s) return;
-    if (lists & ((1u << i) - 1u)) return;             // a lower rank lists it: that group sums the brick
+    if (!((lists >> i) & 1u) || at_own != s) continue;
+    if (lists & ((1u << i) - 1u)) continue;           // a lower rank lists it: that group sums the brick
     // round trip 3: the grid's piece and the other listers' slots
     const int bx = (int)(b % (uint32_t)bxn), by = (int)((b / (uint32_t)bxn) % (uint32_t)byn), bz = (int)(b / (uint32_t)(bxn * byn));
     const int y = by * 4 + (r & 3), z = bz * 4 + (r >> 2);
@@ -1041,7 +1044,7 @@ __global__ __launch_bounds__(256) void bricklist_add_kernel(const unsigned char*
             }
         }
     }
-    if (!inside) return;
+    if (!inside) continue;
     if (VEC) {
 #pragma unroll
         for (int c = 0; c < CH; ++c) reinterpret_cast<float4*>(grid + v * CH)[c] = acc[c];
@@ -1049,6 +1052,7 @@ __global__ __launch_bounds__(256) void bricklist_add_kernel(const unsigned char*
         const float* ff = reinterpret_cast<const float*>(acc);
         for (int x = 0; x < 4 && bx * 4 + x < dx; ++x)
             for (int c = 0; c < CH; ++c) grid[(v + x) * CH + c] = ff[x * CH + c];
+    }
     }
 }
 
@@ -1145,7 +1149,10 @@ int bricklist_root_add(cpm_ctx* ctx, const RootGrid& rg, const RootSegs& S, cons
     CPM_LAUNCH(ctx, bricklist_index_kernel, dim3(w_index), dim3(256), 0, s, b, S, ticket, rg.nb, rg.channels, rg.slot_of, rg.who);
     CPM_LAUNCH_CHECK(ctx, "bricklist_index_kernel");
     const bool vec = (rg.dims[0] & 3) == 0;
-#define CPM_BL_ADD(CH, VEC) CPM_LAUNCH(ctx, (bricklist_add_kernel<CH, VEC>), dim3(w_add), dim3(256), 0, s, b, S, ticket, rg.nb, rg.slot_of, rg.who, rg.dims[0], rg.dims[1], rg.dims[2], rg.bxn, rg.byn, grid, mailbox)
+    // (CPM_ROOT_ADD_WGS: measurement hook for the launch's footprint beside the root's own frame)
+    static const uint32_t add_cap = []() { const char* e = getenv("CPM_ROOT_ADD_WGS"); return e && atoi(e) > 0 ? (uint32_t)atoi(e) : 0u; }();
+    const uint32_t add_wgs = add_cap && add_cap < w_add ? add_cap : w_add;
+#define CPM_BL_ADD(CH, VEC) CPM_LAUNCH(ctx, (bricklist_add_kernel<CH, VEC>), dim3(add_wgs), dim3(256), 0, s, b, S, ticket, rg.nb, rg.slot_of, rg.who, rg.dims[0], rg.dims[1], rg.dims[2], rg.bxn, rg.byn, grid, mailbox, w_add)
     if (rg.channels == 1) { if (vec) CPM_BL_ADD(1, true); else CPM_BL_ADD(1, false); }
     else { if (vec) CPM_BL_ADD(4, true); else CPM_BL_ADD(4, false); }
 #undef CPM_BL_ADD
