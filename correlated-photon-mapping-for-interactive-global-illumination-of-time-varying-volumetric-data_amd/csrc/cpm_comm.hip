@@ -1421,8 +1421,8 @@ int cpm_bricklist_reduce_complete(cpm_ctx* ctx, cpm_bricklist_reduce* br, uint64
     const int rank = br->comm->rank, size = br->comm->size, root = br->root;
     uint64_t sent = 0, received = 0;
     uint32_t listed = 0;
+    CPM_REQUIRE(ctx, sl.completed || sl.exchanged, "cpm_bricklist_reduce_complete: the ticket was opened but never exchanged");
     if (size > 1) {
-        CPM_REQUIRE(ctx, sl.completed || sl.exchanged, "cpm_bricklist_reduce_complete: the ticket was opened but never exchanged");
         const Rccl* R = rccl(ctx);
         if (!R) return CPM_ERR_UNSUPPORTED;
         for (int r = 0; r < size; ++r) {

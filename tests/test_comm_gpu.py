@@ -243,3 +243,46 @@ def test_overlapped_reducer_sparse_on_one_gpu(ctx, cpm):
     assert len(red.info) == 6
     assert [i["n_union"] for i in red.info] == [256 * ((2 + k + 3) // 4) for k in range(6)]
     tr.close()
+
+
+def test_bricklist_ticket_discipline_with_one_rank(ctx, cpm):
+    """cpm_bricklist_reduce_* over a real RCCL communicator of ONE rank: nothing travels, every call still has to come in order -- open (no segment: the
+    only rank is the root and gathers into its grid), exchange once, complete; four open tickets at most; the point-to-point calls refuse a peer that
+    is not there."""
+    B = cpm.binding
+    torch = ctx.torch
+    comm = ctx.comm_create(ctx.comm_unique_id(), 0, 1)
+    gd = B.default_grid_desc((16, 12, 8), 1)
+    br = ctx.bricklist_reduce_create(comm, gd, 0)
+    g = torch.ones(16 * 12 * 8, dtype=torch.float32, device=ctx.device)
+    t1, seg = br.open()
+    assert t1 == 1 and not seg.segment and seg.room == 64 and seg.channels == 1
+    br.pack_grid(t1, g)                        # (nothing to pack at the root)
+    with pytest.raises(B.CpmError):
+        br.complete(t1)                        # opened, never exchanged -- with one rank there is nothing to wait for, but the order is the order
+    br.exchange(t1, g)
+    with pytest.raises(B.CpmError):
+        br.exchange(t1, g)                     # once
+    i = br.complete(t1)
+    assert (i.n_own, i.capacity, i.resent, i.sent_bytes, i.received_bytes, i.listed_bricks) == (0, 0, 0, 0, 0, 0) and i.n_bricks == 4 * 3 * 2
+    assert torch.equal(g, torch.ones_like(g))
+    with pytest.raises(B.CpmError):
+        br.complete(99)
+    with pytest.raises(B.CpmError):
+        br.exchange(2, g)                      # not opened yet
+    tickets = [br.open()[0] for _ in range(4)]
+    with pytest.raises(B.CpmError):
+        br.open()                              # four open and not completed
+    for t in tickets:
+        br.exchange(t, g)
+        br.complete(t)
+    t6 = br.start(g)                           # the one-call form still works beside the step-by-step one
+    assert t6 == 6
+    br.complete(t6)
+    buf = torch.zeros(64, dtype=torch.uint8, device=ctx.device)
+    with pytest.raises(B.CpmError):
+        ctx.comm_send(comm, buf, 64, 0)        # a rank does not send to itself
+    with pytest.raises(B.CpmError):
+        ctx.comm_recv(comm, buf, 64, 1)        # nor receive from a rank that does not exist
+    br.close()
+    comm.close()
