@@ -245,6 +245,13 @@ class PhotonFrame:
             self.ctx.records_forget(b)
         self._described = []
 
+    def __del__(self):
+        try:   # (a described buffer's entry must not outlive the buffer: its memory may come back as something else)
+            if getattr(self, "_described", None) and self.ctx.h:
+                self.forget_described()
+        except Exception:
+            pass
+
     def set_planar_records(self, on=True):
         """The tracer writes -- and the brick bin reads -- the two-plane record layout (CPM_TRACE_PHOTONS_PLANAR / cpm_bin_fast_layout):
         the same records, position + first power channel in one plane; self.photons then holds that layout and `records()` gives
