@@ -90,6 +90,13 @@ def test_bricklist_policy_and_exchange_model_are_host_arithmetic(cpm):
     assert m["brick_lists"]["model_us"] < m["union_reduce"]["model_us"] < m["dense_reduce"]["model_us"]
     one = sh.exchange_model(32768, 1, 1, 6000, 6000, 128 ** 3)
     assert one["brick_lists"]["bytes_per_link"] == 0 and one["dense_reduce"]["bytes_per_link"] == 0
+    # the constants are part of the result: assumed unless measured ones are handed in (bench.py measures them over the communicator at set-up)
+    assert m["constants"]["source"] == "assumed" and m["constants"]["link_gbs"] == sh.XGMI_LINK_GBS and m["constants"]["latency_us"] == sh.COLLECTIVE_LATENCY_US
+    mm = sh.exchange_model(262144, 1, 8, 40520, 6390, 256 ** 3, link_gbs=50.0, latency_us=10.0)
+    assert mm["constants"] == {"link_gbs": 50.0, "latency_us": 10.0, "assumed": {"link_gbs": 100.0, "latency_us": 30.0}, "source": "measured at set-up (measure_p2p)"}
+    assert mm["brick_lists"]["bytes_per_link"] == m["brick_lists"]["bytes_per_link"]
+    assert abs(mm["brick_lists"]["model_us"] - (10.0 + m["brick_lists"]["bytes_per_link"] / 50e3)) < 0.06
+    assert abs(mm["union_reduce"]["model_us"] - (20.0 + m["union_reduce"]["bytes_per_link"] / 50e3)) < 0.06
 
 
 def test_no_cpu_fallback(cpm):
