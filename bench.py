@@ -18,6 +18,10 @@ irradiance grid, through the C-ABI, when N > 1).  Workload at N = 1: BASELINE co
                                                         no GPU and starts the N ranks itself as child processes)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
          --master-port P bench.py --gpus N --steps K --warmup W
+                                                       (either way a rank runs its end of a communicator set-up in a probe
+                                                        process first -- `--rccl-probe`, killed when it hangs -- and sets up
+                                                        in-process only what passed on every rank: C-ABI RCCL -> torch's NCCL
+                                                        group -> gloo; config.transport_probes says which)
 
 Rank 0 prints ONE JSON line.
 """
@@ -319,11 +323,84 @@ def launch_ranks(n_ranks, argv=None, budget_s=None, make_cmd=None):
     return 1
 
 
+PROBE_BUDGET_S = 60.0   # wall clock a probe process gets (CPM_BENCH_PROBE_BUDGET_S): torch is in the page cache by then, a communicator of 8 takes seconds
+
+
+def rccl_probe_child(argv):
+    """`bench.py --rccl-probe KIND RANK WORLD DEVICE WHERE`: one rank's end of a communicator set-up + the collectives the frames use, in a
+    process of its OWN -- started by a rank (probe_in_child) before that rank sets anything up itself.  A set-up that never returns
+    (ncclCommInitRank waiting for a peer, a bootstrap socket nobody answers) cannot be left from inside the process it hangs in; here it
+    hangs in a child the rank kills by PID, and the rank goes on with the next transport.  KIND cabi: the C-ABI's path (cpm_comm_create
+    from the id WHERE in hex, cpm_allreduce_grid, one cpm_comm_send / cpm_comm_recv pair between ranks 1 and 0); KIND torch:
+    torch.distributed's own NCCL group (rendezvous in the file WHERE) and one all_reduce.  Exit code 0 = every result was right."""
+    import ctypes
+    import signal
+    kind, rank, world, device, where = argv[0], int(argv[1]), int(argv[2]), int(argv[3]), argv[4]
+    try:
+        ctypes.CDLL("libc.so.6").prctl(1, int(signal.SIGKILL))   # PR_SET_PDEATHSIG: never outlives the rank that started it
+    except OSError:
+        pass
+    signal.alarm(int(float(os.environ.get("CPM_BENCH_PROBE_BUDGET_S", PROBE_BUDGET_S))) + 30)   # ... nor its own budget by much
+    import torch
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py --rccl-probe needs a GPU")
+    torch.cuda.set_device(device)
+    dev = torch.device("cuda", device)
+    if kind == "cabi":
+        import importlib
+        import cpm_amd
+        sharding = importlib.import_module(cpm_amd.__name__ + ".sharding")
+        ctx = cpm_amd.binding.Context(device)
+        tr = sharding.RcclTransport(ctx, rank, world, root=None, unique_id=bytes.fromhex(where))
+        probe = torch.ones(8, dtype=torch.float32, device=dev)
+        tr.wait(tr.start(probe))
+        torch.cuda.synchronize()
+        ok = bool((probe == float(world)).all().item())
+        if world > 1 and rank < 2:   # the brick lists' calls: rank 1's send meets the display GPU's receive
+            buf = torch.full((256,), 3.0 if rank == 1 else 0.0, dtype=torch.float32, device=dev)
+            with torch.cuda.stream(tr.stream):
+                (ctx.comm_send if rank == 1 else ctx.comm_recv)(tr.comm, buf, buf.numel() * 4, 1 - rank)
+            tr.stream.synchronize()
+            ok = ok and bool((buf == 3.0).all().item())
+        tr.close()
+    elif kind == "torch":
+        import torch.distributed as dist
+        dist.init_process_group("nccl", init_method="file://" + where, rank=rank, world_size=world, device_id=dev)
+        t = torch.ones(8, dtype=torch.float32, device=dev)
+        dist.all_reduce(t)
+        torch.cuda.synchronize()
+        ok = bool((t == float(world)).all().item())
+        dist.destroy_process_group()
+    else:
+        raise SystemExit(f"bench.py --rccl-probe: unknown kind {kind!r}")
+    return 0 if ok else 4
+
+
+def probe_in_child(kind, where, rank, world, device, budget_s):
+    """Run this rank's end of the probe (rccl_probe_child) as a child process; -> (passed, what went wrong).  The child is killed by its PID
+    when the budget runs out (it has no children of its own; it stays in the rank's process group, so whatever ends the rank's group ends it)."""
+    import subprocess
+    cmd = [sys.executable, str(Path(__file__).resolve()), "--rccl-probe", kind, str(rank), str(world), str(device), where]
+    p = subprocess.Popen(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True)
+    try:
+        _, err = p.communicate(timeout=budget_s)
+    except subprocess.TimeoutExpired:
+        p.kill()
+        p.communicate()
+        return False, f"rank {rank}'s probe process did not finish in {budget_s:.0f} s and was killed"
+    if p.returncode == 0:
+        return True, ""
+    last = [l for l in (err or "").strip().splitlines() if l.strip()]
+    return False, f"rank {rank}'s probe process exited with code {p.returncode}" + (f" ({last[-1].strip()[:200]})" if last else "")
+
+
 TIMED_BATCHES = 7   # the timed region is repeated; the median batch is reported
 MIN_WARM_STEPS = 200 # untimed frames before the first timed batch, whatever --warmup says (see main)
 
 
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "--rccl-probe":
+        raise SystemExit(rccl_probe_child(sys.argv[2:]))
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
@@ -453,18 +530,65 @@ def main():
             return sharding.TorchTransport(group=dist.new_group(backend="nccl"), root=root)
         return sharding.TorchTransport(root=root)
 
+    # Probe processes (rccl_probe_child): a set-up that HANGS inside RCCL cannot be left from the process it hangs in -- whoever started
+    # the ranks (torch.distributed.run, the driver's form for N > 1: nothing of ours above the ranks) would wait until its own limit.  So
+    # every rank first runs its end of the set-up + the frames' collectives in a child it can kill, the ranks agree, and only a path whose
+    # probe passed on every rank is set up in the rank itself: C-ABI RCCL -> torch.distributed's own NCCL group -> gloo (sums staged
+    # through the host: slow, labelled, but a line).  Off with CPM_BENCH_RCCL_PROBE=0; ranks that share one GPU (the tests) probe only
+    # when it is 1 (two processes per rank on one card).
+    probe_env = os.environ.get("CPM_BENCH_RCCL_PROBE", "")
+    probing = world > 1 and probe_env != "0" and (not args.test_one_device or probe_env == "1")
+    probe_budget = float(os.environ.get("CPM_BENCH_PROBE_BUDGET_S", PROBE_BUDGET_S))
+    real_nccl = args.test_backend == "nccl" and not args.test_one_device
+    probes = {}
+
+    def probe_all(kind):
+        """Every rank's child at once (the set-up is collective); -> (passed everywhere, the first rank's complaint)."""
+        if kind == "cabi":
+            where = [ctx.comm_unique_id().hex() if rank == 0 else None]
+        else:
+            import tempfile
+            where = [os.path.join(tempfile.gettempdir(), f"cpm_bench_probe_{os.getpid()}_{int(time.time())}") if rank == 0 else None]
+        dist.broadcast_object_list(where, src=0)
+        t0 = time.perf_counter()
+        good, why = probe_in_child(kind, where[0], rank, world, local_rank, probe_budget)
+        whys = [None] * world
+        dist.all_gather_object(whys, why)
+        if kind == "torch" and rank == 0:
+            try:
+                os.unlink(where[0])
+            except OSError:
+                pass
+        good = agree(good)
+        why = next((w for w in whys if w), "")
+        probes[kind] = "passed" if good else why
+        probes[kind + "_s"] = round(time.perf_counter() - t0, 1)
+        return good, why
+
+    def fallback(reason):
+        """The C-ABI's RCCL is out (reason): torch.distributed carries the sums -- over its own NCCL group when THAT passes its probe."""
+        if probing and real_nccl:
+            good, why = probe_all("torch")
+            if not good:
+                return (sharding.TorchTransport(root=root),
+                        f"gloo: the sums are staged through the host ({reason}; torch.distributed's own NCCL group did not pass its probe either: {why})")
+        return torch_transport(), f"torch.distributed ({reason})"
+
     transport = None
-    if world > 1 and args.transport == "rccl" and ((args.test_backend == "nccl" and not args.test_one_device) or fake_rccl):
-        # every rank first checks locally that RCCL can be bound (no communication); the ranks agree; then the collective communicator
-        # set-up and a probe of the collectives the frames will use.  Should a rank fail, ALL ranks fall back to torch.distributed
-        # (the same wire) and the JSON line says so.
+    if world > 1 and args.transport == "rccl" and (real_nccl or fake_rccl):
+        # every rank first checks locally that RCCL can be bound (no communication); the ranks agree; the probe processes; then the
+        # collective communicator set-up and a probe of the collectives the frames will use.  Should a rank fail, ALL ranks fall back to
+        # torch.distributed (the same wire) and the JSON line says so.
         err = ""
         try:
             ctx.comm_unique_id()
             ok = True
         except Exception as e:  # noqa: BLE001
             ok, err = False, str(e)
-        if agree(ok):
+        ok = agree(ok)
+        if ok and probing:
+            ok, err = probe_all("cabi")
+        if ok:
             try:
                 transport = sharding.RcclTransport(ctx, rank, world, root=root)
                 probe = torch.ones(8, dtype=torch.float32, device=ctx.device)
@@ -483,10 +607,13 @@ def main():
                         pass
                 transport = None
         if transport is None:
-            transport = torch_transport()
-            transport_note = "torch.distributed (RCCL through the C-ABI was not usable on some rank" + (f": {err}" if err else "") + ")"
+            transport, transport_note = fallback("RCCL through the C-ABI was not usable on some rank" + (f": {err}" if err else ""))
     if transport is None:
-        transport = torch_transport() if dist is not None else sharding.TorchTransport(root=root)
+        if dist is not None and world > 1 and args.transport == "torch" and probing and real_nccl:
+            transport, note = fallback("--transport torch")
+            transport_note = note if "gloo" in note else None
+        else:
+            transport = torch_transport() if dist is not None else sharding.TorchTransport(root=root)
     rccl = isinstance(transport, sharding.RcclTransport)
     # what one message costs over THIS node's links (SURVEY 8e / DESIGN 6: the exchange model's constants were assumptions): a 1 KB and a
     # 2 MB ping-pong between the display GPU and rank 1 through the C-ABI; every rank gets the figures (gloo) and prices the exchanges with them
@@ -1211,7 +1338,7 @@ def main():
                        # the transport the reduce really used, and the size RCCL itself reports for the communicator
                        # (cpm_comm_size; 0 = the reduce did not go through the C-ABI's RCCL communicator)
                        "transport": type(transport).__name__,
-                       "rccl_ranks": transport.comm.size if rccl else 0},
+                       "rccl_ranks": transport.comm.size if rccl else 0, **({"transport_probes": probes} if probes else {})},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5),
                          # also against what a copy kernel reaches on this part (6.29 TB/s, MI355X_MICROARCH.md)

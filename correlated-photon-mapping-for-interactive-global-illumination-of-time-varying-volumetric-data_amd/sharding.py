@@ -376,11 +376,13 @@ class RcclTransport:
     The communicator id is created on rank 0 (cpm_comm_get_unique_id) and handed to the other ranks over
     whatever the host has -- here one torch.distributed broadcast (any backend)."""
 
-    def __init__(self, ctx, rank: int, world: int, group=None, root=None):
+    def __init__(self, ctx, rank: int, world: int, group=None, root=None, unique_id: bytes = None):
         import torch
-        import torch.distributed as dist
         self.ctx, self.torch, self.world, self.rank, self.root = ctx, torch, world, rank, root
-        if world > 1:
+        if unique_id is not None:   # (the host already distributed it: bench.py's probe processes get it on their command line)
+            uid = unique_id
+        elif world > 1:
+            import torch.distributed as dist
             uid = [ctx.comm_unique_id() if rank == 0 else None]
             dist.broadcast_object_list(uid, src=0, group=group)
             uid = uid[0]

@@ -134,3 +134,19 @@ def test_a_first_set_that_succeeds_is_relayed_untouched(tmp_path):
     assert rc == 0
     d = json.loads(out.strip())
     assert d["config"]["transport"] == "RcclTransport" and "launcher_note" not in d["config"]
+
+
+def test_a_probe_process_reports_how_it_ended(monkeypatch):
+    """The ranks' probe processes (bench.py --rccl-probe: a communicator set-up that may hang runs in a child the rank can kill): one that
+    fails says so with its last line, one that overruns its budget is killed by PID and said to have been."""
+    import time
+    import torch
+    sys.path.insert(0, str(REPO))
+    import importlib
+    bench = importlib.import_module("bench")
+    if not torch.cuda.is_available():
+        ok, why = bench.probe_in_child("cabi", "00" * 128, 0, 2, 0, 120.0)
+        assert not ok and "rank 0's probe process exited with code 1" in why and "needs a GPU" in why
+    t0 = time.time()
+    ok, why = bench.probe_in_child("cabi", "00" * 128, 1, 2, 0, 0.05)     # (still importing when the budget ends)
+    assert not ok and why == "rank 1's probe process did not finish in 0 s and was killed" and time.time() - t0 < 30

@@ -206,7 +206,8 @@ def test_bench_two_frames_in_flight():
     assert d["config"]["frames_in_flight"] == 2 and d["value"] > 0
     sys.path.insert(0, str(REPO / "tests" / "fake_rccl"))
     import build as fake_build
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", CPM_RCCL_LIBRARY=str(fake_build.build()))
+    # (CPM_BENCH_RCCL_PROBE=1: every rank first runs its end of the communicator set-up in a probe process -- what real multi-GPU runs do)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", CPM_RCCL_LIBRARY=str(fake_build.build()), CPM_BENCH_RCCL_PROBE="1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", "29541", str(REPO / "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "3", "--workload", "config1",
            "--scaling", "strong", "--test-backend", "gloo", "--test-one-device", "--transport", "rccl", "--frames-in-flight", "2"]
@@ -214,6 +215,7 @@ def test_bench_two_frames_in_flight():
     assert r.returncode == 0, (r.stdout + r.stderr)[-4000:]
     d = _last_json(r.stdout)
     assert d["config"]["frames_in_flight"] == 2 and d["config"]["exchange"] == "lists" and d["reduce"]["self_check"]["ok"]
+    assert d["config"]["transport"] == "RcclTransport" and d["config"]["transport_probes"]["cabi"] == "passed"
 
 
 def test_bench_survives_a_communicator_set_up_that_never_returns():
@@ -236,3 +238,45 @@ def test_bench_survives_a_communicator_set_up_that_never_returns():
     note = d["config"]["launcher_note"]
     assert "20 s after they were up" in note and "were killed" in note and "--transport torch --exchange union" in note
     assert "starting a fresh set of ranks" in r.stderr
+
+
+def test_ranks_started_by_torchrun_leave_a_set_up_that_never_returns():
+    """The driver starts N > 1 ranks with torch.distributed.run itself: nothing of bench.py's stands above them, so a communicator set-up
+    that hangs would hang until the driver's limit.  Every rank therefore runs its end of the set-up in a PROBE PROCESS first (bench.py
+    --rccl-probe) and kills it when its budget runs out; the ranks agree and carry on over torch.distributed -- same processes, one JSON
+    line, which says what happened.  Here: the RCCL double whose ncclCommInitRank blocks for ever, two ranks on one GPU."""
+    sys.path.insert(0, str(REPO / "tests" / "fake_rccl"))
+    import build as fake_build
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", CPM_RCCL_LIBRARY=str(fake_build.build()), FAKE_RCCL_BLOCK_INIT="1",
+               CPM_BENCH_RCCL_PROBE="1", CPM_BENCH_PROBE_BUDGET_S="15")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29547", str(REPO / "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2", "--workload", "config1",
+           "--test-backend", "gloo", "--test-one-device", "--transport", "rccl", "--no-extras", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=str(REPO), env=env)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-4000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["value"] > 0 and d["config"]["transport"] == "TorchTransport" and d["config"]["rccl_ranks"] == 0
+    probes = d["config"]["transport_probes"]
+    assert "probe process did not finish in 15 s and was killed" in probes["cabi"] and 15 <= probes["cabi_s"] < 60
+    assert "probe process did not finish in 15 s" in json.dumps(d["config"])      # ... and in the line's own description of its reduce
+
+
+def test_probe_processes_over_the_real_rccl_with_one_rank(ctx, tmp_path):
+    """Both kinds of probe process against the REAL RCCL (one rank is all one GPU allows): the C-ABI's set-up from an id made in this
+    process + its all-reduce, and torch.distributed's own NCCL group from a file rendezvous."""
+    sys.path.insert(0, str(REPO))
+    import importlib
+    bench = importlib.import_module("bench")
+    env_was = os.environ.pop("CPM_RCCL_LIBRARY", None)
+    try:
+        ok, why = bench.probe_in_child("cabi", ctx.comm_unique_id().hex(), 0, 1, 0, 300.0)
+        assert ok, why
+        ok, why = bench.probe_in_child("torch", str(tmp_path / "rendezvous"), 0, 1, 0, 300.0)
+        assert ok, why
+        ok, why = bench.probe_in_child("nonsense", "-", 0, 1, 0, 300.0)
+        assert not ok and "unknown kind" in why
+    finally:
+        if env_was is not None:
+            os.environ["CPM_RCCL_LIBRARY"] = env_was
