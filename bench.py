@@ -391,7 +391,8 @@ def probe_in_child(kind, where, rank, world, device, budget_s):
     if p.returncode == 0:
         return True, ""
     last = [l for l in (err or "").strip().splitlines() if l.strip()]
-    return False, f"rank {rank}'s probe process exited with code {p.returncode}" + (f" ({last[-1].strip()[:200]})" if last else "")
+    said = [l for l in last if "rror" in l and "Warning" not in l] or last   # (the exception's line rather than an exit-time warning behind it)
+    return False, f"rank {rank}'s probe process exited with code {p.returncode}" + (f" ({said[-1].strip()[:200]})" if said else "")
 
 
 TIMED_BATCHES = 7   # the timed region is repeated; the median batch is reported
@@ -526,7 +527,7 @@ def main():
 
     def torch_transport():
         """torch.distributed carries the sums: over its own NCCL (= RCCL) group on real multi-GPU runs, over gloo in the tests."""
-        if world > 1 and args.test_backend == "nccl" and not args.test_one_device:
+        if world > 1 and real_nccl:
             return sharding.TorchTransport(group=dist.new_group(backend="nccl"), root=root)
         return sharding.TorchTransport(root=root)
 
@@ -539,7 +540,9 @@ def main():
     probe_env = os.environ.get("CPM_BENCH_RCCL_PROBE", "")
     probing = world > 1 and probe_env != "0" and (not args.test_one_device or probe_env == "1")
     probe_budget = float(os.environ.get("CPM_BENCH_PROBE_BUDGET_S", PROBE_BUDGET_S))
-    real_nccl = args.test_backend == "nccl" and not args.test_one_device
+    # (testing, CPM_BENCH_TEST_SHARED_NCCL=1: the REAL RCCL with every rank on one GPU -- it refuses such a communicator, which walks the
+    # ladder below with real errors from both RCCL paths)
+    real_nccl = args.test_backend == "nccl" and (not args.test_one_device or os.environ.get("CPM_BENCH_TEST_SHARED_NCCL") == "1")
     probes = {}
 
     def probe_all(kind):

@@ -280,3 +280,24 @@ def test_probe_processes_over_the_real_rccl_with_one_rank(ctx, tmp_path):
     finally:
         if env_was is not None:
             os.environ["CPM_RCCL_LIBRARY"] = env_was
+
+
+def test_the_ladder_ends_on_gloo_when_the_real_rccl_refuses_both_paths():
+    """The ladder's lower rungs with REAL errors: two ranks on one GPU and the real RCCL (CPM_BENCH_TEST_SHARED_NCCL=1), which refuses a
+    communicator whose ranks share a device.  The C-ABI's probe process fails, torch.distributed's own NCCL group fails its probe too, the
+    ranks -- the same processes, nothing set up in them yet -- carry the sums over gloo and the line says all of that."""
+    env = {k: v for k, v in os.environ.items() if k != "CPM_RCCL_LIBRARY"}
+    env.update(MASTER_ADDR="127.0.0.1", CPM_BENCH_RCCL_PROBE="1", CPM_BENCH_TEST_SHARED_NCCL="1", CPM_BENCH_PROBE_BUDGET_S="40")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29549", str(REPO / "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2", "--workload", "config1",
+           "--test-one-device", "--transport", "rccl", "--no-extras", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=str(REPO), env=env)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-4000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    probes = d["config"]["transport_probes"]
+    assert probes["cabi"] != "passed" and probes["torch"] != "passed", probes
+    assert d["n_gpus"] == 2 and d["value"] > 0 and d["config"]["transport"] == "TorchTransport" and d["config"]["rccl_ranks"] == 0
+    assert "gloo: the sums are staged through the host" in json.dumps(d["config"])
+    print(probes)
